@@ -1,0 +1,151 @@
+/* jxl_tiny_amd.h -- C ABI of the MI355X-native JPEG XL "tiny" encoder hot path.
+ *
+ * The reference (libjxl-tiny) has no plugin/FFI surface; its boundary is the
+ * C++ call chain cjxl_tiny -> EncodeFile -> EncodeFrame.  This ABI is what the
+ * replacement EncodeFrame binds instead of the serial per-stripe loop at
+ *   /root/reference/encoder/enc_frame.cc:716-757   (ProcessDCGroup body:
+ *     CopyAndPadImage, ToXYB, ProcessTile{ComputeAdaptiveQuantFieldTile,
+ *     ComputeCmapTile, FindBest16x16Transform, AdjustQuantField}, WriteACGroup)
+ * Plain pointers and sizes only; no C++ or torch types; no exceptions cross it.
+ * Every function returns 0 on success and a negative JXLT_ERR_* otherwise;
+ * jxlt_last_error() gives a human-readable message.
+ *
+ * Two libraries export these symbols:
+ *   libjxltiny_hip.so   (hipcc, gfx950)  jxlt_context_* / jxlt_image_* /
+ *                                        jxlt_encode_* / jxlt_fetch_* / jxlt_debug_*
+ *   libjxltiny_host.so  (g++)            jxlt_assemble_frame, jxlt_encode_file_planar,
+ *                                        jxlt_compute_distance_params
+ */
+#ifndef JXL_TINY_AMD_H_
+#define JXL_TINY_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JXLT_OK 0
+#define JXLT_ERR_INVALID_ARGUMENT (-1)
+#define JXLT_ERR_NO_DEVICE (-2)   /* no usable HIP device / HIP runtime error */
+#define JXLT_ERR_OUT_OF_MEMORY (-3)
+#define JXLT_ERR_UNSUPPORTED (-4) /* e.g. image that fits one 8x8 block (reference traps) */
+#define JXLT_ERR_INTERNAL (-5)
+
+/* Scalars of the reference's DistanceParams (enc_frame.cc:104-156) that the
+ * device pipeline consumes, plus mode flags. */
+typedef struct {
+  float distance;      /* butteraugli distance */
+  float scale;         /* global_scale / 65536 */
+  float inv_scale;     /* 1 / scale */
+  float scale_dc;      /* quant_dc * scale */
+  uint32_t x_qm_scale; /* 2..5 */
+  uint32_t flags;      /* JXLT_FLAG_* */
+} jxlt_params;
+
+#define JXLT_FLAG_FORCE_DCT8 1u /* == OPTIMIZE_BLOCK_SIZES 0 (config.h:12) */
+#define JXLT_FLAG_DEBUG_DUMP 2u /* keep XYB/quant-field/masking/entropy intermediates */
+#define JXLT_FLAG_PROFILE 4u    /* record per-kernel HIP event timings */
+
+/* Full DistanceParams for the host back-end (enc_frame.cc:104-156). */
+typedef struct {
+  float distance;
+  int32_t global_scale;
+  int32_t quant_dc;
+  float scale;
+  float inv_scale;
+  float scale_dc;
+  uint32_t x_qm_scale;
+  uint32_t epf_iters;
+} jxlt_distance_params;
+
+/* Host-visible result of one pass of the hot path over the current image.
+ * All pointers are owned by the context (pinned host memory) and stay valid
+ * until the next jxlt_fetch_result()/jxlt_context_destroy() on that context.
+ * Grids are image-absolute: blocks = 8x8 px (pitch xsize_blocks), tiles = 64x64
+ * px (pitch xsize_tiles).  Mirrors DCGroupData (dc_group_data.h:19-37) and the
+ * per-group raw token sections (enc_group.cc:468-470,483-485). */
+typedef struct {
+  size_t xsize, ysize;
+  size_t xsize_blocks, ysize_blocks;
+  size_t xsize_tiles, ysize_tiles;
+  size_t num_groups;                 /* ceil(x/256) * ceil(y/256), raster order */
+  const int16_t* quant_dc[3];        /* X, Y, B */
+  const uint8_t* raw_quant_field;
+  const uint8_t* ac_strategy;        /* (type << 1) | is_first_block */
+  const int8_t* ytox_map;
+  const int8_t* ytob_map;
+  const uint8_t* tokens;             /* all groups, concatenated 3-byte records */
+  const uint64_t* group_token_offset; /* [num_groups + 1], byte offsets into tokens */
+} jxlt_frame_result;
+
+typedef struct jxlt_context jxlt_context; /* one per (host thread, device) */
+
+/* ---- libjxltiny_hip.so ------------------------------------------------- */
+
+int jxlt_context_create(int device_ordinal, jxlt_context** ctx);
+void jxlt_context_destroy(jxlt_context* ctx);
+/* ctx may be NULL: returns the message of the last failed create. */
+const char* jxlt_last_error(const jxlt_context* ctx);
+
+/* Copies three planar f32 linear-sRGB planes (row pitch in bytes, as
+ * Image3F::bytes_per_row(), image.h:382) into context-owned HBM.  Replaces the
+ * host reads of CopyAndPadImage (enc_frame.cc:597-617). */
+int jxlt_image_upload(jxlt_context* ctx, const float* const planes[3], size_t pitch_bytes,
+                      size_t xsize, size_t ysize);
+/* Borrows planes already resident in HBM (e.g. a torch tensor's data_ptr). */
+int jxlt_image_set_device(jxlt_context* ctx, const void* const device_planes[3],
+                          size_t pitch_bytes, size_t xsize, size_t ysize);
+
+/* Enqueues the whole per-group pipeline for the current image on the context's
+ * stream (asynchronous).  One call == one "step" of the hot path. */
+int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params);
+/* Blocks until the enqueued work has finished. */
+int jxlt_synchronize(jxlt_context* ctx);
+/* Copies results to pinned host memory (blocking) and fills *out. */
+int jxlt_fetch_result(jxlt_context* ctx, jxlt_frame_result* out);
+
+/* Timing of the kernels of the last jxlt_encode_enqueue (needs JXLT_FLAG_PROFILE):
+ * writes up to `cap` entries; returns the number of kernels, or < 0. */
+typedef struct {
+  const char* name;
+  float milliseconds;
+} jxlt_kernel_time;
+int jxlt_kernel_times(jxlt_context* ctx, jxlt_kernel_time* out, int cap);
+
+/* Debug intermediates of the last encode run with JXLT_FLAG_DEBUG_DUMP.
+ * what: 0,1,2 = XYB planes f32 (xsize_blocks*8 x ysize_blocks*8);
+ *       3 = quant field f32 per block; 4 = masking f32 per block;
+ *       5 = entropy estimates f32, 8 per 2x2-block cell, grid
+ *           (xsize_blocks/2+1) x (ysize_blocks/2+1). */
+int jxlt_debug_fetch(jxlt_context* ctx, int what, void* host_dst, size_t bytes);
+
+/* ---- libjxltiny_host.so ------------------------------------------------ */
+
+void jxlt_compute_distance_params(float distance, jxlt_distance_params* out);
+
+/* Host bitstream back-end (enc_frame.cc:765-858 after the pixel pipeline):
+ * appends frame header, TOC and all sections for `frame` to a malloc'ed buffer
+ * (*out_bytes, caller frees with jxlt_free).  num_threads <= 0: all cores. */
+int jxlt_assemble_frame(const jxlt_frame_result* frame, const jxlt_distance_params* distp,
+                        int num_threads, uint8_t** out_bytes, size_t* out_size);
+/* As above but with separately allocated per-group token buffers. */
+int jxlt_assemble_frame_groups(const jxlt_frame_result* frame, const uint8_t* const* group_tokens,
+                               const size_t* group_token_bytes, const jxlt_distance_params* distp,
+                               int num_threads, uint8_t** out_bytes, size_t* out_size);
+
+/* C entry to the drop-in EncodeFile (enc_file.h:20-21): planar f32 in host
+ * memory -> complete .jxl codestream (malloc'ed, free with jxlt_free).
+ * device_ordinal selects the GPU. */
+int jxlt_encode_file_planar(const float* const planes[3], size_t pitch_bytes, size_t xsize,
+                            size_t ysize, float distance, int device_ordinal,
+                            uint8_t** out_bytes, size_t* out_size);
+/* Codestream + image headers that precede the frame (enc_file.cc:70-95). */
+int jxlt_write_file_header(size_t xsize, size_t ysize, uint8_t** out_bytes, size_t* out_size);
+void jxlt_free(void* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JXL_TINY_AMD_H_ */

@@ -1,0 +1,1284 @@
+// jxlt_device.h -- gfx950 device code of the JPEG XL tiny encoder hot path.
+//
+// Pure device code (kernels + __device__ helpers); the launches live in
+// jxlt_capi.hip.  tests/ compile this same file against a fiber-based HIP
+// execution model on the CPU (tests/hipsim) to check it bit-for-bit against the
+// oracle without a GPU; the product only ever builds it with hipcc.
+//
+// MUST be compiled with -ffp-contract=off: the arithmetic model is "every
+// operation one IEEE binary32 operation, fused only where __builtin_fmaf is
+// written" (SURVEY.md Appendix B, 8-lane canonical model).  The 8 SIMD lanes of
+// the reference map onto 8 adjacent GPU lanes ("octets"); SumOfLanes becomes a
+// 3-step xor butterfly inside the octet, which reproduces the halving tree.
+//
+// Kernels:
+//   tile_kernel      one 512-thread workgroup per 64x64 tile: edge-replicated
+//                    load + XYB -> LDS, adaptive quant field, chroma-from-luma,
+//                    DCT8/16x8/8x16 strategy search, quantisation, DC, nzeros;
+//                    writes side-band grids + scan-ordered quantised coefficients.
+//                    (ref: enc_frame.cc:597-683 + enc_group.cc:304-443)
+//   group_scan_kernel exclusive scan of per-group token counts.
+//   token_kernel     one workgroup per 256x256 group: context modelling and raw
+//                    3-byte token records in stream order (ref: enc_group.cc:444-494)
+#ifndef JXLT_DEVICE_H_
+#define JXLT_DEVICE_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace jxlt_dev {
+
+// ---------------------------------------------------------------------------
+// Kernel arguments
+// ---------------------------------------------------------------------------
+
+// Constant tables, resident in HBM (built on the host by jxlt_capi.hip).
+struct DeviceTables {
+  float weights[576];      // dequant weights (quant_weights.cc:17-134)
+  float inv_weights[576];  // float(1.0 / w), LLF zeroed (quant_weights.cc:144-153)
+  float inv_qac[256];      // float(1.0 / (double)(scale * q)) (enc_group.cc:289)
+  uint16_t table_offset[9];
+  uint8_t coeff_order[192];
+  uint16_t freq_context[64];
+  uint16_t nnz_context[64];
+  uint8_t block_context_map[81];
+  uint8_t ac_context_map[1980];
+};
+
+struct FrameGeom {
+  int xsize, ysize;                // pixels
+  int xsize_blocks, ysize_blocks;  // 8x8
+  int xsize_tiles, ysize_tiles;    // 64x64
+  int xsize_groups, ysize_groups;  // 256x256
+};
+
+struct TileArgs {
+  const float* planes[3];
+  size_t pitch;  // floats per row
+  FrameGeom g;
+  float distance, scale, inv_scale, scale_dc;
+  float x_qm_mul;  // 1.25^(x_qm_scale-2)
+  uint32_t flags;  // bit0: force DCT8
+  const DeviceTables* tab;
+  // outputs (image-absolute grids)
+  int16_t* quant_dc[3];
+  uint8_t* raw_quant;
+  uint8_t* strategy;
+  int8_t* ytox;
+  int8_t* ytob;
+  uint8_t* nzgrid[3];   // value used for context prediction, per block & channel
+  uint8_t* blk_nz;      // [block*3 + c]: number of nonzeros (token value)
+  uint8_t* blk_nscan;   // [block*3 + c]: scan positions up to the last nonzero
+  int16_t* coef_scan;   // [block*3 + c][64] quantised coefficients in scan order
+  uint32_t* group_ntok; // per group token count (atomic)
+  // debug (may be null)
+  float* dbg_xyb[3];
+  float* dbg_qf;
+  float* dbg_mask;
+  float* dbg_ent8;
+};
+
+struct TokenArgs {
+  FrameGeom g;
+  const DeviceTables* tab;
+  const uint8_t* strategy;
+  const uint8_t* nzgrid[3];
+  const uint8_t* blk_nz;
+  const uint8_t* blk_nscan;
+  const int16_t* coef_scan;
+  const uint64_t* group_tok_offset;  // exclusive scan of group_ntok (tokens)
+  uint8_t* tokens;                   // 3 bytes per token
+};
+
+// ---------------------------------------------------------------------------
+// Arithmetic primitives
+// ---------------------------------------------------------------------------
+
+#define JXLT_DI __device__ __forceinline__
+
+JXLT_DI float fma32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+JXLT_DI float nfma32(float a, float b, float c) { return __builtin_fmaf(-a, b, c); }
+JXLT_DI float zero_if_negative(float v) {
+  return (__float_as_uint(v) & 0x80000000u) ? 0.0f : v;
+}
+// SumOfLanes over the 8 lanes of an octet: (i)+(i^4), (i)+(i^2), (i)+(i^1).
+JXLT_DI float octet_sum(float v) {
+  v = v + __shfl_xor(v, 4);
+  v = v + __shfl_xor(v, 2);
+  v = v + __shfl_xor(v, 1);
+  return v;
+}
+JXLT_DI int octet_sum_int(int v) {
+  v = v + __shfl_xor(v, 4);
+  v = v + __shfl_xor(v, 2);
+  v = v + __shfl_xor(v, 1);
+  return v;
+}
+JXLT_DI int ceil_log2_nonzero(uint32_t x) {
+  const int fl = 31 - __clz((int)x);
+  return (x & (x - 1)) == 0 ? fl : fl + 1;
+}
+JXLT_DI uint32_t pack_signed(int32_t v) {  // common.h:54-58
+  return ((uint32_t)v << 1) ^ (((uint32_t)(~v) >> 31) - 1);
+}
+
+// fast_math-inl.h:113-133 + :74-108
+JXLT_DI float fast_log2f(float x) {
+  const float p0 = -1.8503833400518310E-06f, p1 = 1.4287160470083755E+00f,
+              p2 = 7.4245873327820566E-01f;
+  const float q0 = 9.9032814277590719E-01f, q1 = 1.0096718572241148E+00f,
+              q2 = 1.7409343003366853E-01f;
+  const int32_t x_bits = __float_as_int(x);
+  const int32_t exp_bits = x_bits - 0x3f2aaaab;
+  const int32_t exp_shifted = exp_bits >> 23;
+  const float mantissa = __int_as_float(x_bits - (int32_t)((uint32_t)exp_shifted << 23));
+  const float exp_val = (float)exp_shifted;
+  const float t = mantissa - 1.0f;
+  float yp = p2, yq = q2;
+  yp = fma32(yp, t, p1);
+  yq = fma32(yq, t, q1);
+  yp = fma32(yp, t, p0);
+  yq = fma32(yq, t, q0);
+  return yp / yq + exp_val;
+}
+
+// fast_math-inl.h:137-151
+JXLT_DI float fast_pow2f(float x) {
+  const float floorx = floorf(x);
+  const float e = __int_as_float((int32_t)((uint32_t)((int32_t)floorx + 127) << 23));
+  const float frac = x - floorx;
+  float num = frac + (float)1.01749063e+01;
+  num = fma32(num, frac, (float)4.88687798e+01);
+  num = fma32(num, frac, (float)9.85506591e+01);
+  num = num * e;
+  float den = fma32(frac, (float)2.10242958e-01, (float)-2.22328856e-02);
+  den = fma32(den, frac, (float)-1.94414990e+01);
+  den = fma32(den, frac, (float)9.85506633e+01);
+  return num / den;
+}
+
+// fast_math-inl.h:178-213
+JXLT_DI float cube_root_and_add(float x, float add) {
+  const float k1_3 = 1.0f / 3, k4_3 = 4.0f / 3;
+  const float xa_3 = k1_3 * x;
+  const int32_t m1 = __float_as_int(x);
+  const int32_t m2 = (m1 == 0) ? 0 : (int32_t)(0x54800000u - (uint32_t)(m1 >> 23) * 0x002AAAAAu);
+  float r = __int_as_float(m2);
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const float r2 = r * r;
+    r = nfma32(xa_3, r2 * r2, k4_3 * r);
+  }
+  float r2 = r * r;
+  r = fma32(k1_3, nfma32(x, r2 * r2, r), r);
+  r2 = r * r;
+  r = fma32(r2, x, add);
+  return r;
+}
+
+// enc_xyb.cc:30-81
+JXLT_DI void linear_to_xyb(float r, float g, float b, float* ox, float* oy, float* ob) {
+  const float kM02 = 0.078f, kM00 = 0.30f, kM01 = 1.0f - kM02 - kM00;
+  const float kM12 = 0.078f, kM10 = 0.23f, kM11 = 1.0f - kM12 - kM10;
+  const float kM20 = 0.24342268924547819f, kM21 = 0.20476744424496821f,
+              kM22 = 1.0f - kM20 - kM21;
+  const float bias = 0.0037930732552754493f;
+  const float neg_bias_cbrt = -0.15595420054f;
+  const float mixed0 = fma32(kM00, r, fma32(kM01, g, fma32(kM02, b, bias)));
+  const float mixed1 = fma32(kM10, r, fma32(kM11, g, fma32(kM12, b, bias)));
+  const float mixed2 = fma32(kM20, r, fma32(kM21, g, fma32(kM22, b, bias)));
+  const float tm0 = cube_root_and_add(zero_if_negative(mixed0), neg_bias_cbrt);
+  const float tm1 = cube_root_and_add(zero_if_negative(mixed1), neg_bias_cbrt);
+  const float tm2 = cube_root_and_add(zero_if_negative(mixed2), neg_bias_cbrt);
+  *ox = 0.5f * (tm0 - tm1);
+  *oy = 0.5f * (tm0 + tm1);
+  *ob = tm2;
+}
+
+// ---------------------------------------------------------------------------
+// 1-D DCTs held in registers (enc_transforms-inl.h:292-425, dct_scales.h:82-107)
+// ---------------------------------------------------------------------------
+
+#define JXLT_SQRT2 1.41421356237f
+
+JXLT_DI void dct4(float& m0, float& m1, float& m2, float& m3) {
+  const float kW0 = (float)0.541196100146197, kW1 = (float)1.3065629648763764;
+  const float t0 = m0 + m3, t1 = m1 + m2;
+  const float u0 = t0 + t1, u1 = t0 - t1;
+  const float t2 = (m0 - m3) * kW0, t3 = (m1 - m2) * kW1;
+  float w0 = t2 + t3;
+  const float w1 = t2 - t3;
+  w0 = fma32(w0, JXLT_SQRT2, w1);
+  m0 = u0;
+  m1 = w0;
+  m2 = u1;
+  m3 = w1;
+}
+
+JXLT_DI void dct8(float* m) {
+  const float kW[4] = {(float)0.5097955791041592, (float)0.6013448869350453,
+                       (float)0.8999762231364156, (float)2.5629154477415055};
+  float a0 = m[0] + m[7], a1 = m[1] + m[6], a2 = m[2] + m[5], a3 = m[3] + m[4];
+  dct4(a0, a1, a2, a3);
+  float b0 = (m[0] - m[7]) * kW[0], b1 = (m[1] - m[6]) * kW[1], b2 = (m[2] - m[5]) * kW[2],
+        b3 = (m[3] - m[4]) * kW[3];
+  dct4(b0, b1, b2, b3);
+  b0 = fma32(b0, JXLT_SQRT2, b1);
+  b1 = b1 + b2;
+  b2 = b2 + b3;
+  m[0] = a0; m[1] = b0; m[2] = a1; m[3] = b1;
+  m[4] = a2; m[5] = b2; m[6] = a3; m[7] = b3;
+}
+
+JXLT_DI void dct16(float* m) {
+  const float kW[8] = {(float)0.5024192861881557, (float)0.5224986149396889,
+                       (float)0.5669440348163577, (float)0.6468217833599901,
+                       (float)0.7881546234512502, (float)1.060677685990347,
+                       (float)1.7224470982383342, (float)5.101148618689155};
+  float a[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) a[i] = m[i] + m[15 - i];
+  dct8(a);
+#pragma unroll
+  for (int i = 0; i < 8; i++) b[i] = (m[i] - m[15 - i]) * kW[i];
+  dct8(b);
+  b[0] = fma32(b[0], JXLT_SQRT2, b[1]);
+#pragma unroll
+  for (int i = 1; i < 7; i++) b[i] = b[i] + b[i + 1];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    m[2 * i] = a[i];
+    m[2 * i + 1] = b[i];
+  }
+}
+
+// 8x8 transpose across the 8 lanes of an octet: lane l holds v[j] = M[j][l] and
+// ends with v[j] = M[l][j].  Three butterfly stages, static register indices.
+JXLT_DI void octet_transpose(float* v, int l) {
+#pragma unroll
+  for (int s = 4; s >= 1; s >>= 1) {
+    const bool hi = (l & s) != 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (j & s) continue;
+      const float send = hi ? v[j] : v[j | s];
+      const float recv = __shfl_xor(send, s);
+      if (hi) v[j] = recv; else v[j | s] = recv;
+    }
+  }
+}
+
+// Block transforms.  `px` points at the block's top-left sample in an LDS plane
+// of row pitch `pitch`; l = lane within the octet.  Results are the lane's
+// "rows of 8": coefficient index i = r*8 + l (the reference's SIMD layout).
+
+// ComputeScaledDCT<8,8> (enc_transforms-inl.h:527-546): i = h*8 + v
+JXLT_DI void block_dct8x8(const float* px, int pitch, int l, float* c) {
+#pragma unroll
+  for (int y = 0; y < 8; y++) c[y] = px[y * pitch + l];
+  dct8(c);
+#pragma unroll
+  for (int y = 0; y < 8; y++) c[y] = (1.0f / 8) * c[y];
+  octet_transpose(c, l);  // lane v now holds A[v][x], x = 0..7
+  dct8(c);
+#pragma unroll
+  for (int y = 0; y < 8; y++) c[y] = (1.0f / 8) * c[y];  // c[h] = C[h][v=l]
+}
+
+// ComputeScaledDCT<16,8>: 16 rows x 8 cols, i = h*16 + v; r = 2h + (v>=8), lane = v&7
+JXLT_DI void block_dct16x8(const float* px, int pitch, int l, float* c) {
+  float col[16];
+#pragma unroll
+  for (int y = 0; y < 16; y++) col[y] = px[y * pitch + l];
+  dct16(col);
+  float lo[8], hi[8];
+#pragma unroll
+  for (int v = 0; v < 8; v++) {
+    lo[v] = (1.0f / 16) * col[v];
+    hi[v] = (1.0f / 16) * col[v + 8];
+  }
+  octet_transpose(lo, l);  // lane t: A[t][x]
+  octet_transpose(hi, l);  // lane t: A[t+8][x]
+  dct8(lo);
+  dct8(hi);
+#pragma unroll
+  for (int h = 0; h < 8; h++) {
+    c[2 * h] = (1.0f / 8) * lo[h];
+    c[2 * h + 1] = (1.0f / 8) * hi[h];
+  }
+}
+
+// ComputeScaledDCT<8,16>: 8 rows x 16 cols, i = v*16 + h; r = 2v + (h>=8), lane = h&7
+JXLT_DI void block_dct8x16(const float* px, int pitch, int l, float* c) {
+  float lo[8], hi[8];
+#pragma unroll
+  for (int y = 0; y < 8; y++) {
+    lo[y] = px[y * pitch + l];
+    hi[y] = px[y * pitch + l + 8];
+  }
+  dct8(lo);
+  dct8(hi);
+#pragma unroll
+  for (int v = 0; v < 8; v++) {
+    lo[v] = (1.0f / 8) * lo[v];
+    hi[v] = (1.0f / 8) * hi[v];
+  }
+  octet_transpose(lo, l);  // lane v: A[v][x], x < 8
+  octet_transpose(hi, l);  // lane v: A[v][x], x >= 8
+  float row[16];
+#pragma unroll
+  for (int x = 0; x < 8; x++) {
+    row[x] = lo[x];
+    row[x + 8] = hi[x];
+  }
+  dct16(row);
+#pragma unroll
+  for (int h = 0; h < 8; h++) {
+    lo[h] = (1.0f / 16) * row[h];
+    hi[h] = (1.0f / 16) * row[h + 8];
+  }
+  octet_transpose(lo, l);  // lane t: C[v][h=t], v = 0..7
+  octet_transpose(hi, l);  // lane t: C[v][h=t+8]
+#pragma unroll
+  for (int v = 0; v < 8; v++) {
+    c[2 * v] = lo[v];
+    c[2 * v + 1] = hi[v];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Adaptive quantisation helpers (enc_adaptive_quantization.cc)
+// ---------------------------------------------------------------------------
+
+// :78-104
+JXLT_DI float ratio_of_derivatives(float v, bool invert) {
+  const float kSGmul = 226.0480446705883f;
+  const float kSGmul2 = 1.0f / 73.377132366608819f;
+  const float kLog2 = 0.693147181f;
+  const float kSGRetMul = kSGmul2 * 18.6580932135f * kLog2;
+  const float kSGVOffset = 7.14672470003f;
+  const float kEpsilon = (float)1e-2;
+  v = zero_if_negative(v);
+  const float kNumMul = kSGRetMul * 3 * kSGmul;
+  const float kVOffset = kSGVOffset * kLog2 + kEpsilon;
+  const float kDenMul = kLog2 * kSGmul;
+  const float v2 = v * v;
+  const float num = fma32(kNumMul, v2, kEpsilon);
+  const float den = fma32(kDenMul * v, v2, kVOffset);
+  return invert ? num / den : den / num;
+}
+
+// :287-294.  sqrt(float(kMul * 1e8)) is a constant of the model; it is passed in
+// so that it is computed once (correctly rounded) per thread.
+JXLT_DI float masking_sqrt(float v, float sqrt_mul) {
+  const float kLogOffset = 26.481471032459346f;
+  return 0.25f * sqrtf(fma32(v, sqrt_mul, kLogOffset));
+}
+JXLT_DI float masking_sqrt_mul() {
+  const float kMul = 211.50759899638012f;
+  const float mul_v = (float)(kMul * 1e8);
+  return sqrtf(mul_v);
+}
+
+// :52-75
+JXLT_DI float compute_mask(float out_val) {
+  const float kBase = -0.74174993f, kMul4 = 3.2353257320940401f, kMul2 = 12.906028311180409f,
+              kOffset2 = 305.04035728311436f, kMul3 = 5.0220313103171232f,
+              kOffset3 = 2.1925739705298404f, kMul0 = 0.74760422233706747f;
+  const float kOffset4 = 0.25f * kOffset3;
+  const float v1 = fmaxf(out_val * kMul0, 1e-3f);
+  const float v2 = 1.0f / (v1 + kOffset2);
+  const float v3 = 1.0f / fma32(v1, v1, kOffset3);
+  const float v4 = 1.0f / fma32(v1, v1, kOffset4);
+  return kBase + fma32(kMul4, v4, fma32(kMul2, v2, kMul3 * v3));
+}
+
+// :296-320
+JXLT_DI void store_min4(float v, float& min0, float& min1, float& min2, float& min3) {
+  if (v < min3) {
+    if (v < min0) {
+      min3 = min2; min2 = min1; min1 = min0; min0 = v;
+    } else if (v < min1) {
+      min3 = min2; min2 = min1; min1 = v;
+    } else if (v < min2) {
+      min3 = min2; min2 = v;
+    } else {
+      min3 = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Tile kernel
+// ---------------------------------------------------------------------------
+
+constexpr int kTileThreads = 512;
+constexpr int kHalo = 5;                 // AQ: +-4 px window, +-1 px Laplacian tap
+constexpr int kXYPitch = 64 + 2 * kHalo + 1;  // 75 floats (odd: conflict-free columns)
+constexpr int kBPitch = 65;
+constexpr int kPrePitch = 19;
+constexpr int kCflChunkBlocks = 4;       // blocks per CfL hand-off chunk
+
+struct alignas(16) TileShared {
+  float x[64 * kXYPitch];
+  float y[64 * kXYPitch];
+  float b[64 * kBPitch];
+  float inv_w[576];
+  float y_w[192];          // dequant weights of Y: [0,64) DCT8, [64,192) two-block
+  float rowsum[16 * 72];   // AQ: per 4-row band, per column
+  float pre_erosion[16 * kPrePitch];
+  float erosion[16 * 16];
+  float aq[64];            // quant field (tile-local 8x8)
+  float mask[64];
+  float ent8[16 * 8];      // candidate entropies per 2x2 cell
+  float cfl_terms[2][kCflChunkBlocks * 64 * 4];  // (m_x, s_x, m_b, s_b) per coefficient
+  int cmap[2];             // ytox, ytob
+  uint8_t raw_quant[64];
+  uint8_t strat[64];
+  uint32_t ntok;
+};
+// After the last pixel read the XYB planes are dead and are reused as the
+// staging area for quantised coefficients (64 blocks x 3 channels x 64 int16).
+
+JXLT_DI int imin(int a, int b) { return a < b ? a : b; }
+JXLT_DI int imax(int a, int b) { return a > b ? a : b; }
+
+// Per-octet entropy estimate of one transform (enc_ac_strategy.cc:51-146).
+// cy/cx/cb: the lane's rows of the Y/X/B coefficients; NR rows (8 or 16).
+template <int NR>
+JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb, const float* inv_x,
+                               const float* inv_y, const float* inv_b, int l, float quant,
+                               float masking, float cmap_x, float cmap_b, float distance) {
+  const float num_blocks = (float)(NR / 8);
+  const float kInfoLossMultiplier = 138.0f;
+  const float kInfoLossMultiplier2 = (float)50.46839691767866;
+  const float kCost2 = 4.4628149885273363f;
+  const float kCostDelta = 5.3359184934516337f;
+  const float kZerosMul = 7.565053364251793f;
+  const float slope = fminf(1.0f, distance * (1.0f / 3));
+  const float cost_of_1 = 1 + slope * 8.8703248061477744f;
+  float entropy = 0.0f;
+  float info_loss = 0.0f, info_loss2 = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const float* in_c = c == 0 ? cx : c == 1 ? cy : cb;
+    const float* inv = c == 0 ? inv_x : c == 1 ? inv_y : inv_b;
+    const float cmap_factor = c == 0 ? cmap_x : c == 1 ? 0.0f : cmap_b;
+    float entropy_v = 0.0f, nzeros_v = 0.0f;
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+      const float in = in_c[r];
+      const float in_y = cy[r] * cmap_factor;
+      const float im = inv[r * 8 + l];
+      const float val = (in - in_y) * (im * quant);
+      const float rval = rintf(val);
+      const float diff = fabsf(val - rval);
+      info_loss = info_loss + diff;
+      info_loss2 = fma32(diff, diff, info_loss2);
+      const float q = fabsf(rval);
+      entropy_v = entropy_v + (q >= 1.5f ? kCost2 : 0.0f);
+      entropy_v = fma32(sqrtf(q), kCostDelta, entropy_v);
+      nzeros_v = nzeros_v + (q == 0.0f ? 0.0f : 1.0f);
+    }
+    entropy_v = fma32(nzeros_v, cost_of_1, entropy_v);
+    entropy += octet_sum(entropy_v);
+    const uint32_t num_nzeros = (uint32_t)octet_sum(nzeros_v);
+    const uint32_t nbits = (uint32_t)ceil_log2_nonzero(num_nzeros + 1) + 1;
+    entropy += kZerosMul * (float)(ceil_log2_nonzero(nbits + 17) + nbits);
+  }
+  const float infoloss = octet_sum(info_loss);
+  const float infoloss2 = sqrtf(num_blocks * octet_sum(info_loss2));
+  const float info_loss_score = (kInfoLossMultiplier * infoloss + kInfoLossMultiplier2 * infoloss2);
+  return entropy + masking * info_loss_score;
+}
+
+// enc_group.cc:186-218
+JXLT_DI float adjust_quant_bias_y(int32_t quant_i) {
+  const float kBias1 = 1.0f - 0.07005449891748593f;  // kDefaultQuantBias[1]
+  const float kBias3 = 0.145f;
+  const float quant = (float)quant_i;
+  const uint32_t sign = __float_as_uint(quant) & 0x80000000u;
+  const float abs_quant = __uint_as_float(__float_as_uint(quant) & 0x7FFFFFFFu);
+  const bool is_01 = abs_quant < 1.125f;
+  const bool not_0 = abs_quant > 0.0f;
+  const float one_bias = not_0 ? __uint_as_float(__float_as_uint(kBias1) ^ sign) : 0.0f;
+  const float bias = nfma32(kBias3, 1.0f / quant, quant);
+  return is_01 ? one_bias : bias;
+}
+
+// enc_group.cc:221-278 for the lane's rows.  NR = 8: xsize=ysize=1; NR = 16: xsize=2, ysize=1.
+template <int NR>
+JXLT_DI void quantize_rows(const float* in, int c, const float* inv, int l, float quantv, int* out) {
+  float thres[4] = {0.58f, 0.635f, 0.66f, 0.7f};
+  if (c == 0) {
+    thres[1] += 0.08f; thres[2] += 0.08f; thres[3] += 0.08f;
+  }
+  if (c == 2) {
+    thres[1] = 0.75f; thres[2] = 0.75f; thres[3] = 0.75f;
+  }
+  if (NR == 16) {
+    const float dec = 0.003f * 2 * 1;  // Clamp1(0.003f*xsize*ysize, 0, 0.08|0.12)
+#pragma unroll
+    for (int i = 0; i < 4; i++) thres[i] -= dec;
+  }
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    int tix;
+    if (NR == 8) tix = (r >= 4 ? 2 : 0) + (l >= 4 ? 1 : 0);
+    else tix = ((r >> 1) >= 4 ? 2 : 0) + (r & 1);
+    const float thr = thres[tix];
+    const float q = inv[r * 8 + l] * quantv;
+    const float val = q * in[r];
+    const bool nz = fabsf(val) >= thr;
+    out[r] = nz ? (int)rintf(val) : 0;
+  }
+}
+
+// Quantise + DC + nzeros for one transform held in registers, then stage the
+// quantised coefficients (natural layout) in LDS.  enc_group.cc:392-443.
+// slot_a / slot_b: staging bases (3 x 64 int16 each) for i < 64 / i >= 64.
+template <int NR>
+JXLT_DI void quantize_transform(float* cx, float* cy, float* cb, const TileShared& S, int strategy,
+                                int l, int quant_ac, const TileArgs& A, float x_factor,
+                                float b_factor, int ibx, int iby, int16_t* slot_a, int16_t* slot_b) {
+  const DeviceTables* T = A.tab;
+  const int kind_off = strategy * 3;
+  const float* inv_x = S.inv_w + T->table_offset[kind_off + 0];
+  const float* inv_y = S.inv_w + T->table_offset[kind_off + 1];
+  const float* inv_b = S.inv_w + T->table_offset[kind_off + 2];
+  const float* ydq = S.y_w + (NR == 8 ? 0 : 64);
+  const float kInvDCQuant[3] = {4096.0f, 512.0f, 256.0f};
+  const float kScale1 = (float)0.901764195028874394;
+  const float qac = A.scale * quant_ac;
+  const size_t bstride = (size_t)A.g.xsize_blocks;
+  const size_t pos0 = (size_t)iby * bstride + ibx;
+  const size_t pos1 = pos0 + (strategy == 1 ? bstride : 1);
+
+  // --- Y: DC from the unquantised transform, then quantise + roundtrip (:392-409)
+  float dc_a, dc_b = 0.0f;
+  {
+    const float c0 = __shfl(cy[0], (int)(threadIdx.x & 56) | 0, 64);
+    const float c1 = __shfl(cy[0], (int)(threadIdx.x & 56) | 1, 64);
+    if (NR == 8) {
+      dc_a = c0;
+    } else {
+      const float b0 = c0 * 1.0f * 1.0f, b1 = c1 * 1.0f * kScale1;
+      dc_a = b0 + b1;
+      dc_b = b0 - b1;
+    }
+  }
+  const float inv_factor_y = kInvDCQuant[1] * A.scale_dc;
+  const int16_t dcy_a = (int16_t)roundf(inv_factor_y * dc_a);
+  const int16_t dcy_b = (int16_t)roundf(inv_factor_y * dc_b);
+  if (l == 0) {
+    A.quant_dc[1][pos0] = dcy_a;
+    if (NR == 16) A.quant_dc[1][pos1] = dcy_b;
+  }
+  int qy[NR], qx[NR], qb[NR];
+  quantize_rows<NR>(cy, 1, inv_y, l, qac * 1.0f, qy);
+  const float inv_qac = T->inv_qac[quant_ac];
+#pragma unroll
+  for (int r = 0; r < NR; r++) cy[r] = (adjust_quant_bias_y(qy[r]) * ydq[r * 8 + l]) * inv_qac;
+
+  // --- X, B: undo colour correlation with the roundtripped Y (:417-425), quantise, DC
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    cx[r] = nfma32(x_factor, cy[r], cx[r]);
+    cb[r] = nfma32(b_factor, cy[r], cb[r]);
+  }
+  quantize_rows<NR>(cx, 0, inv_x, l, qac * A.x_qm_mul, qx);
+  quantize_rows<NR>(cb, 2, inv_b, l, qac * (float)1.0, qb);
+#pragma unroll
+  for (int c = 0; c <= 2; c += 2) {
+    const float* cc = c == 0 ? cx : cb;
+    const float c0 = __shfl(cc[0], (int)(threadIdx.x & 56) | 0, 64);
+    const float c1 = __shfl(cc[0], (int)(threadIdx.x & 56) | 1, 64);
+    float d_a, d_b = 0.0f;
+    if (NR == 8) {
+      d_a = c0;
+    } else {
+      const float b0 = c0 * 1.0f * 1.0f, b1 = c1 * 1.0f * kScale1;
+      d_a = b0 + b1;
+      d_b = b0 - b1;
+    }
+    const float inv_factor = kInvDCQuant[c] * A.scale_dc;
+    const float cfl_factor = c == 0 ? 0.0f : kInvDCQuant[2] * (1.0f / kInvDCQuant[1]);
+    if (l == 0) {
+      A.quant_dc[c][pos0] = (int16_t)roundf(d_a * inv_factor - dcy_a * cfl_factor);
+      if (NR == 16) A.quant_dc[c][pos1] = (int16_t)roundf(d_b * inv_factor - dcy_b * cfl_factor);
+    }
+  }
+
+  // --- nzeros (enc_group.cc:51-148) and staging
+  const int covered = NR / 8;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const int* q = c == 0 ? qx : c == 1 ? qy : qb;
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+      const bool llf = (r == 0) && (l < covered);
+      cnt += (!llf && q[r] != 0) ? 1 : 0;
+      int16_t* dst = (r * 8 + l < 64) ? slot_a : slot_b;
+      dst[c * 64 + ((r * 8 + l) & 63)] = (int16_t)q[r];
+    }
+    const int nzeros = octet_sum_int(cnt);
+    if (l == 0) {
+      A.blk_nz[pos0 * 3 + c] = (uint8_t)nzeros;
+      if (NR == 8) {
+        A.nzgrid[c][pos0] = (uint8_t)nzeros;
+      } else {
+        const uint8_t shifted = (uint8_t)((nzeros + 1) >> 1);
+        A.nzgrid[c][pos0] = shifted;
+        A.nzgrid[c][pos1] = shifted;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A) {
+  __shared__ TileShared S;
+  const int tid = (int)threadIdx.x;
+  const int l = tid & 7;    // lane within octet
+  const int oct = tid >> 3;  // octet index == block index within tile (0..63)
+  const DeviceTables* T = A.tab;
+
+  // ---- geometry (enc_frame.cc:716-751) ------------------------------------
+  const int tile_id = (int)blockIdx.x;
+  const int tx_img = tile_id % A.g.xsize_tiles, ty_img = tile_id / A.g.xsize_tiles;
+  const int gx = tx_img >> 2;
+  const int sx0 = gx * 256, sy0 = ty_img * 64;            // stripe origin (pixels)
+  const int sw = imin(256, A.g.xsize - sx0), sh = imin(64, A.g.ysize - sy0);
+  const int swp = (sw + 7) & ~7, shp = (sh + 7) & ~7;       // padded stripe size
+  const int tbx0 = (tx_img & 3) * 8;                        // tile origin in stripe blocks
+  const int nbx = imin(8, swp / 8 - tbx0), nby = shp / 8;   // tile size in blocks
+  const int px0 = tbx0 * 8;                                 // tile origin in stripe pixels
+  const int bx_img0 = gx * 32 + tbx0, by_img0 = ty_img * 8; // image-absolute block origin
+  const int obx = oct & 7, oby = oct >> 3;                  // octet's block in the tile
+  const bool blk_valid = obx < nbx && oby < nby;
+  const size_t bstride = (size_t)A.g.xsize_blocks;
+
+  // ---- P0: tables -> LDS; load + XYB (enc_frame.cc:597-617, enc_xyb.cc) -----
+  for (int i = tid; i < 576; i += kTileThreads) S.inv_w[i] = T->inv_weights[i];
+  if (tid < 64) S.y_w[tid] = T->weights[T->table_offset[1] + tid];
+  if (tid < 128) S.y_w[64 + tid] = T->weights[T->table_offset[4] + tid];
+  if (tid == 0) S.ntok = 0;
+  {
+    const int base = px0 - kHalo;  // stripe x of LDS column 0
+    for (int i = tid; i < 64 * (64 + 2 * kHalo); i += kTileThreads) {
+      const int y = i / (64 + 2 * kHalo), cx = i % (64 + 2 * kHalo);
+      const int x = base + cx;
+      if (y >= shp || x < 0 || x >= swp || x >= px0 + nbx * 8 + kHalo) continue;
+      const size_t src = (size_t)(sy0 + imin(y, sh - 1)) * A.pitch + (size_t)(sx0 + imin(x, sw - 1));
+      float vx, vy, vb;
+      linear_to_xyb(A.planes[0][src], A.planes[1][src], A.planes[2][src], &vx, &vy, &vb);
+      S.x[y * kXYPitch + cx] = vx;
+      S.y[y * kXYPitch + cx] = vy;
+      if (cx >= kHalo && cx < kHalo + 64) S.b[y * kBPitch + cx - kHalo] = vb;
+      if (A.dbg_xyb[0] && cx >= kHalo && cx < kHalo + nbx * 8) {
+        const size_t d = (size_t)(by_img0 * 8 + y) * (bstride * 8) + (size_t)(bx_img0 * 8 + cx - kHalo);
+        A.dbg_xyb[0][d] = vx;
+        A.dbg_xyb[1][d] = vy;
+        A.dbg_xyb[2][d] = vb;
+      }
+    }
+  }
+  __syncthreads();
+  // LDS column of stripe pixel x is (x - px0 + kHalo).
+#define SX(yy, xx) S.x[(yy) * kXYPitch + ((xx) - px0 + kHalo)]
+#define SY(yy, xx) S.y[(yy) * kXYPitch + ((xx) - px0 + kHalo)]
+
+  // ---- P1: AQ per-pixel masked Laplacian energy, summed over 4-row bands ----
+  // (enc_adaptive_quantization.cc:376-483)
+  int aq_x0 = px0, aq_x1 = px0 + nbx * 8;
+  if (aq_x0 != 0) aq_x0 -= 4;
+  if (aq_x1 != swp) aq_x1 += 4;
+  const int aq_w = aq_x1 - aq_x0;  // <= 72
+  {
+    const float match_gamma_offset = (float)0.019;
+    const float kXMul = 23.426802998210313f;
+    const float sqrt_mul = masking_sqrt_mul();
+    // Positions handled by the reference's 8-lane vector loop: [vs, ve).
+    const int vs = aq_x0 == 0 ? 1 : aq_x0;
+    const int nvec = (aq_x1 - 10 >= vs) ? ((aq_x1 - 10 - vs) / 8 + 1) : 0;
+    const int ve = vs + 8 * nvec;
+    const int nbands = nby * 2;
+    for (int i = tid; i < nbands * aq_w; i += kTileThreads) {
+      const int q = i / aq_w, x = aq_x0 + i % aq_w;
+      const bool vec = x >= vs && x < ve;
+      const int xl = x > 0 ? x - 1 : x, xr = x + 1 < swp ? x + 1 : x;
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int y = q * 4 + k;
+        const int yu = y > 0 ? y - 1 : y, yd = y + 1 < shp ? y + 1 : y;
+        const float in = SY(y, x), in_l = SY(y, xl), in_r = SY(y, xr), in_u = SY(yu, x), in_d = SY(yd, x);
+        const float base = vec ? 0.25f * ((in_r + in_l) + (in_d + in_u))
+                               : 0.25f * (in_d + in_u + in_l + in_r);
+        const float gammac = ratio_of_derivatives(in + match_gamma_offset, false);
+        float diff = gammac * (in - base);
+        diff = diff * diff;
+        const float ix = SX(y, x), ix_l = SX(y, xl), ix_r = SX(y, xr), ix_u = SX(yu, x), ix_d = SX(yd, x);
+        const float base_x = vec ? 0.25f * ((ix_r + ix_l) + (ix_d + ix_u))
+                                 : 0.25f * (ix_d + ix_u + ix_l + ix_r);
+        float diff_x = gammac * (ix - base_x);
+        diff_x = diff_x * diff_x;
+        diff = vec ? fma32(kXMul, diff_x, diff) : diff + kXMul * diff_x;
+        diff = masking_sqrt(diff, sqrt_mul);
+        acc = (k == 0) ? diff : acc + diff;
+      }
+      S.rowsum[q * 72 + (x - aq_x0)] = acc;
+    }
+  }
+  __syncthreads();
+  // ---- P2: 4-column average -> pre_erosion (:484-491) ------------------------
+  const int pre_xs = aq_w / 4, pre_ys = nby * 2;
+  for (int i = tid; i < pre_ys * pre_xs; i += kTileThreads) {
+    const int q = i / pre_xs, j = i % pre_xs;
+    const float* r = &S.rowsum[q * 72 + j * 4];
+    S.pre_erosion[q * kPrePitch + j] = (r[0] + r[1] + r[2] + r[3]) * 0.25f;
+  }
+  __syncthreads();
+  // ---- P3: fuzzy erosion (:322-374) ------------------------------------------
+  {
+    const int rx0 = (aq_x0 % 8 == 0) ? 0 : 1;
+    const int exs = nbx * 2, eys = nby * 2;
+    for (int i = tid; i < exs * eys; i += kTileThreads) {
+      const int fy = i / exs, fx = i % exs;
+      const int y = fy, x = fx + rx0;
+      const int ym1 = y >= 1 ? y - 1 : y, yp1 = y + 1 < pre_ys ? y + 1 : y;
+      const int xm1 = x >= 1 ? x - 1 : x, xp1 = x + 1 < pre_xs ? x + 1 : x;
+      const float* rowt = &S.pre_erosion[ym1 * kPrePitch];
+      const float* row = &S.pre_erosion[y * kPrePitch];
+      const float* rowb = &S.pre_erosion[yp1 * kPrePitch];
+      float min0 = row[x], min1 = row[xm1], min2 = row[xp1], min3 = rowt[xm1], t;
+#define JXLT_SWAP_GT(a, b) if (a > b) { t = a; a = b; b = t; }
+      JXLT_SWAP_GT(min0, min1);
+      JXLT_SWAP_GT(min0, min2);
+      JXLT_SWAP_GT(min0, min3);
+      JXLT_SWAP_GT(min1, min2);
+      JXLT_SWAP_GT(min1, min3);
+      JXLT_SWAP_GT(min2, min3);
+#undef JXLT_SWAP_GT
+      store_min4(rowt[x], min0, min1, min2, min3);
+      store_min4(rowt[xp1], min0, min1, min2, min3);
+      store_min4(rowb[xm1], min0, min1, min2, min3);
+      store_min4(rowb[x], min0, min1, min2, min3);
+      store_min4(rowb[xp1], min0, min1, min2, min3);
+      const float kMul = 0.05f;
+      S.erosion[fy * 16 + fx] = kMul * row[x] + kMul * min0 + kMul * min1 + kMul * min2 + kMul * min3;
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int by = tid >> 3, bx = tid & 7;
+    if (bx < nbx && by < nby) {
+      const float* e = &S.erosion[(2 * by) * 16 + 2 * bx];
+      const float v = ((e[0] + e[1]) + e[16]) + e[17];
+      S.aq[tid] = v;
+      S.mask[tid] = 1.0f / (v + 0.001f);  // ComputeMaskForAcStrategyUse (:46-50)
+    } else {
+      S.aq[tid] = 0.0f;
+      S.mask[tid] = 0.0f;
+    }
+  }
+  __syncthreads();
+  // ---- P4: per-block modulations, one octet per block (:114-285) -------------
+  {
+    float out_val = 0.0f;
+    const int bxp = px0 + obx * 8, byp = oby * 8;  // block origin (stripe pixels)
+    if (blk_valid) {
+      out_val = compute_mask(S.aq[oct]);
+    }
+    // HfModulation (:209-247): lane l = column l of the block
+    float hf = 0.0f, red = 0.0f, blue = 0.0f, gam = 0.0f;
+    const float kBias = 0.16f;
+    const float kRedRampStart = (float)0.0073200141118951231;
+    const float kRedRampLength = (float)0.019421555948474039;
+    const float kBlueRampLength = (float)0.086890611400405895;
+    const float kBlueRampStart = (float)0.26973418507870539;
+    if (blk_valid) {
+#pragma unroll
+      for (int dy = 0; dy < 8; dy++) {
+        const int yy = byp + dy, xx = bxp + l;
+        const float p = SY(yy, xx);
+        const float right = (l < 7) ? fabsf(p - SY(yy, xx + 1)) : 0.0f;
+        hf = hf + right;
+        const float pd = (dy == 7) ? p : SY(yy + 1, xx);
+        hf = hf + fabsf(p - pd);
+        // ColorModulation (:146-207)
+        const float vx = SX(yy, xx);
+        const float vb = S.b[yy * kBPitch + obx * 8 + l];
+        const float pixel_x = fmaxf(0.0f, vx - kRedRampStart);
+        const float pixel_b = fmaxf(0.0f, vb - (p + kBlueRampStart));
+        red = red + fminf(pixel_x, kRedRampLength);
+        blue = blue + fminf(pixel_b, kBlueRampLength);
+        // GammaModulation (:114-144)
+        const float iny = p + kBias;
+        const float rr = iny - vx, gg = iny + vx;
+        const float ratio_r = ratio_of_derivatives(rr, true);
+        const float ratio_g = ratio_of_derivatives(gg, true);
+        gam = gam + 0.5f * (ratio_r + ratio_g);
+      }
+    }
+    hf = octet_sum(hf);
+    red = octet_sum(red);
+    blue = octet_sum(blue);
+    gam = octet_sum(gam);
+    if (blk_valid) {
+      out_val = fma32(hf, -2.0052193233688884f / 112, out_val);
+      {
+        const float kStrengthMul = (float)2.177823400325309;
+        const double butteraugli_target = (double)A.distance;
+        const float strength = (float)(kStrengthMul * (1.0f - 0.25f * butteraugli_target));
+        if (!(strength < 0)) {
+          const float red_strength = strength * 5.992297772961519f;
+          const float blue_strength = strength;
+          const float offset = strength * -0.009174542291185913f;
+          out_val = out_val + offset;
+          const float ratio = 30.610615782142737f;
+          float overall_red = fminf(red, ratio * kRedRampLength);
+          overall_red = overall_red * (red_strength / ratio);
+          float overall_blue = fminf(blue, ratio * kBlueRampLength);
+          overall_blue = overall_blue * (blue_strength / ratio);
+          out_val = overall_red + (overall_blue + out_val);
+        }
+      }
+      {
+        const float overall_ratio = gam * (1.0f / 64);
+        const float kGam = -0.15526878023684174f * 0.693147180559945f;
+        out_val = fma32(kGam, fast_log2f(overall_ratio), out_val);
+      }
+      // PerBlockModulations tail (:249-285) + raw quant (:518-534)
+      const float kAcQuant = 0.8294f;
+      const float scale = kAcQuant / A.distance;
+      const float base_level = 0.5f * scale;
+      float dampen = 1.0f;
+      if (A.distance >= 7.0f) {
+        dampen = 1.0f - ((A.distance - 7.0f) / (14.0f - 7.0f));
+        if (dampen < 0) dampen = 0;
+      }
+      const float mul = scale * dampen;
+      const float add = (1.0f - dampen) * base_level;
+      const float qf = fast_pow2f(out_val * 1.442695041f) * mul + add;
+      if (l == 0) {
+        S.aq[oct] = qf;
+        int v = (int)(qf * A.inv_scale + 0.5f);
+        v = v < 1 ? 1 : v > 255 ? 255 : v;
+        S.raw_quant[oct] = (uint8_t)v;
+        S.strat[oct] = 1;  // DCT8, first block (FillDCT8)
+        if (A.dbg_qf) {
+          const size_t pos = (size_t)(by_img0 + oby) * bstride + bx_img0 + obx;
+          A.dbg_qf[pos] = qf;
+          A.dbg_mask[pos] = S.mask[oct];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- P5: DCT8 of every block (kept in registers) + chroma-from-luma -------
+  // (enc_chroma_from_luma.cc:40-131)
+  float c8x[8], c8y[8], c8b[8];
+  {
+    const float* pxp = &S.x[(oby * 8) * kXYPitch + obx * 8 + kHalo];
+    const float* pyp = &S.y[(oby * 8) * kXYPitch + obx * 8 + kHalo];
+    const float* pbp = &S.b[(oby * 8) * kBPitch + obx * 8];
+    if (blk_valid) {
+      block_dct8x8(pxp, kXYPitch, l, c8x);
+      block_dct8x8(pyp, kXYPitch, l, c8y);
+      block_dct8x8(pbp, kBPitch, l, c8b);
+    } else {
+      // (cross-lane traffic never leaves an octet, so idle octets may skip it)
+#pragma unroll
+      for (int r = 0; r < 8; r++) { c8x[r] = 0; c8y[r] = 0; c8b[r] = 0; }
+    }
+  }
+  {
+    // Sequential per-lane fma chains over the tile's blocks in raster order; the
+    // terms are handed to wave 0 through LDS in chunks of kCflChunkBlocks blocks.
+    const float* qm_x = S.inv_w + 0;        // InvMatrix(DCT, 0)
+    const float* qm_b = S.inv_w + 128;      // InvMatrix(DCT, 2)
+    const int nblk = nbx * nby;             // valid blocks, raster order index
+    const int my_seq = blk_valid ? oby * nbx + obx : -1;
+    const int nchunks = (nblk + kCflChunkBlocks - 1) / kCflChunkBlocks;
+    float ca = 0.0f, cb = 0.0f;             // tid < 32: chain (stream = tid>>4, kind = (tid>>3)&1)
+    for (int ch = 0; ch <= nchunks; ch++) {
+      // Phase ch: the octets of chunk ch publish their terms into buffer ch&1
+      // while the chain lanes consume chunk ch-1 from buffer (ch-1)&1.
+      if (ch < nchunks && my_seq >= ch * kCflChunkBlocks && my_seq < (ch + 1) * kCflChunkBlocks) {
+        float* dst = &S.cfl_terms[ch & 1][(my_seq - ch * kCflChunkBlocks) * 256];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          const bool dc = (r == 0 && l == 0);  // block_*[0] = 0 (:109-111)
+          const float by_ = dc ? 0.0f : c8y[r], bx_ = dc ? 0.0f : c8x[r], bb_ = dc ? 0.0f : c8b[r];
+          const float qx = qm_x[r * 8 + l], qb = qm_b[r * 8 + l];
+          float4 t;
+          t.x = by_ * qx;  // coeffs_yx
+          t.y = bx_ * qx;  // coeffs_x
+          t.z = by_ * qb;  // coeffs_yb
+          t.w = bb_ * qb;  // coeffs_b
+          *(float4*)&dst[(r * 8 + l) * 4] = t;
+        }
+      }
+      if (ch >= 1 && tid < 16) {
+        // chunk ch-1: lanes 0-7 -> X stream, 8-15 -> B stream; each runs ca and cb.
+        const int stream = tid >> 3;
+        const float base = stream == 0 ? 0.0f : 1.0f;
+        const float kInvColorFactor = 1.0f / 84;
+        const int cbeg = (ch - 1) * kCflChunkBlocks;
+        const int cn = imin(kCflChunkBlocks, nblk - cbeg);
+        const float* src = &S.cfl_terms[(ch - 1) & 1][0];
+        for (int k = 0; k < cn * 8; k++) {
+          const float4 t = *(const float4*)&src[(k * 8 + l) * 4];
+          const float m = stream == 0 ? t.x : t.z;
+          const float sv = stream == 0 ? t.y : t.w;
+          const float a = kInvColorFactor * m;
+          const float b = base * m - sv;
+          ca = fma32(a, a, ca);
+          cb = fma32(a, b, cb);
+        }
+      }
+      __syncthreads();
+    }
+    // FindBestMultiplier tail (:56-61)
+    const float sum_ca = octet_sum(ca), sum_cb = octet_sum(cb);
+    if (tid < 16 && l == 0) {
+      const float kDistanceMultiplierAC = 1e-3f;
+      const float num = (float)(nblk * 64);
+      float xq = -sum_cb / (sum_ca + num * kDistanceMultiplierAC * 0.5f);
+      xq = fmaxf(-128.0f, fminf(127.0f, roundf(xq)));
+      S.cmap[tid >> 3] = (int)xq;
+    }
+  }
+  __syncthreads();
+  const int ytox = S.cmap[0], ytob = S.cmap[1];
+  const float kInvColorFactorF = 1.0f / 84;
+  const float cmap_x = (float)ytox * kInvColorFactorF;           // YtoXRatio
+  const float cmap_b = 1.0f + (float)ytob * kInvColorFactorF;    // YtoBRatio
+  if (tid == 0) {
+    A.ytox[(size_t)ty_img * A.g.xsize_tiles + tx_img] = (int8_t)ytox;
+    A.ytob[(size_t)ty_img * A.g.xsize_tiles + tx_img] = (int8_t)ytob;
+  }
+
+  // ---- P6: strategy search (enc_ac_strategy.cc:51-238) ----------------------
+  // Candidate two-block transforms: waves 0-3 take the 32 DCT16X8 candidates,
+  // waves 4-7 the 32 DCT8X16 candidates; coefficients stay in registers for P8.
+  float c16x[16], c16y[16], c16b[16];
+  const bool search = (A.flags & 1u) == 0;
+  const int cand = oct & 31;           // candidate index within its type
+  const int cell = cand >> 1;          // 2x2 cell index (4x4 cells per tile)
+  const int ccx = (cell & 3) * 2, ccy = (cell >> 2) * 2;  // cell origin (tile blocks)
+  const bool is_tall = oct < 32;       // DCT16X8 (16 rows x 8 cols)
+  const int cbx = is_tall ? ccx + (cand & 1) : ccx;       // candidate's first block
+  const int cby = is_tall ? ccy : ccy + (cand & 1);
+  const bool cell_valid = search && (ccx + 1 < nbx) && (ccy + 1 < nby);
+  if (search) {
+    // DCT8 estimate for this octet's own block
+    if (blk_valid) {
+      const float e = estimate_entropy<8>(c8x, c8y, c8b, S.inv_w + 0, S.inv_w + 64, S.inv_w + 128, l,
+                                          fmaxf(0.0f, S.aq[oct]), fmaxf(0.0f, S.mask[oct]), cmap_x, cmap_b,
+                                          A.distance);
+      const float k8x8mul1 = (float)(-0.55 * 0.75f);
+      const float k8x8mul2 = 1.0735757687292623f * 0.75f;
+      const float k8x8base = (float)1.4;
+      const float mul8x8 = k8x8mul2 + k8x8mul1 / (A.distance + k8x8base);
+      float e8 = 3.0f * mul8x8;
+      e8 += mul8x8 * e;
+      if (l == 0) S.ent8[((oby >> 1) * 4 + (obx >> 1)) * 8 + (oby & 1) * 2 + (obx & 1)] = e8;
+    }
+    // Two-block candidate
+    if (cell_valid) {
+      const float* pxp = &S.x[(cby * 8) * kXYPitch + cbx * 8 + kHalo];
+      const float* pyp = &S.y[(cby * 8) * kXYPitch + cbx * 8 + kHalo];
+      const float* pbp = &S.b[(cby * 8) * kBPitch + cbx * 8];
+      if (is_tall) {
+        block_dct16x8(pxp, kXYPitch, l, c16x);
+        block_dct16x8(pyp, kXYPitch, l, c16y);
+        block_dct16x8(pbp, kBPitch, l, c16b);
+      } else {
+        block_dct8x16(pxp, kXYPitch, l, c16x);
+        block_dct8x16(pyp, kXYPitch, l, c16y);
+        block_dct8x16(pbp, kBPitch, l, c16b);
+      }
+      const int o2 = is_tall ? 8 : 1;  // second covered block in the 8x8 tile grid
+      const int bi = cby * 8 + cbx;
+      const float quant = fmaxf(fmaxf(0.0f, S.aq[bi]), S.aq[bi + o2]);
+      const float masking = fmaxf(fmaxf(0.0f, S.mask[bi]), S.mask[bi + o2]);
+      const int toff = is_tall ? 3 : 6;
+      const float e = estimate_entropy<16>(c16x, c16y, c16b, S.inv_w + T->table_offset[toff],
+                                           S.inv_w + T->table_offset[toff + 1],
+                                           S.inv_w + T->table_offset[toff + 2], l, quant, masking,
+                                           cmap_x, cmap_b, A.distance);
+      const float k8X16mul1 = (float)-0.55, k8X16mul2 = (float)0.9019587899705066,
+                  k8X16base = (float)1.6;
+      const float mul16x8 = k8X16mul2 + k8X16mul1 / (A.distance + k8X16base);
+      if (l == 0) S.ent8[cell * 8 + (is_tall ? 4 : 6) + (cand & 1)] = mul16x8 * e;
+    }
+  }
+  __syncthreads();
+  // ---- P7: decision (:213-237) + AdjustQuantField (:240-266) ------------------
+  if (search && tid < 16) {
+    const int cx = (tid & 3) * 2, cy = (tid >> 2) * 2;
+    if (cx + 1 < nbx && cy + 1 < nby) {
+      const float* e = &S.ent8[tid * 8];
+      const float e00 = e[0], e01 = e[1], e10 = e[2], e11 = e[3];
+      const float l16 = e[4], r16 = e[5], t16 = e[6], b16 = e[7];
+      const float cost16x8 = fminf(l16, e00 + e10) + fminf(r16, e01 + e11);
+      const float cost8x16 = fminf(t16, e00 + e01) + fminf(b16, e10 + e11);
+      const int b00 = cy * 8 + cx;
+      if (cost16x8 < cost8x16) {
+        if (l16 < e00 + e10) { S.strat[b00] = (1 << 1) | 1; S.strat[b00 + 8] = (1 << 1); }
+        if (r16 < e01 + e11) { S.strat[b00 + 1] = (1 << 1) | 1; S.strat[b00 + 9] = (1 << 1); }
+      } else {
+        if (t16 < e00 + e01) { S.strat[b00] = (2 << 1) | 1; S.strat[b00 + 1] = (2 << 1); }
+        if (b16 < e10 + e11) { S.strat[b00 + 8] = (2 << 1) | 1; S.strat[b00 + 9] = (2 << 1); }
+      }
+      if (A.dbg_ent8) {
+        const size_t cells_x = (size_t)A.g.xsize_blocks / 2 + 1;
+        float* d = A.dbg_ent8 + (((size_t)(by_img0 + cy) / 2) * cells_x + (size_t)(bx_img0 + cx) / 2) * 8;
+        for (int k = 0; k < 8; k++) d[k] = e[k];
+      }
+      // AdjustQuantField for the cell's transforms
+      for (int k = 0; k < 4; k++) {
+        const int bi = b00 + (k >> 1) * 8 + (k & 1);
+        const uint8_t a = S.strat[bi];
+        if (!(a & 1) || (a >> 1) == 0) continue;
+        const int o2 = (a >> 1) == 1 ? 8 : 1;
+        const uint8_t m = S.raw_quant[bi] > S.raw_quant[bi + o2] ? S.raw_quant[bi] : S.raw_quant[bi + o2];
+        S.raw_quant[bi] = m;
+        S.raw_quant[bi + o2] = m;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 64 && (tid & 7) < nbx && (tid >> 3) < nby) {
+    const size_t pos = (size_t)(by_img0 + (tid >> 3)) * bstride + bx_img0 + (tid & 7);
+    A.strategy[pos] = S.strat[tid];
+    A.raw_quant[pos] = S.raw_quant[tid];
+  }
+  // All pixel reads are done (transforms live in registers): from here on the
+  // XYB planes are reused as the quantised-coefficient staging area.
+  __syncthreads();
+  int16_t* stage = reinterpret_cast<int16_t*>(&S.x[0]);  // [64 blocks][3][64]
+
+  // ---- P8: quantise (enc_group.cc:304-443) -----------------------------------
+  {
+    // (a) this octet's own block, if it stayed DCT8
+    const bool do8 = blk_valid && S.strat[oct] == 1;
+    if (do8) {
+      quantize_transform<8>(c8x, c8y, c8b, S, 0, l, S.raw_quant[oct], A, cmap_x, cmap_b,
+                            bx_img0 + obx, by_img0 + oby, stage + oct * 192, stage + oct * 192);
+    }
+    // (b) this octet's two-block candidate, if it was selected
+    const int bi = cby * 8 + cbx;
+    const bool do16 = cell_valid && S.strat[bi] == (uint8_t)(((is_tall ? 1 : 2) << 1) | 1);
+    if (do16) {
+      const int o2 = is_tall ? 8 : 1;
+      quantize_transform<16>(c16x, c16y, c16b, S, is_tall ? 1 : 2, l, S.raw_quant[bi], A, cmap_x,
+                             cmap_b, bx_img0 + cbx, by_img0 + cby, stage + bi * 192,
+                             stage + (bi + o2) * 192);
+    }
+  }
+  __syncthreads();
+
+  // ---- P9: scan-order store; one wave per (block, channel) --------------------
+  {
+    const int wave = tid >> 6, lane = tid & 63;
+    uint32_t my_tokens = 0;
+    for (int item = wave; item < 64 * 3; item += kTileThreads / 64) {
+      const int bi = item / 3, c = item % 3;
+      const int bx = bi & 7, by = bi >> 3;
+      if (bx >= nbx || by >= nby) continue;
+      const uint8_t a = S.strat[bi];
+      if (!(a & 1)) continue;
+      const int st = a >> 1;
+      const int covered = st == 0 ? 1 : 2;
+      const int o2 = st == 1 ? 8 : 1;
+      const uint8_t* order = &T->coeff_order[st == 0 ? 0 : 64];
+      const size_t pos0 = (size_t)(by_img0 + by) * bstride + bx_img0 + bx;
+      const size_t pos1 = pos0 + (st == 1 ? bstride : 1);
+      int nscan = 0;
+      for (int half = 0; half < covered; half++) {
+        const int k = half * 64 + lane;
+        const int i = order[k];
+        const int16_t v = (i < 64 ? stage[bi * 192 + c * 64 + i] : stage[(bi + o2) * 192 + c * 64 + i - 64]);
+        const bool nz = (k >= covered) && v != 0;
+        const unsigned long long m = __ballot(nz);
+        if (m != 0) nscan = half * 64 + (64 - __clzll((long long)m));
+        int16_t* dst = A.coef_scan + ((half == 0 ? pos0 : pos1) * 3 + c) * 64;
+        dst[lane] = v;
+      }
+      if (lane == 0) {
+        A.blk_nscan[pos0 * 3 + c] = (uint8_t)nscan;
+        my_tokens += 1 + (nscan > covered ? nscan - covered : 0);
+      }
+    }
+    if (lane == 0 && my_tokens) atomicAdd(&S.ntok, my_tokens);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int group = (ty_img >> 2) * A.g.xsize_groups + gx;
+    atomicAdd(&A.group_ntok[group], S.ntok);
+  }
+#undef SX
+#undef SY
+}
+
+// ---------------------------------------------------------------------------
+// Exclusive scan of per-group token counts (single workgroup)
+// ---------------------------------------------------------------------------
+__global__ void group_scan_kernel(const uint32_t* counts, uint64_t* offsets, int n) {
+  __shared__ uint64_t carry;
+  __shared__ uint64_t part[256];
+  const int tid = (int)threadIdx.x;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 256) {
+    const int i = base + tid;
+    const uint64_t v = i < n ? counts[i] : 0;
+    part[tid] = v;
+    __syncthreads();
+    for (int s = 1; s < 256; s <<= 1) {
+      const uint64_t add = tid >= s ? part[tid - s] : 0;
+      __syncthreads();
+      part[tid] += add;
+      __syncthreads();
+    }
+    if (i < n) offsets[i] = carry + part[tid] - v;
+    __syncthreads();
+    if (tid == 0) carry += part[255];
+    __syncthreads();
+  }
+  if (tid == 0) offsets[n] = carry;
+}
+
+// ---------------------------------------------------------------------------
+// Token kernel: one workgroup per 256x256 group (enc_group.cc:444-494)
+// ---------------------------------------------------------------------------
+constexpr int kTokenThreads = 256;
+
+__global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A) {
+  __shared__ uint32_t offs[3072 + 1];
+  __shared__ uint32_t wsum[kTokenThreads / 64];
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const DeviceTables* T = A.tab;
+  const int group = (int)blockIdx.x;
+  const int ggx = group % A.g.xsize_groups, ggy = group / A.g.xsize_groups;
+  const int bx0 = ggx * 32, by0 = ggy * 32;
+  const int nbx = imin(32, A.g.xsize_blocks - bx0), nby = imin(32, A.g.ysize_blocks - by0);
+  const size_t bstride = (size_t)A.g.xsize_blocks;
+  const int nent = nbx * nby * 3;  // entries in stream order: (by, bx, ci), channels Y, X, B
+
+  // token count per entry
+  for (int e = tid; e < nent; e += kTokenThreads) {
+    const int ci = e % 3, b = e / 3;
+    const int bx = b % nbx, by = b / nbx;
+    const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
+    const size_t pos = (size_t)(by0 + by) * bstride + bx0 + bx;
+    const uint8_t a = A.strategy[pos];
+    uint32_t n = 0;
+    if (a & 1) {
+      const int covered = (a >> 1) == 0 ? 1 : 2;
+      const int nscan = A.blk_nscan[pos * 3 + c];
+      n = 1 + (nscan > covered ? nscan - covered : 0);
+    }
+    offs[e + 1] = n;
+  }
+  if (tid == 0) offs[0] = 0;
+  __syncthreads();
+  // inclusive scan over offs[1..nent] (blocked: each thread owns a contiguous run)
+  {
+    const int per = (nent + kTokenThreads - 1) / kTokenThreads;
+    const int beg = 1 + tid * per, end = imin(1 + nent, beg + per);
+    uint32_t s = 0;
+    for (int i = beg; i < end; i++) s += offs[i];
+    // scan of per-thread sums: wave scan + cross-wave
+    uint32_t incl = s;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wave; w++) wbase += wsum[w];
+    uint32_t run = wbase + incl - s;
+    for (int i = beg; i < end; i++) {
+      run += offs[i];
+      offs[i] = run;
+    }
+  }
+  __syncthreads();
+
+  uint8_t* out = A.tokens + 3 * A.group_tok_offset[group];
+  // one wave per entry
+  for (int e = wave; e < nent; e += kTokenThreads / 64) {
+    const int ci = e % 3, b = e / 3;
+    const int bx = b % nbx, by = b / nbx;
+    const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
+    const size_t pos = (size_t)(by0 + by) * bstride + bx0 + bx;
+    const uint8_t a = A.strategy[pos];
+    if (!(a & 1)) continue;
+    const int st = a >> 1;
+    const int covered = st == 0 ? 1 : 2;
+    const int log2c = covered == 1 ? 0 : 1;
+    const int size = covered * 64;
+    const size_t pos1 = pos + (st == 1 ? bstride : 1);
+    const uint32_t tok0 = offs[e];
+    const int nzeros = A.blk_nz[pos * 3 + c];
+    const int nscan = A.blk_nscan[pos * 3 + c];
+    // block context (ac_context.h:64-114)
+    const int code = st == 0 ? 0 : st == 1 ? 6 : 7;
+    const int block_ctx = T->block_context_map[c * 27 + code];
+    if (lane == 0) {
+      // PredictFromTopAndLeft (enc_group.cc:150-160), default 32
+      int pred;
+      const uint8_t* nzg = A.nzgrid[c];
+      if (bx == 0) pred = by == 0 ? 32 : nzg[pos - bstride];
+      else if (by == 0) pred = nzg[pos - 1];
+      else pred = (nzg[pos - bstride] + nzg[pos - 1] + 1) / 2;
+      const int bucket = pred < 8 ? pred : pred >= 64 ? 36 : 4 + pred / 2;
+      const int ctx = bucket * 4 + block_ctx;
+      uint8_t* o = out + 3 * (size_t)tok0;
+      o[0] = T->ac_context_map[ctx];
+      o[1] = (uint8_t)(nzeros & 0xFF);
+      o[2] = (uint8_t)(nzeros >> 8);
+    }
+    if (nzeros == 0) continue;
+    const int histo_offset = 4 * 37 + 458 * block_ctx;
+    int nz_before = 0;   // nonzeros at scan positions before the current 64-chunk
+    int carry_flag = 0;  // nonzero flag of the last position of the previous chunk
+    for (int half = 0; half < covered; half++) {
+      const int k = half * 64 + lane;
+      const int16_t v = A.coef_scan[((half == 0 ? pos : pos1) * 3 + c) * 64 + lane];
+      const bool in_range = k >= covered && k < nscan;
+      const bool nz = in_range && v != 0;
+      const unsigned long long m = __ballot(nz);
+      if (in_range) {
+        // nzeros still to come at position k, and whether position k-1 was nonzero
+        const int left = nzeros - (nz_before + __popcll(m & ((1ull << lane) - 1ull)));
+        int p;
+        if (k == covered) p = (nzeros > size / 16) ? 0 : 1;
+        else if (lane == 0) p = carry_flag;
+        else p = (int)((m >> (lane - 1)) & 1ull);
+        const int nl = (left + covered - 1) >> log2c;
+        const int kk = k >> log2c;
+        const int zctx = (T->nnz_context[nl] + T->freq_context[kk]) * 2 + p;
+        const int ctx = histo_offset + zctx;
+        const uint32_t val = pack_signed((int32_t)v);
+        uint8_t* o = out + 3 * ((size_t)tok0 + 1 + (k - covered));
+        o[0] = T->ac_context_map[ctx];
+        o[1] = (uint8_t)(val & 0xFF);
+        o[2] = (uint8_t)((val >> 8) & 0xFF);
+      }
+      nz_before += __popcll(m);
+      carry_flag = (int)((m >> 63) & 1ull);
+    }
+  }
+}
+
+}  // namespace jxlt_dev
+
+#endif  // JXLT_DEVICE_H_

@@ -1,0 +1,56 @@
+// Host-side construction of the constant tables the kernels read
+// (jxlt_dev::DeviceTables) and of the frame geometry.
+#ifndef JXLT_HOST_TABLES_H_
+#define JXLT_HOST_TABLES_H_
+
+#include <string.h>
+
+#include "jxlt_device.h"
+#include "jxlt_tables.h"
+
+namespace jxlt_dev {
+
+// `scale` is DistanceParams.scale (enc_frame.cc:129); the per-quant reciprocal
+// float(1.0 / (scale * q)) is evaluated in double exactly as
+// QuantizeRoundtripYBlockAC does (enc_group.cc:289).
+inline void BuildDeviceTables(float scale, DeviceTables* t) {
+  memset(t, 0, sizeof(*t));
+  for (int i = 0; i < 576; i++) {
+    memcpy(&t->weights[i], &JXLT_kQuantWeightBits[i], 4);
+    t->inv_weights[i] = static_cast<float>(1.0 / t->weights[i]);  // quant_weights.cc:144-146
+  }
+  for (int n = 0; n < 9; n++) {
+    t->table_offset[n] = JXLT_kQuantTableOffset[n];
+    for (int b = 0; b < JXLT_kQuantTableLLF[n]; b++) t->inv_weights[JXLT_kQuantTableOffset[n] + b] = 0.0f;
+  }
+  t->inv_qac[0] = 0.0f;
+  for (int q = 1; q < 256; q++) t->inv_qac[q] = static_cast<float>(1.0 / (scale * q));
+  memcpy(t->coeff_order, JXLT_kCoeffOrder, sizeof(t->coeff_order));
+  memcpy(t->freq_context, JXLT_kCoeffFreqContext, sizeof(t->freq_context));
+  memcpy(t->nnz_context, JXLT_kCoeffNumNonzeroContext, sizeof(t->nnz_context));
+  memcpy(t->block_context_map, JXLT_kBlockContextMap, sizeof(t->block_context_map));
+  memcpy(t->ac_context_map, JXLT_kACContextMap, sizeof(t->ac_context_map));
+}
+
+inline FrameGeom MakeGeom(size_t xsize, size_t ysize) {
+  FrameGeom g;
+  g.xsize = static_cast<int>(xsize);
+  g.ysize = static_cast<int>(ysize);
+  g.xsize_blocks = static_cast<int>((xsize + 7) / 8);
+  g.ysize_blocks = static_cast<int>((ysize + 7) / 8);
+  g.xsize_tiles = static_cast<int>((xsize + 63) / 64);
+  g.ysize_tiles = static_cast<int>((ysize + 63) / 64);
+  g.xsize_groups = static_cast<int>((xsize + 255) / 256);
+  g.ysize_groups = static_cast<int>((ysize + 255) / 256);
+  return g;
+}
+
+inline float XQmMultiplier(uint32_t x_qm_scale) {  // pow(1.25f, x_qm_scale - 2.0f), exact
+  float m = 1.0f;
+  for (uint32_t i = 2; i < x_qm_scale; i++) m *= 1.25f;
+  return m;
+}
+
+}  // namespace jxlt_dev
+
+#endif  // JXLT_HOST_TABLES_H_

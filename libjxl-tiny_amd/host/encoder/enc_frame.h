@@ -1,0 +1,26 @@
+// Drop-in for /root/reference/encoder/enc_frame.h:19-20.
+#ifndef JXLT_HOST_ENCODER_ENC_FRAME_H_
+#define JXLT_HOST_ENCODER_ENC_FRAME_H_
+
+#include "encoder/base/data_parallel.h"
+#include "encoder/enc_bit_writer.h"
+#include "encoder/image.h"
+
+namespace jxl {
+
+using Status = bool;
+
+// Encodes one frame of `linear` (planar linear-sRGB f32) at butteraugli
+// `distance` and appends it to `writer` (byte aligned on entry).  The per-group
+// pixel pipeline runs on the MI355X selected by SetEncoderDevice(); `pool` only
+// supplies the host thread count.  Returns false on failure (no GPU, invalid
+// arguments); never falls back to a CPU path.
+Status EncodeFrame(float distance, const Image3F& linear, ThreadPool* pool, BitWriter* writer);
+
+// Not in the reference: HIP device ordinal used by the calling thread's
+// subsequent EncodeFrame/EncodeFile calls (default 0).
+void SetEncoderDevice(int device_ordinal);
+
+}  // namespace jxl
+
+#endif  // JXLT_HOST_ENCODER_ENC_FRAME_H_

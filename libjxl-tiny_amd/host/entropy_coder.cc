@@ -1,0 +1,515 @@
+// See entropy_coder.h.  The algorithms are the brotli-lineage ones the JPEG XL
+// reference encoder uses; tie-breaking and iteration order are part of the
+// output contract and are kept identical (citations inline).
+#include "entropy_coder.h"
+
+#include <algorithm>
+#include <limits>
+#include <map>
+
+namespace jxlt {
+namespace {
+
+struct Node {
+  uint32_t count;
+  int16_t left;   // -1 for a leaf
+  int16_t right;  // child index, or the symbol for a leaf
+};
+
+void AssignDepths(const std::vector<Node>& pool, int root, uint8_t* depth) {
+  // Iterative pre-order walk (enc_huffman_tree.cc:26-35 is the recursive form).
+  struct Item { int node; uint8_t level; };
+  Item stack[2 * kAlphabetSize + 8];
+  int sp = 0;
+  stack[sp++] = {root, 0};
+  while (sp) {
+    Item it = stack[--sp];
+    const Node& n = pool[it.node];
+    if (n.left >= 0) {
+      stack[sp++] = {n.right, static_cast<uint8_t>(it.level + 1)};
+      stack[sp++] = {n.left, static_cast<uint8_t>(it.level + 1)};
+    } else {
+      depth[n.right] = it.level;
+    }
+  }
+}
+
+}  // namespace
+
+// enc_huffman_tree.cc:65-142.  Leaves are gathered from the highest symbol
+// down, stably sorted by count, then merged with the classic two-queue scheme
+// (ties prefer the leaf queue).  If the tree is deeper than tree_limit the
+// minimum count is doubled and the construction repeated.
+void CreateHuffmanTree(const uint32_t* counts, size_t length, int tree_limit, uint8_t* depth) {
+  for (uint32_t count_limit = 1;; count_limit *= 2) {
+    std::vector<Node> tree;
+    tree.reserve(2 * length + 2);
+    for (size_t i = length; i != 0;) {
+      --i;
+      if (counts[i]) {
+        tree.push_back({std::max(counts[i], count_limit - 1), -1, static_cast<int16_t>(i)});
+      }
+    }
+    const size_t n = tree.size();
+    if (n == 0) return;  // (unreachable from the encoder; reference would misbehave)
+    if (n == 1) {
+      depth[tree[0].right] = 1;  // "fake" depth, kept as-is by the callers
+      return;
+    }
+    std::stable_sort(tree.begin(), tree.end(),
+                     [](const Node& a, const Node& b) { return a.count < b.count; });
+    const Node sentinel = {std::numeric_limits<uint32_t>::max(), -1, -1};
+    tree.push_back(sentinel);  // [n]
+    tree.push_back(sentinel);  // first parent slot, [n + 1]
+    size_t leaf = 0, inner = n + 1;
+    for (size_t k = n - 1; k != 0; --k) {
+      size_t l, r;
+      if (tree[leaf].count <= tree[inner].count) l = leaf++; else l = inner++;
+      if (tree[leaf].count <= tree[inner].count) r = leaf++; else r = inner++;
+      const size_t parent = tree.size() - 1;
+      tree[parent].count = tree[l].count + tree[r].count;
+      tree[parent].left = static_cast<int16_t>(l);
+      tree[parent].right = static_cast<int16_t>(r);
+      tree.push_back(sentinel);
+    }
+    AssignDepths(tree, static_cast<int>(2 * n - 1), depth);
+    if (*std::max_element(depth, depth + length) <= tree_limit) return;
+  }
+}
+
+namespace {
+uint16_t ReverseBits(int num_bits, uint16_t bits) {
+  uint16_t r = 0;
+  for (int i = 0; i < num_bits; ++i) r = static_cast<uint16_t>((r << 1) | ((bits >> i) & 1));
+  return r;
+}
+}  // namespace
+
+// enc_entropy_code.cc:297-324: canonical code assignment, bit-reversed for the
+// LSB-first writer.
+void ConvertBitDepthsToSymbols(const uint8_t* depth, size_t len, uint16_t* bits) {
+  uint16_t bl_count[16] = {0};
+  for (size_t i = 0; i < len; ++i) ++bl_count[depth[i]];
+  bl_count[0] = 0;
+  uint16_t next_code[16];
+  next_code[0] = 0;
+  int code = 0;
+  for (int i = 1; i < 16; ++i) {
+    code = (code + bl_count[i - 1]) << 1;
+    next_code[i] = static_cast<uint16_t>(code);
+  }
+  for (size_t i = 0; i < len; ++i) {
+    if (depth[i]) bits[i] = ReverseBits(depth[i], next_code[depth[i]]++);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Clustering (enc_cluster.cc)
+// ---------------------------------------------------------------------------
+namespace {
+
+void ComputeBitCost(Histogram* h) {  // enc_cluster.cc:18-26
+  h->bit_cost = 0;
+  if (h->total_count == 0) return;
+  uint8_t depths[kAlphabetSize] = {};
+  CreateHuffmanTree(h->counts, kAlphabetSize, 15, depths);
+  for (size_t i = 0; i < kAlphabetSize; ++i) h->bit_cost += static_cast<size_t>(h->counts[i]) * depths[i];
+}
+
+float Distance(const Histogram& a, const Histogram& b) {  // enc_cluster.cc:28-35
+  if (a.total_count == 0 || b.total_count == 0) return 0;
+  Histogram combined;
+  combined.AddHistogram(a);
+  combined.AddHistogram(b);
+  ComputeBitCost(&combined);
+  // size_t arithmetic (may wrap) converted to float, as in the reference.
+  return static_cast<float>(combined.bit_cost - a.bit_cost - b.bit_cost);
+}
+
+}  // namespace
+
+void ClusterHistograms(std::vector<Histogram>* histograms, std::vector<uint8_t>* context_map) {
+  if (histograms->size() <= 1) return;  // enc_cluster.cc:121
+  const size_t max_histograms = std::min<size_t>(8, histograms->size());
+  std::vector<Histogram> in(*histograms);
+  std::vector<Histogram>& out = *histograms;
+  out.clear();
+  out.reserve(max_histograms);
+  std::vector<uint32_t> symbols(in.size(), static_cast<uint32_t>(max_histograms));
+  std::vector<float> dists(in.size(), std::numeric_limits<float>::max());
+  size_t largest = 0;
+  for (size_t i = 0; i < in.size(); i++) {  // enc_cluster.cc:48-58
+    if (in[i].total_count == 0) {
+      symbols[i] = 0;
+      dists[i] = 0.0f;
+      continue;
+    }
+    ComputeBitCost(&in[i]);
+    if (in[i].total_count > in[largest].total_count) largest = i;
+  }
+  constexpr float kMinDistanceForDistinct = 64.0f;
+  while (out.size() < max_histograms) {  // enc_cluster.cc:61-73
+    symbols[largest] = static_cast<uint32_t>(out.size());
+    out.push_back(in[largest]);
+    dists[largest] = 0.0f;
+    largest = 0;
+    for (size_t i = 0; i < in.size(); i++) {
+      if (dists[i] == 0.0f) continue;
+      dists[i] = std::min(Distance(in[i], out.back()), dists[i]);
+      if (dists[i] > dists[largest]) largest = i;
+    }
+    if (dists[largest] < kMinDistanceForDistinct) break;
+  }
+  for (size_t i = 0; i < in.size(); i++) {  // enc_cluster.cc:75-90
+    if (symbols[i] != max_histograms) continue;
+    size_t best = 0;
+    float best_dist = Distance(in[i], out[best]);
+    for (size_t j = 1; j < out.size(); j++) {
+      const float d = Distance(in[i], out[j]);
+      if (d < best_dist) {
+        best = j;
+        best_dist = d;
+      }
+    }
+    out[best].AddHistogram(in[i]);
+    ComputeBitCost(&out[best]);
+    symbols[i] = static_cast<uint32_t>(best);
+  }
+  // Canonical renumbering in order of first use (enc_cluster.cc:98-115).
+  std::vector<Histogram> tmp(out);
+  std::map<uint32_t, uint32_t> new_index;
+  uint32_t next = 0;
+  for (uint32_t s : symbols) {
+    if (new_index.find(s) == new_index.end()) {
+      new_index[s] = next;
+      out[next] = tmp[s];
+      ++next;
+    }
+  }
+  out.resize(next);
+  context_map->resize(symbols.size());
+  for (size_t i = 0; i < symbols.size(); ++i) (*context_map)[i] = static_cast<uint8_t>(new_index[symbols[i]]);
+}
+
+// ---------------------------------------------------------------------------
+// Code construction (enc_entropy_code.cc:455-514)
+// ---------------------------------------------------------------------------
+namespace {
+
+void BuildHuffmanCodes(const std::vector<Histogram>& histograms, EntropyCode* code) {
+  code->prefix_codes.assign(histograms.size(), PrefixCode{});
+  for (size_t i = 0; i < histograms.size(); ++i) {
+    PrefixCode& pc = code->prefix_codes[i];
+    const uint32_t* counts = histograms[i].counts;
+    size_t length = kAlphabetSize;
+    while (length > 0 && counts[length - 1] == 0) --length;
+    CreateHuffmanTree(counts, length, 15, pc.depths);
+    ConvertBitDepthsToSymbols(pc.depths, length, pc.bits);
+  }
+}
+
+}  // namespace
+
+void OptimizeEntropyCode(const std::vector<Token>& tokens, size_t num_contexts, EntropyCode* code) {
+  std::vector<Histogram> histograms(num_contexts);
+  for (const Token& t : tokens) {
+    uint32_t tok, nbits, bits;
+    HybridUintEncode(t.value, &tok, &nbits, &bits);
+    histograms[t.context].Add(tok);
+  }
+  code->orig_context_map.clear();
+  code->context_map.clear();
+  ClusterHistograms(&histograms, &code->context_map);
+  if (code->context_map.empty()) code->context_map.assign(num_contexts, 0);
+  BuildHuffmanCodes(histograms, code);
+}
+
+void OptimizeEntropyCode(std::vector<Histogram>* histograms, const uint8_t* static_map,
+                         size_t num_static_contexts, EntropyCode* code) {
+  const size_t num_hist = histograms->size();
+  code->context_map.clear();
+  ClusterHistograms(histograms, &code->context_map);
+  if (code->context_map.empty()) code->context_map.assign(num_hist, 0);
+  code->orig_context_map.assign(static_map, static_map + num_static_contexts);
+  BuildHuffmanCodes(*histograms, code);
+}
+
+// ---------------------------------------------------------------------------
+// Serialisation (enc_entropy_code.cc:18-453, 516-553)
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int kCodeLengthCodes = 18;
+
+// Run-length pieces of the code-length sequence (enc_entropy_code.cc:125-196).
+void EmitRepeat(uint8_t previous_value, uint8_t value, size_t reps, std::vector<uint8_t>* tree,
+                std::vector<uint8_t>* extra) {
+  if (previous_value != value) {
+    tree->push_back(value);
+    extra->push_back(0);
+    --reps;
+  }
+  if (reps == 7) {
+    tree->push_back(value);
+    extra->push_back(0);
+    --reps;
+  }
+  if (reps < 3) {
+    for (size_t i = 0; i < reps; ++i) {
+      tree->push_back(value);
+      extra->push_back(0);
+    }
+  } else {
+    reps -= 3;
+    const size_t start = tree->size();
+    while (true) {
+      tree->push_back(16);
+      extra->push_back(reps & 0x3);
+      reps >>= 2;
+      if (reps == 0) break;
+      --reps;
+    }
+    std::reverse(tree->begin() + start, tree->end());
+    std::reverse(extra->begin() + start, extra->end());
+  }
+}
+
+void EmitZeroRepeat(size_t reps, std::vector<uint8_t>* tree, std::vector<uint8_t>* extra) {
+  if (reps == 11) {
+    tree->push_back(0);
+    extra->push_back(0);
+    --reps;
+  }
+  if (reps < 3) {
+    for (size_t i = 0; i < reps; ++i) {
+      tree->push_back(0);
+      extra->push_back(0);
+    }
+  } else {
+    reps -= 3;
+    const size_t start = tree->size();
+    while (true) {
+      tree->push_back(17);
+      extra->push_back(reps & 0x7);
+      reps >>= 3;
+      if (reps == 0) break;
+      --reps;
+    }
+    std::reverse(tree->begin() + start, tree->end());
+    std::reverse(extra->begin() + start, extra->end());
+  }
+}
+
+// enc_entropy_code.cc:198-224
+void DecideRle(const uint8_t* depth, size_t length, bool* rle_nonzero, bool* rle_zero) {
+  size_t total_zero = 0, total_nonzero = 0, count_zero = 1, count_nonzero = 1;
+  for (size_t i = 0; i < length;) {
+    const uint8_t value = depth[i];
+    size_t reps = 1;
+    for (size_t k = i + 1; k < length && depth[k] == value; ++k) ++reps;
+    if (reps >= 3 && value == 0) {
+      total_zero += reps;
+      ++count_zero;
+    }
+    if (reps >= 4 && value != 0) {
+      total_nonzero += reps;
+      ++count_nonzero;
+    }
+    i += reps;
+  }
+  *rle_nonzero = total_nonzero > count_nonzero * 2;
+  *rle_zero = total_zero > count_zero * 2;
+}
+
+// enc_entropy_code.cc:229-275
+void CodeLengthSequence(const uint8_t* depth, size_t length, std::vector<uint8_t>* tree,
+                        std::vector<uint8_t>* extra) {
+  uint8_t previous_value = 8;
+  size_t new_length = length;
+  while (new_length > 0 && depth[new_length - 1] == 0) --new_length;
+  bool rle_nonzero = false, rle_zero = false;
+  if (length > 50) DecideRle(depth, new_length, &rle_nonzero, &rle_zero);
+  for (size_t i = 0; i < new_length;) {
+    const uint8_t value = depth[i];
+    size_t reps = 1;
+    if ((value != 0 && rle_nonzero) || (value == 0 && rle_zero)) {
+      for (size_t k = i + 1; k < new_length && depth[k] == value; ++k) ++reps;
+    }
+    if (value == 0) {
+      EmitZeroRepeat(reps, tree, extra);
+    } else {
+      EmitRepeat(previous_value, value, reps, tree, extra);
+      previous_value = value;
+    }
+    i += reps;
+  }
+}
+
+// enc_entropy_code.cc:326-375 + :22-66 + :68-87
+void StoreComplexPrefixCode(const uint8_t* depths, size_t num, jxl::BitWriter* writer) {
+  std::vector<uint8_t> tree, extra;
+  CodeLengthSequence(depths, num, &tree, &extra);
+  uint32_t histogram[kCodeLengthCodes] = {0};
+  for (uint8_t s : tree) ++histogram[s];
+  int num_codes = 0, single_code = 0;
+  for (int i = 0; i < kCodeLengthCodes; ++i) {
+    if (histogram[i]) {
+      if (num_codes == 0) {
+        single_code = i;
+        num_codes = 1;
+      } else if (num_codes == 1) {
+        num_codes = 2;
+        break;
+      }
+    }
+  }
+  uint8_t cl_depth[kCodeLengthCodes] = {0};
+  uint16_t cl_bits[kCodeLengthCodes] = {0};
+  CreateHuffmanTree(histogram, kCodeLengthCodes, 5, cl_depth);
+  ConvertBitDepthsToSymbols(cl_depth, kCodeLengthCodes, cl_bits);
+
+  // Code-length-code lengths in the fixed storage order with a fixed code.
+  static const uint8_t kStorageOrder[kCodeLengthCodes] = {1, 2, 3, 4, 0, 5, 17, 6, 16,
+                                                          7, 8, 9, 10, 11, 12, 13, 14, 15};
+  static const uint8_t kLenSymbols[6] = {0, 7, 3, 2, 1, 15};
+  static const uint8_t kLenBits[6] = {2, 4, 3, 2, 2, 4};
+  size_t codes_to_store = kCodeLengthCodes;
+  if (num_codes > 1) {
+    for (; codes_to_store > 0; --codes_to_store) {
+      if (cl_depth[kStorageOrder[codes_to_store - 1]] != 0) break;
+    }
+  }
+  size_t skip_some = 0;
+  if (cl_depth[kStorageOrder[0]] == 0 && cl_depth[kStorageOrder[1]] == 0) {
+    skip_some = 2;
+    if (cl_depth[kStorageOrder[2]] == 0) skip_some = 3;
+  }
+  writer->Write(2, skip_some);
+  for (size_t i = skip_some; i < codes_to_store; ++i) {
+    const size_t l = cl_depth[kStorageOrder[i]];
+    writer->Write(kLenBits[l], kLenSymbols[l]);
+  }
+  if (num_codes == 1) cl_depth[single_code] = 0;
+  for (size_t i = 0; i < tree.size(); ++i) {
+    const size_t ix = tree[i];
+    writer->Write(cl_depth[ix], cl_bits[ix]);
+    if (ix == 16) writer->Write(2, extra[i]);
+    if (ix == 17) writer->Write(3, extra[i]);
+  }
+}
+
+// enc_entropy_code.cc:89-123
+void StoreSimplePrefixCode(const uint8_t* depths, size_t symbols[4], size_t num_symbols,
+                           size_t max_bits, jxl::BitWriter* writer) {
+  writer->Write(2, 1);
+  writer->Write(2, num_symbols - 1);
+  for (size_t i = 0; i < num_symbols; i++) {
+    for (size_t j = i + 1; j < num_symbols; j++) {
+      if (depths[symbols[j]] < depths[symbols[i]]) std::swap(symbols[j], symbols[i]);
+    }
+  }
+  for (size_t i = 0; i < num_symbols; ++i) writer->Write(max_bits, symbols[i]);
+  if (num_symbols == 4) writer->Write(1, depths[symbols[0]] == 1 ? 1 : 0);
+}
+
+void StoreVarLenUint16(size_t n, jxl::BitWriter* writer) {  // :377-387
+  if (n == 0) {
+    writer->Write(1, 0);
+  } else {
+    writer->Write(1, 1);
+    const size_t nbits = 63 ^ static_cast<size_t>(__builtin_clzll(n));
+    writer->Write(4, nbits);
+    writer->Write(nbits, n - (1ULL << nbits));
+  }
+}
+
+void WritePrefixCode(const PrefixCode& code, jxl::BitWriter* writer) {  // :389-423
+  size_t count = 0, s4[4] = {0}, length = 0;
+  for (size_t i = 0; i < kAlphabetSize; i++) {
+    if (code.depths[i]) {
+      if (count < 4) s4[count] = i;
+      count++;
+      length = i + 1;
+    }
+  }
+  size_t max_bits_counter = length - 1, max_bits = 0;
+  while (max_bits_counter) {
+    max_bits_counter >>= 1;
+    ++max_bits;
+  }
+  if (count <= 1) {
+    writer->Write(4, 1);
+    writer->Write(max_bits, s4[0]);
+    return;
+  }
+  if (count <= 4) StoreSimplePrefixCode(code.depths, s4, count, max_bits, writer);
+  else StoreComplexPrefixCode(code.depths, length, writer);
+}
+
+size_t NumSymbols(const PrefixCode& pc) {
+  size_t n = 1;
+  for (size_t i = 0; i < kAlphabetSize; i++)
+    if (pc.depths[i]) n = i + 1;
+  return n;
+}
+
+void WritePrefixCodes(const std::vector<PrefixCode>& codes, jxl::BitWriter* writer) {  // :425-453
+  writer->Write(1, 1);  // use_prefix_code
+  for (size_t i = 0; i < codes.size(); ++i) {
+    writer->Write(4, 4);  // split_exponent
+    writer->Write(3, 2);  // msb_in_token
+    writer->Write(2, 0);  // lsb_in_token
+  }
+  for (const PrefixCode& pc : codes) StoreVarLenUint16(NumSymbols(pc) - 1, writer);
+  for (const PrefixCode& pc : codes) {
+    if (NumSymbols(pc) > 1) WritePrefixCode(pc, writer);
+  }
+}
+
+void WriteMapEntries(const std::vector<uint8_t>& entries, jxl::BitWriter* writer) {
+  // enc_entropy_code.cc:516-548 after the "all zero" early-out.
+  writer->Write(3, 0);  // no simple code, no MTF, no LZ77
+  EntropyCode map_code;
+  map_code.context_map.assign(1, 0);
+  std::vector<Histogram> h(1);
+  for (uint8_t e : entries) {
+    uint32_t tok, nbits, bits;
+    HybridUintEncode(e, &tok, &nbits, &bits);
+    h[0].Add(tok);
+  }
+  BuildHuffmanCodes(h, &map_code);
+  WritePrefixCodes(map_code.prefix_codes, writer);
+  for (uint8_t e : entries) WriteToken(0, e, map_code, writer);
+}
+
+}  // namespace
+
+void WriteContextMap(const EntropyCode& code, jxl::BitWriter* writer) {
+  const size_t num_contexts =
+      code.orig_context_map.empty() ? code.context_map.size() : code.orig_context_map.size();
+  if (num_contexts == 0) return;
+  if (*std::max_element(code.context_map.begin(), code.context_map.end()) == 0) {
+    writer->Write(3, 1);  // simple code, 0 bits per entry
+    return;
+  }
+  std::vector<uint8_t> entries;
+  if (!code.orig_context_map.empty()) {
+    for (uint8_t o : code.orig_context_map) entries.push_back(code.context_map[o]);
+  } else {
+    entries = code.context_map;
+  }
+  WriteMapEntries(entries, writer);
+}
+
+void WriteStaticContextMap(const uint8_t* map, size_t n, jxl::BitWriter* writer) {
+  EntropyCode code;
+  code.context_map.assign(map, map + n);
+  WriteContextMap(code, writer);
+}
+
+void WriteEntropyCode(const EntropyCode& code, jxl::BitWriter* writer) {
+  WriteContextMap(code, writer);
+  WritePrefixCodes(code.prefix_codes, writer);
+}
+
+}  // namespace jxlt

@@ -1,0 +1,106 @@
+// Host-side entropy coding for the JPEG XL tiny bitstream: hybrid-uint token
+// split, per-context histograms, greedy histogram clustering (<= 8 clusters),
+// length-limited Huffman codes and their brotli-style serialisation.
+//
+// Behavioural reference (bit-exact output is required):
+//   /root/reference/encoder/token.h:32-48           (UintCoder::Encode)
+//   /root/reference/encoder/enc_cluster.cc:18-131   (clustering)
+//   /root/reference/encoder/enc_huffman_tree.cc:65-142
+//   /root/reference/encoder/enc_entropy_code.cc:18-553
+#ifndef JXLT_HOST_ENTROPY_CODER_H_
+#define JXLT_HOST_ENTROPY_CODER_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "encoder/enc_bit_writer.h"
+
+namespace jxlt {
+
+constexpr size_t kAlphabetSize = 64;
+constexpr uint8_t kMaxContexts = 128;  // record contexts >= this are raw-bit escapes
+constexpr size_t kMaxBitsPerToken = 24;
+
+struct Token {
+  uint32_t context;
+  uint32_t value;
+};
+
+struct PrefixCode {
+  uint8_t depths[kAlphabetSize];
+  uint16_t bits[kAlphabetSize];
+};
+
+struct Histogram {
+  uint32_t counts[kAlphabetSize] = {};
+  size_t total_count = 0;
+  size_t bit_cost = 0;  // filled by ComputeBitCost
+  void Add(uint32_t symbol) {
+    ++counts[symbol];
+    ++total_count;
+  }
+  void AddHistogram(const Histogram& o) {
+    for (size_t i = 0; i < kAlphabetSize; ++i) counts[i] += o.counts[i];
+    total_count += o.total_count;
+  }
+};
+
+// A context map + one prefix code per cluster.  `orig_context_map` is the
+// static pre-clustering that produced the histogram indices (when present the
+// serialised map is the composition).
+struct EntropyCode {
+  std::vector<uint8_t> context_map;
+  std::vector<PrefixCode> prefix_codes;
+  std::vector<uint8_t> orig_context_map;  // empty if none
+};
+
+// token.h:32-48
+inline void HybridUintEncode(uint32_t value, uint32_t* token, uint32_t* nbits, uint32_t* bits) {
+  if (value < 16) {
+    *token = value;
+    *nbits = 0;
+    *bits = 0;
+  } else {
+    const uint32_t n = 31u ^ static_cast<uint32_t>(__builtin_clz(value));
+    const uint32_t m = value - (1u << n);
+    *token = (n << 2) + (m >> (n - 2));
+    *nbits = n - 2;
+    *bits = value & ((1u << *nbits) - 1);
+  }
+}
+
+// enc_entropy_code.h:34-42
+inline void WriteToken(uint32_t cluster_ctx, uint32_t value, const EntropyCode& code,
+                       jxl::BitWriter* writer) {
+  uint32_t tok, nbits, bits;
+  HybridUintEncode(value, &tok, &nbits, &bits);
+  const PrefixCode& pc = code.prefix_codes[code.context_map[cluster_ctx]];
+  uint64_t data = pc.bits[tok];
+  data |= static_cast<uint64_t>(bits) << pc.depths[tok];
+  writer->Write(pc.depths[tok] + nbits, data);
+}
+
+void CreateHuffmanTree(const uint32_t* counts, size_t length, int tree_limit, uint8_t* depth);
+void ConvertBitDepthsToSymbols(const uint8_t* depth, size_t len, uint16_t* bits);
+
+// Clusters `histograms` (in place, result = cluster histograms) and returns the
+// histogram-index -> cluster map.
+void ClusterHistograms(std::vector<Histogram>* histograms, std::vector<uint8_t>* context_map);
+
+// From raw tokens with direct context ids (no pre-clustering).
+void OptimizeEntropyCode(const std::vector<Token>& tokens, size_t num_contexts, EntropyCode* code);
+// From per-pre-cluster histograms; `static_map` (num_contexts -> histogram index)
+// becomes orig_context_map.
+void OptimizeEntropyCode(std::vector<Histogram>* histograms, const uint8_t* static_map,
+                         size_t num_static_contexts, EntropyCode* code);
+
+void WriteContextMap(const EntropyCode& code, jxl::BitWriter* writer);
+// Context map given explicitly (used for the fixed block-context map).
+void WriteStaticContextMap(const uint8_t* map, size_t n, jxl::BitWriter* writer);
+void WriteEntropyCode(const EntropyCode& code, jxl::BitWriter* writer);
+
+}  // namespace jxlt
+
+#endif  // JXLT_HOST_ENTROPY_CODER_H_

@@ -1,0 +1,430 @@
+// See frame_assembler.h.
+#include "frame_assembler.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <thread>
+#include <vector>
+
+#include "../csrc/jxlt_tables.h"
+#include "entropy_coder.h"
+
+namespace jxlt {
+namespace {
+
+inline size_t DivCeil(size_t a, size_t b) { return (a + b - 1) / b; }
+template <typename T>
+inline T Clamp1(T v, T lo, T hi) { return v < lo ? lo : v > hi ? hi : v; }
+inline uint32_t PackSigned(int32_t v) {  // common.h:54-58
+  return (static_cast<uint32_t>(v) << 1) ^ ((static_cast<uint32_t>(~v) >> 31) - 1);
+}
+inline size_t CeilLog2Nonzero(uint64_t x) {  // base/bits.h:128-132
+  const size_t fl = 63 ^ static_cast<size_t>(__builtin_clzll(x));
+  return (x & (x - 1)) == 0 ? fl : fl + 1;
+}
+
+constexpr size_t kNumDCContexts = 45;     // enc_frame.cc:285
+constexpr size_t kNumACPreClusters = 64;  // static_entropy_codes.h:161
+constexpr size_t kNumACContexts = 1980;   // ac_context.h:76-77
+constexpr size_t kNumTreeContexts = 6;    // enc_frame.cc:179
+
+float QuantDC(float distance) {  // enc_frame.cc:95-102
+  const float kDcQuantPow = 0.57f;
+  const float kDcQuant = 1.12f;
+  const float kDcMul = 2.9;
+  float effective_dist = kDcMul * std::pow(distance / kDcMul, kDcQuantPow);
+  effective_dist = Clamp1(effective_dist, 0.5f * distance, distance);
+  return std::min(kDcQuant / effective_dist, 50.f);
+}
+
+template <typename F>
+void ParallelFor(size_t n, int num_threads, const F& f) {
+  if (num_threads <= 0) num_threads = static_cast<int>(std::thread::hardware_concurrency());
+  num_threads = static_cast<int>(std::min<size_t>(std::max(1, num_threads), n));
+  if (num_threads <= 1) {
+    for (size_t i = 0; i < n; ++i) f(i, 0);
+    return;
+  }
+  std::atomic<size_t> next(0);
+  std::vector<std::thread> pool;
+  for (int t = 0; t < num_threads; ++t) {
+    pool.emplace_back([&, t]() {
+      for (size_t i; (i = next.fetch_add(1)) < n;) f(i, t);
+    });
+  }
+  for (auto& th : pool) th.join();
+}
+
+// Raw (un-entropy-coded) section: 3-byte records, context >= 128 = raw bits.
+struct RawSection {
+  const uint8_t* data = nullptr;
+  size_t size = 0;
+  std::vector<uint8_t> owned;
+  void Put(uint8_t ctx, uint16_t value) {
+    owned.push_back(ctx);
+    owned.push_back(static_cast<uint8_t>(value & 0xFF));
+    owned.push_back(static_cast<uint8_t>(value >> 8));
+  }
+  void Seal() {
+    data = owned.data();
+    size = owned.size();
+  }
+};
+
+int32_t ClampedGradient(int32_t n, int32_t w, int32_t l) {  // enc_frame.cc:158-176
+  const int32_t m = std::min(n, w), M = std::max(n, w);
+  const int32_t grad = static_cast<int32_t>(static_cast<uint32_t>(n) + static_cast<uint32_t>(w) -
+                                            static_cast<uint32_t>(l));
+  const int32_t grad_clamp_M = (l < m) ? M : grad;
+  return (l > M) ? m : grad_clamp_M;
+}
+
+// A rectangular window into an image-absolute grid.
+template <typename T>
+struct GridView {
+  const T* base;
+  size_t pitch, xs, ys;
+  T at(size_t x, size_t y) const { return base[y * pitch + x]; }
+};
+
+// enc_frame.cc:287-316 (WriteDCTokens)
+void DCTokens(const GridView<int16_t> dc[3], RawSection* out) {
+  static const int kOrder[3] = {1, 0, 2};
+  for (int c : kOrder) {
+    const GridView<int16_t>& q = dc[c];
+    for (size_t y = 0; y < q.ys; y++) {
+      for (size_t x = 0; x < q.xs; x++) {
+        int64_t left = (x ? q.at(x - 1, y) : y ? q.at(x, y - 1) : 0);
+        int64_t top = (y ? q.at(x, y - 1) : left);
+        int64_t topleft = (x && y ? q.at(x - 1, y - 1) : left);
+        int32_t guess = ClampedGradient(static_cast<int32_t>(top), static_cast<int32_t>(left),
+                                        static_cast<int32_t>(topleft));
+        uint32_t gradprop =
+            static_cast<uint32_t>(Clamp1<int64_t>(512 + top + left - topleft, 0, 1023));
+        int32_t residual = q.at(x, y) - guess;
+        out->Put(JXLT_kGradientContextLut[gradprop], static_cast<uint16_t>(PackSigned(residual)));
+      }
+    }
+  }
+}
+
+inline bool IsFirst(uint8_t acs) { return acs & 1; }
+inline int32_t StrategyCode(uint8_t acs) {  // ac_strategy.h:59-62
+  static const uint8_t kLut[3] = {0, 6, 7};
+  return kLut[acs >> 1];
+}
+
+// enc_frame.cc:329-424 (WriteACMetadataTokens)
+void ACMetadataTokens(const GridView<int8_t>& ytox, const GridView<int8_t>& ytob,
+                      const GridView<uint8_t>& acs, const GridView<uint8_t>& qf, RawSection* out) {
+  for (size_t c = 0; c < 2; ++c) {
+    const GridView<int8_t>& m = (c == 0 ? ytox : ytob);
+    for (size_t y = 0; y < m.ys; y++) {
+      for (size_t x = 0; x < m.xs; x++) {
+        int64_t left = (x ? m.at(x - 1, y) : y ? m.at(x, y - 1) : 0);
+        int64_t top = (y ? m.at(x, y - 1) : left);
+        int64_t topleft = (x && y ? m.at(x - 1, y - 1) : left);
+        int32_t guess = ClampedGradient(static_cast<int32_t>(top), static_cast<int32_t>(left),
+                                        static_cast<int32_t>(topleft));
+        int32_t residual = static_cast<int32_t>(m.at(x, y)) - guess;
+        out->Put(static_cast<uint8_t>(2u - c), static_cast<uint16_t>(PackSigned(residual)));
+      }
+    }
+  }
+  {
+    int32_t left = 0;
+    for (size_t y = 0; y < acs.ys; y++)
+      for (size_t x = 0; x < acs.xs; x++) {
+        if (!IsFirst(acs.at(x, y))) continue;
+        int32_t cur = StrategyCode(acs.at(x, y));
+        uint8_t ctx = (left > 11 ? 7 : left > 5 ? 8 : left > 3 ? 9 : 10);
+        out->Put(ctx, static_cast<uint16_t>(PackSigned(cur)));
+        left = cur;
+      }
+  }
+  {
+    int32_t left = StrategyCode(acs.at(0, 0));  // sic (enc_frame.cc:386)
+    for (size_t y = 0; y < acs.ys; y++)
+      for (size_t x = 0; x < acs.xs; x++) {
+        if (!IsFirst(acs.at(x, y))) continue;
+        size_t cur = qf.at(x, y) - 1;
+        int32_t residual = static_cast<int32_t>(cur - left);
+        uint8_t ctx = (left > 11 ? 3 : left > 5 ? 4 : left > 3 ? 5 : 6);
+        out->Put(ctx, static_cast<uint16_t>(PackSigned(residual)));
+        left = static_cast<int32_t>(cur);
+      }
+  }
+  for (size_t i = 0; i < acs.xs * acs.ys; ++i) out->Put(0, static_cast<uint16_t>(PackSigned(4)));
+}
+
+// enc_frame.cc:536-570 (WriteDCGroup), raw-record form
+void DCGroupSection(const FrameView& f, size_t xsize_blocks, size_t xsize_tiles, size_t dc_gx,
+                    size_t dc_gy, RawSection* out) {
+  const size_t ysize_blocks = DivCeil(f.ysize, 8);
+  const size_t bx0 = dc_gx * 256, by0 = dc_gy * 256;
+  const size_t nbx = std::min<size_t>(256, xsize_blocks - bx0);
+  const size_t nby = std::min<size_t>(256, ysize_blocks - by0);
+  GridView<int16_t> dc[3];
+  for (int c = 0; c < 3; c++) dc[c] = {f.quant_dc[c] + by0 * xsize_blocks + bx0, xsize_blocks, nbx, nby};
+  GridView<uint8_t> acs = {f.ac_strategy + by0 * xsize_blocks + bx0, xsize_blocks, nbx, nby};
+  GridView<uint8_t> qf = {f.raw_quant_field + by0 * xsize_blocks + bx0, xsize_blocks, nbx, nby};
+  const size_t tx0 = dc_gx * 32, ty0 = dc_gy * 32;
+  const size_t ntx = DivCeil(nbx * 8, 64), nty = DivCeil(nby * 8, 64);
+  GridView<int8_t> ytox = {f.ytox_map + ty0 * xsize_tiles + tx0, xsize_tiles, ntx, nty};
+  GridView<int8_t> ytob = {f.ytob_map + ty0 * xsize_tiles + tx0, xsize_tiles, ntx, nty};
+
+  out->owned.reserve(3 * (nbx * nby * 6 + 64));
+  out->Put(kMaxContexts + 6, 12);  // extra_dc_precision(2)=0, global tree etc (4)=3
+  DCTokens(dc, out);
+  size_t num_ac_blocks = 0;
+  for (size_t y = 0; y < nby; y++)
+    for (size_t x = 0; x < nbx; x++) num_ac_blocks += IsFirst(acs.at(x, y));
+  const size_t nb_bits = CeilLog2Nonzero(nbx * nby);
+  if (nb_bits != 0) out->Put(static_cast<uint8_t>(kMaxContexts + nb_bits), static_cast<uint16_t>(num_ac_blocks - 1));
+  out->Put(kMaxContexts + 4, 3);
+  ACMetadataTokens(ytox, ytob, acs, qf, out);
+  out->Seal();
+}
+
+// enc_frame.cc:765-802 (OptimizeSections)
+void OptimizeSections(const std::vector<RawSection>& raw, size_t num_histograms,
+                      const uint8_t* static_map, size_t num_static_contexts, EntropyCode* code,
+                      std::vector<jxl::BitWriter>* encoded, int num_threads) {
+  int nt = num_threads <= 0 ? static_cast<int>(std::thread::hardware_concurrency()) : num_threads;
+  nt = std::max(1, nt);
+  std::vector<std::vector<Histogram>> partial(nt, std::vector<Histogram>(num_histograms));
+  ParallelFor(raw.size(), nt, [&](size_t i, int t) {
+    std::vector<Histogram>& h = partial[t];
+    const uint8_t* p = raw[i].data;
+    for (size_t j = 0; j < raw[i].size; j += 3) {
+      const uint8_t context = p[j];
+      if (context >= kMaxContexts) continue;
+      const uint32_t value = (static_cast<uint32_t>(p[j + 2]) << 8) + p[j + 1];
+      uint32_t tok, nbits, bits;
+      HybridUintEncode(value, &tok, &nbits, &bits);
+      h[context].Add(tok);
+    }
+  });
+  std::vector<Histogram> histograms(num_histograms);
+  for (const auto& ph : partial)
+    for (size_t k = 0; k < num_histograms; ++k) histograms[k].AddHistogram(ph[k]);
+  OptimizeEntropyCode(&histograms, static_map, num_static_contexts, code);
+
+  encoded->clear();
+  encoded->resize(raw.size());
+  ParallelFor(raw.size(), nt, [&](size_t i, int) {
+    jxl::BitWriter& w = (*encoded)[i];
+    const uint8_t* p = raw[i].data;
+    w.Reserve(raw[i].size / 3 + 16);
+    for (size_t j = 0; j < raw[i].size; j += 3) {
+      const uint8_t context = p[j];
+      const uint32_t value = (static_cast<uint32_t>(p[j + 2]) << 8) + p[j + 1];
+      if (context >= kMaxContexts) w.Write(context - kMaxContexts, value);
+      else WriteToken(context, value, *code, &w);
+    }
+  });
+}
+
+void WriteFrameHeader(uint32_t x_qm_scale, uint32_t epf_iters, jxl::BitWriter* writer) {
+  // enc_frame.cc:426-457
+  writer->Write(1, 0);    // not all default
+  writer->Write(2, 0);    // regular frame
+  writer->Write(1, 0);    // vardct
+  writer->Write(2, 2);    // flags selector bits (17 .. 272)
+  writer->Write(8, 111);  // skip adaptive dc flag (128)
+  writer->Write(2, 0);    // no upsampling
+  writer->Write(3, x_qm_scale);
+  writer->Write(3, 2);  // b_qm_scale
+  writer->Write(2, 0);  // one pass
+  writer->Write(1, 0);  // no custom frame size or origin
+  writer->Write(2, 0);  // replace blend mode
+  writer->Write(1, 1);  // last frame
+  writer->Write(2, 0);  // no name
+  if (epf_iters == 2) {
+    writer->Write(1, 1);  // default loop filter
+  } else {
+    writer->Write(1, 0);  // not default loop filter
+    writer->Write(1, 0);  // no gaborish
+    writer->Write(2, epf_iters);
+    if (epf_iters > 0) {
+      writer->Write(1, 0);  // default epf sharpness
+      writer->Write(1, 0);  // default epf weights
+      writer->Write(1, 0);  // default epf sigma
+    }
+    writer->Write(2, 0);  // no loop filter extensions
+  }
+  writer->Write(2, 0);  // no frame header extensions
+}
+
+void WriteQuantScales(int global_scale, int quant_dc, jxl::BitWriter* writer) {
+  // enc_frame.cc:459-486
+  if (global_scale < 2049) {
+    writer->Write(2, 0);
+    writer->Write(11, global_scale - 1);
+  } else if (global_scale < 4097) {
+    writer->Write(2, 1);
+    writer->Write(11, global_scale - 2049);
+  } else if (global_scale < 8193) {
+    writer->Write(2, 2);
+    writer->Write(12, global_scale - 4097);
+  } else {
+    writer->Write(2, 3);
+    writer->Write(16, global_scale - 8193);
+  }
+  if (quant_dc == 16) {
+    writer->Write(2, 0);
+  } else if (quant_dc < 33) {
+    writer->Write(2, 1);
+    writer->Write(5, quant_dc - 1);
+  } else if (quant_dc < 257) {
+    writer->Write(2, 2);
+    writer->Write(8, quant_dc - 1);
+  } else {
+    writer->Write(2, 3);
+    writer->Write(16, quant_dc - 1);
+  }
+}
+
+void WriteContextTree(size_t num_dc_groups, jxl::BitWriter* writer) {  // enc_frame.cc:488-503
+  std::vector<Token> tokens(313);
+  for (size_t i = 0; i < 313; ++i)
+    tokens[i] = {JXLT_kContextTreeTokens[2 * i], JXLT_kContextTreeTokens[2 * i + 1]};
+  tokens[1].value = PackSigned(static_cast<int32_t>(1 + num_dc_groups));
+  EntropyCode code;
+  OptimizeEntropyCode(tokens, kNumTreeContexts, &code);
+  writer->Write(1, 1);  // not an empty tree
+  writer->Write(1, 0);  // no lz77
+  WriteEntropyCode(code, writer);
+  for (const Token& t : tokens) WriteToken(t.context, t.value, code, writer);
+}
+
+void WriteDCGlobal(const DistanceParams& distp, size_t num_dc_groups, const EntropyCode& dc_code,
+                   jxl::BitWriter* writer) {  // enc_frame.cc:505-522
+  writer->Write(1, 1);  // default dequant dc
+  WriteQuantScales(distp.global_scale, distp.quant_dc, writer);
+  writer->Write(1, 0);   // non-default BlockCtxMap
+  writer->Write(16, 0);  // no dc ctx, no qft
+  WriteStaticContextMap(JXLT_kCompactBlockContextMap, 39, writer);
+  writer->Write(1, 1);  // default DC camp
+  WriteContextTree(num_dc_groups, writer);
+  writer->Write(1, 0);  // no lz77
+  WriteEntropyCode(dc_code, writer);
+}
+
+void WriteACGlobal(size_t num_groups, const EntropyCode& ac_code, jxl::BitWriter* writer) {
+  // enc_frame.cc:524-534
+  writer->Write(1, 1);  // all default quant matrices
+  const size_t num_histo_bits = CeilLog2Nonzero(num_groups);
+  if (num_histo_bits != 0) writer->Write(num_histo_bits, 0);
+  writer->Write(2, 3);
+  writer->Write(13, 0);  // all default coeff order
+  writer->Write(1, 0);   // no lz77
+  WriteEntropyCode(ac_code, writer);
+}
+
+bool WriteTOC(const std::vector<jxl::BitWriter>& sections, jxl::BitWriter* output) {
+  // enc_frame.cc:572-595
+  output->Write(1, 0);  // no permutation
+  output->ZeroPadToByte();
+  for (const jxl::BitWriter& s : sections) {
+    const size_t section_size = DivCeil(s.BitsWritten(), 8);
+    if (section_size >= (1u << 22)) return false;
+    size_t offset = 0;
+    static const size_t kBits[4] = {10, 14, 22, 30};
+    for (size_t i = 0; i < 4; ++i) {
+      if (section_size < offset + (1u << kBits[i])) {
+        output->Write(2, i);
+        output->Write(kBits[i], section_size - offset);
+        break;
+      }
+      offset += (1u << kBits[i]);
+    }
+  }
+  output->ZeroPadToByte();
+  return true;
+}
+
+}  // namespace
+
+DistanceParams ComputeDistanceParams(float distance) {  // enc_frame.cc:115-156
+  DistanceParams p;
+  p.distance = distance;
+  constexpr int kGlobalScaleDenom = 1 << 16;
+  constexpr int kGlobalScaleNumerator = 4096;
+  constexpr float kAcQuant = 0.8f;
+  constexpr float kQuantFieldTarget = 5;
+  float quant_dc = QuantDC(distance);
+  float scale = kGlobalScaleDenom * kAcQuant / (distance * kQuantFieldTarget);
+  scale = Clamp1(scale, 1.0f, 1.0f * (1 << 15));
+  int scaled_quant_dc = static_cast<int>(quant_dc * kGlobalScaleNumerator * 1.6);
+  p.global_scale = Clamp1(static_cast<int>(scale), 1, scaled_quant_dc);
+  p.scale = p.global_scale * (1.0f / kGlobalScaleDenom);
+  p.inv_scale = 1.0f / p.scale;
+  p.quant_dc = static_cast<int>(quant_dc / p.scale + 0.5f);
+  p.quant_dc = Clamp1(p.quant_dc, 1, 1 << 16);
+  p.scale_dc = p.quant_dc * p.scale;
+  p.x_qm_scale = 2;
+  const float x_qm_scale_steps[2] = {1.25f, 9.0f};
+  for (float step : x_qm_scale_steps)
+    if (distance > step) p.x_qm_scale++;
+  if (distance < 0.299f) p.x_qm_scale++;
+  constexpr float kEpfThresholds[3] = {0.7, 1.5, 4.0};
+  p.epf_iters = 0;
+  for (size_t i = 0; i < 3; i++)
+    if (distance >= kEpfThresholds[i]) p.epf_iters++;
+  return p;
+}
+
+bool AssembleFrame(const FrameView& f, const DistanceParams& distp, jxl::BitWriter* writer,
+                   int num_threads) {
+  const size_t xsize_blocks = DivCeil(f.xsize, 8);
+  const size_t xsize_tiles = DivCeil(f.xsize, 64);
+  const size_t xsize_groups = DivCeil(f.xsize, 256), ysize_groups = DivCeil(f.ysize, 256);
+  const size_t xsize_dc_groups = DivCeil(f.xsize, 2048), ysize_dc_groups = DivCeil(f.ysize, 2048);
+  const size_t num_groups = xsize_groups * ysize_groups;
+  const size_t num_dc_groups = xsize_dc_groups * ysize_dc_groups;
+
+  // Raw DC-group sections (enc_frame.cc:760-761).
+  std::vector<RawSection> dc_raw(num_dc_groups);
+  ParallelFor(num_dc_groups, num_threads, [&](size_t i, int) {
+    DCGroupSection(f, xsize_blocks, xsize_tiles, i % xsize_dc_groups, i / xsize_dc_groups, &dc_raw[i]);
+  });
+  std::vector<RawSection> ac_raw(num_groups);
+  for (size_t i = 0; i < num_groups; ++i) {
+    if (f.group_token_bytes[i] % 3 != 0) return false;
+    ac_raw[i].data = f.group_tokens[i];
+    ac_raw[i].size = f.group_token_bytes[i];
+  }
+
+  // Entropy-code optimisation (enc_frame.cc:846-850).
+  uint8_t dc_identity[kNumDCContexts];
+  for (size_t i = 0; i < kNumDCContexts; ++i) dc_identity[i] = static_cast<uint8_t>(i);
+  EntropyCode dc_code, ac_code;
+  std::vector<jxl::BitWriter> dc_sections, ac_sections;
+  OptimizeSections(dc_raw, kNumDCContexts, dc_identity, kNumDCContexts, &dc_code, &dc_sections,
+                   num_threads);
+  OptimizeSections(ac_raw, kNumACPreClusters, JXLT_kACContextMap, kNumACContexts, &ac_code,
+                   &ac_sections, num_threads);
+
+  // Section order: DCGlobal, DC groups, ACGlobal, AC groups (enc_frame.cc:721-722,853-854).
+  std::vector<jxl::BitWriter> sections;
+  sections.reserve(2 + num_dc_groups + num_groups);
+  sections.emplace_back();
+  WriteDCGlobal(distp, num_dc_groups, dc_code, &sections.back());
+  for (auto& s : dc_sections) sections.push_back(std::move(s));
+  sections.emplace_back();
+  WriteACGlobal(num_groups, ac_code, &sections.back());
+  for (auto& s : ac_sections) sections.push_back(std::move(s));
+
+  WriteFrameHeader(distp.x_qm_scale, distp.epf_iters, writer);
+  if (sections.size() == 4) {  // enc_frame.cc:805-811: single group => one section
+    for (size_t i = 1; i < 4; ++i) sections[0].Append(sections[i]);
+    sections.resize(1);
+  }
+  if (!WriteTOC(sections, writer)) return false;
+  writer->AppendByteAligned(&sections);
+  return true;
+}
+
+}  // namespace jxlt

@@ -1,0 +1,53 @@
+// Host bitstream back-end: turns the hot path's outputs (per-group raw AC token
+// records + the DC-group side-band grids) into the JPEG XL frame bitstream.
+//
+// Replaces, on the host, the part of the reference's EncodeFrame that follows
+// the per-group pixel pipeline:
+//   /root/reference/encoder/enc_frame.cc:287-424  DC / AC-metadata tokenisers
+//   /root/reference/encoder/enc_frame.cc:426-595  headers, globals, TOC
+//   /root/reference/encoder/enc_frame.cc:765-816  OptimizeSections, CombineSections
+#ifndef JXLT_HOST_FRAME_ASSEMBLER_H_
+#define JXLT_HOST_FRAME_ASSEMBLER_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "encoder/enc_bit_writer.h"
+
+namespace jxlt {
+
+// enc_frame.cc:104-156
+struct DistanceParams {
+  float distance;
+  int global_scale;
+  int quant_dc;
+  float scale;
+  float inv_scale;
+  float scale_dc;
+  uint32_t x_qm_scale;
+  uint32_t epf_iters;
+};
+DistanceParams ComputeDistanceParams(float distance);
+
+// Image-absolute grids: blocks are 8x8 px (row pitch xsize_blocks), tiles 64x64
+// px (row pitch xsize_tiles); one raw token buffer per 256x256 group in raster
+// group order ([u8 pre-clustered ctx][u16 LE value] records).
+struct FrameView {
+  size_t xsize, ysize;
+  const int16_t* quant_dc[3];
+  const uint8_t* raw_quant_field;
+  const uint8_t* ac_strategy;  // (type << 1) | is_first
+  const int8_t* ytox_map;
+  const int8_t* ytob_map;
+  const uint8_t* const* group_tokens;
+  const size_t* group_token_bytes;
+};
+
+// Appends frame header + TOC + all sections to `writer` (must be byte aligned).
+// num_threads <= 0 selects std::thread::hardware_concurrency().
+bool AssembleFrame(const FrameView& frame, const DistanceParams& distp, jxl::BitWriter* writer,
+                   int num_threads);
+
+}  // namespace jxlt
+
+#endif  // JXLT_HOST_FRAME_ASSEMBLER_H_

@@ -1,0 +1,112 @@
+// C ABI of libjxltiny_host.so (see include/jxl_tiny_amd.h).
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/jxl_tiny_amd.h"
+#include "encoder/enc_file.h"
+#include "encoder/enc_frame.h"
+#include "frame_assembler.h"
+#include "host_internal.h"
+
+namespace {
+
+int ToMalloc(const std::vector<uint8_t>& bytes, uint8_t** out_bytes, size_t* out_size) {
+  uint8_t* p = static_cast<uint8_t*>(malloc(bytes.size() ? bytes.size() : 1));
+  if (!p) return JXLT_ERR_OUT_OF_MEMORY;
+  memcpy(p, bytes.data(), bytes.size());
+  *out_bytes = p;
+  *out_size = bytes.size();
+  return JXLT_OK;
+}
+
+jxlt::DistanceParams FromC(const jxlt_distance_params& d) {
+  jxlt::DistanceParams p;
+  p.distance = d.distance;
+  p.global_scale = d.global_scale;
+  p.quant_dc = d.quant_dc;
+  p.scale = d.scale;
+  p.inv_scale = d.inv_scale;
+  p.scale_dc = d.scale_dc;
+  p.x_qm_scale = d.x_qm_scale;
+  p.epf_iters = d.epf_iters;
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+void jxlt_compute_distance_params(float distance, jxlt_distance_params* out) {
+  const jxlt::DistanceParams p = jxlt::ComputeDistanceParams(distance);
+  out->distance = p.distance;
+  out->global_scale = p.global_scale;
+  out->quant_dc = p.quant_dc;
+  out->scale = p.scale;
+  out->inv_scale = p.inv_scale;
+  out->scale_dc = p.scale_dc;
+  out->x_qm_scale = p.x_qm_scale;
+  out->epf_iters = p.epf_iters;
+}
+
+int jxlt_assemble_frame_groups(const jxlt_frame_result* frame, const uint8_t* const* group_tokens,
+                               const size_t* group_token_bytes, const jxlt_distance_params* distp,
+                               int num_threads, uint8_t** out_bytes, size_t* out_size) {
+  if (!frame || !group_tokens || !group_token_bytes || !distp || !out_bytes || !out_size)
+    return JXLT_ERR_INVALID_ARGUMENT;
+  jxlt::FrameView view;
+  view.xsize = frame->xsize;
+  view.ysize = frame->ysize;
+  for (int c = 0; c < 3; ++c) view.quant_dc[c] = frame->quant_dc[c];
+  view.raw_quant_field = frame->raw_quant_field;
+  view.ac_strategy = frame->ac_strategy;
+  view.ytox_map = frame->ytox_map;
+  view.ytob_map = frame->ytob_map;
+  view.group_tokens = group_tokens;
+  view.group_token_bytes = group_token_bytes;
+  jxl::BitWriter writer;
+  if (!jxlt::AssembleFrame(view, FromC(*distp), &writer, num_threads)) return JXLT_ERR_INTERNAL;
+  return ToMalloc(writer.TakeBytes(), out_bytes, out_size);
+}
+
+int jxlt_assemble_frame(const jxlt_frame_result* frame, const jxlt_distance_params* distp,
+                        int num_threads, uint8_t** out_bytes, size_t* out_size) {
+  if (!frame || !frame->tokens || !frame->group_token_offset) return JXLT_ERR_INVALID_ARGUMENT;
+  std::vector<const uint8_t*> ptr(frame->num_groups);
+  std::vector<size_t> len(frame->num_groups);
+  for (size_t g = 0; g < frame->num_groups; ++g) {
+    ptr[g] = frame->tokens + frame->group_token_offset[g];
+    len[g] = static_cast<size_t>(frame->group_token_offset[g + 1] - frame->group_token_offset[g]);
+  }
+  return jxlt_assemble_frame_groups(frame, ptr.data(), len.data(), distp, num_threads, out_bytes,
+                                    out_size);
+}
+
+int jxlt_write_file_header(size_t xsize, size_t ysize, uint8_t** out_bytes, size_t* out_size) {
+  jxl::BitWriter writer;
+  if (!jxlt::WriteFileHeader(xsize, ysize, &writer)) return JXLT_ERR_INVALID_ARGUMENT;
+  return ToMalloc(writer.TakeBytes(), out_bytes, out_size);
+}
+
+int jxlt_encode_file_planar(const float* const planes[3], size_t pitch_bytes, size_t xsize,
+                            size_t ysize, float distance, int device_ordinal, uint8_t** out_bytes,
+                            size_t* out_size) {
+  if (!planes || !out_bytes || !out_size || xsize == 0 || ysize == 0 ||
+      pitch_bytes < xsize * sizeof(float) || pitch_bytes % sizeof(float))
+    return JXLT_ERR_INVALID_ARGUMENT;
+  jxl::Image3F img(xsize, ysize);
+  if (!img.valid()) return JXLT_ERR_OUT_OF_MEMORY;
+  for (size_t c = 0; c < 3; ++c)
+    for (size_t y = 0; y < ysize; ++y)
+      memcpy(img.PlaneRow(c, y), reinterpret_cast<const uint8_t*>(planes[c]) + y * pitch_bytes,
+             xsize * sizeof(float));
+  jxl::SetEncoderDevice(device_ordinal);
+  std::vector<uint8_t> out;
+  if (!jxl::EncodeFile(img, distance, &out)) return JXLT_ERR_INTERNAL;
+  return ToMalloc(out, out_bytes, out_size);
+}
+
+void jxlt_free(void* p) { free(p); }
+
+}  // extern "C"

@@ -1,0 +1,14 @@
+// Internal declarations shared by the host sources.
+#ifndef JXLT_HOST_INTERNAL_H_
+#define JXLT_HOST_INTERNAL_H_
+
+#include <stddef.h>
+
+#include "encoder/enc_bit_writer.h"
+
+namespace jxlt {
+bool WriteFileHeader(size_t xsize, size_t ysize, jxl::BitWriter* writer);
+bool NormalizeDistance(float* distance);
+}  // namespace jxlt
+
+#endif  // JXLT_HOST_INTERNAL_H_

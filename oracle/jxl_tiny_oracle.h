@@ -1,0 +1,95 @@
+/* TEST INFRASTRUCTURE -- NOT PART OF THE PRODUCT.
+ *
+ * CPU restatement ("oracle") of the libjxl-tiny per-group encode hot path:
+ *   CopyAndPadImage -> ToXYB -> ComputeAdaptiveQuantFieldTile -> ComputeCmapTile
+ *   -> FindBest16x16Transform/AdjustQuantField -> WriteACGroup (DCT, quantise,
+ *   DC, nzeros, raw 3-byte tokens).
+ * Reference: /root/reference/encoder/enc_frame.cc:685-763 and the files it calls
+ * (each function in jxl_tiny_oracle.c cites the file:line it follows).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
+ * anything under oracle/.  The product (libjxl-tiny_amd/) never links it.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for
+ * this path and cannot be built in this image (its Highway
+ * dependency is an empty submodule and there is no network), so
+ * this restatement is pinned only by (a) line-by-line citation and (b) the
+ * size-only known answers recorded in SURVEY.md Appendix C from a one-off probe
+ * build (see tests/test_oracle_known_answers.py).
+ *
+ * Canonical arithmetic model: Highway vectors of 8 float
+ * lanes (AVX2-like), MulAdd/NegMulAdd fused (fmaf), every other operation a
+ * single IEEE-754 binary32 operation with no contraction, SumOfLanes = halving
+ * tree (+4, +2, +1), ApproximateReciprocal(x) = 1/x, Round = ties-to-even,
+ * non-scalar branch of enc_adaptive_quantization.cc:230, strategy multipliers
+ * computed from the call's distance.
+ */
+#ifndef JXL_TINY_ORACLE_H_
+#define JXL_TINY_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* enc_frame.cc:104-156 */
+typedef struct {
+  float distance;
+  int32_t global_scale;
+  int32_t quant_dc;
+  float scale;
+  float inv_scale;
+  float scale_dc;
+  uint32_t x_qm_scale;
+  uint32_t epf_iters;
+} orc_distance_params;
+
+void orc_compute_distance_params(float distance, orc_distance_params* p);
+
+/* Whole-image result of the hot path.  Block grids are xsize_blocks x
+ * ysize_blocks (row-major, image-absolute block coordinates); tile grids are
+ * xsize_tiles x ysize_tiles (64x64 tiles).  Token buffers are one per 256x256
+ * group, in raster group order, holding the reference's raw 3-byte records
+ * [pre-clustered context u8][value u16 LE] (enc_group.cc:468-470). */
+typedef struct {
+  size_t xsize, ysize;
+  size_t xsize_blocks, ysize_blocks;
+  size_t xsize_tiles, ysize_tiles;
+  size_t xsize_groups, ysize_groups;
+  int16_t* quant_dc[3];     /* dc_group_data.h:33 */
+  uint8_t* raw_quant_field; /* dc_group_data.h:34 */
+  uint8_t* ac_strategy;     /* (type<<1)|is_first, ac_strategy.h:151-165 */
+  int8_t* ytox_map;         /* dc_group_data.h:36 */
+  int8_t* ytob_map;
+  uint8_t** group_tokens;   /* [num_groups] */
+  size_t* group_token_bytes;
+  /* optional intermediates (always filled): */
+  float* xyb[3];       /* (xsize_blocks*8) x (ysize_blocks*8), XYB incl. padding */
+  float* quant_field;  /* per block, float AQ field (tile-local aq_map) */
+  float* masking;      /* per block */
+  float* entropy8;     /* per 2x2 cell: 8 floats (e00,e01,e10,e11,16x8 L,R,8x16 T,B),
+                          grid (xsize_blocks/2+1) x (ysize_blocks/2+1), NaN if not evaluated */
+} orc_frame;
+
+/* planes[c] + y*stride_floats addresses row y of channel c (linear sRGB).
+ * force_dct8 != 0 mimics OPTIMIZE_BLOCK_SIZES 0 (config.h:12).
+ * Returns 0 on success, nonzero for invalid arguments. */
+int orc_encode_hot_path(const float* const planes[3], size_t stride_floats,
+                        size_t xsize, size_t ysize, float distance,
+                        int force_dct8, orc_frame* out);
+void orc_frame_free(orc_frame* f);
+
+/* Stage-level entry points for unit parity tests. */
+void orc_to_xyb(float* r, float* g, float* b, size_t n); /* in place */
+void orc_dct8x8(const float* px, size_t stride, float* out64);
+void orc_dct16x8(const float* px, size_t stride, float* out128);
+void orc_dct8x16(const float* px, size_t stride, float* out128);
+float orc_fast_log2f(float x);
+float orc_fast_pow2f(float x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JXL_TINY_ORACLE_H_ */

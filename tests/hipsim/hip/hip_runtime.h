@@ -1,0 +1,280 @@
+// TEST INFRASTRUCTURE -- a tiny HIP *execution model* on the CPU.
+//
+// Lets tests compile libjxl-tiny_amd/csrc/jxlt_device.h (pure device code)
+// with g++ and run its kernels workgroup by workgroup, so every kernel can be
+// compared bit-for-bit with the oracle in a container that has no GPU.  It is
+// never linked into the product libraries (those are built by hipcc only).
+//
+// Model: one workgroup at a time; every HIP thread is a ucontext fiber.
+//  * __syncthreads(): block barrier (all unfinished fibers must arrive;
+//    anything else is reported as a divergent-barrier deadlock).
+//  * __shfl/__shfl_xor/__shfl_up: point-to-point exchange keyed by a per-lane
+//    call counter, so lanes that communicate must execute the same shuffle
+//    sequence (as on hardware) but unrelated lane groups may diverge.
+//  * __ballot: wave-wide rendezvous of all unfinished lanes of the wave.
+#ifndef HIPSIM_HIP_RUNTIME_H_
+#define HIPSIM_HIP_RUNTIME_H_
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float4 {
+  float x, y, z, w;
+} __attribute__((aligned(16)));
+
+namespace hipsim {
+
+constexpr int kWave = 64;
+constexpr int kRing = 256;
+
+enum State { kRunnable, kAtBlockBarrier, kAtWaveBarrier, kWaitLane, kDone };
+
+struct Fiber {
+  ucontext_t ctx;
+  std::vector<char> stack;
+  State state = kRunnable;
+  dim3 tid;
+  uint64_t shfl_epoch = 0;
+  uint64_t ring[kRing];
+  int wait_lane = -1;        // absolute thread index we are waiting for
+  uint64_t wait_epoch = 0;
+  uint64_t ballot_arg = 0;
+};
+
+struct Machine {
+  std::vector<Fiber> fibers;
+  ucontext_t sched;
+  int current = -1;
+  dim3 block_idx, block_dim, grid_dim;
+  std::function<void()> body;
+  std::vector<uint64_t> ballot_result;  // per wave
+};
+
+inline Machine& M() {
+  static Machine m;
+  return m;
+}
+inline Fiber& cur() { return M().fibers[M().current]; }
+inline void yield_to_scheduler() { swapcontext(&cur().ctx, &M().sched); }
+
+inline void trampoline() {
+  M().body();
+  cur().state = kDone;
+  yield_to_scheduler();
+}
+
+inline void run_block(const std::function<void()>& body, dim3 grid, dim3 block, dim3 bidx) {
+  Machine& m = M();
+  const int n = (int)(block.x * block.y * block.z);
+  m.body = body;
+  m.block_idx = bidx;
+  m.block_dim = block;
+  m.grid_dim = grid;
+  if ((int)m.fibers.size() != n) m.fibers.assign(n, Fiber());
+  m.ballot_result.assign((n + kWave - 1) / kWave, 0);
+  for (int i = 0; i < n; i++) {
+    Fiber& f = m.fibers[i];
+    if (f.stack.empty()) f.stack.resize(128 * 1024);
+    f.state = kRunnable;
+    f.shfl_epoch = 0;
+    f.tid = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack.data();
+    f.ctx.uc_stack.ss_size = f.stack.size();
+    f.ctx.uc_link = &m.sched;
+    makecontext(&f.ctx, (void (*)())trampoline, 0);
+  }
+  for (;;) {
+    bool progress = false;
+    int done = 0;
+    for (int i = 0; i < n; i++) {
+      Fiber& f = m.fibers[i];
+      if (f.state == kWaitLane) {
+        const Fiber& src = m.fibers[f.wait_lane];
+        if (src.shfl_epoch >= f.wait_epoch) f.state = kRunnable;
+        else if (src.state == kDone) {
+          fprintf(stderr, "hipsim: thread %d shuffles from finished thread %d\n", i, f.wait_lane);
+          abort();
+        }
+      }
+      if (f.state == kRunnable) {
+        m.current = i;
+        swapcontext(&m.sched, &f.ctx);
+        progress = true;
+      }
+      if (f.state == kDone) done++;
+    }
+    if (done == n) break;
+    // wave barriers (ballot)
+    const int nw = (n + kWave - 1) / kWave;
+    for (int w = 0; w < nw; w++) {
+      int waiting = 0, live = 0;
+      uint64_t mask = 0;
+      for (int l = 0; l < kWave && w * kWave + l < n; l++) {
+        const Fiber& f = m.fibers[w * kWave + l];
+        if (f.state == kDone) continue;
+        live++;
+        if (f.state == kAtWaveBarrier) {
+          waiting++;
+          if (f.ballot_arg) mask |= 1ull << l;
+        }
+      }
+      if (live > 0 && waiting == live) {
+        m.ballot_result[w] = mask;
+        for (int l = 0; l < kWave && w * kWave + l < n; l++) {
+          Fiber& f = m.fibers[w * kWave + l];
+          if (f.state == kAtWaveBarrier) f.state = kRunnable;
+        }
+        progress = true;
+      }
+    }
+    // block barrier
+    {
+      int waiting = 0, live = 0;
+      for (int i = 0; i < n; i++) {
+        if (m.fibers[i].state == kDone) continue;
+        live++;
+        if (m.fibers[i].state == kAtBlockBarrier) waiting++;
+      }
+      if (live > 0 && waiting == live) {
+        for (int i = 0; i < n; i++)
+          if (m.fibers[i].state == kAtBlockBarrier) m.fibers[i].state = kRunnable;
+        progress = true;
+      }
+    }
+    if (!progress) {
+      int nb = 0, nwv = 0, nl = 0;
+      for (int i = 0; i < n; i++) {
+        nb += m.fibers[i].state == kAtBlockBarrier;
+        nwv += m.fibers[i].state == kAtWaveBarrier;
+        nl += m.fibers[i].state == kWaitLane;
+      }
+      fprintf(stderr,
+              "hipsim: DEADLOCK in block %u (divergent barrier/shuffle): %d at __syncthreads, "
+              "%d at ballot, %d waiting for a shuffle partner, %d done\n",
+              bidx.x, nb, nwv, nl, done);
+      abort();
+    }
+  }
+}
+
+// Launches `kernel(args...)` over the whole grid, one workgroup after another.
+template <typename K, typename... Args>
+void launch(K kernel, dim3 grid, dim3 block, Args... args) {
+  for (unsigned bz = 0; bz < grid.z; bz++)
+    for (unsigned by = 0; by < grid.y; by++)
+      for (unsigned bx = 0; bx < grid.x; bx++)
+        run_block([&]() { kernel(args...); }, grid, block, dim3(bx, by, bz));
+}
+
+inline uint64_t exchange(uint64_t v, int src_lane_in_wave) {
+  Machine& m = M();
+  Fiber& f = cur();
+  const int me = m.current;
+  const int wave_base = me - (me % kWave);
+  int src = wave_base + src_lane_in_wave;
+  const int n = (int)m.fibers.size();
+  const uint64_t e = ++f.shfl_epoch;
+  f.ring[e % kRing] = v;
+  if (src < 0 || src >= n || src == me) return v;
+  Fiber& s = m.fibers[src];
+  if (s.shfl_epoch < e) {
+    f.state = kWaitLane;
+    f.wait_lane = src;
+    f.wait_epoch = e;
+    yield_to_scheduler();
+  }
+  if (s.shfl_epoch - e >= (uint64_t)kRing) {
+    fprintf(stderr, "hipsim: shuffle ring overflow\n");
+    abort();
+  }
+  return s.ring[e % kRing];
+}
+
+}  // namespace hipsim
+
+#define threadIdx (hipsim::cur().tid)
+#define blockIdx (hipsim::M().block_idx)
+#define blockDim (hipsim::M().block_dim)
+#define gridDim (hipsim::M().grid_dim)
+
+inline void __syncthreads() {
+  hipsim::cur().state = hipsim::kAtBlockBarrier;
+  hipsim::yield_to_scheduler();
+}
+
+template <typename T>
+inline T hipsim_shfl_bits(T v, int src_lane) {
+  static_assert(sizeof(T) <= 8, "shuffle payload");
+  uint64_t u = 0;
+  memcpy(&u, &v, sizeof(T));
+  u = hipsim::exchange(u, src_lane);
+  T r;
+  memcpy(&r, &u, sizeof(T));
+  return r;
+}
+inline int hipsim_lane() { return hipsim::M().current % hipsim::kWave; }
+
+template <typename T>
+inline T __shfl_xor(T v, int mask, int width = 64) {
+  (void)width;
+  return hipsim_shfl_bits(v, hipsim_lane() ^ mask);
+}
+template <typename T>
+inline T __shfl(T v, int src_lane, int width = 64) {
+  const int lane = hipsim_lane();
+  const int src = (lane & ~(width - 1)) | (src_lane & (width - 1));
+  return hipsim_shfl_bits(v, src);
+}
+template <typename T>
+inline T __shfl_up(T v, unsigned delta, int width = 64) {
+  (void)width;
+  const int lane = hipsim_lane();
+  const int src = lane - (int)delta;
+  // lanes below delta keep their own value, but must still take part in the exchange
+  return hipsim_shfl_bits(v, src < 0 ? lane : src);
+}
+inline unsigned long long __ballot(int pred) {
+  hipsim::Fiber& f = hipsim::cur();
+  f.ballot_arg = pred ? 1 : 0;
+  f.state = hipsim::kAtWaveBarrier;
+  hipsim::yield_to_scheduler();
+  return hipsim::M().ballot_result[hipsim::M().current / hipsim::kWave];
+}
+
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline int __clzll(long long x) { return x == 0 ? 64 : __builtin_clzll((unsigned long long)x); }
+inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }
+inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+inline int32_t __float_as_int(float f) { int32_t u; memcpy(&u, &f, 4); return u; }
+inline float __int_as_float(int32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+// One workgroup runs at a time and fibers never preempt: plain RMW is atomic.
+template <typename T>
+inline T atomicAdd(T* p, T v) {
+  T old = *p;
+  *p = old + v;
+  return old;
+}
+
+#endif  // HIPSIM_HIP_RUNTIME_H_

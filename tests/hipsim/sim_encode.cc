@@ -1,0 +1,122 @@
+// TEST INFRASTRUCTURE: runs the product's device kernels (jxlt_device.h) on the
+// CPU execution model in hip/hip_runtime.h and exposes the result through a C
+// function with the same output structure as the oracle, so tests can diff them.
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../libjxl-tiny_amd/csrc/jxlt_host_tables.h"
+
+using namespace jxlt_dev;
+
+extern "C" {
+
+struct sim_result {
+  size_t xsize_blocks, ysize_blocks, xsize_tiles, ysize_tiles, num_groups;
+  int16_t* quant_dc[3];
+  uint8_t* raw_quant;
+  uint8_t* strategy;
+  int8_t* ytox;
+  int8_t* ytob;
+  uint8_t* tokens;
+  uint64_t* group_tok_offset;  // [num_groups+1], in tokens
+  float* xyb[3];
+  float* qf;
+  float* mask;
+  float* ent8;
+};
+
+int sim_encode(const float* const planes[3], size_t pitch_floats, size_t xsize, size_t ysize,
+               float distance, float scale, float inv_scale, float scale_dc, uint32_t x_qm_scale,
+               uint32_t flags, sim_result* r) {
+  const FrameGeom g = MakeGeom(xsize, ysize);
+  DeviceTables* tab = new DeviceTables;
+  BuildDeviceTables(scale, tab);
+  const size_t nblocks = (size_t)g.xsize_blocks * g.ysize_blocks;
+  const size_t ntiles = (size_t)g.xsize_tiles * g.ysize_tiles;
+  const size_t ngroups = (size_t)g.xsize_groups * g.ysize_groups;
+  memset(r, 0, sizeof(*r));
+  r->xsize_blocks = g.xsize_blocks;
+  r->ysize_blocks = g.ysize_blocks;
+  r->xsize_tiles = g.xsize_tiles;
+  r->ysize_tiles = g.ysize_tiles;
+  r->num_groups = ngroups;
+  TileArgs A;
+  memset(&A, 0, sizeof(A));
+  for (int c = 0; c < 3; c++) {
+    A.planes[c] = planes[c];
+    A.quant_dc[c] = r->quant_dc[c] = (int16_t*)calloc(nblocks, 2);
+    A.nzgrid[c] = (uint8_t*)calloc(nblocks, 1);
+    A.dbg_xyb[c] = r->xyb[c] = (float*)calloc(nblocks * 64, 4);
+  }
+  A.pitch = pitch_floats;
+  A.g = g;
+  A.distance = distance;
+  A.scale = scale;
+  A.inv_scale = inv_scale;
+  A.scale_dc = scale_dc;
+  A.x_qm_mul = XQmMultiplier(x_qm_scale);
+  A.flags = flags;
+  A.tab = tab;
+  A.raw_quant = r->raw_quant = (uint8_t*)calloc(nblocks, 1);
+  A.strategy = r->strategy = (uint8_t*)calloc(nblocks, 1);
+  A.ytox = r->ytox = (int8_t*)calloc(ntiles, 1);
+  A.ytob = r->ytob = (int8_t*)calloc(ntiles, 1);
+  A.blk_nz = (uint8_t*)calloc(nblocks * 3, 1);
+  A.blk_nscan = (uint8_t*)calloc(nblocks * 3, 1);
+  A.coef_scan = (int16_t*)calloc(nblocks * 3 * 64, 2);
+  A.group_ntok = (uint32_t*)calloc(ngroups, 4);
+  A.dbg_qf = r->qf = (float*)calloc(nblocks, 4);
+  A.dbg_mask = r->mask = (float*)calloc(nblocks, 4);
+  const size_t ncells = ((size_t)g.xsize_blocks / 2 + 1) * ((size_t)g.ysize_blocks / 2 + 1);
+  A.dbg_ent8 = r->ent8 = (float*)malloc(ncells * 8 * 4);
+  for (size_t i = 0; i < ncells * 8; i++) A.dbg_ent8[i] = __builtin_nanf("");
+
+  hipsim::launch(tile_kernel, dim3((unsigned)ntiles), dim3(kTileThreads), A);
+
+  r->group_tok_offset = (uint64_t*)calloc(ngroups + 1, 8);
+  hipsim::launch(group_scan_kernel, dim3(1), dim3(256), (const uint32_t*)A.group_ntok,
+                 r->group_tok_offset, (int)ngroups);
+  const uint64_t total = r->group_tok_offset[ngroups];
+  r->tokens = (uint8_t*)calloc(total * 3 + 1, 1);
+  TokenArgs K;
+  memset(&K, 0, sizeof(K));
+  K.g = g;
+  K.tab = tab;
+  K.strategy = A.strategy;
+  for (int c = 0; c < 3; c++) K.nzgrid[c] = A.nzgrid[c];
+  K.blk_nz = A.blk_nz;
+  K.blk_nscan = A.blk_nscan;
+  K.coef_scan = A.coef_scan;
+  K.group_tok_offset = r->group_tok_offset;
+  K.tokens = r->tokens;
+  hipsim::launch(token_kernel, dim3((unsigned)ngroups), dim3(kTokenThreads), K);
+
+  for (int c = 0; c < 3; c++) free(A.nzgrid[c]);
+  free(A.blk_nz);
+  free(A.blk_nscan);
+  free(A.coef_scan);
+  free(A.group_ntok);
+  delete tab;
+  return 0;
+}
+
+void sim_free(sim_result* r) {
+  for (int c = 0; c < 3; c++) {
+    free(r->quant_dc[c]);
+    free(r->xyb[c]);
+  }
+  free(r->raw_quant);
+  free(r->strategy);
+  free(r->ytox);
+  free(r->ytob);
+  free(r->tokens);
+  free(r->group_tok_offset);
+  free(r->qf);
+  free(r->mask);
+  free(r->ent8);
+  memset(r, 0, sizeof(*r));
+}
+
+}  // extern "C"

@@ -1,0 +1,253 @@
+"""Shared helpers for the tests: ctypes bindings of the oracle (oracle/liboracle.so),
+of the CPU execution model of the kernels (tests/hipsim/libjxlt_sim.so) and the
+synthetic image generator of SURVEY.md section 8(d)."""
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+PKG = ROOT / "libjxl-tiny_amd"
+fp = C.POINTER(C.c_float)
+
+
+# --------------------------------------------------------------------------- images
+def synthetic_image(w, h, seed=1234, hard=False):
+    """deterministic linear-sRGB test image, float32 [h, w, 3]."""
+    rng = np.random.default_rng(4321 if hard else seed)
+    if hard:
+        return rng.random((h, w, 3)).astype(np.float32)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    r = 0.5 + 0.4 * np.sin(x / 37) * np.cos(y / 53)
+    g = 0.5 + 0.4 * np.sin((x + y) / 91)
+    b = 0.3 + 0.3 * np.cos(x / 19 - y / 29)
+    img = np.stack([r, g, b], axis=-1)
+    img *= (0.6 + 0.4 * ((np.floor(x / 48) + np.floor(y / 80)) % 2))[..., None]
+    img += rng.normal(0, 0.02, img.shape)
+    img = np.clip(img, 0, 1) ** 2.2
+    return img.astype(np.float32)
+
+
+def to_planes(img):
+    """[h, w, 3] -> contiguous [3, h, w] float32."""
+    return np.ascontiguousarray(np.moveaxis(img, -1, 0), dtype=np.float32)
+
+
+def write_pfm(path, img):
+    h, w, _ = img.shape
+    with open(path, "wb") as f:
+        f.write(b"PF\n%d %d\n-1.0\n" % (w, h))
+        f.write(np.ascontiguousarray(img[::-1], dtype="<f4").tobytes())
+
+
+# --------------------------------------------------------------------------- builds
+def _run(cmd, cwd):
+    subprocess.run(cmd, cwd=cwd, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+
+
+def build_oracle():
+    _run(["make", "-s", "-C", str(ROOT / "oracle")], ROOT)
+    return ROOT / "oracle" / "liboracle.so"
+
+
+def build_sim():
+    d = ROOT / "tests" / "hipsim"
+    out = d / "libjxlt_sim.so"
+    srcs = [d / "sim_encode.cc", d / "hip" / "hip_runtime.h", PKG / "csrc" / "jxlt_device.h",
+            PKG / "csrc" / "jxlt_host_tables.h", PKG / "csrc" / "jxlt_tables.h"]
+    if not out.exists() or any(s.stat().st_mtime > out.stat().st_mtime for s in srcs):
+        _run(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-mfma", "-fPIC", "-shared", "-I.",
+              "-x", "c++", "sim_encode.cc", "-o", "libjxlt_sim.so"], d)
+    return out
+
+
+# --------------------------------------------------------------------------- oracle
+class OrcDistanceParams(C.Structure):
+    _fields_ = [("distance", C.c_float), ("global_scale", C.c_int32), ("quant_dc", C.c_int32),
+                ("scale", C.c_float), ("inv_scale", C.c_float), ("scale_dc", C.c_float),
+                ("x_qm_scale", C.c_uint32), ("epf_iters", C.c_uint32)]
+
+
+class OrcFrame(C.Structure):
+    _fields_ = [("xsize", C.c_size_t), ("ysize", C.c_size_t),
+                ("xsize_blocks", C.c_size_t), ("ysize_blocks", C.c_size_t),
+                ("xsize_tiles", C.c_size_t), ("ysize_tiles", C.c_size_t),
+                ("xsize_groups", C.c_size_t), ("ysize_groups", C.c_size_t),
+                ("quant_dc", C.POINTER(C.c_int16) * 3),
+                ("raw_quant_field", C.POINTER(C.c_uint8)),
+                ("ac_strategy", C.POINTER(C.c_uint8)),
+                ("ytox_map", C.POINTER(C.c_int8)), ("ytob_map", C.POINTER(C.c_int8)),
+                ("group_tokens", C.POINTER(C.POINTER(C.c_uint8))),
+                ("group_token_bytes", C.POINTER(C.c_size_t)),
+                ("xyb", fp * 3), ("quant_field", fp), ("masking", fp), ("entropy8", fp)]
+
+
+def _np(ptr, shape, dtype):
+    n = int(np.prod(shape))
+    if n == 0:
+        return np.zeros(shape, dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype).reshape(shape).copy()
+
+
+class HotPathResult:
+    """Plain numpy view of one hot-path run (oracle, simulator or GPU)."""
+    __slots__ = ("quant_dc", "raw_quant", "strategy", "ytox", "ytob", "group_tokens",
+                 "xyb", "qf", "mask", "ent8", "xsize", "ysize")
+
+    def all_tokens(self):
+        return b"".join(self.group_tokens)
+
+
+_oracle = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        L = C.CDLL(str(build_oracle()))
+        L.orc_encode_hot_path.argtypes = [C.POINTER(fp), C.c_size_t, C.c_size_t, C.c_size_t,
+                                          C.c_float, C.c_int, C.POINTER(OrcFrame)]
+        L.orc_encode_hot_path.restype = C.c_int
+        L.orc_frame_free.argtypes = [C.POINTER(OrcFrame)]
+        L.orc_compute_distance_params.argtypes = [C.c_float, C.POINTER(OrcDistanceParams)]
+        _oracle = L
+    return _oracle
+
+
+def distance_params(distance):
+    p = OrcDistanceParams()
+    oracle().orc_compute_distance_params(C.c_float(distance), C.byref(p))
+    return p
+
+
+def _plane_ptrs(planes):
+    assert planes.dtype == np.float32 and planes.flags.c_contiguous and planes.shape[0] == 3
+    arr = (fp * 3)()
+    for c in range(3):
+        arr[c] = planes[c].ctypes.data_as(fp)
+    return arr
+
+
+def oracle_hot_path(planes, distance, force_dct8=False, keep=False):
+    """planes: [3, h, w] float32.  Returns HotPathResult (and the raw frame if keep)."""
+    L = oracle()
+    _, h, w = planes.shape
+    f = OrcFrame()
+    rc = L.orc_encode_hot_path(_plane_ptrs(planes), w, w, h, C.c_float(distance), int(force_dct8),
+                               C.byref(f))
+    if rc != 0:
+        raise ValueError("oracle rejected input: rc=%d" % rc)
+    r = HotPathResult()
+    r.xsize, r.ysize = w, h
+    xb, yb, xt, yt = f.xsize_blocks, f.ysize_blocks, f.xsize_tiles, f.ysize_tiles
+    ng = f.xsize_groups * f.ysize_groups
+    r.quant_dc = np.stack([_np(f.quant_dc[c], (yb, xb), np.int16) for c in range(3)])
+    r.raw_quant = _np(f.raw_quant_field, (yb, xb), np.uint8)
+    r.strategy = _np(f.ac_strategy, (yb, xb), np.uint8)
+    r.ytox = _np(f.ytox_map, (yt, xt), np.int8)
+    r.ytob = _np(f.ytob_map, (yt, xt), np.int8)
+    r.group_tokens = [C.string_at(f.group_tokens[g], f.group_token_bytes[g]) for g in range(ng)]
+    r.xyb = np.stack([_np(f.xyb[c], (yb * 8, xb * 8), np.float32) for c in range(3)])
+    r.qf = _np(f.quant_field, (yb, xb), np.float32)
+    r.mask = _np(f.masking, (yb, xb), np.float32)
+    r.ent8 = _np(f.entropy8, (yb // 2 + 1, xb // 2 + 1, 8), np.float32)
+    if keep:
+        return r, f
+    L.orc_frame_free(C.byref(f))
+    return r
+
+
+# --------------------------------------------------------------------------- simulator
+class SimResult(C.Structure):
+    _fields_ = [("xsize_blocks", C.c_size_t), ("ysize_blocks", C.c_size_t),
+                ("xsize_tiles", C.c_size_t), ("ysize_tiles", C.c_size_t), ("num_groups", C.c_size_t),
+                ("quant_dc", C.POINTER(C.c_int16) * 3), ("raw_quant", C.POINTER(C.c_uint8)),
+                ("strategy", C.POINTER(C.c_uint8)), ("ytox", C.POINTER(C.c_int8)),
+                ("ytob", C.POINTER(C.c_int8)), ("tokens", C.POINTER(C.c_uint8)),
+                ("group_tok_offset", C.POINTER(C.c_uint64)),
+                ("xyb", fp * 3), ("qf", fp), ("mask", fp), ("ent8", fp)]
+
+
+_sim = None
+
+
+def sim_hot_path(planes, distance, force_dct8=False):
+    """Runs the product's HIP kernels on the CPU execution model (tests only)."""
+    global _sim
+    if _sim is None:
+        _sim = C.CDLL(str(build_sim()))
+        _sim.sim_encode.argtypes = [C.POINTER(fp), C.c_size_t, C.c_size_t, C.c_size_t, C.c_float,
+                                    C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
+                                    C.POINTER(SimResult)]
+    _, h, w = planes.shape
+    p = distance_params(distance)
+    s = SimResult()
+    rc = _sim.sim_encode(_plane_ptrs(planes), w, w, h, p.distance, p.scale, p.inv_scale, p.scale_dc,
+                         p.x_qm_scale, 1 if force_dct8 else 0, C.byref(s))
+    assert rc == 0
+    r = HotPathResult()
+    r.xsize, r.ysize = w, h
+    xb, yb, xt, yt, ng = s.xsize_blocks, s.ysize_blocks, s.xsize_tiles, s.ysize_tiles, s.num_groups
+    r.quant_dc = np.stack([_np(s.quant_dc[c], (yb, xb), np.int16) for c in range(3)])
+    r.raw_quant = _np(s.raw_quant, (yb, xb), np.uint8)
+    r.strategy = _np(s.strategy, (yb, xb), np.uint8)
+    r.ytox = _np(s.ytox, (yt, xt), np.int8)
+    r.ytob = _np(s.ytob, (yt, xt), np.int8)
+    offs = [s.group_tok_offset[g] for g in range(ng + 1)]
+    blob = C.string_at(s.tokens, offs[ng] * 3)
+    r.group_tokens = [blob[3 * offs[g]:3 * offs[g + 1]] for g in range(ng)]
+    r.xyb = np.stack([_np(s.xyb[c], (yb * 8, xb * 8), np.float32) for c in range(3)])
+    r.qf = _np(s.qf, (yb, xb), np.float32)
+    r.mask = _np(s.mask, (yb, xb), np.float32)
+    r.ent8 = _np(s.ent8, (yb // 2 + 1, xb // 2 + 1, 8), np.float32)
+    _sim.sim_free(C.byref(s))
+    return r
+
+
+def compare_results(a, b, what_a="A", what_b="B", check_debug=True):
+    """Returns a list of human-readable mismatches (empty == bit-exact)."""
+    bad = []
+
+    def cmp(name, x, y, bits=False):
+        if bits:
+            x, y = x.view(np.uint32), y.view(np.uint32)
+        if x.shape != y.shape:
+            bad.append("%s: shape %s vs %s" % (name, x.shape, y.shape))
+            return
+        ne = np.argwhere(x != y)
+        if len(ne):
+            i = tuple(ne[0])
+            bad.append("%s: %d mismatches, first at %s: %s=%r %s=%r" %
+                       (name, len(ne), i, what_a, x[i], what_b, y[i]))
+
+    if check_debug:
+        cmp("xyb", a.xyb, b.xyb, bits=True)
+        cmp("quant_field", a.qf, b.qf, bits=True)
+        cmp("masking", a.mask, b.mask, bits=True)
+    cmp("ytox", a.ytox, b.ytox)
+    cmp("ytob", a.ytob, b.ytob)
+    if check_debug:
+        ea, eb = a.ent8.view(np.uint32), b.ent8.view(np.uint32)
+        valid = ~np.isnan(a.ent8)
+        if not np.array_equal(np.isnan(a.ent8), np.isnan(b.ent8)):
+            bad.append("ent8: evaluated-cell sets differ")
+        elif np.any(ea[valid] != eb[valid]):
+            ne = np.argwhere((ea != eb) & valid)
+            i = tuple(ne[0])
+            bad.append("ent8: %d mismatches, first at %s: %r vs %r" % (len(ne), i, a.ent8[i], b.ent8[i]))
+    cmp("ac_strategy", a.strategy, b.strategy)
+    cmp("raw_quant", a.raw_quant, b.raw_quant)
+    cmp("quant_dc", a.quant_dc, b.quant_dc)
+    if len(a.group_tokens) != len(b.group_tokens):
+        bad.append("group count differs")
+    else:
+        for g, (ta, tb) in enumerate(zip(a.group_tokens, b.group_tokens)):
+            if ta != tb:
+                n = min(len(ta), len(tb))
+                first = next((i for i in range(n) if ta[i] != tb[i]), n)
+                bad.append("tokens group %d: len %d vs %d, first diff at byte %d (token %d)" %
+                           (g, len(ta), len(tb), first, first // 3))
+                break
+    return bad
