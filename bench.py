@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpixels/s of the MI355X-native JPEG XL tiny encoder.
+
+One "step" = one full encode of a synthetic linear-sRGB frame that is already
+resident in HBM as three planar f32 planes: the per-group device pipeline
+(tile_kernel -> group_scan_kernel -> token_kernel), the D2H of tokens + side-band
+grids and the host bitstream assembly, ending with the complete .jxl codestream
+bytes in host memory.  PFM file I/O and the H2D upload are outside the timed
+region (DESIGN.md quotes the PCIe-inclusive rate separately).
+
+    python bench.py --gpus N --steps K --warmup W [--size S]
+
+For N > 1 launch through torch.distributed.run (one rank per GPU); every rank
+encodes its own SxS frame (frames are independent units: no data-path
+collective, scaling = weak); the timed region is bracketed by a barrier +
+torch.cuda.synchronize() and the reported time is the max over ranks.
+
+Prints ONE JSON line on rank 0 (see the keys at the end of main()).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALGO_BYTES_PER_PIXEL = 12.0  # 3 planes x f32, each pixel read once
+
+
+def make_frame_on_device(torch, size, seed, device):
+    """SURVEY.md 8(d) generator evaluated on the GPU (float64 math, torch RNG for
+    the N(0, 0.02) noise), returned as a [3, size, size] float32 tensor."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + seed)
+    out = torch.empty((3, size, size), dtype=torch.float32, device=device)
+    rows = 1024
+    x = torch.arange(size, dtype=torch.float64, device=device)[None, :]
+    for y0 in range(0, size, rows):
+        y1 = min(size, y0 + rows)
+        y = torch.arange(y0, y1, dtype=torch.float64, device=device)[:, None]
+        r = 0.5 + 0.4 * torch.sin(x / 37) * torch.cos(y / 53)
+        g = 0.5 + 0.4 * torch.sin((x + y) / 91)
+        b = 0.3 + 0.3 * torch.cos(x / 19 - y / 29)
+        m = 0.6 + 0.4 * ((torch.floor(x / 48) + torch.floor(y / 80)) % 2)
+        for c, p in enumerate((r, g, b)):
+            v = p * m + torch.randn(p.shape, dtype=torch.float64, device=device, generator=gen) * 0.02
+            out[c, y0:y1] = (v.clamp_(0, 1) ** 2.2).to(torch.float32)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=16384, help="frame is size x size pixels")
+    ap.add_argument("--distance", type=float, default=1.0)
+    ap.add_argument("--cpu-sample", type=int, default=4096,
+                    help="edge of the top-left crop the CPU oracle encodes (baseline + parity gate)")
+    ap.add_argument("--host-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__
+    pkg = __graft_entry__.load_package()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    size = args.size
+    frame = make_frame_on_device(torch, size, rank, device)
+    torch.cuda.synchronize()
+    enc = pkg.Encoder(local_rank)
+    ptrs = [frame[c].data_ptr() for c in range(3)]
+    enc.set_device_image(ptrs, size * 4, size, size, keepalive=frame)
+
+    def step(flags=0):
+        return enc.encode_resident(args.distance, num_threads=args.host_threads, flags=flags)
+
+    for _ in range(args.warmup):
+        jxl = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        jxl = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel timing on the encoder's own stream (HIP events), device-only rate
+    ktimes = {}
+    reps = max(3, args.steps)
+    dev_t0 = None
+    for i in range(reps):
+        enc.enqueue(args.distance, pkg.FLAG_PROFILE)
+        enc.synchronize()
+        for k, v in enc.kernel_times().items():
+            ktimes[k] = ktimes.get(k, 0.0) + v / reps
+    t1 = time.perf_counter()
+    for i in range(reps):
+        enc.enqueue(args.distance, 0)
+    enc.synchronize()
+    device_only_s = (time.perf_counter() - t1) / reps
+    fr = enc.fetch_raw()
+    token_bytes = int(fr.group_token_offset[fr.num_groups])
+
+    mpix = size * size / 1e6
+    value = world * mpix * args.steps / elapsed
+    tile_ms = ktimes.get("tile_kernel", float("nan"))
+    achieved = ALGO_BYTES_PER_PIXEL * size * size / (tile_ms * 1e-3) / 1e9
+
+    result = {
+        "metric": "Mpixels/s encode (PFM->.jxl), frame resident in HBM, codestream bytes in host memory",
+        "value": round(value, 2),
+        "unit": "Mpixels/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "%dx%d synthetic linear-sRGB frame per GPU, distance %.2f, full 8x8/16x8/8x16 "
+                               "strategy search + adaptive quant + chroma-from-luma" % (size, size, args.distance),
+                   "groups_per_gpu": int(fr.num_groups), "parallelism": "frames sharded by rank, no collective",
+                   "codestream_bytes": len(jxl), "raw_token_bytes": token_bytes},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "tile_kernel", "kernel_ms": round(tile_ms, 3),
+                     "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PIXEL * size * size},
+        "kernel_ms": {k: round(v, 3) for k, v in ktimes.items()},
+        "device_only_mpix_s": round(mpix / device_only_s, 1),
+    }
+
+    if rank == 0:
+        # ---- CPU baseline + parity gate on a bounded, group-aligned crop of the same frame
+        import jxlt_testlib as T
+        s = min(args.cpu_sample, size)
+        s -= s % 256 if s >= 256 else 0
+        crop = np.ascontiguousarray(frame[:, :s, :s].cpu().numpy())
+        t2 = time.perf_counter()
+        want = T.oracle_hot_path(crop, args.distance)
+        cpu_jxl = T.assemble_codestream(want, args.distance, num_threads=1)
+        cpu_s = time.perf_counter() - t2
+        result["cpu_baseline"] = {
+            "value": round(s * s / 1e6 / cpu_s, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+            "sample": "top-left %dx%d crop of the benchmark frame: oracle hot path + host assembly, 1 thread, "
+                      "%.1f s" % (s, s, cpu_s),
+            "cpu": _cpu_model(), "host_cores": os.cpu_count(), "codestream_bytes": len(cpu_jxl)}
+        # groups of the crop must equal the same groups of the full-frame GPU encode
+        gpg = (size + 255) // 256
+        offs = np.ctypeslib.as_array(fr.group_token_offset, shape=(fr.num_groups + 1,)).copy()
+        import ctypes as C
+        bad = 0
+        for gy in range(s // 256):
+            for gx in range(s // 256):
+                g = gy * gpg + gx
+                got = C.string_at(C.addressof(fr.tokens.contents) + int(offs[g]), int(offs[g + 1] - offs[g]))
+                bad += got != want.group_tokens[gy * (s // 256) + gx]
+        result["parity_gate"] = {"groups_checked": (s // 256) ** 2, "groups_mismatching": int(bad)}
+        print(json.dumps(result), flush=True)
+        if bad:
+            raise SystemExit("parity gate failed: %d groups differ from the oracle" % bad)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+if __name__ == "__main__":
+    main()

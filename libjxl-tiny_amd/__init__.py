@@ -1,0 +1,289 @@
+"""libjxl-tiny_amd -- MI355X-native JPEG XL "tiny" encoder hot path.
+
+Thin ctypes binding of the two native libraries (see include/jxl_tiny_amd.h):
+
+* ``csrc/libjxltiny_hip.so``  hand-written HIP kernels for gfx950 + device C ABI
+* ``host/libjxltiny_host.so`` C++ drop-in EncodeFile/EncodeFrame + bitstream back-end
+
+The package directory name contains a hyphen; import it with
+``importlib.util.spec_from_file_location("libjxl_tiny_amd", ".../libjxl-tiny_amd/__init__.py")``
+(``__graft_entry__.load_package()`` does that).
+
+There is no CPU implementation in this package: every compute entry point needs
+a HIP device and raises ``JxlTinyError`` otherwise.
+"""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+ROOT = PKG_DIR.parent
+HIP_LIB = PKG_DIR / "csrc" / "libjxltiny_hip.so"
+HOST_LIB = PKG_DIR / "host" / "libjxltiny_host.so"
+CJXL_TINY = PKG_DIR / "host" / "cjxl_tiny"
+
+fp = C.POINTER(C.c_float)
+FLAG_FORCE_DCT8, FLAG_DEBUG_DUMP, FLAG_PROFILE = 1, 2, 4
+
+# Symbols include/jxl_tiny_amd.h declares, per library (checked by the tests).
+HIP_SYMBOLS = ["jxlt_context_create", "jxlt_context_destroy", "jxlt_last_error",
+               "jxlt_image_upload", "jxlt_image_set_device", "jxlt_encode_enqueue",
+               "jxlt_synchronize", "jxlt_fetch_result", "jxlt_kernel_times", "jxlt_debug_fetch"]
+HOST_SYMBOLS = ["jxlt_compute_distance_params", "jxlt_assemble_frame", "jxlt_assemble_frame_groups",
+                "jxlt_encode_file_planar", "jxlt_write_file_header", "jxlt_free"]
+
+
+class JxlTinyError(RuntimeError):
+    pass
+
+
+class DistanceParams(C.Structure):
+    _fields_ = [("distance", C.c_float), ("global_scale", C.c_int32), ("quant_dc", C.c_int32),
+                ("scale", C.c_float), ("inv_scale", C.c_float), ("scale_dc", C.c_float),
+                ("x_qm_scale", C.c_uint32), ("epf_iters", C.c_uint32)]
+
+
+class Params(C.Structure):
+    _fields_ = [("distance", C.c_float), ("scale", C.c_float), ("inv_scale", C.c_float),
+                ("scale_dc", C.c_float), ("x_qm_scale", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class FrameResult(C.Structure):
+    _fields_ = [("xsize", C.c_size_t), ("ysize", C.c_size_t),
+                ("xsize_blocks", C.c_size_t), ("ysize_blocks", C.c_size_t),
+                ("xsize_tiles", C.c_size_t), ("ysize_tiles", C.c_size_t),
+                ("num_groups", C.c_size_t),
+                ("quant_dc", C.POINTER(C.c_int16) * 3),
+                ("raw_quant_field", C.POINTER(C.c_uint8)),
+                ("ac_strategy", C.POINTER(C.c_uint8)),
+                ("ytox_map", C.POINTER(C.c_int8)), ("ytob_map", C.POINTER(C.c_int8)),
+                ("tokens", C.POINTER(C.c_uint8)),
+                ("group_token_offset", C.POINTER(C.c_uint64))]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("milliseconds", C.c_float)]
+
+
+def build(verbose=False):
+    """Compiles both native libraries and cjxl_tiny in-tree (hipcc, gfx950)."""
+    out = subprocess.run(["make", "-C", str(PKG_DIR)], stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True)
+    if verbose or out.returncode != 0:
+        print(out.stdout)
+    if out.returncode != 0:
+        raise JxlTinyError("native build failed")
+
+
+_hip = None
+_host = None
+
+
+def hip_lib():
+    global _hip
+    if _hip is None:
+        if not HIP_LIB.exists():
+            raise JxlTinyError("%s is missing: run __graft_entry__.build()" % HIP_LIB)
+        L = C.CDLL(str(HIP_LIB))
+        L.jxlt_context_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.jxlt_context_destroy.argtypes = [C.c_void_p]
+        L.jxlt_context_destroy.restype = None
+        L.jxlt_last_error.argtypes = [C.c_void_p]
+        L.jxlt_last_error.restype = C.c_char_p
+        L.jxlt_image_upload.argtypes = [C.c_void_p, C.POINTER(fp), C.c_size_t, C.c_size_t, C.c_size_t]
+        L.jxlt_image_set_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_size_t,
+                                            C.c_size_t]
+        L.jxlt_encode_enqueue.argtypes = [C.c_void_p, C.POINTER(Params)]
+        L.jxlt_synchronize.argtypes = [C.c_void_p]
+        L.jxlt_fetch_result.argtypes = [C.c_void_p, C.POINTER(FrameResult)]
+        L.jxlt_kernel_times.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_int]
+        L.jxlt_debug_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        _hip = L
+    return _hip
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        hip_lib()
+        if not HOST_LIB.exists():
+            raise JxlTinyError("%s is missing: run __graft_entry__.build()" % HOST_LIB)
+        L = C.CDLL(str(HOST_LIB))
+        L.jxlt_compute_distance_params.argtypes = [C.c_float, C.POINTER(DistanceParams)]
+        L.jxlt_compute_distance_params.restype = None
+        L.jxlt_assemble_frame.argtypes = [C.POINTER(FrameResult), C.POINTER(DistanceParams), C.c_int,
+                                          C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        L.jxlt_assemble_frame_groups.argtypes = [C.POINTER(FrameResult), C.POINTER(C.POINTER(C.c_uint8)),
+                                                 C.POINTER(C.c_size_t), C.POINTER(DistanceParams), C.c_int,
+                                                 C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        L.jxlt_encode_file_planar.argtypes = [C.POINTER(fp), C.c_size_t, C.c_size_t, C.c_size_t, C.c_float,
+                                              C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        L.jxlt_write_file_header.argtypes = [C.c_size_t, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)),
+                                             C.POINTER(C.c_size_t)]
+        L.jxlt_free.argtypes = [C.c_void_p]
+        L.jxlt_free.restype = None
+        _host = L
+    return _host
+
+
+def distance_params(distance):
+    """DistanceParams of the reference (enc_frame.cc:115-156), after EncodeFile's clamp."""
+    if not distance > 0:
+        raise JxlTinyError("distance must be > 0")
+    if distance <= 0.03:
+        distance = 0.03
+    p = DistanceParams()
+    host_lib().jxlt_compute_distance_params(C.c_float(distance), C.byref(p))
+    return p
+
+
+def _take_bytes(ptr, n):
+    data = C.string_at(ptr, n.value)
+    host_lib().jxlt_free(ptr)
+    return data
+
+
+def file_header(xsize, ysize):
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    if host_lib().jxlt_write_file_header(xsize, ysize, C.byref(out), C.byref(n)) != 0:
+        raise JxlTinyError("invalid image size")
+    return _take_bytes(out, n)
+
+
+class HotPathOutput:
+    """numpy copy of one pass of the device hot path."""
+
+    def __init__(self, fr, debug=None):
+        yb, xb, yt, xt, ng = fr.ysize_blocks, fr.xsize_blocks, fr.ysize_tiles, fr.xsize_tiles, fr.num_groups
+
+        def arr(ptr, shape, dtype):
+            n = int(np.prod(shape))
+            return np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype).reshape(shape).copy()
+
+        self.xsize, self.ysize = fr.xsize, fr.ysize
+        self.quant_dc = np.stack([arr(fr.quant_dc[c], (yb, xb), np.int16) for c in range(3)])
+        self.raw_quant = arr(fr.raw_quant_field, (yb, xb), np.uint8)
+        self.strategy = arr(fr.ac_strategy, (yb, xb), np.uint8)
+        self.ytox = arr(fr.ytox_map, (yt, xt), np.int8)
+        self.ytob = arr(fr.ytob_map, (yt, xt), np.int8)
+        offs = [fr.group_token_offset[g] for g in range(ng + 1)]
+        blob = C.string_at(fr.tokens, offs[ng]) if offs[ng] else b""
+        self.group_tokens = [blob[offs[g]:offs[g + 1]] for g in range(ng)]
+        self.xyb = self.qf = self.mask = self.ent8 = None
+        if debug:
+            self.xyb, self.qf, self.mask, self.ent8 = debug
+
+    def all_tokens(self):
+        return b"".join(self.group_tokens)
+
+
+class Encoder:
+    """One device context (one per GPU / host thread)."""
+
+    def __init__(self, device=0):
+        self._L = hip_lib()
+        self._ctx = C.c_void_p()
+        rc = self._L.jxlt_context_create(device, C.byref(self._ctx))
+        if rc != 0:
+            raise JxlTinyError("jxlt_context_create failed (%d): %s" %
+                               (rc, self._L.jxlt_last_error(None).decode()))
+        self.device = device
+        self._keepalive = None
+
+    def close(self):
+        if self._ctx:
+            self._L.jxlt_context_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise JxlTinyError("%s failed (%d): %s" % (what, rc, self._L.jxlt_last_error(self._ctx).decode()))
+        return rc
+
+    def upload(self, planes):
+        """planes: float32 [3, h, w] C-contiguous host array."""
+        assert planes.dtype == np.float32 and planes.ndim == 3 and planes.shape[0] == 3
+        planes = np.ascontiguousarray(planes)
+        _, h, w = planes.shape
+        ptrs = (fp * 3)(*[planes[c].ctypes.data_as(fp) for c in range(3)])
+        self._check(self._L.jxlt_image_upload(self._ctx, ptrs, w * 4, w, h), "jxlt_image_upload")
+
+    def set_device_image(self, ptrs, pitch_bytes, w, h, keepalive=None):
+        """ptrs: three device addresses (ints), e.g. torch tensor data_ptr()."""
+        arr = (C.c_void_p * 3)(*ptrs)
+        self._check(self._L.jxlt_image_set_device(self._ctx, arr, pitch_bytes, w, h), "jxlt_image_set_device")
+        self._keepalive = keepalive
+
+    def enqueue(self, distance, flags=0):
+        dp = distance_params(distance)
+        p = Params(dp.distance, dp.scale, dp.inv_scale, dp.scale_dc, dp.x_qm_scale, flags)
+        self._check(self._L.jxlt_encode_enqueue(self._ctx, C.byref(p)), "jxlt_encode_enqueue")
+        self._last = (dp, flags)
+        return dp
+
+    def synchronize(self):
+        self._check(self._L.jxlt_synchronize(self._ctx), "jxlt_synchronize")
+
+    def fetch_raw(self):
+        fr = FrameResult()
+        self._check(self._L.jxlt_fetch_result(self._ctx, C.byref(fr)), "jxlt_fetch_result")
+        return fr
+
+    def kernel_times(self):
+        arr = (KernelTime * 8)()
+        n = self._check(self._L.jxlt_kernel_times(self._ctx, arr, 8), "jxlt_kernel_times")
+        return {arr[i].name.decode(): arr[i].milliseconds for i in range(n)}
+
+    def hot_path(self, planes, distance, force_dct8=False, debug=False):
+        """Upload + one pass of the hot path + fetch; returns HotPathOutput."""
+        self.upload(planes)
+        flags = (FLAG_FORCE_DCT8 if force_dct8 else 0) | (FLAG_DEBUG_DUMP if debug else 0)
+        self.enqueue(distance, flags)
+        fr = self.fetch_raw()
+        dbg = None
+        if debug:
+            yb, xb = fr.ysize_blocks, fr.xsize_blocks
+
+            def get(what, shape):
+                a = np.empty(shape, np.float32)
+                self._check(self._L.jxlt_debug_fetch(self._ctx, what, a.ctypes.data, a.nbytes), "jxlt_debug_fetch")
+                return a
+
+            xyb = np.stack([get(c, (yb * 8, xb * 8)) for c in range(3)])
+            dbg = (xyb, get(3, (yb, xb)), get(4, (yb, xb)), get(5, (yb // 2 + 1, xb // 2 + 1, 8)))
+        return HotPathOutput(fr, dbg)
+
+    def assemble(self, fr, dp, num_threads=0):
+        """Frame bitstream (header + TOC + sections) from a fetched FrameResult."""
+        out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+        rc = host_lib().jxlt_assemble_frame(C.byref(fr), C.byref(dp), num_threads, C.byref(out), C.byref(n))
+        if rc != 0:
+            raise JxlTinyError("jxlt_assemble_frame failed (%d)" % rc)
+        return _take_bytes(out, n)
+
+    def encode_resident(self, distance, num_threads=0, flags=0):
+        """Full codestream of the image currently set/uploaded on the device."""
+        dp = self.enqueue(distance, flags)
+        fr = self.fetch_raw()
+        return file_header(fr.xsize, fr.ysize) + self.assemble(fr, dp, num_threads)
+
+
+def encode_file(planes, distance, device=0):
+    """Drop-in EncodeFile through the C++ host library: float32 [3,h,w] -> .jxl bytes."""
+    planes = np.ascontiguousarray(planes, dtype=np.float32)
+    _, h, w = planes.shape
+    ptrs = (fp * 3)(*[planes[c].ctypes.data_as(fp) for c in range(3)])
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    rc = host_lib().jxlt_encode_file_planar(ptrs, w * 4, w, h, C.c_float(distance), device, C.byref(out),
+                                            C.byref(n))
+    if rc != 0:
+        raise JxlTinyError("jxlt_encode_file_planar failed (%d)" % rc)
+    return _take_bytes(out, n)

@@ -1,0 +1,477 @@
+// jxlt_capi.hip -- C ABI of libjxltiny_hip.so (see include/jxl_tiny_amd.h).
+//
+// One jxlt_context = one HIP device + one stream + all device/pinned buffers of
+// the per-group pipeline.  A whole frame is processed by three launches on the
+// context's stream:
+//   tile_kernel  (one workgroup per 64x64 tile)  -> side-band grids, coefficients
+//   group_scan_kernel                            -> per-group token offsets
+//   token_kernel (one workgroup per 256x256 group) -> raw 3-byte token records
+// There is no CPU fallback: without a usable HIP device every entry point
+// returns JXLT_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/jxl_tiny_amd.h"
+#include "jxlt_device.h"
+#include "jxlt_host_tables.h"
+
+using namespace jxlt_dev;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+template <typename T>
+struct DeviceBuf {
+  T* p = nullptr;
+  size_t cap = 0;  // elements
+};
+
+template <typename T>
+struct PinnedBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct jxlt_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string error;
+
+  // input image
+  DeviceBuf<float> own_planes[3];
+  const float* planes[3] = {nullptr, nullptr, nullptr};
+  size_t pitch_floats = 0;
+  size_t xsize = 0, ysize = 0;
+
+  // constant tables (rebuilt when `scale` changes)
+  DeviceTables* d_tab = nullptr;
+  float tab_scale = -1.0f;
+
+  // device outputs / intermediates
+  DeviceBuf<int16_t> quant_dc[3];
+  DeviceBuf<uint8_t> raw_quant, strategy, nzgrid[3], blk_nz, blk_nscan, tokens;
+  DeviceBuf<int8_t> ytox, ytob;
+  DeviceBuf<int16_t> coef_scan;
+  DeviceBuf<uint32_t> group_ntok;
+  DeviceBuf<uint64_t> group_off;
+  DeviceBuf<float> dbg_xyb[3], dbg_qf, dbg_mask, dbg_ent8;
+
+  // pinned host mirrors
+  PinnedBuf<int16_t> h_quant_dc[3];
+  PinnedBuf<uint8_t> h_raw_quant, h_strategy, h_tokens;
+  PinnedBuf<int8_t> h_ytox, h_ytob;
+  PinnedBuf<uint64_t> h_group_off;
+
+  FrameGeom geom = {};
+  bool encoded = false;
+  uint32_t last_flags = 0;
+
+  // profiling
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool profiled = false;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                  \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      (ctx)->error = std::string(#expr) + ": " + hipGetErrorString(e_);                     \
+      return e_ == hipErrorOutOfMemory ? JXLT_ERR_OUT_OF_MEMORY : JXLT_ERR_NO_DEVICE;       \
+    }                                                                                       \
+  } while (0)
+
+template <typename T>
+int EnsureDevice(jxlt_context* ctx, DeviceBuf<T>* b, size_t n) {
+  if (b->cap >= n && b->p) return JXLT_OK;
+  if (b->p) HIP_TRY(ctx, hipFree(b->p));
+  b->p = nullptr;
+  b->cap = 0;
+  HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&b->p), (n ? n : 1) * sizeof(T)));
+  b->cap = n;
+  return JXLT_OK;
+}
+
+template <typename T>
+int EnsurePinned(jxlt_context* ctx, PinnedBuf<T>* b, size_t n) {
+  if (b->cap >= n && b->p) return JXLT_OK;
+  if (b->p) HIP_TRY(ctx, hipHostFree(b->p));
+  b->p = nullptr;
+  b->cap = 0;
+  HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&b->p), (n ? n : 1) * sizeof(T), hipHostMallocDefault));
+  b->cap = n;
+  return JXLT_OK;
+}
+
+template <typename T>
+void FreeDevice(DeviceBuf<T>* b) {
+  if (b->p) (void)hipFree(b->p);
+  b->p = nullptr;
+  b->cap = 0;
+}
+template <typename T>
+void FreePinned(PinnedBuf<T>* b) {
+  if (b->p) (void)hipHostFree(b->p);
+  b->p = nullptr;
+  b->cap = 0;
+}
+
+int CheckImageArgs(jxlt_context* ctx, const void* const planes[3], size_t pitch_bytes, size_t xsize,
+                   size_t ysize) {
+  if (!ctx) return JXLT_ERR_INVALID_ARGUMENT;
+  if (!planes || !planes[0] || !planes[1] || !planes[2] || xsize == 0 || ysize == 0 ||
+      xsize > 0x3FFFFFFFull || ysize > 0x3FFFFFFFull || pitch_bytes < xsize * sizeof(float) ||
+      pitch_bytes % sizeof(float) != 0) {
+    ctx->error = "invalid image arguments";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  if (xsize <= 8 && ysize <= 8) {
+    // The reference traps on images that fit a single 8x8 block.
+    ctx->error = "images of at most one 8x8 block are not supported";
+    return JXLT_ERR_UNSUPPORTED;
+  }
+  return JXLT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int jxlt_context_create(int device_ordinal, jxlt_context** out) {
+  if (!out) return JXLT_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    g_create_error = std::string("no HIP device available: ") +
+                     (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    return JXLT_ERR_NO_DEVICE;
+  }
+  if (device_ordinal < 0 || device_ordinal >= count) {
+    g_create_error = "device ordinal out of range";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  jxlt_context* ctx = new jxlt_context;
+  ctx->device = device_ordinal;
+  if ((e = hipSetDevice(device_ordinal)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipMalloc(reinterpret_cast<void**>(&ctx->d_tab), sizeof(DeviceTables))) != hipSuccess) {
+    g_create_error = std::string("context setup failed: ") + hipGetErrorString(e);
+    delete ctx;
+    return JXLT_ERR_NO_DEVICE;
+  }
+  for (auto& ev : ctx->ev) (void)hipEventCreate(&ev);
+  *out = ctx;
+  return JXLT_OK;
+}
+
+void jxlt_context_destroy(jxlt_context* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (int c = 0; c < 3; c++) {
+    FreeDevice(&ctx->own_planes[c]);
+    FreeDevice(&ctx->quant_dc[c]);
+    FreeDevice(&ctx->nzgrid[c]);
+    FreeDevice(&ctx->dbg_xyb[c]);
+    FreePinned(&ctx->h_quant_dc[c]);
+  }
+  FreeDevice(&ctx->raw_quant);
+  FreeDevice(&ctx->strategy);
+  FreeDevice(&ctx->blk_nz);
+  FreeDevice(&ctx->blk_nscan);
+  FreeDevice(&ctx->tokens);
+  FreeDevice(&ctx->ytox);
+  FreeDevice(&ctx->ytob);
+  FreeDevice(&ctx->coef_scan);
+  FreeDevice(&ctx->group_ntok);
+  FreeDevice(&ctx->group_off);
+  FreeDevice(&ctx->dbg_qf);
+  FreeDevice(&ctx->dbg_mask);
+  FreeDevice(&ctx->dbg_ent8);
+  FreePinned(&ctx->h_raw_quant);
+  FreePinned(&ctx->h_strategy);
+  FreePinned(&ctx->h_tokens);
+  FreePinned(&ctx->h_ytox);
+  FreePinned(&ctx->h_ytob);
+  FreePinned(&ctx->h_group_off);
+  if (ctx->d_tab) (void)hipFree(ctx->d_tab);
+  for (auto& ev : ctx->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* jxlt_last_error(const jxlt_context* ctx) {
+  return ctx ? ctx->error.c_str() : g_create_error.c_str();
+}
+
+int jxlt_image_upload(jxlt_context* ctx, const float* const planes[3], size_t pitch_bytes,
+                      size_t xsize, size_t ysize) {
+  int rc = CheckImageArgs(ctx, reinterpret_cast<const void* const*>(planes), pitch_bytes, xsize, ysize);
+  if (rc != JXLT_OK) return rc;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t pitch_floats = (xsize + 63) & ~size_t(63);
+  for (int c = 0; c < 3; c++) {
+    rc = EnsureDevice(ctx, &ctx->own_planes[c], pitch_floats * ysize);
+    if (rc != JXLT_OK) return rc;
+    HIP_TRY(ctx, hipMemcpy2DAsync(ctx->own_planes[c].p, pitch_floats * sizeof(float), planes[c],
+                                  pitch_bytes, xsize * sizeof(float), ysize, hipMemcpyHostToDevice,
+                                  ctx->stream));
+    ctx->planes[c] = ctx->own_planes[c].p;
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // caller may reuse its buffers
+  ctx->pitch_floats = pitch_floats;
+  ctx->xsize = xsize;
+  ctx->ysize = ysize;
+  ctx->encoded = false;
+  return JXLT_OK;
+}
+
+int jxlt_image_set_device(jxlt_context* ctx, const void* const device_planes[3], size_t pitch_bytes,
+                          size_t xsize, size_t ysize) {
+  int rc = CheckImageArgs(ctx, device_planes, pitch_bytes, xsize, ysize);
+  if (rc != JXLT_OK) return rc;
+  for (int c = 0; c < 3; c++) ctx->planes[c] = static_cast<const float*>(device_planes[c]);
+  ctx->pitch_floats = pitch_bytes / sizeof(float);
+  ctx->xsize = xsize;
+  ctx->ysize = ysize;
+  ctx->encoded = false;
+  return JXLT_OK;
+}
+
+int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
+  if (!ctx || !params) return JXLT_ERR_INVALID_ARGUMENT;
+  if (!ctx->planes[0]) {
+    ctx->error = "no image set";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  if (!(params->distance > 0) || !(params->scale > 0) || params->x_qm_scale < 2 || params->x_qm_scale > 5) {
+    ctx->error = "invalid encode parameters";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const FrameGeom g = MakeGeom(ctx->xsize, ctx->ysize);
+  const size_t nblocks = (size_t)g.xsize_blocks * g.ysize_blocks;
+  const size_t ntiles = (size_t)g.xsize_tiles * g.ysize_tiles;
+  const size_t ngroups = (size_t)g.xsize_groups * g.ysize_groups;
+  const bool debug = (params->flags & JXLT_FLAG_DEBUG_DUMP) != 0;
+  int rc;
+#define ENSURE(buf, n) if ((rc = EnsureDevice(ctx, &ctx->buf, (n))) != JXLT_OK) return rc
+  for (int c = 0; c < 3; c++) {
+    ENSURE(quant_dc[c], nblocks);
+    ENSURE(nzgrid[c], nblocks);
+    if (debug) ENSURE(dbg_xyb[c], nblocks * 64);
+  }
+  ENSURE(raw_quant, nblocks);
+  ENSURE(strategy, nblocks);
+  ENSURE(blk_nz, nblocks * 3);
+  ENSURE(blk_nscan, nblocks * 3);
+  ENSURE(ytox, ntiles);
+  ENSURE(ytob, ntiles);
+  ENSURE(coef_scan, nblocks * 3 * 64);
+  ENSURE(group_ntok, ngroups);
+  ENSURE(group_off, ngroups + 1);
+  // worst case: every coefficient of every block is a token, plus one nzeros token
+  ENSURE(tokens, nblocks * 3 * 64 * 3);
+  const size_t ncells = ((size_t)g.xsize_blocks / 2 + 1) * ((size_t)g.ysize_blocks / 2 + 1);
+  if (debug) {
+    ENSURE(dbg_qf, nblocks);
+    ENSURE(dbg_mask, nblocks);
+    ENSURE(dbg_ent8, ncells * 8);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dbg_ent8.p, 0xFF, ncells * 8 * sizeof(float), ctx->stream));  // NaN
+  }
+#undef ENSURE
+
+  if (ctx->tab_scale != params->scale) {
+    // Pageable source: the copy is staged by the runtime before the call returns.
+    DeviceTables host_tab;
+    BuildDeviceTables(params->scale, &host_tab);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tab, &host_tab, sizeof(host_tab), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->tab_scale = params->scale;
+  }
+
+  TileArgs A;
+  memset(&A, 0, sizeof(A));
+  for (int c = 0; c < 3; c++) {
+    A.planes[c] = ctx->planes[c];
+    A.quant_dc[c] = ctx->quant_dc[c].p;
+    A.nzgrid[c] = ctx->nzgrid[c].p;
+    A.dbg_xyb[c] = debug ? ctx->dbg_xyb[c].p : nullptr;
+  }
+  A.pitch = ctx->pitch_floats;
+  A.g = g;
+  A.distance = params->distance;
+  A.scale = params->scale;
+  A.inv_scale = params->inv_scale;
+  A.scale_dc = params->scale_dc;
+  A.x_qm_mul = XQmMultiplier(params->x_qm_scale);
+  A.flags = (params->flags & JXLT_FLAG_FORCE_DCT8) ? 1u : 0u;
+  A.tab = ctx->d_tab;
+  A.raw_quant = ctx->raw_quant.p;
+  A.strategy = ctx->strategy.p;
+  A.ytox = ctx->ytox.p;
+  A.ytob = ctx->ytob.p;
+  A.blk_nz = ctx->blk_nz.p;
+  A.blk_nscan = ctx->blk_nscan.p;
+  A.coef_scan = ctx->coef_scan.p;
+  A.group_ntok = ctx->group_ntok.p;
+  A.dbg_qf = debug ? ctx->dbg_qf.p : nullptr;
+  A.dbg_mask = debug ? ctx->dbg_mask.p : nullptr;
+  A.dbg_ent8 = debug ? ctx->dbg_ent8.p : nullptr;
+
+  TokenArgs K;
+  memset(&K, 0, sizeof(K));
+  K.g = g;
+  K.tab = ctx->d_tab;
+  K.strategy = ctx->strategy.p;
+  for (int c = 0; c < 3; c++) K.nzgrid[c] = ctx->nzgrid[c].p;
+  K.blk_nz = ctx->blk_nz.p;
+  K.blk_nscan = ctx->blk_nscan.p;
+  K.coef_scan = ctx->coef_scan.p;
+  K.group_tok_offset = ctx->group_off.p;
+  K.tokens = ctx->tokens.p;
+
+  const bool profile = (params->flags & JXLT_FLAG_PROFILE) != 0;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->group_ntok.p, 0, ngroups * sizeof(uint32_t), ctx->stream));
+  if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+  hipLaunchKernelGGL(tile_kernel, dim3((unsigned)ntiles), dim3(kTileThreads), 0, ctx->stream, A);
+  if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, ctx->stream,
+                     (const uint32_t*)ctx->group_ntok.p, ctx->group_off.p, (int)ngroups);
+  if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+  hipLaunchKernelGGL(token_kernel, dim3((unsigned)ngroups), dim3(kTokenThreads), 0, ctx->stream, K);
+  if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+  HIP_TRY(ctx, hipGetLastError());
+  ctx->geom = g;
+  ctx->encoded = true;
+  ctx->last_flags = params->flags;
+  ctx->profiled = profile;
+  return JXLT_OK;
+}
+
+int jxlt_synchronize(jxlt_context* ctx) {
+  if (!ctx) return JXLT_ERR_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return JXLT_OK;
+}
+
+int jxlt_fetch_result(jxlt_context* ctx, jxlt_frame_result* out) {
+  if (!ctx || !out) return JXLT_ERR_INVALID_ARGUMENT;
+  if (!ctx->encoded) {
+    ctx->error = "nothing encoded yet";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const FrameGeom& g = ctx->geom;
+  const size_t nblocks = (size_t)g.xsize_blocks * g.ysize_blocks;
+  const size_t ntiles = (size_t)g.xsize_tiles * g.ysize_tiles;
+  const size_t ngroups = (size_t)g.xsize_groups * g.ysize_groups;
+  int rc;
+#define ENSUREH(buf, n) if ((rc = EnsurePinned(ctx, &ctx->buf, (n))) != JXLT_OK) return rc
+  for (int c = 0; c < 3; c++) ENSUREH(h_quant_dc[c], nblocks);
+  ENSUREH(h_raw_quant, nblocks);
+  ENSUREH(h_strategy, nblocks);
+  ENSUREH(h_ytox, ntiles);
+  ENSUREH(h_ytob, ntiles);
+  ENSUREH(h_group_off, ngroups + 1);
+#define D2H(dst, src, bytes) HIP_TRY(ctx, hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, ctx->stream))
+  D2H(ctx->h_group_off.p, ctx->group_off.p, (ngroups + 1) * sizeof(uint64_t));
+  for (int c = 0; c < 3; c++) D2H(ctx->h_quant_dc[c].p, ctx->quant_dc[c].p, nblocks * sizeof(int16_t));
+  D2H(ctx->h_raw_quant.p, ctx->raw_quant.p, nblocks);
+  D2H(ctx->h_strategy.p, ctx->strategy.p, nblocks);
+  D2H(ctx->h_ytox.p, ctx->ytox.p, ntiles);
+  D2H(ctx->h_ytob.p, ctx->ytob.p, ntiles);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const uint64_t total_tokens = ctx->h_group_off.p[ngroups];
+  if (total_tokens * 3 > ctx->tokens.cap) {
+    ctx->error = "internal error: token count exceeds the worst-case bound";
+    return JXLT_ERR_INTERNAL;
+  }
+  if (ctx->h_tokens.cap < total_tokens * 3) ENSUREH(h_tokens, total_tokens * 3 + total_tokens / 4 + 4096);
+  if (total_tokens) D2H(ctx->h_tokens.p, ctx->tokens.p, total_tokens * 3);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+#undef D2H
+#undef ENSUREH
+  for (size_t i = 0; i <= ngroups; i++) ctx->h_group_off.p[i] *= 3;  // tokens -> bytes
+  out->xsize = ctx->xsize;
+  out->ysize = ctx->ysize;
+  out->xsize_blocks = g.xsize_blocks;
+  out->ysize_blocks = g.ysize_blocks;
+  out->xsize_tiles = g.xsize_tiles;
+  out->ysize_tiles = g.ysize_tiles;
+  out->num_groups = ngroups;
+  for (int c = 0; c < 3; c++) out->quant_dc[c] = ctx->h_quant_dc[c].p;
+  out->raw_quant_field = ctx->h_raw_quant.p;
+  out->ac_strategy = ctx->h_strategy.p;
+  out->ytox_map = ctx->h_ytox.p;
+  out->ytob_map = ctx->h_ytob.p;
+  out->tokens = ctx->h_tokens.p;
+  out->group_token_offset = ctx->h_group_off.p;
+  ctx->encoded = false;  // offsets were converted in place; a re-fetch needs a new encode
+  return JXLT_OK;
+}
+
+int jxlt_kernel_times(jxlt_context* ctx, jxlt_kernel_time* out, int cap) {
+  if (!ctx || !out || cap < 0) return JXLT_ERR_INVALID_ARGUMENT;
+  if (!ctx->profiled) {
+    ctx->error = "last encode was not run with JXLT_FLAG_PROFILE";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipEventSynchronize(ctx->ev[3]));
+  static const char* kNames[3] = {"tile_kernel", "group_scan_kernel", "token_kernel"};
+  for (int i = 0; i < 3 && i < cap; i++) {
+    float ms = 0.0f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
+    out[i].name = kNames[i];
+    out[i].milliseconds = ms;
+  }
+  return 3;
+}
+
+int jxlt_debug_fetch(jxlt_context* ctx, int what, void* host_dst, size_t bytes) {
+  if (!ctx || !host_dst) return JXLT_ERR_INVALID_ARGUMENT;
+  if (!(ctx->last_flags & JXLT_FLAG_DEBUG_DUMP)) {
+    ctx->error = "last encode was not run with JXLT_FLAG_DEBUG_DUMP";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const FrameGeom& g = ctx->geom;
+  const size_t nblocks = (size_t)g.xsize_blocks * g.ysize_blocks;
+  const size_t ncells = ((size_t)g.xsize_blocks / 2 + 1) * ((size_t)g.ysize_blocks / 2 + 1);
+  const void* src = nullptr;
+  size_t need = 0;
+  if (what >= 0 && what <= 2) {
+    src = ctx->dbg_xyb[what].p;
+    need = nblocks * 64 * sizeof(float);
+  } else if (what == 3) {
+    src = ctx->dbg_qf.p;
+    need = nblocks * sizeof(float);
+  } else if (what == 4) {
+    src = ctx->dbg_mask.p;
+    need = nblocks * sizeof(float);
+  } else if (what == 5) {
+    src = ctx->dbg_ent8.p;
+    need = ncells * 8 * sizeof(float);
+  }
+  if (!src || bytes != need) {
+    ctx->error = "bad debug selector or size";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpy(host_dst, src, need, hipMemcpyDeviceToHost));
+  return JXLT_OK;
+}
+
+}  // extern "C"

@@ -24,11 +24,25 @@
 
 #define LANES 8 /* HWY_FULL(float) in the canonical model */
 
+/* ORC_FMA=0 builds the "unfused" variant of the model (hwy MulAdd = mul, add),
+ * used only by tests/test_oracle_known_answers.py to compare against the
+ * size-only known answers of SURVEY.md Appendix C. */
+#ifndef ORC_FMA
+#define ORC_FMA 1
+#endif
 static inline float fma32(float a, float b, float c) { /* hwy MulAdd */
+#if ORC_FMA
   return __builtin_fmaf(a, b, c);
+#else
+  return a * b + c;
+#endif
 }
 static inline float nfma32(float a, float b, float c) { /* hwy NegMulAdd: c-a*b */
+#if ORC_FMA
   return __builtin_fmaf(-a, b, c);
+#else
+  return c - a * b;
+#endif
 }
 static inline uint32_t f2u(float f) {
   uint32_t u;

@@ -27,7 +27,7 @@ struct sim_result {
   float* ent8;
 };
 
-int sim_encode(const float* const planes[3], size_t pitch_floats, size_t xsize, size_t ysize,
+__attribute__((visibility("default"))) int sim_encode(const float* const planes[3], size_t pitch_floats, size_t xsize, size_t ysize,
                float distance, float scale, float inv_scale, float scale_dc, uint32_t x_qm_scale,
                uint32_t flags, sim_result* r) {
   const FrameGeom g = MakeGeom(xsize, ysize);
@@ -102,7 +102,7 @@ int sim_encode(const float* const planes[3], size_t pitch_floats, size_t xsize, 
   return 0;
 }
 
-void sim_free(sim_result* r) {
+__attribute__((visibility("default"))) void sim_free(sim_result* r) {
   for (int c = 0; c < 3; c++) {
     free(r->quant_dc[c]);
     free(r->xyb[c]);

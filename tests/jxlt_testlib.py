@@ -2,8 +2,8 @@
 of the CPU execution model of the kernels (tests/hipsim/libjxlt_sim.so) and the
 synthetic image generator of SURVEY.md section 8(d)."""
 import ctypes as C
-import os
 import subprocess
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -58,8 +58,11 @@ def build_sim():
     srcs = [d / "sim_encode.cc", d / "hip" / "hip_runtime.h", PKG / "csrc" / "jxlt_device.h",
             PKG / "csrc" / "jxlt_host_tables.h", PKG / "csrc" / "jxlt_tables.h"]
     if not out.exists() or any(s.stat().st_mtime > out.stat().st_mtime for s in srcs):
+        # -Bsymbolic/hidden visibility: the kernels' names also exist (as HIP launch stubs) in
+        # libjxltiny_hip.so; the simulator must bind to its own definitions.
         _run(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-mfma", "-fPIC", "-shared", "-I.",
-              "-x", "c++", "sim_encode.cc", "-o", "libjxlt_sim.so"], d)
+              "-fvisibility=hidden", "-Wl,-Bsymbolic", "-x", "c++", "sim_encode.cc", "-o",
+              "libjxlt_sim.so"], d)
     return out
 
 
@@ -251,3 +254,45 @@ def compare_results(a, b, what_a="A", what_b="B", check_debug=True):
                            (g, len(ta), len(tb), first, first // 3))
                 break
     return bad
+
+
+# --------------------------------------------------------------------------- product
+def product():
+    """The libjxl-tiny_amd package (ctypes binding of the product libraries)."""
+    sys.path.insert(0, str(ROOT))
+    import __graft_entry__
+    return __graft_entry__.load_package()
+
+
+def assemble_codestream(res, distance, num_threads=1):
+    """Full .jxl bytes from a HotPathResult via the product's host back-end
+    (jxlt_write_file_header + jxlt_assemble_frame)."""
+    P = product()
+    H = P.host_lib()
+    dp = P.distance_params(distance)
+    fr = P.FrameResult()
+    fr.xsize, fr.ysize = res.xsize, res.ysize
+    yb, xb = res.raw_quant.shape
+    yt, xt = res.ytox.shape
+    fr.xsize_blocks, fr.ysize_blocks, fr.xsize_tiles, fr.ysize_tiles = xb, yb, xt, yt
+    fr.num_groups = len(res.group_tokens)
+    keep = [np.ascontiguousarray(res.quant_dc[c]) for c in range(3)]
+    for c in range(3):
+        fr.quant_dc[c] = keep[c].ctypes.data_as(C.POINTER(C.c_int16))
+    rq, st = np.ascontiguousarray(res.raw_quant), np.ascontiguousarray(res.strategy)
+    tx, tb = np.ascontiguousarray(res.ytox), np.ascontiguousarray(res.ytob)
+    fr.raw_quant_field = rq.ctypes.data_as(C.POINTER(C.c_uint8))
+    fr.ac_strategy = st.ctypes.data_as(C.POINTER(C.c_uint8))
+    fr.ytox_map = tx.ctypes.data_as(C.POINTER(C.c_int8))
+    fr.ytob_map = tb.ctypes.data_as(C.POINTER(C.c_int8))
+    blob = np.frombuffer(b"".join(res.group_tokens) + b"\0", dtype=np.uint8).copy()
+    offs = np.zeros(fr.num_groups + 1, np.uint64)
+    offs[1:] = np.cumsum([len(t) for t in res.group_tokens])
+    fr.tokens = blob.ctypes.data_as(C.POINTER(C.c_uint8))
+    fr.group_token_offset = offs.ctypes.data_as(C.POINTER(C.c_uint64))
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    rc = H.jxlt_assemble_frame(C.byref(fr), C.byref(dp), num_threads, C.byref(out), C.byref(n))
+    assert rc == 0, rc
+    frame = C.string_at(out, n.value)
+    H.jxlt_free(out)
+    return P.file_header(res.xsize, res.ysize) + frame

@@ -1,0 +1,49 @@
+"""The C-ABI libraries load, export every function include/jxl_tiny_amd.h
+declares, and fail loudly (no CPU fallback) when no HIP device is present."""
+import ctypes as C
+import re
+
+import numpy as np
+import pytest
+
+import jxlt_testlib as T
+
+
+def _declared_functions():
+    text = (T.ROOT / "include" / "jxl_tiny_amd.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(jxlt_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(built):
+    declared = _declared_functions()
+    assert len(declared) >= 16
+    hip, host = built.hip_lib(), built.host_lib()
+    for name in declared:
+        assert hasattr(hip, name) or hasattr(host, name), name
+    assert sorted(built.HIP_SYMBOLS + built.HOST_SYMBOLS) == declared
+
+
+def test_distance_params_match_oracle(built):
+    for d in [0.03, 0.1, 0.299, 0.5, 1.0, 1.25, 1.5, 2.0, 4.0, 8.0, 9.5, 16.0, 25.0]:
+        a, b = built.distance_params(d), T.distance_params(d)
+        for f, _ in a._fields_:
+            assert getattr(a, f) == getattr(b, f), (d, f)
+
+
+def test_file_header_bits(built):
+    h = built.file_header(256, 256)
+    assert h[:2] == b"\xff\x0a" and len(h) >= 6
+    with pytest.raises(built.JxlTinyError):
+        built.file_header(0, 5)
+
+
+def test_no_cpu_fallback_without_gpu(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(built.JxlTinyError, match="no HIP device"):
+        built.Encoder(0)
+    planes = np.zeros((3, 16, 16), np.float32)
+    with pytest.raises(built.JxlTinyError):
+        built.encode_file(planes, 1.0)

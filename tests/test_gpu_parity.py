@@ -1,0 +1,132 @@
+"""Parity tests proper: the HIP path on a real MI355X, called through the C ABI
+(libjxltiny_hip.so / libjxltiny_host.so), against the CPU oracle on the same
+seeded inputs.  Bar: bit-exact -- XYB / quant-field / masking / entropy floats to
+0 ULP (the kernels implement the oracle's arithmetic model operation by
+operation), every integer output and the token stream byte for byte."""
+import subprocess
+
+import numpy as np
+import pytest
+
+import jxlt_testlib as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def enc(built):
+    e = built.Encoder(0)
+    yield e
+    e.close()
+
+
+CASES = [
+    # w, h, distance, hard, force_dct8
+    (256, 256, 1.0, False, False),    # BASELINE config #1: one group
+    (9, 7, 1.0, False, False),
+    (96, 72, 1.0, False, False),
+    (200, 137, 1.0, False, False),
+    (300, 264, 2.0, False, False),
+    (64, 64, 0.5, False, False),
+    (130, 70, 8.0, False, False),
+    (72, 72, 16.0, False, False),
+    (65, 65, 0.1, True, False),
+    (17, 300, 3.0, False, False),
+    (512, 512, 1.0, True, False),     # uniform noise, token heavy
+    (1024, 1024, 1.0, False, True),   # fixed DCT8 (config #2 mode)
+    (1024, 1024, 1.0, False, False),
+    (2100, 300, 1.0, False, False),   # two DC groups wide
+    (520, 2100, 4.0, False, False),   # two DC groups tall, bottom group 52 px
+    (1920, 1080, 1.0, False, False),  # 135-group frame shape of config #5 at half size
+]
+
+
+@pytest.mark.parametrize("w,h,distance,hard,dct8", CASES)
+def test_hot_path_bit_exact_vs_oracle(enc, w, h, distance, hard, dct8):
+    planes = T.to_planes(T.synthetic_image(w, h, hard=hard))
+    want = T.oracle_hot_path(planes, distance, dct8)
+    got = enc.hot_path(planes, distance, force_dct8=dct8, debug=True)
+    assert T.compare_results(want, got, "oracle", "gpu") == []
+
+
+@pytest.mark.parametrize("w,h,distance", [(256, 256, 1.0), (200, 137, 0.5), (700, 520, 2.0), (2100, 300, 1.0)])
+def test_dropin_encode_file_matches_oracle_codestream(built, w, h, distance):
+    planes = T.to_planes(T.synthetic_image(w, h))
+    want = T.assemble_codestream(T.oracle_hot_path(planes, distance), distance)
+    assert built.encode_file(planes, distance) == want
+
+
+def test_cjxl_tiny_cli(built, tmp_path):
+    img = T.synthetic_image(300, 200)
+    pfm, out = tmp_path / "in.pfm", tmp_path / "out.jxl"
+    T.write_pfm(pfm, img)
+    r = subprocess.run([str(built.CJXL_TINY), str(pfm), str(out), "-d", "1.5"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Read 300x200 pixels input image." in r.stderr
+    want = T.assemble_codestream(T.oracle_hot_path(T.to_planes(img), 1.5), 1.5)
+    assert out.read_bytes() == want
+    assert ("Compressed to %d bytes." % len(want)) in r.stderr
+
+
+def test_error_behaviour(built, enc):
+    # EncodeFile rejects distance <= 0 (enc_file.cc:57-62) and empty images
+    planes = T.to_planes(T.synthetic_image(32, 32))
+    for bad in (0.0, -1.0):
+        with pytest.raises(built.JxlTinyError):
+            built.encode_file(planes, bad)
+    # distance <= 0.03 is clamped to 0.03 (enc_file.cc:63-65)
+    assert built.encode_file(planes, 0.01) == built.encode_file(planes, 0.03)
+    # images that fit one 8x8 block trap in the reference; here: an error
+    with pytest.raises(built.JxlTinyError):
+        enc.upload(np.zeros((3, 8, 8), np.float32))
+
+
+def test_values_outside_unit_range(enc):
+    rng = np.random.default_rng(7)
+    planes = (rng.random((3, 72, 136)) * 3.0 - 1.0).astype(np.float32)  # [-1, 2): negative + HDR
+    want = T.oracle_hot_path(planes, 1.0)
+    got = enc.hot_path(planes, 1.0, debug=True)
+    assert T.compare_results(want, got, "oracle", "gpu") == []
+
+
+def test_full_size_properties(built, enc):
+    """BASELINE-scale input (4096x4096 = config #2 size, too slow for a full oracle
+    pass in the test budget): size-independent properties instead.
+      * determinism: two passes give identical bytes
+      * shard independence: any group-aligned crop encodes to the same per-group
+        token streams and side-band cells as those groups of the full frame
+      * the crop itself is checked against the oracle."""
+    size = 4096
+    img = T.synthetic_image(size, size)
+    planes = T.to_planes(img)
+    a = enc.hot_path(planes, 1.0)
+    b = enc.hot_path(planes, 1.0)
+    assert a.all_tokens() == b.all_tokens()
+    assert np.array_equal(a.quant_dc, b.quant_dc)
+    gpr = size // 256
+    x0, y0, s = 2048, 1024, 768  # a 3x3-group window away from the origin
+    crop = np.ascontiguousarray(planes[:, y0:y0 + s, x0:x0 + s])
+    c = enc.hot_path(crop, 1.0)
+    for gy in range(s // 256):
+        for gx in range(s // 256):
+            full_g = (y0 // 256 + gy) * gpr + (x0 // 256 + gx)
+            assert c.group_tokens[gy * (s // 256) + gx] == a.group_tokens[full_g], (gx, gy)
+    bs = slice(y0 // 8, (y0 + s) // 8), slice(x0 // 8, (x0 + s) // 8)
+    assert np.array_equal(c.strategy, a.strategy[bs])
+    assert np.array_equal(c.raw_quant, a.raw_quant[bs])
+    assert np.array_equal(c.quant_dc, a.quant_dc[(slice(None),) + bs])
+    want = T.oracle_hot_path(crop, 1.0)
+    assert T.compare_results(want, c, "oracle", "gpu", check_debug=False) == []
+
+
+def test_device_resident_entry_point(built, enc):
+    """jxlt_image_set_device: planes living in a torch tensor (pitch != width)."""
+    import torch
+    w, h = 200, 137
+    planes = T.to_planes(T.synthetic_image(w, h))
+    t = torch.zeros((3, h, 256), dtype=torch.float32, device="cuda")
+    t[:, :, :w] = torch.from_numpy(planes).cuda()
+    torch.cuda.synchronize()
+    enc.set_device_image([t[c].data_ptr() for c in range(3)], 256 * 4, w, h, keepalive=t)
+    jxl = enc.encode_resident(1.0)
+    assert jxl == T.assemble_codestream(T.oracle_hot_path(planes, 1.0), 1.0)
