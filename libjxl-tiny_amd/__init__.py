@@ -86,6 +86,12 @@ def hip_lib():
     if _hip is None:
         if not HIP_LIB.exists():
             raise JxlTinyError("%s is missing: run __graft_entry__.build()" % HIP_LIB)
+        try:
+            # PyTorch-ROCm bundles its own libamdhip64; two HIP runtimes in one process do not
+            # coexist, so when torch is installed let it load its runtime first and share it.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(str(HIP_LIB))
         L.jxlt_context_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.jxlt_context_destroy.argtypes = [C.c_void_p]
