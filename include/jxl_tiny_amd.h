@@ -118,7 +118,9 @@ int jxlt_kernel_times(jxlt_context* ctx, jxlt_kernel_time* out, int cap);
  * what: 0,1,2 = XYB planes f32 (xsize_blocks*8 x ysize_blocks*8);
  *       3 = quant field f32 per block; 4 = masking f32 per block;
  *       5 = entropy estimates f32, 8 per 2x2-block cell, grid
- *           (xsize_blocks/2+1) x (ysize_blocks/2+1). */
+ *           (xsize_blocks/2+1) x (ysize_blocks/2+1).
+ *       6 = u64[16] shader cycles per tile_kernel phase, summed over tiles (needs
+ *           JXLT_FLAG_PROFILE instead of JXLT_FLAG_DEBUG_DUMP). */
 int jxlt_debug_fetch(jxlt_context* ctx, int what, void* host_dst, size_t bytes);
 
 /* ---- libjxltiny_host.so ------------------------------------------------ */

@@ -62,6 +62,7 @@ struct jxlt_context {
   DeviceBuf<uint32_t> group_ntok;
   DeviceBuf<uint64_t> group_off;
   DeviceBuf<float> dbg_xyb[3], dbg_qf, dbg_mask, dbg_ent8;
+  DeviceBuf<unsigned long long> dbg_phase;
 
   // pinned host mirrors
   PinnedBuf<int16_t> h_quant_dc[3];
@@ -197,6 +198,7 @@ void jxlt_context_destroy(jxlt_context* ctx) {
   FreeDevice(&ctx->dbg_qf);
   FreeDevice(&ctx->dbg_mask);
   FreeDevice(&ctx->dbg_ent8);
+  FreeDevice(&ctx->dbg_phase);
   FreePinned(&ctx->h_raw_quant);
   FreePinned(&ctx->h_strategy);
   FreePinned(&ctx->h_tokens);
@@ -289,6 +291,11 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
     ENSURE(dbg_ent8, ncells * 8);
     HIP_TRY(ctx, hipMemsetAsync(ctx->dbg_ent8.p, 0xFF, ncells * 8 * sizeof(float), ctx->stream));  // NaN
   }
+  const bool profile = (params->flags & JXLT_FLAG_PROFILE) != 0;
+  if (profile) {
+    ENSURE(dbg_phase, 16);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dbg_phase.p, 0, 16 * sizeof(unsigned long long), ctx->stream));
+  }
 #undef ENSURE
 
   if (ctx->tab_scale != params->scale) {
@@ -328,6 +335,7 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   A.dbg_qf = debug ? ctx->dbg_qf.p : nullptr;
   A.dbg_mask = debug ? ctx->dbg_mask.p : nullptr;
   A.dbg_ent8 = debug ? ctx->dbg_ent8.p : nullptr;
+  A.dbg_phase = profile ? ctx->dbg_phase.p : nullptr;
 
   TokenArgs K;
   memset(&K, 0, sizeof(K));
@@ -341,7 +349,6 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   K.group_tok_offset = ctx->group_off.p;
   K.tokens = ctx->tokens.p;
 
-  const bool profile = (params->flags & JXLT_FLAG_PROFILE) != 0;
   HIP_TRY(ctx, hipMemsetAsync(ctx->group_ntok.p, 0, ngroups * sizeof(uint32_t), ctx->stream));
   if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   hipLaunchKernelGGL(tile_kernel, dim3((unsigned)ntiles), dim3(kTileThreads), 0, ctx->stream, A);
@@ -442,11 +449,20 @@ int jxlt_kernel_times(jxlt_context* ctx, jxlt_kernel_time* out, int cap) {
 
 int jxlt_debug_fetch(jxlt_context* ctx, int what, void* host_dst, size_t bytes) {
   if (!ctx || !host_dst) return JXLT_ERR_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (what == 6) {  // per-phase shader-cycle totals of tile_kernel (JXLT_FLAG_PROFILE)
+    if (!(ctx->last_flags & JXLT_FLAG_PROFILE) || bytes != 16 * sizeof(unsigned long long)) {
+      ctx->error = "phase counters need JXLT_FLAG_PROFILE and a 128-byte buffer";
+      return JXLT_ERR_INVALID_ARGUMENT;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(host_dst, ctx->dbg_phase.p, bytes, hipMemcpyDeviceToHost));
+    return JXLT_OK;
+  }
   if (!(ctx->last_flags & JXLT_FLAG_DEBUG_DUMP)) {
     ctx->error = "last encode was not run with JXLT_FLAG_DEBUG_DUMP";
     return JXLT_ERR_INVALID_ARGUMENT;
   }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
   const FrameGeom& g = ctx->geom;
   const size_t nblocks = (size_t)g.xsize_blocks * g.ysize_blocks;
   const size_t ncells = ((size_t)g.xsize_blocks / 2 + 1) * ((size_t)g.ysize_blocks / 2 + 1);

@@ -76,6 +76,7 @@ struct TileArgs {
   float* dbg_qf;
   float* dbg_mask;
   float* dbg_ent8;
+  unsigned long long* dbg_phase;  // [16] accumulated shader cycles per phase (thread 0 of each tile)
 };
 
 struct TokenArgs {
@@ -642,6 +643,13 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
   const int l = tid & 7;    // lane within octet
   const int oct = tid >> 3;  // octet index == block index within tile (0..63)
   const DeviceTables* T = A.tab;
+  long long t_prev = A.dbg_phase ? clock64() : 0;
+#define JXLT_MARK(i)                                                        \
+  if (A.dbg_phase && tid == 0) {                                            \
+    const long long t_now = clock64();                                      \
+    atomicAdd(&A.dbg_phase[i], (unsigned long long)(t_now - t_prev));       \
+    t_prev = t_now;                                                         \
+  }
 
   // ---- geometry (enc_frame.cc:716-751) ------------------------------------
   const int tile_id = (int)blockIdx.x;
@@ -684,6 +692,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
     }
   }
   __syncthreads();
+  JXLT_MARK(0);
   // LDS column of stripe pixel x is (x - px0 + kHalo).
 #define SX(yy, xx) S.x[(yy) * kXYPitch + ((xx) - px0 + kHalo)]
 #define SY(yy, xx) S.y[(yy) * kXYPitch + ((xx) - px0 + kHalo)]
@@ -731,6 +740,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
     }
   }
   __syncthreads();
+  JXLT_MARK(1);
   // ---- P2: 4-column average -> pre_erosion (:484-491) ------------------------
   const int pre_xs = aq_w / 4, pre_ys = nby * 2;
   for (int i = tid; i < pre_ys * pre_xs; i += kTileThreads) {
@@ -783,6 +793,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
     }
   }
   __syncthreads();
+  JXLT_MARK(2);
   // ---- P4: per-block modulations, one octet per block (:114-285) -------------
   {
     float out_val = 0.0f;
@@ -876,6 +887,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
     }
   }
   __syncthreads();
+  JXLT_MARK(3);
 
   // ---- P5: DCT8 of every block (kept in registers) + chroma-from-luma -------
   // (enc_chroma_from_luma.cc:40-131)
@@ -894,6 +906,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
       for (int r = 0; r < 8; r++) { c8x[r] = 0; c8y[r] = 0; c8b[r] = 0; }
     }
   }
+  JXLT_MARK(4);
   {
     // Sequential per-lane fma chains over the tile's blocks in raster order; the
     // terms are handed to wave 0 through LDS in chunks of kCflChunkBlocks blocks.
@@ -952,6 +965,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
     }
   }
   __syncthreads();
+  JXLT_MARK(5);
   const int ytox = S.cmap[0], ytob = S.cmap[1];
   const float kInvColorFactorF = 1.0f / 84;
   const float cmap_x = (float)ytox * kInvColorFactorF;           // YtoXRatio
@@ -1017,6 +1031,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
     }
   }
   __syncthreads();
+  JXLT_MARK(6);
   // ---- P7: decision (:213-237) + AdjustQuantField (:240-266) ------------------
   if (search && tid < 16) {
     const int cx = (tid & 3) * 2, cy = (tid >> 2) * 2;
@@ -1060,6 +1075,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
   // All pixel reads are done (transforms live in registers): from here on the
   // XYB planes are reused as the quantised-coefficient staging area.
   __syncthreads();
+  JXLT_MARK(7);
   int16_t* stage = reinterpret_cast<int16_t*>(&S.x[0]);  // [64 blocks][3][64]
 
   // ---- P8: quantise (enc_group.cc:304-443) -----------------------------------
@@ -1081,6 +1097,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
     }
   }
   __syncthreads();
+  JXLT_MARK(8);
 
   // ---- P9: scan-order store; one wave per (block, channel) --------------------
   {
@@ -1117,10 +1134,12 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
     if (lane == 0 && my_tokens) atomicAdd(&S.ntok, my_tokens);
   }
   __syncthreads();
+  JXLT_MARK(9);
   if (tid == 0) {
     const int group = (ty_img >> 2) * A.g.xsize_groups + gx;
     atomicAdd(&A.group_ntok[group], S.ntok);
   }
+#undef JXLT_MARK
 #undef SX
 #undef SY
 }

@@ -269,6 +269,8 @@ inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f;
 inline int32_t __float_as_int(float f) { int32_t u; memcpy(&u, &f, 4); return u; }
 inline float __int_as_float(int32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
+inline long long clock64() { return 0; }
+
 // One workgroup runs at a time and fibers never preempt: plain RMW is atomic.
 template <typename T>
 inline T atomicAdd(T* p, T v) {

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Prints where time goes for one frame: per-phase shader cycles of tile_kernel
+(thread 0 of every tile, JXLT_FLAG_PROFILE), per-kernel HIP-event times, and the
+host stages (D2H fetch, bitstream assembly).  Usage: profile_phases.py [size]"""
+import ctypes as C
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import __graft_entry__  # noqa: E402
+import bench  # noqa: E402
+
+PHASES = ["P0 load+XYB", "P1 AQ energy", "P2-3 erosion", "P4 modulations", "P5a DCT8", "P5b CfL chain",
+          "P6 strategy search", "P7 decision", "P8 quantise", "P9 scan store"]
+
+
+def main():
+    import torch
+    size = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    pkg = __graft_entry__.load_package()
+    dev = torch.device("cuda", 0)
+    frame = bench.make_frame_on_device(torch, size, 0, dev)
+    torch.cuda.synchronize()
+    enc = pkg.Encoder(0)
+    enc.set_device_image([frame[c].data_ptr() for c in range(3)], size * 4, size, size, keepalive=frame)
+    for _ in range(2):
+        enc.enqueue(1.0, 0)
+        enc.synchronize()
+    enc.enqueue(1.0, pkg.FLAG_PROFILE)
+    enc.synchronize()
+    kt = enc.kernel_times()
+    ph = np.zeros(16, np.uint64)
+    enc._check(enc._L.jxlt_debug_fetch(enc._ctx, 6, ph.ctypes.data, ph.nbytes), "phase fetch")
+    ntiles = (size // 64) ** 2
+    tot = float(ph.sum())
+    print("frame %dx%d, %d tiles; kernel ms: %s" % (size, size, ntiles, {k: round(v, 3) for k, v in kt.items()}))
+    for name, c in zip(PHASES, ph):
+        print("  %-20s %9.0f cycles/tile  %5.1f %%" % (name, float(c) / ntiles, 100.0 * float(c) / tot))
+    print("  total %.0f cycles/tile (profiled run)" % (tot / ntiles))
+    # host stages
+    for rep in range(2):
+        t0 = time.perf_counter()
+        dp = enc.enqueue(1.0, 0)
+        enc.synchronize()
+        t1 = time.perf_counter()
+        fr = enc.fetch_raw()
+        t2 = time.perf_counter()
+        blob = enc.assemble(fr, dp, 0)
+        t3 = time.perf_counter()
+    print("host: device %.2f ms, fetch(D2H) %.2f ms, assemble %.2f ms (%d bytes)" %
+          (1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), len(blob)))
+    for nt in (1, 8, 32, 64):
+        enc.enqueue(1.0, 0)
+        fr = enc.fetch_raw()
+        t2 = time.perf_counter()
+        enc.assemble(fr, dp, nt)
+        print("  assemble with %3d threads: %.2f ms" % (nt, 1e3 * (time.perf_counter() - t2)))
+
+
+if __name__ == "__main__":
+    main()
