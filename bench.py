@@ -97,8 +97,8 @@ def main():
     ptrs = [frame[c].data_ptr() for c in range(3)]
     enc.set_device_image(ptrs, size * 4, size, size, keepalive=frame)
 
-    def step(flags=0):
-        return enc.encode_resident(args.distance, num_threads=args.host_threads, flags=flags)
+    def step():
+        return enc.encode_resident(args.distance, num_threads=args.host_threads)
 
     for _ in range(args.warmup):
         jxl = step()

@@ -98,6 +98,9 @@ int jxlt_image_upload(jxlt_context* ctx, const float* const planes[3], size_t pi
 int jxlt_image_set_device(jxlt_context* ctx, const void* const device_planes[3],
                           size_t pitch_bytes, size_t xsize, size_t ysize);
 
+/* Size of the image currently set on the context. */
+int jxlt_image_size(const jxlt_context* ctx, size_t* xsize, size_t* ysize);
+
 /* Enqueues the whole per-group pipeline for the current image on the context's
  * stream (asynchronous).  One call == one "step" of the hot path. */
 int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params);
@@ -105,6 +108,23 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params);
 int jxlt_synchronize(jxlt_context* ctx);
 /* Copies results to pinned host memory (blocking) and fills *out. */
 int jxlt_fetch_result(jxlt_context* ctx, jxlt_frame_result* out);
+
+/* Production path: the raw tokens stay in HBM.
+ * jxlt_fetch_side_info copies only the side-band grids and the AC symbol
+ * histograms ([64 pre-clustered contexts][64 hybrid-uint symbols], u32, what
+ * OptimizeSections counts at enc_frame.cc:767-782); out->tokens is NULL.
+ * jxlt_pack_ac_sections then entropy-codes every AC group section on the device
+ * (the WriteToken loop of enc_frame.cc:784-800) with the caller's prefix code:
+ * code_table[ctx * 64 + symbol] = (depth << 16) | bits for pre-clustered context
+ * ctx, and returns the byte-aligned sections concatenated in group order. */
+typedef struct {
+  const uint8_t* bytes;            /* pinned host memory, owned by the context */
+  const uint64_t* section_offset;  /* [num_sections + 1] byte offsets into bytes */
+  const uint32_t* section_bits;    /* [num_sections] exact bit length of each section */
+  size_t num_sections;
+} jxlt_packed_sections;
+int jxlt_fetch_side_info(jxlt_context* ctx, jxlt_frame_result* out, const uint32_t** ac_histograms);
+int jxlt_pack_ac_sections(jxlt_context* ctx, const uint32_t* code_table, jxlt_packed_sections* out);
 
 /* Timing of the kernels of the last jxlt_encode_enqueue (needs JXLT_FLAG_PROFILE):
  * writes up to `cap` entries; returns the number of kernels, or < 0. */
@@ -136,6 +156,12 @@ int jxlt_assemble_frame(const jxlt_frame_result* frame, const jxlt_distance_para
 int jxlt_assemble_frame_groups(const jxlt_frame_result* frame, const uint8_t* const* group_tokens,
                                const size_t* group_token_bytes, const jxlt_distance_params* distp,
                                int num_threads, uint8_t** out_bytes, size_t* out_size);
+
+/* Full codestream (file header + frame) of the image currently set on `ctx`
+ * (jxlt_image_upload / jxlt_image_set_device): device pipeline, device-side
+ * section packing, host assembly.  malloc'ed result, free with jxlt_free. */
+int jxlt_encode_resident(jxlt_context* ctx, float distance, int num_threads, uint8_t** out_bytes,
+                         size_t* out_size);
 
 /* C entry to the drop-in EncodeFile (enc_file.h:20-21): planar f32 in host
  * memory -> complete .jxl codestream (malloc'ed, free with jxlt_free).

@@ -29,10 +29,11 @@ FLAG_FORCE_DCT8, FLAG_DEBUG_DUMP, FLAG_PROFILE = 1, 2, 4
 
 # Symbols include/jxl_tiny_amd.h declares, per library (checked by the tests).
 HIP_SYMBOLS = ["jxlt_context_create", "jxlt_context_destroy", "jxlt_last_error",
-               "jxlt_image_upload", "jxlt_image_set_device", "jxlt_encode_enqueue",
+               "jxlt_image_upload", "jxlt_image_set_device", "jxlt_image_size", "jxlt_encode_enqueue",
+               "jxlt_fetch_side_info", "jxlt_pack_ac_sections",
                "jxlt_synchronize", "jxlt_fetch_result", "jxlt_kernel_times", "jxlt_debug_fetch"]
 HOST_SYMBOLS = ["jxlt_compute_distance_params", "jxlt_assemble_frame", "jxlt_assemble_frame_groups",
-                "jxlt_encode_file_planar", "jxlt_write_file_header", "jxlt_free"]
+                "jxlt_encode_file_planar", "jxlt_encode_resident", "jxlt_write_file_header", "jxlt_free"]
 
 
 class JxlTinyError(RuntimeError):
@@ -126,6 +127,8 @@ def host_lib():
                                                  C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         L.jxlt_encode_file_planar.argtypes = [C.POINTER(fp), C.c_size_t, C.c_size_t, C.c_size_t, C.c_float,
                                               C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        L.jxlt_encode_resident.argtypes = [C.c_void_p, C.c_float, C.c_int, C.POINTER(C.POINTER(C.c_uint8)),
+                                           C.POINTER(C.c_size_t)]
         L.jxlt_write_file_header.argtypes = [C.c_size_t, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)),
                                              C.POINTER(C.c_size_t)]
         L.jxlt_free.argtypes = [C.c_void_p]
@@ -275,8 +278,19 @@ class Encoder:
             raise JxlTinyError("jxlt_assemble_frame failed (%d)" % rc)
         return _take_bytes(out, n)
 
-    def encode_resident(self, distance, num_threads=0, flags=0):
-        """Full codestream of the image currently set/uploaded on the device."""
+    def encode_resident(self, distance, num_threads=0):
+        """Full codestream of the image currently set/uploaded on the device (production path:
+        device pipeline + device section packing + host assembly, jxlt_encode_resident)."""
+        out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+        rc = host_lib().jxlt_encode_resident(self._ctx, C.c_float(distance), num_threads, C.byref(out),
+                                             C.byref(n))
+        if rc != 0:
+            raise JxlTinyError("jxlt_encode_resident failed (%d): %s" %
+                               (rc, self._L.jxlt_last_error(self._ctx).decode()))
+        return _take_bytes(out, n)
+
+    def encode_resident_raw_tokens(self, distance, num_threads=0, flags=0):
+        """Same result through the raw-token route (tokens copied to the host and packed there)."""
         dp = self.enqueue(distance, flags)
         fr = self.fetch_raw()
         return file_header(fr.xsize, fr.ysize) + self.assemble(fr, dp, num_threads)

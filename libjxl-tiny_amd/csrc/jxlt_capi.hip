@@ -63,12 +63,18 @@ struct jxlt_context {
   DeviceBuf<uint64_t> group_off;
   DeviceBuf<float> dbg_xyb[3], dbg_qf, dbg_mask, dbg_ent8;
   DeviceBuf<unsigned long long> dbg_phase;
+  DeviceBuf<uint32_t> hist, code_table, sec_bits, sec_bytes;
+  DeviceBuf<uint64_t> sec_byte_off;
+  DeviceBuf<uint8_t> slots, packed;
 
   // pinned host mirrors
   PinnedBuf<int16_t> h_quant_dc[3];
   PinnedBuf<uint8_t> h_raw_quant, h_strategy, h_tokens;
   PinnedBuf<int8_t> h_ytox, h_ytob;
-  PinnedBuf<uint64_t> h_group_off;
+  PinnedBuf<uint64_t> h_group_off, h_sec_byte_off;
+  PinnedBuf<uint32_t> h_hist, h_sec_bits;
+  PinnedBuf<uint8_t> h_packed;
+  bool side_info_fetched = false;
 
   FrameGeom geom = {};
   bool encoded = false;
@@ -199,6 +205,17 @@ void jxlt_context_destroy(jxlt_context* ctx) {
   FreeDevice(&ctx->dbg_mask);
   FreeDevice(&ctx->dbg_ent8);
   FreeDevice(&ctx->dbg_phase);
+  FreeDevice(&ctx->hist);
+  FreeDevice(&ctx->code_table);
+  FreeDevice(&ctx->sec_bits);
+  FreeDevice(&ctx->sec_bytes);
+  FreeDevice(&ctx->sec_byte_off);
+  FreeDevice(&ctx->slots);
+  FreeDevice(&ctx->packed);
+  FreePinned(&ctx->h_sec_byte_off);
+  FreePinned(&ctx->h_hist);
+  FreePinned(&ctx->h_sec_bits);
+  FreePinned(&ctx->h_packed);
   FreePinned(&ctx->h_raw_quant);
   FreePinned(&ctx->h_strategy);
   FreePinned(&ctx->h_tokens);
@@ -250,6 +267,13 @@ int jxlt_image_set_device(jxlt_context* ctx, const void* const device_planes[3],
   return JXLT_OK;
 }
 
+int jxlt_image_size(const jxlt_context* ctx, size_t* xsize, size_t* ysize) {
+  if (!ctx || !xsize || !ysize || !ctx->planes[0]) return JXLT_ERR_INVALID_ARGUMENT;
+  *xsize = ctx->xsize;
+  *ysize = ctx->ysize;
+  return JXLT_OK;
+}
+
 int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   if (!ctx || !params) return JXLT_ERR_INVALID_ARGUMENT;
   if (!ctx->planes[0]) {
@@ -282,6 +306,7 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   ENSURE(coef_scan, nblocks * 3 * 64);
   ENSURE(group_ntok, ngroups);
   ENSURE(group_off, ngroups + 1);
+  ENSURE(hist, 64 * 64);
   // worst case: every coefficient of every block is a token, plus one nzeros token
   ENSURE(tokens, nblocks * 3 * 64 * 3);
   const size_t ncells = ((size_t)g.xsize_blocks / 2 + 1) * ((size_t)g.ysize_blocks / 2 + 1);
@@ -348,8 +373,10 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   K.coef_scan = ctx->coef_scan.p;
   K.group_tok_offset = ctx->group_off.p;
   K.tokens = ctx->tokens.p;
+  K.histogram = ctx->hist.p;
 
   HIP_TRY(ctx, hipMemsetAsync(ctx->group_ntok.p, 0, ngroups * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->hist.p, 0, 64 * 64 * sizeof(uint32_t), ctx->stream));
   if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   hipLaunchKernelGGL(tile_kernel, dim3((unsigned)ntiles), dim3(kTileThreads), 0, ctx->stream, A);
   if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
@@ -361,6 +388,7 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   HIP_TRY(ctx, hipGetLastError());
   ctx->geom = g;
   ctx->encoded = true;
+  ctx->side_info_fetched = false;
   ctx->last_flags = params->flags;
   ctx->profiled = profile;
   return JXLT_OK;
@@ -373,12 +401,11 @@ int jxlt_synchronize(jxlt_context* ctx) {
   return JXLT_OK;
 }
 
-int jxlt_fetch_result(jxlt_context* ctx, jxlt_frame_result* out) {
-  if (!ctx || !out) return JXLT_ERR_INVALID_ARGUMENT;
-  if (!ctx->encoded) {
-    ctx->error = "nothing encoded yet";
-    return JXLT_ERR_INVALID_ARGUMENT;
-  }
+namespace {
+
+// Copies grids, per-group token offsets and histograms to pinned memory; fills *out
+// (tokens left NULL).  Leaves group offsets in TOKENS (not bytes) in h_group_off.
+int FetchSideInfo(jxlt_context* ctx, jxlt_frame_result* out) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const FrameGeom& g = ctx->geom;
   const size_t nblocks = (size_t)g.xsize_blocks * g.ysize_blocks;
@@ -391,26 +418,25 @@ int jxlt_fetch_result(jxlt_context* ctx, jxlt_frame_result* out) {
   ENSUREH(h_strategy, nblocks);
   ENSUREH(h_ytox, ntiles);
   ENSUREH(h_ytob, ntiles);
-  ENSUREH(h_group_off, ngroups + 1);
+  ENSUREH(h_group_off, 2 * (ngroups + 1));  // [0, n]: tokens, [n+1, 2n+1]: bytes
+  ENSUREH(h_hist, 64 * 64);
+#undef ENSUREH
 #define D2H(dst, src, bytes) HIP_TRY(ctx, hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, ctx->stream))
   D2H(ctx->h_group_off.p, ctx->group_off.p, (ngroups + 1) * sizeof(uint64_t));
+  D2H(ctx->h_hist.p, ctx->hist.p, 64 * 64 * sizeof(uint32_t));
   for (int c = 0; c < 3; c++) D2H(ctx->h_quant_dc[c].p, ctx->quant_dc[c].p, nblocks * sizeof(int16_t));
   D2H(ctx->h_raw_quant.p, ctx->raw_quant.p, nblocks);
   D2H(ctx->h_strategy.p, ctx->strategy.p, nblocks);
   D2H(ctx->h_ytox.p, ctx->ytox.p, ntiles);
   D2H(ctx->h_ytob.p, ctx->ytob.p, ntiles);
+#undef D2H
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  const uint64_t total_tokens = ctx->h_group_off.p[ngroups];
-  if (total_tokens * 3 > ctx->tokens.cap) {
+  uint64_t* byte_off = ctx->h_group_off.p + ngroups + 1;
+  for (size_t i = 0; i <= ngroups; i++) byte_off[i] = ctx->h_group_off.p[i] * 3;
+  if (ctx->h_group_off.p[ngroups] * 3 > ctx->tokens.cap) {
     ctx->error = "internal error: token count exceeds the worst-case bound";
     return JXLT_ERR_INTERNAL;
   }
-  if (ctx->h_tokens.cap < total_tokens * 3) ENSUREH(h_tokens, total_tokens * 3 + total_tokens / 4 + 4096);
-  if (total_tokens) D2H(ctx->h_tokens.p, ctx->tokens.p, total_tokens * 3);
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-#undef D2H
-#undef ENSUREH
-  for (size_t i = 0; i <= ngroups; i++) ctx->h_group_off.p[i] *= 3;  // tokens -> bytes
   out->xsize = ctx->xsize;
   out->ysize = ctx->ysize;
   out->xsize_blocks = g.xsize_blocks;
@@ -423,9 +449,105 @@ int jxlt_fetch_result(jxlt_context* ctx, jxlt_frame_result* out) {
   out->ac_strategy = ctx->h_strategy.p;
   out->ytox_map = ctx->h_ytox.p;
   out->ytob_map = ctx->h_ytob.p;
+  out->tokens = nullptr;
+  out->group_token_offset = byte_off;
+  ctx->side_info_fetched = true;
+  return JXLT_OK;
+}
+
+}  // namespace
+
+int jxlt_fetch_side_info(jxlt_context* ctx, jxlt_frame_result* out, const uint32_t** ac_histograms) {
+  if (!ctx || !out) return JXLT_ERR_INVALID_ARGUMENT;
+  if (!ctx->encoded) {
+    ctx->error = "nothing encoded yet";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = FetchSideInfo(ctx, out);
+  if (rc == JXLT_OK && ac_histograms) *ac_histograms = ctx->h_hist.p;
+  return rc;
+}
+
+int jxlt_fetch_result(jxlt_context* ctx, jxlt_frame_result* out) {
+  if (!ctx || !out) return JXLT_ERR_INVALID_ARGUMENT;
+  if (!ctx->encoded) {
+    ctx->error = "nothing encoded yet";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  int rc = FetchSideInfo(ctx, out);
+  if (rc != JXLT_OK) return rc;
+  const size_t ngroups = out->num_groups;
+  const uint64_t total_bytes = out->group_token_offset[ngroups];
+  if (ctx->h_tokens.cap < total_bytes &&
+      (rc = EnsurePinned(ctx, &ctx->h_tokens, total_bytes + total_bytes / 4 + 4096)) != JXLT_OK)
+    return rc;
+  if (total_bytes) {
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_tokens.p, ctx->tokens.p, total_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if ((rc = EnsurePinned(ctx, &ctx->h_tokens, 1)) != JXLT_OK) return rc;
   out->tokens = ctx->h_tokens.p;
-  out->group_token_offset = ctx->h_group_off.p;
-  ctx->encoded = false;  // offsets were converted in place; a re-fetch needs a new encode
+  return JXLT_OK;
+}
+
+int jxlt_pack_ac_sections(jxlt_context* ctx, const uint32_t* code_table, jxlt_packed_sections* out) {
+  if (!ctx || !code_table || !out) return JXLT_ERR_INVALID_ARGUMENT;
+  if (!ctx->encoded || !ctx->side_info_fetched) {
+    ctx->error = "jxlt_pack_ac_sections needs jxlt_encode_enqueue + jxlt_fetch_side_info first";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const FrameGeom& g = ctx->geom;
+  const size_t ngroups = (size_t)g.xsize_groups * g.ysize_groups;
+  const uint64_t total_tokens = ctx->h_group_off.p[ngroups];
+  int rc;
+#define ENSURE(buf, n) if ((rc = EnsureDevice(ctx, &ctx->buf, (n))) != JXLT_OK) return rc
+  ENSURE(code_table, 64 * 64);
+  ENSURE(sec_bits, ngroups);
+  ENSURE(sec_bytes, ngroups);
+  ENSURE(sec_byte_off, ngroups + 1);
+  if (ctx->slots.cap < 4 * total_tokens + 16) ENSURE(slots, 4 * total_tokens + total_tokens / 2 + 4096);
+  if (ctx->packed.cap < 4 * total_tokens + 16) ENSURE(packed, 4 * total_tokens + total_tokens / 2 + 4096);
+#undef ENSURE
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->code_table.p, code_table, 64 * 64 * sizeof(uint32_t), hipMemcpyHostToDevice,
+                              ctx->stream));
+  PackArgs P;
+  P.records = ctx->tokens.p;
+  P.sec_rec_offset = ctx->group_off.p;
+  P.code_table = ctx->code_table.p;
+  P.slots = ctx->slots.p;
+  P.sec_bits = ctx->sec_bits.p;
+  P.sec_bytes = ctx->sec_bytes.p;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ngroups), dim3(kPackThreads), 0, ctx->stream, P);
+  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->sec_bytes.p,
+                     ctx->sec_byte_off.p, (int)ngroups);
+  CompactArgs Cp;
+  Cp.slots = ctx->slots.p;
+  Cp.sec_rec_offset = ctx->group_off.p;
+  Cp.sec_bytes = ctx->sec_bytes.p;
+  Cp.sec_byte_offset = ctx->sec_byte_off.p;
+  Cp.out = ctx->packed.p;
+  hipLaunchKernelGGL(compact_kernel, dim3((unsigned)ngroups), dim3(256), 0, ctx->stream, Cp);
+  HIP_TRY(ctx, hipGetLastError());
+  if ((rc = EnsurePinned(ctx, &ctx->h_sec_byte_off, ngroups + 1)) != JXLT_OK) return rc;
+  if ((rc = EnsurePinned(ctx, &ctx->h_sec_bits, ngroups)) != JXLT_OK) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_sec_byte_off.p, ctx->sec_byte_off.p, (ngroups + 1) * sizeof(uint64_t),
+                              hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_sec_bits.p, ctx->sec_bits.p, ngroups * sizeof(uint32_t),
+                              hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const uint64_t total_bytes = ctx->h_sec_byte_off.p[ngroups];
+  if (ctx->h_packed.cap < total_bytes + 1 &&
+      (rc = EnsurePinned(ctx, &ctx->h_packed, total_bytes + total_bytes / 4 + 4096)) != JXLT_OK)
+    return rc;
+  if (total_bytes) {
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_packed.p, ctx->packed.p, total_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  out->bytes = ctx->h_packed.p;
+  out->section_offset = ctx->h_sec_byte_off.p;
+  out->section_bits = ctx->h_sec_bits.p;
+  out->num_sections = ngroups;
   return JXLT_OK;
 }
 

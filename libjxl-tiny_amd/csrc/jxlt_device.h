@@ -89,6 +89,25 @@ struct TokenArgs {
   const int16_t* coef_scan;
   const uint64_t* group_tok_offset;  // exclusive scan of group_ntok (tokens)
   uint8_t* tokens;                   // 3 bytes per token
+  uint32_t* histogram;               // optional [64 pre-clusters][64 symbols] (enc_frame.cc:767-782)
+};
+
+// Bit packing of raw 3-byte-record sections with a prefix code (enc_frame.cc:784-800).
+struct PackArgs {
+  const uint8_t* records;           // [u8 ctx][u16 value]; ctx >= 128: (ctx-128) raw bits
+  const uint64_t* sec_rec_offset;   // [nsec + 1], in records
+  const uint32_t* code_table;       // [64][64]: (depth << 16) | bits, per (context, symbol)
+  uint8_t* slots;                   // section s is written at byte 4 * sec_rec_offset[s]
+  uint32_t* sec_bits;               // [nsec] bits written
+  uint32_t* sec_bytes;              // [nsec] ceil(bits / 8)
+};
+
+struct CompactArgs {
+  const uint8_t* slots;
+  const uint64_t* sec_rec_offset;
+  const uint32_t* sec_bytes;
+  const uint64_t* sec_byte_offset;  // exclusive scan of sec_bytes
+  uint8_t* out;
 };
 
 // ---------------------------------------------------------------------------
@@ -121,6 +140,21 @@ JXLT_DI int ceil_log2_nonzero(uint32_t x) {
 }
 JXLT_DI uint32_t pack_signed(int32_t v) {  // common.h:54-58
   return ((uint32_t)v << 1) ^ (((uint32_t)(~v) >> 31) - 1);
+}
+
+// token.h:32-48 (UintCoder::Encode): symbol, number of extra bits, extra bits
+JXLT_DI void hybrid_uint(uint32_t value, uint32_t* sym, uint32_t* nbits, uint32_t* bits) {
+  if (value < 16) {
+    *sym = value;
+    *nbits = 0;
+    *bits = 0;
+  } else {
+    const uint32_t n = 31u - (uint32_t)__clz((int)value);
+    const uint32_t m = value - (1u << n);
+    *sym = (n << 2) + (m >> (n - 2));
+    *nbits = n - 2;
+    *bits = value & ((1u << (n - 2)) - 1);
+  }
 }
 
 // fast_math-inl.h:113-133 + :74-108
@@ -1180,10 +1214,14 @@ constexpr int kTokenThreads = 256;
 __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A) {
   __shared__ uint32_t offs[3072 + 1];
   __shared__ uint32_t wsum[kTokenThreads / 64];
+  __shared__ uint32_t hist[64 * 64];
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const DeviceTables* T = A.tab;
   const int group = (int)blockIdx.x;
+  const bool do_hist = A.histogram != nullptr;
+  if (do_hist)
+    for (int i = tid; i < 64 * 64; i += kTokenThreads) hist[i] = 0;
   const int ggx = group % A.g.xsize_groups, ggy = group / A.g.xsize_groups;
   const int bx0 = ggx * 32, by0 = ggy * 32;
   const int nbx = imin(32, A.g.xsize_blocks - bx0), nby = imin(32, A.g.ysize_blocks - by0);
@@ -1261,9 +1299,15 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
       const int bucket = pred < 8 ? pred : pred >= 64 ? 36 : 4 + pred / 2;
       const int ctx = bucket * 4 + block_ctx;
       uint8_t* o = out + 3 * (size_t)tok0;
-      o[0] = T->ac_context_map[ctx];
+      const uint8_t cm = T->ac_context_map[ctx];
+      o[0] = cm;
       o[1] = (uint8_t)(nzeros & 0xFF);
       o[2] = (uint8_t)(nzeros >> 8);
+      if (do_hist) {
+        uint32_t sym, nb, eb;
+        hybrid_uint((uint32_t)nzeros, &sym, &nb, &eb);
+        atomicAdd(&hist[cm * 64 + sym], 1u);
+      }
     }
     if (nzeros == 0) continue;
     const int histo_offset = 4 * 37 + 458 * block_ctx;
@@ -1288,14 +1332,139 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
         const int ctx = histo_offset + zctx;
         const uint32_t val = pack_signed((int32_t)v);
         uint8_t* o = out + 3 * ((size_t)tok0 + 1 + (k - covered));
-        o[0] = T->ac_context_map[ctx];
+        const uint8_t cm = T->ac_context_map[ctx];
+        o[0] = cm;
         o[1] = (uint8_t)(val & 0xFF);
         o[2] = (uint8_t)((val >> 8) & 0xFF);
+        if (do_hist) {
+          uint32_t sym, nb, eb;
+          hybrid_uint(val & 0xFFFFu, &sym, &nb, &eb);
+          atomicAdd(&hist[cm * 64 + sym], 1u);
+        }
       }
       nz_before += __popcll(m);
       carry_flag = (int)((m >> 63) & 1ull);
     }
   }
+  if (do_hist) {
+    __syncthreads();
+    for (int i = tid; i < 64 * 64; i += kTokenThreads)
+      if (hist[i]) atomicAdd(&A.histogram[i], hist[i]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Section bit packing: one workgroup per section (enc_frame.cc:784-800 with
+// WriteToken, enc_entropy_code.h:34-42).  Tiles of kPackTile records: every
+// thread owns kPackPerThread consecutive records, a block scan of their bit
+// lengths gives its bit offset, bits are OR-ed into an LDS window that is then
+// flushed with coalesced dword stores.
+// ---------------------------------------------------------------------------
+constexpr int kPackThreads = 256;
+constexpr int kPackPerThread = 16;
+constexpr int kPackTile = kPackThreads * kPackPerThread;        // 4096 records
+constexpr int kPackWindowWords = kPackTile * 28 / 32 + 4;        // <= 28 bits per record
+
+__global__ void __launch_bounds__(kPackThreads) pack_kernel(const PackArgs A) {
+  __shared__ uint32_t table[64 * 64];
+  __shared__ uint32_t window[kPackWindowWords];
+  __shared__ uint32_t scan[kPackThreads];
+  __shared__ uint8_t bytes[kPackTile * 3 + 8];
+  const int tid = (int)threadIdx.x;
+  const int sec = (int)blockIdx.x;
+  for (int i = tid; i < 64 * 64; i += kPackThreads) table[i] = A.code_table[i];
+  const uint64_t rec0 = A.sec_rec_offset[sec], rec1 = A.sec_rec_offset[sec + 1];
+  const uint8_t* src = A.records + 3 * rec0;
+  uint32_t* dst = reinterpret_cast<uint32_t*>(A.slots + 4 * rec0);
+  uint64_t total_bits = 0;     // bits of all completed tiles
+  uint32_t carry = 0;          // partial last word of the previous tile
+  uint64_t words_out = 0;      // complete words already stored
+  for (uint64_t t0 = 0; t0 < rec1 - rec0; t0 += kPackTile) {
+    const int n = (int)((rec1 - rec0 - t0) < (uint64_t)kPackTile ? (rec1 - rec0 - t0) : (uint64_t)kPackTile);
+    __syncthreads();  // previous tile fully flushed; table loaded
+    for (int i = tid; i < n * 3; i += kPackThreads) bytes[i] = src[3 * t0 + i];
+    for (int i = tid; i < kPackWindowWords; i += kPackThreads) window[i] = (i == 0) ? carry : 0u;
+    __syncthreads();
+    // pass 1: bit length of this thread's records
+    uint32_t nb[kPackPerThread];
+    uint32_t data[kPackPerThread];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < kPackPerThread; j++) {
+      const int r = tid * kPackPerThread + j;
+      nb[j] = 0;
+      data[j] = 0;
+      if (r < n) {
+        const uint32_t ctx = bytes[3 * r];
+        const uint32_t value = (uint32_t)bytes[3 * r + 1] | ((uint32_t)bytes[3 * r + 2] << 8);
+        if (ctx >= 128) {
+          nb[j] = ctx - 128;
+          data[j] = value;
+        } else {
+          uint32_t sym, nbits, extra;
+          hybrid_uint(value, &sym, &nbits, &extra);
+          const uint32_t e = table[ctx * 64 + sym];
+          const uint32_t depth = e >> 16;
+          nb[j] = depth + nbits;
+          data[j] = (e & 0xFFFFu) | (extra << depth);
+        }
+        mine += nb[j];
+      }
+    }
+    scan[tid] = mine;
+    __syncthreads();
+    for (int sft = 1; sft < kPackThreads; sft <<= 1) {
+      const uint32_t add = tid >= sft ? scan[tid - sft] : 0;
+      __syncthreads();
+      scan[tid] += add;
+      __syncthreads();
+    }
+    const uint32_t tile_bits = scan[kPackThreads - 1];
+    // bit position inside the window: the window starts at the last incomplete word
+    const uint32_t lead = (uint32_t)(total_bits & 31u);
+    uint32_t pos = lead + scan[tid] - mine;
+    // pass 2: OR the bits into the window
+    {
+      uint32_t w = pos >> 5;
+      uint32_t fill = pos & 31u;
+      unsigned long long acc = 0;
+#pragma unroll
+      for (int j = 0; j < kPackPerThread; j++) {
+        acc |= (unsigned long long)data[j] << fill;
+        fill += nb[j];
+        if (fill >= 32) {
+          atomicOr(&window[w], (uint32_t)acc);
+          acc >>= 32;
+          fill -= 32;
+          w++;
+        }
+      }
+      if (fill) atomicOr(&window[w], (uint32_t)acc);
+    }
+    __syncthreads();
+    const uint32_t end_bits = lead + tile_bits;
+    const uint32_t full_words = end_bits >> 5;
+    for (uint32_t i = tid; i < full_words; i += kPackThreads) dst[words_out + i] = window[i];
+    const uint32_t next_carry = (end_bits & 31u) ? window[full_words] : 0u;
+    __syncthreads();
+    carry = next_carry;
+    words_out += full_words;
+    total_bits += tile_bits;
+  }
+  if (tid == 0) {
+    if (total_bits & 31u) dst[words_out] = carry;
+    A.sec_bits[sec] = (uint32_t)total_bits;
+    A.sec_bytes[sec] = (uint32_t)((total_bits + 7) >> 3);
+  }
+}
+
+// Gathers the packed sections into one contiguous byte stream.
+__global__ void __launch_bounds__(256) compact_kernel(const CompactArgs A) {
+  const int sec = (int)blockIdx.x;
+  const uint8_t* src = A.slots + 4 * A.sec_rec_offset[sec];
+  uint8_t* dst = A.out + A.sec_byte_offset[sec];
+  const uint32_t n = A.sec_bytes[sec];
+  for (uint32_t i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
 }
 
 }  // namespace jxlt_dev

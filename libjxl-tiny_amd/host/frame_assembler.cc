@@ -323,12 +323,11 @@ void WriteACGlobal(size_t num_groups, const EntropyCode& ac_code, jxl::BitWriter
   WriteEntropyCode(ac_code, writer);
 }
 
-bool WriteTOC(const std::vector<jxl::BitWriter>& sections, jxl::BitWriter* output) {
+bool WriteTOCSizes(const std::vector<size_t>& section_sizes, jxl::BitWriter* output) {
   // enc_frame.cc:572-595
   output->Write(1, 0);  // no permutation
   output->ZeroPadToByte();
-  for (const jxl::BitWriter& s : sections) {
-    const size_t section_size = DivCeil(s.BitsWritten(), 8);
+  for (const size_t section_size : section_sizes) {
     if (section_size >= (1u << 22)) return false;
     size_t offset = 0;
     static const size_t kBits[4] = {10, 14, 22, 30};
@@ -343,6 +342,13 @@ bool WriteTOC(const std::vector<jxl::BitWriter>& sections, jxl::BitWriter* outpu
   }
   output->ZeroPadToByte();
   return true;
+}
+
+bool WriteTOC(const std::vector<jxl::BitWriter>& sections, jxl::BitWriter* output) {
+  std::vector<size_t> sizes;
+  sizes.reserve(sections.size());
+  for (const jxl::BitWriter& s : sections) sizes.push_back(DivCeil(s.BitsWritten(), 8));
+  return WriteTOCSizes(sizes, output);
 }
 
 }  // namespace
@@ -374,6 +380,69 @@ DistanceParams ComputeDistanceParams(float distance) {  // enc_frame.cc:115-156
   for (size_t i = 0; i < 3; i++)
     if (distance >= kEpfThresholds[i]) p.epf_iters++;
   return p;
+}
+
+void BuildDcSections(const FrameView& f, int num_threads, EntropyCode* dc_code,
+                     std::vector<jxl::BitWriter>* dc_sections) {
+  const size_t xsize_blocks = DivCeil(f.xsize, 8);
+  const size_t xsize_tiles = DivCeil(f.xsize, 64);
+  const size_t xsize_dc_groups = DivCeil(f.xsize, 2048), ysize_dc_groups = DivCeil(f.ysize, 2048);
+  const size_t num_dc_groups = xsize_dc_groups * ysize_dc_groups;
+  std::vector<RawSection> dc_raw(num_dc_groups);
+  ParallelFor(num_dc_groups, num_threads, [&](size_t i, int) {
+    DCGroupSection(f, xsize_blocks, xsize_tiles, i % xsize_dc_groups, i / xsize_dc_groups, &dc_raw[i]);
+  });
+  uint8_t dc_identity[kNumDCContexts];
+  for (size_t i = 0; i < kNumDCContexts; ++i) dc_identity[i] = static_cast<uint8_t>(i);
+  OptimizeSections(dc_raw, kNumDCContexts, dc_identity, kNumDCContexts, dc_code, dc_sections, num_threads);
+}
+
+void BuildAcCode(const uint32_t* histograms, EntropyCode* ac_code) {
+  std::vector<Histogram> h(kNumACPreClusters);
+  for (size_t c = 0; c < kNumACPreClusters; ++c)
+    for (size_t s = 0; s < kAlphabetSize; ++s) {
+      h[c].counts[s] = histograms[c * kAlphabetSize + s];
+      h[c].total_count += histograms[c * kAlphabetSize + s];
+    }
+  OptimizeEntropyCode(&h, JXLT_kACContextMap, kNumACContexts, ac_code);
+}
+
+void FillCodeTable(const EntropyCode& code, uint32_t* table) {
+  for (size_t c = 0; c < 64; ++c) {
+    for (size_t s = 0; s < kAlphabetSize; ++s) {
+      uint32_t e = 0;
+      if (c < code.context_map.size()) {
+        const PrefixCode& pc = code.prefix_codes[code.context_map[c]];
+        e = (static_cast<uint32_t>(pc.depths[s]) << 16) | pc.bits[s];
+      }
+      table[c * kAlphabetSize + s] = e;
+    }
+  }
+}
+
+bool FinishFrame(const FrameView& f, const DistanceParams& distp, const EntropyCode& dc_code,
+                 std::vector<jxl::BitWriter>* dc_sections, const EntropyCode& ac_code,
+                 const PackedSections& ac, jxl::BitWriter* writer) {
+  const size_t num_groups = DivCeil(f.xsize, 256) * DivCeil(f.ysize, 256);
+  const size_t num_dc_groups = DivCeil(f.xsize, 2048) * DivCeil(f.ysize, 2048);
+  if (ac.n != num_groups || dc_sections->size() != num_dc_groups || 2 + num_dc_groups + num_groups == 4)
+    return false;
+  std::vector<jxl::BitWriter> head;
+  head.reserve(2 + num_dc_groups);
+  head.emplace_back();
+  WriteDCGlobal(distp, num_dc_groups, dc_code, &head.back());
+  for (auto& s : *dc_sections) head.push_back(std::move(s));
+  head.emplace_back();
+  WriteACGlobal(num_groups, ac_code, &head.back());
+  std::vector<size_t> sizes;
+  sizes.reserve(head.size() + num_groups);
+  for (const jxl::BitWriter& s : head) sizes.push_back(DivCeil(s.BitsWritten(), 8));
+  for (size_t g = 0; g < num_groups; ++g) sizes.push_back(static_cast<size_t>(ac.offset[g + 1] - ac.offset[g]));
+  WriteFrameHeader(distp.x_qm_scale, distp.epf_iters, writer);
+  if (!WriteTOCSizes(sizes, writer)) return false;
+  writer->AppendByteAligned(&head);
+  writer->AppendBytes(ac.bytes, static_cast<size_t>(ac.offset[num_groups]));
+  return true;
 }
 
 bool AssembleFrame(const FrameView& f, const DistanceParams& distp, jxl::BitWriter* writer,

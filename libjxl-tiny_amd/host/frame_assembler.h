@@ -12,7 +12,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "encoder/enc_bit_writer.h"
+#include "entropy_coder.h"
 
 namespace jxlt {
 
@@ -42,6 +45,27 @@ struct FrameView {
   const uint8_t* const* group_tokens;
   const size_t* group_token_bytes;
 };
+
+// ---- production path: AC sections entropy-coded on the device -----------------
+// DC-group tokenisation + code optimisation + section encoding (host).
+void BuildDcSections(const FrameView& frame, int num_threads, EntropyCode* dc_code,
+                     std::vector<jxl::BitWriter>* dc_sections);
+// AC prefix codes from the device's [64][64] symbol histograms (enc_frame.cc:783 onwards).
+void BuildAcCode(const uint32_t* histograms, EntropyCode* ac_code);
+// table[ctx * 64 + sym] = (depth << 16) | bits for pre-clustered context ctx.
+void FillCodeTable(const EntropyCode& code, uint32_t* table);
+struct PackedSections {
+  const uint8_t* bytes;
+  const uint64_t* offset;  // [n + 1]
+  const uint32_t* bits;    // [n]
+  size_t n;
+};
+// Frame header + TOC + DCGlobal + DC groups + ACGlobal + packed AC groups.
+// Not valid for single-group frames (their sections are bit-concatenated,
+// enc_frame.cc:805-811): use AssembleFrame there.
+bool FinishFrame(const FrameView& frame, const DistanceParams& distp, const EntropyCode& dc_code,
+                 std::vector<jxl::BitWriter>* dc_sections, const EntropyCode& ac_code,
+                 const PackedSections& ac, jxl::BitWriter* writer);
 
 // Appends frame header + TOC + all sections to `writer` (must be byte aligned).
 // num_threads <= 0 selects std::thread::hardware_concurrency().

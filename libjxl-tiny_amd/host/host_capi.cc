@@ -107,6 +107,19 @@ int jxlt_encode_file_planar(const float* const planes[3], size_t pitch_bytes, si
   return ToMalloc(out, out_bytes, out_size);
 }
 
+int jxlt_encode_resident(jxlt_context* ctx, float distance, int num_threads, uint8_t** out_bytes,
+                         size_t* out_size) {
+  if (!ctx || !out_bytes || !out_size) return JXLT_ERR_INVALID_ARGUMENT;
+  if (!jxlt::NormalizeDistance(&distance)) return JXLT_ERR_INVALID_ARGUMENT;
+  jxl::BitWriter writer;
+  // The context knows the image size; the header needs it, so ask the device path first.
+  size_t xsize = 0, ysize = 0;
+  if (jxlt_image_size(ctx, &xsize, &ysize) != JXLT_OK) return JXLT_ERR_INVALID_ARGUMENT;
+  if (!jxlt::WriteFileHeader(xsize, ysize, &writer)) return JXLT_ERR_INVALID_ARGUMENT;
+  if (!jxlt::EncodeFrameOnContext(ctx, distance, num_threads, &writer)) return JXLT_ERR_INTERNAL;
+  return ToMalloc(writer.TakeBytes(), out_bytes, out_size);
+}
+
 void jxlt_free(void* p) { free(p); }
 
 }  // extern "C"

@@ -6,7 +6,10 @@
 
 #include "encoder/enc_bit_writer.h"
 
+struct jxlt_context;
+
 namespace jxlt {
+bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jxl::BitWriter* writer);
 bool WriteFileHeader(size_t xsize, size_t ysize, jxl::BitWriter* writer);
 bool NormalizeDistance(float* distance);
 }  // namespace jxlt

@@ -273,6 +273,12 @@ inline long long clock64() { return 0; }
 
 // One workgroup runs at a time and fibers never preempt: plain RMW is atomic.
 template <typename T>
+inline T atomicOr(T* p, T v) {
+  T old = *p;
+  *p = old | v;
+  return old;
+}
+template <typename T>
 inline T atomicAdd(T* p, T v) {
   T old = *p;
   *p = old + v;

@@ -25,6 +25,7 @@ struct sim_result {
   float* qf;
   float* mask;
   float* ent8;
+  uint32_t* histogram;  // [64*64]
 };
 
 __attribute__((visibility("default"))) int sim_encode(const float* const planes[3], size_t pitch_floats, size_t xsize, size_t ysize,
@@ -91,6 +92,7 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   K.coef_scan = A.coef_scan;
   K.group_tok_offset = r->group_tok_offset;
   K.tokens = r->tokens;
+  K.histogram = r->histogram = (uint32_t*)calloc(64 * 64, 4);
   hipsim::launch(token_kernel, dim3((unsigned)ngroups), dim3(kTokenThreads), K);
 
   for (int c = 0; c < 3; c++) free(A.nzgrid[c]);
@@ -116,7 +118,35 @@ __attribute__((visibility("default"))) void sim_free(sim_result* r) {
   free(r->qf);
   free(r->mask);
   free(r->ent8);
+  free(r->histogram);
   memset(r, 0, sizeof(*r));
+}
+
+// Runs pack_kernel + group_scan_kernel + compact_kernel over `nsec` sections of 3-byte records.
+// out_bytes must hold 4 * total_records + 16 bytes; out_offset [nsec+1]; out_bits [nsec].
+__attribute__((visibility("default"))) int sim_pack(const uint8_t* records, const uint64_t* sec_rec_offset,
+                                                     int nsec, const uint32_t* code_table, uint8_t* out_bytes,
+                                                     uint64_t* out_offset, uint32_t* out_bits) {
+  const uint64_t total = sec_rec_offset[nsec];
+  std::vector<uint8_t> slots(4 * total + 16, 0xCD);  // poison: every output byte must be written
+  std::vector<uint32_t> sec_bytes(nsec);
+  PackArgs P;
+  P.records = records;
+  P.sec_rec_offset = sec_rec_offset;
+  P.code_table = code_table;
+  P.slots = slots.data();
+  P.sec_bits = out_bits;
+  P.sec_bytes = sec_bytes.data();
+  hipsim::launch(pack_kernel, dim3((unsigned)nsec), dim3(kPackThreads), P);
+  hipsim::launch(group_scan_kernel, dim3(1), dim3(256), (const uint32_t*)sec_bytes.data(), out_offset, nsec);
+  CompactArgs Cp;
+  Cp.slots = slots.data();
+  Cp.sec_rec_offset = sec_rec_offset;
+  Cp.sec_bytes = sec_bytes.data();
+  Cp.sec_byte_offset = out_offset;
+  Cp.out = out_bytes;
+  hipsim::launch(compact_kernel, dim3((unsigned)nsec), dim3(256), Cp);
+  return 0;
 }
 
 }  // extern "C"

@@ -97,7 +97,7 @@ def _np(ptr, shape, dtype):
 class HotPathResult:
     """Plain numpy view of one hot-path run (oracle, simulator or GPU)."""
     __slots__ = ("quant_dc", "raw_quant", "strategy", "ytox", "ytob", "group_tokens",
-                 "xyb", "qf", "mask", "ent8", "xsize", "ysize")
+                 "xyb", "qf", "mask", "ent8", "xsize", "ysize", "histogram")
 
     def all_tokens(self):
         return b"".join(self.group_tokens)
@@ -170,20 +170,85 @@ class SimResult(C.Structure):
                 ("strategy", C.POINTER(C.c_uint8)), ("ytox", C.POINTER(C.c_int8)),
                 ("ytob", C.POINTER(C.c_int8)), ("tokens", C.POINTER(C.c_uint8)),
                 ("group_tok_offset", C.POINTER(C.c_uint64)),
-                ("xyb", fp * 3), ("qf", fp), ("mask", fp), ("ent8", fp)]
+                ("xyb", fp * 3), ("qf", fp), ("mask", fp), ("ent8", fp),
+                ("histogram", C.POINTER(C.c_uint32))]
 
 
 _sim = None
 
 
-def sim_hot_path(planes, distance, force_dct8=False):
-    """Runs the product's HIP kernels on the CPU execution model (tests only)."""
+def _sim_lib():
     global _sim
     if _sim is None:
         _sim = C.CDLL(str(build_sim()))
         _sim.sim_encode.argtypes = [C.POINTER(fp), C.c_size_t, C.c_size_t, C.c_size_t, C.c_float,
                                     C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
                                     C.POINTER(SimResult)]
+        _sim.sim_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]
+    return _sim
+
+
+def hybrid_uint(value):
+    """token.h:32-48 -> (symbol, nbits, extra bits)."""
+    if value < 16:
+        return value, 0, 0
+    n = value.bit_length() - 1
+    m = value - (1 << n)
+    return (n << 2) + (m >> (n - 2)), n - 2, value & ((1 << (n - 2)) - 1)
+
+
+def token_histogram(token_bytes):
+    """[64][64] counts of (pre-clustered context, hybrid-uint symbol) of raw 3-byte records."""
+    h = np.zeros((64, 64), np.uint32)
+    a = np.frombuffer(token_bytes, np.uint8).reshape(-1, 3)
+    for ctx, lo, hi in a:
+        if ctx < 128:
+            h[ctx, hybrid_uint(int(lo) | (int(hi) << 8))[0]] += 1
+    return h
+
+
+def pack_sections_python(sections, table):
+    """Reference bit packer (enc_frame.cc:784-800): list of record bytes -> list of (bytes, nbits)."""
+    out = []
+    for rec in sections:
+        acc, nbits = 0, 0
+        a = np.frombuffer(rec, np.uint8).reshape(-1, 3)
+        for ctx, lo, hi in a:
+            value = int(lo) | (int(hi) << 8)
+            if ctx >= 128:
+                n, data = int(ctx) - 128, value
+            else:
+                sym, nb, extra = hybrid_uint(value)
+                e = int(table[int(ctx) * 64 + sym])
+                depth = e >> 16
+                n, data = depth + nb, (e & 0xFFFF) | (extra << depth)
+            acc |= data << nbits
+            nbits += n
+        out.append((acc.to_bytes((nbits + 7) // 8, "little"), nbits))
+    return out
+
+
+def sim_pack_sections(sections, table):
+    """pack_kernel + scan + compact on the CPU execution model."""
+    L = _sim_lib()
+    blob = np.frombuffer(b"".join(sections) + b"\0\0\0\0", np.uint8).copy()
+    offs = np.zeros(len(sections) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(x) // 3 for x in sections])
+    table = np.ascontiguousarray(table, np.uint32)
+    out = np.zeros(4 * int(offs[-1]) + 16, np.uint8)
+    out_off = np.zeros(len(sections) + 1, np.uint64)
+    out_bits = np.zeros(len(sections), np.uint32)
+    L.sim_pack(blob.ctypes.data, offs.ctypes.data, len(sections), table.ctypes.data, out.ctypes.data,
+               out_off.ctypes.data, out_bits.ctypes.data)
+    return [(out[int(out_off[i]):int(out_off[i + 1])].tobytes(), int(out_bits[i])) for i in range(len(sections))]
+
+
+def sim_hot_path(planes, distance, force_dct8=False):
+    """Runs the product's HIP kernels on the CPU execution model (tests only)."""
+    _sim = _sim_lib()
+    if False:
+        pass
     _, h, w = planes.shape
     p = distance_params(distance)
     s = SimResult()
@@ -205,6 +270,7 @@ def sim_hot_path(planes, distance, force_dct8=False):
     r.qf = _np(s.qf, (yb, xb), np.float32)
     r.mask = _np(s.mask, (yb, xb), np.float32)
     r.ent8 = _np(s.ent8, (yb // 2 + 1, xb // 2 + 1, 8), np.float32)
+    r.histogram = _np(s.histogram, (64, 64), np.uint32)
     _sim.sim_free(C.byref(s))
     return r
 

@@ -130,3 +130,15 @@ def test_device_resident_entry_point(built, enc):
     enc.set_device_image([t[c].data_ptr() for c in range(3)], 256 * 4, w, h, keepalive=t)
     jxl = enc.encode_resident(1.0)
     assert jxl == T.assemble_codestream(T.oracle_hot_path(planes, 1.0), 1.0)
+
+
+@pytest.mark.parametrize("w,h,distance", [(700, 520, 1.0), (2100, 300, 2.0), (256, 256, 1.0), (1030, 1030, 0.5)])
+def test_device_packed_sections_equal_host_packed(built, enc, w, h, distance):
+    """Production route (symbol histograms + section bit packing on the device) vs the
+    raw-token route (tokens copied to the host, packed by the host back-end) vs the oracle."""
+    planes = T.to_planes(T.synthetic_image(w, h, hard=(w == 700)))
+    enc.upload(planes)
+    a = enc.encode_resident(distance)
+    b = enc.encode_resident_raw_tokens(distance)
+    assert a == b
+    assert a == T.assemble_codestream(T.oracle_hot_path(planes, distance), distance)

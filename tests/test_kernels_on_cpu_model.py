@@ -29,3 +29,37 @@ def test_kernels_match_oracle_bit_exact(built, w, h, distance, hard, dct8):
     want = T.oracle_hot_path(planes, distance, dct8)
     got = T.sim_hot_path(planes, distance, dct8)
     assert T.compare_results(want, got, "oracle", "kernels") == []
+
+
+def test_token_kernel_histogram_matches_tokens(built):
+    planes = T.to_planes(T.synthetic_image(300, 264))
+    got = T.sim_hot_path(planes, 1.0)
+    want = T.token_histogram(got.all_tokens())
+    assert (got.histogram == want).all()
+    assert int(got.histogram.sum()) == len(got.all_tokens()) // 3
+
+
+def _random_code_table(rng):
+    """A valid-looking table: arbitrary depths 1..15 and bit patterns below 2^depth."""
+    depth = rng.integers(1, 16, size=64 * 64)
+    bits = rng.integers(0, 1 << 15, size=64 * 64) & ((1 << depth) - 1)
+    return ((depth << 16) | bits).astype("uint32")
+
+
+@pytest.mark.parametrize("sizes", [[0], [1], [5, 0, 17], [4095, 4096, 4097], [9000, 3], [300] * 7])
+def test_pack_kernel_matches_reference_packer(built, sizes):
+    import numpy as np
+    rng = np.random.default_rng(sum(sizes) + len(sizes))
+    table = _random_code_table(rng)
+    sections = []
+    for n in sizes:
+        ctx = rng.integers(0, 64, size=n).astype(np.uint8)
+        # mix of small values, large values and raw-bit escapes (ctx >= 128)
+        val = np.where(rng.random(n) < 0.8, rng.integers(0, 20, size=n), rng.integers(0, 65536, size=n))
+        esc = rng.random(n) < 0.02
+        nb = rng.integers(1, 17, size=n)
+        ctx = np.where(esc, 128 + nb, ctx).astype(np.uint8)
+        val = np.where(esc, val & ((1 << nb) - 1), val).astype(np.uint16)
+        rec = np.stack([ctx, (val & 0xFF).astype(np.uint8), (val >> 8).astype(np.uint8)], axis=1)
+        sections.append(rec.astype(np.uint8).tobytes())
+    assert T.sim_pack_sections(sections, table) == T.pack_sections_python(sections, table)
