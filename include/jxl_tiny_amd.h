@@ -125,6 +125,13 @@ typedef struct {
 } jxlt_packed_sections;
 int jxlt_fetch_side_info(jxlt_context* ctx, jxlt_frame_result* out, const uint32_t** ac_histograms);
 int jxlt_pack_ac_sections(jxlt_context* ctx, const uint32_t* code_table, jxlt_packed_sections* out);
+/* Leanest form: only the two [64][64] symbol histograms leave the device -- AC
+ * (pre-clustered contexts, static_entropy_codes.h:165) and DC (the 45 DC/metadata
+ * contexts of WriteDCTokens/WriteACMetadataTokens, enc_frame.cc:287-424, which the
+ * device tokenises too).  jxlt_pack_sections(kind): 0 = DC-group sections (the
+ * raw-record form of WriteDCGroup, enc_frame.cc:536-570), 1 = AC-group sections. */
+int jxlt_fetch_histograms(jxlt_context* ctx, const uint32_t** ac_histograms, const uint32_t** dc_histograms);
+int jxlt_pack_sections(jxlt_context* ctx, int kind, const uint32_t* code_table, jxlt_packed_sections* out);
 
 /* Timing of the kernels of the last jxlt_encode_enqueue (needs JXLT_FLAG_PROFILE):
  * writes up to `cap` entries; returns the number of kernels, or < 0. */
@@ -171,6 +178,10 @@ int jxlt_encode_file_planar(const float* const planes[3], size_t pitch_bytes, si
                             uint8_t** out_bytes, size_t* out_size);
 /* Codestream + image headers that precede the frame (enc_file.cc:70-95). */
 int jxlt_write_file_header(size_t xsize, size_t ysize, uint8_t** out_bytes, size_t* out_size);
+/* Test hook: the raw 3-byte records of DC group `dc_group_index` exactly as the host
+ * tokeniser (WriteDCGroup in raw-record form, enc_frame.cc:536-570) produces them. */
+int jxlt_debug_dc_records(const jxlt_frame_result* frame, size_t dc_group_index, uint8_t** out_bytes,
+                          size_t* out_size);
 void jxlt_free(void* p);
 
 #ifdef __cplusplus

@@ -30,10 +30,10 @@ FLAG_FORCE_DCT8, FLAG_DEBUG_DUMP, FLAG_PROFILE = 1, 2, 4
 # Symbols include/jxl_tiny_amd.h declares, per library (checked by the tests).
 HIP_SYMBOLS = ["jxlt_context_create", "jxlt_context_destroy", "jxlt_last_error",
                "jxlt_image_upload", "jxlt_image_set_device", "jxlt_image_size", "jxlt_encode_enqueue",
-               "jxlt_fetch_side_info", "jxlt_pack_ac_sections",
+               "jxlt_fetch_side_info", "jxlt_fetch_histograms", "jxlt_pack_ac_sections", "jxlt_pack_sections",
                "jxlt_synchronize", "jxlt_fetch_result", "jxlt_kernel_times", "jxlt_debug_fetch"]
 HOST_SYMBOLS = ["jxlt_compute_distance_params", "jxlt_assemble_frame", "jxlt_assemble_frame_groups",
-                "jxlt_encode_file_planar", "jxlt_encode_resident", "jxlt_write_file_header", "jxlt_free"]
+                "jxlt_encode_file_planar", "jxlt_encode_resident", "jxlt_write_file_header", "jxlt_debug_dc_records", "jxlt_free"]
 
 
 class JxlTinyError(RuntimeError):
@@ -131,6 +131,8 @@ def host_lib():
                                            C.POINTER(C.c_size_t)]
         L.jxlt_write_file_header.argtypes = [C.c_size_t, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)),
                                              C.POINTER(C.c_size_t)]
+        L.jxlt_debug_dc_records.argtypes = [C.POINTER(FrameResult), C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)),
+                                            C.POINTER(C.c_size_t)]
         L.jxlt_free.argtypes = [C.c_void_p]
         L.jxlt_free.restype = None
         _host = L

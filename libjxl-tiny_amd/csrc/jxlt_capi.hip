@@ -63,25 +63,36 @@ struct jxlt_context {
   DeviceBuf<uint64_t> group_off;
   DeviceBuf<float> dbg_xyb[3], dbg_qf, dbg_mask, dbg_ent8;
   DeviceBuf<unsigned long long> dbg_phase;
-  DeviceBuf<uint32_t> hist, code_table, sec_bits, sec_bytes;
-  DeviceBuf<uint64_t> sec_byte_off;
-  DeviceBuf<uint8_t> slots, packed;
+  DeviceBuf<uint32_t> hist;  // [0,4096): AC, [4096,8192): DC symbol histograms
+  // DC-group record streams (fixed stride per DC group)
+  DeviceBuf<uint8_t> dc_records;
+  DeviceBuf<uint32_t> dc_nac, dc_count;
+  DeviceBuf<uint64_t> dc_rec_off;
+  size_t dc_rec_off_n = 0;
+  // section packing, [0] = DC groups, [1] = AC groups
+  struct PackSet {
+    DeviceBuf<uint32_t> code_table, sec_bits, sec_bytes;
+    DeviceBuf<uint64_t> sec_byte_off;
+    DeviceBuf<uint8_t> slots, packed;
+    PinnedBuf<uint64_t> h_sec_byte_off;
+    PinnedBuf<uint32_t> h_sec_bits;
+    PinnedBuf<uint8_t> h_packed;
+  } pack[2];
 
   // pinned host mirrors
   PinnedBuf<int16_t> h_quant_dc[3];
   PinnedBuf<uint8_t> h_raw_quant, h_strategy, h_tokens;
   PinnedBuf<int8_t> h_ytox, h_ytob;
-  PinnedBuf<uint64_t> h_group_off, h_sec_byte_off;
-  PinnedBuf<uint32_t> h_hist, h_sec_bits;
-  PinnedBuf<uint8_t> h_packed;
-  bool side_info_fetched = false;
+  PinnedBuf<uint64_t> h_group_off;
+  PinnedBuf<uint32_t> h_hist;
+  bool offsets_fetched = false;
 
   FrameGeom geom = {};
   bool encoded = false;
   uint32_t last_flags = 0;
 
   // profiling
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool profiled = false;
 };
 
@@ -206,16 +217,22 @@ void jxlt_context_destroy(jxlt_context* ctx) {
   FreeDevice(&ctx->dbg_ent8);
   FreeDevice(&ctx->dbg_phase);
   FreeDevice(&ctx->hist);
-  FreeDevice(&ctx->code_table);
-  FreeDevice(&ctx->sec_bits);
-  FreeDevice(&ctx->sec_bytes);
-  FreeDevice(&ctx->sec_byte_off);
-  FreeDevice(&ctx->slots);
-  FreeDevice(&ctx->packed);
-  FreePinned(&ctx->h_sec_byte_off);
+  FreeDevice(&ctx->dc_records);
+  FreeDevice(&ctx->dc_nac);
+  FreeDevice(&ctx->dc_count);
+  FreeDevice(&ctx->dc_rec_off);
   FreePinned(&ctx->h_hist);
-  FreePinned(&ctx->h_sec_bits);
-  FreePinned(&ctx->h_packed);
+  for (auto& ps : ctx->pack) {
+    FreeDevice(&ps.code_table);
+    FreeDevice(&ps.sec_bits);
+    FreeDevice(&ps.sec_bytes);
+    FreeDevice(&ps.sec_byte_off);
+    FreeDevice(&ps.slots);
+    FreeDevice(&ps.packed);
+    FreePinned(&ps.h_sec_byte_off);
+    FreePinned(&ps.h_sec_bits);
+    FreePinned(&ps.h_packed);
+  }
   FreePinned(&ctx->h_raw_quant);
   FreePinned(&ctx->h_strategy);
   FreePinned(&ctx->h_tokens);
@@ -306,7 +323,20 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   ENSURE(coef_scan, nblocks * 3 * 64);
   ENSURE(group_ntok, ngroups);
   ENSURE(group_off, ngroups + 1);
-  ENSURE(hist, 64 * 64);
+  ENSURE(hist, 2 * 64 * 64);
+  const size_t ndc = ((ctx->xsize + 2047) / 2048) * ((ctx->ysize + 2047) / 2048);
+  // records per DC group, worst case: 2 + 3nb + 2nt + 2nb + nb with nb = 65536, nt = 1024
+  const size_t kDcStride = 6 * 65536 + 2 * 1024 + 8;
+  ENSURE(dc_records, ndc * kDcStride * 3);
+  ENSURE(dc_nac, ndc);
+  ENSURE(dc_count, ndc);
+  ENSURE(dc_rec_off, ndc + 1);
+  if (ctx->dc_rec_off_n != ndc) {
+    std::vector<uint64_t> off(ndc + 1);
+    for (size_t i = 0; i <= ndc; i++) off[i] = i * kDcStride;
+    HIP_TRY(ctx, hipMemcpy(ctx->dc_rec_off.p, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    ctx->dc_rec_off_n = ndc;
+  }
   // worst case: every coefficient of every block is a token, plus one nzeros token
   ENSURE(tokens, nblocks * 3 * 64 * 3);
   const size_t ncells = ((size_t)g.xsize_blocks / 2 + 1) * ((size_t)g.ysize_blocks / 2 + 1);
@@ -357,6 +387,7 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   A.blk_nscan = ctx->blk_nscan.p;
   A.coef_scan = ctx->coef_scan.p;
   A.group_ntok = ctx->group_ntok.p;
+  A.dc_nac = ctx->dc_nac.p;
   A.dbg_qf = debug ? ctx->dbg_qf.p : nullptr;
   A.dbg_mask = debug ? ctx->dbg_mask.p : nullptr;
   A.dbg_ent8 = debug ? ctx->dbg_ent8.p : nullptr;
@@ -376,7 +407,8 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   K.histogram = ctx->hist.p;
 
   HIP_TRY(ctx, hipMemsetAsync(ctx->group_ntok.p, 0, ngroups * sizeof(uint32_t), ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->hist.p, 0, 64 * 64 * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->hist.p, 0, 2 * 64 * 64 * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->dc_nac.p, 0, ndc * sizeof(uint32_t), ctx->stream));
   if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   hipLaunchKernelGGL(tile_kernel, dim3((unsigned)ntiles), dim3(kTileThreads), 0, ctx->stream, A);
   if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
@@ -385,10 +417,29 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
   hipLaunchKernelGGL(token_kernel, dim3((unsigned)ngroups), dim3(kTokenThreads), 0, ctx->stream, K);
   if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+  {
+    DcArgs D;
+    memset(&D, 0, sizeof(D));
+    D.g = g;
+    D.tab = ctx->d_tab;
+    for (int c = 0; c < 3; c++) D.quant_dc[c] = ctx->quant_dc[c].p;
+    D.raw_quant = ctx->raw_quant.p;
+    D.strategy = ctx->strategy.p;
+    D.ytox = ctx->ytox.p;
+    D.ytob = ctx->ytob.p;
+    D.dc_nac = ctx->dc_nac.p;
+    D.dc_rec_offset = ctx->dc_rec_off.p;
+    D.records = ctx->dc_records.p;
+    D.dc_count = ctx->dc_count.p;
+    D.histogram = ctx->hist.p + 64 * 64;
+    hipLaunchKernelGGL(dc_elementwise_kernel, dim3((unsigned)(ndc * kDcParts)), dim3(256), 0, ctx->stream, D);
+    hipLaunchKernelGGL(dc_chain_kernel, dim3((unsigned)ndc), dim3(kDcChainThreads), 0, ctx->stream, D);
+  }
+  if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
   HIP_TRY(ctx, hipGetLastError());
   ctx->geom = g;
   ctx->encoded = true;
-  ctx->side_info_fetched = false;
+  ctx->offsets_fetched = false;
   ctx->last_flags = params->flags;
   ctx->profiled = profile;
   return JXLT_OK;
@@ -419,11 +470,11 @@ int FetchSideInfo(jxlt_context* ctx, jxlt_frame_result* out) {
   ENSUREH(h_ytox, ntiles);
   ENSUREH(h_ytob, ntiles);
   ENSUREH(h_group_off, 2 * (ngroups + 1));  // [0, n]: tokens, [n+1, 2n+1]: bytes
-  ENSUREH(h_hist, 64 * 64);
+  ENSUREH(h_hist, 2 * 64 * 64);
 #undef ENSUREH
 #define D2H(dst, src, bytes) HIP_TRY(ctx, hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, ctx->stream))
   D2H(ctx->h_group_off.p, ctx->group_off.p, (ngroups + 1) * sizeof(uint64_t));
-  D2H(ctx->h_hist.p, ctx->hist.p, 64 * 64 * sizeof(uint32_t));
+  D2H(ctx->h_hist.p, ctx->hist.p, 2 * 64 * 64 * sizeof(uint32_t));
   for (int c = 0; c < 3; c++) D2H(ctx->h_quant_dc[c].p, ctx->quant_dc[c].p, nblocks * sizeof(int16_t));
   D2H(ctx->h_raw_quant.p, ctx->raw_quant.p, nblocks);
   D2H(ctx->h_strategy.p, ctx->strategy.p, nblocks);
@@ -451,7 +502,7 @@ int FetchSideInfo(jxlt_context* ctx, jxlt_frame_result* out) {
   out->ytob_map = ctx->h_ytob.p;
   out->tokens = nullptr;
   out->group_token_offset = byte_off;
-  ctx->side_info_fetched = true;
+  ctx->offsets_fetched = true;
   return JXLT_OK;
 }
 
@@ -490,65 +541,97 @@ int jxlt_fetch_result(jxlt_context* ctx, jxlt_frame_result* out) {
   return JXLT_OK;
 }
 
-int jxlt_pack_ac_sections(jxlt_context* ctx, const uint32_t* code_table, jxlt_packed_sections* out) {
-  if (!ctx || !code_table || !out) return JXLT_ERR_INVALID_ARGUMENT;
-  if (!ctx->encoded || !ctx->side_info_fetched) {
-    ctx->error = "jxlt_pack_ac_sections needs jxlt_encode_enqueue + jxlt_fetch_side_info first";
+int jxlt_fetch_histograms(jxlt_context* ctx, const uint32_t** ac_histograms, const uint32_t** dc_histograms) {
+  if (!ctx) return JXLT_ERR_INVALID_ARGUMENT;
+  if (!ctx->encoded) {
+    ctx->error = "nothing encoded yet";
     return JXLT_ERR_INVALID_ARGUMENT;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const FrameGeom& g = ctx->geom;
   const size_t ngroups = (size_t)g.xsize_groups * g.ysize_groups;
-  const uint64_t total_tokens = ctx->h_group_off.p[ngroups];
   int rc;
-#define ENSURE(buf, n) if ((rc = EnsureDevice(ctx, &ctx->buf, (n))) != JXLT_OK) return rc
-  ENSURE(code_table, 64 * 64);
-  ENSURE(sec_bits, ngroups);
-  ENSURE(sec_bytes, ngroups);
-  ENSURE(sec_byte_off, ngroups + 1);
-  if (ctx->slots.cap < 4 * total_tokens + 16) ENSURE(slots, 4 * total_tokens + total_tokens / 2 + 4096);
-  if (ctx->packed.cap < 4 * total_tokens + 16) ENSURE(packed, 4 * total_tokens + total_tokens / 2 + 4096);
-#undef ENSURE
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->code_table.p, code_table, 64 * 64 * sizeof(uint32_t), hipMemcpyHostToDevice,
+  if ((rc = EnsurePinned(ctx, &ctx->h_group_off, 2 * (ngroups + 1))) != JXLT_OK) return rc;
+  if ((rc = EnsurePinned(ctx, &ctx->h_hist, 2 * 64 * 64)) != JXLT_OK) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hist.p, ctx->hist.p, 2 * 64 * 64 * sizeof(uint32_t), hipMemcpyDeviceToHost,
                               ctx->stream));
-  PackArgs P;
-  P.records = ctx->tokens.p;
-  P.sec_rec_offset = ctx->group_off.p;
-  P.code_table = ctx->code_table.p;
-  P.slots = ctx->slots.p;
-  P.sec_bits = ctx->sec_bits.p;
-  P.sec_bytes = ctx->sec_bytes.p;
-  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ngroups), dim3(kPackThreads), 0, ctx->stream, P);
-  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->sec_bytes.p,
-                     ctx->sec_byte_off.p, (int)ngroups);
-  CompactArgs Cp;
-  Cp.slots = ctx->slots.p;
-  Cp.sec_rec_offset = ctx->group_off.p;
-  Cp.sec_bytes = ctx->sec_bytes.p;
-  Cp.sec_byte_offset = ctx->sec_byte_off.p;
-  Cp.out = ctx->packed.p;
-  hipLaunchKernelGGL(compact_kernel, dim3((unsigned)ngroups), dim3(256), 0, ctx->stream, Cp);
-  HIP_TRY(ctx, hipGetLastError());
-  if ((rc = EnsurePinned(ctx, &ctx->h_sec_byte_off, ngroups + 1)) != JXLT_OK) return rc;
-  if ((rc = EnsurePinned(ctx, &ctx->h_sec_bits, ngroups)) != JXLT_OK) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_sec_byte_off.p, ctx->sec_byte_off.p, (ngroups + 1) * sizeof(uint64_t),
-                              hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_sec_bits.p, ctx->sec_bits.p, ngroups * sizeof(uint32_t),
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_group_off.p + ngroups, ctx->group_off.p + ngroups, sizeof(uint64_t),
                               hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  const uint64_t total_bytes = ctx->h_sec_byte_off.p[ngroups];
-  if (ctx->h_packed.cap < total_bytes + 1 &&
-      (rc = EnsurePinned(ctx, &ctx->h_packed, total_bytes + total_bytes / 4 + 4096)) != JXLT_OK)
+  ctx->offsets_fetched = true;
+  if (ac_histograms) *ac_histograms = ctx->h_hist.p;
+  if (dc_histograms) *dc_histograms = ctx->h_hist.p + 64 * 64;
+  return JXLT_OK;
+}
+
+int jxlt_pack_sections(jxlt_context* ctx, int kind, const uint32_t* code_table, jxlt_packed_sections* out) {
+  if (!ctx || !code_table || !out || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
+  if (!ctx->encoded || !ctx->offsets_fetched) {
+    ctx->error = "jxlt_pack_sections needs jxlt_encode_enqueue + jxlt_fetch_histograms/side_info first";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const FrameGeom& g = ctx->geom;
+  const size_t ngroups = (size_t)g.xsize_groups * g.ysize_groups;
+  const size_t ndc = ((ctx->xsize + 2047) / 2048) * ((ctx->ysize + 2047) / 2048);
+  const size_t nsec = kind == 1 ? ngroups : ndc;
+  // upper bound of the record index space the slots must cover
+  const uint64_t rec_space = kind == 1 ? ctx->h_group_off.p[ngroups] : ctx->dc_records.cap / 3;
+  jxlt_context::PackSet& ps = ctx->pack[kind];
+  int rc;
+#define ENSURE(buf, n) if ((rc = EnsureDevice(ctx, &ps.buf, (n))) != JXLT_OK) return rc
+  ENSURE(code_table, 64 * 64);
+  ENSURE(sec_bits, nsec);
+  ENSURE(sec_bytes, nsec);
+  ENSURE(sec_byte_off, nsec + 1);
+  if (ps.slots.cap < 4 * rec_space + 16) ENSURE(slots, 4 * rec_space + rec_space / 2 + 4096);
+  if (ps.packed.cap < 4 * rec_space + 16) ENSURE(packed, 4 * rec_space + rec_space / 2 + 4096);
+#undef ENSURE
+  HIP_TRY(ctx, hipMemcpyAsync(ps.code_table.p, code_table, 64 * 64 * sizeof(uint32_t), hipMemcpyHostToDevice,
+                              ctx->stream));
+  PackArgs P;
+  P.records = kind == 1 ? ctx->tokens.p : ctx->dc_records.p;
+  P.sec_rec_offset = kind == 1 ? ctx->group_off.p : ctx->dc_rec_off.p;
+  P.sec_rec_count = kind == 1 ? nullptr : ctx->dc_count.p;
+  P.code_table = ps.code_table.p;
+  P.slots = ps.slots.p;
+  P.sec_bits = ps.sec_bits.p;
+  P.sec_bytes = ps.sec_bytes.p;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)nsec), dim3(kPackThreads), 0, ctx->stream, P);
+  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t*)ps.sec_bytes.p,
+                     ps.sec_byte_off.p, (int)nsec);
+  CompactArgs Cp;
+  Cp.slots = ps.slots.p;
+  Cp.sec_rec_offset = P.sec_rec_offset;
+  Cp.sec_bytes = ps.sec_bytes.p;
+  Cp.sec_byte_offset = ps.sec_byte_off.p;
+  Cp.out = ps.packed.p;
+  hipLaunchKernelGGL(compact_kernel, dim3((unsigned)nsec), dim3(256), 0, ctx->stream, Cp);
+  HIP_TRY(ctx, hipGetLastError());
+  if ((rc = EnsurePinned(ctx, &ps.h_sec_byte_off, nsec + 1)) != JXLT_OK) return rc;
+  if ((rc = EnsurePinned(ctx, &ps.h_sec_bits, nsec)) != JXLT_OK) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ps.h_sec_byte_off.p, ps.sec_byte_off.p, (nsec + 1) * sizeof(uint64_t),
+                              hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ps.h_sec_bits.p, ps.sec_bits.p, nsec * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                              ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const uint64_t total_bytes = ps.h_sec_byte_off.p[nsec];
+  if (ps.h_packed.cap < total_bytes + 1 &&
+      (rc = EnsurePinned(ctx, &ps.h_packed, total_bytes + total_bytes / 4 + 4096)) != JXLT_OK)
     return rc;
   if (total_bytes) {
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_packed.p, ctx->packed.p, total_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ps.h_packed.p, ps.packed.p, total_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
-  out->bytes = ctx->h_packed.p;
-  out->section_offset = ctx->h_sec_byte_off.p;
-  out->section_bits = ctx->h_sec_bits.p;
-  out->num_sections = ngroups;
+  out->bytes = ps.h_packed.p;
+  out->section_offset = ps.h_sec_byte_off.p;
+  out->section_bits = ps.h_sec_bits.p;
+  out->num_sections = nsec;
   return JXLT_OK;
+}
+
+int jxlt_pack_ac_sections(jxlt_context* ctx, const uint32_t* code_table, jxlt_packed_sections* out) {
+  return jxlt_pack_sections(ctx, 1, code_table, out);
 }
 
 int jxlt_kernel_times(jxlt_context* ctx, jxlt_kernel_time* out, int cap) {
@@ -558,15 +641,15 @@ int jxlt_kernel_times(jxlt_context* ctx, jxlt_kernel_time* out, int cap) {
     return JXLT_ERR_INVALID_ARGUMENT;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipEventSynchronize(ctx->ev[3]));
-  static const char* kNames[3] = {"tile_kernel", "group_scan_kernel", "token_kernel"};
-  for (int i = 0; i < 3 && i < cap; i++) {
+  HIP_TRY(ctx, hipEventSynchronize(ctx->ev[4]));
+  static const char* kNames[4] = {"tile_kernel", "group_scan_kernel", "token_kernel", "dc_kernels"};
+  for (int i = 0; i < 4 && i < cap; i++) {
     float ms = 0.0f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
     out[i].name = kNames[i];
     out[i].milliseconds = ms;
   }
-  return 3;
+  return 4;
 }
 
 int jxlt_debug_fetch(jxlt_context* ctx, int what, void* host_dst, size_t bytes) {

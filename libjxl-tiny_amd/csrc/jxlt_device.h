@@ -24,6 +24,7 @@
 #define JXLT_DEVICE_H_
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 namespace jxlt_dev {
@@ -43,6 +44,7 @@ struct DeviceTables {
   uint16_t nnz_context[64];
   uint8_t block_context_map[81];
   uint8_t ac_context_map[1980];
+  uint8_t gradient_lut[1024];  // enc_frame.cc:226-281
 };
 
 struct FrameGeom {
@@ -71,6 +73,7 @@ struct TileArgs {
   uint8_t* blk_nscan;   // [block*3 + c]: scan positions up to the last nonzero
   int16_t* coef_scan;   // [block*3 + c][64] quantised coefficients in scan order
   uint32_t* group_ntok; // per group token count (atomic)
+  uint32_t* dc_nac;     // per DC group: number of first blocks (atomic)
   // debug (may be null)
   float* dbg_xyb[3];
   float* dbg_qf;
@@ -100,6 +103,7 @@ struct PackArgs {
   uint8_t* slots;                   // section s is written at byte 4 * sec_rec_offset[s]
   uint32_t* sec_bits;               // [nsec] bits written
   uint32_t* sec_bytes;              // [nsec] ceil(bits / 8)
+  const uint32_t* sec_rec_count;    // optional [nsec]: records in section (else offset[s+1]-offset[s])
 };
 
 struct CompactArgs {
@@ -471,6 +475,7 @@ struct alignas(16) TileShared {
   uint8_t raw_quant[64];
   uint8_t strat[64];
   uint32_t ntok;
+  uint32_t nfirst;
 };
 // After the last pixel read the XYB planes are dead and are reused as the
 // staging area for quantised coefficients (64 blocks x 3 channels x 64 int16).
@@ -704,7 +709,10 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
   for (int i = tid; i < 576; i += kTileThreads) S.inv_w[i] = T->inv_weights[i];
   if (tid < 64) S.y_w[tid] = T->weights[T->table_offset[1] + tid];
   if (tid < 128) S.y_w[64 + tid] = T->weights[T->table_offset[4] + tid];
-  if (tid == 0) S.ntok = 0;
+  if (tid == 0) {
+    S.ntok = 0;
+    S.nfirst = 0;
+  }
   {
     const int base = px0 - kHalo;  // stripe x of LDS column 0
     for (int i = tid; i < 64 * (64 + 2 * kHalo); i += kTileThreads) {
@@ -1104,6 +1112,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
   if (tid < 64 && (tid & 7) < nbx && (tid >> 3) < nby) {
     const size_t pos = (size_t)(by_img0 + (tid >> 3)) * bstride + bx_img0 + (tid & 7);
     A.strategy[pos] = S.strat[tid];
+    if (S.strat[tid] & 1) atomicAdd(&S.nfirst, 1u);
     A.raw_quant[pos] = S.raw_quant[tid];
   }
   // All pixel reads are done (transforms live in registers): from here on the
@@ -1172,6 +1181,8 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
   if (tid == 0) {
     const int group = (ty_img >> 2) * A.g.xsize_groups + gx;
     atomicAdd(&A.group_ntok[group], S.ntok);
+    const int dcg = (ty_img >> 5) * ((A.g.xsize + 2047) / 2048) + (tx_img >> 5);
+    atomicAdd(&A.dc_nac[dcg], S.nfirst);
   }
 #undef JXLT_MARK
 #undef SX
@@ -1373,7 +1384,8 @@ __global__ void __launch_bounds__(kPackThreads) pack_kernel(const PackArgs A) {
   const int tid = (int)threadIdx.x;
   const int sec = (int)blockIdx.x;
   for (int i = tid; i < 64 * 64; i += kPackThreads) table[i] = A.code_table[i];
-  const uint64_t rec0 = A.sec_rec_offset[sec], rec1 = A.sec_rec_offset[sec + 1];
+  const uint64_t rec0 = A.sec_rec_offset[sec];
+  const uint64_t rec1 = A.sec_rec_count ? rec0 + A.sec_rec_count[sec] : A.sec_rec_offset[sec + 1];
   const uint8_t* src = A.records + 3 * rec0;
   uint32_t* dst = reinterpret_cast<uint32_t*>(A.slots + 4 * rec0);
   uint64_t total_bits = 0;     // bits of all completed tiles
@@ -1456,6 +1468,208 @@ __global__ void __launch_bounds__(kPackThreads) pack_kernel(const PackArgs A) {
     A.sec_bits[sec] = (uint32_t)total_bits;
     A.sec_bytes[sec] = (uint32_t)((total_bits + 7) >> 3);
   }
+}
+
+
+// ---------------------------------------------------------------------------
+// DC-group sections as raw records (enc_frame.cc:287-424, 536-570):
+//   [esc 6 bits][DC tokens Y,X,B][esc nb_bits][esc 4 bits][ytox][ytob]
+//   [strategy per first block][quant field per first block][EPF per block]
+// Contexts are the reference's DC context ids (identity pre-clustering).
+// dc_elementwise_kernel: every token whose position needs no scan.
+// dc_chain_kernel: the two per-first-block token runs ("left" = previous first block).
+// ---------------------------------------------------------------------------
+struct DcArgs {
+  FrameGeom g;
+  const DeviceTables* tab;
+  const int16_t* quant_dc[3];
+  const uint8_t* raw_quant;
+  const uint8_t* strategy;
+  const int8_t* ytox;
+  const int8_t* ytob;
+  const uint32_t* dc_nac;         // [ndc] first blocks per DC group
+  const uint64_t* dc_rec_offset;  // [ndc] start of each DC group's records (fixed stride)
+  uint8_t* records;
+  uint32_t* dc_count;             // [ndc] records per DC group
+  uint32_t* histogram;            // [64 * 64]
+};
+
+struct DcGeom {
+  int bx0, by0, nbx, nby, nb;      // block rect of the DC group
+  int tx0, ty0, ntx, nty, nt;      // tile rect
+  uint32_t pos_dc, pos_esc, pos_cmap, pos_strategy, pos_qf, pos_epf, total;
+};
+
+JXLT_DI DcGeom dc_geom(const FrameGeom& g, int dcg, uint32_t nac) {
+  DcGeom d;
+  const int xdc = (g.xsize + 2047) / 2048;
+  const int gx = dcg % xdc, gy = dcg / xdc;
+  d.bx0 = gx * 256;
+  d.by0 = gy * 256;
+  d.nbx = imin(256, g.xsize_blocks - d.bx0);
+  d.nby = imin(256, g.ysize_blocks - d.by0);
+  d.nb = d.nbx * d.nby;
+  d.tx0 = gx * 32;
+  d.ty0 = gy * 32;
+  d.ntx = (d.nbx * 8 + 63) / 64;
+  d.nty = (d.nby * 8 + 63) / 64;
+  d.nt = d.ntx * d.nty;
+  d.pos_dc = 1;
+  d.pos_esc = 1 + 3 * (uint32_t)d.nb;
+  d.pos_cmap = d.pos_esc + (d.nb > 1 ? 2 : 1);
+  d.pos_strategy = d.pos_cmap + 2 * (uint32_t)d.nt;
+  d.pos_qf = d.pos_strategy + nac;
+  d.pos_epf = d.pos_qf + nac;
+  d.total = d.pos_epf + (uint32_t)d.nb;
+  return d;
+}
+
+JXLT_DI int clamped_gradient(int n, int w, int l) {  // enc_frame.cc:158-176
+  const int m = n < w ? n : w, M = n < w ? w : n;
+  const int grad = (int)((uint32_t)n + (uint32_t)w - (uint32_t)l);
+  const int grad_clamp_M = (l < m) ? M : grad;
+  return (l > M) ? m : grad_clamp_M;
+}
+
+JXLT_DI void put_record(uint8_t* rec, uint32_t pos, uint32_t ctx, uint32_t value, uint32_t* hist) {
+  uint8_t* o = rec + 3 * (size_t)pos;
+  o[0] = (uint8_t)ctx;
+  o[1] = (uint8_t)(value & 0xFF);
+  o[2] = (uint8_t)((value >> 8) & 0xFF);
+  if (ctx < 128) {
+    uint32_t sym, nb, eb;
+    hybrid_uint(value & 0xFFFFu, &sym, &nb, &eb);
+    atomicAdd(&hist[ctx * 64 + sym], 1u);
+  }
+}
+
+constexpr int kDcParts = 32;  // workgroups per DC group in dc_elementwise_kernel
+
+__global__ void __launch_bounds__(256) dc_elementwise_kernel(const DcArgs A) {
+  __shared__ uint32_t hist[64 * 64];
+  const int tid = (int)threadIdx.x;
+  const int dcg = (int)blockIdx.x / kDcParts, part = (int)blockIdx.x % kDcParts;
+  for (int i = tid; i < 64 * 64; i += 256) hist[i] = 0;
+  __syncthreads();
+  const uint32_t nac = A.dc_nac[dcg];
+  const DcGeom d = dc_geom(A.g, dcg, nac);
+  uint8_t* rec = A.records + 3 * A.dc_rec_offset[dcg];
+  const size_t bstride = (size_t)A.g.xsize_blocks;
+  if (part == 0 && tid == 0) {
+    put_record(rec, 0, 128 + 6, 12, hist);  // extra_dc_precision = 0, global tree / default wp
+    uint32_t p = d.pos_esc;
+    if (d.nb > 1) put_record(rec, p++, 128 + (uint32_t)ceil_log2_nonzero((uint32_t)d.nb), nac - 1, hist);
+    put_record(rec, p, 128 + 4, 3, hist);
+    A.dc_count[dcg] = d.total;
+  }
+  // DC tokens (WriteDCTokens, enc_frame.cc:287-316)
+  const int per = (3 * d.nb + kDcParts - 1) / kDcParts;
+  const int ibeg = part * per, iend = imin(3 * d.nb, ibeg + per);
+  for (int i = ibeg + tid; i < iend; i += 256) {
+    const int ci = i / d.nb, r = i % d.nb;
+    const int y = r / d.nbx, x = r % d.nbx;
+    const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
+    const int16_t* q = A.quant_dc[c] + (size_t)(d.by0 + y) * bstride + d.bx0 + x;
+    const int left = x ? q[-1] : y ? q[-(ptrdiff_t)bstride] : 0;
+    const int top = y ? q[-(ptrdiff_t)bstride] : left;
+    const int topleft = (x && y) ? q[-(ptrdiff_t)bstride - 1] : left;
+    const int guess = clamped_gradient(top, left, topleft);
+    int gp = 512 + top + left - topleft;
+    gp = gp < 0 ? 0 : gp > 1023 ? 1023 : gp;
+    const int residual = (int)q[0] - guess;
+    put_record(rec, d.pos_dc + (uint32_t)i, A.tab->gradient_lut[gp], pack_signed(residual), hist);
+  }
+  // YtoX / YtoB tokens (enc_frame.cc:339-362)
+  const int perc = (2 * d.nt + kDcParts - 1) / kDcParts;
+  for (int i = part * perc + tid; i < imin(2 * d.nt, (part + 1) * perc); i += 256) {
+    const int c = i / d.nt, r = i % d.nt;
+    const int y = r / d.ntx, x = r % d.ntx;
+    const int8_t* m = (c == 0 ? A.ytox : A.ytob) + (size_t)(d.ty0 + y) * A.g.xsize_tiles + d.tx0 + x;
+    const ptrdiff_t ts = A.g.xsize_tiles;
+    const int left = x ? m[-1] : y ? m[-ts] : 0;
+    const int top = y ? m[-ts] : left;
+    const int topleft = (x && y) ? m[-ts - 1] : left;
+    const int residual = (int)m[0] - clamped_gradient(top, left, topleft);
+    put_record(rec, d.pos_cmap + (uint32_t)i, 2u - (uint32_t)c, pack_signed(residual), hist);
+  }
+  // EPF tokens (enc_frame.cc:410-423)
+  const int pere = (d.nb + kDcParts - 1) / kDcParts;
+  for (int i = part * pere + tid; i < imin(d.nb, (part + 1) * pere); i += 256)
+    put_record(rec, d.pos_epf + (uint32_t)i, 0, pack_signed(4), hist);
+  __syncthreads();
+  for (int i = tid; i < 64 * 64; i += 256)
+    if (hist[i]) atomicAdd(&A.histogram[i], hist[i]);
+}
+
+constexpr int kDcChainThreads = 1024;
+
+__global__ void __launch_bounds__(kDcChainThreads) dc_chain_kernel(const DcArgs A) {
+  __shared__ uint32_t hist[64 * 64];
+  __shared__ uint32_t wsum[kDcChainThreads / 64];
+  __shared__ uint16_t compact[kDcChainThreads + 1];  // (code << 8) | (qf - 1) of the chunk's first blocks
+  __shared__ uint32_t carry_rank;
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int dcg = (int)blockIdx.x;
+  for (int i = tid; i < 64 * 64; i += kDcChainThreads) hist[i] = 0;
+  const uint32_t nac = A.dc_nac[dcg];
+  const DcGeom d = dc_geom(A.g, dcg, nac);
+  uint8_t* rec = A.records + 3 * A.dc_rec_offset[dcg];
+  const size_t bstride = (size_t)A.g.xsize_blocks;
+  // "left" before the first first-block: 0 for the strategy run, StrategyCode(acs(0,0)) for
+  // the quant-field run (sic, enc_frame.cc:386)
+  const uint8_t a00 = A.strategy[(size_t)d.by0 * bstride + d.bx0];
+  const int code00 = (a00 >> 1) == 0 ? 0 : (a00 >> 1) == 1 ? 6 : 7;
+  if (tid == 0) {
+    carry_rank = 0;
+    compact[0] = (uint16_t)((0 << 8) | code00);  // slot 0 = predecessor of the chunk's first entry
+  }
+  __syncthreads();
+  for (int base = 0; base < d.nb; base += kDcChainThreads) {
+    const int i = base + tid;
+    bool first = false;
+    int code = 0, qfm1 = 0;
+    if (i < d.nb) {
+      const size_t pos = (size_t)(d.by0 + i / d.nbx) * bstride + d.bx0 + i % d.nbx;
+      const uint8_t a = A.strategy[pos];
+      first = (a & 1) != 0;
+      code = (a >> 1) == 0 ? 0 : (a >> 1) == 1 ? 6 : 7;
+      qfm1 = (int)A.raw_quant[pos] - 1;
+    }
+    // exclusive rank of first blocks inside the chunk
+    const unsigned long long m = __ballot(first);
+    const uint32_t in_wave = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t wbase = 0, chunk_total = 0;
+    for (int w = 0; w < kDcChainThreads / 64; w++) {
+      if (w < wave) wbase += wsum[w];
+      chunk_total += wsum[w];
+    }
+    const uint32_t r = wbase + in_wave;  // rank within chunk
+    if (first) compact[1 + r] = (uint16_t)((code << 8) | qfm1);
+    __syncthreads();
+    if (first) {
+      const uint16_t prev = compact[r];  // previous first block (or the carried one)
+      const uint32_t grank = carry_rank + r;
+      // strategy token (enc_frame.cc:364-383): left = previous code (0 for the very first)
+      const int left_s = (grank == 0) ? 0 : (prev >> 8);
+      const uint32_t ctx_s = left_s > 11 ? 7 : left_s > 5 ? 8 : left_s > 3 ? 9 : 10;
+      put_record(rec, d.pos_strategy + grank, ctx_s, pack_signed(code), hist);
+      // quant-field token (:384-408): left = previous (qf-1), initially code of block (0,0)
+      const int left_q = (grank == 0) ? code00 : (prev & 0xFF);
+      const uint32_t ctx_q = left_q > 11 ? 3 : left_q > 5 ? 4 : left_q > 3 ? 5 : 6;
+      put_record(rec, d.pos_qf + grank, ctx_q, pack_signed(qfm1 - left_q), hist);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      if (chunk_total) compact[0] = compact[chunk_total];
+      carry_rank += chunk_total;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < 64 * 64; i += kDcChainThreads)
+    if (hist[i]) atomicAdd(&A.histogram[i], hist[i]);
 }
 
 // Gathers the packed sections into one contiguous byte stream.

@@ -30,6 +30,7 @@ inline void BuildDeviceTables(float scale, DeviceTables* t) {
   memcpy(t->nnz_context, JXLT_kCoeffNumNonzeroContext, sizeof(t->nnz_context));
   memcpy(t->block_context_map, JXLT_kBlockContextMap, sizeof(t->block_context_map));
   memcpy(t->ac_context_map, JXLT_kACContextMap, sizeof(t->ac_context_map));
+  memcpy(t->gradient_lut, JXLT_kGradientContextLut, sizeof(t->gradient_lut));
 }
 
 inline FrameGeom MakeGeom(size_t xsize, size_t ysize) {

@@ -6,6 +6,8 @@
 
 #include <stdio.h>
 
+#include <chrono>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -37,6 +39,12 @@ FrameView ViewOf(const jxlt_frame_result& res, const uint8_t* const* group_ptr, 
 // device packs the AC sections.  Single-group frames (bit-concatenated sections,
 // enc_frame.cc:805-811) take the raw-token route.
 bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jxl::BitWriter* writer) {
+  static const bool trace = getenv("JXLT_TRACE") != nullptr;
+  auto now = []() { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count();
+  };
+  const auto t0 = now();
   const DistanceParams distp = ComputeDistanceParams(distance);
   jxlt_params params;
   params.distance = distp.distance;
@@ -49,36 +57,51 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
     fprintf(stderr, "jxl_tiny_amd: device encode failed: %s\n", jxlt_last_error(ctx));
     return false;
   }
-  jxlt_frame_result res;
-  const uint32_t* hist = nullptr;
-  if (jxlt_fetch_side_info(ctx, &res, &hist) != JXLT_OK) {
-    fprintf(stderr, "jxl_tiny_amd: fetch failed: %s\n", jxlt_last_error(ctx));
-    return false;
-  }
-  const size_t num_dc_groups = ((res.xsize + 2047) / 2048) * ((res.ysize + 2047) / 2048);
-  if (res.num_groups + num_dc_groups == 2) {
+  size_t xsize = 0, ysize = 0;
+  if (jxlt_image_size(ctx, &xsize, &ysize) != JXLT_OK) return false;
+  const size_t num_groups = ((xsize + 255) / 256) * ((ysize + 255) / 256);
+  const size_t num_dc_groups = ((xsize + 2047) / 2048) * ((ysize + 2047) / 2048);
+  if (num_groups + num_dc_groups == 2) {
+    jxlt_frame_result res;
     if (jxlt_fetch_result(ctx, &res) != JXLT_OK) return false;
     const uint8_t* ptr = res.tokens;
     const size_t len = static_cast<size_t>(res.group_token_offset[1]);
     return AssembleFrame(ViewOf(res, &ptr, &len), distp, writer, num_threads);
   }
-  const FrameView view = ViewOf(res, nullptr, nullptr);
+  const uint32_t *ac_hist = nullptr, *dc_hist = nullptr;
+  if (jxlt_fetch_histograms(ctx, &ac_hist, &dc_hist) != JXLT_OK) {
+    fprintf(stderr, "jxl_tiny_amd: fetch failed: %s\n", jxlt_last_error(ctx));
+    return false;
+  }
+  const auto t1 = now();
   EntropyCode ac_code, dc_code;
-  std::vector<jxl::BitWriter> dc_sections;
-  BuildAcCode(hist, &ac_code);
-  std::vector<uint32_t> table(64 * 64);
-  FillCodeTable(ac_code, table.data());
-  // DC groups on host threads while the device packs the AC sections.
-  std::thread dc_thread([&]() { BuildDcSections(view, num_threads, &dc_code, &dc_sections); });
-  jxlt_packed_sections packed;
-  const int rc = jxlt_pack_ac_sections(ctx, table.data(), &packed);
-  dc_thread.join();
-  if (rc != JXLT_OK) {
+  std::vector<uint32_t> ac_table(64 * 64), dc_table(64 * 64);
+  {
+    // The two code constructions are independent: one extra host thread.
+    std::thread dc_thread([&]() {
+      BuildDcCode(dc_hist, &dc_code);
+      FillCodeTable(dc_code, dc_table.data());
+    });
+    BuildAcCode(ac_hist, &ac_code);
+    FillCodeTable(ac_code, ac_table.data());
+    dc_thread.join();
+  }
+  const auto t2 = now();
+  jxlt_packed_sections dcp, acp;
+  if (jxlt_pack_sections(ctx, 0, dc_table.data(), &dcp) != JXLT_OK ||
+      jxlt_pack_sections(ctx, 1, ac_table.data(), &acp) != JXLT_OK) {
     fprintf(stderr, "jxl_tiny_amd: section packing failed: %s\n", jxlt_last_error(ctx));
     return false;
   }
-  PackedSections ac = {packed.bytes, packed.section_offset, packed.section_bits, packed.num_sections};
-  return FinishFrame(view, distp, dc_code, &dc_sections, ac_code, ac, writer);
+  const auto t3 = now();
+  PackedSections dc = {dcp.bytes, dcp.section_offset, dcp.section_bits, dcp.num_sections};
+  PackedSections ac = {acp.bytes, acp.section_offset, acp.section_bits, acp.num_sections};
+  const bool ok = FinishFrame(xsize, ysize, distp, dc_code, dc, ac_code, ac, writer);
+  if (trace)
+    fprintf(stderr, "jxlt trace: device+histograms %.2f ms | codes %.2f | pack dc+ac (device) %.2f | finish %.2f\n",
+            ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
+  (void)num_threads;
+  return ok;
 }
 
 }  // namespace jxlt

@@ -382,19 +382,11 @@ DistanceParams ComputeDistanceParams(float distance) {  // enc_frame.cc:115-156
   return p;
 }
 
-void BuildDcSections(const FrameView& f, int num_threads, EntropyCode* dc_code,
-                     std::vector<jxl::BitWriter>* dc_sections) {
-  const size_t xsize_blocks = DivCeil(f.xsize, 8);
-  const size_t xsize_tiles = DivCeil(f.xsize, 64);
-  const size_t xsize_dc_groups = DivCeil(f.xsize, 2048), ysize_dc_groups = DivCeil(f.ysize, 2048);
-  const size_t num_dc_groups = xsize_dc_groups * ysize_dc_groups;
-  std::vector<RawSection> dc_raw(num_dc_groups);
-  ParallelFor(num_dc_groups, num_threads, [&](size_t i, int) {
-    DCGroupSection(f, xsize_blocks, xsize_tiles, i % xsize_dc_groups, i / xsize_dc_groups, &dc_raw[i]);
-  });
-  uint8_t dc_identity[kNumDCContexts];
-  for (size_t i = 0; i < kNumDCContexts; ++i) dc_identity[i] = static_cast<uint8_t>(i);
-  OptimizeSections(dc_raw, kNumDCContexts, dc_identity, kNumDCContexts, dc_code, dc_sections, num_threads);
+std::vector<uint8_t> DcGroupRecords(const FrameView& f, size_t index) {
+  const size_t xsize_dc_groups = DivCeil(f.xsize, 2048);
+  RawSection sec;
+  DCGroupSection(f, DivCeil(f.xsize, 8), DivCeil(f.xsize, 64), index % xsize_dc_groups, index / xsize_dc_groups, &sec);
+  return sec.owned;
 }
 
 void BuildAcCode(const uint32_t* histograms, EntropyCode* ac_code) {
@@ -420,27 +412,44 @@ void FillCodeTable(const EntropyCode& code, uint32_t* table) {
   }
 }
 
-bool FinishFrame(const FrameView& f, const DistanceParams& distp, const EntropyCode& dc_code,
-                 std::vector<jxl::BitWriter>* dc_sections, const EntropyCode& ac_code,
-                 const PackedSections& ac, jxl::BitWriter* writer) {
-  const size_t num_groups = DivCeil(f.xsize, 256) * DivCeil(f.ysize, 256);
-  const size_t num_dc_groups = DivCeil(f.xsize, 2048) * DivCeil(f.ysize, 2048);
-  if (ac.n != num_groups || dc_sections->size() != num_dc_groups || 2 + num_dc_groups + num_groups == 4)
-    return false;
-  std::vector<jxl::BitWriter> head;
-  head.reserve(2 + num_dc_groups);
-  head.emplace_back();
-  WriteDCGlobal(distp, num_dc_groups, dc_code, &head.back());
-  for (auto& s : *dc_sections) head.push_back(std::move(s));
-  head.emplace_back();
-  WriteACGlobal(num_groups, ac_code, &head.back());
+void BuildDcCode(const uint32_t* histograms, EntropyCode* dc_code) {
+  std::vector<Histogram> h(kNumDCContexts);
+  uint8_t dc_identity[kNumDCContexts];
+  for (size_t c = 0; c < kNumDCContexts; ++c) {
+    dc_identity[c] = static_cast<uint8_t>(c);
+    for (size_t s = 0; s < kAlphabetSize; ++s) {
+      h[c].counts[s] = histograms[c * kAlphabetSize + s];
+      h[c].total_count += histograms[c * kAlphabetSize + s];
+    }
+  }
+  OptimizeEntropyCode(&h, dc_identity, kNumDCContexts, dc_code);
+}
+
+bool FinishFrame(size_t xsize, size_t ysize, const DistanceParams& distp, const EntropyCode& dc_code,
+                 const PackedSections& dc, const EntropyCode& ac_code, const PackedSections& ac,
+                 jxl::BitWriter* writer) {
+  const size_t num_groups = DivCeil(xsize, 256) * DivCeil(ysize, 256);
+  const size_t num_dc_groups = DivCeil(xsize, 2048) * DivCeil(ysize, 2048);
+  if (ac.n != num_groups || dc.n != num_dc_groups || 2 + num_dc_groups + num_groups == 4) return false;
+  jxl::BitWriter dc_global, ac_global;
+  WriteDCGlobal(distp, num_dc_groups, dc_code, &dc_global);
+  WriteACGlobal(num_groups, ac_code, &ac_global);
+  dc_global.ZeroPadToByte();
+  ac_global.ZeroPadToByte();
   std::vector<size_t> sizes;
-  sizes.reserve(head.size() + num_groups);
-  for (const jxl::BitWriter& s : head) sizes.push_back(DivCeil(s.BitsWritten(), 8));
+  sizes.reserve(2 + num_dc_groups + num_groups);
+  sizes.push_back(dc_global.BitsWritten() / 8);
+  for (size_t g = 0; g < num_dc_groups; ++g) sizes.push_back(static_cast<size_t>(dc.offset[g + 1] - dc.offset[g]));
+  sizes.push_back(ac_global.BitsWritten() / 8);
   for (size_t g = 0; g < num_groups; ++g) sizes.push_back(static_cast<size_t>(ac.offset[g + 1] - ac.offset[g]));
   WriteFrameHeader(distp.x_qm_scale, distp.epf_iters, writer);
   if (!WriteTOCSizes(sizes, writer)) return false;
-  writer->AppendByteAligned(&head);
+  writer->Reserve(static_cast<size_t>(dc.offset[num_dc_groups] + ac.offset[num_groups]) + 65536);
+  const std::vector<uint8_t>& dg = dc_global.Bytes();
+  writer->AppendBytes(dg.data(), dg.size());
+  writer->AppendBytes(dc.bytes, static_cast<size_t>(dc.offset[num_dc_groups]));
+  const std::vector<uint8_t>& ag = ac_global.Bytes();
+  writer->AppendBytes(ag.data(), ag.size());
   writer->AppendBytes(ac.bytes, static_cast<size_t>(ac.offset[num_groups]));
   return true;
 }

@@ -47,12 +47,12 @@ struct FrameView {
 };
 
 // ---- production path: AC sections entropy-coded on the device -----------------
-// DC-group tokenisation + code optimisation + section encoding (host).
-void BuildDcSections(const FrameView& frame, int num_threads, EntropyCode* dc_code,
-                     std::vector<jxl::BitWriter>* dc_sections);
-// AC prefix codes from the device's [64][64] symbol histograms (enc_frame.cc:783 onwards).
+// Prefix codes from the device's [64][64] symbol histograms (the second half of
+// OptimizeSections, enc_frame.cc:783): AC uses the static 1980 -> 64 pre-clustering,
+// DC the identity map over its 45 contexts.
 void BuildAcCode(const uint32_t* histograms, EntropyCode* ac_code);
-// table[ctx * 64 + sym] = (depth << 16) | bits for pre-clustered context ctx.
+void BuildDcCode(const uint32_t* histograms, EntropyCode* dc_code);
+// table[ctx * 64 + sym] = (depth << 16) | bits for (pre-clustered) context ctx.
 void FillCodeTable(const EntropyCode& code, uint32_t* table);
 struct PackedSections {
   const uint8_t* bytes;
@@ -60,12 +60,16 @@ struct PackedSections {
   const uint32_t* bits;    // [n]
   size_t n;
 };
-// Frame header + TOC + DCGlobal + DC groups + ACGlobal + packed AC groups.
+// Frame header + TOC + DCGlobal + DC groups + ACGlobal + AC groups, with both
+// kinds of group sections already entropy-coded (byte-aligned) by the device.
 // Not valid for single-group frames (their sections are bit-concatenated,
 // enc_frame.cc:805-811): use AssembleFrame there.
-bool FinishFrame(const FrameView& frame, const DistanceParams& distp, const EntropyCode& dc_code,
-                 std::vector<jxl::BitWriter>* dc_sections, const EntropyCode& ac_code,
-                 const PackedSections& ac, jxl::BitWriter* writer);
+bool FinishFrame(size_t xsize, size_t ysize, const DistanceParams& distp, const EntropyCode& dc_code,
+                 const PackedSections& dc, const EntropyCode& ac_code, const PackedSections& ac,
+                 jxl::BitWriter* writer);
+
+// Raw 3-byte records of DC group `index` as the host tokeniser produces them (tests).
+std::vector<uint8_t> DcGroupRecords(const FrameView& frame, size_t index);
 
 // Appends frame header + TOC + all sections to `writer` (must be byte aligned).
 // num_threads <= 0 selects std::thread::hardware_concurrency().

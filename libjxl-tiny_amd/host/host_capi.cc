@@ -120,6 +120,22 @@ int jxlt_encode_resident(jxlt_context* ctx, float distance, int num_threads, uin
   return ToMalloc(writer.TakeBytes(), out_bytes, out_size);
 }
 
+int jxlt_debug_dc_records(const jxlt_frame_result* frame, size_t dc_group_index, uint8_t** out_bytes,
+                          size_t* out_size) {
+  if (!frame || !out_bytes || !out_size) return JXLT_ERR_INVALID_ARGUMENT;
+  jxlt::FrameView view;
+  view.xsize = frame->xsize;
+  view.ysize = frame->ysize;
+  for (int c = 0; c < 3; ++c) view.quant_dc[c] = frame->quant_dc[c];
+  view.raw_quant_field = frame->raw_quant_field;
+  view.ac_strategy = frame->ac_strategy;
+  view.ytox_map = frame->ytox_map;
+  view.ytob_map = frame->ytob_map;
+  view.group_tokens = nullptr;
+  view.group_token_bytes = nullptr;
+  return ToMalloc(jxlt::DcGroupRecords(view, dc_group_index), out_bytes, out_size);
+}
+
 void jxlt_free(void* p) { free(p); }
 
 }  // extern "C"

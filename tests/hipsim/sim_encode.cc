@@ -25,7 +25,11 @@ struct sim_result {
   float* qf;
   float* mask;
   float* ent8;
-  uint32_t* histogram;  // [64*64]
+  uint32_t* histogram;  // [2][64*64]: AC, DC
+  uint8_t* dc_records;  // DC-group record streams, fixed stride
+  uint64_t* dc_rec_offset;  // [ndc + 1]
+  uint32_t* dc_count;   // [ndc]
+  size_t num_dc_groups;
 };
 
 __attribute__((visibility("default"))) int sim_encode(const float* const planes[3], size_t pitch_floats, size_t xsize, size_t ysize,
@@ -68,6 +72,8 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   A.blk_nscan = (uint8_t*)calloc(nblocks * 3, 1);
   A.coef_scan = (int16_t*)calloc(nblocks * 3 * 64, 2);
   A.group_ntok = (uint32_t*)calloc(ngroups, 4);
+  const size_t ndc = ((xsize + 2047) / 2048) * ((ysize + 2047) / 2048);
+  A.dc_nac = (uint32_t*)calloc(ndc, 4);
   A.dbg_qf = r->qf = (float*)calloc(nblocks, 4);
   A.dbg_mask = r->mask = (float*)calloc(nblocks, 4);
   const size_t ncells = ((size_t)g.xsize_blocks / 2 + 1) * ((size_t)g.ysize_blocks / 2 + 1);
@@ -92,9 +98,35 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   K.coef_scan = A.coef_scan;
   K.group_tok_offset = r->group_tok_offset;
   K.tokens = r->tokens;
-  K.histogram = r->histogram = (uint32_t*)calloc(64 * 64, 4);
+  K.histogram = r->histogram = (uint32_t*)calloc(2 * 64 * 64, 4);
   hipsim::launch(token_kernel, dim3((unsigned)ngroups), dim3(kTokenThreads), K);
 
+  {
+    const size_t kDcStride = 6 * 65536 + 2 * 1024 + 8;
+    r->num_dc_groups = ndc;
+    r->dc_rec_offset = (uint64_t*)calloc(ndc + 1, 8);
+    for (size_t i = 0; i <= ndc; i++) r->dc_rec_offset[i] = i * kDcStride;
+    r->dc_records = (uint8_t*)malloc(ndc * kDcStride * 3);
+    memset(r->dc_records, 0xEE, ndc * kDcStride * 3);
+    r->dc_count = (uint32_t*)calloc(ndc, 4);
+    DcArgs D;
+    memset(&D, 0, sizeof(D));
+    D.g = g;
+    D.tab = tab;
+    for (int c = 0; c < 3; c++) D.quant_dc[c] = A.quant_dc[c];
+    D.raw_quant = A.raw_quant;
+    D.strategy = A.strategy;
+    D.ytox = A.ytox;
+    D.ytob = A.ytob;
+    D.dc_nac = A.dc_nac;
+    D.dc_rec_offset = r->dc_rec_offset;
+    D.records = r->dc_records;
+    D.dc_count = r->dc_count;
+    D.histogram = r->histogram + 64 * 64;
+    hipsim::launch(dc_elementwise_kernel, dim3((unsigned)(ndc * kDcParts)), dim3(256), D);
+    hipsim::launch(dc_chain_kernel, dim3((unsigned)ndc), dim3(kDcChainThreads), D);
+  }
+  free(A.dc_nac);
   for (int c = 0; c < 3; c++) free(A.nzgrid[c]);
   free(A.blk_nz);
   free(A.blk_nscan);
@@ -119,6 +151,9 @@ __attribute__((visibility("default"))) void sim_free(sim_result* r) {
   free(r->mask);
   free(r->ent8);
   free(r->histogram);
+  free(r->dc_records);
+  free(r->dc_rec_offset);
+  free(r->dc_count);
   memset(r, 0, sizeof(*r));
 }
 

@@ -97,7 +97,7 @@ def _np(ptr, shape, dtype):
 class HotPathResult:
     """Plain numpy view of one hot-path run (oracle, simulator or GPU)."""
     __slots__ = ("quant_dc", "raw_quant", "strategy", "ytox", "ytob", "group_tokens",
-                 "xyb", "qf", "mask", "ent8", "xsize", "ysize", "histogram")
+                 "xyb", "qf", "mask", "ent8", "xsize", "ysize", "histogram", "dc_histogram", "dc_records")
 
     def all_tokens(self):
         return b"".join(self.group_tokens)
@@ -171,7 +171,9 @@ class SimResult(C.Structure):
                 ("ytob", C.POINTER(C.c_int8)), ("tokens", C.POINTER(C.c_uint8)),
                 ("group_tok_offset", C.POINTER(C.c_uint64)),
                 ("xyb", fp * 3), ("qf", fp), ("mask", fp), ("ent8", fp),
-                ("histogram", C.POINTER(C.c_uint32))]
+                ("histogram", C.POINTER(C.c_uint32)), ("dc_records", C.POINTER(C.c_uint8)),
+                ("dc_rec_offset", C.POINTER(C.c_uint64)), ("dc_count", C.POINTER(C.c_uint32)),
+                ("num_dc_groups", C.c_size_t)]
 
 
 _sim = None
@@ -270,7 +272,10 @@ def sim_hot_path(planes, distance, force_dct8=False):
     r.qf = _np(s.qf, (yb, xb), np.float32)
     r.mask = _np(s.mask, (yb, xb), np.float32)
     r.ent8 = _np(s.ent8, (yb // 2 + 1, xb // 2 + 1, 8), np.float32)
-    r.histogram = _np(s.histogram, (64, 64), np.uint32)
+    hh = _np(s.histogram, (2, 64, 64), np.uint32)
+    r.histogram, r.dc_histogram = hh[0], hh[1]
+    r.dc_records = [C.string_at(C.addressof(s.dc_records.contents) + 3 * s.dc_rec_offset[i], 3 * s.dc_count[i])
+                    for i in range(s.num_dc_groups)]
     _sim.sim_free(C.byref(s))
     return r
 
@@ -330,12 +335,38 @@ def product():
     return __graft_entry__.load_package()
 
 
+def host_dc_records(res):
+    """Raw DC-group records of the host tokeniser (jxlt_debug_dc_records) for a HotPathResult."""
+    P = product()
+    H = P.host_lib()
+    fr, keep = _frame_struct(res)
+    ndc = ((res.xsize + 2047) // 2048) * ((res.ysize + 2047) // 2048)
+    out = []
+    for i in range(ndc):
+        p, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+        assert H.jxlt_debug_dc_records(C.byref(fr), i, C.byref(p), C.byref(n)) == 0
+        out.append(C.string_at(p, n.value))
+        H.jxlt_free(p)
+    return out
+
+
 def assemble_codestream(res, distance, num_threads=1):
     """Full .jxl bytes from a HotPathResult via the product's host back-end
     (jxlt_write_file_header + jxlt_assemble_frame)."""
     P = product()
     H = P.host_lib()
     dp = P.distance_params(distance)
+    fr, keep = _frame_struct(res)
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    rc = H.jxlt_assemble_frame(C.byref(fr), C.byref(dp), num_threads, C.byref(out), C.byref(n))
+    assert rc == 0, rc
+    frame = C.string_at(out, n.value)
+    H.jxlt_free(out)
+    return P.file_header(res.xsize, res.ysize) + frame
+
+
+def _frame_struct(res):
+    P = product()
     fr = P.FrameResult()
     fr.xsize, fr.ysize = res.xsize, res.ysize
     yb, xb = res.raw_quant.shape
@@ -356,9 +387,4 @@ def assemble_codestream(res, distance, num_threads=1):
     offs[1:] = np.cumsum([len(t) for t in res.group_tokens])
     fr.tokens = blob.ctypes.data_as(C.POINTER(C.c_uint8))
     fr.group_token_offset = offs.ctypes.data_as(C.POINTER(C.c_uint64))
-    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
-    rc = H.jxlt_assemble_frame(C.byref(fr), C.byref(dp), num_threads, C.byref(out), C.byref(n))
-    assert rc == 0, rc
-    frame = C.string_at(out, n.value)
-    H.jxlt_free(out)
-    return P.file_header(res.xsize, res.ysize) + frame
+    return fr, (keep, rq, st, tx, tb, blob, offs)

@@ -63,3 +63,14 @@ def test_pack_kernel_matches_reference_packer(built, sizes):
         rec = np.stack([ctx, (val & 0xFF).astype(np.uint8), (val >> 8).astype(np.uint8)], axis=1)
         sections.append(rec.astype(np.uint8).tobytes())
     assert T.sim_pack_sections(sections, table) == T.pack_sections_python(sections, table)
+
+
+@pytest.mark.parametrize("w,h,distance", [(200, 137, 1.0), (9, 7, 1.0), (300, 264, 2.0), (2100, 40, 1.0), (64, 64, 8.0)])
+def test_dc_kernels_match_host_tokeniser(built, w, h, distance):
+    """dc_elementwise_kernel + dc_chain_kernel vs the host's WriteDCGroup restatement."""
+    planes = T.to_planes(T.synthetic_image(w, h))
+    got = T.sim_hot_path(planes, distance)
+    want = T.host_dc_records(got)
+    assert got.dc_records == want
+    h = sum((T.token_histogram(r) for r in want))
+    assert (got.dc_histogram == h).all()
