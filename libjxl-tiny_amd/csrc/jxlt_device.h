@@ -499,15 +499,16 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
   const float cost_of_1 = 1 + slope * 8.8703248061477744f;
   float entropy = 0.0f;
   float info_loss = 0.0f, info_loss2 = 0.0f;
-#pragma unroll
+  // The channel loop stays rolled (one copy of the body): the kernel must fit the
+  // instruction cache; the wave-uniform selects cost two VALU ops per coefficient.
+#pragma clang loop unroll(disable)
   for (int c = 0; c < 3; c++) {
-    const float* in_c = c == 0 ? cx : c == 1 ? cy : cb;
     const float* inv = c == 0 ? inv_x : c == 1 ? inv_y : inv_b;
     const float cmap_factor = c == 0 ? cmap_x : c == 1 ? 0.0f : cmap_b;
     float entropy_v = 0.0f, nzeros_v = 0.0f;
 #pragma unroll
     for (int r = 0; r < NR; r++) {
-      const float in = in_c[r];
+      const float in = c == 0 ? cx[r] : c == 1 ? cy[r] : cb[r];
       const float in_y = cy[r] * cmap_factor;
       const float im = inv[r * 8 + l];
       const float val = (in - in_y) * (im * quant);
@@ -549,24 +550,23 @@ JXLT_DI float adjust_quant_bias_y(int32_t quant_i) {
 // enc_group.cc:221-278 for the lane's rows.  NR = 8: xsize=ysize=1; NR = 16: xsize=2, ysize=1.
 template <int NR>
 JXLT_DI void quantize_rows(const float* in, int c, const float* inv, int l, float quantv, int* out) {
-  float thres[4] = {0.58f, 0.635f, 0.66f, 0.7f};
-  if (c == 0) {
-    thres[1] += 0.08f; thres[2] += 0.08f; thres[3] += 0.08f;
-  }
-  if (c == 2) {
-    thres[1] = 0.75f; thres[2] = 0.75f; thres[3] = 0.75f;
-  }
+  // thresholds of the four quadrants (enc_group.cc:227-242)
+  float t0 = 0.58f;
+  float t1 = c == 0 ? 0.635f + 0.08f : c == 2 ? 0.75f : 0.635f;
+  float t2 = c == 0 ? 0.66f + 0.08f : c == 2 ? 0.75f : 0.66f;
+  float t3 = c == 0 ? 0.7f + 0.08f : c == 2 ? 0.75f : 0.7f;
   if (NR == 16) {
     const float dec = 0.003f * 2 * 1;  // Clamp1(0.003f*xsize*ysize, 0, 0.08|0.12)
-#pragma unroll
-    for (int i = 0; i < 4; i++) thres[i] -= dec;
+    t0 -= dec; t1 -= dec; t2 -= dec; t3 -= dec;
   }
+  // NR == 8: the quadrant's column half depends on the lane; NR == 16: on the row parity
+  const float lo_a = (NR == 8) ? (l >= 4 ? t1 : t0) : t0, lo_b = (NR == 8) ? lo_a : t1;
+  const float hi_a = (NR == 8) ? (l >= 4 ? t3 : t2) : t2, hi_b = (NR == 8) ? hi_a : t3;
 #pragma unroll
   for (int r = 0; r < NR; r++) {
-    int tix;
-    if (NR == 8) tix = (r >= 4 ? 2 : 0) + (l >= 4 ? 1 : 0);
-    else tix = ((r >> 1) >= 4 ? 2 : 0) + (r & 1);
-    const float thr = thres[tix];
+    const bool lower_half = (NR == 8) ? (r >= 4) : ((r >> 1) >= 4);
+    const bool second = (NR == 16) && (r & 1);
+    const float thr = lower_half ? (second ? hi_b : hi_a) : (second ? lo_b : lo_a);
     const float q = inv[r * 8 + l] * quantv;
     const float val = q * in[r];
     const bool nz = fabsf(val) >= thr;
@@ -614,46 +614,9 @@ JXLT_DI void quantize_transform(float* cx, float* cy, float* cb, const TileShare
     A.quant_dc[1][pos0] = dcy_a;
     if (NR == 16) A.quant_dc[1][pos1] = dcy_b;
   }
-  int qy[NR], qx[NR], qb[NR];
-  quantize_rows<NR>(cy, 1, inv_y, l, qac * 1.0f, qy);
-  const float inv_qac = T->inv_qac[quant_ac];
-#pragma unroll
-  for (int r = 0; r < NR; r++) cy[r] = (adjust_quant_bias_y(qy[r]) * ydq[r * 8 + l]) * inv_qac;
-
-  // --- X, B: undo colour correlation with the roundtripped Y (:417-425), quantise, DC
-#pragma unroll
-  for (int r = 0; r < NR; r++) {
-    cx[r] = nfma32(x_factor, cy[r], cx[r]);
-    cb[r] = nfma32(b_factor, cy[r], cb[r]);
-  }
-  quantize_rows<NR>(cx, 0, inv_x, l, qac * A.x_qm_mul, qx);
-  quantize_rows<NR>(cb, 2, inv_b, l, qac * (float)1.0, qb);
-#pragma unroll
-  for (int c = 0; c <= 2; c += 2) {
-    const float* cc = c == 0 ? cx : cb;
-    const float c0 = __shfl(cc[0], (int)(threadIdx.x & 56) | 0, 64);
-    const float c1 = __shfl(cc[0], (int)(threadIdx.x & 56) | 1, 64);
-    float d_a, d_b = 0.0f;
-    if (NR == 8) {
-      d_a = c0;
-    } else {
-      const float b0 = c0 * 1.0f * 1.0f, b1 = c1 * 1.0f * kScale1;
-      d_a = b0 + b1;
-      d_b = b0 - b1;
-    }
-    const float inv_factor = kInvDCQuant[c] * A.scale_dc;
-    const float cfl_factor = c == 0 ? 0.0f : kInvDCQuant[2] * (1.0f / kInvDCQuant[1]);
-    if (l == 0) {
-      A.quant_dc[c][pos0] = (int16_t)roundf(d_a * inv_factor - dcy_a * cfl_factor);
-      if (NR == 16) A.quant_dc[c][pos1] = (int16_t)roundf(d_b * inv_factor - dcy_b * cfl_factor);
-    }
-  }
-
-  // --- nzeros (enc_group.cc:51-148) and staging
   const int covered = NR / 8;
-#pragma unroll
-  for (int c = 0; c < 3; c++) {
-    const int* q = c == 0 ? qx : c == 1 ? qy : qb;
+  // nzeros (enc_group.cc:51-148) + staging of one channel's quantised rows
+  auto stage_channel = [&](int c, const int* q) {
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < NR; r++) {
@@ -673,6 +636,45 @@ JXLT_DI void quantize_transform(float* cx, float* cy, float* cb, const TileShare
         A.nzgrid[c][pos1] = shifted;
       }
     }
+  };
+  {
+    int qy[NR];
+    quantize_rows<NR>(cy, 1, inv_y, l, qac * 1.0f, qy);
+    stage_channel(1, qy);
+    const float inv_qac = T->inv_qac[quant_ac];
+#pragma unroll
+    for (int r = 0; r < NR; r++) cy[r] = (adjust_quant_bias_y(qy[r]) * ydq[r * 8 + l]) * inv_qac;
+  }
+
+  // --- X, B: undo colour correlation with the roundtripped Y (:417-425), quantise, DC.
+  // Rolled loop over the two chroma channels (instruction-cache footprint).
+#pragma clang loop unroll(disable)
+  for (int c = 0; c <= 2; c += 2) {
+    const float factor = c == 0 ? x_factor : b_factor;
+    const float* inv = c == 0 ? inv_x : inv_b;
+    const float qmul = c == 0 ? A.x_qm_mul : (float)1.0;
+    float cur[NR];
+    int q[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) cur[r] = nfma32(factor, cy[r], c == 0 ? cx[r] : cb[r]);
+    quantize_rows<NR>(cur, c, inv, l, qac * qmul, q);
+    const float c0 = __shfl(cur[0], (int)(threadIdx.x & 56) | 0, 64);
+    const float c1 = __shfl(cur[0], (int)(threadIdx.x & 56) | 1, 64);
+    float d_a, d_b = 0.0f;
+    if (NR == 8) {
+      d_a = c0;
+    } else {
+      const float b0 = c0 * 1.0f * 1.0f, b1 = c1 * 1.0f * kScale1;
+      d_a = b0 + b1;
+      d_b = b0 - b1;
+    }
+    const float inv_factor = (c == 0 ? kInvDCQuant[0] : kInvDCQuant[2]) * A.scale_dc;
+    const float cfl_factor = c == 0 ? 0.0f : kInvDCQuant[2] * (1.0f / kInvDCQuant[1]);
+    if (l == 0) {
+      A.quant_dc[c][pos0] = (int16_t)roundf(d_a * inv_factor - dcy_a * cfl_factor);
+      if (NR == 16) A.quant_dc[c][pos1] = (int16_t)roundf(d_b * inv_factor - dcy_b * cfl_factor);
+    }
+    stage_channel(c, q);
   }
 }
 
@@ -938,14 +940,22 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
     const float* pxp = &S.x[(oby * 8) * kXYPitch + obx * 8 + kHalo];
     const float* pyp = &S.y[(oby * 8) * kXYPitch + obx * 8 + kHalo];
     const float* pbp = &S.b[(oby * 8) * kBPitch + obx * 8];
-    if (blk_valid) {
-      block_dct8x8(pxp, kXYPitch, l, c8x);
-      block_dct8x8(pyp, kXYPitch, l, c8y);
-      block_dct8x8(pbp, kBPitch, l, c8b);
-    } else {
-      // (cross-lane traffic never leaves an octet, so idle octets may skip it)
+#pragma clang loop unroll(disable)
+    for (int c = 0; c < 3; c++) {
+      float t[8];
+      if (blk_valid) {
+        block_dct8x8(c == 0 ? pxp : c == 1 ? pyp : pbp, c == 2 ? kBPitch : kXYPitch, l, t);
+      } else {
+        // (cross-lane traffic never leaves an octet, so idle octets may skip it)
 #pragma unroll
-      for (int r = 0; r < 8; r++) { c8x[r] = 0; c8y[r] = 0; c8b[r] = 0; }
+        for (int r = 0; r < 8; r++) t[r] = 0.0f;
+      }
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        if (c == 0) c8x[r] = t[r];
+        else if (c == 1) c8y[r] = t[r];
+        else c8b[r] = t[r];
+      }
     }
   }
   JXLT_MARK(4);
@@ -1048,14 +1058,19 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
       const float* pxp = &S.x[(cby * 8) * kXYPitch + cbx * 8 + kHalo];
       const float* pyp = &S.y[(cby * 8) * kXYPitch + cbx * 8 + kHalo];
       const float* pbp = &S.b[(cby * 8) * kBPitch + cbx * 8];
-      if (is_tall) {
-        block_dct16x8(pxp, kXYPitch, l, c16x);
-        block_dct16x8(pyp, kXYPitch, l, c16y);
-        block_dct16x8(pbp, kBPitch, l, c16b);
-      } else {
-        block_dct8x16(pxp, kXYPitch, l, c16x);
-        block_dct8x16(pyp, kXYPitch, l, c16y);
-        block_dct8x16(pbp, kBPitch, l, c16b);
+#pragma clang loop unroll(disable)
+      for (int c = 0; c < 3; c++) {
+        float t[16];
+        const float* pp = c == 0 ? pxp : c == 1 ? pyp : pbp;
+        const int pitch = c == 2 ? kBPitch : kXYPitch;
+        if (is_tall) block_dct16x8(pp, pitch, l, t);
+        else block_dct8x16(pp, pitch, l, t);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          if (c == 0) c16x[r] = t[r];
+          else if (c == 1) c16y[r] = t[r];
+          else c16b[r] = t[r];
+        }
       }
       const int o2 = is_tall ? 8 : 1;  // second covered block in the 8x8 tile grid
       const int bi = cby * 8 + cbx;
