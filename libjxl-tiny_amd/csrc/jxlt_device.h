@@ -300,9 +300,11 @@ JXLT_DI void octet_transpose(float* v, int l) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       if (j & s) continue;
-      const float send = hi ? v[j] : v[j | s];
-      const float recv = __shfl_xor(send, s);
-      if (hi) v[j] = recv; else v[j | s] = recv;
+      const float a = v[j], b = v[j | s];
+      const float recv = __shfl_xor(hi ? a : b, s);
+      // value selects (not a selected destination): keeps v[] in registers
+      v[j] = hi ? recv : a;
+      v[j | s] = hi ? b : recv;
     }
   }
 }
@@ -433,18 +435,16 @@ JXLT_DI float compute_mask(float out_val) {
 }
 
 // :296-320
+// Keeps the four smallest of {min0<=min1<=min2<=min3, v}, sorted.  Same result as the
+// reference's branchy insertion for non-NaN inputs (equal values are interchangeable).
 JXLT_DI void store_min4(float v, float& min0, float& min1, float& min2, float& min3) {
-  if (v < min3) {
-    if (v < min0) {
-      min3 = min2; min2 = min1; min1 = min0; min0 = v;
-    } else if (v < min1) {
-      min3 = min2; min2 = min1; min1 = v;
-    } else if (v < min2) {
-      min3 = min2; min2 = v;
-    } else {
-      min3 = v;
-    }
-  }
+  float t = fmaxf(min0, v);
+  min0 = fminf(min0, v);
+  float u = fmaxf(min1, t);
+  min1 = fminf(min1, t);
+  t = fmaxf(min2, u);
+  min2 = fminf(min2, u);
+  min3 = fminf(min3, t);
 }
 
 // ---------------------------------------------------------------------------
@@ -456,24 +456,28 @@ constexpr int kHalo = 5;                 // AQ: +-4 px window, +-1 px Laplacian 
 constexpr int kXYPitch = 64 + 2 * kHalo + 1;  // 75 floats (odd: conflict-free columns)
 constexpr int kBPitch = 65;
 constexpr int kPrePitch = 19;
-constexpr int kCflChunkBlocks = 4;       // blocks per CfL hand-off chunk
+constexpr int kCflTermFloats = 64 * 64 * 4;  // LDS floats overlaid by the CfL terms
 
 struct alignas(16) TileShared {
   float x[64 * kXYPitch];
   float y[64 * kXYPitch];
   float b[64 * kBPitch];
-  float inv_w[576];
-  float y_w[192];          // dequant weights of Y: [0,64) DCT8, [64,192) two-block
   float rowsum[16 * 72];   // AQ: per 4-row band, per column
   float pre_erosion[16 * kPrePitch];
   float erosion[16 * 16];
+  float cfl_pad[kCflTermFloats - (2 * 64 * kXYPitch + 64 * kBPitch + 16 * 72 + 16 * kPrePitch + 16 * 16)];
+  // ^ x..cfl_pad (64 KB) are overlaid by the chroma-from-luma terms once every pixel
+  //   read is done: 64 blocks x 64 coefficients x (a_x, b_x, a_b, b_b).
+  float inv_w[576];
+  float y_w[192];          // dequant weights of Y: [0,64) DCT8, [64,192) two-block
   float aq[64];            // quant field (tile-local 8x8)
   float mask[64];
   float ent8[16 * 8];      // candidate entropies per 2x2 cell
-  float cfl_terms[2][kCflChunkBlocks * 64 * 4];  // (m_x, s_x, m_b, s_b) per coefficient
+  float cfl_sum[4];        // ca_x, cb_x, ca_b, cb_b
   int cmap[2];             // ytox, ytob
   uint8_t raw_quant[64];
   uint8_t strat[64];
+  uint8_t order[192];      // coefficient scan orders (enc_group.cc:166-183)
   uint32_t ntok;
   uint32_t nfirst;
 };
@@ -627,13 +631,16 @@ JXLT_DI void quantize_transform(float* cx, float* cy, float* cb, const TileShare
     }
     const int nzeros = octet_sum_int(cnt);
     if (l == 0) {
+      // (select, not A.nzgrid[c]: indexing a kernel-argument array by a runtime value
+      // would force the argument block into scratch memory)
+      uint8_t* nzg = c == 0 ? A.nzgrid[0] : c == 1 ? A.nzgrid[1] : A.nzgrid[2];
       A.blk_nz[pos0 * 3 + c] = (uint8_t)nzeros;
       if (NR == 8) {
-        A.nzgrid[c][pos0] = (uint8_t)nzeros;
+        nzg[pos0] = (uint8_t)nzeros;
       } else {
         const uint8_t shifted = (uint8_t)((nzeros + 1) >> 1);
-        A.nzgrid[c][pos0] = shifted;
-        A.nzgrid[c][pos1] = shifted;
+        nzg[pos0] = shifted;
+        nzg[pos1] = shifted;
       }
     }
   };
@@ -671,8 +678,9 @@ JXLT_DI void quantize_transform(float* cx, float* cy, float* cb, const TileShare
     const float inv_factor = (c == 0 ? kInvDCQuant[0] : kInvDCQuant[2]) * A.scale_dc;
     const float cfl_factor = c == 0 ? 0.0f : kInvDCQuant[2] * (1.0f / kInvDCQuant[1]);
     if (l == 0) {
-      A.quant_dc[c][pos0] = (int16_t)roundf(d_a * inv_factor - dcy_a * cfl_factor);
-      if (NR == 16) A.quant_dc[c][pos1] = (int16_t)roundf(d_b * inv_factor - dcy_b * cfl_factor);
+      int16_t* qdc = c == 0 ? A.quant_dc[0] : A.quant_dc[2];
+      qdc[pos0] = (int16_t)roundf(d_a * inv_factor - dcy_a * cfl_factor);
+      if (NR == 16) qdc[pos1] = (int16_t)roundf(d_b * inv_factor - dcy_b * cfl_factor);
     }
     stage_channel(c, q);
   }
@@ -715,23 +723,46 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
     S.ntok = 0;
     S.nfirst = 0;
   }
+  if (tid < 192) S.order[tid] = T->coeff_order[tid];
   {
+    // Two batches of five pixels per thread: all fifteen global loads of a batch are
+    // issued before the first use so that their HBM latencies overlap.
     const int base = px0 - kHalo;  // stripe x of LDS column 0
-    for (int i = tid; i < 64 * (64 + 2 * kHalo); i += kTileThreads) {
-      const int y = i / (64 + 2 * kHalo), cx = i % (64 + 2 * kHalo);
-      const int x = base + cx;
-      if (y >= shp || x < 0 || x >= swp || x >= px0 + nbx * 8 + kHalo) continue;
-      const size_t src = (size_t)(sy0 + imin(y, sh - 1)) * A.pitch + (size_t)(sx0 + imin(x, sw - 1));
-      float vx, vy, vb;
-      linear_to_xyb(A.planes[0][src], A.planes[1][src], A.planes[2][src], &vx, &vy, &vb);
-      S.x[y * kXYPitch + cx] = vx;
-      S.y[y * kXYPitch + cx] = vy;
-      if (cx >= kHalo && cx < kHalo + 64) S.b[y * kBPitch + cx - kHalo] = vb;
-      if (A.dbg_xyb[0] && cx >= kHalo && cx < kHalo + nbx * 8) {
-        const size_t d = (size_t)(by_img0 * 8 + y) * (bstride * 8) + (size_t)(bx_img0 * 8 + cx - kHalo);
-        A.dbg_xyb[0][d] = vx;
-        A.dbg_xyb[1][d] = vy;
-        A.dbg_xyb[2][d] = vb;
+    constexpr int kWin = 64 + 2 * kHalo;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      float pr[5], pg[5], pb[5];
+      int py[5], pcx[5];
+      bool ok[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        const int i = tid + (h * 5 + k) * kTileThreads;
+        const int y = i / kWin, cx = i % kWin;
+        const int x = base + cx;
+        ok[k] = i < 64 * kWin && y < shp && x >= 0 && x < swp && x < px0 + nbx * 8 + kHalo;
+        py[k] = y;
+        pcx[k] = cx;
+        const int ys = ok[k] ? imin(y, sh - 1) : 0, xs = ok[k] ? imin(x, sw - 1) : 0;
+        const size_t src = (size_t)(sy0 + ys) * A.pitch + (size_t)(sx0 + xs);
+        pr[k] = A.planes[0][src];
+        pg[k] = A.planes[1][src];
+        pb[k] = A.planes[2][src];
+      }
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        if (!ok[k]) continue;
+        const int y = py[k], cx = pcx[k];
+        float vx, vy, vb;
+        linear_to_xyb(pr[k], pg[k], pb[k], &vx, &vy, &vb);
+        S.x[y * kXYPitch + cx] = vx;
+        S.y[y * kXYPitch + cx] = vy;
+        if (cx >= kHalo && cx < kHalo + 64) S.b[y * kBPitch + cx - kHalo] = vb;
+        if (A.dbg_xyb[0] && cx >= kHalo && cx < kHalo + nbx * 8) {
+          const size_t d = (size_t)(by_img0 * 8 + y) * (bstride * 8) + (size_t)(bx_img0 * 8 + cx - kHalo);
+          A.dbg_xyb[0][d] = vx;
+          A.dbg_xyb[1][d] = vy;
+          A.dbg_xyb[2][d] = vb;
+        }
       }
     }
   }
@@ -806,7 +837,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
       const float* row = &S.pre_erosion[y * kPrePitch];
       const float* rowb = &S.pre_erosion[yp1 * kPrePitch];
       float min0 = row[x], min1 = row[xm1], min2 = row[xp1], min3 = rowt[xm1], t;
-#define JXLT_SWAP_GT(a, b) if (a > b) { t = a; a = b; b = t; }
+#define JXLT_SWAP_GT(a, b) { t = fminf(a, b); b = fmaxf(a, b); a = t; }
       JXLT_SWAP_GT(min0, min1);
       JXLT_SWAP_GT(min0, min2);
       JXLT_SWAP_GT(min0, min3);
@@ -959,77 +990,10 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
     }
   }
   JXLT_MARK(4);
-  {
-    // Sequential per-lane fma chains over the tile's blocks in raster order; the
-    // terms are handed to wave 0 through LDS in chunks of kCflChunkBlocks blocks.
-    const float* qm_x = S.inv_w + 0;        // InvMatrix(DCT, 0)
-    const float* qm_b = S.inv_w + 128;      // InvMatrix(DCT, 2)
-    const int nblk = nbx * nby;             // valid blocks, raster order index
-    const int my_seq = blk_valid ? oby * nbx + obx : -1;
-    const int nchunks = (nblk + kCflChunkBlocks - 1) / kCflChunkBlocks;
-    float ca = 0.0f, cb = 0.0f;             // tid < 32: chain (stream = tid>>4, kind = (tid>>3)&1)
-    for (int ch = 0; ch <= nchunks; ch++) {
-      // Phase ch: the octets of chunk ch publish their terms into buffer ch&1
-      // while the chain lanes consume chunk ch-1 from buffer (ch-1)&1.
-      if (ch < nchunks && my_seq >= ch * kCflChunkBlocks && my_seq < (ch + 1) * kCflChunkBlocks) {
-        float* dst = &S.cfl_terms[ch & 1][(my_seq - ch * kCflChunkBlocks) * 256];
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-          const bool dc = (r == 0 && l == 0);  // block_*[0] = 0 (:109-111)
-          const float by_ = dc ? 0.0f : c8y[r], bx_ = dc ? 0.0f : c8x[r], bb_ = dc ? 0.0f : c8b[r];
-          const float qx = qm_x[r * 8 + l], qb = qm_b[r * 8 + l];
-          float4 t;
-          t.x = by_ * qx;  // coeffs_yx
-          t.y = bx_ * qx;  // coeffs_x
-          t.z = by_ * qb;  // coeffs_yb
-          t.w = bb_ * qb;  // coeffs_b
-          *(float4*)&dst[(r * 8 + l) * 4] = t;
-        }
-      }
-      if (ch >= 1 && tid < 16) {
-        // chunk ch-1: lanes 0-7 -> X stream, 8-15 -> B stream; each runs ca and cb.
-        const int stream = tid >> 3;
-        const float base = stream == 0 ? 0.0f : 1.0f;
-        const float kInvColorFactor = 1.0f / 84;
-        const int cbeg = (ch - 1) * kCflChunkBlocks;
-        const int cn = imin(kCflChunkBlocks, nblk - cbeg);
-        const float* src = &S.cfl_terms[(ch - 1) & 1][0];
-        for (int k = 0; k < cn * 8; k++) {
-          const float4 t = *(const float4*)&src[(k * 8 + l) * 4];
-          const float m = stream == 0 ? t.x : t.z;
-          const float sv = stream == 0 ? t.y : t.w;
-          const float a = kInvColorFactor * m;
-          const float b = base * m - sv;
-          ca = fma32(a, a, ca);
-          cb = fma32(a, b, cb);
-        }
-      }
-      __syncthreads();
-    }
-    // FindBestMultiplier tail (:56-61)
-    const float sum_ca = octet_sum(ca), sum_cb = octet_sum(cb);
-    if (tid < 16 && l == 0) {
-      const float kDistanceMultiplierAC = 1e-3f;
-      const float num = (float)(nblk * 64);
-      float xq = -sum_cb / (sum_ca + num * kDistanceMultiplierAC * 0.5f);
-      xq = fmaxf(-128.0f, fminf(127.0f, roundf(xq)));
-      S.cmap[tid >> 3] = (int)xq;
-    }
-  }
-  __syncthreads();
-  JXLT_MARK(5);
-  const int ytox = S.cmap[0], ytob = S.cmap[1];
-  const float kInvColorFactorF = 1.0f / 84;
-  const float cmap_x = (float)ytox * kInvColorFactorF;           // YtoXRatio
-  const float cmap_b = 1.0f + (float)ytob * kInvColorFactorF;    // YtoBRatio
-  if (tid == 0) {
-    A.ytox[(size_t)ty_img * A.g.xsize_tiles + tx_img] = (int8_t)ytox;
-    A.ytob[(size_t)ty_img * A.g.xsize_tiles + tx_img] = (int8_t)ytob;
-  }
-
-  // ---- P6: strategy search (enc_ac_strategy.cc:51-238) ----------------------
-  // Candidate two-block transforms: waves 0-3 take the 32 DCT16X8 candidates,
-  // waves 4-7 the 32 DCT8X16 candidates; coefficients stay in registers for P8.
+  // ---- P6a: candidate two-block transforms (enc_ac_strategy.cc:62-66) -------
+  // Waves 0-3 take the 32 DCT16X8 candidates, waves 4-7 the 32 DCT8X16 candidates.
+  // Done before chroma-from-luma so that afterwards no pixel is needed any more; the
+  // coefficients stay in registers for the entropy estimate and for P8.
   float c16x[16], c16y[16], c16b[16];
   const bool search = (A.flags & 1u) == 0;
   const int cand = oct & 31;           // candidate index within its type
@@ -1039,6 +1003,90 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
   const int cbx = is_tall ? ccx + (cand & 1) : ccx;       // candidate's first block
   const int cby = is_tall ? ccy : ccy + (cand & 1);
   const bool cell_valid = search && (ccx + 1 < nbx) && (ccy + 1 < nby);
+  if (cell_valid) {
+    const float* pxp = &S.x[(cby * 8) * kXYPitch + cbx * 8 + kHalo];
+    const float* pyp = &S.y[(cby * 8) * kXYPitch + cbx * 8 + kHalo];
+    const float* pbp = &S.b[(cby * 8) * kBPitch + cbx * 8];
+#pragma clang loop unroll(disable)
+    for (int c = 0; c < 3; c++) {
+      float t[16];
+      const float* pp = c == 0 ? pxp : c == 1 ? pyp : pbp;
+      const int pitch = c == 2 ? kBPitch : kXYPitch;
+      if (is_tall) block_dct16x8(pp, pitch, l, t);
+      else block_dct8x16(pp, pitch, l, t);
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        if (c == 0) c16x[r] = t[r];
+        else if (c == 1) c16y[r] = t[r];
+        else c16b[r] = t[r];
+      }
+    }
+  }
+  __syncthreads();  // all pixel reads done: the planes are dead from here on
+  JXLT_MARK(5);
+  // ---- P5b: chroma-from-luma (enc_chroma_from_luma.cc:40-131) ----------------
+  {
+    // Every octet publishes the terms of its block, a = m/84 and b = base*m - s with
+    // m = Y*qm, s = C*qm (:49-53,117-120), then 32 lanes run the four sequential
+    // per-lane fma chains (ca, cb for X and B) over the blocks in raster order.
+    float* terms = &S.x[0];
+    const float* qm_x = S.inv_w + 0;    // InvMatrix(DCT, 0)
+    const float* qm_b = S.inv_w + 128;  // InvMatrix(DCT, 2)
+    const int nblk = nbx * nby;
+    const float kInvColorFactor = 1.0f / 84;
+    if (blk_valid) {
+      float* dst = &terms[(oby * nbx + obx) * 256];
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const bool dc = (r == 0 && l == 0);  // block_*[0] = 0 (:109-111)
+        const float by_ = dc ? 0.0f : c8y[r], bx_ = dc ? 0.0f : c8x[r], bb_ = dc ? 0.0f : c8b[r];
+        const float qx = qm_x[r * 8 + l], qb = qm_b[r * 8 + l];
+        const float m_x = by_ * qx, s_x = bx_ * qx, m_b = by_ * qb, s_b = bb_ * qb;
+        float4 t;
+        t.x = kInvColorFactor * m_x;
+        t.y = 0.0f * m_x - s_x;
+        t.z = kInvColorFactor * m_b;
+        t.w = 1.0f * m_b - s_b;
+        *(float4*)&dst[(r * 8 + l) * 4] = t;
+      }
+    }
+    __syncthreads();
+    float acc = 0.0f;
+    if (tid < 32) {
+      const int kind = tid >> 3;  // 0: ca_x, 1: cb_x, 2: ca_b, 3: cb_b
+      const bool is_cb = (kind & 1) != 0;
+      const float* src = terms + (kind >> 1) * 2 + l * 4;
+#pragma clang loop unroll(disable)
+      for (int blk = 0; blk < nblk; blk++) {
+        float2 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) v[r] = *(const float2*)&src[(blk * 64 + r * 8) * 4];
+#pragma unroll
+        for (int r = 0; r < 8; r++) acc = fma32(v[r].x, is_cb ? v[r].y : v[r].x, acc);
+      }
+    }
+    const float total = octet_sum(acc);
+    if (tid < 32 && l == 0) S.cfl_sum[tid >> 3] = total;
+    __syncthreads();
+    if (tid < 2) {  // FindBestMultiplier tail (:56-61)
+      const float kDistanceMultiplierAC = 1e-3f;
+      const float num = (float)(nblk * 64);
+      float xq = -S.cfl_sum[tid * 2 + 1] / (S.cfl_sum[tid * 2] + num * kDistanceMultiplierAC * 0.5f);
+      xq = fmaxf(-128.0f, fminf(127.0f, roundf(xq)));
+      S.cmap[tid] = (int)xq;
+    }
+  }
+  __syncthreads();
+  const int ytox = S.cmap[0], ytob = S.cmap[1];
+  const float kInvColorFactorF = 1.0f / 84;
+  const float cmap_x = (float)ytox * kInvColorFactorF;           // YtoXRatio
+  const float cmap_b = 1.0f + (float)ytob * kInvColorFactorF;    // YtoBRatio
+  if (tid == 0) {
+    A.ytox[(size_t)ty_img * A.g.xsize_tiles + tx_img] = (int8_t)ytox;
+    A.ytob[(size_t)ty_img * A.g.xsize_tiles + tx_img] = (int8_t)ytob;
+  }
+
+  // ---- P6b: entropy estimates (enc_ac_strategy.cc:68-146,187-212) -----------
   if (search) {
     // DCT8 estimate for this octet's own block
     if (blk_valid) {
@@ -1053,25 +1101,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
       e8 += mul8x8 * e;
       if (l == 0) S.ent8[((oby >> 1) * 4 + (obx >> 1)) * 8 + (oby & 1) * 2 + (obx & 1)] = e8;
     }
-    // Two-block candidate
     if (cell_valid) {
-      const float* pxp = &S.x[(cby * 8) * kXYPitch + cbx * 8 + kHalo];
-      const float* pyp = &S.y[(cby * 8) * kXYPitch + cbx * 8 + kHalo];
-      const float* pbp = &S.b[(cby * 8) * kBPitch + cbx * 8];
-#pragma clang loop unroll(disable)
-      for (int c = 0; c < 3; c++) {
-        float t[16];
-        const float* pp = c == 0 ? pxp : c == 1 ? pyp : pbp;
-        const int pitch = c == 2 ? kBPitch : kXYPitch;
-        if (is_tall) block_dct16x8(pp, pitch, l, t);
-        else block_dct8x16(pp, pitch, l, t);
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          if (c == 0) c16x[r] = t[r];
-          else if (c == 1) c16y[r] = t[r];
-          else c16b[r] = t[r];
-        }
-      }
       const int o2 = is_tall ? 8 : 1;  // second covered block in the 8x8 tile grid
       const int bi = cby * 8 + cbx;
       const float quant = fmaxf(fmaxf(0.0f, S.aq[bi]), S.aq[bi + o2]);
@@ -1170,7 +1200,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
       const int st = a >> 1;
       const int covered = st == 0 ? 1 : 2;
       const int o2 = st == 1 ? 8 : 1;
-      const uint8_t* order = &T->coeff_order[st == 0 ? 0 : 64];
+      const uint8_t* order = &S.order[st == 0 ? 0 : 64];
       const size_t pos0 = (size_t)(by_img0 + by) * bstride + bx_img0 + bx;
       const size_t pos1 = pos0 + (st == 1 ? bstride : 1);
       int nscan = 0;

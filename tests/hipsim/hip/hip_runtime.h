@@ -37,6 +37,9 @@ struct dim3 {
   unsigned x, y, z;
   dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
+struct float2 {
+  float x, y;
+} __attribute__((aligned(8)));
 struct float4 {
   float x, y, z, w;
 } __attribute__((aligned(16)));
