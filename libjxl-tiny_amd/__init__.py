@@ -156,6 +156,30 @@ def _take_bytes(ptr, n):
     return data
 
 
+class NativeBytes:
+    """A codestream living in a malloc'ed buffer of libjxltiny_host.so."""
+
+    def __init__(self, ptr, size):
+        self.ptr, self.size = ptr, size
+
+    def __len__(self):
+        return self.size
+
+    def tobytes(self):
+        return C.string_at(self.ptr, self.size)
+
+    def free(self):
+        if self.ptr:
+            host_lib().jxlt_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def file_header(xsize, ysize):
     out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
     if host_lib().jxlt_write_file_header(xsize, ysize, C.byref(out), C.byref(n)) != 0:
@@ -280,16 +304,17 @@ class Encoder:
             raise JxlTinyError("jxlt_assemble_frame failed (%d)" % rc)
         return _take_bytes(out, n)
 
-    def encode_resident(self, distance, num_threads=0):
+    def encode_resident(self, distance, num_threads=0, copy=True):
         """Full codestream of the image currently set/uploaded on the device (production path:
-        device pipeline + device section packing + host assembly, jxlt_encode_resident)."""
+        device pipeline + device section packing + host assembly, jxlt_encode_resident).
+        copy=False returns a NativeBytes handle on the malloc'ed result (no Python copy)."""
         out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
         rc = host_lib().jxlt_encode_resident(self._ctx, C.c_float(distance), num_threads, C.byref(out),
                                              C.byref(n))
         if rc != 0:
             raise JxlTinyError("jxlt_encode_resident failed (%d): %s" %
                                (rc, self._L.jxlt_last_error(self._ctx).decode()))
-        return _take_bytes(out, n)
+        return _take_bytes(out, n) if copy else NativeBytes(out, n.value)
 
     def encode_resident_raw_tokens(self, distance, num_threads=0, flags=0):
         """Same result through the raw-token route (tokens copied to the host and packed there)."""

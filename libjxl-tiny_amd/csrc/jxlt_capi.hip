@@ -151,6 +151,11 @@ int CheckImageArgs(jxlt_context* ctx, const void* const planes[3], size_t pitch_
     ctx->error = "invalid image arguments";
     return JXLT_ERR_INVALID_ARGUMENT;
   }
+  if (((xsize + 7) / 8) * ((ysize + 7) / 8) > (size_t(1) << 24)) {
+    // the kernels index blocks with 32 bits (2^24 blocks = 1 Gpixel per frame)
+    ctx->error = "frames above 2^24 8x8 blocks are not supported by the device path";
+    return JXLT_ERR_UNSUPPORTED;
+  }
   if (xsize <= 8 && ysize <= 8) {
     // The reference traps on images that fit a single 8x8 block.
     ctx->error = "images of at most one 8x8 block are not supported";

@@ -313,17 +313,20 @@ JXLT_DI void octet_transpose(float* v, int l) {
 // of row pitch `pitch`; l = lane within the octet.  Results are the lane's
 // "rows of 8": coefficient index i = r*8 + l (the reference's SIMD layout).
 
+// The reference scales by 1/N after each 1-D pass (StoreToBlockAndScale, :387-390).  Those
+// factors are powers of two, and scaling by a power of two commutes exactly with every
+// rounded add/mul/fma of the second pass (no over/underflow at these magnitudes: pixel
+// differences are 0 or >= 1 ulp of O(0.1) values), so both are applied once at the end.
+
 // ComputeScaledDCT<8,8> (enc_transforms-inl.h:527-546): i = h*8 + v
 JXLT_DI void block_dct8x8(const float* px, int pitch, int l, float* c) {
 #pragma unroll
   for (int y = 0; y < 8; y++) c[y] = px[y * pitch + l];
   dct8(c);
-#pragma unroll
-  for (int y = 0; y < 8; y++) c[y] = (1.0f / 8) * c[y];
-  octet_transpose(c, l);  // lane v now holds A[v][x], x = 0..7
+  octet_transpose(c, l);  // lane v now holds 8*A[v][x], x = 0..7
   dct8(c);
 #pragma unroll
-  for (int y = 0; y < 8; y++) c[y] = (1.0f / 8) * c[y];  // c[h] = C[h][v=l]
+  for (int y = 0; y < 8; y++) c[y] = (1.0f / 64) * c[y];  // c[h] = C[h][v=l]
 }
 
 // ComputeScaledDCT<16,8>: 16 rows x 8 cols, i = h*16 + v; r = 2h + (v>=8), lane = v&7
@@ -335,8 +338,8 @@ JXLT_DI void block_dct16x8(const float* px, int pitch, int l, float* c) {
   float lo[8], hi[8];
 #pragma unroll
   for (int v = 0; v < 8; v++) {
-    lo[v] = (1.0f / 16) * col[v];
-    hi[v] = (1.0f / 16) * col[v + 8];
+    lo[v] = col[v];
+    hi[v] = col[v + 8];
   }
   octet_transpose(lo, l);  // lane t: A[t][x]
   octet_transpose(hi, l);  // lane t: A[t+8][x]
@@ -344,8 +347,8 @@ JXLT_DI void block_dct16x8(const float* px, int pitch, int l, float* c) {
   dct8(hi);
 #pragma unroll
   for (int h = 0; h < 8; h++) {
-    c[2 * h] = (1.0f / 8) * lo[h];
-    c[2 * h + 1] = (1.0f / 8) * hi[h];
+    c[2 * h] = (1.0f / 128) * lo[h];
+    c[2 * h + 1] = (1.0f / 128) * hi[h];
   }
 }
 
@@ -359,11 +362,6 @@ JXLT_DI void block_dct8x16(const float* px, int pitch, int l, float* c) {
   }
   dct8(lo);
   dct8(hi);
-#pragma unroll
-  for (int v = 0; v < 8; v++) {
-    lo[v] = (1.0f / 8) * lo[v];
-    hi[v] = (1.0f / 8) * hi[v];
-  }
   octet_transpose(lo, l);  // lane v: A[v][x], x < 8
   octet_transpose(hi, l);  // lane v: A[v][x], x >= 8
   float row[16];
@@ -375,8 +373,8 @@ JXLT_DI void block_dct8x16(const float* px, int pitch, int l, float* c) {
   dct16(row);
 #pragma unroll
   for (int h = 0; h < 8; h++) {
-    lo[h] = (1.0f / 16) * row[h];
-    hi[h] = (1.0f / 16) * row[h + 8];
+    lo[h] = (1.0f / 128) * row[h];
+    hi[h] = (1.0f / 128) * row[h + 8];
   }
   octet_transpose(lo, l);  // lane t: C[v][h=t], v = 0..7
   octet_transpose(hi, l);  // lane t: C[v][h=t+8]
@@ -522,6 +520,8 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
       info_loss2 = fma32(diff, diff, info_loss2);
       const float q = fabsf(rval);
       entropy_v = entropy_v + (q >= 1.5f ? kCost2 : 0.0f);
+      // (a 64-entry LDS table of sqrtf(i) was tried here and measured slower: the random
+      // LDS reads and the extra register pressure cost more than the IEEE sqrt sequence)
       entropy_v = fma32(sqrtf(q), kCostDelta, entropy_v);
       nzeros_v = nzeros_v + (q == 0.0f ? 0.0f : 1.0f);
     }
@@ -594,9 +594,10 @@ JXLT_DI void quantize_transform(float* cx, float* cy, float* cb, const TileShare
   const float kInvDCQuant[3] = {4096.0f, 512.0f, 256.0f};
   const float kScale1 = (float)0.901764195028874394;
   const float qac = A.scale * quant_ac;
-  const size_t bstride = (size_t)A.g.xsize_blocks;
-  const size_t pos0 = (size_t)iby * bstride + ibx;
-  const size_t pos1 = pos0 + (strategy == 1 ? bstride : 1);
+  // 32-bit block indices (the C ABI limits a frame to 2^24 blocks): one VGPR per address
+  const uint32_t bstride = (uint32_t)A.g.xsize_blocks;
+  const uint32_t pos0 = (uint32_t)iby * bstride + (uint32_t)ibx;
+  const uint32_t pos1 = pos0 + (strategy == 1 ? bstride : 1u);
 
   // --- Y: DC from the unquantised transform, then quantise + roundtrip (:392-409)
   float dc_a, dc_b = 0.0f;
@@ -713,7 +714,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
   const int bx_img0 = gx * 32 + tbx0, by_img0 = ty_img * 8; // image-absolute block origin
   const int obx = oct & 7, oby = oct >> 3;                  // octet's block in the tile
   const bool blk_valid = obx < nbx && oby < nby;
-  const size_t bstride = (size_t)A.g.xsize_blocks;
+  const uint32_t bstride = (uint32_t)A.g.xsize_blocks;
 
   // ---- P0: tables -> LDS; load + XYB (enc_frame.cc:597-617, enc_xyb.cc) -----
   for (int i = tid; i < 576; i += kTileThreads) S.inv_w[i] = T->inv_weights[i];
@@ -758,7 +759,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
         S.y[y * kXYPitch + cx] = vy;
         if (cx >= kHalo && cx < kHalo + 64) S.b[y * kBPitch + cx - kHalo] = vb;
         if (A.dbg_xyb[0] && cx >= kHalo && cx < kHalo + nbx * 8) {
-          const size_t d = (size_t)(by_img0 * 8 + y) * (bstride * 8) + (size_t)(bx_img0 * 8 + cx - kHalo);
+          const size_t d = (size_t)(by_img0 * 8 + y) * ((size_t)bstride * 8) + (size_t)(bx_img0 * 8 + cx - kHalo);
           A.dbg_xyb[0][d] = vx;
           A.dbg_xyb[1][d] = vy;
           A.dbg_xyb[2][d] = vb;
@@ -954,7 +955,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
         S.raw_quant[oct] = (uint8_t)v;
         S.strat[oct] = 1;  // DCT8, first block (FillDCT8)
         if (A.dbg_qf) {
-          const size_t pos = (size_t)(by_img0 + oby) * bstride + bx_img0 + obx;
+          const uint32_t pos = (uint32_t)(by_img0 + oby) * bstride + (uint32_t)(bx_img0 + obx);
           A.dbg_qf[pos] = qf;
           A.dbg_mask[pos] = S.mask[oct];
         }
@@ -1155,7 +1156,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
   }
   __syncthreads();
   if (tid < 64 && (tid & 7) < nbx && (tid >> 3) < nby) {
-    const size_t pos = (size_t)(by_img0 + (tid >> 3)) * bstride + bx_img0 + (tid & 7);
+    const uint32_t pos = (uint32_t)(by_img0 + (tid >> 3)) * bstride + (uint32_t)(bx_img0 + (tid & 7));
     A.strategy[pos] = S.strat[tid];
     if (S.strat[tid] & 1) atomicAdd(&S.nfirst, 1u);
     A.raw_quant[pos] = S.raw_quant[tid];
@@ -1201,8 +1202,8 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
       const int covered = st == 0 ? 1 : 2;
       const int o2 = st == 1 ? 8 : 1;
       const uint8_t* order = &S.order[st == 0 ? 0 : 64];
-      const size_t pos0 = (size_t)(by_img0 + by) * bstride + bx_img0 + bx;
-      const size_t pos1 = pos0 + (st == 1 ? bstride : 1);
+      const uint32_t pos0 = (uint32_t)(by_img0 + by) * bstride + (uint32_t)(bx_img0 + bx);
+      const uint32_t pos1 = pos0 + (st == 1 ? bstride : 1u);
       int nscan = 0;
       for (int half = 0; half < covered; half++) {
         const int k = half * 64 + lane;
@@ -1265,12 +1266,15 @@ __global__ void group_scan_kernel(const uint32_t* counts, uint64_t* offsets, int
 // ---------------------------------------------------------------------------
 // Token kernel: one workgroup per 256x256 group (enc_group.cc:444-494)
 // ---------------------------------------------------------------------------
-constexpr int kTokenThreads = 256;
+constexpr int kTokenThreads = 512;
 
 __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A) {
-  __shared__ uint32_t offs[3072 + 1];
+  __shared__ uint32_t offs[3072 + 1];   // token offset of every (block, channel) entry
+  __shared__ uint32_t meta[3072];       // strategy byte | nzeros << 8 | nscan << 16
   __shared__ uint32_t wsum[kTokenThreads / 64];
   __shared__ uint32_t hist[64 * 64];
+  __shared__ uint16_t s_nnz_ctx[64], s_freq_ctx[64];
+  __shared__ uint8_t s_ctx_map[1980];
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const DeviceTables* T = A.tab;
@@ -1278,26 +1282,33 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   const bool do_hist = A.histogram != nullptr;
   if (do_hist)
     for (int i = tid; i < 64 * 64; i += kTokenThreads) hist[i] = 0;
+  for (int i = tid; i < 1980; i += kTokenThreads) s_ctx_map[i] = T->ac_context_map[i];
+  if (tid < 64) {
+    s_nnz_ctx[tid] = T->nnz_context[tid];
+    s_freq_ctx[tid] = T->freq_context[tid];
+  }
   const int ggx = group % A.g.xsize_groups, ggy = group / A.g.xsize_groups;
   const int bx0 = ggx * 32, by0 = ggy * 32;
   const int nbx = imin(32, A.g.xsize_blocks - bx0), nby = imin(32, A.g.ysize_blocks - by0);
   const size_t bstride = (size_t)A.g.xsize_blocks;
   const int nent = nbx * nby * 3;  // entries in stream order: (by, bx, ci), channels Y, X, B
 
-  // token count per entry
+  // token count + metadata per entry
   for (int e = tid; e < nent; e += kTokenThreads) {
     const int ci = e % 3, b = e / 3;
     const int bx = b % nbx, by = b / nbx;
     const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
     const size_t pos = (size_t)(by0 + by) * bstride + bx0 + bx;
-    const uint8_t a = A.strategy[pos];
-    uint32_t n = 0;
+    const uint32_t a = A.strategy[pos];
+    uint32_t n = 0, m = a;
     if (a & 1) {
       const int covered = (a >> 1) == 0 ? 1 : 2;
-      const int nscan = A.blk_nscan[pos * 3 + c];
-      n = 1 + (nscan > covered ? nscan - covered : 0);
+      const uint32_t nscan = A.blk_nscan[pos * 3 + c];
+      n = 1 + (nscan > (uint32_t)covered ? nscan - covered : 0);
+      m = a | ((uint32_t)A.blk_nz[pos * 3 + c] << 8) | (nscan << 16);
     }
     offs[e + 1] = n;
+    meta[e] = m;
   }
   if (tid == 0) offs[0] = 0;
   __syncthreads();
@@ -1307,7 +1318,6 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     const int beg = 1 + tid * per, end = imin(1 + nent, beg + per);
     uint32_t s = 0;
     for (int i = beg; i < end; i++) s += offs[i];
-    // scan of per-thread sums: wave scan + cross-wave
     uint32_t incl = s;
     for (int d = 1; d < 64; d <<= 1) {
       const uint32_t o = __shfl_up(incl, d);
@@ -1326,36 +1336,48 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   __syncthreads();
 
   uint8_t* out = A.tokens + 3 * A.group_tok_offset[group];
-  // one wave per entry
-  for (int e = wave; e < nent; e += kTokenThreads / 64) {
+  constexpr int kWaves = kTokenThreads / 64;
+  // One wave per entry, lane = scan position.  The coefficients of the wave's next entry
+  // are requested before the current one is processed (HBM latency overlap).
+  auto entry_coef_ptr = [&](int e) -> const int16_t* {
+    const int ci = e % 3, b = e / 3;
+    const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
+    const size_t pos = (size_t)(by0 + b / nbx) * bstride + bx0 + b % nbx;
+    return A.coef_scan + (pos * 3 + c) * 64;
+  };
+  int16_t next_v = 0;
+  if (wave < nent) next_v = entry_coef_ptr(wave)[lane];
+  for (int e = wave; e < nent; e += kWaves) {
+    const int16_t v0 = next_v;
+    if (e + kWaves < nent) next_v = entry_coef_ptr(e + kWaves)[lane];
+    const uint32_t m = meta[e];
+    if (!(m & 1)) continue;
     const int ci = e % 3, b = e / 3;
     const int bx = b % nbx, by = b / nbx;
     const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
     const size_t pos = (size_t)(by0 + by) * bstride + bx0 + bx;
-    const uint8_t a = A.strategy[pos];
-    if (!(a & 1)) continue;
-    const int st = a >> 1;
+    const int st = (int)((m >> 1) & 0x7F);
     const int covered = st == 0 ? 1 : 2;
     const int log2c = covered == 1 ? 0 : 1;
     const int size = covered * 64;
     const size_t pos1 = pos + (st == 1 ? bstride : 1);
     const uint32_t tok0 = offs[e];
-    const int nzeros = A.blk_nz[pos * 3 + c];
-    const int nscan = A.blk_nscan[pos * 3 + c];
-    // block context (ac_context.h:64-114)
-    const int code = st == 0 ? 0 : st == 1 ? 6 : 7;
-    const int block_ctx = T->block_context_map[c * 27 + code];
+    const int nzeros = (int)((m >> 8) & 0xFF);
+    const int nscan = (int)(m >> 16);
+    // block context (ac_context.h:64-114): kBlockContextMap[c*27 + code] is 0/1 for Y and
+    // 2/3 for X,B, the odd value for the two-block strategy codes 6 and 7
+    const int block_ctx = (c == 1 ? 0 : 2) + (st == 0 ? 0 : 1);
     if (lane == 0) {
       // PredictFromTopAndLeft (enc_group.cc:150-160), default 32
       int pred;
-      const uint8_t* nzg = A.nzgrid[c];
+      const uint8_t* nzg = c == 0 ? A.nzgrid[0] : c == 1 ? A.nzgrid[1] : A.nzgrid[2];
       if (bx == 0) pred = by == 0 ? 32 : nzg[pos - bstride];
       else if (by == 0) pred = nzg[pos - 1];
       else pred = (nzg[pos - bstride] + nzg[pos - 1] + 1) / 2;
       const int bucket = pred < 8 ? pred : pred >= 64 ? 36 : 4 + pred / 2;
       const int ctx = bucket * 4 + block_ctx;
       uint8_t* o = out + 3 * (size_t)tok0;
-      const uint8_t cm = T->ac_context_map[ctx];
+      const uint8_t cm = s_ctx_map[ctx];
       o[0] = cm;
       o[1] = (uint8_t)(nzeros & 0xFF);
       o[2] = (uint8_t)(nzeros >> 8);
@@ -1369,26 +1391,27 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     const int histo_offset = 4 * 37 + 458 * block_ctx;
     int nz_before = 0;   // nonzeros at scan positions before the current 64-chunk
     int carry_flag = 0;  // nonzero flag of the last position of the previous chunk
-    for (int half = 0; half < covered; half++) {
+    const int nhalf = nscan > 64 ? 2 : 1;  // the second 64 positions only if tokens reach them
+    for (int half = 0; half < nhalf; half++) {
       const int k = half * 64 + lane;
-      const int16_t v = A.coef_scan[((half == 0 ? pos : pos1) * 3 + c) * 64 + lane];
+      const int16_t v = half == 0 ? v0 : A.coef_scan[(pos1 * 3 + c) * 64 + lane];
       const bool in_range = k >= covered && k < nscan;
       const bool nz = in_range && v != 0;
-      const unsigned long long m = __ballot(nz);
+      const unsigned long long mk = __ballot(nz);
       if (in_range) {
         // nzeros still to come at position k, and whether position k-1 was nonzero
-        const int left = nzeros - (nz_before + __popcll(m & ((1ull << lane) - 1ull)));
+        const int left = nzeros - (nz_before + __popcll(mk & ((1ull << lane) - 1ull)));
         int p;
         if (k == covered) p = (nzeros > size / 16) ? 0 : 1;
         else if (lane == 0) p = carry_flag;
-        else p = (int)((m >> (lane - 1)) & 1ull);
+        else p = (int)((mk >> (lane - 1)) & 1ull);
         const int nl = (left + covered - 1) >> log2c;
         const int kk = k >> log2c;
-        const int zctx = (T->nnz_context[nl] + T->freq_context[kk]) * 2 + p;
+        const int zctx = (s_nnz_ctx[nl] + s_freq_ctx[kk]) * 2 + p;
         const int ctx = histo_offset + zctx;
         const uint32_t val = pack_signed((int32_t)v);
         uint8_t* o = out + 3 * ((size_t)tok0 + 1 + (k - covered));
-        const uint8_t cm = T->ac_context_map[ctx];
+        const uint8_t cm = s_ctx_map[ctx];
         o[0] = cm;
         o[1] = (uint8_t)(val & 0xFF);
         o[2] = (uint8_t)((val >> 8) & 0xFF);
@@ -1398,8 +1421,8 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
           atomicAdd(&hist[cm * 64 + sym], 1u);
         }
       }
-      nz_before += __popcll(m);
-      carry_flag = (int)((m >> 63) & 1ull);
+      nz_before += __popcll(mk);
+      carry_flag = (int)((mk >> 63) & 1ull);
     }
   }
   if (do_hist) {

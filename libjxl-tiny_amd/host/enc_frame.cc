@@ -8,6 +8,7 @@
 
 #include <chrono>
 #include <cstdlib>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -38,7 +39,10 @@ FrameView ViewOf(const jxlt_frame_result& res, const uint8_t* const* group_ptr, 
 // host builds the prefix codes (and, concurrently, the DC-group sections), the
 // device packs the AC sections.  Single-group frames (bit-concatenated sections,
 // enc_frame.cc:805-811) take the raw-token route.
-bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jxl::BitWriter* writer) {
+// Appends the frame to `writer` (if non-null) or, for the malloc-returning C entry,
+// hands the pieces to `sink(ptr, size)` in order.
+bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jxl::BitWriter* writer,
+                          const std::function<void(const uint8_t*, size_t)>* sink) {
   static const bool trace = getenv("JXLT_TRACE") != nullptr;
   auto now = []() { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
@@ -66,7 +70,14 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
     if (jxlt_fetch_result(ctx, &res) != JXLT_OK) return false;
     const uint8_t* ptr = res.tokens;
     const size_t len = static_cast<size_t>(res.group_token_offset[1]);
-    return AssembleFrame(ViewOf(res, &ptr, &len), distp, writer, num_threads);
+    jxl::BitWriter local;
+    jxl::BitWriter* w = writer ? writer : &local;
+    if (!AssembleFrame(ViewOf(res, &ptr, &len), distp, w, num_threads)) return false;
+    if (!writer) {
+      const std::vector<uint8_t>& b = local.Bytes();
+      (*sink)(b.data(), b.size());
+    }
+    return true;
   }
   const uint32_t *ac_hist = nullptr, *dc_hist = nullptr;
   if (jxlt_fetch_histograms(ctx, &ac_hist, &dc_hist) != JXLT_OK) {
@@ -96,7 +107,23 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   const auto t3 = now();
   PackedSections dc = {dcp.bytes, dcp.section_offset, dcp.section_bits, dcp.num_sections};
   PackedSections ac = {acp.bytes, acp.section_offset, acp.section_bits, acp.num_sections};
-  const bool ok = FinishFrame(xsize, ysize, distp, dc_code, dc, ac_code, ac, writer);
+  FramePieces pieces;
+  const bool ok = FinishFrame(xsize, ysize, distp, dc_code, dc, ac_code, ac, &pieces);
+  if (ok) {
+    const size_t dc_bytes = static_cast<size_t>(dc.offset[dc.n]), ac_bytes = static_cast<size_t>(ac.offset[ac.n]);
+    if (writer) {
+      writer->Reserve(pieces.head.size() + dc_bytes + pieces.ac_global.size() + ac_bytes);
+      writer->AppendBytes(pieces.head.data(), pieces.head.size());
+      writer->AppendBytes(dc.bytes, dc_bytes);
+      writer->AppendBytes(pieces.ac_global.data(), pieces.ac_global.size());
+      writer->AppendBytes(ac.bytes, ac_bytes);
+    } else {
+      (*sink)(pieces.head.data(), pieces.head.size());
+      (*sink)(dc.bytes, dc_bytes);
+      (*sink)(pieces.ac_global.data(), pieces.ac_global.size());
+      (*sink)(ac.bytes, ac_bytes);
+    }
+  }
   if (trace)
     fprintf(stderr, "jxlt trace: device+histograms %.2f ms | codes %.2f | pack dc+ac (device) %.2f | finish %.2f\n",
             ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
@@ -151,7 +178,7 @@ Status EncodeFrame(const float distance, const Image3F& linear, ThreadPool* pool
     fprintf(stderr, "jxl_tiny_amd: upload failed: %s\n", jxlt_last_error(ctx));
     return false;
   }
-  return jxlt::EncodeFrameOnContext(ctx, distance, pool ? pool->NumThreads() : 0, writer);
+  return jxlt::EncodeFrameOnContext(ctx, distance, pool ? pool->NumThreads() : 0, writer, nullptr);
 }
 
 }  // namespace jxl

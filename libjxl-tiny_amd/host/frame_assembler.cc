@@ -427,11 +427,11 @@ void BuildDcCode(const uint32_t* histograms, EntropyCode* dc_code) {
 
 bool FinishFrame(size_t xsize, size_t ysize, const DistanceParams& distp, const EntropyCode& dc_code,
                  const PackedSections& dc, const EntropyCode& ac_code, const PackedSections& ac,
-                 jxl::BitWriter* writer) {
+                 FramePieces* out) {
   const size_t num_groups = DivCeil(xsize, 256) * DivCeil(ysize, 256);
   const size_t num_dc_groups = DivCeil(xsize, 2048) * DivCeil(ysize, 2048);
   if (ac.n != num_groups || dc.n != num_dc_groups || 2 + num_dc_groups + num_groups == 4) return false;
-  jxl::BitWriter dc_global, ac_global;
+  jxl::BitWriter dc_global, ac_global, head;
   WriteDCGlobal(distp, num_dc_groups, dc_code, &dc_global);
   WriteACGlobal(num_groups, ac_code, &ac_global);
   dc_global.ZeroPadToByte();
@@ -442,15 +442,12 @@ bool FinishFrame(size_t xsize, size_t ysize, const DistanceParams& distp, const 
   for (size_t g = 0; g < num_dc_groups; ++g) sizes.push_back(static_cast<size_t>(dc.offset[g + 1] - dc.offset[g]));
   sizes.push_back(ac_global.BitsWritten() / 8);
   for (size_t g = 0; g < num_groups; ++g) sizes.push_back(static_cast<size_t>(ac.offset[g + 1] - ac.offset[g]));
-  WriteFrameHeader(distp.x_qm_scale, distp.epf_iters, writer);
-  if (!WriteTOCSizes(sizes, writer)) return false;
-  writer->Reserve(static_cast<size_t>(dc.offset[num_dc_groups] + ac.offset[num_groups]) + 65536);
+  WriteFrameHeader(distp.x_qm_scale, distp.epf_iters, &head);
+  if (!WriteTOCSizes(sizes, &head)) return false;
   const std::vector<uint8_t>& dg = dc_global.Bytes();
-  writer->AppendBytes(dg.data(), dg.size());
-  writer->AppendBytes(dc.bytes, static_cast<size_t>(dc.offset[num_dc_groups]));
-  const std::vector<uint8_t>& ag = ac_global.Bytes();
-  writer->AppendBytes(ag.data(), ag.size());
-  writer->AppendBytes(ac.bytes, static_cast<size_t>(ac.offset[num_groups]));
+  head.AppendBytes(dg.data(), dg.size());
+  out->head = head.TakeBytes();
+  out->ac_global = ac_global.TakeBytes();
   return true;
 }
 

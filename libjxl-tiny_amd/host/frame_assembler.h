@@ -62,11 +62,17 @@ struct PackedSections {
 };
 // Frame header + TOC + DCGlobal + DC groups + ACGlobal + AC groups, with both
 // kinds of group sections already entropy-coded (byte-aligned) by the device.
+// The frame is the concatenation head | dc.bytes | ac_global | ac.bytes; the two
+// large blobs are not copied here.
 // Not valid for single-group frames (their sections are bit-concatenated,
 // enc_frame.cc:805-811): use AssembleFrame there.
+struct FramePieces {
+  std::vector<uint8_t> head;       // frame header, TOC, DCGlobal
+  std::vector<uint8_t> ac_global;  // ACGlobal
+};
 bool FinishFrame(size_t xsize, size_t ysize, const DistanceParams& distp, const EntropyCode& dc_code,
                  const PackedSections& dc, const EntropyCode& ac_code, const PackedSections& ac,
-                 jxl::BitWriter* writer);
+                 FramePieces* out);
 
 // Raw 3-byte records of DC group `index` as the host tokeniser produces them (tests).
 std::vector<uint8_t> DcGroupRecords(const FrameView& frame, size_t index);

@@ -2,6 +2,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <functional>
 #include <vector>
 
 #include "../../include/jxl_tiny_amd.h"
@@ -116,8 +117,27 @@ int jxlt_encode_resident(jxlt_context* ctx, float distance, int num_threads, uin
   size_t xsize = 0, ysize = 0;
   if (jxlt_image_size(ctx, &xsize, &ysize) != JXLT_OK) return JXLT_ERR_INVALID_ARGUMENT;
   if (!jxlt::WriteFileHeader(xsize, ysize, &writer)) return JXLT_ERR_INVALID_ARGUMENT;
-  if (!jxlt::EncodeFrameOnContext(ctx, distance, num_threads, &writer)) return JXLT_ERR_INTERNAL;
-  return ToMalloc(writer.TakeBytes(), out_bytes, out_size);
+  // Collect the pieces (file header, frame head, DC blob, ACGlobal, AC blob) and copy each
+  // exactly once into the returned buffer.
+  const std::vector<uint8_t> file_header = writer.TakeBytes();
+  uint8_t* buf = nullptr;
+  size_t cap = 0, used = 0;
+  const std::function<void(const uint8_t*, size_t)> sink = [&](const uint8_t* p, size_t n) {
+    if (used + n > cap) {
+      cap = used + n + (used + n) / 8 + 65536;
+      buf = static_cast<uint8_t*>(realloc(buf, cap));
+    }
+    memcpy(buf + used, p, n);
+    used += n;
+  };
+  sink(file_header.data(), file_header.size());
+  if (!jxlt::EncodeFrameOnContext(ctx, distance, num_threads, nullptr, &sink)) {
+    free(buf);
+    return JXLT_ERR_INTERNAL;
+  }
+  *out_bytes = buf;
+  *out_size = used;
+  return JXLT_OK;
 }
 
 int jxlt_debug_dc_records(const jxlt_frame_result* frame, size_t dc_group_index, uint8_t** out_bytes,

@@ -3,13 +3,17 @@
 #define JXLT_HOST_INTERNAL_H_
 
 #include <stddef.h>
+#include <stdint.h>
+
+#include <functional>
 
 #include "encoder/enc_bit_writer.h"
 
 struct jxlt_context;
 
 namespace jxlt {
-bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jxl::BitWriter* writer);
+bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jxl::BitWriter* writer,
+                          const std::function<void(const uint8_t*, size_t)>* sink);
 bool WriteFileHeader(size_t xsize, size_t ysize, jxl::BitWriter* writer);
 bool NormalizeDistance(float* distance);
 }  // namespace jxlt
