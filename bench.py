@@ -2,11 +2,16 @@
 """bench.py -- Mpixels/s of the MI355X-native JPEG XL tiny encoder.
 
 One "step" = one full encode of a synthetic linear-sRGB frame that is already
-resident in HBM as three planar f32 planes: the per-group device pipeline
-(tile_kernel -> group_scan_kernel -> token_kernel), the D2H of tokens + side-band
-grids and the host bitstream assembly, ending with the complete .jxl codestream
-bytes in host memory.  PFM file I/O and the H2D upload are outside the timed
-region (DESIGN.md quotes the PCIe-inclusive rate separately).
+resident in HBM as three planar f32 planes, ending with the complete .jxl
+codestream bytes in host memory:
+  device   tile_kernel (XYB, adaptive quant, chroma-from-luma, strategy search, quantise)
+           group_scan_kernel, token_kernel (+ AC symbol histograms)
+           dc_elementwise_kernel, dc_chain_kernel (DC-group tokens + DC histograms)
+  host     32 KB of histograms D2H -> histogram clustering + Huffman codes (two threads)
+  device   pack_kernel / compact_kernel for the DC-group and AC-group sections
+  host     D2H of the packed sections, frame header + TOC + global sections, one copy
+PFM file I/O and the H2D upload are outside the timed region (DESIGN.md quotes
+the PCIe-inclusive rate separately).
 
     python bench.py --gpus N --steps K --warmup W [--size S]
 
@@ -154,7 +159,7 @@ def main():
                    "groups_per_gpu": int(fr.num_groups), "parallelism": "frames sharded by rank, no collective",
                    "codestream_bytes": len(jxl), "raw_token_bytes": token_bytes},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(size),
                      "kernel": "tile_kernel", "kernel_ms": round(tile_ms, 3),
                      "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PIXEL * size * size},
         "kernel_ms": {k: round(v, 3) for k, v in ktimes.items()},
@@ -193,6 +198,20 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(size):
+    """HBM bytes per tile_kernel launch from the committed PMC profile of this workload
+    (profiles/*_traffic_<size>.json, made by tools/collect_traffic.py from separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes with the calibrated gfx950 correction);
+    None when no profile of this frame size is committed."""
+    best = None
+    for p in sorted((ROOT / "profiles").glob("*_traffic_%d.json" % size)):
+        try:
+            best = json.load(open(p))["kernels"]["tile_kernel"]["hbm_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
+    return best
 
 
 def _cpu_model():

@@ -702,7 +702,17 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
   }
 
   // ---- geometry (enc_frame.cc:716-751) ------------------------------------
-  const int tile_id = (int)blockIdx.x;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed placement, used for
+  // speed only), and each XCD has its own L2.  Give every XCD one contiguous raster range
+  // of tiles so that horizontally adjacent tiles -- which share the +-5 px halo columns and
+  // the partially covered 128-byte lines -- are served by the same L2.
+  int tile_id;
+  {
+    const int n = A.g.xsize_tiles * A.g.ysize_tiles;
+    const int b = (int)blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int q = n >> 3, r = n & 7;
+    tile_id = xcd * q + (xcd < r ? xcd : r) + idx;
+  }
   const int tx_img = tile_id % A.g.xsize_tiles, ty_img = tile_id / A.g.xsize_tiles;
   const int gx = tx_img >> 2;
   const int sx0 = gx * 256, sy0 = ty_img * 64;            // stripe origin (pixels)
@@ -965,31 +975,6 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
   __syncthreads();
   JXLT_MARK(3);
 
-  // ---- P5: DCT8 of every block (kept in registers) + chroma-from-luma -------
-  // (enc_chroma_from_luma.cc:40-131)
-  float c8x[8], c8y[8], c8b[8];
-  {
-    const float* pxp = &S.x[(oby * 8) * kXYPitch + obx * 8 + kHalo];
-    const float* pyp = &S.y[(oby * 8) * kXYPitch + obx * 8 + kHalo];
-    const float* pbp = &S.b[(oby * 8) * kBPitch + obx * 8];
-#pragma clang loop unroll(disable)
-    for (int c = 0; c < 3; c++) {
-      float t[8];
-      if (blk_valid) {
-        block_dct8x8(c == 0 ? pxp : c == 1 ? pyp : pbp, c == 2 ? kBPitch : kXYPitch, l, t);
-      } else {
-        // (cross-lane traffic never leaves an octet, so idle octets may skip it)
-#pragma unroll
-        for (int r = 0; r < 8; r++) t[r] = 0.0f;
-      }
-#pragma unroll
-      for (int r = 0; r < 8; r++) {
-        if (c == 0) c8x[r] = t[r];
-        else if (c == 1) c8y[r] = t[r];
-        else c8b[r] = t[r];
-      }
-    }
-  }
   JXLT_MARK(4);
   // ---- P6a: candidate two-block transforms (enc_ac_strategy.cc:62-66) -------
   // Waves 0-3 take the 32 DCT16X8 candidates, waves 4-7 the 32 DCT8X16 candidates.
@@ -1020,6 +1005,32 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
         if (c == 0) c16x[r] = t[r];
         else if (c == 1) c16y[r] = t[r];
         else c16b[r] = t[r];
+      }
+    }
+  }
+  JXLT_MARK(4);
+  // ---- P5: DCT8 of every block (kept in registers) + chroma-from-luma -------
+  // (enc_chroma_from_luma.cc:40-131)
+  float c8x[8], c8y[8], c8b[8];
+  {
+    const float* pxp = &S.x[(oby * 8) * kXYPitch + obx * 8 + kHalo];
+    const float* pyp = &S.y[(oby * 8) * kXYPitch + obx * 8 + kHalo];
+    const float* pbp = &S.b[(oby * 8) * kBPitch + obx * 8];
+#pragma clang loop unroll(disable)
+    for (int c = 0; c < 3; c++) {
+      float t[8];
+      if (blk_valid) {
+        block_dct8x8(c == 0 ? pxp : c == 1 ? pyp : pbp, c == 2 ? kBPitch : kXYPitch, l, t);
+      } else {
+        // (cross-lane traffic never leaves an octet, so idle octets may skip it)
+#pragma unroll
+        for (int r = 0; r < 8; r++) t[r] = 0.0f;
+      }
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        if (c == 0) c8x[r] = t[r];
+        else if (c == 1) c8y[r] = t[r];
+        else c8b[r] = t[r];
       }
     }
   }
@@ -1205,16 +1216,20 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
       const uint32_t pos0 = (uint32_t)(by_img0 + by) * bstride + (uint32_t)(bx_img0 + bx);
       const uint32_t pos1 = pos0 + (st == 1 ? bstride : 1u);
       int nscan = 0;
-      for (int half = 0; half < covered; half++) {
+      int16_t vh[2] = {0, 0};
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        if (half >= covered) break;
         const int k = half * 64 + lane;
         const int i = order[k];
-        const int16_t v = (i < 64 ? stage[bi * 192 + c * 64 + i] : stage[(bi + o2) * 192 + c * 64 + i - 64]);
-        const bool nz = (k >= covered) && v != 0;
+        vh[half] = (i < 64 ? stage[bi * 192 + c * 64 + i] : stage[(bi + o2) * 192 + c * 64 + i - 64]);
+        const bool nz = (k >= covered) && vh[half] != 0;
         const unsigned long long m = __ballot(nz);
         if (m != 0) nscan = half * 64 + (64 - __clzll((long long)m));
-        int16_t* dst = A.coef_scan + ((half == 0 ? pos0 : pos1) * 3 + c) * 64;
-        dst[lane] = v;
       }
+      // only scan positions below nscan (= up to the last nonzero) are ever read again
+      if (lane < nscan) A.coef_scan[(pos0 * 3 + c) * 64 + lane] = vh[0];
+      if (64 + lane < nscan) A.coef_scan[(pos1 * 3 + c) * 64 + lane] = vh[1];
       if (lane == 0) {
         A.blk_nscan[pos0 * 3 + c] = (uint8_t)nscan;
         my_tokens += 1 + (nscan > covered ? nscan - covered : 0);
@@ -1345,11 +1360,13 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     const size_t pos = (size_t)(by0 + b / nbx) * bstride + bx0 + b % nbx;
     return A.coef_scan + (pos * 3 + c) * 64;
   };
+  // (only scan positions below nscan were written by tile_kernel)
   int16_t next_v = 0;
-  if (wave < nent) next_v = entry_coef_ptr(wave)[lane];
+  if (wave < nent && lane < (int)(meta[wave] >> 16)) next_v = entry_coef_ptr(wave)[lane];
   for (int e = wave; e < nent; e += kWaves) {
     const int16_t v0 = next_v;
-    if (e + kWaves < nent) next_v = entry_coef_ptr(e + kWaves)[lane];
+    next_v = 0;
+    if (e + kWaves < nent && lane < (int)(meta[e + kWaves] >> 16)) next_v = entry_coef_ptr(e + kWaves)[lane];
     const uint32_t m = meta[e];
     if (!(m & 1)) continue;
     const int ci = e % 3, b = e / 3;
@@ -1394,7 +1411,7 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     const int nhalf = nscan > 64 ? 2 : 1;  // the second 64 positions only if tokens reach them
     for (int half = 0; half < nhalf; half++) {
       const int k = half * 64 + lane;
-      const int16_t v = half == 0 ? v0 : A.coef_scan[(pos1 * 3 + c) * 64 + lane];
+      const int16_t v = half == 0 ? v0 : (64 + lane < nscan ? A.coef_scan[(pos1 * 3 + c) * 64 + lane] : (int16_t)0);
       const bool in_range = k >= covered && k < nscan;
       const bool nz = in_range && v != 0;
       const unsigned long long mk = __ballot(nz);

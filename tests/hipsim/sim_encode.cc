@@ -70,7 +70,8 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   A.ytob = r->ytob = (int8_t*)calloc(ntiles, 1);
   A.blk_nz = (uint8_t*)calloc(nblocks * 3, 1);
   A.blk_nscan = (uint8_t*)calloc(nblocks * 3, 1);
-  A.coef_scan = (int16_t*)calloc(nblocks * 3 * 64, 2);
+  A.coef_scan = (int16_t*)malloc(nblocks * 3 * 64 * 2);
+  memset(A.coef_scan, 0xBB, nblocks * 3 * 64 * 2);  // unwritten positions must never be consumed
   A.group_ntok = (uint32_t*)calloc(ngroups, 4);
   const size_t ndc = ((xsize + 2047) / 2048) * ((ysize + 2047) / 2048);
   A.dc_nac = (uint32_t*)calloc(ndc, 4);

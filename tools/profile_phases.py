@@ -14,7 +14,7 @@ sys.path.insert(0, str(ROOT))
 import __graft_entry__  # noqa: E402
 import bench  # noqa: E402
 
-PHASES = ["P0 load+XYB", "P1 AQ energy", "P2-3 erosion", "P4 modulations", "P5a DCT8", "P6a 2-block DCTs",
+PHASES = ["P0 load+XYB", "P1 AQ energy", "P2-3 erosion", "P4 modulations", "P6a 2-block DCTs", "P5a DCT8",
           "P5b CfL + P6b entropy", "P7 decision", "P8 quantise", "P9 scan store"]
 
 
