@@ -178,6 +178,21 @@ int jxlt_encode_file_planar(const float* const planes[3], size_t pitch_bytes, si
                             uint8_t** out_bytes, size_t* out_size);
 /* Codestream + image headers that precede the frame (enc_file.cc:70-95). */
 int jxlt_write_file_header(size_t xsize, size_t ysize, uint8_t** out_bytes, size_t* out_size);
+/* ---- one frame sharded over several contexts / GPUs / processes ----------------
+ * Row slabs whose height is a multiple of 2048 (whole DC groups) are encoded
+ * independently (jxlt_image_* + jxlt_encode_enqueue + jxlt_fetch_histograms per slab).
+ * The only cross-slab dependency is the pair of global prefix codes: sum the
+ * histograms of all slabs (e.g. torch.distributed.all_reduce), call
+ * jxlt_build_code_tables on every slab, pack (jxlt_pack_sections), gather the packed
+ * sections in slab order and let one process call jxlt_finish_frame. */
+int jxlt_build_code_tables(const uint32_t* ac_histograms, const uint32_t* dc_histograms,
+                           uint32_t* ac_code_table, uint32_t* dc_code_table);
+/* Complete codestream (file header + frame) of an xsize x ysize frame from the summed
+ * histograms and the DC-group / AC-group sections of the whole frame in raster order. */
+int jxlt_finish_frame(size_t xsize, size_t ysize, float distance, const uint32_t* ac_histograms,
+                      const uint32_t* dc_histograms, const jxlt_packed_sections* dc_sections,
+                      const jxlt_packed_sections* ac_sections, uint8_t** out_bytes, size_t* out_size);
+
 /* Test hook: the raw 3-byte records of DC group `dc_group_index` exactly as the host
  * tokeniser (WriteDCGroup in raw-record form, enc_frame.cc:536-570) produces them. */
 int jxlt_debug_dc_records(const jxlt_frame_result* frame, size_t dc_group_index, uint8_t** out_bytes,

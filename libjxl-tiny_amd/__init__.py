@@ -33,7 +33,8 @@ HIP_SYMBOLS = ["jxlt_context_create", "jxlt_context_destroy", "jxlt_last_error",
                "jxlt_fetch_side_info", "jxlt_fetch_histograms", "jxlt_pack_ac_sections", "jxlt_pack_sections",
                "jxlt_synchronize", "jxlt_fetch_result", "jxlt_kernel_times", "jxlt_debug_fetch"]
 HOST_SYMBOLS = ["jxlt_compute_distance_params", "jxlt_assemble_frame", "jxlt_assemble_frame_groups",
-                "jxlt_encode_file_planar", "jxlt_encode_resident", "jxlt_write_file_header", "jxlt_debug_dc_records", "jxlt_free"]
+                "jxlt_encode_file_planar", "jxlt_encode_resident", "jxlt_write_file_header", "jxlt_build_code_tables", "jxlt_finish_frame",
+                "jxlt_debug_dc_records", "jxlt_free"]
 
 
 class JxlTinyError(RuntimeError):
@@ -62,6 +63,11 @@ class FrameResult(C.Structure):
                 ("ytox_map", C.POINTER(C.c_int8)), ("ytob_map", C.POINTER(C.c_int8)),
                 ("tokens", C.POINTER(C.c_uint8)),
                 ("group_token_offset", C.POINTER(C.c_uint64))]
+
+
+class PackedSections(C.Structure):
+    _fields_ = [("bytes", C.POINTER(C.c_uint8)), ("section_offset", C.POINTER(C.c_uint64)),
+                ("section_bits", C.POINTER(C.c_uint32)), ("num_sections", C.c_size_t)]
 
 
 class KernelTime(C.Structure):
@@ -105,6 +111,9 @@ def hip_lib():
         L.jxlt_encode_enqueue.argtypes = [C.c_void_p, C.POINTER(Params)]
         L.jxlt_synchronize.argtypes = [C.c_void_p]
         L.jxlt_fetch_result.argtypes = [C.c_void_p, C.POINTER(FrameResult)]
+        L.jxlt_fetch_histograms.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)),
+                                            C.POINTER(C.POINTER(C.c_uint32))]
+        L.jxlt_pack_sections.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(PackedSections)]
         L.jxlt_kernel_times.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_int]
         L.jxlt_debug_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         _hip = L
@@ -131,6 +140,10 @@ def host_lib():
                                            C.POINTER(C.c_size_t)]
         L.jxlt_write_file_header.argtypes = [C.c_size_t, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)),
                                              C.POINTER(C.c_size_t)]
+        L.jxlt_build_code_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.jxlt_finish_frame.argtypes = [C.c_size_t, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p,
+                                        C.POINTER(PackedSections), C.POINTER(PackedSections),
+                                        C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         L.jxlt_debug_dc_records.argtypes = [C.POINTER(FrameResult), C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)),
                                             C.POINTER(C.c_size_t)]
         L.jxlt_free.argtypes = [C.c_void_p]
@@ -272,6 +285,26 @@ class Encoder:
         self._check(self._L.jxlt_fetch_result(self._ctx, C.byref(fr)), "jxlt_fetch_result")
         return fr
 
+    def fetch_histograms(self):
+        """(ac, dc) symbol histograms [64, 64] uint32 of the last enqueue (jxlt_fetch_histograms)."""
+        a, d = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)()
+        self._check(self._L.jxlt_fetch_histograms(self._ctx, C.byref(a), C.byref(d)), "jxlt_fetch_histograms")
+        cp = lambda p: np.ctypeslib.as_array(p, shape=(4096,)).reshape(64, 64).copy()
+        return cp(a), cp(d)
+
+    def pack_sections(self, kind, table):
+        """Device-side packing of the DC-group (kind 0) or AC-group (kind 1) sections with the code
+        table [4096] uint32; returns (bytes uint8[], offsets uint64[n+1], bits uint32[n]) copies."""
+        table = np.ascontiguousarray(table, np.uint32).reshape(-1)
+        ps = PackedSections()
+        self._check(self._L.jxlt_pack_sections(self._ctx, kind, table.ctypes.data, C.byref(ps)), "jxlt_pack_sections")
+        n = ps.num_sections
+        off = np.ctypeslib.as_array(ps.section_offset, shape=(n + 1,)).copy()
+        bits = np.ctypeslib.as_array(ps.section_bits, shape=(n,)).copy()
+        total = int(off[n])
+        data = np.ctypeslib.as_array(ps.bytes, shape=(max(total, 1),))[:total].copy()
+        return data, off, bits
+
     def kernel_times(self):
         arr = (KernelTime * 8)()
         n = self._check(self._L.jxlt_kernel_times(self._ctx, arr, 8), "jxlt_kernel_times")
@@ -321,6 +354,47 @@ class Encoder:
         dp = self.enqueue(distance, flags)
         fr = self.fetch_raw()
         return file_header(fr.xsize, fr.ysize) + self.assemble(fr, dp, num_threads)
+
+
+def build_code_tables(ac_hist, dc_hist):
+    """Prefix-code tables [4096] uint32 ((depth << 16) | bits) from (summed) histograms."""
+    ac_hist = np.ascontiguousarray(ac_hist, np.uint32)
+    dc_hist = np.ascontiguousarray(dc_hist, np.uint32)
+    ac_t, dc_t = np.zeros(4096, np.uint32), np.zeros(4096, np.uint32)
+    rc = host_lib().jxlt_build_code_tables(ac_hist.ctypes.data, dc_hist.ctypes.data, ac_t.ctypes.data,
+                                           dc_t.ctypes.data)
+    if rc != 0:
+        raise JxlTinyError("jxlt_build_code_tables failed (%d)" % rc)
+    return ac_t, dc_t
+
+
+def finish_frame(xsize, ysize, distance, ac_hist, dc_hist, dc_sections, ac_sections):
+    """Codestream of the whole frame from summed histograms and all packed sections in raster
+    order; *_sections = (bytes uint8[], offsets uint64[n+1], bits uint32[n])."""
+    keep = []
+
+    def mk(sec):
+        data, off, bits = (np.ascontiguousarray(sec[0], np.uint8), np.ascontiguousarray(sec[1], np.uint64),
+                           np.ascontiguousarray(sec[2], np.uint32))
+        if data.size == 0:
+            data = np.zeros(1, np.uint8)
+        keep.extend([data, off, bits])
+        ps = PackedSections()
+        ps.bytes = data.ctypes.data_as(C.POINTER(C.c_uint8))
+        ps.section_offset = off.ctypes.data_as(C.POINTER(C.c_uint64))
+        ps.section_bits = bits.ctypes.data_as(C.POINTER(C.c_uint32))
+        ps.num_sections = len(bits)
+        return ps
+
+    ac_hist = np.ascontiguousarray(ac_hist, np.uint32)
+    dc_hist = np.ascontiguousarray(dc_hist, np.uint32)
+    dcs, acs = mk(dc_sections), mk(ac_sections)
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    rc = host_lib().jxlt_finish_frame(xsize, ysize, C.c_float(distance), ac_hist.ctypes.data, dc_hist.ctypes.data,
+                                      C.byref(dcs), C.byref(acs), C.byref(out), C.byref(n))
+    if rc != 0:
+        raise JxlTinyError("jxlt_finish_frame failed (%d)" % rc)
+    return _take_bytes(out, n)
 
 
 def encode_file(planes, distance, device=0):

@@ -140,6 +140,55 @@ int jxlt_encode_resident(jxlt_context* ctx, float distance, int num_threads, uin
   return JXLT_OK;
 }
 
+int jxlt_build_code_tables(const uint32_t* ac_histograms, const uint32_t* dc_histograms,
+                           uint32_t* ac_code_table, uint32_t* dc_code_table) {
+  if (!ac_histograms || !dc_histograms || !ac_code_table || !dc_code_table) return JXLT_ERR_INVALID_ARGUMENT;
+  jxlt::EntropyCode ac_code, dc_code;
+  jxlt::BuildAcCode(ac_histograms, &ac_code);
+  jxlt::BuildDcCode(dc_histograms, &dc_code);
+  jxlt::FillCodeTable(ac_code, ac_code_table);
+  jxlt::FillCodeTable(dc_code, dc_code_table);
+  return JXLT_OK;
+}
+
+int jxlt_finish_frame(size_t xsize, size_t ysize, float distance, const uint32_t* ac_histograms,
+                      const uint32_t* dc_histograms, const jxlt_packed_sections* dc_sections,
+                      const jxlt_packed_sections* ac_sections, uint8_t** out_bytes, size_t* out_size) {
+  if (!ac_histograms || !dc_histograms || !dc_sections || !ac_sections || !out_bytes || !out_size)
+    return JXLT_ERR_INVALID_ARGUMENT;
+  if (!jxlt::NormalizeDistance(&distance)) return JXLT_ERR_INVALID_ARGUMENT;
+  jxl::BitWriter writer;
+  if (!jxlt::WriteFileHeader(xsize, ysize, &writer)) return JXLT_ERR_INVALID_ARGUMENT;
+  jxlt::EntropyCode ac_code, dc_code;
+  jxlt::BuildAcCode(ac_histograms, &ac_code);
+  jxlt::BuildDcCode(dc_histograms, &dc_code);
+  const jxlt::PackedSections dc = {dc_sections->bytes, dc_sections->section_offset,
+                                   dc_sections->section_bits, dc_sections->num_sections};
+  const jxlt::PackedSections ac = {ac_sections->bytes, ac_sections->section_offset,
+                                   ac_sections->section_bits, ac_sections->num_sections};
+  jxlt::FramePieces pieces;
+  if (!jxlt::FinishFrame(xsize, ysize, jxlt::ComputeDistanceParams(distance), dc_code, dc, ac_code, ac, &pieces))
+    return JXLT_ERR_INVALID_ARGUMENT;
+  const std::vector<uint8_t> file_header = writer.TakeBytes();
+  const size_t dc_bytes = static_cast<size_t>(dc.offset[dc.n]), ac_bytes = static_cast<size_t>(ac.offset[ac.n]);
+  const size_t total = file_header.size() + pieces.head.size() + dc_bytes + pieces.ac_global.size() + ac_bytes;
+  uint8_t* buf = static_cast<uint8_t*>(malloc(total ? total : 1));
+  if (!buf) return JXLT_ERR_OUT_OF_MEMORY;
+  size_t pos = 0;
+  auto put = [&](const uint8_t* p, size_t n) {
+    memcpy(buf + pos, p, n);
+    pos += n;
+  };
+  put(file_header.data(), file_header.size());
+  put(pieces.head.data(), pieces.head.size());
+  put(dc.bytes, dc_bytes);
+  put(pieces.ac_global.data(), pieces.ac_global.size());
+  put(ac.bytes, ac_bytes);
+  *out_bytes = buf;
+  *out_size = total;
+  return JXLT_OK;
+}
+
 int jxlt_debug_dc_records(const jxlt_frame_result* frame, size_t dc_group_index, uint8_t** out_bytes,
                           size_t* out_size) {
   if (!frame || !out_bytes || !out_size) return JXLT_ERR_INVALID_ARGUMENT;

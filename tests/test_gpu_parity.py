@@ -142,3 +142,33 @@ def test_device_packed_sections_equal_host_packed(built, enc, w, h, distance):
     b = enc.encode_resident_raw_tokens(distance)
     assert a == b
     assert a == T.assemble_codestream(T.oracle_hot_path(planes, distance), distance)
+
+
+def test_sharded_slabs_on_one_gpu(built):
+    """SURVEY.md 8(e) on real device contexts: two slabs of whole DC groups encoded by two
+    independent contexts, histograms summed, sections packed per slab and merged -- must equal
+    the single-context codestream of the whole frame (and therefore the oracle's)."""
+    w, h, d = 520, 2048 + 300, 1.0
+    planes = T.to_planes(T.synthetic_image(w, h))
+    slabs = [np.ascontiguousarray(planes[:, :2048]), np.ascontiguousarray(planes[:, 2048:])]
+    encs = [built.Encoder(0), built.Encoder(0)]
+    hists = []
+    for e, s in zip(encs, slabs):
+        e.upload(s)
+        e.enqueue(d, 0)
+        hists.append(e.fetch_histograms())
+    ac_h = sum(x[0].astype(np.uint64) for x in hists).astype(np.uint32)
+    dc_h = sum(x[1].astype(np.uint64) for x in hists).astype(np.uint32)
+    ac_t, dc_t = built.build_code_tables(ac_h, dc_h)
+    merged = []
+    for kind, table in ((0, dc_t), (1, ac_t)):
+        parts = [e.pack_sections(kind, table) for e in encs]
+        sizes = np.concatenate([np.diff(p[1]) for p in parts])
+        off = np.zeros(len(sizes) + 1, np.uint64)
+        off[1:] = np.cumsum(sizes)
+        merged.append((np.concatenate([p[0] for p in parts]), off, np.concatenate([p[2] for p in parts])))
+    got = built.finish_frame(w, h, d, ac_h, dc_h, merged[0], merged[1])
+    assert got == built.encode_file(planes, d)
+    assert got == T.assemble_codestream(T.oracle_hot_path(planes, d), d)
+    for e in encs:
+        e.close()
