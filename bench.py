@@ -70,6 +70,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4096,
                     help="edge of the top-left crop the CPU oracle encodes (baseline + parity gate)")
     ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--shard-frame", action="store_true",
+                    help="N > 1 only: the ranks' frames are the row slabs of ONE frame of size x (size*N) pixels; "
+                         "histograms are all-reduced and the packed sections gathered on rank 0 "
+                         "(libjxl-tiny_amd/sharded.py).  Default: one independent frame per rank.")
     args = ap.parse_args()
 
     import torch
@@ -102,7 +106,19 @@ def main():
     ptrs = [frame[c].data_ptr() for c in range(3)]
     enc.set_device_image(ptrs, size * 4, size, size, keepalive=frame)
 
+    sharded = comm = None
+    if args.shard_frame and world > 1:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("jxlt_sharded", str(ROOT / "libjxl-tiny_amd" / "sharded.py"))
+        sharded = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(sharded)
+        comm = sharded.TorchComm(dist, device)
+
     def step():
+        if sharded is not None:
+            out = sharded.encode_sharded(sharded.GpuSlab(enc, args.distance), comm, size, size * world,
+                                         args.distance, pkg)
+            return out if out is not None else b""
         # the codestream stays in the library's malloc'ed host buffer (no Python-side copy)
         return enc.encode_resident(args.distance, num_threads=args.host_threads, copy=False)
 
@@ -156,7 +172,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%dx%d synthetic linear-sRGB frame per GPU, distance %.2f, full 8x8/16x8/8x16 "
                                "strategy search + adaptive quant + chroma-from-luma" % (size, size, args.distance),
-                   "groups_per_gpu": int(fr.num_groups), "parallelism": "frames sharded by rank, no collective",
+                   "groups_per_gpu": int(fr.num_groups), "parallelism": ("one %dx%d frame, row slabs of whole DC groups per rank; histogram all-reduce + "
+                                   "section gather" % (size, size * world)) if sharded is not None else
+                   "one independent frame per rank, no data-path collective",
                    "codestream_bytes": len(jxl), "raw_token_bytes": token_bytes},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(size),

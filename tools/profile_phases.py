@@ -53,6 +53,20 @@ def main():
         t3 = time.perf_counter()
     print("host: device %.2f ms, fetch(D2H) %.2f ms, assemble %.2f ms (%d bytes)" %
           (1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), len(blob)))
+    # drop-in EncodeFile from pageable host planes (H2D inclusive)
+    if size <= 8192:
+        host = frame.cpu().numpy()
+        for rep in range(2):
+            t0 = time.perf_counter()
+            jxl = pkg.encode_file(host, 1.0)
+            t1 = time.perf_counter()
+        print("EncodeFile from host planes (H2D + encode + copy out): %.2f ms = %.0f MP/s (%d bytes)" %
+              (1e3 * (t1 - t0), size * size / 1e6 / (t1 - t0), len(jxl)))
+        t0 = time.perf_counter()
+        nb = enc.encode_resident(1.0, copy=False)
+        print("encode_resident (frame in HBM): %.2f ms = %.0f MP/s" %
+              (1e3 * (time.perf_counter() - t0), size * size / 1e6 / (time.perf_counter() - t0)))
+    return
     for nt in (1, 8, 32, 64):
         enc.enqueue(1.0, 0)
         fr = enc.fetch_raw()
