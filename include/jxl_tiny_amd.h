@@ -94,6 +94,12 @@ const char* jxlt_last_error(const jxlt_context* ctx);
  * host reads of CopyAndPadImage (enc_frame.cc:597-617). */
 int jxlt_image_upload(jxlt_context* ctx, const float* const planes[3], size_t pitch_bytes,
                       size_t xsize, size_t ysize);
+/* Page-locked host memory (hipHostMalloc) for image planes: uploads from it run at PCIe
+ * speed without staging.  Returns NULL when no HIP device is usable (callers fall back to
+ * ordinary memory).  Free with jxlt_pinned_free. */
+void* jxlt_pinned_alloc(size_t bytes);
+void jxlt_pinned_free(void* p);
+
 /* Borrows planes already resident in HBM (e.g. a torch tensor's data_ptr). */
 int jxlt_image_set_device(jxlt_context* ctx, const void* const device_planes[3],
                           size_t pitch_bytes, size_t xsize, size_t ysize);

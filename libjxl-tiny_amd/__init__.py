@@ -29,7 +29,8 @@ FLAG_FORCE_DCT8, FLAG_DEBUG_DUMP, FLAG_PROFILE = 1, 2, 4
 
 # Symbols include/jxl_tiny_amd.h declares, per library (checked by the tests).
 HIP_SYMBOLS = ["jxlt_context_create", "jxlt_context_destroy", "jxlt_last_error",
-               "jxlt_image_upload", "jxlt_image_set_device", "jxlt_image_size", "jxlt_encode_enqueue",
+               "jxlt_image_upload", "jxlt_image_set_device", "jxlt_image_size", "jxlt_pinned_alloc",
+               "jxlt_pinned_free", "jxlt_encode_enqueue",
                "jxlt_fetch_side_info", "jxlt_fetch_histograms", "jxlt_pack_ac_sections", "jxlt_pack_sections",
                "jxlt_synchronize", "jxlt_fetch_result", "jxlt_kernel_times", "jxlt_debug_fetch"]
 HOST_SYMBOLS = ["jxlt_compute_distance_params", "jxlt_assemble_frame", "jxlt_assemble_frame_groups",

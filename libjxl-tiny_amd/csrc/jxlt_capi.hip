@@ -12,7 +12,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/jxl_tiny_amd.h"
@@ -49,6 +52,10 @@ struct jxlt_context {
   const float* planes[3] = {nullptr, nullptr, nullptr};
   size_t pitch_floats = 0;
   size_t xsize = 0, ysize = 0;
+
+  // pinned staging ring for uploads from pageable memory
+  PinnedBuf<uint8_t> stage[2];
+  hipEvent_t stage_done[2] = {nullptr, nullptr};
 
   // constant tables (rebuilt when `scale` changes)
   DeviceTables* d_tab = nullptr;
@@ -192,6 +199,7 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
     return JXLT_ERR_NO_DEVICE;
   }
   for (auto& ev : ctx->ev) (void)hipEventCreate(&ev);
+  for (auto& ev : ctx->stage_done) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   *out = ctx;
   return JXLT_OK;
 }
@@ -245,6 +253,9 @@ void jxlt_context_destroy(jxlt_context* ctx) {
   FreePinned(&ctx->h_ytob);
   FreePinned(&ctx->h_group_off);
   if (ctx->d_tab) (void)hipFree(ctx->d_tab);
+  for (auto& st : ctx->stage) FreePinned(&st);
+  for (auto& ev : ctx->stage_done)
+    if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->ev)
     if (ev) (void)hipEventDestroy(ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -261,13 +272,50 @@ int jxlt_image_upload(jxlt_context* ctx, const float* const planes[3], size_t pi
   if (rc != JXLT_OK) return rc;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t pitch_floats = (xsize + 63) & ~size_t(63);
+  const size_t row_bytes = xsize * sizeof(float);
+  // Pinned / registered host memory goes straight over PCIe.  Pageable memory is staged
+  // through two pinned buffers: host threads copy a band of rows while the previous band
+  // is in flight (a pageable hipMemcpy2D is synchronous and runs at a few GB/s).
+  hipPointerAttribute_t attr;
+  const bool pinned = hipPointerGetAttributes(&attr, planes[0]) == hipSuccess &&
+                      attr.type == hipMemoryTypeHost;
+  (void)hipGetLastError();  // a pageable pointer is not an error
+  constexpr size_t kStageBytes = size_t(32) << 20;
+  const size_t band_rows = std::max<size_t>(1, std::min(ysize, kStageBytes / row_bytes));
+  if (!pinned)
+    for (auto& st : ctx->stage)
+      if ((rc = EnsurePinned(ctx, &st, band_rows * row_bytes)) != JXLT_OK) return rc;
+  int turn = 0;
   for (int c = 0; c < 3; c++) {
     rc = EnsureDevice(ctx, &ctx->own_planes[c], pitch_floats * ysize);
     if (rc != JXLT_OK) return rc;
-    HIP_TRY(ctx, hipMemcpy2DAsync(ctx->own_planes[c].p, pitch_floats * sizeof(float), planes[c],
-                                  pitch_bytes, xsize * sizeof(float), ysize, hipMemcpyHostToDevice,
-                                  ctx->stream));
     ctx->planes[c] = ctx->own_planes[c].p;
+    if (pinned) {
+      HIP_TRY(ctx, hipMemcpy2DAsync(ctx->own_planes[c].p, pitch_floats * sizeof(float), planes[c], pitch_bytes,
+                                    row_bytes, ysize, hipMemcpyHostToDevice, ctx->stream));
+      continue;
+    }
+    for (size_t y0 = 0; y0 < ysize; y0 += band_rows, turn ^= 1) {
+      const size_t rows = std::min(band_rows, ysize - y0);
+      uint8_t* dst = ctx->stage[turn].p;
+      HIP_TRY(ctx, hipEventSynchronize(ctx->stage_done[turn]));  // previous use of this buffer
+      const uint8_t* src = reinterpret_cast<const uint8_t*>(planes[c]) + y0 * pitch_bytes;
+      const int nthreads = rows * row_bytes > (size_t(4) << 20) ? 4 : 1;
+      auto copy_rows = [&](size_t a, size_t b) {
+        for (size_t y = a; y < b; y++) memcpy(dst + y * row_bytes, src + y * pitch_bytes, row_bytes);
+      };
+      if (nthreads == 1) {
+        copy_rows(0, rows);
+      } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; t++)
+          pool.emplace_back(copy_rows, rows * t / nthreads, rows * (t + 1) / nthreads);
+        for (auto& th : pool) th.join();
+      }
+      HIP_TRY(ctx, hipMemcpy2DAsync(ctx->own_planes[c].p + y0 * pitch_floats, pitch_floats * sizeof(float), dst,
+                                    row_bytes, row_bytes, rows, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(ctx, hipEventRecord(ctx->stage_done[turn], ctx->stream));
+    }
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // caller may reuse its buffers
   ctx->pitch_floats = pitch_floats;
@@ -275,6 +323,24 @@ int jxlt_image_upload(jxlt_context* ctx, const float* const planes[3], size_t pi
   ctx->ysize = ysize;
   ctx->encoded = false;
   return JXLT_OK;
+}
+
+void* jxlt_pinned_alloc(size_t bytes) {
+  void* p = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+
+void jxlt_pinned_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 
 int jxlt_image_set_device(jxlt_context* ctx, const void* const device_planes[3], size_t pitch_bytes,

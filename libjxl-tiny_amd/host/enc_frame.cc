@@ -148,7 +148,9 @@ struct ThreadContext {
 };
 thread_local ThreadContext g_tls;
 
-jxlt_context* AcquireContext() {
+}  // namespace
+
+jxlt_context* AcquireContextForThread() {
   if (g_tls.ctx && g_tls.device == g_device) return g_tls.ctx;
   if (g_tls.ctx) {
     jxlt_context_destroy(g_tls.ctx);
@@ -163,14 +165,20 @@ jxlt_context* AcquireContext() {
   return g_tls.ctx;
 }
 
-}  // namespace
-
 void SetEncoderDevice(int device_ordinal) { g_device = device_ordinal; }
+
+}  // namespace jxl
+
+namespace jxlt {
+jxlt_context* AcquireThreadContext() { return jxl::AcquireContextForThread(); }
+}  // namespace jxlt
+
+namespace jxl {
 
 Status EncodeFrame(const float distance, const Image3F& linear, ThreadPool* pool,
                    BitWriter* writer) {
   if (linear.xsize() == 0 || linear.ysize() == 0 || !(distance > 0)) return false;
-  jxlt_context* ctx = AcquireContext();
+  jxlt_context* ctx = AcquireContextForThread();
   if (!ctx) return false;  // no CPU fallback by design
   const float* planes[3] = {linear.ConstPlaneRow(0, 0), linear.ConstPlaneRow(1, 0),
                             linear.ConstPlaneRow(2, 0)};

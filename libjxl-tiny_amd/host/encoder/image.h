@@ -10,8 +10,12 @@
 #include <stdint.h>
 #include <stdlib.h>
 
-#include <memory>
 #include <utility>
+
+extern "C" {
+void* jxlt_pinned_alloc(size_t bytes);  // libjxltiny_hip.so (include/jxl_tiny_amd.h)
+void jxlt_pinned_free(void* p);
+}
 
 namespace jxl {
 
@@ -24,12 +28,27 @@ class Plane {
     bytes_per_row_ = ((xsize * sizeof(T) + 127) / 128) * 128;
     if (bytes_per_row_ == 0) bytes_per_row_ = 128;
     const size_t total = bytes_per_row_ * (ysize ? ysize : 1);
-    void* p = nullptr;
-    if (posix_memalign(&p, 64, total) != 0) p = nullptr;
-    bytes_.reset(static_cast<uint8_t*>(p));
+    // Page-locked when a GPU is present (EncodeFile's upload then needs no staging copy).
+    void* p = jxlt_pinned_alloc(total);
+    pinned_ = p != nullptr;
+    if (!p && posix_memalign(&p, 64, total) != 0) p = nullptr;
+    bytes_ = static_cast<uint8_t*>(p);
   }
-  Plane(Plane&&) = default;
-  Plane& operator=(Plane&&) = default;
+  ~Plane() { Release(); }
+  Plane(Plane&& o) noexcept { *this = std::move(o); }
+  Plane& operator=(Plane&& o) noexcept {
+    if (this != &o) {
+      Release();
+      xsize_ = o.xsize_;
+      ysize_ = o.ysize_;
+      bytes_per_row_ = o.bytes_per_row_;
+      bytes_ = o.bytes_;
+      pinned_ = o.pinned_;
+      o.bytes_ = nullptr;
+      o.xsize_ = o.ysize_ = o.bytes_per_row_ = 0;
+    }
+    return *this;
+  }
   Plane(const Plane&) = delete;
   Plane& operator=(const Plane&) = delete;
 
@@ -37,17 +56,22 @@ class Plane {
   size_t ysize() const { return ysize_; }
   size_t bytes_per_row() const { return bytes_per_row_; }
   intptr_t PixelsPerRow() const { return static_cast<intptr_t>(bytes_per_row_ / sizeof(T)); }
-  T* Row(size_t y) { return reinterpret_cast<T*>(bytes_.get() + y * bytes_per_row_); }
-  const T* Row(size_t y) const { return reinterpret_cast<const T*>(bytes_.get() + y * bytes_per_row_); }
+  T* Row(size_t y) { return reinterpret_cast<T*>(bytes_ + y * bytes_per_row_); }
+  const T* Row(size_t y) const { return reinterpret_cast<const T*>(bytes_ + y * bytes_per_row_); }
   const T* ConstRow(size_t y) const { return Row(y); }
   bool valid() const { return bytes_ != nullptr; }
 
  private:
-  struct Free {
-    void operator()(uint8_t* p) const { free(p); }
-  };
+  void Release() {
+    if (bytes_) {
+      if (pinned_) jxlt_pinned_free(bytes_);
+      else free(bytes_);
+    }
+    bytes_ = nullptr;
+  }
   size_t xsize_ = 0, ysize_ = 0, bytes_per_row_ = 0;
-  std::unique_ptr<uint8_t, Free> bytes_;
+  uint8_t* bytes_ = nullptr;
+  bool pinned_ = false;
 };
 
 using ImageF = Plane<float>;

@@ -96,16 +96,18 @@ int jxlt_encode_file_planar(const float* const planes[3], size_t pitch_bytes, si
   if (!planes || !out_bytes || !out_size || xsize == 0 || ysize == 0 ||
       pitch_bytes < xsize * sizeof(float) || pitch_bytes % sizeof(float))
     return JXLT_ERR_INVALID_ARGUMENT;
-  jxl::Image3F img(xsize, ysize);
-  if (!img.valid()) return JXLT_ERR_OUT_OF_MEMORY;
-  for (size_t c = 0; c < 3; ++c)
-    for (size_t y = 0; y < ysize; ++y)
-      memcpy(img.PlaneRow(c, y), reinterpret_cast<const uint8_t*>(planes[c]) + y * pitch_bytes,
-             xsize * sizeof(float));
+  // Same as jxl::EncodeFile (enc_file.cc:55-105) but the planes go to the device straight from
+  // the caller's memory (no intermediate Image3F copy).
   jxl::SetEncoderDevice(device_ordinal);
-  std::vector<uint8_t> out;
-  if (!jxl::EncodeFile(img, distance, &out)) return JXLT_ERR_INTERNAL;
-  return ToMalloc(out, out_bytes, out_size);
+  jxlt_context* ctx = jxlt::AcquireThreadContext();
+  if (!ctx) return JXLT_ERR_NO_DEVICE;
+  {
+    float d = distance;
+    if (!jxlt::NormalizeDistance(&d)) return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = jxlt_image_upload(ctx, planes, pitch_bytes, xsize, ysize);
+  if (rc != JXLT_OK) return rc;
+  return jxlt_encode_resident(ctx, distance, 0, out_bytes, out_size);
 }
 
 int jxlt_encode_resident(jxlt_context* ctx, float distance, int num_threads, uint8_t** out_bytes,

@@ -12,6 +12,8 @@
 struct jxlt_context;
 
 namespace jxlt {
+// Device context of the calling thread for the device chosen by jxl::SetEncoderDevice (or null).
+jxlt_context* AcquireThreadContext();
 bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jxl::BitWriter* writer,
                           const std::function<void(const uint8_t*, size_t)>* sink);
 bool WriteFileHeader(size_t xsize, size_t ysize, jxl::BitWriter* writer);
