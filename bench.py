@@ -119,7 +119,7 @@ def main():
             out = sharded.encode_sharded(sharded.GpuSlab(enc, args.distance), comm, size, size * world,
                                          args.distance, pkg)
             return out if out is not None else b""
-        # the codestream stays in the library's malloc'ed host buffer (no Python-side copy)
+        # the codestream is assembled in the context's page-locked host buffer (no extra copy)
         return enc.encode_resident(args.distance, num_threads=args.host_threads, copy=False)
 
     for _ in range(args.warmup):

@@ -138,6 +138,15 @@ int jxlt_pack_ac_sections(jxlt_context* ctx, const uint32_t* code_table, jxlt_pa
  * raw-record form of WriteDCGroup, enc_frame.cc:536-570), 1 = AC-group sections. */
 int jxlt_fetch_histograms(jxlt_context* ctx, const uint32_t** ac_histograms, const uint32_t** dc_histograms);
 int jxlt_pack_sections(jxlt_context* ctx, int kind, const uint32_t* code_table, jxlt_packed_sections* out);
+/* The same in two steps, so that the (large) AC blob can land directly where the caller is
+ * assembling the codestream: _sizes runs the kernels and returns offsets/bit counts
+ * (out->bytes is NULL), _copy then copies the concatenated sections to `dst` (host memory,
+ * ideally page-locked).  jxlt_output_buffer lends a page-locked, context-owned buffer of at
+ * least `bytes` bytes (valid until the next call that asks for a larger one / destroy). */
+int jxlt_pack_sections_sizes(jxlt_context* ctx, int kind, const uint32_t* code_table,
+                             jxlt_packed_sections* out);
+int jxlt_pack_sections_copy(jxlt_context* ctx, int kind, uint8_t* dst);
+int jxlt_output_buffer(jxlt_context* ctx, size_t bytes, uint8_t** out);
 
 /* Timing of the kernels of the last jxlt_encode_enqueue (needs JXLT_FLAG_PROFILE):
  * writes up to `cap` entries; returns the number of kernels, or < 0. */
@@ -175,6 +184,12 @@ int jxlt_assemble_frame_groups(const jxlt_frame_result* frame, const uint8_t* co
  * section packing, host assembly.  malloc'ed result, free with jxlt_free. */
 int jxlt_encode_resident(jxlt_context* ctx, float distance, int num_threads, uint8_t** out_bytes,
                          size_t* out_size);
+
+/* Same, without the final host copy: the codestream is assembled in the context's
+ * page-locked output buffer (the packed AC sections are copied from the device straight
+ * into place); *bytes stays valid until the next encode on `ctx`. */
+int jxlt_encode_resident_view(jxlt_context* ctx, float distance, int num_threads, const uint8_t** bytes,
+                              size_t* size);
 
 /* C entry to the drop-in EncodeFile (enc_file.h:20-21): planar f32 in host
  * memory -> complete .jxl codestream (malloc'ed, free with jxlt_free).

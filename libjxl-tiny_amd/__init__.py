@@ -32,9 +32,10 @@ HIP_SYMBOLS = ["jxlt_context_create", "jxlt_context_destroy", "jxlt_last_error",
                "jxlt_image_upload", "jxlt_image_set_device", "jxlt_image_size", "jxlt_pinned_alloc",
                "jxlt_pinned_free", "jxlt_encode_enqueue",
                "jxlt_fetch_side_info", "jxlt_fetch_histograms", "jxlt_pack_ac_sections", "jxlt_pack_sections",
+               "jxlt_pack_sections_sizes", "jxlt_pack_sections_copy", "jxlt_output_buffer",
                "jxlt_synchronize", "jxlt_fetch_result", "jxlt_kernel_times", "jxlt_debug_fetch"]
 HOST_SYMBOLS = ["jxlt_compute_distance_params", "jxlt_assemble_frame", "jxlt_assemble_frame_groups",
-                "jxlt_encode_file_planar", "jxlt_encode_resident", "jxlt_write_file_header", "jxlt_build_code_tables", "jxlt_finish_frame",
+                "jxlt_encode_file_planar", "jxlt_encode_resident", "jxlt_encode_resident_view", "jxlt_write_file_header", "jxlt_build_code_tables", "jxlt_finish_frame",
                 "jxlt_debug_dc_records", "jxlt_free"]
 
 
@@ -139,6 +140,8 @@ def host_lib():
                                               C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         L.jxlt_encode_resident.argtypes = [C.c_void_p, C.c_float, C.c_int, C.POINTER(C.POINTER(C.c_uint8)),
                                            C.POINTER(C.c_size_t)]
+        L.jxlt_encode_resident_view.argtypes = [C.c_void_p, C.c_float, C.c_int, C.POINTER(C.POINTER(C.c_uint8)),
+                                                C.POINTER(C.c_size_t)]
         L.jxlt_write_file_header.argtypes = [C.c_size_t, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)),
                                              C.POINTER(C.c_size_t)]
         L.jxlt_build_code_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -170,8 +173,8 @@ def _take_bytes(ptr, n):
     return data
 
 
-class NativeBytes:
-    """A codestream living in a malloc'ed buffer of libjxltiny_host.so."""
+class NativeView:
+    """A codestream in a buffer owned by the native library (not freed from Python)."""
 
     def __init__(self, ptr, size):
         self.ptr, self.size = ptr, size
@@ -181,17 +184,6 @@ class NativeBytes:
 
     def tobytes(self):
         return C.string_at(self.ptr, self.size)
-
-    def free(self):
-        if self.ptr:
-            host_lib().jxlt_free(self.ptr)
-            self.ptr = None
-
-    def __del__(self):
-        try:
-            self.free()
-        except Exception:
-            pass
 
 
 def file_header(xsize, ysize):
@@ -340,15 +332,18 @@ class Encoder:
 
     def encode_resident(self, distance, num_threads=0, copy=True):
         """Full codestream of the image currently set/uploaded on the device (production path:
-        device pipeline + device section packing + host assembly, jxlt_encode_resident).
-        copy=False returns a NativeBytes handle on the malloc'ed result (no Python copy)."""
+        device pipeline + device section packing + host assembly).
+        copy=True  -> Python bytes (jxlt_encode_resident);
+        copy=False -> NativeView on the context's page-locked output buffer, valid until the next
+                      encode on this Encoder (jxlt_encode_resident_view: no host-side copy of the
+                      packed sections at all)."""
         out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
-        rc = host_lib().jxlt_encode_resident(self._ctx, C.c_float(distance), num_threads, C.byref(out),
-                                             C.byref(n))
+        fn = host_lib().jxlt_encode_resident if copy else host_lib().jxlt_encode_resident_view
+        rc = fn(self._ctx, C.c_float(distance), num_threads, C.byref(out), C.byref(n))
         if rc != 0:
             raise JxlTinyError("jxlt_encode_resident failed (%d): %s" %
                                (rc, self._L.jxlt_last_error(self._ctx).decode()))
-        return _take_bytes(out, n) if copy else NativeBytes(out, n.value)
+        return _take_bytes(out, n) if copy else NativeView(out, n.value)
 
     def encode_resident_raw_tokens(self, distance, num_threads=0, flags=0):
         """Same result through the raw-token route (tokens copied to the host and packed there)."""

@@ -84,7 +84,9 @@ struct jxlt_context {
     PinnedBuf<uint64_t> h_sec_byte_off;
     PinnedBuf<uint32_t> h_sec_bits;
     PinnedBuf<uint8_t> h_packed;
+    size_t packed_sections = 0;
   } pack[2];
+  PinnedBuf<uint8_t> h_output;  // jxlt_output_buffer
 
   // pinned host mirrors
   PinnedBuf<int16_t> h_quant_dc[3];
@@ -254,6 +256,7 @@ void jxlt_context_destroy(jxlt_context* ctx) {
   FreePinned(&ctx->h_group_off);
   if (ctx->d_tab) (void)hipFree(ctx->d_tab);
   for (auto& st : ctx->stage) FreePinned(&st);
+  FreePinned(&ctx->h_output);
   for (auto& ev : ctx->stage_done)
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->ev)
@@ -511,6 +514,7 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   ctx->geom = g;
   ctx->encoded = true;
   ctx->offsets_fetched = false;
+  ctx->pack[0].packed_sections = ctx->pack[1].packed_sections = 0;
   ctx->last_flags = params->flags;
   ctx->profiled = profile;
   return JXLT_OK;
@@ -635,7 +639,7 @@ int jxlt_fetch_histograms(jxlt_context* ctx, const uint32_t** ac_histograms, con
   return JXLT_OK;
 }
 
-int jxlt_pack_sections(jxlt_context* ctx, int kind, const uint32_t* code_table, jxlt_packed_sections* out) {
+int jxlt_pack_sections_sizes(jxlt_context* ctx, int kind, const uint32_t* code_table, jxlt_packed_sections* out) {
   if (!ctx || !code_table || !out || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
   if (!ctx->encoded || !ctx->offsets_fetched) {
     ctx->error = "jxlt_pack_sections needs jxlt_encode_enqueue + jxlt_fetch_histograms/side_info first";
@@ -686,18 +690,51 @@ int jxlt_pack_sections(jxlt_context* ctx, int kind, const uint32_t* code_table, 
   HIP_TRY(ctx, hipMemcpyAsync(ps.h_sec_bits.p, ps.sec_bits.p, nsec * sizeof(uint32_t), hipMemcpyDeviceToHost,
                               ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  const uint64_t total_bytes = ps.h_sec_byte_off.p[nsec];
-  if (ps.h_packed.cap < total_bytes + 1 &&
-      (rc = EnsurePinned(ctx, &ps.h_packed, total_bytes + total_bytes / 4 + 4096)) != JXLT_OK)
-    return rc;
-  if (total_bytes) {
-    HIP_TRY(ctx, hipMemcpyAsync(ps.h_packed.p, ps.packed.p, total_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  }
-  out->bytes = ps.h_packed.p;
+  out->bytes = nullptr;
   out->section_offset = ps.h_sec_byte_off.p;
   out->section_bits = ps.h_sec_bits.p;
   out->num_sections = nsec;
+  ps.packed_sections = nsec;
+  return JXLT_OK;
+}
+
+int jxlt_pack_sections_copy(jxlt_context* ctx, int kind, uint8_t* dst) {
+  if (!ctx || !dst || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
+  jxlt_context::PackSet& ps = ctx->pack[kind];
+  if (ps.packed_sections == 0) {
+    ctx->error = "jxlt_pack_sections_copy needs jxlt_pack_sections_sizes first";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint64_t total_bytes = ps.h_sec_byte_off.p[ps.packed_sections];
+  if (total_bytes) {
+    HIP_TRY(ctx, hipMemcpyAsync(dst, ps.packed.p, total_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return JXLT_OK;
+}
+
+int jxlt_pack_sections(jxlt_context* ctx, int kind, const uint32_t* code_table, jxlt_packed_sections* out) {
+  int rc = jxlt_pack_sections_sizes(ctx, kind, code_table, out);
+  if (rc != JXLT_OK) return rc;
+  jxlt_context::PackSet& ps = ctx->pack[kind];
+  const uint64_t total_bytes = ps.h_sec_byte_off.p[ps.packed_sections];
+  if (ps.h_packed.cap < total_bytes + 1 &&
+      (rc = EnsurePinned(ctx, &ps.h_packed, total_bytes + total_bytes / 4 + 4096)) != JXLT_OK)
+    return rc;
+  if ((rc = jxlt_pack_sections_copy(ctx, kind, ps.h_packed.p)) != JXLT_OK) return rc;
+  out->bytes = ps.h_packed.p;
+  return JXLT_OK;
+}
+
+int jxlt_output_buffer(jxlt_context* ctx, size_t bytes, uint8_t** out) {
+  if (!ctx || !out) return JXLT_ERR_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->h_output.cap < bytes) {
+    const int rc = EnsurePinned(ctx, &ctx->h_output, bytes + bytes / 8 + 65536);
+    if (rc != JXLT_OK) return rc;
+  }
+  *out = ctx->h_output.p;
   return JXLT_OK;
 }
 

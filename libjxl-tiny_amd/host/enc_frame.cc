@@ -5,6 +5,7 @@
 #include "encoder/enc_frame.h"
 
 #include <stdio.h>
+#include <string.h>
 
 #include <chrono>
 #include <cstdlib>
@@ -39,10 +40,10 @@ FrameView ViewOf(const jxlt_frame_result& res, const uint8_t* const* group_ptr, 
 // host builds the prefix codes (and, concurrently, the DC-group sections), the
 // device packs the AC sections.  Single-group frames (bit-concatenated sections,
 // enc_frame.cc:805-811) take the raw-token route.
-// Appends the frame to `writer` (if non-null) or, for the malloc-returning C entry,
-// hands the pieces to `sink(ptr, size)` in order.
+// Appends the frame to `writer` (if non-null); otherwise asks `placer(frame_bytes)` for the
+// destination and writes the frame there (the AC blob comes straight from the device).
 bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jxl::BitWriter* writer,
-                          const std::function<void(const uint8_t*, size_t)>* sink) {
+                          const std::function<uint8_t*(size_t)>* placer) {
   static const bool trace = getenv("JXLT_TRACE") != nullptr;
   auto now = []() { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
@@ -75,7 +76,9 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
     if (!AssembleFrame(ViewOf(res, &ptr, &len), distp, w, num_threads)) return false;
     if (!writer) {
       const std::vector<uint8_t>& b = local.Bytes();
-      (*sink)(b.data(), b.size());
+      uint8_t* dst = (*placer)(b.size());
+      if (!dst) return false;
+      memcpy(dst, b.data(), b.size());
     }
     return true;
   }
@@ -98,34 +101,50 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
     dc_thread.join();
   }
   const auto t2 = now();
+  // DC sections are small: fetched into the context's pinned buffer.  For the AC sections
+  // only the sizes are needed to write the TOC; the blob is copied once, to its final place.
   jxlt_packed_sections dcp, acp;
   if (jxlt_pack_sections(ctx, 0, dc_table.data(), &dcp) != JXLT_OK ||
-      jxlt_pack_sections(ctx, 1, ac_table.data(), &acp) != JXLT_OK) {
+      jxlt_pack_sections_sizes(ctx, 1, ac_table.data(), &acp) != JXLT_OK) {
     fprintf(stderr, "jxl_tiny_amd: section packing failed: %s\n", jxlt_last_error(ctx));
     return false;
   }
   const auto t3 = now();
   PackedSections dc = {dcp.bytes, dcp.section_offset, dcp.section_bits, dcp.num_sections};
-  PackedSections ac = {acp.bytes, acp.section_offset, acp.section_bits, acp.num_sections};
+  PackedSections ac = {nullptr, acp.section_offset, acp.section_bits, acp.num_sections};
   FramePieces pieces;
-  const bool ok = FinishFrame(xsize, ysize, distp, dc_code, dc, ac_code, ac, &pieces);
-  if (ok) {
-    const size_t dc_bytes = static_cast<size_t>(dc.offset[dc.n]), ac_bytes = static_cast<size_t>(ac.offset[ac.n]);
-    if (writer) {
-      writer->Reserve(pieces.head.size() + dc_bytes + pieces.ac_global.size() + ac_bytes);
+  if (!FinishFrame(xsize, ysize, distp, dc_code, dc, ac_code, ac, &pieces)) return false;
+  const size_t dc_bytes = static_cast<size_t>(dc.offset[dc.n]), ac_bytes = static_cast<size_t>(ac.offset[ac.n]);
+  const size_t frame_bytes = pieces.head.size() + dc_bytes + pieces.ac_global.size() + ac_bytes;
+  bool ok = true;
+  if (writer) {
+    // BitWriter API of the drop-in EncodeFrame: append, AC blob via one staging copy
+    uint8_t* tmp = nullptr;
+    ok = jxlt_output_buffer(ctx, ac_bytes ? ac_bytes : 1, &tmp) == JXLT_OK &&
+         jxlt_pack_sections_copy(ctx, 1, tmp) == JXLT_OK;
+    if (ok) {
+      writer->Reserve(frame_bytes);
       writer->AppendBytes(pieces.head.data(), pieces.head.size());
       writer->AppendBytes(dc.bytes, dc_bytes);
       writer->AppendBytes(pieces.ac_global.data(), pieces.ac_global.size());
-      writer->AppendBytes(ac.bytes, ac_bytes);
-    } else {
-      (*sink)(pieces.head.data(), pieces.head.size());
-      (*sink)(dc.bytes, dc_bytes);
-      (*sink)(pieces.ac_global.data(), pieces.ac_global.size());
-      (*sink)(ac.bytes, ac_bytes);
+      writer->AppendBytes(tmp, ac_bytes);
+    }
+  } else {
+    // placer(frame_bytes) returns where the frame must be written
+    uint8_t* dst = (*placer)(frame_bytes);
+    ok = dst != nullptr;
+    if (ok) {
+      memcpy(dst, pieces.head.data(), pieces.head.size());
+      dst += pieces.head.size();
+      memcpy(dst, dc.bytes, dc_bytes);
+      dst += dc_bytes;
+      memcpy(dst, pieces.ac_global.data(), pieces.ac_global.size());
+      dst += pieces.ac_global.size();
+      ok = jxlt_pack_sections_copy(ctx, 1, dst) == JXLT_OK;
     }
   }
   if (trace)
-    fprintf(stderr, "jxlt trace: device+histograms %.2f ms | codes %.2f | pack dc+ac (device) %.2f | finish %.2f\n",
+    fprintf(stderr, "jxlt trace: device+histograms %.2f ms | codes %.2f | pack (device) %.2f | finish+copy %.2f\n",
             ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
   (void)num_threads;
   return ok;

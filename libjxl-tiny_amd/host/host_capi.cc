@@ -110,35 +110,54 @@ int jxlt_encode_file_planar(const float* const planes[3], size_t pitch_bytes, si
   return jxlt_encode_resident(ctx, distance, 0, out_bytes, out_size);
 }
 
+namespace {
+// Shared by the two resident entry points: file header + frame into the buffer `alloc` returns.
+int EncodeResident(jxlt_context* ctx, float distance, int num_threads,
+                   const std::function<uint8_t*(size_t)>& alloc, size_t* out_size) {
+  if (!jxlt::NormalizeDistance(&distance)) return JXLT_ERR_INVALID_ARGUMENT;
+  size_t xsize = 0, ysize = 0;
+  if (jxlt_image_size(ctx, &xsize, &ysize) != JXLT_OK) return JXLT_ERR_INVALID_ARGUMENT;
+  jxl::BitWriter writer;
+  if (!jxlt::WriteFileHeader(xsize, ysize, &writer)) return JXLT_ERR_INVALID_ARGUMENT;
+  const std::vector<uint8_t> file_header = writer.TakeBytes();
+  const std::function<uint8_t*(size_t)> placer = [&](size_t frame_bytes) -> uint8_t* {
+    uint8_t* buf = alloc(file_header.size() + frame_bytes);
+    if (!buf) return nullptr;
+    memcpy(buf, file_header.data(), file_header.size());
+    *out_size = file_header.size() + frame_bytes;
+    return buf + file_header.size();
+  };
+  return jxlt::EncodeFrameOnContext(ctx, distance, num_threads, nullptr, &placer) ? JXLT_OK : JXLT_ERR_INTERNAL;
+}
+}  // namespace
+
 int jxlt_encode_resident(jxlt_context* ctx, float distance, int num_threads, uint8_t** out_bytes,
                          size_t* out_size) {
   if (!ctx || !out_bytes || !out_size) return JXLT_ERR_INVALID_ARGUMENT;
-  if (!jxlt::NormalizeDistance(&distance)) return JXLT_ERR_INVALID_ARGUMENT;
-  jxl::BitWriter writer;
-  // The context knows the image size; the header needs it, so ask the device path first.
-  size_t xsize = 0, ysize = 0;
-  if (jxlt_image_size(ctx, &xsize, &ysize) != JXLT_OK) return JXLT_ERR_INVALID_ARGUMENT;
-  if (!jxlt::WriteFileHeader(xsize, ysize, &writer)) return JXLT_ERR_INVALID_ARGUMENT;
-  // Collect the pieces (file header, frame head, DC blob, ACGlobal, AC blob) and copy each
-  // exactly once into the returned buffer.
-  const std::vector<uint8_t> file_header = writer.TakeBytes();
   uint8_t* buf = nullptr;
-  size_t cap = 0, used = 0;
-  const std::function<void(const uint8_t*, size_t)> sink = [&](const uint8_t* p, size_t n) {
-    if (used + n > cap) {
-      cap = used + n + (used + n) / 8 + 65536;
-      buf = static_cast<uint8_t*>(realloc(buf, cap));
-    }
-    memcpy(buf + used, p, n);
-    used += n;
-  };
-  sink(file_header.data(), file_header.size());
-  if (!jxlt::EncodeFrameOnContext(ctx, distance, num_threads, nullptr, &sink)) {
+  const int rc = EncodeResident(ctx, distance, num_threads, [&](size_t n) {
+    buf = static_cast<uint8_t*>(malloc(n ? n : 1));
+    return buf;
+  }, out_size);
+  if (rc != JXLT_OK) {
     free(buf);
-    return JXLT_ERR_INTERNAL;
+    return rc;
   }
   *out_bytes = buf;
-  *out_size = used;
+  return JXLT_OK;
+}
+
+int jxlt_encode_resident_view(jxlt_context* ctx, float distance, int num_threads, const uint8_t** bytes,
+                              size_t* size) {
+  if (!ctx || !bytes || !size) return JXLT_ERR_INVALID_ARGUMENT;
+  uint8_t* buf = nullptr;
+  // The codestream lives after a 64 MiB-independent offset of the context's pinned output
+  // buffer; the same buffer is also used as AC staging by the BitWriter path, never both.
+  const int rc = EncodeResident(ctx, distance, num_threads, [&](size_t n) -> uint8_t* {
+    return jxlt_output_buffer(ctx, n, &buf) == JXLT_OK ? buf : nullptr;
+  }, size);
+  if (rc != JXLT_OK) return rc;
+  *bytes = buf;
   return JXLT_OK;
 }
 

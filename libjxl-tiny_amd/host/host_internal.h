@@ -15,7 +15,7 @@ namespace jxlt {
 // Device context of the calling thread for the device chosen by jxl::SetEncoderDevice (or null).
 jxlt_context* AcquireThreadContext();
 bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jxl::BitWriter* writer,
-                          const std::function<void(const uint8_t*, size_t)>* sink);
+                          const std::function<uint8_t*(size_t)>* placer);
 bool WriteFileHeader(size_t xsize, size_t ysize, jxl::BitWriter* writer);
 bool NormalizeDistance(float* distance);
 }  // namespace jxlt

@@ -141,6 +141,7 @@ def test_device_packed_sections_equal_host_packed(built, enc, w, h, distance):
     a = enc.encode_resident(distance)
     b = enc.encode_resident_raw_tokens(distance)
     assert a == b
+    assert enc.encode_resident(distance, copy=False).tobytes() == a  # page-locked view variant
     assert a == T.assemble_codestream(T.oracle_hot_path(planes, distance), distance)
 
 
