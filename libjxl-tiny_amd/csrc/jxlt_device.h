@@ -125,17 +125,40 @@ JXLT_DI float nfma32(float a, float b, float c) { return __builtin_fmaf(-a, b, c
 JXLT_DI float zero_if_negative(float v) {
   return (__float_as_uint(v) & 0x80000000u) ? 0.0f : v;
 }
+// Cross-lane moves inside an octet use DPP (data-parallel primitives: a VALU move with a
+// lane permutation, no LDS round trip).  quad_perm covers xor 1 and xor 2; xor 4 is two
+// row shifts by 4 whose bank masks pick the lanes that have a partner in that direction
+// (a DPP bank = 4 lanes, a row = 16 lanes, octets never straddle a row).
+constexpr int kDppXor1 = 0xB1;       // quad_perm:[1,0,3,2]
+constexpr int kDppXor2 = 0x4E;       // quad_perm:[2,3,0,1]
+constexpr int kDppRowShl4 = 0x104;   // lane i reads lane i + 4
+constexpr int kDppRowShr4 = 0x114;   // lane i reads lane i - 4
+
+// value of lane (l ^ S) for S in {1, 2, 4}
+template <int S>
+JXLT_DI int octet_xor_i(int v) {
+  if (S == 4) {
+    int t = __builtin_amdgcn_update_dpp(0, v, kDppRowShl4, 0xF, 0x5, false);  // lanes 0-3 of each octet
+    return __builtin_amdgcn_update_dpp(t, v, kDppRowShr4, 0xF, 0xA, false);   // lanes 4-7
+  }
+  return __builtin_amdgcn_update_dpp(0, v, S == 1 ? kDppXor1 : kDppXor2, 0xF, 0xF, true);
+}
+template <int S>
+JXLT_DI float octet_xor(float v) {
+  return __int_as_float(octet_xor_i<S>(__float_as_int(v)));
+}
+
 // SumOfLanes over the 8 lanes of an octet: (i)+(i^4), (i)+(i^2), (i)+(i^1).
 JXLT_DI float octet_sum(float v) {
-  v = v + __shfl_xor(v, 4);
-  v = v + __shfl_xor(v, 2);
-  v = v + __shfl_xor(v, 1);
+  v = v + octet_xor<4>(v);
+  v = v + octet_xor<2>(v);
+  v = v + octet_xor<1>(v);
   return v;
 }
 JXLT_DI int octet_sum_int(int v) {
-  v = v + __shfl_xor(v, 4);
-  v = v + __shfl_xor(v, 2);
-  v = v + __shfl_xor(v, 1);
+  v = v + octet_xor_i<4>(v);
+  v = v + octet_xor_i<2>(v);
+  v = v + octet_xor_i<1>(v);
   return v;
 }
 JXLT_DI int ceil_log2_nonzero(uint32_t x) {
@@ -291,22 +314,39 @@ JXLT_DI void dct16(float* m) {
   }
 }
 
+// One butterfly exchange of an octet transpose: lanes with (l & S) == 0 keep `a` and receive
+// their partner's `a` into `b`; the other lanes keep `b` and receive their partner's `b` into
+// `a` (partner = lane l ^ S).
+template <int S>
+JXLT_DI void octet_exchange(float& a, float& b, int l) {
+  const int ai = __float_as_int(a), bi = __float_as_int(b);
+  if (S == 4) {
+    // bank-masked row shifts do the select and the move in one instruction each
+    a = __int_as_float(__builtin_amdgcn_update_dpp(ai, bi, kDppRowShr4, 0xF, 0xA, false));
+    b = __int_as_float(__builtin_amdgcn_update_dpp(bi, ai, kDppRowShl4, 0xF, 0x5, false));
+  } else {
+    const bool hi = (l & S) != 0;
+    const int pa = octet_xor_i<S>(ai), pb = octet_xor_i<S>(bi);
+    a = hi ? __int_as_float(pb) : a;
+    b = hi ? b : __int_as_float(pa);
+  }
+}
+
 // 8x8 transpose across the 8 lanes of an octet: lane l holds v[j] = M[j][l] and
 // ends with v[j] = M[l][j].  Three butterfly stages, static register indices.
 JXLT_DI void octet_transpose(float* v, int l) {
-#pragma unroll
-  for (int s = 4; s >= 1; s >>= 1) {
-    const bool hi = (l & s) != 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      if (j & s) continue;
-      const float a = v[j], b = v[j | s];
-      const float recv = __shfl_xor(hi ? a : b, s);
-      // value selects (not a selected destination): keeps v[] in registers
-      v[j] = hi ? recv : a;
-      v[j | s] = hi ? b : recv;
-    }
-  }
+  octet_exchange<4>(v[0], v[4], l);
+  octet_exchange<4>(v[1], v[5], l);
+  octet_exchange<4>(v[2], v[6], l);
+  octet_exchange<4>(v[3], v[7], l);
+  octet_exchange<2>(v[0], v[2], l);
+  octet_exchange<2>(v[1], v[3], l);
+  octet_exchange<2>(v[4], v[6], l);
+  octet_exchange<2>(v[5], v[7], l);
+  octet_exchange<1>(v[0], v[1], l);
+  octet_exchange<1>(v[2], v[3], l);
+  octet_exchange<1>(v[4], v[5], l);
+  octet_exchange<1>(v[6], v[7], l);
 }
 
 // Block transforms.  `px` points at the block's top-left sample in an LDS plane

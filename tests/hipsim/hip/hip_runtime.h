@@ -264,6 +264,36 @@ inline unsigned long long __ballot(int pred) {
   return hipsim::M().ballot_result[hipsim::M().current / hipsim::kWave];
 }
 
+// DPP move (llvm.amdgcn.update.dpp): lane i reads `src` of the lane selected by dpp_ctrl; lanes
+// whose row/bank is masked out, or whose source lane is outside the row, keep `old`
+// (or get 0 with bound_ctrl).  Supported controls: quad_perm (0x00-0xFF), row_shl:n
+// (0x101-0x10F, reads lane i+n), row_shr:n (0x111-0x11F, reads lane i-n).
+inline int __builtin_amdgcn_update_dpp(int old, int src, int dpp_ctrl, int row_mask, int bank_mask,
+                                       bool bound_ctrl) {
+  const int lane = hipsim_lane();
+  const int row = lane >> 4, in_row = lane & 15, bank = in_row >> 2;
+  int src_lane = -1;
+  if (dpp_ctrl >= 0 && dpp_ctrl <= 0xFF) {
+    src_lane = (lane & ~3) | ((dpp_ctrl >> (2 * (lane & 3))) & 3);
+  } else if (dpp_ctrl >= 0x101 && dpp_ctrl <= 0x10F) {
+    const int t = in_row + (dpp_ctrl - 0x100);
+    src_lane = t < 16 ? (lane & ~15) | t : -1;
+  } else if (dpp_ctrl >= 0x111 && dpp_ctrl <= 0x11F) {
+    const int t = in_row - (dpp_ctrl - 0x110);
+    src_lane = t >= 0 ? (lane & ~15) | t : -1;
+  } else {
+    fprintf(stderr, "hipsim: unsupported dpp_ctrl 0x%x\n", dpp_ctrl);
+    abort();
+  }
+  // every lane publishes `src`; masked-out lanes read nobody (their nominal source lane may
+  // belong to a diverged octet)
+  const bool enabled = ((row_mask >> row) & 1) && ((bank_mask >> bank) & 1);
+  const int got = hipsim_shfl_bits(src, (src_lane < 0 || !enabled) ? lane : src_lane);
+  if (!enabled) return old;
+  if (src_lane < 0) return bound_ctrl ? 0 : old;
+  return got;
+}
+
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __clzll(long long x) { return x == 0 ? 64 : __builtin_clzll((unsigned long long)x); }
 inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }
