@@ -452,6 +452,7 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   A.scale_dc = params->scale_dc;
   A.x_qm_mul = XQmMultiplier(params->x_qm_scale);
   A.flags = (params->flags & JXLT_FLAG_FORCE_DCT8) ? 1u : 0u;
+  A.flags |= params->flags & 0xF00u;  // profiling only: truncate tile_kernel after phase n-1 (tools/profile_phases.py)
   A.tab = ctx->d_tab;
   A.raw_quant = ctx->raw_quant.p;
   A.strategy = ctx->strategy.p;

@@ -184,6 +184,22 @@ JXLT_DI void hybrid_uint(uint32_t value, uint32_t* sym, uint32_t* nbits, uint32_
   }
 }
 
+// Correctly rounded sqrtf for x == 0 or x in [2^-64, 2^64]: the hardware root (<= 1 ulp off)
+// plus the usual neighbour test -- the residuals x - s_down*s and x - s_up*s tell whether a
+// neighbour is the rounded root.  This is the generic sqrtf expansion minus its input scaling
+// and its zero/infinity fix-up, which these argument ranges do not need.  (x == 0: s = 0, the
+// "down" neighbour is a NaN pattern and the "up" residual is -0, both tests fail, s stays 0.)
+JXLT_DI float sqrt_exact_midrange(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float s_dn = __int_as_float(__float_as_int(s) - 1);
+  const float s_up = __int_as_float(__float_as_int(s) + 1);
+  const float r_dn = nfma32(s_dn, s, x);
+  const float r_up = nfma32(s_up, s, x);
+  float r = (r_dn <= 0.0f) ? s_dn : s;
+  r = (r_up > 0.0f) ? s_up : r;
+  return r;
+}
+
 // fast_math-inl.h:113-133 + :74-108
 JXLT_DI float fast_log2f(float x) {
   const float p0 = -1.8503833400518310E-06f, p1 = 1.4287160470083755E+00f,
@@ -451,7 +467,7 @@ JXLT_DI float ratio_of_derivatives(float v, bool invert) {
 // so that it is computed once (correctly rounded) per thread.
 JXLT_DI float masking_sqrt(float v, float sqrt_mul) {
   const float kLogOffset = 26.481471032459346f;
-  return 0.25f * sqrtf(fma32(v, sqrt_mul, kLogOffset));
+  return 0.25f * sqrt_exact_midrange(fma32(v, sqrt_mul, kLogOffset));  // argument >= kLogOffset
 }
 JXLT_DI float masking_sqrt_mul() {
   const float kMul = 211.50759899638012f;
@@ -562,7 +578,7 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
       entropy_v = entropy_v + (q >= 1.5f ? kCost2 : 0.0f);
       // (a 64-entry LDS table of sqrtf(i) was tried here and measured slower: the random
       // LDS reads and the extra register pressure cost more than the IEEE sqrt sequence)
-      entropy_v = fma32(sqrtf(q), kCostDelta, entropy_v);
+      entropy_v = fma32(sqrt_exact_midrange(q), kCostDelta, entropy_v);  // q is 0 or an integer >= 1
       nzeros_v = nzeros_v + (q == 0.0f ? 0.0f : 1.0f);
     }
     entropy_v = fma32(nzeros_v, cost_of_1, entropy_v);
@@ -734,12 +750,20 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
   const int oct = tid >> 3;  // octet index == block index within tile (0..63)
   const DeviceTables* T = A.tab;
   long long t_prev = A.dbg_phase ? clock64() : 0;
+  // Profiling builds (-DJXLT_PHASE_STOPS, tools/phase_pmc.py) can truncate the kernel after
+  // phase i; the early exits perturb code generation, so production builds leave them out.
+#ifdef JXLT_PHASE_STOPS
+#define JXLT_STOP(i) if (((A.flags >> 8) & 15u) == (unsigned)(i) + 1u) return;
+#else
+#define JXLT_STOP(i)
+#endif
 #define JXLT_MARK(i)                                                        \
   if (A.dbg_phase && tid == 0) {                                            \
     const long long t_now = clock64();                                      \
     atomicAdd(&A.dbg_phase[i], (unsigned long long)(t_now - t_prev));       \
     t_prev = t_now;                                                         \
-  }
+  }                                                                         \
+  JXLT_STOP(i)
 
   // ---- geometry (enc_frame.cc:716-751) ------------------------------------
   // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed placement, used for
@@ -1015,7 +1039,6 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
   __syncthreads();
   JXLT_MARK(3);
 
-  JXLT_MARK(4);
   // ---- P6a: candidate two-block transforms (enc_ac_strategy.cc:62-66) -------
   // Waves 0-3 take the 32 DCT16X8 candidates, waves 4-7 the 32 DCT8X16 candidates.
   // Done before chroma-from-luma so that afterwards no pixel is needed any more; the
@@ -1239,15 +1262,17 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
   __syncthreads();
   JXLT_MARK(8);
 
-  // ---- P9: scan-order store; one wave per (block, channel) --------------------
+  // ---- P9: scan-order store; wave w stores block row w of the tile -------------
   {
-    const int wave = tid >> 6, lane = tid & 63;
-    uint32_t my_tokens = 0;
-    for (int item = wave; item < 64 * 3; item += kTileThreads / 64) {
-      const int bi = item / 3, c = item % 3;
-      const int bx = bi & 7, by = bi >> 3;
-      if (bx >= nbx || by >= nby) continue;
-      const uint8_t a = S.strat[bi];
+    // Everything but the coefficient itself is wave-uniform here (block, strategy, output
+    // positions, last-nonzero position), so the wave index is pinned to a scalar register and
+    // the bookkeeping runs on the scalar unit.
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    uint32_t wave_tokens = 0;
+    const int by = wave;
+    for (int bx = 0; by < nby && bx < nbx; bx++) {
+      const int bi = by * 8 + bx;
+      const int a = __builtin_amdgcn_readfirstlane((int)S.strat[bi]);
       if (!(a & 1)) continue;
       const int st = a >> 1;
       const int covered = st == 0 ? 1 : 2;
@@ -1255,27 +1280,34 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
       const uint8_t* order = &S.order[st == 0 ? 0 : 64];
       const uint32_t pos0 = (uint32_t)(by_img0 + by) * bstride + (uint32_t)(bx_img0 + bx);
       const uint32_t pos1 = pos0 + (st == 1 ? bstride : 1u);
-      int nscan = 0;
-      int16_t vh[2] = {0, 0};
-#pragma unroll
-      for (int half = 0; half < 2; half++) {
-        if (half >= covered) break;
-        const int k = half * 64 + lane;
-        const int i = order[k];
-        vh[half] = (i < 64 ? stage[bi * 192 + c * 64 + i] : stage[(bi + o2) * 192 + c * 64 + i - 64]);
-        const bool nz = (k >= covered) && vh[half] != 0;
-        const unsigned long long m = __ballot(nz);
-        if (m != 0) nscan = half * 64 + (64 - __clzll((long long)m));
+      // staging index (channel 0) of this lane's scan position, per 64-position half
+      const int i0 = order[lane];
+      const int src0 = i0 < 64 ? bi * 192 + i0 : (bi + o2) * 192 + i0 - 64;
+      int src1 = src0;
+      if (covered == 2) {
+        const int i1 = order[64 + lane];
+        src1 = i1 < 64 ? bi * 192 + i1 : (bi + o2) * 192 + i1 - 64;
       }
-      // only scan positions below nscan (= up to the last nonzero) are ever read again
-      if (lane < nscan) A.coef_scan[(pos0 * 3 + c) * 64 + lane] = vh[0];
-      if (64 + lane < nscan) A.coef_scan[(pos1 * 3 + c) * 64 + lane] = vh[1];
-      if (lane == 0) {
-        A.blk_nscan[pos0 * 3 + c] = (uint8_t)nscan;
-        my_tokens += 1 + (nscan > covered ? nscan - covered : 0);
+      const unsigned long long llf_mask = covered == 2 ? 3ull : 1ull;  // scan positions < covered
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const int16_t v0 = stage[src0 + c * 64];
+        const unsigned long long m0 = __ballot(v0 != 0) & ~llf_mask;
+        int nscan = m0 != 0 ? 64 - __clzll((long long)m0) : 0;
+        int16_t v1 = 0;
+        if (covered == 2) {
+          v1 = stage[src1 + c * 64];
+          const unsigned long long m1 = __ballot(v1 != 0);
+          if (m1 != 0) nscan = 128 - __clzll((long long)m1);
+        }
+        // only scan positions below nscan (= up to the last nonzero) are ever read again
+        if (lane < nscan) A.coef_scan[(pos0 * 3 + c) * 64 + lane] = v0;
+        if (64 + lane < nscan) A.coef_scan[(pos1 * 3 + c) * 64 + lane] = v1;
+        if (lane == 0) A.blk_nscan[pos0 * 3 + c] = (uint8_t)nscan;
+        wave_tokens += 1 + (nscan > covered ? nscan - covered : 0);
       }
     }
-    if (lane == 0 && my_tokens) atomicAdd(&S.ntok, my_tokens);
+    if (lane == 0 && wave_tokens) atomicAdd(&S.ntok, wave_tokens);
   }
   __syncthreads();
   JXLT_MARK(9);
@@ -1286,6 +1318,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
     atomicAdd(&A.dc_nac[dcg], S.nfirst);
   }
 #undef JXLT_MARK
+#undef JXLT_STOP
 #undef SX
 #undef SY
 }

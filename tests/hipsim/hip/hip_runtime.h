@@ -294,6 +294,28 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int dpp_ctrl, int row_m
   return got;
 }
 
+// v_sqrt_f32: the hardware result is within 1 ulp of the root, not always correctly rounded.
+// The model returns the correctly rounded root pushed one ulp up or down (pseudo-randomly,
+// never for 0), so that code relying on more than the 1-ulp guarantee fails here.
+inline float __builtin_amdgcn_sqrtf(float x) {
+  float s = sqrtf(x);
+  if (!(x > 0.0f) || !(s > 0.0f) || s != s || s > 3.0e38f) return s;
+  uint32_t b;
+  memcpy(&b, &s, 4);
+  uint32_t h;
+  memcpy(&h, &x, 4);
+  h = (h ^ (h >> 15)) * 0x2c1b3c6du;
+  h ^= h >> 12;
+  const uint32_t pick = h % 3u;  // 0: exact, 1: one ulp up, 2: one ulp down
+  if (pick == 1) b += 1;
+  if (pick == 2) b -= 1;
+  memcpy(&s, &b, 4);
+  return s;
+}
+
+// v_readfirstlane: only used on values that are wave-uniform by construction.
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __clzll(long long x) { return x == 0 ? 64 : __builtin_clzll((unsigned long long)x); }
 inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }

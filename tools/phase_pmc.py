@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Per-phase dynamic instruction counts of tile_kernel.
+
+Run under rocprofv3 with instruction counters:
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv \
+      -d gpurun_out/phase_pmc -- python3 tools/phase_pmc.py run [size]
+The script launches the hot path ten times, truncating tile_kernel after phase 0..9
+(flags bits 8-11, profiling only), so the i-th tile_kernel dispatch carries the cumulative
+counts up to phase i.  Then:
+  python3 tools/phase_pmc.py report gpurun_out/phase_pmc
+prints per-phase instructions per wave."""
+import csv
+import glob
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+PHASES = ["P0 load+XYB", "P1 AQ energy", "P2-3 erosion", "P4 modulations", "P6a 2-block DCTs", "P5a DCT8",
+          "P5b CfL + P6b entropy", "P7 decision", "P8 quantise", "P9 scan store"]
+
+
+def run(size):
+    import torch
+    import __graft_entry__
+    import bench
+    pkg = __graft_entry__.load_package()
+    frame = bench.make_frame_on_device(torch, size, 0, torch.device("cuda", 0))
+    torch.cuda.synchronize()
+    enc = pkg.Encoder(0)
+    enc.set_device_image([frame[c].data_ptr() for c in range(3)], size * 4, size, size, keepalive=frame)
+    for i in range(len(PHASES)):
+        enc.enqueue(1.0, (i + 1) << 8)
+        enc.synchronize()
+
+
+def report(d):
+    rows = []
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        rows += list(csv.DictReader(open(f)))
+    tile = [r for r in rows if "tile_kernel" in r["Kernel_Name"]]
+    by_disp = {}
+    for r in tile:
+        by_disp.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
+    disp = [by_disp[k] for k in sorted(by_disp)]
+    assert len(disp) == len(PHASES), len(disp)
+    prev = {}
+    print("%-24s %10s %10s %10s   (instructions per wave, this phase)" % ("phase", "VALU", "SALU", "LDS"))
+    for name, c in zip(PHASES, disp):
+        w = c["SQ_WAVES"]
+        cur = {k: c[k] / w for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS")}
+        print("%-24s %10.0f %10.0f %10.0f" % (name, *[cur[k] - prev.get(k, 0.0) for k in cur]))
+        prev = cur
+    print("%-24s %10.0f %10.0f %10.0f" % ("total", *[prev[k] for k in prev]))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "run":
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 4096)
+    else:
+        report(sys.argv[2])

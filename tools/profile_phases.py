@@ -41,6 +41,24 @@ def main():
     for name, c in zip(PHASES, ph):
         print("  %-20s %9.0f cycles/tile  %5.1f %%" % (name, float(c) / ntiles, 100.0 * float(c) / tot))
     print("  total %.0f cycles/tile (profiled run)" % (tot / ntiles))
+    # throughput view: run the kernel truncated after each phase (flags bits 8-11)
+    for _ in range(30):  # settle clocks
+        enc.enqueue(1.0, 0)
+    enc.synchronize()
+    res = {}
+    for order in (range(len(PHASES)), reversed(range(len(PHASES)))):
+        for i in order:
+            ts = []
+            for rep in range(5):
+                enc.enqueue(1.0, pkg.FLAG_PROFILE | ((i + 1) << 8))
+                enc.synchronize()
+                ts.append(enc.kernel_times()["tile_kernel"])
+            res.setdefault(i, []).append(min(ts))
+    prev = 0.0
+    for i, name in enumerate(PHASES):
+        t = min(res[i])
+        print("  stop after %-22s %7.3f ms  (+%.3f)   [%s]" % (name, t, t - prev, " ".join("%.3f" % v for v in res[i])))
+        prev = t
     # host stages
     for rep in range(2):
         t0 = time.perf_counter()
