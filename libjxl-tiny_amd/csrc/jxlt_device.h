@@ -122,8 +122,29 @@ struct CompactArgs {
 
 JXLT_DI float fma32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 JXLT_DI float nfma32(float a, float b, float c) { return __builtin_fmaf(-a, b, c); }
+
+// Two independent binary32 values processed by one packed instruction (v_pk_mul_f32,
+// v_pk_add_f32, v_pk_fma_f32: same IEEE results per component as the scalar forms, twice the
+// rate).  The CPU model of the kernels (tests/hipsim) uses the plain two-float struct.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float f2 __attribute__((ext_vector_type(2)));
+JXLT_DI f2 f2_make(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+JXLT_DI f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+JXLT_DI f2 f2_nfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(-a, b, c); }
+#else
+struct f2 { float x, y; };
+JXLT_DI f2 f2_make(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+JXLT_DI f2 operator+(f2 a, f2 b) { return f2_make(a.x + b.x, a.y + b.y); }
+JXLT_DI f2 operator-(f2 a, f2 b) { return f2_make(a.x - b.x, a.y - b.y); }
+JXLT_DI f2 operator*(f2 a, f2 b) { return f2_make(a.x * b.x, a.y * b.y); }
+JXLT_DI f2 f2_fma(f2 a, f2 b, f2 c) { return f2_make(__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)); }
+JXLT_DI f2 f2_nfma(f2 a, f2 b, f2 c) { return f2_make(__builtin_fmaf(-a.x, b.x, c.x), __builtin_fmaf(-a.y, b.y, c.y)); }
+#endif
+JXLT_DI f2 f2_splat(float a) { return f2_make(a, a); }
 JXLT_DI float zero_if_negative(float v) {
-  return (__float_as_uint(v) & 0x80000000u) ? 0.0f : v;
+  // sign bit set -> +0: as a signed integer every such pattern is negative (one v_max_i32)
+  const int bits = __float_as_int(v);
+  return __int_as_float(bits < 0 ? 0 : bits);
 }
 // Cross-lane moves inside an octet use DPP (data-parallel primitives: a VALU move with a
 // lane permutation, no LDS round trip).  quad_perm covers xor 1 and xor 2; xor 4 is two
@@ -252,6 +273,50 @@ JXLT_DI float cube_root_and_add(float x, float add) {
   r2 = r * r;
   r = fma32(r2, x, add);
   return r;
+}
+
+// cube_root_and_add for two values at once
+JXLT_DI int cube_root_seed(float x) {
+  const int32_t m1 = __float_as_int(x);
+  return (m1 == 0) ? 0 : (int32_t)(0x54800000u - (uint32_t)(m1 >> 23) * 0x002AAAAAu);
+}
+JXLT_DI f2 cube_root_and_add2(f2 x, float add) {
+  const f2 k1_3 = f2_splat(1.0f / 3), k4_3 = f2_splat(4.0f / 3);
+  const f2 xa_3 = k1_3 * x;
+  f2 r = f2_make(__int_as_float(cube_root_seed(x.x)), __int_as_float(cube_root_seed(x.y)));
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const f2 r2 = r * r;
+    r = f2_nfma(xa_3, r2 * r2, k4_3 * r);
+  }
+  f2 r2 = r * r;
+  r = f2_fma(k1_3, f2_nfma(x, r2 * r2, r), r);
+  r2 = r * r;
+  r = f2_fma(r2, x, f2_splat(add));
+  return r;
+}
+
+// linear_to_xyb for two pixels at once (same arithmetic per pixel)
+JXLT_DI void linear_to_xyb2(f2 r, f2 g, f2 b, f2* ox, f2* oy, f2* ob) {
+  const float kM02 = 0.078f, kM00 = 0.30f, kM01 = 1.0f - kM02 - kM00;
+  const float kM12 = 0.078f, kM10 = 0.23f, kM11 = 1.0f - kM12 - kM10;
+  const float kM20 = 0.24342268924547819f, kM21 = 0.20476744424496821f,
+              kM22 = 1.0f - kM20 - kM21;
+  const f2 bias = f2_splat(0.0037930732552754493f);
+  const float neg_bias_cbrt = -0.15595420054f;
+  f2 mixed0 = f2_fma(f2_splat(kM00), r, f2_fma(f2_splat(kM01), g, f2_fma(f2_splat(kM02), b, bias)));
+  f2 mixed1 = f2_fma(f2_splat(kM10), r, f2_fma(f2_splat(kM11), g, f2_fma(f2_splat(kM12), b, bias)));
+  f2 mixed2 = f2_fma(f2_splat(kM20), r, f2_fma(f2_splat(kM21), g, f2_fma(f2_splat(kM22), b, bias)));
+  mixed0 = f2_make(zero_if_negative(mixed0.x), zero_if_negative(mixed0.y));
+  mixed1 = f2_make(zero_if_negative(mixed1.x), zero_if_negative(mixed1.y));
+  mixed2 = f2_make(zero_if_negative(mixed2.x), zero_if_negative(mixed2.y));
+  const f2 tm0 = cube_root_and_add2(mixed0, neg_bias_cbrt);
+  const f2 tm1 = cube_root_and_add2(mixed1, neg_bias_cbrt);
+  const f2 tm2 = cube_root_and_add2(mixed2, neg_bias_cbrt);
+  const f2 half = f2_splat(0.5f);
+  *ox = half * (tm0 - tm1);
+  *oy = half * (tm0 + tm1);
+  *ob = tm2;
 }
 
 // enc_xyb.cc:30-81
@@ -800,43 +865,54 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
   }
   if (tid < 192) S.order[tid] = T->coeff_order[tid];
   {
-    // Two batches of five pixels per thread: all fifteen global loads of a batch are
-    // issued before the first use so that their HBM latencies overlap.
-    const int base = px0 - kHalo;  // stripe x of LDS column 0
+    // 16 lanes along x, 32 rows per pass: a thread owns 5 columns x 2 rows of the
+    // (64 + 2*kHalo)-wide window, so the row and column clamps are shared, the two rows of a
+    // column go through the colour transform as one packed pair, and all thirty loads are in
+    // flight before the first use.
     constexpr int kWin = 64 + 2 * kHalo;
+    const int base = px0 - kHalo;  // stripe x of LDS column 0
+    const int lx = tid & 15, ly = tid >> 4;
+    const float* rowp[2][3];
+    bool yok[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-      float pr[5], pg[5], pb[5];
-      int py[5], pcx[5];
-      bool ok[5];
+      const int y = ly + 32 * h;
+      yok[h] = y < shp;
+      const size_t off = (size_t)(sy0 + imin(y, sh - 1)) * A.pitch + (size_t)sx0;
+      rowp[h][0] = A.planes[0] + off;
+      rowp[h][1] = A.planes[1] + off;
+      rowp[h][2] = A.planes[2] + off;
+    }
+    f2 pr[5], pg[5], pb[5];
+    bool xok[5];
 #pragma unroll
-      for (int k = 0; k < 5; k++) {
-        const int i = tid + (h * 5 + k) * kTileThreads;
-        const int y = i / kWin, cx = i % kWin;
-        const int x = base + cx;
-        ok[k] = i < 64 * kWin && y < shp && x >= 0 && x < swp && x < px0 + nbx * 8 + kHalo;
-        py[k] = y;
-        pcx[k] = cx;
-        const int ys = ok[k] ? imin(y, sh - 1) : 0, xs = ok[k] ? imin(x, sw - 1) : 0;
-        const size_t src = (size_t)(sy0 + ys) * A.pitch + (size_t)(sx0 + xs);
-        pr[k] = A.planes[0][src];
-        pg[k] = A.planes[1][src];
-        pb[k] = A.planes[2][src];
-      }
+    for (int j = 0; j < 5; j++) {
+      const int cx = lx + 16 * j, x = base + cx;
+      xok[j] = cx < kWin && x >= 0 && x < swp && x < px0 + nbx * 8 + kHalo;
+      const int xs = xok[j] ? imin(x, sw - 1) : 0;
+      pr[j] = f2_make(rowp[0][0][xs], rowp[1][0][xs]);
+      pg[j] = f2_make(rowp[0][1][xs], rowp[1][1][xs]);
+      pb[j] = f2_make(rowp[0][2][xs], rowp[1][2][xs]);
+    }
 #pragma unroll
-      for (int k = 0; k < 5; k++) {
-        if (!ok[k]) continue;
-        const int y = py[k], cx = pcx[k];
-        float vx, vy, vb;
-        linear_to_xyb(pr[k], pg[k], pb[k], &vx, &vy, &vb);
-        S.x[y * kXYPitch + cx] = vx;
-        S.y[y * kXYPitch + cx] = vy;
-        if (cx >= kHalo && cx < kHalo + 64) S.b[y * kBPitch + cx - kHalo] = vb;
+    for (int j = 0; j < 5; j++) {
+      if (!xok[j]) continue;
+      const int cx = lx + 16 * j;
+      f2 vx, vy, vb;
+      linear_to_xyb2(pr[j], pg[j], pb[j], &vx, &vy, &vb);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        if (!yok[h]) continue;
+        const int y = ly + 32 * h;
+        const float px_ = h ? vx.y : vx.x, py_ = h ? vy.y : vy.x, pb_ = h ? vb.y : vb.x;
+        S.x[y * kXYPitch + cx] = px_;
+        S.y[y * kXYPitch + cx] = py_;
+        if (cx >= kHalo && cx < kHalo + 64) S.b[y * kBPitch + cx - kHalo] = pb_;
         if (A.dbg_xyb[0] && cx >= kHalo && cx < kHalo + nbx * 8) {
           const size_t d = (size_t)(by_img0 * 8 + y) * ((size_t)bstride * 8) + (size_t)(bx_img0 * 8 + cx - kHalo);
-          A.dbg_xyb[0][d] = vx;
-          A.dbg_xyb[1][d] = vy;
-          A.dbg_xyb[2][d] = vb;
+          A.dbg_xyb[0][d] = px_;
+          A.dbg_xyb[1][d] = py_;
+          A.dbg_xyb[2][d] = pb_;
         }
       }
     }
@@ -1152,6 +1228,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
     }
   }
   __syncthreads();
+  JXLT_MARK(10);
   const int ytox = S.cmap[0], ytob = S.cmap[1];
   const float kInvColorFactorF = 1.0f / 84;
   const float cmap_x = (float)ytox * kInvColorFactorF;           // YtoXRatio

@@ -15,7 +15,8 @@ import __graft_entry__  # noqa: E402
 import bench  # noqa: E402
 
 PHASES = ["P0 load+XYB", "P1 AQ energy", "P2-3 erosion", "P4 modulations", "P6a 2-block DCTs", "P5a DCT8",
-          "P5b CfL + P6b entropy", "P7 decision", "P8 quantise", "P9 scan store"]
+          "P6b entropy", "P7 decision", "P8 quantise", "P9 scan store", "P5b CfL"]
+ORDER = [0, 1, 2, 3, 4, 5, 10, 6, 7, 8, 9]  # execution order of the phase slots
 
 
 def main():
