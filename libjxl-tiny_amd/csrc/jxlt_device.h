@@ -38,7 +38,7 @@ struct DeviceTables {
   float weights[576];      // dequant weights (quant_weights.cc:17-134)
   float inv_weights[576];  // float(1.0 / w), LLF zeroed (quant_weights.cc:144-153)
   float inv_qac[256];      // float(1.0 / (double)(scale * q)) (enc_group.cc:289)
-  uint16_t table_offset[9];
+  uint16_t table_offset[9];  // host copy of quant_table_offset() below (checked when the tables are built)
   uint8_t coeff_order[192];
   uint16_t freq_context[64];
   uint16_t nnz_context[64];
@@ -46,6 +46,10 @@ struct DeviceTables {
   uint8_t ac_context_map[1980];
   uint8_t gradient_lut[1024];  // enc_frame.cc:226-281
 };
+
+// Offset of quant table n = strategy * 3 + channel inside weights[] / inv_weights[]: three
+// 64-entry DCT8 tables, then three 128-entry tables shared by DCT16X8 and DCT8X16.
+__host__ __device__ constexpr int quant_table_offset(int n) { return n < 3 ? n * 64 : 192 + ((n - 3) % 3) * 128; }
 
 struct FrameGeom {
   int xsize, ysize;                // pixels
@@ -708,9 +712,9 @@ JXLT_DI void quantize_transform(float* cx, float* cy, float* cb, const TileShare
                                 float b_factor, int ibx, int iby, int16_t* slot_a, int16_t* slot_b) {
   const DeviceTables* T = A.tab;
   const int kind_off = strategy * 3;
-  const float* inv_x = S.inv_w + T->table_offset[kind_off + 0];
-  const float* inv_y = S.inv_w + T->table_offset[kind_off + 1];
-  const float* inv_b = S.inv_w + T->table_offset[kind_off + 2];
+  const float* inv_x = S.inv_w + quant_table_offset(kind_off + 0);
+  const float* inv_y = S.inv_w + quant_table_offset(kind_off + 1);
+  const float* inv_b = S.inv_w + quant_table_offset(kind_off + 2);
   const float* ydq = S.y_w + (NR == 8 ? 0 : 64);
   const float kInvDCQuant[3] = {4096.0f, 512.0f, 256.0f};
   const float kScale1 = (float)0.901764195028874394;
@@ -857,8 +861,8 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
 
   // ---- P0: tables -> LDS; load + XYB (enc_frame.cc:597-617, enc_xyb.cc) -----
   for (int i = tid; i < 576; i += kTileThreads) S.inv_w[i] = T->inv_weights[i];
-  if (tid < 64) S.y_w[tid] = T->weights[T->table_offset[1] + tid];
-  if (tid < 128) S.y_w[64 + tid] = T->weights[T->table_offset[4] + tid];
+  if (tid < 64) S.y_w[tid] = T->weights[quant_table_offset(1) + tid];
+  if (tid < 128) S.y_w[64 + tid] = T->weights[quant_table_offset(4) + tid];
   if (tid == 0) {
     S.ntok = 0;
     S.nfirst = 0;
@@ -1178,46 +1182,91 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
   // ---- P5b: chroma-from-luma (enc_chroma_from_luma.cc:40-131) ----------------
   {
     // Every octet publishes the terms of its block, a = m/84 and b = base*m - s with
-    // m = Y*qm, s = C*qm (:49-53,117-120), then 32 lanes run the four sequential
-    // per-lane fma chains (ca, cb for X and B) over the blocks in raster order.
+    // m = Y*qm, s = C*qm (:49-53,117-120); then four sequential per-lane fma chains
+    // (ca = sum a*a, cb = sum a*b, for X and for B) run over the blocks in raster order.
+    // Term layout: [block][lane l][chunk], a chunk = (a, b) of two consecutive rows of one
+    // chroma channel (chunk = channel * 4 + row / 2), i.e. the eight rows a chain lane needs
+    // from a block are four 16-byte reads.  The chunk slot is XORed with l so that the eight
+    // lanes of an octet hit different banks.
     float* terms = &S.x[0];
     const float* qm_x = S.inv_w + 0;    // InvMatrix(DCT, 0)
     const float* qm_b = S.inv_w + 128;  // InvMatrix(DCT, 2)
     const int nblk = nbx * nby;
     const float kInvColorFactor = 1.0f / 84;
     if (blk_valid) {
-      float* dst = &terms[(oby * nbx + obx) * 256];
+      float* dst = &terms[(oby * nbx + obx) * 256 + l * 32];
 #pragma unroll
-      for (int r = 0; r < 8; r++) {
-        const bool dc = (r == 0 && l == 0);  // block_*[0] = 0 (:109-111)
-        const float by_ = dc ? 0.0f : c8y[r], bx_ = dc ? 0.0f : c8x[r], bb_ = dc ? 0.0f : c8b[r];
-        const float qx = qm_x[r * 8 + l], qb = qm_b[r * 8 + l];
-        const float m_x = by_ * qx, s_x = bx_ * qx, m_b = by_ * qb, s_b = bb_ * qb;
-        float4 t;
-        t.x = kInvColorFactor * m_x;
-        t.y = 0.0f * m_x - s_x;
-        t.z = kInvColorFactor * m_b;
-        t.w = 1.0f * m_b - s_b;
-        *(float4*)&dst[(r * 8 + l) * 4] = t;
+      for (int r = 0; r < 8; r += 2) {
+        float4 tx, tb;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int rr = r + h;
+          const bool dc = (rr == 0 && l == 0);  // block_*[0] = 0 (:109-111)
+          const float by_ = dc ? 0.0f : c8y[rr], bx_ = dc ? 0.0f : c8x[rr], bb_ = dc ? 0.0f : c8b[rr];
+          const float qx = qm_x[rr * 8 + l], qb = qm_b[rr * 8 + l];
+          const float m_x = by_ * qx, s_x = bx_ * qx, m_b = by_ * qb, s_b = bb_ * qb;
+          const float ax = kInvColorFactor * m_x, bx2 = 0.0f * m_x - s_x;
+          const float ab = kInvColorFactor * m_b, bb2 = 1.0f * m_b - s_b;
+          if (h == 0) { tx.x = ax; tx.y = bx2; tb.x = ab; tb.y = bb2; }
+          else { tx.z = ax; tx.w = bx2; tb.z = ab; tb.w = bb2; }
+        }
+        *(float4*)&dst[(((r >> 1)) ^ l) * 4] = tx;
+        *(float4*)&dst[((4 + (r >> 1)) ^ l) * 4] = tb;
       }
     }
     __syncthreads();
+    // Chain lanes: wave 0 lanes 0-15 run ca (X: 0-7, B: 8-15), wave 1 lanes 0-15 run cb.
+    // The 512 fused multiply-adds of a chain are strictly sequential, so these two waves are
+    // the critical path of the workgroup: they run at raised issue priority, and the reads
+    // of block blk + 1 are issued before the arithmetic of block blk.
     float acc = 0.0f;
-    if (tid < 32) {
-      const int kind = tid >> 3;  // 0: ca_x, 1: cb_x, 2: ca_b, 3: cb_b
-      const bool is_cb = (kind & 1) != 0;
-      const float* src = terms + (kind >> 1) * 2 + l * 4;
+    const int cw = tid >> 6, cl = tid & 63;
+    if (cw < 2 && cl < 16) {
+      __builtin_amdgcn_s_setprio(3);
+      const int ch = cl >> 3;  // 0: X, 1: B
+      const float* src = terms + l * 32;
+      int slot[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) slot[q] = ((ch * 4 + q) ^ l) * 4;
+      float4 cur[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) cur[q] = *(const float4*)&src[slot[q]];
+      if (cw == 0) {
 #pragma clang loop unroll(disable)
-      for (int blk = 0; blk < nblk; blk++) {
-        float2 v[8];
+        for (int blk = 0; blk < nblk; blk++) {
+          float4 nxt[4];
+          const int nb = blk + 1 < nblk ? blk + 1 : blk;
 #pragma unroll
-        for (int r = 0; r < 8; r++) v[r] = *(const float2*)&src[(blk * 64 + r * 8) * 4];
+          for (int q = 0; q < 4; q++) nxt[q] = *(const float4*)&src[nb * 256 + slot[q]];
 #pragma unroll
-        for (int r = 0; r < 8; r++) acc = fma32(v[r].x, is_cb ? v[r].y : v[r].x, acc);
+          for (int q = 0; q < 4; q++) {
+            acc = fma32(cur[q].x, cur[q].x, acc);
+            acc = fma32(cur[q].z, cur[q].z, acc);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) cur[q] = nxt[q];
+        }
+      } else {
+#pragma clang loop unroll(disable)
+        for (int blk = 0; blk < nblk; blk++) {
+          float4 nxt[4];
+          const int nb = blk + 1 < nblk ? blk + 1 : blk;
+#pragma unroll
+          for (int q = 0; q < 4; q++) nxt[q] = *(const float4*)&src[nb * 256 + slot[q]];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            acc = fma32(cur[q].x, cur[q].y, acc);
+            acc = fma32(cur[q].z, cur[q].w, acc);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) cur[q] = nxt[q];
+        }
       }
+      __builtin_amdgcn_s_setprio(0);
     }
     const float total = octet_sum(acc);
-    if (tid < 32 && l == 0) S.cfl_sum[tid >> 3] = total;
+    // cfl_sum: ca_x, cb_x, ca_b, cb_b
+    if (cw < 2 && cl < 16 && l == 0) S.cfl_sum[(cl >> 3) * 2 + cw] = total;
     __syncthreads();
     if (tid < 2) {  // FindBestMultiplier tail (:56-61)
       const float kDistanceMultiplierAC = 1e-3f;
@@ -1259,9 +1308,9 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
       const float quant = fmaxf(fmaxf(0.0f, S.aq[bi]), S.aq[bi + o2]);
       const float masking = fmaxf(fmaxf(0.0f, S.mask[bi]), S.mask[bi + o2]);
       const int toff = is_tall ? 3 : 6;
-      const float e = estimate_entropy<16>(c16x, c16y, c16b, S.inv_w + T->table_offset[toff],
-                                           S.inv_w + T->table_offset[toff + 1],
-                                           S.inv_w + T->table_offset[toff + 2], l, quant, masking,
+      const float e = estimate_entropy<16>(c16x, c16y, c16b, S.inv_w + quant_table_offset(toff),
+                                           S.inv_w + quant_table_offset(toff + 1),
+                                           S.inv_w + quant_table_offset(toff + 2), l, quant, masking,
                                            cmap_x, cmap_b, A.distance);
       const float k8X16mul1 = (float)-0.55, k8X16mul2 = (float)0.9019587899705066,
                   k8X16base = (float)1.6;
@@ -1366,17 +1415,19 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
         src1 = i1 < 64 ? bi * 192 + i1 : (bi + o2) * 192 + i1 - 64;
       }
       const unsigned long long llf_mask = covered == 2 ? 3ull : 1ull;  // scan positions < covered
+      int16_t v0s[3], v1s[3];
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        const int16_t v0 = stage[src0 + c * 64];
+        v0s[c] = stage[src0 + c * 64];
+        v1s[c] = covered == 2 ? stage[src1 + c * 64] : (int16_t)0;
+      }
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const int16_t v0 = v0s[c], v1 = v1s[c];
         const unsigned long long m0 = __ballot(v0 != 0) & ~llf_mask;
         int nscan = m0 != 0 ? 64 - __clzll((long long)m0) : 0;
-        int16_t v1 = 0;
-        if (covered == 2) {
-          v1 = stage[src1 + c * 64];
-          const unsigned long long m1 = __ballot(v1 != 0);
-          if (m1 != 0) nscan = 128 - __clzll((long long)m1);
-        }
+        const unsigned long long m1 = __ballot(v1 != 0);
+        if (m1 != 0) nscan = 128 - __clzll((long long)m1);
         // only scan positions below nscan (= up to the last nonzero) are ever read again
         if (lane < nscan) A.coef_scan[(pos0 * 3 + c) * 64 + lane] = v0;
         if (64 + lane < nscan) A.coef_scan[(pos1 * 3 + c) * 64 + lane] = v1;

@@ -21,6 +21,10 @@ inline void BuildDeviceTables(float scale, DeviceTables* t) {
   }
   for (int n = 0; n < 9; n++) {
     t->table_offset[n] = JXLT_kQuantTableOffset[n];
+    if ((int)JXLT_kQuantTableOffset[n] != jxlt_dev::quant_table_offset(n)) {
+      fprintf(stderr, "jxlt: quant table layout changed; update quant_table_offset()\n");
+      abort();
+    }
     for (int b = 0; b < JXLT_kQuantTableLLF[n]; b++) t->inv_weights[JXLT_kQuantTableOffset[n] + b] = 0.0f;
   }
   t->inv_qac[0] = 0.0f;

@@ -316,6 +316,8 @@ inline float __builtin_amdgcn_sqrtf(float x) {
 // v_readfirstlane: only used on values that are wave-uniform by construction.
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 
+inline void __builtin_amdgcn_s_setprio(int) {}  // issue priority: no effect on results
+
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __clzll(long long x) { return x == 0 ? 64 : __builtin_clzll((unsigned long long)x); }
 inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }

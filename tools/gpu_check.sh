@@ -13,6 +13,7 @@ rm -rf gpurun_out/phase_pmc
 timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv \
   -d gpurun_out/phase_pmc -- python3 tools/phase_pmc.py run 4096 > gpurun_out/phase_pmc.log 2>&1
 python3 tools/phase_pmc.py report gpurun_out/phase_pmc
+timeout 200 python3 tools/profile_phases.py 8192 2>&1 | grep -E "cycles/tile|stop after"
 cp /tmp/prod_hip.so libjxl-tiny_amd/csrc/libjxltiny_hip.so
 fi
 timeout 300 python bench.py "$@" 2>&1 | tail -1 | python3 -c "

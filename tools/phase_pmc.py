@@ -31,7 +31,7 @@ def run(size):
     torch.cuda.synchronize()
     enc = pkg.Encoder(0)
     enc.set_device_image([frame[c].data_ptr() for c in range(3)], size * 4, size, size, keepalive=frame)
-    for i in range(len(PHASES)):
+    for i in ORDER:
         enc.enqueue(1.0, (i + 1) << 8)
         enc.synchronize()
 
@@ -48,7 +48,7 @@ def report(d):
     assert len(disp) == len(PHASES), len(disp)
     prev = {}
     print("%-24s %10s %10s %10s   (instructions per wave, this phase)" % ("phase", "VALU", "SALU", "LDS"))
-    for name, c in zip(PHASES, disp):
+    for name, c in zip([PHASES[i] for i in ORDER], disp):
         w = c["SQ_WAVES"]
         cur = {k: c[k] / w for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS")}
         print("%-24s %10.0f %10.0f %10.0f" % (name, *[cur[k] - prev.get(k, 0.0) for k in cur]))

@@ -39,7 +39,7 @@ def main():
     ntiles = (size // 64) ** 2
     tot = float(ph.sum())
     print("frame %dx%d, %d tiles; kernel ms: %s" % (size, size, ntiles, {k: round(v, 3) for k, v in kt.items()}))
-    for name, c in zip(PHASES, ph):
+    for name, c in [(PHASES[i], ph[i]) for i in ORDER]:
         print("  %-20s %9.0f cycles/tile  %5.1f %%" % (name, float(c) / ntiles, 100.0 * float(c) / tot))
     print("  total %.0f cycles/tile (profiled run)" % (tot / ntiles))
     # throughput view: run the kernel truncated after each phase (flags bits 8-11)
@@ -47,7 +47,7 @@ def main():
         enc.enqueue(1.0, 0)
     enc.synchronize()
     res = {}
-    for order in (range(len(PHASES)), reversed(range(len(PHASES)))):
+    for order in (ORDER, list(reversed(ORDER))):
         for i in order:
             ts = []
             for rep in range(5):
@@ -56,7 +56,8 @@ def main():
                 ts.append(enc.kernel_times()["tile_kernel"])
             res.setdefault(i, []).append(min(ts))
     prev = 0.0
-    for i, name in enumerate(PHASES):
+    for i in ORDER:
+        name = PHASES[i]
         t = min(res[i])
         print("  stop after %-22s %7.3f ms  (+%.3f)   [%s]" % (name, t, t - prev, " ".join("%.3f" % v for v in res[i])))
         prev = t
