@@ -123,6 +123,7 @@ struct CompactArgs {
 // ---------------------------------------------------------------------------
 
 #define JXLT_DI __device__ __forceinline__
+#define JXLT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)  // no instruction is scheduled across
 
 JXLT_DI float fma32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 JXLT_DI float nfma32(float a, float b, float c) { return __builtin_fmaf(-a, b, c); }
@@ -626,16 +627,18 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
   const float cost_of_1 = 1 + slope * 8.8703248061477744f;
   float entropy = 0.0f;
   float info_loss = 0.0f, info_loss2 = 0.0f;
-  // The channel loop stays rolled (one copy of the body): the kernel must fit the
-  // instruction cache; the wave-uniform selects cost two VALU ops per coefficient.
-#pragma clang loop unroll(disable)
+  // One copy of the body per channel (no per-coefficient operand selects); the scheduling
+  // fences keep the channels from being interleaved, which would spill.
+#pragma unroll
   for (int c = 0; c < 3; c++) {
     const float* inv = c == 0 ? inv_x : c == 1 ? inv_y : inv_b;
+    const float* cin = c == 0 ? cx : c == 1 ? cy : cb;
     const float cmap_factor = c == 0 ? cmap_x : c == 1 ? 0.0f : cmap_b;
     float entropy_v = 0.0f, nzeros_v = 0.0f;
+    JXLT_SCHED_FENCE();
 #pragma unroll
     for (int r = 0; r < NR; r++) {
-      const float in = c == 0 ? cx[r] : c == 1 ? cy[r] : cb[r];
+      const float in = cin[r];
       const float in_y = cy[r] * cmap_factor;
       const float im = inv[r * 8 + l];
       const float val = (in - in_y) * (im * quant);
@@ -1136,20 +1139,22 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
     const float* pxp = &S.x[(cby * 8) * kXYPitch + cbx * 8 + kHalo];
     const float* pyp = &S.y[(cby * 8) * kXYPitch + cbx * 8 + kHalo];
     const float* pbp = &S.b[(cby * 8) * kBPitch + cbx * 8];
-#pragma clang loop unroll(disable)
-    for (int c = 0; c < 3; c++) {
-      float t[16];
-      const float* pp = c == 0 ? pxp : c == 1 ? pyp : pbp;
-      const int pitch = c == 2 ? kBPitch : kXYPitch;
-      if (is_tall) block_dct16x8(pp, pitch, l, t);
-      else block_dct8x16(pp, pitch, l, t);
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        if (c == 0) c16x[r] = t[r];
-        else if (c == 1) c16y[r] = t[r];
-        else c16b[r] = t[r];
-      }
+    // (scheduling fences: interleaving the three independent transforms would triple the
+    // live registers and spill)
+    if (is_tall) {
+      block_dct16x8(pxp, kXYPitch, l, c16x);
+      JXLT_SCHED_FENCE();
+      block_dct16x8(pyp, kXYPitch, l, c16y);
+      JXLT_SCHED_FENCE();
+      block_dct16x8(pbp, kBPitch, l, c16b);
+    } else {
+      block_dct8x16(pxp, kXYPitch, l, c16x);
+      JXLT_SCHED_FENCE();
+      block_dct8x16(pyp, kXYPitch, l, c16y);
+      JXLT_SCHED_FENCE();
+      block_dct8x16(pbp, kBPitch, l, c16b);
     }
+    JXLT_SCHED_FENCE();
   }
   JXLT_MARK(4);
   // ---- P5: DCT8 of every block (kept in registers) + chroma-from-luma -------
@@ -1159,22 +1164,17 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
     const float* pxp = &S.x[(oby * 8) * kXYPitch + obx * 8 + kHalo];
     const float* pyp = &S.y[(oby * 8) * kXYPitch + obx * 8 + kHalo];
     const float* pbp = &S.b[(oby * 8) * kBPitch + obx * 8];
-#pragma clang loop unroll(disable)
-    for (int c = 0; c < 3; c++) {
-      float t[8];
-      if (blk_valid) {
-        block_dct8x8(c == 0 ? pxp : c == 1 ? pyp : pbp, c == 2 ? kBPitch : kXYPitch, l, t);
-      } else {
-        // (cross-lane traffic never leaves an octet, so idle octets may skip it)
+    if (blk_valid) {
+      block_dct8x8(pxp, kXYPitch, l, c8x);
+      JXLT_SCHED_FENCE();
+      block_dct8x8(pyp, kXYPitch, l, c8y);
+      JXLT_SCHED_FENCE();
+      block_dct8x8(pbp, kBPitch, l, c8b);
+      JXLT_SCHED_FENCE();
+    } else {
+      // (cross-lane traffic never leaves an octet, so idle octets may skip it)
 #pragma unroll
-        for (int r = 0; r < 8; r++) t[r] = 0.0f;
-      }
-#pragma unroll
-      for (int r = 0; r < 8; r++) {
-        if (c == 0) c8x[r] = t[r];
-        else if (c == 1) c8y[r] = t[r];
-        else c8b[r] = t[r];
-      }
+      for (int r = 0; r < 8; r++) c8x[r] = c8y[r] = c8b[r] = 0.0f;
     }
   }
   __syncthreads();  // all pixel reads done: the planes are dead from here on
@@ -1228,38 +1228,52 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
       int slot[4];
 #pragma unroll
       for (int q = 0; q < 4; q++) slot[q] = ((ch * 4 + q) ^ l) * 4;
-      float4 cur[4];
+      // two blocks per iteration, ping-pong buffers (no register copies in the loop)
+      float4 ta[4], tb[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) cur[q] = *(const float4*)&src[slot[q]];
+      for (int q = 0; q < 4; q++) ta[q] = *(const float4*)&src[slot[q]];
+      const int last = nblk - 1;
       if (cw == 0) {
 #pragma clang loop unroll(disable)
-        for (int blk = 0; blk < nblk; blk++) {
-          float4 nxt[4];
-          const int nb = blk + 1 < nblk ? blk + 1 : blk;
+        for (int blk = 0; blk < nblk; blk += 2) {
+          const int n1 = imin(blk + 1, last), n2 = imin(blk + 2, last);
 #pragma unroll
-          for (int q = 0; q < 4; q++) nxt[q] = *(const float4*)&src[nb * 256 + slot[q]];
+          for (int q = 0; q < 4; q++) tb[q] = *(const float4*)&src[n1 * 256 + slot[q]];
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            acc = fma32(cur[q].x, cur[q].x, acc);
-            acc = fma32(cur[q].z, cur[q].z, acc);
+            acc = fma32(ta[q].x, ta[q].x, acc);
+            acc = fma32(ta[q].z, ta[q].z, acc);
           }
 #pragma unroll
-          for (int q = 0; q < 4; q++) cur[q] = nxt[q];
+          for (int q = 0; q < 4; q++) ta[q] = *(const float4*)&src[n2 * 256 + slot[q]];
+          if (blk + 1 < nblk) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              acc = fma32(tb[q].x, tb[q].x, acc);
+              acc = fma32(tb[q].z, tb[q].z, acc);
+            }
+          }
         }
       } else {
 #pragma clang loop unroll(disable)
-        for (int blk = 0; blk < nblk; blk++) {
-          float4 nxt[4];
-          const int nb = blk + 1 < nblk ? blk + 1 : blk;
+        for (int blk = 0; blk < nblk; blk += 2) {
+          const int n1 = imin(blk + 1, last), n2 = imin(blk + 2, last);
 #pragma unroll
-          for (int q = 0; q < 4; q++) nxt[q] = *(const float4*)&src[nb * 256 + slot[q]];
+          for (int q = 0; q < 4; q++) tb[q] = *(const float4*)&src[n1 * 256 + slot[q]];
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            acc = fma32(cur[q].x, cur[q].y, acc);
-            acc = fma32(cur[q].z, cur[q].w, acc);
+            acc = fma32(ta[q].x, ta[q].y, acc);
+            acc = fma32(ta[q].z, ta[q].w, acc);
           }
 #pragma unroll
-          for (int q = 0; q < 4; q++) cur[q] = nxt[q];
+          for (int q = 0; q < 4; q++) ta[q] = *(const float4*)&src[n2 * 256 + slot[q]];
+          if (blk + 1 < nblk) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              acc = fma32(tb[q].x, tb[q].y, acc);
+              acc = fma32(tb[q].z, tb[q].w, acc);
+            }
+          }
         }
       }
       __builtin_amdgcn_s_setprio(0);
@@ -1302,6 +1316,16 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
       e8 += mul8x8 * e;
       if (l == 0) S.ent8[((oby >> 1) * 4 + (obx >> 1)) * 8 + (oby & 1) * 2 + (obx & 1)] = e8;
     }
+    // The DCT8 coefficients are needed again in P8; they wait in the (now dead) term area
+    // while the two-block estimate runs, which would otherwise spill.
+    float* park = &S.x[0] + tid;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      park[(r)*kTileThreads] = c8x[r];
+      park[(8 + r) * kTileThreads] = c8y[r];
+      park[(16 + r) * kTileThreads] = c8b[r];
+    }
+    JXLT_SCHED_FENCE();
     if (cell_valid) {
       const int o2 = is_tall ? 8 : 1;  // second covered block in the 8x8 tile grid
       const int bi = cby * 8 + cbx;
@@ -1316,6 +1340,13 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
                   k8X16base = (float)1.6;
       const float mul16x8 = k8X16mul2 + k8X16mul1 / (A.distance + k8X16base);
       if (l == 0) S.ent8[cell * 8 + (is_tall ? 4 : 6) + (cand & 1)] = mul16x8 * e;
+    }
+    JXLT_SCHED_FENCE();
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      c8x[r] = park[(r)*kTileThreads];
+      c8y[r] = park[(8 + r) * kTileThreads];
+      c8b[r] = park[(16 + r) * kTileThreads];
     }
   }
   __syncthreads();

@@ -318,6 +318,8 @@ inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 
 inline void __builtin_amdgcn_s_setprio(int) {}  // issue priority: no effect on results
 
+inline void __builtin_amdgcn_sched_barrier(int) {}  // compiler scheduling fence
+
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __clzll(long long x) { return x == 0 ? 64 : __builtin_clzll((unsigned long long)x); }
 inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }
