@@ -1522,8 +1522,10 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   __shared__ uint32_t hist[64 * 64];
   __shared__ uint16_t s_nnz_ctx[64], s_freq_ctx[64];
   __shared__ uint8_t s_ctx_map[1980];
+  __shared__ uint8_t s_nzg[3 * 1024];   // nzeros grid of the group (PredictFromTopAndLeft input)
   const int tid = (int)threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  // (wave index pinned to a scalar register: the per-entry bookkeeping below is wave-uniform)
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const DeviceTables* T = A.tab;
   const int group = (int)blockIdx.x;
   const bool do_hist = A.histogram != nullptr;
@@ -1540,22 +1542,26 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   const size_t bstride = (size_t)A.g.xsize_blocks;
   const int nent = nbx * nby * 3;  // entries in stream order: (by, bx, ci), channels Y, X, B
 
-  // token count + metadata per entry
-  for (int e = tid; e < nent; e += kTokenThreads) {
-    const int ci = e % 3, b = e / 3;
+  // token count + metadata per entry; predicted-nzeros grid of the group -> LDS
+  const int nblk = nbx * nby;
+  for (int b = tid; b < nblk; b += kTokenThreads) {
     const int bx = b % nbx, by = b / nbx;
-    const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
     const size_t pos = (size_t)(by0 + by) * bstride + bx0 + bx;
     const uint32_t a = A.strategy[pos];
-    uint32_t n = 0, m = a;
-    if (a & 1) {
-      const int covered = (a >> 1) == 0 ? 1 : 2;
-      const uint32_t nscan = A.blk_nscan[pos * 3 + c];
-      n = 1 + (nscan > (uint32_t)covered ? nscan - covered : 0);
-      m = a | ((uint32_t)A.blk_nz[pos * 3 + c] << 8) | (nscan << 16);
+    const int covered = (a >> 1) == 0 ? 1 : 2;
+#pragma unroll
+    for (int ci = 0; ci < 3; ci++) {
+      const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
+      uint32_t n = 0, m = a;
+      if (a & 1) {
+        const uint32_t nscan = A.blk_nscan[pos * 3 + c];
+        n = 1 + (nscan > (uint32_t)covered ? nscan - covered : 0);
+        m = a | ((uint32_t)A.blk_nz[pos * 3 + c] << 8) | (nscan << 16);
+      }
+      offs[b * 3 + ci + 1] = n;
+      meta[b * 3 + ci] = m;
+      s_nzg[c * 1024 + b] = A.nzgrid[c][pos];
     }
-    offs[e + 1] = n;
-    meta[e] = m;
   }
   if (tid == 0) offs[0] = 0;
   __syncthreads();
@@ -1584,94 +1590,109 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
 
   uint8_t* out = A.tokens + 3 * A.group_tok_offset[group];
   constexpr int kWaves = kTokenThreads / 64;
-  // One wave per entry, lane = scan position.  The coefficients of the wave's next entry
-  // are requested before the current one is processed (HBM latency overlap).
-  auto entry_coef_ptr = [&](int e) -> const int16_t* {
-    const int ci = e % 3, b = e / 3;
-    const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
-    const size_t pos = (size_t)(by0 + b / nbx) * bstride + bx0 + b % nbx;
-    return A.coef_scan + (pos * 3 + c) * 64;
-  };
+  // Wave w takes blocks w, w + 8, ... of the group (stream order) and their three channel
+  // entries; lane = scan position.  The coefficients of the wave's next block are requested
+  // before the current one is processed (HBM latency overlap).
   // (only scan positions below nscan were written by tile_kernel)
-  int16_t next_v = 0;
-  if (wave < nent && lane < (int)(meta[wave] >> 16)) next_v = entry_coef_ptr(wave)[lane];
-  for (int e = wave; e < nent; e += kWaves) {
-    const int16_t v0 = next_v;
-    next_v = 0;
-    if (e + kWaves < nent && lane < (int)(meta[e + kWaves] >> 16)) next_v = entry_coef_ptr(e + kWaves)[lane];
-    const uint32_t m = meta[e];
-    if (!(m & 1)) continue;
-    const int ci = e % 3, b = e / 3;
-    const int bx = b % nbx, by = b / nbx;
-    const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
-    const size_t pos = (size_t)(by0 + by) * bstride + bx0 + bx;
-    const int st = (int)((m >> 1) & 0x7F);
-    const int covered = st == 0 ? 1 : 2;
-    const int log2c = covered == 1 ? 0 : 1;
-    const int size = covered * 64;
-    const size_t pos1 = pos + (st == 1 ? bstride : 1);
-    const uint32_t tok0 = offs[e];
-    const int nzeros = (int)((m >> 8) & 0xFF);
-    const int nscan = (int)(m >> 16);
-    // block context (ac_context.h:64-114): kBlockContextMap[c*27 + code] is 0/1 for Y and
-    // 2/3 for X,B, the odd value for the two-block strategy codes 6 and 7
-    const int block_ctx = (c == 1 ? 0 : 2) + (st == 0 ? 0 : 1);
-    if (lane == 0) {
-      // PredictFromTopAndLeft (enc_group.cc:150-160), default 32
-      int pred;
-      const uint8_t* nzg = c == 0 ? A.nzgrid[0] : c == 1 ? A.nzgrid[1] : A.nzgrid[2];
-      if (bx == 0) pred = by == 0 ? 32 : nzg[pos - bstride];
-      else if (by == 0) pred = nzg[pos - 1];
-      else pred = (nzg[pos - bstride] + nzg[pos - 1] + 1) / 2;
-      const int bucket = pred < 8 ? pred : pred >= 64 ? 36 : 4 + pred / 2;
-      const int ctx = bucket * 4 + block_ctx;
-      uint8_t* o = out + 3 * (size_t)tok0;
-      const uint8_t cm = s_ctx_map[ctx];
-      o[0] = cm;
-      o[1] = (uint8_t)(nzeros & 0xFF);
-      o[2] = (uint8_t)(nzeros >> 8);
-      if (do_hist) {
-        uint32_t sym, nb, eb;
-        hybrid_uint((uint32_t)nzeros, &sym, &nb, &eb);
-        atomicAdd(&hist[cm * 64 + sym], 1u);
-      }
+  int bx = wave % nbx, by = wave / nbx;
+  const int dbx = kWaves % nbx, dby = kWaves / nbx;
+  auto load_block = [&](int b, int bxx, int byy, int16_t* v) {
+    const size_t pos = (size_t)(by0 + byy) * bstride + bx0 + bxx;
+#pragma unroll
+    for (int ci = 0; ci < 3; ci++) {
+      const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
+      const int nscan = (int)(__builtin_amdgcn_readfirstlane((int)meta[b * 3 + ci]) >> 16);
+      v[ci] = lane < nscan ? A.coef_scan[(pos * 3 + c) * 64 + lane] : (int16_t)0;
     }
-    if (nzeros == 0) continue;
-    const int histo_offset = 4 * 37 + 458 * block_ctx;
-    int nz_before = 0;   // nonzeros at scan positions before the current 64-chunk
-    int carry_flag = 0;  // nonzero flag of the last position of the previous chunk
-    const int nhalf = nscan > 64 ? 2 : 1;  // the second 64 positions only if tokens reach them
-    for (int half = 0; half < nhalf; half++) {
-      const int k = half * 64 + lane;
-      const int16_t v = half == 0 ? v0 : (64 + lane < nscan ? A.coef_scan[(pos1 * 3 + c) * 64 + lane] : (int16_t)0);
-      const bool in_range = k >= covered && k < nscan;
-      const bool nz = in_range && v != 0;
-      const unsigned long long mk = __ballot(nz);
-      if (in_range) {
-        // nzeros still to come at position k, and whether position k-1 was nonzero
-        const int left = nzeros - (nz_before + __popcll(mk & ((1ull << lane) - 1ull)));
-        int p;
-        if (k == covered) p = (nzeros > size / 16) ? 0 : 1;
-        else if (lane == 0) p = carry_flag;
-        else p = (int)((mk >> (lane - 1)) & 1ull);
-        const int nl = (left + covered - 1) >> log2c;
-        const int kk = k >> log2c;
-        const int zctx = (s_nnz_ctx[nl] + s_freq_ctx[kk]) * 2 + p;
-        const int ctx = histo_offset + zctx;
-        const uint32_t val = pack_signed((int32_t)v);
-        uint8_t* o = out + 3 * ((size_t)tok0 + 1 + (k - covered));
+  };
+  int16_t next_v[3] = {0, 0, 0};
+  if (wave < nblk) load_block(wave, bx, by, next_v);
+  for (int b = wave; b < nblk; b += kWaves) {
+    const int16_t cur_v[3] = {next_v[0], next_v[1], next_v[2]};
+    const int cbx = bx, cby = by;
+    bx += dbx;
+    by += dby;
+    if (bx >= nbx) {
+      bx -= nbx;
+      by++;
+    }
+    if (b + kWaves < nblk) load_block(b + kWaves, bx, by, next_v);
+    const size_t pos = (size_t)(by0 + cby) * bstride + bx0 + cbx;
+#pragma unroll
+    for (int ci = 0; ci < 3; ci++) {
+      const int e = b * 3 + ci;
+      const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
+      const int16_t v0 = cur_v[ci];
+      const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta[e]);
+      if (!(m & 1)) continue;
+      const int st = (int)((m >> 1) & 0x7F);
+      const int covered = st == 0 ? 1 : 2;
+      const int log2c = covered == 1 ? 0 : 1;
+      const int size = covered * 64;
+      const size_t pos1 = pos + (st == 1 ? bstride : 1);
+      const uint32_t tok0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)offs[e]);
+      const int nzeros = (int)((m >> 8) & 0xFF);
+      const int nscan = (int)(m >> 16);
+      // block context (ac_context.h:64-114): kBlockContextMap[c*27 + code] is 0/1 for Y and
+      // 2/3 for X,B, the odd value for the two-block strategy codes 6 and 7
+      const int block_ctx = (c == 1 ? 0 : 2) + (st == 0 ? 0 : 1);
+      if (lane == 0) {
+        // PredictFromTopAndLeft (enc_group.cc:150-160), default 32
+        int pred;
+        const uint8_t* nzg = &s_nzg[c * 1024 + b];
+        if (cbx == 0) pred = cby == 0 ? 32 : nzg[-nbx];
+        else if (cby == 0) pred = nzg[-1];
+        else pred = (nzg[-nbx] + nzg[-1] + 1) / 2;
+        const int bucket = pred < 8 ? pred : pred >= 64 ? 36 : 4 + pred / 2;
+        const int ctx = bucket * 4 + block_ctx;
+        uint8_t* o = out + 3 * (size_t)tok0;
         const uint8_t cm = s_ctx_map[ctx];
         o[0] = cm;
-        o[1] = (uint8_t)(val & 0xFF);
-        o[2] = (uint8_t)((val >> 8) & 0xFF);
+        o[1] = (uint8_t)(nzeros & 0xFF);
+        o[2] = (uint8_t)(nzeros >> 8);
         if (do_hist) {
           uint32_t sym, nb, eb;
-          hybrid_uint(val & 0xFFFFu, &sym, &nb, &eb);
+          hybrid_uint((uint32_t)nzeros, &sym, &nb, &eb);
           atomicAdd(&hist[cm * 64 + sym], 1u);
         }
       }
-      nz_before += __popcll(mk);
-      carry_flag = (int)((mk >> 63) & 1ull);
+      if (nzeros == 0) continue;
+      const int histo_offset = 4 * 37 + 458 * block_ctx;
+      int nz_before = 0;   // nonzeros at scan positions before the current 64-chunk
+      int carry_flag = 0;  // nonzero flag of the last position of the previous chunk
+      const int nhalf = nscan > 64 ? 2 : 1;  // the second 64 positions only if tokens reach them
+      for (int half = 0; half < nhalf; half++) {
+        const int k = half * 64 + lane;
+        const int16_t v = half == 0 ? v0 : (64 + lane < nscan ? A.coef_scan[(pos1 * 3 + c) * 64 + lane] : (int16_t)0);
+        const bool in_range = k >= covered && k < nscan;
+        const bool nz = in_range && v != 0;
+        const unsigned long long mk = __ballot(nz);
+        if (in_range) {
+          // nzeros still to come at position k, and whether position k-1 was nonzero
+          const int left = nzeros - (nz_before + __popcll(mk & ((1ull << lane) - 1ull)));
+          int p;
+          if (k == covered) p = (nzeros > size / 16) ? 0 : 1;
+          else if (lane == 0) p = carry_flag;
+          else p = (int)((mk >> (lane - 1)) & 1ull);
+          const int nl = (left + covered - 1) >> log2c;
+          const int kk = k >> log2c;
+          const int zctx = (s_nnz_ctx[nl] + s_freq_ctx[kk]) * 2 + p;
+          const int ctx = histo_offset + zctx;
+          const uint32_t val = pack_signed((int32_t)v);
+          uint8_t* o = out + 3 * ((size_t)tok0 + 1 + (k - covered));
+          const uint8_t cm = s_ctx_map[ctx];
+          o[0] = cm;
+          o[1] = (uint8_t)(val & 0xFF);
+          o[2] = (uint8_t)((val >> 8) & 0xFF);
+          if (do_hist) {
+            uint32_t sym, nb, eb;
+            hybrid_uint(val & 0xFFFFu, &sym, &nb, &eb);
+            atomicAdd(&hist[cm * 64 + sym], 1u);
+          }
+        }
+        nz_before += __popcll(mk);
+        carry_flag = (int)((mk >> 63) & 1ull);
+      }
     }
   }
   if (do_hist) {
