@@ -1679,8 +1679,8 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
           const int zctx = (s_nnz_ctx[nl] + s_freq_ctx[kk]) * 2 + p;
           const int ctx = histo_offset + zctx;
           const uint32_t val = pack_signed((int32_t)v);
-          uint8_t* o = out + 3 * ((size_t)tok0 + 1 + (k - covered));
           const uint8_t cm = s_ctx_map[ctx];
+          uint8_t* o = out + 3 * ((size_t)tok0 + 1 + (k - covered));
           o[0] = cm;
           o[1] = (uint8_t)(val & 0xFF);
           o[2] = (uint8_t)((val >> 8) & 0xFF);

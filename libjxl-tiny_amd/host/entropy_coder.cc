@@ -4,8 +4,13 @@
 #include "entropy_coder.h"
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <limits>
 #include <map>
+#include <mutex>
+#include <thread>
 
 namespace jxlt {
 namespace {
@@ -16,7 +21,7 @@ struct Node {
   int16_t right;  // child index, or the symbol for a leaf
 };
 
-void AssignDepths(const std::vector<Node>& pool, int root, uint8_t* depth) {
+void AssignDepths(const Node* pool, int root, uint8_t* depth) {
   // Iterative pre-order walk (enc_huffman_tree.cc:26-35 is the recursive form).
   struct Item { int node; uint8_t level; };
   Item stack[2 * kAlphabetSize + 8];
@@ -41,36 +46,44 @@ void AssignDepths(const std::vector<Node>& pool, int root, uint8_t* depth) {
 // (ties prefer the leaf queue).  If the tree is deeper than tree_limit the
 // minimum count is doubled and the construction repeated.
 void CreateHuffmanTree(const uint32_t* counts, size_t length, int tree_limit, uint8_t* depth) {
+  // Called ~1000 times per frame by the clustering (Distance): fixed-size node pool on the
+  // stack, and a stable insertion sort (the leaves arrive nearly sorted: histograms fall off
+  // towards the high symbols, which are gathered first).
+  if (length > kAlphabetSize) length = kAlphabetSize;
+  Node tree[2 * kAlphabetSize + 2];
   for (uint32_t count_limit = 1;; count_limit *= 2) {
-    std::vector<Node> tree;
-    tree.reserve(2 * length + 2);
+    size_t n = 0;
     for (size_t i = length; i != 0;) {
       --i;
       if (counts[i]) {
-        tree.push_back({std::max(counts[i], count_limit - 1), -1, static_cast<int16_t>(i)});
+        const Node leaf = {std::max(counts[i], count_limit - 1), -1, static_cast<int16_t>(i)};
+        size_t k = n++;
+        while (k != 0 && tree[k - 1].count > leaf.count) {  // strict: equal counts keep gathering order
+          tree[k] = tree[k - 1];
+          --k;
+        }
+        tree[k] = leaf;
       }
     }
-    const size_t n = tree.size();
     if (n == 0) return;  // (unreachable from the encoder; reference would misbehave)
     if (n == 1) {
       depth[tree[0].right] = 1;  // "fake" depth, kept as-is by the callers
       return;
     }
-    std::stable_sort(tree.begin(), tree.end(),
-                     [](const Node& a, const Node& b) { return a.count < b.count; });
     const Node sentinel = {std::numeric_limits<uint32_t>::max(), -1, -1};
-    tree.push_back(sentinel);  // [n]
-    tree.push_back(sentinel);  // first parent slot, [n + 1]
+    tree[n] = sentinel;
+    tree[n + 1] = sentinel;  // first parent slot
+    size_t size = n + 2;
     size_t leaf = 0, inner = n + 1;
     for (size_t k = n - 1; k != 0; --k) {
       size_t l, r;
       if (tree[leaf].count <= tree[inner].count) l = leaf++; else l = inner++;
       if (tree[leaf].count <= tree[inner].count) r = leaf++; else r = inner++;
-      const size_t parent = tree.size() - 1;
+      const size_t parent = size - 1;
       tree[parent].count = tree[l].count + tree[r].count;
       tree[parent].left = static_cast<int16_t>(l);
       tree[parent].right = static_cast<int16_t>(r);
-      tree.push_back(sentinel);
+      tree[size++] = sentinel;
     }
     AssignDepths(tree, static_cast<int>(2 * n - 1), depth);
     if (*std::max_element(depth, depth + length) <= tree_limit) return;
@@ -128,6 +141,127 @@ float Distance(const Histogram& a, const Histogram& b) {  // enc_cluster.cc:28-3
 
 }  // namespace
 
+namespace {
+
+// A handful of helper threads for the clustering's independent Huffman-cost evaluations
+// (integer arithmetic: the results do not depend on who computes them).  The helpers sleep
+// on a condition variable between sessions and spin between the ~130 short parallel loops of
+// one session, whose bodies are only a few microseconds long.  Helpers are optional: a loop
+// is complete when all its items are done, whoever ran them (the caller takes part).
+class ClusterPool {
+ public:
+  static ClusterPool& Get() {
+    static ClusterPool pool;
+    return pool;
+  }
+  // Exclusive use for one clustering; false if there are no helpers or another host thread
+  // holds the pool (the caller then runs its loops serially).
+  bool Open() {
+    if (workers_.empty() || !session_mu_.try_lock()) return false;
+    used_ = 0;
+    cur_.store(nullptr, std::memory_order_relaxed);
+    closed_.store(false, std::memory_order_release);
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      open_ = true;
+    }
+    cv_.notify_all();
+    return true;
+  }
+  void Close() {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      open_ = false;
+    }
+    closed_.store(true, std::memory_order_release);
+    // job slots are reused by the next session: no helper may still look at them
+    while (spinning_.load(std::memory_order_acquire) != 0) Pause();
+    session_mu_.unlock();
+  }
+  // fn(i) for i in [0, n).  Only between Open() and Close().
+  void Run(size_t n, const std::function<void(size_t)>& fn) {
+    if (used_ == kMaxJobs) {
+      for (size_t i = 0; i < n; i++) fn(i);
+      return;
+    }
+    Job& j = jobs_[used_++];
+    j.fn = &fn;
+    j.n = n;
+    j.next.store(0, std::memory_order_relaxed);
+    j.done.store(0, std::memory_order_relaxed);
+    cur_.store(&j, std::memory_order_release);
+    Drain(&j);
+    while (j.done.load(std::memory_order_acquire) != n) Pause();
+  }
+
+ private:
+  struct Job {
+    const std::function<void(size_t)>* fn = nullptr;
+    size_t n = 0;
+    std::atomic<size_t> next{0}, done{0};
+  };
+  static constexpr size_t kMaxJobs = 256;
+
+  ClusterPool() {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned n = hw >= 16 ? 7 : hw >= 4 ? hw / 2 - 1 : 0;
+    for (unsigned i = 0; i < n; i++) workers_.emplace_back([this] { Work(); });
+  }
+  ~ClusterPool() {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      quit_ = true;
+    }
+    cv_.notify_all();
+    for (std::thread& t : workers_) t.join();
+  }
+  static void Pause() {
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  static void Drain(Job* j) {
+    size_t ran = 0;
+    for (size_t i; (i = j->next.fetch_add(1, std::memory_order_relaxed)) < j->n;) {
+      (*j->fn)(i);
+      ++ran;
+    }
+    if (ran) j->done.fetch_add(ran, std::memory_order_release);
+  }
+  void Work() {
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [this] { return open_ || quit_; });
+        if (quit_) return;
+        spinning_.fetch_add(1, std::memory_order_relaxed);
+      }
+      Job* last = nullptr;
+      while (!closed_.load(std::memory_order_acquire)) {
+        Job* j = cur_.load(std::memory_order_acquire);
+        if (j != nullptr && j != last) {
+          Drain(j);
+          last = j;
+        } else {
+          Pause();
+        }
+      }
+      spinning_.fetch_sub(1, std::memory_order_release);
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex session_mu_, mu_;
+  std::condition_variable cv_;
+  bool open_ = false, quit_ = false;
+  std::atomic<bool> closed_{true};
+  std::atomic<int> spinning_{0};
+  std::atomic<Job*> cur_{nullptr};
+  Job jobs_[kMaxJobs];
+  size_t used_ = 0;
+};
+
+}  // namespace
+
 void ClusterHistograms(std::vector<Histogram>* histograms, std::vector<uint8_t>* context_map) {
   if (histograms->size() <= 1) return;  // enc_cluster.cc:121
   const size_t max_histograms = std::min<size_t>(8, histograms->size());
@@ -137,44 +271,63 @@ void ClusterHistograms(std::vector<Histogram>* histograms, std::vector<uint8_t>*
   out.reserve(max_histograms);
   std::vector<uint32_t> symbols(in.size(), static_cast<uint32_t>(max_histograms));
   std::vector<float> dists(in.size(), std::numeric_limits<float>::max());
+  // The independent cost evaluations of each step run on the helper pool when it is free;
+  // selections and ties are then resolved serially in the reference's order.
+  ClusterPool& pool = ClusterPool::Get();
+  const bool pooled = in.size() >= 16 && pool.Open();
+  auto parallel_for = [&](size_t n, const std::function<void(size_t)>& fn) {
+    if (pooled) {
+      pool.Run(n, fn);
+    } else {
+      for (size_t i = 0; i < n; i++) fn(i);
+    }
+  };
   size_t largest = 0;
-  for (size_t i = 0; i < in.size(); i++) {  // enc_cluster.cc:48-58
+  parallel_for(in.size(), [&](size_t i) {  // enc_cluster.cc:48-58
     if (in[i].total_count == 0) {
       symbols[i] = 0;
       dists[i] = 0.0f;
-      continue;
+    } else {
+      ComputeBitCost(&in[i]);
     }
-    ComputeBitCost(&in[i]);
-    if (in[i].total_count > in[largest].total_count) largest = i;
+  });
+  for (size_t i = 0; i < in.size(); i++) {
+    if (in[i].total_count != 0 && in[i].total_count > in[largest].total_count) largest = i;
   }
   constexpr float kMinDistanceForDistinct = 64.0f;
   while (out.size() < max_histograms) {  // enc_cluster.cc:61-73
     symbols[largest] = static_cast<uint32_t>(out.size());
     out.push_back(in[largest]);
     dists[largest] = 0.0f;
+    const Histogram& newest = out.back();
+    parallel_for(in.size(), [&](size_t i) {
+      if (dists[i] != 0.0f) dists[i] = std::min(Distance(in[i], newest), dists[i]);
+    });
+    // (every dists[largest] the reference compares against is already updated: largest < i)
     largest = 0;
     for (size_t i = 0; i < in.size(); i++) {
       if (dists[i] == 0.0f) continue;
-      dists[i] = std::min(Distance(in[i], out.back()), dists[i]);
       if (dists[i] > dists[largest]) largest = i;
     }
     if (dists[largest] < kMinDistanceForDistinct) break;
   }
+  float cand[8];
   for (size_t i = 0; i < in.size(); i++) {  // enc_cluster.cc:75-90
     if (symbols[i] != max_histograms) continue;
+    parallel_for(out.size(), [&](size_t j) { cand[j] = Distance(in[i], out[j]); });
     size_t best = 0;
-    float best_dist = Distance(in[i], out[best]);
+    float best_dist = cand[0];
     for (size_t j = 1; j < out.size(); j++) {
-      const float d = Distance(in[i], out[j]);
-      if (d < best_dist) {
+      if (cand[j] < best_dist) {
         best = j;
-        best_dist = d;
+        best_dist = cand[j];
       }
     }
     out[best].AddHistogram(in[i]);
     ComputeBitCost(&out[best]);
     symbols[i] = static_cast<uint32_t>(best);
   }
+  if (pooled) pool.Close();
   // Canonical renumbering in order of first use (enc_cluster.cc:98-115).
   std::vector<Histogram> tmp(out);
   std::map<uint32_t, uint32_t> new_index;
