@@ -90,16 +90,11 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   const auto t1 = now();
   EntropyCode ac_code, dc_code;
   std::vector<uint32_t> ac_table(64 * 64), dc_table(64 * 64);
-  {
-    // The two code constructions are independent: one extra host thread.
-    std::thread dc_thread([&]() {
-      BuildDcCode(dc_hist, &dc_code);
-      FillCodeTable(dc_code, dc_table.data());
-    });
-    BuildAcCode(ac_hist, &ac_code);
-    FillCodeTable(ac_code, ac_table.data());
-    dc_thread.join();
-  }
+  // (each construction spreads its cost evaluations over the helper pool of entropy_coder.cc)
+  BuildAcCode(ac_hist, &ac_code);
+  FillCodeTable(ac_code, ac_table.data());
+  BuildDcCode(dc_hist, &dc_code);
+  FillCodeTable(dc_code, dc_table.data());
   const auto t2 = now();
   // DC sections are small: fetched into the context's pinned buffer.  For the AC sections
   // only the sizes are needed to write the TOC; the blob is copied once, to its final place.
