@@ -226,6 +226,16 @@ JXLT_DI float sqrt_exact_midrange(float x) {
   return r;
 }
 
+// Correctly rounded 1.0f / q for integer-valued q (0 < |q| <= 2^31): the hardware reciprocal
+// (1 ulp) plus one residual correction.  On gfx950 this equals IEEE division for every such q
+// (tools/rcp_probe.hip checks all 2^32 - 1 of them; tests/test_gpu_parity.py runs it), at 3
+// instructions instead of the 11 of the generic division expansion.
+JXLT_DI float rcp_int_exact(float q) {
+  const float r0 = __builtin_amdgcn_rcpf(q);
+  const float e0 = nfma32(q, r0, 1.0f);
+  return fma32(e0, r0, r0);
+}
+
 // fast_math-inl.h:113-133 + :74-108
 JXLT_DI float fast_log2f(float x) {
   const float p0 = -1.8503833400518310E-06f, p1 = 1.4287160470083755E+00f,
@@ -651,7 +661,7 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
       // (a 64-entry LDS table of sqrtf(i) was tried here and measured slower: the random
       // LDS reads and the extra register pressure cost more than the IEEE sqrt sequence)
       entropy_v = fma32(sqrt_exact_midrange(q), kCostDelta, entropy_v);  // q is 0 or an integer >= 1
-      nzeros_v = nzeros_v + (q == 0.0f ? 0.0f : 1.0f);
+      nzeros_v = nzeros_v + fminf(q, 1.0f);  // q is a non-negative integer: 0 -> 0, else 1
     }
     entropy_v = fma32(nzeros_v, cost_of_1, entropy_v);
     entropy += octet_sum(entropy_v);
@@ -675,7 +685,7 @@ JXLT_DI float adjust_quant_bias_y(int32_t quant_i) {
   const bool is_01 = abs_quant < 1.125f;
   const bool not_0 = abs_quant > 0.0f;
   const float one_bias = not_0 ? __uint_as_float(__float_as_uint(kBias1) ^ sign) : 0.0f;
-  const float bias = nfma32(kBias3, 1.0f / quant, quant);
+  const float bias = nfma32(kBias3, rcp_int_exact(quant), quant);  // (quant == 0: selected away below)
   return is_01 ? one_bias : bias;
 }
 

@@ -320,6 +320,9 @@ inline void __builtin_amdgcn_s_setprio(int) {}  // issue priority: no effect on 
 
 inline void __builtin_amdgcn_sched_barrier(int) {}  // compiler scheduling fence
 
+// v_rcp_f32 (1 ulp on hardware; the model returns the correctly rounded reciprocal)
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __clzll(long long x) { return x == 0 ? 64 : __builtin_clzll((unsigned long long)x); }
 inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }

@@ -173,3 +173,21 @@ def test_sharded_slabs_on_one_gpu(built):
     assert got == T.assemble_codestream(T.oracle_hot_path(planes, d), d)
     for e in encs:
         e.close()
+
+
+def test_hardware_shortcuts_are_exact_on_this_gpu():
+    """tile_kernel replaces two generic IEEE sequences by shorter ones whose exactness depends on
+    the accuracy of this GPU's v_rcp_f32 (jxlt_device.h: rcp_int_exact).  tools/rcp_probe checks
+    the shortcut against IEEE division for every integer-valued float the quantiser can produce
+    (all 2^32 - 1 non-zero int32 values); variant 2 is the one the kernel uses."""
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parent.parent
+    exe = root / "tools" / "rcp_probe"
+    if not exe.exists():
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O2", "-ffp-contract=off", "-o", str(exe),
+                        str(root / "tools" / "rcp_probe.hip")], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, timeout=300).stdout
+    lines = [l for l in out.splitlines() if l.startswith("variant 2 ")]
+    assert len(lines) == 3, out
+    for l in lines:
+        assert "mismatches=0 " in l, l
