@@ -146,7 +146,21 @@ int jxlt_pack_sections(jxlt_context* ctx, int kind, const uint32_t* code_table, 
 int jxlt_pack_sections_sizes(jxlt_context* ctx, int kind, const uint32_t* code_table,
                              jxlt_packed_sections* out);
 int jxlt_pack_sections_copy(jxlt_context* ctx, int kind, uint8_t* dst);
+/* Asynchronous, copy-free variant for a destination in page-locked host memory obtained from
+ * jxlt_output_buffer / jxlt_pinned_alloc (device-visible): the compaction kernel writes the
+ * sections straight to `dst` over PCIe.  Complete after the next jxlt_synchronize. */
+int jxlt_pack_sections_place(jxlt_context* ctx, int kind, uint8_t* dst);
 int jxlt_output_buffer(jxlt_context* ctx, size_t bytes, uint8_t** out);
+/* Copy-free packing in two passes.  jxlt_pack_measure uploads both code tables and returns
+ * the exact bit / byte sizes of every DC-group and AC-group section (bytes == NULL), which is
+ * all the TOC needs.  jxlt_pack_write then entropy-codes the sections again, this time storing
+ * every section at its final place: dc_dst / ac_dst receive the byte-aligned sections of each
+ * kind back to back (offsets as returned by jxlt_pack_measure).  Both destinations must be
+ * device-visible (page-locked host memory from jxlt_output_buffer / jxlt_pinned_alloc, or device
+ * memory); the call is asynchronous and complete after the next jxlt_synchronize. */
+int jxlt_pack_measure(jxlt_context* ctx, const uint32_t* dc_code_table, const uint32_t* ac_code_table,
+                      jxlt_packed_sections* dc, jxlt_packed_sections* ac);
+int jxlt_pack_write(jxlt_context* ctx, uint8_t* dc_dst, uint8_t* ac_dst);
 
 /* Timing of the kernels of the last jxlt_encode_enqueue (needs JXLT_FLAG_PROFILE):
  * writes up to `cap` entries; returns the number of kernels, or < 0. */

@@ -85,6 +85,13 @@ struct jxlt_context {
     PinnedBuf<uint32_t> h_sec_bits;
     PinnedBuf<uint8_t> h_packed;
     size_t packed_sections = 0;
+    bool compacted = false;  // `packed` holds the sections of the last jxlt_pack_sections_sizes
+    size_t measured_sections = 0;  // jxlt_pack_measure done for this many sections
+    DeviceBuf<uint32_t> sec_tiles, tile_bits;
+    DeviceBuf<PackTileInfo> tile_info;
+    DeviceBuf<uint64_t> tile_base;
+    PinnedBuf<uint64_t> h_tile_base;
+    size_t max_tiles = 0;
   } pack[2];
   PinnedBuf<uint8_t> h_output;  // jxlt_output_buffer
 
@@ -102,6 +109,11 @@ struct jxlt_context {
 
   // profiling
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // jxlt_pack_write: packing on `stream`, chunked copies to the destination on `copy_stream`
+  hipStream_t copy_stream = nullptr;
+  static constexpr int kWriteChunks = 6;
+  hipEvent_t chunk_packed[kWriteChunks + 1] = {};
+  bool copies_pending = false;
   bool profiled = false;
 };
 
@@ -202,6 +214,8 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
   }
   for (auto& ev : ctx->ev) (void)hipEventCreate(&ev);
   for (auto& ev : ctx->stage_done) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  (void)hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+  for (auto& ev : ctx->chunk_packed) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   *out = ctx;
   return JXLT_OK;
 }
@@ -261,6 +275,9 @@ void jxlt_context_destroy(jxlt_context* ctx) {
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->ev)
     if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : ctx->chunk_packed)
+    if (ev) (void)hipEventDestroy(ev);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -401,7 +418,7 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   const size_t ndc = ((ctx->xsize + 2047) / 2048) * ((ctx->ysize + 2047) / 2048);
   // records per DC group, worst case: 2 + 3nb + 2nt + 2nb + nb with nb = 65536, nt = 1024
   const size_t kDcStride = 6 * 65536 + 2 * 1024 + 8;
-  ENSURE(dc_records, ndc * kDcStride * 3);
+  ENSURE(dc_records, ndc * kDcStride * 3 + 16);  // (+ slack: tiles are staged with aligned dword loads)
   ENSURE(dc_nac, ndc);
   ENSURE(dc_count, ndc);
   ENSURE(dc_rec_off, ndc + 1);
@@ -412,7 +429,7 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
     ctx->dc_rec_off_n = ndc;
   }
   // worst case: every coefficient of every block is a token, plus one nzeros token
-  ENSURE(tokens, nblocks * 3 * 64 * 3);
+  ENSURE(tokens, nblocks * 3 * 64 * 3 + 16);
   const size_t ncells = ((size_t)g.xsize_blocks / 2 + 1) * ((size_t)g.ysize_blocks / 2 + 1);
   if (debug) {
     ENSURE(dbg_qf, nblocks);
@@ -516,6 +533,7 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   ctx->encoded = true;
   ctx->offsets_fetched = false;
   ctx->pack[0].packed_sections = ctx->pack[1].packed_sections = 0;
+  ctx->pack[0].measured_sections = ctx->pack[1].measured_sections = 0;
   ctx->last_flags = params->flags;
   ctx->profiled = profile;
   return JXLT_OK;
@@ -525,6 +543,10 @@ int jxlt_synchronize(jxlt_context* ctx) {
   if (!ctx) return JXLT_ERR_INVALID_ARGUMENT;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->copies_pending) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+    ctx->copies_pending = false;
+  }
   return JXLT_OK;
 }
 
@@ -673,17 +695,14 @@ int jxlt_pack_sections_sizes(jxlt_context* ctx, int kind, const uint32_t* code_t
   P.slots = ps.slots.p;
   P.sec_bits = ps.sec_bits.p;
   P.sec_bytes = ps.sec_bytes.p;
+  P.out = nullptr;
+  P.sec_base = 0;
+  P.sec_byte_offset = nullptr;
   hipLaunchKernelGGL(pack_kernel, dim3((unsigned)nsec), dim3(kPackThreads), 0, ctx->stream, P);
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t*)ps.sec_bytes.p,
                      ps.sec_byte_off.p, (int)nsec);
-  CompactArgs Cp;
-  Cp.slots = ps.slots.p;
-  Cp.sec_rec_offset = P.sec_rec_offset;
-  Cp.sec_bytes = ps.sec_bytes.p;
-  Cp.sec_byte_offset = ps.sec_byte_off.p;
-  Cp.out = ps.packed.p;
-  hipLaunchKernelGGL(compact_kernel, dim3((unsigned)nsec), dim3(256), 0, ctx->stream, Cp);
   HIP_TRY(ctx, hipGetLastError());
+  ps.compacted = false;
   if ((rc = EnsurePinned(ctx, &ps.h_sec_byte_off, nsec + 1)) != JXLT_OK) return rc;
   if ((rc = EnsurePinned(ctx, &ps.h_sec_bits, nsec)) != JXLT_OK) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(ps.h_sec_byte_off.p, ps.sec_byte_off.p, (nsec + 1) * sizeof(uint64_t),
@@ -699,6 +718,34 @@ int jxlt_pack_sections_sizes(jxlt_context* ctx, int kind, const uint32_t* code_t
   return JXLT_OK;
 }
 
+namespace {
+// Sections of `kind` from their slots to `out` (device memory, or device-visible host memory)
+// at their byte offsets; asynchronous.
+int LaunchCompact(jxlt_context* ctx, int kind, uint8_t* out) {
+  jxlt_context::PackSet& ps = ctx->pack[kind];
+  CompactArgs Cp;
+  Cp.slots = ps.slots.p;
+  Cp.sec_rec_offset = kind == 1 ? ctx->group_off.p : ctx->dc_rec_off.p;
+  Cp.sec_bytes = ps.sec_bytes.p;
+  Cp.sec_byte_offset = ps.sec_byte_off.p;
+  Cp.out = out;
+  hipLaunchKernelGGL(compact_kernel, dim3((unsigned)ps.packed_sections), dim3(256), 0, ctx->stream, Cp);
+  HIP_TRY(ctx, hipGetLastError());
+  return JXLT_OK;
+}
+}  // namespace
+
+int jxlt_pack_sections_place(jxlt_context* ctx, int kind, uint8_t* dst) {
+  if (!ctx || !dst || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
+  jxlt_context::PackSet& ps = ctx->pack[kind];
+  if (ps.packed_sections == 0) {
+    ctx->error = "jxlt_pack_sections_place needs jxlt_pack_sections_sizes first";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return LaunchCompact(ctx, kind, dst);
+}
+
 int jxlt_pack_sections_copy(jxlt_context* ctx, int kind, uint8_t* dst) {
   if (!ctx || !dst || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
   jxlt_context::PackSet& ps = ctx->pack[kind];
@@ -708,6 +755,11 @@ int jxlt_pack_sections_copy(jxlt_context* ctx, int kind, uint8_t* dst) {
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint64_t total_bytes = ps.h_sec_byte_off.p[ps.packed_sections];
+  if (!ps.compacted) {
+    const int rc = LaunchCompact(ctx, kind, ps.packed.p);
+    if (rc != JXLT_OK) return rc;
+    ps.compacted = true;
+  }
   if (total_bytes) {
     HIP_TRY(ctx, hipMemcpyAsync(dst, ps.packed.p, total_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -725,6 +777,146 @@ int jxlt_pack_sections(jxlt_context* ctx, int kind, const uint32_t* code_table, 
     return rc;
   if ((rc = jxlt_pack_sections_copy(ctx, kind, ps.h_packed.p)) != JXLT_OK) return rc;
   out->bytes = ps.h_packed.p;
+  return JXLT_OK;
+}
+
+namespace {
+// Common argument block of the tile-granular packing kernels for sections of `kind`.
+PackTileArgs TileArgsOf(jxlt_context* ctx, int kind, size_t nsec) {
+  jxlt_context::PackSet& ps = ctx->pack[kind];
+  PackTileArgs P;
+  P.records = kind == 1 ? ctx->tokens.p : ctx->dc_records.p;
+  P.sec_rec_offset = kind == 1 ? ctx->group_off.p : ctx->dc_rec_off.p;
+  P.sec_rec_count = kind == 1 ? nullptr : ctx->dc_count.p;
+  P.nsec = (int)nsec;
+  P.code_table = ps.code_table.p;
+  P.sec_tiles = ps.sec_tiles.p;
+  P.tile_base = ps.tile_base.p;
+  P.tile_bits = ps.tile_bits.p;
+  P.tile_info = ps.tile_info.p;
+  P.sec_bits = ps.sec_bits.p;
+  P.sec_bytes = ps.sec_bytes.p;
+  P.sec_byte_offset = ps.sec_byte_off.p;
+  P.out = ps.packed.p;
+  P.tile_first = 0;
+  P.tile_end = 0xFFFFFFFFu;
+  return P;
+}
+}  // namespace
+
+int jxlt_pack_measure(jxlt_context* ctx, const uint32_t* dc_code_table, const uint32_t* ac_code_table,
+                      jxlt_packed_sections* dc, jxlt_packed_sections* ac) {
+  if (!ctx || !dc_code_table || !ac_code_table || !dc || !ac) return JXLT_ERR_INVALID_ARGUMENT;
+  if (!ctx->encoded || !ctx->offsets_fetched) {
+    ctx->error = "jxlt_pack_measure needs jxlt_encode_enqueue + jxlt_fetch_histograms/side_info first";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const FrameGeom& g = ctx->geom;
+  const size_t ngroups = (size_t)g.xsize_groups * g.ysize_groups;
+  const size_t nsecs[2] = {((ctx->xsize + 2047) / 2048) * ((ctx->ysize + 2047) / 2048), ngroups};
+  // upper bounds of the record counts (the exact per-section counts live on the device)
+  const uint64_t rec_bound[2] = {ctx->dc_records.cap / 3, ctx->h_group_off.p[ngroups]};
+  const uint32_t* tables[2] = {dc_code_table, ac_code_table};
+  jxlt_packed_sections* outs[2] = {dc, ac};
+  int rc;
+  for (int kind = 0; kind < 2; kind++) {
+    jxlt_context::PackSet& ps = ctx->pack[kind];
+    const size_t nsec = nsecs[kind];
+    const size_t max_tiles = (size_t)(rec_bound[kind] / kPackTile) + nsec + 1;
+#define ENSURE(buf, n) if ((rc = EnsureDevice(ctx, &ps.buf, (n))) != JXLT_OK) return rc
+    ENSURE(code_table, 64 * 64);
+    ENSURE(sec_bits, nsec);
+    ENSURE(sec_bytes, nsec);
+    ENSURE(sec_byte_off, nsec + 1);
+    ENSURE(sec_tiles, nsec);
+    ENSURE(tile_base, nsec + 1);
+    ENSURE(tile_bits, max_tiles);
+    ENSURE(tile_info, max_tiles);
+#undef ENSURE
+    if ((rc = EnsurePinned(ctx, &ps.h_sec_byte_off, nsec + 1)) != JXLT_OK) return rc;
+    if ((rc = EnsurePinned(ctx, &ps.h_sec_bits, nsec)) != JXLT_OK) return rc;
+    if ((rc = EnsurePinned(ctx, &ps.h_tile_base, nsec + 1)) != JXLT_OK) return rc;
+    ps.max_tiles = max_tiles;
+    HIP_TRY(ctx, hipMemcpyAsync(ps.code_table.p, tables[kind], 64 * 64 * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                ctx->stream));
+    const PackTileArgs P = TileArgsOf(ctx, kind, nsec);
+    const unsigned sec_blocks = (unsigned)((nsec + 255) / 256);
+    hipLaunchKernelGGL(pack_tile_count_kernel, dim3(sec_blocks), dim3(256), 0, ctx->stream, P);
+    hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t*)ps.sec_tiles.p,
+                       ps.tile_base.p, (int)nsec);
+    hipLaunchKernelGGL(pack_tile_plan_kernel, dim3(sec_blocks), dim3(256), 0, ctx->stream, P);
+    hipLaunchKernelGGL(pack_tile_measure_kernel, dim3((unsigned)((max_tiles + kPackTilesPerGroup - 1) / kPackTilesPerGroup)),
+                       dim3(kPackThreads), 0, ctx->stream, P);
+    hipLaunchKernelGGL(pack_tile_offsets_kernel, dim3(sec_blocks), dim3(256), 0, ctx->stream, P);
+    hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t*)ps.sec_bytes.p,
+                       ps.sec_byte_off.p, (int)nsec);
+    hipLaunchKernelGGL(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), 0, ctx->stream,
+                       P);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ps.h_sec_byte_off.p, ps.sec_byte_off.p, (nsec + 1) * sizeof(uint64_t),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ps.h_sec_bits.p, ps.sec_bits.p, nsec * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ps.h_tile_base.p, ps.tile_base.p, (nsec + 1) * sizeof(uint64_t),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    ps.packed_sections = 0;  // nothing in slots / packed
+    ps.measured_sections = nsec;
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int kind = 0; kind < 2; kind++) {
+    jxlt_context::PackSet& ps = ctx->pack[kind];
+    outs[kind]->bytes = nullptr;
+    outs[kind]->section_offset = ps.h_sec_byte_off.p;
+    outs[kind]->section_bits = ps.h_sec_bits.p;
+    outs[kind]->num_sections = nsecs[kind];
+  }
+  return JXLT_OK;
+}
+
+int jxlt_pack_write(jxlt_context* ctx, uint8_t* dc_dst, uint8_t* ac_dst) {
+  if (!ctx || !dc_dst || !ac_dst) return JXLT_ERR_INVALID_ARGUMENT;
+  if (ctx->pack[0].measured_sections == 0 || ctx->pack[1].measured_sections == 0) {
+    ctx->error = "jxlt_pack_write needs jxlt_pack_measure first";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // Tiles are packed at their final bit positions into a device blob per kind; the blob leaves in
+  // chunks on the copy stream while later chunks are still being packed.  DC first, then the AC
+  // sections in kWriteChunks - 1 ranges of whole sections.
+  uint8_t* dsts[2] = {dc_dst, ac_dst};
+  int rc;
+  int ev = 0;
+  for (int kind = 0; kind < 2; kind++) {
+    jxlt_context::PackSet& ps = ctx->pack[kind];
+    const size_t nsec = ps.measured_sections;
+    const uint64_t* off = ps.h_sec_byte_off.p;
+    const uint64_t* tb = ps.h_tile_base.p;
+    const uint64_t total = off[nsec];
+    if (ps.packed.cap < total + 16 && (rc = EnsureDevice(ctx, &ps.packed, total + total / 4 + 4096)) != JXLT_OK)
+      return rc;
+    const int nchunks = kind == 0 ? 1 : (int)std::min<size_t>(jxlt_context::kWriteChunks - 1, nsec);
+    for (int c = 0; c < nchunks; c++) {
+      const size_t s0 = nsec * c / nchunks, s1 = nsec * (c + 1) / nchunks;
+      if (s1 == s0) continue;
+      if (tb[s1] > tb[s0]) {
+        PackTileArgs P = TileArgsOf(ctx, kind, nsec);
+        P.tile_first = (uint32_t)tb[s0];
+        P.tile_end = (uint32_t)tb[s1];
+        hipLaunchKernelGGL(pack_tile_write_kernel,
+                           dim3((unsigned)((tb[s1] - tb[s0] + kPackTilesPerGroup - 1) / kPackTilesPerGroup)),
+                           dim3(kPackThreads), 0, ctx->stream, P);
+        HIP_TRY(ctx, hipGetLastError());
+      }
+      HIP_TRY(ctx, hipEventRecord(ctx->chunk_packed[ev], ctx->stream));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->chunk_packed[ev], 0));
+      ev++;
+      if (off[s1] > off[s0])
+        HIP_TRY(ctx, hipMemcpyAsync(dsts[kind] + off[s0], ps.packed.p + off[s0], off[s1] - off[s0], hipMemcpyDefault,
+                                    ctx->copy_stream));
+    }
+  }
+  ctx->copies_pending = true;
   return JXLT_OK;
 }
 

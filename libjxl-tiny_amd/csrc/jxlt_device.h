@@ -108,6 +108,9 @@ struct PackArgs {
   uint32_t* sec_bits;               // [nsec] bits written
   uint32_t* sec_bytes;              // [nsec] ceil(bits / 8)
   const uint32_t* sec_rec_count;    // optional [nsec]: records in section (else offset[s+1]-offset[s])
+  uint8_t* out;                     // pack_direct_kernel: destination of section 0
+  int sec_base;                     // first section of this launch (section = sec_base + workgroup index)
+  const uint64_t* sec_byte_offset;  // pack_direct_kernel: [nsec] byte offset of each section in `out`
 };
 
 struct CompactArgs {
@@ -1719,26 +1722,40 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
 // lengths gives its bit offset, bits are OR-ed into an LDS window that is then
 // flushed with coalesced dword stores.
 // ---------------------------------------------------------------------------
-constexpr int kPackThreads = 256;
-constexpr int kPackPerThread = 16;
+constexpr int kPackThreads = 512;
+constexpr int kPackPerThread = 8;
 constexpr int kPackTile = kPackThreads * kPackPerThread;        // 4096 records
 constexpr int kPackWindowWords = kPackTile * 28 / 32 + 4;        // <= 28 bits per record
 
-__global__ void __launch_bounds__(kPackThreads) pack_kernel(const PackArgs A) {
+// kMode 0: sections to dword-aligned slots (4 * first record index), sizes written out.
+// kMode 2: sections to their final byte offsets A.out + A.sec_byte_offset[sec] (device memory or
+//          device-visible host memory); the section's first byte may sit anywhere inside a
+//          dword that it shares with its neighbour, so the bit stream starts 8 * (address & 3)
+//          bits into an aligned window and the two edge dwords are written bytewise.
+template <int kMode>
+JXLT_DI void pack_section(const PackArgs& A) {
   __shared__ uint32_t table[64 * 64];
   __shared__ uint32_t window[kPackWindowWords];
   __shared__ uint32_t scan[kPackThreads];
   __shared__ uint8_t bytes[kPackTile * 3 + 8];
   const int tid = (int)threadIdx.x;
-  const int sec = (int)blockIdx.x;
+  const int sec = A.sec_base + (int)blockIdx.x;
   for (int i = tid; i < 64 * 64; i += kPackThreads) table[i] = A.code_table[i];
   const uint64_t rec0 = A.sec_rec_offset[sec];
   const uint64_t rec1 = A.sec_rec_count ? rec0 + A.sec_rec_count[sec] : A.sec_rec_offset[sec + 1];
   const uint8_t* src = A.records + 3 * rec0;
-  uint32_t* dst = reinterpret_cast<uint32_t*>(A.slots + 4 * rec0);
-  uint64_t total_bits = 0;     // bits of all completed tiles
-  uint32_t carry = 0;          // partial last word of the previous tile
-  uint64_t words_out = 0;      // complete words already stored
+  uint32_t* dst = nullptr;
+  uint32_t lead_bits = 0;
+  if (kMode == 0) dst = reinterpret_cast<uint32_t*>(A.slots + 4 * rec0);
+  if (kMode == 2) {
+    uint8_t* d = A.out + A.sec_byte_offset[sec];
+    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(d) & 3u);
+    dst = reinterpret_cast<uint32_t*>(d - mis);
+    lead_bits = 8 * mis;
+  }
+  uint64_t total_bits = lead_bits;  // bits of all completed tiles (+ the alignment lead)
+  uint32_t carry = 0;               // partial last word of the previous tile
+  uint64_t words_out = 0;           // complete words already stored
   for (uint64_t t0 = 0; t0 < rec1 - rec0; t0 += kPackTile) {
     const int n = (int)((rec1 - rec0 - t0) < (uint64_t)kPackTile ? (rec1 - rec0 - t0) : (uint64_t)kPackTile);
     __syncthreads();  // previous tile fully flushed; table loaded
@@ -1804,7 +1821,15 @@ __global__ void __launch_bounds__(kPackThreads) pack_kernel(const PackArgs A) {
     __syncthreads();
     const uint32_t end_bits = lead + tile_bits;
     const uint32_t full_words = end_bits >> 5;
-    for (uint32_t i = tid; i < full_words; i += kPackThreads) dst[words_out + i] = window[i];
+    for (uint32_t i = tid; i < full_words; i += kPackThreads) {
+      if (kMode == 2 && words_out + i == 0 && lead_bits != 0) {
+        // first dword of the section: its low bytes belong to the previous section
+        uint8_t* b = reinterpret_cast<uint8_t*>(dst);
+        for (uint32_t k = lead_bits >> 3; k < 4; k++) b[k] = (uint8_t)(window[0] >> (8 * k));
+      } else {
+        dst[words_out + i] = window[i];
+      }
+    }
     const uint32_t next_carry = (end_bits & 31u) ? window[full_words] : 0u;
     __syncthreads();
     carry = next_carry;
@@ -1812,12 +1837,362 @@ __global__ void __launch_bounds__(kPackThreads) pack_kernel(const PackArgs A) {
     total_bits += tile_bits;
   }
   if (tid == 0) {
-    if (total_bits & 31u) dst[words_out] = carry;
-    A.sec_bits[sec] = (uint32_t)total_bits;
-    A.sec_bytes[sec] = (uint32_t)((total_bits + 7) >> 3);
+    if (kMode == 0) {
+      if (total_bits & 31u) dst[words_out] = carry;
+    } else if (kMode == 2) {
+      // last, partial dword: only the bytes the section owns
+      const uint32_t rem_bytes = (uint32_t)(((total_bits & 31u) + 7) >> 3);
+      const uint32_t first = words_out == 0 ? (lead_bits >> 3) : 0u;
+      uint8_t* b = reinterpret_cast<uint8_t*>(dst + words_out);
+      for (uint32_t k = first; k < rem_bytes; k++) b[k] = (uint8_t)(carry >> (8 * k));
+    }
+    if (kMode != 2) {
+      A.sec_bits[sec] = (uint32_t)(total_bits - lead_bits);
+      A.sec_bytes[sec] = (uint32_t)((total_bits - lead_bits + 7) >> 3);
+    }
   }
 }
 
+__global__ void __launch_bounds__(kPackThreads) pack_kernel(const PackArgs A) { pack_section<0>(A); }
+
+// ---------------------------------------------------------------------------
+// Copy-free packing at tile granularity (kPackTile records per workgroup, whatever section they
+// belong to): DC-group sections hold ~100 tiles each, AC-group sections <= 48, so per-section
+// workgroups leave most of the machine idle on the 64 DC sections of a 16384^2 frame.
+//   pack_tile_count_kernel    tiles per section            (+ group_scan_kernel -> tile_base)
+//   pack_tile_plan_kernel     per section: the record range of each of its tiles
+//   pack_tile_measure_kernel  bit length of every tile
+//   pack_tile_offsets_kernel  per section: bit offset of each tile, section bits / bytes
+//                             (+ group_scan_kernel -> byte offset of each section)
+//   pack_tile_finalize_kernel per tile: absolute bit positions
+//   pack_tile_write_kernel    entropy-codes a tile at its final bit position of the blob
+// (a tile's workgroup finds everything it needs in one 32-byte PackTileInfo: no dependent
+// global loads in front of the record loads)
+// Two tiles of a section meet inside a dword.  The later tile owns that dword: it re-derives
+// the trailing bits of its predecessor(s) from their last records, so every dword is stored by
+// exactly one workgroup with plain stores (no atomics, no zero-initialised destination).  Where
+// two *sections* meet inside a dword (sections are byte aligned) each stores its own bytes.
+// ---------------------------------------------------------------------------
+struct alignas(16) PackTileInfo {
+  uint64_t rec_first;      // absolute index of the tile's first record
+  uint64_t bit_pos;        // bit position of the tile in the blob (section-relative until finalised)
+  uint64_t sec_start_bit;  // bit position of the tile's section in the blob (section index until finalised)
+  uint32_t n_last;         // records in the tile | last tile of its section << 31
+  uint32_t before;         // records of the section in front of the tile
+};
+
+struct PackTileArgs {
+  const uint8_t* records;           // 3-byte records
+  const uint64_t* sec_rec_offset;   // [nsec (+1)] first record of each section
+  const uint32_t* sec_rec_count;    // optional [nsec] (else offset[s+1] - offset[s])
+  int nsec;
+  const uint32_t* code_table;       // [64][64]: (depth << 16) | bits
+  uint32_t* sec_tiles;              // [nsec] tiles per section
+  const uint64_t* tile_base;        // [nsec + 1] exclusive scan of sec_tiles
+  uint32_t* tile_bits;              // [tiles] bit length of each tile
+  PackTileInfo* tile_info;          // [tiles] where each tile's records and bits are
+  uint32_t* sec_bits;               // [nsec]
+  uint32_t* sec_bytes;              // [nsec]
+  const uint64_t* sec_byte_offset;  // [nsec + 1] exclusive scan of sec_bytes
+  uint8_t* out;                     // blob (4-byte aligned)
+  uint32_t tile_first;              // first tile of this launch
+  uint32_t tile_end;                // one past the last tile of this launch (clamped to the tile count)
+};
+
+JXLT_DI uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+JXLT_DI uint32_t pack_section_records(const PackTileArgs& A, int sec) {
+  return A.sec_rec_count ? A.sec_rec_count[sec] : (uint32_t)(A.sec_rec_offset[sec + 1] - A.sec_rec_offset[sec]);
+}
+
+__global__ void __launch_bounds__(256) pack_tile_count_kernel(const PackTileArgs A) {
+  const int s = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (s < A.nsec) A.sec_tiles[s] = (pack_section_records(A, s) + kPackTile - 1) / kPackTile;
+}
+
+__global__ void __launch_bounds__(256) pack_tile_plan_kernel(const PackTileArgs A) {
+  const int s = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (s >= A.nsec) return;
+  const uint32_t t0 = (uint32_t)A.tile_base[s], t1 = (uint32_t)A.tile_base[s + 1];
+  const uint32_t cnt = pack_section_records(A, s);
+  const uint64_t rec0 = A.sec_rec_offset[s];
+  for (uint32_t t = t0; t < t1; t++) {
+    const uint32_t before = (t - t0) * kPackTile;
+    const uint32_t n = cnt - before < (uint32_t)kPackTile ? cnt - before : (uint32_t)kPackTile;
+    PackTileInfo info;
+    info.rec_first = rec0 + before;
+    info.bit_pos = 0;
+    info.sec_start_bit = (uint64_t)s;
+    info.n_last = n | (t + 1 == t1 ? 0x80000000u : 0u);
+    info.before = before;
+    A.tile_info[t] = info;
+  }
+}
+
+// (nb, data) of one record: code of the hybrid-uint symbol followed by its extra bits, or the
+// raw bits of an escape record (ctx >= 128).
+JXLT_DI void pack_record_bits(const uint8_t* rec, const uint32_t* table, uint32_t* nb, uint32_t* data) {
+  const uint32_t ctx = rec[0];
+  const uint32_t value = (uint32_t)rec[1] | ((uint32_t)rec[2] << 8);
+  if (ctx >= 128) {
+    *nb = ctx - 128;
+    *data = value;
+  } else {
+    uint32_t sym, nbits, extra;
+    hybrid_uint(value, &sym, &nbits, &extra);
+    const uint32_t e = table[ctx * 64 + sym];
+    const uint32_t depth = e >> 16;
+    *nb = depth + nbits;
+    *data = (e & 0xFFFFu) | (extra << depth);
+  }
+}
+
+// Records of a tile -> LDS, realigned so that the first record starts at stage[0]: aligned dword
+// loads from memory, each staged dword assembled from two of them (v_alignbyte).
+JXLT_DI void pack_stage_tile(const uint8_t* src, int n, uint32_t* stage, int tid) {
+  const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3u);
+  const uint32_t* srcw = reinterpret_cast<const uint32_t*>(src - mis);
+  const int nw = (3 * n + 3) >> 2;
+  for (int i = tid; i < nw; i += kPackThreads) stage[i] = __builtin_amdgcn_alignbyte(srcw[i + 1], srcw[i], mis);
+}
+
+// The kPackPerThread consecutive records of thread `tid` (3 * kPackPerThread bytes = 12 dwords,
+// dword aligned in the staged tile) with wide LDS reads; record j is the 24 bits at byte 3 * j.
+struct PackThreadRecords {
+  uint32_t w[kPackPerThread * 3 / 4 + 1];
+};
+JXLT_DI void pack_load_thread_records(const uint32_t* stage_tile, int tid, PackThreadRecords* out) {
+  static_assert(kPackPerThread * 3 % 8 == 0, "whole 8-byte reads per thread");
+  const uint2* p = reinterpret_cast<const uint2*>(stage_tile + tid * (kPackPerThread * 3 / 4));
+#pragma unroll
+  for (int q = 0; q < kPackPerThread * 3 / 8; q++) {
+    const uint2 v = p[q];
+    out->w[2 * q + 0] = v.x;
+    out->w[2 * q + 1] = v.y;
+  }
+  out->w[kPackPerThread * 3 / 4] = 0;
+}
+JXLT_DI uint32_t pack_thread_record(const PackThreadRecords& r, int j) {  // ctx | value << 8
+  const int byte = 3 * j;
+  return __builtin_amdgcn_alignbyte(r.w[(byte >> 2) + 1], r.w[byte >> 2], (uint32_t)(byte & 3)) & 0xFFFFFFu;
+}
+JXLT_DI void pack_bits_of(uint32_t rec24, const uint32_t* table, uint32_t* nb, uint32_t* data) {
+  const uint32_t ctx = rec24 & 0xFFu, value = rec24 >> 8;
+  if (ctx >= 128) {
+    *nb = ctx - 128;
+    *data = value;
+  } else {
+    uint32_t sym, nbits, extra;
+    hybrid_uint(value, &sym, &nbits, &extra);
+    const uint32_t e = table[ctx * 64 + sym];
+    const uint32_t depth = e >> 16;
+    *nb = depth + nbits;
+    *data = (e & 0xFFFFu) | (extra << depth);
+  }
+}
+
+constexpr int kPackTilesPerGroup = 4;  // consecutive tiles per workgroup (amortises the table load)
+
+__global__ void __launch_bounds__(kPackThreads) pack_tile_measure_kernel(const PackTileArgs A) {
+  __shared__ uint8_t depth[64 * 64];
+  __shared__ alignas(16) uint32_t stage[kPackTile * 3 / 4 + 4];
+  __shared__ uint32_t total[kPackTilesPerGroup];
+  const int tid = (int)threadIdx.x;
+  const uint32_t ntiles_all = umin32((uint32_t)A.tile_base[A.nsec], A.tile_end);
+  const uint32_t first = A.tile_first + blockIdx.x * kPackTilesPerGroup;
+  if (first >= ntiles_all) return;
+  for (int i = tid; i < 64 * 64; i += kPackThreads) depth[i] = (uint8_t)(A.code_table[i] >> 16);
+  if (tid < kPackTilesPerGroup) total[tid] = 0;
+  for (int k = 0; k < kPackTilesPerGroup; k++) {
+    const uint32_t tile = first + k;
+    if (tile >= ntiles_all) break;
+    __syncthreads();  // previous tile's stage consumed; tables loaded
+    const PackTileInfo info = A.tile_info[tile];
+    const int n = (int)(info.n_last & 0x7FFFFFFFu);
+    pack_stage_tile(A.records + 3 * info.rec_first, n, stage, tid);
+    __syncthreads();
+    PackThreadRecords recs;
+    pack_load_thread_records(stage, tid, &recs);
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < kPackPerThread; j++) {
+      const int r = tid * kPackPerThread + j;
+      if (r < n) {
+        const uint32_t rec24 = pack_thread_record(recs, j);
+        const uint32_t ctx = rec24 & 0xFFu, value = rec24 >> 8;
+        if (ctx >= 128) {
+          mine += ctx - 128;
+        } else {
+          uint32_t sym, nbits, extra;
+          hybrid_uint(value, &sym, &nbits, &extra);
+          mine += depth[ctx * 64 + sym] + nbits;
+        }
+      }
+    }
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    if ((tid & 63) == 0) atomicAdd(&total[k], mine);
+  }
+  __syncthreads();
+  if (tid < kPackTilesPerGroup && first + tid < ntiles_all) A.tile_bits[first + tid] = total[tid];
+}
+
+__global__ void __launch_bounds__(256) pack_tile_offsets_kernel(const PackTileArgs A) {
+  const int s = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (s >= A.nsec) return;
+  const uint32_t t0 = (uint32_t)A.tile_base[s], t1 = (uint32_t)A.tile_base[s + 1];
+  uint32_t off = 0;
+  for (uint32_t t = t0; t < t1; t++) {
+    A.tile_info[t].bit_pos = off;
+    off += A.tile_bits[t];
+  }
+  A.sec_bits[s] = off;
+  A.sec_bytes[s] = (off + 7) >> 3;
+}
+
+__global__ void __launch_bounds__(256) pack_tile_finalize_kernel(const PackTileArgs A) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= (uint32_t)A.tile_base[A.nsec]) return;
+  PackTileInfo info = A.tile_info[t];
+  const uint64_t start = 8 * A.sec_byte_offset[info.sec_start_bit];
+  info.bit_pos += start;
+  info.sec_start_bit = start;
+  A.tile_info[t] = info;
+}
+
+__global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const PackTileArgs A) {
+  __shared__ uint32_t table[64 * 64];
+  __shared__ uint32_t window[kPackWindowWords];
+  __shared__ uint32_t wave_sum[kPackThreads / 64];
+  __shared__ alignas(16) uint32_t stage[(kPackTile + 64) * 3 / 4 + 4];  // the tile and the 64 records before it
+  const int tid = (int)threadIdx.x;
+  const uint32_t ntiles_all = umin32((uint32_t)A.tile_base[A.nsec], A.tile_end);
+  const uint32_t first_tile = A.tile_first + blockIdx.x * kPackTilesPerGroup;
+  if (first_tile >= ntiles_all) return;
+  for (int i = tid; i < 64 * 64; i += kPackThreads) table[i] = A.code_table[i];
+  uint32_t* outw = reinterpret_cast<uint32_t*>(A.out);
+  for (int kt = 0; kt < kPackTilesPerGroup; kt++) {
+    const uint32_t tile = first_tile + kt;
+    if (tile >= ntiles_all) break;
+    __syncthreads();  // previous tile flushed; table loaded
+    for (int i = tid; i < kPackWindowWords; i += kPackThreads) window[i] = 0u;
+    const PackTileInfo info = A.tile_info[tile];
+    const int n = (int)(info.n_last & 0x7FFFFFFFu);
+    const bool last_tile = (info.n_last >> 31) != 0;
+    const uint8_t* tile_src = A.records + 3 * info.rec_first;
+    const int pre = info.before != 0 ? 64 : 0;  // records before the tile staged for the look-back
+    pack_stage_tile(tile_src - 3 * pre, n + pre, stage, tid);
+    const uint32_t* stage_tile = stage + pre * 3 / 4;  // 64 records = 48 dwords
+    const uint64_t sec_start_bit = info.sec_start_bit;
+    const uint64_t pos_bit = info.bit_pos;  // where this tile's bits start
+    const uint32_t lead = (uint32_t)(pos_bit & 31u);
+    const uint64_t word0 = pos_bit >> 5;
+    // ---- the bits of earlier records of this section that share the tile's first dword
+    const uint64_t word0_bit = word0 << 5;
+    const uint32_t need = word0_bit >= sec_start_bit ? lead : (uint32_t)(pos_bit - sec_start_bit);
+    __syncthreads();  // stage complete
+    if (need != 0 && tid < 64) {
+      // wave 0 walks backwards, 64 records at a time, until `need` bits are covered
+      // (first round from the staged copy, further rounds -- rare -- from memory)
+      const uint8_t* staged = reinterpret_cast<const uint8_t*>(stage_tile);
+      uint32_t covered = 0;                  // bits before pos_bit already accounted for
+      uint32_t back = info.before;           // records of the section before this tile not yet visited
+      while (covered < need && back != 0) {
+        const bool have = (uint32_t)tid < back;
+        uint32_t nb = 0, data = 0;
+        if (have) {
+          const bool first_round = back == info.before;
+          pack_record_bits(first_round ? staged - 3 * (1 + tid) : tile_src - 3 * (size_t)(info.before - back + 1 + tid),
+                           table, &nb, &data);
+        }
+        // bits between this record's end and pos_bit: records tid' < tid of this round + covered
+        uint32_t after = nb;
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t o = __shfl_up(after, d);
+          if (tid >= d) after += o;
+        }
+        const uint32_t round_bits = __shfl(after, 63);
+        after = covered + after - nb;
+        if (have && nb != 0 && after < need) {
+          // the record's bits occupy [lead - after - nb, lead - after) of the first dword
+          const int hi = (int)lead - (int)after, lo = hi - (int)nb;
+          const uint32_t v = lo >= 0 ? (data << lo) : (data >> (-lo));
+          const uint32_t mask = hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u);
+          atomicOr(&window[0], v & mask);
+        }
+        covered += round_bits;
+        back = back > 64 ? back - 64 : 0;
+      }
+    }
+    __syncthreads();
+    // pass 1: bit length of this thread's records
+    PackThreadRecords recs;
+    pack_load_thread_records(stage_tile, tid, &recs);
+    uint32_t nb[kPackPerThread];
+    uint32_t data[kPackPerThread];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < kPackPerThread; j++) {
+      const int r = tid * kPackPerThread + j;
+      nb[j] = 0;
+      data[j] = 0;
+      if (r < n) pack_bits_of(pack_thread_record(recs, j), table, &nb[j], &data[j]);
+      mine += nb[j];
+    }
+    // exclusive prefix of `mine` over the workgroup: wave scan + per-wave totals
+    uint32_t incl = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d);
+      if ((tid & 63) >= d) incl += o;
+    }
+    if ((tid & 63) == 63) wave_sum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0, tile_bits = 0;
+#pragma unroll
+    for (int w = 0; w < kPackThreads / 64; w++) {
+      const uint32_t v = wave_sum[w];
+      if (w < (tid >> 6)) wave_base += v;
+      tile_bits += v;
+    }
+    // pass 2: OR the bits into the window
+    {
+      const uint32_t pos = lead + wave_base + incl - mine;
+      uint32_t w = pos >> 5;
+      uint32_t fill = pos & 31u;
+      unsigned long long acc = 0;
+#pragma unroll
+      for (int j = 0; j < kPackPerThread; j++) {
+        acc |= (unsigned long long)data[j] << fill;
+        fill += nb[j];
+        if (fill >= 32) {
+          atomicOr(&window[w], (uint32_t)acc);
+          acc >>= 32;
+          fill -= 32;
+          w++;
+        }
+      }
+      if (fill) atomicOr(&window[w], (uint32_t)acc);
+    }
+    __syncthreads();
+    // stores: complete dwords; the trailing partial dword only if the section ends here (its
+    // successor tile owns it otherwise); bytes below the section's first byte are never touched
+    const uint32_t end_bits = lead + tile_bits;
+    const uint32_t full_words = end_bits >> 5;
+    const uint32_t own_first = word0_bit < sec_start_bit ? (uint32_t)((sec_start_bit - word0_bit) >> 3) : 0u;
+    for (uint32_t i = tid; i < full_words; i += kPackThreads) {
+      if (i == 0 && own_first != 0) {
+        uint8_t* b = reinterpret_cast<uint8_t*>(outw + word0);
+        for (uint32_t k = own_first; k < 4; k++) b[k] = (uint8_t)(window[0] >> (8 * k));
+      } else {
+        outw[word0 + i] = window[i];
+      }
+    }
+    if (tid == 0 && last_tile && (end_bits & 31u) != 0) {
+      const uint32_t rem_bytes = ((end_bits & 31u) + 7) >> 3;
+      const uint32_t first = full_words == 0 ? own_first : 0u;
+      uint8_t* b = reinterpret_cast<uint8_t*>(outw + word0 + full_words);
+      for (uint32_t k = first; k < rem_bytes; k++) b[k] = (uint8_t)(window[full_words] >> (8 * k));
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------
 // DC-group sections as raw records (enc_frame.cc:287-424, 536-570):
@@ -2022,11 +2397,26 @@ __global__ void __launch_bounds__(kDcChainThreads) dc_chain_kernel(const DcArgs 
 
 // Gathers the packed sections into one contiguous byte stream.
 __global__ void __launch_bounds__(256) compact_kernel(const CompactArgs A) {
-  const int sec = (int)blockIdx.x;
-  const uint8_t* src = A.slots + 4 * A.sec_rec_offset[sec];
+  // The slot is dword aligned, the destination only byte aligned (sections are byte-aligned in
+  // the codestream; the destination may be host memory behind PCIe): aligned dword stores for
+  // the body, each assembled from two source dwords, and byte stores for the <= 3 + 3 edge bytes.
+  const int sec = (int)blockIdx.x, tid = (int)threadIdx.x;
+  const uint8_t* srcb = A.slots + 4 * A.sec_rec_offset[sec];
+  const uint32_t* srcw = reinterpret_cast<const uint32_t*>(srcb);
   uint8_t* dst = A.out + A.sec_byte_offset[sec];
   const uint32_t n = A.sec_bytes[sec];
-  for (uint32_t i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+  uint32_t lead = (4u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u;
+  if (lead > n) lead = n;
+  if ((uint32_t)tid < lead) dst[tid] = srcb[tid];
+  const uint32_t body = (n - lead) >> 2;
+  uint32_t* dw = reinterpret_cast<uint32_t*>(dst + lead);
+  const uint32_t sh = lead * 8;
+  for (uint32_t i = tid; i < body; i += 256) {
+    const uint32_t lo = srcw[i];
+    dw[i] = sh ? (lo >> sh) | (srcw[i + 1] << (32 - sh)) : lo;
+  }
+  const uint32_t tail0 = lead + 4 * body;
+  if ((uint32_t)tid < n - tail0) dst[tail0 + tid] = srcb[tail0 + tid];
 }
 
 }  // namespace jxlt_dev

@@ -43,7 +43,7 @@ FrameView ViewOf(const jxlt_frame_result& res, const uint8_t* const* group_ptr, 
 // Appends the frame to `writer` (if non-null); otherwise asks `placer(frame_bytes)` for the
 // destination and writes the frame there (the AC blob comes straight from the device).
 bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jxl::BitWriter* writer,
-                          const std::function<uint8_t*(size_t)>* placer) {
+                          const std::function<uint8_t*(size_t)>* placer, ContextOutput* in_context) {
   static const bool trace = getenv("JXLT_TRACE") != nullptr;
   auto now = []() { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
@@ -74,7 +74,16 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
     jxl::BitWriter local;
     jxl::BitWriter* w = writer ? writer : &local;
     if (!AssembleFrame(ViewOf(res, &ptr, &len), distp, w, num_threads)) return false;
-    if (!writer) {
+    if (in_context) {
+      const std::vector<uint8_t>& b = local.Bytes();
+      const size_t pre = in_context->prefix ? in_context->prefix->size() : 0;
+      uint8_t* buf = nullptr;
+      if (jxlt_output_buffer(ctx, pre + b.size(), &buf) != JXLT_OK) return false;
+      if (pre) memcpy(buf, in_context->prefix->data(), pre);
+      memcpy(buf + pre, b.data(), b.size());
+      in_context->data = buf;
+      in_context->size = pre + b.size();
+    } else if (!writer) {
       const std::vector<uint8_t>& b = local.Bytes();
       uint8_t* dst = (*placer)(b.size());
       if (!dst) return false;
@@ -96,6 +105,45 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   BuildDcCode(dc_hist, &dc_code);
   FillCodeTable(dc_code, dc_table.data());
   const auto t2 = now();
+  if (in_context) {
+    // Copy-free output: one pass measures every section (all the TOC needs), then the device
+    // writes the sections to their final places in the context's page-locked output buffer
+    // while the host builds header and TOC.  The buffer position of the sections is fixed
+    // before the head exists: the head is bounded from above and right-aligned in front.
+    jxlt_packed_sections dcm, acm;
+    if (jxlt_pack_measure(ctx, dc_table.data(), ac_table.data(), &dcm, &acm) != JXLT_OK) {
+      fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
+      return false;
+    }
+    const auto t3 = now();
+    const PackedSections dc = {nullptr, dcm.section_offset, dcm.section_bits, dcm.num_sections};
+    const PackedSections ac = {nullptr, acm.section_offset, acm.section_bits, acm.num_sections};
+    FrameGlobals globals;
+    BuildFrameGlobals(xsize, ysize, distp, dc_code, ac_code, &globals);
+    const size_t pre = in_context->prefix ? in_context->prefix->size() : 0;
+    const size_t dc_bytes = static_cast<size_t>(dc.offset[dc.n]), ac_bytes = static_cast<size_t>(ac.offset[ac.n]);
+    const size_t dc_at = (pre + HeadSizeBound(xsize, ysize, globals) + 255) & ~static_cast<size_t>(255);
+    const size_t ac_at = dc_at + dc_bytes + globals.ac_global.size();
+    uint8_t* buf = nullptr;
+    if (jxlt_output_buffer(ctx, ac_at + ac_bytes + 16, &buf) != JXLT_OK ||
+        jxlt_pack_write(ctx, buf + dc_at, buf + ac_at) != JXLT_OK) {
+      fprintf(stderr, "jxl_tiny_amd: section placement failed: %s\n", jxlt_last_error(ctx));
+      return false;
+    }
+    std::vector<uint8_t> head;
+    if (!BuildFrameHead(xsize, ysize, distp, globals, dc, ac, &head)) return false;
+    uint8_t* dst = buf + dc_at - (pre + head.size());
+    in_context->data = dst;
+    in_context->size = pre + head.size() + dc_bytes + globals.ac_global.size() + ac_bytes;
+    if (pre) memcpy(dst, in_context->prefix->data(), pre);
+    memcpy(dst + pre, head.data(), head.size());
+    memcpy(buf + dc_at + dc_bytes, globals.ac_global.data(), globals.ac_global.size());
+    const bool ok = jxlt_synchronize(ctx) == JXLT_OK;
+    if (trace)
+      fprintf(stderr, "jxlt trace: device+histograms %.2f ms | codes %.2f | measure %.2f | head + place %.2f\n",
+              ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
+    return ok;
+  }
   // DC sections are small: fetched into the context's pinned buffer.  For the AC sections
   // only the sizes are needed to write the TOC; the blob is copied once, to its final place.
   jxlt_packed_sections dcp, acp;

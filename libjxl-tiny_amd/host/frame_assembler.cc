@@ -425,29 +425,52 @@ void BuildDcCode(const uint32_t* histograms, EntropyCode* dc_code) {
   OptimizeEntropyCode(&h, dc_identity, kNumDCContexts, dc_code);
 }
 
-bool FinishFrame(size_t xsize, size_t ysize, const DistanceParams& distp, const EntropyCode& dc_code,
-                 const PackedSections& dc, const EntropyCode& ac_code, const PackedSections& ac,
-                 FramePieces* out) {
+void BuildFrameGlobals(size_t xsize, size_t ysize, const DistanceParams& distp, const EntropyCode& dc_code,
+                       const EntropyCode& ac_code, FrameGlobals* out) {
   const size_t num_groups = DivCeil(xsize, 256) * DivCeil(ysize, 256);
   const size_t num_dc_groups = DivCeil(xsize, 2048) * DivCeil(ysize, 2048);
-  if (ac.n != num_groups || dc.n != num_dc_groups || 2 + num_dc_groups + num_groups == 4) return false;
-  jxl::BitWriter dc_global, ac_global, head;
+  jxl::BitWriter dc_global, ac_global;
   WriteDCGlobal(distp, num_dc_groups, dc_code, &dc_global);
   WriteACGlobal(num_groups, ac_code, &ac_global);
   dc_global.ZeroPadToByte();
   ac_global.ZeroPadToByte();
+  out->dc_global = dc_global.TakeBytes();
+  out->ac_global = ac_global.TakeBytes();
+}
+
+size_t HeadSizeBound(size_t xsize, size_t ysize, const FrameGlobals& globals) {
+  const size_t num_groups = DivCeil(xsize, 256) * DivCeil(ysize, 256);
+  const size_t num_dc_groups = DivCeil(xsize, 2048) * DivCeil(ysize, 2048);
+  // frame header (a few bytes) + permutation flag + <= 32 bits per TOC entry + DCGlobal
+  return 64 + 4 * (2 + num_dc_groups + num_groups) + globals.dc_global.size();
+}
+
+bool BuildFrameHead(size_t xsize, size_t ysize, const DistanceParams& distp, const FrameGlobals& globals,
+                    const PackedSections& dc, const PackedSections& ac, std::vector<uint8_t>* head_out) {
+  const size_t num_groups = DivCeil(xsize, 256) * DivCeil(ysize, 256);
+  const size_t num_dc_groups = DivCeil(xsize, 2048) * DivCeil(ysize, 2048);
+  if (ac.n != num_groups || dc.n != num_dc_groups || 2 + num_dc_groups + num_groups == 4) return false;
   std::vector<size_t> sizes;
   sizes.reserve(2 + num_dc_groups + num_groups);
-  sizes.push_back(dc_global.BitsWritten() / 8);
+  sizes.push_back(globals.dc_global.size());
   for (size_t g = 0; g < num_dc_groups; ++g) sizes.push_back(static_cast<size_t>(dc.offset[g + 1] - dc.offset[g]));
-  sizes.push_back(ac_global.BitsWritten() / 8);
+  sizes.push_back(globals.ac_global.size());
   for (size_t g = 0; g < num_groups; ++g) sizes.push_back(static_cast<size_t>(ac.offset[g + 1] - ac.offset[g]));
+  jxl::BitWriter head;
   WriteFrameHeader(distp.x_qm_scale, distp.epf_iters, &head);
   if (!WriteTOCSizes(sizes, &head)) return false;
-  const std::vector<uint8_t>& dg = dc_global.Bytes();
-  head.AppendBytes(dg.data(), dg.size());
-  out->head = head.TakeBytes();
-  out->ac_global = ac_global.TakeBytes();
+  head.AppendBytes(globals.dc_global.data(), globals.dc_global.size());
+  *head_out = head.TakeBytes();
+  return true;
+}
+
+bool FinishFrame(size_t xsize, size_t ysize, const DistanceParams& distp, const EntropyCode& dc_code,
+                 const PackedSections& dc, const EntropyCode& ac_code, const PackedSections& ac,
+                 FramePieces* out) {
+  FrameGlobals globals;
+  BuildFrameGlobals(xsize, ysize, distp, dc_code, ac_code, &globals);
+  if (!BuildFrameHead(xsize, ysize, distp, globals, dc, ac, &out->head)) return false;
+  out->ac_global = std::move(globals.ac_global);
   return true;
 }
 

@@ -73,6 +73,17 @@ struct FramePieces {
 bool FinishFrame(size_t xsize, size_t ysize, const DistanceParams& distp, const EntropyCode& dc_code,
                  const PackedSections& dc, const EntropyCode& ac_code, const PackedSections& ac,
                  FramePieces* out);
+// The same in two steps, for callers that place the AC blob before its section sizes reach
+// the host: the two global sections depend on the codes only; the head (frame header + TOC +
+// DCGlobal) needs every section size.  HeadSizeBound() bounds head.size() from above.
+struct FrameGlobals {
+  std::vector<uint8_t> dc_global, ac_global;
+};
+void BuildFrameGlobals(size_t xsize, size_t ysize, const DistanceParams& distp, const EntropyCode& dc_code,
+                       const EntropyCode& ac_code, FrameGlobals* out);
+size_t HeadSizeBound(size_t xsize, size_t ysize, const FrameGlobals& globals);
+bool BuildFrameHead(size_t xsize, size_t ysize, const DistanceParams& distp, const FrameGlobals& globals,
+                    const PackedSections& dc, const PackedSections& ac, std::vector<uint8_t>* head);
 
 // Raw 3-byte records of DC group `index` as the host tokeniser produces them (tests).
 std::vector<uint8_t> DcGroupRecords(const FrameView& frame, size_t index);

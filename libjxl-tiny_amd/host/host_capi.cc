@@ -150,14 +150,19 @@ int jxlt_encode_resident(jxlt_context* ctx, float distance, int num_threads, uin
 int jxlt_encode_resident_view(jxlt_context* ctx, float distance, int num_threads, const uint8_t** bytes,
                               size_t* size) {
   if (!ctx || !bytes || !size) return JXLT_ERR_INVALID_ARGUMENT;
-  uint8_t* buf = nullptr;
-  // The codestream lives after a 64 MiB-independent offset of the context's pinned output
-  // buffer; the same buffer is also used as AC staging by the BitWriter path, never both.
-  const int rc = EncodeResident(ctx, distance, num_threads, [&](size_t n) -> uint8_t* {
-    return jxlt_output_buffer(ctx, n, &buf) == JXLT_OK ? buf : nullptr;
-  }, size);
-  if (rc != JXLT_OK) return rc;
-  *bytes = buf;
+  if (!jxlt::NormalizeDistance(&distance)) return JXLT_ERR_INVALID_ARGUMENT;
+  size_t xsize = 0, ysize = 0;
+  if (jxlt_image_size(ctx, &xsize, &ysize) != JXLT_OK) return JXLT_ERR_INVALID_ARGUMENT;
+  jxl::BitWriter writer;
+  if (!jxlt::WriteFileHeader(xsize, ysize, &writer)) return JXLT_ERR_INVALID_ARGUMENT;
+  const std::vector<uint8_t> file_header = writer.TakeBytes();
+  // The codestream is assembled in the context's page-locked output buffer; the device
+  // writes the AC sections there itself (jxlt_pack_sections_place).
+  jxlt::ContextOutput out;
+  out.prefix = &file_header;
+  if (!jxlt::EncodeFrameOnContext(ctx, distance, num_threads, nullptr, nullptr, &out)) return JXLT_ERR_INTERNAL;
+  *bytes = out.data;
+  *size = out.size;
   return JXLT_OK;
 }
 

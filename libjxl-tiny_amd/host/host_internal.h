@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <functional>
+#include <vector>
 
 #include "encoder/enc_bit_writer.h"
 
@@ -14,8 +15,16 @@ struct jxlt_context;
 namespace jxlt {
 // Device context of the calling thread for the device chosen by jxl::SetEncoderDevice (or null).
 jxlt_context* AcquireThreadContext();
+// Where EncodeFrameOnContext leaves the frame: appended to `writer`; or written to the address
+// `placer(frame_bytes)` returns; or (in_context) assembled, behind the bytes of `prefix`, in the
+// context's page-locked output buffer, where the device places the AC sections itself.
+struct ContextOutput {
+  const std::vector<uint8_t>* prefix = nullptr;  // e.g. the file header
+  const uint8_t* data = nullptr;                 // result: prefix + frame, valid until the next encode
+  size_t size = 0;
+};
 bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jxl::BitWriter* writer,
-                          const std::function<uint8_t*(size_t)>* placer);
+                          const std::function<uint8_t*(size_t)>* placer, ContextOutput* in_context = nullptr);
 bool WriteFileHeader(size_t xsize, size_t ysize, jxl::BitWriter* writer);
 bool NormalizeDistance(float* distance);
 }  // namespace jxlt

@@ -43,6 +43,12 @@ struct float2 {
 struct float4 {
   float x, y, z, w;
 } __attribute__((aligned(16)));
+struct uint2 {
+  uint32_t x, y;
+} __attribute__((aligned(8)));
+struct uint4 {
+  uint32_t x, y, z, w;
+} __attribute__((aligned(16)));
 
 namespace hipsim {
 
@@ -322,6 +328,11 @@ inline void __builtin_amdgcn_sched_barrier(int) {}  // compiler scheduling fence
 
 // v_rcp_f32 (1 ulp on hardware; the model returns the correctly rounded reciprocal)
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+
+// v_alignbyte_b32: ({hi, lo} >> (8 * (shift & 3))) & 0xffffffff
+inline uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, uint32_t shift) {
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (shift & 3)));
+}
 
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __clzll(long long x) { return x == 0 ? 64 : __builtin_clzll((unsigned long long)x); }

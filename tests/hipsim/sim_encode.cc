@@ -166,7 +166,7 @@ __attribute__((visibility("default"))) int sim_pack(const uint8_t* records, cons
   const uint64_t total = sec_rec_offset[nsec];
   std::vector<uint8_t> slots(4 * total + 16, 0xCD);  // poison: every output byte must be written
   std::vector<uint32_t> sec_bytes(nsec);
-  PackArgs P;
+  PackArgs P = {};
   P.records = records;
   P.sec_rec_offset = sec_rec_offset;
   P.code_table = code_table;
@@ -182,6 +182,54 @@ __attribute__((visibility("default"))) int sim_pack(const uint8_t* records, cons
   Cp.sec_byte_offset = out_offset;
   Cp.out = out_bytes;
   hipsim::launch(compact_kernel, dim3((unsigned)nsec), dim3(256), Cp);
+  return 0;
+}
+
+// The copy-free, tile-granular packing: count / scan / measure / offsets / scan, then
+// pack_tile_write_kernel in `nlaunch` tile ranges, storing every tile at its final bit position
+// behind `out_bytes + 4 * misalign_words` (the blob base must be dword aligned).  out_bytes
+// arrives poisoned by the caller, who checks that nothing outside the sections was touched.
+__attribute__((visibility("default"))) int sim_pack_direct(const uint8_t* records, const uint64_t* sec_rec_offset,
+                                                            int nsec, const uint32_t* code_table, uint8_t* out_bytes,
+                                                            int misalign_words, int nlaunch, uint64_t* out_offset,
+                                                            uint32_t* out_bits) {
+  const uint64_t total = sec_rec_offset[nsec];
+  const size_t max_tiles = total / kPackTile + nsec + 1;
+  std::vector<uint32_t> sec_bytes(nsec), sec_tiles(nsec), tile_bits(max_tiles, 0xDEADu);
+  std::vector<PackTileInfo> tile_info(max_tiles);
+  std::vector<uint64_t> tile_base(nsec + 1);
+  PackTileArgs P = {};
+  P.records = records;
+  P.sec_rec_offset = sec_rec_offset;
+  P.nsec = nsec;
+  P.code_table = code_table;
+  P.sec_tiles = sec_tiles.data();
+  P.tile_base = tile_base.data();
+  P.tile_bits = tile_bits.data();
+  P.tile_info = tile_info.data();
+  P.sec_bits = out_bits;
+  P.sec_bytes = sec_bytes.data();
+  P.sec_byte_offset = out_offset;
+  P.out = out_bytes + 4 * misalign_words;
+  P.tile_end = 0xFFFFFFFFu;
+  const unsigned sec_blocks = (unsigned)((nsec + 255) / 256);
+  hipsim::launch(pack_tile_count_kernel, dim3(sec_blocks), dim3(256), P);
+  hipsim::launch(group_scan_kernel, dim3(1), dim3(256), (const uint32_t*)sec_tiles.data(), tile_base.data(), nsec);
+  hipsim::launch(pack_tile_plan_kernel, dim3(sec_blocks), dim3(256), P);
+  hipsim::launch(pack_tile_measure_kernel, dim3((unsigned)((max_tiles + kPackTilesPerGroup - 1) / kPackTilesPerGroup)),
+                 dim3(kPackThreads), P);
+  hipsim::launch(pack_tile_offsets_kernel, dim3(sec_blocks), dim3(256), P);
+  hipsim::launch(group_scan_kernel, dim3(1), dim3(256), (const uint32_t*)sec_bytes.data(), out_offset, nsec);
+  hipsim::launch(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), P);
+  const uint64_t ntiles = tile_base[nsec];
+  for (int c = 0; c < nlaunch; c++) {
+    const uint64_t t0 = ntiles * c / nlaunch, t1 = ntiles * (c + 1) / nlaunch;
+    if (t1 == t0) continue;
+    P.tile_first = (uint32_t)t0;
+    P.tile_end = (uint32_t)t1;
+    hipsim::launch(pack_tile_write_kernel, dim3((unsigned)((t1 - t0 + kPackTilesPerGroup - 1) / kPackTilesPerGroup)),
+                   dim3(kPackThreads), P);
+  }
   return 0;
 }
 

@@ -188,6 +188,8 @@ def _sim_lib():
                                     C.POINTER(SimResult)]
         _sim.sim_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p]
+        _sim.sim_pack_direct.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_int, C.c_void_p, C.c_void_p]
     return _sim
 
 
@@ -244,6 +246,26 @@ def sim_pack_sections(sections, table):
     L.sim_pack(blob.ctypes.data, offs.ctypes.data, len(sections), table.ctypes.data, out.ctypes.data,
                out_off.ctypes.data, out_bits.ctypes.data)
     return [(out[int(out_off[i]):int(out_off[i + 1])].tobytes(), int(out_bits[i])) for i in range(len(sections))]
+
+
+def sim_pack_sections_direct(sections, table, misalign=0, nlaunch=1):
+    """Tile-granular measure + write kernels on the CPU execution model (blob base = out + 4 *
+    misalign words); also checks that no byte outside the sections' final places was written."""
+    L = _sim_lib()
+    blob = np.frombuffer(b"".join(sections) + b"\0\0\0\0", np.uint8).copy()
+    offs = np.zeros(len(sections) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(x) // 3 for x in sections])
+    table = np.ascontiguousarray(table, np.uint32)
+    out = np.full(4 * int(offs[-1]) + 64, 0xCD, np.uint8)
+    out_off = np.zeros(len(sections) + 1, np.uint64)
+    out_bits = np.zeros(len(sections), np.uint32)
+    L.sim_pack_direct(blob.ctypes.data, offs.ctypes.data, len(sections), table.ctypes.data, out.ctypes.data,
+                      misalign, nlaunch, out_off.ctypes.data, out_bits.ctypes.data)
+    total = int(out_off[-1])
+    base = 4 * misalign
+    assert (out[:base] == 0xCD).all() and (out[base + total:] == 0xCD).all(), "stray stores"
+    body = out[base:base + total]
+    return [(body[int(out_off[i]):int(out_off[i + 1])].tobytes(), int(out_bits[i])) for i in range(len(sections))]
 
 
 def sim_hot_path(planes, distance, force_dct8=False):

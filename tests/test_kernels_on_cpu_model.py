@@ -46,7 +46,7 @@ def _random_code_table(rng):
     return ((depth << 16) | bits).astype("uint32")
 
 
-@pytest.mark.parametrize("sizes", [[0], [1], [5, 0, 17], [4095, 4096, 4097], [9000, 3], [300] * 7])
+@pytest.mark.parametrize("sizes", [[0], [1], [5, 0, 17], [4095, 4096, 4097], [9000, 3], [300] * 7, [0, 13000, 0, 2, 8200]])
 def test_pack_kernel_matches_reference_packer(built, sizes):
     import numpy as np
     rng = np.random.default_rng(sum(sizes) + len(sizes))
@@ -62,7 +62,34 @@ def test_pack_kernel_matches_reference_packer(built, sizes):
         val = np.where(esc, val & ((1 << nb) - 1), val).astype(np.uint16)
         rec = np.stack([ctx, (val & 0xFF).astype(np.uint8), (val >> 8).astype(np.uint8)], axis=1)
         sections.append(rec.astype(np.uint8).tobytes())
-    assert T.sim_pack_sections(sections, table) == T.pack_sections_python(sections, table)
+    want = T.pack_sections_python(sections, table)
+    assert T.sim_pack_sections(sections, table) == want
+    # copy-free pair (measure, then store at the final byte offsets), every destination alignment
+    for words in range(2):
+        assert T.sim_pack_sections_direct(sections, table, words, nlaunch=1 + words) == want
+
+
+def test_pack_tiles_with_short_codes(built):
+    """Tile boundaries inside a dword: the later tile re-derives its predecessors' trailing bits.
+    One-bit codes and zero-length escapes make many records share one dword, also across more
+    than one 64-record look-back round and across a whole tile."""
+    import numpy as np
+    rng = np.random.default_rng(7)
+    depth = np.ones(64 * 64, np.int64)
+    bits = rng.integers(0, 2, size=64 * 64)
+    table = ((depth << 16) | bits).astype("uint32")
+    sections = []
+    for n, p_zero in [(3 * 4096 + 77, 0.0), (2 * 4096 + 5, 0.97), (4096 + 1, 1.0), (4096, 0.5)]:
+        ctx = rng.integers(0, 64, size=n).astype(np.uint8)
+        val = rng.integers(0, 16, size=n).astype(np.uint16)  # no extra bits: 1 bit per coded record
+        zero = rng.random(n) < p_zero                          # escape with 0 raw bits
+        ctx = np.where(zero, 128, ctx).astype(np.uint8)
+        val = np.where(zero, 0, val).astype(np.uint16)
+        rec = np.stack([ctx, (val & 0xFF).astype(np.uint8), (val >> 8).astype(np.uint8)], axis=1)
+        sections.append(rec.astype(np.uint8).tobytes())
+    want = T.pack_sections_python(sections, table)
+    assert T.sim_pack_sections(sections, table) == want
+    assert T.sim_pack_sections_direct(sections, table, 0, nlaunch=3) == want
 
 
 @pytest.mark.parametrize("w,h,distance", [(200, 137, 1.0), (9, 7, 1.0), (300, 264, 2.0), (2100, 40, 1.0), (64, 64, 8.0)])
