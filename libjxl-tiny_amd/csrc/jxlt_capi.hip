@@ -111,7 +111,7 @@ struct jxlt_context {
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   // jxlt_pack_write: packing on `stream`, chunked copies to the destination on `copy_stream`
   hipStream_t copy_stream = nullptr;
-  static constexpr int kWriteChunks = 6;
+  static constexpr int kWriteChunks = 4;
   hipEvent_t chunk_packed[kWriteChunks + 1] = {};
   bool copies_pending = false;
   bool profiled = false;

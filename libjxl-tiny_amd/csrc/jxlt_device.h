@@ -1961,14 +1961,10 @@ struct PackThreadRecords {
   uint32_t w[kPackPerThread * 3 / 4 + 1];
 };
 JXLT_DI void pack_load_thread_records(const uint32_t* stage_tile, int tid, PackThreadRecords* out) {
-  static_assert(kPackPerThread * 3 % 8 == 0, "whole 8-byte reads per thread");
-  const uint2* p = reinterpret_cast<const uint2*>(stage_tile + tid * (kPackPerThread * 3 / 4));
+  static_assert(kPackPerThread * 3 % 4 == 0, "whole dwords per thread");
+  const uint32_t* p = stage_tile + tid * (kPackPerThread * 3 / 4);
 #pragma unroll
-  for (int q = 0; q < kPackPerThread * 3 / 8; q++) {
-    const uint2 v = p[q];
-    out->w[2 * q + 0] = v.x;
-    out->w[2 * q + 1] = v.y;
-  }
+  for (int q = 0; q < kPackPerThread * 3 / 4; q++) out->w[q] = p[q];
   out->w[kPackPerThread * 3 / 4] = 0;
 }
 JXLT_DI uint32_t pack_thread_record(const PackThreadRecords& r, int j) {  // ctx | value << 8
@@ -1990,7 +1986,7 @@ JXLT_DI void pack_bits_of(uint32_t rec24, const uint32_t* table, uint32_t* nb, u
   }
 }
 
-constexpr int kPackTilesPerGroup = 4;  // consecutive tiles per workgroup (amortises the table load)
+constexpr int kPackTilesPerGroup = 2;  // consecutive tiles per workgroup (amortises the table load)
 
 __global__ void __launch_bounds__(kPackThreads) pack_tile_measure_kernel(const PackTileArgs A) {
   __shared__ uint8_t depth[64 * 64];

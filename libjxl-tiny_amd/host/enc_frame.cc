@@ -91,12 +91,17 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
     }
     return true;
   }
+  // The histograms arrive when the device pipeline is done; its duration is the previous
+  // frame's, to a good approximation (same context, usually same geometry).
+  static thread_local double expected_device_ms = 0.0;
+  if (expected_device_ms > 1.0) WarmCodeConstruction(expected_device_ms - 0.5, expected_device_ms + 1.5);
   const uint32_t *ac_hist = nullptr, *dc_hist = nullptr;
   if (jxlt_fetch_histograms(ctx, &ac_hist, &dc_hist) != JXLT_OK) {
     fprintf(stderr, "jxl_tiny_amd: fetch failed: %s\n", jxlt_last_error(ctx));
     return false;
   }
   const auto t1 = now();
+  expected_device_ms = ms(t0, t1);
   EntropyCode ac_code, dc_code;
   std::vector<uint32_t> ac_table(64 * 64), dc_table(64 * 64);
   // (each construction spreads its cost evaluations over the helper pool of entropy_coder.cc)

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <limits>
@@ -164,11 +165,28 @@ class ClusterPool {
     {
       std::lock_guard<std::mutex> g(mu_);
       open_ = true;
+      warm_ = false;
     }
+    open_flag_.store(true, std::memory_order_release);
     cv_.notify_all();
     return true;
   }
+  // Announces a session for about `start`: the helpers wake up then and spin until a session
+  // opens or `deadline` passes, so that the session does not start with sleeping helpers
+  // (a futex wake-up costs as much as half of a clustering).
+  void Warm(std::chrono::steady_clock::time_point start, std::chrono::steady_clock::time_point deadline) {
+    if (workers_.empty()) return;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      if (open_) return;
+      warm_ = true;
+      warm_start_ = start;
+      warm_deadline_ = deadline;
+    }
+    cv_.notify_all();
+  }
   void Close() {
+    open_flag_.store(false, std::memory_order_release);
     {
       std::lock_guard<std::mutex> g(mu_);
       open_ = false;
@@ -232,8 +250,23 @@ class ClusterPool {
     for (;;) {
       {
         std::unique_lock<std::mutex> g(mu_);
-        cv_.wait(g, [this] { return open_ || quit_; });
+        cv_.wait(g, [this] { return open_ || quit_ || warm_; });
         if (quit_) return;
+        if (!open_) {
+          // announced session: sleep until its expected start, then spin (unlocked) for it
+          const auto start = warm_start_, deadline = warm_deadline_;
+          if (cv_.wait_until(g, start, [this] { return open_ || quit_; })) {
+            if (quit_) return;
+          } else {
+            g.unlock();
+            while (!open_flag_.load(std::memory_order_acquire) && std::chrono::steady_clock::now() < deadline) Pause();
+            g.lock();
+          }
+          if (!open_) {
+            if (std::chrono::steady_clock::now() >= warm_deadline_) warm_ = false;
+            continue;
+          }
+        }
         spinning_.fetch_add(1, std::memory_order_relaxed);
       }
       Job* last = nullptr;
@@ -252,7 +285,9 @@ class ClusterPool {
   std::vector<std::thread> workers_;
   std::mutex session_mu_, mu_;
   std::condition_variable cv_;
-  bool open_ = false, quit_ = false;
+  bool open_ = false, quit_ = false, warm_ = false;
+  std::chrono::steady_clock::time_point warm_start_, warm_deadline_;
+  std::atomic<bool> open_flag_{false};
   std::atomic<bool> closed_{true};
   std::atomic<int> spinning_{0};
   std::atomic<Job*> cur_{nullptr};
@@ -261,6 +296,12 @@ class ClusterPool {
 };
 
 }  // namespace
+
+void WarmCodeConstruction(double start_in_ms, double give_up_in_ms) {
+  const auto now = std::chrono::steady_clock::now();
+  ClusterPool::Get().Warm(now + std::chrono::microseconds(static_cast<long long>(start_in_ms * 1e3)),
+                          now + std::chrono::microseconds(static_cast<long long>(give_up_in_ms * 1e3)));
+}
 
 void ClusterHistograms(std::vector<Histogram>* histograms, std::vector<uint8_t>* context_map) {
   if (histograms->size() <= 1) return;  // enc_cluster.cc:121

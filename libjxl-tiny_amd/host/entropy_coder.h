@@ -83,6 +83,12 @@ inline void WriteToken(uint32_t cluster_ctx, uint32_t value, const EntropyCode& 
 }
 
 void CreateHuffmanTree(const uint32_t* counts, size_t length, int tree_limit, uint8_t* depth);
+
+// Code construction spreads its cost evaluations over a few helper threads that sleep between
+// frames.  A caller that knows when the histograms will arrive (e.g. from the duration of the
+// previous frame's device pipeline) can announce it: the helpers wake up `start_in_ms` from now
+// and spin for the session until `give_up_in_ms` from now.  Purely a latency hint.
+void WarmCodeConstruction(double start_in_ms, double give_up_in_ms);
 void ConvertBitDepthsToSymbols(const uint8_t* depth, size_t len, uint16_t* bits);
 
 // Clusters `histograms` (in place, result = cluster histograms) and returns the
