@@ -78,20 +78,14 @@ struct jxlt_context {
   size_t dc_rec_off_n = 0;
   // section packing, [0] = DC groups, [1] = AC groups
   struct PackSet {
-    DeviceBuf<uint32_t> code_table, sec_bits, sec_bytes;
-    DeviceBuf<uint64_t> sec_byte_off;
-    DeviceBuf<uint8_t> slots, packed;
-    PinnedBuf<uint64_t> h_sec_byte_off;
+    DeviceBuf<uint32_t> code_table, sec_bits, sec_bytes, sec_tiles, tile_bits;
+    DeviceBuf<uint64_t> sec_byte_off, tile_base;
+    DeviceBuf<PackTileInfo> tile_info;
+    DeviceBuf<uint8_t> packed;  // the sections at their final byte offsets
+    PinnedBuf<uint64_t> h_sec_byte_off, h_tile_base;
     PinnedBuf<uint32_t> h_sec_bits;
     PinnedBuf<uint8_t> h_packed;
-    size_t packed_sections = 0;
-    bool compacted = false;  // `packed` holds the sections of the last jxlt_pack_sections_sizes
-    size_t measured_sections = 0;  // jxlt_pack_measure done for this many sections
-    DeviceBuf<uint32_t> sec_tiles, tile_bits;
-    DeviceBuf<PackTileInfo> tile_info;
-    DeviceBuf<uint64_t> tile_base;
-    PinnedBuf<uint64_t> h_tile_base;
-    size_t max_tiles = 0;
+    size_t measured_sections = 0;  // sections of the last measuring pass (0: none for this frame)
   } pack[2];
   PinnedBuf<uint8_t> h_output;  // jxlt_output_buffer
 
@@ -256,8 +250,12 @@ void jxlt_context_destroy(jxlt_context* ctx) {
     FreeDevice(&ps.sec_bits);
     FreeDevice(&ps.sec_bytes);
     FreeDevice(&ps.sec_byte_off);
-    FreeDevice(&ps.slots);
+    FreeDevice(&ps.sec_tiles);
+    FreeDevice(&ps.tile_bits);
+    FreeDevice(&ps.tile_base);
+    FreeDevice(&ps.tile_info);
     FreeDevice(&ps.packed);
+    FreePinned(&ps.h_tile_base);
     FreePinned(&ps.h_sec_byte_off);
     FreePinned(&ps.h_sec_bits);
     FreePinned(&ps.h_packed);
@@ -532,7 +530,6 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   ctx->geom = g;
   ctx->encoded = true;
   ctx->offsets_fetched = false;
-  ctx->pack[0].packed_sections = ctx->pack[1].packed_sections = 0;
   ctx->pack[0].measured_sections = ctx->pack[1].measured_sections = 0;
   ctx->last_flags = params->flags;
   ctx->profiled = profile;
@@ -662,124 +659,6 @@ int jxlt_fetch_histograms(jxlt_context* ctx, const uint32_t** ac_histograms, con
   return JXLT_OK;
 }
 
-int jxlt_pack_sections_sizes(jxlt_context* ctx, int kind, const uint32_t* code_table, jxlt_packed_sections* out) {
-  if (!ctx || !code_table || !out || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
-  if (!ctx->encoded || !ctx->offsets_fetched) {
-    ctx->error = "jxlt_pack_sections needs jxlt_encode_enqueue + jxlt_fetch_histograms/side_info first";
-    return JXLT_ERR_INVALID_ARGUMENT;
-  }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const FrameGeom& g = ctx->geom;
-  const size_t ngroups = (size_t)g.xsize_groups * g.ysize_groups;
-  const size_t ndc = ((ctx->xsize + 2047) / 2048) * ((ctx->ysize + 2047) / 2048);
-  const size_t nsec = kind == 1 ? ngroups : ndc;
-  // upper bound of the record index space the slots must cover
-  const uint64_t rec_space = kind == 1 ? ctx->h_group_off.p[ngroups] : ctx->dc_records.cap / 3;
-  jxlt_context::PackSet& ps = ctx->pack[kind];
-  int rc;
-#define ENSURE(buf, n) if ((rc = EnsureDevice(ctx, &ps.buf, (n))) != JXLT_OK) return rc
-  ENSURE(code_table, 64 * 64);
-  ENSURE(sec_bits, nsec);
-  ENSURE(sec_bytes, nsec);
-  ENSURE(sec_byte_off, nsec + 1);
-  if (ps.slots.cap < 4 * rec_space + 16) ENSURE(slots, 4 * rec_space + rec_space / 2 + 4096);
-  if (ps.packed.cap < 4 * rec_space + 16) ENSURE(packed, 4 * rec_space + rec_space / 2 + 4096);
-#undef ENSURE
-  HIP_TRY(ctx, hipMemcpyAsync(ps.code_table.p, code_table, 64 * 64 * sizeof(uint32_t), hipMemcpyHostToDevice,
-                              ctx->stream));
-  PackArgs P;
-  P.records = kind == 1 ? ctx->tokens.p : ctx->dc_records.p;
-  P.sec_rec_offset = kind == 1 ? ctx->group_off.p : ctx->dc_rec_off.p;
-  P.sec_rec_count = kind == 1 ? nullptr : ctx->dc_count.p;
-  P.code_table = ps.code_table.p;
-  P.slots = ps.slots.p;
-  P.sec_bits = ps.sec_bits.p;
-  P.sec_bytes = ps.sec_bytes.p;
-  P.out = nullptr;
-  P.sec_base = 0;
-  P.sec_byte_offset = nullptr;
-  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)nsec), dim3(kPackThreads), 0, ctx->stream, P);
-  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t*)ps.sec_bytes.p,
-                     ps.sec_byte_off.p, (int)nsec);
-  HIP_TRY(ctx, hipGetLastError());
-  ps.compacted = false;
-  if ((rc = EnsurePinned(ctx, &ps.h_sec_byte_off, nsec + 1)) != JXLT_OK) return rc;
-  if ((rc = EnsurePinned(ctx, &ps.h_sec_bits, nsec)) != JXLT_OK) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(ps.h_sec_byte_off.p, ps.sec_byte_off.p, (nsec + 1) * sizeof(uint64_t),
-                              hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(ps.h_sec_bits.p, ps.sec_bits.p, nsec * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                              ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  out->bytes = nullptr;
-  out->section_offset = ps.h_sec_byte_off.p;
-  out->section_bits = ps.h_sec_bits.p;
-  out->num_sections = nsec;
-  ps.packed_sections = nsec;
-  return JXLT_OK;
-}
-
-namespace {
-// Sections of `kind` from their slots to `out` (device memory, or device-visible host memory)
-// at their byte offsets; asynchronous.
-int LaunchCompact(jxlt_context* ctx, int kind, uint8_t* out) {
-  jxlt_context::PackSet& ps = ctx->pack[kind];
-  CompactArgs Cp;
-  Cp.slots = ps.slots.p;
-  Cp.sec_rec_offset = kind == 1 ? ctx->group_off.p : ctx->dc_rec_off.p;
-  Cp.sec_bytes = ps.sec_bytes.p;
-  Cp.sec_byte_offset = ps.sec_byte_off.p;
-  Cp.out = out;
-  hipLaunchKernelGGL(compact_kernel, dim3((unsigned)ps.packed_sections), dim3(256), 0, ctx->stream, Cp);
-  HIP_TRY(ctx, hipGetLastError());
-  return JXLT_OK;
-}
-}  // namespace
-
-int jxlt_pack_sections_place(jxlt_context* ctx, int kind, uint8_t* dst) {
-  if (!ctx || !dst || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
-  jxlt_context::PackSet& ps = ctx->pack[kind];
-  if (ps.packed_sections == 0) {
-    ctx->error = "jxlt_pack_sections_place needs jxlt_pack_sections_sizes first";
-    return JXLT_ERR_INVALID_ARGUMENT;
-  }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  return LaunchCompact(ctx, kind, dst);
-}
-
-int jxlt_pack_sections_copy(jxlt_context* ctx, int kind, uint8_t* dst) {
-  if (!ctx || !dst || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
-  jxlt_context::PackSet& ps = ctx->pack[kind];
-  if (ps.packed_sections == 0) {
-    ctx->error = "jxlt_pack_sections_copy needs jxlt_pack_sections_sizes first";
-    return JXLT_ERR_INVALID_ARGUMENT;
-  }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const uint64_t total_bytes = ps.h_sec_byte_off.p[ps.packed_sections];
-  if (!ps.compacted) {
-    const int rc = LaunchCompact(ctx, kind, ps.packed.p);
-    if (rc != JXLT_OK) return rc;
-    ps.compacted = true;
-  }
-  if (total_bytes) {
-    HIP_TRY(ctx, hipMemcpyAsync(dst, ps.packed.p, total_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  }
-  return JXLT_OK;
-}
-
-int jxlt_pack_sections(jxlt_context* ctx, int kind, const uint32_t* code_table, jxlt_packed_sections* out) {
-  int rc = jxlt_pack_sections_sizes(ctx, kind, code_table, out);
-  if (rc != JXLT_OK) return rc;
-  jxlt_context::PackSet& ps = ctx->pack[kind];
-  const uint64_t total_bytes = ps.h_sec_byte_off.p[ps.packed_sections];
-  if (ps.h_packed.cap < total_bytes + 1 &&
-      (rc = EnsurePinned(ctx, &ps.h_packed, total_bytes + total_bytes / 4 + 4096)) != JXLT_OK)
-    return rc;
-  if ((rc = jxlt_pack_sections_copy(ctx, kind, ps.h_packed.p)) != JXLT_OK) return rc;
-  out->bytes = ps.h_packed.p;
-  return JXLT_OK;
-}
-
 namespace {
 // Common argument block of the tile-granular packing kernels for sections of `kind`.
 PackTileArgs TileArgsOf(jxlt_context* ctx, int kind, size_t nsec) {
@@ -802,75 +681,164 @@ PackTileArgs TileArgsOf(jxlt_context* ctx, int kind, size_t nsec) {
   P.tile_end = 0xFFFFFFFFu;
   return P;
 }
+
+size_t NumSections(const jxlt_context* ctx, int kind) {
+  return kind == 1 ? (size_t)ctx->geom.xsize_groups * ctx->geom.ysize_groups
+                   : ((ctx->xsize + 2047) / 2048) * ((ctx->ysize + 2047) / 2048);
+}
+
+// Measuring pass for the sections of `kind` (asynchronous): exact bit / byte size of every
+// section, byte offsets, tile bookkeeping; results are copied to the pinned mirrors.
+int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
+  jxlt_context::PackSet& ps = ctx->pack[kind];
+  const size_t nsec = NumSections(ctx, kind);
+  // upper bound of the record count (the exact per-section counts live on the device)
+  const uint64_t rec_bound = kind == 1 ? ctx->h_group_off.p[nsec] : ctx->dc_records.cap / 3;
+  const size_t max_tiles = (size_t)(rec_bound / kPackTile) + nsec + 1;
+  int rc;
+#define ENSURE(buf, n) if ((rc = EnsureDevice(ctx, &ps.buf, (n))) != JXLT_OK) return rc
+  ENSURE(code_table, 64 * 64);
+  ENSURE(sec_bits, nsec);
+  ENSURE(sec_bytes, nsec);
+  ENSURE(sec_byte_off, nsec + 1);
+  ENSURE(sec_tiles, nsec);
+  ENSURE(tile_base, nsec + 1);
+  ENSURE(tile_bits, max_tiles);
+  ENSURE(tile_info, max_tiles);
+#undef ENSURE
+  if ((rc = EnsurePinned(ctx, &ps.h_sec_byte_off, nsec + 1)) != JXLT_OK) return rc;
+  if ((rc = EnsurePinned(ctx, &ps.h_sec_bits, nsec)) != JXLT_OK) return rc;
+  if ((rc = EnsurePinned(ctx, &ps.h_tile_base, nsec + 1)) != JXLT_OK) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ps.code_table.p, code_table, 64 * 64 * sizeof(uint32_t), hipMemcpyHostToDevice,
+                              ctx->stream));
+  const PackTileArgs P = TileArgsOf(ctx, kind, nsec);
+  const unsigned sec_blocks = (unsigned)((nsec + 255) / 256);
+  hipLaunchKernelGGL(pack_tile_count_kernel, dim3(sec_blocks), dim3(256), 0, ctx->stream, P);
+  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t*)ps.sec_tiles.p,
+                     ps.tile_base.p, (int)nsec);
+  hipLaunchKernelGGL(pack_tile_plan_kernel, dim3(sec_blocks), dim3(256), 0, ctx->stream, P);
+  hipLaunchKernelGGL(pack_tile_measure_kernel, dim3((unsigned)((max_tiles + kPackTilesPerGroup - 1) / kPackTilesPerGroup)),
+                     dim3(kPackThreads), 0, ctx->stream, P);
+  hipLaunchKernelGGL(pack_tile_offsets_kernel, dim3(sec_blocks), dim3(256), 0, ctx->stream, P);
+  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t*)ps.sec_bytes.p,
+                     ps.sec_byte_off.p, (int)nsec);
+  hipLaunchKernelGGL(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), 0, ctx->stream, P);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(ps.h_sec_byte_off.p, ps.sec_byte_off.p, (nsec + 1) * sizeof(uint64_t),
+                              hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ps.h_sec_bits.p, ps.sec_bits.p, nsec * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                              ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ps.h_tile_base.p, ps.tile_base.p, (nsec + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                              ctx->stream));
+  ps.measured_sections = nsec;
+  return JXLT_OK;
+}
+
+void FillMeasured(jxlt_context* ctx, int kind, jxlt_packed_sections* out) {
+  jxlt_context::PackSet& ps = ctx->pack[kind];
+  out->bytes = nullptr;
+  out->section_offset = ps.h_sec_byte_off.p;
+  out->section_bits = ps.h_sec_bits.p;
+  out->num_sections = ps.measured_sections;
+}
+
+// Writing pass for the measured sections of `kind` (asynchronous): tiles are packed at their
+// final bit positions into the device blob, which leaves for `dst` in `nchunks` ranges of
+// whole sections on the copy stream while later ranges are still being packed.
+int EnqueueWrite(jxlt_context* ctx, int kind, uint8_t* dst, int nchunks, int* ev) {
+  jxlt_context::PackSet& ps = ctx->pack[kind];
+  const size_t nsec = ps.measured_sections;
+  const uint64_t* off = ps.h_sec_byte_off.p;
+  const uint64_t* tb = ps.h_tile_base.p;
+  const uint64_t total = off[nsec];
+  int rc;
+  if (ps.packed.cap < total + 16 && (rc = EnsureDevice(ctx, &ps.packed, total + total / 4 + 4096)) != JXLT_OK)
+    return rc;
+  nchunks = (int)std::min<size_t>((size_t)nchunks, nsec);
+  for (int c = 0; c < nchunks; c++) {
+    const size_t s0 = nsec * c / nchunks, s1 = nsec * (c + 1) / nchunks;
+    if (s1 == s0) continue;
+    if (tb[s1] > tb[s0]) {
+      PackTileArgs P = TileArgsOf(ctx, kind, nsec);
+      P.tile_first = (uint32_t)tb[s0];
+      P.tile_end = (uint32_t)tb[s1];
+      hipLaunchKernelGGL(pack_tile_write_kernel,
+                         dim3((unsigned)((tb[s1] - tb[s0] + kPackTilesPerGroup - 1) / kPackTilesPerGroup)),
+                         dim3(kPackThreads), 0, ctx->stream, P);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->chunk_packed[*ev], ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->chunk_packed[*ev], 0));
+    (*ev)++;
+    if (off[s1] > off[s0])
+      HIP_TRY(ctx, hipMemcpyAsync(dst + off[s0], ps.packed.p + off[s0], off[s1] - off[s0], hipMemcpyDefault,
+                                  ctx->copy_stream));
+  }
+  ctx->copies_pending = true;
+  return JXLT_OK;
+}
+
+int CheckPackCall(jxlt_context* ctx, const char* what) {
+  if (!ctx->encoded || !ctx->offsets_fetched) {
+    ctx->error = std::string(what) + " needs jxlt_encode_enqueue + jxlt_fetch_histograms/side_info first";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  return JXLT_OK;
+}
 }  // namespace
+
+int jxlt_pack_sections_sizes(jxlt_context* ctx, int kind, const uint32_t* code_table, jxlt_packed_sections* out) {
+  if (!ctx || !code_table || !out || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
+  int rc = CheckPackCall(ctx, "jxlt_pack_sections_sizes");
+  if (rc != JXLT_OK) return rc;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if ((rc = EnqueueMeasure(ctx, kind, code_table)) != JXLT_OK) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  FillMeasured(ctx, kind, out);
+  return JXLT_OK;
+}
+
+int jxlt_pack_sections_place(jxlt_context* ctx, int kind, uint8_t* dst) {
+  if (!ctx || !dst || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
+  if (ctx->pack[kind].measured_sections == 0) {
+    ctx->error = "jxlt_pack_sections_place needs jxlt_pack_sections_sizes first";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int ev = 0;
+  return EnqueueWrite(ctx, kind, dst, kind == 0 ? 1 : jxlt_context::kWriteChunks - 1, &ev);
+}
+
+int jxlt_pack_sections_copy(jxlt_context* ctx, int kind, uint8_t* dst) {
+  const int rc = jxlt_pack_sections_place(ctx, kind, dst);
+  if (rc != JXLT_OK) return rc;
+  return jxlt_synchronize(ctx);
+}
+
+int jxlt_pack_sections(jxlt_context* ctx, int kind, const uint32_t* code_table, jxlt_packed_sections* out) {
+  int rc = jxlt_pack_sections_sizes(ctx, kind, code_table, out);
+  if (rc != JXLT_OK) return rc;
+  jxlt_context::PackSet& ps = ctx->pack[kind];
+  const uint64_t total_bytes = ps.h_sec_byte_off.p[ps.measured_sections];
+  if (ps.h_packed.cap < total_bytes + 1 &&
+      (rc = EnsurePinned(ctx, &ps.h_packed, total_bytes + total_bytes / 4 + 4096)) != JXLT_OK)
+    return rc;
+  if ((rc = jxlt_pack_sections_copy(ctx, kind, ps.h_packed.p)) != JXLT_OK) return rc;
+  out->bytes = ps.h_packed.p;
+  return JXLT_OK;
+}
 
 int jxlt_pack_measure(jxlt_context* ctx, const uint32_t* dc_code_table, const uint32_t* ac_code_table,
                       jxlt_packed_sections* dc, jxlt_packed_sections* ac) {
   if (!ctx || !dc_code_table || !ac_code_table || !dc || !ac) return JXLT_ERR_INVALID_ARGUMENT;
-  if (!ctx->encoded || !ctx->offsets_fetched) {
-    ctx->error = "jxlt_pack_measure needs jxlt_encode_enqueue + jxlt_fetch_histograms/side_info first";
-    return JXLT_ERR_INVALID_ARGUMENT;
-  }
+  int rc = CheckPackCall(ctx, "jxlt_pack_measure");
+  if (rc != JXLT_OK) return rc;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const FrameGeom& g = ctx->geom;
-  const size_t ngroups = (size_t)g.xsize_groups * g.ysize_groups;
-  const size_t nsecs[2] = {((ctx->xsize + 2047) / 2048) * ((ctx->ysize + 2047) / 2048), ngroups};
-  // upper bounds of the record counts (the exact per-section counts live on the device)
-  const uint64_t rec_bound[2] = {ctx->dc_records.cap / 3, ctx->h_group_off.p[ngroups]};
-  const uint32_t* tables[2] = {dc_code_table, ac_code_table};
-  jxlt_packed_sections* outs[2] = {dc, ac};
-  int rc;
-  for (int kind = 0; kind < 2; kind++) {
-    jxlt_context::PackSet& ps = ctx->pack[kind];
-    const size_t nsec = nsecs[kind];
-    const size_t max_tiles = (size_t)(rec_bound[kind] / kPackTile) + nsec + 1;
-#define ENSURE(buf, n) if ((rc = EnsureDevice(ctx, &ps.buf, (n))) != JXLT_OK) return rc
-    ENSURE(code_table, 64 * 64);
-    ENSURE(sec_bits, nsec);
-    ENSURE(sec_bytes, nsec);
-    ENSURE(sec_byte_off, nsec + 1);
-    ENSURE(sec_tiles, nsec);
-    ENSURE(tile_base, nsec + 1);
-    ENSURE(tile_bits, max_tiles);
-    ENSURE(tile_info, max_tiles);
-#undef ENSURE
-    if ((rc = EnsurePinned(ctx, &ps.h_sec_byte_off, nsec + 1)) != JXLT_OK) return rc;
-    if ((rc = EnsurePinned(ctx, &ps.h_sec_bits, nsec)) != JXLT_OK) return rc;
-    if ((rc = EnsurePinned(ctx, &ps.h_tile_base, nsec + 1)) != JXLT_OK) return rc;
-    ps.max_tiles = max_tiles;
-    HIP_TRY(ctx, hipMemcpyAsync(ps.code_table.p, tables[kind], 64 * 64 * sizeof(uint32_t), hipMemcpyHostToDevice,
-                                ctx->stream));
-    const PackTileArgs P = TileArgsOf(ctx, kind, nsec);
-    const unsigned sec_blocks = (unsigned)((nsec + 255) / 256);
-    hipLaunchKernelGGL(pack_tile_count_kernel, dim3(sec_blocks), dim3(256), 0, ctx->stream, P);
-    hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t*)ps.sec_tiles.p,
-                       ps.tile_base.p, (int)nsec);
-    hipLaunchKernelGGL(pack_tile_plan_kernel, dim3(sec_blocks), dim3(256), 0, ctx->stream, P);
-    hipLaunchKernelGGL(pack_tile_measure_kernel, dim3((unsigned)((max_tiles + kPackTilesPerGroup - 1) / kPackTilesPerGroup)),
-                       dim3(kPackThreads), 0, ctx->stream, P);
-    hipLaunchKernelGGL(pack_tile_offsets_kernel, dim3(sec_blocks), dim3(256), 0, ctx->stream, P);
-    hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t*)ps.sec_bytes.p,
-                       ps.sec_byte_off.p, (int)nsec);
-    hipLaunchKernelGGL(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), 0, ctx->stream,
-                       P);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(ps.h_sec_byte_off.p, ps.sec_byte_off.p, (nsec + 1) * sizeof(uint64_t),
-                                hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ps.h_sec_bits.p, ps.sec_bits.p, nsec * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                                ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ps.h_tile_base.p, ps.tile_base.p, (nsec + 1) * sizeof(uint64_t),
-                                hipMemcpyDeviceToHost, ctx->stream));
-    ps.packed_sections = 0;  // nothing in slots / packed
-    ps.measured_sections = nsec;
-  }
+  if ((rc = EnqueueMeasure(ctx, 0, dc_code_table)) != JXLT_OK) return rc;
+  if ((rc = EnqueueMeasure(ctx, 1, ac_code_table)) != JXLT_OK) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  for (int kind = 0; kind < 2; kind++) {
-    jxlt_context::PackSet& ps = ctx->pack[kind];
-    outs[kind]->bytes = nullptr;
-    outs[kind]->section_offset = ps.h_sec_byte_off.p;
-    outs[kind]->section_bits = ps.h_sec_bits.p;
-    outs[kind]->num_sections = nsecs[kind];
-  }
+  FillMeasured(ctx, 0, dc);
+  FillMeasured(ctx, 1, ac);
   return JXLT_OK;
 }
 
@@ -881,43 +849,10 @@ int jxlt_pack_write(jxlt_context* ctx, uint8_t* dc_dst, uint8_t* ac_dst) {
     return JXLT_ERR_INVALID_ARGUMENT;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  // Tiles are packed at their final bit positions into a device blob per kind; the blob leaves in
-  // chunks on the copy stream while later chunks are still being packed.  DC first, then the AC
-  // sections in kWriteChunks - 1 ranges of whole sections.
-  uint8_t* dsts[2] = {dc_dst, ac_dst};
-  int rc;
   int ev = 0;
-  for (int kind = 0; kind < 2; kind++) {
-    jxlt_context::PackSet& ps = ctx->pack[kind];
-    const size_t nsec = ps.measured_sections;
-    const uint64_t* off = ps.h_sec_byte_off.p;
-    const uint64_t* tb = ps.h_tile_base.p;
-    const uint64_t total = off[nsec];
-    if (ps.packed.cap < total + 16 && (rc = EnsureDevice(ctx, &ps.packed, total + total / 4 + 4096)) != JXLT_OK)
-      return rc;
-    const int nchunks = kind == 0 ? 1 : (int)std::min<size_t>(jxlt_context::kWriteChunks - 1, nsec);
-    for (int c = 0; c < nchunks; c++) {
-      const size_t s0 = nsec * c / nchunks, s1 = nsec * (c + 1) / nchunks;
-      if (s1 == s0) continue;
-      if (tb[s1] > tb[s0]) {
-        PackTileArgs P = TileArgsOf(ctx, kind, nsec);
-        P.tile_first = (uint32_t)tb[s0];
-        P.tile_end = (uint32_t)tb[s1];
-        hipLaunchKernelGGL(pack_tile_write_kernel,
-                           dim3((unsigned)((tb[s1] - tb[s0] + kPackTilesPerGroup - 1) / kPackTilesPerGroup)),
-                           dim3(kPackThreads), 0, ctx->stream, P);
-        HIP_TRY(ctx, hipGetLastError());
-      }
-      HIP_TRY(ctx, hipEventRecord(ctx->chunk_packed[ev], ctx->stream));
-      HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->chunk_packed[ev], 0));
-      ev++;
-      if (off[s1] > off[s0])
-        HIP_TRY(ctx, hipMemcpyAsync(dsts[kind] + off[s0], ps.packed.p + off[s0], off[s1] - off[s0], hipMemcpyDefault,
-                                    ctx->copy_stream));
-    }
-  }
-  ctx->copies_pending = true;
-  return JXLT_OK;
+  int rc = EnqueueWrite(ctx, 0, dc_dst, 1, &ev);
+  if (rc != JXLT_OK) return rc;
+  return EnqueueWrite(ctx, 1, ac_dst, jxlt_context::kWriteChunks - 1, &ev);
 }
 
 int jxlt_output_buffer(jxlt_context* ctx, size_t bytes, uint8_t** out) {

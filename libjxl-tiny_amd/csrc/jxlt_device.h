@@ -99,28 +99,6 @@ struct TokenArgs {
   uint32_t* histogram;               // optional [64 pre-clusters][64 symbols] (enc_frame.cc:767-782)
 };
 
-// Bit packing of raw 3-byte-record sections with a prefix code (enc_frame.cc:784-800).
-struct PackArgs {
-  const uint8_t* records;           // [u8 ctx][u16 value]; ctx >= 128: (ctx-128) raw bits
-  const uint64_t* sec_rec_offset;   // [nsec + 1], in records
-  const uint32_t* code_table;       // [64][64]: (depth << 16) | bits, per (context, symbol)
-  uint8_t* slots;                   // section s is written at byte 4 * sec_rec_offset[s]
-  uint32_t* sec_bits;               // [nsec] bits written
-  uint32_t* sec_bytes;              // [nsec] ceil(bits / 8)
-  const uint32_t* sec_rec_count;    // optional [nsec]: records in section (else offset[s+1]-offset[s])
-  uint8_t* out;                     // pack_direct_kernel: destination of section 0
-  int sec_base;                     // first section of this launch (section = sec_base + workgroup index)
-  const uint64_t* sec_byte_offset;  // pack_direct_kernel: [nsec] byte offset of each section in `out`
-};
-
-struct CompactArgs {
-  const uint8_t* slots;
-  const uint64_t* sec_rec_offset;
-  const uint32_t* sec_bytes;
-  const uint64_t* sec_byte_offset;  // exclusive scan of sec_bytes
-  uint8_t* out;
-};
-
 // ---------------------------------------------------------------------------
 // Arithmetic primitives
 // ---------------------------------------------------------------------------
@@ -1727,134 +1705,6 @@ constexpr int kPackPerThread = 8;
 constexpr int kPackTile = kPackThreads * kPackPerThread;        // 4096 records
 constexpr int kPackWindowWords = kPackTile * 28 / 32 + 4;        // <= 28 bits per record
 
-// kMode 0: sections to dword-aligned slots (4 * first record index), sizes written out.
-// kMode 2: sections to their final byte offsets A.out + A.sec_byte_offset[sec] (device memory or
-//          device-visible host memory); the section's first byte may sit anywhere inside a
-//          dword that it shares with its neighbour, so the bit stream starts 8 * (address & 3)
-//          bits into an aligned window and the two edge dwords are written bytewise.
-template <int kMode>
-JXLT_DI void pack_section(const PackArgs& A) {
-  __shared__ uint32_t table[64 * 64];
-  __shared__ uint32_t window[kPackWindowWords];
-  __shared__ uint32_t scan[kPackThreads];
-  __shared__ uint8_t bytes[kPackTile * 3 + 8];
-  const int tid = (int)threadIdx.x;
-  const int sec = A.sec_base + (int)blockIdx.x;
-  for (int i = tid; i < 64 * 64; i += kPackThreads) table[i] = A.code_table[i];
-  const uint64_t rec0 = A.sec_rec_offset[sec];
-  const uint64_t rec1 = A.sec_rec_count ? rec0 + A.sec_rec_count[sec] : A.sec_rec_offset[sec + 1];
-  const uint8_t* src = A.records + 3 * rec0;
-  uint32_t* dst = nullptr;
-  uint32_t lead_bits = 0;
-  if (kMode == 0) dst = reinterpret_cast<uint32_t*>(A.slots + 4 * rec0);
-  if (kMode == 2) {
-    uint8_t* d = A.out + A.sec_byte_offset[sec];
-    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(d) & 3u);
-    dst = reinterpret_cast<uint32_t*>(d - mis);
-    lead_bits = 8 * mis;
-  }
-  uint64_t total_bits = lead_bits;  // bits of all completed tiles (+ the alignment lead)
-  uint32_t carry = 0;               // partial last word of the previous tile
-  uint64_t words_out = 0;           // complete words already stored
-  for (uint64_t t0 = 0; t0 < rec1 - rec0; t0 += kPackTile) {
-    const int n = (int)((rec1 - rec0 - t0) < (uint64_t)kPackTile ? (rec1 - rec0 - t0) : (uint64_t)kPackTile);
-    __syncthreads();  // previous tile fully flushed; table loaded
-    for (int i = tid; i < n * 3; i += kPackThreads) bytes[i] = src[3 * t0 + i];
-    for (int i = tid; i < kPackWindowWords; i += kPackThreads) window[i] = (i == 0) ? carry : 0u;
-    __syncthreads();
-    // pass 1: bit length of this thread's records
-    uint32_t nb[kPackPerThread];
-    uint32_t data[kPackPerThread];
-    uint32_t mine = 0;
-#pragma unroll
-    for (int j = 0; j < kPackPerThread; j++) {
-      const int r = tid * kPackPerThread + j;
-      nb[j] = 0;
-      data[j] = 0;
-      if (r < n) {
-        const uint32_t ctx = bytes[3 * r];
-        const uint32_t value = (uint32_t)bytes[3 * r + 1] | ((uint32_t)bytes[3 * r + 2] << 8);
-        if (ctx >= 128) {
-          nb[j] = ctx - 128;
-          data[j] = value;
-        } else {
-          uint32_t sym, nbits, extra;
-          hybrid_uint(value, &sym, &nbits, &extra);
-          const uint32_t e = table[ctx * 64 + sym];
-          const uint32_t depth = e >> 16;
-          nb[j] = depth + nbits;
-          data[j] = (e & 0xFFFFu) | (extra << depth);
-        }
-        mine += nb[j];
-      }
-    }
-    scan[tid] = mine;
-    __syncthreads();
-    for (int sft = 1; sft < kPackThreads; sft <<= 1) {
-      const uint32_t add = tid >= sft ? scan[tid - sft] : 0;
-      __syncthreads();
-      scan[tid] += add;
-      __syncthreads();
-    }
-    const uint32_t tile_bits = scan[kPackThreads - 1];
-    // bit position inside the window: the window starts at the last incomplete word
-    const uint32_t lead = (uint32_t)(total_bits & 31u);
-    uint32_t pos = lead + scan[tid] - mine;
-    // pass 2: OR the bits into the window
-    {
-      uint32_t w = pos >> 5;
-      uint32_t fill = pos & 31u;
-      unsigned long long acc = 0;
-#pragma unroll
-      for (int j = 0; j < kPackPerThread; j++) {
-        acc |= (unsigned long long)data[j] << fill;
-        fill += nb[j];
-        if (fill >= 32) {
-          atomicOr(&window[w], (uint32_t)acc);
-          acc >>= 32;
-          fill -= 32;
-          w++;
-        }
-      }
-      if (fill) atomicOr(&window[w], (uint32_t)acc);
-    }
-    __syncthreads();
-    const uint32_t end_bits = lead + tile_bits;
-    const uint32_t full_words = end_bits >> 5;
-    for (uint32_t i = tid; i < full_words; i += kPackThreads) {
-      if (kMode == 2 && words_out + i == 0 && lead_bits != 0) {
-        // first dword of the section: its low bytes belong to the previous section
-        uint8_t* b = reinterpret_cast<uint8_t*>(dst);
-        for (uint32_t k = lead_bits >> 3; k < 4; k++) b[k] = (uint8_t)(window[0] >> (8 * k));
-      } else {
-        dst[words_out + i] = window[i];
-      }
-    }
-    const uint32_t next_carry = (end_bits & 31u) ? window[full_words] : 0u;
-    __syncthreads();
-    carry = next_carry;
-    words_out += full_words;
-    total_bits += tile_bits;
-  }
-  if (tid == 0) {
-    if (kMode == 0) {
-      if (total_bits & 31u) dst[words_out] = carry;
-    } else if (kMode == 2) {
-      // last, partial dword: only the bytes the section owns
-      const uint32_t rem_bytes = (uint32_t)(((total_bits & 31u) + 7) >> 3);
-      const uint32_t first = words_out == 0 ? (lead_bits >> 3) : 0u;
-      uint8_t* b = reinterpret_cast<uint8_t*>(dst + words_out);
-      for (uint32_t k = first; k < rem_bytes; k++) b[k] = (uint8_t)(carry >> (8 * k));
-    }
-    if (kMode != 2) {
-      A.sec_bits[sec] = (uint32_t)(total_bits - lead_bits);
-      A.sec_bytes[sec] = (uint32_t)((total_bits - lead_bits + 7) >> 3);
-    }
-  }
-}
-
-__global__ void __launch_bounds__(kPackThreads) pack_kernel(const PackArgs A) { pack_section<0>(A); }
-
 // ---------------------------------------------------------------------------
 // Copy-free packing at tile granularity (kPackTile records per workgroup, whatever section they
 // belong to): DC-group sections hold ~100 tiles each, AC-group sections <= 48, so per-section
@@ -2389,30 +2239,6 @@ __global__ void __launch_bounds__(kDcChainThreads) dc_chain_kernel(const DcArgs 
   }
   for (int i = tid; i < 64 * 64; i += kDcChainThreads)
     if (hist[i]) atomicAdd(&A.histogram[i], hist[i]);
-}
-
-// Gathers the packed sections into one contiguous byte stream.
-__global__ void __launch_bounds__(256) compact_kernel(const CompactArgs A) {
-  // The slot is dword aligned, the destination only byte aligned (sections are byte-aligned in
-  // the codestream; the destination may be host memory behind PCIe): aligned dword stores for
-  // the body, each assembled from two source dwords, and byte stores for the <= 3 + 3 edge bytes.
-  const int sec = (int)blockIdx.x, tid = (int)threadIdx.x;
-  const uint8_t* srcb = A.slots + 4 * A.sec_rec_offset[sec];
-  const uint32_t* srcw = reinterpret_cast<const uint32_t*>(srcb);
-  uint8_t* dst = A.out + A.sec_byte_offset[sec];
-  const uint32_t n = A.sec_bytes[sec];
-  uint32_t lead = (4u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u;
-  if (lead > n) lead = n;
-  if ((uint32_t)tid < lead) dst[tid] = srcb[tid];
-  const uint32_t body = (n - lead) >> 2;
-  uint32_t* dw = reinterpret_cast<uint32_t*>(dst + lead);
-  const uint32_t sh = lead * 8;
-  for (uint32_t i = tid; i < body; i += 256) {
-    const uint32_t lo = srcw[i];
-    dw[i] = sh ? (lo >> sh) | (srcw[i + 1] << (32 - sh)) : lo;
-  }
-  const uint32_t tail0 = lead + 4 * body;
-  if ((uint32_t)tid < n - tail0) dst[tail0 + tid] = srcb[tail0 + tid];
 }
 
 }  // namespace jxlt_dev

@@ -110,89 +110,72 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   BuildDcCode(dc_hist, &dc_code);
   FillCodeTable(dc_code, dc_table.data());
   const auto t2 = now();
+  // One pass measures every section (all the TOC needs); then the device entropy-codes the
+  // sections straight to their final byte offsets and copies them to where the frame is being
+  // assembled, while the host builds header and TOC.
+  jxlt_packed_sections dcm, acm;
+  if (jxlt_pack_measure(ctx, dc_table.data(), ac_table.data(), &dcm, &acm) != JXLT_OK) {
+    fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
+    return false;
+  }
+  const auto t3 = now();
+  const PackedSections dc = {nullptr, dcm.section_offset, dcm.section_bits, dcm.num_sections};
+  const PackedSections ac = {nullptr, acm.section_offset, acm.section_bits, acm.num_sections};
+  FrameGlobals globals;
+  BuildFrameGlobals(xsize, ysize, distp, dc_code, ac_code, &globals);
+  const size_t dc_bytes = static_cast<size_t>(dc.offset[dc.n]), ac_bytes = static_cast<size_t>(ac.offset[ac.n]);
+  const size_t acg_bytes = globals.ac_global.size();
+  std::vector<uint8_t> head;
+  bool ok = true;
   if (in_context) {
-    // Copy-free output: one pass measures every section (all the TOC needs), then the device
-    // writes the sections to their final places in the context's page-locked output buffer
-    // while the host builds header and TOC.  The buffer position of the sections is fixed
-    // before the head exists: the head is bounded from above and right-aligned in front.
-    jxlt_packed_sections dcm, acm;
-    if (jxlt_pack_measure(ctx, dc_table.data(), ac_table.data(), &dcm, &acm) != JXLT_OK) {
-      fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
-      return false;
-    }
-    const auto t3 = now();
-    const PackedSections dc = {nullptr, dcm.section_offset, dcm.section_bits, dcm.num_sections};
-    const PackedSections ac = {nullptr, acm.section_offset, acm.section_bits, acm.num_sections};
-    FrameGlobals globals;
-    BuildFrameGlobals(xsize, ysize, distp, dc_code, ac_code, &globals);
+    // Context buffer: the position of the sections is fixed before the head exists (the head
+    // is bounded from above and right-aligned in front of them), so the device starts at once.
     const size_t pre = in_context->prefix ? in_context->prefix->size() : 0;
-    const size_t dc_bytes = static_cast<size_t>(dc.offset[dc.n]), ac_bytes = static_cast<size_t>(ac.offset[ac.n]);
     const size_t dc_at = (pre + HeadSizeBound(xsize, ysize, globals) + 255) & ~static_cast<size_t>(255);
-    const size_t ac_at = dc_at + dc_bytes + globals.ac_global.size();
+    const size_t ac_at = dc_at + dc_bytes + acg_bytes;
     uint8_t* buf = nullptr;
     if (jxlt_output_buffer(ctx, ac_at + ac_bytes + 16, &buf) != JXLT_OK ||
         jxlt_pack_write(ctx, buf + dc_at, buf + ac_at) != JXLT_OK) {
       fprintf(stderr, "jxl_tiny_amd: section placement failed: %s\n", jxlt_last_error(ctx));
       return false;
     }
-    std::vector<uint8_t> head;
     if (!BuildFrameHead(xsize, ysize, distp, globals, dc, ac, &head)) return false;
     uint8_t* dst = buf + dc_at - (pre + head.size());
     in_context->data = dst;
-    in_context->size = pre + head.size() + dc_bytes + globals.ac_global.size() + ac_bytes;
+    in_context->size = pre + head.size() + dc_bytes + acg_bytes + ac_bytes;
     if (pre) memcpy(dst, in_context->prefix->data(), pre);
     memcpy(dst + pre, head.data(), head.size());
-    memcpy(buf + dc_at + dc_bytes, globals.ac_global.data(), globals.ac_global.size());
-    const bool ok = jxlt_synchronize(ctx) == JXLT_OK;
-    if (trace)
-      fprintf(stderr, "jxlt trace: device+histograms %.2f ms | codes %.2f | measure %.2f | head + place %.2f\n",
-              ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
-    return ok;
-  }
-  // DC sections are small: fetched into the context's pinned buffer.  For the AC sections
-  // only the sizes are needed to write the TOC; the blob is copied once, to its final place.
-  jxlt_packed_sections dcp, acp;
-  if (jxlt_pack_sections(ctx, 0, dc_table.data(), &dcp) != JXLT_OK ||
-      jxlt_pack_sections_sizes(ctx, 1, ac_table.data(), &acp) != JXLT_OK) {
-    fprintf(stderr, "jxl_tiny_amd: section packing failed: %s\n", jxlt_last_error(ctx));
-    return false;
-  }
-  const auto t3 = now();
-  PackedSections dc = {dcp.bytes, dcp.section_offset, dcp.section_bits, dcp.num_sections};
-  PackedSections ac = {nullptr, acp.section_offset, acp.section_bits, acp.num_sections};
-  FramePieces pieces;
-  if (!FinishFrame(xsize, ysize, distp, dc_code, dc, ac_code, ac, &pieces)) return false;
-  const size_t dc_bytes = static_cast<size_t>(dc.offset[dc.n]), ac_bytes = static_cast<size_t>(ac.offset[ac.n]);
-  const size_t frame_bytes = pieces.head.size() + dc_bytes + pieces.ac_global.size() + ac_bytes;
-  bool ok = true;
-  if (writer) {
-    // BitWriter API of the drop-in EncodeFrame: append, AC blob via one staging copy
-    uint8_t* tmp = nullptr;
-    ok = jxlt_output_buffer(ctx, ac_bytes ? ac_bytes : 1, &tmp) == JXLT_OK &&
-         jxlt_pack_sections_copy(ctx, 1, tmp) == JXLT_OK;
-    if (ok) {
-      writer->Reserve(frame_bytes);
-      writer->AppendBytes(pieces.head.data(), pieces.head.size());
-      writer->AppendBytes(dc.bytes, dc_bytes);
-      writer->AppendBytes(pieces.ac_global.data(), pieces.ac_global.size());
-      writer->AppendBytes(tmp, ac_bytes);
-    }
+    memcpy(buf + dc_at + dc_bytes, globals.ac_global.data(), acg_bytes);
+    ok = jxlt_synchronize(ctx) == JXLT_OK;
   } else {
-    // placer(frame_bytes) returns where the frame must be written
-    uint8_t* dst = (*placer)(frame_bytes);
-    ok = dst != nullptr;
-    if (ok) {
-      memcpy(dst, pieces.head.data(), pieces.head.size());
-      dst += pieces.head.size();
-      memcpy(dst, dc.bytes, dc_bytes);
-      dst += dc_bytes;
-      memcpy(dst, pieces.ac_global.data(), pieces.ac_global.size());
-      dst += pieces.ac_global.size();
-      ok = jxlt_pack_sections_copy(ctx, 1, dst) == JXLT_OK;
+    if (!BuildFrameHead(xsize, ysize, distp, globals, dc, ac, &head)) return false;
+    const size_t frame_bytes = head.size() + dc_bytes + acg_bytes + ac_bytes;
+    if (writer) {
+      // BitWriter API of the drop-in EncodeFrame: the sections pass through the page-locked buffer
+      uint8_t* tmp = nullptr;
+      ok = jxlt_output_buffer(ctx, dc_bytes + ac_bytes + 16, &tmp) == JXLT_OK &&
+           jxlt_pack_write(ctx, tmp, tmp + dc_bytes) == JXLT_OK && jxlt_synchronize(ctx) == JXLT_OK;
+      if (ok) {
+        writer->Reserve(frame_bytes);
+        writer->AppendBytes(head.data(), head.size());
+        writer->AppendBytes(tmp, dc_bytes);
+        writer->AppendBytes(globals.ac_global.data(), acg_bytes);
+        writer->AppendBytes(tmp + dc_bytes, ac_bytes);
+      }
+    } else {
+      // placer(frame_bytes) returns where the frame must be written
+      uint8_t* dst = (*placer)(frame_bytes);
+      ok = dst != nullptr &&
+           jxlt_pack_write(ctx, dst + head.size(), dst + head.size() + dc_bytes + acg_bytes) == JXLT_OK;
+      if (ok) {
+        memcpy(dst, head.data(), head.size());
+        memcpy(dst + head.size() + dc_bytes, globals.ac_global.data(), acg_bytes);
+        ok = jxlt_synchronize(ctx) == JXLT_OK;
+      }
     }
   }
   if (trace)
-    fprintf(stderr, "jxlt trace: device+histograms %.2f ms | codes %.2f | pack (device) %.2f | finish+copy %.2f\n",
+    fprintf(stderr, "jxlt trace: device+histograms %.2f ms | codes %.2f | measure %.2f | head + place %.2f\n",
             ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
   (void)num_threads;
   return ok;

@@ -158,33 +158,6 @@ __attribute__((visibility("default"))) void sim_free(sim_result* r) {
   memset(r, 0, sizeof(*r));
 }
 
-// Runs pack_kernel + group_scan_kernel + compact_kernel over `nsec` sections of 3-byte records.
-// out_bytes must hold 4 * total_records + 16 bytes; out_offset [nsec+1]; out_bits [nsec].
-__attribute__((visibility("default"))) int sim_pack(const uint8_t* records, const uint64_t* sec_rec_offset,
-                                                     int nsec, const uint32_t* code_table, uint8_t* out_bytes,
-                                                     uint64_t* out_offset, uint32_t* out_bits) {
-  const uint64_t total = sec_rec_offset[nsec];
-  std::vector<uint8_t> slots(4 * total + 16, 0xCD);  // poison: every output byte must be written
-  std::vector<uint32_t> sec_bytes(nsec);
-  PackArgs P = {};
-  P.records = records;
-  P.sec_rec_offset = sec_rec_offset;
-  P.code_table = code_table;
-  P.slots = slots.data();
-  P.sec_bits = out_bits;
-  P.sec_bytes = sec_bytes.data();
-  hipsim::launch(pack_kernel, dim3((unsigned)nsec), dim3(kPackThreads), P);
-  hipsim::launch(group_scan_kernel, dim3(1), dim3(256), (const uint32_t*)sec_bytes.data(), out_offset, nsec);
-  CompactArgs Cp;
-  Cp.slots = slots.data();
-  Cp.sec_rec_offset = sec_rec_offset;
-  Cp.sec_bytes = sec_bytes.data();
-  Cp.sec_byte_offset = out_offset;
-  Cp.out = out_bytes;
-  hipsim::launch(compact_kernel, dim3((unsigned)nsec), dim3(256), Cp);
-  return 0;
-}
-
 // The copy-free, tile-granular packing: count / scan / measure / offsets / scan, then
 // pack_tile_write_kernel in `nlaunch` tile ranges, storing every tile at its final bit position
 // behind `out_bytes + 4 * misalign_words` (the blob base must be dword aligned).  out_bytes

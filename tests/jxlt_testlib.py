@@ -186,8 +186,6 @@ def _sim_lib():
         _sim.sim_encode.argtypes = [C.POINTER(fp), C.c_size_t, C.c_size_t, C.c_size_t, C.c_float,
                                     C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
                                     C.POINTER(SimResult)]
-        _sim.sim_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_void_p]
         _sim.sim_pack_direct.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_int, C.c_void_p, C.c_void_p]
     return _sim
@@ -233,22 +231,7 @@ def pack_sections_python(sections, table):
     return out
 
 
-def sim_pack_sections(sections, table):
-    """pack_kernel + scan + compact on the CPU execution model."""
-    L = _sim_lib()
-    blob = np.frombuffer(b"".join(sections) + b"\0\0\0\0", np.uint8).copy()
-    offs = np.zeros(len(sections) + 1, np.uint64)
-    offs[1:] = np.cumsum([len(x) // 3 for x in sections])
-    table = np.ascontiguousarray(table, np.uint32)
-    out = np.zeros(4 * int(offs[-1]) + 16, np.uint8)
-    out_off = np.zeros(len(sections) + 1, np.uint64)
-    out_bits = np.zeros(len(sections), np.uint32)
-    L.sim_pack(blob.ctypes.data, offs.ctypes.data, len(sections), table.ctypes.data, out.ctypes.data,
-               out_off.ctypes.data, out_bits.ctypes.data)
-    return [(out[int(out_off[i]):int(out_off[i + 1])].tobytes(), int(out_bits[i])) for i in range(len(sections))]
-
-
-def sim_pack_sections_direct(sections, table, misalign=0, nlaunch=1):
+def sim_pack_sections(sections, table, misalign=0, nlaunch=1):
     """Tile-granular measure + write kernels on the CPU execution model (blob base = out + 4 *
     misalign words); also checks that no byte outside the sections' final places was written."""
     L = _sim_lib()
