@@ -411,7 +411,73 @@ JXLT_DI void octet_exchange(float& a, float& b, int l) {
 
 // 8x8 transpose across the 8 lanes of an octet: lane l holds v[j] = M[j][l] and
 // ends with v[j] = M[l][j].  Three butterfly stages, static register indices.
+//
+// On the GPU the whole transpose is one assembly block of 24 v_cndmask_b32_dpp: each new value
+// is a select fused with the lane permutation, D = vcc ? src1 : dpp(src0) with vcc = the lanes
+// that keep their own value.  The compiler does not form this instruction from the builtins
+// (it emits a DPP move plus a select, and a copy where the DPP move's tied destination is
+// still live: 44 instructions per transpose), and the transposes are half of the transform
+// phases' VALU work.  bound_ctrl makes an out-of-row source read 0 (those lanes select src1).
+// The producers of a DPP operand are always >= 3 instructions back inside the block; the
+// leading s_nop covers the caller's last writes.  The CPU model runs the generic exchanges.
 JXLT_DI void octet_transpose(float* v, int l) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  (void)l;
+  float o0, o1, o2, o3, o4, o5, o6, o7, u0, u1, u2, u3, u4, u5, u6, u7;
+  const unsigned long long lo4 = 0x0F0F0F0F0F0F0F0Full, lo2 = 0x3333333333333333ull, lo1 = 0x5555555555555555ull;
+  const unsigned long long hi4 = ~lo4, hi2 = ~lo2, hi1 = ~lo1;
+#define JXLT_SHR4 " row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define JXLT_SHL4 " row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define JXLT_QP2 " quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+#define JXLT_QP1 " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+  asm("s_nop 1\n\t"
+      // distance 4: pairs (0,4) (1,5) (2,6) (3,7)
+      "s_mov_b64 vcc, %[lo4]\n\t"
+      "v_cndmask_b32_dpp %[o0], %[i4], %[i0], vcc" JXLT_SHR4
+      "v_cndmask_b32_dpp %[o1], %[i5], %[i1], vcc" JXLT_SHR4
+      "v_cndmask_b32_dpp %[o2], %[i6], %[i2], vcc" JXLT_SHR4
+      "v_cndmask_b32_dpp %[o3], %[i7], %[i3], vcc" JXLT_SHR4
+      "s_mov_b64 vcc, %[hi4]\n\t"
+      "v_cndmask_b32_dpp %[o4], %[i0], %[i4], vcc" JXLT_SHL4
+      "v_cndmask_b32_dpp %[o5], %[i1], %[i5], vcc" JXLT_SHL4
+      "v_cndmask_b32_dpp %[o6], %[i2], %[i6], vcc" JXLT_SHL4
+      "v_cndmask_b32_dpp %[o7], %[i3], %[i7], vcc" JXLT_SHL4
+      // distance 2: pairs (0,2) (1,3) (4,6) (5,7)
+      "s_mov_b64 vcc, %[lo2]\n\t"
+      "v_cndmask_b32_dpp %[u0], %[o2], %[o0], vcc" JXLT_QP2
+      "v_cndmask_b32_dpp %[u1], %[o3], %[o1], vcc" JXLT_QP2
+      "v_cndmask_b32_dpp %[u4], %[o6], %[o4], vcc" JXLT_QP2
+      "v_cndmask_b32_dpp %[u5], %[o7], %[o5], vcc" JXLT_QP2
+      "s_mov_b64 vcc, %[hi2]\n\t"
+      "v_cndmask_b32_dpp %[u2], %[o0], %[o2], vcc" JXLT_QP2
+      "v_cndmask_b32_dpp %[u3], %[o1], %[o3], vcc" JXLT_QP2
+      "v_cndmask_b32_dpp %[u6], %[o4], %[o6], vcc" JXLT_QP2
+      "v_cndmask_b32_dpp %[u7], %[o5], %[o7], vcc" JXLT_QP2
+      // distance 1: pairs (0,1) (2,3) (4,5) (6,7)
+      "s_mov_b64 vcc, %[lo1]\n\t"
+      "v_cndmask_b32_dpp %[o0], %[u1], %[u0], vcc" JXLT_QP1
+      "v_cndmask_b32_dpp %[o2], %[u3], %[u2], vcc" JXLT_QP1
+      "v_cndmask_b32_dpp %[o4], %[u5], %[u4], vcc" JXLT_QP1
+      "v_cndmask_b32_dpp %[o6], %[u7], %[u6], vcc" JXLT_QP1
+      "s_mov_b64 vcc, %[hi1]\n\t"
+      "v_cndmask_b32_dpp %[o1], %[u0], %[u1], vcc" JXLT_QP1
+      "v_cndmask_b32_dpp %[o3], %[u2], %[u3], vcc" JXLT_QP1
+      "v_cndmask_b32_dpp %[o5], %[u4], %[u5], vcc" JXLT_QP1
+      "v_cndmask_b32_dpp %[o7], %[u6], %[u7], vcc" JXLT_QP1
+      : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [o4] "=&v"(o4), [o5] "=&v"(o5),
+        [o6] "=&v"(o6), [o7] "=&v"(o7), [u0] "=&v"(u0), [u1] "=&v"(u1), [u2] "=&v"(u2), [u3] "=&v"(u3),
+        [u4] "=&v"(u4), [u5] "=&v"(u5), [u6] "=&v"(u6), [u7] "=&v"(u7)
+      : [i0] "v"(v[0]), [i1] "v"(v[1]), [i2] "v"(v[2]), [i3] "v"(v[3]), [i4] "v"(v[4]), [i5] "v"(v[5]),
+        [i6] "v"(v[6]), [i7] "v"(v[7]), [lo4] "s"(lo4), [hi4] "s"(hi4), [lo2] "s"(lo2), [hi2] "s"(hi2),
+        [lo1] "s"(lo1), [hi1] "s"(hi1)
+      : "vcc");
+#undef JXLT_SHR4
+#undef JXLT_SHL4
+#undef JXLT_QP2
+#undef JXLT_QP1
+  v[0] = o0; v[1] = o1; v[2] = o2; v[3] = o3;
+  v[4] = o4; v[5] = o5; v[6] = o6; v[7] = o7;
+#else
   octet_exchange<4>(v[0], v[4], l);
   octet_exchange<4>(v[1], v[5], l);
   octet_exchange<4>(v[2], v[6], l);
@@ -424,6 +490,7 @@ JXLT_DI void octet_transpose(float* v, int l) {
   octet_exchange<1>(v[2], v[3], l);
   octet_exchange<1>(v[4], v[5], l);
   octet_exchange<1>(v[6], v[7], l);
+#endif
 }
 
 // Block transforms.  `px` points at the block's top-left sample in an LDS plane
