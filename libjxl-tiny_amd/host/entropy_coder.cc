@@ -47,25 +47,24 @@ void AssignDepths(const Node* pool, int root, uint8_t* depth) {
 // (ties prefer the leaf queue).  If the tree is deeper than tree_limit the
 // minimum count is doubled and the construction repeated.
 void CreateHuffmanTree(const uint32_t* counts, size_t length, int tree_limit, uint8_t* depth) {
-  // Called ~1000 times per frame by the clustering (Distance): fixed-size node pool on the
-  // stack, and a stable insertion sort (the leaves arrive nearly sorted: histograms fall off
-  // towards the high symbols, which are gathered first).
+  // Called ~1000 times per frame by the clustering (Distance): fixed-size node pool on the stack.
   if (length > kAlphabetSize) length = kAlphabetSize;
   Node tree[2 * kAlphabetSize + 2];
   for (uint32_t count_limit = 1;; count_limit *= 2) {
+    // Stable sort by count of the leaves in gathering order (highest symbol first): the keys
+    // (count, gathering position) are unique, so an ordinary sort of packed keys is stable.
+    uint64_t keys[kAlphabetSize];
     size_t n = 0;
     for (size_t i = length; i != 0;) {
       --i;
       if (counts[i]) {
-        const Node leaf = {std::max(counts[i], count_limit - 1), -1, static_cast<int16_t>(i)};
-        size_t k = n++;
-        while (k != 0 && tree[k - 1].count > leaf.count) {  // strict: equal counts keep gathering order
-          tree[k] = tree[k - 1];
-          --k;
-        }
-        tree[k] = leaf;
+        keys[n] = (static_cast<uint64_t>(std::max(counts[i], count_limit - 1)) << 16) | (n << 8) | i;
+        ++n;
       }
     }
+    std::sort(keys, keys + n);
+    for (size_t k = 0; k < n; ++k)
+      tree[k] = {static_cast<uint32_t>(keys[k] >> 16), -1, static_cast<int16_t>(keys[k] & 0xFF)};
     if (n == 0) return;  // (unreachable from the encoder; reference would misbehave)
     if (n == 1) {
       depth[tree[0].right] = 1;  // "fake" depth, kept as-is by the callers
@@ -76,6 +75,7 @@ void CreateHuffmanTree(const uint32_t* counts, size_t length, int tree_limit, ui
     tree[n + 1] = sentinel;  // first parent slot
     size_t size = n + 2;
     size_t leaf = 0, inner = n + 1;
+    uint8_t height[2 * kAlphabetSize + 2] = {};  // of the subtree below each node (leaves: 0)
     for (size_t k = n - 1; k != 0; --k) {
       size_t l, r;
       if (tree[leaf].count <= tree[inner].count) l = leaf++; else l = inner++;
@@ -84,10 +84,14 @@ void CreateHuffmanTree(const uint32_t* counts, size_t length, int tree_limit, ui
       tree[parent].count = tree[l].count + tree[r].count;
       tree[parent].left = static_cast<int16_t>(l);
       tree[parent].right = static_cast<int16_t>(r);
+      height[parent] = static_cast<uint8_t>(std::max(height[l], height[r]) + 1);
       tree[size++] = sentinel;
     }
+    // The deepest leaf sits at the root's height: too deep -> next limit without walking the tree.
+    // (symbols outside this tree keep the depth the caller initialised, 0, as in the reference)
+    if (height[2 * n - 1] > tree_limit) continue;
     AssignDepths(tree, static_cast<int>(2 * n - 1), depth);
-    if (*std::max_element(depth, depth + length) <= tree_limit) return;
+    return;
   }
 }
 
