@@ -137,6 +137,9 @@ int jxlt_pack_ac_sections(jxlt_context* ctx, const uint32_t* code_table, jxlt_pa
  * device tokenises too).  jxlt_pack_sections(kind): 0 = DC-group sections (the
  * raw-record form of WriteDCGroup, enc_frame.cc:536-570), 1 = AC-group sections. */
 int jxlt_fetch_histograms(jxlt_context* ctx, const uint32_t** ac_histograms, const uint32_t** dc_histograms);
+/* The DC histogram alone, as soon as the DC-group tokenisation is done (it runs before the AC
+ * tokenisation): lets the caller build the DC code while the device is still busy. */
+int jxlt_fetch_dc_histogram(jxlt_context* ctx, const uint32_t** dc_histogram);
 int jxlt_pack_sections(jxlt_context* ctx, int kind, const uint32_t* code_table, jxlt_packed_sections* out);
 /* The same in two steps, so that the (large) AC blob can land directly where the caller is
  * assembling the codestream: _sizes runs the kernels and returns offsets/bit counts

@@ -105,6 +105,7 @@ struct jxlt_context {
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   // jxlt_pack_write: packing on `stream`, chunked copies to the destination on `copy_stream`
   hipStream_t copy_stream = nullptr;
+  hipEvent_t dc_hist_ready = nullptr;  // DC histogram of the last enqueue is in h_hist
   static constexpr int kWriteChunks = 4;
   hipEvent_t chunk_packed[kWriteChunks + 1] = {};
   bool copies_pending = false;
@@ -209,6 +210,7 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
   for (auto& ev : ctx->ev) (void)hipEventCreate(&ev);
   for (auto& ev : ctx->stage_done) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   (void)hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+  (void)hipEventCreateWithFlags(&ctx->dc_hist_ready, hipEventDisableTiming);
   for (auto& ev : ctx->chunk_packed) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   *out = ctx;
   return JXLT_OK;
@@ -275,6 +277,7 @@ void jxlt_context_destroy(jxlt_context* ctx) {
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->chunk_packed)
     if (ev) (void)hipEventDestroy(ev);
+  if (ctx->dc_hist_ready) (void)hipEventDestroy(ctx->dc_hist_ready);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -502,11 +505,8 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   hipLaunchKernelGGL(tile_kernel, dim3((unsigned)ntiles), dim3(kTileThreads), 0, ctx->stream, A);
   if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, ctx->stream,
-                     (const uint32_t*)ctx->group_ntok.p, ctx->group_off.p, (int)ngroups);
-  if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-  hipLaunchKernelGGL(token_kernel, dim3((unsigned)ngroups), dim3(kTokenThreads), 0, ctx->stream, K);
-  if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+  // DC-group tokenisation first: it only needs tile_kernel's outputs, and its histogram leaves
+  // for the host at once, so that the DC code is built while token_kernel is still running.
   {
     DcArgs D;
     memset(&D, 0, sizeof(D));
@@ -525,6 +525,18 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
     hipLaunchKernelGGL(dc_elementwise_kernel, dim3((unsigned)(ndc * kDcParts)), dim3(256), 0, ctx->stream, D);
     hipLaunchKernelGGL(dc_chain_kernel, dim3((unsigned)ndc), dim3(kDcChainThreads), 0, ctx->stream, D);
   }
+  if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+  {
+    int rc2;
+    if ((rc2 = EnsurePinned(ctx, &ctx->h_hist, 2 * 64 * 64)) != JXLT_OK) return rc2;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hist.p + 64 * 64, ctx->hist.p + 64 * 64, 64 * 64 * sizeof(uint32_t),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->dc_hist_ready, ctx->stream));
+  }
+  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, ctx->stream,
+                     (const uint32_t*)ctx->group_ntok.p, ctx->group_off.p, (int)ngroups);
+  if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+  hipLaunchKernelGGL(token_kernel, dim3((unsigned)ngroups), dim3(kTokenThreads), 0, ctx->stream, K);
   if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
   HIP_TRY(ctx, hipGetLastError());
   ctx->geom = g;
@@ -636,6 +648,18 @@ int jxlt_fetch_result(jxlt_context* ctx, jxlt_frame_result* out) {
   return JXLT_OK;
 }
 
+int jxlt_fetch_dc_histogram(jxlt_context* ctx, const uint32_t** dc_histogram) {
+  if (!ctx || !dc_histogram) return JXLT_ERR_INVALID_ARGUMENT;
+  if (!ctx->encoded) {
+    ctx->error = "nothing encoded yet";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipEventSynchronize(ctx->dc_hist_ready));
+  *dc_histogram = ctx->h_hist.p + 64 * 64;
+  return JXLT_OK;
+}
+
 int jxlt_fetch_histograms(jxlt_context* ctx, const uint32_t** ac_histograms, const uint32_t** dc_histograms) {
   if (!ctx) return JXLT_ERR_INVALID_ARGUMENT;
   if (!ctx->encoded) {
@@ -648,7 +672,8 @@ int jxlt_fetch_histograms(jxlt_context* ctx, const uint32_t** ac_histograms, con
   int rc;
   if ((rc = EnsurePinned(ctx, &ctx->h_group_off, 2 * (ngroups + 1))) != JXLT_OK) return rc;
   if ((rc = EnsurePinned(ctx, &ctx->h_hist, 2 * 64 * 64)) != JXLT_OK) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hist.p, ctx->hist.p, 2 * 64 * 64 * sizeof(uint32_t), hipMemcpyDeviceToHost,
+  // (the DC half was copied right behind the DC kernels, see jxlt_encode_enqueue)
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hist.p, ctx->hist.p, 64 * 64 * sizeof(uint32_t), hipMemcpyDeviceToHost,
                               ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_group_off.p + ngroups, ctx->group_off.p + ngroups, sizeof(uint64_t),
                               hipMemcpyDeviceToHost, ctx->stream));
@@ -878,7 +903,7 @@ int jxlt_kernel_times(jxlt_context* ctx, jxlt_kernel_time* out, int cap) {
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipEventSynchronize(ctx->ev[4]));
-  static const char* kNames[4] = {"tile_kernel", "group_scan_kernel", "token_kernel", "dc_kernels"};
+  static const char* kNames[4] = {"tile_kernel", "dc_kernels", "group_scan_kernel", "token_kernel"};
   for (int i = 0; i < 4 && i < cap; i++) {
     float ms = 0.0f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));

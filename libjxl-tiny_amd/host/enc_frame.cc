@@ -91,27 +91,40 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
     }
     return true;
   }
-  // The histograms arrive when the device pipeline is done; its duration is the previous
-  // frame's, to a good approximation (same context, usually same geometry).
-  static thread_local double expected_device_ms = 0.0;
-  if (expected_device_ms > 1.0) WarmCodeConstruction(expected_device_ms - 0.5, expected_device_ms + 1.5);
+  // The DC histogram arrives first (the DC-group tokenisation runs ahead of the AC one): the DC
+  // code is built while the device is still tokenising.  The arrival times are the previous
+  // frame's, to a good approximation (same context, usually same geometry); the helper threads
+  // of the code construction are woken just before (entropy_coder.h).
+  static thread_local double expected_dc_ms = 0.0, expected_ac_ms = 0.0;
+  EntropyCode ac_code, dc_code;
+  std::vector<uint32_t> ac_table(64 * 64), dc_table(64 * 64);
+  if (expected_dc_ms > 1.0) WarmCodeConstruction(expected_dc_ms - 0.5, expected_dc_ms + 1.5);
   const uint32_t *ac_hist = nullptr, *dc_hist = nullptr;
-  if (jxlt_fetch_histograms(ctx, &ac_hist, &dc_hist) != JXLT_OK) {
+  if (jxlt_fetch_dc_histogram(ctx, &dc_hist) != JXLT_OK) {
+    fprintf(stderr, "jxl_tiny_amd: fetch failed: %s\n", jxlt_last_error(ctx));
+    return false;
+  }
+  const auto t0a = now();
+  expected_dc_ms = ms(t0, t0a);
+  BuildDcCode(dc_hist, &dc_code);
+  FillCodeTable(dc_code, dc_table.data());
+  const auto t0b = now();
+  {
+    const double left = expected_ac_ms - ms(t0, t0b);  // until the AC histogram is expected
+    if (expected_ac_ms > 1.0) WarmCodeConstruction(left > 0.5 ? left - 0.5 : 0.0, (left > 0.0 ? left : 0.0) + 1.5);
+  }
+  if (jxlt_fetch_histograms(ctx, &ac_hist, nullptr) != JXLT_OK) {
     fprintf(stderr, "jxl_tiny_amd: fetch failed: %s\n", jxlt_last_error(ctx));
     return false;
   }
   const auto t1 = now();
-  expected_device_ms = ms(t0, t1);
-  EntropyCode ac_code, dc_code;
-  std::vector<uint32_t> ac_table(64 * 64), dc_table(64 * 64);
-  // (each construction spreads its cost evaluations over the helper pool of entropy_coder.cc)
+  expected_ac_ms = ms(t0, t1);
   BuildAcCode(ac_hist, &ac_code);
-  const auto t1a = now();
   FillCodeTable(ac_code, ac_table.data());
-  BuildDcCode(dc_hist, &dc_code);
-  FillCodeTable(dc_code, dc_table.data());
   const auto t2 = now();
-  if (trace) fprintf(stderr, "jxlt trace: codes: ac %.3f ms | dc + tables %.3f ms\n", ms(t1, t1a), ms(t1a, t2));
+  if (trace)
+    fprintf(stderr, "jxlt trace: dc histogram after %.2f ms, dc code %.3f ms (overlapped) | ac code %.3f ms\n",
+            ms(t0, t0a), ms(t0a, t0b), ms(t1, t2));
   // One pass measures every section (all the TOC needs); then the device entropy-codes the
   // sections straight to their final byte offsets and copies them to where the frame is being
   // assembled, while the host builds header and TOC.
