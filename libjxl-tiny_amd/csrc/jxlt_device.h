@@ -1574,7 +1574,7 @@ __global__ void group_scan_kernel(const uint32_t* counts, uint64_t* offsets, int
 constexpr int kTokenThreads = 512;
 
 __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A) {
-  __shared__ uint32_t offs[3072 + 1];   // token offset of every (block, channel) entry
+  __shared__ uint32_t offs[1024 + 1];   // token offset of every block's first entry (exclusive scan)
   __shared__ uint32_t meta[3072];       // strategy byte | nzeros << 8 | nscan << 16
   __shared__ uint32_t wsum[kTokenThreads / 64];
   __shared__ uint32_t hist[64 * 64];
@@ -1598,7 +1598,6 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   const int bx0 = ggx * 32, by0 = ggy * 32;
   const int nbx = imin(32, A.g.xsize_blocks - bx0), nby = imin(32, A.g.ysize_blocks - by0);
   const size_t bstride = (size_t)A.g.xsize_blocks;
-  const int nent = nbx * nby * 3;  // entries in stream order: (by, bx, ci), channels Y, X, B
 
   // token count + metadata per entry; predicted-nzeros grid of the group -> LDS
   const int nblk = nbx * nby;
@@ -1607,6 +1606,7 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     const size_t pos = (size_t)(by0 + by) * bstride + bx0 + bx;
     const uint32_t a = A.strategy[pos];
     const int covered = (a >> 1) == 0 ? 1 : 2;
+    uint32_t nsum = 0;
 #pragma unroll
     for (int ci = 0; ci < 3; ci++) {
       const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
@@ -1616,17 +1616,18 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
         n = 1 + (nscan > (uint32_t)covered ? nscan - covered : 0);
         m = a | ((uint32_t)A.blk_nz[pos * 3 + c] << 8) | (nscan << 16);
       }
-      offs[b * 3 + ci + 1] = n;
+      nsum += n;
       meta[b * 3 + ci] = m;
       s_nzg[c * 1024 + b] = A.nzgrid[c][pos];
     }
+    offs[b + 1] = nsum;
   }
   if (tid == 0) offs[0] = 0;
   __syncthreads();
-  // inclusive scan over offs[1..nent] (blocked: each thread owns a contiguous run)
+  // inclusive scan over offs[1..nblk] (blocked: each thread owns a contiguous run)
   {
-    const int per = (nent + kTokenThreads - 1) / kTokenThreads;
-    const int beg = 1 + tid * per, end = imin(1 + nent, beg + per);
+    const int per = (nblk + kTokenThreads - 1) / kTokenThreads;
+    const int beg = 1 + tid * per, end = imin(1 + nblk, beg + per);
     uint32_t s = 0;
     for (int i = beg; i < end; i++) s += offs[i];
     uint32_t incl = s;
@@ -1676,6 +1677,7 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     }
     if (b + kWaves < nblk) load_block(b + kWaves, bx, by, next_v);
     const size_t pos = (size_t)(by0 + cby) * bstride + bx0 + cbx;
+    uint32_t tok_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)offs[b]);  // first token of the block
 #pragma unroll
     for (int ci = 0; ci < 3; ci++) {
       const int e = b * 3 + ci;
@@ -1688,9 +1690,10 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
       const int log2c = covered == 1 ? 0 : 1;
       const int size = covered * 64;
       const size_t pos1 = pos + (st == 1 ? bstride : 1);
-      const uint32_t tok0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)offs[e]);
       const int nzeros = (int)((m >> 8) & 0xFF);
       const int nscan = (int)(m >> 16);
+      const uint32_t tok0 = tok_next;
+      tok_next += 1 + (nscan > covered ? nscan - covered : 0);
       // block context (ac_context.h:64-114): kBlockContextMap[c*27 + code] is 0/1 for Y and
       // 2/3 for X,B, the odd value for the two-block strategy codes 6 and 7
       const int block_ctx = (c == 1 ? 0 : 2) + (st == 0 ? 0 : 1);
