@@ -3,13 +3,14 @@
 
 One "step" = one full encode of a synthetic linear-sRGB frame that is already
 resident in HBM as three planar f32 planes, ending with the complete .jxl
-codestream bytes in host memory:
+codestream bytes in host memory (jxlt_encode_resident_view):
   device   tile_kernel (XYB, adaptive quant, chroma-from-luma, strategy search, quantise)
-           group_scan_kernel, token_kernel (+ AC symbol histograms)
-           dc_elementwise_kernel, dc_chain_kernel (DC-group tokens + DC histograms)
-  host     32 KB of histograms D2H -> histogram clustering + Huffman codes (two threads)
-  device   pack_kernel / compact_kernel for the DC-group and AC-group sections
-  host     D2H of the packed sections, frame header + TOC + global sections, one copy
+           dc_elementwise_kernel, dc_chain_kernel (DC-group tokens + DC histogram)
+           group_scan_kernel, token_kernel (AC tokens + AC histogram)
+  host     DC histogram D2H -> DC code (while token_kernel runs); AC histogram D2H -> AC code
+  device   pack_tile_measure (exact section sizes) -> pack_tile_write (sections at their final
+           bit positions), copied in ranges to the page-locked output buffer while the host
+           writes frame header + TOC + global sections in front of them
 PFM file I/O and the H2D upload are outside the timed region (DESIGN.md quotes
 the PCIe-inclusive rate separately).
 
@@ -67,7 +68,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=16384, help="frame is size x size pixels")
     ap.add_argument("--distance", type=float, default=1.0)
-    ap.add_argument("--cpu-sample", type=int, default=4096,
+    ap.add_argument("--cpu-sample", type=int, default=8192,
                     help="edge of the top-left crop the CPU oracle encodes (baseline + parity gate)")
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--shard-frame", action="store_true",
@@ -125,9 +126,15 @@ def main():
     for _ in range(args.warmup):
         jxl = step()
     barrier()
+    # Per-stage device times of the timed steps themselves: HIP events that the C ABI records on
+    # the encoder's own stream around every stage of every encode (read after each step).
+    ktimes = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         jxl = step()
+        if sharded is None:
+            for k, v in enc.kernel_times().items():
+                ktimes[k] = ktimes.get(k, 0.0) + v / args.steps
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -135,15 +142,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- per-kernel timing on the encoder's own stream (HIP events), device-only rate
-    ktimes = {}
+    # ---- device-only rate (the pipeline without code construction and packing)
     reps = max(3, args.steps)
-    dev_t0 = None
-    for i in range(reps):
-        enc.enqueue(args.distance, pkg.FLAG_PROFILE)
-        enc.synchronize()
-        for k, v in enc.kernel_times().items():
-            ktimes[k] = ktimes.get(k, 0.0) + v / reps
+    if not ktimes:  # sharded steps: separate passes
+        for i in range(reps):
+            enc.enqueue(args.distance, 0)
+            enc.synchronize()
+            for k, v in enc.kernel_times().items():
+                ktimes[k] = ktimes.get(k, 0.0) + v / reps
     t1 = time.perf_counter()
     for i in range(reps):
         enc.enqueue(args.distance, 0)

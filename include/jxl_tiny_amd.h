@@ -165,8 +165,9 @@ int jxlt_pack_measure(jxlt_context* ctx, const uint32_t* dc_code_table, const ui
                       jxlt_packed_sections* dc, jxlt_packed_sections* ac);
 int jxlt_pack_write(jxlt_context* ctx, uint8_t* dc_dst, uint8_t* ac_dst);
 
-/* Timing of the kernels of the last jxlt_encode_enqueue (needs JXLT_FLAG_PROFILE):
- * writes up to `cap` entries; returns the number of kernels, or < 0. */
+/* Timing of the device stages of the last jxlt_encode_enqueue (HIP events on the context's
+ * stream, always recorded): writes up to `cap` entries; returns the number of stages, or < 0.
+ * Waits for the device pipeline of that encode. */
 typedef struct {
   const char* name;
   float milliseconds;

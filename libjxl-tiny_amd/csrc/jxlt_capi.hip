@@ -502,9 +502,9 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   HIP_TRY(ctx, hipMemsetAsync(ctx->group_ntok.p, 0, ngroups * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->hist.p, 0, 2 * 64 * 64 * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->dc_nac.p, 0, ndc * sizeof(uint32_t), ctx->stream));
-  if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   hipLaunchKernelGGL(tile_kernel, dim3((unsigned)ntiles), dim3(kTileThreads), 0, ctx->stream, A);
-  if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
   // DC-group tokenisation first: it only needs tile_kernel's outputs, and its histogram leaves
   // for the host at once, so that the DC code is built while token_kernel is still running.
   {
@@ -525,7 +525,7 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
     hipLaunchKernelGGL(dc_elementwise_kernel, dim3((unsigned)(ndc * kDcParts)), dim3(256), 0, ctx->stream, D);
     hipLaunchKernelGGL(dc_chain_kernel, dim3((unsigned)ndc), dim3(kDcChainThreads), 0, ctx->stream, D);
   }
-  if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
   {
     int rc2;
     if ((rc2 = EnsurePinned(ctx, &ctx->h_hist, 2 * 64 * 64)) != JXLT_OK) return rc2;
@@ -535,16 +535,16 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   }
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, ctx->stream,
                      (const uint32_t*)ctx->group_ntok.p, ctx->group_off.p, (int)ngroups);
-  if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
   hipLaunchKernelGGL(token_kernel, dim3((unsigned)ngroups), dim3(kTokenThreads), 0, ctx->stream, K);
-  if (profile) HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
   HIP_TRY(ctx, hipGetLastError());
   ctx->geom = g;
   ctx->encoded = true;
   ctx->offsets_fetched = false;
   ctx->pack[0].measured_sections = ctx->pack[1].measured_sections = 0;
   ctx->last_flags = params->flags;
-  ctx->profiled = profile;
+  ctx->profiled = true;  // the five stage events are always recorded (a few microseconds per frame)
   return JXLT_OK;
 }
 
@@ -898,7 +898,7 @@ int jxlt_pack_ac_sections(jxlt_context* ctx, const uint32_t* code_table, jxlt_pa
 int jxlt_kernel_times(jxlt_context* ctx, jxlt_kernel_time* out, int cap) {
   if (!ctx || !out || cap < 0) return JXLT_ERR_INVALID_ARGUMENT;
   if (!ctx->profiled) {
-    ctx->error = "last encode was not run with JXLT_FLAG_PROFILE";
+    ctx->error = "nothing encoded yet";
     return JXLT_ERR_INVALID_ARGUMENT;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
