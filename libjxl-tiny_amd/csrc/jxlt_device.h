@@ -108,25 +108,6 @@ struct TokenArgs {
 
 JXLT_DI float fma32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 JXLT_DI float nfma32(float a, float b, float c) { return __builtin_fmaf(-a, b, c); }
-
-// Two independent binary32 values processed by one packed instruction (v_pk_mul_f32,
-// v_pk_add_f32, v_pk_fma_f32: same IEEE results per component as the scalar forms, twice the
-// rate).  The CPU model of the kernels (tests/hipsim) uses the plain two-float struct.
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef float f2 __attribute__((ext_vector_type(2)));
-JXLT_DI f2 f2_make(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
-JXLT_DI f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-JXLT_DI f2 f2_nfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(-a, b, c); }
-#else
-struct f2 { float x, y; };
-JXLT_DI f2 f2_make(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
-JXLT_DI f2 operator+(f2 a, f2 b) { return f2_make(a.x + b.x, a.y + b.y); }
-JXLT_DI f2 operator-(f2 a, f2 b) { return f2_make(a.x - b.x, a.y - b.y); }
-JXLT_DI f2 operator*(f2 a, f2 b) { return f2_make(a.x * b.x, a.y * b.y); }
-JXLT_DI f2 f2_fma(f2 a, f2 b, f2 c) { return f2_make(__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)); }
-JXLT_DI f2 f2_nfma(f2 a, f2 b, f2 c) { return f2_make(__builtin_fmaf(-a.x, b.x, c.x), __builtin_fmaf(-a.y, b.y, c.y)); }
-#endif
-JXLT_DI f2 f2_splat(float a) { return f2_make(a, a); }
 JXLT_DI float zero_if_negative(float v) {
   // sign bit set -> +0: as a signed integer every such pattern is negative (one v_max_i32)
   const int bits = __float_as_int(v);
@@ -271,50 +252,6 @@ JXLT_DI float cube_root_and_add(float x, float add) {
   return r;
 }
 
-// cube_root_and_add for two values at once
-JXLT_DI int cube_root_seed(float x) {
-  const int32_t m1 = __float_as_int(x);
-  return (m1 == 0) ? 0 : (int32_t)(0x54800000u - (uint32_t)(m1 >> 23) * 0x002AAAAAu);
-}
-JXLT_DI f2 cube_root_and_add2(f2 x, float add) {
-  const f2 k1_3 = f2_splat(1.0f / 3), k4_3 = f2_splat(4.0f / 3);
-  const f2 xa_3 = k1_3 * x;
-  f2 r = f2_make(__int_as_float(cube_root_seed(x.x)), __int_as_float(cube_root_seed(x.y)));
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-    const f2 r2 = r * r;
-    r = f2_nfma(xa_3, r2 * r2, k4_3 * r);
-  }
-  f2 r2 = r * r;
-  r = f2_fma(k1_3, f2_nfma(x, r2 * r2, r), r);
-  r2 = r * r;
-  r = f2_fma(r2, x, f2_splat(add));
-  return r;
-}
-
-// linear_to_xyb for two pixels at once (same arithmetic per pixel)
-JXLT_DI void linear_to_xyb2(f2 r, f2 g, f2 b, f2* ox, f2* oy, f2* ob) {
-  const float kM02 = 0.078f, kM00 = 0.30f, kM01 = 1.0f - kM02 - kM00;
-  const float kM12 = 0.078f, kM10 = 0.23f, kM11 = 1.0f - kM12 - kM10;
-  const float kM20 = 0.24342268924547819f, kM21 = 0.20476744424496821f,
-              kM22 = 1.0f - kM20 - kM21;
-  const f2 bias = f2_splat(0.0037930732552754493f);
-  const float neg_bias_cbrt = -0.15595420054f;
-  f2 mixed0 = f2_fma(f2_splat(kM00), r, f2_fma(f2_splat(kM01), g, f2_fma(f2_splat(kM02), b, bias)));
-  f2 mixed1 = f2_fma(f2_splat(kM10), r, f2_fma(f2_splat(kM11), g, f2_fma(f2_splat(kM12), b, bias)));
-  f2 mixed2 = f2_fma(f2_splat(kM20), r, f2_fma(f2_splat(kM21), g, f2_fma(f2_splat(kM22), b, bias)));
-  mixed0 = f2_make(zero_if_negative(mixed0.x), zero_if_negative(mixed0.y));
-  mixed1 = f2_make(zero_if_negative(mixed1.x), zero_if_negative(mixed1.y));
-  mixed2 = f2_make(zero_if_negative(mixed2.x), zero_if_negative(mixed2.y));
-  const f2 tm0 = cube_root_and_add2(mixed0, neg_bias_cbrt);
-  const f2 tm1 = cube_root_and_add2(mixed1, neg_bias_cbrt);
-  const f2 tm2 = cube_root_and_add2(mixed2, neg_bias_cbrt);
-  const f2 half = f2_splat(0.5f);
-  *ox = half * (tm0 - tm1);
-  *oy = half * (tm0 + tm1);
-  *ob = tm2;
-}
-
 // enc_xyb.cc:30-81
 JXLT_DI void linear_to_xyb(float r, float g, float b, float* ox, float* oy, float* ob) {
   const float kM02 = 0.078f, kM00 = 0.30f, kM01 = 1.0f - kM02 - kM00;
@@ -419,11 +356,13 @@ JXLT_DI void octet_exchange(float& a, float& b, int l) {
 // still live: 44 instructions per transpose), and the transposes are half of the transform
 // phases' VALU work.  bound_ctrl makes an out-of-row source read 0 (those lanes select src1).
 // The producers of a DPP operand are always >= 3 instructions back inside the block; the
-// leading s_nop covers the caller's last writes.  The CPU model runs the generic exchanges.
+// leading s_nop covers the caller's last writes.  The input registers double as the second
+// stage's destination (16 registers in all).  The CPU model runs the generic exchanges.
 JXLT_DI void octet_transpose(float* v, int l) {
 #if defined(__HIP_DEVICE_COMPILE__)
   (void)l;
-  float o0, o1, o2, o3, o4, o5, o6, o7, u0, u1, u2, u3, u4, u5, u6, u7;
+  float o0, o1, o2, o3, o4, o5, o6, o7;
+  float i0 = v[0], i1 = v[1], i2 = v[2], i3 = v[3], i4 = v[4], i5 = v[5], i6 = v[6], i7 = v[7];  // also stage-2 results
   const unsigned long long lo4 = 0x0F0F0F0F0F0F0F0Full, lo2 = 0x3333333333333333ull, lo1 = 0x5555555555555555ull;
   const unsigned long long hi4 = ~lo4, hi2 = ~lo2, hi1 = ~lo1;
 #define JXLT_SHR4 " row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -444,32 +383,30 @@ JXLT_DI void octet_transpose(float* v, int l) {
       "v_cndmask_b32_dpp %[o7], %[i3], %[i7], vcc" JXLT_SHL4
       // distance 2: pairs (0,2) (1,3) (4,6) (5,7)
       "s_mov_b64 vcc, %[lo2]\n\t"
-      "v_cndmask_b32_dpp %[u0], %[o2], %[o0], vcc" JXLT_QP2
-      "v_cndmask_b32_dpp %[u1], %[o3], %[o1], vcc" JXLT_QP2
-      "v_cndmask_b32_dpp %[u4], %[o6], %[o4], vcc" JXLT_QP2
-      "v_cndmask_b32_dpp %[u5], %[o7], %[o5], vcc" JXLT_QP2
+      "v_cndmask_b32_dpp %[i0], %[o2], %[o0], vcc" JXLT_QP2
+      "v_cndmask_b32_dpp %[i1], %[o3], %[o1], vcc" JXLT_QP2
+      "v_cndmask_b32_dpp %[i4], %[o6], %[o4], vcc" JXLT_QP2
+      "v_cndmask_b32_dpp %[i5], %[o7], %[o5], vcc" JXLT_QP2
       "s_mov_b64 vcc, %[hi2]\n\t"
-      "v_cndmask_b32_dpp %[u2], %[o0], %[o2], vcc" JXLT_QP2
-      "v_cndmask_b32_dpp %[u3], %[o1], %[o3], vcc" JXLT_QP2
-      "v_cndmask_b32_dpp %[u6], %[o4], %[o6], vcc" JXLT_QP2
-      "v_cndmask_b32_dpp %[u7], %[o5], %[o7], vcc" JXLT_QP2
+      "v_cndmask_b32_dpp %[i2], %[o0], %[o2], vcc" JXLT_QP2
+      "v_cndmask_b32_dpp %[i3], %[o1], %[o3], vcc" JXLT_QP2
+      "v_cndmask_b32_dpp %[i6], %[o4], %[o6], vcc" JXLT_QP2
+      "v_cndmask_b32_dpp %[i7], %[o5], %[o7], vcc" JXLT_QP2
       // distance 1: pairs (0,1) (2,3) (4,5) (6,7)
       "s_mov_b64 vcc, %[lo1]\n\t"
-      "v_cndmask_b32_dpp %[o0], %[u1], %[u0], vcc" JXLT_QP1
-      "v_cndmask_b32_dpp %[o2], %[u3], %[u2], vcc" JXLT_QP1
-      "v_cndmask_b32_dpp %[o4], %[u5], %[u4], vcc" JXLT_QP1
-      "v_cndmask_b32_dpp %[o6], %[u7], %[u6], vcc" JXLT_QP1
+      "v_cndmask_b32_dpp %[o0], %[i1], %[i0], vcc" JXLT_QP1
+      "v_cndmask_b32_dpp %[o2], %[i3], %[i2], vcc" JXLT_QP1
+      "v_cndmask_b32_dpp %[o4], %[i5], %[i4], vcc" JXLT_QP1
+      "v_cndmask_b32_dpp %[o6], %[i7], %[i6], vcc" JXLT_QP1
       "s_mov_b64 vcc, %[hi1]\n\t"
-      "v_cndmask_b32_dpp %[o1], %[u0], %[u1], vcc" JXLT_QP1
-      "v_cndmask_b32_dpp %[o3], %[u2], %[u3], vcc" JXLT_QP1
-      "v_cndmask_b32_dpp %[o5], %[u4], %[u5], vcc" JXLT_QP1
-      "v_cndmask_b32_dpp %[o7], %[u6], %[u7], vcc" JXLT_QP1
+      "v_cndmask_b32_dpp %[o1], %[i0], %[i1], vcc" JXLT_QP1
+      "v_cndmask_b32_dpp %[o3], %[i2], %[i3], vcc" JXLT_QP1
+      "v_cndmask_b32_dpp %[o5], %[i4], %[i5], vcc" JXLT_QP1
+      "v_cndmask_b32_dpp %[o7], %[i6], %[i7], vcc" JXLT_QP1
       : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [o4] "=&v"(o4), [o5] "=&v"(o5),
-        [o6] "=&v"(o6), [o7] "=&v"(o7), [u0] "=&v"(u0), [u1] "=&v"(u1), [u2] "=&v"(u2), [u3] "=&v"(u3),
-        [u4] "=&v"(u4), [u5] "=&v"(u5), [u6] "=&v"(u6), [u7] "=&v"(u7)
-      : [i0] "v"(v[0]), [i1] "v"(v[1]), [i2] "v"(v[2]), [i3] "v"(v[3]), [i4] "v"(v[4]), [i5] "v"(v[5]),
-        [i6] "v"(v[6]), [i7] "v"(v[7]), [lo4] "s"(lo4), [hi4] "s"(hi4), [lo2] "s"(lo2), [hi2] "s"(hi2),
-        [lo1] "s"(lo1), [hi1] "s"(hi1)
+        [o6] "=&v"(o6), [o7] "=&v"(o7), [i0] "+v"(i0), [i1] "+v"(i1), [i2] "+v"(i2), [i3] "+v"(i3),
+        [i4] "+v"(i4), [i5] "+v"(i5), [i6] "+v"(i6), [i7] "+v"(i7)
+      : [lo4] "s"(lo4), [hi4] "s"(hi4), [lo2] "s"(lo2), [hi2] "s"(hi2), [lo1] "s"(lo1), [hi1] "s"(hi1)
       : "vcc");
 #undef JXLT_SHR4
 #undef JXLT_SHL4
@@ -931,9 +868,8 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
   if (tid < 192) S.order[tid] = T->coeff_order[tid];
   {
     // 16 lanes along x, 32 rows per pass: a thread owns 5 columns x 2 rows of the
-    // (64 + 2*kHalo)-wide window, so the row and column clamps are shared, the two rows of a
-    // column go through the colour transform as one packed pair, and all thirty loads are in
-    // flight before the first use.
+    // (64 + 2*kHalo)-wide window, so the row and column clamps are shared and all thirty loads
+    // are in flight before the first use.
     constexpr int kWin = 64 + 2 * kHalo;
     const int base = px0 - kHalo;  // stripe x of LDS column 0
     const int lx = tid & 15, ly = tid >> 4;
@@ -948,28 +884,33 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
       rowp[h][1] = A.planes[1] + off;
       rowp[h][2] = A.planes[2] + off;
     }
-    f2 pr[5], pg[5], pb[5];
+    // (scalar arithmetic on purpose: on gfx950 a packed v_pk_*_f32 costs at least as much as its
+    // two scalar halves -- tools/pk_probe.hip -- and the packed variant of this loop measured
+    // 3 % slower for the whole kernel)
+    float pr[5][2], pg[5][2], pb[5][2];
     bool xok[5];
 #pragma unroll
     for (int j = 0; j < 5; j++) {
       const int cx = lx + 16 * j, x = base + cx;
       xok[j] = cx < kWin && x >= 0 && x < swp && x < px0 + nbx * 8 + kHalo;
       const int xs = xok[j] ? imin(x, sw - 1) : 0;
-      pr[j] = f2_make(rowp[0][0][xs], rowp[1][0][xs]);
-      pg[j] = f2_make(rowp[0][1][xs], rowp[1][1][xs]);
-      pb[j] = f2_make(rowp[0][2][xs], rowp[1][2][xs]);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        pr[j][h] = rowp[h][0][xs];
+        pg[j][h] = rowp[h][1][xs];
+        pb[j][h] = rowp[h][2][xs];
+      }
     }
 #pragma unroll
     for (int j = 0; j < 5; j++) {
       if (!xok[j]) continue;
       const int cx = lx + 16 * j;
-      f2 vx, vy, vb;
-      linear_to_xyb2(pr[j], pg[j], pb[j], &vx, &vy, &vb);
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         if (!yok[h]) continue;
         const int y = ly + 32 * h;
-        const float px_ = h ? vx.y : vx.x, py_ = h ? vy.y : vy.x, pb_ = h ? vb.y : vb.x;
+        float px_, py_, pb_;
+        linear_to_xyb(pr[j][h], pg[j][h], pb[j][h], &px_, &py_, &pb_);
         S.x[y * kXYPitch + cx] = px_;
         S.y[y * kXYPitch + cx] = py_;
         if (cx >= kHalo && cx < kHalo + 64) S.b[y * kBPitch + cx - kHalo] = pb_;
