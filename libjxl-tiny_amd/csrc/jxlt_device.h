@@ -108,6 +108,8 @@ struct TokenArgs {
 
 JXLT_DI float fma32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 JXLT_DI float nfma32(float a, float b, float c) { return __builtin_fmaf(-a, b, c); }
+// min(max(x, 0), 1): folds into the clamp modifier of the instruction that produces x.
+JXLT_DI float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 JXLT_DI float zero_if_negative(float v) {
   // sign bit set -> +0: as a signed integer every such pattern is negative (one v_max_i32)
   const int bits = __float_as_int(v);
@@ -348,73 +350,10 @@ JXLT_DI void octet_exchange(float& a, float& b, int l) {
 
 // 8x8 transpose across the 8 lanes of an octet: lane l holds v[j] = M[j][l] and
 // ends with v[j] = M[l][j].  Three butterfly stages, static register indices.
-//
-// On the GPU the whole transpose is one assembly block of 24 v_cndmask_b32_dpp: each new value
-// is a select fused with the lane permutation, D = vcc ? src1 : dpp(src0) with vcc = the lanes
-// that keep their own value.  The compiler does not form this instruction from the builtins
-// (it emits a DPP move plus a select, and a copy where the DPP move's tied destination is
-// still live: 44 instructions per transpose), and the transposes are half of the transform
-// phases' VALU work.  bound_ctrl makes an out-of-row source read 0 (those lanes select src1).
-// The producers of a DPP operand are always >= 3 instructions back inside the block; the
-// leading s_nop covers the caller's last writes.  The input registers double as the second
-// stage's destination (16 registers in all).  The CPU model runs the generic exchanges.
+// (Measured alternatives, both slower on gfx950: one assembly block of 24 fused
+// v_cndmask_b32_dpp -- a VOP2 select whose mask does not come from a VALU compare is very slow,
+// tools/op_probe.hip -- and a round trip through a private LDS scratch of the octet.)
 JXLT_DI void octet_transpose(float* v, int l) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  (void)l;
-  float o0, o1, o2, o3, o4, o5, o6, o7;
-  float i0 = v[0], i1 = v[1], i2 = v[2], i3 = v[3], i4 = v[4], i5 = v[5], i6 = v[6], i7 = v[7];  // also stage-2 results
-  const unsigned long long lo4 = 0x0F0F0F0F0F0F0F0Full, lo2 = 0x3333333333333333ull, lo1 = 0x5555555555555555ull;
-  const unsigned long long hi4 = ~lo4, hi2 = ~lo2, hi1 = ~lo1;
-#define JXLT_SHR4 " row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-#define JXLT_SHL4 " row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-#define JXLT_QP2 " quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-#define JXLT_QP1 " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-  asm("s_nop 1\n\t"
-      // distance 4: pairs (0,4) (1,5) (2,6) (3,7)
-      "s_mov_b64 vcc, %[lo4]\n\t"
-      "v_cndmask_b32_dpp %[o0], %[i4], %[i0], vcc" JXLT_SHR4
-      "v_cndmask_b32_dpp %[o1], %[i5], %[i1], vcc" JXLT_SHR4
-      "v_cndmask_b32_dpp %[o2], %[i6], %[i2], vcc" JXLT_SHR4
-      "v_cndmask_b32_dpp %[o3], %[i7], %[i3], vcc" JXLT_SHR4
-      "s_mov_b64 vcc, %[hi4]\n\t"
-      "v_cndmask_b32_dpp %[o4], %[i0], %[i4], vcc" JXLT_SHL4
-      "v_cndmask_b32_dpp %[o5], %[i1], %[i5], vcc" JXLT_SHL4
-      "v_cndmask_b32_dpp %[o6], %[i2], %[i6], vcc" JXLT_SHL4
-      "v_cndmask_b32_dpp %[o7], %[i3], %[i7], vcc" JXLT_SHL4
-      // distance 2: pairs (0,2) (1,3) (4,6) (5,7)
-      "s_mov_b64 vcc, %[lo2]\n\t"
-      "v_cndmask_b32_dpp %[i0], %[o2], %[o0], vcc" JXLT_QP2
-      "v_cndmask_b32_dpp %[i1], %[o3], %[o1], vcc" JXLT_QP2
-      "v_cndmask_b32_dpp %[i4], %[o6], %[o4], vcc" JXLT_QP2
-      "v_cndmask_b32_dpp %[i5], %[o7], %[o5], vcc" JXLT_QP2
-      "s_mov_b64 vcc, %[hi2]\n\t"
-      "v_cndmask_b32_dpp %[i2], %[o0], %[o2], vcc" JXLT_QP2
-      "v_cndmask_b32_dpp %[i3], %[o1], %[o3], vcc" JXLT_QP2
-      "v_cndmask_b32_dpp %[i6], %[o4], %[o6], vcc" JXLT_QP2
-      "v_cndmask_b32_dpp %[i7], %[o5], %[o7], vcc" JXLT_QP2
-      // distance 1: pairs (0,1) (2,3) (4,5) (6,7)
-      "s_mov_b64 vcc, %[lo1]\n\t"
-      "v_cndmask_b32_dpp %[o0], %[i1], %[i0], vcc" JXLT_QP1
-      "v_cndmask_b32_dpp %[o2], %[i3], %[i2], vcc" JXLT_QP1
-      "v_cndmask_b32_dpp %[o4], %[i5], %[i4], vcc" JXLT_QP1
-      "v_cndmask_b32_dpp %[o6], %[i7], %[i6], vcc" JXLT_QP1
-      "s_mov_b64 vcc, %[hi1]\n\t"
-      "v_cndmask_b32_dpp %[o1], %[i0], %[i1], vcc" JXLT_QP1
-      "v_cndmask_b32_dpp %[o3], %[i2], %[i3], vcc" JXLT_QP1
-      "v_cndmask_b32_dpp %[o5], %[i4], %[i5], vcc" JXLT_QP1
-      "v_cndmask_b32_dpp %[o7], %[i6], %[i7], vcc" JXLT_QP1
-      : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [o4] "=&v"(o4), [o5] "=&v"(o5),
-        [o6] "=&v"(o6), [o7] "=&v"(o7), [i0] "+v"(i0), [i1] "+v"(i1), [i2] "+v"(i2), [i3] "+v"(i3),
-        [i4] "+v"(i4), [i5] "+v"(i5), [i6] "+v"(i6), [i7] "+v"(i7)
-      : [lo4] "s"(lo4), [hi4] "s"(hi4), [lo2] "s"(lo2), [hi2] "s"(hi2), [lo1] "s"(lo1), [hi1] "s"(hi1)
-      : "vcc");
-#undef JXLT_SHR4
-#undef JXLT_SHL4
-#undef JXLT_QP2
-#undef JXLT_QP1
-  v[0] = o0; v[1] = o1; v[2] = o2; v[3] = o3;
-  v[4] = o4; v[5] = o5; v[6] = o6; v[7] = o7;
-#else
   octet_exchange<4>(v[0], v[4], l);
   octet_exchange<4>(v[1], v[5], l);
   octet_exchange<4>(v[2], v[6], l);
@@ -427,7 +366,6 @@ JXLT_DI void octet_transpose(float* v, int l) {
   octet_exchange<1>(v[2], v[3], l);
   octet_exchange<1>(v[4], v[5], l);
   octet_exchange<1>(v[6], v[7], l);
-#endif
 }
 
 // Block transforms.  `px` points at the block's top-left sample in an LDS plane
@@ -631,6 +569,10 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
     const float cmap_factor = c == 0 ? cmap_x : c == 1 ? 0.0f : cmap_b;
     float entropy_v = 0.0f, nzeros_v = 0.0f;
     JXLT_SCHED_FENCE();
+    // Selects and compares are the expensive kind of VALU instruction on gfx950
+    // (tools/op_probe.hip), multiply-adds with the (free) clamp modifier are not.  With q a
+    // non-negative integer:  [q >= 2] = clamp01(q - 1),  [q >= 1] = clamp01(4 * q),  and
+    // x + (c ? k : 0) == fma(c, k, x) for c in {0, 1}.
 #pragma unroll
     for (int r = 0; r < NR; r++) {
       const float in = cin[r];
@@ -642,11 +584,12 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
       info_loss = info_loss + diff;
       info_loss2 = fma32(diff, diff, info_loss2);
       const float q = fabsf(rval);
-      entropy_v = entropy_v + (q >= 1.5f ? kCost2 : 0.0f);
-      // (a 64-entry LDS table of sqrtf(i) was tried here and measured slower: the random
-      // LDS reads and the extra register pressure cost more than the IEEE sqrt sequence)
+      entropy_v = fma32(clamp01(q - 1.0f), kCost2, entropy_v);  // + (q >= 1.5 ? kCost2 : 0)
+      // (a 64-entry LDS table of sqrtf(i) was tried here and measured slower; so was skipping
+      // the root with a branch where a whole wave has q <= 1: the control flow makes the
+      // register allocator spill)
       entropy_v = fma32(sqrt_exact_midrange(q), kCostDelta, entropy_v);  // q is 0 or an integer >= 1
-      nzeros_v = nzeros_v + fminf(q, 1.0f);  // q is a non-negative integer: 0 -> 0, else 1
+      nzeros_v = nzeros_v + clamp01(4.0f * q);  // + (q == 0 ? 0 : 1)
     }
     entropy_v = fma32(nzeros_v, cost_of_1, entropy_v);
     entropy += octet_sum(entropy_v);
