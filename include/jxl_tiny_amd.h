@@ -104,6 +104,17 @@ void jxlt_pinned_free(void* p);
 int jxlt_image_set_device(jxlt_context* ctx, const void* const device_planes[3],
                           size_t pitch_bytes, size_t xsize, size_t ysize);
 
+/* PFM ingest on the device (read_pfm.cc:199-209 semantics without a host pass over the pixels):
+ * the frame is the sample payload of a PFM file -- xsize * ysize interleaved RGB f32 triples,
+ * bottom row first, byte-reversed when the file is big endian (positive scale line).  The
+ * kernels read it in place.  _upload_pfm copies the payload from host memory (page-locked
+ * memory from jxlt_pinned_alloc goes over PCIe in one piece); _set_device_pfm takes a payload
+ * that already is in device memory (not copied, must stay valid until the encode is done). */
+int jxlt_image_upload_pfm(jxlt_context* ctx, const void* host_payload, size_t xsize, size_t ysize,
+                          int big_endian);
+int jxlt_image_set_device_pfm(jxlt_context* ctx, const void* device_payload, size_t xsize, size_t ysize,
+                              int big_endian);
+
 /* Size of the image currently set on the context. */
 int jxlt_image_size(const jxlt_context* ctx, size_t* xsize, size_t* ysize);
 
@@ -215,6 +226,11 @@ int jxlt_encode_resident_view(jxlt_context* ctx, float distance, int num_threads
 int jxlt_encode_file_planar(const float* const planes[3], size_t pitch_bytes, size_t xsize,
                             size_t ysize, float distance, int device_ordinal,
                             uint8_t** out_bytes, size_t* out_size);
+/* cjxl_tiny's whole job in one call: PFM file -> .jxl codestream (malloc'ed, free with
+ * jxlt_free), with the PFM payload de-interleaved / flipped / byte-swapped by the device
+ * kernels (jxlt_image_upload_pfm) instead of by a host pass. */
+int jxlt_encode_pfm_file(const char* filename, float distance, int device_ordinal, uint8_t** out_bytes,
+                         size_t* out_size);
 /* Codestream + image headers that precede the frame (enc_file.cc:70-95). */
 int jxlt_write_file_header(size_t xsize, size_t ysize, uint8_t** out_bytes, size_t* out_size);
 /* ---- one frame sharded over several contexts / GPUs / processes ----------------

@@ -29,14 +29,14 @@ FLAG_FORCE_DCT8, FLAG_DEBUG_DUMP, FLAG_PROFILE = 1, 2, 4
 
 # Symbols include/jxl_tiny_amd.h declares, per library (checked by the tests).
 HIP_SYMBOLS = ["jxlt_context_create", "jxlt_context_destroy", "jxlt_last_error",
-               "jxlt_image_upload", "jxlt_image_set_device", "jxlt_image_size", "jxlt_pinned_alloc",
+               "jxlt_image_upload", "jxlt_image_set_device", "jxlt_image_upload_pfm", "jxlt_image_set_device_pfm", "jxlt_image_size", "jxlt_pinned_alloc",
                "jxlt_pinned_free", "jxlt_encode_enqueue",
                "jxlt_fetch_side_info", "jxlt_fetch_histograms", "jxlt_fetch_dc_histogram", "jxlt_pack_ac_sections", "jxlt_pack_sections",
                "jxlt_pack_sections_sizes", "jxlt_pack_sections_copy", "jxlt_pack_sections_place", "jxlt_pack_measure", "jxlt_pack_write",
                "jxlt_output_buffer",
                "jxlt_synchronize", "jxlt_fetch_result", "jxlt_kernel_times", "jxlt_debug_fetch"]
 HOST_SYMBOLS = ["jxlt_compute_distance_params", "jxlt_assemble_frame", "jxlt_assemble_frame_groups",
-                "jxlt_encode_file_planar", "jxlt_encode_resident", "jxlt_encode_resident_view", "jxlt_write_file_header", "jxlt_build_code_tables", "jxlt_finish_frame",
+                "jxlt_encode_file_planar", "jxlt_encode_pfm_file", "jxlt_encode_resident", "jxlt_encode_resident_view", "jxlt_write_file_header", "jxlt_build_code_tables", "jxlt_finish_frame",
                 "jxlt_debug_dc_records", "jxlt_free"]
 
 
@@ -391,6 +391,18 @@ def finish_frame(xsize, ysize, distance, ac_hist, dc_hist, dc_sections, ac_secti
                                       C.byref(dcs), C.byref(acs), C.byref(out), C.byref(n))
     if rc != 0:
         raise JxlTinyError("jxlt_finish_frame failed (%d)" % rc)
+    return _take_bytes(out, n)
+
+
+def encode_pfm_file(path, distance, device=0):
+    """cjxl_tiny in one call: PFM file -> .jxl bytes, PFM payload ingested by the device kernels."""
+    L = host_lib()
+    L.jxlt_encode_pfm_file.argtypes = [C.c_char_p, C.c_float, C.c_int, C.POINTER(C.POINTER(C.c_uint8)),
+                                       C.POINTER(C.c_size_t)]
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    rc = L.jxlt_encode_pfm_file(str(path).encode(), C.c_float(distance), device, C.byref(out), C.byref(n))
+    if rc != 0:
+        raise JxlTinyError("jxlt_encode_pfm_file failed (%d)" % rc)
     return _take_bytes(out, n)
 
 

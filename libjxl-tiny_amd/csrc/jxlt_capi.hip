@@ -50,7 +50,10 @@ struct jxlt_context {
   // input image
   DeviceBuf<float> own_planes[3];
   const float* planes[3] = {nullptr, nullptr, nullptr};
-  size_t pitch_floats = 0;
+  ptrdiff_t pitch_floats = 0;  // floats per row (negative for a bottom-up PFM payload)
+  int pix_stride = 1;          // floats between adjacent samples of a plane (3: interleaved RGB)
+  int byteswap = 0;            // big-endian samples
+  DeviceBuf<float> own_payload;  // jxlt_image_upload_pfm
   size_t xsize = 0, ysize = 0;
 
   // pinned staging ring for uploads from pageable memory
@@ -220,6 +223,7 @@ void jxlt_context_destroy(jxlt_context* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  FreeDevice(&ctx->own_payload);
   for (int c = 0; c < 3; c++) {
     FreeDevice(&ctx->own_planes[c]);
     FreeDevice(&ctx->quant_dc[c]);
@@ -339,7 +343,9 @@ int jxlt_image_upload(jxlt_context* ctx, const float* const planes[3], size_t pi
     }
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // caller may reuse its buffers
-  ctx->pitch_floats = pitch_floats;
+  ctx->pitch_floats = (ptrdiff_t)pitch_floats;
+  ctx->pix_stride = 1;
+  ctx->byteswap = 0;
   ctx->xsize = xsize;
   ctx->ysize = ysize;
   ctx->encoded = false;
@@ -369,11 +375,55 @@ int jxlt_image_set_device(jxlt_context* ctx, const void* const device_planes[3],
   int rc = CheckImageArgs(ctx, device_planes, pitch_bytes, xsize, ysize);
   if (rc != JXLT_OK) return rc;
   for (int c = 0; c < 3; c++) ctx->planes[c] = static_cast<const float*>(device_planes[c]);
-  ctx->pitch_floats = pitch_bytes / sizeof(float);
+  ctx->pitch_floats = (ptrdiff_t)(pitch_bytes / sizeof(float));
+  ctx->pix_stride = 1;
+  ctx->byteswap = 0;
   ctx->xsize = xsize;
   ctx->ysize = ysize;
   ctx->encoded = false;
   return JXLT_OK;
+}
+
+namespace {
+// The frame is the sample payload of a PFM file at `payload` (device memory): interleaved RGB
+// f32, bottom row first, byte-reversed if big endian (read_pfm.cc:199-209).  tile_kernel reads
+// it in place: no de-interleaving pass anywhere.
+int SetPfmView(jxlt_context* ctx, const float* payload, size_t xsize, size_t ysize, int big_endian) {
+  for (int c = 0; c < 3; c++) ctx->planes[c] = payload + (ysize - 1) * xsize * 3 + c;
+  ctx->pitch_floats = -(ptrdiff_t)(xsize * 3);
+  ctx->pix_stride = 3;
+  ctx->byteswap = big_endian ? 1 : 0;
+  ctx->xsize = xsize;
+  ctx->ysize = ysize;
+  ctx->encoded = false;
+  return JXLT_OK;
+}
+int CheckPfmArgs(jxlt_context* ctx, const void* payload, size_t xsize, size_t ysize) {
+  if (!ctx) return JXLT_ERR_INVALID_ARGUMENT;
+  const void* const three[3] = {payload, payload, payload};
+  return CheckImageArgs(ctx, three, xsize * 3 * sizeof(float), xsize, ysize);
+}
+}  // namespace
+
+int jxlt_image_set_device_pfm(jxlt_context* ctx, const void* device_payload, size_t xsize, size_t ysize,
+                              int big_endian) {
+  const int rc = CheckPfmArgs(ctx, device_payload, xsize, ysize);
+  if (rc != JXLT_OK) return rc;
+  return SetPfmView(ctx, static_cast<const float*>(device_payload), xsize, ysize, big_endian);
+}
+
+int jxlt_image_upload_pfm(jxlt_context* ctx, const void* host_payload, size_t xsize, size_t ysize,
+                          int big_endian) {
+  int rc = CheckPfmArgs(ctx, host_payload, xsize, ysize);
+  if (rc != JXLT_OK) return rc;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t nfloats = xsize * ysize * 3;
+  if ((rc = EnsureDevice(ctx, &ctx->own_payload, nfloats)) != JXLT_OK) return rc;
+  // one contiguous block: full PCIe rate when `host_payload` is page-locked (jxlt_pinned_alloc)
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->own_payload.p, host_payload, nfloats * sizeof(float), hipMemcpyHostToDevice,
+                              ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // caller may reuse its buffer
+  return SetPfmView(ctx, ctx->own_payload.p, xsize, ysize, big_endian);
 }
 
 int jxlt_image_size(const jxlt_context* ctx, size_t* xsize, size_t* ysize) {
@@ -463,6 +513,8 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
     A.dbg_xyb[c] = debug ? ctx->dbg_xyb[c].p : nullptr;
   }
   A.pitch = ctx->pitch_floats;
+  A.pix_stride = ctx->pix_stride;
+  A.byteswap = ctx->byteswap;
   A.g = g;
   A.distance = params->distance;
   A.scale = params->scale;

@@ -59,8 +59,14 @@ struct FrameGeom {
 };
 
 struct TileArgs {
+  // Input samples: sample (c, y, x) is planes[c][y * pitch + x * pix_stride].  Planar frames use
+  // three base pointers and pix_stride 1; a raw PFM payload (read_pfm.cc:199-209: interleaved
+  // RGB, bottom row first, possibly big endian) is one buffer with pix_stride 3, base pointers
+  // one float apart that point at its LAST row, a negative pitch, and byteswap set.
   const float* planes[3];
-  size_t pitch;  // floats per row
+  ptrdiff_t pitch;  // floats per row (may be negative)
+  int pix_stride;   // floats between horizontally adjacent samples of a plane
+  int byteswap;     // samples are stored byte-reversed
   FrameGeom g;
   float distance, scale, inv_scale, scale_dc;
   float x_qm_mul;  // 1.25^(x_qm_scale-2)
@@ -822,7 +828,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
     for (int h = 0; h < 2; h++) {
       const int y = ly + 32 * h;
       yok[h] = y < shp;
-      const size_t off = (size_t)(sy0 + imin(y, sh - 1)) * A.pitch + (size_t)sx0;
+      const ptrdiff_t off = (ptrdiff_t)(sy0 + imin(y, sh - 1)) * A.pitch + (ptrdiff_t)sx0 * A.pix_stride;
       rowp[h][0] = A.planes[0] + off;
       rowp[h][1] = A.planes[1] + off;
       rowp[h][2] = A.planes[2] + off;
@@ -836,12 +842,23 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
     for (int j = 0; j < 5; j++) {
       const int cx = lx + 16 * j, x = base + cx;
       xok[j] = cx < kWin && x >= 0 && x < swp && x < px0 + nbx * 8 + kHalo;
-      const int xs = xok[j] ? imin(x, sw - 1) : 0;
+      const int xs = (xok[j] ? imin(x, sw - 1) : 0) * A.pix_stride;
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         pr[j][h] = rowp[h][0][xs];
         pg[j][h] = rowp[h][1][xs];
         pb[j][h] = rowp[h][2][xs];
+      }
+    }
+    if (A.byteswap) {  // big-endian PFM payload (BSwapFloat, read_pfm.cc:206)
+#pragma unroll
+      for (int j = 0; j < 5; j++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          pr[j][h] = __uint_as_float(__builtin_bswap32(__float_as_uint(pr[j][h])));
+          pg[j][h] = __uint_as_float(__builtin_bswap32(__float_as_uint(pg[j][h])));
+          pb[j][h] = __uint_as_float(__builtin_bswap32(__float_as_uint(pb[j][h])));
+        }
       }
     }
 #pragma unroll

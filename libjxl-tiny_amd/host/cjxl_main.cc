@@ -1,6 +1,7 @@
 // cjxl_tiny command line: <file in.pfm> [<file out.jxl>] [-d distance]
 // Same interface as /root/reference/encoder/cjxl_main.cc:40-101, plus
-// --device N to pick the GPU.
+// --device N to pick the GPU and --host-ingest to de-interleave the PFM on the host
+// (ReadPFM + EncodeFile, as the reference does) instead of on the device.
 #include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -16,7 +17,7 @@ namespace {
 
 void Usage(const char* arg0) {
   fprintf(stderr,
-          "Usage: %s <file in> [<file out>] [-d distance] [--device N]\n\n"
+          "Usage: %s <file in> [<file out>] [-d distance] [--device N] [--host-ingest]\n\n"
           "  NOTE: <file in> is a .pfm file in linear SRGB colorspace\n",
           arg0);
 }
@@ -42,7 +43,12 @@ int main(int argc, char** argv) {
   const char* file_in = nullptr;
   const char* file_out = nullptr;
   float distance = 1.0f;
+  bool host_ingest = false;
   for (int i = 1; i < argc; i++) {
+    if (!strcmp("--host-ingest", argv[i])) {
+      host_ingest = true;
+      continue;
+    }
     if (!strcmp("-h", argv[i]) || !strcmp("--help", argv[i])) {
       Usage(argv[0]);
       return EXIT_SUCCESS;
@@ -76,16 +82,26 @@ int main(int argc, char** argv) {
     fprintf(stderr, "Missing input file.\n");
     return EXIT_FAILURE;
   }
-  jxl::Image3F image;
-  if (!jxl::ReadPFM(file_in, &image)) {
-    fprintf(stderr, "Error reading PFM input file.\n");
-    return EXIT_FAILURE;
-  }
-  fprintf(stderr, "Read %zux%zu pixels input image.\n", image.xsize(), image.ysize());
   std::vector<uint8_t> output;
-  if (!jxl::EncodeFile(image, distance, &output)) {
-    fprintf(stderr, "Encoding failed.\n");
-    return EXIT_FAILURE;
+  if (host_ingest) {
+    jxl::Image3F image;
+    if (!jxl::ReadPFM(file_in, &image)) {
+      fprintf(stderr, "Error reading PFM input file.\n");
+      return EXIT_FAILURE;
+    }
+    fprintf(stderr, "Read %zux%zu pixels input image.\n", image.xsize(), image.ysize());
+    if (!jxl::EncodeFile(image, distance, &output)) {
+      fprintf(stderr, "Encoding failed.\n");
+      return EXIT_FAILURE;
+    }
+  } else {
+    size_t xsize = 0, ysize = 0;
+    const bool ok = jxl::EncodePFMFile(file_in, distance, &output, &xsize, &ysize);
+    if (xsize) fprintf(stderr, "Read %zux%zu pixels input image.\n", xsize, ysize);
+    if (!ok) {
+      fprintf(stderr, xsize ? "Encoding failed.\n" : "Error reading PFM input file.\n");
+      return EXIT_FAILURE;
+    }
   }
   fprintf(stderr, "Compressed to %zu bytes.\n", output.size());
   if (file_out && !Save(file_out, output)) {

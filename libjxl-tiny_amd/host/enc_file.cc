@@ -7,6 +7,7 @@
 #include "encoder/enc_bit_writer.h"
 #include "encoder/enc_frame.h"
 #include "host_internal.h"
+#include "../../include/jxl_tiny_amd.h"
 
 namespace jxlt {
 
@@ -81,6 +82,48 @@ bool EncodeFile(const Image3F& input, float distance, std::vector<uint8_t>* outp
   ThreadPool pool;
   if (!EncodeFrame(distance, input, &pool, &writer)) return false;
   *output = writer.TakeBytes();
+  return true;
+}
+
+bool EncodePFMFile(const char* filename, float distance, std::vector<uint8_t>* output, size_t* xsize_out,
+                   size_t* ysize_out) {
+  if (!jxlt::NormalizeDistance(&distance)) return false;
+  jxlt_context* ctx = jxlt::AcquireThreadContext();
+  if (!ctx) {
+    fprintf(stderr, "jxl_tiny_amd: no usable HIP device (there is no CPU fallback)\n");
+    return false;
+  }
+  // whole file -> page-locked memory (the H2D copy of the payload then runs at PCIe rate)
+  FILE* f = fopen(filename, "rb");
+  if (!f) {
+    fprintf(stderr, "Could not read %s\n", filename);
+    return false;
+  }
+  bool ok = fseek(f, 0, SEEK_END) == 0;
+  const long size = ok ? ftell(f) : -1;
+  ok = ok && size >= 2 && fseek(f, 0, SEEK_SET) == 0;
+  uint8_t* data = ok ? static_cast<uint8_t*>(jxlt_pinned_alloc(static_cast<size_t>(size))) : nullptr;
+  ok = ok && data != nullptr && fread(data, 1, static_cast<size_t>(size), f) == static_cast<size_t>(size);
+  ok = (fclose(f) == 0) && ok;
+  size_t xsize = 0, ysize = 0, payload_offset = 0;
+  bool big_endian = false;
+  ok = ok && jxlt::ParsePFMHeader(data, static_cast<size_t>(size), &xsize, &ysize, &big_endian, &payload_offset);
+  if (!ok) fprintf(stderr, "Could not read %s\n", filename);
+  if (ok && xsize_out) *xsize_out = xsize;
+  if (ok && ysize_out) *ysize_out = ysize;
+  BitWriter writer;
+  ok = ok && jxlt::WriteFileHeader(xsize, ysize, &writer);
+  if (ok && jxlt_image_upload_pfm(ctx, data + payload_offset, xsize, ysize, big_endian ? 1 : 0) != JXLT_OK) {
+    fprintf(stderr, "jxl_tiny_amd: upload failed: %s\n", jxlt_last_error(ctx));
+    ok = false;
+  }
+  if (data) jxlt_pinned_free(data);
+  if (!ok) return false;
+  const std::vector<uint8_t> file_header = writer.TakeBytes();
+  jxlt::ContextOutput out;
+  out.prefix = &file_header;
+  if (!jxlt::EncodeFrameOnContext(ctx, distance, 0, nullptr, nullptr, &out)) return false;
+  output->assign(out.data, out.data + out.size);
   return true;
 }
 

@@ -84,6 +84,20 @@ int jxlt_assemble_frame(const jxlt_frame_result* frame, const jxlt_distance_para
                                     out_size);
 }
 
+int jxlt_encode_pfm_file(const char* filename, float distance, int device_ordinal, uint8_t** out_bytes,
+                         size_t* out_size) {
+  if (!filename || !out_bytes || !out_size) return JXLT_ERR_INVALID_ARGUMENT;
+  jxl::SetEncoderDevice(device_ordinal);
+  std::vector<uint8_t> out;
+  if (!jxl::EncodePFMFile(filename, distance, &out)) return JXLT_ERR_INTERNAL;
+  uint8_t* buf = static_cast<uint8_t*>(malloc(out.size() ? out.size() : 1));
+  if (!buf) return JXLT_ERR_OUT_OF_MEMORY;
+  memcpy(buf, out.data(), out.size());
+  *out_bytes = buf;
+  *out_size = out.size();
+  return JXLT_OK;
+}
+
 int jxlt_write_file_header(size_t xsize, size_t ysize, uint8_t** out_bytes, size_t* out_size) {
   jxl::BitWriter writer;
   if (!jxlt::WriteFileHeader(xsize, ysize, &writer)) return JXLT_ERR_INVALID_ARGUMENT;

@@ -26,6 +26,8 @@ struct ContextOutput {
 bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jxl::BitWriter* writer,
                           const std::function<uint8_t*(size_t)>* placer, ContextOutput* in_context = nullptr);
 bool WriteFileHeader(size_t xsize, size_t ysize, jxl::BitWriter* writer);
+bool ParsePFMHeader(const uint8_t* data, size_t size, size_t* xsize, size_t* ysize, bool* big_endian,
+                    size_t* payload_offset);
 bool NormalizeDistance(float* distance);
 }  // namespace jxlt
 

@@ -86,17 +86,18 @@ bool Slurp(const char* filename, std::vector<uint8_t>* out) {
 
 }  // namespace
 
-bool ReadPFM(const char* filename, Image3F* image) {
-  std::vector<uint8_t> data;
-  if (!Slurp(filename, &data)) {
-    fprintf(stderr, "Could not read %s\n", filename);
-    return false;
-  }
-  if (data.size() < 2 || data[0] != 'P' || data[1] != 'F') {
+}  // namespace jxl
+
+namespace jxlt {
+// Header of a colour PFM (read_pfm.cc:27-147): "PF", sizes, scale +-1 (sign = byte order).
+bool ParsePFMHeader(const uint8_t* data, size_t size, size_t* xsize_out, size_t* ysize_out, bool* big_endian,
+                    size_t* payload_offset) {
+  using namespace jxl;
+  if (size < 2 || data[0] != 'P' || data[1] != 'F') {
     fprintf(stderr, "PFM: bad magic.\n");
     return false;
   }
-  Cursor c = {data.data() + 2, data.data() + data.size()};
+  Cursor c = {data + 2, data + size};
   size_t xsize = 0, ysize = 0;
   double scale = 0;
   if (!EatOneWhitespace(&c) || !ParseSize(&c, &xsize) || !EatBlank(&c) || !ParseSize(&c, &ysize) ||
@@ -108,16 +109,34 @@ bool ReadPFM(const char* filename, Image3F* image) {
     fprintf(stderr, "PFM: bad scale factor value.\n");
     return false;
   }
-  const bool big_endian = scale > 0.0;
   if (xsize == 0 || ysize == 0 || xsize > 0x3FFFFFFFull || ysize > 0x3FFFFFFFull) return false;
   const size_t need = xsize * ysize * 3 * sizeof(float);
   if (static_cast<size_t>(c.end - c.p) < need) {
     fprintf(stderr, "PFM: truncated pixel data.\n");
     return false;
   }
+  *xsize_out = xsize;
+  *ysize_out = ysize;
+  *big_endian = scale > 0.0;
+  *payload_offset = static_cast<size_t>(c.p - data);
+  return true;
+}
+}  // namespace jxlt
+
+namespace jxl {
+
+bool ReadPFM(const char* filename, Image3F* image) {
+  std::vector<uint8_t> data;
+  if (!Slurp(filename, &data)) {
+    fprintf(stderr, "Could not read %s\n", filename);
+    return false;
+  }
+  size_t xsize = 0, ysize = 0, payload_offset = 0;
+  bool big_endian = false;
+  if (!jxlt::ParsePFMHeader(data.data(), data.size(), &xsize, &ysize, &big_endian, &payload_offset)) return false;
   Image3F img(xsize, ysize);
   if (!img.valid()) return false;
-  const uint8_t* payload = c.p;
+  const uint8_t* payload = data.data() + payload_offset;
   const size_t row_bytes = xsize * 3 * sizeof(float);
   for (size_t y = 0; y < ysize; ++y) {
     const uint8_t* row_in = payload + (ysize - 1 - y) * row_bytes;  // bottom-to-top

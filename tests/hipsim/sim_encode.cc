@@ -55,7 +55,16 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
     A.nzgrid[c] = (uint8_t*)calloc(nblocks, 1);
     A.dbg_xyb[c] = r->xyb[c] = (float*)calloc(nblocks * 64, 4);
   }
-  A.pitch = pitch_floats;
+  A.pitch = (ptrdiff_t)pitch_floats;
+  A.pix_stride = 1;
+  A.byteswap = 0;
+  if (flags & 0x100u) {
+    // planes[0] is a raw PFM payload: interleaved RGB, bottom row first (read_pfm.cc:199-209)
+    for (int c = 0; c < 3; c++) A.planes[c] = planes[0] + (ysize - 1) * xsize * 3 + c;
+    A.pitch = -(ptrdiff_t)(xsize * 3);
+    A.pix_stride = 3;
+    A.byteswap = (flags & 0x200u) ? 1 : 0;
+  }
   A.g = g;
   A.distance = distance;
   A.scale = scale;

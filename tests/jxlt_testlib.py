@@ -35,11 +35,11 @@ def to_planes(img):
     return np.ascontiguousarray(np.moveaxis(img, -1, 0), dtype=np.float32)
 
 
-def write_pfm(path, img):
+def write_pfm(path, img, big_endian=False):
     h, w, _ = img.shape
     with open(path, "wb") as f:
-        f.write(b"PF\n%d %d\n-1.0\n" % (w, h))
-        f.write(np.ascontiguousarray(img[::-1], dtype="<f4").tobytes())
+        f.write(b"PF\n%d %d\n%s\n" % (w, h, b"1.0" if big_endian else b"-1.0"))
+        f.write(np.ascontiguousarray(img[::-1]).astype(">f4" if big_endian else "<f4").tobytes())
 
 
 # --------------------------------------------------------------------------- builds
@@ -251,16 +251,29 @@ def sim_pack_sections(sections, table, misalign=0, nlaunch=1):
     return [(body[int(out_off[i]):int(out_off[i + 1])].tobytes(), int(out_bits[i])) for i in range(len(sections))]
 
 
-def sim_hot_path(planes, distance, force_dct8=False):
-    """Runs the product's HIP kernels on the CPU execution model (tests only)."""
+def pfm_payload(planes, big_endian=False):
+    """The sample payload of a PFM file holding `planes` ([3, h, w] float32): interleaved RGB,
+    bottom row first (read_pfm.cc:199-209), byte-swapped for the big-endian flavour."""
+    a = np.ascontiguousarray(np.transpose(planes, (1, 2, 0))[::-1], np.float32)
+    return a.astype(">f4" if big_endian else "<f4").view(np.float32).reshape(-1).copy()
+
+
+def sim_hot_path(planes, distance, force_dct8=False, as_pfm=None):
+    """Runs the product's HIP kernels on the CPU execution model (tests only).  as_pfm = "le" /
+    "be": the kernels read the frame from a raw PFM payload instead of planar planes."""
     _sim = _sim_lib()
-    if False:
-        pass
     _, h, w = planes.shape
     p = distance_params(distance)
     s = SimResult()
-    rc = _sim.sim_encode(_plane_ptrs(planes), w, w, h, p.distance, p.scale, p.inv_scale, p.scale_dc,
-                         p.x_qm_scale, 1 if force_dct8 else 0, C.byref(s))
+    flags = 1 if force_dct8 else 0
+    if as_pfm:
+        payload = pfm_payload(planes, as_pfm == "be")
+        ptrs = (fp * 3)(payload.ctypes.data_as(fp), None, None)
+        flags |= 0x100 | (0x200 if as_pfm == "be" else 0)
+    else:
+        ptrs = _plane_ptrs(planes)
+    rc = _sim.sim_encode(ptrs, w, w, h, p.distance, p.scale, p.inv_scale, p.scale_dc,
+                         p.x_qm_scale, flags, C.byref(s))
     assert rc == 0
     r = HotPathResult()
     r.xsize, r.ysize = w, h

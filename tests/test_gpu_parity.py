@@ -56,11 +56,16 @@ def test_dropin_encode_file_matches_oracle_codestream(built, w, h, distance):
     assert built.encode_file(planes, distance) == want
 
 
-def test_cjxl_tiny_cli(built, tmp_path):
+@pytest.mark.parametrize("big_endian", [False, True])
+@pytest.mark.parametrize("host_ingest", [False, True])
+def test_cjxl_tiny_cli(built, tmp_path, host_ingest, big_endian):
+    """The command line tool, with the PFM payload ingested by the device kernels (default) or
+    de-interleaved on the host like the reference's ReadPFM (--host-ingest); both byte orders."""
     img = T.synthetic_image(300, 200)
     pfm, out = tmp_path / "in.pfm", tmp_path / "out.jxl"
-    T.write_pfm(pfm, img)
-    r = subprocess.run([str(built.CJXL_TINY), str(pfm), str(out), "-d", "1.5"], capture_output=True, text=True)
+    T.write_pfm(pfm, img, big_endian)
+    cmd = [str(built.CJXL_TINY), str(pfm), str(out), "-d", "1.5"] + (["--host-ingest"] if host_ingest else [])
+    r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "Read 300x200 pixels input image." in r.stderr
     want = T.assemble_codestream(T.oracle_hot_path(T.to_planes(img), 1.5), 1.5)
@@ -191,3 +196,14 @@ def test_hardware_shortcuts_are_exact_on_this_gpu():
     assert len(lines) == 3, out
     for l in lines:
         assert "mismatches=0 " in l, l
+
+
+def test_pfm_file_ingest_on_device(built, tmp_path):
+    """jxlt_encode_pfm_file: a frame wider and taller than one group, big-endian payload, rows
+    bottom-up -- read in place by tile_kernel."""
+    img = T.synthetic_image(700, 520)
+    pfm = tmp_path / "in.pfm"
+    T.write_pfm(pfm, img, big_endian=True)
+    got = built.encode_pfm_file(pfm, 2.0)
+    want = T.assemble_codestream(T.oracle_hot_path(T.to_planes(img), 2.0), 2.0)
+    assert got == want

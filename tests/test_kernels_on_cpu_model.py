@@ -99,3 +99,13 @@ def test_dc_kernels_match_host_tokeniser(built, w, h, distance):
     assert got.dc_records == want
     h = sum((T.token_histogram(r) for r in want))
     assert (got.dc_histogram == h).all()
+
+
+@pytest.mark.parametrize("flavour", ["le", "be"])
+def test_pfm_payload_ingest_on_cpu_model(built, flavour):
+    """tile_kernel reading the frame straight from a raw PFM payload (interleaved, bottom-up,
+    either byte order) produces what it produces from the planar frame."""
+    planes = T.to_planes(T.synthetic_image(200, 137))
+    a = T.sim_hot_path(planes, 1.0)
+    b = T.sim_hot_path(planes, 1.0, as_pfm=flavour)
+    T.compare_results(a, b, "planar", "pfm payload")
