@@ -419,9 +419,40 @@ int jxlt_image_upload_pfm(jxlt_context* ctx, const void* host_payload, size_t xs
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t nfloats = xsize * ysize * 3;
   if ((rc = EnsureDevice(ctx, &ctx->own_payload, nfloats)) != JXLT_OK) return rc;
-  // one contiguous block: full PCIe rate when `host_payload` is page-locked (jxlt_pinned_alloc)
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->own_payload.p, host_payload, nfloats * sizeof(float), hipMemcpyHostToDevice,
-                              ctx->stream));
+  // Page-locked memory goes over PCIe in one piece.  Pageable memory (e.g. the mmap of the
+  // file) is staged through the two pinned buffers: host threads fill one while the other is
+  // in flight, so the file's pages are touched once, by several cores, overlapped with the DMA.
+  const size_t nbytes = nfloats * sizeof(float);
+  const uint8_t* src = static_cast<const uint8_t*>(host_payload);
+  uint8_t* dst = reinterpret_cast<uint8_t*>(ctx->own_payload.p);
+  hipPointerAttribute_t attr;
+  const bool pinned = hipPointerGetAttributes(&attr, host_payload) == hipSuccess && attr.type == hipMemoryTypeHost;
+  (void)hipGetLastError();  // a pageable pointer is not an error
+  if (pinned) {
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, nbytes, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    constexpr size_t kStageBytes = size_t(32) << 20;
+    for (auto& st : ctx->stage)
+      if ((rc = EnsurePinned(ctx, &st, std::min(kStageBytes, nbytes))) != JXLT_OK) return rc;
+    int turn = 0;
+    for (size_t o = 0; o < nbytes; o += kStageBytes, turn ^= 1) {
+      const size_t n = std::min(kStageBytes, nbytes - o);
+      uint8_t* stage = ctx->stage[turn].p;
+      HIP_TRY(ctx, hipEventSynchronize(ctx->stage_done[turn]));  // previous use of this buffer
+      const int nthreads = n > (size_t(4) << 20) ? 8 : 1;
+      if (nthreads == 1) {
+        memcpy(stage, src + o, n);
+      } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; t++)
+          pool.emplace_back([=] { memcpy(stage + n * t / nthreads, src + o + n * t / nthreads,
+                                         n * (t + 1) / nthreads - n * t / nthreads); });
+        for (auto& th : pool) th.join();
+      }
+      HIP_TRY(ctx, hipMemcpyAsync(dst + o, stage, n, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(ctx, hipEventRecord(ctx->stage_done[turn], ctx->stream));
+    }
+  }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // caller may reuse its buffer
   return SetPfmView(ctx, ctx->own_payload.p, xsize, ysize, big_endian);
 }

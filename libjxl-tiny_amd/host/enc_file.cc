@@ -2,7 +2,11 @@
 // one frame.  Bit layout follows /root/reference/encoder/enc_file.cc:26-105.
 #include "encoder/enc_file.h"
 
+#include <fcntl.h>
 #include <stdio.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "encoder/enc_bit_writer.h"
 #include "encoder/enc_frame.h"
@@ -93,22 +97,27 @@ bool EncodePFMFile(const char* filename, float distance, std::vector<uint8_t>* o
     fprintf(stderr, "jxl_tiny_amd: no usable HIP device (there is no CPU fallback)\n");
     return false;
   }
-  // whole file -> page-locked memory (the H2D copy of the payload then runs at PCIe rate)
-  FILE* f = fopen(filename, "rb");
-  if (!f) {
+  // The file is mapped, not read: its pages go from the page cache into the device library's
+  // page-locked staging buffers (several threads) and from there over PCIe, overlapped.
+  const int fd = open(filename, O_RDONLY);
+  struct stat st;
+  if (fd < 0 || fstat(fd, &st) != 0 || st.st_size < 2) {
+    if (fd >= 0) close(fd);
     fprintf(stderr, "Could not read %s\n", filename);
     return false;
   }
-  bool ok = fseek(f, 0, SEEK_END) == 0;
-  const long size = ok ? ftell(f) : -1;
-  ok = ok && size >= 2 && fseek(f, 0, SEEK_SET) == 0;
-  uint8_t* data = ok ? static_cast<uint8_t*>(jxlt_pinned_alloc(static_cast<size_t>(size))) : nullptr;
-  ok = ok && data != nullptr && fread(data, 1, static_cast<size_t>(size), f) == static_cast<size_t>(size);
-  ok = (fclose(f) == 0) && ok;
+  const size_t size = static_cast<size_t>(st.st_size);
+  void* map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (map == MAP_FAILED) {
+    fprintf(stderr, "Could not read %s\n", filename);
+    return false;
+  }
+  (void)madvise(map, size, MADV_SEQUENTIAL);
+  const uint8_t* data = static_cast<const uint8_t*>(map);
   size_t xsize = 0, ysize = 0, payload_offset = 0;
   bool big_endian = false;
-  ok = ok && jxlt::ParsePFMHeader(data, static_cast<size_t>(size), &xsize, &ysize, &big_endian, &payload_offset);
-  if (!ok) fprintf(stderr, "Could not read %s\n", filename);
+  bool ok = jxlt::ParsePFMHeader(data, size, &xsize, &ysize, &big_endian, &payload_offset);
   if (ok && xsize_out) *xsize_out = xsize;
   if (ok && ysize_out) *ysize_out = ysize;
   BitWriter writer;
@@ -117,7 +126,7 @@ bool EncodePFMFile(const char* filename, float distance, std::vector<uint8_t>* o
     fprintf(stderr, "jxl_tiny_amd: upload failed: %s\n", jxlt_last_error(ctx));
     ok = false;
   }
-  if (data) jxlt_pinned_free(data);
+  munmap(map, size);
   if (!ok) return false;
   const std::vector<uint8_t> file_header = writer.TakeBytes();
   jxlt::ContextOutput out;

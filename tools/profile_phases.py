@@ -82,6 +82,22 @@ def main():
             t1 = time.perf_counter()
         print("EncodeFile from host planes (H2D + encode + copy out): %.2f ms = %.0f MP/s (%d bytes)" %
               (1e3 * (t1 - t0), size * size / 1e6 / (t1 - t0), len(jxl)))
+        # cjxl_tiny's route: PFM file (tmpfs) -> page-locked read -> payload H2D -> device ingest
+        import os, tempfile
+        d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+        path = os.path.join(d, "jxlt_profile_%d.pfm" % os.getpid())
+        with open(path, "wb") as f:
+            f.write(b"PF\n%d %d\n-1.0\n" % (size, size))
+            f.write(np.ascontiguousarray(np.transpose(host, (1, 2, 0))[::-1]).tobytes())
+        try:
+            for rep in range(2):
+                t0 = time.perf_counter()
+                jxl2 = pkg.encode_pfm_file(path, 1.0)
+                t1 = time.perf_counter()
+            print("EncodePFMFile (file in tmpfs -> .jxl bytes, device ingest): %.2f ms = %.0f MP/s (%s)" %
+                  (1e3 * (t1 - t0), size * size / 1e6 / (t1 - t0), "same bytes" if jxl2 == jxl else "DIFFERENT BYTES"))
+        finally:
+            os.unlink(path)
         t0 = time.perf_counter()
         nb = enc.encode_resident(1.0, copy=False)
         print("encode_resident (frame in HBM): %.2f ms = %.0f MP/s" %
