@@ -191,7 +191,9 @@ int jxlt_kernel_times(jxlt_context* ctx, jxlt_kernel_time* out, int cap);
  *       5 = entropy estimates f32, 8 per 2x2-block cell, grid
  *           (xsize_blocks/2+1) x (ysize_blocks/2+1).
  *       6 = u64[16] shader cycles per tile_kernel phase, summed over tiles (needs
- *           JXLT_FLAG_PROFILE instead of JXLT_FLAG_DEBUG_DUMP). */
+ *           JXLT_FLAG_PROFILE instead of JXLT_FLAG_DEBUG_DUMP).
+ *       7 = u32: encodes of this context that were redone with tile_kernel_exact_roots because a
+ *           quantised magnitude exceeded tile_kernel's square-root table (always allowed). */
 int jxlt_debug_fetch(jxlt_context* ctx, int what, void* host_dst, size_t bytes);
 
 /* ---- libjxltiny_host.so ------------------------------------------------ */

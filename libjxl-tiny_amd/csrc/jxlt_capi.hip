@@ -109,6 +109,14 @@ struct jxlt_context {
   // jxlt_pack_write: packing on `stream`, chunked copies to the destination on `copy_stream`
   hipStream_t copy_stream = nullptr;
   hipEvent_t dc_hist_ready = nullptr;  // DC histogram of the last enqueue is in h_hist
+  // Root-table overflow of tile_kernel (a quantised magnitude >= kSqrtLutSize): checked at the
+  // first host synchronisation point; the pipeline is then redone with tile_kernel_exact_roots.
+  DeviceBuf<uint32_t> lut_overflow;
+  PinnedBuf<uint32_t> h_lut_overflow;
+  hipEvent_t overflow_ready = nullptr;
+  jxlt_params last_params = {};
+  bool overflow_checked = true;
+  uint32_t exact_reruns = 0;
   static constexpr int kWriteChunks = 4;
   hipEvent_t chunk_packed[kWriteChunks + 1] = {};
   bool copies_pending = false;
@@ -214,6 +222,7 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
   for (auto& ev : ctx->stage_done) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   (void)hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
   (void)hipEventCreateWithFlags(&ctx->dc_hist_ready, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&ctx->overflow_ready, hipEventDisableTiming);
   for (auto& ev : ctx->chunk_packed) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   *out = ctx;
   return JXLT_OK;
@@ -282,6 +291,9 @@ void jxlt_context_destroy(jxlt_context* ctx) {
   for (auto& ev : ctx->chunk_packed)
     if (ev) (void)hipEventDestroy(ev);
   if (ctx->dc_hist_ready) (void)hipEventDestroy(ctx->dc_hist_ready);
+  if (ctx->overflow_ready) (void)hipEventDestroy(ctx->overflow_ready);
+  FreeDevice(&ctx->lut_overflow);
+  FreePinned(&ctx->h_lut_overflow);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -464,7 +476,8 @@ int jxlt_image_size(const jxlt_context* ctx, size_t* xsize, size_t* ysize) {
   return JXLT_OK;
 }
 
-int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
+namespace {
+int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roots) {
   if (!ctx || !params) return JXLT_ERR_INVALID_ARGUMENT;
   if (!ctx->planes[0]) {
     ctx->error = "no image set";
@@ -502,6 +515,8 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   const size_t kDcStride = 6 * 65536 + 2 * 1024 + 8;
   ENSURE(dc_records, ndc * kDcStride * 3 + 16);  // (+ slack: tiles are staged with aligned dword loads)
   ENSURE(dc_nac, ndc);
+  ENSURE(lut_overflow, 1);
+  if ((rc = EnsurePinned(ctx, &ctx->h_lut_overflow, 1)) != JXLT_OK) return rc;
   ENSURE(dc_count, ndc);
   ENSURE(dc_rec_off, ndc + 1);
   if (ctx->dc_rec_off_n != ndc) {
@@ -553,7 +568,7 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   A.scale_dc = params->scale_dc;
   A.x_qm_mul = XQmMultiplier(params->x_qm_scale);
   A.flags = (params->flags & JXLT_FLAG_FORCE_DCT8) ? 1u : 0u;
-  A.flags |= params->flags & 0xF00u;  // profiling only: truncate tile_kernel after phase n-1 (tools/profile_phases.py)
+  A.flags |= params->flags & 0x1F00u;  // profiling only: truncate tile_kernel after phase n-1 (tools/profile_phases.py)
   A.tab = ctx->d_tab;
   A.raw_quant = ctx->raw_quant.p;
   A.strategy = ctx->strategy.p;
@@ -564,6 +579,7 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   A.coef_scan = ctx->coef_scan.p;
   A.group_ntok = ctx->group_ntok.p;
   A.dc_nac = ctx->dc_nac.p;
+  A.lut_overflow = ctx->lut_overflow.p;
   A.dbg_qf = debug ? ctx->dbg_qf.p : nullptr;
   A.dbg_mask = debug ? ctx->dbg_mask.p : nullptr;
   A.dbg_ent8 = debug ? ctx->dbg_ent8.p : nullptr;
@@ -585,9 +601,16 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   HIP_TRY(ctx, hipMemsetAsync(ctx->group_ntok.p, 0, ngroups * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->hist.p, 0, 2 * 64 * 64 * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->dc_nac.p, 0, ndc * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->lut_overflow.p, 0, sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  hipLaunchKernelGGL(tile_kernel, dim3((unsigned)ntiles), dim3(kTileThreads), 0, ctx->stream, A);
+  if (exact_roots)
+    hipLaunchKernelGGL(tile_kernel_exact_roots, dim3((unsigned)ntiles), dim3(kTileThreads), 0, ctx->stream, A);
+  else
+    hipLaunchKernelGGL(tile_kernel, dim3((unsigned)ntiles), dim3(kTileThreads), 0, ctx->stream, A);
   HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_lut_overflow.p, ctx->lut_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                              ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->overflow_ready, ctx->stream));
   // DC-group tokenisation first: it only needs tile_kernel's outputs, and its histogram leaves
   // for the host at once, so that the DC code is built while token_kernel is still running.
   {
@@ -628,12 +651,35 @@ int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) {
   ctx->pack[0].measured_sections = ctx->pack[1].measured_sections = 0;
   ctx->last_flags = params->flags;
   ctx->profiled = true;  // the five stage events are always recorded (a few microseconds per frame)
+  ctx->last_params = *params;
+  ctx->overflow_checked = exact_roots;  // (nothing to check after the exact variant)
   return JXLT_OK;
 }
+
+// First host synchronisation point after an enqueue: did tile_kernel meet a quantised magnitude
+// beyond its root table?  Then its strategy decisions may be wrong: the whole pipeline is redone
+// with the kernel variant that computes every root (identical results otherwise).
+int ResolveRootTableOverflow(jxlt_context* ctx) {
+  if (!ctx->encoded || ctx->overflow_checked) return JXLT_OK;
+  HIP_TRY(ctx, hipEventSynchronize(ctx->overflow_ready));
+  ctx->overflow_checked = true;
+  if (ctx->h_lut_overflow.p[0] == 0) return JXLT_OK;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // let the superseded pipeline drain
+  ctx->exact_reruns++;
+  const jxlt_params params = ctx->last_params;
+  return EnqueuePipeline(ctx, &params, true);
+}
+}  // namespace
+
+int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) { return EnqueuePipeline(ctx, params, false); }
 
 int jxlt_synchronize(jxlt_context* ctx) {
   if (!ctx) return JXLT_ERR_INVALID_ARGUMENT;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    const int rc0 = ResolveRootTableOverflow(ctx);
+    if (rc0 != JXLT_OK) return rc0;
+  }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->copies_pending) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
@@ -647,6 +693,10 @@ namespace {
 // Copies grids, per-group token offsets and histograms to pinned memory; fills *out
 // (tokens left NULL).  Leaves group offsets in TOKENS (not bytes) in h_group_off.
 int FetchSideInfo(jxlt_context* ctx, jxlt_frame_result* out) {
+  {
+    const int rc0 = ResolveRootTableOverflow(ctx);
+    if (rc0 != JXLT_OK) return rc0;
+  }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const FrameGeom& g = ctx->geom;
   const size_t nblocks = (size_t)g.xsize_blocks * g.ysize_blocks;
@@ -738,6 +788,10 @@ int jxlt_fetch_dc_histogram(jxlt_context* ctx, const uint32_t** dc_histogram) {
     return JXLT_ERR_INVALID_ARGUMENT;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    const int rc0 = ResolveRootTableOverflow(ctx);
+    if (rc0 != JXLT_OK) return rc0;
+  }
   HIP_TRY(ctx, hipEventSynchronize(ctx->dc_hist_ready));
   *dc_histogram = ctx->h_hist.p + 64 * 64;
   return JXLT_OK;
@@ -750,6 +804,10 @@ int jxlt_fetch_histograms(jxlt_context* ctx, const uint32_t** ac_histograms, con
     return JXLT_ERR_INVALID_ARGUMENT;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    const int rc0 = ResolveRootTableOverflow(ctx);
+    if (rc0 != JXLT_OK) return rc0;
+  }
   const FrameGeom& g = ctx->geom;
   const size_t ngroups = (size_t)g.xsize_groups * g.ysize_groups;
   int rc;
@@ -985,6 +1043,10 @@ int jxlt_kernel_times(jxlt_context* ctx, jxlt_kernel_time* out, int cap) {
     return JXLT_ERR_INVALID_ARGUMENT;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    const int rc0 = ResolveRootTableOverflow(ctx);
+    if (rc0 != JXLT_OK) return rc0;
+  }
   HIP_TRY(ctx, hipEventSynchronize(ctx->ev[4]));
   static const char* kNames[4] = {"tile_kernel", "dc_kernels", "group_scan_kernel", "token_kernel"};
   for (int i = 0; i < 4 && i < cap; i++) {
@@ -999,6 +1061,15 @@ int jxlt_kernel_times(jxlt_context* ctx, jxlt_kernel_time* out, int cap) {
 int jxlt_debug_fetch(jxlt_context* ctx, int what, void* host_dst, size_t bytes) {
   if (!ctx || !host_dst) return JXLT_ERR_INVALID_ARGUMENT;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    const int rc0 = ResolveRootTableOverflow(ctx);
+    if (rc0 != JXLT_OK) return rc0;
+  }
+  if (what == 7) {  // how many encodes of this context had to be redone with computed roots
+    if (bytes != sizeof(uint32_t)) return JXLT_ERR_INVALID_ARGUMENT;
+    memcpy(host_dst, &ctx->exact_reruns, sizeof(uint32_t));
+    return JXLT_OK;
+  }
   if (what == 6) {  // per-phase shader-cycle totals of tile_kernel (JXLT_FLAG_PROFILE)
     if (!(ctx->last_flags & JXLT_FLAG_PROFILE) || bytes != 16 * sizeof(unsigned long long)) {
       ctx->error = "phase counters need JXLT_FLAG_PROFILE and a 128-byte buffer";

@@ -45,11 +45,20 @@ struct DeviceTables {
   uint8_t block_context_map[81];
   uint8_t ac_context_map[1980];
   uint8_t gradient_lut[1024];  // enc_frame.cc:226-281
+  float sqrt_lut[1024];        // sqrtf(i), correctly rounded (EstimateEntropy's cost of a coefficient)
 };
 
 // Offset of quant table n = strategy * 3 + channel inside weights[] / inv_weights[]: three
 // 64-entry DCT8 tables, then three 128-entry tables shared by DCT16X8 and DCT8X16.
 __host__ __device__ constexpr int quant_table_offset(int n) { return n < 3 ? n * 64 : 192 + ((n - 3) % 3) * 128; }
+
+// Entries of the square-root table of the entropy estimate (a power of two; tests build the CPU
+// model with a tiny table to exercise the overflow path on ordinary images).
+#ifndef JXLT_SQRT_LUT_SIZE
+#define JXLT_SQRT_LUT_SIZE 1024
+#endif
+constexpr int kSqrtLutSize = JXLT_SQRT_LUT_SIZE;  // DeviceTables::sqrt_lut, TileShared::sqrt_lut
+static_assert((kSqrtLutSize & (kSqrtLutSize - 1)) == 0 && kSqrtLutSize <= 1024, "power of two, fits DeviceTables");
 
 struct FrameGeom {
   int xsize, ysize;                // pixels
@@ -84,6 +93,7 @@ struct TileArgs {
   int16_t* coef_scan;   // [block*3 + c][64] quantised coefficients in scan order
   uint32_t* group_ntok; // per group token count (atomic)
   uint32_t* dc_nac;     // per DC group: number of first blocks (atomic)
+  uint32_t* lut_overflow;  // [1] set when a quantised magnitude did not fit the root table
   // debug (may be null)
   float* dbg_xyb[3];
   float* dbg_qf;
@@ -531,6 +541,7 @@ struct alignas(16) TileShared {
   float cfl_pad[kCflTermFloats - (2 * 64 * kXYPitch + 64 * kBPitch + 16 * 72 + 16 * kPrePitch + 16 * 16)];
   // ^ x..cfl_pad (64 KB) are overlaid by the chroma-from-luma terms once every pixel
   //   read is done: 64 blocks x 64 coefficients x (a_x, b_x, a_b, b_b).
+  float sqrt_lut[kSqrtLutSize];  // sqrtf of the quantised magnitudes below kSqrtLutSize
   float inv_w[576];
   float y_w[192];          // dequant weights of Y: [0,64) DCT8, [64,192) two-block
   float aq[64];            // quant field (tile-local 8x8)
@@ -552,10 +563,15 @@ JXLT_DI int imax(int a, int b) { return a > b ? a : b; }
 
 // Per-octet entropy estimate of one transform (enc_ac_strategy.cc:51-146).
 // cy/cx/cb: the lane's rows of the Y/X/B coefficients; NR rows (8 or 16).
-template <int NR>
+// kLut: the roots come from the LDS table S.sqrt_lut (a multiply, a convert, a mask and an LDS
+// read instead of v_sqrt + the exact-rounding fix-up, ~40 cycles); *qmax then receives the
+// largest magnitude seen, and the caller redoes the estimate with kLut = false if it is beyond
+// the table (quantised coefficients >= 1024: practically never, but results must not depend on it).
+template <int NR, bool kLut>
 JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb, const float* inv_x,
                                const float* inv_y, const float* inv_b, int l, float quant,
-                               float masking, float cmap_x, float cmap_b, float distance) {
+                               float masking, float cmap_x, float cmap_b, float distance,
+                               const float* sqrt_lut, float* qmax) {
   const float num_blocks = (float)(NR / 8);
   const float kInfoLossMultiplier = 138.0f;
   const float kInfoLossMultiplier2 = (float)50.46839691767866;
@@ -566,6 +582,7 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
   const float cost_of_1 = 1 + slope * 8.8703248061477744f;
   float entropy = 0.0f;
   float info_loss = 0.0f, info_loss2 = 0.0f;
+  float qm = 0.0f;
   // One copy of the body per channel (no per-coefficient operand selects); the scheduling
   // fences keep the channels from being interleaved, which would spill.
 #pragma unroll
@@ -591,10 +608,18 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
       info_loss2 = fma32(diff, diff, info_loss2);
       const float q = fabsf(rval);
       entropy_v = fma32(clamp01(q - 1.0f), kCost2, entropy_v);  // + (q >= 1.5 ? kCost2 : 0)
-      // (a 64-entry LDS table of sqrtf(i) was tried here and measured slower; so was skipping
-      // the root with a branch where a whole wave has q <= 1: the control flow makes the
-      // register allocator spill)
-      entropy_v = fma32(sqrt_exact_midrange(q), kCostDelta, entropy_v);  // q is 0 or an integer >= 1
+      float root;
+      if (kLut) {
+        // byte offset 4 * q, wrapped into the table (a wrapped read is redone by the caller)
+        const uint32_t off = (uint32_t)(q * 4.0f) & (uint32_t)(kSqrtLutSize * 4 - 4);
+        root = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sqrt_lut) + off);
+        qm = fmaxf(qm, q);
+      } else {
+        // (skipping the root with a branch where a whole wave has q <= 1 was tried: control flow
+        // inside this loop makes the register allocator spill)
+        root = sqrt_exact_midrange(q);  // q is 0 or an integer >= 1
+      }
+      entropy_v = fma32(root, kCostDelta, entropy_v);
       nzeros_v = nzeros_v + clamp01(4.0f * q);  // + (q == 0 ? 0 : 1)
     }
     entropy_v = fma32(nzeros_v, cost_of_1, entropy_v);
@@ -606,6 +631,7 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
   const float infoloss = octet_sum(info_loss);
   const float infoloss2 = sqrtf(num_blocks * octet_sum(info_loss2));
   const float info_loss_score = (kInfoLossMultiplier * infoloss + kInfoLossMultiplier2 * infoloss2);
+  if (kLut) *qmax = qm;
   return entropy + masking * info_loss_score;
 }
 
@@ -759,7 +785,8 @@ JXLT_DI void quantize_transform(float* cx, float* cy, float* cb, const TileShare
   }
 }
 
-__global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A) {
+template <bool kLutRoots>
+JXLT_DI void tile_kernel_body(const TileArgs& A) {
   __shared__ TileShared S;
   const int tid = (int)threadIdx.x;
   const int l = tid & 7;    // lane within octet
@@ -808,6 +835,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
 
   // ---- P0: tables -> LDS; load + XYB (enc_frame.cc:597-617, enc_xyb.cc) -----
   for (int i = tid; i < 576; i += kTileThreads) S.inv_w[i] = T->inv_weights[i];
+  for (int i = tid; i < kSqrtLutSize; i += kTileThreads) S.sqrt_lut[i] = T->sqrt_lut[i];
   if (tid < 64) S.y_w[tid] = T->weights[quant_table_offset(1) + tid];
   if (tid < 128) S.y_w[64 + tid] = T->weights[quant_table_offset(4) + tid];
   if (tid == 0) {
@@ -1261,12 +1289,13 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
   }
 
   // ---- P6b: entropy estimates (enc_ac_strategy.cc:68-146,187-212) -----------
+  float qmax = 0.0f;  // largest quantised magnitude whose root was taken from the table
   if (search) {
     // DCT8 estimate for this octet's own block
     if (blk_valid) {
-      const float e = estimate_entropy<8>(c8x, c8y, c8b, S.inv_w + 0, S.inv_w + 64, S.inv_w + 128, l,
-                                          fmaxf(0.0f, S.aq[oct]), fmaxf(0.0f, S.mask[oct]), cmap_x, cmap_b,
-                                          A.distance);
+      const float e = estimate_entropy<8, kLutRoots>(c8x, c8y, c8b, S.inv_w + 0, S.inv_w + 64, S.inv_w + 128, l,
+                                                     fmaxf(0.0f, S.aq[oct]), fmaxf(0.0f, S.mask[oct]), cmap_x,
+                                                     cmap_b, A.distance, S.sqrt_lut, &qmax);
       const float k8x8mul1 = (float)(-0.55 * 0.75f);
       const float k8x8mul2 = 1.0735757687292623f * 0.75f;
       const float k8x8base = (float)1.4;
@@ -1291,10 +1320,12 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
       const float quant = fmaxf(fmaxf(0.0f, S.aq[bi]), S.aq[bi + o2]);
       const float masking = fmaxf(fmaxf(0.0f, S.mask[bi]), S.mask[bi + o2]);
       const int toff = is_tall ? 3 : 6;
-      const float e = estimate_entropy<16>(c16x, c16y, c16b, S.inv_w + quant_table_offset(toff),
-                                           S.inv_w + quant_table_offset(toff + 1),
-                                           S.inv_w + quant_table_offset(toff + 2), l, quant, masking,
-                                           cmap_x, cmap_b, A.distance);
+      float qmax16 = 0.0f;
+      const float e = estimate_entropy<16, kLutRoots>(c16x, c16y, c16b, S.inv_w + quant_table_offset(toff),
+                                                      S.inv_w + quant_table_offset(toff + 1),
+                                                      S.inv_w + quant_table_offset(toff + 2), l, quant, masking,
+                                                      cmap_x, cmap_b, A.distance, S.sqrt_lut, &qmax16);
+      qmax = fmaxf(qmax, qmax16);
       const float k8X16mul1 = (float)-0.55, k8X16mul2 = (float)0.9019587899705066,
                   k8X16base = (float)1.6;
       const float mul16x8 = k8X16mul2 + k8X16mul1 / (A.distance + k8X16base);
@@ -1308,6 +1339,9 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
       c8b[r] = park[(16 + r) * kTileThreads];
     }
   }
+  // A magnitude beyond the root table invalidates this tile's estimates: the frame is then
+  // redone by the kernel variant that computes every root (jxlt_capi.hip; practically never).
+  if (kLutRoots && (qmax >= (float)kSqrtLutSize || (A.flags & 0x1000u) != 0)) A.lut_overflow[0] = 1u;  // (0x1000: test hook)
   __syncthreads();
   JXLT_MARK(6);
   // ---- P7: decision (:213-237) + AdjustQuantField (:240-266) ------------------
@@ -1439,6 +1473,14 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
 #undef JXLT_STOP
 #undef SX
 #undef SY
+}
+
+// tile_kernel: roots of the entropy estimate from the LDS table (the product path);
+// tile_kernel_exact_roots: every root computed -- the same results, needed only for frames in
+// which tile_kernel met a quantised magnitude beyond the table.
+__global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A) { tile_kernel_body<true>(A); }
+__global__ void __launch_bounds__(kTileThreads, 4) tile_kernel_exact_roots(const TileArgs A) {
+  tile_kernel_body<false>(A);
 }
 
 // ---------------------------------------------------------------------------

@@ -3,6 +3,7 @@
 #ifndef JXLT_HOST_TABLES_H_
 #define JXLT_HOST_TABLES_H_
 
+#include <math.h>
 #include <string.h>
 
 #include "jxlt_device.h"
@@ -35,6 +36,7 @@ inline void BuildDeviceTables(float scale, DeviceTables* t) {
   memcpy(t->block_context_map, JXLT_kBlockContextMap, sizeof(t->block_context_map));
   memcpy(t->ac_context_map, JXLT_kACContextMap, sizeof(t->ac_context_map));
   memcpy(t->gradient_lut, JXLT_kGradientContextLut, sizeof(t->gradient_lut));
+  for (int i = 0; i < 1024; i++) t->sqrt_lut[i] = sqrtf((float)i);  // IEEE: correctly rounded
 }
 
 inline FrameGeom MakeGeom(size_t xsize, size_t ysize) {

@@ -30,7 +30,10 @@ struct sim_result {
   uint64_t* dc_rec_offset;  // [ndc + 1]
   uint32_t* dc_count;   // [ndc]
   size_t num_dc_groups;
+  uint32_t exact_reruns;  // 1: the frame was redone with tile_kernel_exact_roots
 };
+
+__attribute__((visibility("default"))) void sim_free(sim_result* r);
 
 __attribute__((visibility("default"))) int sim_encode(const float* const planes[3], size_t pitch_floats, size_t xsize, size_t ysize,
                float distance, float scale, float inv_scale, float scale_dc, uint32_t x_qm_scale,
@@ -90,7 +93,25 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   A.dbg_ent8 = r->ent8 = (float*)malloc(ncells * 8 * 4);
   for (size_t i = 0; i < ncells * 8; i++) A.dbg_ent8[i] = __builtin_nanf("");
 
-  hipsim::launch(tile_kernel, dim3((unsigned)ntiles), dim3(kTileThreads), A);
+  // as jxlt_capi.hip: the table-root kernel first; a frame with a quantised magnitude beyond the
+  // table is redone from scratch by the variant that computes every root
+  uint32_t lut_overflow = 0;
+  A.lut_overflow = &lut_overflow;
+  if (flags & 0x400u) {
+    hipsim::launch(tile_kernel_exact_roots, dim3((unsigned)ntiles), dim3(kTileThreads), A);
+  } else {
+    hipsim::launch(tile_kernel, dim3((unsigned)ntiles), dim3(kTileThreads), A);
+    if (lut_overflow) {
+      sim_free(r);
+      for (int c = 0; c < 3; c++) free(A.nzgrid[c]);
+      free(A.blk_nz); free(A.blk_nscan); free(A.coef_scan); free(A.group_ntok); free(A.dc_nac);
+      delete tab;
+      const int rc = sim_encode(planes, pitch_floats, xsize, ysize, distance, scale, inv_scale, scale_dc, x_qm_scale,
+                                flags | 0x400u, r);
+      r->exact_reruns = 1;
+      return rc;
+    }
+  }
 
   r->group_tok_offset = (uint64_t*)calloc(ngroups + 1, 8);
   hipsim::launch(group_scan_kernel, dim3(1), dim3(256), (const uint32_t*)A.group_ntok,

@@ -52,17 +52,20 @@ def build_oracle():
     return ROOT / "oracle" / "liboracle.so"
 
 
-def build_sim():
+def build_sim(tiny_root_table=False):
+    """The kernels on the CPU execution model.  tiny_root_table: a second build whose square-root
+    table has 16 entries, so that ordinary images take tile_kernel's overflow path."""
     d = ROOT / "tests" / "hipsim"
-    out = d / "libjxlt_sim.so"
+    name = "libjxlt_sim_lut16.so" if tiny_root_table else "libjxlt_sim.so"
+    out = d / name
     srcs = [d / "sim_encode.cc", d / "hip" / "hip_runtime.h", PKG / "csrc" / "jxlt_device.h",
             PKG / "csrc" / "jxlt_host_tables.h", PKG / "csrc" / "jxlt_tables.h"]
     if not out.exists() or any(s.stat().st_mtime > out.stat().st_mtime for s in srcs):
         # -Bsymbolic/hidden visibility: the kernels' names also exist (as HIP launch stubs) in
         # libjxltiny_hip.so; the simulator must bind to its own definitions.
         _run(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-mfma", "-fPIC", "-shared", "-I.",
-              "-fvisibility=hidden", "-Wl,-Bsymbolic", "-x", "c++", "sim_encode.cc", "-o",
-              "libjxlt_sim.so"], d)
+              "-fvisibility=hidden", "-Wl,-Bsymbolic"] + (["-DJXLT_SQRT_LUT_SIZE=16"] if tiny_root_table else []) +
+             ["-x", "c++", "sim_encode.cc", "-o", name], d)
     return out
 
 
@@ -97,7 +100,8 @@ def _np(ptr, shape, dtype):
 class HotPathResult:
     """Plain numpy view of one hot-path run (oracle, simulator or GPU)."""
     __slots__ = ("quant_dc", "raw_quant", "strategy", "ytox", "ytob", "group_tokens",
-                 "xyb", "qf", "mask", "ent8", "xsize", "ysize", "histogram", "dc_histogram", "dc_records")
+                 "xyb", "qf", "mask", "ent8", "xsize", "ysize", "histogram", "dc_histogram", "dc_records",
+                 "exact_reruns")
 
     def all_tokens(self):
         return b"".join(self.group_tokens)
@@ -173,14 +177,24 @@ class SimResult(C.Structure):
                 ("xyb", fp * 3), ("qf", fp), ("mask", fp), ("ent8", fp),
                 ("histogram", C.POINTER(C.c_uint32)), ("dc_records", C.POINTER(C.c_uint8)),
                 ("dc_rec_offset", C.POINTER(C.c_uint64)), ("dc_count", C.POINTER(C.c_uint32)),
-                ("num_dc_groups", C.c_size_t)]
+                ("num_dc_groups", C.c_size_t), ("exact_reruns", C.c_uint32)]
 
 
 _sim = None
 
 
-def _sim_lib():
-    global _sim
+_sim_tiny = None
+
+
+def _sim_lib(tiny_root_table=False):
+    global _sim, _sim_tiny
+    if tiny_root_table:
+        if _sim_tiny is None:
+            _sim_tiny = C.CDLL(str(build_sim(True)))
+            _sim_tiny.sim_encode.argtypes = [C.POINTER(fp), C.c_size_t, C.c_size_t, C.c_size_t, C.c_float,
+                                             C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
+                                             C.POINTER(SimResult)]
+        return _sim_tiny
     if _sim is None:
         _sim = C.CDLL(str(build_sim()))
         _sim.sim_encode.argtypes = [C.POINTER(fp), C.c_size_t, C.c_size_t, C.c_size_t, C.c_float,
@@ -258,10 +272,10 @@ def pfm_payload(planes, big_endian=False):
     return a.astype(">f4" if big_endian else "<f4").view(np.float32).reshape(-1).copy()
 
 
-def sim_hot_path(planes, distance, force_dct8=False, as_pfm=None):
+def sim_hot_path(planes, distance, force_dct8=False, as_pfm=None, tiny_root_table=False):
     """Runs the product's HIP kernels on the CPU execution model (tests only).  as_pfm = "le" /
     "be": the kernels read the frame from a raw PFM payload instead of planar planes."""
-    _sim = _sim_lib()
+    _sim = _sim_lib(tiny_root_table)
     _, h, w = planes.shape
     p = distance_params(distance)
     s = SimResult()
@@ -286,6 +300,7 @@ def sim_hot_path(planes, distance, force_dct8=False, as_pfm=None):
     offs = [s.group_tok_offset[g] for g in range(ng + 1)]
     blob = C.string_at(s.tokens, offs[ng] * 3)
     r.group_tokens = [blob[3 * offs[g]:3 * offs[g + 1]] for g in range(ng)]
+    r.exact_reruns = int(s.exact_reruns)
     r.xyb = np.stack([_np(s.xyb[c], (yb * 8, xb * 8), np.float32) for c in range(3)])
     r.qf = _np(s.qf, (yb, xb), np.float32)
     r.mask = _np(s.mask, (yb, xb), np.float32)

@@ -207,3 +207,27 @@ def test_pfm_file_ingest_on_device(built, tmp_path):
     got = built.encode_pfm_file(pfm, 2.0)
     want = T.assemble_codestream(T.oracle_hot_path(T.to_planes(img), 2.0), 2.0)
     assert got == want
+
+
+def test_root_table_overflow_rerun_on_gpu(built, enc):
+    """The C ABI redoes an encode with tile_kernel_exact_roots when tile_kernel reports a
+    quantised magnitude beyond its square-root table (flag 0x1000 makes it report one)."""
+    planes = T.to_planes(T.synthetic_image(300, 264))
+    want = T.oracle_hot_path(planes, 2.0)
+
+    def reruns():
+        n = np.zeros(1, np.uint32)
+        enc._check(enc._L.jxlt_debug_fetch(enc._ctx, 7, n.ctypes.data, 4), "jxlt_debug_fetch")
+        return int(n[0])
+
+    enc.upload(planes)
+    before = reruns()
+    dp = enc.enqueue(2.0, 0x1000)
+    fr = enc.fetch_raw()
+    assert reruns() == before + 1
+    frame = enc.assemble(fr, dp, 0)
+    assert built.file_header(300, 264) + frame == T.assemble_codestream(want, 2.0)
+    # an ordinary encode afterwards is not redone
+    enc.enqueue(2.0, 0)
+    enc.synchronize()
+    assert reruns() == before + 1

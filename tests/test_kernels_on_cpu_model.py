@@ -109,3 +109,19 @@ def test_pfm_payload_ingest_on_cpu_model(built, flavour):
     a = T.sim_hot_path(planes, 1.0)
     b = T.sim_hot_path(planes, 1.0, as_pfm=flavour)
     T.compare_results(a, b, "planar", "pfm payload")
+
+
+def test_root_table_overflow_falls_back_to_computed_roots(built):
+    """tile_kernel takes the square roots of the entropy estimate from a table; a frame with a
+    quantised magnitude beyond it must be detected and redone with computed roots.  Magnitudes
+    >= 1024 hardly occur (the adaptive quantiser sees to that), so this runs a build of the
+    kernels whose table has 16 entries: ordinary images overflow it."""
+    planes = T.to_planes(T.synthetic_image(200, 137, hard=True))
+    got = T.sim_hot_path(planes, 0.5, tiny_root_table=True)
+    assert got.exact_reruns == 1, "the test image no longer overflows the 16-entry root table"
+    want = T.oracle_hot_path(planes, 0.5)
+    assert T.compare_results(want, got, "oracle", "cpu model, computed roots") == []
+    # the product build stays on the table path for the same image, with the same result
+    same = T.sim_hot_path(planes, 0.5)
+    assert same.exact_reruns == 0
+    assert T.compare_results(want, same, "oracle", "cpu model, table roots") == []
