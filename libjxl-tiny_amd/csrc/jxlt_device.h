@@ -1540,13 +1540,15 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   const int ggx = group % A.g.xsize_groups, ggy = group / A.g.xsize_groups;
   const int bx0 = ggx * 32, by0 = ggy * 32;
   const int nbx = imin(32, A.g.xsize_blocks - bx0), nby = imin(32, A.g.ysize_blocks - by0);
-  const size_t bstride = (size_t)A.g.xsize_blocks;
+  // 32-bit block / record indices (the C ABI limits a frame to 2^24 blocks, a group's tokens to
+  // 196 608 records): addresses are scalar base + 32-bit lane offset, no 64-bit vector arithmetic
+  const uint32_t bstride = (uint32_t)A.g.xsize_blocks;
 
   // token count + metadata per entry; predicted-nzeros grid of the group -> LDS
   const int nblk = nbx * nby;
   for (int b = tid; b < nblk; b += kTokenThreads) {
     const int bx = b % nbx, by = b / nbx;
-    const size_t pos = (size_t)(by0 + by) * bstride + bx0 + bx;
+    const uint32_t pos = (uint32_t)(by0 + by) * bstride + (uint32_t)(bx0 + bx);
     const uint32_t a = A.strategy[pos];
     const int covered = (a >> 1) == 0 ? 1 : 2;
     uint32_t nsum = 0;
@@ -1599,7 +1601,7 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   int bx = wave % nbx, by = wave / nbx;
   const int dbx = kWaves % nbx, dby = kWaves / nbx;
   auto load_block = [&](int b, int bxx, int byy, int16_t* v) {
-    const size_t pos = (size_t)(by0 + byy) * bstride + bx0 + bxx;
+    const uint32_t pos = (uint32_t)(by0 + byy) * bstride + (uint32_t)(bx0 + bxx);
 #pragma unroll
     for (int ci = 0; ci < 3; ci++) {
       const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
@@ -1619,7 +1621,7 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
       by++;
     }
     if (b + kWaves < nblk) load_block(b + kWaves, bx, by, next_v);
-    const size_t pos = (size_t)(by0 + cby) * bstride + bx0 + cbx;
+    const uint32_t pos = (uint32_t)(by0 + cby) * bstride + (uint32_t)(bx0 + cbx);
     uint32_t tok_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)offs[b]);  // first token of the block
 #pragma unroll
     for (int ci = 0; ci < 3; ci++) {
@@ -1632,7 +1634,7 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
       const int covered = st == 0 ? 1 : 2;
       const int log2c = covered == 1 ? 0 : 1;
       const int size = covered * 64;
-      const size_t pos1 = pos + (st == 1 ? bstride : 1);
+      const uint32_t pos1 = pos + (st == 1 ? bstride : 1u);
       const int nzeros = (int)((m >> 8) & 0xFF);
       const int nscan = (int)(m >> 16);
       const uint32_t tok0 = tok_next;
@@ -1649,7 +1651,7 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
         else pred = (nzg[-nbx] + nzg[-1] + 1) / 2;
         const int bucket = pred < 8 ? pred : pred >= 64 ? 36 : 4 + pred / 2;
         const int ctx = bucket * 4 + block_ctx;
-        uint8_t* o = out + 3 * (size_t)tok0;
+        uint8_t* o = out + 3u * tok0;
         const uint8_t cm = s_ctx_map[ctx];
         o[0] = cm;
         o[1] = (uint8_t)(nzeros & 0xFF);
@@ -1684,7 +1686,7 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
           const int ctx = histo_offset + zctx;
           const uint32_t val = pack_signed((int32_t)v);
           const uint8_t cm = s_ctx_map[ctx];
-          uint8_t* o = out + 3 * ((size_t)tok0 + 1 + (k - covered));
+          uint8_t* o = out + 3u * (tok0 + 1u + (uint32_t)(k - covered));
           o[0] = cm;
           o[1] = (uint8_t)(val & 0xFF);
           o[2] = (uint8_t)((val >> 8) & 0xFF);
