@@ -1673,13 +1673,18 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
         const bool in_range = k >= covered && k < nscan;
         const bool nz = in_range && v != 0;
         const unsigned long long mk = __ballot(nz);
+        // the previous lane's flag (wave_shr:1 DPP; lane 0 takes the carry of the previous chunk)
+        const int prev_nz = __builtin_amdgcn_update_dpp(0, nz ? 1 : 0, 0x138, 0xF, 0xF, false);
         if (in_range) {
           // nzeros still to come at position k, and whether position k-1 was nonzero
-          const int left = nzeros - (nz_before + __popcll(mk & ((1ull << lane) - 1ull)));
+          // (v_mbcnt: set bits of the ballot below this lane)
+          const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+          const int left = nzeros - (nz_before + below);
           int p;
           if (k == covered) p = (nzeros > size / 16) ? 0 : 1;
           else if (lane == 0) p = carry_flag;
-          else p = (int)((mk >> (lane - 1)) & 1ull);
+          else p = prev_nz;
           const int nl = (left + covered - 1) >> log2c;
           const int kk = k >> log2c;
           const int zctx = (s_nnz_ctx[nl] + s_freq_ctx[kk]) * 2 + p;

@@ -287,6 +287,8 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int dpp_ctrl, int row_m
   } else if (dpp_ctrl >= 0x111 && dpp_ctrl <= 0x11F) {
     const int t = in_row - (dpp_ctrl - 0x110);
     src_lane = t >= 0 ? (lane & ~15) | t : -1;
+  } else if (dpp_ctrl == 0x138) {  // wave_shr:1 -- lane i reads lane i - 1 of the whole wave
+    src_lane = lane >= 1 ? lane - 1 : -1;
   } else {
     fprintf(stderr, "hipsim: unsupported dpp_ctrl 0x%x\n", dpp_ctrl);
     abort();
@@ -332,6 +334,18 @@ inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 // v_alignbyte_b32: ({hi, lo} >> (8 * (shift & 3))) & 0xffffffff
 inline uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, uint32_t shift) {
   return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (shift & 3)));
+}
+
+// v_mbcnt_lo/hi: add the number of set mask bits below the calling lane
+inline uint32_t __builtin_amdgcn_mbcnt_lo(uint32_t mask, uint32_t add) {
+  const int lane = hipsim_lane();
+  const uint32_t below = lane >= 32 ? 0xFFFFFFFFu : ((1u << lane) - 1u);
+  return add + (uint32_t)__builtin_popcount(mask & below);
+}
+inline uint32_t __builtin_amdgcn_mbcnt_hi(uint32_t mask, uint32_t add) {
+  const int lane = hipsim_lane();
+  const uint32_t below = lane <= 32 ? 0u : (lane >= 64 ? 0xFFFFFFFFu : ((1u << (lane - 32)) - 1u));
+  return add + (uint32_t)__builtin_popcount(mask & below);
 }
 
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
