@@ -1622,76 +1622,123 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     }
     if (b + kWaves < nblk) load_block(b + kWaves, bx, by, next_v);
     const uint32_t pos = (uint32_t)(by0 + cby) * bstride + (uint32_t)(bx0 + cbx);
-    uint32_t tok_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)offs[b]);  // first token of the block
+    // The three channel entries of a block are independent: their ballots, table look-ups and
+    // stores are written as straight-line code (no branches in between) so that the dependent
+    // LDS reads of one entry overlap with the other two (the kernel is latency bound).
+    const uint32_t m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta[b * 3]);
+    if (!(m0 & 1)) continue;  // not the first block of a transform: no entries
+    const uint32_t ms[3] = {m0, (uint32_t)__builtin_amdgcn_readfirstlane((int)meta[b * 3 + 1]),
+                            (uint32_t)__builtin_amdgcn_readfirstlane((int)meta[b * 3 + 2])};
+    const int st = (int)((m0 >> 1) & 0x7F);
+    const int covered = st == 0 ? 1 : 2;
+    const int log2c = covered == 1 ? 0 : 1;
+    const int size = covered * 64;
+    const uint32_t pos1 = pos + (st == 1 ? bstride : 1u);
+    int nzeros[3], nscan[3];
+    uint32_t tok0[3];
+    {
+      uint32_t tok = (uint32_t)__builtin_amdgcn_readfirstlane((int)offs[b]);  // first token of the block
+#pragma unroll
+      for (int ci = 0; ci < 3; ci++) {
+        nzeros[ci] = (int)((ms[ci] >> 8) & 0xFF);
+        nscan[ci] = (int)(ms[ci] >> 16);
+        tok0[ci] = tok;
+        tok += 1 + (nscan[ci] > covered ? nscan[ci] - covered : 0);
+      }
+    }
+    // block context (ac_context.h:64-114): kBlockContextMap[c*27 + code] is 0/1 for Y and
+    // 2/3 for X,B, the odd value for the two-block strategy codes 6 and 7
+    const int bctx_y = st == 0 ? 0 : 1, bctx_c = 2 + bctx_y;
+    // (1) the nzeros token of each entry: lanes 0..2, one channel each
+    if (lane < 3) {
+      const int c = lane == 0 ? 1 : lane == 1 ? 0 : 2;
+      const int nzl = lane == 0 ? nzeros[0] : lane == 1 ? nzeros[1] : nzeros[2];
+      const uint32_t tl = lane == 0 ? tok0[0] : lane == 1 ? tok0[1] : tok0[2];
+      // PredictFromTopAndLeft (enc_group.cc:150-160), default 32
+      int pred;
+      const uint8_t* nzg = &s_nzg[c * 1024 + b];
+      if (cbx == 0) pred = cby == 0 ? 32 : nzg[-nbx];
+      else if (cby == 0) pred = nzg[-1];
+      else pred = (nzg[-nbx] + nzg[-1] + 1) / 2;
+      const int bucket = pred < 8 ? pred : pred >= 64 ? 36 : 4 + pred / 2;
+      const int ctx = bucket * 4 + (lane == 0 ? bctx_y : bctx_c);
+      uint8_t* o = out + 3u * tl;
+      const uint8_t cm = s_ctx_map[ctx];
+      o[0] = cm;
+      o[1] = (uint8_t)(nzl & 0xFF);
+      o[2] = (uint8_t)(nzl >> 8);
+      if (do_hist) {
+        uint32_t sym, nb, eb;
+        hybrid_uint((uint32_t)nzl, &sym, &nb, &eb);
+        atomicAdd(&hist[cm * 64 + sym], 1u);
+      }
+    }
+    // (2) scan positions 0..63 of the three entries
+    unsigned long long mk[3];
+    bool inr[3];
+    int zidx[3], p_prev[3];
 #pragma unroll
     for (int ci = 0; ci < 3; ci++) {
-      const int e = b * 3 + ci;
-      const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
-      const int16_t v0 = cur_v[ci];
-      const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta[e]);
-      if (!(m & 1)) continue;
-      const int st = (int)((m >> 1) & 0x7F);
-      const int covered = st == 0 ? 1 : 2;
-      const int log2c = covered == 1 ? 0 : 1;
-      const int size = covered * 64;
-      const uint32_t pos1 = pos + (st == 1 ? bstride : 1u);
-      const int nzeros = (int)((m >> 8) & 0xFF);
-      const int nscan = (int)(m >> 16);
-      const uint32_t tok0 = tok_next;
-      tok_next += 1 + (nscan > covered ? nscan - covered : 0);
-      // block context (ac_context.h:64-114): kBlockContextMap[c*27 + code] is 0/1 for Y and
-      // 2/3 for X,B, the odd value for the two-block strategy codes 6 and 7
-      const int block_ctx = (c == 1 ? 0 : 2) + (st == 0 ? 0 : 1);
-      if (lane == 0) {
-        // PredictFromTopAndLeft (enc_group.cc:150-160), default 32
-        int pred;
-        const uint8_t* nzg = &s_nzg[c * 1024 + b];
-        if (cbx == 0) pred = cby == 0 ? 32 : nzg[-nbx];
-        else if (cby == 0) pred = nzg[-1];
-        else pred = (nzg[-nbx] + nzg[-1] + 1) / 2;
-        const int bucket = pred < 8 ? pred : pred >= 64 ? 36 : 4 + pred / 2;
-        const int ctx = bucket * 4 + block_ctx;
-        uint8_t* o = out + 3u * tok0;
-        const uint8_t cm = s_ctx_map[ctx];
-        o[0] = cm;
-        o[1] = (uint8_t)(nzeros & 0xFF);
-        o[2] = (uint8_t)(nzeros >> 8);
+      inr[ci] = lane >= covered && lane < nscan[ci];
+      const bool nz = inr[ci] && cur_v[ci] != 0;
+      mk[ci] = __ballot(nz);
+      // the previous lane's flag (wave_shr:1 DPP)
+      p_prev[ci] = __builtin_amdgcn_update_dpp(0, nz ? 1 : 0, 0x138, 0xF, 0xF, false);
+    }
+#pragma unroll
+    for (int ci = 0; ci < 3; ci++) {
+      // nzeros still to come at this position (v_mbcnt: set bits of the ballot below this lane)
+      const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk[ci] >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)mk[ci], 0u));
+      const int left = nzeros[ci] - below;
+      const int nl = inr[ci] ? (left + covered - 1) >> log2c : 0;
+      zidx[ci] = s_nnz_ctx[nl] + s_freq_ctx[lane >> log2c];
+    }
+    uint8_t cms[3];
+#pragma unroll
+    for (int ci = 0; ci < 3; ci++) {
+      const int p = lane == covered ? ((nzeros[ci] > size / 16) ? 0 : 1) : p_prev[ci];
+      const int ctx = 4 * 37 + 458 * (ci == 0 ? bctx_y : bctx_c) + zidx[ci] * 2 + p;
+      cms[ci] = s_ctx_map[inr[ci] ? ctx : 0];
+    }
+#pragma unroll
+    for (int ci = 0; ci < 3; ci++) {
+      if (inr[ci]) {
+        const uint32_t val = pack_signed((int32_t)cur_v[ci]);
+        uint8_t* o = out + 3u * (tok0[ci] + 1u + (uint32_t)(lane - covered));
+        o[0] = cms[ci];
+        o[1] = (uint8_t)(val & 0xFF);
+        o[2] = (uint8_t)((val >> 8) & 0xFF);
         if (do_hist) {
           uint32_t sym, nb, eb;
-          hybrid_uint((uint32_t)nzeros, &sym, &nb, &eb);
-          atomicAdd(&hist[cm * 64 + sym], 1u);
+          hybrid_uint(val & 0xFFFFu, &sym, &nb, &eb);
+          atomicAdd(&hist[cms[ci] * 64 + sym], 1u);
         }
       }
-      if (nzeros == 0) continue;
-      const int histo_offset = 4 * 37 + 458 * block_ctx;
-      int nz_before = 0;   // nonzeros at scan positions before the current 64-chunk
-      int carry_flag = 0;  // nonzero flag of the last position of the previous chunk
-      const int nhalf = nscan > 64 ? 2 : 1;  // the second 64 positions only if tokens reach them
-      for (int half = 0; half < nhalf; half++) {
-        const int k = half * 64 + lane;
-        const int16_t v = half == 0 ? v0 : (64 + lane < nscan ? A.coef_scan[(pos1 * 3 + c) * 64 + lane] : (int16_t)0);
-        const bool in_range = k >= covered && k < nscan;
+    }
+    // (3) two-block transforms whose tokens reach beyond scan position 63 (uncommon)
+    if (nscan[0] > 64 || nscan[1] > 64 || nscan[2] > 64) {
+#pragma unroll
+      for (int ci = 0; ci < 3; ci++) {
+        if (nscan[ci] <= 64) continue;
+        const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
+        const int k = 64 + lane;
+        const int16_t v = k < nscan[ci] ? A.coef_scan[(pos1 * 3 + c) * 64 + lane] : (int16_t)0;
+        const bool in_range = k < nscan[ci];
         const bool nz = in_range && v != 0;
-        const unsigned long long mk = __ballot(nz);
-        // the previous lane's flag (wave_shr:1 DPP; lane 0 takes the carry of the previous chunk)
+        const unsigned long long mk2 = __ballot(nz);
         const int prev_nz = __builtin_amdgcn_update_dpp(0, nz ? 1 : 0, 0x138, 0xF, 0xF, false);
         if (in_range) {
-          // nzeros still to come at position k, and whether position k-1 was nonzero
-          // (v_mbcnt: set bits of the ballot below this lane)
-          const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32),
-                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-          const int left = nzeros - (nz_before + below);
-          int p;
-          if (k == covered) p = (nzeros > size / 16) ? 0 : 1;
-          else if (lane == 0) p = carry_flag;
-          else p = prev_nz;
+          const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk2 >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)mk2, 0u));
+          const int left = nzeros[ci] - (__popcll(mk[ci]) + below);
+          const int p = lane == 0 ? (int)((mk[ci] >> 63) & 1ull) : prev_nz;
           const int nl = (left + covered - 1) >> log2c;
-          const int kk = k >> log2c;
-          const int zctx = (s_nnz_ctx[nl] + s_freq_ctx[kk]) * 2 + p;
-          const int ctx = histo_offset + zctx;
+          const int zctx = (s_nnz_ctx[nl] + s_freq_ctx[k >> log2c]) * 2 + p;
+          const int ctx = 4 * 37 + 458 * (ci == 0 ? bctx_y : bctx_c) + zctx;
           const uint32_t val = pack_signed((int32_t)v);
           const uint8_t cm = s_ctx_map[ctx];
-          uint8_t* o = out + 3u * (tok0 + 1u + (uint32_t)(k - covered));
+          uint8_t* o = out + 3u * (tok0[ci] + 1u + (uint32_t)(k - covered));
           o[0] = cm;
           o[1] = (uint8_t)(val & 0xFF);
           o[2] = (uint8_t)((val >> 8) & 0xFF);
@@ -1701,8 +1748,6 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
             atomicAdd(&hist[cm * 64 + sym], 1u);
           }
         }
-        nz_before += __popcll(mk);
-        carry_flag = (int)((mk >> 63) & 1ull);
       }
     }
   }
