@@ -1971,9 +1971,15 @@ __global__ void __launch_bounds__(256) pack_tile_finalize_kernel(const PackTileA
 
 __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const PackTileArgs A) {
   __shared__ uint32_t table[64 * 64];
-  __shared__ uint32_t window[kPackWindowWords];
+  // The staged records (the tile and the 64 records before it) are dead once every thread holds
+  // its records' bits; the bit window then uses the same memory (31 KB of LDS per workgroup
+  // instead of 44: a fourth workgroup per CU).
+  constexpr int kStageWords = (kPackTile + 64) * 3 / 4 + 4;
+  __shared__ alignas(16) uint32_t stage_or_window[kPackWindowWords > kStageWords ? kPackWindowWords : kStageWords];
+  uint32_t* const stage = stage_or_window;
+  uint32_t* const window = stage_or_window;
   __shared__ uint32_t wave_sum[kPackThreads / 64];
-  __shared__ alignas(16) uint32_t stage[(kPackTile + 64) * 3 / 4 + 4];  // the tile and the 64 records before it
+  __shared__ uint32_t first_word;  // bits of earlier records in the tile's first dword
   const int tid = (int)threadIdx.x;
   const uint32_t ntiles_all = umin32((uint32_t)A.tile_base[A.nsec], A.tile_end);
   const uint32_t first_tile = A.tile_first + blockIdx.x * kPackTilesPerGroup;
@@ -1984,7 +1990,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
     const uint32_t tile = first_tile + kt;
     if (tile >= ntiles_all) break;
     __syncthreads();  // previous tile flushed; table loaded
-    for (int i = tid; i < kPackWindowWords; i += kPackThreads) window[i] = 0u;
+    if (tid == 0) first_word = 0u;
     const PackTileInfo info = A.tile_info[tile];
     const int n = (int)(info.n_last & 0x7FFFFFFFu);
     const bool last_tile = (info.n_last >> 31) != 0;
@@ -2027,7 +2033,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
           const int hi = (int)lead - (int)after, lo = hi - (int)nb;
           const uint32_t v = lo >= 0 ? (data << lo) : (data >> (-lo));
           const uint32_t mask = hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u);
-          atomicOr(&window[0], v & mask);
+          atomicOr(&first_word, v & mask);
         }
         covered += round_bits;
         back = back > 64 ? back - 64 : 0;
@@ -2055,6 +2061,8 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
       if ((tid & 63) >= d) incl += o;
     }
     if ((tid & 63) == 63) wave_sum[tid >> 6] = incl;
+    __syncthreads();  // every thread has read its records: the staging memory becomes the window
+    for (int i = tid; i < kPackWindowWords; i += kPackThreads) window[i] = i == 0 ? first_word : 0u;
     __syncthreads();
     uint32_t wave_base = 0, tile_bits = 0;
 #pragma unroll
