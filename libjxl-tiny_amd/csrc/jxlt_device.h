@@ -1867,7 +1867,24 @@ JXLT_DI void pack_stage_tile(const uint8_t* src, int n, uint32_t* stage, int tid
   const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3u);
   const uint32_t* srcw = reinterpret_cast<const uint32_t*>(src - mis);
   const int nw = (3 * n + 3) >> 2;
-  for (int i = tid; i < nw; i += kPackThreads) stage[i] = __builtin_amdgcn_alignbyte(srcw[i + 1], srcw[i], mis);
+  // Fixed trip count, every load issued before the first use: a loop over a run-time count
+  // waits for each load in turn (seven memory latencies per tile instead of one).
+  constexpr int kIters = ((kPackTile + 64) * 3 / 4 + kPackThreads - 1) / kPackThreads;
+  uint32_t lo[kIters], hi[kIters];
+#pragma unroll
+  for (int k = 0; k < kIters; k++) {
+    const int i = tid + k * kPackThreads;
+    lo[k] = hi[k] = 0;
+    if (i < nw) {
+      lo[k] = srcw[i];
+      hi[k] = srcw[i + 1];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kIters; k++) {
+    const int i = tid + k * kPackThreads;
+    if (i < nw) stage[i] = __builtin_amdgcn_alignbyte(hi[k], lo[k], mis);
+  }
 }
 
 // The kPackPerThread consecutive records of thread `tid` (3 * kPackPerThread bytes = 12 dwords,
@@ -1901,7 +1918,7 @@ JXLT_DI void pack_bits_of(uint32_t rec24, const uint32_t* table, uint32_t* nb, u
   }
 }
 
-constexpr int kPackTilesPerGroup = 2;  // consecutive tiles per workgroup (amortises the table load)
+constexpr int kPackTilesPerGroup = 4;  // consecutive tiles per workgroup (amortises the table load)
 
 __global__ void __launch_bounds__(kPackThreads) pack_tile_measure_kernel(const PackTileArgs A) {
   __shared__ uint8_t depth[64 * 64];
@@ -1913,11 +1930,14 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_measure_kernel(const P
   if (first >= ntiles_all) return;
   for (int i = tid; i < 64 * 64; i += kPackThreads) depth[i] = (uint8_t)(A.code_table[i] >> 16);
   if (tid < kPackTilesPerGroup) total[tid] = 0;
+  PackTileInfo next_info = A.tile_info[first];
   for (int k = 0; k < kPackTilesPerGroup; k++) {
     const uint32_t tile = first + k;
     if (tile >= ntiles_all) break;
     __syncthreads();  // previous tile's stage consumed; tables loaded
-    const PackTileInfo info = A.tile_info[tile];
+    const PackTileInfo info = next_info;
+    // (the next tile's descriptor is requested now: one memory latency less per tile)
+    next_info = A.tile_info[tile + 1 < ntiles_all ? tile + 1 : tile];
     const int n = (int)(info.n_last & 0x7FFFFFFFu);
     pack_stage_tile(A.records + 3 * info.rec_first, n, stage, tid);
     __syncthreads();
@@ -1986,12 +2006,14 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
   if (first_tile >= ntiles_all) return;
   for (int i = tid; i < 64 * 64; i += kPackThreads) table[i] = A.code_table[i];
   uint32_t* outw = reinterpret_cast<uint32_t*>(A.out);
+  PackTileInfo next_info = A.tile_info[first_tile];
   for (int kt = 0; kt < kPackTilesPerGroup; kt++) {
     const uint32_t tile = first_tile + kt;
     if (tile >= ntiles_all) break;
     __syncthreads();  // previous tile flushed; table loaded
     if (tid == 0) first_word = 0u;
-    const PackTileInfo info = A.tile_info[tile];
+    const PackTileInfo info = next_info;
+    next_info = A.tile_info[tile + 1 < ntiles_all ? tile + 1 : tile];  // requested one tile ahead
     const int n = (int)(info.n_last & 0x7FFFFFFFu);
     const bool last_tile = (info.n_last >> 31) != 0;
     const uint8_t* tile_src = A.records + 3 * info.rec_first;
