@@ -2004,7 +2004,13 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
   const uint32_t ntiles_all = umin32((uint32_t)A.tile_base[A.nsec], A.tile_end);
   const uint32_t first_tile = A.tile_first + blockIdx.x * kPackTilesPerGroup;
   if (first_tile >= ntiles_all) return;
-  for (int i = tid; i < 64 * 64; i += kPackThreads) table[i] = A.code_table[i];
+  {  // (all eight loads of the code table in flight before the first LDS store)
+    uint32_t tl[64 * 64 / kPackThreads];
+#pragma unroll
+    for (int q = 0; q < 64 * 64 / kPackThreads; q++) tl[q] = A.code_table[tid + q * kPackThreads];
+#pragma unroll
+    for (int q = 0; q < 64 * 64 / kPackThreads; q++) table[tid + q * kPackThreads] = tl[q];
+  }
   uint32_t* outw = reinterpret_cast<uint32_t*>(A.out);
   PackTileInfo next_info = A.tile_info[first_tile];
   for (int kt = 0; kt < kPackTilesPerGroup; kt++) {
