@@ -231,3 +231,24 @@ def test_root_table_overflow_rerun_on_gpu(built, enc):
     enc.enqueue(2.0, 0)
     enc.synchronize()
     assert reruns() == before + 1
+
+
+def _random_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(n):
+        w = int(rng.integers(9, 900))
+        h = int(rng.integers(9, 700))
+        d = float(np.round(10 ** rng.uniform(-1.3, 1.2), 3))  # 0.05 .. 16
+        cases.append((w, h, d, int(rng.integers(0, 1 << 30))))
+    return cases
+
+
+@pytest.mark.parametrize("w,h,distance,seed", _random_cases(10, 20260902))
+def test_random_frames_codestream_equals_oracle(built, w, h, distance, seed):
+    """Random geometries (partial tiles, stripes and groups on both axes), distances across the
+    supported range and per-case pixel seeds: the drop-in's codestream equals the oracle's."""
+    img = T.synthetic_image(w, h, seed=seed, hard=(seed % 3 == 0))
+    planes = T.to_planes(img)
+    want = T.assemble_codestream(T.oracle_hot_path(planes, distance), distance)
+    assert built.encode_file(planes, distance) == want
