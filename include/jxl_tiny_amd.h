@@ -123,6 +123,11 @@ int jxlt_image_size(const jxlt_context* ctx, size_t* xsize, size_t* ysize);
 int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params);
 /* Blocks until the enqueued work has finished. */
 int jxlt_synchronize(jxlt_context* ctx);
+/* The reference computes two multipliers of its transform search from the distance of the FIRST
+ * EncodeFile call of the process and reuses them afterwards (function-local static constants,
+ * enc_ac_strategy.cc:178-185).  To reproduce a later call of such a process bit for bit, pass
+ * that first distance here; 0 (default) = every encode uses its own distance. */
+int jxlt_set_strategy_distance(jxlt_context* ctx, float first_call_distance);
 /* Copies results to pinned host memory (blocking) and fills *out. */
 int jxlt_fetch_result(jxlt_context* ctx, jxlt_frame_result* out);
 
@@ -233,6 +238,10 @@ int jxlt_encode_file_planar(const float* const planes[3], size_t pitch_bytes, si
  * kernels (jxlt_image_upload_pfm) instead of by a host pass. */
 int jxlt_encode_pfm_file(const char* filename, float distance, int device_ordinal, uint8_t** out_bytes,
                          size_t* out_size);
+/* jxl::EmulateReferenceStaticConstants (host/encoder/enc_frame.h): latch the first distance this
+ * process encodes with for the transform search's two multipliers, as the reference library
+ * does (enc_ac_strategy.cc:178-185).  Off by default. */
+void jxlt_emulate_reference_static_constants(int on);
 /* Codestream + image headers that precede the frame (enc_file.cc:70-95). */
 int jxlt_write_file_header(size_t xsize, size_t ysize, uint8_t** out_bytes, size_t* out_size);
 /* ---- one frame sharded over several contexts / GPUs / processes ----------------

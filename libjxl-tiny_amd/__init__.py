@@ -30,13 +30,13 @@ FLAG_FORCE_DCT8, FLAG_DEBUG_DUMP, FLAG_PROFILE = 1, 2, 4
 # Symbols include/jxl_tiny_amd.h declares, per library (checked by the tests).
 HIP_SYMBOLS = ["jxlt_context_create", "jxlt_context_destroy", "jxlt_last_error",
                "jxlt_image_upload", "jxlt_image_set_device", "jxlt_image_upload_pfm", "jxlt_image_set_device_pfm", "jxlt_image_size", "jxlt_pinned_alloc",
-               "jxlt_pinned_free", "jxlt_encode_enqueue",
+               "jxlt_pinned_free", "jxlt_encode_enqueue", "jxlt_set_strategy_distance",
                "jxlt_fetch_side_info", "jxlt_fetch_histograms", "jxlt_fetch_dc_histogram", "jxlt_pack_ac_sections", "jxlt_pack_sections",
                "jxlt_pack_sections_sizes", "jxlt_pack_sections_copy", "jxlt_pack_sections_place", "jxlt_pack_measure", "jxlt_pack_write",
                "jxlt_output_buffer",
                "jxlt_synchronize", "jxlt_fetch_result", "jxlt_kernel_times", "jxlt_debug_fetch"]
 HOST_SYMBOLS = ["jxlt_compute_distance_params", "jxlt_assemble_frame", "jxlt_assemble_frame_groups",
-                "jxlt_encode_file_planar", "jxlt_encode_pfm_file", "jxlt_encode_resident", "jxlt_encode_resident_view", "jxlt_write_file_header", "jxlt_build_code_tables", "jxlt_finish_frame",
+                "jxlt_encode_file_planar", "jxlt_encode_pfm_file", "jxlt_emulate_reference_static_constants", "jxlt_encode_resident", "jxlt_encode_resident_view", "jxlt_write_file_header", "jxlt_build_code_tables", "jxlt_finish_frame",
                 "jxlt_debug_dc_records", "jxlt_free"]
 
 
@@ -264,6 +264,13 @@ class Encoder:
         self._check(self._L.jxlt_image_set_device(self._ctx, arr, pitch_bytes, w, h), "jxlt_image_set_device")
         self._keepalive = keepalive
 
+    def set_strategy_distance(self, first_call_distance):
+        """Reproduce a later EncodeFile call of a reference process whose first call used this
+        distance (jxlt_set_strategy_distance); 0 switches it off."""
+        self._L.jxlt_set_strategy_distance.argtypes = [C.c_void_p, C.c_float]
+        self._check(self._L.jxlt_set_strategy_distance(self._ctx, C.c_float(first_call_distance)),
+                    "jxlt_set_strategy_distance")
+
     def enqueue(self, distance, flags=0):
         dp = distance_params(distance)
         p = Params(dp.distance, dp.scale, dp.inv_scale, dp.scale_dc, dp.x_qm_scale, flags)
@@ -392,6 +399,12 @@ def finish_frame(xsize, ysize, distance, ac_hist, dc_hist, dc_sections, ac_secti
     if rc != 0:
         raise JxlTinyError("jxlt_finish_frame failed (%d)" % rc)
     return _take_bytes(out, n)
+
+
+def emulate_reference_static_constants(on):
+    """jxl::EmulateReferenceStaticConstants: latch the process's first distance for the transform
+    search's multipliers like the reference library (enc_ac_strategy.cc:178-185)."""
+    host_lib().jxlt_emulate_reference_static_constants(1 if on else 0)
 
 
 def encode_pfm_file(path, distance, device=0):

@@ -53,6 +53,7 @@ struct jxlt_context {
   ptrdiff_t pitch_floats = 0;  // floats per row (negative for a bottom-up PFM payload)
   int pix_stride = 1;          // floats between adjacent samples of a plane (3: interleaved RGB)
   int byteswap = 0;            // big-endian samples
+  float strategy_distance = 0.0f;  // jxlt_set_strategy_distance (0: each encode's own distance)
   DeviceBuf<float> own_payload;  // jxlt_image_upload_pfm
   size_t xsize = 0, ysize = 0;
 
@@ -563,6 +564,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
   A.byteswap = ctx->byteswap;
   A.g = g;
   A.distance = params->distance;
+  A.strategy_distance = ctx->strategy_distance > 0.0f ? ctx->strategy_distance : params->distance;
   A.scale = params->scale;
   A.inv_scale = params->inv_scale;
   A.scale_dc = params->scale_dc;
@@ -672,6 +674,12 @@ int ResolveRootTableOverflow(jxlt_context* ctx) {
 }  // namespace
 
 int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) { return EnqueuePipeline(ctx, params, false); }
+
+int jxlt_set_strategy_distance(jxlt_context* ctx, float first_call_distance) {
+  if (!ctx || !(first_call_distance >= 0.0f)) return JXLT_ERR_INVALID_ARGUMENT;
+  ctx->strategy_distance = first_call_distance;
+  return JXLT_OK;
+}
 
 int jxlt_synchronize(jxlt_context* ctx) {
   if (!ctx) return JXLT_ERR_INVALID_ARGUMENT;

@@ -79,6 +79,8 @@ struct TileArgs {
   FrameGeom g;
   float distance, scale, inv_scale, scale_dc;
   float x_qm_mul;  // 1.25^(x_qm_scale-2)
+  float strategy_distance;  // distance behind mul8x8 / mul16x8 (enc_ac_strategy.cc:178-185: the
+                            // reference freezes them at its first call; normally == distance)
   uint32_t flags;  // bit0: force DCT8
   const DeviceTables* tab;
   // outputs (image-absolute grids)
@@ -1299,7 +1301,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       const float k8x8mul1 = (float)(-0.55 * 0.75f);
       const float k8x8mul2 = 1.0735757687292623f * 0.75f;
       const float k8x8base = (float)1.4;
-      const float mul8x8 = k8x8mul2 + k8x8mul1 / (A.distance + k8x8base);
+      const float mul8x8 = k8x8mul2 + k8x8mul1 / (A.strategy_distance + k8x8base);
       float e8 = 3.0f * mul8x8;
       e8 += mul8x8 * e;
       if (l == 0) S.ent8[((oby >> 1) * 4 + (obx >> 1)) * 8 + (oby & 1) * 2 + (obx & 1)] = e8;
@@ -1328,7 +1330,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       qmax = fmaxf(qmax, qmax16);
       const float k8X16mul1 = (float)-0.55, k8X16mul2 = (float)0.9019587899705066,
                   k8X16base = (float)1.6;
-      const float mul16x8 = k8X16mul2 + k8X16mul1 / (A.distance + k8X16base);
+      const float mul16x8 = k8X16mul2 + k8X16mul1 / (A.strategy_distance + k8X16base);
       if (l == 0) S.ent8[cell * 8 + (is_tall ? 4 : 6) + (cand & 1)] = mul16x8 * e;
     }
     JXLT_SCHED_FENCE();

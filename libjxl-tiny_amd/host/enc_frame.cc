@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <functional>
@@ -42,6 +43,16 @@ FrameView ViewOf(const jxlt_frame_result& res, const uint8_t* const* group_ptr, 
 // enc_frame.cc:805-811) take the raw-token route.
 // Appends the frame to `writer` (if non-null); otherwise asks `placer(frame_bytes)` for the
 // destination and writes the frame there (the AC blob comes straight from the device).
+namespace {
+std::atomic<bool> g_emulate_static_constants{false};
+std::atomic<float> g_first_distance{0.0f};  // latched by the first frame while the emulation is on
+}  // namespace
+
+void SetStaticConstantEmulation(bool on) {
+  g_emulate_static_constants.store(on);
+  if (!on) g_first_distance.store(0.0f);
+}
+
 bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jxl::BitWriter* writer,
                           const std::function<uint8_t*(size_t)>* placer, ContextOutput* in_context) {
   static const bool trace = getenv("JXLT_TRACE") != nullptr;
@@ -58,6 +69,15 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   params.scale_dc = distp.scale_dc;
   params.x_qm_scale = distp.x_qm_scale;
   params.flags = 0;
+  {
+    float latched = 0.0f;
+    if (g_emulate_static_constants.load()) {
+      float expected = 0.0f;
+      g_first_distance.compare_exchange_strong(expected, distp.distance);  // first frame wins
+      latched = g_first_distance.load();
+    }
+    jxlt_set_strategy_distance(ctx, latched);
+  }
   if (jxlt_encode_enqueue(ctx, &params) != JXLT_OK) {
     fprintf(stderr, "jxl_tiny_amd: device encode failed: %s\n", jxlt_last_error(ctx));
     return false;
@@ -231,6 +251,8 @@ jxlt_context* AcquireContextForThread() {
 }
 
 void SetEncoderDevice(int device_ordinal) { g_device = device_ordinal; }
+
+void EmulateReferenceStaticConstants(bool on) { jxlt::SetStaticConstantEmulation(on); }
 
 }  // namespace jxl
 

@@ -21,6 +21,14 @@ Status EncodeFrame(float distance, const Image3F& linear, ThreadPool* pool, BitW
 // subsequent EncodeFrame/EncodeFile calls (default 0).
 void SetEncoderDevice(int device_ordinal);
 
+// Not in the reference: the reference derives two multipliers of its transform search from the
+// distance of the FIRST frame the process encodes (function-local static constants,
+// enc_ac_strategy.cc:178-185) and reuses them for every later frame.  Off (default): every frame
+// uses its own distance, which is what a single-image cjxl_tiny run does anyway.  On: the first
+// distance this process encodes with is latched the same way, so that a multi-image process is
+// byte-identical to the reference library used the same way.
+void EmulateReferenceStaticConstants(bool on);
+
 }  // namespace jxl
 
 #endif  // JXLT_HOST_ENCODER_ENC_FRAME_H_

@@ -98,6 +98,8 @@ int jxlt_encode_pfm_file(const char* filename, float distance, int device_ordina
   return JXLT_OK;
 }
 
+void jxlt_emulate_reference_static_constants(int on) { jxl::EmulateReferenceStaticConstants(on != 0); }
+
 int jxlt_write_file_header(size_t xsize, size_t ysize, uint8_t** out_bytes, size_t* out_size) {
   jxl::BitWriter writer;
   if (!jxlt::WriteFileHeader(xsize, ysize, &writer)) return JXLT_ERR_INVALID_ARGUMENT;

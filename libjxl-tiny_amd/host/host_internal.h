@@ -29,6 +29,7 @@ bool WriteFileHeader(size_t xsize, size_t ysize, jxl::BitWriter* writer);
 bool ParsePFMHeader(const uint8_t* data, size_t size, size_t* xsize, size_t* ysize, bool* big_endian,
                     size_t* payload_offset);
 bool NormalizeDistance(float* distance);
+void SetStaticConstantEmulation(bool on);  // jxl::EmulateReferenceStaticConstants
 }  // namespace jxlt
 
 #endif  // JXLT_HOST_INTERNAL_H_

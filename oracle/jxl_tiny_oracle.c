@@ -826,6 +826,14 @@ static float estimate_entropy(int strategy, const stripe_t* s, size_t bx, size_t
 /* ref: enc_ac_strategy.cc:167-238 (FindBest16x16Transform).  strat points at the
  * image-absolute ac_strategy byte of block (tile bx0+cx, by0+cy); sstride = grid pitch.
  * ent8 (optional) receives the 8 candidate entropies. */
+/* ref: enc_ac_strategy.cc:178-185: mul8x8 / mul16x8 are function-local `static const`s of the
+ * reference, i.e. computed from the distance of the FIRST call in the process and reused for every
+ * later frame.  A single-image process (cjxl_tiny) never notices.  g_strategy_distance > 0
+ * reproduces a later call of such a process (the two multipliers come from that distance);
+ * 0 (default) uses the frame's own distance. */
+static float g_strategy_distance = 0.0f;
+void orc_set_strategy_distance(float first_call_distance) { g_strategy_distance = first_call_distance; }
+
 static void find_best_16x16(const stripe_t* s, size_t bx, size_t by, size_t cx, size_t cy,
                             float distance, const dequant_matrices* dq, const float* qf,
                             const float* maskf, int8_t ytox, int8_t ytob, uint8_t* strat,
@@ -833,11 +841,12 @@ static void find_best_16x16(const stripe_t* s, size_t bx, size_t by, size_t cx, 
   const float k8x8mul1 = (float)(-0.55 * 0.75f);
   const float k8x8mul2 = 1.0735757687292623f * 0.75f;
   const float k8x8base = (float)1.4;
-  const float mul8x8 = k8x8mul2 + k8x8mul1 / (distance + k8x8base);
+  const float sdist = g_strategy_distance > 0.0f ? g_strategy_distance : distance;
+  const float mul8x8 = k8x8mul2 + k8x8mul1 / (sdist + k8x8base);
   const float k8X16mul1 = (float)-0.55;
   const float k8X16mul2 = (float)0.9019587899705066;
   const float k8X16base = (float)1.6;
-  const float mul16x8 = k8X16mul2 + k8X16mul1 / (distance + k8X16base);
+  const float mul16x8 = k8X16mul2 + k8X16mul1 / (sdist + k8X16base);
   float entropy[2][2];
   for (size_t dy = 0; dy < 2; ++dy)
     for (size_t dx = 0; dx < 2; ++dx) {

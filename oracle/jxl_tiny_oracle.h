@@ -80,6 +80,9 @@ int orc_encode_hot_path(const float* const planes[3], size_t stride_floats,
                         size_t xsize, size_t ysize, float distance,
                         int force_dct8, orc_frame* out);
 void orc_frame_free(orc_frame* f);
+/* Emulates a later EncodeFile call of a process whose first call used `first_call_distance`
+ * (the reference's function-local static constants, enc_ac_strategy.cc:178-185); 0 = off. */
+void orc_set_strategy_distance(float first_call_distance);
 
 /* Stage-level entry points for unit parity tests. */
 void orc_to_xyb(float* r, float* g, float* b, size_t n); /* in place */

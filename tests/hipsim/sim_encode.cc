@@ -34,6 +34,8 @@ struct sim_result {
 };
 
 __attribute__((visibility("default"))) void sim_free(sim_result* r);
+static float g_sim_strategy_distance = 0.0f;
+__attribute__((visibility("default"))) void sim_set_strategy_distance(float d) { g_sim_strategy_distance = d; }
 
 __attribute__((visibility("default"))) int sim_encode(const float* const planes[3], size_t pitch_floats, size_t xsize, size_t ysize,
                float distance, float scale, float inv_scale, float scale_dc, uint32_t x_qm_scale,
@@ -70,6 +72,7 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   }
   A.g = g;
   A.distance = distance;
+  A.strategy_distance = g_sim_strategy_distance > 0.0f ? g_sim_strategy_distance : distance;
   A.scale = scale;
   A.inv_scale = inv_scale;
   A.scale_dc = scale_dc;

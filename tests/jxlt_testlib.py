@@ -137,6 +137,19 @@ def _plane_ptrs(planes):
     return arr
 
 
+def set_strategy_distance(first_call_distance):
+    """Oracle and CPU model: emulate a later call of a reference process whose first call used
+    this distance (enc_ac_strategy.cc:178-185 static constants); 0 = off."""
+    L = oracle()
+    L.orc_set_strategy_distance.argtypes = [C.c_float]
+    L.orc_set_strategy_distance.restype = None
+    L.orc_set_strategy_distance(C.c_float(first_call_distance))
+    S = _sim_lib()
+    S.sim_set_strategy_distance.argtypes = [C.c_float]
+    S.sim_set_strategy_distance.restype = None
+    S.sim_set_strategy_distance(C.c_float(first_call_distance))
+
+
 def oracle_hot_path(planes, distance, force_dct8=False, keep=False):
     """planes: [3, h, w] float32.  Returns HotPathResult (and the raw frame if keep)."""
     L = oracle()

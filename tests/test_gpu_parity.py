@@ -252,3 +252,33 @@ def test_random_frames_codestream_equals_oracle(built, w, h, distance, seed):
     planes = T.to_planes(img)
     want = T.assemble_codestream(T.oracle_hot_path(planes, distance), distance)
     assert built.encode_file(planes, distance) == want
+
+
+def test_static_constant_emulation_on_gpu(built, enc):
+    """jxlt_set_strategy_distance / jxl::EmulateReferenceStaticConstants: a frame at distance 0.5
+    of a process whose first frame was encoded at distance 16 (reference quirk,
+    enc_ac_strategy.cc:178-185)."""
+    planes = T.to_planes(T.synthetic_image(200, 137))
+    plain = T.oracle_hot_path(planes, 0.5)
+    T.set_strategy_distance(16.0)
+    try:
+        want = T.oracle_hot_path(planes, 0.5)
+    finally:
+        T.set_strategy_distance(0.0)
+    assert (want.strategy != plain.strategy).any()  # the quirk matters for this frame
+    jxl_want = T.assemble_codestream(want, 0.5)
+    # C ABI
+    enc.set_strategy_distance(16.0)
+    try:
+        got = enc.hot_path(planes, 0.5)
+    finally:
+        enc.set_strategy_distance(0.0)
+    assert T.compare_results(want, got, "oracle", "gpu", check_debug=False) == []
+    # host switch: the first frame of the "process" latches 16
+    built.emulate_reference_static_constants(True)
+    try:
+        built.encode_file(T.to_planes(T.synthetic_image(64, 64)), 16.0)
+        assert built.encode_file(planes, 0.5) == jxl_want
+    finally:
+        built.emulate_reference_static_constants(False)
+    assert built.encode_file(planes, 0.5) == T.assemble_codestream(plain, 0.5)

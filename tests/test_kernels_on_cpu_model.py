@@ -125,3 +125,20 @@ def test_root_table_overflow_falls_back_to_computed_roots(built):
     same = T.sim_hot_path(planes, 0.5)
     assert same.exact_reruns == 0
     assert T.compare_results(want, same, "oracle", "cpu model, table roots") == []
+
+
+def test_static_constant_emulation_on_cpu_model(built):
+    """The reference freezes the transform search's two multipliers at the distance of the first
+    frame of the process (enc_ac_strategy.cc:178-185).  With that emulated (first distance 16,
+    this frame 0.5) oracle and kernels still agree, and the result differs from the unemulated one
+    (otherwise the test would not test anything)."""
+    planes = T.to_planes(T.synthetic_image(200, 137))
+    plain = T.oracle_hot_path(planes, 0.5)
+    T.set_strategy_distance(16.0)
+    try:
+        want = T.oracle_hot_path(planes, 0.5)
+        got = T.sim_hot_path(planes, 0.5)
+    finally:
+        T.set_strategy_distance(0.0)
+    assert T.compare_results(want, got, "oracle", "cpu model") == []
+    assert (want.strategy != plain.strategy).any()
