@@ -88,12 +88,19 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # (test hook: JXLT_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 with a gloo process group, so
+    # that the N > 1 control flow can be exercised on a single-GPU box; not a measurement mode)
+    one_device = os.environ.get("JXLT_BENCH_ONE_DEVICE") == "1"
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     def barrier():
         if dist is not None:
@@ -103,7 +110,7 @@ def main():
     size = args.size
     frame = make_frame_on_device(torch, size, rank, device)
     torch.cuda.synchronize()
-    enc = pkg.Encoder(local_rank)
+    enc = pkg.Encoder(dev_index)
     ptrs = [frame[c].data_ptr() for c in range(3)]
     enc.set_device_image(ptrs, size * 4, size, size, keepalive=frame)
 
@@ -113,7 +120,7 @@ def main():
         spec = importlib.util.spec_from_file_location("jxlt_sharded", str(ROOT / "libjxl-tiny_amd" / "sharded.py"))
         sharded = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(sharded)
-        comm = sharded.TorchComm(dist, device)
+        comm = sharded.TorchComm(dist, "cpu" if one_device else device)
 
     def step():
         if sharded is not None:
@@ -138,7 +145,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
