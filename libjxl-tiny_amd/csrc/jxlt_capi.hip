@@ -113,6 +113,7 @@ struct jxlt_context {
   // Root-table overflow of tile_kernel (a quantised magnitude >= kSqrtLutSize): checked at the
   // first host synchronisation point; the pipeline is then redone with tile_kernel_exact_roots.
   DeviceBuf<uint32_t> lut_overflow;
+  DeviceBuf<uint32_t> dc_chain_summary;
   PinnedBuf<uint32_t> h_lut_overflow;
   hipEvent_t overflow_ready = nullptr;
   jxlt_params last_params = {};
@@ -294,6 +295,7 @@ void jxlt_context_destroy(jxlt_context* ctx) {
   if (ctx->dc_hist_ready) (void)hipEventDestroy(ctx->dc_hist_ready);
   if (ctx->overflow_ready) (void)hipEventDestroy(ctx->overflow_ready);
   FreeDevice(&ctx->lut_overflow);
+  FreeDevice(&ctx->dc_chain_summary);
   FreePinned(&ctx->h_lut_overflow);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -516,6 +518,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
   const size_t kDcStride = 6 * 65536 + 2 * 1024 + 8;
   ENSURE(dc_records, ndc * kDcStride * 3 + 16);  // (+ slack: tiles are staged with aligned dword loads)
   ENSURE(dc_nac, ndc);
+  ENSURE(dc_chain_summary, ndc * kDcChainChunks);
   ENSURE(lut_overflow, 1);
   if ((rc = EnsurePinned(ctx, &ctx->h_lut_overflow, 1)) != JXLT_OK) return rc;
   ENSURE(dc_count, ndc);
@@ -630,8 +633,11 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
     D.records = ctx->dc_records.p;
     D.dc_count = ctx->dc_count.p;
     D.histogram = ctx->hist.p + 64 * 64;
+    D.chain_summary = ctx->dc_chain_summary.p;
     hipLaunchKernelGGL(dc_elementwise_kernel, dim3((unsigned)(ndc * kDcParts)), dim3(256), 0, ctx->stream, D);
-    hipLaunchKernelGGL(dc_chain_kernel, dim3((unsigned)ndc), dim3(kDcChainThreads), 0, ctx->stream, D);
+    hipLaunchKernelGGL(dc_chain_summary_kernel, dim3((unsigned)(ndc * kDcChainChunks)), dim3(kDcChainThreads), 0,
+                       ctx->stream, D);
+    hipLaunchKernelGGL(dc_chain_kernel, dim3((unsigned)(ndc * kDcChainChunks)), dim3(kDcChainThreads), 0, ctx->stream, D);
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
   {

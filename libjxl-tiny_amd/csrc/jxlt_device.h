@@ -2164,6 +2164,7 @@ struct DcArgs {
   uint8_t* records;
   uint32_t* dc_count;             // [ndc] records per DC group
   uint32_t* histogram;            // [64 * 64]
+  uint32_t* chain_summary;        // [ndc * kDcChainChunks]: first blocks in the chunk | last one's (code << 8 | qf - 1) << 16
 };
 
 struct DcGeom {
@@ -2275,49 +2276,99 @@ __global__ void __launch_bounds__(256) dc_elementwise_kernel(const DcArgs A) {
 
 constexpr int kDcChainThreads = 1024;
 
+// The two per-first-block token runs need, for every first block, its rank among the DC group's
+// first blocks and the previous first block's (strategy code, quant field).  One workgroup per
+// chunk of kDcChainThreads blocks (64 chunks per full DC group, all of them in parallel):
+// dc_chain_summary_kernel records each chunk's first-block count and its last first block's
+// values; dc_chain_kernel derives a chunk's carry from the summaries of its predecessors.
+constexpr int kDcChainChunks = 65536 / kDcChainThreads;  // per DC group (256 x 256 blocks)
+
+struct DcChunkBlock {
+  bool first;
+  int code, qfm1;
+};
+JXLT_DI DcChunkBlock dc_chunk_block(const DcArgs& A, const DcGeom& d, int i) {
+  DcChunkBlock b = {false, 0, 0};
+  if (i < d.nb) {
+    const size_t pos = (size_t)(d.by0 + i / d.nbx) * (size_t)A.g.xsize_blocks + d.bx0 + i % d.nbx;
+    const uint8_t a = A.strategy[pos];
+    b.first = (a & 1) != 0;
+    b.code = (a >> 1) == 0 ? 0 : (a >> 1) == 1 ? 6 : 7;
+    b.qfm1 = (int)A.raw_quant[pos] - 1;
+  }
+  return b;
+}
+
+__global__ void __launch_bounds__(kDcChainThreads) dc_chain_summary_kernel(const DcArgs A) {
+  __shared__ uint32_t count;
+  __shared__ int last_idx;
+  __shared__ uint32_t last_val;
+  const int tid = (int)threadIdx.x;
+  const int dcg = (int)blockIdx.x / kDcChainChunks, chunk = (int)blockIdx.x % kDcChainChunks;
+  const DcGeom d = dc_geom(A.g, dcg, 0);
+  if (tid == 0) {
+    count = 0;
+    last_idx = -1;
+    last_val = 0;
+  }
+  __syncthreads();
+  const DcChunkBlock b = dc_chunk_block(A, d, chunk * kDcChainThreads + tid);
+  const unsigned long long m = __ballot(b.first);
+  if ((tid & 63) == 0 && m != 0) {
+    atomicAdd(&count, (uint32_t)__popcll(m));
+    atomicMax(&last_idx, (tid & ~63) + 63 - __clzll((long long)m));
+  }
+  __syncthreads();
+  if (b.first && tid == last_idx) last_val = (uint32_t)((b.code << 8) | b.qfm1);
+  __syncthreads();
+  if (tid == 0) A.chain_summary[dcg * kDcChainChunks + chunk] = count | (last_val << 16);
+}
+
 __global__ void __launch_bounds__(kDcChainThreads) dc_chain_kernel(const DcArgs A) {
-  __shared__ uint32_t hist[64 * 64];
+  __shared__ uint32_t hist[16 * 64];  // the two runs only use contexts 3..10
   __shared__ uint32_t wsum[kDcChainThreads / 64];
   __shared__ uint16_t compact[kDcChainThreads + 1];  // (code << 8) | (qf - 1) of the chunk's first blocks
   __shared__ uint32_t carry_rank;
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int dcg = (int)blockIdx.x;
-  for (int i = tid; i < 64 * 64; i += kDcChainThreads) hist[i] = 0;
+  const int dcg = (int)blockIdx.x / kDcChainChunks, chunk = (int)blockIdx.x % kDcChainChunks;
   const uint32_t nac = A.dc_nac[dcg];
   const DcGeom d = dc_geom(A.g, dcg, nac);
+  if (chunk * kDcChainThreads >= d.nb) return;  // (partial DC groups have fewer chunks)
+  for (int i = tid; i < 16 * 64; i += kDcChainThreads) hist[i] = 0;
   uint8_t* rec = A.records + 3 * A.dc_rec_offset[dcg];
   const size_t bstride = (size_t)A.g.xsize_blocks;
   // "left" before the first first-block: 0 for the strategy run, StrategyCode(acs(0,0)) for
   // the quant-field run (sic, enc_frame.cc:386)
   const uint8_t a00 = A.strategy[(size_t)d.by0 * bstride + d.bx0];
   const int code00 = (a00 >> 1) == 0 ? 0 : (a00 >> 1) == 1 ? 6 : 7;
-  if (tid == 0) {
-    carry_rank = 0;
-    compact[0] = (uint16_t)((0 << 8) | code00);  // slot 0 = predecessor of the chunk's first entry
+  if (tid < 64) {
+    // carry from the preceding chunks: their first-block counts, and the values of the last
+    // first block before this chunk (lane c looks at chunk c; 64 chunks = one wave)
+    const uint32_t sm = (tid < chunk) ? A.chain_summary[dcg * kDcChainChunks + tid] : 0u;
+    uint32_t cnt = sm & 0xFFFFu;
+    const unsigned long long nonempty = __ballot(cnt != 0);
+    for (int dd = 32; dd >= 1; dd >>= 1) cnt += __shfl_xor(cnt, dd);
+    const int src = nonempty ? 63 - __clzll((long long)nonempty) : 0;
+    const uint32_t prev = __shfl(sm >> 16, src);
+    if (tid == 0) {
+      carry_rank = cnt;
+      compact[0] = nonempty ? (uint16_t)prev : (uint16_t)((0 << 8) | code00);  // predecessor of the chunk's first entry
+    }
   }
   __syncthreads();
-  for (int base = 0; base < d.nb; base += kDcChainThreads) {
-    const int i = base + tid;
-    bool first = false;
-    int code = 0, qfm1 = 0;
-    if (i < d.nb) {
-      const size_t pos = (size_t)(d.by0 + i / d.nbx) * bstride + d.bx0 + i % d.nbx;
-      const uint8_t a = A.strategy[pos];
-      first = (a & 1) != 0;
-      code = (a >> 1) == 0 ? 0 : (a >> 1) == 1 ? 6 : 7;
-      qfm1 = (int)A.raw_quant[pos] - 1;
-    }
+  {
+    const DcChunkBlock b = dc_chunk_block(A, d, chunk * kDcChainThreads + tid);
+    const bool first = b.first;
+    const int code = b.code, qfm1 = b.qfm1;
     // exclusive rank of first blocks inside the chunk
     const unsigned long long m = __ballot(first);
     const uint32_t in_wave = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     if (lane == 0) wsum[wave] = (uint32_t)__popcll(m);
     __syncthreads();
-    uint32_t wbase = 0, chunk_total = 0;
-    for (int w = 0; w < kDcChainThreads / 64; w++) {
+    uint32_t wbase = 0;
+    for (int w = 0; w < kDcChainThreads / 64; w++)
       if (w < wave) wbase += wsum[w];
-      chunk_total += wsum[w];
-    }
     const uint32_t r = wbase + in_wave;  // rank within chunk
     if (first) compact[1 + r] = (uint16_t)((code << 8) | qfm1);
     __syncthreads();
@@ -2333,14 +2384,9 @@ __global__ void __launch_bounds__(kDcChainThreads) dc_chain_kernel(const DcArgs 
       const uint32_t ctx_q = left_q > 11 ? 3 : left_q > 5 ? 4 : left_q > 3 ? 5 : 6;
       put_record(rec, d.pos_qf + grank, ctx_q, pack_signed(qfm1 - left_q), hist);
     }
-    __syncthreads();
-    if (tid == 0) {
-      if (chunk_total) compact[0] = compact[chunk_total];
-      carry_rank += chunk_total;
-    }
-    __syncthreads();
   }
-  for (int i = tid; i < 64 * 64; i += kDcChainThreads)
+  __syncthreads();
+  for (int i = tid; i < 16 * 64; i += kDcChainThreads)
     if (hist[i]) atomicAdd(&A.histogram[i], hist[i]);
 }
 

@@ -348,6 +348,13 @@ inline uint32_t __builtin_amdgcn_mbcnt_hi(uint32_t mask, uint32_t add) {
   return add + (uint32_t)__builtin_popcount(mask & below);
 }
 
+template <typename T>
+inline T atomicMax(T* p, T v) {
+  const T old = *p;
+  if (v > old) *p = v;
+  return old;
+}
+
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __clzll(long long x) { return x == 0 ? 64 : __builtin_clzll((unsigned long long)x); }
 inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }

@@ -158,7 +158,10 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
     D.dc_count = r->dc_count;
     D.histogram = r->histogram + 64 * 64;
     hipsim::launch(dc_elementwise_kernel, dim3((unsigned)(ndc * kDcParts)), dim3(256), D);
-    hipsim::launch(dc_chain_kernel, dim3((unsigned)ndc), dim3(kDcChainThreads), D);
+    std::vector<uint32_t> chain_summary(ndc * kDcChainChunks, 0xFFFFFFFFu);
+    D.chain_summary = chain_summary.data();
+    hipsim::launch(dc_chain_summary_kernel, dim3((unsigned)(ndc * kDcChainChunks)), dim3(kDcChainThreads), D);
+    hipsim::launch(dc_chain_kernel, dim3((unsigned)(ndc * kDcChainChunks)), dim3(kDcChainThreads), D);
   }
   free(A.dc_nac);
   for (int c = 0; c < 3; c++) free(A.nzgrid[c]);
