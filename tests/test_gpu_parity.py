@@ -282,3 +282,33 @@ def test_static_constant_emulation_on_gpu(built, enc):
     finally:
         built.emulate_reference_static_constants(False)
     assert built.encode_file(planes, 0.5) == T.assemble_codestream(plain, 0.5)
+
+
+def test_frame_batch_on_two_contexts(built):
+    """BASELINE config #5 in miniature: a batch of 3840x2160 frames (135 groups, bottom group row
+    112 px), encoded through two device contexts driven by two host threads so that one frame's
+    upload overlaps the other's encode; every codestream equals the oracle's."""
+    import threading
+    frames = [T.to_planes(T.synthetic_image(3840, 2160, seed=100 + i)) for i in range(4)]
+    want = [T.assemble_codestream(T.oracle_hot_path(p, 1.0), 1.0) for p in frames]
+    got = [None] * len(frames)
+    errors = []
+
+    def worker(k):
+        try:
+            enc = built.Encoder(0)
+            for i in range(k, len(frames), 2):
+                enc.upload(frames[i])
+                got[i] = enc.encode_resident(1.0, copy=True)
+            enc.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(len(frames)):
+        assert got[i] == want[i], "frame %d" % i
