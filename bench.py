@@ -75,6 +75,12 @@ def main():
                     help="N > 1 only: the ranks' frames are the row slabs of ONE frame of size x (size*N) pixels; "
                          "histograms are all-reduced and the packed sections gathered on rank 0 "
                          "(libjxl-tiny_amd/sharded.py).  Default: one independent frame per rank.")
+    ap.add_argument("--frame-batch", type=int, default=0,
+                    help="secondary workload (BASELINE config #5, PCIe-inclusive, never the headline value): a step "
+                         "is a batch of this many --frame-size frames in page-locked HOST memory encoded through "
+                         "jxlt_batch_encoder_run (uploads, kernels and downloads of different frames overlap)")
+    ap.add_argument("--frame-size", default="3840x2160")
+    ap.add_argument("--lanes", type=int, default=3, help="device contexts of the frame-batch encoder")
     args = ap.parse_args()
 
     import torch
@@ -106,6 +112,10 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.frame_batch > 0:
+        run_frame_batch(args, torch, pkg, dist, barrier, rank, world, dev_index, device, one_device)
+        return
 
     size = args.size
     frame = make_frame_on_device(torch, size, rank, device)
@@ -226,6 +236,65 @@ def main():
         print(json.dumps(result), flush=True)
         if bad:
             raise SystemExit("parity gate failed: %d groups differ from the oracle" % bad)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_frame_batch(args, torch, pkg, dist, barrier, rank, world, dev_index, device, one_device):
+    """Secondary workload: batches of frames from page-locked host memory (PCIe-inclusive)."""
+    w, h = (int(v) for v in args.frame_size.lower().split("x"))
+    distinct = min(args.frame_batch, 8)
+    side = max(w, h)
+    frames, owners = [], []
+    for i in range(distinct):
+        full = make_frame_on_device(torch, side, 100 * rank + i, device)
+        arr, owner = pkg.pinned_empty((3, h, w))
+        arr[...] = full[:, :h, :w].cpu().numpy()
+        frames.append(arr)
+        owners.append(owner)
+        del full
+    enc = pkg.BatchEncoder(dev_index, lanes=args.lanes)
+    descs, keep = enc.describe([frames[i % distinct] for i in range(args.frame_batch)])
+    n = args.frame_batch
+    first = enc.run_described(descs, n, args.distance)
+    for _ in range(max(0, args.warmup - 1)):
+        enc.run_described(descs, n, args.distance, take=False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        total_bytes = enc.run_described(descs, n, args.distance, take=False)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    mpix = n * w * h / 1e6
+    h2d_gbs = world * 12.0 * n * w * h * args.steps / elapsed / 1e9
+    result = {
+        "metric": "Mpixels/s encode, frames in page-locked host memory -> codestream bytes in host memory (PCIe-inclusive)",
+        "value": round(world * mpix * args.steps / elapsed, 2), "unit": "Mpixels/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "batch of %d frames %dx%d per GPU per step (%d distinct), distance %.2f, %d lanes"
+                               % (n, w, h, distinct, args.distance, args.lanes),
+                   "frames_per_s": round(world * n * args.steps / elapsed, 1),
+                   "parallelism": "independent frames, round-robin over lanes and ranks, no collective",
+                   "codestream_bytes_per_batch": int(total_bytes)},
+        "roofline": {"bound": "pcie", "achieved": round(h2d_gbs / world, 2), "peak": 63.0, "unit": "GB/s",
+                     "frac": round(h2d_gbs / world / 63.0, 4), "traffic": None,
+                     "note": "host->device bytes of the frames (12 B/pixel) per GPU; peak = PCIe 5.0 x16 payload rate"},
+    }
+    if rank == 0:
+        import jxlt_testlib as T
+        want = T.assemble_codestream(T.oracle_hot_path(np.ascontiguousarray(frames[0]), args.distance), args.distance)
+        result["parity_gate"] = {"frames_checked": 1, "frames_mismatching": int(first[0] != want)}
+        print(json.dumps(result), flush=True)
+        if first[0] != want:
+            raise SystemExit("parity gate failed: frame 0 differs from the oracle")
+    del keep, owners
+    enc.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -238,6 +238,31 @@ int jxlt_encode_file_planar(const float* const planes[3], size_t pitch_bytes, si
  * kernels (jxlt_image_upload_pfm) instead of by a host pass. */
 int jxlt_encode_pfm_file(const char* filename, float distance, int device_ordinal, uint8_t** out_bytes,
                          size_t* out_size);
+/* ---- frame batches (BASELINE config #5) ------------------------------------------
+ * A batch of independent frames on one GPU: `lanes` device contexts, each driven by its own host
+ * thread with its own HIP stream, take frames from a shared queue, so that the upload of one
+ * frame (PCIe) overlaps the kernels of another and the download of a third.  Every frame gives
+ * the same bytes as jxlt_encode_file_planar / jxlt_encode_pfm_file.  The reference has no batch
+ * entry (cjxl_tiny is one image per process, cjxl_main.cc:49-101); this is the loop a caller
+ * would write around EncodeFile (enc_file.h:20-21), moved behind the boundary so that the
+ * overlap is the library's business.  Frames may differ in size.  Page-locked source memory
+ * (jxlt_pinned_alloc) is copied at PCIe speed; ordinary memory is staged by the lane's thread. */
+typedef struct {
+  const float* planes[3];  /* planar f32 with row pitch pitch_bytes; all NULL when pfm_payload is set */
+  size_t pitch_bytes;
+  const void* pfm_payload; /* or: interleaved bottom-up RGB f32 payload of a PFM file (read_pfm.cc:199-209) */
+  int pfm_big_endian;
+  size_t xsize, ysize;
+} jxlt_batch_frame;
+typedef struct jxlt_batch_encoder jxlt_batch_encoder;
+/* lanes <= 0: 3 (upload / encode / download in flight at once). */
+int jxlt_batch_encoder_create(int device_ordinal, int lanes, jxlt_batch_encoder** out);
+void jxlt_batch_encoder_destroy(jxlt_batch_encoder* enc);
+/* Encodes frames[0..num_frames) at `distance`.  out_bytes[i] (malloc'ed, free with jxlt_free) and
+ * out_sizes[i] receive the codestream of frame i.  Returns the first failing frame's error; the
+ * outputs of failed frames are NULL / 0. */
+int jxlt_batch_encoder_run(jxlt_batch_encoder* enc, const jxlt_batch_frame* frames, size_t num_frames,
+                           float distance, uint8_t** out_bytes, size_t* out_sizes);
 /* jxl::EmulateReferenceStaticConstants (host/encoder/enc_frame.h): latch the first distance this
  * process encodes with for the transform search's two multipliers, as the reference library
  * does (enc_ac_strategy.cc:178-185).  Off by default. */

@@ -37,7 +37,8 @@ HIP_SYMBOLS = ["jxlt_context_create", "jxlt_context_destroy", "jxlt_last_error",
                "jxlt_synchronize", "jxlt_fetch_result", "jxlt_kernel_times", "jxlt_debug_fetch"]
 HOST_SYMBOLS = ["jxlt_compute_distance_params", "jxlt_assemble_frame", "jxlt_assemble_frame_groups",
                 "jxlt_encode_file_planar", "jxlt_encode_pfm_file", "jxlt_emulate_reference_static_constants", "jxlt_encode_resident", "jxlt_encode_resident_view", "jxlt_write_file_header", "jxlt_build_code_tables", "jxlt_finish_frame",
-                "jxlt_debug_dc_records", "jxlt_free"]
+                "jxlt_debug_dc_records", "jxlt_free", "jxlt_batch_encoder_create", "jxlt_batch_encoder_destroy",
+                "jxlt_batch_encoder_run"]
 
 
 class JxlTinyError(RuntimeError):
@@ -430,3 +431,105 @@ def encode_file(planes, distance, device=0):
     if rc != 0:
         raise JxlTinyError("jxlt_encode_file_planar failed (%d)" % rc)
     return _take_bytes(out, n)
+
+
+class BatchFrame(C.Structure):
+    _fields_ = [("planes", fp * 3), ("pitch_bytes", C.c_size_t), ("pfm_payload", C.c_void_p),
+                ("pfm_big_endian", C.c_int), ("xsize", C.c_size_t), ("ysize", C.c_size_t)]
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """numpy array in page-locked host memory (jxlt_pinned_alloc); keep the returned owner alive."""
+    L = hip_lib()
+    L.jxlt_pinned_alloc.argtypes = [C.c_size_t]
+    L.jxlt_pinned_alloc.restype = C.c_void_p
+    L.jxlt_pinned_free.argtypes = [C.c_void_p]
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = L.jxlt_pinned_alloc(n)
+    if not p:
+        raise JxlTinyError("jxlt_pinned_alloc failed (no usable HIP device)")
+    buf = (C.c_uint8 * n).from_address(p)
+    arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    class _Owner:
+        def __del__(self, p=p, free=L.jxlt_pinned_free):
+            free(p)
+    return arr, _Owner()
+
+
+class BatchEncoder:
+    """jxlt_batch_encoder_*: a batch of independent frames on one GPU through several device contexts
+    (uploads, kernels and downloads of different frames overlap).  BASELINE config #5."""
+
+    def __init__(self, device=0, lanes=3):
+        self._L = host_lib()
+        L = self._L
+        L.jxlt_batch_encoder_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.jxlt_batch_encoder_destroy.argtypes = [C.c_void_p]
+        L.jxlt_batch_encoder_destroy.restype = None
+        L.jxlt_batch_encoder_run.argtypes = [C.c_void_p, C.POINTER(BatchFrame), C.c_size_t, C.c_float,
+                                             C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        self._enc = C.c_void_p()
+        rc = L.jxlt_batch_encoder_create(device, lanes, C.byref(self._enc))
+        if rc != 0:
+            raise JxlTinyError("jxlt_batch_encoder_create failed (%d): %s" %
+                               (rc, hip_lib().jxlt_last_error(None).decode()))
+
+    def close(self):
+        if self._enc:
+            self._L.jxlt_batch_encoder_destroy(self._enc)
+            self._enc = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def describe(self, frames):
+        """frames: float32 [3,h,w] arrays (planar), or (payload_bytes_or_array, w, h, big_endian) tuples
+        (raw PFM payloads).  Returns (ctypes array, keepalive)."""
+        descs = (BatchFrame * len(frames))()
+        keep = []
+        for d, f in zip(descs, frames):
+            if isinstance(f, tuple):
+                payload, w, h, big = f
+                a = np.frombuffer(payload, dtype=np.uint8) if not isinstance(payload, np.ndarray) else payload
+                keep.append(a)
+                d.pfm_payload = a.ctypes.data
+                d.pfm_big_endian = 1 if big else 0
+                d.xsize, d.ysize = w, h
+            else:
+                assert f.dtype == np.float32 and f.ndim == 3 and f.shape[0] == 3
+                assert f.strides[2] == 4 and f.strides[1] % 4 == 0
+                keep.append(f)
+                for c in range(3):
+                    d.planes[c] = f[c].ctypes.data_as(fp)
+                d.pitch_bytes = f.strides[1]
+                d.xsize, d.ysize = f.shape[2], f.shape[1]
+        return descs, keep
+
+    def run_described(self, descs, n, distance, take=True):
+        outs = (C.POINTER(C.c_uint8) * n)()
+        sizes = (C.c_size_t * n)()
+        rc = self._L.jxlt_batch_encoder_run(self._enc, descs, n, C.c_float(distance), outs, sizes)
+        if rc != 0:
+            for i in range(n):
+                if outs[i]:
+                    self._L.jxlt_free(outs[i])
+            raise JxlTinyError("jxlt_batch_encoder_run failed (%d)" % rc)
+        if take:
+            res = [C.string_at(outs[i], sizes[i]) for i in range(n)]
+            for i in range(n):
+                self._L.jxlt_free(outs[i])
+            return res
+        total = sum(sizes[i] for i in range(n))
+        for i in range(n):
+            self._L.jxlt_free(outs[i])
+        return total
+
+    def encode(self, frames, distance):
+        descs, keep = self.describe(frames)
+        out = self.run_described(descs, len(frames), distance)
+        del keep
+        return out

@@ -47,3 +47,5 @@ def test_no_cpu_fallback_without_gpu(built):
     planes = np.zeros((3, 16, 16), np.float32)
     with pytest.raises(built.JxlTinyError):
         built.encode_file(planes, 1.0)
+    with pytest.raises(built.JxlTinyError, match="no HIP device"):
+        built.BatchEncoder(0, lanes=2)

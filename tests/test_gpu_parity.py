@@ -312,3 +312,39 @@ def test_frame_batch_on_two_contexts(built):
     assert not errors, errors
     for i in range(len(frames)):
         assert got[i] == want[i], "frame %d" % i
+
+
+@pytest.mark.gpu
+def test_frame_batch_encoder(built):
+    """jxlt_batch_encoder_*: frames of different geometry, planar and raw-PFM-payload sources, pinned and
+    ordinary memory, more frames than lanes; every codestream equals the oracle's."""
+    sizes = [(3840, 2160), (200, 137), (1030, 520), (256, 256), (3840, 2160), (700, 300), (64, 72)]
+    frames, want = [], []
+    keep = []
+    for i, (w, h) in enumerate(sizes):
+        planes = T.to_planes(T.synthetic_image(w, h, seed=300 + i))
+        want.append(T.assemble_codestream(T.oracle_hot_path(planes, 2.0), 2.0))
+        if i % 3 == 1:  # PFM payload: interleaved, bottom row first, big endian
+            payload = np.ascontiguousarray(planes.transpose(1, 2, 0)[::-1]).astype(">f4")
+            frames.append((payload.view(np.uint8).reshape(-1), w, h, True))
+        elif i % 3 == 2:  # page-locked planes with a row pitch
+            arr, owner = built.pinned_empty((3, h, w + 24))
+            arr[:, :, :w] = planes
+            keep.append(owner)
+            frames.append(arr[:, :, :w])
+        else:
+            frames.append(planes)
+    enc = built.BatchEncoder(0, lanes=3)
+    got = enc.encode(frames, 2.0)
+    again = enc.encode(frames[:2], 2.0)  # the encoder is reusable
+    enc.close()
+    for i in range(len(sizes)):
+        assert got[i] == want[i], "frame %d %s" % (i, sizes[i])
+    assert again == want[:2]
+    # error behaviour: a frame without a source is rejected, the others are still encoded
+    enc = built.BatchEncoder(0, lanes=2)
+    descs, k = enc.describe(frames[:2])
+    descs[1].pfm_payload = None
+    with pytest.raises(built.JxlTinyError):
+        enc.run_described(descs, 2, 2.0)
+    enc.close()
