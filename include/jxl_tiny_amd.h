@@ -267,6 +267,14 @@ int jxlt_batch_encoder_run(jxlt_batch_encoder* enc, const jxlt_batch_frame* fram
  * process encodes with for the transform search's two multipliers, as the reference library
  * does (enc_ac_strategy.cc:178-185).  Off by default. */
 void jxlt_emulate_reference_static_constants(int on);
+/* jxl::EmulateReferenceSingleSymbolCodes (host/encoder/enc_frame.h).  A prefix code with a single
+ * used symbol is serialised as a one-symbol code, which decoders read with zero bits per token;
+ * the reference nevertheless writes one bit per such token (enc_huffman_tree.cc:84-87 leaves a
+ * placeholder depth that enc_entropy_code.cc:411-416 never resets), so its output cannot be
+ * decoded in those (rare, flat-content) cases.  Default 0: conformant zero-bit tokens -- the
+ * codestream equals the reference's whenever the reference's is decodable.  1: the reference's
+ * bytes in every case. */
+void jxlt_emulate_reference_single_symbol_codes(int on);
 /* Codestream + image headers that precede the frame (enc_file.cc:70-95). */
 int jxlt_write_file_header(size_t xsize, size_t ysize, uint8_t** out_bytes, size_t* out_size);
 /* ---- one frame sharded over several contexts / GPUs / processes ----------------

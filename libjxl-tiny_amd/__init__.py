@@ -36,7 +36,7 @@ HIP_SYMBOLS = ["jxlt_context_create", "jxlt_context_destroy", "jxlt_last_error",
                "jxlt_output_buffer",
                "jxlt_synchronize", "jxlt_fetch_result", "jxlt_kernel_times", "jxlt_debug_fetch"]
 HOST_SYMBOLS = ["jxlt_compute_distance_params", "jxlt_assemble_frame", "jxlt_assemble_frame_groups",
-                "jxlt_encode_file_planar", "jxlt_encode_pfm_file", "jxlt_emulate_reference_static_constants", "jxlt_encode_resident", "jxlt_encode_resident_view", "jxlt_write_file_header", "jxlt_build_code_tables", "jxlt_finish_frame",
+                "jxlt_encode_file_planar", "jxlt_encode_pfm_file", "jxlt_emulate_reference_static_constants", "jxlt_emulate_reference_single_symbol_codes", "jxlt_encode_resident", "jxlt_encode_resident_view", "jxlt_write_file_header", "jxlt_build_code_tables", "jxlt_finish_frame",
                 "jxlt_debug_dc_records", "jxlt_free", "jxlt_batch_encoder_create", "jxlt_batch_encoder_destroy",
                 "jxlt_batch_encoder_run"]
 
@@ -406,6 +406,12 @@ def emulate_reference_static_constants(on):
     """jxl::EmulateReferenceStaticConstants: latch the process's first distance for the transform
     search's multipliers like the reference library (enc_ac_strategy.cc:178-185)."""
     host_lib().jxlt_emulate_reference_static_constants(1 if on else 0)
+
+
+def emulate_reference_single_symbol_codes(on):
+    """jxl::EmulateReferenceSingleSymbolCodes: write one bit per token of a single-symbol prefix code like
+    the reference does (undecodable output in those cases) instead of the conformant zero bits."""
+    host_lib().jxlt_emulate_reference_single_symbol_codes(1 if on else 0)
 
 
 def encode_pfm_file(path, distance, device=0):

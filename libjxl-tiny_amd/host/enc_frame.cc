@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/jxl_tiny_amd.h"
+#include "entropy_coder.h"
 #include "frame_assembler.h"
 #include "host_internal.h"
 
@@ -253,6 +254,7 @@ jxlt_context* AcquireContextForThread() {
 void SetEncoderDevice(int device_ordinal) { g_device = device_ordinal; }
 
 void EmulateReferenceStaticConstants(bool on) { jxlt::SetStaticConstantEmulation(on); }
+void EmulateReferenceSingleSymbolCodes(bool on) { jxlt::SetReferenceSingleSymbolEmulation(on); }
 
 }  // namespace jxl
 

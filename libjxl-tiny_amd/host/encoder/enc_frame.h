@@ -28,6 +28,14 @@ void SetEncoderDevice(int device_ordinal);
 // distance this process encodes with is latched the same way, so that a multi-image process is
 // byte-identical to the reference library used the same way.
 void EmulateReferenceStaticConstants(bool on);
+// Not in the reference either: when a (clustered) histogram has a single used symbol, the reference
+// serialises a one-symbol prefix code -- which a decoder reads with zero bits per token -- but
+// still writes the construction's placeholder depth of one bit per token
+// (enc_huffman_tree.cc:84-87, enc_entropy_code.cc:411-416, enc_entropy_code.h:34-42), i.e. a
+// stream that cannot be decoded.  Rare (flat synthetic content).  Off (default): such tokens get
+// zero bits, output conformant; everything else is byte-identical to the reference.  On: the
+// reference's bytes in those cases too.
+void EmulateReferenceSingleSymbolCodes(bool on);
 
 }  // namespace jxl
 

@@ -403,10 +403,19 @@ void BuildHuffmanCodes(const std::vector<Histogram>& histograms, EntropyCode* co
     while (length > 0 && counts[length - 1] == 0) --length;
     CreateHuffmanTree(counts, length, 15, pc.depths);
     ConvertBitDepthsToSymbols(pc.depths, length, pc.bits);
+    size_t used = 0;
+    for (size_t s = 0; s < length; ++s) used += counts[s] != 0;
+    pc.single_symbol = used == 1 && !ReferenceSingleSymbolEmulation();
   }
 }
 
 }  // namespace
+
+namespace {
+std::atomic<bool> g_reference_single_symbol{false};
+}
+void SetReferenceSingleSymbolEmulation(bool on) { g_reference_single_symbol.store(on); }
+bool ReferenceSingleSymbolEmulation() { return g_reference_single_symbol.load(); }
 
 void OptimizeEntropyCode(const std::vector<Token>& tokens, size_t num_contexts, EntropyCode* code) {
   std::vector<Histogram> histograms(num_contexts);

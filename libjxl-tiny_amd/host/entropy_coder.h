@@ -31,7 +31,20 @@ struct Token {
 struct PrefixCode {
   uint8_t depths[kAlphabetSize];
   uint16_t bits[kAlphabetSize];
+  // The histogram has exactly one used symbol.  Such a code is serialised as a simple code with
+  // one symbol, which a decoder reads with ZERO bits per token (18181-1 / RFC 7932 3.4).  The
+  // reference leaves the construction's placeholder depth 1 in place (enc_huffman_tree.cc:84-87,
+  // "will be fixed on upper level" -- enc_entropy_code.cc:411-416 does not) and so writes one
+  // bit per token of such a context: a stream no decoder can read.  Set unless
+  // SetReferenceSingleSymbolEmulation(true); tokens of a flagged code are written with depth 0.
+  bool single_symbol;
+  uint32_t TokenDepth(uint32_t tok) const { return single_symbol ? 0u : depths[tok]; }
 };
+
+// true: reproduce the reference's one-bit-per-token output for single-symbol codes byte for byte
+// (undecodable streams in exactly those cases).  Default false: conformant output.
+void SetReferenceSingleSymbolEmulation(bool on);
+bool ReferenceSingleSymbolEmulation();
 
 struct Histogram {
   uint32_t counts[kAlphabetSize] = {};
@@ -77,9 +90,10 @@ inline void WriteToken(uint32_t cluster_ctx, uint32_t value, const EntropyCode& 
   uint32_t tok, nbits, bits;
   HybridUintEncode(value, &tok, &nbits, &bits);
   const PrefixCode& pc = code.prefix_codes[code.context_map[cluster_ctx]];
-  uint64_t data = pc.bits[tok];
-  data |= static_cast<uint64_t>(bits) << pc.depths[tok];
-  writer->Write(pc.depths[tok] + nbits, data);
+  const uint32_t depth = pc.TokenDepth(tok);
+  uint64_t data = depth ? pc.bits[tok] : 0;
+  data |= static_cast<uint64_t>(bits) << depth;
+  writer->Write(depth + nbits, data);
 }
 
 void CreateHuffmanTree(const uint32_t* counts, size_t length, int tree_limit, uint8_t* depth);

@@ -405,7 +405,7 @@ void FillCodeTable(const EntropyCode& code, uint32_t* table) {
       uint32_t e = 0;
       if (c < code.context_map.size()) {
         const PrefixCode& pc = code.prefix_codes[code.context_map[c]];
-        e = (static_cast<uint32_t>(pc.depths[s]) << 16) | pc.bits[s];
+        e = pc.single_symbol ? 0u : (static_cast<uint32_t>(pc.depths[s]) << 16) | pc.bits[s];
       }
       table[c * kAlphabetSize + s] = e;
     }

@@ -99,6 +99,7 @@ int jxlt_encode_pfm_file(const char* filename, float distance, int device_ordina
 }
 
 void jxlt_emulate_reference_static_constants(int on) { jxl::EmulateReferenceStaticConstants(on != 0); }
+void jxlt_emulate_reference_single_symbol_codes(int on) { jxl::EmulateReferenceSingleSymbolCodes(on != 0); }
 
 int jxlt_write_file_header(size_t xsize, size_t ysize, uint8_t** out_bytes, size_t* out_size) {
   jxl::BitWriter writer;

@@ -1,6 +1,7 @@
 """Shared helpers for the tests: ctypes bindings of the oracle (oracle/liboracle.so),
 of the CPU execution model of the kernels (tests/hipsim/libjxlt_sim.so) and the
 synthetic image generator of SURVEY.md section 8(d)."""
+import contextlib
 import ctypes as C
 import subprocess
 import sys
@@ -394,6 +395,19 @@ def host_dc_records(res):
         out.append(C.string_at(p, n.value))
         H.jxlt_free(p)
     return out
+
+
+@contextlib.contextmanager
+def reference_single_symbol_codes():
+    """While active the host back-end writes one bit per token of a single-symbol prefix code, as the
+    reference does (jxl::EmulateReferenceSingleSymbolCodes): byte-identical to the reference even where
+    its output cannot be decoded.  Fixtures / known answers that pin REFERENCE bytes use this."""
+    P = product()
+    P.emulate_reference_single_symbol_codes(True)
+    try:
+        yield
+    finally:
+        P.emulate_reference_single_symbol_codes(False)
 
 
 def assemble_codestream(res, distance, num_threads=1):

@@ -30,7 +30,8 @@ def test_oracle_reproduces_golden(built, path):
     r = T.oracle_hot_path(fx["planes"], float(fx["distance"]), bool(fx["force_dct8"]))
     _check(fx, r, True)
     if not bool(fx["force_dct8"]):
-        assert T.assemble_codestream(r, float(fx["distance"])) == fx["codestream"].tobytes()
+        with T.reference_single_symbol_codes():  # the fixtures hold the reference's bytes
+            assert T.assemble_codestream(r, float(fx["distance"])) == fx["codestream"].tobytes()
 
 
 @pytest.mark.parametrize("path", GOLDEN[:3], ids=[p.stem for p in GOLDEN[:3]])
@@ -48,5 +49,6 @@ def test_gpu_reproduces_golden(built, path):
     r = enc.hot_path(fx["planes"], float(fx["distance"]), force_dct8=bool(fx["force_dct8"]), debug=True)
     _check(fx, r, True)
     if not bool(fx["force_dct8"]):
-        assert built.encode_file(fx["planes"], float(fx["distance"])) == fx["codestream"].tobytes()
+        with T.reference_single_symbol_codes():
+            assert built.encode_file(fx["planes"], float(fx["distance"])) == fx["codestream"].tobytes()
     enc.close()
