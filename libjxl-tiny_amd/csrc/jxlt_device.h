@@ -367,11 +367,52 @@ JXLT_DI void octet_exchange(float& a, float& b, int l) {
 }
 
 // 8x8 transpose across the 8 lanes of an octet: lane l holds v[j] = M[j][l] and
-// ends with v[j] = M[l][j].  Three butterfly stages, static register indices.
+// ends with v[j] = M[l][j].
+// JXLT_LDS_TRANSPOSE = 1: through a private LDS scratch of the octet (kTransposePitch floats,
+// 8 more than the 64 it holds so that the eight octets of a wave fall into different banks):
+// eight dword writes (immediate offsets j * 32 bytes), two 16-byte reads of the lane's row.  The
+// wave's LDS operations execute in order, so no barrier is needed between them; what this buys is
+// VALU issue slots -- the register variant below costs 40 "full-rate" instructions (24 DPP moves +
+// 16 selects, ~190 cycles per wave and transpose, tools/op_probe.hip), this one 10 LDS
+// instructions that other waves' VALU work overlaps.
+// JXLT_LDS_TRANSPOSE = 0: three butterfly stages in registers, static register indices.
 // (Measured alternatives, both slower on gfx950: one assembly block of 24 fused
 // v_cndmask_b32_dpp -- a VOP2 select whose mask does not come from a VALU compare is very slow,
-// tools/op_probe.hip -- and a round trip through a private LDS scratch of the octet.)
-JXLT_DI void octet_transpose(float* v, int l) {
+// tools/op_probe.hip.)
+#ifndef JXLT_LDS_TRANSPOSE
+#define JXLT_LDS_TRANSPOSE 1
+#endif
+constexpr int kTransposePitch = 72;
+#ifdef HIPSIM_HIP_RUNTIME_H_
+// CPU execution model: lanes are fibers, so "in order within the wave" has to be made explicit --
+// a butterfly of dummy exchanges synchronises exactly the eight lanes of the octet (octets may
+// have diverged, a wave-wide barrier would deadlock the model).
+#define JXLT_OCTET_SYNC()                                         \
+  do {                                                            \
+    (void)__shfl_xor(0, 1);                                       \
+    (void)__shfl_xor(0, 2);                                       \
+    (void)__shfl_xor(0, 4);                                       \
+  } while (0)
+#else
+#define JXLT_OCTET_SYNC() __builtin_amdgcn_wave_barrier()  // no instruction: keeps the compiler from reordering
+#endif
+JXLT_DI void octet_transpose(float* v, float* sc, int l) {
+#if JXLT_LDS_TRANSPOSE
+  // Element (row r, column c) lives at (c >> 2) * 36 + r * 4 + (c & 3): the two 16-byte halves of
+  // the rows form two dense 128-byte runs (the reads of the eight lanes are consecutive 16-byte
+  // chunks), and the 4-dword gap between the runs puts the eight dwords a store instruction
+  // writes per octet (column l of row j) into eight consecutive banks.
+  float* const w = sc + (l >> 2) * 36 + (l & 3);
+#pragma unroll
+  for (int j = 0; j < 8; j++) w[j * 4] = v[j];
+  JXLT_OCTET_SYNC();
+  const float4 a = *reinterpret_cast<const float4*>(sc + l * 4);
+  const float4 b = *reinterpret_cast<const float4*>(sc + 36 + l * 4);
+  JXLT_OCTET_SYNC();  // (the next transpose overwrites the scratch)
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+#else
+  (void)sc;
   octet_exchange<4>(v[0], v[4], l);
   octet_exchange<4>(v[1], v[5], l);
   octet_exchange<4>(v[2], v[6], l);
@@ -384,6 +425,7 @@ JXLT_DI void octet_transpose(float* v, int l) {
   octet_exchange<1>(v[2], v[3], l);
   octet_exchange<1>(v[4], v[5], l);
   octet_exchange<1>(v[6], v[7], l);
+#endif
 }
 
 // Block transforms.  `px` points at the block's top-left sample in an LDS plane
@@ -396,18 +438,18 @@ JXLT_DI void octet_transpose(float* v, int l) {
 // differences are 0 or >= 1 ulp of O(0.1) values), so both are applied once at the end.
 
 // ComputeScaledDCT<8,8> (enc_transforms-inl.h:527-546): i = h*8 + v
-JXLT_DI void block_dct8x8(const float* px, int pitch, int l, float* c) {
+JXLT_DI void block_dct8x8(const float* px, int pitch, int l, float* sc, float* c) {
 #pragma unroll
   for (int y = 0; y < 8; y++) c[y] = px[y * pitch + l];
   dct8(c);
-  octet_transpose(c, l);  // lane v now holds 8*A[v][x], x = 0..7
+  octet_transpose(c, sc, l);  // lane v now holds 8*A[v][x], x = 0..7
   dct8(c);
 #pragma unroll
   for (int y = 0; y < 8; y++) c[y] = (1.0f / 64) * c[y];  // c[h] = C[h][v=l]
 }
 
 // ComputeScaledDCT<16,8>: 16 rows x 8 cols, i = h*16 + v; r = 2h + (v>=8), lane = v&7
-JXLT_DI void block_dct16x8(const float* px, int pitch, int l, float* c) {
+JXLT_DI void block_dct16x8(const float* px, int pitch, int l, float* sc, float* c) {
   float col[16];
 #pragma unroll
   for (int y = 0; y < 16; y++) col[y] = px[y * pitch + l];
@@ -418,8 +460,8 @@ JXLT_DI void block_dct16x8(const float* px, int pitch, int l, float* c) {
     lo[v] = col[v];
     hi[v] = col[v + 8];
   }
-  octet_transpose(lo, l);  // lane t: A[t][x]
-  octet_transpose(hi, l);  // lane t: A[t+8][x]
+  octet_transpose(lo, sc, l);  // lane t: A[t][x]
+  octet_transpose(hi, sc, l);  // lane t: A[t+8][x]
   dct8(lo);
   dct8(hi);
 #pragma unroll
@@ -430,7 +472,7 @@ JXLT_DI void block_dct16x8(const float* px, int pitch, int l, float* c) {
 }
 
 // ComputeScaledDCT<8,16>: 8 rows x 16 cols, i = v*16 + h; r = 2v + (h>=8), lane = h&7
-JXLT_DI void block_dct8x16(const float* px, int pitch, int l, float* c) {
+JXLT_DI void block_dct8x16(const float* px, int pitch, int l, float* sc, float* c) {
   float lo[8], hi[8];
 #pragma unroll
   for (int y = 0; y < 8; y++) {
@@ -439,8 +481,8 @@ JXLT_DI void block_dct8x16(const float* px, int pitch, int l, float* c) {
   }
   dct8(lo);
   dct8(hi);
-  octet_transpose(lo, l);  // lane v: A[v][x], x < 8
-  octet_transpose(hi, l);  // lane v: A[v][x], x >= 8
+  octet_transpose(lo, sc, l);  // lane v: A[v][x], x < 8
+  octet_transpose(hi, sc, l);  // lane v: A[v][x], x >= 8
   float row[16];
 #pragma unroll
   for (int x = 0; x < 8; x++) {
@@ -453,8 +495,8 @@ JXLT_DI void block_dct8x16(const float* px, int pitch, int l, float* c) {
     lo[h] = (1.0f / 128) * row[h];
     hi[h] = (1.0f / 128) * row[h + 8];
   }
-  octet_transpose(lo, l);  // lane t: C[v][h=t], v = 0..7
-  octet_transpose(hi, l);  // lane t: C[v][h=t+8]
+  octet_transpose(lo, sc, l);  // lane t: C[v][h=t], v = 0..7
+  octet_transpose(hi, sc, l);  // lane t: C[v][h=t+8]
 #pragma unroll
   for (int v = 0; v < 8; v++) {
     c[2 * v] = lo[v];
@@ -543,12 +585,15 @@ struct alignas(16) TileShared {
   float cfl_pad[kCflTermFloats - (2 * 64 * kXYPitch + 64 * kBPitch + 16 * 72 + 16 * kPrePitch + 16 * 16)];
   // ^ x..cfl_pad (64 KB) are overlaid by the chroma-from-luma terms once every pixel
   //   read is done: 64 blocks x 64 coefficients x (a_x, b_x, a_b, b_b).
+  // rowsum..transpose_pad: during the transforms (the AQ buffers are dead by then) the octets'
+  // transpose scratch, 64 x kTransposePitch floats.
+  float transpose_pad[64 * 72 - (kCflTermFloats - (2 * 64 * kXYPitch + 64 * kBPitch))];
+  // (its first 128 floats hold the candidate entropies of the 2x2 cells during the strategy search, "ent8")
   float sqrt_lut[kSqrtLutSize];  // sqrtf of the quantised magnitudes below kSqrtLutSize
   float inv_w[576];
   float y_w[192];          // dequant weights of Y: [0,64) DCT8, [64,192) two-block
   float aq[64];            // quant field (tile-local 8x8)
   float mask[64];
-  float ent8[16 * 8];      // candidate entropies per 2x2 cell
   float cfl_sum[4];        // ca_x, cb_x, ca_b, cb_b
   int cmap[2];             // ytox, ytob
   uint8_t raw_quant[64];
@@ -1115,6 +1160,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
   // Waves 0-3 take the 32 DCT16X8 candidates, waves 4-7 the 32 DCT8X16 candidates.
   // Done before chroma-from-luma so that afterwards no pixel is needed any more; the
   // coefficients stay in registers for the entropy estimate and for P8.
+  float* const tsc = &S.rowsum[0] + oct * kTransposePitch;  // octet's transpose scratch (AQ buffers are dead)
   float c16x[16], c16y[16], c16b[16];
   const bool search = (A.flags & 1u) == 0;
   const int cand = oct & 31;           // candidate index within its type
@@ -1131,17 +1177,17 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     // (scheduling fences: interleaving the three independent transforms would triple the
     // live registers and spill)
     if (is_tall) {
-      block_dct16x8(pxp, kXYPitch, l, c16x);
+      block_dct16x8(pxp, kXYPitch, l, tsc, c16x);
       JXLT_SCHED_FENCE();
-      block_dct16x8(pyp, kXYPitch, l, c16y);
+      block_dct16x8(pyp, kXYPitch, l, tsc, c16y);
       JXLT_SCHED_FENCE();
-      block_dct16x8(pbp, kBPitch, l, c16b);
+      block_dct16x8(pbp, kBPitch, l, tsc, c16b);
     } else {
-      block_dct8x16(pxp, kXYPitch, l, c16x);
+      block_dct8x16(pxp, kXYPitch, l, tsc, c16x);
       JXLT_SCHED_FENCE();
-      block_dct8x16(pyp, kXYPitch, l, c16y);
+      block_dct8x16(pyp, kXYPitch, l, tsc, c16y);
       JXLT_SCHED_FENCE();
-      block_dct8x16(pbp, kBPitch, l, c16b);
+      block_dct8x16(pbp, kBPitch, l, tsc, c16b);
     }
     JXLT_SCHED_FENCE();
   }
@@ -1154,11 +1200,11 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     const float* pyp = &S.y[(oby * 8) * kXYPitch + obx * 8 + kHalo];
     const float* pbp = &S.b[(oby * 8) * kBPitch + obx * 8];
     if (blk_valid) {
-      block_dct8x8(pxp, kXYPitch, l, c8x);
+      block_dct8x8(pxp, kXYPitch, l, tsc, c8x);
       JXLT_SCHED_FENCE();
-      block_dct8x8(pyp, kXYPitch, l, c8y);
+      block_dct8x8(pyp, kXYPitch, l, tsc, c8y);
       JXLT_SCHED_FENCE();
-      block_dct8x8(pbp, kBPitch, l, c8b);
+      block_dct8x8(pbp, kBPitch, l, tsc, c8b);
       JXLT_SCHED_FENCE();
     } else {
       // (cross-lane traffic never leaves an octet, so idle octets may skip it)
@@ -1304,7 +1350,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       const float mul8x8 = k8x8mul2 + k8x8mul1 / (A.strategy_distance + k8x8base);
       float e8 = 3.0f * mul8x8;
       e8 += mul8x8 * e;
-      if (l == 0) S.ent8[((oby >> 1) * 4 + (obx >> 1)) * 8 + (oby & 1) * 2 + (obx & 1)] = e8;
+      if (l == 0) S.transpose_pad[((oby >> 1) * 4 + (obx >> 1)) * 8 + (oby & 1) * 2 + (obx & 1)] = e8;
     }
     // The DCT8 coefficients are needed again in P8; they wait in the (now dead) term area
     // while the two-block estimate runs, which would otherwise spill.
@@ -1331,7 +1377,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       const float k8X16mul1 = (float)-0.55, k8X16mul2 = (float)0.9019587899705066,
                   k8X16base = (float)1.6;
       const float mul16x8 = k8X16mul2 + k8X16mul1 / (A.strategy_distance + k8X16base);
-      if (l == 0) S.ent8[cell * 8 + (is_tall ? 4 : 6) + (cand & 1)] = mul16x8 * e;
+      if (l == 0) S.transpose_pad[cell * 8 + (is_tall ? 4 : 6) + (cand & 1)] = mul16x8 * e;
     }
     JXLT_SCHED_FENCE();
 #pragma unroll
@@ -1350,7 +1396,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
   if (search && tid < 16) {
     const int cx = (tid & 3) * 2, cy = (tid >> 2) * 2;
     if (cx + 1 < nbx && cy + 1 < nby) {
-      const float* e = &S.ent8[tid * 8];
+      const float* e = &S.transpose_pad[tid * 8];
       const float e00 = e[0], e01 = e[1], e10 = e[2], e11 = e[3];
       const float l16 = e[4], r16 = e[5], t16 = e[6], b16 = e[7];
       const float cost16x8 = fminf(l16, e00 + e10) + fminf(r16, e01 + e11);
