@@ -629,7 +629,7 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
   const float cost_of_1 = 1 + slope * 8.8703248061477744f;
   float entropy = 0.0f;
   float info_loss = 0.0f, info_loss2 = 0.0f;
-  float qm = 0.0f;
+  uint32_t qbits = 0;  // OR of the table offsets before wrapping (a v_or is cheaper than a v_max)
   // One copy of the body per channel (no per-coefficient operand selects); the scheduling
   // fences keep the channels from being interleaved, which would spill.
 #pragma unroll
@@ -646,9 +646,10 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
 #pragma unroll
     for (int r = 0; r < NR; r++) {
       const float in = cin[r];
-      const float in_y = cy[r] * cmap_factor;
       const float im = inv[r * 8 + l];
-      const float val = (in - in_y) * (im * quant);
+      // (skipping the subtraction of cy * 0 for the Y channel saves two instructions per
+      // coefficient on paper; the register allocator then spills 90 VGPRs)
+      const float val = (in - cy[r] * cmap_factor) * (im * quant);
       const float rval = rintf(val);
       const float diff = fabsf(val - rval);
       info_loss = info_loss + diff;
@@ -658,9 +659,10 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
       float root;
       if (kLut) {
         // byte offset 4 * q, wrapped into the table (a wrapped read is redone by the caller)
-        const uint32_t off = (uint32_t)(q * 4.0f) & (uint32_t)(kSqrtLutSize * 4 - 4);
+        const uint32_t off_raw = (uint32_t)(q * 4.0f);  // (saturates for huge q)
+        const uint32_t off = off_raw & (uint32_t)(kSqrtLutSize * 4 - 4);
         root = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sqrt_lut) + off);
-        qm = fmaxf(qm, q);
+        qbits |= off_raw;
       } else {
         // (skipping the root with a branch where a whole wave has q <= 1 was tried: control flow
         // inside this loop makes the register allocator spill)
@@ -678,27 +680,25 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
   const float infoloss = octet_sum(info_loss);
   const float infoloss2 = sqrtf(num_blocks * octet_sum(info_loss2));
   const float info_loss_score = (kInfoLossMultiplier * infoloss + kInfoLossMultiplier2 * infoloss2);
-  if (kLut) *qmax = qm;
+  if (kLut) *qmax = qbits >= (uint32_t)(kSqrtLutSize * 4) ? (float)kSqrtLutSize : 0.0f;
   return entropy + masking * info_loss_score;
 }
 
-// enc_group.cc:186-218
-JXLT_DI float adjust_quant_bias_y(int32_t quant_i) {
+// enc_group.cc:186-218 for channel 1.  `quant` is the quantised coefficient as a float: 0 (+0, the
+// thresholded case) or an integer of magnitude >= 1.  |quant| <= 1: the reference selects
+// +-kBias1 by sign, 0 for 0 -- which is quant * kBias1 exactly; otherwise quant - kBias3 / quant.
+JXLT_DI float adjust_quant_bias_y(float quant) {
   const float kBias1 = 1.0f - 0.07005449891748593f;  // kDefaultQuantBias[1]
   const float kBias3 = 0.145f;
-  const float quant = (float)quant_i;
-  const uint32_t sign = __float_as_uint(quant) & 0x80000000u;
-  const float abs_quant = __uint_as_float(__float_as_uint(quant) & 0x7FFFFFFFu);
-  const bool is_01 = abs_quant < 1.125f;
-  const bool not_0 = abs_quant > 0.0f;
-  const float one_bias = not_0 ? __uint_as_float(__float_as_uint(kBias1) ^ sign) : 0.0f;
+  const float small = quant * kBias1;
   const float bias = nfma32(kBias3, rcp_int_exact(quant), quant);  // (quant == 0: selected away below)
-  return is_01 ? one_bias : bias;
+  return fabsf(quant) < 1.125f ? small : bias;
 }
 
 // enc_group.cc:221-278 for the lane's rows.  NR = 8: xsize=ysize=1; NR = 16: xsize=2, ysize=1.
-template <int NR>
-JXLT_DI void quantize_rows(const float* in, int c, const float* inv, int l, float quantv, int* out) {
+template <int NR, bool kKeepFloat = false>
+JXLT_DI void quantize_rows(const float* in, int c, const float* inv, int l, float quantv, int* out,
+                           float* outf = nullptr) {
   // thresholds of the four quadrants (enc_group.cc:227-242)
   float t0 = 0.58f;
   float t1 = c == 0 ? 0.635f + 0.08f : c == 2 ? 0.75f : 0.635f;
@@ -719,7 +719,11 @@ JXLT_DI void quantize_rows(const float* in, int c, const float* inv, int l, floa
     const float q = inv[r * 8 + l] * quantv;
     const float val = q * in[r];
     const bool nz = fabsf(val) >= thr;
-    out[r] = nz ? (int)rintf(val) : 0;
+    if (kKeepFloat) {
+      outf[r] = nz ? rintf(val) : 0.0f;
+    } else {
+      out[r] = nz ? (int)rintf(val) : 0;
+    }
   }
 }
 
@@ -766,14 +770,14 @@ JXLT_DI void quantize_transform(float* cx, float* cy, float* cb, const TileShare
   }
   const int covered = NR / 8;
   // nzeros (enc_group.cc:51-148) + staging of one channel's quantised rows
-  auto stage_channel = [&](int c, const int* q) {
+  auto stage_channel = [&](int c, const auto* q) {  // q: the quantised rows, int or integer-valued float
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < NR; r++) {
       const bool llf = (r == 0) && (l < covered);
       cnt += (!llf && q[r] != 0) ? 1 : 0;
       int16_t* dst = (r * 8 + l < 64) ? slot_a : slot_b;
-      dst[c * 64 + ((r * 8 + l) & 63)] = (int16_t)q[r];
+      dst[c * 64 + ((r * 8 + l) & 63)] = (int16_t)(int)q[r];
     }
     const int nzeros = octet_sum_int(cnt);
     if (l == 0) {
@@ -791,12 +795,12 @@ JXLT_DI void quantize_transform(float* cx, float* cy, float* cb, const TileShare
     }
   };
   {
-    int qy[NR];
-    quantize_rows<NR>(cy, 1, inv_y, l, qac * 1.0f, qy);
-    stage_channel(1, qy);
+    float qyf[NR];
+    quantize_rows<NR, true>(cy, 1, inv_y, l, qac * 1.0f, nullptr, qyf);
+    stage_channel(1, qyf);
     const float inv_qac = T->inv_qac[quant_ac];
 #pragma unroll
-    for (int r = 0; r < NR; r++) cy[r] = (adjust_quant_bias_y(qy[r]) * ydq[r * 8 + l]) * inv_qac;
+    for (int r = 0; r < NR; r++) cy[r] = (adjust_quant_bias_y(qyf[r]) * ydq[r * 8 + l]) * inv_qac;
   }
 
   // --- X, B: undo colour correlation with the roundtripped Y (:417-425), quantise, DC.
