@@ -176,9 +176,15 @@ int jxlt_output_buffer(jxlt_context* ctx, size_t bytes, uint8_t** out);
  * every section at its final place: dc_dst / ac_dst receive the byte-aligned sections of each
  * kind back to back (offsets as returned by jxlt_pack_measure).  Both destinations must be
  * device-visible (page-locked host memory from jxlt_output_buffer / jxlt_pinned_alloc, or device
- * memory); the call is asynchronous and complete after the next jxlt_synchronize. */
+ * memory); the call is asynchronous and complete after the next jxlt_synchronize.
+ * (The writing kernels are queued by the measuring call itself -- they need nothing from the host --
+ * and fill a device blob; jxlt_pack_write adds the copies, range by range as the kernels finish.) */
 int jxlt_pack_measure(jxlt_context* ctx, const uint32_t* dc_code_table, const uint32_t* ac_code_table,
                       jxlt_packed_sections* dc, jxlt_packed_sections* ac);
+/* Starts the pass of one kind early and asynchronously (0 = DC-group sections: their code is known
+ * while the device still tokenises the AC groups, so their packing fills the time the host needs for
+ * the AC code).  A later jxlt_pack_measure takes NULL for that kind's table and does not repeat it. */
+int jxlt_pack_measure_begin(jxlt_context* ctx, int kind, const uint32_t* code_table);
 int jxlt_pack_write(jxlt_context* ctx, uint8_t* dc_dst, uint8_t* ac_dst);
 
 /* Timing of the device stages of the last jxlt_encode_enqueue (HIP events on the context's

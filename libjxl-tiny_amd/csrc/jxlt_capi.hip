@@ -90,6 +90,13 @@ struct jxlt_context {
     PinnedBuf<uint32_t> h_sec_bits;
     PinnedBuf<uint8_t> h_packed;
     size_t measured_sections = 0;  // sections of the last measuring pass (0: none for this frame)
+    // The writing kernels are queued right behind the measuring kernels (they need nothing from
+    // the host): launch i covers tiles [launch_t0[i], launch_t0[i + 1]) and signals launch_done[i].
+    static constexpr int kMaxLaunches = 6;
+    int launches = 0;
+    uint32_t launch_t0[kMaxLaunches + 1] = {};
+    hipEvent_t launch_done[kMaxLaunches] = {};
+    hipEvent_t measured = nullptr;  // the host mirrors of the measuring pass are valid
   } pack[2];
   PinnedBuf<uint8_t> h_output;  // jxlt_output_buffer
 
@@ -110,6 +117,7 @@ struct jxlt_context {
   // jxlt_pack_write: packing on `stream`, chunked copies to the destination on `copy_stream`
   hipStream_t copy_stream = nullptr;
   hipEvent_t dc_hist_ready = nullptr;  // DC histogram of the last enqueue is in h_hist
+  hipEvent_t ac_hist_ready = nullptr;  // AC histogram + total token count of the last enqueue are in their mirrors
   // Root-table overflow of tile_kernel (a quantised magnitude >= kSqrtLutSize): checked at the
   // first host synchronisation point; the pipeline is then redone with tile_kernel_exact_roots.
   DeviceBuf<uint32_t> lut_overflow;
@@ -119,8 +127,6 @@ struct jxlt_context {
   jxlt_params last_params = {};
   bool overflow_checked = true;
   uint32_t exact_reruns = 0;
-  static constexpr int kWriteChunks = 4;
-  hipEvent_t chunk_packed[kWriteChunks + 1] = {};
   bool copies_pending = false;
   bool profiled = false;
 };
@@ -224,8 +230,12 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
   for (auto& ev : ctx->stage_done) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   (void)hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
   (void)hipEventCreateWithFlags(&ctx->dc_hist_ready, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&ctx->ac_hist_ready, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&ctx->overflow_ready, hipEventDisableTiming);
-  for (auto& ev : ctx->chunk_packed) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  for (auto& ps : ctx->pack) {
+    (void)hipEventCreateWithFlags(&ps.measured, hipEventDisableTiming);
+    for (auto& ev : ps.launch_done) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  }
   *out = ctx;
   return JXLT_OK;
 }
@@ -290,9 +300,13 @@ void jxlt_context_destroy(jxlt_context* ctx) {
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->ev)
     if (ev) (void)hipEventDestroy(ev);
-  for (auto& ev : ctx->chunk_packed)
-    if (ev) (void)hipEventDestroy(ev);
+  for (auto& ps : ctx->pack) {
+    if (ps.measured) (void)hipEventDestroy(ps.measured);
+    for (auto& ev : ps.launch_done)
+      if (ev) (void)hipEventDestroy(ev);
+  }
   if (ctx->dc_hist_ready) (void)hipEventDestroy(ctx->dc_hist_ready);
+  if (ctx->ac_hist_ready) (void)hipEventDestroy(ctx->ac_hist_ready);
   if (ctx->overflow_ready) (void)hipEventDestroy(ctx->overflow_ready);
   FreeDevice(&ctx->lut_overflow);
   FreeDevice(&ctx->dc_chain_summary);
@@ -653,10 +667,22 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
   hipLaunchKernelGGL(token_kernel, dim3((unsigned)ngroups), dim3(kTokenThreads), 0, ctx->stream, K);
   HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
   HIP_TRY(ctx, hipGetLastError());
+  {
+    // AC histogram + total token count leave right behind token_kernel: work queued later (the
+    // DC-section packing, which only needs the DC code) does not delay their arrival
+    int rc2;
+    if ((rc2 = EnsurePinned(ctx, &ctx->h_group_off, 2 * (ngroups + 1))) != JXLT_OK) return rc2;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hist.p, ctx->hist.p, 64 * 64 * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_group_off.p + ngroups, ctx->group_off.p + ngroups, sizeof(uint64_t),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ac_hist_ready, ctx->stream));
+  }
   ctx->geom = g;
   ctx->encoded = true;
   ctx->offsets_fetched = false;
   ctx->pack[0].measured_sections = ctx->pack[1].measured_sections = 0;
+  ctx->pack[0].launches = ctx->pack[1].launches = 0;
   ctx->last_flags = params->flags;
   ctx->profiled = true;  // the five stage events are always recorded (a few microseconds per frame)
   ctx->last_params = *params;
@@ -824,15 +850,9 @@ int jxlt_fetch_histograms(jxlt_context* ctx, const uint32_t** ac_histograms, con
   }
   const FrameGeom& g = ctx->geom;
   const size_t ngroups = (size_t)g.xsize_groups * g.ysize_groups;
-  int rc;
-  if ((rc = EnsurePinned(ctx, &ctx->h_group_off, 2 * (ngroups + 1))) != JXLT_OK) return rc;
-  if ((rc = EnsurePinned(ctx, &ctx->h_hist, 2 * 64 * 64)) != JXLT_OK) return rc;
-  // (the DC half was copied right behind the DC kernels, see jxlt_encode_enqueue)
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hist.p, ctx->hist.p, 64 * 64 * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                              ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_group_off.p + ngroups, ctx->group_off.p + ngroups, sizeof(uint64_t),
-                              hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  (void)ngroups;
+  // (both halves were copied right behind their kernels, see jxlt_encode_enqueue)
+  HIP_TRY(ctx, hipEventSynchronize(ctx->ac_hist_ready));
   ctx->offsets_fetched = true;
   if (ac_histograms) *ac_histograms = ctx->h_hist.p;
   if (dc_histograms) *dc_histograms = ctx->h_hist.p + 64 * 64;
@@ -910,7 +930,33 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
                               ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ps.h_tile_base.p, ps.tile_base.p, (nsec + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost,
                               ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ps.measured, ctx->stream));
   ps.measured_sections = nsec;
+  // The writing pass needs nothing from the host (tile positions are in device memory), so it is
+  // queued right here, in a few launches over equal shares of the tile range (an upper bound: the
+  // kernel clamps to the real tile count); the host picks the section sizes up meanwhile and
+  // later only adds the copies (EnqueueCopies).  Blob capacity: <= 28 bits per record.
+  const uint64_t blob_bound = rec_bound * 4 + nsec * 8 + 64;
+  if (ps.packed.cap < blob_bound && (rc = EnsureDevice(ctx, &ps.packed, blob_bound + blob_bound / 8)) != JXLT_OK)
+    return rc;
+  const int want = kind == 0 ? 1 : 5;
+  ps.launches = (int)std::min<size_t>((size_t)want, std::max<size_t>(1, max_tiles / 64));
+  // (shrinking shares: the copy of the last share is the only one nothing overlaps)
+  for (int i = 0; i <= ps.launches; i++) {
+    const double x = (double)i / ps.launches;
+    ps.launch_t0[i] = i == ps.launches ? (uint32_t)max_tiles : (uint32_t)((double)max_tiles * x * (1.4 - 0.4 * x));
+  }
+  for (int i = 0; i < ps.launches; i++) {
+    PackTileArgs W = TileArgsOf(ctx, kind, nsec);
+    W.tile_first = ps.launch_t0[i];
+    W.tile_end = ps.launch_t0[i + 1];
+    if (W.tile_end > W.tile_first)
+      hipLaunchKernelGGL(pack_tile_write_kernel,
+                         dim3((unsigned)((W.tile_end - W.tile_first + kPackTilesPerGroup - 1) / kPackTilesPerGroup)),
+                         dim3(kPackThreads), 0, ctx->stream, W);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ps.launch_done[i], ctx->stream));
+  }
   return JXLT_OK;
 }
 
@@ -922,39 +968,31 @@ void FillMeasured(jxlt_context* ctx, int kind, jxlt_packed_sections* out) {
   out->num_sections = ps.measured_sections;
 }
 
-// Writing pass for the measured sections of `kind` (asynchronous): tiles are packed at their
-// final bit positions into the device blob, which leaves for `dst` in `nchunks` ranges of
-// whole sections on the copy stream while later ranges are still being packed.
-int EnqueueWrite(jxlt_context* ctx, int kind, uint8_t* dst, int nchunks, int* ev) {
+// The copies of the measured and (being) written sections of `kind` to `dst` (asynchronous, on the
+// copy stream): after every launch of the writing pass the whole sections it completed leave,
+// while later launches are still packing.  Needs the host mirrors (wait for ps.measured first).
+int EnqueueCopies(jxlt_context* ctx, int kind, uint8_t* dst) {
   jxlt_context::PackSet& ps = ctx->pack[kind];
   const size_t nsec = ps.measured_sections;
+  HIP_TRY(ctx, hipEventSynchronize(ps.measured));
   const uint64_t* off = ps.h_sec_byte_off.p;
   const uint64_t* tb = ps.h_tile_base.p;
-  const uint64_t total = off[nsec];
-  int rc;
-  if (ps.packed.cap < total + 16 && (rc = EnsureDevice(ctx, &ps.packed, total + total / 4 + 4096)) != JXLT_OK)
-    return rc;
-  nchunks = (int)std::min<size_t>((size_t)nchunks, nsec);
-  for (int c = 0; c < nchunks; c++) {
-    const size_t s0 = nsec * c / nchunks, s1 = nsec * (c + 1) / nchunks;
-    if (s1 == s0) continue;
-    if (tb[s1] > tb[s0]) {
-      PackTileArgs P = TileArgsOf(ctx, kind, nsec);
-      P.tile_first = (uint32_t)tb[s0];
-      P.tile_end = (uint32_t)tb[s1];
-      hipLaunchKernelGGL(pack_tile_write_kernel,
-                         dim3((unsigned)((tb[s1] - tb[s0] + kPackTilesPerGroup - 1) / kPackTilesPerGroup)),
-                         dim3(kPackThreads), 0, ctx->stream, P);
-      HIP_TRY(ctx, hipGetLastError());
+  size_t s_lo = 0;
+  for (int i = 0; i < ps.launches; i++) {
+    // sections whose tiles all lie in front of the end of launch i
+    size_t s_hi = nsec;
+    if (i + 1 < ps.launches) {
+      s_hi = (size_t)(std::upper_bound(tb, tb + nsec + 1, (uint64_t)ps.launch_t0[i + 1]) - tb) - 1;
+      if (s_hi < s_lo) s_hi = s_lo;
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->chunk_packed[*ev], ctx->stream));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->chunk_packed[*ev], 0));
-    (*ev)++;
-    if (off[s1] > off[s0])
-      HIP_TRY(ctx, hipMemcpyAsync(dst + off[s0], ps.packed.p + off[s0], off[s1] - off[s0], hipMemcpyDefault,
+    if (off[s_hi] > off[s_lo]) {
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ps.launch_done[i], 0));
+      HIP_TRY(ctx, hipMemcpyAsync(dst + off[s_lo], ps.packed.p + off[s_lo], off[s_hi] - off[s_lo], hipMemcpyDefault,
                                   ctx->copy_stream));
+      ctx->copies_pending = true;
+    }
+    s_lo = s_hi;
   }
-  ctx->copies_pending = true;
   return JXLT_OK;
 }
 
@@ -973,7 +1011,7 @@ int jxlt_pack_sections_sizes(jxlt_context* ctx, int kind, const uint32_t* code_t
   if (rc != JXLT_OK) return rc;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if ((rc = EnqueueMeasure(ctx, kind, code_table)) != JXLT_OK) return rc;
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipEventSynchronize(ctx->pack[kind].measured));
   FillMeasured(ctx, kind, out);
   return JXLT_OK;
 }
@@ -985,8 +1023,7 @@ int jxlt_pack_sections_place(jxlt_context* ctx, int kind, uint8_t* dst) {
     return JXLT_ERR_INVALID_ARGUMENT;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  int ev = 0;
-  return EnqueueWrite(ctx, kind, dst, kind == 0 ? 1 : jxlt_context::kWriteChunks - 1, &ev);
+  return EnqueueCopies(ctx, kind, dst);
 }
 
 int jxlt_pack_sections_copy(jxlt_context* ctx, int kind, uint8_t* dst) {
@@ -1008,15 +1045,35 @@ int jxlt_pack_sections(jxlt_context* ctx, int kind, const uint32_t* code_table, 
   return JXLT_OK;
 }
 
+int jxlt_pack_measure_begin(jxlt_context* ctx, int kind, const uint32_t* code_table) {
+  if (!ctx || !code_table || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
+  if (!ctx->encoded || (kind == 1 && !ctx->offsets_fetched)) {
+    ctx->error = "jxlt_pack_measure_begin needs jxlt_encode_enqueue (+ jxlt_fetch_histograms for the AC sections) first";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    const int rc0 = ResolveRootTableOverflow(ctx);
+    if (rc0 != JXLT_OK) return rc0;
+  }
+  return EnqueueMeasure(ctx, kind, code_table);
+}
+
 int jxlt_pack_measure(jxlt_context* ctx, const uint32_t* dc_code_table, const uint32_t* ac_code_table,
                       jxlt_packed_sections* dc, jxlt_packed_sections* ac) {
-  if (!ctx || !dc_code_table || !ac_code_table || !dc || !ac) return JXLT_ERR_INVALID_ARGUMENT;
+  if (!ctx || !dc || !ac) return JXLT_ERR_INVALID_ARGUMENT;
   int rc = CheckPackCall(ctx, "jxlt_pack_measure");
   if (rc != JXLT_OK) return rc;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if ((rc = EnqueueMeasure(ctx, 0, dc_code_table)) != JXLT_OK) return rc;
-  if ((rc = EnqueueMeasure(ctx, 1, ac_code_table)) != JXLT_OK) return rc;
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  // (a kind whose pass was started with jxlt_pack_measure_begin is not measured again)
+  for (int kind = 0; kind < 2; kind++) {
+    const uint32_t* table = kind == 0 ? dc_code_table : ac_code_table;
+    if (ctx->pack[kind].measured_sections != 0) continue;
+    if (!table) return JXLT_ERR_INVALID_ARGUMENT;
+    if ((rc = EnqueueMeasure(ctx, kind, table)) != JXLT_OK) return rc;
+  }
+  HIP_TRY(ctx, hipEventSynchronize(ctx->pack[0].measured));
+  HIP_TRY(ctx, hipEventSynchronize(ctx->pack[1].measured));
   FillMeasured(ctx, 0, dc);
   FillMeasured(ctx, 1, ac);
   return JXLT_OK;
@@ -1029,10 +1086,9 @@ int jxlt_pack_write(jxlt_context* ctx, uint8_t* dc_dst, uint8_t* ac_dst) {
     return JXLT_ERR_INVALID_ARGUMENT;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  int ev = 0;
-  int rc = EnqueueWrite(ctx, 0, dc_dst, 1, &ev);
+  const int rc = EnqueueCopies(ctx, 0, dc_dst);
   if (rc != JXLT_OK) return rc;
-  return EnqueueWrite(ctx, 1, ac_dst, jxlt_context::kWriteChunks - 1, &ev);
+  return EnqueueCopies(ctx, 1, ac_dst);
 }
 
 int jxlt_output_buffer(jxlt_context* ctx, size_t bytes, uint8_t** out) {

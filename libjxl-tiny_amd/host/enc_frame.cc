@@ -129,6 +129,11 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   expected_dc_ms = ms(t0, t0a);
   BuildDcCode(dc_hist, &dc_code);
   FillCodeTable(dc_code, dc_table.data());
+  // the DC-group sections are packed behind token_kernel, while the host builds the AC code
+  if (jxlt_pack_measure_begin(ctx, 0, dc_table.data()) != JXLT_OK) {
+    fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
+    return false;
+  }
   const auto t0b = now();
   {
     const double left = expected_ac_ms - ms(t0, t0b);  // until the AC histogram is expected
@@ -150,7 +155,7 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   // sections straight to their final byte offsets and copies them to where the frame is being
   // assembled, while the host builds header and TOC.
   jxlt_packed_sections dcm, acm;
-  if (jxlt_pack_measure(ctx, dc_table.data(), ac_table.data(), &dcm, &acm) != JXLT_OK) {
+  if (jxlt_pack_measure(ctx, nullptr, ac_table.data(), &dcm, &acm) != JXLT_OK) {
     fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
     return false;
   }
