@@ -1068,8 +1068,10 @@ int jxlt_pack_measure(jxlt_context* ctx, const uint32_t* dc_code_table, const ui
   // (a kind whose pass was started with jxlt_pack_measure_begin is not measured again)
   for (int kind = 0; kind < 2; kind++) {
     const uint32_t* table = kind == 0 ? dc_code_table : ac_code_table;
-    if (ctx->pack[kind].measured_sections != 0) continue;
-    if (!table) return JXLT_ERR_INVALID_ARGUMENT;
+    if (!table) {
+      if (ctx->pack[kind].measured_sections == 0) return JXLT_ERR_INVALID_ARGUMENT;
+      continue;
+    }
     if ((rc = EnqueueMeasure(ctx, kind, table)) != JXLT_OK) return rc;
   }
   HIP_TRY(ctx, hipEventSynchronize(ctx->pack[0].measured));
