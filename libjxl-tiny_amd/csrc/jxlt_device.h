@@ -629,7 +629,7 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
   const float cost_of_1 = 1 + slope * 8.8703248061477744f;
   float entropy = 0.0f;
   float info_loss = 0.0f, info_loss2 = 0.0f;
-  uint32_t qbits = 0;  // OR of the table offsets before wrapping (a v_or is cheaper than a v_max)
+  uint32_t qbits = 0;  // OR of the offset words before masking (a v_or is cheaper than a v_max)
   // One copy of the body per channel (no per-coefficient operand selects); the scheduling
   // fences keep the channels from being interleaved, which would spill.
 #pragma unroll
@@ -659,7 +659,11 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
       float root;
       if (kLut) {
         // byte offset 4 * q, wrapped into the table (a wrapped read is redone by the caller)
-        const uint32_t off_raw = (uint32_t)(q * 4.0f);  // (saturates for huge q)
+        // 4 * q + 2^23 is exact for q < 2^21 and its bit pattern is 0x4B000000 + 4 * q: the byte
+        // offset comes out of a multiply-add and a mask, no float -> int conversion (a full-rate
+        // instruction, tools/op_probe.hip).  Larger q (or NaN) disturb the bits above the offset
+        // field, which the OR below keeps for the caller's overflow test.
+        const uint32_t off_raw = __float_as_uint(fma32(q, 4.0f, 8388608.0f));
         const uint32_t off = off_raw & (uint32_t)(kSqrtLutSize * 4 - 4);
         root = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sqrt_lut) + off);
         qbits |= off_raw;
@@ -680,7 +684,8 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
   const float infoloss = octet_sum(info_loss);
   const float infoloss2 = sqrtf(num_blocks * octet_sum(info_loss2));
   const float info_loss_score = (kInfoLossMultiplier * infoloss + kInfoLossMultiplier2 * infoloss2);
-  if (kLut) *qmax = qbits >= (uint32_t)(kSqrtLutSize * 4) ? (float)kSqrtLutSize : 0.0f;
+  // every offset stayed inside the table <=> nothing above the offset field differs from 2^23's pattern
+  if (kLut) *qmax = ((qbits | 0x4B000000u) & ~(uint32_t)(kSqrtLutSize * 4 - 1)) != 0x4B000000u ? (float)kSqrtLutSize : 0.0f;
   return entropy + masking * info_loss_score;
 }
 
