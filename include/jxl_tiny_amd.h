@@ -165,9 +165,10 @@ int jxlt_pack_sections(jxlt_context* ctx, int kind, const uint32_t* code_table, 
 int jxlt_pack_sections_sizes(jxlt_context* ctx, int kind, const uint32_t* code_table,
                              jxlt_packed_sections* out);
 int jxlt_pack_sections_copy(jxlt_context* ctx, int kind, uint8_t* dst);
-/* Asynchronous, copy-free variant for a destination in page-locked host memory obtained from
- * jxlt_output_buffer / jxlt_pinned_alloc (device-visible): the compaction kernel writes the
- * sections straight to `dst` over PCIe.  Complete after the next jxlt_synchronize. */
+/* Asynchronous variant for a destination in page-locked host memory obtained from
+ * jxlt_output_buffer / jxlt_pinned_alloc (or in device memory): the sections leave the device blob
+ * for `dst` range by range on a copy stream, each range as soon as the writing kernels have
+ * completed it.  Complete after the next jxlt_synchronize. */
 int jxlt_pack_sections_place(jxlt_context* ctx, int kind, uint8_t* dst);
 int jxlt_output_buffer(jxlt_context* ctx, size_t bytes, uint8_t** out);
 /* Copy-free packing in two passes.  jxlt_pack_measure uploads both code tables and returns
