@@ -207,6 +207,17 @@ def main():
         "device_only_mpix_s": round(mpix / device_only_s, 1),
     }
 
+    valu = pmc_valu(size)
+    if valu is not None and tile_ms == tile_ms:
+        # Supplementary: the kernel is VALU-issue bound, not HBM bound.  Instructions per wave
+        # from the committed counter profile, duration measured live; peak = one wave64 VALU instruction per
+        # two cycles and SIMD (MI355X_MICROARCH.md, "Wave scheduling"): 256 CUs x 4 SIMDs x 2.4 GHz / 2.
+        peak = 256 * 4 * 2.4e9 / 2 / 1e12
+        ach = valu["valu_insts_per_wave"] * valu["waves"] / (tile_ms * 1e-3) / 1e12
+        result["roofline"]["valu_issue"] = {"achieved": round(ach, 4), "peak": round(peak, 4),
+                                            "unit": "T wave64 VALU instructions/s", "frac": round(ach / peak, 4),
+                                            "valu_insts_per_wave": valu["valu_insts_per_wave"]}
+
     if rank == 0:
         # ---- CPU baseline + parity gate on a bounded, group-aligned crop of the same frame
         import jxlt_testlib as T
@@ -311,6 +322,19 @@ def pmc_traffic(size):
             best = json.load(open(p))["kernels"]["tile_kernel"]["hbm_bytes"]
         except (OSError, KeyError, ValueError):
             pass
+    return best
+
+
+def pmc_valu(size):
+    """VALU instructions per wave of tile_kernel from the committed counter profile
+    (profiles/*_tile_valu_<size>.json, made with tools/tile_cycles.sh); None if absent."""
+    best = None
+    for p in sorted((ROOT / "profiles").glob("*_tile_valu_%d.json" % size)):
+        try:
+            best = json.load(open(p))
+            best["valu_insts_per_wave"], best["waves"]
+        except (OSError, KeyError, ValueError):
+            best = None
     return best
 
 
