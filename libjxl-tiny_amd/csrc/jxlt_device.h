@@ -574,6 +574,10 @@ constexpr int kXYPitch = 64 + 2 * kHalo + 1;  // 75 floats (odd: conflict-free c
 constexpr int kBPitch = 65;
 constexpr int kPrePitch = 19;
 constexpr int kCflTermFloats = 64 * 64 * 4;  // LDS floats overlaid by the CfL terms
+// int16 stride between the blocks of the quantised-coefficient staging area (3 x 64 values each):
+// 200 halfwords = 100 dwords = 4 (mod 32), so the 16-byte runs the octets of a wave store land in
+// different banks (192 = 0 mod 32 dwords made every staging store an 8-way conflict)
+constexpr int kStageStride = 200;
 
 struct alignas(16) TileShared {
   float x[64 * kXYPitch];
@@ -1454,7 +1458,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     const bool do8 = blk_valid && S.strat[oct] == 1;
     if (do8) {
       quantize_transform<8>(c8x, c8y, c8b, S, 0, l, S.raw_quant[oct], A, cmap_x, cmap_b,
-                            bx_img0 + obx, by_img0 + oby, stage + oct * 192, stage + oct * 192);
+                            bx_img0 + obx, by_img0 + oby, stage + oct * kStageStride, stage + oct * kStageStride);
     }
     // (b) this octet's two-block candidate, if it was selected
     const int bi = cby * 8 + cbx;
@@ -1462,8 +1466,8 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     if (do16) {
       const int o2 = is_tall ? 8 : 1;
       quantize_transform<16>(c16x, c16y, c16b, S, is_tall ? 1 : 2, l, S.raw_quant[bi], A, cmap_x,
-                             cmap_b, bx_img0 + cbx, by_img0 + cby, stage + bi * 192,
-                             stage + (bi + o2) * 192);
+                             cmap_b, bx_img0 + cbx, by_img0 + cby, stage + bi * kStageStride,
+                             stage + (bi + o2) * kStageStride);
     }
   }
   __syncthreads();
@@ -1489,11 +1493,11 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       const uint32_t pos1 = pos0 + (st == 1 ? bstride : 1u);
       // staging index (channel 0) of this lane's scan position, per 64-position half
       const int i0 = order[lane];
-      const int src0 = i0 < 64 ? bi * 192 + i0 : (bi + o2) * 192 + i0 - 64;
+      const int src0 = i0 < 64 ? bi * kStageStride + i0 : (bi + o2) * kStageStride + i0 - 64;
       int src1 = src0;
       if (covered == 2) {
         const int i1 = order[64 + lane];
-        src1 = i1 < 64 ? bi * 192 + i1 : (bi + o2) * 192 + i1 - 64;
+        src1 = i1 < 64 ? bi * kStageStride + i1 : (bi + o2) * kStageStride + i1 - 64;
       }
       const unsigned long long llf_mask = covered == 2 ? 3ull : 1ull;  // scan positions < covered
       int16_t v0s[3], v1s[3];
