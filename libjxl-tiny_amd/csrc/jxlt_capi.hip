@@ -15,6 +15,7 @@
 #include <algorithm>
 
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -320,6 +321,68 @@ const char* jxlt_last_error(const jxlt_context* ctx) {
   return ctx ? ctx->error.c_str() : g_create_error.c_str();
 }
 
+}  // extern "C"
+
+namespace {
+// Staging of pageable host memory through the context's two page-locked buffers: `nthreads` host
+// threads (the caller is one of them) live for the whole upload and fill band after band --
+// fill(band, t, nthreads, stage) copies thread t's share -- while the previous band is in flight;
+// issue(band, stage) enqueues the band's host-to-device copy.  (Spawning threads per band cost
+// more than the copies of a 32 MB band.)
+// Host threads per staged upload (JXLT_STAGE_THREADS overrides; capped by the machine).
+int StageThreads() {
+  static const int n = [] {
+    const char* e = getenv("JXLT_STAGE_THREADS");
+    int v = e ? atoi(e) : 8;
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 0 && v > hw) v = hw;
+    return v < 1 ? 1 : v > 64 ? 64 : v;
+  }();
+  return n;
+}
+
+template <typename Fill, typename Issue>
+int StagedUpload(jxlt_context* ctx, size_t nbands, int nthreads, const Fill& fill, const Issue& issue) {
+  std::atomic<size_t> released(0), finished(0);
+  std::atomic<bool> aborted(false);
+  auto worker = [&](int t) {
+    for (size_t b = 0; b < nbands; b++) {
+      while (released.load(std::memory_order_acquire) <= b) {
+        if (aborted.load(std::memory_order_relaxed)) return;
+        std::this_thread::yield();
+      }
+      if (aborted.load(std::memory_order_relaxed)) return;
+      fill(b, t, nthreads, ctx->stage[b & 1].p);
+      finished.fetch_add(1, std::memory_order_release);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nthreads; t++) pool.emplace_back(worker, t);
+  int rc = JXLT_OK;
+  for (size_t b = 0; b < nbands && rc == JXLT_OK; b++) {
+    uint8_t* stage = ctx->stage[b & 1].p;
+    if (hipEventSynchronize(ctx->stage_done[b & 1]) != hipSuccess) {  // previous use of this buffer
+      rc = JXLT_ERR_NO_DEVICE;
+      break;
+    }
+    released.store(b + 1, std::memory_order_release);
+    fill(b, 0, nthreads, stage);
+    while (finished.load(std::memory_order_acquire) < (b + 1) * (size_t)(nthreads - 1)) std::this_thread::yield();
+    rc = issue(b, stage);
+    if (rc == JXLT_OK && hipEventRecord(ctx->stage_done[b & 1], ctx->stream) != hipSuccess) rc = JXLT_ERR_NO_DEVICE;
+  }
+  if (rc != JXLT_OK) {
+    aborted.store(true);
+    released.store(nbands);
+    ctx->error = "staged upload failed";
+  }
+  for (auto& th : pool) th.join();
+  return rc;
+}
+}  // namespace
+
+extern "C" {
+
 int jxlt_image_upload(jxlt_context* ctx, const float* const planes[3], size_t pitch_bytes,
                       size_t xsize, size_t ysize) {
   int rc = CheckImageArgs(ctx, reinterpret_cast<const void* const*>(planes), pitch_bytes, xsize, ysize);
@@ -339,37 +402,36 @@ int jxlt_image_upload(jxlt_context* ctx, const float* const planes[3], size_t pi
   if (!pinned)
     for (auto& st : ctx->stage)
       if ((rc = EnsurePinned(ctx, &st, band_rows * row_bytes)) != JXLT_OK) return rc;
-  int turn = 0;
   for (int c = 0; c < 3; c++) {
     rc = EnsureDevice(ctx, &ctx->own_planes[c], pitch_floats * ysize);
     if (rc != JXLT_OK) return rc;
     ctx->planes[c] = ctx->own_planes[c].p;
-    if (pinned) {
+    if (pinned)
       HIP_TRY(ctx, hipMemcpy2DAsync(ctx->own_planes[c].p, pitch_floats * sizeof(float), planes[c], pitch_bytes,
                                     row_bytes, ysize, hipMemcpyHostToDevice, ctx->stream));
-      continue;
-    }
-    for (size_t y0 = 0; y0 < ysize; y0 += band_rows, turn ^= 1) {
-      const size_t rows = std::min(band_rows, ysize - y0);
-      uint8_t* dst = ctx->stage[turn].p;
-      HIP_TRY(ctx, hipEventSynchronize(ctx->stage_done[turn]));  // previous use of this buffer
-      const uint8_t* src = reinterpret_cast<const uint8_t*>(planes[c]) + y0 * pitch_bytes;
-      const int nthreads = rows * row_bytes > (size_t(4) << 20) ? 4 : 1;
-      auto copy_rows = [&](size_t a, size_t b) {
-        for (size_t y = a; y < b; y++) memcpy(dst + y * row_bytes, src + y * pitch_bytes, row_bytes);
-      };
-      if (nthreads == 1) {
-        copy_rows(0, rows);
-      } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nthreads; t++)
-          pool.emplace_back(copy_rows, rows * t / nthreads, rows * (t + 1) / nthreads);
-        for (auto& th : pool) th.join();
-      }
-      HIP_TRY(ctx, hipMemcpy2DAsync(ctx->own_planes[c].p + y0 * pitch_floats, pitch_floats * sizeof(float), dst,
-                                    row_bytes, row_bytes, rows, hipMemcpyHostToDevice, ctx->stream));
-      HIP_TRY(ctx, hipEventRecord(ctx->stage_done[turn], ctx->stream));
-    }
+  }
+  if (!pinned) {
+    // bands of all three planes in one staged sequence
+    const size_t bands_per_plane = (ysize + band_rows - 1) / band_rows;
+    const int nthreads = ysize * row_bytes > (size_t(4) << 20) ? StageThreads() : 1;
+    rc = StagedUpload(
+        ctx, 3 * bands_per_plane, nthreads,
+        [&](size_t band, int t, int nt, uint8_t* stage) {
+          const size_t c = band / bands_per_plane, y0 = (band % bands_per_plane) * band_rows;
+          const size_t rows = std::min(band_rows, ysize - y0);
+          const uint8_t* src = reinterpret_cast<const uint8_t*>(planes[c]) + y0 * pitch_bytes;
+          for (size_t y = rows * t / nt; y < rows * (t + 1) / nt; y++)
+            memcpy(stage + y * row_bytes, src + y * pitch_bytes, row_bytes);
+        },
+        [&](size_t band, uint8_t* stage) {
+          const size_t c = band / bands_per_plane, y0 = (band % bands_per_plane) * band_rows;
+          const size_t rows = std::min(band_rows, ysize - y0);
+          return hipMemcpy2DAsync(ctx->own_planes[c].p + y0 * pitch_floats, pitch_floats * sizeof(float), stage,
+                                  row_bytes, row_bytes, rows, hipMemcpyHostToDevice, ctx->stream) == hipSuccess
+                     ? JXLT_OK
+                     : JXLT_ERR_NO_DEVICE;
+        });
+    if (rc != JXLT_OK) return rc;
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // caller may reuse its buffers
   ctx->pitch_floats = (ptrdiff_t)pitch_floats;
@@ -463,24 +525,19 @@ int jxlt_image_upload_pfm(jxlt_context* ctx, const void* host_payload, size_t xs
     constexpr size_t kStageBytes = size_t(32) << 20;
     for (auto& st : ctx->stage)
       if ((rc = EnsurePinned(ctx, &st, std::min(kStageBytes, nbytes))) != JXLT_OK) return rc;
-    int turn = 0;
-    for (size_t o = 0; o < nbytes; o += kStageBytes, turn ^= 1) {
-      const size_t n = std::min(kStageBytes, nbytes - o);
-      uint8_t* stage = ctx->stage[turn].p;
-      HIP_TRY(ctx, hipEventSynchronize(ctx->stage_done[turn]));  // previous use of this buffer
-      const int nthreads = n > (size_t(4) << 20) ? 8 : 1;
-      if (nthreads == 1) {
-        memcpy(stage, src + o, n);
-      } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nthreads; t++)
-          pool.emplace_back([=] { memcpy(stage + n * t / nthreads, src + o + n * t / nthreads,
-                                         n * (t + 1) / nthreads - n * t / nthreads); });
-        for (auto& th : pool) th.join();
-      }
-      HIP_TRY(ctx, hipMemcpyAsync(dst + o, stage, n, hipMemcpyHostToDevice, ctx->stream));
-      HIP_TRY(ctx, hipEventRecord(ctx->stage_done[turn], ctx->stream));
-    }
+    const size_t nbands = (nbytes + kStageBytes - 1) / kStageBytes;
+    rc = StagedUpload(
+        ctx, nbands, nbytes > (size_t(4) << 20) ? StageThreads() : 1,
+        [&](size_t band, int t, int nt, uint8_t* stage) {
+          const size_t o = band * kStageBytes, n = std::min(kStageBytes, nbytes - o);
+          memcpy(stage + n * t / nt, src + o + n * t / nt, n * (t + 1) / nt - n * t / nt);
+        },
+        [&](size_t band, uint8_t* stage) {
+          const size_t o = band * kStageBytes, n = std::min(kStageBytes, nbytes - o);
+          return hipMemcpyAsync(dst + o, stage, n, hipMemcpyHostToDevice, ctx->stream) == hipSuccess ? JXLT_OK
+                                                                                                     : JXLT_ERR_NO_DEVICE;
+        });
+    if (rc != JXLT_OK) return rc;
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // caller may reuse its buffer
   return SetPfmView(ctx, ctx->own_payload.p, xsize, ysize, big_endian);
