@@ -233,6 +233,21 @@ def main():
             "sample": "top-left %dx%d crop of the benchmark frame: oracle hot path + host assembly, 1 thread, "
                       "%.1f s" % (s, s, cpu_s),
             "cpu": _cpu_model(), "host_cores": os.cpu_count(), "codestream_bytes": len(cpu_jxl)}
+        # the same crop on many cores: 256-row strips are independent units of the hot path (no vertical
+        # context crosses a group row), one oracle call per strip on a thread pool (ctypes drops the GIL)
+        from concurrent.futures import ThreadPoolExecutor
+        strips = [np.ascontiguousarray(crop[:, y:y + 256, :]) for y in range(0, s, 256)]
+        nthr = max(1, min(len(strips), os.cpu_count() or 1))
+        t3 = time.perf_counter()
+        with ThreadPoolExecutor(nthr) as ex:
+            par = list(ex.map(lambda p_: T.oracle_hot_path(p_, args.distance), strips))
+        par_s = time.perf_counter() - t3
+        strips_ok = all(par[i].group_tokens == want.group_tokens[i * (s // 256):(i + 1) * (s // 256)]
+                        for i in range(len(strips))) if s >= 256 else True
+        result["cpu_baseline"]["all_cores"] = {
+            "value": round(s * s / 1e6 / par_s, 1), "unit": "Mpixels/s", "cores": nthr,
+            "sample": "same crop, oracle hot path only (no bitstream assembly), %d strips of 256 rows on %d "
+                      "threads, %.2f s" % (len(strips), nthr, par_s), "strips_equal_whole_crop": bool(strips_ok)}
         # groups of the crop must equal the same groups of the full-frame GPU encode
         gpg = (size + 255) // 256
         offs = np.ctypeslib.as_array(fr.group_token_offset, shape=(fr.num_groups + 1,)).copy()
