@@ -394,7 +394,15 @@ constexpr int kTransposePitch = 72;
     (void)__shfl_xor(0, 4);                                       \
   } while (0)
 #else
-#define JXLT_OCTET_SYNC() __builtin_amdgcn_wave_barrier()  // no instruction: keeps the compiler from reordering
+// No instruction: the wave's LDS operations execute in order.  What has to be stopped is the
+// compiler -- the stores and the loads of a transpose go through different types (float / float4),
+// which type-based alias analysis treats as independent -- hence the memory clobber.
+#define JXLT_OCTET_SYNC()                  \
+  do {                                     \
+    asm volatile("" ::: "memory");         \
+    __builtin_amdgcn_wave_barrier();       \
+    asm volatile("" ::: "memory");         \
+  } while (0)
 #endif
 JXLT_DI void octet_transpose(float* v, float* sc, int l) {
 #if JXLT_LDS_TRANSPOSE
