@@ -371,7 +371,8 @@ JXLT_DI void octet_exchange(float& a, float& b, int l) {
 // JXLT_LDS_TRANSPOSE = 1: through a private LDS scratch of the octet (kTransposePitch floats,
 // 8 more than the 64 it holds so that the eight octets of a wave fall into different banks):
 // eight dword writes (immediate offsets j * 32 bytes), two 16-byte reads of the lane's row.  The
-// wave's LDS operations execute in order, so no barrier is needed between them; what this buys is
+// wave's LDS operations execute in order (tools/lds_order_probe.hip checks exactly this on the
+// GPU), so no barrier is needed between them; what this buys is
 // VALU issue slots -- the register variant below costs 40 "full-rate" instructions (24 DPP moves +
 // 16 selects, ~190 cycles per wave and transpose, tools/op_probe.hip), this one 10 LDS
 // instructions that other waves' VALU work overlaps.

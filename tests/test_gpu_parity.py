@@ -198,6 +198,21 @@ def test_hardware_shortcuts_are_exact_on_this_gpu():
         assert "mismatches=0 " in l, l
 
 
+def test_lds_store_load_order_on_this_gpu():
+    """tile_kernel's octet transposes store to LDS and load what OTHER lanes of the wave stored, with
+    no s_waitcnt and no barrier in between: that relies on a wave's LDS operations executing in program
+    order.  tools/lds_order_probe checks it for the layout in use (and a second one), 8 M elements each."""
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parent.parent
+    exe = root / "tools" / "lds_order_probe"
+    if not exe.exists():
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-o", str(exe),
+                        str(root / "tools" / "lds_order_probe.hip")], check=True)
+    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout
+    assert res.stdout.count(": 0 wrong of") == 4, res.stdout
+
+
 def test_pfm_file_ingest_on_device(built, tmp_path):
     """jxlt_encode_pfm_file: a frame wider and taller than one group, big-endian payload, rows
     bottom-up -- read in place by tile_kernel."""
