@@ -27,6 +27,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace jxlt_dev {
 
 // ---------------------------------------------------------------------------
@@ -1674,14 +1676,21 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   // (only scan positions below nscan were written by tile_kernel)
   int bx = wave % nbx, by = wave / nbx;
   const int dbx = kWaves % nbx, dby = kWaves / nbx;
+  // Chroma entries are short on ordinary content (the X and B entries of the bench frame average
+  // 0.6 tokens against 39 of Y): when both end within 32 scan positions they share ONE 64-lane pass,
+  // X on lanes 0-31 and B on lanes 32-63 -- B's coefficients are then loaded 32 lanes up.
   auto load_block = [&](int b, int bxx, int byy, int16_t* v) {
     const uint32_t pos = (uint32_t)(by0 + byy) * bstride + (uint32_t)(bx0 + bxx);
+    int ns[3];
 #pragma unroll
-    for (int ci = 0; ci < 3; ci++) {
-      const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
-      const int nscan = (int)(__builtin_amdgcn_readfirstlane((int)meta[b * 3 + ci]) >> 16);
-      v[ci] = lane < nscan ? A.coef_scan[(pos * 3 + c) * 64 + lane] : (int16_t)0;
-    }
+    for (int ci = 0; ci < 3; ci++) ns[ci] = (int)(__builtin_amdgcn_readfirstlane((int)meta[b * 3 + ci]) >> 16);
+    const bool packed = ns[1] <= 32 && ns[2] <= 32;
+    v[0] = v[1] = v[2] = 0;
+    if ((ns[0] | ns[1] | ns[2]) == 0) return;  // not a first block, or nothing to read (wave-uniform)
+    v[0] = lane < ns[0] ? A.coef_scan[(pos * 3 + 1) * 64 + lane] : (int16_t)0;
+    v[1] = lane < ns[1] ? A.coef_scan[(pos * 3 + 0) * 64 + lane] : (int16_t)0;
+    const int lb = packed ? lane - 32 : lane;  // B's scan position on this lane
+    v[2] = (lb >= 0 && lb < ns[2]) ? A.coef_scan[(pos * 3 + 2) * 64 + lb] : (int16_t)0;
   };
   int16_t next_v[3] = {0, 0, 0};
   if (wave < nblk) load_block(wave, bx, by, next_v);
@@ -1747,48 +1756,85 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
         atomicAdd(&hist[cm * 64 + sym], 1u);
       }
     }
-    // (2) scan positions 0..63 of the three entries
-    unsigned long long mk[3];
-    bool inr[3];
-    int zidx[3], p_prev[3];
+    // (2) scan positions 0..63 of the entries: NP passes of 64 lanes.  Pass parameters per lane:
+    // coefficient, in-range flag, scan position, nzeros / first token of its entry, block context,
+    // set bits of the nonzero ballot below it, previous lane's nonzero flag.
+    auto coef_passes = [&](auto np_tag, const int16_t* pv, const bool* pin, const int* pk, const int* pnz,
+                           const uint32_t* ptok, const int* pbctx, const int* pbelow, const int* pprev) {
+      constexpr int NP = decltype(np_tag)::value;
+      int zidx[NP];
+      uint8_t cms[NP];
 #pragma unroll
-    for (int ci = 0; ci < 3; ci++) {
-      inr[ci] = lane >= covered && lane < nscan[ci];
-      const bool nz = inr[ci] && cur_v[ci] != 0;
-      mk[ci] = __ballot(nz);
-      // the previous lane's flag (wave_shr:1 DPP)
-      p_prev[ci] = __builtin_amdgcn_update_dpp(0, nz ? 1 : 0, 0x138, 0xF, 0xF, false);
-    }
+      for (int p = 0; p < NP; p++) {
+        const int left = pnz[p] - pbelow[p];  // nzeros still to come at this position
+        const int nl = pin[p] ? (left + covered - 1) >> log2c : 0;
+        zidx[p] = s_nnz_ctx[nl] + s_freq_ctx[pk[p] >> log2c];
+      }
 #pragma unroll
-    for (int ci = 0; ci < 3; ci++) {
-      // nzeros still to come at this position (v_mbcnt: set bits of the ballot below this lane)
-      const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk[ci] >> 32),
-                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)mk[ci], 0u));
-      const int left = nzeros[ci] - below;
-      const int nl = inr[ci] ? (left + covered - 1) >> log2c : 0;
-      zidx[ci] = s_nnz_ctx[nl] + s_freq_ctx[lane >> log2c];
-    }
-    uint8_t cms[3];
+      for (int p = 0; p < NP; p++) {
+        const int pp = pk[p] == covered ? ((pnz[p] > size / 16) ? 0 : 1) : pprev[p];
+        const int ctx = 4 * 37 + 458 * pbctx[p] + zidx[p] * 2 + pp;
+        cms[p] = s_ctx_map[pin[p] ? ctx : 0];
+      }
 #pragma unroll
-    for (int ci = 0; ci < 3; ci++) {
-      const int p = lane == covered ? ((nzeros[ci] > size / 16) ? 0 : 1) : p_prev[ci];
-      const int ctx = 4 * 37 + 458 * (ci == 0 ? bctx_y : bctx_c) + zidx[ci] * 2 + p;
-      cms[ci] = s_ctx_map[inr[ci] ? ctx : 0];
-    }
-#pragma unroll
-    for (int ci = 0; ci < 3; ci++) {
-      if (inr[ci]) {
-        const uint32_t val = pack_signed((int32_t)cur_v[ci]);
-        uint8_t* o = out + 3u * (tok0[ci] + 1u + (uint32_t)(lane - covered));
-        o[0] = cms[ci];
-        o[1] = (uint8_t)(val & 0xFF);
-        o[2] = (uint8_t)((val >> 8) & 0xFF);
-        if (do_hist) {
-          uint32_t sym, nb, eb;
-          hybrid_uint(val & 0xFFFFu, &sym, &nb, &eb);
-          atomicAdd(&hist[cms[ci] * 64 + sym], 1u);
+      for (int p = 0; p < NP; p++) {
+        if (pin[p]) {
+          const uint32_t val = pack_signed((int32_t)pv[p]);
+          uint8_t* o = out + 3u * (ptok[p] + 1u + (uint32_t)(pk[p] - covered));
+          o[0] = cms[p];
+          o[1] = (uint8_t)(val & 0xFF);
+          o[2] = (uint8_t)((val >> 8) & 0xFF);
+          if (do_hist) {
+            uint32_t sym, nb, eb;
+            hybrid_uint(val & 0xFFFFu, &sym, &nb, &eb);
+            atomicAdd(&hist[cms[p] * 64 + sym], 1u);
+          }
         }
       }
+    };
+    unsigned long long mk[3] = {0, 0, 0};
+    const bool packed = nscan[1] <= 32 && nscan[2] <= 32;  // (the same test load_block made)
+    if (packed) {
+      // pass 0: Y; pass 1: X on lanes 0-31 and B on lanes 32-63
+      const int half = lane >> 5, k1 = lane & 31;
+      const int16_t pv[2] = {cur_v[0], (int16_t)(cur_v[1] | cur_v[2])};  // (each is 0 on the other's lanes)
+      const int pk[2] = {lane, k1};
+      const int pnz[2] = {nzeros[0], half ? nzeros[2] : nzeros[1]};
+      const uint32_t ptok[2] = {tok0[0], half ? tok0[2] : tok0[1]};
+      const int pbctx[2] = {bctx_y, bctx_c};
+      const bool pin[2] = {lane >= covered && lane < nscan[0], k1 >= covered && k1 < (half ? nscan[2] : nscan[1])};
+      int pbelow[2], pprev[2];
+      const bool nz0 = pin[0] && pv[0] != 0, nz1 = pin[1] && pv[1] != 0;
+      mk[0] = __ballot(nz0);
+      const unsigned long long m1 = __ballot(nz1);
+      pprev[0] = __builtin_amdgcn_update_dpp(0, nz0 ? 1 : 0, 0x138, 0xF, 0xF, false);
+      pprev[1] = __builtin_amdgcn_update_dpp(0, nz1 ? 1 : 0, 0x138, 0xF, 0xF, false);
+      pbelow[0] = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk[0] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[0], 0u));
+      // set bits below the lane within its own half of the ballot
+      const int below_lo = (int)__builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u);
+      const int below_hi = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), 0u);
+      pbelow[1] = half ? below_hi : below_lo;
+      coef_passes(std::integral_constant<int, 2>(), pv, pin, pk, pnz, ptok, pbctx, pbelow, pprev);
+    } else {
+      // The three channel entries are independent: their ballots, table look-ups and stores are
+      // written as straight-line code so that the dependent LDS reads of one entry overlap with
+      // the other two.
+      const int pk[3] = {lane, lane, lane};
+      const int pbctx[3] = {bctx_y, bctx_c, bctx_c};
+      bool pin[3];
+      int pbelow[3], pprev[3];
+#pragma unroll
+      for (int ci = 0; ci < 3; ci++) {
+        pin[ci] = lane >= covered && lane < nscan[ci];
+        const bool nz = pin[ci] && cur_v[ci] != 0;
+        mk[ci] = __ballot(nz);
+        pprev[ci] = __builtin_amdgcn_update_dpp(0, nz ? 1 : 0, 0x138, 0xF, 0xF, false);  // wave_shr:1
+      }
+#pragma unroll
+      for (int ci = 0; ci < 3; ci++)
+        pbelow[ci] = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk[ci] >> 32),
+                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mk[ci], 0u));
+      coef_passes(std::integral_constant<int, 3>(), cur_v, pin, pk, nzeros, tok0, pbctx, pbelow, pprev);
     }
     // (3) two-block transforms whose tokens reach beyond scan position 63 (uncommon)
     if (nscan[0] > 64 || nscan[1] > 64 || nscan[2] > 64) {
