@@ -275,6 +275,7 @@ JXLT_DI float cube_root_and_add(float x, float add) {
 }
 
 // enc_xyb.cc:30-81
+template <bool kNeedB = true>
 JXLT_DI void linear_to_xyb(float r, float g, float b, float* ox, float* oy, float* ob) {
   const float kM02 = 0.078f, kM00 = 0.30f, kM01 = 1.0f - kM02 - kM00;
   const float kM12 = 0.078f, kM10 = 0.23f, kM11 = 1.0f - kM12 - kM10;
@@ -284,13 +285,14 @@ JXLT_DI void linear_to_xyb(float r, float g, float b, float* ox, float* oy, floa
   const float neg_bias_cbrt = -0.15595420054f;
   const float mixed0 = fma32(kM00, r, fma32(kM01, g, fma32(kM02, b, bias)));
   const float mixed1 = fma32(kM10, r, fma32(kM11, g, fma32(kM12, b, bias)));
-  const float mixed2 = fma32(kM20, r, fma32(kM21, g, fma32(kM22, b, bias)));
   const float tm0 = cube_root_and_add(zero_if_negative(mixed0), neg_bias_cbrt);
   const float tm1 = cube_root_and_add(zero_if_negative(mixed1), neg_bias_cbrt);
-  const float tm2 = cube_root_and_add(zero_if_negative(mixed2), neg_bias_cbrt);
   *ox = 0.5f * (tm0 - tm1);
   *oy = 0.5f * (tm0 + tm1);
-  *ob = tm2;
+  if (kNeedB) {  // (the halo columns only feed the adaptive quantisation, which reads X and Y)
+    const float mixed2 = fma32(kM20, r, fma32(kM21, g, fma32(kM22, b, bias)));
+    *ob = cube_root_and_add(zero_if_negative(mixed2), neg_bias_cbrt);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -917,7 +919,8 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
   {
     // 16 lanes along x, 32 rows per pass: a thread owns 5 columns x 2 rows of the
     // (64 + 2*kHalo)-wide window, so the row and column clamps are shared and all thirty loads
-    // are in flight before the first use.
+    // are in flight before the first use.  Column slots 0-3 cover the 64 interior columns; slot 4
+    // takes the ten halo columns (lanes 0-4 left, 5-9 right), which need X and Y only.
     constexpr int kWin = 64 + 2 * kHalo;
     const int base = px0 - kHalo;  // stripe x of LDS column 0
     const int lx = tid & 15, ly = tid >> 4;
@@ -939,7 +942,8 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     bool xok[5];
 #pragma unroll
     for (int j = 0; j < 5; j++) {
-      const int cx = lx + 16 * j, x = base + cx;
+      const int cx = j < 4 ? kHalo + lx + 16 * j : (lx < kHalo ? lx : lx < 2 * kHalo ? 64 + lx : kWin);
+      const int x = base + cx;
       xok[j] = cx < kWin && x >= 0 && x < swp && x < px0 + nbx * 8 + kHalo;
       const int xs = (xok[j] ? imin(x, sw - 1) : 0) * A.pix_stride;
 #pragma unroll
@@ -963,17 +967,18 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
 #pragma unroll
     for (int j = 0; j < 5; j++) {
       if (!xok[j]) continue;
-      const int cx = lx + 16 * j;
+      const int cx = j < 4 ? kHalo + lx + 16 * j : (lx < kHalo ? lx : 64 + lx);
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         if (!yok[h]) continue;
         const int y = ly + 32 * h;
-        float px_, py_, pb_;
-        linear_to_xyb(pr[j][h], pg[j][h], pb[j][h], &px_, &py_, &pb_);
+        float px_, py_, pb_ = 0.0f;
+        if (j < 4) linear_to_xyb<true>(pr[j][h], pg[j][h], pb[j][h], &px_, &py_, &pb_);
+        else linear_to_xyb<false>(pr[j][h], pg[j][h], pb[j][h], &px_, &py_, &pb_);
         S.x[y * kXYPitch + cx] = px_;
         S.y[y * kXYPitch + cx] = py_;
-        if (cx >= kHalo && cx < kHalo + 64) S.b[y * kBPitch + cx - kHalo] = pb_;
-        if (A.dbg_xyb[0] && cx >= kHalo && cx < kHalo + nbx * 8) {
+        if (j < 4) S.b[y * kBPitch + cx - kHalo] = pb_;
+        if (j < 4 && A.dbg_xyb[0] && cx < kHalo + nbx * 8) {
           const size_t d = (size_t)(by_img0 * 8 + y) * ((size_t)bstride * 8) + (size_t)(bx_img0 * 8 + cx - kHalo);
           A.dbg_xyb[0][d] = px_;
           A.dbg_xyb[1][d] = py_;
