@@ -220,6 +220,24 @@ JXLT_DI float rcp_int_exact(float q) {
   return fma32(e0, r0, r0);
 }
 
+// IEEE-correct num / den where operands and quotient are far from the overflow / underflow
+// thresholds: the hardware reciprocal and the refinement steps of the generic expansion, without
+// that expansion's operand scaling (v_div_scale x 2) and special-case fix-up (v_div_fixup) -- 8
+// instructions instead of 11, the three dropped ones full-rate.  Every division of the kernels is
+// of this kind for finite input of ordinary magnitude (denominators between 1e-3 and 1e6;
+// DESIGN.md "domain of the guarantee").  tools/div_probe.hip compares it with the compiler's
+// division on 2^32 operand pairs of magnitudes 2^-40 .. 2^40 (tests/test_gpu_parity.py runs it).
+JXLT_DI float div_normal(float num, float den) {
+  const float r0 = __builtin_amdgcn_rcpf(den);
+  const float e0 = nfma32(den, r0, 1.0f);
+  const float r1 = fma32(e0, r0, r0);
+  const float q0 = num * r1;
+  const float e1 = nfma32(den, q0, num);
+  const float q1 = fma32(e1, r1, q0);
+  const float e2 = nfma32(den, q1, num);
+  return fma32(e2, r1, q1);
+}
+
 // fast_math-inl.h:113-133 + :74-108
 JXLT_DI float fast_log2f(float x) {
   const float p0 = -1.8503833400518310E-06f, p1 = 1.4287160470083755E+00f,
@@ -237,7 +255,7 @@ JXLT_DI float fast_log2f(float x) {
   yq = fma32(yq, t, q1);
   yp = fma32(yp, t, p0);
   yq = fma32(yq, t, q0);
-  return yp / yq + exp_val;
+  return div_normal(yp, yq) + exp_val;
 }
 
 // fast_math-inl.h:137-151
@@ -252,7 +270,7 @@ JXLT_DI float fast_pow2f(float x) {
   float den = fma32(frac, (float)2.10242958e-01, (float)-2.22328856e-02);
   den = fma32(den, frac, (float)-1.94414990e+01);
   den = fma32(den, frac, (float)9.85506633e+01);
-  return num / den;
+  return div_normal(num, den);
 }
 
 // fast_math-inl.h:178-213
@@ -536,7 +554,7 @@ JXLT_DI float ratio_of_derivatives(float v, bool invert) {
   const float v2 = v * v;
   const float num = fma32(kNumMul, v2, kEpsilon);
   const float den = fma32(kDenMul * v, v2, kVOffset);
-  return invert ? num / den : den / num;
+  return invert ? div_normal(num, den) : div_normal(den, num);
 }
 
 // :287-294.  sqrt(float(kMul * 1e8)) is a constant of the model; it is passed in
@@ -558,9 +576,9 @@ JXLT_DI float compute_mask(float out_val) {
               kOffset3 = 2.1925739705298404f, kMul0 = 0.74760422233706747f;
   const float kOffset4 = 0.25f * kOffset3;
   const float v1 = fmaxf(out_val * kMul0, 1e-3f);
-  const float v2 = 1.0f / (v1 + kOffset2);
-  const float v3 = 1.0f / fma32(v1, v1, kOffset3);
-  const float v4 = 1.0f / fma32(v1, v1, kOffset4);
+  const float v2 = div_normal(1.0f, v1 + kOffset2);
+  const float v3 = div_normal(1.0f, fma32(v1, v1, kOffset3));
+  const float v4 = div_normal(1.0f, fma32(v1, v1, kOffset4));
   return kBase + fma32(kMul4, v4, fma32(kMul2, v2, kMul3 * v3));
 }
 
@@ -1082,7 +1100,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       const float* e = &S.erosion[(2 * by) * 16 + 2 * bx];
       const float v = ((e[0] + e[1]) + e[16]) + e[17];
       S.aq[tid] = v;
-      S.mask[tid] = 1.0f / (v + 0.001f);  // ComputeMaskForAcStrategyUse (:46-50)
+      S.mask[tid] = div_normal(1.0f, v + 0.001f);  // ComputeMaskForAcStrategyUse (:46-50)
     } else {
       S.aq[tid] = 0.0f;
       S.mask[tid] = 0.0f;
@@ -1158,7 +1176,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       }
       // PerBlockModulations tail (:249-285) + raw quant (:518-534)
       const float kAcQuant = 0.8294f;
-      const float scale = kAcQuant / A.distance;
+      const float scale = div_normal(kAcQuant, A.distance);
       const float base_level = 0.5f * scale;
       float dampen = 1.0f;
       if (A.distance >= 7.0f) {
@@ -1380,7 +1398,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       const float k8x8mul1 = (float)(-0.55 * 0.75f);
       const float k8x8mul2 = 1.0735757687292623f * 0.75f;
       const float k8x8base = (float)1.4;
-      const float mul8x8 = k8x8mul2 + k8x8mul1 / (A.strategy_distance + k8x8base);
+      const float mul8x8 = k8x8mul2 + div_normal(k8x8mul1, A.strategy_distance + k8x8base);
       float e8 = 3.0f * mul8x8;
       e8 += mul8x8 * e;
       if (l == 0) S.transpose_pad[((oby >> 1) * 4 + (obx >> 1)) * 8 + (oby & 1) * 2 + (obx & 1)] = e8;
@@ -1409,7 +1427,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       qmax = fmaxf(qmax, qmax16);
       const float k8X16mul1 = (float)-0.55, k8X16mul2 = (float)0.9019587899705066,
                   k8X16base = (float)1.6;
-      const float mul16x8 = k8X16mul2 + k8X16mul1 / (A.strategy_distance + k8X16base);
+      const float mul16x8 = k8X16mul2 + div_normal(k8X16mul1, A.strategy_distance + k8X16base);
       if (l == 0) S.transpose_pad[cell * 8 + (is_tall ? 4 : 6) + (cand & 1)] = mul16x8 * e;
     }
     JXLT_SCHED_FENCE();

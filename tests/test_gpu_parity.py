@@ -198,6 +198,20 @@ def test_hardware_shortcuts_are_exact_on_this_gpu():
         assert "mismatches=0 " in l, l
 
 
+def test_short_division_equals_ieee_on_this_gpu():
+    """The kernels divide with v_rcp_f32 + the refinement steps of the IEEE expansion, without its operand
+    scaling and fix-up (jxlt_device.h: div_normal).  tools/div_probe compares that with the compiler's
+    division on 2^32 operand pairs (magnitudes 2^-40 .. 2^40) and on reciprocals."""
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parent.parent
+    exe = root / "tools" / "div_probe"
+    if not exe.exists():
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O2", "-ffp-contract=off", "-o", str(exe),
+                        str(root / "tools" / "div_probe.hip")], check=True)
+    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "mismatches=0 of 4294967296; reciprocals: mismatches=0" in res.stdout, res.stdout
+
+
 def test_lds_store_load_order_on_this_gpu():
     """tile_kernel's octet transposes store to LDS and load what OTHER lanes of the wave stored, with
     no s_waitcnt and no barrier in between: that relies on a wave's LDS operations executing in program
