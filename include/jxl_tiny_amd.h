@@ -260,6 +260,8 @@ typedef struct {
   const void* pfm_payload; /* or: interleaved bottom-up RGB f32 payload of a PFM file (read_pfm.cc:199-209) */
   int pfm_big_endian;
   size_t xsize, ysize;
+  int in_device_memory;    /* non-zero: planes / pfm_payload point into device memory of the encoder's GPU and
+                              are read in place (jxlt_image_set_device*); they must stay valid during the run */
 } jxlt_batch_frame;
 typedef struct jxlt_batch_encoder jxlt_batch_encoder;
 /* lanes <= 0: 3 (upload / encode / download in flight at once). */

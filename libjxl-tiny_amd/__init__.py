@@ -441,7 +441,8 @@ def encode_file(planes, distance, device=0):
 
 class BatchFrame(C.Structure):
     _fields_ = [("planes", fp * 3), ("pitch_bytes", C.c_size_t), ("pfm_payload", C.c_void_p),
-                ("pfm_big_endian", C.c_int), ("xsize", C.c_size_t), ("ysize", C.c_size_t)]
+                ("pfm_big_endian", C.c_int), ("xsize", C.c_size_t), ("ysize", C.c_size_t),
+                ("in_device_memory", C.c_int)]
 
 
 def pinned_empty(shape, dtype=np.float32):
@@ -498,6 +499,15 @@ class BatchEncoder:
         descs = (BatchFrame * len(frames))()
         keep = []
         for d, f in zip(descs, frames):
+            if hasattr(f, "data_ptr"):  # a torch tensor [3, h, w] float32 on the encoder's GPU: read in place
+                assert f.dim() == 3 and f.shape[0] == 3 and f.stride(2) == 1
+                keep.append(f)
+                for c in range(3):
+                    d.planes[c] = C.cast(C.c_void_p(f[c].data_ptr()), fp)
+                d.pitch_bytes = f.stride(1) * 4
+                d.xsize, d.ysize = f.shape[2], f.shape[1]
+                d.in_device_memory = 1
+                continue
             if isinstance(f, tuple):
                 payload, w, h, big = f
                 a = np.frombuffer(payload, dtype=np.uint8) if not isinstance(payload, np.ndarray) else payload

@@ -30,8 +30,15 @@ int EncodeOne(jxlt_context* ctx, const jxlt_batch_frame& f, float distance, uint
   jxl::BitWriter writer;
   if (!jxlt::WriteFileHeader(f.xsize, f.ysize, &writer)) return JXLT_ERR_INVALID_ARGUMENT;
   const std::vector<uint8_t> file_header = writer.TakeBytes();
-  const int rc = planar ? jxlt_image_upload(ctx, f.planes, f.pitch_bytes, f.xsize, f.ysize)
-                        : jxlt_image_upload_pfm(ctx, f.pfm_payload, f.xsize, f.ysize, f.pfm_big_endian);
+  int rc;
+  if (f.in_device_memory) {
+    const void* const dev[3] = {f.planes[0], f.planes[1], f.planes[2]};
+    rc = planar ? jxlt_image_set_device(ctx, dev, f.pitch_bytes, f.xsize, f.ysize)
+                : jxlt_image_set_device_pfm(ctx, f.pfm_payload, f.xsize, f.ysize, f.pfm_big_endian);
+  } else {
+    rc = planar ? jxlt_image_upload(ctx, f.planes, f.pitch_bytes, f.xsize, f.ysize)
+                : jxlt_image_upload_pfm(ctx, f.pfm_payload, f.xsize, f.ysize, f.pfm_big_endian);
+  }
   if (rc != JXLT_OK) return rc;
   jxlt::ContextOutput out;
   out.prefix = &file_header;

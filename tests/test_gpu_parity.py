@@ -363,6 +363,11 @@ def test_frame_batch_encoder(built):
             frames.append(arr[:, :, :w])
         else:
             frames.append(planes)
+    import torch
+    dev_frame = torch.from_numpy(T.to_planes(T.synthetic_image(520, 300, seed=77))).to("cuda:0")
+    frames.append(dev_frame)  # a frame that already is in device memory (read in place)
+    want.append(T.assemble_codestream(T.oracle_hot_path(dev_frame.cpu().numpy(), 2.0), 2.0))
+    sizes = sizes + [(520, 300)]
     enc = built.BatchEncoder(0, lanes=3)
     got = enc.encode(frames, 2.0)
     again = enc.encode(frames[:2], 2.0)  # the encoder is reusable
