@@ -210,6 +210,29 @@ def main():
         "device_only_mpix_s": round(mpix / device_only_s, 1),
     }
 
+    # ---- supplementary: PCIe-inclusive rate (SURVEY.md 8(d) "end-to-end"): a frame in page-locked HOST memory ->
+    # upload + encode -> codestream bytes in host memory; never the headline value.  8192 x 8192 crop (805 MB).
+    if rank == 0 and size >= 8192:
+        ps = 8192
+        host, owner = pkg.pinned_empty((3, ps, ps))
+        host[...] = frame[:, :ps, :ps].cpu().numpy()
+        enc2 = pkg.Encoder(dev_index)
+        for _ in range(2):
+            enc2.upload(host)
+            enc2.encode_resident(args.distance, num_threads=args.host_threads, copy=False)
+        t3 = time.perf_counter()
+        reps2 = 3
+        for _ in range(reps2):
+            enc2.upload(host)
+            enc2.encode_resident(args.distance, num_threads=args.host_threads, copy=False)
+        pcie_s = (time.perf_counter() - t3) / reps2
+        enc2.close()
+        del host, owner
+        result["pcie_inclusive"] = {"workload": "%dx%d crop in page-locked host memory -> upload + encode -> bytes in host "
+                                                "memory" % (ps, ps), "ms_per_frame": round(pcie_s * 1e3, 2),
+                                    "value": round(ps * ps / pcie_s / 1e6, 1), "unit": "Mpixels/s",
+                                    "h2d_gb_s": round(12.0 * ps * ps / pcie_s / 1e9, 1)}
+
     valu = pmc_valu(size)
     if valu is not None and tile_ms == tile_ms:
         # Supplementary: the kernel is VALU-issue bound, not HBM bound.  Instructions per wave
