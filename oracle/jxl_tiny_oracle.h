@@ -92,6 +92,35 @@ void orc_dct8x16(const float* px, size_t stride, float* out128);
 float orc_fast_log2f(float x);
 float orc_fast_pow2f(float x);
 
+/* ---- bitstream stage (oracle/jxl_tiny_bitstream_oracle.c) ------------------------------
+ * Everything EncodeFile / EncodeFrame do after the pixel pipeline (enc_file.cc:55-105,
+ * enc_frame.cc:287-595, 766-858 with enc_cluster.cc, enc_huffman_tree.cc,
+ * enc_entropy_code.cc): DC-group tokenisation, code optimisation, section writing,
+ * headers, TOC.  Independent of the product's host back-end. */
+typedef struct {
+  size_t xsize, ysize;
+  const int16_t* quant_dc[3];      /* image-absolute block grids (pitch ceil(xsize / 8)) */
+  const uint8_t* raw_quant_field;
+  const uint8_t* ac_strategy;      /* (type << 1) | is_first */
+  const int8_t* ytox_map;          /* image-absolute 64x64-tile grids (pitch ceil(xsize / 64)) */
+  const int8_t* ytob_map;
+  const uint8_t* const* group_tokens; /* raw 3-byte records per 256x256 group, raster order */
+  const size_t* group_token_bytes;
+} orc_bs_input;
+/* The complete .jxl file.  reference_single_symbol: 1 = one bit per token of a single-symbol
+ * prefix code as the reference writes it (undecodable there), 0 = zero bits.  *out is
+ * malloc'ed (orc_bs_free).  Returns 0 on success. */
+int orc_bs_encode_file(const orc_bs_input* in, float distance, int reference_single_symbol, uint8_t** out,
+                       size_t* out_size);
+/* Raw records of one DC-group section (WriteDCGroup with OPTIMIZE_CODE, enc_frame.cc:536-570). */
+int orc_bs_dc_group_records(const orc_bs_input* in, size_t dc_group, uint8_t** out, size_t* out_size);
+/* Code tables (depth << 16 | bits per [context][symbol]) from the [64][64] AC histograms
+ * (per pre-clustered context) and DC histograms (45 contexts): what OptimizeSections
+ * (enc_frame.cc:766-783) arrives at. */
+void orc_bs_build_code_tables(const uint32_t* ac_hist, const uint32_t* dc_hist, int reference_single_symbol,
+                              uint32_t* ac_table, uint32_t* dc_table);
+void orc_bs_free(void* p);
+
 #ifdef __cplusplus
 }
 #endif

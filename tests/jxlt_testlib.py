@@ -397,22 +397,121 @@ def host_dc_records(res):
     return out
 
 
+_reference_single_symbol = False
+
+
 @contextlib.contextmanager
 def reference_single_symbol_codes():
-    """While active the host back-end writes one bit per token of a single-symbol prefix code, as the
-    reference does (jxl::EmulateReferenceSingleSymbolCodes): byte-identical to the reference even where
-    its output cannot be decoded.  Fixtures / known answers that pin REFERENCE bytes use this."""
+    """While active both back-ends -- the oracle's (oracle_codestream / assemble_codestream) and the product's
+    host library (jxl::EmulateReferenceSingleSymbolCodes) -- write one bit per token of a single-symbol prefix
+    code, as the reference does: byte-identical to the reference even where its output cannot be decoded.
+    Fixtures / known answers that pin REFERENCE bytes use this."""
+    global _reference_single_symbol
     P = product()
     P.emulate_reference_single_symbol_codes(True)
+    _reference_single_symbol = True
     try:
         yield
     finally:
         P.emulate_reference_single_symbol_codes(False)
+        _reference_single_symbol = False
+
+
+class OrcBsInput(C.Structure):
+    _fields_ = [("xsize", C.c_size_t), ("ysize", C.c_size_t), ("quant_dc", C.POINTER(C.c_int16) * 3),
+                ("raw_quant_field", C.POINTER(C.c_uint8)), ("ac_strategy", C.POINTER(C.c_uint8)),
+                ("ytox_map", C.POINTER(C.c_int8)), ("ytob_map", C.POINTER(C.c_int8)),
+                ("group_tokens", C.POINTER(C.POINTER(C.c_uint8))), ("group_token_bytes", C.POINTER(C.c_size_t))]
+
+
+def _bs_input(res):
+    """orc_bs_input over a HotPathResult (oracle, simulator or GPU); returns (struct, keepalive)."""
+    b = OrcBsInput()
+    b.xsize, b.ysize = res.xsize, res.ysize
+    qd = [np.ascontiguousarray(res.quant_dc[c], np.int16) for c in range(3)]
+    for c in range(3):
+        b.quant_dc[c] = qd[c].ctypes.data_as(C.POINTER(C.c_int16))
+    rq, st = np.ascontiguousarray(res.raw_quant, np.uint8), np.ascontiguousarray(res.strategy, np.uint8)
+    tx, tb = np.ascontiguousarray(res.ytox, np.int8), np.ascontiguousarray(res.ytob, np.int8)
+    b.raw_quant_field = rq.ctypes.data_as(C.POINTER(C.c_uint8))
+    b.ac_strategy = st.ctypes.data_as(C.POINTER(C.c_uint8))
+    b.ytox_map = tx.ctypes.data_as(C.POINTER(C.c_int8))
+    b.ytob_map = tb.ctypes.data_as(C.POINTER(C.c_int8))
+    n = len(res.group_tokens)
+    bufs = [np.frombuffer(t + b"\0", np.uint8).copy() for t in res.group_tokens]
+    ptrs = (C.POINTER(C.c_uint8) * max(n, 1))()
+    lens = (C.c_size_t * max(n, 1))()
+    for i, t in enumerate(res.group_tokens):
+        ptrs[i] = bufs[i].ctypes.data_as(C.POINTER(C.c_uint8))
+        lens[i] = len(t)
+    b.group_tokens = C.cast(ptrs, C.POINTER(C.POINTER(C.c_uint8)))
+    b.group_token_bytes = C.cast(lens, C.POINTER(C.c_size_t))
+    return b, (qd, rq, st, tx, tb, bufs, ptrs, lens)
+
+
+def _oracle_bs():
+    L = oracle()
+    L.orc_bs_encode_file.argtypes = [C.POINTER(OrcBsInput), C.c_float, C.c_int, C.POINTER(C.POINTER(C.c_uint8)),
+                                     C.POINTER(C.c_size_t)]
+    L.orc_bs_encode_file.restype = C.c_int
+    L.orc_bs_dc_group_records.argtypes = [C.POINTER(OrcBsInput), C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)),
+                                          C.POINTER(C.c_size_t)]
+    L.orc_bs_dc_group_records.restype = C.c_int
+    L.orc_bs_build_code_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.orc_bs_build_code_tables.restype = None
+    L.orc_bs_free.argtypes = [C.c_void_p]
+    L.orc_bs_free.restype = None
+    return L
+
+
+def oracle_codestream(res, distance, reference_single_symbol=None):
+    """Full .jxl bytes from a HotPathResult through the ORACLE's bitstream stage
+    (oracle/jxl_tiny_bitstream_oracle.c): no product code involved."""
+    L = _oracle_bs()
+    b, keep = _bs_input(res)
+    ref = _reference_single_symbol if reference_single_symbol is None else reference_single_symbol
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    rc = L.orc_bs_encode_file(C.byref(b), C.c_float(distance), int(ref), C.byref(out), C.byref(n))
+    assert rc == 0, rc
+    data = C.string_at(out, n.value)
+    L.orc_bs_free(out)
+    return data
+
+
+def oracle_dc_records(res):
+    """Raw DC-group records (WriteDCGroup, OPTIMIZE_CODE form) from the oracle's bitstream stage."""
+    L = _oracle_bs()
+    b, keep = _bs_input(res)
+    ndc = ((res.xsize + 2047) // 2048) * ((res.ysize + 2047) // 2048)
+    out = []
+    for i in range(ndc):
+        p, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+        assert L.orc_bs_dc_group_records(C.byref(b), i, C.byref(p), C.byref(n)) == 0
+        out.append(C.string_at(p, n.value))
+        L.orc_bs_free(p)
+    return out
+
+
+def oracle_code_tables(ac_hist, dc_hist, reference_single_symbol=None):
+    """(ac_table, dc_table) uint32[4096] each from [64][64] histograms, by the oracle's clustering + Huffman."""
+    L = _oracle_bs()
+    ref = _reference_single_symbol if reference_single_symbol is None else reference_single_symbol
+    a = np.ascontiguousarray(ac_hist, np.uint32).reshape(-1)
+    d = np.ascontiguousarray(dc_hist, np.uint32).reshape(-1)
+    at, dt = np.zeros(4096, np.uint32), np.zeros(4096, np.uint32)
+    L.orc_bs_build_code_tables(a.ctypes.data, d.ctypes.data, int(ref), at.ctypes.data, dt.ctypes.data)
+    return at, dt
 
 
 def assemble_codestream(res, distance, num_threads=1):
-    """Full .jxl bytes from a HotPathResult via the product's host back-end
-    (jxlt_write_file_header + jxlt_assemble_frame)."""
+    """Full .jxl bytes for a HotPathResult: the checker's codestream, produced by the oracle's own
+    bitstream stage (independent of libjxltiny_host.so)."""
+    return oracle_codestream(res, distance)
+
+
+def host_assemble_codestream(res, distance, num_threads=1):
+    """Full .jxl bytes from a HotPathResult via the PRODUCT's host back-end
+    (jxlt_write_file_header + jxlt_assemble_frame) -- the thing under test, not a checker."""
     P = product()
     H = P.host_lib()
     dp = P.distance_params(distance)

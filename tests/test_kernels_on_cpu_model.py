@@ -91,11 +91,11 @@ def test_pack_tiles_with_short_codes(built):
 
 
 @pytest.mark.parametrize("w,h,distance", [(200, 137, 1.0), (9, 7, 1.0), (300, 264, 2.0), (2100, 40, 1.0), (64, 64, 8.0)])
-def test_dc_kernels_match_host_tokeniser(built, w, h, distance):
-    """dc_elementwise_kernel + dc_chain_kernel vs the host's WriteDCGroup restatement."""
+def test_dc_kernels_match_oracle_tokeniser(built, w, h, distance):
+    """dc_elementwise_kernel + dc_chain_kernel vs the oracle's WriteDCGroup restatement."""
     planes = T.to_planes(T.synthetic_image(w, h))
     got = T.sim_hot_path(planes, distance)
-    want = T.host_dc_records(got)
+    want = T.oracle_dc_records(got)
     assert got.dc_records == want
     h = sum((T.token_histogram(r) for r in want))
     assert (got.dc_histogram == h).all()

@@ -2,8 +2,8 @@
 libjxl-tiny_amd/sharded.py -- histogram all_reduce, identical code tables, per-rank section
 packing, gather, assembly on rank 0 -- must give byte-for-byte the single-process codestream.
 
-Here the per-slab "device" is replaced by test infrastructure (oracle tokens, host DC
-tokeniser hook, reference bit packer) so that the test runs without a GPU; the GPU variant
+Here the per-slab "device" is replaced by test infrastructure (oracle tokens, oracle DC
+tokeniser, reference bit packer) so that the test runs without a GPU; the GPU variant
 (test_gpu_parity.py::test_sharded_slabs_on_one_gpu) uses real device contexts."""
 import multiprocessing as mp
 import os
@@ -22,7 +22,7 @@ class OracleSlab:
 
     def __init__(self, planes, distance):
         self.res = T.oracle_hot_path(planes, distance)
-        self.dc_records = T.host_dc_records(self.res)
+        self.dc_records = T.oracle_dc_records(self.res)
 
     def histograms(self):
         ac = T.token_histogram(self.res.all_tokens())
