@@ -1,67 +1,56 @@
 #!/usr/bin/env python3
 """bench.py -- Mpixels/s of the MI355X-native JPEG XL tiny encoder.
 
-One "step" = one full encode of a synthetic linear-sRGB frame that is already
-resident in HBM as three planar f32 planes, ending with the complete .jxl
-codestream bytes in host memory (jxlt_encode_resident_view):
-  device   tile_kernel (XYB, adaptive quant, chroma-from-luma, strategy search, quantise)
-           dc_elementwise_kernel, dc_chain_kernel (DC-group tokens + DC histogram)
-           group_scan_kernel, token_kernel (AC tokens + AC histogram)
-  host     DC histogram D2H -> DC code (while token_kernel runs); AC histogram D2H -> AC code
-  device   pack_tile_measure (exact section sizes) -> pack_tile_write (sections at their final
-           bit positions), copied in ranges to the page-locked output buffer while the host
-           writes frame header + TOC + global sections in front of them
-PFM file I/O and the H2D upload are outside the timed region (DESIGN.md quotes
-the PCIe-inclusive rate separately).
-
     python bench.py --gpus N --steps K --warmup W [--size S]
 
-For N > 1 launch through torch.distributed.run (one rank per GPU); every rank
-encodes its own SxS frame (frames are independent units: no data-path
-collective, scaling = weak); the timed region is bracketed by a barrier +
-torch.cuda.synchronize() and the reported time is the max over ranks.
+One "step" = one full encode of ONE synthetic S x S linear-sRGB frame (default 16384 x 16384,
+BASELINE config #4) that is already resident in HBM as planar f32, ending with the complete
+.jxl codestream bytes in host memory.
 
-Prints ONE JSON line on rank 0 (see the keys at the end of main()).
+N = 1   jxlt_encode_resident_view on one GPU:
+          device   tile_kernel (XYB, adaptive quant, chroma-from-luma, strategy search, quantise),
+                   DC-group tokenisation, group_scan + token_kernel (AC tokens + histograms)
+          host     DC / AC histograms -> prefix codes
+          device   pack_tile_measure (exact section sizes) -> pack_tile_write, copied in ranges to
+                   the page-locked output buffer while the host writes header + TOC in front
+N > 1   the SAME frame, cut into row slabs of whole DC groups (2048 rows), slab r resident on GPU r
+        (BASELINE config #4: "groups sharded by index across the GPUs, host-side assembly").  One
+        process per GPU; the ranks meet in a POSIX shared-memory segment (jxlt_shard_group_*): the
+        2 x 64 x 64 histograms are summed by rank 0, which hands the code tables back; every GPU
+        packs its sections and copies them straight into its byte range of the one output buffer.
+        No RCCL on the data path (torch.distributed/RCCL only for the barrier and the max-reduce
+        of the timing).  scaling = "strong" (the frame is fixed, N grows).
+        --replicas: every rank encodes its own S x S frame instead ("weak").
+
+Launch: for N > 1 either through `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`
+or bare (`python bench.py --gpus N`): without WORLD_SIZE in the environment the script starts that
+launcher itself as a child process, before anything touches a GPU, and relays its output.
+
+PFM file I/O and the H2D upload are outside the timed region of `value`; the PCIe-inclusive rate of the
+metric as written (PFM payload in page-locked host memory -> .jxl bytes) is reported beside it as
+`pfm_inclusive` (N = 1).  Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
-
-import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PCIE_PEAK_GBS = 63.0   # same guide: PCIe Gen5 x16 host link
 ALGO_BYTES_PER_PIXEL = 12.0  # 3 planes x f32, each pixel read once
+CHUNK_ROWS = 1024  # generator granularity: the frame's content does not depend on how it is cut into slabs
 
 
-def make_frame_on_device(torch, size, seed, device):
-    """SURVEY.md 8(d) generator evaluated on the GPU (float64 math, torch RNG for
-    the N(0, 0.02) noise), returned as a [3, size, size] float32 tensor."""
-    gen = torch.Generator(device=device)
-    gen.manual_seed(1234 + seed)
-    out = torch.empty((3, size, size), dtype=torch.float32, device=device)
-    rows = 1024
-    x = torch.arange(size, dtype=torch.float64, device=device)[None, :]
-    for y0 in range(0, size, rows):
-        y1 = min(size, y0 + rows)
-        y = torch.arange(y0, y1, dtype=torch.float64, device=device)[:, None]
-        r = 0.5 + 0.4 * torch.sin(x / 37) * torch.cos(y / 53)
-        g = 0.5 + 0.4 * torch.sin((x + y) / 91)
-        b = 0.3 + 0.3 * torch.cos(x / 19 - y / 29)
-        m = 0.6 + 0.4 * ((torch.floor(x / 48) + torch.floor(y / 80)) % 2)
-        for c, p in enumerate((r, g, b)):
-            v = p * m + torch.randn(p.shape, dtype=torch.float64, device=device, generator=gen) * 0.02
-            out[c, y0:y1] = (v.clamp_(0, 1) ** 2.2).to(torch.float32)
-    return out
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -69,23 +58,63 @@ def main():
     ap.add_argument("--size", type=int, default=16384, help="frame is size x size pixels")
     ap.add_argument("--distance", type=float, default=1.0)
     ap.add_argument("--cpu-sample", type=int, default=8192,
-                    help="edge of the top-left crop the CPU oracle encodes (baseline + parity gate)")
+                    help="edge of the crop of the frame the CPU oracle encodes (cpu_baseline)")
     ap.add_argument("--host-threads", type=int, default=0)
-    ap.add_argument("--shard-frame", action="store_true",
-                    help="N > 1 only: the ranks' frames are the row slabs of ONE frame of size x (size*N) pixels; "
-                         "histograms are all-reduced and the packed sections gathered on rank 0 "
-                         "(libjxl-tiny_amd/sharded.py).  Default: one independent frame per rank.")
+    ap.add_argument("--replicas", action="store_true",
+                    help="N > 1: one independent frame per rank (weak scaling) instead of one frame over all ranks")
+    ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / pfm_inclusive / parity legs")
     ap.add_argument("--frame-batch", type=int, default=0,
                     help="secondary workload (BASELINE config #5, PCIe-inclusive, never the headline value): a step "
-                         "is a batch of this many --frame-size frames in page-locked HOST memory encoded through "
-                         "jxlt_batch_encoder_run (uploads, kernels and downloads of different frames overlap)")
+                         "is a batch of this many --frame-size frames in page-locked HOST memory PER GPU encoded "
+                         "through jxlt_batch_encoder_run (uploads, kernels and downloads of different frames overlap)")
     ap.add_argument("--frame-size", default="3840x2160")
-    ap.add_argument("--lanes", type=int, default=3, help="device contexts of the frame-batch encoder")
+    ap.add_argument("--lanes", type=int, default=3, help="device contexts per GPU of the frame-batch encoder")
     ap.add_argument("--frames-resident", action="store_true",
-                    help="frame-batch workload with the frames already in HBM (no PCIe upload): what the lanes buy "
-                         "for frames too small to fill the GPU")
-    args = ap.parse_args()
+                    help="frame-batch workload with the frames already in HBM (no PCIe upload)")
+    return ap.parse_args()
 
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks as children (nothing in this process has
+    touched a GPU yet, and it never will)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def frame_rows_on_device(torch, size, y0, y1, seed, device):
+    """Rows [y0, y1) of the SURVEY.md 8(d) synthetic frame, evaluated on the GPU (float64 math, N(0, 0.02) noise
+    from a torch generator seeded per 1024-row chunk, so that any row range gives the same samples as the whole
+    frame).  Returns a [3, y1 - y0, size] float32 tensor."""
+    assert y0 % CHUNK_ROWS == 0
+    out = torch.empty((3, y1 - y0, size), dtype=torch.float32, device=device)
+    x = torch.arange(size, dtype=torch.float64, device=device)[None, :]
+    gen = torch.Generator(device=device)
+    for c0 in range(y0, y1, CHUNK_ROWS):
+        c1 = min(y1, c0 + CHUNK_ROWS)
+        gen.manual_seed(1234 + 1000003 * seed + c0 // CHUNK_ROWS)
+        y = torch.arange(c0, c1, dtype=torch.float64, device=device)[:, None]
+        r = 0.5 + 0.4 * torch.sin(x / 37) * torch.cos(y / 53)
+        g = 0.5 + 0.4 * torch.sin((x + y) / 91)
+        b = 0.3 + 0.3 * torch.cos(x / 19 - y / 29)
+        m = 0.6 + 0.4 * ((torch.floor(x / 48) + torch.floor(y / 80)) % 2)
+        for c, p in enumerate((r, g, b)):
+            v = p * m + torch.randn(p.shape, dtype=torch.float64, device=device, generator=gen) * 0.02
+            out[c, c0 - y0:c1 - y0] = (v.clamp_(0, 1) ** 2.2).to(torch.float32)
+    return out
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(relaunch_under_torchrun(args))
+
+    import numpy as np
     import torch
     import __graft_entry__
     pkg = __graft_entry__.load_package()
@@ -94,11 +123,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
-    # (test hook: JXLT_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 with a gloo process group, so
-    # that the N > 1 control flow can be exercised on a single-GPU box; not a measurement mode)
+    # (test hook: JXLT_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 with a gloo process group, so that the
+    # N > 1 control flow can be exercised on a single-GPU box; not a measurement mode)
     one_device = os.environ.get("JXLT_BENCH_ONE_DEVICE") == "1"
     dev_index = 0 if one_device else local_rank
     torch.cuda.set_device(dev_index)
@@ -116,73 +145,81 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(seconds):
+        if dist is None:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if one_device else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     if args.frame_batch > 0:
-        run_frame_batch(args, torch, pkg, dist, barrier, rank, world, dev_index, device, one_device)
+        run_frame_batch(args, np, torch, pkg, dist, barrier, max_over_ranks, rank, world, dev_index, device)
         return
 
-    size = args.size
-    frame = make_frame_on_device(torch, size, rank, device)
+    size, d = args.size, args.distance
+    sharded = world > 1 and not args.replicas
+    if sharded:
+        y0, y1 = pkg.shard_rows(size, world, rank)
+    else:
+        y0, y1 = 0, size
+    seed = rank if (world > 1 and args.replicas) else 0
+    slab = frame_rows_on_device(torch, size, y0, y1, seed, device) if y1 > y0 else None
     torch.cuda.synchronize()
     enc = pkg.Encoder(dev_index)
-    ptrs = [frame[c].data_ptr() for c in range(3)]
-    enc.set_device_image(ptrs, size * 4, size, size, keepalive=frame)
+    if slab is not None:
+        enc.set_device_image([slab[c].data_ptr() for c in range(3)], size * 4, size, y1 - y0, keepalive=slab)
 
-    sharded = comm = None
-    if args.shard_frame and world > 1:
-        import importlib.util
-        spec = importlib.util.spec_from_file_location("jxlt_sharded", str(ROOT / "libjxl-tiny_amd" / "sharded.py"))
-        sharded = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(sharded)
-        comm = sharded.TorchComm(dist, "cpu" if one_device else device)
+    group = None
+    if sharded:
+        # the ranks' meeting point; rank 0 creates it, the others attach after the barrier
+        name = "/jxlt-bench-%s" % os.environ.get("MASTER_PORT", "0")
+        sections = ((size + 2047) // 2048) ** 2 + ((size + 255) // 256) ** 2
+        capacity = max(64 << 20, size * size)  # 1 byte per pixel (the 16384^2 bench frame needs 0.09)
+        if rank == 0:
+            group = pkg.ShardGroup(name, 0, world, capacity, sections + 64)
+        barrier()
+        if rank != 0:
+            group = pkg.ShardGroup(name, rank, world, capacity, sections + 64)
 
     def step():
-        if sharded is not None:
-            out = sharded.encode_sharded(sharded.GpuSlab(enc, args.distance), comm, size, size * world,
-                                         args.distance, pkg)
-            return out if out is not None else b""
+        if group is not None:
+            return group.encode(enc, size, size, d)
         # the codestream is assembled in the context's page-locked host buffer (no extra copy)
-        return enc.encode_resident(args.distance, num_threads=args.host_threads, copy=False)
+        return enc.encode_resident(d, num_threads=args.host_threads, copy=False)
 
     for _ in range(args.warmup):
         jxl = step()
     barrier()
-    # Per-stage device times of the timed steps themselves: HIP events that the C ABI records on
-    # the encoder's own stream around every stage of every encode (read after each step).
+    # Per-stage device times of the timed steps themselves: HIP events that the C ABI records on the encoder's
+    # own stream around every stage of every encode (read after each step).
     ktimes = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         jxl = step()
-        if sharded is None:
+        if slab is not None:
             for k, v in enc.kernel_times().items():
                 ktimes[k] = ktimes.get(k, 0.0) + v / args.steps
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
 
-    # ---- device-only rate (the pipeline without code construction and packing)
-    reps = max(3, args.steps)
-    if not ktimes:  # sharded steps: separate passes
-        for i in range(reps):
-            enc.enqueue(args.distance, 0)
-            enc.synchronize()
-            for k, v in enc.kernel_times().items():
-                ktimes[k] = ktimes.get(k, 0.0) + v / reps
-    t1 = time.perf_counter()
-    for i in range(reps):
-        enc.enqueue(args.distance, 0)
-    enc.synchronize()
-    device_only_s = (time.perf_counter() - t1) / reps
-    fr = enc.fetch_raw()
-    token_bytes = int(fr.group_token_offset[fr.num_groups])
-
+    frames = world if (world > 1 and args.replicas) else 1
     mpix = size * size / 1e6
-    value = world * mpix * args.steps / elapsed
+    value = frames * mpix * args.steps / elapsed
     tile_ms = ktimes.get("tile_kernel", float("nan"))
-    achieved = ALGO_BYTES_PER_PIXEL * size * size / (tile_ms * 1e-3) / 1e9
+    slab_pixels = (y1 - y0) * size
+    achieved = ALGO_BYTES_PER_PIXEL * slab_pixels / (tile_ms * 1e-3) / 1e9 if slab_pixels else float("nan")
 
+    if rank != 0:
+        if dist is not None:
+            if sharded and not args.no_extras:
+                dist.barrier()  # rank 0's single-GPU cross-check of the sharded codestream
+            dist.barrier()
+            dist.destroy_process_group()
+        if group is not None:
+            group.close()
+        return
+
+    jxl_bytes = jxl.tobytes()
     result = {
         "metric": "Mpixels/s encode (PFM->.jxl), frame resident in HBM, codestream bytes in host memory",
         "value": round(value, 2),
@@ -192,115 +229,220 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if sharded else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "%dx%d synthetic linear-sRGB frame per GPU, distance %.2f, full 8x8/16x8/8x16 "
-                               "strategy search + adaptive quant + chroma-from-luma" % (size, size, args.distance),
-                   "groups_per_gpu": int(fr.num_groups), "parallelism": ("one %dx%d frame, row slabs of whole DC groups per rank; histogram all-reduce + "
-                                   "section gather" % (size, size * world)) if sharded is not None else
-                   "one independent frame per rank, no data-path collective",
-                   "codestream_bytes": len(jxl), "raw_token_bytes": token_bytes},
+        "config": {
+            "workload": ("ONE %dx%d synthetic linear-sRGB frame%s, distance %.2f, full 8x8/16x8/8x16 strategy search + "
+                         "adaptive quant + chroma-from-luma" %
+                         (size, size, " sharded over %d GPUs in row slabs of whole DC groups (BASELINE config #4)" % world
+                          if sharded else (" per GPU (independent replicas)" if world > 1 else ""), d)),
+            "parallelism": ("DC-group rows r -> GPU r*N/rows; host-side histogram sum on rank 0 (shared memory), every "
+                            "GPU writes its sections into one output buffer; no RCCL on the data path" if sharded else
+                            "one independent frame per rank, no data-path collective" if world > 1 else "single GPU"),
+            "rows_on_rank0": [y0, y1], "codestream_bytes": len(jxl_bytes),
+            "codestream_sha256": hashlib.sha256(jxl_bytes).hexdigest()[:16]},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(size),
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(size) if world == 1 else None,
                      "kernel": "tile_kernel", "kernel_ms": round(tile_ms, 3),
-                     "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PIXEL * size * size},
+                     "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PIXEL * slab_pixels,
+                     "note": "rank 0's launch (its slab of the frame)" if sharded else "whole frame"},
         "kernel_ms": {k: round(v, 3) for k, v in ktimes.items()},
-        "device_only_mpix_s": round(mpix / device_only_s, 1),
     }
-
-    # ---- supplementary: PCIe-inclusive rate (SURVEY.md 8(d) "end-to-end"): a frame in page-locked HOST memory ->
-    # upload + encode -> codestream bytes in host memory; never the headline value.  8192 x 8192 crop (805 MB).
-    if rank == 0 and size >= 8192:
-        ps = 8192
-        host, owner = pkg.pinned_empty((3, ps, ps))
-        host[...] = frame[:, :ps, :ps].cpu().numpy()
-        enc2 = pkg.Encoder(dev_index)
-        for _ in range(2):
-            enc2.upload(host)
-            enc2.encode_resident(args.distance, num_threads=args.host_threads, copy=False)
-        t3 = time.perf_counter()
-        reps2 = 3
-        for _ in range(reps2):
-            enc2.upload(host)
-            enc2.encode_resident(args.distance, num_threads=args.host_threads, copy=False)
-        pcie_s = (time.perf_counter() - t3) / reps2
-        enc2.close()
-        del host, owner
-        result["pcie_inclusive"] = {"workload": "%dx%d crop in page-locked host memory -> upload + encode -> bytes in host "
-                                                "memory" % (ps, ps), "ms_per_frame": round(pcie_s * 1e3, 2),
-                                    "value": round(ps * ps / pcie_s / 1e6, 1), "unit": "Mpixels/s",
-                                    "h2d_gb_s": round(12.0 * ps * ps / pcie_s / 1e9, 1)}
-
     valu = pmc_valu(size)
-    if valu is not None and tile_ms == tile_ms:
-        # Supplementary: the kernel is VALU-issue bound, not HBM bound.  Instructions per wave
-        # from the committed counter profile, duration measured live; peak = one wave64 VALU instruction per
-        # two cycles and SIMD (MI355X_MICROARCH.md, "Wave scheduling"): 256 CUs x 4 SIMDs x 2.4 GHz / 2.
+    if world == 1 and valu is not None and tile_ms == tile_ms:
+        # Supplementary: the kernel is VALU-issue bound, not HBM bound.  Instructions per wave from the
+        # committed counter profile, duration measured live; peak = one wave64 VALU instruction per 2 cycles and SIMD
+        # (MI355X_MICROARCH.md "Wave scheduling", confirmed by tools/valu_issue_probe.hip -> profiles/): 256 CUs x 4 SIMDs
+        # x 2.4 GHz / 2.
         peak = 256 * 4 * 2.4e9 / 2 / 1e12
         ach = valu["valu_insts_per_wave"] * valu["waves"] / (tile_ms * 1e-3) / 1e12
         result["roofline"]["valu_issue"] = {"achieved": round(ach, 4), "peak": round(peak, 4),
                                             "unit": "T wave64 VALU instructions/s", "frac": round(ach / peak, 4),
                                             "valu_insts_per_wave": valu["valu_insts_per_wave"]}
 
-    if rank == 0:
-        # ---- CPU baseline + parity gate on a bounded, group-aligned crop of the same frame
-        import jxlt_testlib as T
-        s = min(args.cpu_sample, size)
-        s -= s % 256 if s >= 256 else 0
-        crop = np.ascontiguousarray(frame[:, :s, :s].cpu().numpy())
-        t2 = time.perf_counter()
-        want = T.oracle_hot_path(crop, args.distance)
-        cpu_jxl = T.assemble_codestream(want, args.distance, num_threads=1)
-        cpu_s = time.perf_counter() - t2
-        result["cpu_baseline"] = {
-            "value": round(s * s / 1e6 / cpu_s, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-            "sample": "top-left %dx%d crop of the benchmark frame: oracle hot path + host assembly, 1 thread, "
-                      "%.1f s" % (s, s, cpu_s),
-            "cpu": _cpu_model(), "host_cores": os.cpu_count(), "codestream_bytes": len(cpu_jxl)}
-        # the same crop on many cores: 256-row strips are independent units of the hot path (no vertical
-        # context crosses a group row), one oracle call per strip on a thread pool (ctypes drops the GIL)
-        from concurrent.futures import ThreadPoolExecutor
-        strips = [np.ascontiguousarray(crop[:, y:y + 256, :]) for y in range(0, s, 256)]
-        nthr = max(1, min(len(strips), os.cpu_count() or 1))
-        t3 = time.perf_counter()
-        with ThreadPoolExecutor(nthr) as ex:
-            par = list(ex.map(lambda p_: T.oracle_hot_path(p_, args.distance), strips))
-        par_s = time.perf_counter() - t3
-        strips_ok = all(par[i].group_tokens == want.group_tokens[i * (s // 256):(i + 1) * (s // 256)]
-                        for i in range(len(strips))) if s >= 256 else True
-        result["cpu_baseline"]["all_cores"] = {
-            "value": round(s * s / 1e6 / par_s, 1), "unit": "Mpixels/s", "cores": nthr,
-            "sample": "same crop, oracle hot path only (no bitstream assembly), %d strips of 256 rows on %d "
-                      "threads, %.2f s" % (len(strips), nthr, par_s), "strips_equal_whole_crop": bool(strips_ok)}
-        # groups of the crop must equal the same groups of the full-frame GPU encode
-        gpg = (size + 255) // 256
-        offs = np.ctypeslib.as_array(fr.group_token_offset, shape=(fr.num_groups + 1,)).copy()
-        import ctypes as C
-        bad = 0
-        for gy in range(s // 256):
-            for gx in range(s // 256):
-                g = gy * gpg + gx
-                got = C.string_at(C.addressof(fr.tokens.contents) + int(offs[g]), int(offs[g + 1] - offs[g]))
-                bad += got != want.group_tokens[gy * (s // 256) + gx]
-        result["parity_gate"] = {"groups_checked": (s // 256) ** 2, "groups_mismatching": int(bad)}
-        print(json.dumps(result), flush=True)
-        if bad:
-            raise SystemExit("parity gate failed: %d groups differ from the oracle" % bad)
+    if not args.no_extras:
+        if sharded:
+            # the sharded codestream must be the single-GPU codestream of the same frame, byte for byte
+            full = frame_rows_on_device(torch, size, 0, size, 0, device)
+            enc1 = pkg.Encoder(dev_index)
+            enc1.set_device_image([full[c].data_ptr() for c in range(3)], size * 4, size, size, keepalive=full)
+            single = enc1.encode_resident(d, copy=False).tobytes()
+            result["parity_gate"] = {"sharded_equals_single_gpu_codestream": single == jxl_bytes,
+                                     "single_gpu_sha256": hashlib.sha256(single).hexdigest()[:16]}
+            enc1.close()
+            del full
+            if dist is not None:
+                dist.barrier()
+        else:
+            extras_single_gpu(args, np, torch, pkg, enc, slab, dev_index, device, result)
+    print(json.dumps(result), flush=True)
+    gate = result.get("parity_gate", {})
+    if gate.get("groups_mismatching", 0) or gate.get("sharded_equals_single_gpu_codestream") is False:
+        raise SystemExit("parity gate failed: %s" % json.dumps(gate))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if group is not None:
+        group.close()
 
 
-def run_frame_batch(args, torch, pkg, dist, barrier, rank, world, dev_index, device, one_device):
-    """Secondary workload: batches of frames from page-locked host memory (PCIe-inclusive)."""
+def extras_single_gpu(args, np, torch, pkg, enc, frame, dev_index, device, result):
+    """N = 1 legs outside the timed region: device-only rate, parity gate over the whole frame, CPU baseline,
+    and the metric as written (PFM payload in page-locked host memory -> .jxl bytes)."""
+    import ctypes as C
+    import jxlt_testlib as T
+    size, d = args.size, args.distance
+    mpix = size * size / 1e6
+
+    # ---- device-only rate (the pipeline without code construction and packing)
+    reps = max(3, args.steps)
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        enc.enqueue(d, 0)
+    enc.synchronize()
+    result["device_only_mpix_s"] = round(mpix / ((time.perf_counter() - t1) / reps), 1)
+    fr = enc.fetch_raw()
+    result["config"]["raw_token_bytes"] = int(fr.group_token_offset[fr.num_groups])
+
+    # ---- parity gate: groups sampled over the WHOLE frame (corners, last row / column, an interior lattice)
+    # against the oracle run on the matching 256 x 256 crops (an AC group depends on nothing outside itself,
+    # SURVEY.md F9): token bytes, quantised DC, quant field, strategies, chroma-from-luma factors
+    gpg = (size + 255) // 256
+    lattice = sorted(set([0, gpg - 1] + [int(round(i * (gpg - 1) / 7.0)) for i in range(8)]))
+    picks = sorted(set((gy, gx) for gy in lattice for gx in lattice))
+    offs = np.ctypeslib.as_array(fr.group_token_offset, shape=(fr.num_groups + 1,)).copy()
+    xb = fr.xsize_blocks
+
+    def grid(ptr, dtype, pitch, rows):
+        return np.ctypeslib.as_array(ptr, shape=(rows * pitch,)).view(dtype).reshape(rows, pitch)
+
+    qdc = [grid(fr.quant_dc[c], np.int16, xb, fr.ysize_blocks) for c in range(3)]
+    rq = grid(fr.raw_quant_field, np.uint8, xb, fr.ysize_blocks)
+    st = grid(fr.ac_strategy, np.uint8, xb, fr.ysize_blocks)
+    ytox = grid(fr.ytox_map, np.int8, fr.xsize_tiles, fr.ysize_tiles)
+    ytob = grid(fr.ytob_map, np.int8, fr.xsize_tiles, fr.ysize_tiles)
+    bad = 0
+    t2 = time.perf_counter()
+    for gy, gx in picks:
+        crop = np.ascontiguousarray(frame[:, gy * 256:(gy + 1) * 256, gx * 256:(gx + 1) * 256].cpu().numpy())
+        want = T.oracle_hot_path(crop, d)
+        g = gy * gpg + gx
+        got = C.string_at(C.addressof(fr.tokens.contents) + int(offs[g]), int(offs[g + 1] - offs[g]))
+        hb, wb = want.raw_quant.shape
+        by, bx = gy * 32, gx * 32
+        ok = (got == want.group_tokens[0] and
+              all(np.array_equal(qdc[c][by:by + hb, bx:bx + wb], want.quant_dc[c]) for c in range(3)) and
+              np.array_equal(rq[by:by + hb, bx:bx + wb], want.raw_quant) and
+              np.array_equal(st[by:by + hb, bx:bx + wb], want.strategy) and
+              np.array_equal(ytox[gy * 4:gy * 4 + want.ytox.shape[0], gx * 4:gx * 4 + want.ytox.shape[1]], want.ytox) and
+              np.array_equal(ytob[gy * 4:gy * 4 + want.ytob.shape[0], gx * 4:gx * 4 + want.ytob.shape[1]], want.ytob))
+        bad += not ok
+    result["parity_gate"] = {"groups_checked": len(picks), "groups_mismatching": int(bad),
+                             "sample": "%d groups on an %dx%d lattice over the whole frame incl. corners and last "
+                                       "row/column; tokens + side-band grids vs the oracle on the same crops, %.1f s"
+                                       % (len(picks), len(lattice), len(lattice), time.perf_counter() - t2)}
+
+    # ---- CPU baseline on a bounded, group-aligned crop of the same frame (centre of the frame)
+    s = min(args.cpu_sample, size)
+    s -= s % 256 if s >= 256 else 0
+    o = ((size - s) // 2) // 256 * 256
+    crop = np.ascontiguousarray(frame[:, o:o + s, o:o + s].cpu().numpy())
+    t3 = time.perf_counter()
+    want = T.oracle_hot_path(crop, d)
+    cpu_jxl = T.oracle_codestream(want, d)
+    cpu_s = time.perf_counter() - t3
+    result["cpu_baseline"] = {
+        "value": round(s * s / 1e6 / cpu_s, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+        "sample": "centre %dx%d crop of the benchmark frame: oracle pixel pipeline + oracle bitstream stage "
+                  "(the reference's own structure: one thread), %.1f s" % (s, s, cpu_s),
+        "cpu": _cpu_model(), "host_cores": os.cpu_count(), "codestream_bytes": len(cpu_jxl)}
+    # the same crop with the reference's independent units -- the 256 x 256 groups -- spread over ALL host cores;
+    # the bitstream stage stays serial like the reference's OptimizeSections.  Same work, same bytes.
+    from concurrent.futures import ThreadPoolExecutor
+    ng = s // 256
+    if ng >= 2:
+        nthr = max(1, min(ng * ng, os.cpu_count() or 1))
+        tiles = [(gy, gx) for gy in range(ng) for gx in range(ng)]
+        t4 = time.perf_counter()
+        with ThreadPoolExecutor(nthr) as ex:
+            parts = list(ex.map(lambda t: T.oracle_hot_path(
+                np.ascontiguousarray(crop[:, t[0] * 256:(t[0] + 1) * 256, t[1] * 256:(t[1] + 1) * 256]), d), tiles))
+        merged = T.HotPathResult()
+        merged.xsize = merged.ysize = s
+        merged.quant_dc = np.zeros((3, s // 8, s // 8), np.int16)
+        merged.raw_quant = np.zeros((s // 8, s // 8), np.uint8)
+        merged.strategy = np.zeros((s // 8, s // 8), np.uint8)
+        merged.ytox = np.zeros((s // 64, s // 64), np.int8)
+        merged.ytob = np.zeros((s // 64, s // 64), np.int8)
+        merged.group_tokens = []
+        for (gy, gx), p in zip(tiles, parts):
+            merged.quant_dc[:, gy * 32:gy * 32 + 32, gx * 32:gx * 32 + 32] = p.quant_dc
+            merged.raw_quant[gy * 32:gy * 32 + 32, gx * 32:gx * 32 + 32] = p.raw_quant
+            merged.strategy[gy * 32:gy * 32 + 32, gx * 32:gx * 32 + 32] = p.strategy
+            merged.ytox[gy * 4:gy * 4 + 4, gx * 4:gx * 4 + 4] = p.ytox
+            merged.ytob[gy * 4:gy * 4 + 4, gx * 4:gx * 4 + 4] = p.ytob
+            merged.group_tokens.append(p.group_tokens[0])
+        par_jxl = T.oracle_codestream(merged, d)
+        par_s = time.perf_counter() - t4
+        result["cpu_baseline"]["all_cores"] = {
+            "value": round(s * s / 1e6 / par_s, 1), "unit": "Mpixels/s", "cores": nthr,
+            "sample": "same crop and same work: %d groups over %d threads + the serial bitstream stage, %.2f s"
+                      % (ng * ng, nthr, par_s), "same_bytes_as_one_thread": par_jxl == cpu_jxl}
+        # the GPU's codestream of that crop must be those bytes too
+        gpu_crop = pkg.encode_file(crop, d, device=dev_index)
+        result["parity_gate"]["crop_codestream_equals_oracle"] = gpu_crop == cpu_jxl
+        if gpu_crop != cpu_jxl:
+            result["parity_gate"]["groups_mismatching"] += 1
+
+    # ---- the metric as written: PFM payload (interleaved, bottom-up f32) in page-locked HOST memory -> .jxl bytes;
+    # the upload is part of the encode, pipelined in DC-group rows under tile_kernel (jxlt_image_attach_host_pfm)
+    try:
+        payload, owner = pkg.pinned_empty((size * size * 3,), np.float32)
+    except pkg.JxlTinyError:
+        payload = None
+    if payload is not None:
+        rows = 2048
+        view = payload.reshape(size, size, 3)
+        for r0 in range(0, size, rows):  # bottom-up: image row y is payload row size - 1 - y
+            blk = frame[:, r0:r0 + rows].permute(1, 2, 0).flip(0).contiguous().cpu().numpy()
+            view[size - r0 - blk.shape[0]:size - r0] = blk
+        enc2 = pkg.Encoder(dev_index)
+        for _ in range(2):
+            enc2.attach_host_pfm(payload, size, size)
+            pfm_jxl = enc2.encode_resident(d, num_threads=args.host_threads, copy=False)
+        reps2 = 3
+        t5 = time.perf_counter()
+        for _ in range(reps2):
+            enc2.attach_host_pfm(payload, size, size)
+            pfm_jxl = enc2.encode_resident(d, num_threads=args.host_threads, copy=False)
+        pfm_s = (time.perf_counter() - t5) / reps2
+        same = hashlib.sha256(pfm_jxl.tobytes()).hexdigest()[:16] == result["config"]["codestream_sha256"]
+        enc2.close()
+        del view, payload, owner
+        bound = PCIE_PEAK_GBS / ALGO_BYTES_PER_PIXEL * 1e3
+        result["pfm_inclusive"] = {
+            "workload": "%dx%d PFM payload in page-locked host memory -> row-wise upload under the kernels -> .jxl "
+                        "bytes in host memory" % (size, size),
+            "ms_per_frame": round(pfm_s * 1e3, 2), "value": round(mpix / pfm_s, 1), "unit": "Mpixels/s",
+            "h2d_gb_s": round(ALGO_BYTES_PER_PIXEL * size * size / pfm_s / 1e9, 1),
+            "pcie_bound_mpix_s": round(bound, 1), "frac_of_pcie_bound": round(mpix / pfm_s / bound, 3),
+            "same_bytes_as_resident_encode": bool(same)}
+        if not same:
+            result["parity_gate"]["groups_mismatching"] += 1
+
+
+def run_frame_batch(args, np, torch, pkg, dist, barrier, max_over_ranks, rank, world, dev_index, device):
+    """Secondary workload (BASELINE config #5): batches of frames from page-locked host memory (PCIe-inclusive),
+    `--frame-batch` frames per GPU and step; one batch encoder (several lanes) per rank / GPU."""
+    import jxlt_testlib as T
     w, h = (int(v) for v in args.frame_size.lower().split("x"))
     distinct = min(args.frame_batch, 8)
-    side = max(w, h)
     frames, owners = [], []
+    hh = (h + CHUNK_ROWS - 1) // CHUNK_ROWS * CHUNK_ROWS
     for i in range(distinct):
-        full = make_frame_on_device(torch, side, 100 * rank + i, device)
+        full = frame_rows_on_device(torch, max(w, 16), 0, hh, 100 * rank + i + 1, device)
         if args.frames_resident:
             frames.append(full[:, :h, :w].contiguous())
         else:
@@ -320,11 +462,7 @@ def run_frame_batch(args, torch, pkg, dist, barrier, rank, world, dev_index, dev
     for _ in range(args.steps):
         total_bytes = enc.run_described(descs, n, args.distance, take=False)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     mpix = n * w * h / 1e6
     h2d_gbs = world * 12.0 * n * w * h * args.steps / elapsed / 1e9
     result = {
@@ -333,17 +471,16 @@ def run_frame_batch(args, torch, pkg, dist, barrier, rank, world, dev_index, dev
         "value": round(world * mpix * args.steps / elapsed, 2), "unit": "Mpixels/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "batch of %d frames %dx%d per GPU per step (%d distinct), distance %.2f, %d lanes"
+        "config": {"workload": "batch of %d frames %dx%d per GPU per step (%d distinct), distance %.2f, %d lanes per GPU"
                                % (n, w, h, distinct, args.distance, args.lanes),
                    "frames_per_s": round(world * n * args.steps / elapsed, 1),
-                   "parallelism": "independent frames, round-robin over lanes and ranks, no collective",
+                   "parallelism": "independent frames, one frame queue per GPU, no collective",
                    "codestream_bytes_per_batch": int(total_bytes)},
-        "roofline": {"bound": "pcie", "achieved": round(h2d_gbs / world, 2), "peak": 63.0, "unit": "GB/s",
-                     "frac": round(h2d_gbs / world / 63.0, 4), "traffic": None,
+        "roofline": {"bound": "pcie", "achieved": round(h2d_gbs / world, 2), "peak": PCIE_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(h2d_gbs / world / PCIE_PEAK_GBS, 4), "traffic": None,
                      "note": "host->device bytes of the frames (12 B/pixel) per GPU; peak = PCIe 5.0 x16 payload rate"},
     }
     if rank == 0:
-        import jxlt_testlib as T
         f0 = frames[0].cpu().numpy() if args.frames_resident else frames[0]
         want = T.assemble_codestream(T.oracle_hot_path(np.ascontiguousarray(f0), args.distance), args.distance)
         result["parity_gate"] = {"frames_checked": 1, "frames_mismatching": int(first[0] != want)}

@@ -99,6 +99,11 @@ int jxlt_image_upload(jxlt_context* ctx, const float* const planes[3], size_t pi
  * ordinary memory).  Free with jxlt_pinned_free. */
 void* jxlt_pinned_alloc(size_t bytes);
 void jxlt_pinned_free(void* p);
+/* Page-locks memory the caller already owns (e.g. a shared-memory mapping that several processes assemble
+ * one codestream in) so that the devices can copy from / to it directly.  Undo with jxlt_pinned_unregister
+ * before the memory goes away. */
+int jxlt_pinned_register(void* p, size_t bytes);
+void jxlt_pinned_unregister(void* p);
 
 /* Borrows planes already resident in HBM (e.g. a torch tensor's data_ptr). */
 int jxlt_image_set_device(jxlt_context* ctx, const void* const device_planes[3],
@@ -114,6 +119,19 @@ int jxlt_image_upload_pfm(jxlt_context* ctx, const void* host_payload, size_t xs
                           int big_endian);
 int jxlt_image_set_device_pfm(jxlt_context* ctx, const void* device_payload, size_t xsize, size_t ysize,
                               int big_endian);
+
+/* Upload pipelined under the kernels.  The frame stays in the caller's PAGE-LOCKED memory (jxlt_pinned_alloc /
+ * jxlt_pinned_register; anything else is refused) until the next jxlt_encode_enqueue on the context, which
+ * fetches it in rows of DC groups (2048 pixel rows) and starts tile_kernel on each row as soon as that row
+ * has arrived: all kernels but the last row's run under the PCIe transfer.  Planar planes (row pitch
+ * pitch_bytes) or the raw payload of a PFM file (see jxlt_image_upload_pfm).  The memory must stay valid and
+ * unchanged until that encode has been synchronised (any jxlt_fetch_* / jxlt_synchronize / jxlt_encode_resident*).
+ * Replaces, like jxlt_image_upload, the host reads of CopyAndPadImage (enc_frame.cc:597-617) and of
+ * ReadPFM's sample loop (read_pfm.cc:196-213). */
+int jxlt_image_attach_host(jxlt_context* ctx, const float* const planes[3], size_t pitch_bytes, size_t xsize,
+                           size_t ysize);
+int jxlt_image_attach_host_pfm(jxlt_context* ctx, const void* host_payload, size_t xsize, size_t ysize,
+                               int big_endian);
 
 /* Size of the image currently set on the context. */
 int jxlt_image_size(const jxlt_context* ctx, size_t* xsize, size_t* ysize);
@@ -262,10 +280,17 @@ typedef struct {
   size_t xsize, ysize;
   int in_device_memory;    /* non-zero: planes / pfm_payload point into device memory of the encoder's GPU and
                               are read in place (jxlt_image_set_device*); they must stay valid during the run */
+  int device_ordinal;      /* in_device_memory frames of a multi-device encoder: the GPU that holds them */
 } jxlt_batch_frame;
 typedef struct jxlt_batch_encoder jxlt_batch_encoder;
 /* lanes <= 0: 3 (upload / encode / download in flight at once). */
 int jxlt_batch_encoder_create(int device_ordinal, int lanes, jxlt_batch_encoder** out);
+/* The same over several GPUs (BASELINE config #5: frames round-robin over 8 GPUs): lanes_per_device contexts
+ * on every listed device, all fed from one frame queue.  Frames in host memory go to whichever lane is free
+ * (page-locked memory from jxlt_pinned_alloc is visible to every device); a frame with in_device_memory set
+ * is taken by a lane of the device named in its device_ordinal field. */
+int jxlt_batch_encoder_create_multi(const int* device_ordinals, int num_devices, int lanes_per_device,
+                                    jxlt_batch_encoder** out);
 void jxlt_batch_encoder_destroy(jxlt_batch_encoder* enc);
 /* Encodes frames[0..num_frames) at `distance`.  out_bytes[i] (malloc'ed, free with jxlt_free) and
  * out_sizes[i] receive the codestream of frame i.  Returns the first failing frame's error; the
@@ -286,17 +311,81 @@ void jxlt_emulate_reference_static_constants(int on);
 void jxlt_emulate_reference_single_symbol_codes(int on);
 /* Codestream + image headers that precede the frame (enc_file.cc:70-95). */
 int jxlt_write_file_header(size_t xsize, size_t ysize, uint8_t** out_bytes, size_t* out_size);
-/* ---- one frame sharded over several contexts / GPUs / processes ----------------
- * Row slabs whose height is a multiple of 2048 (whole DC groups) are encoded
- * independently (jxlt_image_* + jxlt_encode_enqueue + jxlt_fetch_histograms per slab).
- * The only cross-slab dependency is the pair of global prefix codes: sum the
- * histograms of all slabs (e.g. torch.distributed.all_reduce), call
- * jxlt_build_code_tables on every slab, pack (jxlt_pack_sections), gather the packed
- * sections in slab order and let one process call jxlt_finish_frame. */
+/* ---- one frame sharded over several GPUs (BASELINE config #4) -----------------
+ * The reference's unit of independent work is the DC group (the loop enc_frame.cc:839-844); its one global
+ * synchronisation point is the code optimisation over all sections (enc_frame.cc:846-850).  Here a frame is
+ * cut into row slabs of whole DC groups (2048 rows; jxlt_shard_rows), one per participant; every participant
+ * runs the complete device pipeline on its slab with its own device context.  The only exchange is on the
+ * host: the 2 x 64 x 64 symbol histograms are summed by participant 0, which builds the two prefix codes and
+ * hands the code tables back; every participant then entropy-codes its sections on its GPU and copies them
+ * straight into its byte range of ONE output buffer, where participant 0 writes frame header, TOC and the
+ * global sections in front.  No device-to-device traffic, no RCCL.
+ *
+ * Participants are host threads of one process (jxlt_multi_encoder_*, also behind jxl::EncodeFile when
+ * jxl::SetEncoderDevices / JXLT_DEVICES names several GPUs) or one process per GPU that meet in a POSIX
+ * shared-memory segment (jxlt_shard_group_*: what bench.py's ranks use). */
+
+/* Rows [*y0, *y1) of participant `rank` of `world` for a frame of ysize rows: whole DC-group rows, balanced,
+ * in order (an empty range when there are fewer DC-group rows than participants). */
+int jxlt_shard_rows(size_t ysize, int world, int rank, size_t* y0, size_t* y1);
+
+typedef struct jxlt_multi_encoder jxlt_multi_encoder;
+/* One device context + one host thread per entry of device_ordinals (an ordinal may repeat: several
+ * contexts on one GPU). */
+int jxlt_multi_encoder_create(const int* device_ordinals, int num_devices, jxlt_multi_encoder** out);
+void jxlt_multi_encoder_destroy(jxlt_multi_encoder* enc);
+const char* jxlt_multi_encoder_last_error(const jxlt_multi_encoder* enc);
+/* EncodeFile (enc_file.h:20-21) over all devices: every device uploads its slab of the caller's planes
+ * (planar f32, row pitch pitch_bytes; page-locked memory from jxlt_pinned_alloc goes over each GPU's own
+ * PCIe link at full speed) and encodes it.  *bytes: the complete codestream, owned by the encoder, valid
+ * until its next encode.  Same bytes as jxlt_encode_file_planar. */
+int jxlt_multi_encoder_encode(jxlt_multi_encoder* enc, const float* const planes[3], size_t pitch_bytes,
+                              size_t xsize, size_t ysize, float distance, const uint8_t** bytes, size_t* size);
+/* The same for the raw sample payload of a PFM file (jxlt_image_upload_pfm). */
+int jxlt_multi_encoder_encode_pfm(jxlt_multi_encoder* enc, const void* host_payload, size_t xsize, size_t ysize,
+                                  int big_endian, float distance, const uint8_t** bytes, size_t* size);
+/* A frame that already is in the devices' HBM: slab `slab` (rows jxlt_shard_rows(ysize, num_devices, slab))
+ * as three planes in the memory of that slab's device; then encode.  The planes are read in place. */
+int jxlt_multi_encoder_set_device_slab(jxlt_multi_encoder* enc, int slab, const void* const device_planes[3],
+                                       size_t pitch_bytes, size_t xsize, size_t rows);
+int jxlt_multi_encoder_encode_resident(jxlt_multi_encoder* enc, size_t xsize, size_t ysize, float distance,
+                                       const uint8_t** bytes, size_t* size);
+
+/* One process per GPU.  Rank 0 creates the segment `shm_name` ("/name"; control block, section-size tables
+ * for up to max_sections sections, output_capacity bytes for the codestream), the others attach to it AFTER
+ * rank 0's call has returned (callers barrier in between).  Closing detaches; rank 0 also unlinks. */
+typedef struct jxlt_shard_group jxlt_shard_group;
+int jxlt_shard_group_open(const char* shm_name, int rank, int world, size_t output_capacity, size_t max_sections,
+                          jxlt_shard_group** out);
+void jxlt_shard_group_close(jxlt_shard_group* group);
+const char* jxlt_shard_group_last_error(const jxlt_shard_group* group);
+/* Collective over the group's ranks: `ctx` holds this rank's slab of an xsize x ysize frame (rows
+ * jxlt_shard_rows(ysize, world, rank); jxlt_image_upload* / jxlt_image_set_device* with that many rows; ranks
+ * with an empty range pass any context).  On rank 0 *bytes / *size receive the complete codestream (inside
+ * the segment, valid until the next encode); NULL / 0 on the other ranks. */
+int jxlt_shard_encode(jxlt_shard_group* group, jxlt_context* ctx, size_t xsize, size_t ysize, float distance,
+                      const uint8_t** bytes, size_t* size);
+/* The same protocol over caller-supplied slab operations instead of a device context (what jxlt_shard_encode
+ * binds to the jxlt_* calls named on the right); lets the CPU test-suite run the protocol without a GPU.
+ * Every callback returns JXLT_OK or an error; `write` may be asynchronous, `finish` completes it. */
+typedef struct {
+  void* self;
+  int (*enqueue)(void* self, const jxlt_params* params);                     /* jxlt_encode_enqueue */
+  int (*dc_histogram)(void* self, const uint32_t** histogram);               /* jxlt_fetch_dc_histogram */
+  int (*begin_dc_pack)(void* self, const uint32_t* dc_code_table);           /* jxlt_pack_measure_begin(0) */
+  int (*ac_histogram)(void* self, const uint32_t** histogram);               /* jxlt_fetch_histograms */
+  int (*measure)(void* self, const uint32_t* ac_code_table, jxlt_packed_sections* dc,
+                 jxlt_packed_sections* ac);                                  /* jxlt_pack_measure */
+  int (*write)(void* self, uint8_t* dc_dst, uint8_t* ac_dst);                /* jxlt_pack_write */
+  int (*finish)(void* self);                                                 /* jxlt_synchronize */
+} jxlt_slab_ops;
+int jxlt_shard_encode_ops(jxlt_shard_group* group, const jxlt_slab_ops* ops, size_t xsize, size_t ysize,
+                          float distance, const uint8_t** bytes, size_t* size);
+
+/* Building blocks of the above (also usable on their own): code tables from summed histograms, and the
+ * complete codestream from summed histograms + all packed sections in raster order. */
 int jxlt_build_code_tables(const uint32_t* ac_histograms, const uint32_t* dc_histograms,
                            uint32_t* ac_code_table, uint32_t* dc_code_table);
-/* Complete codestream (file header + frame) of an xsize x ysize frame from the summed
- * histograms and the DC-group / AC-group sections of the whole frame in raster order. */
 int jxlt_finish_frame(size_t xsize, size_t ysize, float distance, const uint32_t* ac_histograms,
                       const uint32_t* dc_histograms, const jxlt_packed_sections* dc_sections,
                       const jxlt_packed_sections* ac_sections, uint8_t** out_bytes, size_t* out_size);

@@ -29,16 +29,21 @@ FLAG_FORCE_DCT8, FLAG_DEBUG_DUMP, FLAG_PROFILE = 1, 2, 4
 
 # Symbols include/jxl_tiny_amd.h declares, per library (checked by the tests).
 HIP_SYMBOLS = ["jxlt_context_create", "jxlt_context_destroy", "jxlt_last_error",
-               "jxlt_image_upload", "jxlt_image_set_device", "jxlt_image_upload_pfm", "jxlt_image_set_device_pfm", "jxlt_image_size", "jxlt_pinned_alloc",
-               "jxlt_pinned_free", "jxlt_encode_enqueue", "jxlt_set_strategy_distance",
+               "jxlt_image_upload", "jxlt_image_set_device", "jxlt_image_upload_pfm", "jxlt_image_set_device_pfm", "jxlt_image_attach_host", "jxlt_image_attach_host_pfm", "jxlt_image_size", "jxlt_pinned_alloc",
+               "jxlt_pinned_free", "jxlt_pinned_register", "jxlt_pinned_unregister", "jxlt_encode_enqueue", "jxlt_set_strategy_distance",
                "jxlt_fetch_side_info", "jxlt_fetch_histograms", "jxlt_fetch_dc_histogram", "jxlt_pack_ac_sections", "jxlt_pack_sections",
                "jxlt_pack_sections_sizes", "jxlt_pack_sections_copy", "jxlt_pack_sections_place", "jxlt_pack_measure", "jxlt_pack_measure_begin", "jxlt_pack_write",
                "jxlt_output_buffer",
                "jxlt_synchronize", "jxlt_fetch_result", "jxlt_kernel_times", "jxlt_debug_fetch"]
 HOST_SYMBOLS = ["jxlt_compute_distance_params", "jxlt_assemble_frame", "jxlt_assemble_frame_groups",
                 "jxlt_encode_file_planar", "jxlt_encode_pfm_file", "jxlt_emulate_reference_static_constants", "jxlt_emulate_reference_single_symbol_codes", "jxlt_encode_resident", "jxlt_encode_resident_view", "jxlt_write_file_header", "jxlt_build_code_tables", "jxlt_finish_frame",
-                "jxlt_debug_dc_records", "jxlt_free", "jxlt_batch_encoder_create", "jxlt_batch_encoder_destroy",
-                "jxlt_batch_encoder_run"]
+                "jxlt_debug_dc_records", "jxlt_free", "jxlt_batch_encoder_create", "jxlt_batch_encoder_create_multi",
+                "jxlt_batch_encoder_destroy", "jxlt_batch_encoder_run",
+                "jxlt_shard_rows", "jxlt_multi_encoder_create", "jxlt_multi_encoder_destroy",
+                "jxlt_multi_encoder_last_error", "jxlt_multi_encoder_encode", "jxlt_multi_encoder_encode_pfm",
+                "jxlt_multi_encoder_set_device_slab", "jxlt_multi_encoder_encode_resident",
+                "jxlt_shard_group_open", "jxlt_shard_group_close", "jxlt_shard_group_last_error",
+                "jxlt_shard_encode", "jxlt_shard_encode_ops"]
 
 
 class JxlTinyError(RuntimeError):
@@ -259,6 +264,23 @@ class Encoder:
         ptrs = (fp * 3)(*[planes[c].ctypes.data_as(fp) for c in range(3)])
         self._check(self._L.jxlt_image_upload(self._ctx, ptrs, w * 4, w, h), "jxlt_image_upload")
 
+    def attach_host(self, planes):
+        """planes: float32 [3, h, w] in page-locked memory (pinned_empty): stays there until the next encode,
+        whose kernels run under the row-wise upload (jxlt_image_attach_host)."""
+        assert planes.dtype == np.float32 and planes.ndim == 3 and planes.shape[0] == 3 and planes.strides[2] == 4
+        _, h, w = planes.shape
+        ptrs = (fp * 3)(*[planes[c].ctypes.data_as(fp) for c in range(3)])
+        self._L.jxlt_image_attach_host.argtypes = [C.c_void_p, C.POINTER(fp), C.c_size_t, C.c_size_t, C.c_size_t]
+        self._check(self._L.jxlt_image_attach_host(self._ctx, ptrs, planes.strides[1], w, h), "jxlt_image_attach_host")
+        self._keepalive = planes
+
+    def attach_host_pfm(self, payload, w, h, big_endian=False):
+        """payload: numpy array over the raw PFM sample payload in page-locked memory (jxlt_image_attach_host_pfm)."""
+        self._L.jxlt_image_attach_host_pfm.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+        self._check(self._L.jxlt_image_attach_host_pfm(self._ctx, payload.ctypes.data, w, h, 1 if big_endian else 0),
+                    "jxlt_image_attach_host_pfm")
+        self._keepalive = payload
+
     def set_device_image(self, ptrs, pitch_bytes, w, h, keepalive=None):
         """ptrs: three device addresses (ints), e.g. torch tensor data_ptr()."""
         arr = (C.c_void_p * 3)(*ptrs)
@@ -442,7 +464,7 @@ def encode_file(planes, distance, device=0):
 class BatchFrame(C.Structure):
     _fields_ = [("planes", fp * 3), ("pitch_bytes", C.c_size_t), ("pfm_payload", C.c_void_p),
                 ("pfm_big_endian", C.c_int), ("xsize", C.c_size_t), ("ysize", C.c_size_t),
-                ("in_device_memory", C.c_int)]
+                ("in_device_memory", C.c_int), ("device_ordinal", C.c_int)]
 
 
 def pinned_empty(shape, dtype=np.float32):
@@ -468,16 +490,23 @@ class BatchEncoder:
     """jxlt_batch_encoder_*: a batch of independent frames on one GPU through several device contexts
     (uploads, kernels and downloads of different frames overlap).  BASELINE config #5."""
 
-    def __init__(self, device=0, lanes=3):
+    def __init__(self, device=0, lanes=3, devices=None):
+        """devices: list of GPU ordinals for a multi-device encoder (`lanes` contexts on each, one frame queue:
+        jxlt_batch_encoder_create_multi); default: `lanes` contexts on `device`."""
         self._L = host_lib()
         L = self._L
         L.jxlt_batch_encoder_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.jxlt_batch_encoder_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.jxlt_batch_encoder_destroy.argtypes = [C.c_void_p]
         L.jxlt_batch_encoder_destroy.restype = None
         L.jxlt_batch_encoder_run.argtypes = [C.c_void_p, C.POINTER(BatchFrame), C.c_size_t, C.c_float,
                                              C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         self._enc = C.c_void_p()
-        rc = L.jxlt_batch_encoder_create(device, lanes, C.byref(self._enc))
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            rc = L.jxlt_batch_encoder_create_multi(arr, len(devices), lanes, C.byref(self._enc))
+        else:
+            rc = L.jxlt_batch_encoder_create(device, lanes, C.byref(self._enc))
         if rc != 0:
             raise JxlTinyError("jxlt_batch_encoder_create failed (%d): %s" %
                                (rc, hip_lib().jxlt_last_error(None).decode()))
@@ -507,6 +536,7 @@ class BatchEncoder:
                 d.pitch_bytes = f.stride(1) * 4
                 d.xsize, d.ysize = f.shape[2], f.shape[1]
                 d.in_device_memory = 1
+                d.device_ordinal = f.device.index or 0
                 continue
             if isinstance(f, tuple):
                 payload, w, h, big = f
@@ -549,3 +579,157 @@ class BatchEncoder:
         out = self.run_described(descs, len(frames), distance)
         del keep
         return out
+
+
+# --------------------------------------------------------------------------- one frame over several GPUs
+def shard_rows(ysize, world, rank):
+    """(y0, y1): rows of participant `rank` of `world` (whole DC-group rows; jxlt_shard_rows)."""
+    L = host_lib()
+    L.jxlt_shard_rows.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    y0, y1 = C.c_size_t(), C.c_size_t()
+    if L.jxlt_shard_rows(ysize, world, rank, C.byref(y0), C.byref(y1)) != 0:
+        raise JxlTinyError("jxlt_shard_rows: invalid arguments")
+    return y0.value, y1.value
+
+
+class MultiEncoder:
+    """jxlt_multi_encoder_*: ONE frame over several GPUs of this process (one device context and host thread
+    per entry of `devices`; an ordinal may repeat).  BASELINE config #4."""
+
+    def __init__(self, devices):
+        self._L = host_lib()
+        L = self._L
+        L.jxlt_multi_encoder_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+        L.jxlt_multi_encoder_destroy.argtypes = [C.c_void_p]
+        L.jxlt_multi_encoder_destroy.restype = None
+        L.jxlt_multi_encoder_last_error.argtypes = [C.c_void_p]
+        L.jxlt_multi_encoder_last_error.restype = C.c_char_p
+        L.jxlt_multi_encoder_encode.argtypes = [C.c_void_p, C.POINTER(fp), C.c_size_t, C.c_size_t, C.c_size_t, C.c_float,
+                                                C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        L.jxlt_multi_encoder_encode_pfm.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_float,
+                                                    C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        L.jxlt_multi_encoder_set_device_slab.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_size_t,
+                                                         C.c_size_t, C.c_size_t]
+        L.jxlt_multi_encoder_encode_resident.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_float,
+                                                         C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        self.devices = list(devices)
+        self._enc = C.c_void_p()
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        rc = L.jxlt_multi_encoder_create(arr, len(self.devices), C.byref(self._enc))
+        if rc != 0:
+            raise JxlTinyError("jxlt_multi_encoder_create failed (%d): %s" % (rc, hip_lib().jxlt_last_error(None).decode()))
+        self._keep = {}
+
+    def close(self):
+        if self._enc:
+            self._L.jxlt_multi_encoder_destroy(self._enc)
+            self._enc = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise JxlTinyError("%s failed (%d): %s" % (what, rc, self._L.jxlt_multi_encoder_last_error(self._enc).decode()))
+
+    def encode(self, planes, distance):
+        """planes: float32 [3, h, w] host array (page-locked memory from pinned_empty uploads at PCIe speed).
+        Returns a NativeView on the encoder's output buffer (valid until its next encode)."""
+        assert planes.dtype == np.float32 and planes.ndim == 3 and planes.shape[0] == 3 and planes.strides[2] == 4
+        _, h, w = planes.shape
+        ptrs = (fp * 3)(*[planes[c].ctypes.data_as(fp) for c in range(3)])
+        out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+        self._check(self._L.jxlt_multi_encoder_encode(self._enc, ptrs, planes.strides[1], w, h, C.c_float(distance),
+                                                      C.byref(out), C.byref(n)), "jxlt_multi_encoder_encode")
+        return NativeView(out, n.value)
+
+    def encode_pfm(self, payload, w, h, big_endian, distance):
+        a = np.frombuffer(payload, dtype=np.uint8) if not isinstance(payload, np.ndarray) else payload
+        out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+        self._check(self._L.jxlt_multi_encoder_encode_pfm(self._enc, a.ctypes.data, w, h, 1 if big_endian else 0,
+                                                          C.c_float(distance), C.byref(out), C.byref(n)),
+                    "jxlt_multi_encoder_encode_pfm")
+        return NativeView(out, n.value)
+
+    def set_device_slab(self, slab, ptrs, pitch_bytes, w, rows, keepalive=None):
+        arr = (C.c_void_p * 3)(*ptrs)
+        self._check(self._L.jxlt_multi_encoder_set_device_slab(self._enc, slab, arr, pitch_bytes, w, rows),
+                    "jxlt_multi_encoder_set_device_slab")
+        self._keep[slab] = keepalive
+
+    def encode_resident(self, w, h, distance):
+        out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+        self._check(self._L.jxlt_multi_encoder_encode_resident(self._enc, w, h, C.c_float(distance), C.byref(out),
+                                                               C.byref(n)), "jxlt_multi_encoder_encode_resident")
+        return NativeView(out, n.value)
+
+
+_SLAB_FN = {
+    "enqueue": C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Params)),
+    "dc_histogram": C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.POINTER(C.c_uint32))),
+    "begin_dc_pack": C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32)),
+    "ac_histogram": C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.POINTER(C.c_uint32))),
+    "measure": C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(PackedSections), C.POINTER(PackedSections)),
+    "write": C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)),
+    "finish": C.CFUNCTYPE(C.c_int, C.c_void_p),
+}
+
+
+class SlabOps(C.Structure):
+    """jxlt_slab_ops: the slab operations the shard protocol runs on (a device context in production;
+    the CPU tests bind their own)."""
+    _fields_ = [("self", C.c_void_p)] + [(k, v) for k, v in _SLAB_FN.items()]
+
+
+class ShardGroup:
+    """jxlt_shard_group_*: the ranks of a one-process-per-GPU job assemble ONE frame in a POSIX shared-memory
+    segment.  Rank 0 must have returned from the constructor before the other ranks construct theirs."""
+
+    def __init__(self, name, rank, world, output_capacity, max_sections):
+        self._L = host_lib()
+        L = self._L
+        L.jxlt_shard_group_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.jxlt_shard_group_close.argtypes = [C.c_void_p]
+        L.jxlt_shard_group_close.restype = None
+        L.jxlt_shard_group_last_error.argtypes = [C.c_void_p]
+        L.jxlt_shard_group_last_error.restype = C.c_char_p
+        L.jxlt_shard_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float,
+                                        C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        L.jxlt_shard_encode_ops.argtypes = [C.c_void_p, C.POINTER(SlabOps), C.c_size_t, C.c_size_t, C.c_float,
+                                            C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        self.rank, self.world = rank, world
+        self._g = C.c_void_p()
+        rc = L.jxlt_shard_group_open(name.encode(), rank, world, output_capacity, max_sections, C.byref(self._g))
+        if rc != 0:
+            raise JxlTinyError("jxlt_shard_group_open(%s, rank %d) failed (%d)" % (name, rank, rc))
+
+    def close(self):
+        if self._g:
+            self._L.jxlt_shard_group_close(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _result(self, rc, out, n, what):
+        if rc != 0:
+            raise JxlTinyError("%s failed (%d): %s" % (what, rc, self._L.jxlt_shard_group_last_error(self._g).decode()))
+        return NativeView(out, n.value) if out else None
+
+    def encode(self, enc, w, h, distance):
+        """Collective: `enc` (an Encoder) holds this rank's slab; returns a NativeView of the whole codestream
+        on rank 0, None elsewhere."""
+        out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+        rc = self._L.jxlt_shard_encode(self._g, enc._ctx, w, h, C.c_float(distance), C.byref(out), C.byref(n))
+        return self._result(rc, out, n, "jxlt_shard_encode")
+
+    def encode_ops(self, ops, w, h, distance):
+        out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+        rc = self._L.jxlt_shard_encode_ops(self._g, C.byref(ops), w, h, C.c_float(distance), C.byref(out), C.byref(n))
+        return self._result(rc, out, n, "jxlt_shard_encode_ops")

@@ -57,6 +57,13 @@ struct jxlt_context {
   float strategy_distance = 0.0f;  // jxlt_set_strategy_distance (0: each encode's own distance)
   DeviceBuf<float> own_payload;  // jxlt_image_upload_pfm
   size_t xsize = 0, ysize = 0;
+  // jxlt_image_attach_host*: the frame is still in the caller's page-locked memory; the next enqueue
+  // uploads it in DC-group rows on `upload_stream`, each row's tile_kernel launch waiting for its rows only
+  int host_src_kind = 0;  // 0: frame is in device memory, 1: planar planes, 2: PFM payload
+  const uint8_t* host_src[3] = {nullptr, nullptr, nullptr};
+  size_t host_pitch_bytes = 0;
+  hipStream_t upload_stream = nullptr;
+  std::vector<hipEvent_t> slab_ready;
 
   // pinned staging ring for uploads from pageable memory
   PinnedBuf<uint8_t> stage[2];
@@ -90,6 +97,7 @@ struct jxlt_context {
     PinnedBuf<uint64_t> h_sec_byte_off, h_tile_base;
     PinnedBuf<uint32_t> h_sec_bits;
     PinnedBuf<uint8_t> h_packed;
+    PinnedBuf<uint32_t> h_code_table;  // staging of the caller's table (asynchronous upload needs page-locked memory)
     size_t measured_sections = 0;  // sections of the last measuring pass (0: none for this frame)
     // The writing kernels are queued right behind the measuring kernels (they need nothing from
     // the host): launch i covers tiles [launch_t0[i], launch_t0[i + 1]) and signals launch_done[i].
@@ -227,15 +235,25 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
     delete ctx;
     return JXLT_ERR_NO_DEVICE;
   }
-  for (auto& ev : ctx->ev) (void)hipEventCreate(&ev);
-  for (auto& ev : ctx->stage_done) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-  (void)hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
-  (void)hipEventCreateWithFlags(&ctx->dc_hist_ready, hipEventDisableTiming);
-  (void)hipEventCreateWithFlags(&ctx->ac_hist_ready, hipEventDisableTiming);
-  (void)hipEventCreateWithFlags(&ctx->overflow_ready, hipEventDisableTiming);
+  // every stream / event of the context; a failure anywhere releases what exists so far
+  e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking);
+  for (auto& ev : ctx->ev)
+    if (e == hipSuccess) e = hipEventCreate(&ev);
+  for (auto& ev : ctx->stage_done)
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->dc_hist_ready, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ac_hist_ready, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->overflow_ready, hipEventDisableTiming);
   for (auto& ps : ctx->pack) {
-    (void)hipEventCreateWithFlags(&ps.measured, hipEventDisableTiming);
-    for (auto& ev : ps.launch_done) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ps.measured, hipEventDisableTiming);
+    for (auto& ev : ps.launch_done)
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  }
+  if (e != hipSuccess) {
+    g_create_error = std::string("context setup failed: ") + hipGetErrorString(e);
+    jxlt_context_destroy(ctx);  // (handles partially built contexts: every handle is checked for null)
+    return e == hipErrorOutOfMemory ? JXLT_ERR_OUT_OF_MEMORY : JXLT_ERR_NO_DEVICE;
   }
   *out = ctx;
   return JXLT_OK;
@@ -287,6 +305,7 @@ void jxlt_context_destroy(jxlt_context* ctx) {
     FreePinned(&ps.h_sec_byte_off);
     FreePinned(&ps.h_sec_bits);
     FreePinned(&ps.h_packed);
+    FreePinned(&ps.h_code_table);
   }
   FreePinned(&ctx->h_raw_quant);
   FreePinned(&ctx->h_strategy);
@@ -312,6 +331,12 @@ void jxlt_context_destroy(jxlt_context* ctx) {
   FreeDevice(&ctx->lut_overflow);
   FreeDevice(&ctx->dc_chain_summary);
   FreePinned(&ctx->h_lut_overflow);
+  for (hipEvent_t ev : ctx->slab_ready)
+    if (ev) (void)hipEventDestroy(ev);
+  if (ctx->upload_stream) {
+    (void)hipStreamSynchronize(ctx->upload_stream);
+    (void)hipStreamDestroy(ctx->upload_stream);
+  }
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -434,6 +459,7 @@ int jxlt_image_upload(jxlt_context* ctx, const float* const planes[3], size_t pi
     if (rc != JXLT_OK) return rc;
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // caller may reuse its buffers
+  ctx->host_src_kind = 0;
   ctx->pitch_floats = (ptrdiff_t)pitch_floats;
   ctx->pix_stride = 1;
   ctx->byteswap = 0;
@@ -450,11 +476,30 @@ void* jxlt_pinned_alloc(size_t bytes) {
     (void)hipGetLastError();
     return nullptr;
   }
-  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+  // portable: every device of the process may DMA from / to it (frames and outputs shared by several GPUs)
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
     (void)hipGetLastError();
     return nullptr;
   }
   return p;
+}
+
+int jxlt_pinned_register(void* p, size_t bytes) {
+  if (!p || !bytes) return JXLT_ERR_INVALID_ARGUMENT;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    return JXLT_ERR_NO_DEVICE;
+  }
+  if (hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) {
+    (void)hipGetLastError();
+    return JXLT_ERR_NO_DEVICE;
+  }
+  return JXLT_OK;
+}
+
+void jxlt_pinned_unregister(void* p) {
+  if (p) (void)hipHostUnregister(p);
 }
 
 void jxlt_pinned_free(void* p) {
@@ -466,6 +511,7 @@ int jxlt_image_set_device(jxlt_context* ctx, const void* const device_planes[3],
   int rc = CheckImageArgs(ctx, device_planes, pitch_bytes, xsize, ysize);
   if (rc != JXLT_OK) return rc;
   for (int c = 0; c < 3; c++) ctx->planes[c] = static_cast<const float*>(device_planes[c]);
+  ctx->host_src_kind = 0;
   ctx->pitch_floats = (ptrdiff_t)(pitch_bytes / sizeof(float));
   ctx->pix_stride = 1;
   ctx->byteswap = 0;
@@ -480,6 +526,7 @@ namespace {
 // f32, bottom row first, byte-reversed if big endian (read_pfm.cc:199-209).  tile_kernel reads
 // it in place: no de-interleaving pass anywhere.
 int SetPfmView(jxlt_context* ctx, const float* payload, size_t xsize, size_t ysize, int big_endian) {
+  ctx->host_src_kind = 0;
   for (int c = 0; c < 3; c++) ctx->planes[c] = payload + (ysize - 1) * xsize * 3 + c;
   ctx->pitch_floats = -(ptrdiff_t)(xsize * 3);
   ctx->pix_stride = 3;
@@ -541,6 +588,57 @@ int jxlt_image_upload_pfm(jxlt_context* ctx, const void* host_payload, size_t xs
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // caller may reuse its buffer
   return SetPfmView(ctx, ctx->own_payload.p, xsize, ysize, big_endian);
+}
+
+namespace {
+bool IsPageLocked(const void* p) {
+  hipPointerAttribute_t attr;
+  const bool pinned = hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeHost;
+  (void)hipGetLastError();  // a pageable pointer is not an error
+  return pinned;
+}
+}  // namespace
+
+int jxlt_image_attach_host(jxlt_context* ctx, const float* const planes[3], size_t pitch_bytes, size_t xsize,
+                           size_t ysize) {
+  int rc = CheckImageArgs(ctx, reinterpret_cast<const void* const*>(planes), pitch_bytes, xsize, ysize);
+  if (rc != JXLT_OK) return rc;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!IsPageLocked(planes[0]) || !IsPageLocked(planes[1]) || !IsPageLocked(planes[2])) {
+    ctx->error = "jxlt_image_attach_host needs page-locked memory (jxlt_pinned_alloc / jxlt_pinned_register)";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  const size_t pitch_floats = (xsize + 63) & ~size_t(63);
+  for (int c = 0; c < 3; c++) {
+    if ((rc = EnsureDevice(ctx, &ctx->own_planes[c], pitch_floats * ysize)) != JXLT_OK) return rc;
+    ctx->planes[c] = ctx->own_planes[c].p;
+    ctx->host_src[c] = reinterpret_cast<const uint8_t*>(planes[c]);
+  }
+  ctx->host_pitch_bytes = pitch_bytes;
+  ctx->pitch_floats = (ptrdiff_t)pitch_floats;
+  ctx->pix_stride = 1;
+  ctx->byteswap = 0;
+  ctx->xsize = xsize;
+  ctx->ysize = ysize;
+  ctx->encoded = false;
+  ctx->host_src_kind = 1;
+  return JXLT_OK;
+}
+
+int jxlt_image_attach_host_pfm(jxlt_context* ctx, const void* host_payload, size_t xsize, size_t ysize,
+                               int big_endian) {
+  int rc = CheckPfmArgs(ctx, host_payload, xsize, ysize);
+  if (rc != JXLT_OK) return rc;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!IsPageLocked(host_payload)) {
+    ctx->error = "jxlt_image_attach_host_pfm needs page-locked memory (jxlt_pinned_alloc / jxlt_pinned_register)";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  if ((rc = EnsureDevice(ctx, &ctx->own_payload, xsize * ysize * 3)) != JXLT_OK) return rc;
+  rc = SetPfmView(ctx, ctx->own_payload.p, xsize, ysize, big_endian);
+  ctx->host_src[0] = static_cast<const uint8_t*>(host_payload);
+  ctx->host_src_kind = 2;
+  return rc;
 }
 
 int jxlt_image_size(const jxlt_context* ctx, size_t* xsize, size_t* ysize) {
@@ -679,10 +777,69 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
   HIP_TRY(ctx, hipMemsetAsync(ctx->dc_nac.p, 0, ndc * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->lut_overflow.p, 0, sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  if (exact_roots)
-    hipLaunchKernelGGL(tile_kernel_exact_roots, dim3((unsigned)ntiles), dim3(kTileThreads), 0, ctx->stream, A);
-  else
-    hipLaunchKernelGGL(tile_kernel, dim3((unsigned)ntiles), dim3(kTileThreads), 0, ctx->stream, A);
+  if (ctx->host_src_kind == 0) {
+    if (exact_roots)
+      hipLaunchKernelGGL(tile_kernel_exact_roots, dim3((unsigned)ntiles), dim3(kTileThreads), 0, ctx->stream, A);
+    else
+      hipLaunchKernelGGL(tile_kernel, dim3((unsigned)ntiles), dim3(kTileThreads), 0, ctx->stream, A);
+  } else {
+    // The frame is still in page-locked host memory (jxlt_image_attach_host*): it comes over PCIe in
+    // DC-group rows (2048 pixel rows) on the upload stream, and every row of DC groups is a tile_kernel
+    // launch of its own that waits for its rows only -- all but the last row's kernels hide under the
+    // transfer.  A slab of whole DC-group rows is a frame of its own to the kernel (nothing crosses a group
+    // boundary): same code, base pointers moved to the slab.
+    const size_t rows_per_slab = 2048;
+    const size_t nslabs = (ctx->ysize + rows_per_slab - 1) / rows_per_slab;
+    while (ctx->slab_ready.size() < nslabs) {
+      hipEvent_t ev = nullptr;
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      ctx->slab_ready.push_back(ev);
+    }
+    const size_t xb = (size_t)g.xsize_blocks, row_bytes = ctx->xsize * sizeof(float);
+    for (size_t sl = 0; sl < nslabs; sl++) {
+      const size_t y0 = sl * rows_per_slab, y1 = std::min(ctx->ysize, y0 + rows_per_slab), rows = y1 - y0;
+      if (ctx->host_src_kind == 1) {
+        for (int c = 0; c < 3; c++)
+          HIP_TRY(ctx, hipMemcpy2DAsync(ctx->own_planes[c].p + y0 * (size_t)ctx->pitch_floats,
+                                        (size_t)ctx->pitch_floats * sizeof(float), ctx->host_src[c] + y0 * ctx->host_pitch_bytes,
+                                        ctx->host_pitch_bytes, row_bytes, rows, hipMemcpyHostToDevice, ctx->upload_stream));
+      } else {
+        // bottom-up payload: image rows [y0, y1) are the payload rows [ysize - y1, ysize - y0)
+        const size_t off = (ctx->ysize - y1) * ctx->xsize * 3 * sizeof(float);
+        HIP_TRY(ctx, hipMemcpyAsync(reinterpret_cast<uint8_t*>(ctx->own_payload.p) + off, ctx->host_src[0] + off,
+                                    rows * ctx->xsize * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->upload_stream));
+      }
+      HIP_TRY(ctx, hipEventRecord(ctx->slab_ready[sl], ctx->upload_stream));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->slab_ready[sl], 0));
+      TileArgs S = A;
+      S.g = MakeGeom(ctx->xsize, rows);
+      const size_t b0 = (y0 / 8) * xb;  // first block of the slab
+      for (int c = 0; c < 3; c++) {
+        S.planes[c] = A.planes[c] + (ptrdiff_t)y0 * ctx->pitch_floats;
+        S.quant_dc[c] = A.quant_dc[c] + b0;
+        S.nzgrid[c] = A.nzgrid[c] + b0;
+        if (A.dbg_xyb[c]) S.dbg_xyb[c] = A.dbg_xyb[c] + y0 * xb * 8;
+      }
+      S.raw_quant = A.raw_quant + b0;
+      S.strategy = A.strategy + b0;
+      S.blk_nz = A.blk_nz + 3 * b0;
+      S.blk_nscan = A.blk_nscan + 3 * b0;
+      S.coef_scan = A.coef_scan + 3 * 64 * b0;
+      S.ytox = A.ytox + (y0 / 64) * (size_t)g.xsize_tiles;
+      S.ytob = A.ytob + (y0 / 64) * (size_t)g.xsize_tiles;
+      S.group_ntok = A.group_ntok + (y0 / 256) * (size_t)g.xsize_groups;
+      S.dc_nac = A.dc_nac + (y0 / 2048) * ((ctx->xsize + 2047) / 2048);
+      if (A.dbg_qf) S.dbg_qf = A.dbg_qf + b0;
+      if (A.dbg_mask) S.dbg_mask = A.dbg_mask + b0;
+      if (A.dbg_ent8) S.dbg_ent8 = A.dbg_ent8 + (y0 / 16) * (xb / 2 + 1) * 8;
+      const unsigned slab_tiles = (unsigned)((size_t)S.g.xsize_tiles * S.g.ysize_tiles);
+      if (exact_roots)
+        hipLaunchKernelGGL(tile_kernel_exact_roots, dim3(slab_tiles), dim3(kTileThreads), 0, ctx->stream, S);
+      else
+        hipLaunchKernelGGL(tile_kernel, dim3(slab_tiles), dim3(kTileThreads), 0, ctx->stream, S);
+    }
+    ctx->host_src_kind = 0;  // the frame is resident now (a redo with exact roots must not fetch it again)
+  }
   HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_lut_overflow.p, ctx->lut_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost,
                               ctx->stream));
@@ -966,7 +1123,12 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
   if ((rc = EnsurePinned(ctx, &ps.h_sec_byte_off, nsec + 1)) != JXLT_OK) return rc;
   if ((rc = EnsurePinned(ctx, &ps.h_sec_bits, nsec)) != JXLT_OK) return rc;
   if ((rc = EnsurePinned(ctx, &ps.h_tile_base, nsec + 1)) != JXLT_OK) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(ps.code_table.p, code_table, 64 * 64 * sizeof(uint32_t), hipMemcpyHostToDevice,
+  // The caller's table is pageable as a rule: an asynchronous copy from it would make this call wait for
+  // everything queued on the stream (token_kernel!).  Staged through the context's page-locked copy instead;
+  // its previous use (last frame's upload) finished before that frame's sizes were returned.
+  if ((rc = EnsurePinned(ctx, &ps.h_code_table, 64 * 64)) != JXLT_OK) return rc;
+  memcpy(ps.h_code_table.p, code_table, 64 * 64 * sizeof(uint32_t));
+  HIP_TRY(ctx, hipMemcpyAsync(ps.code_table.p, ps.h_code_table.p, 64 * 64 * sizeof(uint32_t), hipMemcpyHostToDevice,
                               ctx->stream));
   const PackTileArgs P = TileArgsOf(ctx, kind, nsec);
   const unsigned sec_blocks = (unsigned)((nsec + 255) / 256);

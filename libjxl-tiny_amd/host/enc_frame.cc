@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -54,6 +55,22 @@ void SetStaticConstantEmulation(bool on) {
   if (!on) g_first_distance.store(0.0f);
 }
 
+// The reference's function-local static constants (enc_ac_strategy.cc:178-185): while the emulation is on,
+// every encode of the process uses the FIRST frame's distance for the two multipliers.  Off (default): the
+// context keeps whatever its owner set through jxlt_set_strategy_distance (0 = each encode's own distance).
+void ApplyStrategyDistanceEmulation(jxlt_context* ctx, float distance) {
+  static thread_local jxlt_context* touched = nullptr;  // a context this thread switched to a latched distance
+  if (g_emulate_static_constants.load()) {
+    float expected = 0.0f;
+    g_first_distance.compare_exchange_strong(expected, distance);  // first frame wins
+    jxlt_set_strategy_distance(ctx, g_first_distance.load());
+    touched = ctx;
+  } else if (touched == ctx) {
+    jxlt_set_strategy_distance(ctx, 0.0f);  // emulation was switched off again: undo our own setting only
+    touched = nullptr;
+  }
+}
+
 bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jxl::BitWriter* writer,
                           const std::function<uint8_t*(size_t)>* placer, ContextOutput* in_context) {
   static const bool trace = getenv("JXLT_TRACE") != nullptr;
@@ -70,15 +87,7 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   params.scale_dc = distp.scale_dc;
   params.x_qm_scale = distp.x_qm_scale;
   params.flags = 0;
-  {
-    float latched = 0.0f;
-    if (g_emulate_static_constants.load()) {
-      float expected = 0.0f;
-      g_first_distance.compare_exchange_strong(expected, distp.distance);  // first frame wins
-      latched = g_first_distance.load();
-    }
-    jxlt_set_strategy_distance(ctx, latched);
-  }
+  ApplyStrategyDistanceEmulation(ctx, distp.distance);
   if (jxlt_encode_enqueue(ctx, &params) != JXLT_OK) {
     fprintf(stderr, "jxl_tiny_amd: device encode failed: %s\n", jxlt_last_error(ctx));
     return false;
@@ -269,13 +278,85 @@ jxlt_context* AcquireThreadContext() { return jxl::AcquireContextForThread(); }
 
 namespace jxl {
 
+namespace {
+// The process-wide device list for sharded frames (SetEncoderDevices / JXLT_DEVICES) and the encoder built
+// on it.  One frame at a time: the multi encoder is not re-entrant, callers are serialised.
+std::mutex g_multi_mu;
+std::vector<int> g_devices;
+bool g_devices_from_env_done = false;
+jxlt_multi_encoder* g_multi = nullptr;
+std::vector<int> g_multi_devices;
+
+void DevicesFromEnvironment() {
+  if (g_devices_from_env_done) return;
+  g_devices_from_env_done = true;
+  const char* e = getenv("JXLT_DEVICES");
+  if (!e || !*e || !g_devices.empty()) return;
+  if (strcmp(e, "all") == 0) {
+    // as many contexts as the runtime reports: probe by creating throw-away contexts is wasteful, so ask
+    // for ordinals until one is refused
+    for (int d = 0; d < 64; ++d) {
+      jxlt_context* probe = nullptr;
+      if (jxlt_context_create(d, &probe) != JXLT_OK) break;
+      jxlt_context_destroy(probe);
+      g_devices.push_back(d);
+    }
+    return;
+  }
+  for (const char* p = e; *p;) {
+    char* end = nullptr;
+    const long v = strtol(p, &end, 10);
+    if (end == p) break;
+    if (v >= 0 && v < 1024) g_devices.push_back(static_cast<int>(v));
+    p = *end == ',' ? end + 1 : end;
+  }
+}
+}  // namespace
+
+void SetEncoderDevices(const int* device_ordinals, int n) {
+  std::lock_guard<std::mutex> lock(g_multi_mu);
+  g_devices_from_env_done = true;  // an explicit call wins over the environment
+  g_devices.assign(device_ordinals, device_ordinals + (n > 0 && device_ordinals ? n : 0));
+}
+
 Status EncodeFrame(const float distance, const Image3F& linear, ThreadPool* pool,
                    BitWriter* writer) {
   if (linear.xsize() == 0 || linear.ysize() == 0 || !(distance > 0)) return false;
-  jxlt_context* ctx = AcquireContextForThread();
-  if (!ctx) return false;  // no CPU fallback by design
   const float* planes[3] = {linear.ConstPlaneRow(0, 0), linear.ConstPlaneRow(1, 0),
                             linear.ConstPlaneRow(2, 0)};
+  {
+    std::lock_guard<std::mutex> lock(g_multi_mu);
+    DevicesFromEnvironment();
+    if (g_devices.size() > 1 && linear.ysize() > 2048) {
+      if (g_multi && g_multi_devices != g_devices) {
+        jxlt_multi_encoder_destroy(g_multi);
+        g_multi = nullptr;
+      }
+      if (!g_multi) {
+        if (jxlt_multi_encoder_create(g_devices.data(), static_cast<int>(g_devices.size()), &g_multi) != JXLT_OK) {
+          fprintf(stderr, "jxl_tiny_amd: cannot create device contexts: %s\n", jxlt_last_error(nullptr));
+          g_multi = nullptr;
+          return false;  // no CPU fallback by design
+        }
+        g_multi_devices = g_devices;
+      }
+      const uint8_t* bytes = nullptr;
+      size_t size = 0;
+      if (jxlt_multi_encoder_encode(g_multi, planes, linear.bytes_per_row(), linear.xsize(), linear.ysize(),
+                                    distance, &bytes, &size) != JXLT_OK) {
+        fprintf(stderr, "jxl_tiny_amd: sharded encode failed: %s\n", jxlt_multi_encoder_last_error(g_multi));
+        return false;
+      }
+      // the multi encoder returns the whole codestream; the caller's writer already holds the file header
+      BitWriter header;
+      if (!jxlt::WriteFileHeader(linear.xsize(), linear.ysize(), &header)) return false;
+      const size_t skip = header.TakeBytes().size();
+      writer->AppendBytes(bytes + skip, size - skip);
+      return true;
+    }
+  }
+  jxlt_context* ctx = AcquireContextForThread();
+  if (!ctx) return false;  // no CPU fallback by design
   if (jxlt_image_upload(ctx, planes, linear.bytes_per_row(), linear.xsize(), linear.ysize()) != JXLT_OK) {
     fprintf(stderr, "jxl_tiny_amd: upload failed: %s\n", jxlt_last_error(ctx));
     return false;

@@ -3,12 +3,11 @@
 #define JXLT_HOST_ENCODER_ENC_FRAME_H_
 
 #include "encoder/base/data_parallel.h"
+#include "encoder/base/status.h"
 #include "encoder/enc_bit_writer.h"
 #include "encoder/image.h"
 
 namespace jxl {
-
-using Status = bool;
 
 // Encodes one frame of `linear` (planar linear-sRGB f32) at butteraugli
 // `distance` and appends it to `writer` (byte aligned on entry).  The per-group
@@ -20,6 +19,12 @@ Status EncodeFrame(float distance, const Image3F& linear, ThreadPool* pool, BitW
 // Not in the reference: HIP device ordinal used by the calling thread's
 // subsequent EncodeFrame/EncodeFile calls (default 0).
 void SetEncoderDevice(int device_ordinal);
+// Not in the reference: several GPUs for ONE frame (process-wide).  With more than one ordinal, frames of
+// at least two DC-group rows (> 2048 pixel rows) are cut into row slabs of whole DC groups, one per device
+// (the reference's loop over DC groups, enc_frame.cc:839-844, spread over the GPUs; include/jxl_tiny_amd.h,
+// jxlt_multi_encoder_*); same bytes as on one GPU.  n <= 1 returns to the single-device path.  The environment
+// variable JXLT_DEVICES ("0,1,2,3" or "all") sets the same list for unmodified callers such as cjxl_tiny.
+void SetEncoderDevices(const int* device_ordinals, int n);
 
 // Not in the reference: the reference derives two multipliers of its transform search from the
 // distance of the FIRST frame the process encodes (function-local static constants,

@@ -15,8 +15,8 @@
 #include "host_internal.h"
 
 struct jxlt_batch_encoder {
-  int device = 0;
   std::vector<jxlt_context*> lanes;
+  std::vector<int> lane_device;  // GPU ordinal of every lane
 };
 
 namespace {
@@ -55,24 +55,34 @@ int EncodeOne(jxlt_context* ctx, const jxlt_batch_frame& f, float distance, uint
 
 extern "C" {
 
-int jxlt_batch_encoder_create(int device_ordinal, int lanes, jxlt_batch_encoder** out) {
+int jxlt_batch_encoder_create_multi(const int* device_ordinals, int num_devices, int lanes_per_device,
+                                    jxlt_batch_encoder** out) {
   if (!out) return JXLT_ERR_INVALID_ARGUMENT;
   *out = nullptr;
-  if (lanes <= 0) lanes = 3;
-  if (lanes > 16) lanes = 16;
+  if (!device_ordinals || num_devices < 1 || num_devices > 64) return JXLT_ERR_INVALID_ARGUMENT;
+  if (lanes_per_device <= 0) lanes_per_device = 3;
+  if (lanes_per_device > 16) lanes_per_device = 16;
   jxlt_batch_encoder* enc = new jxlt_batch_encoder;
-  enc->device = device_ordinal;
-  for (int i = 0; i < lanes; ++i) {
-    jxlt_context* ctx = nullptr;
-    const int rc = jxlt_context_create(device_ordinal, &ctx);
-    if (rc != JXLT_OK) {  // no device: no CPU fallback
-      jxlt_batch_encoder_destroy(enc);
-      return rc;
+  // lane order: one lane of every device first, then the second of every device, ... so that a short batch
+  // spreads over the GPUs before it doubles up on one
+  for (int l = 0; l < lanes_per_device; ++l) {
+    for (int d = 0; d < num_devices; ++d) {
+      jxlt_context* ctx = nullptr;
+      const int rc = jxlt_context_create(device_ordinals[d], &ctx);
+      if (rc != JXLT_OK) {  // no device: no CPU fallback
+        jxlt_batch_encoder_destroy(enc);
+        return rc;
+      }
+      enc->lanes.push_back(ctx);
+      enc->lane_device.push_back(device_ordinals[d]);
     }
-    enc->lanes.push_back(ctx);
   }
   *out = enc;
   return JXLT_OK;
+}
+
+int jxlt_batch_encoder_create(int device_ordinal, int lanes, jxlt_batch_encoder** out) {
+  return jxlt_batch_encoder_create_multi(&device_ordinal, 1, lanes, out);
 }
 
 void jxlt_batch_encoder_destroy(jxlt_batch_encoder* enc) {
@@ -89,16 +99,42 @@ int jxlt_batch_encoder_run(jxlt_batch_encoder* enc, const jxlt_batch_frame* fram
     out_bytes[i] = nullptr;
     out_sizes[i] = 0;
   }
-  std::atomic<size_t> next(0);
-  std::vector<int> status(num_frames, JXLT_OK);
-  auto lane = [&](jxlt_context* ctx) {
-    for (size_t i; (i = next.fetch_add(1)) < num_frames;)
+  // One queue: a lane claims the first frame nobody has taken that it can take -- any frame in host memory,
+  // or a frame in the memory of the lane's own GPU.
+  std::vector<std::atomic<bool>> taken(num_frames);
+  for (auto& t : taken) t.store(false);
+  std::vector<int> status(num_frames, JXLT_ERR_INVALID_ARGUMENT);  // (stays for device frames no lane could take)
+  bool multi_device = false;
+  for (int d : enc->lane_device) multi_device |= d != enc->lane_device[0];
+  auto lane = [&](size_t l) {
+    jxlt_context* ctx = enc->lanes[l];
+    const int dev = enc->lane_device[l];
+    size_t from = 0;
+    for (;;) {
+      size_t i = from;
+      bool advanced_past_all_mine = true;
+      for (; i < num_frames; ++i) {
+        if (taken[i].load(std::memory_order_relaxed)) {
+          if (advanced_past_all_mine) from = i + 1;
+          continue;
+        }
+        const bool mine = !frames[i].in_device_memory || !multi_device || frames[i].device_ordinal == dev;
+        if (!mine) {
+          advanced_past_all_mine = false;
+          continue;
+        }
+        bool expected = false;
+        if (taken[i].compare_exchange_strong(expected, true)) break;
+      }
+      if (i >= num_frames) return;
       status[i] = EncodeOne(ctx, frames[i], distance, &out_bytes[i], &out_sizes[i]);
+    }
   };
-  const size_t used = num_frames < enc->lanes.size() ? num_frames : enc->lanes.size();
+  // (a multi-device encoder starts every lane: a frame in device memory needs a lane of ITS device)
+  const size_t used = multi_device || num_frames >= enc->lanes.size() ? enc->lanes.size() : num_frames;
   std::vector<std::thread> threads;
-  for (size_t l = 1; l < used; ++l) threads.emplace_back(lane, enc->lanes[l]);
-  if (used) lane(enc->lanes[0]);
+  for (size_t l = 1; l < used; ++l) threads.emplace_back(lane, l);
+  if (used) lane(0);
   for (std::thread& t : threads) t.join();
   for (size_t i = 0; i < num_frames; ++i)
     if (status[i] != JXLT_OK) return status[i];

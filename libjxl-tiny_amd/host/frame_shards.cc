@@ -1,0 +1,747 @@
+// One frame over several GPUs: row slabs of whole DC groups, one participant (device context + host
+// thread or process) per slab.  See include/jxl_tiny_amd.h ("one frame sharded over several GPUs").
+//
+// Counterpart in the reference: the DC-group loop /root/reference/encoder/enc_frame.cc:839-844 (independent
+// units), the code optimisation over ALL sections :846-850 (the one global dependency: here a host-side sum
+// of the participants' 2 x 64 x 64 histograms), and CombineSections :804-816 (here: every participant's
+// sections land in their byte range of one buffer, participant 0 writes header + TOC + globals in front).
+//
+// The participants meet in a control block that lives either on the heap (threads of one process) or in a
+// POSIX shared-memory segment (one process per GPU).  All synchronisation is a handful of monotonic
+// atomic counters in that block; nothing here touches the GPUs except through the slab operations.
+#include <fcntl.h>
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/jxl_tiny_amd.h"
+#include "encoder/enc_bit_writer.h"
+#include "entropy_coder.h"
+#include "frame_assembler.h"
+#include "host_internal.h"
+
+namespace jxlt {
+namespace {
+
+constexpr int kMaxWorld = 64;
+constexpr uint64_t kMagic = 0x6a786c7473686431ull;  // "jxltshd1"
+constexpr size_t kHistWords = 64 * 64;
+
+// Phases every participant arrives at / values participant 0 publishes (per frame).
+enum Arrival { kDcHist = 0, kAcHist, kSizes, kPlaced, kNumArrivals };
+enum Publication { kDcTable = 0, kAcTable, kLayout, kNumPublications };
+
+// Lives at offset 0 of the region.  Plain data + lock-free atomics only (shared between processes).
+struct Control {
+  uint64_t magic;
+  uint32_t world;
+  uint32_t reserved;
+  uint64_t max_sections;     // capacity of the two section tables behind the control block
+  uint64_t output_offset;    // where the codestream is assembled, from the start of the region
+  uint64_t output_capacity;
+  uint64_t region_bytes;
+  std::atomic<uint64_t> arrived[kNumArrivals];       // += 1 per participant and frame
+  std::atomic<uint64_t> published[kNumPublications];  // = frame number
+  std::atomic<int32_t> failed;                        // sticky first error
+  uint64_t dc_at[kMaxWorld], ac_at[kMaxWorld];        // kLayout: where each participant's sections go
+  uint32_t dc_table[kHistWords], ac_table[kHistWords];
+  uint32_t hist[kMaxWorld][2][kHistWords];            // [participant][0 = AC, 1 = DC]
+};
+static_assert(std::atomic<uint64_t>::is_always_lock_free, "the control block needs lock-free atomics");
+
+size_t ControlBytes() { return (sizeof(Control) + 4095) & ~size_t(4095); }
+size_t TablesBytes(size_t max_sections) { return (2 * max_sections * sizeof(uint32_t) + 4095) & ~size_t(4095); }
+
+}  // namespace
+}  // namespace jxlt
+
+struct jxlt_shard_group {
+  uint8_t* base = nullptr;   // region: Control | sec_bits[max] | sec_bytes[max] | output
+  size_t bytes = 0;
+  jxlt::Control* ctl = nullptr;
+  int rank = 0;              // -1: in-process group (participants pass their rank explicitly)
+  int world = 1;
+  bool shm = false;
+  bool registered = false;   // output area page-locked for this process's devices
+  std::string name;
+  std::string error;         // first failure (several participants of one process may report)
+  std::mutex error_mu;
+  void SetError(const std::string& what) {
+    std::lock_guard<std::mutex> lock(error_mu);
+    if (error.empty() || ctl == nullptr || ctl->failed.load() == 0) error = what;
+  }
+  uint64_t frame[jxlt::kMaxWorld] = {};  // frames begun, per participant of this process
+  uint32_t* sec_bits() const { return reinterpret_cast<uint32_t*>(base + jxlt::ControlBytes()); }
+  uint32_t* sec_bytes() const { return sec_bits() + ctl->max_sections; }
+  uint8_t* output() const { return base + ctl->output_offset; }
+};
+
+namespace jxlt {
+namespace {
+
+void ShardRows(size_t ysize, int world, int rank, size_t* y0, size_t* y1) {
+  // whole DC-group rows, the remainder to the first participants (so a frame with a single
+  // DC-group row belongs to participant 0)
+  const size_t ndc = (ysize + 2047) / 2048, w = static_cast<size_t>(world), r = static_cast<size_t>(rank);
+  const size_t lo = (ndc / w) * r + std::min(r, ndc % w);
+  const size_t hi = lo + ndc / w + (r < ndc % w ? 1 : 0);
+  *y0 = std::min(ysize, lo * 2048);
+  *y1 = std::min(ysize, hi * 2048);
+}
+
+int NonEmptySlabs(size_t ysize, int world) {
+  int n = 0;
+  for (int r = 0; r < world; ++r) {
+    size_t y0, y1;
+    ShardRows(ysize, world, r, &y0, &y1);
+    n += y1 > y0;
+  }
+  return n;
+}
+
+void InitControl(Control* c, int world, size_t max_sections, size_t output_capacity, size_t region_bytes) {
+  memset(static_cast<void*>(c), 0, sizeof(Control));
+  for (auto& a : c->arrived) new (&a) std::atomic<uint64_t>(0);
+  for (auto& a : c->published) new (&a) std::atomic<uint64_t>(0);
+  new (&c->failed) std::atomic<int32_t>(0);
+  c->world = static_cast<uint32_t>(world);
+  c->max_sections = max_sections;
+  c->output_offset = ControlBytes() + TablesBytes(max_sections);
+  c->output_capacity = output_capacity;
+  c->region_bytes = region_bytes;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  c->magic = kMagic;
+}
+
+// Waits until pred() holds; gives up when a participant has failed or after two minutes (a peer died).
+template <typename Pred>
+int WaitFor(jxlt_shard_group* g, const Pred& pred) {
+  Control* c = g->ctl;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint64_t spins = 0;; ++spins) {
+    if (pred()) return JXLT_OK;
+    const int32_t f = c->failed.load(std::memory_order_acquire);
+    if (f != 0) {
+      {
+        std::lock_guard<std::mutex> lock(g->error_mu);
+        if (g->error.empty()) g->error = "another participant of the sharded frame failed";
+      }
+      return f;
+    }
+    if ((spins & 63) == 63) sched_yield();
+    if ((spins & 0xFFFF) == 0xFFFF &&
+        std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+      g->SetError("timed out waiting for the other participants of the sharded frame");
+      int32_t expected = 0;
+      c->failed.compare_exchange_strong(expected, JXLT_ERR_INTERNAL);
+      return JXLT_ERR_INTERNAL;
+    }
+  }
+}
+
+int Fail(jxlt_shard_group* g, int rc, const char* what) {
+  g->SetError(what);
+  int32_t expected = 0;
+  g->ctl->failed.compare_exchange_strong(expected, rc);
+  return rc;
+}
+
+// The protocol, run by every participant with its own slab operations.
+int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t xsize, size_t ysize,
+                float distance, const uint8_t** bytes, size_t* size) {
+  Control* c = g->ctl;
+  const int world = g->world;
+  if (bytes) *bytes = nullptr;
+  if (size) *size = 0;
+  if (c->failed.load() != 0) {
+    g->SetError("the shard group is in a failed state (an earlier frame failed)");
+    return c->failed.load();
+  }
+  const uint64_t frame = ++g->frame[rank];
+  const uint64_t all = frame * static_cast<uint64_t>(world);
+  size_t y0, y1;
+  ShardRows(ysize, world, rank, &y0, &y1);
+  const bool empty = y1 == y0;
+  const size_t xdc = (xsize + 2047) / 2048, xgroups = (xsize + 255) / 256;
+  const size_t ndc_frame = xdc * ((ysize + 2047) / 2048), ngroups_frame = xgroups * ((ysize + 255) / 256);
+  // first section of this slab in the frame's raster order
+  const size_t dc_first = xdc * (y0 / 2048), ac_first = xgroups * (y0 / 256);
+  const size_t ndc = xdc * ((y1 - y0 + 2047) / 2048), nac = xgroups * ((y1 - y0 + 255) / 256);
+  if (ndc_frame + ngroups_frame > c->max_sections)
+    return Fail(g, JXLT_ERR_OUT_OF_MEMORY, "frame has more sections than the shard group was opened for");
+  if (ndc_frame + ngroups_frame == 2)
+    return Fail(g, JXLT_ERR_UNSUPPORTED, "single-group frames are not sharded");
+
+  const DistanceParams distp = ComputeDistanceParams(distance);
+  jxlt_params params;
+  params.distance = distp.distance;
+  params.scale = distp.scale;
+  params.inv_scale = distp.inv_scale;
+  params.scale_dc = distp.scale_dc;
+  params.x_qm_scale = distp.x_qm_scale;
+  params.flags = 0;
+  int rc;
+#define SLAB(call, what)                                   \
+  if (!empty && (rc = (call)) != JXLT_OK) return Fail(g, rc, what)
+
+  SLAB(ops->enqueue(ops->self, &params), "device pipeline failed");
+
+  // ---- DC histograms -> DC code (participant 0) -> every participant packs its DC-group sections
+  const uint32_t* h = nullptr;
+  SLAB(ops->dc_histogram(ops->self, &h), "DC histogram fetch failed");
+  if (empty) memset(c->hist[rank][1], 0, sizeof(c->hist[rank][1]));
+  else memcpy(c->hist[rank][1], h, sizeof(c->hist[rank][1]));
+  c->arrived[kDcHist].fetch_add(1, std::memory_order_acq_rel);
+  EntropyCode dc_code, ac_code;
+  std::vector<uint32_t> sum(kHistWords);
+  if (rank == 0) {
+    if ((rc = WaitFor(g, [&] { return c->arrived[kDcHist].load(std::memory_order_acquire) >= all; })) != JXLT_OK)
+      return rc;
+    std::fill(sum.begin(), sum.end(), 0u);
+    for (int r = 0; r < world; ++r)
+      for (size_t i = 0; i < kHistWords; ++i) sum[i] += c->hist[r][1][i];
+    BuildDcCode(sum.data(), &dc_code);
+    FillCodeTable(dc_code, c->dc_table);
+    c->published[kDcTable].store(frame, std::memory_order_release);
+  } else if ((rc = WaitFor(g, [&] { return c->published[kDcTable].load(std::memory_order_acquire) >= frame; })) !=
+             JXLT_OK) {
+    return rc;
+  }
+  SLAB(ops->begin_dc_pack(ops->self, c->dc_table), "DC section measuring failed");
+
+  // ---- AC histograms -> AC code
+  SLAB(ops->ac_histogram(ops->self, &h), "AC histogram fetch failed");
+  if (empty) memset(c->hist[rank][0], 0, sizeof(c->hist[rank][0]));
+  else memcpy(c->hist[rank][0], h, sizeof(c->hist[rank][0]));
+  c->arrived[kAcHist].fetch_add(1, std::memory_order_acq_rel);
+  FrameGlobals globals;
+  if (rank == 0) {
+    if ((rc = WaitFor(g, [&] { return c->arrived[kAcHist].load(std::memory_order_acquire) >= all; })) != JXLT_OK)
+      return rc;
+    std::fill(sum.begin(), sum.end(), 0u);
+    for (int r = 0; r < world; ++r)
+      for (size_t i = 0; i < kHistWords; ++i) sum[i] += c->hist[r][0][i];
+    BuildAcCode(sum.data(), &ac_code);
+    FillCodeTable(ac_code, c->ac_table);
+    c->published[kAcTable].store(frame, std::memory_order_release);
+    BuildFrameGlobals(xsize, ysize, distp, dc_code, ac_code, &globals);  // (while the devices measure)
+  } else if ((rc = WaitFor(g, [&] { return c->published[kAcTable].load(std::memory_order_acquire) >= frame; })) !=
+             JXLT_OK) {
+    return rc;
+  }
+
+  // ---- exact section sizes of every slab -> layout of the one output buffer
+  jxlt_packed_sections dcm = {nullptr, nullptr, nullptr, 0}, acm = {nullptr, nullptr, nullptr, 0};
+  SLAB(ops->measure(ops->self, c->ac_table, &dcm, &acm), "section measuring failed");
+  if (!empty) {
+    if (dcm.num_sections != ndc || acm.num_sections != nac)
+      return Fail(g, JXLT_ERR_INTERNAL, "slab geometry does not match the frame (wrong number of rows set?)");
+    uint32_t* bits = g->sec_bits();
+    uint32_t* sizes = g->sec_bytes();
+    for (size_t i = 0; i < ndc; ++i) {
+      bits[dc_first + i] = dcm.section_bits[i];
+      sizes[dc_first + i] = static_cast<uint32_t>(dcm.section_offset[i + 1] - dcm.section_offset[i]);
+    }
+    for (size_t i = 0; i < nac; ++i) {
+      bits[ndc_frame + ac_first + i] = acm.section_bits[i];
+      sizes[ndc_frame + ac_first + i] = static_cast<uint32_t>(acm.section_offset[i + 1] - acm.section_offset[i]);
+    }
+  }
+  c->arrived[kSizes].fetch_add(1, std::memory_order_acq_rel);
+  std::vector<uint64_t> dc_off, ac_off;
+  std::vector<uint8_t> file_header;
+  size_t dc_begin = 0, ac_global_at = 0, total_end = 0;
+  if (rank == 0) {
+    if ((rc = WaitFor(g, [&] { return c->arrived[kSizes].load(std::memory_order_acquire) >= all; })) != JXLT_OK)
+      return rc;
+    jxl::BitWriter fh;
+    if (!WriteFileHeader(xsize, ysize, &fh)) return Fail(g, JXLT_ERR_INVALID_ARGUMENT, "invalid frame size");
+    file_header = fh.TakeBytes();
+    const uint32_t* sizes = g->sec_bytes();
+    dc_off.assign(ndc_frame + 1, 0);
+    ac_off.assign(ngroups_frame + 1, 0);
+    for (size_t i = 0; i < ndc_frame; ++i) dc_off[i + 1] = dc_off[i] + sizes[i];
+    for (size_t i = 0; i < ngroups_frame; ++i) ac_off[i + 1] = ac_off[i] + sizes[ndc_frame + i];
+    // head (file header + frame header + TOC + DCGlobal) is right-aligned in front of the DC sections: its
+    // size is bounded before it exists, so the devices start copying at once
+    dc_begin = (file_header.size() + HeadSizeBound(xsize, ysize, globals) + 255) & ~size_t(255);
+    ac_global_at = dc_begin + dc_off[ndc_frame];
+    const size_t ac_begin = ac_global_at + globals.ac_global.size();
+    total_end = ac_begin + ac_off[ngroups_frame];
+    if (total_end + 16 > c->output_capacity)
+      return Fail(g, JXLT_ERR_OUT_OF_MEMORY, "codestream does not fit the shard group's output area");
+    for (int r = 0; r < world; ++r) {
+      size_t r0, r1;
+      ShardRows(ysize, world, r, &r0, &r1);
+      c->dc_at[r] = dc_begin + dc_off[xdc * (r0 / 2048)];
+      c->ac_at[r] = ac_begin + ac_off[xgroups * (r0 / 256)];
+    }
+    c->published[kLayout].store(frame, std::memory_order_release);
+  } else if ((rc = WaitFor(g, [&] { return c->published[kLayout].load(std::memory_order_acquire) >= frame; })) !=
+             JXLT_OK) {
+    return rc;
+  }
+
+  // ---- every participant's device writes its sections in place
+  uint8_t* out = g->output();
+  SLAB(ops->write(ops->self, out + c->dc_at[rank], out + c->ac_at[rank]), "section placement failed");
+  size_t frame_begin = 0;
+  if (rank == 0) {
+    const PackedSections dc = {nullptr, dc_off.data(), g->sec_bits(), ndc_frame};
+    const PackedSections ac = {nullptr, ac_off.data(), g->sec_bits() + ndc_frame, ngroups_frame};
+    std::vector<uint8_t> head;
+    if (!BuildFrameHead(xsize, ysize, distp, globals, dc, ac, &head))
+      return Fail(g, JXLT_ERR_INTERNAL, "frame head construction failed");
+    frame_begin = dc_begin - head.size() - file_header.size();
+    memcpy(out + frame_begin, file_header.data(), file_header.size());
+    memcpy(out + frame_begin + file_header.size(), head.data(), head.size());
+    memcpy(out + ac_global_at, globals.ac_global.data(), globals.ac_global.size());
+  }
+  SLAB(ops->finish(ops->self), "device synchronisation failed");
+#undef SLAB
+  c->arrived[kPlaced].fetch_add(1, std::memory_order_acq_rel);
+  if (rank == 0) {
+    if ((rc = WaitFor(g, [&] { return c->arrived[kPlaced].load(std::memory_order_acquire) >= all; })) != JXLT_OK)
+      return rc;
+    if (bytes) *bytes = out + frame_begin;
+    if (size) *size = total_end - frame_begin;
+  }
+  return JXLT_OK;
+}
+
+// ---- slab operations bound to a device context
+int CtxEnqueue(void* self, const jxlt_params* p) {
+  jxlt_context* ctx = static_cast<jxlt_context*>(self);
+  ApplyStrategyDistanceEmulation(ctx, p->distance);
+  return jxlt_encode_enqueue(ctx, p);
+}
+int CtxDcHist(void* self, const uint32_t** h) { return jxlt_fetch_dc_histogram(static_cast<jxlt_context*>(self), h); }
+int CtxBeginDc(void* self, const uint32_t* t) { return jxlt_pack_measure_begin(static_cast<jxlt_context*>(self), 0, t); }
+int CtxAcHist(void* self, const uint32_t** h) {
+  return jxlt_fetch_histograms(static_cast<jxlt_context*>(self), h, nullptr);
+}
+int CtxMeasure(void* self, const uint32_t* t, jxlt_packed_sections* dc, jxlt_packed_sections* ac) {
+  return jxlt_pack_measure(static_cast<jxlt_context*>(self), nullptr, t, dc, ac);
+}
+int CtxWrite(void* self, uint8_t* dc_dst, uint8_t* ac_dst) {
+  return jxlt_pack_write(static_cast<jxlt_context*>(self), dc_dst, ac_dst);
+}
+int CtxFinish(void* self) { return jxlt_synchronize(static_cast<jxlt_context*>(self)); }
+
+jxlt_slab_ops OpsOf(jxlt_context* ctx) {
+  return {ctx, CtxEnqueue, CtxDcHist, CtxBeginDc, CtxAcHist, CtxMeasure, CtxWrite, CtxFinish};
+}
+
+size_t SectionsOf(size_t xsize, size_t ysize) {
+  return ((xsize + 2047) / 2048) * ((ysize + 2047) / 2048) + ((xsize + 255) / 256) * ((ysize + 255) / 256);
+}
+
+}  // namespace
+}  // namespace jxlt
+
+// ---------------------------------------------------------------------------------------------
+// In-process form: one context + one host thread per device.
+struct jxlt_multi_encoder {
+  std::vector<int> devices;
+  std::vector<jxlt_context*> ctx;
+  jxlt_shard_group group;          // heap region, re-made when a frame needs more room
+  std::string error;
+  // persistent workers (participants 1 .. n-1; the caller's thread is participant 0)
+  std::vector<std::thread> workers;
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  uint64_t job_id = 0;
+  int pending = 0;
+  bool quit = false;
+  // the job
+  enum Source { kNone, kHostPlanes, kHostPfm, kResident } source = kNone;
+  const float* planes[3] = {nullptr, nullptr, nullptr};
+  size_t pitch_bytes = 0;
+  const uint8_t* pfm = nullptr;
+  int pfm_big_endian = 0;
+  size_t xsize = 0, ysize = 0;
+  float distance = 1.0f;
+  std::vector<int> status;
+  const uint8_t* out_bytes = nullptr;
+  size_t out_size = 0;
+  // frames set slab by slab (jxlt_multi_encoder_set_device_slab)
+  std::vector<size_t> slab_rows;
+  size_t resident_xsize = 0;
+};
+
+namespace jxlt {
+namespace {
+
+int EnsureLocalRegion(jxlt_multi_encoder* enc, size_t xsize, size_t ysize) {
+  jxlt_shard_group& g = enc->group;
+  const size_t sections = SectionsOf(xsize, ysize);
+  // worst case of the device packer: 28 bits per record, 9.14 B/pixel of records -> bounded by the raw
+  // frame; in practice a few percent of it.  Start with 1 byte per pixel + slack and grow on demand.
+  size_t want_out = g.ctl ? static_cast<size_t>(g.ctl->output_capacity) : 0;
+  const size_t floor_out = xsize * ysize + (size_t(1) << 20);
+  if (want_out < floor_out) want_out = floor_out;
+  if (g.ctl && g.ctl->max_sections >= sections && g.ctl->output_capacity >= want_out) return JXLT_OK;
+  if (g.base) jxlt_pinned_free(g.base);
+  g.base = nullptr;
+  g.ctl = nullptr;
+  const size_t max_sections = sections + sections / 4 + 64;
+  const size_t bytes = ControlBytes() + TablesBytes(max_sections) + want_out;
+  g.base = static_cast<uint8_t*>(jxlt_pinned_alloc(bytes));  // page-locked, visible to every device
+  if (!g.base) {
+    enc->error = "cannot allocate the page-locked output region (no usable HIP device?)";
+    return JXLT_ERR_NO_DEVICE;
+  }
+  g.bytes = bytes;
+  g.ctl = reinterpret_cast<Control*>(g.base);
+  InitControl(g.ctl, g.world, max_sections, want_out, bytes);
+  for (auto& f : g.frame) f = 0;
+  return JXLT_OK;
+}
+
+// What participant `rank` does for the current job.
+int RunParticipant(jxlt_multi_encoder* enc, int rank, const uint8_t** bytes, size_t* size) {
+  jxlt_context* ctx = enc->ctx[rank];
+  size_t y0, y1;
+  ShardRows(enc->ysize, enc->group.world, rank, &y0, &y1);
+  int rc = JXLT_OK;
+  if (y1 > y0) {
+    if (enc->source == jxlt_multi_encoder::kHostPlanes) {
+      const float* slab[3];
+      for (int c = 0; c < 3; ++c)
+        slab[c] = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(enc->planes[c]) + y0 * enc->pitch_bytes);
+      // page-locked memory: the upload is pipelined under the slab's kernels; anything else is staged
+      rc = jxlt_image_attach_host(ctx, slab, enc->pitch_bytes, enc->xsize, y1 - y0);
+      if (rc != JXLT_OK) rc = jxlt_image_upload(ctx, slab, enc->pitch_bytes, enc->xsize, y1 - y0);
+    } else if (enc->source == jxlt_multi_encoder::kHostPfm) {
+      // bottom-up payload: rows [y0, y1) from the top are the payload rows [ysize - y1, ysize - y0)
+      const uint8_t* slab = enc->pfm + (enc->ysize - y1) * enc->xsize * 3 * sizeof(float);
+      rc = jxlt_image_attach_host_pfm(ctx, slab, enc->xsize, y1 - y0, enc->pfm_big_endian);
+      if (rc != JXLT_OK) rc = jxlt_image_upload_pfm(ctx, slab, enc->xsize, y1 - y0, enc->pfm_big_endian);
+    }
+    if (rc != JXLT_OK) {
+      enc->group.SetError(std::string("slab upload failed: ") + jxlt_last_error(ctx));
+      int32_t expected = 0;
+      enc->group.ctl->failed.compare_exchange_strong(expected, rc);
+      return rc;
+    }
+  }
+  const jxlt_slab_ops ops = OpsOf(ctx);
+  return EncodeShard(&enc->group, rank, &ops, enc->xsize, enc->ysize, enc->distance, bytes, size);
+}
+
+void WorkerLoop(jxlt_multi_encoder* enc, int rank) {
+  uint64_t seen = 0;
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lock(enc->mu);
+      enc->cv_go.wait(lock, [&] { return enc->quit || enc->job_id != seen; });
+      if (enc->quit) return;
+      seen = enc->job_id;
+    }
+    const int rc = RunParticipant(enc, rank, nullptr, nullptr);
+    {
+      std::lock_guard<std::mutex> lock(enc->mu);
+      enc->status[rank] = rc;
+      if (--enc->pending == 0) enc->cv_done.notify_all();
+    }
+  }
+}
+
+int RunJob(jxlt_multi_encoder* enc, const uint8_t** bytes, size_t* size) {
+  const int world = enc->group.world;
+  *bytes = nullptr;
+  *size = 0;
+  float d = enc->distance;
+  if (!NormalizeDistance(&d)) {
+    enc->error = "invalid distance";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  enc->distance = d;
+  if (enc->xsize == 0 || enc->ysize == 0) {
+    enc->error = "empty frame";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  if (NonEmptySlabs(enc->ysize, world) <= 1) {
+    // one DC-group row (or a single-group frame): nothing to shard -- the ordinary path on participant 0's
+    // device, which owns the only slab (ShardRows)
+    jxlt_context* ctx = enc->ctx[0];
+    int rc = JXLT_OK;
+    if (enc->source == jxlt_multi_encoder::kHostPlanes)
+      rc = jxlt_image_upload(ctx, enc->planes, enc->pitch_bytes, enc->xsize, enc->ysize);
+    else if (enc->source == jxlt_multi_encoder::kHostPfm)
+      rc = jxlt_image_upload_pfm(ctx, enc->pfm, enc->xsize, enc->ysize, enc->pfm_big_endian);
+    if (rc == JXLT_OK) rc = jxlt_encode_resident_view(ctx, enc->distance, 0, bytes, size);
+    if (rc != JXLT_OK) enc->error = std::string("single-device encode failed: ") + jxlt_last_error(ctx);
+    return rc;
+  }
+  int rc = EnsureLocalRegion(enc, enc->xsize, enc->ysize);
+  if (rc != JXLT_OK) return rc;
+  for (int attempt = 0;; ++attempt) {
+    enc->group.ctl->failed.store(0);
+    {
+      std::lock_guard<std::mutex> lock(enc->mu);
+      enc->status.assign(world, JXLT_OK);
+      enc->pending = world - 1;
+      ++enc->job_id;
+    }
+    enc->cv_go.notify_all();
+    const int rc0 = RunParticipant(enc, 0, bytes, size);
+    {
+      std::unique_lock<std::mutex> lock(enc->mu);
+      enc->cv_done.wait(lock, [&] { return enc->pending == 0; });
+    }
+    rc = rc0;
+    for (int r = 1; r < world && rc == JXLT_OK; ++r) rc = enc->status[r];
+    if (rc == JXLT_ERR_OUT_OF_MEMORY && attempt == 0 &&
+        enc->group.error.find("does not fit") != std::string::npos) {
+      // incompressible content: give the output area the packer's worst case and redo the frame
+      // (every participant is past its last wait: the failure flag released them)
+      Control* c = enc->group.ctl;
+      const size_t worst = 10 * enc->xsize * enc->ysize + (size_t(1) << 20);
+      const size_t max_sections = static_cast<size_t>(c->max_sections);
+      jxlt_pinned_free(enc->group.base);
+      enc->group.base = nullptr;
+      enc->group.ctl = nullptr;
+      const size_t bytes_needed = ControlBytes() + TablesBytes(max_sections) + worst;
+      enc->group.base = static_cast<uint8_t*>(jxlt_pinned_alloc(bytes_needed));
+      if (!enc->group.base) {
+        enc->error = "cannot allocate the page-locked output region";
+        return JXLT_ERR_OUT_OF_MEMORY;
+      }
+      enc->group.bytes = bytes_needed;
+      enc->group.ctl = reinterpret_cast<Control*>(enc->group.base);
+      InitControl(enc->group.ctl, world, max_sections, worst, bytes_needed);
+      for (auto& f : enc->group.frame) f = 0;
+      continue;
+    }
+    break;
+  }
+  if (rc != JXLT_OK) {
+    enc->error = enc->group.error.empty() ? "sharded encode failed" : enc->group.error;
+    // a failed frame leaves the counters of the control block out of step: start over next time
+    InitControl(enc->group.ctl, world, static_cast<size_t>(enc->group.ctl->max_sections),
+                static_cast<size_t>(enc->group.ctl->output_capacity), enc->group.bytes);
+    for (auto& f : enc->group.frame) f = 0;
+  }
+  return rc;
+}
+
+}  // namespace
+}  // namespace jxlt
+
+extern "C" {
+
+int jxlt_shard_rows(size_t ysize, int world, int rank, size_t* y0, size_t* y1) {
+  if (!y0 || !y1 || world < 1 || world > jxlt::kMaxWorld || rank < 0 || rank >= world) return JXLT_ERR_INVALID_ARGUMENT;
+  jxlt::ShardRows(ysize, world, rank, y0, y1);
+  return JXLT_OK;
+}
+
+int jxlt_multi_encoder_create(const int* device_ordinals, int num_devices, jxlt_multi_encoder** out) {
+  if (!out) return JXLT_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (!device_ordinals || num_devices < 1 || num_devices > jxlt::kMaxWorld) return JXLT_ERR_INVALID_ARGUMENT;
+  jxlt_multi_encoder* enc = new jxlt_multi_encoder;
+  enc->group.rank = -1;
+  enc->group.world = num_devices;
+  for (int i = 0; i < num_devices; ++i) {
+    jxlt_context* ctx = nullptr;
+    const int rc = jxlt_context_create(device_ordinals[i], &ctx);
+    if (rc != JXLT_OK) {  // no device: there is no CPU fallback
+      for (jxlt_context* c : enc->ctx) jxlt_context_destroy(c);
+      delete enc;
+      return rc;
+    }
+    enc->devices.push_back(device_ordinals[i]);
+    enc->ctx.push_back(ctx);
+  }
+  enc->slab_rows.assign(num_devices, 0);
+  for (int r = 1; r < num_devices; ++r) enc->workers.emplace_back(jxlt::WorkerLoop, enc, r);
+  *out = enc;
+  return JXLT_OK;
+}
+
+void jxlt_multi_encoder_destroy(jxlt_multi_encoder* enc) {
+  if (!enc) return;
+  {
+    std::lock_guard<std::mutex> lock(enc->mu);
+    enc->quit = true;
+  }
+  enc->cv_go.notify_all();
+  for (std::thread& t : enc->workers) t.join();
+  for (jxlt_context* c : enc->ctx) jxlt_context_destroy(c);
+  if (enc->group.base) jxlt_pinned_free(enc->group.base);
+  delete enc;
+}
+
+const char* jxlt_multi_encoder_last_error(const jxlt_multi_encoder* enc) { return enc ? enc->error.c_str() : ""; }
+
+int jxlt_multi_encoder_encode(jxlt_multi_encoder* enc, const float* const planes[3], size_t pitch_bytes,
+                              size_t xsize, size_t ysize, float distance, const uint8_t** bytes, size_t* size) {
+  if (!enc || !planes || !planes[0] || !planes[1] || !planes[2] || !bytes || !size ||
+      pitch_bytes < xsize * sizeof(float) || pitch_bytes % sizeof(float))
+    return JXLT_ERR_INVALID_ARGUMENT;
+  enc->source = jxlt_multi_encoder::kHostPlanes;
+  for (int c = 0; c < 3; ++c) enc->planes[c] = planes[c];
+  enc->pitch_bytes = pitch_bytes;
+  enc->xsize = xsize;
+  enc->ysize = ysize;
+  enc->distance = distance;
+  return jxlt::RunJob(enc, bytes, size);
+}
+
+int jxlt_multi_encoder_encode_pfm(jxlt_multi_encoder* enc, const void* host_payload, size_t xsize, size_t ysize,
+                                  int big_endian, float distance, const uint8_t** bytes, size_t* size) {
+  if (!enc || !host_payload || !bytes || !size) return JXLT_ERR_INVALID_ARGUMENT;
+  enc->source = jxlt_multi_encoder::kHostPfm;
+  enc->pfm = static_cast<const uint8_t*>(host_payload);
+  enc->pfm_big_endian = big_endian;
+  enc->xsize = xsize;
+  enc->ysize = ysize;
+  enc->distance = distance;
+  return jxlt::RunJob(enc, bytes, size);
+}
+
+int jxlt_multi_encoder_set_device_slab(jxlt_multi_encoder* enc, int slab, const void* const device_planes[3],
+                                       size_t pitch_bytes, size_t xsize, size_t rows) {
+  if (!enc || slab < 0 || slab >= enc->group.world) return JXLT_ERR_INVALID_ARGUMENT;
+  const int rc = jxlt_image_set_device(enc->ctx[slab], device_planes, pitch_bytes, xsize, rows);
+  if (rc != JXLT_OK) {
+    enc->error = jxlt_last_error(enc->ctx[slab]);
+    return rc;
+  }
+  enc->slab_rows[slab] = rows;
+  enc->resident_xsize = xsize;
+  return JXLT_OK;
+}
+
+int jxlt_multi_encoder_encode_resident(jxlt_multi_encoder* enc, size_t xsize, size_t ysize, float distance,
+                                       const uint8_t** bytes, size_t* size) {
+  if (!enc || !bytes || !size) return JXLT_ERR_INVALID_ARGUMENT;
+  for (int r = 0; r < enc->group.world; ++r) {
+    size_t y0, y1;
+    jxlt::ShardRows(ysize, enc->group.world, r, &y0, &y1);
+    if (y1 > y0 && (enc->slab_rows[r] != y1 - y0 || enc->resident_xsize != xsize)) {
+      enc->error = "slab " + std::to_string(r) + " was not set with the rows jxlt_shard_rows gives for this frame";
+      return JXLT_ERR_INVALID_ARGUMENT;
+    }
+  }
+  enc->source = jxlt_multi_encoder::kResident;
+  enc->xsize = xsize;
+  enc->ysize = ysize;
+  enc->distance = distance;
+  return jxlt::RunJob(enc, bytes, size);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One process per GPU: the region is a POSIX shared-memory segment.
+int jxlt_shard_group_open(const char* shm_name, int rank, int world, size_t output_capacity, size_t max_sections,
+                          jxlt_shard_group** out) {
+  if (!out) return JXLT_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (!shm_name || shm_name[0] != '/' || world < 1 || world > jxlt::kMaxWorld || rank < 0 || rank >= world ||
+      output_capacity == 0 || max_sections == 0)
+    return JXLT_ERR_INVALID_ARGUMENT;
+  const size_t bytes = jxlt::ControlBytes() + jxlt::TablesBytes(max_sections) + ((output_capacity + 4095) & ~size_t(4095));
+  int fd;
+  if (rank == 0) {
+    shm_unlink(shm_name);  // a stale segment of a run that died
+    fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, static_cast<off_t>(bytes)) != 0) {
+      if (fd >= 0) close(fd);
+      return JXLT_ERR_OUT_OF_MEMORY;
+    }
+  } else {
+    fd = shm_open(shm_name, O_RDWR, 0600);
+    if (fd < 0) return JXLT_ERR_INVALID_ARGUMENT;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || static_cast<size_t>(st.st_size) != bytes) {
+      close(fd);
+      return JXLT_ERR_INVALID_ARGUMENT;  // opened with other parameters than rank 0's
+    }
+  }
+  void* map = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (map == MAP_FAILED) {
+    if (rank == 0) shm_unlink(shm_name);
+    return JXLT_ERR_OUT_OF_MEMORY;
+  }
+  jxlt_shard_group* g = new jxlt_shard_group;
+  g->base = static_cast<uint8_t*>(map);
+  g->bytes = bytes;
+  g->ctl = reinterpret_cast<jxlt::Control*>(g->base);
+  g->rank = rank;
+  g->world = world;
+  g->shm = true;
+  g->name = shm_name;
+  if (rank == 0) {
+    jxlt::InitControl(g->ctl, world, max_sections, (output_capacity + 4095) & ~size_t(4095), bytes);
+  } else if (g->ctl->magic != jxlt::kMagic || g->ctl->world != static_cast<uint32_t>(world)) {
+    munmap(map, bytes);
+    delete g;
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  *out = g;
+  return JXLT_OK;
+}
+
+void jxlt_shard_group_close(jxlt_shard_group* g) {
+  if (!g) return;
+  if (g->registered) jxlt_pinned_unregister(g->output());
+  if (g->shm) {
+    munmap(g->base, g->bytes);
+    if (g->rank == 0) shm_unlink(g->name.c_str());
+  }
+  delete g;
+}
+
+const char* jxlt_shard_group_last_error(const jxlt_shard_group* g) { return g ? g->error.c_str() : ""; }
+
+int jxlt_shard_encode_ops(jxlt_shard_group* g, const jxlt_slab_ops* ops, size_t xsize, size_t ysize, float distance,
+                          const uint8_t** bytes, size_t* size) {
+  if (!g || !ops || g->rank < 0 || !ops->enqueue || !ops->dc_histogram || !ops->begin_dc_pack || !ops->ac_histogram ||
+      !ops->measure || !ops->write || !ops->finish)
+    return JXLT_ERR_INVALID_ARGUMENT;
+  if (!jxlt::NormalizeDistance(&distance) || xsize == 0 || ysize == 0) return JXLT_ERR_INVALID_ARGUMENT;
+  return jxlt::EncodeShard(g, g->rank, ops, xsize, ysize, distance, bytes, size);
+}
+
+int jxlt_shard_encode(jxlt_shard_group* g, jxlt_context* ctx, size_t xsize, size_t ysize, float distance,
+                      const uint8_t** bytes, size_t* size) {
+  if (!g || !ctx || g->rank < 0) return JXLT_ERR_INVALID_ARGUMENT;
+  if (bytes) *bytes = nullptr;
+  if (size) *size = 0;
+  if (!jxlt::NormalizeDistance(&distance) || xsize == 0 || ysize == 0) return JXLT_ERR_INVALID_ARGUMENT;
+  if (jxlt::NonEmptySlabs(ysize, g->world) <= 1) {
+    // nothing to shard: rank 0 owns the only slab (jxlt_shard_rows) and encodes it the ordinary way; the
+    // other ranks have nothing to do and the control block is not involved
+    if (g->rank != 0) return JXLT_OK;
+    const int rc = jxlt_encode_resident_view(ctx, distance, 0, bytes, size);
+    if (rc != JXLT_OK) g->SetError(std::string("single-device encode failed: ") + jxlt_last_error(ctx));
+    return rc;
+  }
+  if (!g->registered) {
+    // the devices copy their sections straight into the segment: page-lock this process's mapping of it
+    if (jxlt_pinned_register(g->output(), static_cast<size_t>(g->ctl->output_capacity)) != JXLT_OK)
+      return jxlt::Fail(g, JXLT_ERR_NO_DEVICE, "cannot page-lock the shared output area");
+    g->registered = true;
+  }
+  const jxlt_slab_ops ops = jxlt::OpsOf(ctx);
+  return jxlt::EncodeShard(g, g->rank, &ops, xsize, ysize, distance, bytes, size);
+}
+
+}  // extern "C"

@@ -157,6 +157,9 @@ int jxlt_encode_resident(jxlt_context* ctx, float distance, int num_threads, uin
     return buf;
   }, out_size);
   if (rc != JXLT_OK) {
+    // copies into `buf` may already be queued on the context's copy stream: let them land before the
+    // memory goes back to the heap
+    if (buf) (void)jxlt_synchronize(ctx);
     free(buf);
     return rc;
   }

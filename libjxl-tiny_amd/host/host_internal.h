@@ -30,6 +30,9 @@ bool ParsePFMHeader(const uint8_t* data, size_t size, size_t* xsize, size_t* ysi
                     size_t* payload_offset);
 bool NormalizeDistance(float* distance);
 void SetStaticConstantEmulation(bool on);  // jxl::EmulateReferenceStaticConstants
+// While that emulation is on: latches the process's first distance and sets it on `ctx` (a context's own
+// jxlt_set_strategy_distance setting is left alone otherwise).
+void ApplyStrategyDistanceEmulation(jxlt_context* ctx, float distance);
 }  // namespace jxlt
 
 #endif  // JXLT_HOST_INTERNAL_H_

@@ -150,34 +150,217 @@ def test_device_packed_sections_equal_host_packed(built, enc, w, h, distance):
     assert a == T.assemble_codestream(T.oracle_hot_path(planes, distance), distance)
 
 
-def test_sharded_slabs_on_one_gpu(built):
-    """SURVEY.md 8(e) on real device contexts: two slabs of whole DC groups encoded by two
-    independent contexts, histograms summed, sections packed per slab and merged -- must equal
-    the single-context codestream of the whole frame (and therefore the oracle's)."""
-    w, h, d = 520, 2048 + 300, 1.0
+def test_multi_encoder_two_contexts_equal_single_device(built):
+    """jxlt_multi_encoder_* (BASELINE config #4 behind the C boundary): ONE frame cut into row slabs of whole
+    DC groups over two device contexts (both on GPU 0 here), histograms summed on the host, every context
+    writing its sections into the one output buffer -- must equal the single-context codestream and the
+    oracle's, from host planes (pageable and page-locked: the pipelined upload), from a raw PFM payload and
+    from slabs that already are in device memory."""
+    import torch
+    w, h, d = 520, 2048 + 2048 + 300, 1.0   # three DC-group rows: slabs of 2 + 1
     planes = T.to_planes(T.synthetic_image(w, h))
-    slabs = [np.ascontiguousarray(planes[:, :2048]), np.ascontiguousarray(planes[:, 2048:])]
-    encs = [built.Encoder(0), built.Encoder(0)]
-    hists = []
-    for e, s in zip(encs, slabs):
-        e.upload(s)
-        e.enqueue(d, 0)
-        hists.append(e.fetch_histograms())
-    ac_h = sum(x[0].astype(np.uint64) for x in hists).astype(np.uint32)
-    dc_h = sum(x[1].astype(np.uint64) for x in hists).astype(np.uint32)
-    ac_t, dc_t = built.build_code_tables(ac_h, dc_h)
-    merged = []
-    for kind, table in ((0, dc_t), (1, ac_t)):
-        parts = [e.pack_sections(kind, table) for e in encs]
-        sizes = np.concatenate([np.diff(p[1]) for p in parts])
-        off = np.zeros(len(sizes) + 1, np.uint64)
-        off[1:] = np.cumsum(sizes)
-        merged.append((np.concatenate([p[0] for p in parts]), off, np.concatenate([p[2] for p in parts])))
-    got = built.finish_frame(w, h, d, ac_h, dc_h, merged[0], merged[1])
-    assert got == built.encode_file(planes, d)
-    assert got == T.assemble_codestream(T.oracle_hot_path(planes, d), d)
-    for e in encs:
-        e.close()
+    want = T.assemble_codestream(T.oracle_hot_path(planes, d), d)
+    me = built.MultiEncoder([0, 0])
+    assert me.encode(planes, d).tobytes() == want
+    pinned, owner = built.pinned_empty((3, h, w + 8))
+    pinned[:, :, :w] = planes
+    assert me.encode(pinned[:, :, :w], d).tobytes() == want
+    assert me.encode(planes, d).tobytes() == want  # reusable
+    payload = T.pfm_payload(planes, big_endian=True)
+    assert me.encode_pfm(payload.view(np.uint8), w, h, True, d).tobytes() == want
+    # slabs resident in device memory
+    t = torch.from_numpy(planes).cuda()
+    for slab in range(2):
+        y0, y1 = built.shard_rows(h, 2, slab)
+        me.set_device_slab(slab, [t[c, y0:].data_ptr() for c in range(3)], w * 4, w, y1 - y0, keepalive=t)
+    assert me.encode_resident(w, h, d).tobytes() == want
+    # a frame of a single DC-group row takes the ordinary path on the first context
+    small = T.to_planes(T.synthetic_image(300, 264))
+    assert me.encode(small, 2.0).tobytes() == T.assemble_codestream(T.oracle_hot_path(small, 2.0), 2.0)
+    assert built.encode_file(planes, d) == want
+    me.close()
+    # three contexts, one of them without rows (two DC-group rows)
+    w2, h2 = 300, 2048 + 100
+    p2 = T.to_planes(T.synthetic_image(w2, h2, seed=5))
+    me3 = built.MultiEncoder([0, 0, 0])
+    assert me3.encode(p2, 0.5).tobytes() == T.assemble_codestream(T.oracle_hot_path(p2, 0.5), 0.5)
+    me3.close()
+
+
+def _shard_rank(rank, world, name, w, h, d, q, barrier):
+    try:
+        import sys
+        sys.path.insert(0, str(T.ROOT / "tests"))
+        pkg = T.product()
+        planes = T.to_planes(T.synthetic_image(w, h))
+        y0, y1 = pkg.shard_rows(h, world, rank)
+        enc = pkg.Encoder(0)
+        if y1 > y0:
+            enc.upload(np.ascontiguousarray(planes[:, y0:y1]))
+        grp = pkg.ShardGroup(name, 0, world, 8 << 20, 4096) if rank == 0 else None
+        barrier.wait()
+        if grp is None:
+            grp = pkg.ShardGroup(name, rank, world, 8 << 20, 4096)
+        out = []
+        for _ in range(2):
+            v = grp.encode(enc, w, h, d)
+            out.append(v.tobytes() if v is not None else None)
+        barrier.wait()
+        grp.close()
+        enc.close()
+        q.put((rank, out))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, "ERROR: %r" % (e,)))
+
+
+def test_shard_group_two_processes_on_one_gpu(built):
+    """jxlt_shard_group_* / jxlt_shard_encode: the one-process-per-GPU form bench.py's ranks use -- two
+    processes (both on GPU 0 here), the output area in POSIX shared memory page-locked by each of them,
+    each process's GPU copying its sections straight into it."""
+    import multiprocessing as mp
+    import os
+    w, h, d = 600, 2048 + 520, 2.0
+    ctx = mp.get_context("spawn")
+    q, barrier = ctx.Queue(), ctx.Barrier(2)
+    name = "/jxlt-gputest-%d" % os.getpid()
+    procs = [ctx.Process(target=_shard_rank, args=(r, 2, name, w, h, d, q, barrier)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    planes = T.to_planes(T.synthetic_image(w, h))
+    want = T.assemble_codestream(T.oracle_hot_path(planes, d), d)
+    assert results[0] == [want, want], results[0] if isinstance(results[0], str) else "codestream differs"
+    assert results[1] == [None, None], results[1]
+
+
+def test_bench_self_launch_two_ranks_on_one_gpu(built):
+    """`python bench.py --gpus 2` without a launcher (what the driver may run): the script starts its two
+    ranks itself; here both on GPU 0 (JXLT_BENCH_ONE_DEVICE).  The sharded codestream must equal the
+    single-GPU one (the bench's own parity gate) and the run must exit 0 with one JSON line."""
+    import json
+    import os
+    import sys
+    env = dict(os.environ, JXLT_BENCH_ONE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, str(T.ROOT / "bench.py"), "--gpus", "2", "--size", "4096", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["parity_gate"]["sharded_equals_single_gpu_codestream"] is True
+    assert "4096x4096" in out["config"]["workload"]
+
+
+def _check_sampled_groups(planes, got, distance, dct8, picks):
+    """Groups (gy, gx) of a full-frame GPU result against the oracle run on the matching 256x256 crops
+    (an AC group depends on nothing outside itself): tokens and side-band grids."""
+    size_y, size_x = planes.shape[1], planes.shape[2]
+    gpr = (size_x + 255) // 256
+    for gy, gx in picks:
+        crop = np.ascontiguousarray(planes[:, gy * 256:(gy + 1) * 256, gx * 256:(gx + 1) * 256])
+        want = T.oracle_hot_path(crop, distance, dct8)
+        assert got.group_tokens[gy * gpr + gx] == want.group_tokens[0], (gy, gx)
+        hb, wb = want.raw_quant.shape
+        bs = (slice(gy * 32, gy * 32 + hb), slice(gx * 32, gx * 32 + wb))
+        assert np.array_equal(got.quant_dc[(slice(None),) + bs], want.quant_dc), (gy, gx)
+        assert np.array_equal(got.raw_quant[bs], want.raw_quant) and np.array_equal(got.strategy[bs], want.strategy)
+        ts = (slice(gy * 4, gy * 4 + want.ytox.shape[0]), slice(gx * 4, gx * 4 + want.ytox.shape[1]))
+        assert np.array_equal(got.ytox[ts], want.ytox) and np.array_equal(got.ytob[ts], want.ytob), (gy, gx)
+
+
+def _lattice(n, k):
+    pts = sorted(set([0, n - 1] + [int(round(i * (n - 1) / (k - 1.0))) for i in range(k)]))
+    return [(gy, gx) for gy in pts for gx in pts]
+
+
+def test_baseline_config2_4096_fixed_dct8(built, enc):
+    """BASELINE config #2 at its stated size: 4096 x 4096, fixed DCT8 strategy.  The whole frame is encoded once;
+    64 groups on an 8 x 8 lattice over the WHOLE frame (corners, last row / column, interior) are compared with
+    the oracle on the matching crops."""
+    planes = T.to_planes(T.synthetic_image(4096, 4096))
+    got = enc.hot_path(planes, 1.0, force_dct8=True)
+    assert (got.strategy == 1).all()
+    _check_sampled_groups(planes, got, 1.0, True, _lattice(16, 8))
+
+
+def test_baseline_config3_8192_full_search(built, enc):
+    """BASELINE config #3 at its stated size: 8192 x 8192, full strategy search + adaptive quantisation;
+    64 groups sampled across the whole frame against the oracle, and the production codestream (device-side
+    histograms + packing) equals the raw-token route's."""
+    import torch
+    size = 8192
+    import bench  # the benchmark's own frame generator (repo root is on sys.path, tests/conftest.py)
+    t = bench.frame_rows_on_device(torch, size, 0, size, 0, torch.device("cuda", 0))
+    planes = t.cpu().numpy()
+    enc.set_device_image([t[c].data_ptr() for c in range(3)], size * 4, size, size, keepalive=t)
+    enc.enqueue(1.0, 0)
+    got = built.HotPathOutput(enc.fetch_raw())
+    _check_sampled_groups(planes, got, 1.0, False, _lattice(32, 8))
+    a = enc.encode_resident(1.0)
+    assert a == enc.encode_resident_raw_tokens(1.0)
+    # the same frame from page-locked host memory with the upload pipelined under the kernels
+    pinned, owner = built.pinned_empty((3, size, size))
+    pinned[...] = planes
+    enc.attach_host(pinned)
+    assert enc.encode_resident(1.0) == a
+    payload, owner2 = built.pinned_empty((size * size * 3,))
+    payload[...] = T.pfm_payload(planes)
+    enc.attach_host_pfm(payload, size, size)
+    assert enc.encode_resident(1.0) == a
+
+
+def test_attach_host_small_frames(built, enc):
+    """jxlt_image_attach_host*: frames of one and of several DC-group rows, odd sizes, pitch != width,
+    big-endian payload; debug intermediates through the slab-wise launches; refusal of pageable memory."""
+    for w, h, d in [(200, 137, 1.0), (300, 2048 + 77, 2.0), (2100, 4100, 4.0)]:
+        planes = T.to_planes(T.synthetic_image(w, h, seed=w))
+        want = T.oracle_hot_path(planes, d)
+        pinned, owner = built.pinned_empty((3, h, w + 16))
+        pinned[:, :, :w] = planes
+        enc.attach_host(pinned[:, :, :w])
+        assert enc.encode_resident(d) == T.assemble_codestream(want, d), (w, h)
+        payload, owner2 = built.pinned_empty((w * h * 3,))
+        payload[...] = T.pfm_payload(planes, big_endian=True)
+        enc.attach_host_pfm(payload, w, h, big_endian=True)
+        enc.enqueue(d, built.FLAG_DEBUG_DUMP)
+        fr = enc.fetch_raw()
+        yb, xb = fr.ysize_blocks, fr.xsize_blocks
+
+        def get(what, shape):
+            a = np.empty(shape, np.float32)
+            enc._check(enc._L.jxlt_debug_fetch(enc._ctx, what, a.ctypes.data, a.nbytes), "jxlt_debug_fetch")
+            return a
+        dbg = (np.stack([get(c, (yb * 8, xb * 8)) for c in range(3)]), get(3, (yb, xb)), get(4, (yb, xb)),
+               get(5, (yb // 2 + 1, xb // 2 + 1, 8)))
+        assert T.compare_results(want, built.HotPathOutput(fr, dbg), "oracle", "gpu") == [], (w, h)
+    with pytest.raises(built.JxlTinyError, match="page-locked"):
+        enc.attach_host(T.to_planes(T.synthetic_image(64, 64)))
+
+
+def test_context_strategy_distance_survives_host_entry_points(built, enc):
+    """jxlt_set_strategy_distance is a persistent per-context setting (include/jxl_tiny_amd.h): the host-level
+    entry points must not reset it while the process-wide emulation flag is off."""
+    planes = T.to_planes(T.synthetic_image(200, 137))
+    T.set_strategy_distance(16.0)
+    try:
+        want = T.assemble_codestream(T.oracle_hot_path(planes, 0.5), 0.5)
+    finally:
+        T.set_strategy_distance(0.0)
+    plain = T.assemble_codestream(T.oracle_hot_path(planes, 0.5), 0.5)
+    assert want != plain
+    enc.upload(planes)
+    enc.set_strategy_distance(16.0)
+    try:
+        assert enc.encode_resident(0.5) == want
+        assert enc.encode_resident(0.5, copy=False).tobytes() == want
+    finally:
+        enc.set_strategy_distance(0.0)
+    assert enc.encode_resident(0.5) == plain
 
 
 def test_hardware_shortcuts_are_exact_on_this_gpu():
@@ -375,6 +558,12 @@ def test_frame_batch_encoder(built):
     for i in range(len(sizes)):
         assert got[i] == want[i], "frame %d %s" % (i, sizes[i])
     assert again == want[:2]
+    # the multi-device form (BASELINE config #5's shape: one queue, lanes on every listed GPU; here GPU 0 twice)
+    enc = built.BatchEncoder(lanes=2, devices=[0, 0])
+    got = enc.encode(frames, 2.0)
+    enc.close()
+    for i in range(len(sizes)):
+        assert got[i] == want[i], "multi-device frame %d %s" % (i, sizes[i])
     # error behaviour: a frame without a source is rejected, the others are still encoded
     enc = built.BatchEncoder(0, lanes=2)
     descs, k = enc.describe(frames[:2])

@@ -1,58 +1,111 @@
-"""One frame sharded over two processes (world_size 2, gloo, CPU only): the orchestration of
-libjxl-tiny_amd/sharded.py -- histogram all_reduce, identical code tables, per-rank section
-packing, gather, assembly on rank 0 -- must give byte-for-byte the single-process codestream.
+"""One frame sharded over several participants -- the product's C-level protocol
+(libjxl-tiny_amd/host/frame_shards.cc: jxlt_shard_group_* / jxlt_shard_encode_ops) on CPU.
 
-Here the per-slab "device" is replaced by test infrastructure (oracle tokens, oracle DC
-tokeniser, reference bit packer) so that the test runs without a GPU; the GPU variant
-(test_gpu_parity.py::test_sharded_slabs_on_one_gpu) uses real device contexts."""
+The protocol (histogram sum on participant 0, code tables handed back, every participant's
+sections placed in its byte range of ONE shared output buffer, header + TOC in front) is the
+same code the GPU ranks of bench.py run; only the per-slab "device" is replaced through the
+jxlt_slab_ops hook by test infrastructure (oracle tokens, oracle DC tokeniser, reference bit
+packer), so the test needs no GPU.  Expected bytes: the oracle's whole-frame codestream.
+
+* world_size 2, two processes, torch.distributed/gloo for rendezvous + barrier (the launch
+  shape of `torchrun bench.py --gpus 2`);
+* 3 and 8 participants as threads of one process attached to one segment (uneven slabs,
+  participants without rows)."""
+import ctypes as C
 import multiprocessing as mp
 import os
 import socket
+import threading
 
 import numpy as np
 import pytest
 
 import jxlt_testlib as T
 
-W, H, D = 72, 2048 + 2048 + 40, 1.0  # three DC groups tall -> slabs of 2 + 1 DC groups
+W, H, D = 72, 2048 + 2048 + 40, 1.0  # three DC-group rows
 
 
 class OracleSlab:
-    """Slab 'encoder' built from the oracle + reference packer (tests only)."""
+    """Slab operations (jxlt_slab_ops) built from the oracle + the reference packer (tests only)."""
 
-    def __init__(self, planes, distance):
-        self.res = T.oracle_hot_path(planes, distance)
+    def __init__(self, pkg, planes, distance):
+        self.pkg, self.planes, self.distance = pkg, planes, distance
+        fn = pkg._SLAB_FN
+        self.ops = pkg.SlabOps()
+        self._cb = {k: fn[k](getattr(self, "_" + k)) for k in fn}  # keep the thunks alive
+        for k, cb in self._cb.items():
+            setattr(self.ops, k, cb)
+
+    def _enqueue(self, _self, params):
+        assert abs(params.contents.distance - self.distance) < 1e-7
+        self.res = T.oracle_hot_path(self.planes, self.distance)
         self.dc_records = T.oracle_dc_records(self.res)
+        return 0
 
-    def histograms(self):
-        ac = T.token_histogram(self.res.all_tokens())
-        dc = sum((T.token_histogram(r) for r in self.dc_records))
-        return ac, dc
+    def _dc_histogram(self, _self, out):
+        self.dc_hist = np.ascontiguousarray(sum((T.token_histogram(r) for r in self.dc_records)), np.uint32)
+        out[0] = self.dc_hist.ctypes.data_as(C.POINTER(C.c_uint32))
+        return 0
 
-    def pack(self, ac_table, dc_table):
-        def pk(sections, table):
-            packed = T.pack_sections_python(sections, table)
-            data = np.frombuffer(b"".join(p[0] for p in packed), np.uint8)
+    def _begin_dc_pack(self, _self, table):
+        self.dc_table = np.ctypeslib.as_array(table, shape=(4096,)).copy()
+        return 0
+
+    def _ac_histogram(self, _self, out):
+        self.ac_hist = np.ascontiguousarray(T.token_histogram(self.res.all_tokens()), np.uint32)
+        out[0] = self.ac_hist.ctypes.data_as(C.POINTER(C.c_uint32))
+        return 0
+
+    def _measure(self, _self, table, dc, ac):
+        ac_table = np.ctypeslib.as_array(table, shape=(4096,)).copy()
+        self.packed, self.keep = [], []
+        for sections, tab, dst in ((self.dc_records, self.dc_table, dc), (self.res.group_tokens, ac_table, ac)):
+            packed = T.pack_sections_python(sections, tab)
             off = np.zeros(len(packed) + 1, np.uint64)
             off[1:] = np.cumsum([len(p[0]) for p in packed])
-            return data, off, np.array([p[1] for p in packed], np.uint32)
-        return pk(self.dc_records, dc_table), pk(self.res.group_tokens, ac_table)
+            bits = np.array([p[1] for p in packed], np.uint32)
+            self.packed.append(b"".join(p[0] for p in packed))
+            self.keep += [off, bits]
+            dst.contents.bytes = None
+            dst.contents.section_offset = off.ctypes.data_as(C.POINTER(C.c_uint64))
+            dst.contents.section_bits = bits.ctypes.data_as(C.POINTER(C.c_uint32))
+            dst.contents.num_sections = len(packed)
+        return 0
+
+    def _write(self, _self, dc_dst, ac_dst):
+        C.memmove(dc_dst, self.packed[0], len(self.packed[0]))
+        C.memmove(ac_dst, self.packed[1], len(self.packed[1]))
+        return 0
+
+    def _finish(self, _self):
+        return 0
 
 
-def _worker(rank, world, port, q):
+def _participant(pkg, name, rank, world, w, h, d, after_create=None):
+    planes = T.to_planes(T.synthetic_image(w, h))
+    y0, y1 = pkg.shard_rows(h, world, rank)
+    grp = pkg.ShardGroup(name, rank, world, 1 << 20, 4096) if rank == 0 else None
+    if after_create:
+        after_create()
+    if grp is None:
+        grp = pkg.ShardGroup(name, rank, world, 1 << 20, 4096)
+    slab = OracleSlab(pkg, np.ascontiguousarray(planes[:, y0:y1]), d)
+    out = []
+    for _ in range(2):  # two frames through the same group: the control block is reusable
+        view = grp.encode_ops(slab.ops, w, h, d)
+        out.append(view.tobytes() if view is not None else None)
+    if after_create:
+        after_create()  # rank 0 must not unlink the segment while others still use it
+    grp.close()
+    return out
+
+
+def _worker(rank, world, port, name, q):
     try:
         import torch.distributed as dist
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        pkg = T.product()
-        import importlib.util
-        spec = importlib.util.spec_from_file_location("jxlt_sharded", str(T.PKG / "sharded.py"))
-        sharded = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(sharded)
-        planes = T.to_planes(T.synthetic_image(W, H))
-        y0, y1 = sharded.slab_rows(H, world)[rank]
-        slab = OracleSlab(np.ascontiguousarray(planes[:, y0:y1]), D)
-        out = sharded.encode_sharded(slab, sharded.TorchComm(dist), W, H, D, pkg)
+        out = _participant(T.product(), name, rank, world, W, H, D, after_create=dist.barrier)
         q.put((rank, out))
         dist.barrier()
         dist.destroy_process_group()
@@ -66,26 +119,88 @@ def test_two_process_sharded_frame_equals_single_process(built):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    name = "/jxlt-test-%d" % os.getpid()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q)) for r in range(2)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=300) for _ in range(2))
     for p in procs:
         p.join(timeout=60)
-    assert results[1] is None
     assert not isinstance(results[0], str), results[0]
+    assert not isinstance(results[1], str), results[1]
+    assert results[1] == [None, None]
     planes = T.to_planes(T.synthetic_image(W, H))
     want = T.assemble_codestream(T.oracle_hot_path(planes, D), D)
-    assert results[0] == want
+    assert results[0] == [want, want]
 
 
-def test_slab_rows_cover_whole_dc_groups():
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("jxlt_sharded", str(T.PKG / "sharded.py"))
-    sharded = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(sharded)
-    for h, world in [(16384, 8), (16384, 3), (5000, 2), (100, 4), (2049, 2)]:
-        rows = sharded.slab_rows(h, world)
+@pytest.mark.parametrize("world,h", [(3, 2048 + 2048 + 40), (8, 2048 + 300), (2, 2048 * 2)])
+def test_threads_attached_to_one_segment(built, world, h):
+    """Uneven slabs (3 participants, 3 DC-group rows of which the last is short), participants
+    without rows (8 participants, 2 rows), exact multiples."""
+    w, d = 40, 2.0
+    name = "/jxlt-test-thr-%d-%d" % (os.getpid(), world)
+    barrier = threading.Barrier(world)
+    results = [None] * world
+
+    def run(rank):
+        try:
+            results[rank] = _participant(built, name, rank, world, w, h, d, after_create=barrier.wait)
+        except Exception as e:  # pragma: no cover
+            results[rank] = "ERROR: %r" % (e,)
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    planes = T.to_planes(T.synthetic_image(w, h))
+    want = T.assemble_codestream(T.oracle_hot_path(planes, d), d)
+    assert results[0] == [want, want], results[0] if isinstance(results[0], str) else "codestream differs"
+    for r in range(1, world):
+        assert results[r] == [None, None], results[r]
+
+
+def test_shard_rows_cover_whole_dc_groups(built):
+    for h, world in [(16384, 8), (16384, 3), (5000, 2), (100, 4), (2049, 2), (16384, 64)]:
+        rows = [built.shard_rows(h, world, r) for r in range(world)]
         assert rows[0][0] == 0 and rows[-1][1] == h
         for (a0, a1), (b0, b1) in zip(rows, rows[1:]):
             assert a1 == b0 and (a1 % 2048 == 0 or a1 == h)
+        sizes = [(y1 - y0 + 2047) // 2048 for y0, y1 in rows]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    assert built.shard_rows(1000, 4, 0) == (0, 1000)  # a single DC-group row belongs to participant 0
+
+
+def test_failures_propagate_instead_of_hanging(built):
+    """A participant whose slab operation fails must release the others with an error."""
+    world, w, h, d = 2, 40, 4096, 1.0
+    name = "/jxlt-test-fail-%d" % os.getpid()
+    barrier = threading.Barrier(world)
+    errors = [None] * world
+
+    def run(rank):
+        planes = T.to_planes(T.synthetic_image(w, h))
+        y0, y1 = built.shard_rows(h, world, rank)
+        grp = built.ShardGroup(name, rank, world, 1 << 20, 4096) if rank == 0 else None
+        barrier.wait()
+        if grp is None:
+            grp = built.ShardGroup(name, rank, world, 1 << 20, 4096)
+        slab = OracleSlab(built, np.ascontiguousarray(planes[:, y0:y1]), d)
+        if rank == 1:
+            slab._cb["ac_histogram"] = built._SLAB_FN["ac_histogram"](lambda _s, _o: -5)
+            slab.ops.ac_histogram = slab._cb["ac_histogram"]
+        try:
+            grp.encode_ops(slab.ops, w, h, d)
+        except built.JxlTinyError as e:
+            errors[rank] = str(e)
+        barrier.wait()
+        grp.close()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert errors[0] is not None and errors[1] is not None, errors
