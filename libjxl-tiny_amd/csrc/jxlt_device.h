@@ -406,20 +406,12 @@ JXLT_DI void octet_exchange(float& a, float& b, int l) {
 #define JXLT_LDS_TRANSPOSE 1
 #endif
 constexpr int kTransposePitch = 72;
-#ifdef HIPSIM_HIP_RUNTIME_H_
-// CPU execution model: lanes are fibers, so "in order within the wave" has to be made explicit --
-// a butterfly of dummy exchanges synchronises exactly the eight lanes of the octet (octets may
-// have diverged, a wave-wide barrier would deadlock the model).
-#define JXLT_OCTET_SYNC()                                         \
-  do {                                                            \
-    (void)__shfl_xor(0, 1);                                       \
-    (void)__shfl_xor(0, 2);                                       \
-    (void)__shfl_xor(0, 4);                                       \
-  } while (0)
-#else
 // No instruction: the wave's LDS operations execute in order.  What has to be stopped is the
 // compiler -- the stores and the loads of a transpose go through different types (float / float4),
 // which type-based alias analysis treats as independent -- hence the memory clobber.
+// (An execution model in which lanes are not lock-stepped defines its own JXLT_OCTET_SYNC before
+// including this header: tests/hipsim does.)
+#ifndef JXLT_OCTET_SYNC
 #define JXLT_OCTET_SYNC()                  \
   do {                                     \
     asm volatile("" ::: "memory");         \

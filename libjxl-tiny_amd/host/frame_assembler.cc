@@ -29,13 +29,12 @@ constexpr size_t kNumACPreClusters = 64;  // static_entropy_codes.h:161
 constexpr size_t kNumACContexts = 1980;   // ac_context.h:76-77
 constexpr size_t kNumTreeContexts = 6;    // enc_frame.cc:179
 
-float QuantDC(float distance) {  // enc_frame.cc:95-102
-  const float kDcQuantPow = 0.57f;
-  const float kDcQuant = 1.12f;
-  const float kDcMul = 2.9;
-  float effective_dist = kDcMul * std::pow(distance / kDcMul, kDcQuantPow);
-  effective_dist = Clamp1(effective_dist, 0.5f * distance, distance);
-  return std::min(kDcQuant / effective_dist, 50.f);
+// DC quantiser for a distance (enc_frame.cc:95-102): 1.12 / d_eff with d_eff = 2.9 (d / 2.9)^0.57 -- the DC
+// quantisation loosens more slowly than the distance above 2.9 -- kept inside [d / 2, d]; at most 50.
+float QuantDC(float distance) {
+  const float knee = 2.9f;
+  const float softened = knee * std::pow(distance / knee, 0.57f);
+  return std::min(1.12f / Clamp1(softened, 0.5f * distance, distance), 50.f);
 }
 
 template <typename F>
@@ -226,63 +225,62 @@ void OptimizeSections(const std::vector<RawSection>& raw, size_t num_histograms,
   });
 }
 
-void WriteFrameHeader(uint32_t x_qm_scale, uint32_t epf_iters, jxl::BitWriter* writer) {
-  // enc_frame.cc:426-457
-  writer->Write(1, 0);    // not all default
-  writer->Write(2, 0);    // regular frame
-  writer->Write(1, 0);    // vardct
-  writer->Write(2, 2);    // flags selector bits (17 .. 272)
-  writer->Write(8, 111);  // skip adaptive dc flag (128)
-  writer->Write(2, 0);    // no upsampling
-  writer->Write(3, x_qm_scale);
-  writer->Write(3, 2);  // b_qm_scale
-  writer->Write(2, 0);  // one pass
-  writer->Write(1, 0);  // no custom frame size or origin
-  writer->Write(2, 0);  // replace blend mode
-  writer->Write(1, 1);  // last frame
-  writer->Write(2, 0);  // no name
-  if (epf_iters == 2) {
-    writer->Write(1, 1);  // default loop filter
-  } else {
-    writer->Write(1, 0);  // not default loop filter
-    writer->Write(1, 0);  // no gaborish
-    writer->Write(2, epf_iters);
-    if (epf_iters > 0) {
-      writer->Write(1, 0);  // default epf sharpness
-      writer->Write(1, 0);  // default epf weights
-      writer->Write(1, 0);  // default epf sigma
-    }
-    writer->Write(2, 0);  // no loop filter extensions
-  }
-  writer->Write(2, 0);  // no frame header extensions
+// A run of fixed-width header fields.
+struct Field {
+  uint8_t bits;
+  uint32_t value;
+};
+template <size_t N>
+void WriteFields(const Field (&fields)[N], jxl::BitWriter* writer) {
+  for (const Field& f : fields) writer->Write(f.bits, f.value);
 }
 
-void WriteQuantScales(int global_scale, int quant_dc, jxl::BitWriter* writer) {
-  // enc_frame.cc:459-486
-  if (global_scale < 2049) {
-    writer->Write(2, 0);
-    writer->Write(11, global_scale - 1);
-  } else if (global_scale < 4097) {
-    writer->Write(2, 1);
-    writer->Write(11, global_scale - 2049);
-  } else if (global_scale < 8193) {
-    writer->Write(2, 2);
-    writer->Write(12, global_scale - 4097);
-  } else {
-    writer->Write(2, 3);
-    writer->Write(16, global_scale - 8193);
+// JPEG XL "U32" with four direct-offset branches: selector s (2 bits) when value < base[s] + 2^bits[s],
+// then value - base[s] in bits[s] bits.
+void WriteU32(uint32_t value, const uint32_t (&base)[4], const uint8_t (&bits)[4], jxl::BitWriter* writer) {
+  for (uint32_t s = 0; s < 4; ++s) {
+    if (s == 3 || value < base[s] + (1u << bits[s])) {
+      writer->Write(2, s);
+      writer->Write(bits[s], value - base[s]);
+      return;
+    }
   }
-  if (quant_dc == 16) {
-    writer->Write(2, 0);
-  } else if (quant_dc < 33) {
-    writer->Write(2, 1);
-    writer->Write(5, quant_dc - 1);
-  } else if (quant_dc < 257) {
-    writer->Write(2, 2);
-    writer->Write(8, quant_dc - 1);
+}
+
+// Frame header of a single regular VarDCT frame (the field values of enc_frame.cc:426-457): all-default flag
+// off; frame type 0; VarDCT; flags = 128 (skip adaptive DC smoothing), coded as selector 2 + (128 - 17);
+// no upsampling; the two colour-channel quant-matrix scales; one pass; no crop; replace blending; last
+// frame; no name; then the restoration filter: default (gaborish off is NOT default, so only epf_iters == 2
+// may use the shortcut), else gaborish off + the edge-preserving filter's iteration count with default
+// parameters; no extensions anywhere.
+void WriteFrameHeader(uint32_t x_qm_scale, uint32_t epf_iters, jxl::BitWriter* writer) {
+  const Field front[] = {{1, 0}, {2, 0}, {1, 0}, {2, 2}, {8, 128 - 17}, {2, 0}, {3, x_qm_scale}, {3, 2},
+                         {2, 0}, {1, 0}, {2, 0}, {1, 1}, {2, 0}};
+  WriteFields(front, writer);
+  if (epf_iters == 2) {
+    writer->Write(1, 1);
   } else {
-    writer->Write(2, 3);
-    writer->Write(16, quant_dc - 1);
+    const Field filter[] = {{1, 0}, {1, 0}, {2, epf_iters}};
+    WriteFields(filter, writer);
+    if (epf_iters != 0) writer->Write(3, 0);  // sharpness, weights, sigma: three "default" flags
+    writer->Write(2, 0);
+  }
+  writer->Write(2, 0);
+}
+
+// Quantiser scales of DCGlobal (values of enc_frame.cc:459-486): global_scale as U32(1 + u(11), 2049 + u(11),
+// 4097 + u(12), 8193 + u(16)); quant_dc as U32(16, 1 + u(5), 1 + u(8), 1 + u(16)).
+void WriteQuantScales(int global_scale, int quant_dc, jxl::BitWriter* writer) {
+  static const uint32_t kScaleBase[4] = {1, 2049, 4097, 8193};
+  static const uint8_t kScaleBits[4] = {11, 11, 12, 16};
+  WriteU32(static_cast<uint32_t>(global_scale), kScaleBase, kScaleBits, writer);
+  if (quant_dc == 16) {
+    writer->Write(2, 0);  // the constant branch
+  } else {
+    const uint32_t sel = quant_dc < 33 ? 1 : quant_dc < 257 ? 2 : 3;
+    static const uint8_t kDcBits[4] = {0, 5, 8, 16};
+    writer->Write(2, sel);
+    writer->Write(kDcBits[sel], static_cast<uint32_t>(quant_dc - 1));
   }
 }
 
@@ -299,46 +297,43 @@ void WriteContextTree(size_t num_dc_groups, jxl::BitWriter* writer) {  // enc_fr
   for (const Token& t : tokens) WriteToken(t.context, t.value, code, writer);
 }
 
+// DCGlobal (enc_frame.cc:505-522): default DC dequantisation, the quantiser scales, an explicit block context
+// map without DC / quant-field thresholds (the compact 39-entry map), default chroma-from-luma base, the global
+// modular tree, and the DC code itself (no LZ77 either side).
 void WriteDCGlobal(const DistanceParams& distp, size_t num_dc_groups, const EntropyCode& dc_code,
-                   jxl::BitWriter* writer) {  // enc_frame.cc:505-522
-  writer->Write(1, 1);  // default dequant dc
+                   jxl::BitWriter* writer) {
+  writer->Write(1, 1);
   WriteQuantScales(distp.global_scale, distp.quant_dc, writer);
-  writer->Write(1, 0);   // non-default BlockCtxMap
-  writer->Write(16, 0);  // no dc ctx, no qft
+  const Field block_ctx[] = {{1, 0}, {16, 0}};
+  WriteFields(block_ctx, writer);
   WriteStaticContextMap(JXLT_kCompactBlockContextMap, 39, writer);
-  writer->Write(1, 1);  // default DC camp
+  writer->Write(1, 1);
   WriteContextTree(num_dc_groups, writer);
-  writer->Write(1, 0);  // no lz77
+  writer->Write(1, 0);
   WriteEntropyCode(dc_code, writer);
 }
 
+// ACGlobal (enc_frame.cc:524-534): default quantisation matrices, one histogram set (its index field is
+// ceil(log2(num_groups)) bits wide), default coefficient orders (selector 3, 13 zero bits), no LZ77, the AC code.
 void WriteACGlobal(size_t num_groups, const EntropyCode& ac_code, jxl::BitWriter* writer) {
-  // enc_frame.cc:524-534
-  writer->Write(1, 1);  // all default quant matrices
-  const size_t num_histo_bits = CeilLog2Nonzero(num_groups);
-  if (num_histo_bits != 0) writer->Write(num_histo_bits, 0);
-  writer->Write(2, 3);
-  writer->Write(13, 0);  // all default coeff order
-  writer->Write(1, 0);   // no lz77
+  writer->Write(1, 1);
+  if (const size_t index_bits = CeilLog2Nonzero(num_groups)) writer->Write(index_bits, 0);
+  const Field orders[] = {{2, 3}, {13, 0}, {1, 0}};
+  WriteFields(orders, writer);
   WriteEntropyCode(ac_code, writer);
 }
 
+// Table of contents (enc_frame.cc:572-595): no permutation, then every section's byte size as
+// U32(u(10), 1024 + u(14), 17408 + u(22), 4211712 + u(30)), byte aligned before and after.  Sections of
+// 4 MiB and more are refused like the reference does (its assert at :577).
 bool WriteTOCSizes(const std::vector<size_t>& section_sizes, jxl::BitWriter* output) {
-  // enc_frame.cc:572-595
-  output->Write(1, 0);  // no permutation
+  static const uint8_t kSizeBits[4] = {10, 14, 22, 30};
+  static const uint32_t kSizeBase[4] = {0, 1u << 10, (1u << 10) + (1u << 14), (1u << 10) + (1u << 14) + (1u << 22)};
+  output->Write(1, 0);
   output->ZeroPadToByte();
-  for (const size_t section_size : section_sizes) {
-    if (section_size >= (1u << 22)) return false;
-    size_t offset = 0;
-    static const size_t kBits[4] = {10, 14, 22, 30};
-    for (size_t i = 0; i < 4; ++i) {
-      if (section_size < offset + (1u << kBits[i])) {
-        output->Write(2, i);
-        output->Write(kBits[i], section_size - offset);
-        break;
-      }
-      offset += (1u << kBits[i]);
-    }
+  for (const size_t bytes : section_sizes) {
+    if (bytes >= (1u << 22)) return false;
+    WriteU32(static_cast<uint32_t>(bytes), kSizeBase, kSizeBits, output);
   }
   output->ZeroPadToByte();
   return true;
@@ -353,33 +348,27 @@ bool WriteTOC(const std::vector<jxl::BitWriter>& sections, jxl::BitWriter* outpu
 
 }  // namespace
 
-DistanceParams ComputeDistanceParams(float distance) {  // enc_frame.cc:115-156
-  DistanceParams p;
-  p.distance = distance;
-  constexpr int kGlobalScaleDenom = 1 << 16;
-  constexpr int kGlobalScaleNumerator = 4096;
-  constexpr float kAcQuant = 0.8f;
-  constexpr float kQuantFieldTarget = 5;
-  float quant_dc = QuantDC(distance);
-  float scale = kGlobalScaleDenom * kAcQuant / (distance * kQuantFieldTarget);
-  scale = Clamp1(scale, 1.0f, 1.0f * (1 << 15));
-  int scaled_quant_dc = static_cast<int>(quant_dc * kGlobalScaleNumerator * 1.6);
-  p.global_scale = Clamp1(static_cast<int>(scale), 1, scaled_quant_dc);
-  p.scale = p.global_scale * (1.0f / kGlobalScaleDenom);
-  p.inv_scale = 1.0f / p.scale;
-  p.quant_dc = static_cast<int>(quant_dc / p.scale + 0.5f);
-  p.quant_dc = Clamp1(p.quant_dc, 1, 1 << 16);
-  p.scale_dc = p.quant_dc * p.scale;
-  p.x_qm_scale = 2;
-  const float x_qm_scale_steps[2] = {1.25f, 9.0f};
-  for (float step : x_qm_scale_steps)
-    if (distance > step) p.x_qm_scale++;
-  if (distance < 0.299f) p.x_qm_scale++;
-  constexpr float kEpfThresholds[3] = {0.7, 1.5, 4.0};
-  p.epf_iters = 0;
-  for (size_t i = 0; i < 3; i++)
-    if (distance >= kEpfThresholds[i]) p.epf_iters++;
-  return p;
+// The scalars the rest of the encoder derives from the butteraugli distance (enc_frame.cc:104-156), in float
+// arithmetic exactly as there:
+//   AC:  the quant field aims at 5, the AC scale at 0.8 / distance -> global_scale = 65536 * 0.8 / (5 d), kept in
+//        [1, 32768] and below 1.6 * 4096 * (DC quantiser), as an integer; scale = global_scale / 65536
+//   DC:  quant_dc = round(DC quantiser / scale) in [1, 65536]
+//   X channel matrix scale 2, +1 above d = 1.25, +1 above d = 9, +1 below d = 0.299
+//   edge-preserving filter iterations: one per threshold 0.7 / 1.5 / 4.0 reached
+DistanceParams ComputeDistanceParams(float distance) {
+  DistanceParams out;
+  out.distance = distance;
+  const float dc_quantiser = QuantDC(distance);
+  const float ideal = Clamp1(65536 * 0.8f / (distance * 5.0f), 1.0f, 32768.0f);
+  const int ceiling = static_cast<int>(dc_quantiser * 4096 * 1.6);
+  out.global_scale = Clamp1(static_cast<int>(ideal), 1, ceiling);
+  out.scale = out.global_scale * (1.0f / 65536);
+  out.inv_scale = 1.0f / out.scale;
+  out.quant_dc = Clamp1(static_cast<int>(dc_quantiser / out.scale + 0.5f), 1, 65536);
+  out.scale_dc = out.quant_dc * out.scale;
+  out.x_qm_scale = 2u + (distance > 1.25f) + (distance > 9.0f) + (distance < 0.299f);
+  out.epf_iters = 0u + (distance >= 0.7f) + (distance >= 1.5f) + (distance >= 4.0f);
+  return out;
 }
 
 std::vector<uint8_t> DcGroupRecords(const FrameView& f, size_t index) {

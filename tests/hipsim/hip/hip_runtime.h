@@ -379,4 +379,15 @@ inline T atomicAdd(T* p, T v) {
   return old;
 }
 
+// The product's octet transposes rely on a wave's LDS operations executing in program order
+// (jxlt_device.h: JXLT_OCTET_SYNC is a compiler fence there).  Here lanes are fibers, so "in order
+// within the wave" has to be made explicit: a butterfly of dummy exchanges synchronises exactly the
+// eight lanes of the octet (octets may have diverged, a wave-wide barrier would deadlock the model).
+#define JXLT_OCTET_SYNC()     \
+  do {                        \
+    (void)__shfl_xor(0, 1);   \
+    (void)__shfl_xor(0, 2);   \
+    (void)__shfl_xor(0, 4);   \
+  } while (0)
+
 #endif  // HIPSIM_HIP_RUNTIME_H_
