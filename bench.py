@@ -109,6 +109,11 @@ def frame_rows_on_device(torch, size, y0, y1, seed, device):
     return out
 
 
+def make_frame_on_device(torch, size, seed, device):
+    """The whole size x size frame (tools/ use this)."""
+    return frame_rows_on_device(torch, size, 0, size, seed, device)
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -199,6 +199,9 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
   if (!empty && (rc = (call)) != JXLT_OK) return Fail(g, rc, what)
 
   SLAB(ops->enqueue(ops->self, &params), "device pipeline failed");
+  // participant 0 builds both codes: its helper threads (entropy_coder.h) stop sleeping now and spin for
+  // the histograms -- a wake-up would cost as much as half of a code construction
+  if (rank == 0) WarmCodeConstruction(0.0, 8.0);
 
   // ---- DC histograms -> DC code (participant 0) -> every participant packs its DC-group sections
   const uint32_t* h = nullptr;

@@ -24,7 +24,7 @@ def main():
     size = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
     pkg = __graft_entry__.load_package()
     dev = torch.device("cuda", 0)
-    frame = bench.make_frame_on_device(torch, size, 0, dev)
+    frame = bench.frame_rows_on_device(torch, size, 0, size, 0, dev)
     torch.cuda.synchronize()
     enc = pkg.Encoder(0)
     enc.set_device_image([frame[c].data_ptr() for c in range(3)], size * 4, size, size, keepalive=frame)

@@ -16,7 +16,7 @@ def main():
     passes = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     pkg = __graft_entry__.load_package()
     dev = torch.device("cuda", 0)
-    frame = bench.make_frame_on_device(torch, size, 0, dev)
+    frame = bench.frame_rows_on_device(torch, size, 0, size, 0, dev)
     torch.cuda.synchronize()
     enc = pkg.Encoder(0)
     enc.set_device_image([frame[c].data_ptr() for c in range(3)], size * 4, size, size, keepalive=frame)
