@@ -117,6 +117,7 @@ struct TokenArgs {
   const uint64_t* group_tok_offset;  // exclusive scan of group_ntok (tokens)
   uint8_t* tokens;                   // 3 bytes per token
   uint32_t* histogram;               // optional [64 pre-clusters][64 symbols] (enc_frame.cc:767-782)
+  int group_first;                   // workgroup b handles group group_first + b (launches per row of DC groups)
 };
 
 // ---------------------------------------------------------------------------
@@ -292,6 +293,34 @@ JXLT_DI float cube_root_and_add(float x, float add) {
   return r;
 }
 
+// ZeroIfNegative (enc_xyb.cc:73-75) + CubeRootAndAdd in one: `mixed` is the biased mix BEFORE the clamp.
+// The reference's result for an input clamped to zero is exactly `add` (seed 0 -> r stays 0 -> 0 * 0 + add), so
+// the clamp, the zero test of the seed and its select collapse into ONE compare + select at the end; what
+// the arithmetic in between produces for mixed <= 0 is never used.  The seed itself is a bit-field extract
+// and a 24-bit multiply-add: e * -0x2AAAAA + 0x54800000 with the biased exponent e < 256 -- the same integer
+// as 0x54800000 - (bits >> 23) * 0x2AAAAA for every positive input (denormals included: e = 0).
+JXLT_DI float clamped_cube_root_and_add(float mixed, float add) {
+#ifdef JXLT_CBRT_REFERENCE_SHAPE
+  return cube_root_and_add(zero_if_negative(mixed), add);
+#else
+  const float k1_3 = 1.0f / 3, k4_3 = 4.0f / 3;
+  const float x = mixed;
+  const float xa_3 = k1_3 * x;
+  const int32_t e = (int32_t)__builtin_amdgcn_ubfe(__float_as_uint(x), 23, 8);
+  float r = __int_as_float(e * -0x002AAAAA + 0x54800000);
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const float r2 = r * r;
+    r = nfma32(xa_3, r2 * r2, k4_3 * r);
+  }
+  float r2 = r * r;
+  r = fma32(k1_3, nfma32(x, r2 * r2, r), r);
+  r2 = r * r;
+  r = fma32(r2, x, add);
+  return mixed > 0.0f ? r : add;
+#endif
+}
+
 // enc_xyb.cc:30-81
 template <bool kNeedB = true>
 JXLT_DI void linear_to_xyb(float r, float g, float b, float* ox, float* oy, float* ob) {
@@ -303,13 +332,13 @@ JXLT_DI void linear_to_xyb(float r, float g, float b, float* ox, float* oy, floa
   const float neg_bias_cbrt = -0.15595420054f;
   const float mixed0 = fma32(kM00, r, fma32(kM01, g, fma32(kM02, b, bias)));
   const float mixed1 = fma32(kM10, r, fma32(kM11, g, fma32(kM12, b, bias)));
-  const float tm0 = cube_root_and_add(zero_if_negative(mixed0), neg_bias_cbrt);
-  const float tm1 = cube_root_and_add(zero_if_negative(mixed1), neg_bias_cbrt);
+  const float tm0 = clamped_cube_root_and_add(mixed0, neg_bias_cbrt);
+  const float tm1 = clamped_cube_root_and_add(mixed1, neg_bias_cbrt);
   *ox = 0.5f * (tm0 - tm1);
   *oy = 0.5f * (tm0 + tm1);
   if (kNeedB) {  // (the halo columns only feed the adaptive quantisation, which reads X and Y)
     const float mixed2 = fma32(kM20, r, fma32(kM21, g, fma32(kM22, b, bias)));
-    *ob = cube_root_and_add(zero_if_negative(mixed2), neg_bias_cbrt);
+    *ob = clamped_cube_root_and_add(mixed2, neg_bias_cbrt);
   }
 }
 
@@ -1511,6 +1540,59 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     uint32_t wave_tokens = 0;
     const int by = wave;
+#ifndef JXLT_P9_SERIAL
+    // One LDS round trip per block instead of three: the scan tables (loop invariant) and the strategies of
+    // the wave's block row (eight bytes) are fetched once, and the staged coefficients of block bx + 1 are
+    // requested before block bx is balloted and stored (the phase is latency bound: a handful of instructions
+    // per block behind dependent LDS reads).
+    if (by < nby) {
+      const int ord8 = S.order[lane], ord16a = S.order[64 + lane], ord16b = S.order[128 + lane];
+      const uint32_t* srow = reinterpret_cast<const uint32_t*>(&S.strat[by * 8]);
+      const uint32_t srow_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)srow[0]);
+      const uint32_t srow_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)srow[1]);
+      auto strategy_of = [&](int bx) { return (int)(((bx < 4 ? srow_lo : srow_hi) >> (8 * (bx & 3))) & 0xFFu); };
+      auto fetch = [&](int bx, int16_t* v0s, int16_t* v1s) {
+        const int bi = by * 8 + bx;
+        const int st = strategy_of(bx) >> 1;
+        const int o2 = st == 1 ? 8 : 1;
+        const int i0 = st == 0 ? ord8 : ord16a, i1 = ord16b;
+        const int src0 = i0 < 64 ? bi * kStageStride + i0 : (bi + o2) * kStageStride + i0 - 64;
+        const int src1 = i1 < 64 ? bi * kStageStride + i1 : (bi + o2) * kStageStride + i1 - 64;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          v0s[c] = stage[src0 + c * 64];
+          v1s[c] = st != 0 ? stage[src1 + c * 64] : (int16_t)0;
+        }
+      };
+      int16_t n0[3], n1[3];
+      fetch(0, n0, n1);
+#pragma unroll
+      for (int bx = 0; bx < 8; bx++) {
+        const int16_t v0s[3] = {n0[0], n0[1], n0[2]}, v1s[3] = {n1[0], n1[1], n1[2]};
+        if (bx + 1 < 8) fetch(bx + 1, n0, n1);  // (blocks beyond nbx: harmless reads inside the staging area)
+        const int a = strategy_of(bx);
+        if (bx >= nbx || !(a & 1)) continue;
+        const int st = a >> 1;
+        const int covered = st == 0 ? 1 : 2;
+        const uint32_t pos0 = (uint32_t)(by_img0 + by) * bstride + (uint32_t)(bx_img0 + bx);
+        const uint32_t pos1 = pos0 + (st == 1 ? bstride : 1u);
+        const unsigned long long llf_mask = covered == 2 ? 3ull : 1ull;  // scan positions < covered
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const int16_t v0 = v0s[c], v1 = v1s[c];
+          const unsigned long long m0 = __ballot(v0 != 0) & ~llf_mask;
+          int nscan = m0 != 0 ? 64 - __clzll((long long)m0) : 0;
+          const unsigned long long m1 = __ballot(v1 != 0);
+          if (m1 != 0) nscan = 128 - __clzll((long long)m1);
+          // only scan positions below nscan (= up to the last nonzero) are ever read again
+          if (lane < nscan) A.coef_scan[(pos0 * 3 + c) * 64 + lane] = v0;
+          if (64 + lane < nscan) A.coef_scan[(pos1 * 3 + c) * 64 + lane] = v1;
+          if (lane == 0) A.blk_nscan[pos0 * 3 + c] = (uint8_t)nscan;
+          wave_tokens += 1 + (nscan > covered ? nscan - covered : 0);
+        }
+      }
+    }
+#else
     for (int bx = 0; by < nby && bx < nbx; bx++) {
       const int bi = by * 8 + bx;
       const int a = __builtin_amdgcn_readfirstlane((int)S.strat[bi]);
@@ -1550,6 +1632,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
         wave_tokens += 1 + (nscan > covered ? nscan - covered : 0);
       }
     }
+#endif
     if (lane == 0 && wave_tokens) atomicAdd(&S.ntok, wave_tokens);
   }
   __syncthreads();
@@ -1577,11 +1660,13 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel_exact_roots(const
 // ---------------------------------------------------------------------------
 // Exclusive scan of per-group token counts (single workgroup)
 // ---------------------------------------------------------------------------
-__global__ void group_scan_kernel(const uint32_t* counts, uint64_t* offsets, int n) {
+// offsets[0] is the carry-in when `chained` (the total a previous launch over the preceding range left there:
+// the per-slab launches of one frame scan consecutive ranges of one array), 0 otherwise.
+__global__ void group_scan_kernel(const uint32_t* counts, uint64_t* offsets, int n, int chained) {
   __shared__ uint64_t carry;
   __shared__ uint64_t part[256];
   const int tid = (int)threadIdx.x;
-  if (tid == 0) carry = 0;
+  if (tid == 0) carry = chained ? offsets[0] : 0;
   __syncthreads();
   for (int base = 0; base < n; base += 256) {
     const int i = base + tid;
@@ -1619,7 +1704,7 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   // (wave index pinned to a scalar register: the per-entry bookkeeping below is wave-uniform)
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const DeviceTables* T = A.tab;
-  const int group = (int)blockIdx.x;
+  const int group = A.group_first + (int)blockIdx.x;
   const bool do_hist = A.histogram != nullptr;
   if (do_hist)
     for (int i = tid; i < 64 * 64; i += kTokenThreads) hist[i] = 0;
@@ -2298,6 +2383,7 @@ struct DcArgs {
   uint32_t* dc_count;             // [ndc] records per DC group
   uint32_t* histogram;            // [64 * 64]
   uint32_t* chain_summary;        // [ndc * kDcChainChunks]: first blocks in the chunk | last one's (code << 8 | qf - 1) << 16
+  int dcg_first;                  // the launch covers DC groups dcg_first .. (one row of DC groups at a time)
 };
 
 struct DcGeom {
@@ -2354,7 +2440,7 @@ constexpr int kDcParts = 32;  // workgroups per DC group in dc_elementwise_kerne
 __global__ void __launch_bounds__(256) dc_elementwise_kernel(const DcArgs A) {
   __shared__ uint32_t hist[64 * 64];
   const int tid = (int)threadIdx.x;
-  const int dcg = (int)blockIdx.x / kDcParts, part = (int)blockIdx.x % kDcParts;
+  const int dcg = A.dcg_first + (int)blockIdx.x / kDcParts, part = (int)blockIdx.x % kDcParts;
   for (int i = tid; i < 64 * 64; i += 256) hist[i] = 0;
   __syncthreads();
   const uint32_t nac = A.dc_nac[dcg];
@@ -2437,7 +2523,7 @@ __global__ void __launch_bounds__(kDcChainThreads) dc_chain_summary_kernel(const
   __shared__ int last_idx;
   __shared__ uint32_t last_val;
   const int tid = (int)threadIdx.x;
-  const int dcg = (int)blockIdx.x / kDcChainChunks, chunk = (int)blockIdx.x % kDcChainChunks;
+  const int dcg = A.dcg_first + (int)blockIdx.x / kDcChainChunks, chunk = (int)blockIdx.x % kDcChainChunks;
   const DcGeom d = dc_geom(A.g, dcg, 0);
   if (tid == 0) {
     count = 0;
@@ -2464,7 +2550,7 @@ __global__ void __launch_bounds__(kDcChainThreads) dc_chain_kernel(const DcArgs 
   __shared__ uint32_t carry_rank;
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int dcg = (int)blockIdx.x / kDcChainChunks, chunk = (int)blockIdx.x % kDcChainChunks;
+  const int dcg = A.dcg_first + (int)blockIdx.x / kDcChainChunks, chunk = (int)blockIdx.x % kDcChainChunks;
   const uint32_t nac = A.dc_nac[dcg];
   const DcGeom d = dc_geom(A.g, dcg, nac);
   if (chunk * kDcChainThreads >= d.nb) return;  // (partial DC groups have fewer chunks)

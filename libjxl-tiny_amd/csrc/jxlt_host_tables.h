@@ -60,4 +60,35 @@ inline float XQmMultiplier(uint32_t x_qm_scale) {  // pow(1.25f, x_qm_scale - 2.
 
 }  // namespace jxlt_dev
 
+// tile_kernel arguments for rows [y0, y0 + rows) of a frame as a frame of its own (y0 a multiple of 2048: whole
+// rows of DC groups, so every block / tile / group / DC-group index of the slab is the frame's index minus a
+// constant): the kernel never looks across a group boundary, so only the base pointers move.  `pitch` = A.pitch.
+namespace jxlt_dev {
+inline TileArgs SlabTileArgs(const TileArgs& A, size_t y0, size_t rows, ptrdiff_t pitch) {
+  TileArgs S = A;
+  S.g = MakeGeom((size_t)A.g.xsize, rows);
+  const size_t xb = (size_t)A.g.xsize_blocks;
+  const size_t b0 = (y0 / 8) * xb;  // first block of the slab
+  for (int c = 0; c < 3; c++) {
+    S.planes[c] = A.planes[c] + (ptrdiff_t)y0 * pitch;
+    S.quant_dc[c] = A.quant_dc[c] + b0;
+    S.nzgrid[c] = A.nzgrid[c] + b0;
+    if (A.dbg_xyb[c]) S.dbg_xyb[c] = A.dbg_xyb[c] + y0 * xb * 8;
+  }
+  S.raw_quant = A.raw_quant + b0;
+  S.strategy = A.strategy + b0;
+  S.blk_nz = A.blk_nz + 3 * b0;
+  S.blk_nscan = A.blk_nscan + 3 * b0;
+  S.coef_scan = A.coef_scan + 3 * 64 * b0;
+  S.ytox = A.ytox + (y0 / 64) * (size_t)A.g.xsize_tiles;
+  S.ytob = A.ytob + (y0 / 64) * (size_t)A.g.xsize_tiles;
+  S.group_ntok = A.group_ntok + (y0 / 256) * (size_t)A.g.xsize_groups;
+  S.dc_nac = A.dc_nac + (y0 / 2048) * (((size_t)A.g.xsize + 2047) / 2048);
+  if (A.dbg_qf) S.dbg_qf = A.dbg_qf + b0;
+  if (A.dbg_mask) S.dbg_mask = A.dbg_mask + b0;
+  if (A.dbg_ent8) S.dbg_ent8 = A.dbg_ent8 + (y0 / 16) * (xb / 2 + 1) * 8;
+  return S;
+}
+}  // namespace jxlt_dev
+
 #endif  // JXLT_HOST_TABLES_H_

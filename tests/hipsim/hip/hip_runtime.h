@@ -330,6 +330,9 @@ inline void __builtin_amdgcn_sched_barrier(int) {}  // compiler scheduling fence
 
 // v_rcp_f32 (1 ulp on hardware; the model returns the correctly rounded reciprocal)
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+inline uint32_t __builtin_amdgcn_ubfe(uint32_t v, uint32_t offset, uint32_t width) {  // v_bfe_u32
+  return (v >> offset) & ((width >= 32) ? 0xFFFFFFFFu : ((1u << width) - 1u));
+}
 
 // v_alignbyte_b32: ({hi, lo} >> (8 * (shift & 3))) & 0xffffffff
 inline uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, uint32_t shift) {

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "../../libjxl-tiny_amd/csrc/jxlt_host_tables.h"
@@ -100,10 +101,20 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   // table is redone from scratch by the variant that computes every root
   uint32_t lut_overflow = 0;
   A.lut_overflow = &lut_overflow;
+  // one launch per row of DC groups with the slab arguments of the product (jxlt_host_tables.h: SlabTileArgs)
+  auto launch_tiles = [&](auto kernel) {
+    const size_t rows_per_slab = 2048, nsl = (ysize + rows_per_slab - 1) / rows_per_slab;
+    for (size_t sl = 0; sl < nsl; sl++) {
+      const size_t y0 = sl * rows_per_slab, rows = std::min(rows_per_slab, ysize - y0);
+      const TileArgs S = nsl == 1 ? A : SlabTileArgs(A, y0, rows, A.pitch);
+      hipsim::launch(kernel, dim3((unsigned)((size_t)S.g.xsize_tiles * S.g.ysize_tiles)), dim3(kTileThreads), S);
+    }
+  };
+  (void)ntiles;
   if (flags & 0x400u) {
-    hipsim::launch(tile_kernel_exact_roots, dim3((unsigned)ntiles), dim3(kTileThreads), A);
+    launch_tiles(tile_kernel_exact_roots);
   } else {
-    hipsim::launch(tile_kernel, dim3((unsigned)ntiles), dim3(kTileThreads), A);
+    launch_tiles(tile_kernel);
     if (lut_overflow) {
       sim_free(r);
       for (int c = 0; c < 3; c++) free(A.nzgrid[c]);
@@ -117,8 +128,14 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   }
 
   r->group_tok_offset = (uint64_t*)calloc(ngroups + 1, 8);
-  hipsim::launch(group_scan_kernel, dim3(1), dim3(256), (const uint32_t*)A.group_ntok,
-                 r->group_tok_offset, (int)ngroups);
+  // token offsets row of DC groups by row of DC groups, chained, as the product launches them (jxlt_capi.hip)
+  const size_t nslabs = (ysize + 2047) / 2048;
+  for (size_t sl = 0; sl < nslabs; sl++) {
+    const size_t y0 = sl * 2048, rows = std::min<size_t>(2048, ysize - y0);
+    const size_t g0 = (y0 / 256) * (size_t)g.xsize_groups, ng = ((rows + 255) / 256) * (size_t)g.xsize_groups;
+    hipsim::launch(group_scan_kernel, dim3(1), dim3(256), (const uint32_t*)A.group_ntok + g0, r->group_tok_offset + g0,
+                   (int)ng, sl > 0 ? 1 : 0);
+  }
   const uint64_t total = r->group_tok_offset[ngroups];
   r->tokens = (uint8_t*)calloc(total * 3 + 1, 1);
   TokenArgs K;
@@ -133,7 +150,11 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   K.group_tok_offset = r->group_tok_offset;
   K.tokens = r->tokens;
   K.histogram = r->histogram = (uint32_t*)calloc(2 * 64 * 64, 4);
-  hipsim::launch(token_kernel, dim3((unsigned)ngroups), dim3(kTokenThreads), K);
+  for (size_t sl = 0; sl < nslabs; sl++) {
+    const size_t y0 = sl * 2048, rows = std::min<size_t>(2048, ysize - y0);
+    K.group_first = (int)((y0 / 256) * (size_t)g.xsize_groups);
+    hipsim::launch(token_kernel, dim3((unsigned)(((rows + 255) / 256) * (size_t)g.xsize_groups)), dim3(kTokenThreads), K);
+  }
 
   {
     const size_t kDcStride = 6 * 65536 + 2 * 1024 + 8;
@@ -157,11 +178,15 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
     D.records = r->dc_records;
     D.dc_count = r->dc_count;
     D.histogram = r->histogram + 64 * 64;
-    hipsim::launch(dc_elementwise_kernel, dim3((unsigned)(ndc * kDcParts)), dim3(256), D);
     std::vector<uint32_t> chain_summary(ndc * kDcChainChunks, 0xFFFFFFFFu);
     D.chain_summary = chain_summary.data();
-    hipsim::launch(dc_chain_summary_kernel, dim3((unsigned)(ndc * kDcChainChunks)), dim3(kDcChainThreads), D);
-    hipsim::launch(dc_chain_kernel, dim3((unsigned)(ndc * kDcChainChunks)), dim3(kDcChainThreads), D);
+    const size_t xdc = (xsize + 2047) / 2048;
+    for (size_t sl = 0; sl < nslabs; sl++) {
+      D.dcg_first = (int)(sl * xdc);
+      hipsim::launch(dc_elementwise_kernel, dim3((unsigned)(xdc * kDcParts)), dim3(256), D);
+      hipsim::launch(dc_chain_summary_kernel, dim3((unsigned)(xdc * kDcChainChunks)), dim3(kDcChainThreads), D);
+      hipsim::launch(dc_chain_kernel, dim3((unsigned)(xdc * kDcChainChunks)), dim3(kDcChainThreads), D);
+    }
   }
   free(A.dc_nac);
   for (int c = 0; c < 3; c++) free(A.nzgrid[c]);
@@ -223,12 +248,12 @@ __attribute__((visibility("default"))) int sim_pack_direct(const uint8_t* record
   P.tile_end = 0xFFFFFFFFu;
   const unsigned sec_blocks = (unsigned)((nsec + 255) / 256);
   hipsim::launch(pack_tile_count_kernel, dim3(sec_blocks), dim3(256), P);
-  hipsim::launch(group_scan_kernel, dim3(1), dim3(256), (const uint32_t*)sec_tiles.data(), tile_base.data(), nsec);
+  hipsim::launch(group_scan_kernel, dim3(1), dim3(256), (const uint32_t*)sec_tiles.data(), tile_base.data(), nsec, 0);
   hipsim::launch(pack_tile_plan_kernel, dim3(sec_blocks), dim3(256), P);
   hipsim::launch(pack_tile_measure_kernel, dim3((unsigned)((max_tiles + kPackTilesPerGroup - 1) / kPackTilesPerGroup)),
                  dim3(kPackThreads), P);
   hipsim::launch(pack_tile_offsets_kernel, dim3(sec_blocks), dim3(256), P);
-  hipsim::launch(group_scan_kernel, dim3(1), dim3(256), (const uint32_t*)sec_bytes.data(), out_offset, nsec);
+  hipsim::launch(group_scan_kernel, dim3(1), dim3(256), (const uint32_t*)sec_bytes.data(), out_offset, nsec, 0);
   hipsim::launch(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), P);
   const uint64_t ntiles = tile_base[nsec];
   for (int c = 0; c < nlaunch; c++) {

@@ -20,6 +20,8 @@ CASES = [
     (128, 64, 1.0, True, False),    # uniform noise: token heavy
     (128, 64, 1.0, False, True),    # fixed DCT8 (BASELINE config #2 mode)
     (17, 130, 3.0, False, False),   # narrow
+    (24, 2048 + 2048 + 72, 1.0, False, False),  # three rows of DC groups: the row-wise launches (slab arguments,
+                                                # chained token-offset scan, per-row DC kernels) of jxlt_capi.hip
 ]
 
 
@@ -90,7 +92,8 @@ def test_pack_tiles_with_short_codes(built):
     assert T.sim_pack_sections(sections, table, 0, nlaunch=3) == want
 
 
-@pytest.mark.parametrize("w,h,distance", [(200, 137, 1.0), (9, 7, 1.0), (300, 264, 2.0), (2100, 40, 1.0), (64, 64, 8.0)])
+@pytest.mark.parametrize("w,h,distance", [(200, 137, 1.0), (9, 7, 1.0), (300, 264, 2.0), (2100, 40, 1.0), (64, 64, 8.0),
+                                          (2060, 2100, 2.0)])
 def test_dc_kernels_match_oracle_tokeniser(built, w, h, distance):
     """dc_elementwise_kernel + dc_chain_kernel vs the oracle's WriteDCGroup restatement."""
     planes = T.to_planes(T.synthetic_image(w, h))

@@ -1,12 +1,17 @@
 #!/bin/bash
 # A/B of kernel build variants on the GPU box: rebuild the HIP library with extra flags (argument 1: a list of
-# flag sets separated by ';'), report kernel times of a device-only bench run for each.
+# flag sets separated by ';'; an empty set = the production build), then for each: tile_cycles (shader cycles,
+# VALU per wave) and the kernel times of a bench run without extras.  PARITY=1 also runs the quick GPU parity tests.
 cd "${GRAFT_REPO_ROOT:-.}"
 IFS=';' read -ra VARIANTS <<< "$1"
 for v in "${VARIANTS[@]}"; do
+  [ "$v" = "base" ] && v=""
   touch libjxl-tiny_amd/csrc/jxlt_capi.hip
   make -C libjxl-tiny_amd -s csrc/libjxltiny_hip.so HIPFLAGS_EXTRA="$v" 2>&1 | grep -i error
-  timeout 200 python bench.py --no-extras --steps 8 2>&1 | tail -1 | V="$v" python3 -c "
-import json,sys,os
-d=json.loads(sys.stdin.readline()); print('[%s]' % os.environ['V'], d['ms_per_step'], d['kernel_ms'])"
+  echo "== [$v]"
+  if [ -n "$PARITY" ]; then timeout 600 python -m pytest tests -m gpu -x -q -k "hot_path or golden or random or values_outside" 2>&1 | tail -1; fi
+  ./tools/tile_cycles.sh 16384 | grep -E "tile_kernel|token_kernel"
+  timeout 200 python bench.py --no-extras --steps 8 2>&1 | tail -1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], d['kernel_ms'])"
 done
