@@ -8,7 +8,7 @@
 // what could cost extra: waves per SIMD, chain count (dependent-issue distance), operand
 // patterns (distinct VGPR banks / same bank / repeated source / SGPR / literal / inline constant).
 //
-//   c = cycles a wave spent in its stream / (waves on the SIMD x instructions per wave)
+//   c = cycles from the first wave's start to the last wave's end / (waves on the SIMD x instructions per wave)
 //
 // is the issue cost per instruction when the SIMD is the bottleneck (all waves of a SIMD run the same
 // stream at the same time: W / 2 workgroups of 512 threads -- tile_kernel's shape -- are pinned on every CU by
@@ -236,14 +236,19 @@ void run(int waves_per_simd, unsigned long long* d_cycles, float* d_sink, FILE* 
   std::sort(cyc.begin(), cyc.end());
   std::sort(ghz.begin(), ghz.end());
   const double instr = (double)iters * 256;
-  const double per_instr = cyc[nwaves / 2] / (instr * waves_per_simd);
-  // all waves in flight together for this share of the kernel's span (1 = perfectly concurrent)
-  const double overlap = last_start < first_end ? (double)(first_end - last_start) / (double)(last_end - first_start) : 0.0;
-  printf("%-40s W=%d  %6.3f cycles/instr/SIMD  clock %5.3f GHz  overlap %4.2f  (%7.3f ms)\n", kModeNames[MODE],
-         waves_per_simd, per_instr, ghz[nwaves / 2], overlap, ms);
-  fprintf(json, "%s{\"mode\": \"%s\", \"waves_per_simd\": %d, \"cycles_per_instr\": %.4f, \"clock_ghz\": %.4f, "
-                "\"all_waves_concurrent_share\": %.3f, \"kernel_ms\": %.4f}",
-          *first ? "" : ",\n  ", kModeNames[MODE], waves_per_simd, per_instr, ghz[nwaves / 2], overlap, ms);
+  const double clock = ghz[nwaves / 2];
+  // (a) what a wave saw: its own stream's cycles / (W x instructions).  The SIMD arbitrates by age, so older
+  //     waves finish early and this UNDER-states the cost when W > 2.
+  const double per_wave = cyc[nwaves / 2] / (instr * waves_per_simd);
+  // (b) what the SIMD delivered: the chip-wide span first start -> last end (100 MHz ticks x measured clock) over
+  //     the W x instructions every SIMD issued.  Includes the launch ramp (a few microseconds of ~1 ms).
+  const double span_cycles = (double)(last_end - first_start) * 10e-9 * clock * 1e9;
+  const double per_simd = span_cycles / (instr * waves_per_simd);
+  printf("%-40s W=%d  %6.3f cycles/instr/SIMD (span)  %6.3f (median wave)  clock %5.3f GHz  (%7.3f ms)\n",
+         kModeNames[MODE], waves_per_simd, per_simd, per_wave, clock, ms);
+  fprintf(json, "%s{\"mode\": \"%s\", \"waves_per_simd\": %d, \"cycles_per_instr\": %.4f, "
+                "\"cycles_per_instr_median_wave\": %.4f, \"clock_ghz\": %.4f, \"kernel_ms\": %.4f}",
+          *first ? "" : ",\n  ", kModeNames[MODE], waves_per_simd, per_simd, per_wave, clock, ms);
   *first = false;
   hipEventDestroy(e0);
   hipEventDestroy(e1);
