@@ -120,6 +120,15 @@ bool EncodePFMFile(const char* filename, float distance, std::vector<uint8_t>* o
   bool ok = jxlt::ParsePFMHeader(data, size, &xsize, &ysize, &big_endian, &payload_offset);
   if (ok && xsize_out) *xsize_out = xsize;
   if (ok && ysize_out) *ysize_out = ysize;
+  if (ok) {  // several GPUs configured: the payload's row slabs go to one GPU each
+    bool used = false;
+    const bool done = jxlt::EncodeOnDeviceList(nullptr, 0, data + payload_offset, big_endian ? 1 : 0, xsize, ysize,
+                                               distance, output, &used);
+    if (used || !done) {
+      munmap(map, size);
+      return done;
+    }
+  }
   BitWriter writer;
   ok = ok && jxlt::WriteFileHeader(xsize, ysize, &writer);
   if (ok && jxlt_image_upload_pfm(ctx, data + payload_offset, xsize, ysize, big_endian ? 1 : 0) != JXLT_OK) {

@@ -319,39 +319,64 @@ void SetEncoderDevices(const int* device_ordinals, int n) {
   g_devices.assign(device_ordinals, device_ordinals + (n > 0 && device_ordinals ? n : 0));
 }
 
+}  // namespace jxl
+
+namespace jxlt {
+// The frame over the process's device list (jxl::SetEncoderDevices / JXLT_DEVICES) when that names several
+// GPUs and the frame has more than one row of DC groups.  *used = false: not applicable, nothing done.
+// Otherwise the complete codestream (file header + frame) is in *codestream, or false is returned.
+bool EncodeOnDeviceList(const float* const planes[3], size_t pitch_bytes, const void* pfm_payload, int big_endian,
+                        size_t xsize, size_t ysize, float distance, std::vector<uint8_t>* codestream, bool* used) {
+  using namespace jxl;
+  std::lock_guard<std::mutex> lock(g_multi_mu);
+  DevicesFromEnvironment();
+  *used = g_devices.size() > 1 && ysize > 2048;
+  if (!*used) return true;
+  if (g_multi && g_multi_devices != g_devices) {
+    jxlt_multi_encoder_destroy(g_multi);
+    g_multi = nullptr;
+  }
+  if (!g_multi) {
+    if (jxlt_multi_encoder_create(g_devices.data(), static_cast<int>(g_devices.size()), &g_multi) != JXLT_OK) {
+      fprintf(stderr, "jxl_tiny_amd: cannot create device contexts: %s\n", jxlt_last_error(nullptr));
+      g_multi = nullptr;
+      return false;  // no CPU fallback by design
+    }
+    g_multi_devices = g_devices;
+  }
+  const uint8_t* bytes = nullptr;
+  size_t size = 0;
+  const int rc = pfm_payload
+                     ? jxlt_multi_encoder_encode_pfm(g_multi, pfm_payload, xsize, ysize, big_endian, distance, &bytes, &size)
+                     : jxlt_multi_encoder_encode(g_multi, planes, pitch_bytes, xsize, ysize, distance, &bytes, &size);
+  if (rc != JXLT_OK) {
+    fprintf(stderr, "jxl_tiny_amd: sharded encode failed: %s\n", jxlt_multi_encoder_last_error(g_multi));
+    return false;
+  }
+  codestream->assign(bytes, bytes + size);
+  return true;
+}
+}  // namespace jxlt
+
+namespace jxl {
+
 Status EncodeFrame(const float distance, const Image3F& linear, ThreadPool* pool,
                    BitWriter* writer) {
   if (linear.xsize() == 0 || linear.ysize() == 0 || !(distance > 0)) return false;
   const float* planes[3] = {linear.ConstPlaneRow(0, 0), linear.ConstPlaneRow(1, 0),
                             linear.ConstPlaneRow(2, 0)};
   {
-    std::lock_guard<std::mutex> lock(g_multi_mu);
-    DevicesFromEnvironment();
-    if (g_devices.size() > 1 && linear.ysize() > 2048) {
-      if (g_multi && g_multi_devices != g_devices) {
-        jxlt_multi_encoder_destroy(g_multi);
-        g_multi = nullptr;
-      }
-      if (!g_multi) {
-        if (jxlt_multi_encoder_create(g_devices.data(), static_cast<int>(g_devices.size()), &g_multi) != JXLT_OK) {
-          fprintf(stderr, "jxl_tiny_amd: cannot create device contexts: %s\n", jxlt_last_error(nullptr));
-          g_multi = nullptr;
-          return false;  // no CPU fallback by design
-        }
-        g_multi_devices = g_devices;
-      }
-      const uint8_t* bytes = nullptr;
-      size_t size = 0;
-      if (jxlt_multi_encoder_encode(g_multi, planes, linear.bytes_per_row(), linear.xsize(), linear.ysize(),
-                                    distance, &bytes, &size) != JXLT_OK) {
-        fprintf(stderr, "jxl_tiny_amd: sharded encode failed: %s\n", jxlt_multi_encoder_last_error(g_multi));
-        return false;
-      }
-      // the multi encoder returns the whole codestream; the caller's writer already holds the file header
+    std::vector<uint8_t> whole;
+    bool used = false;
+    if (!jxlt::EncodeOnDeviceList(planes, linear.bytes_per_row(), nullptr, 0, linear.xsize(), linear.ysize(), distance,
+                                  &whole, &used))
+      return false;
+    if (used) {
+      // the device list returns the whole codestream; the caller's writer already holds the file header
       BitWriter header;
       if (!jxlt::WriteFileHeader(linear.xsize(), linear.ysize(), &header)) return false;
       const size_t skip = header.TakeBytes().size();
-      writer->AppendBytes(bytes + skip, size - skip);
+      writer->AppendBytes(whole.data() + skip, whole.size() - skip);
       return true;
     }
   }

@@ -26,6 +26,9 @@ struct ContextOutput {
 bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jxl::BitWriter* writer,
                           const std::function<uint8_t*(size_t)>* placer, ContextOutput* in_context = nullptr);
 bool WriteFileHeader(size_t xsize, size_t ysize, jxl::BitWriter* writer);
+// One frame over the process's device list (jxl::SetEncoderDevices / JXLT_DEVICES); see enc_frame.cc.
+bool EncodeOnDeviceList(const float* const planes[3], size_t pitch_bytes, const void* pfm_payload, int big_endian,
+                        size_t xsize, size_t ysize, float distance, std::vector<uint8_t>* codestream, bool* used);
 bool ParsePFMHeader(const uint8_t* data, size_t size, size_t* xsize, size_t* ysize, bool* big_endian,
                     size_t* payload_offset);
 bool NormalizeDistance(float* distance);

@@ -73,6 +73,20 @@ def test_cjxl_tiny_cli(built, tmp_path, host_ingest, big_endian):
     assert ("Compressed to %d bytes." % len(want)) in r.stderr
 
 
+@pytest.mark.parametrize("host_ingest", [False, True])
+def test_cjxl_tiny_over_a_device_list(built, tmp_path, host_ingest):
+    """JXLT_DEVICES: the unmodified command line spreads one frame over several device contexts (here GPU 0
+    twice): PFM payload slabs straight to the devices, or ReadPFM + EncodeFile (--host-ingest)."""
+    import os
+    img = T.synthetic_image(300, 2048 + 260)
+    pfm, out = tmp_path / "in.pfm", tmp_path / "out.jxl"
+    T.write_pfm(pfm, img, big_endian=True)
+    cmd = [str(built.CJXL_TINY), str(pfm), str(out), "-d", "2"] + (["--host-ingest"] if host_ingest else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, JXLT_DEVICES="0,0"))
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == T.assemble_codestream(T.oracle_hot_path(T.to_planes(img), 2.0), 2.0)
+
+
 def test_error_behaviour(built, enc):
     # EncodeFile rejects distance <= 0 (enc_file.cc:57-62) and empty images
     planes = T.to_planes(T.synthetic_image(32, 32))
