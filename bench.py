@@ -64,9 +64,10 @@ def parse_args():
                     help="N > 1: one independent frame per rank (weak scaling) instead of one frame over all ranks")
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / pfm_inclusive / parity legs")
     ap.add_argument("--frame-batch", type=int, default=0,
-                    help="secondary workload (BASELINE config #5, PCIe-inclusive, never the headline value): a step "
-                         "is a batch of this many --frame-size frames in page-locked HOST memory PER GPU encoded "
-                         "through jxlt_batch_encoder_run (uploads, kernels and downloads of different frames overlap)")
+                    help="secondary workload (BASELINE config #5: --frame-batch 256 --gpus 8; PCIe-inclusive, never the "
+                         "headline value): a step is a batch of this many --frame-size frames in page-locked HOST "
+                         "memory, frame i on GPU i mod N, every GPU's share through jxlt_batch_encoder_run (uploads, "
+                         "kernels and downloads of different frames overlap)")
     ap.add_argument("--frame-size", default="3840x2160")
     ap.add_argument("--lanes", type=int, default=3, help="device contexts per GPU of the frame-batch encoder")
     ap.add_argument("--frames-resident", action="store_true",
@@ -179,7 +180,14 @@ def main():
         # the ranks' meeting point; rank 0 creates it, the others attach after the barrier
         name = "/jxlt-bench-%s" % os.environ.get("MASTER_PORT", "0")
         sections = ((size + 2047) // 2048) ** 2 + ((size + 255) // 256) ** 2
-        capacity = max(64 << 20, size * size)  # 1 byte per pixel (the 16384^2 bench frame needs 0.09)
+        # output area in /dev/shm: a quarter byte per pixel (the 16384^2 bench frame needs 0.09), within what
+        # the shared-memory file system has free
+        capacity = max(32 << 20, size * size // 4)
+        try:
+            st = os.statvfs("/dev/shm")
+            capacity = min(capacity, max(16 << 20, st.f_bavail * st.f_frsize // 2))
+        except OSError:
+            pass
         if rank == 0:
             group = pkg.ShardGroup(name, 0, world, capacity, sections + 64)
         barrier()
@@ -443,7 +451,7 @@ def run_frame_batch(args, np, torch, pkg, dist, barrier, max_over_ranks, rank, w
     `--frame-batch` frames per GPU and step; one batch encoder (several lanes) per rank / GPU."""
     import jxlt_testlib as T
     w, h = (int(v) for v in args.frame_size.lower().split("x"))
-    distinct = min(args.frame_batch, 8)
+    distinct = max(1, min(args.frame_batch // max(world, 1), 8))
     frames, owners = [], []
     hh = (h + CHUNK_ROWS - 1) // CHUNK_ROWS * CHUNK_ROWS
     for i in range(distinct):
@@ -457,8 +465,10 @@ def run_frame_batch(args, np, torch, pkg, dist, barrier, max_over_ranks, rank, w
             owners.append(owner)
         del full
     enc = pkg.BatchEncoder(dev_index, lanes=args.lanes)
-    descs, keep = enc.describe([frames[i % distinct] for i in range(args.frame_batch)])
-    n = args.frame_batch
+    total = args.frame_batch
+    mine = list(range(rank, total, world))  # frames round-robin over the GPUs
+    n = len(mine)
+    descs, keep = enc.describe([frames[i % distinct] for i in mine])
     first = enc.run_described(descs, n, args.distance)
     for _ in range(max(0, args.warmup - 1)):
         enc.run_described(descs, n, args.distance, take=False)
@@ -468,19 +478,19 @@ def run_frame_batch(args, np, torch, pkg, dist, barrier, max_over_ranks, rank, w
         total_bytes = enc.run_described(descs, n, args.distance, take=False)
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
-    mpix = n * w * h / 1e6
-    h2d_gbs = world * 12.0 * n * w * h * args.steps / elapsed / 1e9
+    mpix = total * w * h / 1e6
+    h2d_gbs = 12.0 * total * w * h * args.steps / elapsed / 1e9
     result = {
         "metric": ("Mpixels/s encode, frames resident in HBM -> codestream bytes in host memory" if args.frames_resident else
                    "Mpixels/s encode, frames in page-locked host memory -> codestream bytes in host memory (PCIe-inclusive)"),
-        "value": round(world * mpix * args.steps / elapsed, 2), "unit": "Mpixels/s", "n_gpus": world,
+        "value": round(mpix * args.steps / elapsed, 2), "unit": "Mpixels/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "batch of %d frames %dx%d per GPU per step (%d distinct), distance %.2f, %d lanes per GPU"
-                               % (n, w, h, distinct, args.distance, args.lanes),
-                   "frames_per_s": round(world * n * args.steps / elapsed, 1),
-                   "parallelism": "independent frames, one frame queue per GPU, no collective",
-                   "codestream_bytes_per_batch": int(total_bytes)},
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "batch of %d frames %dx%d per step over %d GPU(s) (%d distinct per GPU), distance %.2f, "
+                               "%d lanes per GPU" % (total, w, h, world, distinct, args.distance, args.lanes),
+                   "frames_per_s": round(total * args.steps / elapsed, 1),
+                   "parallelism": "independent frames, frame i on GPU i mod N, one frame queue per GPU, no collective",
+                   "codestream_bytes_per_batch_rank0": int(total_bytes)},
         "roofline": {"bound": "pcie", "achieved": round(h2d_gbs / world, 2), "peak": PCIE_PEAK_GBS, "unit": "GB/s",
                      "frac": round(h2d_gbs / world / PCIE_PEAK_GBS, 4), "traffic": None,
                      "note": "host->device bytes of the frames (12 B/pixel) per GPU; peak = PCIe 5.0 x16 payload rate"},

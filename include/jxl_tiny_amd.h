@@ -353,7 +353,8 @@ int jxlt_multi_encoder_encode_resident(jxlt_multi_encoder* enc, size_t xsize, si
 
 /* One process per GPU.  Rank 0 creates the segment `shm_name` ("/name"; control block, section-size tables
  * for up to max_sections sections, output_capacity bytes for the codestream), the others attach to it AFTER
- * rank 0's call has returned (callers barrier in between).  Closing detaches; rank 0 also unlinks. */
+ * rank 0's call has returned (callers barrier in between) and take its geometry (their own capacity arguments
+ * are not consulted).  Closing detaches; rank 0 also unlinks. */
 typedef struct jxlt_shard_group jxlt_shard_group;
 int jxlt_shard_group_open(const char* shm_name, int rank, int world, size_t output_capacity, size_t max_sections,
                           jxlt_shard_group** out);

@@ -180,6 +180,21 @@ JXLT_DI uint32_t pack_signed(int32_t v) {  // common.h:54-58
   return ((uint32_t)v << 1) ^ (((uint32_t)(~v) >> 31) - 1);
 }
 
+// The symbol alone (histograms).  For value >= 16 it is (n << 2) | (the two bits below the leading one) with
+// n = floor(log2 value): exactly bits 21.. of the value as a float (exponent n + 127, then the top two
+// mantissa bits; values below 2^24 convert exactly), minus 127 << 2.
+JXLT_DI uint32_t hybrid_uint_symbol(uint32_t value) {
+#ifdef JXLT_SYMBOL_BY_CLZ
+  uint32_t sym, nb, eb;
+  if (value < 16) return value;
+  const uint32_t n = 31u - (uint32_t)__clz((int)value);
+  return (n << 2) + ((value - (1u << n)) >> (n - 2));
+#else
+  const uint32_t hi = (__float_as_uint((float)value) >> 21) - (127u << 2);
+  return value < 16 ? value : hi;
+#endif
+}
+
 // token.h:32-48 (UintCoder::Encode): symbol, number of extra bits, extra bits
 JXLT_DI void hybrid_uint(uint32_t value, uint32_t* sym, uint32_t* nbits, uint32_t* bits) {
   if (value < 16) {
@@ -1851,9 +1866,7 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
       o[1] = (uint8_t)(nzl & 0xFF);
       o[2] = (uint8_t)(nzl >> 8);
       if (do_hist) {
-        uint32_t sym, nb, eb;
-        hybrid_uint((uint32_t)nzl, &sym, &nb, &eb);
-        atomicAdd(&hist[cm * 64 + sym], 1u);
+        atomicAdd(&hist[cm * 64 + hybrid_uint_symbol((uint32_t)nzl)], 1u);
       }
     }
     // (2) scan positions 0..63 of the entries: NP passes of 64 lanes.  Pass parameters per lane:
@@ -1885,9 +1898,7 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
           o[1] = (uint8_t)(val & 0xFF);
           o[2] = (uint8_t)((val >> 8) & 0xFF);
           if (do_hist) {
-            uint32_t sym, nb, eb;
-            hybrid_uint(val & 0xFFFFu, &sym, &nb, &eb);
-            atomicAdd(&hist[cms[p] * 64 + sym], 1u);
+            atomicAdd(&hist[cms[p] * 64 + hybrid_uint_symbol(val & 0xFFFFu)], 1u);
           }
         }
       }
@@ -1963,9 +1974,7 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
           o[1] = (uint8_t)(val & 0xFF);
           o[2] = (uint8_t)((val >> 8) & 0xFF);
           if (do_hist) {
-            uint32_t sym, nb, eb;
-            hybrid_uint(val & 0xFFFFu, &sym, &nb, &eb);
-            atomicAdd(&hist[cm * 64 + sym], 1u);
+            atomicAdd(&hist[cm * 64 + hybrid_uint_symbol(val & 0xFFFFu)], 1u);
           }
         }
       }

@@ -659,7 +659,7 @@ int jxlt_shard_group_open(const char* shm_name, int rank, int world, size_t outp
   if (!shm_name || shm_name[0] != '/' || world < 1 || world > jxlt::kMaxWorld || rank < 0 || rank >= world ||
       output_capacity == 0 || max_sections == 0)
     return JXLT_ERR_INVALID_ARGUMENT;
-  const size_t bytes = jxlt::ControlBytes() + jxlt::TablesBytes(max_sections) + ((output_capacity + 4095) & ~size_t(4095));
+  size_t bytes = jxlt::ControlBytes() + jxlt::TablesBytes(max_sections) + ((output_capacity + 4095) & ~size_t(4095));
   int fd;
   if (rank == 0) {
     shm_unlink(shm_name);  // a stale segment of a run that died
@@ -669,13 +669,15 @@ int jxlt_shard_group_open(const char* shm_name, int rank, int world, size_t outp
       return JXLT_ERR_OUT_OF_MEMORY;
     }
   } else {
+    // the segment is what rank 0 made it (its capacity arguments rule; this rank's are not consulted)
     fd = shm_open(shm_name, O_RDWR, 0600);
     if (fd < 0) return JXLT_ERR_INVALID_ARGUMENT;
     struct stat st;
-    if (fstat(fd, &st) != 0 || static_cast<size_t>(st.st_size) != bytes) {
+    if (fstat(fd, &st) != 0 || static_cast<size_t>(st.st_size) < jxlt::ControlBytes()) {
       close(fd);
-      return JXLT_ERR_INVALID_ARGUMENT;  // opened with other parameters than rank 0's
+      return JXLT_ERR_INVALID_ARGUMENT;
     }
+    bytes = static_cast<size_t>(st.st_size);
   }
   void* map = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
   close(fd);
@@ -693,7 +695,8 @@ int jxlt_shard_group_open(const char* shm_name, int rank, int world, size_t outp
   g->name = shm_name;
   if (rank == 0) {
     jxlt::InitControl(g->ctl, world, max_sections, (output_capacity + 4095) & ~size_t(4095), bytes);
-  } else if (g->ctl->magic != jxlt::kMagic || g->ctl->world != static_cast<uint32_t>(world)) {
+  } else if (g->ctl->magic != jxlt::kMagic || g->ctl->world != static_cast<uint32_t>(world) ||
+             g->ctl->region_bytes != bytes) {
     munmap(map, bytes);
     delete g;
     return JXLT_ERR_INVALID_ARGUMENT;
