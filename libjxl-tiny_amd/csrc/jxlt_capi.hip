@@ -852,10 +852,16 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
     }
     const TileArgs S = nslabs == 1 ? A : SlabTileArgs(A, y0, rows, ctx->pitch_floats);
     const unsigned slab_tiles = (unsigned)((size_t)S.g.xsize_tiles * S.g.ysize_tiles);
+    // (experiment knob, tools/: JXLT_TILE_EXTRA_LDS=<bytes> of unused dynamic LDS per workgroup lowers the number
+    // of resident workgroups per CU -- how much of tile_kernel's speed comes from the second one?)
+    static const unsigned extra_lds = [] {
+      const char* e = getenv("JXLT_TILE_EXTRA_LDS");
+      return e ? (unsigned)atoi(e) : 0u;
+    }();
     if (exact_roots)
-      hipLaunchKernelGGL(tile_kernel_exact_roots, dim3(slab_tiles), dim3(kTileThreads), 0, ctx->stream, S);
+      hipLaunchKernelGGL(tile_kernel_exact_roots, dim3(slab_tiles), dim3(kTileThreads), extra_lds, ctx->stream, S);
     else
-      hipLaunchKernelGGL(tile_kernel, dim3(slab_tiles), dim3(kTileThreads), 0, ctx->stream, S);
+      hipLaunchKernelGGL(tile_kernel, dim3(slab_tiles), dim3(kTileThreads), extra_lds, ctx->stream, S);
     if (sl + 1 == nslabs) {
       HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
       HIP_TRY(ctx, hipMemcpyAsync(ctx->h_lut_overflow.p, ctx->lut_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost,
