@@ -201,6 +201,46 @@ def test_multi_encoder_two_contexts_equal_single_device(built):
     me3.close()
 
 
+def test_multi_encoder_grows_its_output_region_and_reports_errors(built):
+    """Incompressible content at a tiny distance needs more than the byte per pixel the output region starts
+    with: the encoder redoes the frame with the packer's worst case.  Then: frames of changing geometry through
+    one encoder, and argument errors."""
+    rng = np.random.default_rng(11)
+    w, h, d = 520, 2048 + 520, 0.03
+    noise = rng.random((3, h, w)).astype(np.float32) * 4.0 - 1.5
+    want = T.assemble_codestream(T.oracle_hot_path(noise, d), d)
+    assert len(want) > w * h + (1 << 20)  # really beyond the initial capacity
+    me = built.MultiEncoder([0, 0])
+    assert me.encode(noise, d).tobytes() == want
+    for ww, hh, dd in [(300, 2048 + 8, 1.0), (2100, 2048 + 2048 + 1, 3.0), (64, 4096, 0.5)]:
+        p = T.to_planes(T.synthetic_image(ww, hh, seed=ww))
+        assert me.encode(p, dd).tobytes() == T.assemble_codestream(T.oracle_hot_path(p, dd), dd), (ww, hh)
+    with pytest.raises(built.JxlTinyError):
+        me.encode(T.to_planes(T.synthetic_image(64, 4096)), 0.0)  # lossless is not supported (enc_file.cc:60-62)
+    with pytest.raises(built.JxlTinyError):
+        me.encode_resident(64, 4096, 1.0)  # no slabs were set for this geometry
+    me.close()
+    with pytest.raises(built.JxlTinyError):
+        built.MultiEncoder([0, 99])  # no such device
+
+
+def test_attached_frame_survives_the_exact_roots_redo(built, enc):
+    """A frame attached from host memory whose encode has to be redone with computed square roots (flag 0x1000
+    makes tile_kernel report a table overflow): the redo must work on the resident copy, not fetch again."""
+    w, h, d = 300, 2048 + 264, 2.0
+    planes = T.to_planes(T.synthetic_image(w, h))
+    pinned, owner = built.pinned_empty((3, h, w))
+    pinned[...] = planes
+    enc.attach_host(pinned)
+    import torch
+    dp = enc.enqueue(d, 0x1000)
+    torch.cuda.synchronize()  # the first pipeline (upload included) is done; the redo has not been triggered yet
+    pinned[...] = 0.0  # the host copy is gone: a second fetch would encode zeros
+    fr = enc.fetch_raw()
+    frame = enc.assemble(fr, dp, 0)
+    assert built.file_header(w, h) + frame == T.assemble_codestream(T.oracle_hot_path(planes, d), d)
+
+
 def _shard_rank(rank, world, name, w, h, d, q, barrier):
     try:
         import sys
