@@ -414,17 +414,26 @@ void BuildDcCode(const uint32_t* histograms, EntropyCode* dc_code) {
   OptimizeEntropyCode(&h, dc_identity, kNumDCContexts, dc_code);
 }
 
+std::vector<uint8_t> BuildDcGlobal(size_t xsize, size_t ysize, const DistanceParams& distp, const EntropyCode& dc_code) {
+  const size_t num_dc_groups = DivCeil(xsize, 2048) * DivCeil(ysize, 2048);
+  jxl::BitWriter w;
+  WriteDCGlobal(distp, num_dc_groups, dc_code, &w);
+  w.ZeroPadToByte();
+  return w.TakeBytes();
+}
+
+std::vector<uint8_t> BuildAcGlobal(size_t xsize, size_t ysize, const EntropyCode& ac_code) {
+  const size_t num_groups = DivCeil(xsize, 256) * DivCeil(ysize, 256);
+  jxl::BitWriter w;
+  WriteACGlobal(num_groups, ac_code, &w);
+  w.ZeroPadToByte();
+  return w.TakeBytes();
+}
+
 void BuildFrameGlobals(size_t xsize, size_t ysize, const DistanceParams& distp, const EntropyCode& dc_code,
                        const EntropyCode& ac_code, FrameGlobals* out) {
-  const size_t num_groups = DivCeil(xsize, 256) * DivCeil(ysize, 256);
-  const size_t num_dc_groups = DivCeil(xsize, 2048) * DivCeil(ysize, 2048);
-  jxl::BitWriter dc_global, ac_global;
-  WriteDCGlobal(distp, num_dc_groups, dc_code, &dc_global);
-  WriteACGlobal(num_groups, ac_code, &ac_global);
-  dc_global.ZeroPadToByte();
-  ac_global.ZeroPadToByte();
-  out->dc_global = dc_global.TakeBytes();
-  out->ac_global = ac_global.TakeBytes();
+  out->dc_global = BuildDcGlobal(xsize, ysize, distp, dc_code);
+  out->ac_global = BuildAcGlobal(xsize, ysize, ac_code);
 }
 
 size_t HeadSizeBound(size_t xsize, size_t ysize, const FrameGlobals& globals) {

@@ -81,6 +81,9 @@ struct FrameGlobals {
 };
 void BuildFrameGlobals(size_t xsize, size_t ysize, const DistanceParams& distp, const EntropyCode& dc_code,
                        const EntropyCode& ac_code, FrameGlobals* out);
+// The two halves (each depends on its own code only; byte aligned).
+std::vector<uint8_t> BuildDcGlobal(size_t xsize, size_t ysize, const DistanceParams& distp, const EntropyCode& dc_code);
+std::vector<uint8_t> BuildAcGlobal(size_t xsize, size_t ysize, const EntropyCode& ac_code);
 size_t HeadSizeBound(size_t xsize, size_t ysize, const FrameGlobals& globals);
 bool BuildFrameHead(size_t xsize, size_t ysize, const DistanceParams& distp, const FrameGlobals& globals,
                     const PackedSections& dc, const PackedSections& ac, std::vector<uint8_t>* head);

@@ -59,6 +59,8 @@ struct Control {
   std::atomic<int32_t> failed;                        // sticky first error
   uint64_t dc_at[kMaxWorld], ac_at[kMaxWorld];        // kLayout: where each participant's sections go
   uint32_t dc_table[kHistWords], ac_table[kHistWords];
+  uint32_t ac_global_size;                            // kAcTable: the serialised ACGlobal section (its builder is
+  uint8_t ac_global[16384];                           // not the participant that assembles the frame)
   uint32_t hist[kMaxWorld][2][kHistWords];            // [participant][0 = AC, 1 = DC]
 };
 static_assert(std::atomic<uint64_t>::is_always_lock_free, "the control block needs lock-free atomics");
@@ -199,18 +201,43 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
   if (!empty && (rc = (call)) != JXLT_OK) return Fail(g, rc, what)
 
   SLAB(ops->enqueue(ops->self, &params), "device pipeline failed");
-  // participant 0 builds both codes: its helper threads (entropy_coder.h) stop sleeping now and spin for
-  // the histograms -- a wake-up would cost as much as half of a code construction
-  if (rank == 0) WarmCodeConstruction(0.0, 8.0);
+  // participants 0 and 1 build the codes: their helper threads (entropy_coder.h) stop sleeping now and spin
+  // for the histograms -- a wake-up would cost as much as half of a code construction
+  if (rank == 0 || rank == 1) WarmCodeConstruction(0.0, 8.0);
 
-  // ---- DC histograms -> DC code (participant 0) -> every participant packs its DC-group sections
+  // ---- both histograms leave for the meeting point, then the two codes are built IN PARALLEL by two
+  // participants: 0 builds the DC code, 1 the AC code (each in its own process / thread, with whatever helper
+  // threads its process has); the tables -- and the serialised ACGlobal section -- come back through the control
+  // block.  (The DC histogram is complete before the AC tokenisation runs; fetching both before waiting for
+  // either table keeps a participant's own tokenisation off the other code's critical path.)
   const uint32_t* h = nullptr;
   SLAB(ops->dc_histogram(ops->self, &h), "DC histogram fetch failed");
   if (empty) memset(c->hist[rank][1], 0, sizeof(c->hist[rank][1]));
   else memcpy(c->hist[rank][1], h, sizeof(c->hist[rank][1]));
   c->arrived[kDcHist].fetch_add(1, std::memory_order_acq_rel);
+  SLAB(ops->ac_histogram(ops->self, &h), "AC histogram fetch failed");
+  if (empty) memset(c->hist[rank][0], 0, sizeof(c->hist[rank][0]));
+  else memcpy(c->hist[rank][0], h, sizeof(c->hist[rank][0]));
+  c->arrived[kAcHist].fetch_add(1, std::memory_order_acq_rel);
+  const int ac_builder = world > 1 ? 1 : 0;
   EntropyCode dc_code, ac_code;
   std::vector<uint32_t> sum(kHistWords);
+  FrameGlobals globals;
+  auto build_ac = [&]() -> int {
+    const int rcw = WaitFor(g, [&] { return c->arrived[kAcHist].load(std::memory_order_acquire) >= all; });
+    if (rcw != JXLT_OK) return rcw;
+    std::fill(sum.begin(), sum.end(), 0u);
+    for (int r = 0; r < world; ++r)
+      for (size_t i = 0; i < kHistWords; ++i) sum[i] += c->hist[r][0][i];
+    BuildAcCode(sum.data(), &ac_code);
+    FillCodeTable(ac_code, c->ac_table);
+    const std::vector<uint8_t> acg = BuildAcGlobal(xsize, ysize, ac_code);
+    if (acg.size() > sizeof(c->ac_global)) return Fail(g, JXLT_ERR_INTERNAL, "ACGlobal section larger than expected");
+    memcpy(c->ac_global, acg.data(), acg.size());
+    c->ac_global_size = static_cast<uint32_t>(acg.size());
+    c->published[kAcTable].store(frame, std::memory_order_release);
+    return JXLT_OK;
+  };
   if (rank == 0) {
     if ((rc = WaitFor(g, [&] { return c->arrived[kDcHist].load(std::memory_order_acquire) >= all; })) != JXLT_OK)
       return rc;
@@ -220,32 +247,15 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
     BuildDcCode(sum.data(), &dc_code);
     FillCodeTable(dc_code, c->dc_table);
     c->published[kDcTable].store(frame, std::memory_order_release);
-  } else if ((rc = WaitFor(g, [&] { return c->published[kDcTable].load(std::memory_order_acquire) >= frame; })) !=
-             JXLT_OK) {
-    return rc;
+    globals.dc_global = BuildDcGlobal(xsize, ysize, distp, dc_code);
   }
+  if (rank == ac_builder && (rc = build_ac()) != JXLT_OK) return rc;
+  if ((rc = WaitFor(g, [&] { return c->published[kDcTable].load(std::memory_order_acquire) >= frame; })) != JXLT_OK)
+    return rc;
   SLAB(ops->begin_dc_pack(ops->self, c->dc_table), "DC section measuring failed");
-
-  // ---- AC histograms -> AC code
-  SLAB(ops->ac_histogram(ops->self, &h), "AC histogram fetch failed");
-  if (empty) memset(c->hist[rank][0], 0, sizeof(c->hist[rank][0]));
-  else memcpy(c->hist[rank][0], h, sizeof(c->hist[rank][0]));
-  c->arrived[kAcHist].fetch_add(1, std::memory_order_acq_rel);
-  FrameGlobals globals;
-  if (rank == 0) {
-    if ((rc = WaitFor(g, [&] { return c->arrived[kAcHist].load(std::memory_order_acquire) >= all; })) != JXLT_OK)
-      return rc;
-    std::fill(sum.begin(), sum.end(), 0u);
-    for (int r = 0; r < world; ++r)
-      for (size_t i = 0; i < kHistWords; ++i) sum[i] += c->hist[r][0][i];
-    BuildAcCode(sum.data(), &ac_code);
-    FillCodeTable(ac_code, c->ac_table);
-    c->published[kAcTable].store(frame, std::memory_order_release);
-    BuildFrameGlobals(xsize, ysize, distp, dc_code, ac_code, &globals);  // (while the devices measure)
-  } else if ((rc = WaitFor(g, [&] { return c->published[kAcTable].load(std::memory_order_acquire) >= frame; })) !=
-             JXLT_OK) {
+  if ((rc = WaitFor(g, [&] { return c->published[kAcTable].load(std::memory_order_acquire) >= frame; })) != JXLT_OK)
     return rc;
-  }
+  if (rank == 0) globals.ac_global.assign(c->ac_global, c->ac_global + c->ac_global_size);
 
   // ---- exact section sizes of every slab -> layout of the one output buffer
   jxlt_packed_sections dcm = {nullptr, nullptr, nullptr, 0}, acm = {nullptr, nullptr, nullptr, 0};
