@@ -803,9 +803,24 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
   // register file, so nothing can run beside it, and row-sized launches only add tails (measured at 16384^2:
   // eight tile_kernel launches 5.7 ms instead of 5.3, eight token_kernel launches 1.46 ms instead of 0.82).
   const bool from_host = ctx->host_src_kind != 0;
-  const size_t rows_per_slab = from_host ? 2048 : ctx->ysize;
-  const size_t nslabs = (ctx->ysize + rows_per_slab - 1) / rows_per_slab;
   const size_t xdc = (ctx->xsize + 2047) / 2048;
+  // Pieces (y0, rows) in upload order.  Host frames: whole rows of DC groups, and the LAST row of DC groups in
+  // rows of groups (256 pixel rows), so that what is left to compute when the last byte has arrived is a
+  // sixteenth of a row's tile_kernel, not all of it.  A piece never crosses a row of DC groups.
+  struct Piece {
+    size_t y0, rows;
+    bool ends_dc_row;  // the tokenisation of its row of DC groups can start behind it
+  };
+  std::vector<Piece> pieces;
+  if (!from_host) {
+    pieces.push_back({0, ctx->ysize, true});
+  } else {
+    const size_t last_row_y0 = ((ctx->ysize - 1) / 2048) * 2048;
+    for (size_t y = 0; y < last_row_y0; y += 2048) pieces.push_back({y, 2048, true});
+    for (size_t y = last_row_y0; y < ctx->ysize; y += 256)
+      pieces.push_back({y, std::min<size_t>(256, ctx->ysize - y), y + 256 >= ctx->ysize});
+  }
+  const size_t nslabs = pieces.size();
   while (ctx->slab_ready.size() < nslabs || ctx->tile_done.size() < nslabs) {
     hipEvent_t ev = nullptr;
     std::vector<hipEvent_t>& v = ctx->slab_ready.size() < nslabs ? ctx->slab_ready : ctx->tile_done;
@@ -833,8 +848,9 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
   const size_t row_bytes = ctx->xsize * sizeof(float);
   const size_t ndc_rows = (ctx->ysize + 2047) / 2048;
   const hipStream_t tok_stream = nslabs == 1 ? ctx->stream : ctx->aux_stream;  // (one launch: nothing to overlap)
+  size_t dc_rows_done = 0;  // rows of DC groups whose tokenisation has been queued
   for (size_t sl = 0; sl < nslabs; sl++) {
-    const size_t y0 = sl * rows_per_slab, y1 = std::min(ctx->ysize, y0 + rows_per_slab), rows = y1 - y0;
+    const size_t y0 = pieces[sl].y0, rows = pieces[sl].rows, y1 = y0 + rows;
     if (from_host) {
       if (ctx->host_src_kind == 1) {
         for (int c = 0; c < 3; c++)
@@ -851,6 +867,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
       HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->slab_ready[sl], 0));
     }
     const TileArgs S = nslabs == 1 ? A : SlabTileArgs(A, y0, rows, ctx->pitch_floats);
+    (void)y1;
     const unsigned slab_tiles = (unsigned)((size_t)S.g.xsize_tiles * S.g.ysize_tiles);
     // (experiment knob, tools/: JXLT_TILE_EXTRA_LDS=<bytes> of unused dynamic LDS per workgroup lowers the number
     // of resident workgroups per CU -- how much of tile_kernel's speed comes from the second one?)
@@ -869,12 +886,15 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
       HIP_TRY(ctx, hipEventRecord(ctx->overflow_ready, ctx->stream));
     }
     HIP_TRY(ctx, hipEventRecord(ctx->tile_done[sl], ctx->stream));
-    // ---- this row's tokenisation, on the aux stream
+    if (!pieces[sl].ends_dc_row) continue;
+    // ---- tokenisation of the row(s) of DC groups this piece completes, on the aux stream
     if (tok_stream != ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(tok_stream, ctx->tile_done[sl], 0));
     // DC groups first: their histogram leaves for the host as soon as the last row's is complete, so that the DC
     // code is built while token_kernel is still running
-    const size_t slab_dc = nslabs == 1 ? xdc * ndc_rows : xdc;  // DC groups of this launch
-    D.dcg_first = nslabs == 1 ? 0 : (int)(sl * xdc);
+    const size_t dc_row0 = dc_rows_done, dc_row1 = nslabs == 1 ? ndc_rows : dc_row0 + 1;
+    dc_rows_done = dc_row1;
+    const size_t slab_dc = (dc_row1 - dc_row0) * xdc;  // DC groups of this launch
+    D.dcg_first = (int)(dc_row0 * xdc);
     hipLaunchKernelGGL(dc_elementwise_kernel, dim3((unsigned)(slab_dc * kDcParts)), dim3(256), 0, tok_stream, D);
     hipLaunchKernelGGL(dc_chain_summary_kernel, dim3((unsigned)(slab_dc * kDcChainChunks)), dim3(kDcChainThreads), 0,
                        tok_stream, D);
@@ -885,10 +905,11 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
                                   hipMemcpyDeviceToHost, tok_stream));
       HIP_TRY(ctx, hipEventRecord(ctx->dc_hist_ready, tok_stream));
     }
-    const size_t g0 = (y0 / 256) * (size_t)g.xsize_groups;
-    const size_t ng = ((rows + 255) / 256) * (size_t)g.xsize_groups;
+    const size_t ty0 = dc_row0 * 2048, ty1 = std::min(ctx->ysize, dc_row1 * 2048);  // pixel rows being tokenised
+    const size_t g0 = (ty0 / 256) * (size_t)g.xsize_groups;
+    const size_t ng = ((ty1 - ty0 + 255) / 256) * (size_t)g.xsize_groups;
     hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, tok_stream,
-                       (const uint32_t*)ctx->group_ntok.p + g0, ctx->group_off.p + g0, (int)ng, sl > 0 ? 1 : 0);
+                       (const uint32_t*)ctx->group_ntok.p + g0, ctx->group_off.p + g0, (int)ng, dc_row0 > 0 ? 1 : 0);
     K.group_first = (int)g0;
     hipLaunchKernelGGL(token_kernel, dim3((unsigned)ng), dim3(kTokenThreads), 0, tok_stream, K);
   }

@@ -60,9 +60,9 @@ inline float XQmMultiplier(uint32_t x_qm_scale) {  // pow(1.25f, x_qm_scale - 2.
 
 }  // namespace jxlt_dev
 
-// tile_kernel arguments for rows [y0, y0 + rows) of a frame as a frame of its own (y0 a multiple of 2048: whole
-// rows of DC groups, so every block / tile / group / DC-group index of the slab is the frame's index minus a
-// constant): the kernel never looks across a group boundary, so only the base pointers move.  `pitch` = A.pitch.
+// tile_kernel arguments for rows [y0, y0 + rows) of a frame as a frame of its own (y0 a multiple of 256 and the
+// rows inside ONE row of DC groups -- or y0 a multiple of 2048 and any number of rows: then every block / tile /
+// group / DC-group index of the slab is the frame's index minus a constant): the kernel never looks across a group boundary, so only the base pointers move.  `pitch` = A.pitch.
 namespace jxlt_dev {
 inline TileArgs SlabTileArgs(const TileArgs& A, size_t y0, size_t rows, ptrdiff_t pitch) {
   TileArgs S = A;
