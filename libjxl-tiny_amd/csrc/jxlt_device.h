@@ -1343,6 +1343,71 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     // of block blk + 1 are issued before the arithmetic of block blk.
     float acc = 0.0f;
     const int cw = tid >> 6, cl = tid & 63;
+#ifndef JXLT_CFL_PINGPONG
+    // The chains as a RELAY over the four 16-lane rows of the wave.  A row = the 16 chain lanes (X: 8, B: 8); row
+    // k handles every fourth block, and the terms of the next four blocks are requested a whole round of four
+    // blocks ahead of their use -- in registers the other rows' lanes have anyway.  The
+    // sixteen accumulators travel from row to row (0 -> 1 -> 3 -> 2 -> 0) with one v_permlane16_swap /
+    // v_permlane32_swap per block (tools/permlane_probe.hip).  With ping-pong buffers in sixteen lanes the terms
+    // of block blk + 1 were requested only eight dependent multiply-adds before their use: less than an LDS round
+    // trip, and the chains are the workgroup's critical path.
+    const int relay_row = cl >> 4;
+    const int relay_pos = relay_row == 0 ? 0 : relay_row == 1 ? 1 : relay_row == 3 ? 2 : 3;  // place in the relay
+    if (cw < 2) {
+      __builtin_amdgcn_s_setprio(3);
+      const int ch = (cl >> 3) & 1;  // 0: X, 1: B
+      const float* src = terms + l * 32;
+      int slot[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) slot[q] = ((ch * 4 + q) ^ lsw) * 4;
+      const int last = nblk - 1;
+      // Two register sets, used in turn by ROUNDS of four blocks (one per row): at the start of a round every row
+      // requests the block it will handle in the NEXT round -- one wave-wide set of four 16-byte loads, a whole
+      // round (32 dependent multiply-adds and four hops) ahead of its use.
+      float4 ta[4], tb[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) ta[q] = *(const float4*)&src[imin(relay_pos, last) * 256 + slot[q]];
+      auto round4 = [&](const float4* t, int first) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (first + j >= nblk) break;  // (wave-uniform)
+          // every lane runs the eight steps; only the row that holds the accumulators has meaningful ones
+          if (cw == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              acc = fma32(t[q].x, t[q].x, acc);
+              acc = fma32(t[q].z, t[q].z, acc);
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              acc = fma32(t[q].x, t[q].y, acc);
+              acc = fma32(t[q].z, t[q].w, acc);
+            }
+          }
+          // the accumulators move on: rows 0 -> 1 and 3 -> 2 with a 16-lane swap, 1 -> 3 and 2 -> 0 with a 32-lane one
+          const unsigned bits = __float_as_uint(acc);
+          if (j == 0) acc = __uint_as_float(__builtin_amdgcn_permlane16_swap(bits, bits, false, false)[0]);
+          if (j == 1) acc = __uint_as_float(__builtin_amdgcn_permlane32_swap(bits, bits, false, false)[0]);
+          if (j == 2) acc = __uint_as_float(__builtin_amdgcn_permlane16_swap(bits, bits, false, false)[1]);
+          if (j == 3) acc = __uint_as_float(__builtin_amdgcn_permlane32_swap(bits, bits, false, false)[1]);
+        }
+      };
+#pragma clang loop unroll(disable)
+      for (int blk = 0; blk < nblk; blk += 8) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) tb[q] = *(const float4*)&src[imin(blk + 4 + relay_pos, last) * 256 + slot[q]];
+        round4(ta, blk);
+#pragma unroll
+        for (int q = 0; q < 4; q++) ta[q] = *(const float4*)&src[imin(blk + 8 + relay_pos, last) * 256 + slot[q]];
+        round4(tb, blk + 4);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    const int final_pos = nblk & 3;  // where the accumulators are after the last hop
+    const bool chain_lane = cw < 2 && relay_pos == final_pos;
+    const int chain_ch = (cl >> 3) & 1;
+#else
     if (cw < 2 && cl < 16) {
       __builtin_amdgcn_s_setprio(3);
       const int ch = cl >> 3;  // 0: X, 1: B
@@ -1400,9 +1465,12 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       }
       __builtin_amdgcn_s_setprio(0);
     }
+    const bool chain_lane = cw < 2 && cl < 16;
+    const int chain_ch = cl >> 3;
+#endif
     const float total = octet_sum(acc);
     // cfl_sum: ca_x, cb_x, ca_b, cb_b
-    if (cw < 2 && cl < 16 && l == 0) S.cfl_sum[(cl >> 3) * 2 + cw] = total;
+    if (chain_lane && l == 0) S.cfl_sum[chain_ch * 2 + cw] = total;
     __syncthreads();
     if (tid < 2) {  // FindBestMultiplier tail (:56-61)
       const float kDistanceMultiplierAC = 1e-3f;

@@ -67,6 +67,8 @@ struct Fiber {
   int wait_lane = -1;        // absolute thread index we are waiting for
   uint64_t wait_epoch = 0;
   uint64_t ballot_arg = 0;
+  uint32_t wave_xchg[2] = {0, 0};  // payload of the whole-wave exchanges (two slots: a lane is at most one ahead)
+  uint32_t wave_xchg_count = 0;
 };
 
 struct Machine {
@@ -300,6 +302,38 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int dpp_ctrl, int row_m
   if (!enabled) return old;
   if (src_lane < 0) return bound_ctrl ? 0 : old;
   return got;
+}
+
+// v_permlane16_swap_b32 / v_permlane32_swap_b32 (gfx950): odd 16-lane rows of the first operand trade places with
+// the even rows of the second (16), the upper half of the first with the lower half of the second (32); [0] is the
+// first operand afterwards, [1] the second (checked on the hardware by tools/permlane_probe.hip).
+struct hipsim_uint2 {
+  unsigned v[2];
+  unsigned operator[](int i) const { return v[i]; }
+};
+// (whole-wave rendezvous through the __ballot barrier: the rows that trade places belong to different octets,
+// whose shuffle counters -- the key of the point-to-point exchange above -- may differ)
+inline unsigned hipsim_wave_read(unsigned v, int src_lane) {
+  hipsim::Fiber& f = hipsim::cur();
+  const uint32_t slot = f.wave_xchg_count++ & 1u;
+  f.wave_xchg[slot] = v;
+  (void)__ballot(0);  // every unfinished lane of the wave has published its value
+  const int me = hipsim::M().current;
+  return hipsim::M().fibers[me - (me % hipsim::kWave) + src_lane].wave_xchg[slot];
+}
+inline hipsim_uint2 __builtin_amdgcn_permlane16_swap(unsigned vdst, unsigned src0, bool, bool) {
+  const int lane = hipsim_lane();
+  const bool odd = (lane >> 4) & 1;
+  const unsigned a = hipsim_wave_read(src0, odd ? lane - 16 : lane);
+  const unsigned b = hipsim_wave_read(vdst, odd ? lane : lane + 16);
+  return {{odd ? a : vdst, odd ? src0 : b}};
+}
+inline hipsim_uint2 __builtin_amdgcn_permlane32_swap(unsigned vdst, unsigned src0, bool, bool) {
+  const int lane = hipsim_lane();
+  const bool upper = lane >= 32;
+  const unsigned a = hipsim_wave_read(src0, upper ? lane - 32 : lane);
+  const unsigned b = hipsim_wave_read(vdst, upper ? lane : lane + 32);
+  return {{upper ? a : vdst, upper ? src0 : b}};
 }
 
 // v_sqrt_f32: the hardware result is within 1 ulp of the root, not always correctly rounded.
