@@ -961,15 +961,20 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
   const uint32_t bstride = (uint32_t)A.g.xsize_blocks;
 
   // ---- P0: tables -> LDS; load + XYB (enc_frame.cc:597-617, enc_xyb.cc) -----
-  for (int i = tid; i < 576; i += kTileThreads) S.inv_w[i] = T->inv_weights[i];
-  for (int i = tid; i < kSqrtLutSize; i += kTileThreads) S.sqrt_lut[i] = T->sqrt_lut[i];
-  if (tid < 64) S.y_w[tid] = T->weights[quant_table_offset(1) + tid];
-  if (tid < 128) S.y_w[64 + tid] = T->weights[quant_table_offset(4) + tid];
+  // The table values are REQUESTED here (every lane, clamped indices: no branches) and stored to LDS behind the
+  // pixel requests below, so that all of the tile's global loads are in flight together.  (Loops of "load, wait,
+  // store to LDS" in front of the pixel loads cost six serial round trips to L2 per tile.)
+  static_assert(kTileThreads == 512 && (kSqrtLutSize <= 512 || kSqrtLutSize == 1024), "table staging below");
+  const float tab_inv0 = T->inv_weights[tid];
+  const float tab_inv1 = T->inv_weights[512 + (tid & 63)];
+  const float tab_root0 = T->sqrt_lut[tid & (kSqrtLutSize - 1)];
+  const float tab_root1 = T->sqrt_lut[(512 + tid) & (kSqrtLutSize - 1)];
+  const float tab_yw = T->weights[tid < 64 ? quant_table_offset(1) + tid : quant_table_offset(4) + ((tid - 64) & 127)];
+  const uint8_t tab_order = T->coeff_order[tid < 192 ? tid : 0];
   if (tid == 0) {
     S.ntok = 0;
     S.nfirst = 0;
   }
-  if (tid < 192) S.order[tid] = T->coeff_order[tid];
   {
     // 16 lanes along x, 32 rows per pass: a thread owns 5 columns x 2 rows of the
     // (64 + 2*kHalo)-wide window, so the row and column clamps are shared and all thirty loads
@@ -1006,6 +1011,15 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
         pg[j][h] = rowp[h][1][xs];
         pb[j][h] = rowp[h][2][xs];
       }
+    }
+    // (table values -> LDS while the pixels are on their way; they were requested first, so the wait is theirs only)
+    S.inv_w[tid] = tab_inv0;
+    if (tid < 64) S.inv_w[512 + tid] = tab_inv1;
+    if (tid < kSqrtLutSize) S.sqrt_lut[tid] = tab_root0;
+    if (kSqrtLutSize > 512) S.sqrt_lut[(512 + tid) & (kSqrtLutSize - 1)] = tab_root1;
+    if (tid < 192) {
+      S.y_w[tid] = tab_yw;
+      S.order[tid] = tab_order;
     }
     if (A.byteswap) {  // big-endian PFM payload (BSwapFloat, read_pfm.cc:206)
 #pragma unroll
