@@ -136,6 +136,11 @@ JXLT_DI float zero_if_negative(float v) {
   const int bits = __float_as_int(v);
   return __int_as_float(bits < 0 ? 0 : bits);
 }
+// Value of lane K of the caller's aligned quad (quad_perm:[K,K,K,K]).
+template <int K>
+JXLT_DI float quad_lane(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K * 0x55, 0xF, 0xF, true));
+}
 // Cross-lane moves inside an octet use DPP (data-parallel primitives: a VALU move with a
 // lane permutation, no LDS round trip).  quad_perm covers xor 1 and xor 2; xor 4 is two
 // row shifts by 4 whose bank masks pick the lanes that have a partner in that direction
@@ -1100,25 +1105,43 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
         diff = masking_sqrt(diff, sqrt_mul);
         acc = (k == 0) ? diff : acc + diff;
       }
+#ifdef JXLT_AQ_UNFUSED
       S.rowsum[q * 72 + (x - aq_x0)] = acc;
+#else
+      // P2, the 4-column average (:484-491), inside the quad: aq_w is a multiple of 4 and so
+      // is the stride, so the four columns of one average sit in one aligned quad of lanes;
+      // summed in the reference's order ((c0 + c1) + c2) + c3 by lane 0 of the quad.
+      float s4 = acc + quad_lane<1>(acc);
+      s4 = s4 + quad_lane<2>(acc);
+      s4 = s4 + quad_lane<3>(acc);
+      if ((i & 3) == 0) S.pre_erosion[q * kPrePitch + ((x - aq_x0) >> 2)] = s4 * 0.25f;
+#endif
     }
   }
   __syncthreads();
   JXLT_MARK(1);
-  // ---- P2: 4-column average -> pre_erosion (:484-491) ------------------------
   const int pre_xs = aq_w / 4, pre_ys = nby * 2;
+#ifdef JXLT_AQ_UNFUSED
+  // ---- P2: 4-column average -> pre_erosion (:484-491) ------------------------
   for (int i = tid; i < pre_ys * pre_xs; i += kTileThreads) {
     const int q = i / pre_xs, j = i % pre_xs;
     const float* r = &S.rowsum[q * 72 + j * 4];
     S.pre_erosion[q * kPrePitch + j] = (r[0] + r[1] + r[2] + r[3]) * 0.25f;
   }
   __syncthreads();
+#endif
   // ---- P3: fuzzy erosion (:322-374) ------------------------------------------
   {
     const int rx0 = (aq_x0 % 8 == 0) ? 0 : 1;
     const int exs = nbx * 2, eys = nby * 2;
     for (int i = tid; i < exs * eys; i += kTileThreads) {
+#ifdef JXLT_AQ_UNFUSED
       const int fy = i / exs, fx = i % exs;
+#else
+      // The four cells of one block share a quad of lanes (cell c = lane & 3, row-major).
+      const int eb = i >> 2, ebx = eb % nbx, eby = eb / nbx;
+      const int fy = 2 * eby + ((i >> 1) & 1), fx = 2 * ebx + (i & 1);
+#endif
       const int y = fy, x = fx + rx0;
       const int ym1 = y >= 1 ? y - 1 : y, yp1 = y + 1 < pre_ys ? y + 1 : y;
       const int xm1 = x >= 1 ? x - 1 : x, xp1 = x + 1 < pre_xs ? x + 1 : x;
@@ -1140,9 +1163,22 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       store_min4(rowb[x], min0, min1, min2, min3);
       store_min4(rowb[xp1], min0, min1, min2, min3);
       const float kMul = 0.05f;
-      S.erosion[fy * 16 + fx] = kMul * row[x] + kMul * min0 + kMul * min1 + kMul * min2 + kMul * min3;
+      const float ev = kMul * row[x] + kMul * min0 + kMul * min1 + kMul * min2 + kMul * min3;
+#ifdef JXLT_AQ_UNFUSED
+      S.erosion[fy * 16 + fx] = ev;
+#else
+      // Block value (:366-373): ((e00 + e01) + e10) + e11, by lane 0 of the quad.
+      float v = ev + quad_lane<1>(ev);
+      v = v + quad_lane<2>(ev);
+      v = v + quad_lane<3>(ev);
+      if ((i & 3) == 0) {
+        S.aq[eby * 8 + ebx] = v;
+        S.mask[eby * 8 + ebx] = div_normal(1.0f, v + 0.001f);  // ComputeMaskForAcStrategyUse (:46-50)
+      }
+#endif
     }
   }
+#ifdef JXLT_AQ_UNFUSED
   __syncthreads();
   if (tid < 64) {
     const int by = tid >> 3, bx = tid & 7;
@@ -1156,6 +1192,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       S.mask[tid] = 0.0f;
     }
   }
+#endif
   __syncthreads();
   JXLT_MARK(2);
   // ---- P4: per-block modulations, one octet per block (:114-285) -------------
@@ -1602,9 +1639,13 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     if (S.strat[tid] & 1) atomicAdd(&S.nfirst, 1u);
     A.raw_quant[pos] = S.raw_quant[tid];
   }
-  // All pixel reads are done (transforms live in registers): from here on the
-  // XYB planes are reused as the quantised-coefficient staging area.
+  // All pixel reads were done before P5b (the transforms live in registers): from here on the
+  // XYB planes are reused as the quantised-coefficient staging area.  No barrier is needed
+  // between the stores above (they read S.strat / S.raw_quant, final since the barrier before
+  // them) and P8; S.nfirst is read after later barriers.
+#ifdef JXLT_P7_SECOND_BARRIER
   __syncthreads();
+#endif
   JXLT_MARK(7);
   int16_t* stage = reinterpret_cast<int16_t*>(&S.x[0]);  // [64 blocks][3][64]
 

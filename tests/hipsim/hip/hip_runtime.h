@@ -62,10 +62,14 @@ struct Fiber {
   std::vector<char> stack;
   State state = kRunnable;
   dim3 tid;
-  uint64_t shfl_epoch = 0;
-  uint64_t ring[kRing];
+  // Point-to-point exchanges are keyed by a per-lane count of exchanges, kept per scope: [0] the
+  // general shuffles / DPP row moves (octets stay in step), [1] the quad-wide DPP broadcasts
+  // (only the four lanes of a quad are known to execute them together).
+  uint64_t shfl_epoch[2] = {0, 0};
+  uint64_t ring[2][kRing];
   int wait_lane = -1;        // absolute thread index we are waiting for
   uint64_t wait_epoch = 0;
+  int wait_scope = 0;
   uint64_t ballot_arg = 0;
   uint32_t wave_xchg[2] = {0, 0};  // payload of the whole-wave exchanges (two slots: a lane is at most one ahead)
   uint32_t wave_xchg_count = 0;
@@ -106,7 +110,7 @@ inline void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
     Fiber& f = m.fibers[i];
     if (f.stack.empty()) f.stack.resize(128 * 1024);
     f.state = kRunnable;
-    f.shfl_epoch = 0;
+    f.shfl_epoch[0] = f.shfl_epoch[1] = 0;
     f.tid = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
     getcontext(&f.ctx);
     f.ctx.uc_stack.ss_sp = f.stack.data();
@@ -121,7 +125,7 @@ inline void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
       Fiber& f = m.fibers[i];
       if (f.state == kWaitLane) {
         const Fiber& src = m.fibers[f.wait_lane];
-        if (src.shfl_epoch >= f.wait_epoch) f.state = kRunnable;
+        if (src.shfl_epoch[f.wait_scope] >= f.wait_epoch) f.state = kRunnable;
         else if (src.state == kDone) {
           fprintf(stderr, "hipsim: thread %d shuffles from finished thread %d\n", i, f.wait_lane);
           abort();
@@ -183,6 +187,13 @@ inline void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
               "hipsim: DEADLOCK in block %u (divergent barrier/shuffle): %d at __syncthreads, "
               "%d at ballot, %d waiting for a shuffle partner, %d done\n",
               bidx.x, nb, nwv, nl, done);
+      for (int i = 0; i < n; i++) {
+        const Fiber& f = m.fibers[i];
+        if (f.state == kWaitLane)
+          fprintf(stderr, "  thread %d (epoch %llu) waits for lane %d (epoch %llu)\n", i,
+                  (unsigned long long)f.wait_epoch, f.wait_lane,
+                  (unsigned long long)m.fibers[f.wait_lane].shfl_epoch[f.wait_scope]);
+      }
       abort();
     }
   }
@@ -197,28 +208,29 @@ void launch(K kernel, dim3 grid, dim3 block, Args... args) {
         run_block([&]() { kernel(args...); }, grid, block, dim3(bx, by, bz));
 }
 
-inline uint64_t exchange(uint64_t v, int src_lane_in_wave) {
+inline uint64_t exchange(uint64_t v, int src_lane_in_wave, int scope = 0) {
   Machine& m = M();
   Fiber& f = cur();
   const int me = m.current;
   const int wave_base = me - (me % kWave);
   int src = wave_base + src_lane_in_wave;
   const int n = (int)m.fibers.size();
-  const uint64_t e = ++f.shfl_epoch;
-  f.ring[e % kRing] = v;
+  const uint64_t e = ++f.shfl_epoch[scope];
+  f.ring[scope][e % kRing] = v;
   if (src < 0 || src >= n || src == me) return v;
   Fiber& s = m.fibers[src];
-  if (s.shfl_epoch < e) {
+  if (s.shfl_epoch[scope] < e) {
     f.state = kWaitLane;
     f.wait_lane = src;
     f.wait_epoch = e;
+    f.wait_scope = scope;
     yield_to_scheduler();
   }
-  if (s.shfl_epoch - e >= (uint64_t)kRing) {
+  if (s.shfl_epoch[scope] - e >= (uint64_t)kRing) {
     fprintf(stderr, "hipsim: shuffle ring overflow\n");
     abort();
   }
-  return s.ring[e % kRing];
+  return s.ring[scope][e % kRing];
 }
 
 }  // namespace hipsim
@@ -234,11 +246,11 @@ inline void __syncthreads() {
 }
 
 template <typename T>
-inline T hipsim_shfl_bits(T v, int src_lane) {
+inline T hipsim_shfl_bits(T v, int src_lane, int scope = 0) {
   static_assert(sizeof(T) <= 8, "shuffle payload");
   uint64_t u = 0;
   memcpy(&u, &v, sizeof(T));
-  u = hipsim::exchange(u, src_lane);
+  u = hipsim::exchange(u, src_lane, scope);
   T r;
   memcpy(&r, &u, sizeof(T));
   return r;
@@ -298,7 +310,8 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int dpp_ctrl, int row_m
   // every lane publishes `src`; masked-out lanes read nobody (their nominal source lane may
   // belong to a diverged octet)
   const bool enabled = ((row_mask >> row) & 1) && ((bank_mask >> bank) & 1);
-  const int got = hipsim_shfl_bits(src, (src_lane < 0 || !enabled) ? lane : src_lane);
+  const bool quad_broadcast = dpp_ctrl >= 0 && dpp_ctrl <= 0xFF && dpp_ctrl % 0x55 == 0;
+  const int got = hipsim_shfl_bits(src, (src_lane < 0 || !enabled) ? lane : src_lane, quad_broadcast ? 1 : 0);
   if (!enabled) return old;
   if (src_lane < 0) return bound_ctrl ? 0 : old;
   return got;
