@@ -1086,6 +1086,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       const bool vec = x >= vs && x < ve;
       const int xl = x > 0 ? x - 1 : x, xr = x + 1 < swp ? x + 1 : x;
       float acc = 0.0f;
+#ifdef JXLT_AQ_BRANCHY
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const int y = q * 4 + k;
@@ -1105,6 +1106,42 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
         diff = masking_sqrt(diff, sqrt_mul);
         acc = (k == 0) ? diff : acc + diff;
       }
+#else
+      // The band's column, rows y0-1 .. y0+4 (clamped to the stripe: only the first and the
+      // last entry can clamp, shp = 8 nby), is read once; both association orders are computed
+      // and selected (a branch per pixel would wait for the LDS before and after each arm).
+      const int y0 = q * 4;
+      const int yu0 = y0 > 0 ? y0 - 1 : y0, yd3 = y0 + 4 < shp ? y0 + 4 : y0 + 3;
+      float cy[6], cxx[6], ly4[4], ry4[4], lx4[4], rx4[4];
+      cy[0] = SY(yu0, x);
+      cxx[0] = SX(yu0, x);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        cy[k + 1] = SY(y0 + k, x);
+        cxx[k + 1] = SX(y0 + k, x);
+        ly4[k] = SY(y0 + k, xl);
+        ry4[k] = SY(y0 + k, xr);
+        lx4[k] = SX(y0 + k, xl);
+        rx4[k] = SX(y0 + k, xr);
+      }
+      cy[5] = SY(yd3, x);
+      cxx[5] = SX(yd3, x);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const float in = cy[k + 1], du = cy[k + 2] + cy[k];
+        const float base = 0.25f * (vec ? (ry4[k] + ly4[k]) + du : (du + ly4[k]) + ry4[k]);
+        const float gammac = ratio_of_derivatives(in + match_gamma_offset, false);
+        float diff = gammac * (in - base);
+        diff = diff * diff;
+        const float ix = cxx[k + 1], dux = cxx[k + 2] + cxx[k];
+        const float base_x = 0.25f * (vec ? (rx4[k] + lx4[k]) + dux : (dux + lx4[k]) + rx4[k]);
+        float diff_x = gammac * (ix - base_x);
+        diff_x = diff_x * diff_x;
+        const float fused = fma32(kXMul, diff_x, diff), unfused = diff + kXMul * diff_x;
+        diff = masking_sqrt(vec ? fused : unfused, sqrt_mul);
+        acc = (k == 0) ? diff : acc + diff;
+      }
+#endif
 #ifdef JXLT_AQ_UNFUSED
       S.rowsum[q * 72 + (x - aq_x0)] = acc;
 #else

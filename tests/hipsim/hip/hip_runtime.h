@@ -284,6 +284,8 @@ inline unsigned long long __ballot(int pred) {
   return hipsim::M().ballot_result[hipsim::M().current / hipsim::kWave];
 }
 
+inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+
 // DPP move (llvm.amdgcn.update.dpp): lane i reads `src` of the lane selected by dpp_ctrl; lanes
 // whose row/bank is masked out, or whose source lane is outside the row, keep `old`
 // (or get 0 with bound_ctrl).  Supported controls: quad_perm (0x00-0xFF), row_shl:n
