@@ -877,6 +877,8 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
     }();
     if (exact_roots)
       hipLaunchKernelGGL(tile_kernel_exact_roots, dim3(slab_tiles), dim3(kTileThreads), extra_lds, ctx->stream, S);
+    else if (debug || profile)
+      hipLaunchKernelGGL(tile_kernel_debug, dim3(slab_tiles), dim3(kTileThreads), extra_lds, ctx->stream, S);
     else
       hipLaunchKernelGGL(tile_kernel, dim3(slab_tiles), dim3(kTileThreads), extra_lds, ctx->stream, S);
     if (sl + 1 == nslabs) {

@@ -917,14 +917,16 @@ JXLT_DI void quantize_transform(float* cx, float* cy, float* cb, const TileShare
   }
 }
 
-template <bool kLutRoots>
+// kDebug: the variant that serves the A.dbg_* outputs (per-phase clocks, intermediate planes for
+// the parity tests); the production variant has none of their tests, branches and registers.
+template <bool kLutRoots, bool kDebug>
 JXLT_DI void tile_kernel_body(const TileArgs& A) {
   __shared__ TileShared S;
   const int tid = (int)threadIdx.x;
   const int l = tid & 7;    // lane within octet
   const int oct = tid >> 3;  // octet index == block index within tile (0..63)
   const DeviceTables* T = A.tab;
-  long long t_prev = A.dbg_phase ? clock64() : 0;
+  long long t_prev = (kDebug && A.dbg_phase) ? clock64() : 0;
   // Profiling builds (-DJXLT_PHASE_STOPS, tools/phase_pmc.py) can truncate the kernel after
   // phase i; the early exits perturb code generation, so production builds leave them out.
 #ifdef JXLT_PHASE_STOPS
@@ -933,7 +935,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
 #define JXLT_STOP(i)
 #endif
 #define JXLT_MARK(i)                                                        \
-  if (A.dbg_phase && tid == 0) {                                            \
+  if (kDebug && A.dbg_phase && tid == 0) {                                  \
     const long long t_now = clock64();                                      \
     atomicAdd(&A.dbg_phase[i], (unsigned long long)(t_now - t_prev));       \
     t_prev = t_now;                                                         \
@@ -1051,7 +1053,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
         S.x[y * kXYPitch + cx] = px_;
         S.y[y * kXYPitch + cx] = py_;
         if (j < 4) S.b[y * kBPitch + cx - kHalo] = pb_;
-        if (j < 4 && A.dbg_xyb[0] && cx < kHalo + nbx * 8) {
+        if (kDebug && j < 4 && A.dbg_xyb[0] && cx < kHalo + nbx * 8) {
           const size_t d = (size_t)(by_img0 * 8 + y) * ((size_t)bstride * 8) + (size_t)(bx_img0 * 8 + cx - kHalo);
           A.dbg_xyb[0][d] = px_;
           A.dbg_xyb[1][d] = py_;
@@ -1316,7 +1318,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
         v = v < 1 ? 1 : v > 255 ? 255 : v;
         S.raw_quant[oct] = (uint8_t)v;
         S.strat[oct] = 1;  // DCT8, first block (FillDCT8)
-        if (A.dbg_qf) {
+        if (kDebug && A.dbg_qf) {
           const uint32_t pos = (uint32_t)(by_img0 + oby) * bstride + (uint32_t)(bx_img0 + obx);
           A.dbg_qf[pos] = qf;
           A.dbg_mask[pos] = S.mask[oct];
@@ -1652,7 +1654,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
         if (t16 < e00 + e01) { S.strat[b00] = (2 << 1) | 1; S.strat[b00 + 1] = (2 << 1); }
         if (b16 < e10 + e11) { S.strat[b00 + 8] = (2 << 1) | 1; S.strat[b00 + 9] = (2 << 1); }
       }
-      if (A.dbg_ent8) {
+      if (kDebug && A.dbg_ent8) {
         const size_t cells_x = (size_t)A.g.xsize_blocks / 2 + 1;
         float* d = A.dbg_ent8 + (((size_t)(by_img0 + cy) / 2) * cells_x + (size_t)(bx_img0 + cx) / 2) * 8;
         for (int k = 0; k < 8; k++) d[k] = e[k];
@@ -1827,9 +1829,10 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
 // tile_kernel: roots of the entropy estimate from the LDS table (the product path);
 // tile_kernel_exact_roots: every root computed -- the same results, needed only for frames in
 // which tile_kernel met a quantised magnitude beyond the table.
-__global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A) { tile_kernel_body<true>(A); }
+__global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A) { tile_kernel_body<true, false>(A); }
+__global__ void __launch_bounds__(kTileThreads, 4) tile_kernel_debug(const TileArgs A) { tile_kernel_body<true, true>(A); }
 __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel_exact_roots(const TileArgs A) {
-  tile_kernel_body<false>(A);
+  tile_kernel_body<false, true>(A);
 }
 
 // ---------------------------------------------------------------------------

@@ -114,7 +114,9 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   if (flags & 0x400u) {
     launch_tiles(tile_kernel_exact_roots);
   } else {
-    launch_tiles(tile_kernel);
+    // 0x800: the production variant (no debug outputs: r->xyb, qf, mask, ent8 stay as initialised)
+    if (flags & 0x800u) launch_tiles(tile_kernel);
+    else launch_tiles(tile_kernel_debug);
     if (lut_overflow) {
       sim_free(r);
       for (int c = 0; c < 3; c++) free(A.nzgrid[c]);

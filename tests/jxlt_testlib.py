@@ -286,14 +286,16 @@ def pfm_payload(planes, big_endian=False):
     return a.astype(">f4" if big_endian else "<f4").view(np.float32).reshape(-1).copy()
 
 
-def sim_hot_path(planes, distance, force_dct8=False, as_pfm=None, tiny_root_table=False):
+def sim_hot_path(planes, distance, force_dct8=False, as_pfm=None, tiny_root_table=False, production_variant=False):
     """Runs the product's HIP kernels on the CPU execution model (tests only).  as_pfm = "le" /
-    "be": the kernels read the frame from a raw PFM payload instead of planar planes."""
+    "be": the kernels read the frame from a raw PFM payload instead of planar planes.
+    production_variant: tile_kernel as the product launches it (without the debug outputs xyb, qf,
+    mask, ent8) instead of tile_kernel_debug."""
     _sim = _sim_lib(tiny_root_table)
     _, h, w = planes.shape
     p = distance_params(distance)
     s = SimResult()
-    flags = 1 if force_dct8 else 0
+    flags = (1 if force_dct8 else 0) | (0x800 if production_variant else 0)
     if as_pfm:
         payload = pfm_payload(planes, as_pfm == "be")
         ptrs = (fp * 3)(payload.ctypes.data_as(fp), None, None)

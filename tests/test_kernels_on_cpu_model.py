@@ -33,6 +33,16 @@ def test_kernels_match_oracle_bit_exact(built, w, h, distance, hard, dct8):
     assert T.compare_results(want, got, "oracle", "kernels") == []
 
 
+@pytest.mark.parametrize("w,h,distance,hard,dct8", [CASES[0], CASES[1], CASES[3], CASES[5], CASES[7]])
+def test_production_variant_of_tile_kernel_matches_oracle(built, w, h, distance, hard, dct8):
+    """tile_kernel as the product launches it (compiled without the debug outputs the test above
+    reads through tile_kernel_debug): everything that reaches the codestream, bit-exact."""
+    planes = T.to_planes(T.synthetic_image(w, h, hard=hard))
+    want = T.oracle_hot_path(planes, distance, dct8)
+    got = T.sim_hot_path(planes, distance, dct8, production_variant=True)
+    assert T.compare_results(want, got, "oracle", "kernels", check_debug=False) == []
+
+
 def test_token_kernel_histogram_matches_tokens(built):
     planes = T.to_planes(T.synthetic_image(300, 264))
     got = T.sim_hot_path(planes, 1.0)
