@@ -1083,35 +1083,29 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     const int nvec = (aq_x1 - 10 >= vs) ? ((aq_x1 - 10 - vs) / 8 + 1) : 0;
     const int ve = vs + 8 * nvec;
     const int nbands = nby * 2;
+    // One pixel's term from its own value, the sum of its vertical neighbours and its horizontal
+    // neighbours; both association orders are computed and selected (a branch per pixel would wait
+    // for the LDS before and after each arm).
+    auto pixel_term = [&](bool vec, float in, float du, float in_l, float in_r, float ix, float dux, float ix_l,
+                          float ix_r) {
+      const float base = 0.25f * (vec ? (in_r + in_l) + du : (du + in_l) + in_r);
+      const float gammac = ratio_of_derivatives(in + match_gamma_offset, false);
+      float diff = gammac * (in - base);
+      diff = diff * diff;
+      const float base_x = 0.25f * (vec ? (ix_r + ix_l) + dux : (dux + ix_l) + ix_r);
+      float diff_x = gammac * (ix - base_x);
+      diff_x = diff_x * diff_x;
+      const float fused = fma32(kXMul, diff_x, diff), unfused = diff + kXMul * diff_x;
+      return masking_sqrt(vec ? fused : unfused, sqrt_mul);
+    };
+    // (Spreading the last, partly filled pass over all threads row by row changes nothing: the
+    // other resident workgroup takes the issue slots the idle waves leave.)
     for (int i = tid; i < nbands * aq_w; i += kTileThreads) {
       const int q = i / aq_w, x = aq_x0 + i % aq_w;
       const bool vec = x >= vs && x < ve;
       const int xl = x > 0 ? x - 1 : x, xr = x + 1 < swp ? x + 1 : x;
-      float acc = 0.0f;
-#ifdef JXLT_AQ_BRANCHY
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int y = q * 4 + k;
-        const int yu = y > 0 ? y - 1 : y, yd = y + 1 < shp ? y + 1 : y;
-        const float in = SY(y, x), in_l = SY(y, xl), in_r = SY(y, xr), in_u = SY(yu, x), in_d = SY(yd, x);
-        const float base = vec ? 0.25f * ((in_r + in_l) + (in_d + in_u))
-                               : 0.25f * (in_d + in_u + in_l + in_r);
-        const float gammac = ratio_of_derivatives(in + match_gamma_offset, false);
-        float diff = gammac * (in - base);
-        diff = diff * diff;
-        const float ix = SX(y, x), ix_l = SX(y, xl), ix_r = SX(y, xr), ix_u = SX(yu, x), ix_d = SX(yd, x);
-        const float base_x = vec ? 0.25f * ((ix_r + ix_l) + (ix_d + ix_u))
-                                 : 0.25f * (ix_d + ix_u + ix_l + ix_r);
-        float diff_x = gammac * (ix - base_x);
-        diff_x = diff_x * diff_x;
-        diff = vec ? fma32(kXMul, diff_x, diff) : diff + kXMul * diff_x;
-        diff = masking_sqrt(diff, sqrt_mul);
-        acc = (k == 0) ? diff : acc + diff;
-      }
-#else
       // The band's column, rows y0-1 .. y0+4 (clamped to the stripe: only the first and the
-      // last entry can clamp, shp = 8 nby), is read once; both association orders are computed
-      // and selected (a branch per pixel would wait for the LDS before and after each arm).
+      // last entry can clamp, shp = 8 nby), is read once.
       const int y0 = q * 4;
       const int yu0 = y0 > 0 ? y0 - 1 : y0, yd3 = y0 + 4 < shp ? y0 + 4 : y0 + 3;
       float cy[6], cxx[6], ly4[4], ry4[4], lx4[4], rx4[4];
@@ -1128,25 +1122,13 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       }
       cy[5] = SY(yd3, x);
       cxx[5] = SX(yd3, x);
+      float acc = 0.0f;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const float in = cy[k + 1], du = cy[k + 2] + cy[k];
-        const float base = 0.25f * (vec ? (ry4[k] + ly4[k]) + du : (du + ly4[k]) + ry4[k]);
-        const float gammac = ratio_of_derivatives(in + match_gamma_offset, false);
-        float diff = gammac * (in - base);
-        diff = diff * diff;
-        const float ix = cxx[k + 1], dux = cxx[k + 2] + cxx[k];
-        const float base_x = 0.25f * (vec ? (rx4[k] + lx4[k]) + dux : (dux + lx4[k]) + rx4[k]);
-        float diff_x = gammac * (ix - base_x);
-        diff_x = diff_x * diff_x;
-        const float fused = fma32(kXMul, diff_x, diff), unfused = diff + kXMul * diff_x;
-        diff = masking_sqrt(vec ? fused : unfused, sqrt_mul);
+        const float diff = pixel_term(vec, cy[k + 1], cy[k + 2] + cy[k], ly4[k], ry4[k], cxx[k + 1],
+                                      cxx[k + 2] + cxx[k], lx4[k], rx4[k]);
         acc = (k == 0) ? diff : acc + diff;
       }
-#endif
-#ifdef JXLT_AQ_UNFUSED
-      S.rowsum[q * 72 + (x - aq_x0)] = acc;
-#else
       // P2, the 4-column average (:484-491), inside the quad: aq_w is a multiple of 4 and so
       // is the stride, so the four columns of one average sit in one aligned quad of lanes;
       // summed in the reference's order ((c0 + c1) + c2) + c3 by lane 0 of the quad.
@@ -1154,33 +1136,20 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       s4 = s4 + quad_lane<2>(acc);
       s4 = s4 + quad_lane<3>(acc);
       if ((i & 3) == 0) S.pre_erosion[q * kPrePitch + ((x - aq_x0) >> 2)] = s4 * 0.25f;
-#endif
     }
   }
   __syncthreads();
   JXLT_MARK(1);
   const int pre_xs = aq_w / 4, pre_ys = nby * 2;
-#ifdef JXLT_AQ_UNFUSED
-  // ---- P2: 4-column average -> pre_erosion (:484-491) ------------------------
-  for (int i = tid; i < pre_ys * pre_xs; i += kTileThreads) {
-    const int q = i / pre_xs, j = i % pre_xs;
-    const float* r = &S.rowsum[q * 72 + j * 4];
-    S.pre_erosion[q * kPrePitch + j] = (r[0] + r[1] + r[2] + r[3]) * 0.25f;
-  }
-  __syncthreads();
-#endif
   // ---- P3: fuzzy erosion (:322-374) ------------------------------------------
   {
     const int rx0 = (aq_x0 % 8 == 0) ? 0 : 1;
-    const int exs = nbx * 2, eys = nby * 2;
-    for (int i = tid; i < exs * eys; i += kTileThreads) {
-#ifdef JXLT_AQ_UNFUSED
-      const int fy = i / exs, fx = i % exs;
-#else
-      // The four cells of one block share a quad of lanes (cell c = lane & 3, row-major).
-      const int eb = i >> 2, ebx = eb % nbx, eby = eb / nbx;
-      const int fy = 2 * eby + ((i >> 1) & 1), fx = 2 * ebx + (i & 1);
-#endif
+    // The four cells of one block share a quad of lanes (cell c = lane & 3, row-major); quad e of
+    // the first 256 threads has block e of the 8x8 grid, blocks outside the tile get aq = mask = 0.
+    if (tid < 256) {
+      const int i = tid, ebx = (tid >> 2) & 7, eby = tid >> 5;
+      const bool eb_valid = ebx < nbx && eby < nby;
+      const int fy = eb_valid ? 2 * eby + ((i >> 1) & 1) : 0, fx = eb_valid ? 2 * ebx + (i & 1) : 0;
       const int y = fy, x = fx + rx0;
       const int ym1 = y >= 1 ? y - 1 : y, yp1 = y + 1 < pre_ys ? y + 1 : y;
       const int xm1 = x >= 1 ? x - 1 : x, xp1 = x + 1 < pre_xs ? x + 1 : x;
@@ -1203,35 +1172,16 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       store_min4(rowb[xp1], min0, min1, min2, min3);
       const float kMul = 0.05f;
       const float ev = kMul * row[x] + kMul * min0 + kMul * min1 + kMul * min2 + kMul * min3;
-#ifdef JXLT_AQ_UNFUSED
-      S.erosion[fy * 16 + fx] = ev;
-#else
       // Block value (:366-373): ((e00 + e01) + e10) + e11, by lane 0 of the quad.
       float v = ev + quad_lane<1>(ev);
       v = v + quad_lane<2>(ev);
       v = v + quad_lane<3>(ev);
       if ((i & 3) == 0) {
-        S.aq[eby * 8 + ebx] = v;
-        S.mask[eby * 8 + ebx] = div_normal(1.0f, v + 0.001f);  // ComputeMaskForAcStrategyUse (:46-50)
+        S.aq[eby * 8 + ebx] = eb_valid ? v : 0.0f;
+        S.mask[eby * 8 + ebx] = eb_valid ? div_normal(1.0f, v + 0.001f) : 0.0f;  // ComputeMaskForAcStrategyUse (:46-50)
       }
-#endif
     }
   }
-#ifdef JXLT_AQ_UNFUSED
-  __syncthreads();
-  if (tid < 64) {
-    const int by = tid >> 3, bx = tid & 7;
-    if (bx < nbx && by < nby) {
-      const float* e = &S.erosion[(2 * by) * 16 + 2 * bx];
-      const float v = ((e[0] + e[1]) + e[16]) + e[17];
-      S.aq[tid] = v;
-      S.mask[tid] = div_normal(1.0f, v + 0.001f);  // ComputeMaskForAcStrategyUse (:46-50)
-    } else {
-      S.aq[tid] = 0.0f;
-      S.mask[tid] = 0.0f;
-    }
-  }
-#endif
   __syncthreads();
   JXLT_MARK(2);
   // ---- P4: per-block modulations, one octet per block (:114-285) -------------
@@ -1248,13 +1198,15 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     const float kRedRampLength = (float)0.019421555948474039;
     const float kBlueRampLength = (float)0.086890611400405895;
     const float kBlueRampStart = (float)0.26973418507870539;
+    const int right_step = l < 7 ? 1 : 0;
     if (blk_valid) {
 #pragma unroll
       for (int dy = 0; dy < 8; dy++) {
         const int yy = byp + dy, xx = bxp + l;
         const float p = SY(yy, xx);
-        const float right = (l < 7) ? fabsf(p - SY(yy, xx + 1)) : 0.0f;
-        hf = hf + right;
+        // column 7 has no right neighbour inside the block: it reads itself (|p - p| = 0, as the
+        // reference adds) instead of branching around the read
+        hf = hf + fabsf(p - SY(yy, xx + right_step));
         const float pd = (dy == 7) ? p : SY(yy + 1, xx);
         hf = hf + fabsf(p - pd);
         // ColorModulation (:146-207)
