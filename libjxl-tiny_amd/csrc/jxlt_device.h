@@ -171,6 +171,12 @@ JXLT_DI float octet_sum(float v) {
   v = v + octet_xor<1>(v);
   return v;
 }
+JXLT_DI float octet_max(float v) {
+  v = fmaxf(v, octet_xor<4>(v));
+  v = fmaxf(v, octet_xor<2>(v));
+  v = fmaxf(v, octet_xor<1>(v));
+  return v;
+}
 JXLT_DI int octet_sum_int(int v) {
   v = v + octet_xor_i<4>(v);
   v = v + octet_xor_i<2>(v);
@@ -777,9 +783,8 @@ JXLT_DI float adjust_quant_bias_y(float quant) {
 }
 
 // enc_group.cc:221-278 for the lane's rows.  NR = 8: xsize=ysize=1; NR = 16: xsize=2, ysize=1.
-template <int NR, bool kKeepFloat = false>
-JXLT_DI void quantize_rows(const float* in, int c, const float* inv, int l, float quantv, int* out,
-                           float* outf = nullptr) {
+template <int NR>
+JXLT_DI void quantize_rows(const float* in, int c, const float* inv, int l, float quantv, float* outf) {
   // thresholds of the four quadrants (enc_group.cc:227-242)
   float t0 = 0.58f;
   float t1 = c == 0 ? 0.635f + 0.08f : c == 2 ? 0.75f : 0.635f;
@@ -800,11 +805,7 @@ JXLT_DI void quantize_rows(const float* in, int c, const float* inv, int l, floa
     const float q = inv[r * 8 + l] * quantv;
     const float val = q * in[r];
     const bool nz = fabsf(val) >= thr;
-    if (kKeepFloat) {
-      outf[r] = nz ? rintf(val) : 0.0f;
-    } else {
-      out[r] = nz ? (int)rintf(val) : 0;
-    }
+    outf[r] = nz ? rintf(val) : 0.0f;  // the quantised coefficient as an integer-valued float
   }
 }
 
@@ -814,7 +815,8 @@ JXLT_DI void quantize_rows(const float* in, int c, const float* inv, int l, floa
 template <int NR>
 JXLT_DI void quantize_transform(float* cx, float* cy, float* cb, const TileShared& S, int strategy,
                                 int l, int quant_ac, const TileArgs& A, float x_factor,
-                                float b_factor, int ibx, int iby, int16_t* slot_a, int16_t* slot_b) {
+                                float b_factor, int ibx, int iby, int16_t* slot_a, int16_t* slot_b,
+                                const float* scan_pos, uint8_t* nscan_entry, uint32_t* tokens) {
   const DeviceTables* T = A.tab;
   const int kind_off = strategy * 3;
   const float* inv_x = S.inv_w + quant_table_offset(kind_off + 0);
@@ -850,22 +852,32 @@ JXLT_DI void quantize_transform(float* cx, float* cy, float* cb, const TileShare
     if (NR == 16) A.quant_dc[1][pos1] = dcy_b;
   }
   const int covered = NR / 8;
-  // nzeros (enc_group.cc:51-148) + staging of one channel's quantised rows
-  auto stage_channel = [&](int c, const auto* q) {  // q: the quantised rows, int or integer-valued float
-    int cnt = 0;
+  // nzeros (enc_group.cc:51-148), the scan position behind the last nonzero coefficient
+  // (enc_group.cc:166-183: what the scan-order store and the tokeniser need) + staging of one
+  // channel's quantised rows.  q: integer-valued floats.  Counted with clamped multiply-adds
+  // (a compare + select pair costs twice as much on gfx950): [q != 0] = clamp01(4 |q|).
+  const float not_llf = l < covered ? 0.0f : 1.0f;
+  auto stage_channel = [&](int c, const float* q) {
+    float cnt = 0.0f, last = 0.0f;
 #pragma unroll
     for (int r = 0; r < NR; r++) {
-      const bool llf = (r == 0) && (l < covered);
-      cnt += (!llf && q[r] != 0) ? 1 : 0;
+      float nz = clamp01(4.0f * fabsf(q[r]));
+      if (r == 0) nz = nz * not_llf;  // the lowest frequencies (DC) are coded elsewhere
+      cnt = cnt + nz;
+      last = fmaxf(last, nz * scan_pos[r * 8 + l]);  // scan position + 1
       int16_t* dst = (r * 8 + l < 64) ? slot_a : slot_b;
       dst[c * 64 + ((r * 8 + l) & 63)] = (int16_t)(int)q[r];
     }
-    const int nzeros = octet_sum_int(cnt);
+    const int nzeros = (int)octet_sum(cnt);
+    const int nscan = (int)octet_max(last);
     if (l == 0) {
       // (select, not A.nzgrid[c]: indexing a kernel-argument array by a runtime value
       // would force the argument block into scratch memory)
       uint8_t* nzg = c == 0 ? A.nzgrid[0] : c == 1 ? A.nzgrid[1] : A.nzgrid[2];
       A.blk_nz[pos0 * 3 + c] = (uint8_t)nzeros;
+      A.blk_nscan[pos0 * 3 + c] = (uint8_t)nscan;
+      nscan_entry[c] = (uint8_t)nscan;
+      *tokens += 1 + (nscan > covered ? nscan - covered : 0);
       if (NR == 8) {
         nzg[pos0] = (uint8_t)nzeros;
       } else {
@@ -877,7 +889,7 @@ JXLT_DI void quantize_transform(float* cx, float* cy, float* cb, const TileShare
   };
   {
     float qyf[NR];
-    quantize_rows<NR, true>(cy, 1, inv_y, l, qac * 1.0f, nullptr, qyf);
+    quantize_rows<NR>(cy, 1, inv_y, l, qac * 1.0f, qyf);
     stage_channel(1, qyf);
     const float inv_qac = T->inv_qac[quant_ac];
 #pragma unroll
@@ -892,7 +904,7 @@ JXLT_DI void quantize_transform(float* cx, float* cy, float* cb, const TileShare
     const float* inv = c == 0 ? inv_x : inv_b;
     const float qmul = c == 0 ? A.x_qm_mul : (float)1.0;
     float cur[NR];
-    int q[NR];
+    float q[NR];
 #pragma unroll
     for (int r = 0; r < NR; r++) cur[r] = nfma32(factor, cy[r], c == 0 ? cx[r] : cb[r]);
     quantize_rows<NR>(cur, c, inv, l, qac * qmul, q);
@@ -1533,6 +1545,14 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     A.ytob[(size_t)ty_img * A.g.xsize_tiles + tx_img] = (int8_t)ytob;
   }
 
+  // The term area is dead again.  Behind what P6b and P8 use of it (the parked coefficients,
+  // 48 KB; the staging area) it holds, from here on:
+  //   scan_pos[n] = 1 + scan position of natural coefficient n ([0,64) DCT8, [64,192) the
+  //     two-block transforms): the inverse of S.order, read by P8;
+  //   nscan_tab[block][channel] = scan position behind the block's last nonzero coefficient (P8 -> P9).
+  float* const scan_pos = &S.x[0] + 24 * kTileThreads;
+  uint8_t* const nscan_tab = reinterpret_cast<uint8_t*>(scan_pos + 192);
+  if (tid < 192) scan_pos[(tid < 64 ? 0 : 64) + S.order[tid]] = (float)((tid < 64 ? tid : tid - 64) + 1);
   // ---- P6b: entropy estimates (enc_ac_strategy.cc:68-146,187-212) -----------
   float qmax = 0.0f;  // largest quantised magnitude whose root was taken from the table
   if (search) {
@@ -1642,11 +1662,13 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
 
   // ---- P8: quantise (enc_group.cc:304-443) -----------------------------------
   {
+    uint32_t octet_tokens = 0;  // lane 0: tokens of the transforms this octet quantises
     // (a) this octet's own block, if it stayed DCT8
     const bool do8 = blk_valid && S.strat[oct] == 1;
     if (do8) {
       quantize_transform<8>(c8x, c8y, c8b, S, 0, l, S.raw_quant[oct], A, cmap_x, cmap_b,
-                            bx_img0 + obx, by_img0 + oby, stage + oct * kStageStride, stage + oct * kStageStride);
+                            bx_img0 + obx, by_img0 + oby, stage + oct * kStageStride, stage + oct * kStageStride,
+                            scan_pos, nscan_tab + oct * 3, &octet_tokens);
     }
     // (b) this octet's two-block candidate, if it was selected
     const int bi = cby * 8 + cbx;
@@ -1655,31 +1677,33 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       const int o2 = is_tall ? 8 : 1;
       quantize_transform<16>(c16x, c16y, c16b, S, is_tall ? 1 : 2, l, S.raw_quant[bi], A, cmap_x,
                              cmap_b, bx_img0 + cbx, by_img0 + cby, stage + bi * kStageStride,
-                             stage + (bi + o2) * kStageStride);
+                             stage + (bi + o2) * kStageStride, scan_pos + 64, nscan_tab + bi * 3, &octet_tokens);
     }
+    if (l == 0 && octet_tokens) atomicAdd(&S.ntok, octet_tokens);
   }
   __syncthreads();
   JXLT_MARK(8);
 
   // ---- P9: scan-order store; wave w stores block row w of the tile -------------
   {
-    // Everything but the coefficient itself is wave-uniform here (block, strategy, output
-    // positions, last-nonzero position), so the wave index is pinned to a scalar register and
-    // the bookkeeping runs on the scalar unit.
+    // Nothing here depends on the coefficient values any more: which positions are stored
+    // (those below the scan position behind the last nonzero, nscan_tab from P8) is wave-uniform
+    // and known before the staged coefficients arrive, so the wave index is pinned to a scalar
+    // register, the bookkeeping runs on the scalar unit and the LDS reads of the next block are
+    // in flight while a block is stored.
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    uint32_t wave_tokens = 0;
     const int by = wave;
-#ifndef JXLT_P9_SERIAL
-    // One LDS round trip per block instead of three: the scan tables (loop invariant) and the strategies of
-    // the wave's block row (eight bytes) are fetched once, and the staged coefficients of block bx + 1 are
-    // requested before block bx is balloted and stored (the phase is latency bound: a handful of instructions
-    // per block behind dependent LDS reads).
     if (by < nby) {
       const int ord8 = S.order[lane], ord16a = S.order[64 + lane], ord16b = S.order[128 + lane];
       const uint32_t* srow = reinterpret_cast<const uint32_t*>(&S.strat[by * 8]);
       const uint32_t srow_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)srow[0]);
       const uint32_t srow_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)srow[1]);
       auto strategy_of = [&](int bx) { return (int)(((bx < 4 ? srow_lo : srow_hi) >> (8 * (bx & 3))) & 0xFFu); };
+      // the row's 24 nscan bytes (block-major, channel-minor) as six scalar words
+      const uint32_t* nsrow = reinterpret_cast<const uint32_t*>(nscan_tab + by * 24);
+      uint32_t nsw[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) nsw[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)nsrow[k]);
       auto fetch = [&](int bx, int16_t* v0s, int16_t* v1s) {
         const int bi = by * 8 + bx;
         const int st = strategy_of(bx) >> 1;
@@ -1702,67 +1726,18 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
         const int a = strategy_of(bx);
         if (bx >= nbx || !(a & 1)) continue;
         const int st = a >> 1;
-        const int covered = st == 0 ? 1 : 2;
         const uint32_t pos0 = (uint32_t)(by_img0 + by) * bstride + (uint32_t)(bx_img0 + bx);
         const uint32_t pos1 = pos0 + (st == 1 ? bstride : 1u);
-        const unsigned long long llf_mask = covered == 2 ? 3ull : 1ull;  // scan positions < covered
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-          const int16_t v0 = v0s[c], v1 = v1s[c];
-          const unsigned long long m0 = __ballot(v0 != 0) & ~llf_mask;
-          int nscan = m0 != 0 ? 64 - __clzll((long long)m0) : 0;
-          const unsigned long long m1 = __ballot(v1 != 0);
-          if (m1 != 0) nscan = 128 - __clzll((long long)m1);
+          const int e = bx * 3 + c;
+          const int nscan = (int)((nsw[e >> 2] >> (8 * (e & 3))) & 0xFFu);
           // only scan positions below nscan (= up to the last nonzero) are ever read again
-          if (lane < nscan) A.coef_scan[(pos0 * 3 + c) * 64 + lane] = v0;
-          if (64 + lane < nscan) A.coef_scan[(pos1 * 3 + c) * 64 + lane] = v1;
-          if (lane == 0) A.blk_nscan[pos0 * 3 + c] = (uint8_t)nscan;
-          wave_tokens += 1 + (nscan > covered ? nscan - covered : 0);
+          if (lane < nscan) A.coef_scan[(pos0 * 3 + c) * 64 + lane] = v0s[c];
+          if (64 + lane < nscan) A.coef_scan[(pos1 * 3 + c) * 64 + lane] = v1s[c];
         }
       }
     }
-#else
-    for (int bx = 0; by < nby && bx < nbx; bx++) {
-      const int bi = by * 8 + bx;
-      const int a = __builtin_amdgcn_readfirstlane((int)S.strat[bi]);
-      if (!(a & 1)) continue;
-      const int st = a >> 1;
-      const int covered = st == 0 ? 1 : 2;
-      const int o2 = st == 1 ? 8 : 1;
-      const uint8_t* order = &S.order[st == 0 ? 0 : 64];
-      const uint32_t pos0 = (uint32_t)(by_img0 + by) * bstride + (uint32_t)(bx_img0 + bx);
-      const uint32_t pos1 = pos0 + (st == 1 ? bstride : 1u);
-      // staging index (channel 0) of this lane's scan position, per 64-position half
-      const int i0 = order[lane];
-      const int src0 = i0 < 64 ? bi * kStageStride + i0 : (bi + o2) * kStageStride + i0 - 64;
-      int src1 = src0;
-      if (covered == 2) {
-        const int i1 = order[64 + lane];
-        src1 = i1 < 64 ? bi * kStageStride + i1 : (bi + o2) * kStageStride + i1 - 64;
-      }
-      const unsigned long long llf_mask = covered == 2 ? 3ull : 1ull;  // scan positions < covered
-      int16_t v0s[3], v1s[3];
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        v0s[c] = stage[src0 + c * 64];
-        v1s[c] = covered == 2 ? stage[src1 + c * 64] : (int16_t)0;
-      }
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        const int16_t v0 = v0s[c], v1 = v1s[c];
-        const unsigned long long m0 = __ballot(v0 != 0) & ~llf_mask;
-        int nscan = m0 != 0 ? 64 - __clzll((long long)m0) : 0;
-        const unsigned long long m1 = __ballot(v1 != 0);
-        if (m1 != 0) nscan = 128 - __clzll((long long)m1);
-        // only scan positions below nscan (= up to the last nonzero) are ever read again
-        if (lane < nscan) A.coef_scan[(pos0 * 3 + c) * 64 + lane] = v0;
-        if (64 + lane < nscan) A.coef_scan[(pos1 * 3 + c) * 64 + lane] = v1;
-        if (lane == 0) A.blk_nscan[pos0 * 3 + c] = (uint8_t)nscan;
-        wave_tokens += 1 + (nscan > covered ? nscan - covered : 0);
-      }
-    }
-#endif
-    if (lane == 0 && wave_tokens) atomicAdd(&S.ntok, wave_tokens);
   }
   __syncthreads();
   JXLT_MARK(9);

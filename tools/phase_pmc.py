@@ -37,23 +37,34 @@ def run(size):
 
 
 def report(d):
+    """Per-phase deltas of every counter found (per wave for SQ_INSTS_*, totals otherwise)."""
     rows = []
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         rows += list(csv.DictReader(open(f)))
     tile = [r for r in rows if "tile_kernel" in r["Kernel_Name"]]
-    by_disp = {}
+    by_set = {}
+    # several rocprofv3 passes (one directory each) may be reported together: dispatch order within a pass
     for r in tile:
-        by_disp.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
-    disp = [by_disp[k] for k in sorted(by_disp)]
-    assert len(disp) == len(PHASES), len(disp)
-    prev = {}
-    print("%-24s %10s %10s %10s   (instructions per wave, this phase)" % ("phase", "VALU", "SALU", "LDS"))
-    for name, c in zip([PHASES[i] for i in ORDER], disp):
-        w = c["SQ_WAVES"]
-        cur = {k: c[k] / w for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS")}
-        print("%-24s %10.0f %10.0f %10.0f" % (name, *[cur[k] - prev.get(k, 0.0) for k in cur]))
-        prev = cur
-    print("%-24s %10.0f %10.0f %10.0f" % ("total", *[prev[k] for k in prev]))
+        by_set.setdefault(r["Counter_Name"], {})[int(r["Dispatch_Id"])] = float(r["Counter_Value"])
+    names = sorted(by_set)
+    series = {}
+    for n in names:
+        vals = [by_set[n][k] for k in sorted(by_set[n])]
+        assert len(vals) % len(PHASES) == 0, (n, len(vals))
+        series[n] = vals[-len(PHASES):]
+    waves = series.get("SQ_WAVES")
+    print("%-24s" % "phase" + "".join("%22s" % n[-21:] for n in names))
+    prev = {n: 0.0 for n in names}
+    for j, name in enumerate([PHASES[i] for i in ORDER]):
+        line = "%-24s" % name
+        for n in names:
+            v = series[n][j]
+            if n.startswith("SQ_INSTS") and waves:
+                v = v / waves[j]
+            line += "%22.1f" % ((v - prev[n]) if n != "SQ_WAVES" else v)
+            prev[n] = v
+        print(line)
+    print("%-24s" % "total" + "".join("%22.1f" % prev[n] for n in names))
 
 
 if __name__ == "__main__":
