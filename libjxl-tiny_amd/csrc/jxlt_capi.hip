@@ -1164,6 +1164,11 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
   memcpy(ps.h_code_table.p, code_table, 64 * 64 * sizeof(uint32_t));
   HIP_TRY(ctx, hipMemcpyAsync(ps.code_table.p, ps.h_code_table.p, 64 * 64 * sizeof(uint32_t), hipMemcpyHostToDevice,
                               ctx->stream));
+  // Blob capacity: <= 28 bits per record.  (Allocated before the measuring pass: its last kernel zeroes the
+  // dwords in which tiles and sections meet.)
+  const uint64_t blob_bound = rec_bound * 4 + nsec * 8 + 64;
+  if (ps.packed.cap < blob_bound && (rc = EnsureDevice(ctx, &ps.packed, blob_bound + blob_bound / 8)) != JXLT_OK)
+    return rc;
   const PackTileArgs P = TileArgsOf(ctx, kind, nsec);
   const unsigned sec_blocks = (unsigned)((nsec + 255) / 256);
   hipLaunchKernelGGL(pack_tile_count_kernel, dim3(sec_blocks), dim3(256), 0, ctx->stream, P);
@@ -1188,10 +1193,7 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
   // The writing pass needs nothing from the host (tile positions are in device memory), so it is
   // queued right here, in a few launches over equal shares of the tile range (an upper bound: the
   // kernel clamps to the real tile count); the host picks the section sizes up meanwhile and
-  // later only adds the copies (EnqueueCopies).  Blob capacity: <= 28 bits per record.
-  const uint64_t blob_bound = rec_bound * 4 + nsec * 8 + 64;
-  if (ps.packed.cap < blob_bound && (rc = EnsureDevice(ctx, &ps.packed, blob_bound + blob_bound / 8)) != JXLT_OK)
-    return rc;
+  // later only adds the copies (EnqueueCopies).
   const int want = kind == 0 ? 1 : 5;
   ps.launches = (int)std::min<size_t>((size_t)want, std::max<size_t>(1, max_tiles / 64));
   // (shrinking shares: the copy of the last share is the only one nothing overlaps)

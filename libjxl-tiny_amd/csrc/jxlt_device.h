@@ -2102,10 +2102,12 @@ constexpr int kPackWindowWords = kPackTile * 28 / 32 + 4;        // <= 28 bits p
 //   pack_tile_write_kernel    entropy-codes a tile at its final bit position of the blob
 // (a tile's workgroup finds everything it needs in one 32-byte PackTileInfo: no dependent
 // global loads in front of the record loads)
-// Two tiles of a section meet inside a dword.  The later tile owns that dword: it re-derives
-// the trailing bits of its predecessor(s) from their last records, so every dword is stored by
-// exactly one workgroup with plain stores (no atomics, no zero-initialised destination).  Where
-// two *sections* meet inside a dword (sections are byte aligned) each stores its own bytes.
+// Two tiles of a section, or two byte-aligned sections, meet inside a dword: those dwords (a tile's
+// first and last) are zeroed by pack_tile_finalize_kernel and OR-ed into by both neighbours; every
+// other dword is stored by exactly one workgroup with plain stores.  (Round 1 had the later tile
+// re-derive its predecessor's trailing bits instead -- one wave walking back through up to 64 records
+// while seven waited, 64 extra records staged per tile, two more barriers.)  Up to 3 bytes behind a
+// blob's last section are zeroed.
 // ---------------------------------------------------------------------------
 struct alignas(16) PackTileInfo {
   uint64_t rec_first;      // absolute index of the tile's first record
@@ -2162,24 +2164,6 @@ __global__ void __launch_bounds__(256) pack_tile_plan_kernel(const PackTileArgs 
   }
 }
 
-// (nb, data) of one record: code of the hybrid-uint symbol followed by its extra bits, or the
-// raw bits of an escape record (ctx >= 128).
-JXLT_DI void pack_record_bits(const uint8_t* rec, const uint32_t* table, uint32_t* nb, uint32_t* data) {
-  const uint32_t ctx = rec[0];
-  const uint32_t value = (uint32_t)rec[1] | ((uint32_t)rec[2] << 8);
-  if (ctx >= 128) {
-    *nb = ctx - 128;
-    *data = value;
-  } else {
-    uint32_t sym, nbits, extra;
-    hybrid_uint(value, &sym, &nbits, &extra);
-    const uint32_t e = table[ctx * 64 + sym];
-    const uint32_t depth = e >> 16;
-    *nb = depth + nbits;
-    *data = (e & 0xFFFFu) | (extra << depth);
-  }
-}
-
 // Records of a tile -> LDS, realigned so that the first record starts at stage[0]: aligned dword
 // loads from memory, each staged dword assembled from two of them (v_alignbyte).
 JXLT_DI void pack_stage_tile(const uint8_t* src, int n, uint32_t* stage, int tid) {
@@ -2187,8 +2171,8 @@ JXLT_DI void pack_stage_tile(const uint8_t* src, int n, uint32_t* stage, int tid
   const uint32_t* srcw = reinterpret_cast<const uint32_t*>(src - mis);
   const int nw = (3 * n + 3) >> 2;
   // Fixed trip count, every load issued before the first use: a loop over a run-time count
-  // waits for each load in turn (seven memory latencies per tile instead of one).
-  constexpr int kIters = ((kPackTile + 64) * 3 / 4 + kPackThreads - 1) / kPackThreads;
+  // waits for each load in turn (six memory latencies per tile instead of one).
+  constexpr int kIters = (kPackTile * 3 / 4 + kPackThreads - 1) / kPackThreads;
   uint32_t lo[kIters], hi[kIters];
 #pragma unroll
   for (int k = 0; k < kIters; k++) {
@@ -2302,23 +2286,26 @@ __global__ void __launch_bounds__(256) pack_tile_finalize_kernel(const PackTileA
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= (uint32_t)A.tile_base[A.nsec]) return;
   PackTileInfo info = A.tile_info[t];
-  const uint64_t start = 8 * A.sec_byte_offset[info.sec_start_bit];
+  const uint32_t sec = (uint32_t)info.sec_start_bit;
+  const uint64_t start = 8 * A.sec_byte_offset[sec];
   info.bit_pos += start;
   info.sec_start_bit = start;
   A.tile_info[t] = info;
+  // The dwords in which two tiles (or two sections) meet are OR-ed into by both: zero them here, before the
+  // writing pass -- the dword a tile starts in, and the dword a section ends in.
+  uint32_t* outw = reinterpret_cast<uint32_t*>(A.out);
+  outw[info.bit_pos >> 5] = 0u;
+  if (info.n_last >> 31) {
+    const uint64_t end = start + A.sec_bits[sec];
+    if (end & 31u) outw[end >> 5] = 0u;
+  }
 }
 
 __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const PackTileArgs A) {
   __shared__ uint32_t table[64 * 64];
-  // The staged records (the tile and the 64 records before it) are dead once every thread holds
-  // its records' bits; the bit window then uses the same memory (31 KB of LDS per workgroup
-  // instead of 44: a fourth workgroup per CU).
-  constexpr int kStageWords = (kPackTile + 64) * 3 / 4 + 4;
-  __shared__ alignas(16) uint32_t stage_or_window[kPackWindowWords > kStageWords ? kPackWindowWords : kStageWords];
-  uint32_t* const stage = stage_or_window;
-  uint32_t* const window = stage_or_window;
+  __shared__ alignas(16) uint32_t stage[kPackTile * 3 / 4 + 4];
+  __shared__ alignas(16) uint32_t window[kPackWindowWords];
   __shared__ uint32_t wave_sum[kPackThreads / 64];
-  __shared__ uint32_t first_word;  // bits of earlier records in the tile's first dword
   const int tid = (int)threadIdx.x;
   const uint32_t ntiles_all = umin32((uint32_t)A.tile_base[A.nsec], A.tile_end);
   const uint32_t first_tile = A.tile_first + blockIdx.x * kPackTilesPerGroup;
@@ -2335,61 +2322,19 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
   for (int kt = 0; kt < kPackTilesPerGroup; kt++) {
     const uint32_t tile = first_tile + kt;
     if (tile >= ntiles_all) break;
-    __syncthreads();  // previous tile flushed; table loaded
-    if (tid == 0) first_word = 0u;
+    __syncthreads();  // previous tile's window stored, its records consumed; table loaded
     const PackTileInfo info = next_info;
     next_info = A.tile_info[tile + 1 < ntiles_all ? tile + 1 : tile];  // requested one tile ahead
     const int n = (int)(info.n_last & 0x7FFFFFFFu);
-    const bool last_tile = (info.n_last >> 31) != 0;
-    const uint8_t* tile_src = A.records + 3 * info.rec_first;
-    const int pre = info.before != 0 ? 64 : 0;  // records before the tile staged for the look-back
-    pack_stage_tile(tile_src - 3 * pre, n + pre, stage, tid);
-    const uint32_t* stage_tile = stage + pre * 3 / 4;  // 64 records = 48 dwords
-    const uint64_t sec_start_bit = info.sec_start_bit;
+    pack_stage_tile(A.records + 3 * info.rec_first, n, stage, tid);
+    for (int i = tid; i < kPackWindowWords; i += kPackThreads) window[i] = 0u;
     const uint64_t pos_bit = info.bit_pos;  // where this tile's bits start
     const uint32_t lead = (uint32_t)(pos_bit & 31u);
     const uint64_t word0 = pos_bit >> 5;
-    // ---- the bits of earlier records of this section that share the tile's first dword
-    const uint64_t word0_bit = word0 << 5;
-    const uint32_t need = word0_bit >= sec_start_bit ? lead : (uint32_t)(pos_bit - sec_start_bit);
-    __syncthreads();  // stage complete
-    if (need != 0 && tid < 64) {
-      // wave 0 walks backwards, 64 records at a time, until `need` bits are covered
-      // (first round from the staged copy, further rounds -- rare -- from memory)
-      const uint8_t* staged = reinterpret_cast<const uint8_t*>(stage_tile);
-      uint32_t covered = 0;                  // bits before pos_bit already accounted for
-      uint32_t back = info.before;           // records of the section before this tile not yet visited
-      while (covered < need && back != 0) {
-        const bool have = (uint32_t)tid < back;
-        uint32_t nb = 0, data = 0;
-        if (have) {
-          const bool first_round = back == info.before;
-          pack_record_bits(first_round ? staged - 3 * (1 + tid) : tile_src - 3 * (size_t)(info.before - back + 1 + tid),
-                           table, &nb, &data);
-        }
-        // bits between this record's end and pos_bit: records tid' < tid of this round + covered
-        uint32_t after = nb;
-        for (int d = 1; d < 64; d <<= 1) {
-          const uint32_t o = __shfl_up(after, d);
-          if (tid >= d) after += o;
-        }
-        const uint32_t round_bits = __shfl(after, 63);
-        after = covered + after - nb;
-        if (have && nb != 0 && after < need) {
-          // the record's bits occupy [lead - after - nb, lead - after) of the first dword
-          const int hi = (int)lead - (int)after, lo = hi - (int)nb;
-          const uint32_t v = lo >= 0 ? (data << lo) : (data >> (-lo));
-          const uint32_t mask = hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u);
-          atomicOr(&first_word, v & mask);
-        }
-        covered += round_bits;
-        back = back > 64 ? back - 64 : 0;
-      }
-    }
-    __syncthreads();
+    __syncthreads();  // stage complete, window clear
     // pass 1: bit length of this thread's records
     PackThreadRecords recs;
-    pack_load_thread_records(stage_tile, tid, &recs);
+    pack_load_thread_records(stage, tid, &recs);
     uint32_t nb[kPackPerThread];
     uint32_t data[kPackPerThread];
     uint32_t mine = 0;
@@ -2408,8 +2353,6 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
       if ((tid & 63) >= d) incl += o;
     }
     if ((tid & 63) == 63) wave_sum[tid >> 6] = incl;
-    __syncthreads();  // every thread has read its records: the staging memory becomes the window
-    for (int i = tid; i < kPackWindowWords; i += kPackThreads) window[i] = i == 0 ? first_word : 0u;
     __syncthreads();
     uint32_t wave_base = 0, tile_bits = 0;
 #pragma unroll
@@ -2438,24 +2381,18 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
       if (fill) atomicOr(&window[w], (uint32_t)acc);
     }
     __syncthreads();
-    // stores: complete dwords; the trailing partial dword only if the section ends here (its
-    // successor tile owns it otherwise); bytes below the section's first byte are never touched
+    // stores: the dwords the tile covers completely with plain stores; its first and its last dword, which it
+    // may share with its neighbours (tiles of the same section, or the byte-aligned neighbour sections), are
+    // OR-ed into memory that pack_tile_finalize_kernel zeroed
     const uint32_t end_bits = lead + tile_bits;
-    const uint32_t full_words = end_bits >> 5;
-    const uint32_t own_first = word0_bit < sec_start_bit ? (uint32_t)((sec_start_bit - word0_bit) >> 3) : 0u;
-    for (uint32_t i = tid; i < full_words; i += kPackThreads) {
-      if (i == 0 && own_first != 0) {
-        uint8_t* b = reinterpret_cast<uint8_t*>(outw + word0);
-        for (uint32_t k = own_first; k < 4; k++) b[k] = (uint8_t)(window[0] >> (8 * k));
+    const uint32_t nwords = (end_bits + 31) >> 5;  // dwords the tile touches
+    for (uint32_t i = tid; i < nwords; i += kPackThreads) {
+      const uint32_t v = window[i];
+      if (i == 0 || (i + 1 == nwords && (end_bits & 31u) != 0)) {
+        if (v) atomicOr(&outw[word0 + i], v);
       } else {
-        outw[word0 + i] = window[i];
+        outw[word0 + i] = v;
       }
-    }
-    if (tid == 0 && last_tile && (end_bits & 31u) != 0) {
-      const uint32_t rem_bytes = ((end_bits & 31u) + 7) >> 3;
-      const uint32_t first = full_words == 0 ? own_first : 0u;
-      uint8_t* b = reinterpret_cast<uint8_t*>(outw + word0 + full_words);
-      for (uint32_t k = first; k < rem_bytes; k++) b[k] = (uint8_t)(window[full_words] >> (8 * k));
     }
   }
 }

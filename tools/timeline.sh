@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 rm -rf gpurun_out/tl
-timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/tl -- python3 bench.py --steps 3 --warmup 1 > gpurun_out/tl.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/tl -- python3 bench.py --no-extras --steps 3 --warmup 1 > gpurun_out/tl.log 2>&1
 python3 - <<'PY'
 import csv,glob
 ev=[]
