@@ -2164,29 +2164,30 @@ __global__ void __launch_bounds__(256) pack_tile_plan_kernel(const PackTileArgs 
   }
 }
 
-// Records of a tile -> LDS, realigned so that the first record starts at stage[0]: aligned dword
-// loads from memory, each staged dword assembled from two of them (v_alignbyte).
-JXLT_DI void pack_stage_tile(const uint8_t* src, int n, uint32_t* stage, int tid) {
-  const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3u);
-  const uint32_t* srcw = reinterpret_cast<const uint32_t*>(src - mis);
+// Records of a tile -> registers -> LDS, so that the first record starts at stage[0].  The records start at
+// any byte: unaligned dword loads (one instruction each on gfx950).  Fixed trip count, every load issued
+// before the first use (a loop over a run-time count waits for each load in turn); the two halves are
+// separate so that a tile's records can be requested while the previous tile is being packed.
+constexpr int kPackStageIters = (kPackTile * 3 / 4 + kPackThreads - 1) / kPackThreads;
+struct PackStagedLoads {
+  uint32_t w[kPackStageIters];
+};
+JXLT_DI void pack_request_tile(const uint8_t* src, int n, int tid, PackStagedLoads* r) {
   const int nw = (3 * n + 3) >> 2;
-  // Fixed trip count, every load issued before the first use: a loop over a run-time count
-  // waits for each load in turn (six memory latencies per tile instead of one).
-  constexpr int kIters = (kPackTile * 3 / 4 + kPackThreads - 1) / kPackThreads;
-  uint32_t lo[kIters], hi[kIters];
 #pragma unroll
-  for (int k = 0; k < kIters; k++) {
+  for (int k = 0; k < kPackStageIters; k++) {
     const int i = tid + k * kPackThreads;
-    lo[k] = hi[k] = 0;
-    if (i < nw) {
-      lo[k] = srcw[i];
-      hi[k] = srcw[i + 1];
-    }
+    uint32_t v = 0;
+    if (i < nw) __builtin_memcpy(&v, src + 4 * (size_t)i, 4);
+    r->w[k] = v;
   }
+}
+JXLT_DI void pack_store_tile(const PackStagedLoads& r, int n, uint32_t* stage, int tid) {
+  const int nw = (3 * n + 3) >> 2;
 #pragma unroll
-  for (int k = 0; k < kIters; k++) {
+  for (int k = 0; k < kPackStageIters; k++) {
     const int i = tid + k * kPackThreads;
-    if (i < nw) stage[i] = __builtin_amdgcn_alignbyte(hi[k], lo[k], mis);
+    if (i < nw) stage[i] = r.w[k];
   }
 }
 
@@ -2233,16 +2234,22 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_measure_kernel(const P
   if (first >= ntiles_all) return;
   for (int i = tid; i < 64 * 64; i += kPackThreads) depth[i] = (uint8_t)(A.code_table[i] >> 16);
   if (tid < kPackTilesPerGroup) total[tid] = 0;
-  PackTileInfo next_info = A.tile_info[first];
+  // The records of tile k + 1 are requested before tile k is summed: its descriptor one tile earlier still.
+  PackTileInfo info = A.tile_info[first];
+  PackTileInfo next_info = A.tile_info[first + 1 < ntiles_all ? first + 1 : first];
+  PackStagedLoads loads;
+  pack_request_tile(A.records + 3 * info.rec_first, (int)(info.n_last & 0x7FFFFFFFu), tid, &loads);
   for (int k = 0; k < kPackTilesPerGroup; k++) {
     const uint32_t tile = first + k;
     if (tile >= ntiles_all) break;
     __syncthreads();  // previous tile's stage consumed; tables loaded
-    const PackTileInfo info = next_info;
-    // (the next tile's descriptor is requested now: one memory latency less per tile)
-    next_info = A.tile_info[tile + 1 < ntiles_all ? tile + 1 : tile];
     const int n = (int)(info.n_last & 0x7FFFFFFFu);
-    pack_stage_tile(A.records + 3 * info.rec_first, n, stage, tid);
+    pack_store_tile(loads, n, stage, tid);
+    if (k + 1 < kPackTilesPerGroup && tile + 1 < ntiles_all) {
+      info = next_info;
+      next_info = A.tile_info[tile + 2 < ntiles_all ? tile + 2 : tile + 1];
+      pack_request_tile(A.records + 3 * info.rec_first, (int)(info.n_last & 0x7FFFFFFFu), tid, &loads);
+    }
     __syncthreads();
     PackThreadRecords recs;
     pack_load_thread_records(stage, tid, &recs);
@@ -2318,19 +2325,26 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
     for (int q = 0; q < 64 * 64 / kPackThreads; q++) table[tid + q * kPackThreads] = tl[q];
   }
   uint32_t* outw = reinterpret_cast<uint32_t*>(A.out);
-  PackTileInfo next_info = A.tile_info[first_tile];
+  // The records of tile kt + 1 are requested before tile kt is packed: its descriptor one tile earlier still.
+  PackTileInfo info = A.tile_info[first_tile];
+  PackTileInfo next_info = A.tile_info[first_tile + 1 < ntiles_all ? first_tile + 1 : first_tile];
+  PackStagedLoads loads;
+  pack_request_tile(A.records + 3 * info.rec_first, (int)(info.n_last & 0x7FFFFFFFu), tid, &loads);
   for (int kt = 0; kt < kPackTilesPerGroup; kt++) {
     const uint32_t tile = first_tile + kt;
     if (tile >= ntiles_all) break;
     __syncthreads();  // previous tile's window stored, its records consumed; table loaded
-    const PackTileInfo info = next_info;
-    next_info = A.tile_info[tile + 1 < ntiles_all ? tile + 1 : tile];  // requested one tile ahead
     const int n = (int)(info.n_last & 0x7FFFFFFFu);
-    pack_stage_tile(A.records + 3 * info.rec_first, n, stage, tid);
+    pack_store_tile(loads, n, stage, tid);
     for (int i = tid; i < kPackWindowWords; i += kPackThreads) window[i] = 0u;
     const uint64_t pos_bit = info.bit_pos;  // where this tile's bits start
     const uint32_t lead = (uint32_t)(pos_bit & 31u);
     const uint64_t word0 = pos_bit >> 5;
+    if (kt + 1 < kPackTilesPerGroup && tile + 1 < ntiles_all) {
+      info = next_info;
+      next_info = A.tile_info[tile + 2 < ntiles_all ? tile + 2 : tile + 1];
+      pack_request_tile(A.records + 3 * info.rec_first, (int)(info.n_last & 0x7FFFFFFFu), tid, &loads);
+    }
     __syncthreads();  // stage complete, window clear
     // pass 1: bit length of this thread's records
     PackThreadRecords recs;
