@@ -1,10 +1,10 @@
 // jxlt_capi.hip -- C ABI of libjxltiny_hip.so (see include/jxl_tiny_amd.h).
 //
 // One jxlt_context = one HIP device + one stream + all device/pinned buffers of
-// the per-group pipeline.  A whole frame is processed by three launches on the
+// the per-group pipeline.  A whole frame is processed by these launches on the
 // context's stream:
 //   tile_kernel  (one workgroup per 64x64 tile)  -> side-band grids, coefficients
-//   group_scan_kernel                            -> per-group token offsets
+//   dc_* kernels (DC-group tokenisation)
 //   token_kernel (one workgroup per 256x256 group) -> raw 3-byte token records
 // There is no CPU fallback: without a usable HIP device every entry point
 // returns JXLT_ERR_NO_DEVICE.
@@ -104,6 +104,7 @@ struct jxlt_context {
     PinnedBuf<uint8_t> h_packed;
     PinnedBuf<uint32_t> h_code_table;  // staging of the caller's table (asynchronous upload needs page-locked memory)
     size_t measured_sections = 0;  // sections of the last measuring pass (0: none for this frame)
+    bool planned = false;          // the frame's tile plan (count / scan / plan kernels) has been queued
     // The writing kernels are queued right behind the measuring kernels (they need nothing from
     // the host): launch i covers tiles [launch_t0[i], launch_t0[i + 1]) and signals launch_done[i].
     static constexpr int kMaxLaunches = 6;
@@ -663,6 +664,8 @@ int jxlt_image_size(const jxlt_context* ctx, size_t* xsize, size_t* ysize) {
 }
 
 namespace {
+int EnqueuePlan(jxlt_context* ctx, int kind, uint64_t rec_bound, hipStream_t stream);  // (below)
+
 int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roots) {
   if (!ctx || !params) return JXLT_ERR_INVALID_ARGUMENT;
   if (!ctx->planes[0]) {
@@ -782,6 +785,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
   K.blk_nz = ctx->blk_nz.p;
   K.blk_nscan = ctx->blk_nscan.p;
   K.coef_scan = ctx->coef_scan.p;
+  K.group_ntok = ctx->group_ntok.p;
   K.group_tok_offset = ctx->group_off.p;
   K.tokens = ctx->tokens.p;
   K.histogram = ctx->hist.p;
@@ -910,8 +914,8 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
     const size_t ty0 = dc_row0 * 2048, ty1 = std::min(ctx->ysize, dc_row1 * 2048);  // pixel rows being tokenised
     const size_t g0 = (ty0 / 256) * (size_t)g.xsize_groups;
     const size_t ng = ((ty1 - ty0 + 255) / 256) * (size_t)g.xsize_groups;
-    hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, tok_stream,
-                       (const uint32_t*)ctx->group_ntok.p + g0, ctx->group_off.p + g0, (int)ng, dc_row0 > 0 ? 1 : 0);
+    // (every token_kernel workgroup finds its group's token offset itself: the counts of all groups before it,
+    // whichever launch tokenised them, are final by now)
     K.group_first = (int)g0;
     hipLaunchKernelGGL(token_kernel, dim3((unsigned)ng), dim3(kTokenThreads), 0, tok_stream, K);
   }
@@ -927,6 +931,13 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
   // whatever is queued on the main stream from here on (section packing) comes after the tokenisation
   if (tok_stream != ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_done, 0));
   ctx->geom = g;
+  // The tile plan of the AC sections needs the groups' token offsets only: it runs now, behind the histogram's
+  // way to the host, while the host builds the codes (upper bound of the record count: the buffer's capacity).
+  ctx->pack[0].planned = ctx->pack[1].planned = false;
+  {
+    const int rcp = EnqueuePlan(ctx, 1, ctx->tokens.cap / 3, ctx->stream);
+    if (rcp != JXLT_OK) return rcp;
+  }
   ctx->encoded = true;
   ctx->offsets_fetched = false;
   ctx->pack[0].measured_sections = ctx->pack[1].measured_sections = 0;
@@ -1135,13 +1146,13 @@ size_t NumSections(const jxlt_context* ctx, int kind) {
                    : ((ctx->xsize + 2047) / 2048) * ((ctx->ysize + 2047) / 2048);
 }
 
-// Measuring pass for the sections of `kind` (asynchronous): exact bit / byte size of every
-// section, byte offsets, tile bookkeeping; results are copied to the pinned mirrors.
-int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
+// The tile plan of the sections of `kind` (asynchronous, on `stream`): tiles per section, their scan, the record
+// range of every tile.  It needs the sections' record counts only, not a code: for the AC sections it is queued
+// right behind the tokenisation (EnqueuePipeline), i.e. it runs while the host builds the AC code.
+// rec_bound: an upper bound of the record count (sizes the per-tile arrays).
+int EnqueuePlan(jxlt_context* ctx, int kind, uint64_t rec_bound, hipStream_t stream) {
   jxlt_context::PackSet& ps = ctx->pack[kind];
   const size_t nsec = NumSections(ctx, kind);
-  // upper bound of the record count (the exact per-section counts live on the device)
-  const uint64_t rec_bound = kind == 1 ? ctx->h_group_off.p[nsec] : ctx->dc_records.cap / 3;
   const size_t max_tiles = (size_t)(rec_bound / kPackTile) + nsec + 1;
   int rc;
 #define ENSURE(buf, n) if ((rc = EnsureDevice(ctx, &ps.buf, (n))) != JXLT_OK) return rc
@@ -1154,6 +1165,27 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
   ENSURE(tile_bits, max_tiles);
   ENSURE(tile_info, max_tiles);
 #undef ENSURE
+  const PackTileArgs P = TileArgsOf(ctx, kind, nsec);
+  const unsigned sec_blocks = (unsigned)((nsec + 255) / 256);
+  hipLaunchKernelGGL(pack_tile_count_kernel, dim3(sec_blocks), dim3(256), 0, stream, P);
+  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(kScanThreads), 0, stream, (const uint32_t*)ps.sec_tiles.p,
+                     ps.tile_base.p, (int)nsec);
+  hipLaunchKernelGGL(pack_tile_plan_kernel, dim3(sec_blocks), dim3(256), 0, stream, P);
+  HIP_TRY(ctx, hipGetLastError());
+  ps.planned = true;
+  return JXLT_OK;
+}
+
+// Measuring pass for the sections of `kind` (asynchronous): exact bit / byte size of every
+// section, byte offsets, tile bookkeeping; results are copied to the pinned mirrors.
+int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
+  jxlt_context::PackSet& ps = ctx->pack[kind];
+  const size_t nsec = NumSections(ctx, kind);
+  // upper bound of the record count (the exact per-section counts live on the device)
+  const uint64_t rec_bound = kind == 1 ? ctx->h_group_off.p[nsec] : ctx->dc_records.cap / 3;
+  const size_t max_tiles = (size_t)(rec_bound / kPackTile) + nsec + 1;
+  int rc;
+  if (!ps.planned && (rc = EnqueuePlan(ctx, kind, rec_bound, ctx->stream)) != JXLT_OK) return rc;
   if ((rc = EnsurePinned(ctx, &ps.h_sec_byte_off, nsec + 1)) != JXLT_OK) return rc;
   if ((rc = EnsurePinned(ctx, &ps.h_sec_bits, nsec)) != JXLT_OK) return rc;
   if ((rc = EnsurePinned(ctx, &ps.h_tile_base, nsec + 1)) != JXLT_OK) return rc;
@@ -1171,15 +1203,11 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
     return rc;
   const PackTileArgs P = TileArgsOf(ctx, kind, nsec);
   const unsigned sec_blocks = (unsigned)((nsec + 255) / 256);
-  hipLaunchKernelGGL(pack_tile_count_kernel, dim3(sec_blocks), dim3(256), 0, ctx->stream, P);
-  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t*)ps.sec_tiles.p,
-                     ps.tile_base.p, (int)nsec, 0);
-  hipLaunchKernelGGL(pack_tile_plan_kernel, dim3(sec_blocks), dim3(256), 0, ctx->stream, P);
   hipLaunchKernelGGL(pack_tile_measure_kernel, dim3((unsigned)((max_tiles + kPackTilesPerGroup - 1) / kPackTilesPerGroup)),
                      dim3(kPackThreads), 0, ctx->stream, P);
   hipLaunchKernelGGL(pack_tile_offsets_kernel, dim3(sec_blocks), dim3(256), 0, ctx->stream, P);
-  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t*)ps.sec_bytes.p,
-                     ps.sec_byte_off.p, (int)nsec, 0);
+  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, (const uint32_t*)ps.sec_bytes.p,
+                     ps.sec_byte_off.p, (int)nsec);
   hipLaunchKernelGGL(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), 0, ctx->stream, P);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(ps.h_sec_byte_off.p, ps.sec_byte_off.p, (nsec + 1) * sizeof(uint64_t),

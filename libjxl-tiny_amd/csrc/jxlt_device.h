@@ -114,7 +114,9 @@ struct TokenArgs {
   const uint8_t* blk_nz;
   const uint8_t* blk_nscan;
   const int16_t* coef_scan;
-  const uint64_t* group_tok_offset;  // exclusive scan of group_ntok (tokens)
+  const uint32_t* group_ntok;         // tokens of every group (tile_kernel's counts)
+  uint64_t* group_tok_offset;        // [groups + 1] OUT: exclusive scan of group_ntok -- every workgroup sums the
+                                     // counts of the groups before its own (no scan kernel in front of this one)
   uint8_t* tokens;                   // 3 bytes per token
   uint32_t* histogram;               // optional [64 pre-clusters][64 symbols] (enc_frame.cc:767-782)
   int group_first;                   // workgroup b handles group group_first + b (launches per row of DC groups)
@@ -1763,33 +1765,41 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel_exact_roots(const
 }
 
 // ---------------------------------------------------------------------------
-// Exclusive scan of per-group token counts (single workgroup)
+// Exclusive scan of up to a few ten thousand 32-bit counts into 64-bit offsets (single workgroup):
+// offsets[i] = counts[0] + ... + counts[i - 1], offsets[n] = the total.  Every thread owns a contiguous run
+// (all of its loads in flight together), one wave scan + one barrier for the runs' totals.
 // ---------------------------------------------------------------------------
-// offsets[0] is the carry-in when `chained` (the total a previous launch over the preceding range left there:
-// the per-slab launches of one frame scan consecutive ranges of one array), 0 otherwise.
-__global__ void group_scan_kernel(const uint32_t* counts, uint64_t* offsets, int n, int chained) {
-  __shared__ uint64_t carry;
-  __shared__ uint64_t part[256];
-  const int tid = (int)threadIdx.x;
-  if (tid == 0) carry = chained ? offsets[0] : 0;
-  __syncthreads();
-  for (int base = 0; base < n; base += 256) {
-    const int i = base + tid;
-    const uint64_t v = i < n ? counts[i] : 0;
-    part[tid] = v;
-    __syncthreads();
-    for (int s = 1; s < 256; s <<= 1) {
-      const uint64_t add = tid >= s ? part[tid - s] : 0;
-      __syncthreads();
-      part[tid] += add;
-      __syncthreads();
-    }
-    if (i < n) offsets[i] = carry + part[tid] - v;
-    __syncthreads();
-    if (tid == 0) carry += part[255];
-    __syncthreads();
+constexpr int kScanThreads = 1024;
+constexpr int kScanMaxPerThread = 32;  // n <= 32 768 (the C ABI's frames have <= 16 448 sections of a kind)
+__global__ void __launch_bounds__(kScanThreads) group_scan_kernel(const uint32_t* counts, uint64_t* offsets, int n) {
+  __shared__ uint64_t wave_total[kScanThreads / 64];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (n + kScanThreads - 1) / kScanThreads;
+  const int beg = tid * per, end = imin(n, beg + per);
+  uint32_t v[kScanMaxPerThread];
+  uint64_t mine = 0;
+#pragma unroll
+  for (int k = 0; k < kScanMaxPerThread; k++) {
+    v[k] = (k < per && beg + k < end) ? counts[beg + k] : 0u;
+    mine += v[k];
   }
-  if (tid == 0) offsets[n] = carry;
+  uint64_t incl = mine;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) wave_total[wave] = incl;
+  __syncthreads();
+  uint64_t run = incl - mine;
+  for (int w = 0; w < wave; w++) run += wave_total[w];
+#pragma unroll
+  for (int k = 0; k < kScanMaxPerThread; k++) {
+    if (k < per && beg + k < end) {
+      offsets[beg + k] = run;
+      run += v[k];
+    }
+  }
+  if (tid == kScanThreads - 1) offsets[n] = run;
 }
 
 // ---------------------------------------------------------------------------
@@ -1817,6 +1827,16 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   if (tid < 64) {
     s_nnz_ctx[tid] = T->nnz_context[tid];
     s_freq_ctx[tid] = T->freq_context[tid];
+  }
+  // Where the group's tokens start: the sum of the counts of all groups before it (<= 16 384 counts, 64 KB,
+  // one round of loads; a scan kernel in front of this one cost 22 us of the step for the same numbers).
+  __shared__ uint64_t s_group_base;
+  __shared__ uint64_t gsum[kTokenThreads / 64];
+  {
+    uint64_t part = 0;
+    for (int i = tid; i < group; i += kTokenThreads) part += A.group_ntok[i];
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+    if (lane == 0) gsum[wave] = part;
   }
   const int ggx = group % A.g.xsize_groups, ggy = group / A.g.xsize_groups;
   const int bx0 = ggx * 32, by0 = ggy * 32;
@@ -1850,6 +1870,14 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   }
   if (tid == 0) offs[0] = 0;
   __syncthreads();
+  if (tid == 0) {
+    uint64_t base = 0;
+    for (int w = 0; w < kTokenThreads / 64; w++) base += gsum[w];
+    s_group_base = base;
+    A.group_tok_offset[group] = base;
+    const int ngroups = A.g.xsize_groups * A.g.ysize_groups;
+    if (group + 1 == ngroups) A.group_tok_offset[ngroups] = base + A.group_ntok[group];
+  }
   // inclusive scan over offs[1..nblk] (blocked: each thread owns a contiguous run)
   {
     const int per = (nblk + kTokenThreads - 1) / kTokenThreads;
@@ -1873,7 +1901,7 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   }
   __syncthreads();
 
-  uint8_t* out = A.tokens + 3 * A.group_tok_offset[group];
+  uint8_t* out = A.tokens + 3 * s_group_base;  // (written before the two barriers of the scan above)
   constexpr int kWaves = kTokenThreads / 64;
   // Wave w takes blocks w, w + 8, ... of the group (stream order) and their three channel
   // entries; lane = scan position.  The coefficients of the wave's next block are requested

@@ -130,15 +130,10 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   }
 
   r->group_tok_offset = (uint64_t*)calloc(ngroups + 1, 8);
-  // token offsets row of DC groups by row of DC groups, chained, as the product launches them (jxlt_capi.hip)
+  // (token_kernel finds every group's token offset itself; the total sizes the token buffer here)
   const size_t nslabs = (ysize + 2047) / 2048;
-  for (size_t sl = 0; sl < nslabs; sl++) {
-    const size_t y0 = sl * 2048, rows = std::min<size_t>(2048, ysize - y0);
-    const size_t g0 = (y0 / 256) * (size_t)g.xsize_groups, ng = ((rows + 255) / 256) * (size_t)g.xsize_groups;
-    hipsim::launch(group_scan_kernel, dim3(1), dim3(256), (const uint32_t*)A.group_ntok + g0, r->group_tok_offset + g0,
-                   (int)ng, sl > 0 ? 1 : 0);
-  }
-  const uint64_t total = r->group_tok_offset[ngroups];
+  uint64_t total = 0;
+  for (size_t i = 0; i < ngroups; i++) total += A.group_ntok[i];
   r->tokens = (uint8_t*)calloc(total * 3 + 1, 1);
   TokenArgs K;
   memset(&K, 0, sizeof(K));
@@ -149,6 +144,7 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   K.blk_nz = A.blk_nz;
   K.blk_nscan = A.blk_nscan;
   K.coef_scan = A.coef_scan;
+  K.group_ntok = A.group_ntok;
   K.group_tok_offset = r->group_tok_offset;
   K.tokens = r->tokens;
   K.histogram = r->histogram = (uint32_t*)calloc(2 * 64 * 64, 4);
@@ -250,12 +246,12 @@ __attribute__((visibility("default"))) int sim_pack_direct(const uint8_t* record
   P.tile_end = 0xFFFFFFFFu;
   const unsigned sec_blocks = (unsigned)((nsec + 255) / 256);
   hipsim::launch(pack_tile_count_kernel, dim3(sec_blocks), dim3(256), P);
-  hipsim::launch(group_scan_kernel, dim3(1), dim3(256), (const uint32_t*)sec_tiles.data(), tile_base.data(), nsec, 0);
+  hipsim::launch(group_scan_kernel, dim3(1), dim3(kScanThreads), (const uint32_t*)sec_tiles.data(), tile_base.data(), nsec);
   hipsim::launch(pack_tile_plan_kernel, dim3(sec_blocks), dim3(256), P);
   hipsim::launch(pack_tile_measure_kernel, dim3((unsigned)((max_tiles + kPackTilesPerGroup - 1) / kPackTilesPerGroup)),
                  dim3(kPackThreads), P);
   hipsim::launch(pack_tile_offsets_kernel, dim3(sec_blocks), dim3(256), P);
-  hipsim::launch(group_scan_kernel, dim3(1), dim3(256), (const uint32_t*)sec_bytes.data(), out_offset, nsec, 0);
+  hipsim::launch(group_scan_kernel, dim3(1), dim3(kScanThreads), (const uint32_t*)sec_bytes.data(), out_offset, nsec);
   hipsim::launch(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), P);
   const uint64_t ntiles = tile_base[nsec];
   for (int c = 0; c < nlaunch; c++) {
