@@ -125,7 +125,13 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   // code is built while the device is still tokenising.  The arrival times are the previous
   // frame's, to a good approximation (same context, usually same geometry); the helper threads
   // of the code construction are woken just before (entropy_coder.h).
+  // (the expectation belongs to a frame size: a frame of another size starts without one)
   static thread_local double expected_dc_ms = 0.0, expected_ac_ms = 0.0;
+  static thread_local size_t expected_for_pixels = 0;
+  if (expected_for_pixels != xsize * ysize) {
+    expected_for_pixels = xsize * ysize;
+    expected_dc_ms = expected_ac_ms = 0.0;
+  }
   EntropyCode ac_code, dc_code;
   std::vector<uint32_t> ac_table(64 * 64), dc_table(64 * 64);
   if (expected_dc_ms > 1.0) WarmCodeConstruction(expected_dc_ms - 0.5, expected_dc_ms + 1.5);
