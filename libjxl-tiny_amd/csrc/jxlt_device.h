@@ -2532,22 +2532,30 @@ __global__ void __launch_bounds__(256) dc_elementwise_kernel(const DcArgs A) {
     put_record(rec, p, 128 + 4, 3, hist);
     A.dc_count[dcg] = d.total;
   }
-  // DC tokens (WriteDCTokens, enc_frame.cc:287-316)
-  const int per = (3 * d.nb + kDcParts - 1) / kDcParts;
-  const int ibeg = part * per, iend = imin(3 * d.nb, ibeg + per);
-  for (int i = ibeg + tid; i < iend; i += 256) {
-    const int ci = i / d.nb, r = i % d.nb;
-    const int y = r / d.nbx, x = r % d.nbx;
-    const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
-    const int16_t* q = A.quant_dc[c] + (size_t)(d.by0 + y) * bstride + d.bx0 + x;
-    const int left = x ? q[-1] : y ? q[-(ptrdiff_t)bstride] : 0;
-    const int top = y ? q[-(ptrdiff_t)bstride] : left;
-    const int topleft = (x && y) ? q[-(ptrdiff_t)bstride - 1] : left;
-    const int guess = clamped_gradient(top, left, topleft);
-    int gp = 512 + top + left - topleft;
-    gp = gp < 0 ? 0 : gp > 1023 ? 1023 : gp;
-    const int residual = (int)q[0] - guess;
-    put_record(rec, d.pos_dc + (uint32_t)i, A.tab->gradient_lut[gp], pack_signed(residual), hist);
+  // DC tokens (WriteDCTokens, enc_frame.cc:287-316): the part's share of the block rows, a thread per block
+  // column (a DC group is at most 256 blocks wide: no index divisions), the three channels in turn.
+  {
+    const int rows_per = (d.nby + kDcParts - 1) / kDcParts;
+    const int y0 = part * rows_per, y1 = imin(d.nby, y0 + rows_per);
+    const int x = tid;
+    if (x < d.nbx) {
+      for (int y = y0; y < y1; y++) {
+#pragma unroll
+        for (int ci = 0; ci < 3; ci++) {
+          const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
+          const int16_t* q = A.quant_dc[c] + (size_t)(d.by0 + y) * bstride + d.bx0 + x;
+          const int left = x ? q[-1] : y ? q[-(ptrdiff_t)bstride] : 0;
+          const int top = y ? q[-(ptrdiff_t)bstride] : left;
+          const int topleft = (x && y) ? q[-(ptrdiff_t)bstride - 1] : left;
+          const int guess = clamped_gradient(top, left, topleft);
+          int gp = 512 + top + left - topleft;
+          gp = gp < 0 ? 0 : gp > 1023 ? 1023 : gp;
+          const int residual = (int)q[0] - guess;
+          put_record(rec, d.pos_dc + (uint32_t)(ci * d.nb + y * d.nbx + x), A.tab->gradient_lut[gp],
+                     pack_signed(residual), hist);
+        }
+      }
+    }
   }
   // YtoX / YtoB tokens (enc_frame.cc:339-362)
   const int perc = (2 * d.nt + kDcParts - 1) / kDcParts;
