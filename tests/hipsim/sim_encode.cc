@@ -266,3 +266,8 @@ __attribute__((visibility("default"))) int sim_pack_direct(const uint8_t* record
 }
 
 }  // extern "C"
+
+// group_scan_kernel alone: offsets[0..n] = exclusive scan of counts[0..n)
+extern "C" __attribute__((visibility("default"))) void sim_group_scan(const uint32_t* counts, int n, uint64_t* offsets) {
+  hipsim::launch(group_scan_kernel, dim3(1), dim3(kScanThreads), counts, offsets, n);
+}

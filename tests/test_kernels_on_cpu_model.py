@@ -155,3 +155,21 @@ def test_static_constant_emulation_on_cpu_model(built):
         T.set_strategy_distance(0.0)
     assert T.compare_results(want, got, "oracle", "cpu model") == []
     assert (want.strategy != plain.strategy).any()
+
+
+@pytest.mark.parametrize("n", [1, 7, 1023, 1024, 1025, 4096, 5000, 16448, 32768])
+def test_group_scan_kernel_matches_cumsum(built, n):
+    """Section bookkeeping of the packing stage: exclusive scan of 32-bit counts into 64-bit offsets, for every
+    run length per thread the kernel can meet (1024 threads, up to 32 counts each), with totals beyond 2^32."""
+    import ctypes as C
+
+    import numpy as np
+    L = T._sim_lib()
+    rng = np.random.default_rng(n)
+    counts = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+    got = np.full(n + 1, 0xDEAD, np.uint64)
+    L.sim_group_scan.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.sim_group_scan.restype = None
+    L.sim_group_scan(counts.ctypes.data, n, got.ctypes.data)
+    want = np.concatenate([[0], np.cumsum(counts.astype(np.uint64))]).astype(np.uint64)
+    assert (got == want).all()
