@@ -128,6 +128,11 @@ struct TokenArgs {
 
 #define JXLT_DI __device__ __forceinline__
 #define JXLT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)  // no instruction is scheduled across
+// A use of a vector register value at this point of the program (no instruction: the compiler has to have
+// waited for the load that produces it).  The CPU execution model of the tests defines this as nothing.
+#ifndef JXLT_TOUCH_VGPR
+#define JXLT_TOUCH_VGPR(x) asm volatile("" ::"v"(x))
+#endif
 
 JXLT_DI float fma32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 JXLT_DI float nfma32(float a, float b, float c) { return __builtin_fmaf(-a, b, c); }
@@ -143,6 +148,17 @@ template <int K>
 JXLT_DI float quad_lane(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K * 0x55, 0xF, 0xF, true));
 }
+// v_writelane_b32: lane `lane` of `reg` becomes `value`; both wave-uniform (scalar registers), the lane
+// select through m0 (a second scalar register operand would exceed gfx9's constant-bus limit).  This
+// compiler has no builtin for it.  (The CPU execution model of the tests defines its own JXLT_WRITE_LANE.)
+#ifndef JXLT_WRITE_LANE
+JXLT_DI int write_lane(int reg, int value, int lane) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(value), "s"(lane) : "m0");
+  return reg;
+}
+#else
+JXLT_DI int write_lane(int reg, int value, int lane) { return JXLT_WRITE_LANE(reg, value, lane); }
+#endif
 // Cross-lane moves inside an octet use DPP (data-parallel primitives: a VALU move with a
 // lane permutation, no LDS round trip).  quad_perm covers xor 1 and xor 2; xor 4 is two
 // row shifts by 4 whose bank masks pick the lanes that have a partner in that direction
@@ -171,12 +187,6 @@ JXLT_DI float octet_sum(float v) {
   v = v + octet_xor<4>(v);
   v = v + octet_xor<2>(v);
   v = v + octet_xor<1>(v);
-  return v;
-}
-JXLT_DI float octet_max(float v) {
-  v = fmaxf(v, octet_xor<4>(v));
-  v = fmaxf(v, octet_xor<2>(v));
-  v = fmaxf(v, octet_xor<1>(v));
   return v;
 }
 JXLT_DI int octet_sum_int(int v) {
@@ -654,10 +664,9 @@ constexpr int kXYPitch = 64 + 2 * kHalo + 1;  // 75 floats (odd: conflict-free c
 constexpr int kBPitch = 65;
 constexpr int kPrePitch = 19;
 constexpr int kCflTermFloats = 64 * 64 * 4;  // LDS floats overlaid by the CfL terms
-// int16 stride between the blocks of the quantised-coefficient staging area (3 x 64 values each):
-// 200 halfwords = 100 dwords = 4 (mod 32), so the 16-byte runs the octets of a wave store land in
-// different banks (192 = 0 mod 32 dwords made every staging store an 8-way conflict)
-constexpr int kStageStride = 200;
+// float stride between the blocks of the coefficient staging area (3 x 64 values each): 200 = 8 (mod 64), so
+// the eight 32-byte runs the octets of a wave store at a time land in different banks
+constexpr int kStageStrideF = 200;
 
 struct alignas(16) TileShared {
   float x[64 * kXYPitch];
@@ -686,8 +695,9 @@ struct alignas(16) TileShared {
   uint32_t ntok;
   uint32_t nfirst;
 };
-// After the last pixel read the XYB planes are dead and are reused as the
-// staging area for quantised coefficients (64 blocks x 3 channels x 64 int16).
+// After the last pixel read the XYB planes are dead and are reused: chroma-from-luma terms, the parked
+// DCT8 coefficients of the entropy estimate, then the staging area of the selected transforms' coefficients
+// (64 blocks x 3 channels x 64 floats).
 
 JXLT_DI int imin(int a, int b) { return a < b ? a : b; }
 JXLT_DI int imax(int a, int b) { return a > b ? a : b; }
@@ -782,153 +792,6 @@ JXLT_DI float adjust_quant_bias_y(float quant) {
   const float small = quant * kBias1;
   const float bias = nfma32(kBias3, rcp_int_exact(quant), quant);  // (quant == 0: selected away below)
   return fabsf(quant) < 1.125f ? small : bias;
-}
-
-// enc_group.cc:221-278 for the lane's rows.  NR = 8: xsize=ysize=1; NR = 16: xsize=2, ysize=1.
-template <int NR>
-JXLT_DI void quantize_rows(const float* in, int c, const float* inv, int l, float quantv, float* outf) {
-  // thresholds of the four quadrants (enc_group.cc:227-242)
-  float t0 = 0.58f;
-  float t1 = c == 0 ? 0.635f + 0.08f : c == 2 ? 0.75f : 0.635f;
-  float t2 = c == 0 ? 0.66f + 0.08f : c == 2 ? 0.75f : 0.66f;
-  float t3 = c == 0 ? 0.7f + 0.08f : c == 2 ? 0.75f : 0.7f;
-  if (NR == 16) {
-    const float dec = 0.003f * 2 * 1;  // Clamp1(0.003f*xsize*ysize, 0, 0.08|0.12)
-    t0 -= dec; t1 -= dec; t2 -= dec; t3 -= dec;
-  }
-  // NR == 8: the quadrant's column half depends on the lane; NR == 16: on the row parity
-  const float lo_a = (NR == 8) ? (l >= 4 ? t1 : t0) : t0, lo_b = (NR == 8) ? lo_a : t1;
-  const float hi_a = (NR == 8) ? (l >= 4 ? t3 : t2) : t2, hi_b = (NR == 8) ? hi_a : t3;
-#pragma unroll
-  for (int r = 0; r < NR; r++) {
-    const bool lower_half = (NR == 8) ? (r >= 4) : ((r >> 1) >= 4);
-    const bool second = (NR == 16) && (r & 1);
-    const float thr = lower_half ? (second ? hi_b : hi_a) : (second ? lo_b : lo_a);
-    const float q = inv[r * 8 + l] * quantv;
-    const float val = q * in[r];
-    const bool nz = fabsf(val) >= thr;
-    outf[r] = nz ? rintf(val) : 0.0f;  // the quantised coefficient as an integer-valued float
-  }
-}
-
-// Quantise + DC + nzeros for one transform held in registers, then stage the
-// quantised coefficients (natural layout) in LDS.  enc_group.cc:392-443.
-// slot_a / slot_b: staging bases (3 x 64 int16 each) for i < 64 / i >= 64.
-template <int NR>
-JXLT_DI void quantize_transform(float* cx, float* cy, float* cb, const TileShared& S, int strategy,
-                                int l, int quant_ac, const TileArgs& A, float x_factor,
-                                float b_factor, int ibx, int iby, int16_t* slot_a, int16_t* slot_b,
-                                const float* scan_pos, uint8_t* nscan_entry, uint32_t* tokens) {
-  const DeviceTables* T = A.tab;
-  const int kind_off = strategy * 3;
-  const float* inv_x = S.inv_w + quant_table_offset(kind_off + 0);
-  const float* inv_y = S.inv_w + quant_table_offset(kind_off + 1);
-  const float* inv_b = S.inv_w + quant_table_offset(kind_off + 2);
-  const float* ydq = S.y_w + (NR == 8 ? 0 : 64);
-  const float kInvDCQuant[3] = {4096.0f, 512.0f, 256.0f};
-  const float kScale1 = (float)0.901764195028874394;
-  const float qac = A.scale * quant_ac;
-  // 32-bit block indices (the C ABI limits a frame to 2^24 blocks): one VGPR per address
-  const uint32_t bstride = (uint32_t)A.g.xsize_blocks;
-  const uint32_t pos0 = (uint32_t)iby * bstride + (uint32_t)ibx;
-  const uint32_t pos1 = pos0 + (strategy == 1 ? bstride : 1u);
-
-  // --- Y: DC from the unquantised transform, then quantise + roundtrip (:392-409)
-  float dc_a, dc_b = 0.0f;
-  {
-    const float c0 = __shfl(cy[0], (int)(threadIdx.x & 56) | 0, 64);
-    const float c1 = __shfl(cy[0], (int)(threadIdx.x & 56) | 1, 64);
-    if (NR == 8) {
-      dc_a = c0;
-    } else {
-      const float b0 = c0 * 1.0f * 1.0f, b1 = c1 * 1.0f * kScale1;
-      dc_a = b0 + b1;
-      dc_b = b0 - b1;
-    }
-  }
-  const float inv_factor_y = kInvDCQuant[1] * A.scale_dc;
-  const int16_t dcy_a = (int16_t)roundf(inv_factor_y * dc_a);
-  const int16_t dcy_b = (int16_t)roundf(inv_factor_y * dc_b);
-  if (l == 0) {
-    A.quant_dc[1][pos0] = dcy_a;
-    if (NR == 16) A.quant_dc[1][pos1] = dcy_b;
-  }
-  const int covered = NR / 8;
-  // nzeros (enc_group.cc:51-148), the scan position behind the last nonzero coefficient
-  // (enc_group.cc:166-183: what the scan-order store and the tokeniser need) + staging of one
-  // channel's quantised rows.  q: integer-valued floats.  Counted with clamped multiply-adds
-  // (a compare + select pair costs twice as much on gfx950): [q != 0] = clamp01(4 |q|).
-  const float not_llf = l < covered ? 0.0f : 1.0f;
-  auto stage_channel = [&](int c, const float* q) {
-    float cnt = 0.0f, last = 0.0f;
-#pragma unroll
-    for (int r = 0; r < NR; r++) {
-      float nz = clamp01(4.0f * fabsf(q[r]));
-      if (r == 0) nz = nz * not_llf;  // the lowest frequencies (DC) are coded elsewhere
-      cnt = cnt + nz;
-      last = fmaxf(last, nz * scan_pos[r * 8 + l]);  // scan position + 1
-      int16_t* dst = (r * 8 + l < 64) ? slot_a : slot_b;
-      dst[c * 64 + ((r * 8 + l) & 63)] = (int16_t)(int)q[r];
-    }
-    const int nzeros = (int)octet_sum(cnt);
-    const int nscan = (int)octet_max(last);
-    if (l == 0) {
-      // (select, not A.nzgrid[c]: indexing a kernel-argument array by a runtime value
-      // would force the argument block into scratch memory)
-      uint8_t* nzg = c == 0 ? A.nzgrid[0] : c == 1 ? A.nzgrid[1] : A.nzgrid[2];
-      A.blk_nz[pos0 * 3 + c] = (uint8_t)nzeros;
-      A.blk_nscan[pos0 * 3 + c] = (uint8_t)nscan;
-      nscan_entry[c] = (uint8_t)nscan;
-      *tokens += 1 + (nscan > covered ? nscan - covered : 0);
-      if (NR == 8) {
-        nzg[pos0] = (uint8_t)nzeros;
-      } else {
-        const uint8_t shifted = (uint8_t)((nzeros + 1) >> 1);
-        nzg[pos0] = shifted;
-        nzg[pos1] = shifted;
-      }
-    }
-  };
-  {
-    float qyf[NR];
-    quantize_rows<NR>(cy, 1, inv_y, l, qac * 1.0f, qyf);
-    stage_channel(1, qyf);
-    const float inv_qac = T->inv_qac[quant_ac];
-#pragma unroll
-    for (int r = 0; r < NR; r++) cy[r] = (adjust_quant_bias_y(qyf[r]) * ydq[r * 8 + l]) * inv_qac;
-  }
-
-  // --- X, B: undo colour correlation with the roundtripped Y (:417-425), quantise, DC.
-  // Rolled loop over the two chroma channels (instruction-cache footprint).
-#pragma clang loop unroll(disable)
-  for (int c = 0; c <= 2; c += 2) {
-    const float factor = c == 0 ? x_factor : b_factor;
-    const float* inv = c == 0 ? inv_x : inv_b;
-    const float qmul = c == 0 ? A.x_qm_mul : (float)1.0;
-    float cur[NR];
-    float q[NR];
-#pragma unroll
-    for (int r = 0; r < NR; r++) cur[r] = nfma32(factor, cy[r], c == 0 ? cx[r] : cb[r]);
-    quantize_rows<NR>(cur, c, inv, l, qac * qmul, q);
-    const float c0 = __shfl(cur[0], (int)(threadIdx.x & 56) | 0, 64);
-    const float c1 = __shfl(cur[0], (int)(threadIdx.x & 56) | 1, 64);
-    float d_a, d_b = 0.0f;
-    if (NR == 8) {
-      d_a = c0;
-    } else {
-      const float b0 = c0 * 1.0f * 1.0f, b1 = c1 * 1.0f * kScale1;
-      d_a = b0 + b1;
-      d_b = b0 - b1;
-    }
-    const float inv_factor = (c == 0 ? kInvDCQuant[0] : kInvDCQuant[2]) * A.scale_dc;
-    const float cfl_factor = c == 0 ? 0.0f : kInvDCQuant[2] * (1.0f / kInvDCQuant[1]);
-    if (l == 0) {
-      int16_t* qdc = c == 0 ? A.quant_dc[0] : A.quant_dc[2];
-      qdc[pos0] = (int16_t)roundf(d_a * inv_factor - dcy_a * cfl_factor);
-      if (NR == 16) qdc[pos1] = (int16_t)roundf(d_b * inv_factor - dcy_b * cfl_factor);
-    }
-    stage_channel(c, q);
-  }
 }
 
 // kDebug: the variant that serves the A.dbg_* outputs (per-phase clocks, intermediate planes for
@@ -1547,14 +1410,6 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     A.ytob[(size_t)ty_img * A.g.xsize_tiles + tx_img] = (int8_t)ytob;
   }
 
-  // The term area is dead again.  Behind what P6b and P8 use of it (the parked coefficients,
-  // 48 KB; the staging area) it holds, from here on:
-  //   scan_pos[n] = 1 + scan position of natural coefficient n ([0,64) DCT8, [64,192) the
-  //     two-block transforms): the inverse of S.order, read by P8;
-  //   nscan_tab[block][channel] = scan position behind the block's last nonzero coefficient (P8 -> P9).
-  float* const scan_pos = &S.x[0] + 24 * kTileThreads;
-  uint8_t* const nscan_tab = reinterpret_cast<uint8_t*>(scan_pos + 192);
-  if (tid < 192) scan_pos[(tid < 64 ? 0 : 64) + S.order[tid]] = (float)((tid < 64 ? tid : tid - 64) + 1);
   // ---- P6b: entropy estimates (enc_ac_strategy.cc:68-146,187-212) -----------
   float qmax = 0.0f;  // largest quantised magnitude whose root was taken from the table
   if (search) {
@@ -1660,86 +1515,237 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
   __syncthreads();
 #endif
   JXLT_MARK(7);
-  int16_t* stage = reinterpret_cast<int16_t*>(&S.x[0]);  // [64 blocks][3][64]
-
-  // ---- P8: quantise (enc_group.cc:304-443) -----------------------------------
+  // ---- P8a: the coefficients of the selected transforms -> LDS ------------------
+  // The transforms that the decision kept are quantised in SCAN ORDER by other lanes than the ones that hold
+  // them: per tile every block belongs to exactly one selected transform, so "one wave pass = the 64 scan
+  // positions of one block and channel" always fills its lanes, whatever the mix of strategies -- while the
+  // octets that hold the coefficients are, by construction, idle for every candidate that lost (half of
+  // the two-block candidates at best).  Natural layout [block][channel x, y, b][64] of floats, the second
+  // half of a two-block transform in its second block's slot.
+  float* const stagef = &S.x[0];
   {
-    uint32_t octet_tokens = 0;  // lane 0: tokens of the transforms this octet quantises
-    // (a) this octet's own block, if it stayed DCT8
-    const bool do8 = blk_valid && S.strat[oct] == 1;
-    if (do8) {
-      quantize_transform<8>(c8x, c8y, c8b, S, 0, l, S.raw_quant[oct], A, cmap_x, cmap_b,
-                            bx_img0 + obx, by_img0 + oby, stage + oct * kStageStride, stage + oct * kStageStride,
-                            scan_pos, nscan_tab + oct * 3, &octet_tokens);
+    // (within a block and channel the slot of coefficient (row r, column l) is l * 8 + r: a lane's eight rows
+    // are two 16-byte stores)
+    auto put8 = [&](float* d, const float* v) {
+      float4 lo, hi;
+      lo.x = v[0]; lo.y = v[1]; lo.z = v[2]; lo.w = v[3];
+      hi.x = v[4]; hi.y = v[5]; hi.z = v[6]; hi.w = v[7];
+      *reinterpret_cast<float4*>(d) = lo;
+      *reinterpret_cast<float4*>(d + 4) = hi;
+    };
+    if (blk_valid && S.strat[oct] == 1) {  // this octet's own block stayed DCT8
+      float* d = stagef + oct * kStageStrideF + l * 8;
+      put8(d, c8x);
+      put8(d + 64, c8y);
+      put8(d + 128, c8b);
     }
-    // (b) this octet's two-block candidate, if it was selected
     const int bi = cby * 8 + cbx;
-    const bool do16 = cell_valid && S.strat[bi] == (uint8_t)(((is_tall ? 1 : 2) << 1) | 1);
-    if (do16) {
-      const int o2 = is_tall ? 8 : 1;
-      quantize_transform<16>(c16x, c16y, c16b, S, is_tall ? 1 : 2, l, S.raw_quant[bi], A, cmap_x,
-                             cmap_b, bx_img0 + cbx, by_img0 + cby, stage + bi * kStageStride,
-                             stage + (bi + o2) * kStageStride, scan_pos + 64, nscan_tab + bi * 3, &octet_tokens);
+    if (cell_valid && S.strat[bi] == (uint8_t)(((is_tall ? 1 : 2) << 1) | 1)) {  // its candidate was selected
+      float* da = stagef + bi * kStageStrideF + l * 8;
+      float* db = stagef + (bi + (is_tall ? 8 : 1)) * kStageStrideF + l * 8;
+      put8(da, c16x);
+      put8(da + 64, c16y);
+      put8(da + 128, c16b);
+      put8(db, c16x + 8);
+      put8(db + 64, c16y + 8);
+      put8(db + 128, c16b + 8);
     }
-    if (l == 0 && octet_tokens) atomicAdd(&S.ntok, octet_tokens);
   }
   __syncthreads();
   JXLT_MARK(8);
 
-  // ---- P9: scan-order store; wave w stores block row w of the tile -------------
+  // ---- P8b + P9: quantise, DC, nzeros, scan-order store (enc_group.cc:166-443) --
+  // One wave pass = one selected transform: lane = scan position (the lane's natural coefficient index, and
+  // with it its quantisation weights and thresholds, are per-lane constants of the strategy class).  The
+  // tile's transforms are dealt out to the waves round robin (in raster order of their first blocks), so every
+  // wave has the same number of them whatever the mix of strategies.  Per transform only the per-coefficient
+  // work is done at once; the DC values and the per-block outputs are collected per lane (lane j = the wave's
+  // j-th transform) and finished in one pass at the end.  Everything else is wave-uniform (scalar unit).
   {
-    // Nothing here depends on the coefficient values any more: which positions are stored
-    // (those below the scan position behind the last nonzero, nscan_tab from P8) is wave-uniform
-    // and known before the staged coefficients arrive, so the wave index is pinned to a scalar
-    // register, the bookkeeping runs on the scalar unit and the LDS reads of the next block are
-    // in flight while a block is stored.
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int by = wave;
-    if (by < nby) {
-      const int ord8 = S.order[lane], ord16a = S.order[64 + lane], ord16b = S.order[128 + lane];
-      const uint32_t* srow = reinterpret_cast<const uint32_t*>(&S.strat[by * 8]);
-      const uint32_t srow_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)srow[0]);
-      const uint32_t srow_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)srow[1]);
-      auto strategy_of = [&](int bx) { return (int)(((bx < 4 ? srow_lo : srow_hi) >> (8 * (bx & 3))) & 0xFFu); };
-      // the row's 24 nscan bytes (block-major, channel-minor) as six scalar words
-      const uint32_t* nsrow = reinterpret_cast<const uint32_t*>(nscan_tab + by * 24);
-      uint32_t nsw[6];
+    uint32_t wave_tokens = 0;
+    struct LaneConsts {
+      float inv[3];  // InvMatrix of x, y, b at the lane's coefficient
+      float ydq;     // dequantisation weight of y
+      float thr[3];  // zeroing threshold of x, y, b (enc_group.cc:227-242)
+    };
+    auto consts_of = [&](int n, bool two_block) {
+      LaneConsts k;
+      const int base = two_block ? 192 : 0, span = two_block ? 128 : 64;
+      const int r = n >> 3;
+      const int quad = two_block ? ((r >= 8 ? 2 : 0) | (r & 1)) : ((r >= 4 ? 2 : 0) | ((n & 7) >= 4 ? 1 : 0));
 #pragma unroll
-      for (int k = 0; k < 6; k++) nsw[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)nsrow[k]);
-      auto fetch = [&](int bx, int16_t* v0s, int16_t* v1s) {
-        const int bi = by * 8 + bx;
-        const int st = strategy_of(bx) >> 1;
-        const int o2 = st == 1 ? 8 : 1;
-        const int i0 = st == 0 ? ord8 : ord16a, i1 = ord16b;
-        const int src0 = i0 < 64 ? bi * kStageStride + i0 : (bi + o2) * kStageStride + i0 - 64;
-        const int src1 = i1 < 64 ? bi * kStageStride + i1 : (bi + o2) * kStageStride + i1 - 64;
+      for (int c = 0; c < 3; c++) {
+        k.inv[c] = S.inv_w[base + c * span + n];
+        float t0 = 0.58f;
+        float t1 = c == 0 ? 0.635f + 0.08f : c == 2 ? 0.75f : 0.635f;
+        float t2 = c == 0 ? 0.66f + 0.08f : c == 2 ? 0.75f : 0.66f;
+        float t3 = c == 0 ? 0.7f + 0.08f : c == 2 ? 0.75f : 0.7f;
+        if (two_block) {
+          const float dec = 0.003f * 2 * 1;  // Clamp1(0.003f*xsize*ysize, 0, 0.08|0.12)
+          t0 -= dec; t1 -= dec; t2 -= dec; t3 -= dec;
+        }
+        k.thr[c] = quad == 0 ? t0 : quad == 1 ? t1 : quad == 2 ? t2 : t3;
+      }
+      k.ydq = S.y_w[(two_block ? 64 : 0) + n];
+      return k;
+    };
+    const int ord8 = S.order[lane], ord16a = S.order[64 + lane], ord16b = S.order[128 + lane];
+    const LaneConsts k8 = consts_of(ord8, false), k16a = consts_of(ord16a, true), k16b = consts_of(ord16b, true);
+    // where the staging area keeps natural coefficient n = r * 8 + l of a block (P8a): l * 8 + r
+    auto slot_of = [](int n) { return (n & 64) | ((n & 7) << 3) | ((n >> 3) & 7); };
+    const int slot8 = slot_of(ord8), slot16a = slot_of(ord16a), slot16b = slot_of(ord16b);
+    // lane b knows block b of the tile; the first blocks of the tile's transforms as a mask
+    const bool lane_blk_valid = (lane & 7) < nbx && (lane >> 3) < nby;
+    const int strat_of_lane = lane_blk_valid ? (int)S.strat[lane] : 0;
+    const int quant_of_lane = (int)S.raw_quant[lane];
+    const float inv_qac_of_lane = A.tab->inv_qac[quant_of_lane];  // (one vector load: no scalar load per transform)
+    unsigned long long todo = __ballot(strat_of_lane & 1);
+    for (int k = 0; k < wave; k++) todo &= todo - 1;  // this wave's first transform is the wave-th
+    // staged coefficients of the transform whose first block is b: [half a / b][channel x, y, b]
+    auto fetch = [&](int b, int st, float (*v)[3]) {
+      const int o2 = st == 1 ? 8 : 1;
+      const int i0 = st == 0 ? slot8 : slot16a, i1 = slot16b;  // (bit 6: the transform's second block)
+      const int src0 = (i0 < 64 ? b : b + o2) * kStageStrideF + (i0 & 63);
+      const int src1 = (i1 < 64 ? b : b + o2) * kStageStrideF + (i1 & 63);
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-          v0s[c] = stage[src0 + c * 64];
-          v1s[c] = st != 0 ? stage[src1 + c * 64] : (int16_t)0;
+      for (int c = 0; c < 3; c++) {
+        v[0][c] = stagef[src0 + c * 64];
+        v[1][c] = st != 0 ? stagef[src1 + c * 64] : 0.0f;
+      }
+    };
+    auto scalar_lane = [&](int v, int l_) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l_)); };
+    // collected per transform (lane j = the wave's j-th transform)
+    float dc0[3] = {0.0f, 0.0f, 0.0f}, dc1[3] = {0.0f, 0.0f, 0.0f};  // the two lowest frequencies of what was quantised
+    int col_nz = 0, col_nscan = 0, col_block = 0;  // nzeros / nscan: a byte per channel; block | strategy << 8
+    auto collect_f = [&](float& reg, float v, int j) {
+      reg = __int_as_float(write_lane(__float_as_int(reg), __float_as_int(v), j));
+    };
+    auto collect_i = [&](int& reg, int v, int j) { reg = write_lane(reg, v, j); };
+    // (a use of the loaded value here: the wait for it belongs in front of the loop -- inside, where loads and
+    // stores share one counter, it would wait for the previous transform's coefficient stores every time)
+    JXLT_TOUCH_VGPR(inv_qac_of_lane);
+    int ntrans = 0;
+    float next_v[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+    int next_b = todo != 0 ? (int)__builtin_ctzll(todo) : -1, next_st = 0;
+    if (next_b >= 0) {
+      next_st = scalar_lane(strat_of_lane, next_b) >> 1;
+      fetch(next_b, next_st, next_v);
+    }
+    while (next_b >= 0) {
+      const int b = next_b, st = next_st;
+      float in[2][3];
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) in[h][c] = next_v[h][c];
+      for (int k = 0; k < 8 && todo != 0; k++) todo &= todo - 1;  // the wave's next transform is eight further
+      next_b = todo != 0 ? (int)__builtin_ctzll(todo) : -1;
+      if (next_b >= 0) {
+        next_st = scalar_lane(strat_of_lane, next_b) >> 1;
+        fetch(next_b, next_st, next_v);  // (requested before this transform is worked on)
+      }
+      const bool two = st != 0;
+      const int covered = two ? 2 : 1;
+      const int quant_ac = scalar_lane(quant_of_lane, b);
+      const float qac = A.scale * quant_ac;
+      const float inv_qac = __int_as_float(scalar_lane(__float_as_int(inv_qac_of_lane), b));
+      const uint32_t pos0 = (uint32_t)(by_img0 + (b >> 3)) * bstride + (uint32_t)(bx_img0 + (b & 7));
+      const uint32_t pos1 = pos0 + (st == 1 ? bstride : 1u);
+      // per scan position: y first (its round trip feeds the chroma channels, :392-425)
+      float quant[2][3], cur0[3];  // quantised values (integer-valued); first half of what was quantised
+      auto half = [&](const LaneConsts& k, const float* v, float* q, float* cur) {
+        auto quantise = [&](int c, float x, float quantv) {
+          const float qq = k.inv[c] * quantv;
+          const float val = qq * x;
+          return fabsf(val) >= k.thr[c] ? rintf(val) : 0.0f;
+        };
+        q[1] = quantise(1, v[1], qac * 1.0f);
+        const float y_back = (adjust_quant_bias_y(q[1]) * k.ydq) * inv_qac;
+        const float cx_ = nfma32(cmap_x, y_back, v[0]), cb_ = nfma32(cmap_b, y_back, v[2]);
+        q[0] = quantise(0, cx_, qac * A.x_qm_mul);
+        q[2] = quantise(2, cb_, qac * (float)1.0);
+        if (cur) {
+          cur[0] = cx_;
+          cur[1] = v[1];
+          cur[2] = cb_;
         }
       };
-      int16_t n0[3], n1[3];
-      fetch(0, n0, n1);
+      if (two) {
+        half(k16a, in[0], quant[0], cur0);
+        half(k16b, in[1], quant[1], nullptr);
+      } else {
+        half(k8, in[0], quant[0], cur0);
+        quant[1][0] = quant[1][1] = quant[1][2] = 0.0f;
+      }
+      collect_i(col_block, b | (st << 8), ntrans);
+      int nz_packed = 0, nscan_packed = 0;
 #pragma unroll
-      for (int bx = 0; bx < 8; bx++) {
-        const int16_t v0s[3] = {n0[0], n0[1], n0[2]}, v1s[3] = {n1[0], n1[1], n1[2]};
-        if (bx + 1 < 8) fetch(bx + 1, n0, n1);  // (blocks beyond nbx: harmless reads inside the staging area)
-        const int a = strategy_of(bx);
-        if (bx >= nbx || !(a & 1)) continue;
-        const int st = a >> 1;
-        const uint32_t pos0 = (uint32_t)(by_img0 + by) * bstride + (uint32_t)(bx_img0 + bx);
-        const uint32_t pos1 = pos0 + (st == 1 ? bstride : 1u);
+      for (int c = 0; c < 3; c++) {
+        collect_f(dc0[c], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur0[c]), 0)), ntrans);
+        collect_f(dc1[c], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur0[c]), 1)), ntrans);
+        // nzeros (enc_group.cc:51-148) and the scan position behind the last nonzero coefficient
+        const unsigned long long llf_mask = covered == 2 ? 3ull : 1ull;  // scan positions < covered: coded as DC
+        const unsigned long long m0 = __ballot(quant[0][c] != 0.0f) & ~llf_mask;
+        const unsigned long long m1 = two ? __ballot(quant[1][c] != 0.0f) : 0ull;
+        const int nzeros = __popcll(m0) + __popcll(m1);
+        const int nscan = m1 != 0 ? 128 - __clzll((long long)m1) : m0 != 0 ? 64 - __clzll((long long)m0) : 0;
+        nz_packed |= nzeros << (8 * c);
+        nscan_packed |= nscan << (8 * c);
+        // only scan positions below nscan (= up to the last nonzero) are ever read again
+        if (lane < nscan) A.coef_scan[(pos0 * 3 + c) * 64 + lane] = (int16_t)(int)quant[0][c];
+        if (64 + lane < nscan) A.coef_scan[(pos1 * 3 + c) * 64 + lane] = (int16_t)(int)quant[1][c];
+        wave_tokens += 1 + (nscan > covered ? nscan - covered : 0);
+      }
+      collect_i(col_nz, nz_packed, ntrans);
+      collect_i(col_nscan, nscan_packed, ntrans);
+      ntrans++;
+    }
+    // the wave's transforms side by side: DC of the covered blocks (:392-443) and the per-block outputs
+    if (lane < ntrans) {
+      const int b = col_block & 0xFF, st = col_block >> 8;
+      const bool two = st != 0;
+      const uint32_t pos0 = (uint32_t)(by_img0 + (b >> 3)) * bstride + (uint32_t)(bx_img0 + (b & 7));
+      const uint32_t pos1 = pos0 + (st == 1 ? bstride : 1u);
+      const float kScale1 = (float)0.901764195028874394;
+      const float kInvDCQuant[3] = {4096.0f, 512.0f, 256.0f};
+      int16_t dcy_a = 0, dcy_b = 0;
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-          const int e = bx * 3 + c;
-          const int nscan = (int)((nsw[e >> 2] >> (8 * (e & 3))) & 0xFFu);
-          // only scan positions below nscan (= up to the last nonzero) are ever read again
-          if (lane < nscan) A.coef_scan[(pos0 * 3 + c) * 64 + lane] = v0s[c];
-          if (64 + lane < nscan) A.coef_scan[(pos1 * 3 + c) * 64 + lane] = v1s[c];
+      for (int ci = 0; ci < 3; ci++) {
+        const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;  // y first: the chroma DC is coded relative to it
+        const float c0 = dc0[c], c1 = dc1[c];
+        const float b0 = c0 * 1.0f * 1.0f, b1 = c1 * 1.0f * kScale1;
+        const float d_a = two ? b0 + b1 : c0, d_b = two ? b0 - b1 : 0.0f;
+        int16_t qdc_a, qdc_b;
+        if (c == 1) {
+          const float inv_factor_y = kInvDCQuant[1] * A.scale_dc;
+          qdc_a = dcy_a = (int16_t)roundf(inv_factor_y * d_a);
+          qdc_b = dcy_b = (int16_t)roundf(inv_factor_y * d_b);
+        } else {
+          const float inv_factor = (c == 0 ? kInvDCQuant[0] : kInvDCQuant[2]) * A.scale_dc;
+          const float cfl_factor = c == 0 ? 0.0f : kInvDCQuant[2] * (1.0f / kInvDCQuant[1]);
+          qdc_a = (int16_t)roundf(d_a * inv_factor - dcy_a * cfl_factor);
+          qdc_b = (int16_t)roundf(d_b * inv_factor - dcy_b * cfl_factor);
+        }
+        // (select, not A.nzgrid[c] / A.quant_dc[c]: indexing a kernel-argument array by a runtime value
+        // would force the argument block into scratch memory)
+        uint8_t* nzg = c == 0 ? A.nzgrid[0] : c == 1 ? A.nzgrid[1] : A.nzgrid[2];
+        int16_t* qdc = c == 0 ? A.quant_dc[0] : c == 1 ? A.quant_dc[1] : A.quant_dc[2];
+        const int nzeros = (col_nz >> (8 * c)) & 0xFF;
+        qdc[pos0] = qdc_a;
+        A.blk_nz[pos0 * 3 + c] = (uint8_t)nzeros;
+        A.blk_nscan[pos0 * 3 + c] = (uint8_t)((col_nscan >> (8 * c)) & 0xFF);
+        if (!two) {
+          nzg[pos0] = (uint8_t)nzeros;
+        } else {
+          qdc[pos1] = qdc_b;
+          const uint8_t shifted = (uint8_t)((nzeros + 1) >> 1);
+          nzg[pos0] = shifted;
+          nzg[pos1] = shifted;
         }
       }
     }
+    if (lane == 0 && wave_tokens) atomicAdd(&S.ntok, wave_tokens);
   }
   __syncthreads();
   JXLT_MARK(9);
