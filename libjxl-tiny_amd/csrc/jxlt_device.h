@@ -1600,8 +1600,12 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     const int strat_of_lane = lane_blk_valid ? (int)S.strat[lane] : 0;
     const int quant_of_lane = (int)S.raw_quant[lane];
     const float inv_qac_of_lane = A.tab->inv_qac[quant_of_lane];  // (one vector load: no scalar load per transform)
-    unsigned long long todo = __ballot(strat_of_lane & 1);
-    for (int k = 0; k < wave; k++) todo &= todo - 1;  // this wave's first transform is the wave-th
+    // (transform number t, in raster order of the first blocks, goes to wave t mod 8: lane b finds its block's
+    // number as the count of first blocks below it, and the wave's own blocks come out of one more ballot)
+    const unsigned long long firsts = __ballot(strat_of_lane & 1);
+    const int rank_of_lane =
+        (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(firsts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)firsts, 0u));
+    unsigned long long todo = __ballot((strat_of_lane & 1) != 0 && (rank_of_lane & 7) == wave);
     // staged coefficients of the transform whose first block is b: [half a / b][channel x, y, b]
     auto fetch = [&](int b, int st, float (*v)[3]) {
       const int o2 = st == 1 ? 8 : 1;
@@ -1616,11 +1620,11 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     };
     auto scalar_lane = [&](int v, int l_) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l_)); };
     // collected per transform (lane j = the wave's j-th transform)
-    float dc0[3] = {0.0f, 0.0f, 0.0f}, dc1[3] = {0.0f, 0.0f, 0.0f};  // the two lowest frequencies of what was quantised
+    // (the two lowest frequencies of what was quantised go through LDS: lanes 0 and 1 store them, lane j reads
+    // its transform's six values at the end -- [wave][transform][channel][2] floats behind the staging area)
+    float* const dc_stage = stagef + 64 * kStageStrideF + wave * (8 * 3 * 2);
+    float* const dc_dump = stagef + 64 * kStageStrideF + 8 * (8 * 3 * 2) + lane;  // where the other lanes' stores go
     int col_nz = 0, col_nscan = 0, col_block = 0;  // nzeros / nscan: a byte per channel; block | strategy << 8
-    auto collect_f = [&](float& reg, float v, int j) {
-      reg = __int_as_float(write_lane(__float_as_int(reg), __float_as_int(v), j));
-    };
     auto collect_i = [&](int& reg, int v, int j) { reg = write_lane(reg, v, j); };
     // (a use of the loaded value here: the wait for it belongs in front of the loop -- inside, where loads and
     // stores share one counter, it would wait for the previous transform's coefficient stores every time)
@@ -1639,7 +1643,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       for (int h = 0; h < 2; h++)
 #pragma unroll
         for (int c = 0; c < 3; c++) in[h][c] = next_v[h][c];
-      for (int k = 0; k < 8 && todo != 0; k++) todo &= todo - 1;  // the wave's next transform is eight further
+      todo &= todo - 1;
       next_b = todo != 0 ? (int)__builtin_ctzll(todo) : -1;
       if (next_b >= 0) {
         next_st = scalar_lane(strat_of_lane, next_b) >> 1;
@@ -1682,8 +1686,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       int nz_packed = 0, nscan_packed = 0;
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        collect_f(dc0[c], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur0[c]), 0)), ntrans);
-        collect_f(dc1[c], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur0[c]), 1)), ntrans);
+        (lane < 2 ? dc_stage + (ntrans * 3 + c) * 2 + lane : dc_dump)[0] = cur0[c];
         // nzeros (enc_group.cc:51-148) and the scan position behind the last nonzero coefficient
         const unsigned long long llf_mask = covered == 2 ? 3ull : 1ull;  // scan positions < covered: coded as DC
         const unsigned long long m0 = __ballot(quant[0][c] != 0.0f) & ~llf_mask;
@@ -1713,7 +1716,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
 #pragma unroll
       for (int ci = 0; ci < 3; ci++) {
         const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;  // y first: the chroma DC is coded relative to it
-        const float c0 = dc0[c], c1 = dc1[c];
+        const float c0 = dc_stage[(lane * 3 + c) * 2], c1 = dc_stage[(lane * 3 + c) * 2 + 1];
         const float b0 = c0 * 1.0f * 1.0f, b1 = c1 * 1.0f * kScale1;
         const float d_a = two ? b0 + b1 : c0, d_b = two ? b0 - b1 : 0.0f;
         int16_t qdc_a, qdc_b;
