@@ -48,7 +48,29 @@ struct DeviceTables {
   uint8_t ac_context_map[1980];
   uint8_t gradient_lut[1024];  // enc_frame.cc:226-281
   float sqrt_lut[1024];        // sqrtf(i), correctly rounded (EstimateEntropy's cost of a coefficient)
+  // What the quantisation needs to know of scan position p (tile_kernel quantises in scan order, lane = scan
+  // position), per position class -- 0: DCT8, 1 / 2: first / second 64 positions of a two-block transform:
+  // [0..2] InvMatrix of x, y, b at the position's coefficient, [3] dequantisation weight of y, [4..6] zeroing
+  // threshold of x, y, b (enc_group.cc:227-242); scan_slot: where the staging area keeps that coefficient
+  // (bit 6: in the transform's second block).
+  float scan_consts[3][7][64];
+  uint8_t scan_slot[3][64];
 };
+
+// The quantiser's zeroing threshold (enc_group.cc:227-242) of channel c in quadrant `quad` of a one-block
+// (8x8) or two-block transform; quadrants: 8x8: (row >= 4) * 2 + (column >= 4); two-block, coefficient
+// index i = r * 8 + l with r = 0..15: (r >= 8) * 2 + (r & 1).
+__host__ __device__ inline float quant_zeroing_threshold(int c, bool two_block, int quad) {
+  float t0 = 0.58f;
+  float t1 = c == 0 ? 0.635f + 0.08f : c == 2 ? 0.75f : 0.635f;
+  float t2 = c == 0 ? 0.66f + 0.08f : c == 2 ? 0.75f : 0.66f;
+  float t3 = c == 0 ? 0.7f + 0.08f : c == 2 ? 0.75f : 0.7f;
+  if (two_block) {
+    const float dec = 0.003f * 2 * 1;  // Clamp1(0.003f*xsize*ysize, 0, 0.08|0.12)
+    t0 -= dec; t1 -= dec; t2 -= dec; t3 -= dec;
+  }
+  return quad == 0 ? t0 : quad == 1 ? t1 : quad == 2 ? t2 : t3;
+}
 
 // Offset of quant table n = strategy * 3 + channel inside weights[] / inv_weights[]: three
 // 64-entry DCT8 tables, then three 128-entry tables shared by DCT16X8 and DCT8X16.
@@ -684,14 +706,12 @@ struct alignas(16) TileShared {
   // (its first 128 floats hold the candidate entropies of the 2x2 cells during the strategy search, "ent8")
   float sqrt_lut[kSqrtLutSize];  // sqrtf of the quantised magnitudes below kSqrtLutSize
   float inv_w[576];
-  float y_w[192];          // dequant weights of Y: [0,64) DCT8, [64,192) two-block
   float aq[64];            // quant field (tile-local 8x8)
   float mask[64];
   float cfl_sum[4];        // ca_x, cb_x, ca_b, cb_b
   int cmap[2];             // ytox, ytob
   uint8_t raw_quant[64];
   uint8_t strat[64];
-  uint8_t order[192];      // coefficient scan orders (enc_group.cc:166-183)
   uint32_t ntok;
   uint32_t nfirst;
 };
@@ -853,8 +873,6 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
   const float tab_inv1 = T->inv_weights[512 + (tid & 63)];
   const float tab_root0 = T->sqrt_lut[tid & (kSqrtLutSize - 1)];
   const float tab_root1 = T->sqrt_lut[(512 + tid) & (kSqrtLutSize - 1)];
-  const float tab_yw = T->weights[tid < 64 ? quant_table_offset(1) + tid : quant_table_offset(4) + ((tid - 64) & 127)];
-  const uint8_t tab_order = T->coeff_order[tid < 192 ? tid : 0];
   if (tid == 0) {
     S.ntok = 0;
     S.nfirst = 0;
@@ -901,10 +919,6 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     if (tid < 64) S.inv_w[512 + tid] = tab_inv1;
     if (tid < kSqrtLutSize) S.sqrt_lut[tid] = tab_root0;
     if (kSqrtLutSize > 512) S.sqrt_lut[(512 + tid) & (kSqrtLutSize - 1)] = tab_root1;
-    if (tid < 192) {
-      S.y_w[tid] = tab_yw;
-      S.order[tid] = tab_order;
-    }
     if (A.byteswap) {  // big-endian PFM payload (BSwapFloat, read_pfm.cc:206)
 #pragma unroll
       for (int j = 0; j < 5; j++) {
@@ -1569,32 +1583,19 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       float ydq;     // dequantisation weight of y
       float thr[3];  // zeroing threshold of x, y, b (enc_group.cc:227-242)
     };
-    auto consts_of = [&](int n, bool two_block) {
+    // (per scan position and position class: tables built by the host, DeviceTables::scan_consts)
+    auto consts_of = [&](int cls) {
       LaneConsts k;
-      const int base = two_block ? 192 : 0, span = two_block ? 128 : 64;
-      const int r = n >> 3;
-      const int quad = two_block ? ((r >= 8 ? 2 : 0) | (r & 1)) : ((r >= 4 ? 2 : 0) | ((n & 7) >= 4 ? 1 : 0));
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        k.inv[c] = S.inv_w[base + c * span + n];
-        float t0 = 0.58f;
-        float t1 = c == 0 ? 0.635f + 0.08f : c == 2 ? 0.75f : 0.635f;
-        float t2 = c == 0 ? 0.66f + 0.08f : c == 2 ? 0.75f : 0.66f;
-        float t3 = c == 0 ? 0.7f + 0.08f : c == 2 ? 0.75f : 0.7f;
-        if (two_block) {
-          const float dec = 0.003f * 2 * 1;  // Clamp1(0.003f*xsize*ysize, 0, 0.08|0.12)
-          t0 -= dec; t1 -= dec; t2 -= dec; t3 -= dec;
-        }
-        k.thr[c] = quad == 0 ? t0 : quad == 1 ? t1 : quad == 2 ? t2 : t3;
+        k.inv[c] = A.tab->scan_consts[cls][c][lane];
+        k.thr[c] = A.tab->scan_consts[cls][4 + c][lane];
       }
-      k.ydq = S.y_w[(two_block ? 64 : 0) + n];
+      k.ydq = A.tab->scan_consts[cls][3][lane];
       return k;
     };
-    const int ord8 = S.order[lane], ord16a = S.order[64 + lane], ord16b = S.order[128 + lane];
-    const LaneConsts k8 = consts_of(ord8, false), k16a = consts_of(ord16a, true), k16b = consts_of(ord16b, true);
-    // where the staging area keeps natural coefficient n = r * 8 + l of a block (P8a): l * 8 + r
-    auto slot_of = [](int n) { return (n & 64) | ((n & 7) << 3) | ((n >> 3) & 7); };
-    const int slot8 = slot_of(ord8), slot16a = slot_of(ord16a), slot16b = slot_of(ord16b);
+    const LaneConsts k8 = consts_of(0), k16a = consts_of(1), k16b = consts_of(2);
+    const int slot8 = A.tab->scan_slot[0][lane], slot16a = A.tab->scan_slot[1][lane], slot16b = A.tab->scan_slot[2][lane];
     // lane b knows block b of the tile; the first blocks of the tile's transforms as a mask
     const bool lane_blk_valid = (lane & 7) < nbx && (lane >> 3) < nby;
     const int strat_of_lane = lane_blk_valid ? (int)S.strat[lane] : 0;
@@ -1629,6 +1630,17 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     // (a use of the loaded value here: the wait for it belongs in front of the loop -- inside, where loads and
     // stores share one counter, it would wait for the previous transform's coefficient stores every time)
     JXLT_TOUCH_VGPR(inv_qac_of_lane);
+    for (const LaneConsts* k : {&k8, &k16a, &k16b}) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        JXLT_TOUCH_VGPR(k->inv[c]);
+        JXLT_TOUCH_VGPR(k->thr[c]);
+      }
+      JXLT_TOUCH_VGPR(k->ydq);
+    }
+    JXLT_TOUCH_VGPR(slot8);
+    JXLT_TOUCH_VGPR(slot16a);
+    JXLT_TOUCH_VGPR(slot16b);
     int ntrans = 0;
     float next_v[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
     int next_b = todo != 0 ? (int)__builtin_ctzll(todo) : -1, next_st = 0;

@@ -37,6 +37,22 @@ inline void BuildDeviceTables(float scale, DeviceTables* t) {
   memcpy(t->ac_context_map, JXLT_kACContextMap, sizeof(t->ac_context_map));
   memcpy(t->gradient_lut, JXLT_kGradientContextLut, sizeof(t->gradient_lut));
   for (int i = 0; i < 1024; i++) t->sqrt_lut[i] = sqrtf((float)i);  // IEEE: correctly rounded
+  // quantisation in scan order: the constants of scan position p, per position class
+  for (int cls = 0; cls < 3; cls++) {
+    const bool two_block = cls != 0;
+    for (int p = 0; p < 64; p++) {
+      const int n = JXLT_kCoeffOrder[cls * 64 + p];  // natural coefficient index (0..63 / 0..127)
+      const int r = n >> 3;
+      const int quad = two_block ? ((r >= 8 ? 2 : 0) | (r & 1)) : ((r >= 4 ? 2 : 0) | ((n & 7) >= 4 ? 1 : 0));
+      for (int c = 0; c < 3; c++) {
+        t->scan_consts[cls][c][p] = t->inv_weights[quant_table_offset((two_block ? 3 : 0) + c) + n];
+        t->scan_consts[cls][4 + c][p] = quant_zeroing_threshold(c, two_block, quad);
+      }
+      t->scan_consts[cls][3][p] = t->weights[quant_table_offset(two_block ? 4 : 1) + n];
+      // staging slot of coefficient (row r, column l) within its block: l * 8 + (r & 7), second block: bit 6
+      t->scan_slot[cls][p] = static_cast<uint8_t>((n & 64) | ((n & 7) << 3) | ((n >> 3) & 7));
+    }
+  }
 }
 
 inline FrameGeom MakeGeom(size_t xsize, size_t ysize) {
