@@ -1649,7 +1649,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       fetch(next_b, next_st, next_v);
     }
     while (next_b >= 0) {
-      const int b = next_b, st = next_st;
+      const int b = __builtin_amdgcn_readfirstlane(next_b), st = __builtin_amdgcn_readfirstlane(next_st);
       float in[2][3];
 #pragma unroll
       for (int h = 0; h < 2; h++)
@@ -1708,8 +1708,11 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
         nz_packed |= nzeros << (8 * c);
         nscan_packed |= nscan << (8 * c);
         // only scan positions below nscan (= up to the last nonzero) are ever read again
-        if (lane < nscan) A.coef_scan[(pos0 * 3 + c) * 64 + lane] = (int16_t)(int)quant[0][c];
-        if (64 + lane < nscan) A.coef_scan[(pos1 * 3 + c) * 64 + lane] = (int16_t)(int)quant[1][c];
+        // (scalar base + lane: one address register per store)
+        int16_t* const out0 = A.coef_scan + (size_t)(pos0 * 3 + c) * 64;
+        int16_t* const out1 = A.coef_scan + (size_t)(pos1 * 3 + c) * 64;
+        if (lane < nscan) out0[lane] = (int16_t)(int)quant[0][c];
+        if (64 + lane < nscan) out1[lane] = (int16_t)(int)quant[1][c];
         wave_tokens += 1 + (nscan > covered ? nscan - covered : 0);
       }
       collect_i(col_nz, nz_packed, ntrans);
