@@ -1623,10 +1623,13 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     // collected per transform (lane j = the wave's j-th transform)
     // (the two lowest frequencies of what was quantised go through LDS: lanes 0 and 1 store them, lane j reads
     // its transform's six values at the end -- [wave][transform][channel][2] floats behind the staging area)
-    float* const dc_stage = stagef + 64 * kStageStrideF + wave * (8 * 3 * 2);
-    float* const dc_dump = stagef + 64 * kStageStrideF + 8 * (8 * 3 * 2) + lane;  // where the other lanes' stores go
-    int col_nz = 0, col_nscan = 0, col_block = 0;  // nzeros / nscan: a byte per channel; block | strategy << 8
-    auto collect_i = [&](int& reg, int v, int j) { reg = write_lane(reg, v, j); };
+    float* const dc_stage = stagef + 64 * kStageStrideF;            // [transform][channel][2]
+    int* const tr_info = reinterpret_cast<int*>(dc_stage + 64 * 6);  // [3][transform]: block | strategy << 8, nzeros, nscan
+    float* const lane_dump = dc_stage + 64 * 6 + 3 * 64 + lane;      // where the stores of the lanes that have nothing to say go
+    // (lane 0 files a wave-uniform value under the transform's number)
+    auto file_int = [&](int which, int t, int v) {
+      (lane == 0 ? tr_info + which * 64 + t : reinterpret_cast<int*>(lane_dump))[0] = v;
+    };
     // (a use of the loaded value here: the wait for it belongs in front of the loop -- inside, where loads and
     // stores share one counter, it would wait for the previous transform's coefficient stores every time)
     JXLT_TOUCH_VGPR(inv_qac_of_lane);
@@ -1694,11 +1697,12 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
         half(k8, in[0], quant[0], cur0);
         quant[1][0] = quant[1][1] = quant[1][2] = 0.0f;
       }
-      collect_i(col_block, b | (st << 8), ntrans);
+      const int t = wave + 8 * ntrans;  // the transform's number in the tile
+      file_int(0, t, b | (st << 8));
       int nz_packed = 0, nscan_packed = 0;
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        (lane < 2 ? dc_stage + (ntrans * 3 + c) * 2 + lane : dc_dump)[0] = cur0[c];
+        (lane < 2 ? dc_stage + (t * 3 + c) * 2 + lane : lane_dump)[0] = cur0[c];
         // nzeros (enc_group.cc:51-148) and the scan position behind the last nonzero coefficient
         const unsigned long long llf_mask = covered == 2 ? 3ull : 1ull;  // scan positions < covered: coded as DC
         const unsigned long long m0 = __ballot(quant[0][c] != 0.0f) & ~llf_mask;
@@ -1715,11 +1719,22 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
         if (64 + lane < nscan) out1[lane] = (int16_t)(int)quant[1][c];
         wave_tokens += 1 + (nscan > covered ? nscan - covered : 0);
       }
-      collect_i(col_nz, nz_packed, ntrans);
-      collect_i(col_nscan, nscan_packed, ntrans);
+      file_int(1, t, nz_packed);
+      file_int(2, t, nscan_packed);
       ntrans++;
     }
-    // the wave's transforms side by side: DC of the covered blocks (:392-443) and the per-block outputs
+    if (lane == 0 && wave_tokens) atomicAdd(&S.ntok, wave_tokens);
+  }
+  __syncthreads();
+  // the tile's transforms side by side, one per lane of wave 0: DC of the covered blocks (:392-443) and the
+  // per-block outputs
+  if (tid < 64) {
+    const int lane = tid;
+    float* const dc_stage = stagef + 64 * kStageStrideF;
+    const int* const tr_info = reinterpret_cast<const int*>(dc_stage + 64 * 6);
+    const bool lane_blk_valid = (lane & 7) < nbx && (lane >> 3) < nby;
+    const int ntrans = __popcll(__ballot(lane_blk_valid && (S.strat[lane] & 1) != 0));
+    const int col_block = tr_info[lane], col_nz = tr_info[64 + lane], col_nscan = tr_info[128 + lane];
     if (lane < ntrans) {
       const int b = col_block & 0xFF, st = col_block >> 8;
       const bool two = st != 0;
@@ -1763,9 +1778,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
         }
       }
     }
-    if (lane == 0 && wave_tokens) atomicAdd(&S.ntok, wave_tokens);
   }
-  __syncthreads();
   JXLT_MARK(9);
   if (tid == 0) {
     const int group = (ty_img >> 2) * A.g.xsize_groups + gx;
