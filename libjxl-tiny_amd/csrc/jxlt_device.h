@@ -1700,24 +1700,33 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       const int t = wave + 8 * ntrans;  // the transform's number in the tile
       file_int(0, t, b | (st << 8));
       int nz_packed = 0, nscan_packed = 0;
+      // nzeros (enc_group.cc:51-148) and the scan position behind the last nonzero coefficient: the six ballots
+      // first, then the scalar arithmetic on them, then the stores (no compare -> scalar -> compare round trip
+      // per channel)
+      const unsigned long long llf_mask = covered == 2 ? 3ull : 1ull;  // scan positions < covered: coded as DC
+      unsigned long long m0[3], m1[3];
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         (lane < 2 ? dc_stage + (t * 3 + c) * 2 + lane : lane_dump)[0] = cur0[c];
-        // nzeros (enc_group.cc:51-148) and the scan position behind the last nonzero coefficient
-        const unsigned long long llf_mask = covered == 2 ? 3ull : 1ull;  // scan positions < covered: coded as DC
-        const unsigned long long m0 = __ballot(quant[0][c] != 0.0f) & ~llf_mask;
-        const unsigned long long m1 = two ? __ballot(quant[1][c] != 0.0f) : 0ull;
-        const int nzeros = __popcll(m0) + __popcll(m1);
-        const int nscan = m1 != 0 ? 128 - __clzll((long long)m1) : m0 != 0 ? 64 - __clzll((long long)m0) : 0;
+        m0[c] = __ballot(quant[0][c] != 0.0f) & ~llf_mask;
+        m1[c] = two ? __ballot(quant[1][c] != 0.0f) : 0ull;
+      }
+      int nscan[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const int nzeros = __popcll(m0[c]) + __popcll(m1[c]);
+        nscan[c] = m1[c] != 0 ? 128 - __clzll((long long)m1[c]) : m0[c] != 0 ? 64 - __clzll((long long)m0[c]) : 0;
         nz_packed |= nzeros << (8 * c);
-        nscan_packed |= nscan << (8 * c);
+        nscan_packed |= nscan[c] << (8 * c);
+        wave_tokens += 1 + (nscan[c] > covered ? nscan[c] - covered : 0);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
         // only scan positions below nscan (= up to the last nonzero) are ever read again
-        // (scalar base + lane: one address register per store)
         int16_t* const out0 = A.coef_scan + (size_t)(pos0 * 3 + c) * 64;
         int16_t* const out1 = A.coef_scan + (size_t)(pos1 * 3 + c) * 64;
-        if (lane < nscan) out0[lane] = (int16_t)(int)quant[0][c];
-        if (64 + lane < nscan) out1[lane] = (int16_t)(int)quant[1][c];
-        wave_tokens += 1 + (nscan > covered ? nscan - covered : 0);
+        if (lane < nscan[c]) out0[lane] = (int16_t)(int)quant[0][c];
+        if (64 + lane < nscan[c]) out1[lane] = (int16_t)(int)quant[1][c];
       }
       file_int(1, t, nz_packed);
       file_int(2, t, nscan_packed);
