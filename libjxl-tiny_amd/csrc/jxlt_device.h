@@ -1948,6 +1948,39 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   __syncthreads();
 
   uint8_t* out = A.tokens + 3 * s_group_base;  // (written before the two barriers of the scan above)
+  // The nzeros token of every entry (the first token of a block's Y, X and B run), a thread per block: in the
+  // block loop below they were three lanes' work per wave pass.
+  for (int b = tid; b < nblk; b += kTokenThreads) {
+    const uint32_t mb[3] = {meta[b * 3], meta[b * 3 + 1], meta[b * 3 + 2]};
+    if (!(mb[0] & 1)) continue;  // not the first block of a transform: no entries
+    const int st = (int)((mb[0] >> 1) & 0x7F);
+    const int covered = st == 0 ? 1 : 2;
+    const int bctx_y = st == 0 ? 0 : 1, bctx_c = 2 + bctx_y;  // (ac_context.h:64-114, see below)
+    const int cbx = b % nbx, cby = b / nbx;
+    uint32_t tl = offs[b];
+#pragma unroll
+    for (int ci = 0; ci < 3; ci++) {
+      const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
+      const int nzl = (int)((mb[ci] >> 8) & 0xFF), nsc = (int)(mb[ci] >> 16);
+      // PredictFromTopAndLeft (enc_group.cc:150-160), default 32
+      int pred;
+      const uint8_t* nzg = &s_nzg[c * 1024 + b];
+      if (cbx == 0) pred = cby == 0 ? 32 : nzg[-nbx];
+      else if (cby == 0) pred = nzg[-1];
+      else pred = (nzg[-nbx] + nzg[-1] + 1) / 2;
+      const int bucket = pred < 8 ? pred : pred >= 64 ? 36 : 4 + pred / 2;
+      const int ctx = bucket * 4 + (ci == 0 ? bctx_y : bctx_c);
+      uint8_t* o = out + 3u * tl;
+      const uint8_t cm = s_ctx_map[ctx];
+      o[0] = cm;
+      o[1] = (uint8_t)(nzl & 0xFF);
+      o[2] = (uint8_t)(nzl >> 8);
+      if (do_hist) {
+        atomicAdd(&hist[cm * 64 + hybrid_uint_symbol((uint32_t)nzl)], 1u);
+      }
+      tl += 1 + (nsc > covered ? nsc - covered : 0);
+    }
+  }
   constexpr int kWaves = kTokenThreads / 64;
   // Wave w takes blocks w, w + 8, ... of the group (stream order) and their three channel
   // entries; lane = scan position.  The coefficients of the wave's next block are requested
@@ -2011,28 +2044,7 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     // block context (ac_context.h:64-114): kBlockContextMap[c*27 + code] is 0/1 for Y and
     // 2/3 for X,B, the odd value for the two-block strategy codes 6 and 7
     const int bctx_y = st == 0 ? 0 : 1, bctx_c = 2 + bctx_y;
-    // (1) the nzeros token of each entry: lanes 0..2, one channel each
-    if (lane < 3) {
-      const int c = lane == 0 ? 1 : lane == 1 ? 0 : 2;
-      const int nzl = lane == 0 ? nzeros[0] : lane == 1 ? nzeros[1] : nzeros[2];
-      const uint32_t tl = lane == 0 ? tok0[0] : lane == 1 ? tok0[1] : tok0[2];
-      // PredictFromTopAndLeft (enc_group.cc:150-160), default 32
-      int pred;
-      const uint8_t* nzg = &s_nzg[c * 1024 + b];
-      if (cbx == 0) pred = cby == 0 ? 32 : nzg[-nbx];
-      else if (cby == 0) pred = nzg[-1];
-      else pred = (nzg[-nbx] + nzg[-1] + 1) / 2;
-      const int bucket = pred < 8 ? pred : pred >= 64 ? 36 : 4 + pred / 2;
-      const int ctx = bucket * 4 + (lane == 0 ? bctx_y : bctx_c);
-      uint8_t* o = out + 3u * tl;
-      const uint8_t cm = s_ctx_map[ctx];
-      o[0] = cm;
-      o[1] = (uint8_t)(nzl & 0xFF);
-      o[2] = (uint8_t)(nzl >> 8);
-      if (do_hist) {
-        atomicAdd(&hist[cm * 64 + hybrid_uint_symbol((uint32_t)nzl)], 1u);
-      }
-    }
+    // (1) the nzeros tokens of the entries were written by the thread-per-block pass in front of this loop
     // (2) scan positions 0..63 of the entries: NP passes of 64 lanes.  Pass parameters per lane:
     // coefficient, in-range flag, scan position, nzeros / first token of its entry, block context,
     // set bits of the nonzero ballot below it, previous lane's nonzero flag.
