@@ -1876,6 +1876,8 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   }
   // Where the group's tokens start: the sum of the counts of all groups before it (<= 16 384 counts, 64 KB,
   // one round of loads; a scan kernel in front of this one cost 22 us of the step for the same numbers).
+  __shared__ uint32_t s_first[1024];  // the group's first blocks (any order): block | column << 10 | row << 15
+  __shared__ uint32_t s_nfirst;
   __shared__ uint64_t s_group_base;
   __shared__ uint64_t gsum[kTokenThreads / 64];
   {
@@ -1914,7 +1916,10 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     }
     offs[b + 1] = nsum;
   }
-  if (tid == 0) offs[0] = 0;
+  if (tid == 0) {
+    offs[0] = 0;
+    s_nfirst = 0;
+  }
   __syncthreads();
   if (tid == 0) {
     uint64_t base = 0;
@@ -1957,6 +1962,7 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     const int covered = st == 0 ? 1 : 2;
     const int bctx_y = st == 0 ? 0 : 1, bctx_c = 2 + bctx_y;  // (ac_context.h:64-114, see below)
     const int cbx = b % nbx, cby = b / nbx;
+    s_first[atomicAdd(&s_nfirst, 1u)] = (uint32_t)b | ((uint32_t)cbx << 10) | ((uint32_t)cby << 15);
     uint32_t tl = offs[b];
 #pragma unroll
     for (int ci = 0; ci < 3; ci++) {
@@ -1986,36 +1992,37 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   // entries; lane = scan position.  The coefficients of the wave's next block are requested
   // before the current one is processed (HBM latency overlap).
   // (only scan positions below nscan were written by tile_kernel)
-  int bx = wave % nbx, by = wave / nbx;
-  const int dbx = kWaves % nbx, dby = kWaves / nbx;
+  __syncthreads();  // the list of first blocks is complete
+  const int nfirst = (int)s_nfirst;
   // Chroma entries are short on ordinary content (the X and B entries of the bench frame average
   // 0.6 tokens against 39 of Y): when both end within 32 scan positions they share ONE 64-lane pass,
   // X on lanes 0-31 and B on lanes 32-63 -- B's coefficients are then loaded 32 lanes up.
-  auto load_block = [&](int b, int bxx, int byy, int16_t* v) {
+  auto load_block = [&](uint32_t entry, int16_t* v) {
+    const int b = (int)(entry & 1023u), bxx = (int)((entry >> 10) & 31u), byy = (int)(entry >> 15);
     const uint32_t pos = (uint32_t)(by0 + byy) * bstride + (uint32_t)(bx0 + bxx);
     int ns[3];
 #pragma unroll
     for (int ci = 0; ci < 3; ci++) ns[ci] = (int)(__builtin_amdgcn_readfirstlane((int)meta[b * 3 + ci]) >> 16);
     const bool packed = ns[1] <= 32 && ns[2] <= 32;
     v[0] = v[1] = v[2] = 0;
-    if ((ns[0] | ns[1] | ns[2]) == 0) return;  // not a first block, or nothing to read (wave-uniform)
+    if ((ns[0] | ns[1] | ns[2]) == 0) return;  // nothing to read (wave-uniform)
     v[0] = lane < ns[0] ? A.coef_scan[(pos * 3 + 1) * 64 + lane] : (int16_t)0;
     v[1] = lane < ns[1] ? A.coef_scan[(pos * 3 + 0) * 64 + lane] : (int16_t)0;
     const int lb = packed ? lane - 32 : lane;  // B's scan position on this lane
     v[2] = (lb >= 0 && lb < ns[2]) ? A.coef_scan[(pos * 3 + 2) * 64 + lb] : (int16_t)0;
   };
+  // Wave w takes the first blocks number w, w + 8, ... of the list.
   int16_t next_v[3] = {0, 0, 0};
-  if (wave < nblk) load_block(wave, bx, by, next_v);
-  for (int b = wave; b < nblk; b += kWaves) {
+  uint32_t next_entry = wave < nfirst ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_first[wave]) : 0u;
+  if (wave < nfirst) load_block(next_entry, next_v);
+  for (int i = wave; i < nfirst; i += kWaves) {
     const int16_t cur_v[3] = {next_v[0], next_v[1], next_v[2]};
-    const int cbx = bx, cby = by;
-    bx += dbx;
-    by += dby;
-    if (bx >= nbx) {
-      bx -= nbx;
-      by++;
+    const uint32_t entry = next_entry;
+    const int b = (int)(entry & 1023u), cbx = (int)((entry >> 10) & 31u), cby = (int)(entry >> 15);
+    if (i + kWaves < nfirst) {
+      next_entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_first[i + kWaves]);
+      load_block(next_entry, next_v);
     }
-    if (b + kWaves < nblk) load_block(b + kWaves, bx, by, next_v);
     const uint32_t pos = (uint32_t)(by0 + cby) * bstride + (uint32_t)(bx0 + cbx);
     // The three channel entries of a block are independent: their ballots, table look-ups and
     // stores are written as straight-line code (no branches in between) so that the dependent
