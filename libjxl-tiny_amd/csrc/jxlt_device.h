@@ -2108,7 +2108,10 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
       const int below_lo = (int)__builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u);
       const int below_hi = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), 0u);
       pbelow[1] = half ? below_hi : below_lo;
-      coef_passes(std::integral_constant<int, 2>(), pv, pin, pk, pnz, ptok, pbctx, pbelow, pprev);
+      if (nscan[1] <= covered && nscan[2] <= covered)  // (no chroma coefficient tokens: Y's pass alone)
+        coef_passes(std::integral_constant<int, 1>(), pv, pin, pk, pnz, ptok, pbctx, pbelow, pprev);
+      else
+        coef_passes(std::integral_constant<int, 2>(), pv, pin, pk, pnz, ptok, pbctx, pbelow, pprev);
     } else {
       // The three channel entries are independent: their ballots, table look-ups and stores are
       // written as straight-line code so that the dependent LDS reads of one entry overlap with
