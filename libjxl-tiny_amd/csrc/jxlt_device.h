@@ -1997,7 +1997,9 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   // Chroma entries are short on ordinary content (the X and B entries of the bench frame average
   // 0.6 tokens against 39 of Y): when both end within 32 scan positions they share ONE 64-lane pass,
   // X on lanes 0-31 and B on lanes 32-63 -- B's coefficients are then loaded 32 lanes up.
-  auto load_block = [&](uint32_t entry, int16_t* v) {
+  // (the coefficients travel as 32-bit values: 16-bit ones are packed in pairs by the compiler right behind the
+  // loads, which puts the wait for the loads there instead of one block later)
+  auto load_block = [&](uint32_t entry, int* v) {
     const int b = (int)(entry & 1023u), bxx = (int)((entry >> 10) & 31u), byy = (int)(entry >> 15);
     const uint32_t pos = (uint32_t)(by0 + byy) * bstride + (uint32_t)(bx0 + bxx);
     int ns[3];
@@ -2006,17 +2008,17 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     const bool packed = ns[1] <= 32 && ns[2] <= 32;
     v[0] = v[1] = v[2] = 0;
     if ((ns[0] | ns[1] | ns[2]) == 0) return;  // nothing to read (wave-uniform)
-    v[0] = lane < ns[0] ? A.coef_scan[(pos * 3 + 1) * 64 + lane] : (int16_t)0;
-    v[1] = lane < ns[1] ? A.coef_scan[(pos * 3 + 0) * 64 + lane] : (int16_t)0;
+    v[0] = lane < ns[0] ? (int)A.coef_scan[(pos * 3 + 1) * 64 + lane] : 0;
+    v[1] = lane < ns[1] ? (int)A.coef_scan[(pos * 3 + 0) * 64 + lane] : 0;
     const int lb = packed ? lane - 32 : lane;  // B's scan position on this lane
-    v[2] = (lb >= 0 && lb < ns[2]) ? A.coef_scan[(pos * 3 + 2) * 64 + lb] : (int16_t)0;
+    v[2] = (lb >= 0 && lb < ns[2]) ? (int)A.coef_scan[(pos * 3 + 2) * 64 + lb] : 0;
   };
   // Wave w takes the first blocks number w, w + 8, ... of the list.
-  int16_t next_v[3] = {0, 0, 0};
+  int next_v[3] = {0, 0, 0};
   uint32_t next_entry = wave < nfirst ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_first[wave]) : 0u;
   if (wave < nfirst) load_block(next_entry, next_v);
   for (int i = wave; i < nfirst; i += kWaves) {
-    const int16_t cur_v[3] = {next_v[0], next_v[1], next_v[2]};
+    const int cur_v[3] = {next_v[0], next_v[1], next_v[2]};
     const uint32_t entry = next_entry;
     const int b = (int)(entry & 1023u), cbx = (int)((entry >> 10) & 31u), cby = (int)(entry >> 15);
     if (i + kWaves < nfirst) {
@@ -2055,7 +2057,7 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     // (2) scan positions 0..63 of the entries: NP passes of 64 lanes.  Pass parameters per lane:
     // coefficient, in-range flag, scan position, nzeros / first token of its entry, block context,
     // set bits of the nonzero ballot below it, previous lane's nonzero flag.
-    auto coef_passes = [&](auto np_tag, const int16_t* pv, const bool* pin, const int* pk, const int* pnz,
+    auto coef_passes = [&](auto np_tag, const int* pv, const bool* pin, const int* pk, const int* pnz,
                            const uint32_t* ptok, const int* pbctx, const int* pbelow, const int* pprev) {
       constexpr int NP = decltype(np_tag)::value;
       int zidx[NP];
@@ -2091,7 +2093,7 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     if (packed) {
       // pass 0: Y; pass 1: X on lanes 0-31 and B on lanes 32-63
       const int half = lane >> 5, k1 = lane & 31;
-      const int16_t pv[2] = {cur_v[0], (int16_t)(cur_v[1] | cur_v[2])};  // (each is 0 on the other's lanes)
+      const int pv[2] = {cur_v[0], cur_v[1] | cur_v[2]};  // (each is 0 on the other's lanes)
       const int pk[2] = {lane, k1};
       const int pnz[2] = {nzeros[0], half ? nzeros[2] : nzeros[1]};
       const uint32_t ptok[2] = {tok0[0], half ? tok0[2] : tok0[1]};
