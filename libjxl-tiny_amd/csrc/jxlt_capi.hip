@@ -81,6 +81,7 @@ struct jxlt_context {
   // device outputs / intermediates
   DeviceBuf<int16_t> quant_dc[3];
   DeviceBuf<uint8_t> raw_quant, strategy, nzgrid[3], blk_nz, blk_nscan, tokens;
+  DeviceBuf<unsigned long long> blk_nzmask;
   DeviceBuf<int8_t> ytox, ytob;
   DeviceBuf<int16_t> coef_scan;
   DeviceBuf<uint32_t> group_ntok;
@@ -283,6 +284,7 @@ void jxlt_context_destroy(jxlt_context* ctx) {
   FreeDevice(&ctx->strategy);
   FreeDevice(&ctx->blk_nz);
   FreeDevice(&ctx->blk_nscan);
+  FreeDevice(&ctx->blk_nzmask);
   FreeDevice(&ctx->tokens);
   FreeDevice(&ctx->ytox);
   FreeDevice(&ctx->ytob);
@@ -693,6 +695,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
   ENSURE(strategy, nblocks);
   ENSURE(blk_nz, nblocks * 3);
   ENSURE(blk_nscan, nblocks * 3);
+  ENSURE(blk_nzmask, nblocks * 6);
   ENSURE(ytox, ntiles);
   ENSURE(ytob, ntiles);
   ENSURE(coef_scan, nblocks * 3 * 64);
@@ -767,6 +770,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
   A.ytob = ctx->ytob.p;
   A.blk_nz = ctx->blk_nz.p;
   A.blk_nscan = ctx->blk_nscan.p;
+  A.blk_nzmask = ctx->blk_nzmask.p;
   A.coef_scan = ctx->coef_scan.p;
   A.group_ntok = ctx->group_ntok.p;
   A.dc_nac = ctx->dc_nac.p;
@@ -784,6 +788,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
   for (int c = 0; c < 3; c++) K.nzgrid[c] = ctx->nzgrid[c].p;
   K.blk_nz = ctx->blk_nz.p;
   K.blk_nscan = ctx->blk_nscan.p;
+  K.blk_nzmask = ctx->blk_nzmask.p;
   K.coef_scan = ctx->coef_scan.p;
   K.group_ntok = ctx->group_ntok.p;
   K.group_tok_offset = ctx->group_off.p;

@@ -116,6 +116,7 @@ struct TileArgs {
   uint8_t* nzgrid[3];   // value used for context prediction, per block & channel
   uint8_t* blk_nz;      // [block*3 + c]: number of nonzeros (token value)
   uint8_t* blk_nscan;   // [block*3 + c]: scan positions up to the last nonzero
+  unsigned long long* blk_nzmask;  // [block*3 + c][2]: which of the scan positions covered .. 127 are nonzero
   int16_t* coef_scan;   // [block*3 + c][64] quantised coefficients in scan order
   uint32_t* group_ntok; // per group token count (atomic)
   uint32_t* dc_nac;     // per DC group: number of first blocks (atomic)
@@ -135,6 +136,7 @@ struct TokenArgs {
   const uint8_t* nzgrid[3];
   const uint8_t* blk_nz;
   const uint8_t* blk_nscan;
+  const unsigned long long* blk_nzmask;
   const int16_t* coef_scan;
   const uint32_t* group_ntok;         // tokens of every group (tile_kernel's counts)
   uint64_t* group_tok_offset;        // [groups + 1] OUT: exclusive scan of group_ntok -- every workgroup sums the
@@ -507,6 +509,10 @@ constexpr int kTransposePitch = 72;
     __builtin_amdgcn_wave_barrier();       \
     asm volatile("" ::: "memory");         \
   } while (0)
+#endif
+// The same for a whole wave (every lane of the wave reaches it).
+#ifndef JXLT_WAVE_SYNC
+#define JXLT_WAVE_SYNC() JXLT_OCTET_SYNC()
 #endif
 JXLT_DI void octet_transpose(float* v, float* sc, int l) {
 #if JXLT_LDS_TRANSPOSE
@@ -1722,6 +1728,12 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       }
 #pragma unroll
       for (int c = 0; c < 3; c++) {
+        // (the tokeniser takes "nonzeros still to come" and "previous coefficient nonzero" from these masks:
+        // lanes 0 and 1 store the two words)
+        if (lane < 2) A.blk_nzmask[(size_t)(pos0 * 3 + c) * 2 + lane] = lane == 0 ? m0[c] : m1[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
         // only scan positions below nscan (= up to the last nonzero) are ever read again
         int16_t* const out0 = A.coef_scan + (size_t)(pos0 * 3 + c) * 64;
         int16_t* const out1 = A.coef_scan + (size_t)(pos1 * 3 + c) * 64;
@@ -1853,16 +1865,27 @@ __global__ void __launch_bounds__(kScanThreads) group_scan_kernel(const uint32_t
 // ---------------------------------------------------------------------------
 constexpr int kTokenThreads = 512;
 
+// A lane per COEFFICIENT TOKEN of the group's stream (window w = tokens 64 w .. 64 w + 63, whatever entries
+// they belong to): a lane finds its block through the per-window index of the block that holds the window's
+// first token plus the block starts inside the window, and needs nothing from its neighbours -- "nonzeros still
+// to come" and "previous coefficient nonzero" come from the nonzero masks tile_kernel leaves per entry.  (A
+// 64-lane pass per entry, the structure until the end of round 2, filled 18 % of its lane slots on ordinary
+// content -- 39 tokens per Y entry, 0.6 per chroma entry -- and kept the CU's one scalar unit busy with
+// per-entry bookkeeping.)  The nzeros tokens (one per entry) are written by a thread-per-block pass.
 __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A) {
-  __shared__ uint32_t offs[1024 + 1];   // token offset of every block's first entry (exclusive scan)
-  __shared__ uint32_t meta[3072];       // strategy byte | nzeros << 8 | nscan << 16
+  __shared__ uint32_t meta[3072];        // per entry (block * 3 + channel y, x, b): strategy byte | nzeros << 8 | nscan << 16
+  // per block: coefficient tokens in front of it (bits 0-19) | first blocks in front of it (bits 20-30)
+  __shared__ uint32_t bstart[1024 + 1];
+  __shared__ uint16_t first_blk[3072 + 8];  // per window: the block that holds its first coefficient token
+  __shared__ uint16_t boundary[kTokenThreads / 64][64];  // per wave: the block that starts at a position of its window
   __shared__ uint32_t wsum[kTokenThreads / 64];
   __shared__ uint32_t hist[64 * 64];
   __shared__ uint16_t s_nnz_ctx[64], s_freq_ctx[64];
   __shared__ uint8_t s_ctx_map[1980];
   __shared__ uint8_t s_nzg[3 * 1024];   // nzeros grid of the group (PredictFromTopAndLeft input)
+  __shared__ uint64_t s_group_base;
+  __shared__ uint64_t gsum[kTokenThreads / 64];
   const int tid = (int)threadIdx.x;
-  // (wave index pinned to a scalar register: the per-entry bookkeeping below is wave-uniform)
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const DeviceTables* T = A.tab;
   const int group = A.group_first + (int)blockIdx.x;
@@ -1876,10 +1899,6 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   }
   // Where the group's tokens start: the sum of the counts of all groups before it (<= 16 384 counts, 64 KB,
   // one round of loads; a scan kernel in front of this one cost 22 us of the step for the same numbers).
-  __shared__ uint32_t s_first[1024];  // the group's first blocks (any order): block | column << 10 | row << 15
-  __shared__ uint32_t s_nfirst;
-  __shared__ uint64_t s_group_base;
-  __shared__ uint64_t gsum[kTokenThreads / 64];
   {
     uint64_t part = 0;
     for (int i = tid; i < group; i += kTokenThreads) part += A.group_ntok[i];
@@ -1892,34 +1911,31 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   // 32-bit block / record indices (the C ABI limits a frame to 2^24 blocks, a group's tokens to
   // 196 608 records): addresses are scalar base + 32-bit lane offset, no 64-bit vector arithmetic
   const uint32_t bstride = (uint32_t)A.g.xsize_blocks;
+  const uint32_t nbx_magic = 65536u / (uint32_t)nbx + 1u;  // b / nbx == (b * magic) >> 16 for b < 1024, nbx <= 32
 
-  // token count + metadata per entry; predicted-nzeros grid of the group -> LDS
+  // metadata per entry, coefficient-token and first-block counts per block, predicted-nzeros grid -> LDS
   const int nblk = nbx * nby;
   for (int b = tid; b < nblk; b += kTokenThreads) {
     const int bx = b % nbx, by = b / nbx;
     const uint32_t pos = (uint32_t)(by0 + by) * bstride + (uint32_t)(bx0 + bx);
     const uint32_t a = A.strategy[pos];
     const int covered = (a >> 1) == 0 ? 1 : 2;
-    uint32_t nsum = 0;
+    uint32_t ncoef = 0;
 #pragma unroll
     for (int ci = 0; ci < 3; ci++) {
       const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
-      uint32_t n = 0, m = a;
+      uint32_t m = a;
       if (a & 1) {
         const uint32_t nscan = A.blk_nscan[pos * 3 + c];
-        n = 1 + (nscan > (uint32_t)covered ? nscan - covered : 0);
+        ncoef += nscan > (uint32_t)covered ? nscan - covered : 0;
         m = a | ((uint32_t)A.blk_nz[pos * 3 + c] << 8) | (nscan << 16);
       }
-      nsum += n;
       meta[b * 3 + ci] = m;
       s_nzg[c * 1024 + b] = A.nzgrid[c][pos];
     }
-    offs[b + 1] = nsum;
+    bstart[b + 1] = ncoef | ((a & 1) << 20);
   }
-  if (tid == 0) {
-    offs[0] = 0;
-    s_nfirst = 0;
-  }
+  if (tid == 0) bstart[0] = 0;
   __syncthreads();
   if (tid == 0) {
     uint64_t base = 0;
@@ -1929,13 +1945,14 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     const int ngroups = A.g.xsize_groups * A.g.ysize_groups;
     if (group + 1 == ngroups) A.group_tok_offset[ngroups] = base + A.group_ntok[group];
   }
-  // inclusive scan over offs[1..nblk] (blocked: each thread owns a contiguous run)
+  // inclusive scan over bstart[1..nblk] (blocked: each thread owns a contiguous run; both fields at once: the
+  // sums stay inside their bit ranges, <= 387 072 coefficient tokens and <= 1024 first blocks)
   {
     const int per = (nblk + kTokenThreads - 1) / kTokenThreads;
     const int beg = 1 + tid * per, end = imin(1 + nblk, beg + per);
-    uint32_t s = 0;
-    for (int i = beg; i < end; i++) s += offs[i];
-    uint32_t incl = s;
+    uint32_t sum = 0;
+    for (int i = beg; i < end; i++) sum += bstart[i];
+    uint32_t incl = sum;
     for (int d = 1; d < 64; d <<= 1) {
       const uint32_t o = __shfl_up(incl, d);
       if (lane >= d) incl += o;
@@ -1944,26 +1961,30 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     __syncthreads();
     uint32_t wbase = 0;
     for (int w = 0; w < wave; w++) wbase += wsum[w];
-    uint32_t run = wbase + incl - s;
+    uint32_t run = wbase + incl - sum;
     for (int i = beg; i < end; i++) {
-      run += offs[i];
-      offs[i] = run;
+      run += bstart[i];
+      bstart[i] = run;
     }
   }
   __syncthreads();
-
+  // bstart[b] is now what lies in front of block b (bstart[nblk]: the totals)
+  const uint32_t kLow = (1u << 20) - 1u;
+  const uint32_t ncoef_total = bstart[nblk] & kLow;
+  const int nwin = (int)((ncoef_total + 63u) >> 6);
   uint8_t* out = A.tokens + 3 * s_group_base;  // (written before the two barriers of the scan above)
-  // The nzeros token of every entry (the first token of a block's Y, X and B run), a thread per block: in the
-  // block loop below they were three lanes' work per wave pass.
+  // per block: its windows' index entries and the nzeros tokens of its three entries
   for (int b = tid; b < nblk; b += kTokenThreads) {
+    const uint32_t here = bstart[b], next = bstart[b + 1];
+    const uint32_t s0 = here & kLow, s1 = next & kLow;
+    for (uint32_t q = (s0 + 63u) >> 6; (q << 6) < s1; q++) first_blk[q] = (uint16_t)b;  // (windows that start in b)
     const uint32_t mb[3] = {meta[b * 3], meta[b * 3 + 1], meta[b * 3 + 2]};
     if (!(mb[0] & 1)) continue;  // not the first block of a transform: no entries
     const int st = (int)((mb[0] >> 1) & 0x7F);
     const int covered = st == 0 ? 1 : 2;
     const int bctx_y = st == 0 ? 0 : 1, bctx_c = 2 + bctx_y;  // (ac_context.h:64-114, see below)
-    const int cbx = b % nbx, cby = b / nbx;
-    s_first[atomicAdd(&s_nfirst, 1u)] = (uint32_t)b | ((uint32_t)cbx << 10) | ((uint32_t)cby << 15);
-    uint32_t tl = offs[b];
+    const int cby = (int)(((uint32_t)b * nbx_magic) >> 16), cbx = b - cby * nbx;
+    uint32_t tl = s0 + 3u * (here >> 20);  // tokens in front of the block: coefficient tokens + three per first block
 #pragma unroll
     for (int ci = 0; ci < 3; ci++) {
       const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
@@ -1987,185 +2008,82 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
       tl += 1 + (nsc > covered ? nsc - covered : 0);
     }
   }
+  __syncthreads();  // the window index is complete
+
+  // ---- the coefficient tokens: wave w takes windows w, w + 8, ... ---------------------------------------------
   constexpr int kWaves = kTokenThreads / 64;
-  // Wave w takes blocks w, w + 8, ... of the group (stream order) and their three channel
-  // entries; lane = scan position.  The coefficients of the wave's next block are requested
-  // before the current one is processed (HBM latency overlap).
-  // (only scan positions below nscan were written by tile_kernel)
-  __syncthreads();  // the list of first blocks is complete
-  const int nfirst = (int)s_nfirst;
-  // Chroma entries are short on ordinary content (the X and B entries of the bench frame average
-  // 0.6 tokens against 39 of Y): when both end within 32 scan positions they share ONE 64-lane pass,
-  // X on lanes 0-31 and B on lanes 32-63 -- B's coefficients are then loaded 32 lanes up.
-  // (the coefficients travel as 32-bit values: 16-bit ones are packed in pairs by the compiler right behind the
-  // loads, which puts the wait for the loads there instead of one block later)
-  auto load_block = [&](uint32_t entry, int* v) {
-    const int b = (int)(entry & 1023u), bxx = (int)((entry >> 10) & 31u), byy = (int)(entry >> 15);
-    const uint32_t pos = (uint32_t)(by0 + byy) * bstride + (uint32_t)(bx0 + bxx);
-    int ns[3];
-#pragma unroll
-    for (int ci = 0; ci < 3; ci++) ns[ci] = (int)(__builtin_amdgcn_readfirstlane((int)meta[b * 3 + ci]) >> 16);
-    const bool packed = ns[1] <= 32 && ns[2] <= 32;
-    v[0] = v[1] = v[2] = 0;
-    if ((ns[0] | ns[1] | ns[2]) == 0) return;  // nothing to read (wave-uniform)
-    v[0] = lane < ns[0] ? (int)A.coef_scan[(pos * 3 + 1) * 64 + lane] : 0;
-    v[1] = lane < ns[1] ? (int)A.coef_scan[(pos * 3 + 0) * 64 + lane] : 0;
-    const int lb = packed ? lane - 32 : lane;  // B's scan position on this lane
-    v[2] = (lb >= 0 && lb < ns[2]) ? (int)A.coef_scan[(pos * 3 + 2) * 64 + lb] : 0;
-  };
-  // Wave w takes the first blocks number w, w + 8, ... of the list.
-  int next_v[3] = {0, 0, 0};
-  uint32_t next_entry = wave < nfirst ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_first[wave]) : 0u;
-  if (wave < nfirst) load_block(next_entry, next_v);
-  for (int i = wave; i < nfirst; i += kWaves) {
-    const int cur_v[3] = {next_v[0], next_v[1], next_v[2]};
-    const uint32_t entry = next_entry;
-    const int b = (int)(entry & 1023u), cbx = (int)((entry >> 10) & 31u), cby = (int)(entry >> 15);
-    if (i + kWaves < nfirst) {
-      next_entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_first[i + kWaves]);
-      load_block(next_entry, next_v);
+  uint16_t* const bnd = &boundary[wave][0];
+  for (int q = wave; q < nwin; q += kWaves) {
+    const uint32_t w0 = (uint32_t)q << 6;  // the window's first token
+    const uint32_t i = w0 + (uint32_t)lane;
+    const int b0 = (int)first_blk[q];      // (wave-uniform)
+    // the blocks that start inside the window, filed under the position of their first token
+    bnd[lane] = 0;
+    JXLT_WAVE_SYNC();
+    for (int base = b0 + 1; base < nblk; base += 64) {
+      const int bb = base + lane;
+      if (bb < nblk) {
+        const uint32_t s0 = bstart[bb] & kLow, s1 = bstart[bb + 1] & kLow;
+        if (s1 > s0 && s0 > w0 && s0 < w0 + 64u) bnd[s0 - w0] = (uint16_t)bb;
+      }
+      const int last = imin(base + 63, nblk - 1);  // (beyond the window from here on?)
+      if ((bstart[last + 1] & kLow) >= w0 + 64u) break;
     }
-    const uint32_t pos = (uint32_t)(by0 + cby) * bstride + (uint32_t)(bx0 + cbx);
-    // The three channel entries of a block are independent: their ballots, table look-ups and
-    // stores are written as straight-line code (no branches in between) so that the dependent
-    // LDS reads of one entry overlap with the other two (the kernel is latency bound).
-    const uint32_t m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta[b * 3]);
-    if (!(m0 & 1)) continue;  // not the first block of a transform: no entries
-    const uint32_t ms[3] = {m0, (uint32_t)__builtin_amdgcn_readfirstlane((int)meta[b * 3 + 1]),
-                            (uint32_t)__builtin_amdgcn_readfirstlane((int)meta[b * 3 + 2])};
-    const int st = (int)((m0 >> 1) & 0x7F);
+    JXLT_WAVE_SYNC();  // (the wave's LDS operations execute in order)
+    const unsigned long long bm = __ballot(bnd[lane] != 0);
+    // the lane's block: the one filed at the highest position <= lane, else the window's first block
+    int blk;
+    {
+      const uint32_t lo = (uint32_t)bm, hi = (uint32_t)(bm >> 32);
+      const uint32_t below_lo = lane < 32 ? lo & ((2u << lane) - 1u) : lo;
+      const uint32_t below_hi = lane < 32 ? 0u : hi & ((2u << (lane - 32)) - 1u);
+      const int at = below_hi ? 63 - __clz((int)below_hi) : below_lo ? 31 - __clz((int)below_lo) : -1;
+      blk = at >= 0 ? (int)bnd[at] : b0;
+    }
+    JXLT_WAVE_SYNC();  // (read before the next window's entries are filed)
+    if (i >= ncoef_total) continue;  // (only in the stream's last window; no wave-wide operation behind this point)
+    const uint32_t here = bstart[blk];
+    const uint32_t in_block = i - (here & kLow);  // coefficient token of the block
+    const uint32_t m_y = meta[blk * 3], m_x = meta[blk * 3 + 1], m_b = meta[blk * 3 + 2];
+    const int st = (int)((m_y >> 1) & 0x7F);
     const int covered = st == 0 ? 1 : 2;
     const int log2c = covered == 1 ? 0 : 1;
     const int size = covered * 64;
+    const uint32_t n_y = imax((int)(m_y >> 16) - covered, 0), n_x = imax((int)(m_x >> 16) - covered, 0);
+    const int ci = (in_block >= n_y ? 1 : 0) + (in_block >= n_y + n_x ? 1 : 0);  // y, x, b in stream order
+    const uint32_t m_e = ci == 0 ? m_y : ci == 1 ? m_x : m_b;
+    const int k = covered + (int)(in_block - (ci == 0 ? 0u : ci == 1 ? n_y : n_y + n_x));  // scan position
+    const int nzeros = (int)((m_e >> 8) & 0xFF);
+    const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
+    const int cby = (int)(((uint32_t)blk * nbx_magic) >> 16), cbx = blk - cby * nbx;
+    const uint32_t pos = (uint32_t)(by0 + cby) * bstride + (uint32_t)(bx0 + cbx);
     const uint32_t pos1 = pos + (st == 1 ? bstride : 1u);
-    int nzeros[3], nscan[3];
-    uint32_t tok0[3];
-    {
-      uint32_t tok = (uint32_t)__builtin_amdgcn_readfirstlane((int)offs[b]);  // first token of the block
-#pragma unroll
-      for (int ci = 0; ci < 3; ci++) {
-        nzeros[ci] = (int)((ms[ci] >> 8) & 0xFF);
-        nscan[ci] = (int)(ms[ci] >> 16);
-        tok0[ci] = tok;
-        tok += 1 + (nscan[ci] > covered ? nscan[ci] - covered : 0);
-      }
-    }
+    const int16_t v = k < 64 ? A.coef_scan[(pos * 3 + (uint32_t)c) * 64 + (uint32_t)k]
+                             : A.coef_scan[(pos1 * 3 + (uint32_t)c) * 64 + (uint32_t)(k - 64)];
+    const unsigned long long nz0 = A.blk_nzmask[(size_t)(pos * 3 + (uint32_t)c) * 2];
+    const unsigned long long nz1 = A.blk_nzmask[(size_t)(pos * 3 + (uint32_t)c) * 2 + 1];
+    // nonzeros at the scan positions in front of k (the masks hold positions covered .. 127), previous one
+    const int below = k <= 64 ? __popcll(k == 64 ? nz0 : nz0 & ((1ull << k) - 1ull))
+                              : __popcll(nz0) + __popcll(nz1 & ((1ull << (k - 64)) - 1ull));
+    const int prev = k <= 64 ? (int)((nz0 >> (k - 1)) & 1ull) : (int)((nz1 >> (k - 65)) & 1ull);
+    const int left = nzeros - below;  // nzeros still to come at this position
+    const int nl = (left + covered - 1) >> log2c;
+    const int zidx = s_nnz_ctx[nl] + s_freq_ctx[k >> log2c];
+    const int pp = k == covered ? ((nzeros > size / 16) ? 0 : 1) : prev;
     // block context (ac_context.h:64-114): kBlockContextMap[c*27 + code] is 0/1 for Y and
     // 2/3 for X,B, the odd value for the two-block strategy codes 6 and 7
-    const int bctx_y = st == 0 ? 0 : 1, bctx_c = 2 + bctx_y;
-    // (1) the nzeros tokens of the entries were written by the thread-per-block pass in front of this loop
-    // (2) scan positions 0..63 of the entries: NP passes of 64 lanes.  Pass parameters per lane:
-    // coefficient, in-range flag, scan position, nzeros / first token of its entry, block context,
-    // set bits of the nonzero ballot below it, previous lane's nonzero flag.
-    auto coef_passes = [&](auto np_tag, const int* pv, const bool* pin, const int* pk, const int* pnz,
-                           const uint32_t* ptok, const int* pbctx, const int* pbelow, const int* pprev) {
-      constexpr int NP = decltype(np_tag)::value;
-      int zidx[NP];
-      uint8_t cms[NP];
-#pragma unroll
-      for (int p = 0; p < NP; p++) {
-        const int left = pnz[p] - pbelow[p];  // nzeros still to come at this position
-        const int nl = pin[p] ? (left + covered - 1) >> log2c : 0;
-        zidx[p] = s_nnz_ctx[nl] + s_freq_ctx[pk[p] >> log2c];
-      }
-#pragma unroll
-      for (int p = 0; p < NP; p++) {
-        const int pp = pk[p] == covered ? ((pnz[p] > size / 16) ? 0 : 1) : pprev[p];
-        const int ctx = 4 * 37 + 458 * pbctx[p] + zidx[p] * 2 + pp;
-        cms[p] = s_ctx_map[pin[p] ? ctx : 0];
-      }
-#pragma unroll
-      for (int p = 0; p < NP; p++) {
-        if (pin[p]) {
-          const uint32_t val = pack_signed((int32_t)pv[p]);
-          uint8_t* o = out + 3u * (ptok[p] + 1u + (uint32_t)(pk[p] - covered));
-          o[0] = cms[p];
-          o[1] = (uint8_t)(val & 0xFF);
-          o[2] = (uint8_t)((val >> 8) & 0xFF);
-          if (do_hist) {
-            atomicAdd(&hist[cms[p] * 64 + hybrid_uint_symbol(val & 0xFFFFu)], 1u);
-          }
-        }
-      }
-    };
-    unsigned long long mk[3] = {0, 0, 0};
-    const bool packed = nscan[1] <= 32 && nscan[2] <= 32;  // (the same test load_block made)
-    if (packed) {
-      // pass 0: Y; pass 1: X on lanes 0-31 and B on lanes 32-63
-      const int half = lane >> 5, k1 = lane & 31;
-      const int pv[2] = {cur_v[0], cur_v[1] | cur_v[2]};  // (each is 0 on the other's lanes)
-      const int pk[2] = {lane, k1};
-      const int pnz[2] = {nzeros[0], half ? nzeros[2] : nzeros[1]};
-      const uint32_t ptok[2] = {tok0[0], half ? tok0[2] : tok0[1]};
-      const int pbctx[2] = {bctx_y, bctx_c};
-      const bool pin[2] = {lane >= covered && lane < nscan[0], k1 >= covered && k1 < (half ? nscan[2] : nscan[1])};
-      int pbelow[2], pprev[2];
-      const bool nz0 = pin[0] && pv[0] != 0, nz1 = pin[1] && pv[1] != 0;
-      mk[0] = __ballot(nz0);
-      const unsigned long long m1 = __ballot(nz1);
-      pprev[0] = __builtin_amdgcn_update_dpp(0, nz0 ? 1 : 0, 0x138, 0xF, 0xF, false);
-      pprev[1] = __builtin_amdgcn_update_dpp(0, nz1 ? 1 : 0, 0x138, 0xF, 0xF, false);
-      pbelow[0] = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk[0] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[0], 0u));
-      // set bits below the lane within its own half of the ballot
-      const int below_lo = (int)__builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u);
-      const int below_hi = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), 0u);
-      pbelow[1] = half ? below_hi : below_lo;
-      if (nscan[1] <= covered && nscan[2] <= covered)  // (no chroma coefficient tokens: Y's pass alone)
-        coef_passes(std::integral_constant<int, 1>(), pv, pin, pk, pnz, ptok, pbctx, pbelow, pprev);
-      else
-        coef_passes(std::integral_constant<int, 2>(), pv, pin, pk, pnz, ptok, pbctx, pbelow, pprev);
-    } else {
-      // The three channel entries are independent: their ballots, table look-ups and stores are
-      // written as straight-line code so that the dependent LDS reads of one entry overlap with
-      // the other two.
-      const int pk[3] = {lane, lane, lane};
-      const int pbctx[3] = {bctx_y, bctx_c, bctx_c};
-      bool pin[3];
-      int pbelow[3], pprev[3];
-#pragma unroll
-      for (int ci = 0; ci < 3; ci++) {
-        pin[ci] = lane >= covered && lane < nscan[ci];
-        const bool nz = pin[ci] && cur_v[ci] != 0;
-        mk[ci] = __ballot(nz);
-        pprev[ci] = __builtin_amdgcn_update_dpp(0, nz ? 1 : 0, 0x138, 0xF, 0xF, false);  // wave_shr:1
-      }
-#pragma unroll
-      for (int ci = 0; ci < 3; ci++)
-        pbelow[ci] = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk[ci] >> 32),
-                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mk[ci], 0u));
-      coef_passes(std::integral_constant<int, 3>(), cur_v, pin, pk, nzeros, tok0, pbctx, pbelow, pprev);
-    }
-    // (3) two-block transforms whose tokens reach beyond scan position 63 (uncommon)
-    if (nscan[0] > 64 || nscan[1] > 64 || nscan[2] > 64) {
-#pragma unroll
-      for (int ci = 0; ci < 3; ci++) {
-        if (nscan[ci] <= 64) continue;
-        const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
-        const int k = 64 + lane;
-        const int16_t v = k < nscan[ci] ? A.coef_scan[(pos1 * 3 + c) * 64 + lane] : (int16_t)0;
-        const bool in_range = k < nscan[ci];
-        const bool nz = in_range && v != 0;
-        const unsigned long long mk2 = __ballot(nz);
-        const int prev_nz = __builtin_amdgcn_update_dpp(0, nz ? 1 : 0, 0x138, 0xF, 0xF, false);
-        if (in_range) {
-          const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk2 >> 32),
-                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)mk2, 0u));
-          const int left = nzeros[ci] - (__popcll(mk[ci]) + below);
-          const int p = lane == 0 ? (int)((mk[ci] >> 63) & 1ull) : prev_nz;
-          const int nl = (left + covered - 1) >> log2c;
-          const int zctx = (s_nnz_ctx[nl] + s_freq_ctx[k >> log2c]) * 2 + p;
-          const int ctx = 4 * 37 + 458 * (ci == 0 ? bctx_y : bctx_c) + zctx;
-          const uint32_t val = pack_signed((int32_t)v);
-          const uint8_t cm = s_ctx_map[ctx];
-          uint8_t* o = out + 3u * (tok0[ci] + 1u + (uint32_t)(k - covered));
-          o[0] = cm;
-          o[1] = (uint8_t)(val & 0xFF);
-          o[2] = (uint8_t)((val >> 8) & 0xFF);
-          if (do_hist) {
-            atomicAdd(&hist[cm * 64 + hybrid_uint_symbol(val & 0xFFFFu)], 1u);
-          }
-        }
-      }
+    const int bctx = (st == 0 ? 0 : 1) + (ci == 0 ? 0 : 2);
+    const int ctx = 4 * 37 + 458 * bctx + zidx * 2 + pp;
+    const uint8_t cm = s_ctx_map[ctx];
+    const uint32_t val = pack_signed((int32_t)v);
+    // tokens in front of the block (coefficient tokens + three per first block), the nzeros tokens of this
+    // and the earlier entries of the block, the coefficient tokens of the block in front of this one
+    uint8_t* o = out + 3u * ((here & kLow) + 3u * (here >> 20) + (uint32_t)(ci + 1) + in_block);
+    o[0] = cm;
+    o[1] = (uint8_t)(val & 0xFF);
+    o[2] = (uint8_t)((val >> 8) & 0xFF);
+    if (do_hist) {
+      atomicAdd(&hist[cm * 64 + hybrid_uint_symbol(val & 0xFFFFu)], 1u);
     }
   }
   if (do_hist) {

@@ -95,6 +95,7 @@ inline TileArgs SlabTileArgs(const TileArgs& A, size_t y0, size_t rows, ptrdiff_
   S.strategy = A.strategy + b0;
   S.blk_nz = A.blk_nz + 3 * b0;
   S.blk_nscan = A.blk_nscan + 3 * b0;
+  S.blk_nzmask = A.blk_nzmask + 6 * b0;
   S.coef_scan = A.coef_scan + 3 * 64 * b0;
   S.ytox = A.ytox + (y0 / 64) * (size_t)A.g.xsize_tiles;
   S.ytob = A.ytob + (y0 / 64) * (size_t)A.g.xsize_tiles;

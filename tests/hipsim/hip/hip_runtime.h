@@ -448,4 +448,7 @@ inline T atomicAdd(T* p, T v) {
     (void)__shfl_xor(0, 4);   \
   } while (0)
 
+// A whole wave: every unfinished lane of the wave has to arrive (a ballot is such a rendezvous).
+#define JXLT_WAVE_SYNC() ((void)__ballot(0))
+
 #endif  // HIPSIM_HIP_RUNTIME_H_

@@ -86,6 +86,7 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   A.ytob = r->ytob = (int8_t*)calloc(ntiles, 1);
   A.blk_nz = (uint8_t*)calloc(nblocks * 3, 1);
   A.blk_nscan = (uint8_t*)calloc(nblocks * 3, 1);
+  A.blk_nzmask = (unsigned long long*)calloc(nblocks * 6, 8);
   A.coef_scan = (int16_t*)malloc(nblocks * 3 * 64 * 2);
   memset(A.coef_scan, 0xBB, nblocks * 3 * 64 * 2);  // unwritten positions must never be consumed
   A.group_ntok = (uint32_t*)calloc(ngroups, 4);
@@ -120,7 +121,7 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
     if (lut_overflow) {
       sim_free(r);
       for (int c = 0; c < 3; c++) free(A.nzgrid[c]);
-      free(A.blk_nz); free(A.blk_nscan); free(A.coef_scan); free(A.group_ntok); free(A.dc_nac);
+      free(A.blk_nz); free(A.blk_nscan); free(A.blk_nzmask); free(A.coef_scan); free(A.group_ntok); free(A.dc_nac);
       delete tab;
       const int rc = sim_encode(planes, pitch_floats, xsize, ysize, distance, scale, inv_scale, scale_dc, x_qm_scale,
                                 flags | 0x400u, r);
@@ -143,6 +144,7 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   for (int c = 0; c < 3; c++) K.nzgrid[c] = A.nzgrid[c];
   K.blk_nz = A.blk_nz;
   K.blk_nscan = A.blk_nscan;
+  K.blk_nzmask = A.blk_nzmask;
   K.coef_scan = A.coef_scan;
   K.group_ntok = A.group_ntok;
   K.group_tok_offset = r->group_tok_offset;
@@ -190,6 +192,7 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   for (int c = 0; c < 3; c++) free(A.nzgrid[c]);
   free(A.blk_nz);
   free(A.blk_nscan);
+  free(A.blk_nzmask);
   free(A.coef_scan);
   free(A.group_ntok);
   delete tab;
