@@ -1890,6 +1890,13 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   const DeviceTables* T = A.tab;
   const int group = A.group_first + (int)blockIdx.x;
   const bool do_hist = A.histogram != nullptr;
+  // LDS histogram slot of (pre-clustered context, symbol): the symbol is rotated by the context, so that the
+  // small symbols nearly all tokens have do not land in the same few banks for every context
+#ifdef JXLT_HIST_PLAIN
+  auto hist_slot = [](uint32_t cm, uint32_t sym) { return cm * 64u + sym; };
+#else
+  auto hist_slot = [](uint32_t cm, uint32_t sym) { return cm * 64u + ((sym + cm) & 63u); };
+#endif
   if (do_hist)
     for (int i = tid; i < 64 * 64; i += kTokenThreads) hist[i] = 0;
   for (int i = tid; i < 1980; i += kTokenThreads) s_ctx_map[i] = T->ac_context_map[i];
@@ -2003,7 +2010,7 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
       o[1] = (uint8_t)(nzl & 0xFF);
       o[2] = (uint8_t)(nzl >> 8);
       if (do_hist) {
-        atomicAdd(&hist[cm * 64 + hybrid_uint_symbol((uint32_t)nzl)], 1u);
+        atomicAdd(&hist[hist_slot(cm, hybrid_uint_symbol((uint32_t)nzl))], 1u);
       }
       tl += 1 + (nsc > covered ? nsc - covered : 0);
     }
@@ -2013,6 +2020,9 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   // ---- the coefficient tokens: wave w takes windows w, w + 8, ... ---------------------------------------------
   constexpr int kWaves = kTokenThreads / 64;
   uint16_t* const bnd = &boundary[wave][0];
+#ifdef JXLT_EXP_NO_MAIN
+  if (nwin > 100000)
+#endif
   for (int q = wave; q < nwin; q += kWaves) {
     const uint32_t w0 = (uint32_t)q << 6;  // the window's first token
     const uint32_t i = w0 + (uint32_t)lane;
@@ -2083,13 +2093,16 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     o[1] = (uint8_t)(val & 0xFF);
     o[2] = (uint8_t)((val >> 8) & 0xFF);
     if (do_hist) {
-      atomicAdd(&hist[cm * 64 + hybrid_uint_symbol(val & 0xFFFFu)], 1u);
+      const uint32_t slot = hist_slot(cm, hybrid_uint_symbol(val & 0xFFFFu));
+      atomicAdd(&hist[slot], 1u);
     }
   }
   if (do_hist) {
     __syncthreads();
-    for (int i = tid; i < 64 * 64; i += kTokenThreads)
-      if (hist[i]) atomicAdd(&A.histogram[i], hist[i]);
+    for (int i = tid; i < 64 * 64; i += kTokenThreads) {
+      const uint32_t n = hist[hist_slot((uint32_t)i >> 6, (uint32_t)i & 63u)];
+      if (n) atomicAdd(&A.histogram[i], n);
+    }
   }
 }
 
