@@ -2018,14 +2018,26 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   __syncthreads();  // the window index is complete
 
   // ---- the coefficient tokens: wave w takes windows w, w + 8, ... ---------------------------------------------
+  // Three stages per window: "locate" finds the lane's block, entry and scan position (LDS only), "request" asks
+  // for its coefficient and its entry's nonzero masks, "emit" (when the values have arrived) derives the context
+  // and stores the record.  The lanes behind the stream's end (last window only) repeat
+  // the last token, so that every emit issues the same three stores -- the wait for the next window's loads
+  // can then be a count (loads and stores share one counter) instead of "everything".
   constexpr int kWaves = kTokenThreads / 64;
   uint16_t* const bnd = &boundary[wave][0];
-#ifdef JXLT_EXP_NO_MAIN
-  if (nwin > 100000)
-#endif
-  for (int q = wave; q < nwin; q += kWaves) {
+  struct Located {
+    uint32_t out_index;  // the token's place in the group's stream
+    int k;               // scan position
+    int nzeros;          // of its entry
+    int st_ci;           // strategy code | channel in stream order << 8 | counts (a real token) << 16
+    uint32_t coef_at, mask_at;  // where its coefficient / its entry's nonzero masks are (element / word index)
+    int coef;            // requested
+    uint32_t nz[4];      // requested: the entry's nonzero masks, positions covered .. 127
+  };
+  auto locate = [&](int q, Located& t) {
     const uint32_t w0 = (uint32_t)q << 6;  // the window's first token
-    const uint32_t i = w0 + (uint32_t)lane;
+    const bool real = w0 + (uint32_t)lane < ncoef_total;
+    const uint32_t i = real ? w0 + (uint32_t)lane : ncoef_total - 1u;
     const int b0 = (int)first_blk[q];      // (wave-uniform)
     // the blocks that start inside the window, filed under the position of their first token
     bnd[lane] = 0;
@@ -2041,61 +2053,95 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     }
     JXLT_WAVE_SYNC();  // (the wave's LDS operations execute in order)
     const unsigned long long bm = __ballot(bnd[lane] != 0);
-    // the lane's block: the one filed at the highest position <= lane, else the window's first block
+    // the lane's block: the one filed at the highest position <= its token's, else the window's first block
     int blk;
     {
+      const int at_most = (int)(i - w0);
       const uint32_t lo = (uint32_t)bm, hi = (uint32_t)(bm >> 32);
-      const uint32_t below_lo = lane < 32 ? lo & ((2u << lane) - 1u) : lo;
-      const uint32_t below_hi = lane < 32 ? 0u : hi & ((2u << (lane - 32)) - 1u);
+      const uint32_t below_lo = at_most < 32 ? lo & ((2u << at_most) - 1u) : lo;
+      const uint32_t below_hi = at_most < 32 ? 0u : hi & ((2u << (at_most - 32)) - 1u);
       const int at = below_hi ? 63 - __clz((int)below_hi) : below_lo ? 31 - __clz((int)below_lo) : -1;
       blk = at >= 0 ? (int)bnd[at] : b0;
     }
     JXLT_WAVE_SYNC();  // (read before the next window's entries are filed)
-    if (i >= ncoef_total) continue;  // (only in the stream's last window; no wave-wide operation behind this point)
     const uint32_t here = bstart[blk];
     const uint32_t in_block = i - (here & kLow);  // coefficient token of the block
     const uint32_t m_y = meta[blk * 3], m_x = meta[blk * 3 + 1], m_b = meta[blk * 3 + 2];
     const int st = (int)((m_y >> 1) & 0x7F);
     const int covered = st == 0 ? 1 : 2;
-    const int log2c = covered == 1 ? 0 : 1;
-    const int size = covered * 64;
     const uint32_t n_y = imax((int)(m_y >> 16) - covered, 0), n_x = imax((int)(m_x >> 16) - covered, 0);
     const int ci = (in_block >= n_y ? 1 : 0) + (in_block >= n_y + n_x ? 1 : 0);  // y, x, b in stream order
     const uint32_t m_e = ci == 0 ? m_y : ci == 1 ? m_x : m_b;
-    const int k = covered + (int)(in_block - (ci == 0 ? 0u : ci == 1 ? n_y : n_y + n_x));  // scan position
-    const int nzeros = (int)((m_e >> 8) & 0xFF);
+    t.k = covered + (int)(in_block - (ci == 0 ? 0u : ci == 1 ? n_y : n_y + n_x));
+    t.nzeros = (int)((m_e >> 8) & 0xFF);
+    t.st_ci = st | (ci << 8) | ((real ? 1 : 0) << 16);
+    // tokens in front of the block (coefficient tokens + three per first block), the nzeros tokens of this
+    // and the earlier entries of the block, the coefficient tokens of the block in front of this one
+    t.out_index = (here & kLow) + 3u * (here >> 20) + (uint32_t)(ci + 1) + in_block;
     const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
     const int cby = (int)(((uint32_t)blk * nbx_magic) >> 16), cbx = blk - cby * nbx;
     const uint32_t pos = (uint32_t)(by0 + cby) * bstride + (uint32_t)(bx0 + cbx);
     const uint32_t pos1 = pos + (st == 1 ? bstride : 1u);
-    const int16_t v = k < 64 ? A.coef_scan[(pos * 3 + (uint32_t)c) * 64 + (uint32_t)k]
-                             : A.coef_scan[(pos1 * 3 + (uint32_t)c) * 64 + (uint32_t)(k - 64)];
-    const unsigned long long nz0 = A.blk_nzmask[(size_t)(pos * 3 + (uint32_t)c) * 2];
-    const unsigned long long nz1 = A.blk_nzmask[(size_t)(pos * 3 + (uint32_t)c) * 2 + 1];
+    t.coef_at = t.k < 64 ? (pos * 3 + (uint32_t)c) * 64 + (uint32_t)t.k : (pos1 * 3 + (uint32_t)c) * 64 + (uint32_t)(t.k - 64);
+    t.mask_at = (pos * 3 + (uint32_t)c) * 4;
+  };
+  auto request = [&](Located& t) {
+    t.coef = (int)A.coef_scan[t.coef_at];
+    const uint32_t* nzw = reinterpret_cast<const uint32_t*>(A.blk_nzmask) + t.mask_at;
+#pragma unroll
+    for (int j = 0; j < 4; j++) t.nz[j] = nzw[j];
+  };
+  auto emit = [&](const Located& t) {
+    const int st = t.st_ci & 0xFF, ci = (t.st_ci >> 8) & 0xFF;
+    const bool real = (t.st_ci >> 16) != 0;
+    const int covered = st == 0 ? 1 : 2;
+    const int log2c = covered == 1 ? 0 : 1;
+    const int size = covered * 64;
+    const int k = t.k;
+    const unsigned long long nz0 = (unsigned long long)t.nz[0] | ((unsigned long long)t.nz[1] << 32);
+    const unsigned long long nz1 = (unsigned long long)t.nz[2] | ((unsigned long long)t.nz[3] << 32);
     // nonzeros at the scan positions in front of k (the masks hold positions covered .. 127), previous one
     const int below = k <= 64 ? __popcll(k == 64 ? nz0 : nz0 & ((1ull << k) - 1ull))
                               : __popcll(nz0) + __popcll(nz1 & ((1ull << (k - 64)) - 1ull));
     const int prev = k <= 64 ? (int)((nz0 >> (k - 1)) & 1ull) : (int)((nz1 >> (k - 65)) & 1ull);
-    const int left = nzeros - below;  // nzeros still to come at this position
+    const int left = t.nzeros - below;  // nzeros still to come at this position
     const int nl = (left + covered - 1) >> log2c;
     const int zidx = s_nnz_ctx[nl] + s_freq_ctx[k >> log2c];
-    const int pp = k == covered ? ((nzeros > size / 16) ? 0 : 1) : prev;
+    const int pp = k == covered ? ((t.nzeros > size / 16) ? 0 : 1) : prev;
     // block context (ac_context.h:64-114): kBlockContextMap[c*27 + code] is 0/1 for Y and
     // 2/3 for X,B, the odd value for the two-block strategy codes 6 and 7
     const int bctx = (st == 0 ? 0 : 1) + (ci == 0 ? 0 : 2);
     const int ctx = 4 * 37 + 458 * bctx + zidx * 2 + pp;
     const uint8_t cm = s_ctx_map[ctx];
-    const uint32_t val = pack_signed((int32_t)v);
-    // tokens in front of the block (coefficient tokens + three per first block), the nzeros tokens of this
-    // and the earlier entries of the block, the coefficient tokens of the block in front of this one
-    uint8_t* o = out + 3u * ((here & kLow) + 3u * (here >> 20) + (uint32_t)(ci + 1) + in_block);
+    const uint32_t val = pack_signed((int32_t)t.coef);
+    uint8_t* o = out + 3u * t.out_index;
     o[0] = cm;
     o[1] = (uint8_t)(val & 0xFF);
     o[2] = (uint8_t)((val >> 8) & 0xFF);
-    if (do_hist) {
+    if (do_hist && real) {
       const uint32_t slot = hist_slot(cm, hybrid_uint_symbol(val & 0xFFFFu));
       atomicAdd(&hist[slot], 1u);
     }
+  };
+  // Three windows in flight per wave: window q is emitted (the first use of its requested values: with loads
+  // and stores on one counter that is a wait for everything the wave has issued), window q + 8 is requested,
+  // window q + 16 is located -- so that a wait comes a whole "locate" (LDS round trips only) behind the last
+  // request and the last stores.  Two sets of registers used in turn, no copies (a copy would be a use).
+  Located even, odd;
+  if (wave < nwin) {
+    locate(wave, even);
+    request(even);
+    if (wave + kWaves < nwin) locate(wave + kWaves, odd);
+  }
+  for (int q = wave; q < nwin; q += 2 * kWaves) {
+    emit(even);
+    if (q + kWaves >= nwin) break;
+    request(odd);
+    if (q + 2 * kWaves < nwin) locate(q + 2 * kWaves, even);
+    emit(odd);
+    if (q + 2 * kWaves >= nwin) break;
+    request(even);
+    if (q + 3 * kWaves < nwin) locate(q + 3 * kWaves, odd);
   }
   if (do_hist) {
     __syncthreads();
