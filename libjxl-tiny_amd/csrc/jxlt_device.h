@@ -1922,25 +1922,45 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
 
   // metadata per entry, coefficient-token and first-block counts per block, predicted-nzeros grid -> LDS
   const int nblk = nbx * nby;
-  for (int b = tid; b < nblk; b += kTokenThreads) {
-    const int bx = b % nbx, by = b / nbx;
-    const uint32_t pos = (uint32_t)(by0 + by) * bstride + (uint32_t)(bx0 + bx);
-    const uint32_t a = A.strategy[pos];
-    const int covered = (a >> 1) == 0 ? 1 : 2;
-    uint32_t ncoef = 0;
+  // (a group has at most 1024 blocks, two per thread: all ten bytes of both are requested before the first is
+  // used, whether the block turns out to be a first block or not -- one round trip instead of four)
+  static_assert(2 * kTokenThreads >= 1024, "two blocks per thread");
+  {
+    uint32_t ld_a[2], ld_nscan[2][3], ld_nz[2][3], ld_grid[2][3];
 #pragma unroll
-    for (int ci = 0; ci < 3; ci++) {
-      const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
-      uint32_t m = a;
-      if (a & 1) {
-        const uint32_t nscan = A.blk_nscan[pos * 3 + c];
-        ncoef += nscan > (uint32_t)covered ? nscan - covered : 0;
-        m = a | ((uint32_t)A.blk_nz[pos * 3 + c] << 8) | (nscan << 16);
+    for (int r = 0; r < 2; r++) {
+      const int b = imin(tid + r * kTokenThreads, nblk - 1);
+      const int by = (int)(((uint32_t)b * nbx_magic) >> 16), bx = b - by * nbx;
+      const uint32_t pos = (uint32_t)(by0 + by) * bstride + (uint32_t)(bx0 + bx);
+      ld_a[r] = A.strategy[pos];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        ld_nscan[r][c] = A.blk_nscan[pos * 3 + c];
+        ld_nz[r][c] = A.blk_nz[pos * 3 + c];
+        ld_grid[r][c] = A.nzgrid[c][pos];
       }
-      meta[b * 3 + ci] = m;
-      s_nzg[c * 1024 + b] = A.nzgrid[c][pos];
     }
-    bstart[b + 1] = ncoef | ((a & 1) << 20);
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int b = tid + r * kTokenThreads;
+      if (b >= nblk) continue;
+      const uint32_t a = ld_a[r];
+      const int covered = (a >> 1) == 0 ? 1 : 2;
+      uint32_t ncoef = 0;
+#pragma unroll
+      for (int ci = 0; ci < 3; ci++) {
+        const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
+        uint32_t m = a;
+        if (a & 1) {
+          const uint32_t nscan = ld_nscan[r][c];
+          ncoef += nscan > (uint32_t)covered ? nscan - covered : 0;
+          m = a | (ld_nz[r][c] << 8) | (nscan << 16);
+        }
+        meta[b * 3 + ci] = m;
+        s_nzg[c * 1024 + b] = (uint8_t)ld_grid[r][c];
+      }
+      bstart[b + 1] = ncoef | ((a & 1) << 20);
+    }
   }
   if (tid == 0) bstart[0] = 0;
   __syncthreads();
