@@ -922,7 +922,13 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
     // (every token_kernel workgroup finds its group's token offset itself: the counts of all groups before it,
     // whichever launch tokenised them, are final by now)
     K.group_first = (int)g0;
-    hipLaunchKernelGGL(token_kernel, dim3((unsigned)ng), dim3(kTokenThreads), 0, tok_stream, K);
+    // (experiment knob, tools/: JXLT_TOKEN_EXTRA_LDS=<bytes> of unused dynamic LDS per workgroup lowers the
+    // number of resident workgroups per CU)
+    static const unsigned token_extra_lds = [] {
+      const char* e = getenv("JXLT_TOKEN_EXTRA_LDS");
+      return e ? (unsigned)atoi(e) : 0u;
+    }();
+    hipLaunchKernelGGL(token_kernel, dim3((unsigned)ng), dim3(kTokenThreads), token_extra_lds, tok_stream, K);
   }
   HIP_TRY(ctx, hipGetLastError());
   ctx->host_src_kind = 0;  // the frame is resident now (a redo with exact roots must not fetch it again)

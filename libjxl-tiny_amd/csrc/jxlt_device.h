@@ -1873,16 +1873,20 @@ constexpr int kTokenThreads = 512;
 // content -- 39 tokens per Y entry, 0.6 per chroma entry -- and kept the CU's one scalar unit busy with
 // per-entry bookkeeping.)  The nzeros tokens (one per entry) are written by a thread-per-block pass.
 __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A) {
-  __shared__ uint32_t meta[3072];        // per entry (block * 3 + channel y, x, b): strategy byte | nzeros << 8 | nscan << 16
+  // per block, two words: strategy byte | nzeros y << 8 | nscan y << 16 | nzeros x << 24, nscan x | nzeros b << 8 |
+  // nscan b << 16 (the entries in stream order y, x, b; 40 KB of LDS in all: four workgroups per CU)
+  __shared__ uint2 meta[1024];
   // per block: coefficient tokens in front of it (bits 0-19) | first blocks in front of it (bits 20-30)
   __shared__ uint32_t bstart[1024 + 1];
   __shared__ uint16_t first_blk[3072 + 8];  // per window: the block that holds its first coefficient token
-  __shared__ uint16_t boundary[kTokenThreads / 64][64];  // per wave: the block that starts at a position of its window
   __shared__ uint32_t wsum[kTokenThreads / 64];
   __shared__ uint32_t hist[64 * 64];
   __shared__ uint16_t s_nnz_ctx[64], s_freq_ctx[64];
   __shared__ uint8_t s_ctx_map[1980];
-  __shared__ uint8_t s_nzg[3 * 1024];   // nzeros grid of the group (PredictFromTopAndLeft input)
+  // nzeros grid of the group (PredictFromTopAndLeft input of the nzeros tokens); once those are written its first
+  // kilobyte is `boundary`: per wave, the block that starts at a position of its window
+  __shared__ alignas(4) uint8_t s_nzg[3 * 1024];
+  uint16_t (*const boundary)[64] = reinterpret_cast<uint16_t (*)[64]>(&s_nzg[0]);
   __shared__ uint64_t s_group_base;
   __shared__ uint64_t gsum[kTokenThreads / 64];
   const int tid = (int)threadIdx.x;
@@ -1947,18 +1951,21 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
       const uint32_t a = ld_a[r];
       const int covered = (a >> 1) == 0 ? 1 : 2;
       uint32_t ncoef = 0;
+      uint32_t nzs[3] = {0, 0, 0}, nscans[3] = {0, 0, 0};  // in stream order y, x, b
 #pragma unroll
       for (int ci = 0; ci < 3; ci++) {
         const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
-        uint32_t m = a;
         if (a & 1) {
-          const uint32_t nscan = ld_nscan[r][c];
-          ncoef += nscan > (uint32_t)covered ? nscan - covered : 0;
-          m = a | (ld_nz[r][c] << 8) | (nscan << 16);
+          nscans[ci] = ld_nscan[r][c];
+          nzs[ci] = ld_nz[r][c];
+          ncoef += nscans[ci] > (uint32_t)covered ? nscans[ci] - covered : 0;
         }
-        meta[b * 3 + ci] = m;
         s_nzg[c * 1024 + b] = (uint8_t)ld_grid[r][c];
       }
+      uint2 mw;
+      mw.x = a | (nzs[0] << 8) | (nscans[0] << 16) | (nzs[1] << 24);
+      mw.y = nscans[1] | (nzs[2] << 8) | (nscans[2] << 16);
+      meta[b] = mw;
       bstart[b + 1] = ncoef | ((a & 1) << 20);
     }
   }
@@ -2005,9 +2012,11 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     const uint32_t here = bstart[b], next = bstart[b + 1];
     const uint32_t s0 = here & kLow, s1 = next & kLow;
     for (uint32_t q = (s0 + 63u) >> 6; (q << 6) < s1; q++) first_blk[q] = (uint16_t)b;  // (windows that start in b)
-    const uint32_t mb[3] = {meta[b * 3], meta[b * 3 + 1], meta[b * 3 + 2]};
-    if (!(mb[0] & 1)) continue;  // not the first block of a transform: no entries
-    const int st = (int)((mb[0] >> 1) & 0x7F);
+    const uint2 mw = meta[b];
+    if (!(mw.x & 1)) continue;  // not the first block of a transform: no entries
+    // (per entry: nzeros << 8 | nscan << 16)
+    const uint32_t mb[3] = {mw.x & 0xFFFF00u, ((mw.x >> 16) & 0xFF00u) | ((mw.y & 0xFFu) << 16), (mw.y & 0xFFFF00u)};
+    const int st = (int)((mw.x >> 1) & 0x7F);
     const int covered = st == 0 ? 1 : 2;
     const int bctx_y = st == 0 ? 0 : 1, bctx_c = 2 + bctx_y;  // (ac_context.h:64-114, see below)
     const int cby = (int)(((uint32_t)b * nbx_magic) >> 16), cbx = b - cby * nbx;
@@ -2086,8 +2095,10 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     JXLT_WAVE_SYNC();  // (read before the next window's entries are filed)
     const uint32_t here = bstart[blk];
     const uint32_t in_block = i - (here & kLow);  // coefficient token of the block
-    const uint32_t m_y = meta[blk * 3], m_x = meta[blk * 3 + 1], m_b = meta[blk * 3 + 2];
-    const int st = (int)((m_y >> 1) & 0x7F);
+    const uint2 mw = meta[blk];
+    // (per entry: nzeros << 8 | nscan << 16)
+    const uint32_t m_y = mw.x & 0xFFFF00u, m_x = ((mw.x >> 16) & 0xFF00u) | ((mw.y & 0xFFu) << 16), m_b = mw.y & 0xFFFF00u;
+    const int st = (int)((mw.x >> 1) & 0x7F);
     const int covered = st == 0 ? 1 : 2;
     const uint32_t n_y = imax((int)(m_y >> 16) - covered, 0), n_x = imax((int)(m_x >> 16) - covered, 0);
     const int ci = (in_block >= n_y ? 1 : 0) + (in_block >= n_y + n_x ? 1 : 0);  // y, x, b in stream order
