@@ -126,22 +126,72 @@ void ConvertBitDepthsToSymbols(const uint8_t* depth, size_t len, uint16_t* bits)
 // ---------------------------------------------------------------------------
 namespace {
 
-void ComputeBitCost(Histogram* h) {  // enc_cluster.cc:18-26
-  h->bit_cost = 0;
-  if (h->total_count == 0) return;
+// sum of counts[i] * depth[i] over the code CreateHuffmanTree(counts, kAlphabetSize, 15) would build, without
+// building the depths when the first tree is not deeper than 15 (then the sum is the sum of the inner nodes'
+// weights): the clustering evaluates about a thousand such costs per frame and needs nothing else of them.
+size_t HuffmanBitCost(const uint32_t* counts) {
+  uint64_t keys[kAlphabetSize];
+  size_t n = 0;
+  for (size_t i = kAlphabetSize; i != 0;) {  // the gathering order and the keys of CreateHuffmanTree, count_limit 1
+    --i;
+    if (counts[i]) {
+      keys[n] = (static_cast<uint64_t>(counts[i]) << 16) | (n << 8) | i;
+      ++n;
+    }
+  }
+  if (n == 0) return 0;
+  if (n == 1) return counts[keys[0] & 0xFF];  // ("fake" depth 1)
+  std::sort(keys, keys + n);
+  // two-queue merge (ties prefer the leaf queue); node weights wrap at 32 bits as the tree's do, the sums
+  // that make up the cost do not
+  uint32_t weight[2 * kAlphabetSize + 2];
+  size_t exact[2 * kAlphabetSize + 2];
+  uint8_t height[2 * kAlphabetSize + 2];
+  for (size_t k = 0; k < n; ++k) {
+    weight[k] = static_cast<uint32_t>(keys[k] >> 16);
+    exact[k] = weight[k];
+    height[k] = 0;
+  }
+  const uint32_t kSentinel = std::numeric_limits<uint32_t>::max();
+  weight[n] = kSentinel;
+  weight[n + 1] = kSentinel;
+  size_t size = n + 2, leaf = 0, inner = n + 1, cost = 0;
+  for (size_t k = n - 1; k != 0; --k) {
+    size_t l, r;
+    if (weight[leaf] <= weight[inner]) l = leaf++; else l = inner++;
+    if (weight[leaf] <= weight[inner]) r = leaf++; else r = inner++;
+    const size_t parent = size - 1;
+    weight[parent] = weight[l] + weight[r];
+    exact[parent] = exact[l] + exact[r];
+    height[parent] = static_cast<uint8_t>(std::max(height[l], height[r]) + 1);
+    cost += exact[parent];
+    weight[size++] = kSentinel;
+  }
+  if (height[2 * n - 1] <= 15) return cost;
+  // deeper than the limit: the general construction (minimum count doubled until the tree fits)
   uint8_t depths[kAlphabetSize] = {};
-  CreateHuffmanTree(h->counts, kAlphabetSize, 15, depths);
-  for (size_t i = 0; i < kAlphabetSize; ++i) h->bit_cost += static_cast<size_t>(h->counts[i]) * depths[i];
+  CreateHuffmanTree(counts, kAlphabetSize, 15, depths);
+  cost = 0;
+  for (size_t i = 0; i < kAlphabetSize; ++i) cost += static_cast<size_t>(counts[i]) * depths[i];
+  return cost;
 }
 
-float Distance(const Histogram& a, const Histogram& b) {  // enc_cluster.cc:28-35
-  if (a.total_count == 0 || b.total_count == 0) return 0;
-  Histogram combined;
-  combined.AddHistogram(a);
-  combined.AddHistogram(b);
-  ComputeBitCost(&combined);
+void ComputeBitCost(Histogram* h) {  // enc_cluster.cc:18-26
+  h->bit_cost = h->total_count == 0 ? 0 : HuffmanBitCost(h->counts);
+}
+
+// enc_cluster.cc:28-35; *combined_cost (optional): the bit cost of the two histograms added up
+float Distance(const Histogram& a, const Histogram& b, size_t* combined_cost = nullptr) {
+  if (a.total_count == 0 || b.total_count == 0) {
+    if (combined_cost) *combined_cost = a.bit_cost + b.bit_cost;  // (the cost of the one that is not empty)
+    return 0;
+  }
+  uint32_t counts[kAlphabetSize];
+  for (size_t i = 0; i < kAlphabetSize; ++i) counts[i] = a.counts[i] + b.counts[i];
+  const size_t cost = HuffmanBitCost(counts);
+  if (combined_cost) *combined_cost = cost;
   // size_t arithmetic (may wrap) converted to float, as in the reference.
-  return static_cast<float>(combined.bit_cost - a.bit_cost - b.bit_cost);
+  return static_cast<float>(cost - a.bit_cost - b.bit_cost);
 }
 
 }  // namespace
@@ -357,9 +407,10 @@ void ClusterHistograms(std::vector<Histogram>* histograms, std::vector<uint8_t>*
     if (dists[largest] < kMinDistanceForDistinct) break;
   }
   float cand[8];
+  size_t cand_cost[8];
   for (size_t i = 0; i < in.size(); i++) {  // enc_cluster.cc:75-90
     if (symbols[i] != max_histograms) continue;
-    parallel_for(out.size(), [&](size_t j) { cand[j] = Distance(in[i], out[j]); });
+    parallel_for(out.size(), [&](size_t j) { cand[j] = Distance(in[i], out[j], &cand_cost[j]); });
     size_t best = 0;
     float best_dist = cand[0];
     for (size_t j = 1; j < out.size(); j++) {
@@ -369,7 +420,7 @@ void ClusterHistograms(std::vector<Histogram>* histograms, std::vector<uint8_t>*
       }
     }
     out[best].AddHistogram(in[i]);
-    ComputeBitCost(&out[best]);
+    out[best].bit_cost = cand_cost[best];  // (what ComputeBitCost(&out[best]) would find again)
     symbols[i] = static_cast<uint32_t>(best);
   }
   if (pooled) pool.Close();
