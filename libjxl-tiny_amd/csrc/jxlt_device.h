@@ -172,17 +172,6 @@ template <int K>
 JXLT_DI float quad_lane(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K * 0x55, 0xF, 0xF, true));
 }
-// v_writelane_b32: lane `lane` of `reg` becomes `value`; both wave-uniform (scalar registers), the lane
-// select through m0 (a second scalar register operand would exceed gfx9's constant-bus limit).  This
-// compiler has no builtin for it.  (The CPU execution model of the tests defines its own JXLT_WRITE_LANE.)
-#ifndef JXLT_WRITE_LANE
-JXLT_DI int write_lane(int reg, int value, int lane) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(value), "s"(lane) : "m0");
-  return reg;
-}
-#else
-JXLT_DI int write_lane(int reg, int value, int lane) { return JXLT_WRITE_LANE(reg, value, lane); }
-#endif
 // Cross-lane moves inside an octet use DPP (data-parallel primitives: a VALU move with a
 // lane permutation, no LDS round trip).  quad_perm covers xor 1 and xor 2; xor 4 is two
 // row shifts by 4 whose bank masks pick the lanes that have a partner in that direction

@@ -375,8 +375,6 @@ inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 // v_readlane: every lane of the wave executes it (wave-uniform control flow) and gets lane l's value
 inline unsigned hipsim_wave_read(unsigned v, int src_lane);
 inline int __builtin_amdgcn_readlane(int v, int l) { return (int)hipsim_wave_read((unsigned)v, l); }
-// v_writelane: `value` (wave-uniform) replaces lane `lane`'s element of `reg`
-#define JXLT_WRITE_LANE(reg, value, lane) (hipsim_lane() == (lane) ? (value) : (reg))
 
 inline void __builtin_amdgcn_s_setprio(int) {}  // issue priority: no effect on results
 
