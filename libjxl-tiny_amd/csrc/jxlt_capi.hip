@@ -133,6 +133,7 @@ struct jxlt_context {
   // jxlt_pack_write: packing on `stream`, chunked copies to the destination on `copy_stream`
   hipStream_t copy_stream = nullptr;
   hipEvent_t dc_hist_ready = nullptr;  // DC histogram of the last enqueue is in h_hist
+  hipEvent_t dc_kernels_done = nullptr;  // (the small downloads wait for their kernels on the copy stream, not in front of the next kernel)
   hipEvent_t ac_hist_ready = nullptr;  // AC histogram + total token count of the last enqueue are in their mirrors
   // Root-table overflow of tile_kernel (a quantised magnitude >= kSqrtLutSize): checked at the
   // first host synchronisation point; the pipeline is then redone with tile_kernel_exact_roots.
@@ -252,6 +253,7 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
   for (auto& ev : ctx->stage_done)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->dc_hist_ready, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->dc_kernels_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ac_hist_ready, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->overflow_ready, hipEventDisableTiming);
   for (auto& ps : ctx->pack) {
@@ -336,6 +338,7 @@ void jxlt_context_destroy(jxlt_context* ctx) {
       if (ev) (void)hipEventDestroy(ev);
   }
   if (ctx->dc_hist_ready) (void)hipEventDestroy(ctx->dc_hist_ready);
+  if (ctx->dc_kernels_done) (void)hipEventDestroy(ctx->dc_kernels_done);
   if (ctx->ac_hist_ready) (void)hipEventDestroy(ctx->ac_hist_ready);
   if (ctx->overflow_ready) (void)hipEventDestroy(ctx->overflow_ready);
   FreeDevice(&ctx->lut_overflow);
@@ -892,9 +895,12 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
       hipLaunchKernelGGL(tile_kernel, dim3(slab_tiles), dim3(kTileThreads), extra_lds, ctx->stream, S);
     if (sl + 1 == nslabs) {
       HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+      // (the four bytes leave on the copy stream: a download in front of the DC-group kernels costs them 10 us)
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[1], 0));
       HIP_TRY(ctx, hipMemcpyAsync(ctx->h_lut_overflow.p, ctx->lut_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost,
-                                  ctx->stream));
-      HIP_TRY(ctx, hipEventRecord(ctx->overflow_ready, ctx->stream));
+                                  ctx->copy_stream));
+      HIP_TRY(ctx, hipEventRecord(ctx->overflow_ready, ctx->copy_stream));
+      ctx->copies_pending = true;
     }
     HIP_TRY(ctx, hipEventRecord(ctx->tile_done[sl], ctx->stream));
     if (!pieces[sl].ends_dc_row) continue;
@@ -912,9 +918,13 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
     hipLaunchKernelGGL(dc_chain_kernel, dim3((unsigned)(slab_dc * kDcChainChunks)), dim3(kDcChainThreads), 0,
                        tok_stream, D);
     if (sl + 1 == nslabs) {
+      // (likewise: the DC histogram leaves beside token_kernel, not in front of it)
+      HIP_TRY(ctx, hipEventRecord(ctx->dc_kernels_done, tok_stream));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->dc_kernels_done, 0));
       HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hist.p + 64 * 64, ctx->hist.p + 64 * 64, 64 * 64 * sizeof(uint32_t),
-                                  hipMemcpyDeviceToHost, tok_stream));
-      HIP_TRY(ctx, hipEventRecord(ctx->dc_hist_ready, tok_stream));
+                                  hipMemcpyDeviceToHost, ctx->copy_stream));
+      HIP_TRY(ctx, hipEventRecord(ctx->dc_hist_ready, ctx->copy_stream));
+      ctx->copies_pending = true;
     }
     const size_t ty0 = dc_row0 * 2048, ty1 = std::min(ctx->ysize, dc_row1 * 2048);  // pixel rows being tokenised
     const size_t g0 = (ty0 / 256) * (size_t)g.xsize_groups;
