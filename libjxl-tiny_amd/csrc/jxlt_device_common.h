@@ -1,0 +1,657 @@
+// jxlt_device_common.h -- kernel argument blocks and __device__ helpers shared by the kernels of the
+// JPEG XL tiny hot path: arithmetic primitives of the canonical 8-lane model, the register-held 1-D DCTs,
+// the adaptive-quantisation helpers.  Part of jxlt_device.h (include that one).
+#ifndef JXLT_DEVICE_COMMON_H_
+#define JXLT_DEVICE_COMMON_H_
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+namespace jxlt_dev {
+
+// ---------------------------------------------------------------------------
+// Kernel arguments
+// ---------------------------------------------------------------------------
+
+// Constant tables, resident in HBM (built on the host by jxlt_capi.hip).
+struct DeviceTables {
+  float weights[576];      // dequant weights (quant_weights.cc:17-134)
+  float inv_weights[576];  // float(1.0 / w), LLF zeroed (quant_weights.cc:144-153)
+  float inv_qac[256];      // float(1.0 / (double)(scale * q)) (enc_group.cc:289)
+  uint16_t table_offset[9];  // host copy of quant_table_offset() below (checked when the tables are built)
+  uint8_t coeff_order[192];
+  uint16_t freq_context[64];
+  uint16_t nnz_context[64];
+  uint8_t block_context_map[81];
+  uint8_t ac_context_map[1980];
+  uint8_t gradient_lut[1024];  // enc_frame.cc:226-281
+  float sqrt_lut[1024];        // sqrtf(i), correctly rounded (EstimateEntropy's cost of a coefficient)
+  // What the quantisation needs to know of scan position p (tile_kernel quantises in scan order, lane = scan
+  // position), per position class -- 0: DCT8, 1 / 2: first / second 64 positions of a two-block transform:
+  // [0..2] InvMatrix of x, y, b at the position's coefficient, [3] dequantisation weight of y, [4..6] zeroing
+  // threshold of x, y, b (enc_group.cc:227-242); scan_slot: where the staging area keeps that coefficient
+  // (bit 6: in the transform's second block).
+  float scan_consts[3][7][64];
+  uint8_t scan_slot[3][64];
+};
+
+// The quantiser's zeroing threshold (enc_group.cc:227-242) of channel c in quadrant `quad` of a one-block
+// (8x8) or two-block transform; quadrants: 8x8: (row >= 4) * 2 + (column >= 4); two-block, coefficient
+// index i = r * 8 + l with r = 0..15: (r >= 8) * 2 + (r & 1).
+__host__ __device__ inline float quant_zeroing_threshold(int c, bool two_block, int quad) {
+  float t0 = 0.58f;
+  float t1 = c == 0 ? 0.635f + 0.08f : c == 2 ? 0.75f : 0.635f;
+  float t2 = c == 0 ? 0.66f + 0.08f : c == 2 ? 0.75f : 0.66f;
+  float t3 = c == 0 ? 0.7f + 0.08f : c == 2 ? 0.75f : 0.7f;
+  if (two_block) {
+    const float dec = 0.003f * 2 * 1;  // Clamp1(0.003f*xsize*ysize, 0, 0.08|0.12)
+    t0 -= dec; t1 -= dec; t2 -= dec; t3 -= dec;
+  }
+  return quad == 0 ? t0 : quad == 1 ? t1 : quad == 2 ? t2 : t3;
+}
+
+// Offset of quant table n = strategy * 3 + channel inside weights[] / inv_weights[]: three
+// 64-entry DCT8 tables, then three 128-entry tables shared by DCT16X8 and DCT8X16.
+__host__ __device__ constexpr int quant_table_offset(int n) { return n < 3 ? n * 64 : 192 + ((n - 3) % 3) * 128; }
+
+// Entries of the square-root table of the entropy estimate (a power of two; tests build the CPU
+// model with a tiny table to exercise the overflow path on ordinary images).
+#ifndef JXLT_SQRT_LUT_SIZE
+#define JXLT_SQRT_LUT_SIZE 1024
+#endif
+constexpr int kSqrtLutSize = JXLT_SQRT_LUT_SIZE;  // DeviceTables::sqrt_lut, TileShared::sqrt_lut
+static_assert((kSqrtLutSize & (kSqrtLutSize - 1)) == 0 && kSqrtLutSize <= 1024, "power of two, fits DeviceTables");
+
+struct FrameGeom {
+  int xsize, ysize;                // pixels
+  int xsize_blocks, ysize_blocks;  // 8x8
+  int xsize_tiles, ysize_tiles;    // 64x64
+  int xsize_groups, ysize_groups;  // 256x256
+};
+
+struct TileArgs {
+  // Input samples: sample (c, y, x) is planes[c][y * pitch + x * pix_stride].  Planar frames use
+  // three base pointers and pix_stride 1; a raw PFM payload (read_pfm.cc:199-209: interleaved
+  // RGB, bottom row first, possibly big endian) is one buffer with pix_stride 3, base pointers
+  // one float apart that point at its LAST row, a negative pitch, and byteswap set.
+  const float* planes[3];
+  ptrdiff_t pitch;  // floats per row (may be negative)
+  int pix_stride;   // floats between horizontally adjacent samples of a plane
+  int byteswap;     // samples are stored byte-reversed
+  FrameGeom g;
+  float distance, scale, inv_scale, scale_dc;
+  float x_qm_mul;  // 1.25^(x_qm_scale-2)
+  float strategy_distance;  // distance behind mul8x8 / mul16x8 (enc_ac_strategy.cc:178-185: the
+                            // reference freezes them at its first call; normally == distance)
+  uint32_t flags;  // bit0: force DCT8
+  const DeviceTables* tab;
+  // outputs (image-absolute grids)
+  int16_t* quant_dc[3];
+  uint8_t* raw_quant;
+  uint8_t* strategy;
+  int8_t* ytox;
+  int8_t* ytob;
+  uint8_t* nzgrid[3];   // value used for context prediction, per block & channel
+  uint8_t* blk_nz;      // [block*3 + c]: number of nonzeros (token value)
+  uint8_t* blk_nscan;   // [block*3 + c]: scan positions up to the last nonzero
+  unsigned long long* blk_nzmask;  // [block*3 + c][2]: which of the scan positions covered .. 127 are nonzero
+  int16_t* coef_scan;   // [block*3 + c][64] quantised coefficients in scan order
+  uint32_t* group_ntok; // per group token count (atomic)
+  uint32_t* dc_nac;     // per DC group: number of first blocks (atomic)
+  uint32_t* lut_overflow;  // [1] set when a quantised magnitude did not fit the root table
+  // debug (may be null)
+  float* dbg_xyb[3];
+  float* dbg_qf;
+  float* dbg_mask;
+  float* dbg_ent8;
+  unsigned long long* dbg_phase;  // [16] accumulated shader cycles per phase (thread 0 of each tile)
+};
+
+struct TokenArgs {
+  FrameGeom g;
+  const DeviceTables* tab;
+  const uint8_t* strategy;
+  const uint8_t* nzgrid[3];
+  const uint8_t* blk_nz;
+  const uint8_t* blk_nscan;
+  const unsigned long long* blk_nzmask;
+  const int16_t* coef_scan;
+  const uint32_t* group_ntok;         // tokens of every group (tile_kernel's counts)
+  uint64_t* group_tok_offset;        // [groups + 1] OUT: exclusive scan of group_ntok -- every workgroup sums the
+                                     // counts of the groups before its own (no scan kernel in front of this one)
+  uint8_t* tokens;                   // 3 bytes per token
+  uint32_t* histogram;               // optional [64 pre-clusters][64 symbols] (enc_frame.cc:767-782)
+  int group_first;                   // workgroup b handles group group_first + b (launches per row of DC groups)
+};
+
+// ---------------------------------------------------------------------------
+// Arithmetic primitives
+// ---------------------------------------------------------------------------
+
+#define JXLT_DI __device__ __forceinline__
+#define JXLT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)  // no instruction is scheduled across
+// A use of a vector register value at this point of the program (no instruction: the compiler has to have
+// waited for the load that produces it).  The CPU execution model of the tests defines this as nothing.
+#ifndef JXLT_TOUCH_VGPR
+#define JXLT_TOUCH_VGPR(x) asm volatile("" ::"v"(x))
+#endif
+
+JXLT_DI float fma32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+JXLT_DI float nfma32(float a, float b, float c) { return __builtin_fmaf(-a, b, c); }
+// min(max(x, 0), 1): folds into the clamp modifier of the instruction that produces x.
+JXLT_DI float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+JXLT_DI float zero_if_negative(float v) {
+  // sign bit set -> +0: as a signed integer every such pattern is negative (one v_max_i32)
+  const int bits = __float_as_int(v);
+  return __int_as_float(bits < 0 ? 0 : bits);
+}
+// Value of lane K of the caller's aligned quad (quad_perm:[K,K,K,K]).
+template <int K>
+JXLT_DI float quad_lane(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K * 0x55, 0xF, 0xF, true));
+}
+// Cross-lane moves inside an octet use DPP (data-parallel primitives: a VALU move with a
+// lane permutation, no LDS round trip).  quad_perm covers xor 1 and xor 2; xor 4 is two
+// row shifts by 4 whose bank masks pick the lanes that have a partner in that direction
+// (a DPP bank = 4 lanes, a row = 16 lanes, octets never straddle a row).
+constexpr int kDppXor1 = 0xB1;       // quad_perm:[1,0,3,2]
+constexpr int kDppXor2 = 0x4E;       // quad_perm:[2,3,0,1]
+constexpr int kDppRowShl4 = 0x104;   // lane i reads lane i + 4
+constexpr int kDppRowShr4 = 0x114;   // lane i reads lane i - 4
+
+// value of lane (l ^ S) for S in {1, 2, 4}
+template <int S>
+JXLT_DI int octet_xor_i(int v) {
+  if (S == 4) {
+    int t = __builtin_amdgcn_update_dpp(0, v, kDppRowShl4, 0xF, 0x5, false);  // lanes 0-3 of each octet
+    return __builtin_amdgcn_update_dpp(t, v, kDppRowShr4, 0xF, 0xA, false);   // lanes 4-7
+  }
+  return __builtin_amdgcn_update_dpp(0, v, S == 1 ? kDppXor1 : kDppXor2, 0xF, 0xF, true);
+}
+template <int S>
+JXLT_DI float octet_xor(float v) {
+  return __int_as_float(octet_xor_i<S>(__float_as_int(v)));
+}
+
+// SumOfLanes over the 8 lanes of an octet: (i)+(i^4), (i)+(i^2), (i)+(i^1).
+JXLT_DI float octet_sum(float v) {
+  v = v + octet_xor<4>(v);
+  v = v + octet_xor<2>(v);
+  v = v + octet_xor<1>(v);
+  return v;
+}
+JXLT_DI int octet_sum_int(int v) {
+  v = v + octet_xor_i<4>(v);
+  v = v + octet_xor_i<2>(v);
+  v = v + octet_xor_i<1>(v);
+  return v;
+}
+JXLT_DI int ceil_log2_nonzero(uint32_t x) {
+  const int fl = 31 - __clz((int)x);
+  return (x & (x - 1)) == 0 ? fl : fl + 1;
+}
+JXLT_DI uint32_t pack_signed(int32_t v) {  // common.h:54-58
+  return ((uint32_t)v << 1) ^ (((uint32_t)(~v) >> 31) - 1);
+}
+
+// The symbol alone (histograms).  For value >= 16 it is (n << 2) | (the two bits below the leading one) with
+// n = floor(log2 value): exactly bits 21.. of the value as a float (exponent n + 127, then the top two
+// mantissa bits; values below 2^24 convert exactly), minus 127 << 2.
+JXLT_DI uint32_t hybrid_uint_symbol(uint32_t value) {
+#ifdef JXLT_SYMBOL_BY_CLZ
+  uint32_t sym, nb, eb;
+  if (value < 16) return value;
+  const uint32_t n = 31u - (uint32_t)__clz((int)value);
+  return (n << 2) + ((value - (1u << n)) >> (n - 2));
+#else
+  const uint32_t hi = (__float_as_uint((float)value) >> 21) - (127u << 2);
+  return value < 16 ? value : hi;
+#endif
+}
+
+// token.h:32-48 (UintCoder::Encode): symbol, number of extra bits, extra bits
+JXLT_DI void hybrid_uint(uint32_t value, uint32_t* sym, uint32_t* nbits, uint32_t* bits) {
+  if (value < 16) {
+    *sym = value;
+    *nbits = 0;
+    *bits = 0;
+  } else {
+    const uint32_t n = 31u - (uint32_t)__clz((int)value);
+    const uint32_t m = value - (1u << n);
+    *sym = (n << 2) + (m >> (n - 2));
+    *nbits = n - 2;
+    *bits = value & ((1u << (n - 2)) - 1);
+  }
+}
+
+// Correctly rounded sqrtf for x == 0 or x in [2^-64, 2^64]: the hardware root (<= 1 ulp off)
+// plus the usual neighbour test -- the residuals x - s_down*s and x - s_up*s tell whether a
+// neighbour is the rounded root.  This is the generic sqrtf expansion minus its input scaling
+// and its zero/infinity fix-up, which these argument ranges do not need.  (x == 0: s = 0, the
+// "down" neighbour is a NaN pattern and the "up" residual is -0, both tests fail, s stays 0.)
+JXLT_DI float sqrt_exact_midrange(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float s_dn = __int_as_float(__float_as_int(s) - 1);
+  const float s_up = __int_as_float(__float_as_int(s) + 1);
+  const float r_dn = nfma32(s_dn, s, x);
+  const float r_up = nfma32(s_up, s, x);
+  float r = (r_dn <= 0.0f) ? s_dn : s;
+  r = (r_up > 0.0f) ? s_up : r;
+  return r;
+}
+
+// Correctly rounded 1.0f / q for integer-valued q (0 < |q| <= 2^31): the hardware reciprocal
+// (1 ulp) plus one residual correction.  On gfx950 this equals IEEE division for every such q
+// (tools/rcp_probe.hip checks all 2^32 - 1 of them; tests/test_gpu_parity.py runs it), at 3
+// instructions instead of the 11 of the generic division expansion.
+JXLT_DI float rcp_int_exact(float q) {
+  const float r0 = __builtin_amdgcn_rcpf(q);
+  const float e0 = nfma32(q, r0, 1.0f);
+  return fma32(e0, r0, r0);
+}
+
+// IEEE-correct num / den where operands and quotient are far from the overflow / underflow
+// thresholds: the hardware reciprocal and the refinement steps of the generic expansion, without
+// that expansion's operand scaling (v_div_scale x 2) and special-case fix-up (v_div_fixup) -- 8
+// instructions instead of 11, the three dropped ones full-rate.  Every division of the kernels is
+// of this kind for finite input of ordinary magnitude (denominators between 1e-3 and 1e6;
+// DESIGN.md "domain of the guarantee").  tools/div_probe.hip compares it with the compiler's
+// division on 2^32 operand pairs of magnitudes 2^-40 .. 2^40 (tests/test_gpu_parity.py runs it).
+JXLT_DI float div_normal(float num, float den) {
+  const float r0 = __builtin_amdgcn_rcpf(den);
+  const float e0 = nfma32(den, r0, 1.0f);
+  const float r1 = fma32(e0, r0, r0);
+  const float q0 = num * r1;
+  const float e1 = nfma32(den, q0, num);
+  const float q1 = fma32(e1, r1, q0);
+  const float e2 = nfma32(den, q1, num);
+  return fma32(e2, r1, q1);
+}
+
+// fast_math-inl.h:113-133 + :74-108
+JXLT_DI float fast_log2f(float x) {
+  const float p0 = -1.8503833400518310E-06f, p1 = 1.4287160470083755E+00f,
+              p2 = 7.4245873327820566E-01f;
+  const float q0 = 9.9032814277590719E-01f, q1 = 1.0096718572241148E+00f,
+              q2 = 1.7409343003366853E-01f;
+  const int32_t x_bits = __float_as_int(x);
+  const int32_t exp_bits = x_bits - 0x3f2aaaab;
+  const int32_t exp_shifted = exp_bits >> 23;
+  const float mantissa = __int_as_float(x_bits - (int32_t)((uint32_t)exp_shifted << 23));
+  const float exp_val = (float)exp_shifted;
+  const float t = mantissa - 1.0f;
+  float yp = p2, yq = q2;
+  yp = fma32(yp, t, p1);
+  yq = fma32(yq, t, q1);
+  yp = fma32(yp, t, p0);
+  yq = fma32(yq, t, q0);
+  return div_normal(yp, yq) + exp_val;
+}
+
+// fast_math-inl.h:137-151
+JXLT_DI float fast_pow2f(float x) {
+  const float floorx = floorf(x);
+  const float e = __int_as_float((int32_t)((uint32_t)((int32_t)floorx + 127) << 23));
+  const float frac = x - floorx;
+  float num = frac + (float)1.01749063e+01;
+  num = fma32(num, frac, (float)4.88687798e+01);
+  num = fma32(num, frac, (float)9.85506591e+01);
+  num = num * e;
+  float den = fma32(frac, (float)2.10242958e-01, (float)-2.22328856e-02);
+  den = fma32(den, frac, (float)-1.94414990e+01);
+  den = fma32(den, frac, (float)9.85506633e+01);
+  return div_normal(num, den);
+}
+
+// fast_math-inl.h:178-213
+JXLT_DI float cube_root_and_add(float x, float add) {
+  const float k1_3 = 1.0f / 3, k4_3 = 4.0f / 3;
+  const float xa_3 = k1_3 * x;
+  const int32_t m1 = __float_as_int(x);
+  const int32_t m2 = (m1 == 0) ? 0 : (int32_t)(0x54800000u - (uint32_t)(m1 >> 23) * 0x002AAAAAu);
+  float r = __int_as_float(m2);
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const float r2 = r * r;
+    r = nfma32(xa_3, r2 * r2, k4_3 * r);
+  }
+  float r2 = r * r;
+  r = fma32(k1_3, nfma32(x, r2 * r2, r), r);
+  r2 = r * r;
+  r = fma32(r2, x, add);
+  return r;
+}
+
+// ZeroIfNegative (enc_xyb.cc:73-75) + CubeRootAndAdd in one: `mixed` is the biased mix BEFORE the clamp.
+// The reference's result for an input clamped to zero is exactly `add` (seed 0 -> r stays 0 -> 0 * 0 + add), so
+// the clamp, the zero test of the seed and its select collapse into ONE compare + select at the end; what
+// the arithmetic in between produces for mixed <= 0 is never used.  The seed itself is a bit-field extract
+// and a 24-bit multiply-add: e * -0x2AAAAA + 0x54800000 with the biased exponent e < 256 -- the same integer
+// as 0x54800000 - (bits >> 23) * 0x2AAAAA for every positive input (denormals included: e = 0).
+JXLT_DI float clamped_cube_root_and_add(float mixed, float add) {
+#ifdef JXLT_CBRT_REFERENCE_SHAPE
+  return cube_root_and_add(zero_if_negative(mixed), add);
+#else
+  const float k1_3 = 1.0f / 3, k4_3 = 4.0f / 3;
+  const float x = mixed;
+  const float xa_3 = k1_3 * x;
+  const int32_t e = (int32_t)__builtin_amdgcn_ubfe(__float_as_uint(x), 23, 8);
+  float r = __int_as_float(e * -0x002AAAAA + 0x54800000);
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const float r2 = r * r;
+    r = nfma32(xa_3, r2 * r2, k4_3 * r);
+  }
+  float r2 = r * r;
+  r = fma32(k1_3, nfma32(x, r2 * r2, r), r);
+  r2 = r * r;
+  r = fma32(r2, x, add);
+  return mixed > 0.0f ? r : add;
+#endif
+}
+
+// enc_xyb.cc:30-81
+template <bool kNeedB = true>
+JXLT_DI void linear_to_xyb(float r, float g, float b, float* ox, float* oy, float* ob) {
+  const float kM02 = 0.078f, kM00 = 0.30f, kM01 = 1.0f - kM02 - kM00;
+  const float kM12 = 0.078f, kM10 = 0.23f, kM11 = 1.0f - kM12 - kM10;
+  const float kM20 = 0.24342268924547819f, kM21 = 0.20476744424496821f,
+              kM22 = 1.0f - kM20 - kM21;
+  const float bias = 0.0037930732552754493f;
+  const float neg_bias_cbrt = -0.15595420054f;
+  const float mixed0 = fma32(kM00, r, fma32(kM01, g, fma32(kM02, b, bias)));
+  const float mixed1 = fma32(kM10, r, fma32(kM11, g, fma32(kM12, b, bias)));
+  const float tm0 = clamped_cube_root_and_add(mixed0, neg_bias_cbrt);
+  const float tm1 = clamped_cube_root_and_add(mixed1, neg_bias_cbrt);
+  *ox = 0.5f * (tm0 - tm1);
+  *oy = 0.5f * (tm0 + tm1);
+  if (kNeedB) {  // (the halo columns only feed the adaptive quantisation, which reads X and Y)
+    const float mixed2 = fma32(kM20, r, fma32(kM21, g, fma32(kM22, b, bias)));
+    *ob = clamped_cube_root_and_add(mixed2, neg_bias_cbrt);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 1-D DCTs held in registers (enc_transforms-inl.h:292-425, dct_scales.h:82-107)
+// ---------------------------------------------------------------------------
+
+#define JXLT_SQRT2 1.41421356237f
+
+JXLT_DI void dct4(float& m0, float& m1, float& m2, float& m3) {
+  const float kW0 = (float)0.541196100146197, kW1 = (float)1.3065629648763764;
+  const float t0 = m0 + m3, t1 = m1 + m2;
+  const float u0 = t0 + t1, u1 = t0 - t1;
+  const float t2 = (m0 - m3) * kW0, t3 = (m1 - m2) * kW1;
+  float w0 = t2 + t3;
+  const float w1 = t2 - t3;
+  w0 = fma32(w0, JXLT_SQRT2, w1);
+  m0 = u0;
+  m1 = w0;
+  m2 = u1;
+  m3 = w1;
+}
+
+JXLT_DI void dct8(float* m) {
+  const float kW[4] = {(float)0.5097955791041592, (float)0.6013448869350453,
+                       (float)0.8999762231364156, (float)2.5629154477415055};
+  float a0 = m[0] + m[7], a1 = m[1] + m[6], a2 = m[2] + m[5], a3 = m[3] + m[4];
+  dct4(a0, a1, a2, a3);
+  float b0 = (m[0] - m[7]) * kW[0], b1 = (m[1] - m[6]) * kW[1], b2 = (m[2] - m[5]) * kW[2],
+        b3 = (m[3] - m[4]) * kW[3];
+  dct4(b0, b1, b2, b3);
+  b0 = fma32(b0, JXLT_SQRT2, b1);
+  b1 = b1 + b2;
+  b2 = b2 + b3;
+  m[0] = a0; m[1] = b0; m[2] = a1; m[3] = b1;
+  m[4] = a2; m[5] = b2; m[6] = a3; m[7] = b3;
+}
+
+JXLT_DI void dct16(float* m) {
+  const float kW[8] = {(float)0.5024192861881557, (float)0.5224986149396889,
+                       (float)0.5669440348163577, (float)0.6468217833599901,
+                       (float)0.7881546234512502, (float)1.060677685990347,
+                       (float)1.7224470982383342, (float)5.101148618689155};
+  float a[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) a[i] = m[i] + m[15 - i];
+  dct8(a);
+#pragma unroll
+  for (int i = 0; i < 8; i++) b[i] = (m[i] - m[15 - i]) * kW[i];
+  dct8(b);
+  b[0] = fma32(b[0], JXLT_SQRT2, b[1]);
+#pragma unroll
+  for (int i = 1; i < 7; i++) b[i] = b[i] + b[i + 1];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    m[2 * i] = a[i];
+    m[2 * i + 1] = b[i];
+  }
+}
+
+// One butterfly exchange of an octet transpose: lanes with (l & S) == 0 keep `a` and receive
+// their partner's `a` into `b`; the other lanes keep `b` and receive their partner's `b` into
+// `a` (partner = lane l ^ S).
+template <int S>
+JXLT_DI void octet_exchange(float& a, float& b, int l) {
+  const int ai = __float_as_int(a), bi = __float_as_int(b);
+  if (S == 4) {
+    // bank-masked row shifts do the select and the move in one instruction each
+    a = __int_as_float(__builtin_amdgcn_update_dpp(ai, bi, kDppRowShr4, 0xF, 0xA, false));
+    b = __int_as_float(__builtin_amdgcn_update_dpp(bi, ai, kDppRowShl4, 0xF, 0x5, false));
+  } else {
+    const bool hi = (l & S) != 0;
+    const int pa = octet_xor_i<S>(ai), pb = octet_xor_i<S>(bi);
+    a = hi ? __int_as_float(pb) : a;
+    b = hi ? b : __int_as_float(pa);
+  }
+}
+
+// 8x8 transpose across the 8 lanes of an octet: lane l holds v[j] = M[j][l] and
+// ends with v[j] = M[l][j].
+// JXLT_LDS_TRANSPOSE = 1: through a private LDS scratch of the octet (kTransposePitch floats,
+// 8 more than the 64 it holds so that the eight octets of a wave fall into different banks):
+// eight dword writes (immediate offsets j * 32 bytes), two 16-byte reads of the lane's row.  The
+// wave's LDS operations execute in order (tools/lds_order_probe.hip checks exactly this on the
+// GPU), so no barrier is needed between them; what this buys is
+// VALU issue slots -- the register variant below costs 40 "full-rate" instructions (24 DPP moves +
+// 16 selects, ~190 cycles per wave and transpose, tools/op_probe.hip), this one 10 LDS
+// instructions that other waves' VALU work overlaps.
+// JXLT_LDS_TRANSPOSE = 0: three butterfly stages in registers, static register indices.
+// (Measured alternatives, both slower on gfx950: one assembly block of 24 fused
+// v_cndmask_b32_dpp -- a VOP2 select whose mask does not come from a VALU compare is very slow,
+// tools/op_probe.hip.)
+#ifndef JXLT_LDS_TRANSPOSE
+#define JXLT_LDS_TRANSPOSE 1
+#endif
+constexpr int kTransposePitch = 72;
+// No instruction: the wave's LDS operations execute in order.  What has to be stopped is the
+// compiler -- the stores and the loads of a transpose go through different types (float / float4),
+// which type-based alias analysis treats as independent -- hence the memory clobber.
+// (An execution model in which lanes are not lock-stepped defines its own JXLT_OCTET_SYNC before
+// including this header: tests/hipsim does.)
+#ifndef JXLT_OCTET_SYNC
+#define JXLT_OCTET_SYNC()                  \
+  do {                                     \
+    asm volatile("" ::: "memory");         \
+    __builtin_amdgcn_wave_barrier();       \
+    asm volatile("" ::: "memory");         \
+  } while (0)
+#endif
+// The same for a whole wave (every lane of the wave reaches it).
+#ifndef JXLT_WAVE_SYNC
+#define JXLT_WAVE_SYNC() JXLT_OCTET_SYNC()
+#endif
+JXLT_DI void octet_transpose(float* v, float* sc, int l) {
+#if JXLT_LDS_TRANSPOSE
+  // Element (row r, column c) lives at (c >> 2) * 36 + r * 4 + (c & 3): the two 16-byte halves of
+  // the rows form two dense 128-byte runs (the reads of the eight lanes are consecutive 16-byte
+  // chunks), and the 4-dword gap between the runs puts the eight dwords a store instruction
+  // writes per octet (column l of row j) into eight consecutive banks.
+  float* const w = sc + (l >> 2) * 36 + (l & 3);
+#pragma unroll
+  for (int j = 0; j < 8; j++) w[j * 4] = v[j];
+  JXLT_OCTET_SYNC();
+  const float4 a = *reinterpret_cast<const float4*>(sc + l * 4);
+  const float4 b = *reinterpret_cast<const float4*>(sc + 36 + l * 4);
+  JXLT_OCTET_SYNC();  // (the next transpose overwrites the scratch)
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+#else
+  (void)sc;
+  octet_exchange<4>(v[0], v[4], l);
+  octet_exchange<4>(v[1], v[5], l);
+  octet_exchange<4>(v[2], v[6], l);
+  octet_exchange<4>(v[3], v[7], l);
+  octet_exchange<2>(v[0], v[2], l);
+  octet_exchange<2>(v[1], v[3], l);
+  octet_exchange<2>(v[4], v[6], l);
+  octet_exchange<2>(v[5], v[7], l);
+  octet_exchange<1>(v[0], v[1], l);
+  octet_exchange<1>(v[2], v[3], l);
+  octet_exchange<1>(v[4], v[5], l);
+  octet_exchange<1>(v[6], v[7], l);
+#endif
+}
+
+// Block transforms.  `px` points at the block's top-left sample in an LDS plane
+// of row pitch `pitch`; l = lane within the octet.  Results are the lane's
+// "rows of 8": coefficient index i = r*8 + l (the reference's SIMD layout).
+
+// The reference scales by 1/N after each 1-D pass (StoreToBlockAndScale, :387-390).  Those
+// factors are powers of two, and scaling by a power of two commutes exactly with every
+// rounded add/mul/fma of the second pass (no over/underflow at these magnitudes: pixel
+// differences are 0 or >= 1 ulp of O(0.1) values), so both are applied once at the end.
+
+// ComputeScaledDCT<8,8> (enc_transforms-inl.h:527-546): i = h*8 + v
+JXLT_DI void block_dct8x8(const float* px, int pitch, int l, float* sc, float* c) {
+#pragma unroll
+  for (int y = 0; y < 8; y++) c[y] = px[y * pitch + l];
+  dct8(c);
+  octet_transpose(c, sc, l);  // lane v now holds 8*A[v][x], x = 0..7
+  dct8(c);
+#pragma unroll
+  for (int y = 0; y < 8; y++) c[y] = (1.0f / 64) * c[y];  // c[h] = C[h][v=l]
+}
+
+// ComputeScaledDCT<16,8>: 16 rows x 8 cols, i = h*16 + v; r = 2h + (v>=8), lane = v&7
+JXLT_DI void block_dct16x8(const float* px, int pitch, int l, float* sc, float* c) {
+  float col[16];
+#pragma unroll
+  for (int y = 0; y < 16; y++) col[y] = px[y * pitch + l];
+  dct16(col);
+  float lo[8], hi[8];
+#pragma unroll
+  for (int v = 0; v < 8; v++) {
+    lo[v] = col[v];
+    hi[v] = col[v + 8];
+  }
+  octet_transpose(lo, sc, l);  // lane t: A[t][x]
+  octet_transpose(hi, sc, l);  // lane t: A[t+8][x]
+  dct8(lo);
+  dct8(hi);
+#pragma unroll
+  for (int h = 0; h < 8; h++) {
+    c[2 * h] = (1.0f / 128) * lo[h];
+    c[2 * h + 1] = (1.0f / 128) * hi[h];
+  }
+}
+
+// ComputeScaledDCT<8,16>: 8 rows x 16 cols, i = v*16 + h; r = 2v + (h>=8), lane = h&7
+JXLT_DI void block_dct8x16(const float* px, int pitch, int l, float* sc, float* c) {
+  float lo[8], hi[8];
+#pragma unroll
+  for (int y = 0; y < 8; y++) {
+    lo[y] = px[y * pitch + l];
+    hi[y] = px[y * pitch + l + 8];
+  }
+  dct8(lo);
+  dct8(hi);
+  octet_transpose(lo, sc, l);  // lane v: A[v][x], x < 8
+  octet_transpose(hi, sc, l);  // lane v: A[v][x], x >= 8
+  float row[16];
+#pragma unroll
+  for (int x = 0; x < 8; x++) {
+    row[x] = lo[x];
+    row[x + 8] = hi[x];
+  }
+  dct16(row);
+#pragma unroll
+  for (int h = 0; h < 8; h++) {
+    lo[h] = (1.0f / 128) * row[h];
+    hi[h] = (1.0f / 128) * row[h + 8];
+  }
+  octet_transpose(lo, sc, l);  // lane t: C[v][h=t], v = 0..7
+  octet_transpose(hi, sc, l);  // lane t: C[v][h=t+8]
+#pragma unroll
+  for (int v = 0; v < 8; v++) {
+    c[2 * v] = lo[v];
+    c[2 * v + 1] = hi[v];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Adaptive quantisation helpers (enc_adaptive_quantization.cc)
+// ---------------------------------------------------------------------------
+
+// :78-104
+JXLT_DI float ratio_of_derivatives(float v, bool invert) {
+  const float kSGmul = 226.0480446705883f;
+  const float kSGmul2 = 1.0f / 73.377132366608819f;
+  const float kLog2 = 0.693147181f;
+  const float kSGRetMul = kSGmul2 * 18.6580932135f * kLog2;
+  const float kSGVOffset = 7.14672470003f;
+  const float kEpsilon = (float)1e-2;
+  v = zero_if_negative(v);
+  const float kNumMul = kSGRetMul * 3 * kSGmul;
+  const float kVOffset = kSGVOffset * kLog2 + kEpsilon;
+  const float kDenMul = kLog2 * kSGmul;
+  const float v2 = v * v;
+  const float num = fma32(kNumMul, v2, kEpsilon);
+  const float den = fma32(kDenMul * v, v2, kVOffset);
+  return invert ? div_normal(num, den) : div_normal(den, num);
+}
+
+// :287-294.  sqrt(float(kMul * 1e8)) is a constant of the model; it is passed in
+// so that it is computed once (correctly rounded) per thread.
+JXLT_DI float masking_sqrt(float v, float sqrt_mul) {
+  const float kLogOffset = 26.481471032459346f;
+  return 0.25f * sqrt_exact_midrange(fma32(v, sqrt_mul, kLogOffset));  // argument >= kLogOffset
+}
+JXLT_DI float masking_sqrt_mul() {
+  const float kMul = 211.50759899638012f;
+  const float mul_v = (float)(kMul * 1e8);
+  return sqrtf(mul_v);
+}
+
+// :52-75
+JXLT_DI float compute_mask(float out_val) {
+  const float kBase = -0.74174993f, kMul4 = 3.2353257320940401f, kMul2 = 12.906028311180409f,
+              kOffset2 = 305.04035728311436f, kMul3 = 5.0220313103171232f,
+              kOffset3 = 2.1925739705298404f, kMul0 = 0.74760422233706747f;
+  const float kOffset4 = 0.25f * kOffset3;
+  const float v1 = fmaxf(out_val * kMul0, 1e-3f);
+  const float v2 = div_normal(1.0f, v1 + kOffset2);
+  const float v3 = div_normal(1.0f, fma32(v1, v1, kOffset3));
+  const float v4 = div_normal(1.0f, fma32(v1, v1, kOffset4));
+  return kBase + fma32(kMul4, v4, fma32(kMul2, v2, kMul3 * v3));
+}
+
+// :296-320
+// Keeps the four smallest of {min0<=min1<=min2<=min3, v}, sorted.  Same result as the
+// reference's branchy insertion for non-NaN inputs (equal values are interchangeable).
+JXLT_DI void store_min4(float v, float& min0, float& min1, float& min2, float& min3) {
+  float t = fmaxf(min0, v);
+  min0 = fminf(min0, v);
+  float u = fmaxf(min1, t);
+  min1 = fminf(min1, t);
+  t = fmaxf(min2, u);
+  min2 = fminf(min2, u);
+  min3 = fminf(min3, t);
+}
+
+}  // namespace jxlt_dev
+
+#endif  // JXLT_DEVICE_COMMON_H_

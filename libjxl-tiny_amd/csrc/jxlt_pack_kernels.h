@@ -1,0 +1,346 @@
+// jxlt_pack_kernels.h -- entropy-coded sections at their final bit positions, tile by tile
+// (enc_frame.cc:784-800, enc_entropy_code.h:34-42).  Part of jxlt_device.h (include that one).
+#ifndef JXLT_PACK_KERNELS_H_
+#define JXLT_PACK_KERNELS_H_
+
+#include "jxlt_device_common.h"
+
+namespace jxlt_dev {
+
+// ---------------------------------------------------------------------------
+// Section bit packing: one workgroup per section (enc_frame.cc:784-800 with
+// WriteToken, enc_entropy_code.h:34-42).  Tiles of kPackTile records: every
+// thread owns kPackPerThread consecutive records, a block scan of their bit
+// lengths gives its bit offset, bits are OR-ed into an LDS window that is then
+// flushed with coalesced dword stores.
+// ---------------------------------------------------------------------------
+constexpr int kPackThreads = 512;
+constexpr int kPackPerThread = 8;
+constexpr int kPackTile = kPackThreads * kPackPerThread;        // 4096 records
+constexpr int kPackWindowWords = kPackTile * 28 / 32 + 4;        // <= 28 bits per record
+
+// ---------------------------------------------------------------------------
+// Copy-free packing at tile granularity (kPackTile records per workgroup, whatever section they
+// belong to): DC-group sections hold ~100 tiles each, AC-group sections <= 48, so per-section
+// workgroups leave most of the machine idle on the 64 DC sections of a 16384^2 frame.
+//   pack_tile_count_kernel    tiles per section            (+ group_scan_kernel -> tile_base)
+//   pack_tile_plan_kernel     per section: the record range of each of its tiles
+//   pack_tile_measure_kernel  bit length of every tile
+//   pack_tile_offsets_kernel  per section: bit offset of each tile, section bits / bytes
+//                             (+ group_scan_kernel -> byte offset of each section)
+//   pack_tile_finalize_kernel per tile: absolute bit positions
+//   pack_tile_write_kernel    entropy-codes a tile at its final bit position of the blob
+// (a tile's workgroup finds everything it needs in one 32-byte PackTileInfo: no dependent
+// global loads in front of the record loads)
+// Two tiles of a section, or two byte-aligned sections, meet inside a dword: those dwords (a tile's
+// first and last) are zeroed by pack_tile_finalize_kernel and OR-ed into by both neighbours; every
+// other dword is stored by exactly one workgroup with plain stores.  (Round 1 had the later tile
+// re-derive its predecessor's trailing bits instead -- one wave walking back through up to 64 records
+// while seven waited, 64 extra records staged per tile, two more barriers.)  Up to 3 bytes behind a
+// blob's last section are zeroed.
+// ---------------------------------------------------------------------------
+struct alignas(16) PackTileInfo {
+  uint64_t rec_first;      // absolute index of the tile's first record
+  uint64_t bit_pos;        // bit position of the tile in the blob (section-relative until finalised)
+  uint64_t sec_start_bit;  // bit position of the tile's section in the blob (section index until finalised)
+  uint32_t n_last;         // records in the tile | last tile of its section << 31
+  uint32_t before;         // records of the section in front of the tile
+};
+
+struct PackTileArgs {
+  const uint8_t* records;           // 3-byte records
+  const uint64_t* sec_rec_offset;   // [nsec (+1)] first record of each section
+  const uint32_t* sec_rec_count;    // optional [nsec] (else offset[s+1] - offset[s])
+  int nsec;
+  const uint32_t* code_table;       // [64][64]: (depth << 16) | bits
+  uint32_t* sec_tiles;              // [nsec] tiles per section
+  const uint64_t* tile_base;        // [nsec + 1] exclusive scan of sec_tiles
+  uint32_t* tile_bits;              // [tiles] bit length of each tile
+  PackTileInfo* tile_info;          // [tiles] where each tile's records and bits are
+  uint32_t* sec_bits;               // [nsec]
+  uint32_t* sec_bytes;              // [nsec]
+  const uint64_t* sec_byte_offset;  // [nsec + 1] exclusive scan of sec_bytes
+  uint8_t* out;                     // blob (4-byte aligned)
+  uint32_t tile_first;              // first tile of this launch
+  uint32_t tile_end;                // one past the last tile of this launch (clamped to the tile count)
+};
+
+JXLT_DI uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+JXLT_DI uint32_t pack_section_records(const PackTileArgs& A, int sec) {
+  return A.sec_rec_count ? A.sec_rec_count[sec] : (uint32_t)(A.sec_rec_offset[sec + 1] - A.sec_rec_offset[sec]);
+}
+
+__global__ void __launch_bounds__(256) pack_tile_count_kernel(const PackTileArgs A) {
+  const int s = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (s < A.nsec) A.sec_tiles[s] = (pack_section_records(A, s) + kPackTile - 1) / kPackTile;
+}
+
+__global__ void __launch_bounds__(256) pack_tile_plan_kernel(const PackTileArgs A) {
+  const int s = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (s >= A.nsec) return;
+  const uint32_t t0 = (uint32_t)A.tile_base[s], t1 = (uint32_t)A.tile_base[s + 1];
+  const uint32_t cnt = pack_section_records(A, s);
+  const uint64_t rec0 = A.sec_rec_offset[s];
+  for (uint32_t t = t0; t < t1; t++) {
+    const uint32_t before = (t - t0) * kPackTile;
+    const uint32_t n = cnt - before < (uint32_t)kPackTile ? cnt - before : (uint32_t)kPackTile;
+    PackTileInfo info;
+    info.rec_first = rec0 + before;
+    info.bit_pos = 0;
+    info.sec_start_bit = (uint64_t)s;
+    info.n_last = n | (t + 1 == t1 ? 0x80000000u : 0u);
+    info.before = before;
+    A.tile_info[t] = info;
+  }
+}
+
+// Records of a tile -> registers -> LDS, so that the first record starts at stage[0].  The records start at
+// any byte: unaligned dword loads (one instruction each on gfx950).  Fixed trip count, every load issued
+// before the first use (a loop over a run-time count waits for each load in turn); the two halves are
+// separate so that a tile's records can be requested while the previous tile is being packed.
+constexpr int kPackStageIters = (kPackTile * 3 / 4 + kPackThreads - 1) / kPackThreads;
+struct PackStagedLoads {
+  uint32_t w[kPackStageIters];
+};
+JXLT_DI void pack_request_tile(const uint8_t* src, int n, int tid, PackStagedLoads* r) {
+  const int nw = (3 * n + 3) >> 2;
+#pragma unroll
+  for (int k = 0; k < kPackStageIters; k++) {
+    const int i = tid + k * kPackThreads;
+    uint32_t v = 0;
+    if (i < nw) __builtin_memcpy(&v, src + 4 * (size_t)i, 4);
+    r->w[k] = v;
+  }
+}
+JXLT_DI void pack_store_tile(const PackStagedLoads& r, int n, uint32_t* stage, int tid) {
+  const int nw = (3 * n + 3) >> 2;
+#pragma unroll
+  for (int k = 0; k < kPackStageIters; k++) {
+    const int i = tid + k * kPackThreads;
+    if (i < nw) stage[i] = r.w[k];
+  }
+}
+
+// The kPackPerThread consecutive records of thread `tid` (3 * kPackPerThread bytes = 12 dwords,
+// dword aligned in the staged tile) with wide LDS reads; record j is the 24 bits at byte 3 * j.
+struct PackThreadRecords {
+  uint32_t w[kPackPerThread * 3 / 4 + 1];
+};
+JXLT_DI void pack_load_thread_records(const uint32_t* stage_tile, int tid, PackThreadRecords* out) {
+  static_assert(kPackPerThread * 3 % 4 == 0, "whole dwords per thread");
+  const uint32_t* p = stage_tile + tid * (kPackPerThread * 3 / 4);
+#pragma unroll
+  for (int q = 0; q < kPackPerThread * 3 / 4; q++) out->w[q] = p[q];
+  out->w[kPackPerThread * 3 / 4] = 0;
+}
+JXLT_DI uint32_t pack_thread_record(const PackThreadRecords& r, int j) {  // ctx | value << 8
+  const int byte = 3 * j;
+  return __builtin_amdgcn_alignbyte(r.w[(byte >> 2) + 1], r.w[byte >> 2], (uint32_t)(byte & 3)) & 0xFFFFFFu;
+}
+JXLT_DI void pack_bits_of(uint32_t rec24, const uint32_t* table, uint32_t* nb, uint32_t* data) {
+  const uint32_t ctx = rec24 & 0xFFu, value = rec24 >> 8;
+  if (ctx >= 128) {
+    *nb = ctx - 128;
+    *data = value;
+  } else {
+    uint32_t sym, nbits, extra;
+    hybrid_uint(value, &sym, &nbits, &extra);
+    const uint32_t e = table[ctx * 64 + sym];
+    const uint32_t depth = e >> 16;
+    *nb = depth + nbits;
+    *data = (e & 0xFFFFu) | (extra << depth);
+  }
+}
+
+constexpr int kPackTilesPerGroup = 4;  // consecutive tiles per workgroup (amortises the table load)
+
+__global__ void __launch_bounds__(kPackThreads) pack_tile_measure_kernel(const PackTileArgs A) {
+  __shared__ uint8_t depth[64 * 64];
+  __shared__ alignas(16) uint32_t stage[kPackTile * 3 / 4 + 4];
+  __shared__ uint32_t total[kPackTilesPerGroup];
+  const int tid = (int)threadIdx.x;
+  const uint32_t ntiles_all = umin32((uint32_t)A.tile_base[A.nsec], A.tile_end);
+  const uint32_t first = A.tile_first + blockIdx.x * kPackTilesPerGroup;
+  if (first >= ntiles_all) return;
+  for (int i = tid; i < 64 * 64; i += kPackThreads) depth[i] = (uint8_t)(A.code_table[i] >> 16);
+  if (tid < kPackTilesPerGroup) total[tid] = 0;
+  // The records of tile k + 1 are requested before tile k is summed: its descriptor one tile earlier still.
+  PackTileInfo info = A.tile_info[first];
+  PackTileInfo next_info = A.tile_info[first + 1 < ntiles_all ? first + 1 : first];
+  PackStagedLoads loads;
+  pack_request_tile(A.records + 3 * info.rec_first, (int)(info.n_last & 0x7FFFFFFFu), tid, &loads);
+  for (int k = 0; k < kPackTilesPerGroup; k++) {
+    const uint32_t tile = first + k;
+    if (tile >= ntiles_all) break;
+    __syncthreads();  // previous tile's stage consumed; tables loaded
+    const int n = (int)(info.n_last & 0x7FFFFFFFu);
+    pack_store_tile(loads, n, stage, tid);
+    if (k + 1 < kPackTilesPerGroup && tile + 1 < ntiles_all) {
+      info = next_info;
+      next_info = A.tile_info[tile + 2 < ntiles_all ? tile + 2 : tile + 1];
+      pack_request_tile(A.records + 3 * info.rec_first, (int)(info.n_last & 0x7FFFFFFFu), tid, &loads);
+    }
+    __syncthreads();
+    PackThreadRecords recs;
+    pack_load_thread_records(stage, tid, &recs);
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < kPackPerThread; j++) {
+      const int r = tid * kPackPerThread + j;
+      if (r < n) {
+        const uint32_t rec24 = pack_thread_record(recs, j);
+        const uint32_t ctx = rec24 & 0xFFu, value = rec24 >> 8;
+        if (ctx >= 128) {
+          mine += ctx - 128;
+        } else {
+          uint32_t sym, nbits, extra;
+          hybrid_uint(value, &sym, &nbits, &extra);
+          mine += depth[ctx * 64 + sym] + nbits;
+        }
+      }
+    }
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    if ((tid & 63) == 0) atomicAdd(&total[k], mine);
+  }
+  __syncthreads();
+  if (tid < kPackTilesPerGroup && first + tid < ntiles_all) A.tile_bits[first + tid] = total[tid];
+}
+
+__global__ void __launch_bounds__(256) pack_tile_offsets_kernel(const PackTileArgs A) {
+  const int s = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (s >= A.nsec) return;
+  const uint32_t t0 = (uint32_t)A.tile_base[s], t1 = (uint32_t)A.tile_base[s + 1];
+  uint32_t off = 0;
+  for (uint32_t t = t0; t < t1; t++) {
+    A.tile_info[t].bit_pos = off;
+    off += A.tile_bits[t];
+  }
+  A.sec_bits[s] = off;
+  A.sec_bytes[s] = (off + 7) >> 3;
+}
+
+__global__ void __launch_bounds__(256) pack_tile_finalize_kernel(const PackTileArgs A) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= (uint32_t)A.tile_base[A.nsec]) return;
+  PackTileInfo info = A.tile_info[t];
+  const uint32_t sec = (uint32_t)info.sec_start_bit;
+  const uint64_t start = 8 * A.sec_byte_offset[sec];
+  info.bit_pos += start;
+  info.sec_start_bit = start;
+  A.tile_info[t] = info;
+  // The dwords in which two tiles (or two sections) meet are OR-ed into by both: zero them here, before the
+  // writing pass -- the dword a tile starts in, and the dword a section ends in.
+  uint32_t* outw = reinterpret_cast<uint32_t*>(A.out);
+  outw[info.bit_pos >> 5] = 0u;
+  if (info.n_last >> 31) {
+    const uint64_t end = start + A.sec_bits[sec];
+    if (end & 31u) outw[end >> 5] = 0u;
+  }
+}
+
+__global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const PackTileArgs A) {
+  __shared__ uint32_t table[64 * 64];
+  __shared__ alignas(16) uint32_t stage[kPackTile * 3 / 4 + 4];
+  __shared__ alignas(16) uint32_t window[kPackWindowWords];
+  __shared__ uint32_t wave_sum[kPackThreads / 64];
+  const int tid = (int)threadIdx.x;
+  const uint32_t ntiles_all = umin32((uint32_t)A.tile_base[A.nsec], A.tile_end);
+  const uint32_t first_tile = A.tile_first + blockIdx.x * kPackTilesPerGroup;
+  if (first_tile >= ntiles_all) return;
+  {  // (all eight loads of the code table in flight before the first LDS store)
+    uint32_t tl[64 * 64 / kPackThreads];
+#pragma unroll
+    for (int q = 0; q < 64 * 64 / kPackThreads; q++) tl[q] = A.code_table[tid + q * kPackThreads];
+#pragma unroll
+    for (int q = 0; q < 64 * 64 / kPackThreads; q++) table[tid + q * kPackThreads] = tl[q];
+  }
+  uint32_t* outw = reinterpret_cast<uint32_t*>(A.out);
+  // The records of tile kt + 1 are requested before tile kt is packed: its descriptor one tile earlier still.
+  PackTileInfo info = A.tile_info[first_tile];
+  PackTileInfo next_info = A.tile_info[first_tile + 1 < ntiles_all ? first_tile + 1 : first_tile];
+  PackStagedLoads loads;
+  pack_request_tile(A.records + 3 * info.rec_first, (int)(info.n_last & 0x7FFFFFFFu), tid, &loads);
+  for (int kt = 0; kt < kPackTilesPerGroup; kt++) {
+    const uint32_t tile = first_tile + kt;
+    if (tile >= ntiles_all) break;
+    __syncthreads();  // previous tile's window stored, its records consumed; table loaded
+    const int n = (int)(info.n_last & 0x7FFFFFFFu);
+    pack_store_tile(loads, n, stage, tid);
+    for (int i = tid; i < kPackWindowWords; i += kPackThreads) window[i] = 0u;
+    const uint64_t pos_bit = info.bit_pos;  // where this tile's bits start
+    const uint32_t lead = (uint32_t)(pos_bit & 31u);
+    const uint64_t word0 = pos_bit >> 5;
+    if (kt + 1 < kPackTilesPerGroup && tile + 1 < ntiles_all) {
+      info = next_info;
+      next_info = A.tile_info[tile + 2 < ntiles_all ? tile + 2 : tile + 1];
+      pack_request_tile(A.records + 3 * info.rec_first, (int)(info.n_last & 0x7FFFFFFFu), tid, &loads);
+    }
+    __syncthreads();  // stage complete, window clear
+    // pass 1: bit length of this thread's records
+    PackThreadRecords recs;
+    pack_load_thread_records(stage, tid, &recs);
+    uint32_t nb[kPackPerThread];
+    uint32_t data[kPackPerThread];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < kPackPerThread; j++) {
+      const int r = tid * kPackPerThread + j;
+      nb[j] = 0;
+      data[j] = 0;
+      if (r < n) pack_bits_of(pack_thread_record(recs, j), table, &nb[j], &data[j]);
+      mine += nb[j];
+    }
+    // exclusive prefix of `mine` over the workgroup: wave scan + per-wave totals
+    uint32_t incl = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d);
+      if ((tid & 63) >= d) incl += o;
+    }
+    if ((tid & 63) == 63) wave_sum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0, tile_bits = 0;
+#pragma unroll
+    for (int w = 0; w < kPackThreads / 64; w++) {
+      const uint32_t v = wave_sum[w];
+      if (w < (tid >> 6)) wave_base += v;
+      tile_bits += v;
+    }
+    // pass 2: OR the bits into the window
+    {
+      const uint32_t pos = lead + wave_base + incl - mine;
+      uint32_t w = pos >> 5;
+      uint32_t fill = pos & 31u;
+      unsigned long long acc = 0;
+#pragma unroll
+      for (int j = 0; j < kPackPerThread; j++) {
+        acc |= (unsigned long long)data[j] << fill;
+        fill += nb[j];
+        if (fill >= 32) {
+          atomicOr(&window[w], (uint32_t)acc);
+          acc >>= 32;
+          fill -= 32;
+          w++;
+        }
+      }
+      if (fill) atomicOr(&window[w], (uint32_t)acc);
+    }
+    __syncthreads();
+    // stores: the dwords the tile covers completely with plain stores; its first and its last dword, which it
+    // may share with its neighbours (tiles of the same section, or the byte-aligned neighbour sections), are
+    // OR-ed into memory that pack_tile_finalize_kernel zeroed
+    const uint32_t end_bits = lead + tile_bits;
+    const uint32_t nwords = (end_bits + 31) >> 5;  // dwords the tile touches
+    for (uint32_t i = tid; i < nwords; i += kPackThreads) {
+      const uint32_t v = window[i];
+      if (i == 0 || (i + 1 == nwords && (end_bits & 31u) != 0)) {
+        if (v) atomicOr(&outw[word0 + i], v);
+      } else {
+        outw[word0 + i] = v;
+      }
+    }
+  }
+}
+
+}  // namespace jxlt_dev
+
+#endif  // JXLT_PACK_KERNELS_H_

@@ -1,0 +1,1153 @@
+// jxlt_tile_kernel.h -- tile_kernel: one 512-thread workgroup per 64x64 tile, pixels to scan-ordered
+// quantised coefficients and side-band grids (enc_frame.cc:597-683 + enc_group.cc:304-443).
+// Part of jxlt_device.h (include that one).
+#ifndef JXLT_TILE_KERNEL_H_
+#define JXLT_TILE_KERNEL_H_
+
+#include "jxlt_device_common.h"
+
+namespace jxlt_dev {
+
+// ---------------------------------------------------------------------------
+// Tile kernel
+// ---------------------------------------------------------------------------
+
+constexpr int kTileThreads = 512;
+constexpr int kHalo = 5;                 // AQ: +-4 px window, +-1 px Laplacian tap
+constexpr int kXYPitch = 64 + 2 * kHalo + 1;  // 75 floats (odd: conflict-free columns)
+constexpr int kBPitch = 65;
+constexpr int kPrePitch = 19;
+constexpr int kCflTermFloats = 64 * 64 * 4;  // LDS floats overlaid by the CfL terms
+// float stride between the blocks of the coefficient staging area (3 x 64 values each): 200 = 8 (mod 64), so
+// the eight 32-byte runs the octets of a wave store at a time land in different banks
+constexpr int kStageStrideF = 200;
+
+struct alignas(16) TileShared {
+  float x[64 * kXYPitch];
+  float y[64 * kXYPitch];
+  float b[64 * kBPitch];
+  float rowsum[16 * 72];   // AQ: per 4-row band, per column
+  float pre_erosion[16 * kPrePitch];
+  float erosion[16 * 16];
+  float cfl_pad[kCflTermFloats - (2 * 64 * kXYPitch + 64 * kBPitch + 16 * 72 + 16 * kPrePitch + 16 * 16)];
+  // ^ x..cfl_pad (64 KB) are overlaid by the chroma-from-luma terms once every pixel
+  //   read is done: 64 blocks x 64 coefficients x (a_x, b_x, a_b, b_b).
+  // rowsum..transpose_pad: during the transforms (the AQ buffers are dead by then) the octets'
+  // transpose scratch, 64 x kTransposePitch floats.
+  float transpose_pad[64 * 72 - (kCflTermFloats - (2 * 64 * kXYPitch + 64 * kBPitch))];
+  // (its first 128 floats hold the candidate entropies of the 2x2 cells during the strategy search, "ent8")
+  float sqrt_lut[kSqrtLutSize];  // sqrtf of the quantised magnitudes below kSqrtLutSize
+  float inv_w[576];
+  float aq[64];            // quant field (tile-local 8x8)
+  float mask[64];
+  float cfl_sum[4];        // ca_x, cb_x, ca_b, cb_b
+  int cmap[2];             // ytox, ytob
+  uint8_t raw_quant[64];
+  uint8_t strat[64];
+  uint32_t ntok;
+  uint32_t nfirst;
+};
+// After the last pixel read the XYB planes are dead and are reused: chroma-from-luma terms, the parked
+// DCT8 coefficients of the entropy estimate, then the staging area of the selected transforms' coefficients
+// (64 blocks x 3 channels x 64 floats).
+
+JXLT_DI int imin(int a, int b) { return a < b ? a : b; }
+JXLT_DI int imax(int a, int b) { return a > b ? a : b; }
+
+// Per-octet entropy estimate of one transform (enc_ac_strategy.cc:51-146).
+// cy/cx/cb: the lane's rows of the Y/X/B coefficients; NR rows (8 or 16).
+// kLut: the roots come from the LDS table S.sqrt_lut (a multiply, a convert, a mask and an LDS
+// read instead of v_sqrt + the exact-rounding fix-up, ~40 cycles); *qmax then receives the
+// largest magnitude seen, and the caller redoes the estimate with kLut = false if it is beyond
+// the table (quantised coefficients >= 1024: practically never, but results must not depend on it).
+template <int NR, bool kLut>
+JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb, const float* inv_x,
+                               const float* inv_y, const float* inv_b, int l, float quant,
+                               float masking, float cmap_x, float cmap_b, float distance,
+                               const float* sqrt_lut, float* qmax) {
+  const float num_blocks = (float)(NR / 8);
+  const float kInfoLossMultiplier = 138.0f;
+  const float kInfoLossMultiplier2 = (float)50.46839691767866;
+  const float kCost2 = 4.4628149885273363f;
+  const float kCostDelta = 5.3359184934516337f;
+  const float kZerosMul = 7.565053364251793f;
+  const float slope = fminf(1.0f, distance * (1.0f / 3));
+  const float cost_of_1 = 1 + slope * 8.8703248061477744f;
+  float entropy = 0.0f;
+  float info_loss = 0.0f, info_loss2 = 0.0f;
+  uint32_t qbits = 0;  // OR of the offset words before masking (a v_or is cheaper than a v_max)
+  // One copy of the body per channel (no per-coefficient operand selects); the scheduling
+  // fences keep the channels from being interleaved, which would spill.
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const float* inv = c == 0 ? inv_x : c == 1 ? inv_y : inv_b;
+    const float* cin = c == 0 ? cx : c == 1 ? cy : cb;
+    const float cmap_factor = c == 0 ? cmap_x : c == 1 ? 0.0f : cmap_b;
+    float entropy_v = 0.0f, nzeros_v = 0.0f;
+    JXLT_SCHED_FENCE();
+    // Selects and compares are the expensive kind of VALU instruction on gfx950
+    // (tools/op_probe.hip), multiply-adds with the (free) clamp modifier are not.  With q a
+    // non-negative integer:  [q >= 2] = clamp01(q - 1),  [q >= 1] = clamp01(4 * q),  and
+    // x + (c ? k : 0) == fma(c, k, x) for c in {0, 1}.
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+      const float in = cin[r];
+      const float im = inv[r * 8 + l];
+      // (skipping the subtraction of cy * 0 for the Y channel saves two instructions per
+      // coefficient on paper; the register allocator then spills 90 VGPRs)
+      const float val = (in - cy[r] * cmap_factor) * (im * quant);
+      const float rval = rintf(val);
+      const float diff = fabsf(val - rval);
+      info_loss = info_loss + diff;
+      info_loss2 = fma32(diff, diff, info_loss2);
+      const float q = fabsf(rval);
+      entropy_v = fma32(clamp01(q - 1.0f), kCost2, entropy_v);  // + (q >= 1.5 ? kCost2 : 0)
+      float root;
+      if (kLut) {
+        // byte offset 4 * q, wrapped into the table (a wrapped read is redone by the caller)
+        // 4 * q + 2^23 is exact for q < 2^21 and its bit pattern is 0x4B000000 + 4 * q: the byte
+        // offset comes out of a multiply-add and a mask, no float -> int conversion (a full-rate
+        // instruction, tools/op_probe.hip).  Larger q (or NaN) disturb the bits above the offset
+        // field, which the OR below keeps for the caller's overflow test.
+        const uint32_t off_raw = __float_as_uint(fma32(q, 4.0f, 8388608.0f));
+        const uint32_t off = off_raw & (uint32_t)(kSqrtLutSize * 4 - 4);
+        root = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sqrt_lut) + off);
+        qbits |= off_raw;
+      } else {
+        // (skipping the root with a branch where a whole wave has q <= 1 was tried: control flow
+        // inside this loop makes the register allocator spill)
+        root = sqrt_exact_midrange(q);  // q is 0 or an integer >= 1
+      }
+      entropy_v = fma32(root, kCostDelta, entropy_v);
+      nzeros_v = nzeros_v + clamp01(4.0f * q);  // + (q == 0 ? 0 : 1)
+    }
+    entropy_v = fma32(nzeros_v, cost_of_1, entropy_v);
+    entropy += octet_sum(entropy_v);
+    const uint32_t num_nzeros = (uint32_t)octet_sum(nzeros_v);
+    const uint32_t nbits = (uint32_t)ceil_log2_nonzero(num_nzeros + 1) + 1;
+    entropy += kZerosMul * (float)(ceil_log2_nonzero(nbits + 17) + nbits);
+  }
+  const float infoloss = octet_sum(info_loss);
+  const float infoloss2 = sqrtf(num_blocks * octet_sum(info_loss2));
+  const float info_loss_score = (kInfoLossMultiplier * infoloss + kInfoLossMultiplier2 * infoloss2);
+  // every offset stayed inside the table <=> nothing above the offset field differs from 2^23's pattern
+  if (kLut) *qmax = ((qbits | 0x4B000000u) & ~(uint32_t)(kSqrtLutSize * 4 - 1)) != 0x4B000000u ? (float)kSqrtLutSize : 0.0f;
+  return entropy + masking * info_loss_score;
+}
+
+// enc_group.cc:186-218 for channel 1.  `quant` is the quantised coefficient as a float: 0 (+0, the
+// thresholded case) or an integer of magnitude >= 1.  |quant| <= 1: the reference selects
+// +-kBias1 by sign, 0 for 0 -- which is quant * kBias1 exactly; otherwise quant - kBias3 / quant.
+JXLT_DI float adjust_quant_bias_y(float quant) {
+  const float kBias1 = 1.0f - 0.07005449891748593f;  // kDefaultQuantBias[1]
+  const float kBias3 = 0.145f;
+  const float small = quant * kBias1;
+  const float bias = nfma32(kBias3, rcp_int_exact(quant), quant);  // (quant == 0: selected away below)
+  return fabsf(quant) < 1.125f ? small : bias;
+}
+
+// kDebug: the variant that serves the A.dbg_* outputs (per-phase clocks, intermediate planes for
+// the parity tests); the production variant has none of their tests, branches and registers.
+template <bool kLutRoots, bool kDebug>
+JXLT_DI void tile_kernel_body(const TileArgs& A) {
+  __shared__ TileShared S;
+  const int tid = (int)threadIdx.x;
+  const int l = tid & 7;    // lane within octet
+  const int oct = tid >> 3;  // octet index == block index within tile (0..63)
+  const DeviceTables* T = A.tab;
+  long long t_prev = (kDebug && A.dbg_phase) ? clock64() : 0;
+  // Profiling builds (-DJXLT_PHASE_STOPS, tools/phase_pmc.py) can truncate the kernel after
+  // phase i; the early exits perturb code generation, so production builds leave them out.
+#ifdef JXLT_PHASE_STOPS
+#define JXLT_STOP(i) if (((A.flags >> 8) & 15u) == (unsigned)(i) + 1u) return;
+#else
+#define JXLT_STOP(i)
+#endif
+#define JXLT_MARK(i)                                                        \
+  if (kDebug && A.dbg_phase && tid == 0) {                                  \
+    const long long t_now = clock64();                                      \
+    atomicAdd(&A.dbg_phase[i], (unsigned long long)(t_now - t_prev));       \
+    t_prev = t_now;                                                         \
+  }                                                                         \
+  JXLT_STOP(i)
+
+  // ---- geometry (enc_frame.cc:716-751) ------------------------------------
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed placement, used for
+  // speed only), and each XCD has its own L2.  Give every XCD one contiguous raster range
+  // of tiles so that horizontally adjacent tiles -- which share the +-5 px halo columns and
+  // the partially covered 128-byte lines -- are served by the same L2.
+  int tile_id;
+  {
+    const int n = A.g.xsize_tiles * A.g.ysize_tiles;
+    const int b = (int)blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int q = n >> 3, r = n & 7;
+    tile_id = xcd * q + (xcd < r ? xcd : r) + idx;
+  }
+  const int tx_img = tile_id % A.g.xsize_tiles, ty_img = tile_id / A.g.xsize_tiles;
+  const int gx = tx_img >> 2;
+  const int sx0 = gx * 256, sy0 = ty_img * 64;            // stripe origin (pixels)
+  const int sw = imin(256, A.g.xsize - sx0), sh = imin(64, A.g.ysize - sy0);
+  const int swp = (sw + 7) & ~7, shp = (sh + 7) & ~7;       // padded stripe size
+  const int tbx0 = (tx_img & 3) * 8;                        // tile origin in stripe blocks
+  const int nbx = imin(8, swp / 8 - tbx0), nby = shp / 8;   // tile size in blocks
+  const int px0 = tbx0 * 8;                                 // tile origin in stripe pixels
+  const int bx_img0 = gx * 32 + tbx0, by_img0 = ty_img * 8; // image-absolute block origin
+  const int obx = oct & 7, oby = oct >> 3;                  // octet's block in the tile
+  const bool blk_valid = obx < nbx && oby < nby;
+  const uint32_t bstride = (uint32_t)A.g.xsize_blocks;
+
+  // ---- P0: tables -> LDS; load + XYB (enc_frame.cc:597-617, enc_xyb.cc) -----
+  // The table values are REQUESTED here (every lane, clamped indices: no branches) and stored to LDS behind the
+  // pixel requests below, so that all of the tile's global loads are in flight together.  (Loops of "load, wait,
+  // store to LDS" in front of the pixel loads cost six serial round trips to L2 per tile.)
+  static_assert(kTileThreads == 512 && (kSqrtLutSize <= 512 || kSqrtLutSize == 1024), "table staging below");
+  const float tab_inv0 = T->inv_weights[tid];
+  const float tab_inv1 = T->inv_weights[512 + (tid & 63)];
+  const float tab_root0 = T->sqrt_lut[tid & (kSqrtLutSize - 1)];
+  const float tab_root1 = T->sqrt_lut[(512 + tid) & (kSqrtLutSize - 1)];
+  if (tid == 0) {
+    S.ntok = 0;
+    S.nfirst = 0;
+  }
+  {
+    // 16 lanes along x, 32 rows per pass: a thread owns 5 columns x 2 rows of the
+    // (64 + 2*kHalo)-wide window, so the row and column clamps are shared and all thirty loads
+    // are in flight before the first use.  Column slots 0-3 cover the 64 interior columns; slot 4
+    // takes the ten halo columns (lanes 0-4 left, 5-9 right), which need X and Y only.
+    constexpr int kWin = 64 + 2 * kHalo;
+    const int base = px0 - kHalo;  // stripe x of LDS column 0
+    const int lx = tid & 15, ly = tid >> 4;
+    const float* rowp[2][3];
+    bool yok[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int y = ly + 32 * h;
+      yok[h] = y < shp;
+      const ptrdiff_t off = (ptrdiff_t)(sy0 + imin(y, sh - 1)) * A.pitch + (ptrdiff_t)sx0 * A.pix_stride;
+      rowp[h][0] = A.planes[0] + off;
+      rowp[h][1] = A.planes[1] + off;
+      rowp[h][2] = A.planes[2] + off;
+    }
+    // (scalar arithmetic on purpose: on gfx950 a packed v_pk_*_f32 costs at least as much as its
+    // two scalar halves -- tools/pk_probe.hip -- and the packed variant of this loop measured
+    // 3 % slower for the whole kernel)
+    float pr[5][2], pg[5][2], pb[5][2];
+    bool xok[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const int cx = j < 4 ? kHalo + lx + 16 * j : (lx < kHalo ? lx : lx < 2 * kHalo ? 64 + lx : kWin);
+      const int x = base + cx;
+      xok[j] = cx < kWin && x >= 0 && x < swp && x < px0 + nbx * 8 + kHalo;
+      const int xs = (xok[j] ? imin(x, sw - 1) : 0) * A.pix_stride;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        pr[j][h] = rowp[h][0][xs];
+        pg[j][h] = rowp[h][1][xs];
+        pb[j][h] = rowp[h][2][xs];
+      }
+    }
+    // (table values -> LDS while the pixels are on their way; they were requested first, so the wait is theirs only)
+    S.inv_w[tid] = tab_inv0;
+    if (tid < 64) S.inv_w[512 + tid] = tab_inv1;
+    if (tid < kSqrtLutSize) S.sqrt_lut[tid] = tab_root0;
+    if (kSqrtLutSize > 512) S.sqrt_lut[(512 + tid) & (kSqrtLutSize - 1)] = tab_root1;
+    if (A.byteswap) {  // big-endian PFM payload (BSwapFloat, read_pfm.cc:206)
+#pragma unroll
+      for (int j = 0; j < 5; j++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          pr[j][h] = __uint_as_float(__builtin_bswap32(__float_as_uint(pr[j][h])));
+          pg[j][h] = __uint_as_float(__builtin_bswap32(__float_as_uint(pg[j][h])));
+          pb[j][h] = __uint_as_float(__builtin_bswap32(__float_as_uint(pb[j][h])));
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      if (!xok[j]) continue;
+      const int cx = j < 4 ? kHalo + lx + 16 * j : (lx < kHalo ? lx : 64 + lx);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        if (!yok[h]) continue;
+        const int y = ly + 32 * h;
+        float px_, py_, pb_ = 0.0f;
+        if (j < 4) linear_to_xyb<true>(pr[j][h], pg[j][h], pb[j][h], &px_, &py_, &pb_);
+        else linear_to_xyb<false>(pr[j][h], pg[j][h], pb[j][h], &px_, &py_, &pb_);
+        S.x[y * kXYPitch + cx] = px_;
+        S.y[y * kXYPitch + cx] = py_;
+        if (j < 4) S.b[y * kBPitch + cx - kHalo] = pb_;
+        if (kDebug && j < 4 && A.dbg_xyb[0] && cx < kHalo + nbx * 8) {
+          const size_t d = (size_t)(by_img0 * 8 + y) * ((size_t)bstride * 8) + (size_t)(bx_img0 * 8 + cx - kHalo);
+          A.dbg_xyb[0][d] = px_;
+          A.dbg_xyb[1][d] = py_;
+          A.dbg_xyb[2][d] = pb_;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  JXLT_MARK(0);
+  // LDS column of stripe pixel x is (x - px0 + kHalo).
+#define SX(yy, xx) S.x[(yy) * kXYPitch + ((xx) - px0 + kHalo)]
+#define SY(yy, xx) S.y[(yy) * kXYPitch + ((xx) - px0 + kHalo)]
+
+  // ---- P1: AQ per-pixel masked Laplacian energy, summed over 4-row bands ----
+  // (enc_adaptive_quantization.cc:376-483)
+  int aq_x0 = px0, aq_x1 = px0 + nbx * 8;
+  if (aq_x0 != 0) aq_x0 -= 4;
+  if (aq_x1 != swp) aq_x1 += 4;
+  const int aq_w = aq_x1 - aq_x0;  // <= 72
+  {
+    const float match_gamma_offset = (float)0.019;
+    const float kXMul = 23.426802998210313f;
+    const float sqrt_mul = masking_sqrt_mul();
+    // Positions handled by the reference's 8-lane vector loop: [vs, ve).
+    const int vs = aq_x0 == 0 ? 1 : aq_x0;
+    const int nvec = (aq_x1 - 10 >= vs) ? ((aq_x1 - 10 - vs) / 8 + 1) : 0;
+    const int ve = vs + 8 * nvec;
+    const int nbands = nby * 2;
+    // One pixel's term from its own value, the sum of its vertical neighbours and its horizontal
+    // neighbours; both association orders are computed and selected (a branch per pixel would wait
+    // for the LDS before and after each arm).
+    auto pixel_term = [&](bool vec, float in, float du, float in_l, float in_r, float ix, float dux, float ix_l,
+                          float ix_r) {
+      const float base = 0.25f * (vec ? (in_r + in_l) + du : (du + in_l) + in_r);
+      const float gammac = ratio_of_derivatives(in + match_gamma_offset, false);
+      float diff = gammac * (in - base);
+      diff = diff * diff;
+      const float base_x = 0.25f * (vec ? (ix_r + ix_l) + dux : (dux + ix_l) + ix_r);
+      float diff_x = gammac * (ix - base_x);
+      diff_x = diff_x * diff_x;
+      const float fused = fma32(kXMul, diff_x, diff), unfused = diff + kXMul * diff_x;
+      return masking_sqrt(vec ? fused : unfused, sqrt_mul);
+    };
+    // (Spreading the last, partly filled pass over all threads row by row changes nothing: the
+    // other resident workgroup takes the issue slots the idle waves leave.)
+    for (int i = tid; i < nbands * aq_w; i += kTileThreads) {
+      const int q = i / aq_w, x = aq_x0 + i % aq_w;
+      const bool vec = x >= vs && x < ve;
+      const int xl = x > 0 ? x - 1 : x, xr = x + 1 < swp ? x + 1 : x;
+      // The band's column, rows y0-1 .. y0+4 (clamped to the stripe: only the first and the
+      // last entry can clamp, shp = 8 nby), is read once.
+      const int y0 = q * 4;
+      const int yu0 = y0 > 0 ? y0 - 1 : y0, yd3 = y0 + 4 < shp ? y0 + 4 : y0 + 3;
+      float cy[6], cxx[6], ly4[4], ry4[4], lx4[4], rx4[4];
+      cy[0] = SY(yu0, x);
+      cxx[0] = SX(yu0, x);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        cy[k + 1] = SY(y0 + k, x);
+        cxx[k + 1] = SX(y0 + k, x);
+        ly4[k] = SY(y0 + k, xl);
+        ry4[k] = SY(y0 + k, xr);
+        lx4[k] = SX(y0 + k, xl);
+        rx4[k] = SX(y0 + k, xr);
+      }
+      cy[5] = SY(yd3, x);
+      cxx[5] = SX(yd3, x);
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const float diff = pixel_term(vec, cy[k + 1], cy[k + 2] + cy[k], ly4[k], ry4[k], cxx[k + 1],
+                                      cxx[k + 2] + cxx[k], lx4[k], rx4[k]);
+        acc = (k == 0) ? diff : acc + diff;
+      }
+      // P2, the 4-column average (:484-491), inside the quad: aq_w is a multiple of 4 and so
+      // is the stride, so the four columns of one average sit in one aligned quad of lanes;
+      // summed in the reference's order ((c0 + c1) + c2) + c3 by lane 0 of the quad.
+      float s4 = acc + quad_lane<1>(acc);
+      s4 = s4 + quad_lane<2>(acc);
+      s4 = s4 + quad_lane<3>(acc);
+      if ((i & 3) == 0) S.pre_erosion[q * kPrePitch + ((x - aq_x0) >> 2)] = s4 * 0.25f;
+    }
+  }
+  __syncthreads();
+  JXLT_MARK(1);
+  const int pre_xs = aq_w / 4, pre_ys = nby * 2;
+  // ---- P3: fuzzy erosion (:322-374) ------------------------------------------
+  {
+    const int rx0 = (aq_x0 % 8 == 0) ? 0 : 1;
+    // The four cells of one block share a quad of lanes (cell c = lane & 3, row-major); quad e of
+    // the first 256 threads has block e of the 8x8 grid, blocks outside the tile get aq = mask = 0.
+    if (tid < 256) {
+      const int i = tid, ebx = (tid >> 2) & 7, eby = tid >> 5;
+      const bool eb_valid = ebx < nbx && eby < nby;
+      const int fy = eb_valid ? 2 * eby + ((i >> 1) & 1) : 0, fx = eb_valid ? 2 * ebx + (i & 1) : 0;
+      const int y = fy, x = fx + rx0;
+      const int ym1 = y >= 1 ? y - 1 : y, yp1 = y + 1 < pre_ys ? y + 1 : y;
+      const int xm1 = x >= 1 ? x - 1 : x, xp1 = x + 1 < pre_xs ? x + 1 : x;
+      const float* rowt = &S.pre_erosion[ym1 * kPrePitch];
+      const float* row = &S.pre_erosion[y * kPrePitch];
+      const float* rowb = &S.pre_erosion[yp1 * kPrePitch];
+      float min0 = row[x], min1 = row[xm1], min2 = row[xp1], min3 = rowt[xm1], t;
+#define JXLT_SWAP_GT(a, b) { t = fminf(a, b); b = fmaxf(a, b); a = t; }
+      JXLT_SWAP_GT(min0, min1);
+      JXLT_SWAP_GT(min0, min2);
+      JXLT_SWAP_GT(min0, min3);
+      JXLT_SWAP_GT(min1, min2);
+      JXLT_SWAP_GT(min1, min3);
+      JXLT_SWAP_GT(min2, min3);
+#undef JXLT_SWAP_GT
+      store_min4(rowt[x], min0, min1, min2, min3);
+      store_min4(rowt[xp1], min0, min1, min2, min3);
+      store_min4(rowb[xm1], min0, min1, min2, min3);
+      store_min4(rowb[x], min0, min1, min2, min3);
+      store_min4(rowb[xp1], min0, min1, min2, min3);
+      const float kMul = 0.05f;
+      const float ev = kMul * row[x] + kMul * min0 + kMul * min1 + kMul * min2 + kMul * min3;
+      // Block value (:366-373): ((e00 + e01) + e10) + e11, by lane 0 of the quad.
+      float v = ev + quad_lane<1>(ev);
+      v = v + quad_lane<2>(ev);
+      v = v + quad_lane<3>(ev);
+      if ((i & 3) == 0) {
+        S.aq[eby * 8 + ebx] = eb_valid ? v : 0.0f;
+        S.mask[eby * 8 + ebx] = eb_valid ? div_normal(1.0f, v + 0.001f) : 0.0f;  // ComputeMaskForAcStrategyUse (:46-50)
+      }
+    }
+  }
+  __syncthreads();
+  JXLT_MARK(2);
+  // ---- P4: per-block modulations, one octet per block (:114-285) -------------
+  {
+    float out_val = 0.0f;
+    const int bxp = px0 + obx * 8, byp = oby * 8;  // block origin (stripe pixels)
+    if (blk_valid) {
+      out_val = compute_mask(S.aq[oct]);
+    }
+    // HfModulation (:209-247): lane l = column l of the block
+    float hf = 0.0f, red = 0.0f, blue = 0.0f, gam = 0.0f;
+    const float kBias = 0.16f;
+    const float kRedRampStart = (float)0.0073200141118951231;
+    const float kRedRampLength = (float)0.019421555948474039;
+    const float kBlueRampLength = (float)0.086890611400405895;
+    const float kBlueRampStart = (float)0.26973418507870539;
+    const int right_step = l < 7 ? 1 : 0;
+    if (blk_valid) {
+#pragma unroll
+      for (int dy = 0; dy < 8; dy++) {
+        const int yy = byp + dy, xx = bxp + l;
+        const float p = SY(yy, xx);
+        // column 7 has no right neighbour inside the block: it reads itself (|p - p| = 0, as the
+        // reference adds) instead of branching around the read
+        hf = hf + fabsf(p - SY(yy, xx + right_step));
+        const float pd = (dy == 7) ? p : SY(yy + 1, xx);
+        hf = hf + fabsf(p - pd);
+        // ColorModulation (:146-207)
+        const float vx = SX(yy, xx);
+        const float vb = S.b[yy * kBPitch + obx * 8 + l];
+        const float pixel_x = fmaxf(0.0f, vx - kRedRampStart);
+        const float pixel_b = fmaxf(0.0f, vb - (p + kBlueRampStart));
+        red = red + fminf(pixel_x, kRedRampLength);
+        blue = blue + fminf(pixel_b, kBlueRampLength);
+        // GammaModulation (:114-144)
+        const float iny = p + kBias;
+        const float rr = iny - vx, gg = iny + vx;
+        const float ratio_r = ratio_of_derivatives(rr, true);
+        const float ratio_g = ratio_of_derivatives(gg, true);
+        gam = gam + 0.5f * (ratio_r + ratio_g);
+      }
+    }
+    hf = octet_sum(hf);
+    red = octet_sum(red);
+    blue = octet_sum(blue);
+    gam = octet_sum(gam);
+    if (blk_valid) {
+      out_val = fma32(hf, -2.0052193233688884f / 112, out_val);
+      {
+        const float kStrengthMul = (float)2.177823400325309;
+        const double butteraugli_target = (double)A.distance;
+        const float strength = (float)(kStrengthMul * (1.0f - 0.25f * butteraugli_target));
+        if (!(strength < 0)) {
+          const float red_strength = strength * 5.992297772961519f;
+          const float blue_strength = strength;
+          const float offset = strength * -0.009174542291185913f;
+          out_val = out_val + offset;
+          const float ratio = 30.610615782142737f;
+          float overall_red = fminf(red, ratio * kRedRampLength);
+          overall_red = overall_red * (red_strength / ratio);
+          float overall_blue = fminf(blue, ratio * kBlueRampLength);
+          overall_blue = overall_blue * (blue_strength / ratio);
+          out_val = overall_red + (overall_blue + out_val);
+        }
+      }
+      {
+        const float overall_ratio = gam * (1.0f / 64);
+        const float kGam = -0.15526878023684174f * 0.693147180559945f;
+        out_val = fma32(kGam, fast_log2f(overall_ratio), out_val);
+      }
+      // PerBlockModulations tail (:249-285) + raw quant (:518-534)
+      const float kAcQuant = 0.8294f;
+      const float scale = div_normal(kAcQuant, A.distance);
+      const float base_level = 0.5f * scale;
+      float dampen = 1.0f;
+      if (A.distance >= 7.0f) {
+        dampen = 1.0f - ((A.distance - 7.0f) / (14.0f - 7.0f));
+        if (dampen < 0) dampen = 0;
+      }
+      const float mul = scale * dampen;
+      const float add = (1.0f - dampen) * base_level;
+      const float qf = fast_pow2f(out_val * 1.442695041f) * mul + add;
+      if (l == 0) {
+        S.aq[oct] = qf;
+        int v = (int)(qf * A.inv_scale + 0.5f);
+        v = v < 1 ? 1 : v > 255 ? 255 : v;
+        S.raw_quant[oct] = (uint8_t)v;
+        S.strat[oct] = 1;  // DCT8, first block (FillDCT8)
+        if (kDebug && A.dbg_qf) {
+          const uint32_t pos = (uint32_t)(by_img0 + oby) * bstride + (uint32_t)(bx_img0 + obx);
+          A.dbg_qf[pos] = qf;
+          A.dbg_mask[pos] = S.mask[oct];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  JXLT_MARK(3);
+
+  // ---- P6a: candidate two-block transforms (enc_ac_strategy.cc:62-66) -------
+  // Waves 0-3 take the 32 DCT16X8 candidates, waves 4-7 the 32 DCT8X16 candidates.
+  // Done before chroma-from-luma so that afterwards no pixel is needed any more; the
+  // coefficients stay in registers for the entropy estimate and for P8.
+  float* const tsc = &S.rowsum[0] + oct * kTransposePitch;  // octet's transpose scratch (AQ buffers are dead)
+  float c16x[16], c16y[16], c16b[16];
+  const bool search = (A.flags & 1u) == 0;
+  const int cand = oct & 31;           // candidate index within its type
+  const int cell = cand >> 1;          // 2x2 cell index (4x4 cells per tile)
+  const int ccx = (cell & 3) * 2, ccy = (cell >> 2) * 2;  // cell origin (tile blocks)
+  const bool is_tall = oct < 32;       // DCT16X8 (16 rows x 8 cols)
+  const int cbx = is_tall ? ccx + (cand & 1) : ccx;       // candidate's first block
+  const int cby = is_tall ? ccy : ccy + (cand & 1);
+  const bool cell_valid = search && (ccx + 1 < nbx) && (ccy + 1 < nby);
+  if (cell_valid) {
+    const float* pxp = &S.x[(cby * 8) * kXYPitch + cbx * 8 + kHalo];
+    const float* pyp = &S.y[(cby * 8) * kXYPitch + cbx * 8 + kHalo];
+    const float* pbp = &S.b[(cby * 8) * kBPitch + cbx * 8];
+    // (scheduling fences: interleaving the three independent transforms would triple the
+    // live registers and spill)
+    if (is_tall) {
+      block_dct16x8(pxp, kXYPitch, l, tsc, c16x);
+      JXLT_SCHED_FENCE();
+      block_dct16x8(pyp, kXYPitch, l, tsc, c16y);
+      JXLT_SCHED_FENCE();
+      block_dct16x8(pbp, kBPitch, l, tsc, c16b);
+    } else {
+      block_dct8x16(pxp, kXYPitch, l, tsc, c16x);
+      JXLT_SCHED_FENCE();
+      block_dct8x16(pyp, kXYPitch, l, tsc, c16y);
+      JXLT_SCHED_FENCE();
+      block_dct8x16(pbp, kBPitch, l, tsc, c16b);
+    }
+    JXLT_SCHED_FENCE();
+  }
+  JXLT_MARK(4);
+  // ---- P5: DCT8 of every block (kept in registers) + chroma-from-luma -------
+  // (enc_chroma_from_luma.cc:40-131)
+  float c8x[8], c8y[8], c8b[8];
+  {
+    const float* pxp = &S.x[(oby * 8) * kXYPitch + obx * 8 + kHalo];
+    const float* pyp = &S.y[(oby * 8) * kXYPitch + obx * 8 + kHalo];
+    const float* pbp = &S.b[(oby * 8) * kBPitch + obx * 8];
+    if (blk_valid) {
+      block_dct8x8(pxp, kXYPitch, l, tsc, c8x);
+      JXLT_SCHED_FENCE();
+      block_dct8x8(pyp, kXYPitch, l, tsc, c8y);
+      JXLT_SCHED_FENCE();
+      block_dct8x8(pbp, kBPitch, l, tsc, c8b);
+      JXLT_SCHED_FENCE();
+    } else {
+      // (cross-lane traffic never leaves an octet, so idle octets may skip it)
+#pragma unroll
+      for (int r = 0; r < 8; r++) c8x[r] = c8y[r] = c8b[r] = 0.0f;
+    }
+  }
+  __syncthreads();  // all pixel reads done: the planes are dead from here on
+  JXLT_MARK(5);
+  // ---- P5b: chroma-from-luma (enc_chroma_from_luma.cc:40-131) ----------------
+  {
+    // Every octet publishes the terms of its block, a = m/84 and b = base*m - s with
+    // m = Y*qm, s = C*qm (:49-53,117-120); then four sequential per-lane fma chains
+    // (ca = sum a*a, cb = sum a*b, for X and for B) run over the blocks in raster order.
+    // Term layout: [block][lane l][chunk], a chunk = (a, b) of two consecutive rows of one
+    // chroma channel (chunk = channel * 4 + row / 2), i.e. the eight rows a chain lane needs
+    // from a block are four 16-byte reads.  The chunk slot is XORed with l so that the eight
+    // lanes of an octet hit different banks.
+    float* terms = &S.x[0];
+    // (swizzle key: l for lanes 0-3, l ^ 1 for lanes 4-7 -- a 16-byte LDS load is serviced in 16-lane
+    // groups that pair lanes 0-3 of the X chain with lanes 4-7 of the B chain, MI355X_MICROARCH.md;
+    // with the plain key those read the same banks)
+    const int lsw = l ^ (l >> 2);
+    const float* qm_x = S.inv_w + 0;    // InvMatrix(DCT, 0)
+    const float* qm_b = S.inv_w + 128;  // InvMatrix(DCT, 2)
+    const int nblk = nbx * nby;
+    const float kInvColorFactor = 1.0f / 84;
+    if (blk_valid) {
+      float* dst = &terms[(oby * nbx + obx) * 256 + l * 32];
+#pragma unroll
+      for (int r = 0; r < 8; r += 2) {
+        float4 tx, tb;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int rr = r + h;
+          const bool dc = (rr == 0 && l == 0);  // block_*[0] = 0 (:109-111)
+          const float by_ = dc ? 0.0f : c8y[rr], bx_ = dc ? 0.0f : c8x[rr], bb_ = dc ? 0.0f : c8b[rr];
+          const float qx = qm_x[rr * 8 + l], qb = qm_b[rr * 8 + l];
+          const float m_x = by_ * qx, s_x = bx_ * qx, m_b = by_ * qb, s_b = bb_ * qb;
+          const float ax = kInvColorFactor * m_x, bx2 = 0.0f * m_x - s_x;
+          const float ab = kInvColorFactor * m_b, bb2 = 1.0f * m_b - s_b;
+          if (h == 0) { tx.x = ax; tx.y = bx2; tb.x = ab; tb.y = bb2; }
+          else { tx.z = ax; tx.w = bx2; tb.z = ab; tb.w = bb2; }
+        }
+        *(float4*)&dst[(((r >> 1)) ^ lsw) * 4] = tx;
+        *(float4*)&dst[((4 + (r >> 1)) ^ lsw) * 4] = tb;
+      }
+    }
+    __syncthreads();
+    // Chain lanes: wave 0 lanes 0-15 run ca (X: 0-7, B: 8-15), wave 1 lanes 0-15 run cb.
+    // The 512 fused multiply-adds of a chain are strictly sequential, so these two waves are
+    // the critical path of the workgroup: they run at raised issue priority, and the reads
+    // of block blk + 1 are issued before the arithmetic of block blk.
+    float acc = 0.0f;
+    const int cw = tid >> 6, cl = tid & 63;
+#ifndef JXLT_CFL_PINGPONG
+    // The chains as a RELAY over the four 16-lane rows of the wave.  A row = the 16 chain lanes (X: 8, B: 8); row
+    // k handles every fourth block, and the terms of the next four blocks are requested a whole round of four
+    // blocks ahead of their use -- in registers the other rows' lanes have anyway.  The
+    // sixteen accumulators travel from row to row (0 -> 1 -> 3 -> 2 -> 0) with one v_permlane16_swap /
+    // v_permlane32_swap per block (tools/permlane_probe.hip).  With ping-pong buffers in sixteen lanes the terms
+    // of block blk + 1 were requested only eight dependent multiply-adds before their use: less than an LDS round
+    // trip, and the chains are the workgroup's critical path.
+    const int relay_row = cl >> 4;
+    const int relay_pos = relay_row == 0 ? 0 : relay_row == 1 ? 1 : relay_row == 3 ? 2 : 3;  // place in the relay
+    if (cw < 2) {
+      __builtin_amdgcn_s_setprio(3);
+      const int ch = (cl >> 3) & 1;  // 0: X, 1: B
+      const float* src = terms + l * 32;
+      int slot[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) slot[q] = ((ch * 4 + q) ^ lsw) * 4;
+      const int last = nblk - 1;
+      // Two register sets, used in turn by ROUNDS of four blocks (one per row): at the start of a round every row
+      // requests the block it will handle in the NEXT round -- one wave-wide set of four 16-byte loads, a whole
+      // round (32 dependent multiply-adds and four hops) ahead of its use.
+      float4 ta[4], tb[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) ta[q] = *(const float4*)&src[imin(relay_pos, last) * 256 + slot[q]];
+      auto round4 = [&](const float4* t, int first) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (first + j >= nblk) break;  // (wave-uniform)
+          // every lane runs the eight steps; only the row that holds the accumulators has meaningful ones
+          if (cw == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              acc = fma32(t[q].x, t[q].x, acc);
+              acc = fma32(t[q].z, t[q].z, acc);
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              acc = fma32(t[q].x, t[q].y, acc);
+              acc = fma32(t[q].z, t[q].w, acc);
+            }
+          }
+          // the accumulators move on: rows 0 -> 1 and 3 -> 2 with a 16-lane swap, 1 -> 3 and 2 -> 0 with a 32-lane one
+          const unsigned bits = __float_as_uint(acc);
+          if (j == 0) acc = __uint_as_float(__builtin_amdgcn_permlane16_swap(bits, bits, false, false)[0]);
+          if (j == 1) acc = __uint_as_float(__builtin_amdgcn_permlane32_swap(bits, bits, false, false)[0]);
+          if (j == 2) acc = __uint_as_float(__builtin_amdgcn_permlane16_swap(bits, bits, false, false)[1]);
+          if (j == 3) acc = __uint_as_float(__builtin_amdgcn_permlane32_swap(bits, bits, false, false)[1]);
+        }
+      };
+#pragma clang loop unroll(disable)
+      for (int blk = 0; blk < nblk; blk += 8) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) tb[q] = *(const float4*)&src[imin(blk + 4 + relay_pos, last) * 256 + slot[q]];
+        round4(ta, blk);
+#pragma unroll
+        for (int q = 0; q < 4; q++) ta[q] = *(const float4*)&src[imin(blk + 8 + relay_pos, last) * 256 + slot[q]];
+        round4(tb, blk + 4);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    const int final_pos = nblk & 3;  // where the accumulators are after the last hop
+    const bool chain_lane = cw < 2 && relay_pos == final_pos;
+    const int chain_ch = (cl >> 3) & 1;
+#else
+    if (cw < 2 && cl < 16) {
+      __builtin_amdgcn_s_setprio(3);
+      const int ch = cl >> 3;  // 0: X, 1: B
+      const float* src = terms + l * 32;
+      int slot[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) slot[q] = ((ch * 4 + q) ^ lsw) * 4;
+      // two blocks per iteration, ping-pong buffers (no register copies in the loop)
+      float4 ta[4], tb[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) ta[q] = *(const float4*)&src[slot[q]];
+      const int last = nblk - 1;
+      if (cw == 0) {
+#pragma clang loop unroll(disable)
+        for (int blk = 0; blk < nblk; blk += 2) {
+          const int n1 = imin(blk + 1, last), n2 = imin(blk + 2, last);
+#pragma unroll
+          for (int q = 0; q < 4; q++) tb[q] = *(const float4*)&src[n1 * 256 + slot[q]];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            acc = fma32(ta[q].x, ta[q].x, acc);
+            acc = fma32(ta[q].z, ta[q].z, acc);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) ta[q] = *(const float4*)&src[n2 * 256 + slot[q]];
+          if (blk + 1 < nblk) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              acc = fma32(tb[q].x, tb[q].x, acc);
+              acc = fma32(tb[q].z, tb[q].z, acc);
+            }
+          }
+        }
+      } else {
+#pragma clang loop unroll(disable)
+        for (int blk = 0; blk < nblk; blk += 2) {
+          const int n1 = imin(blk + 1, last), n2 = imin(blk + 2, last);
+#pragma unroll
+          for (int q = 0; q < 4; q++) tb[q] = *(const float4*)&src[n1 * 256 + slot[q]];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            acc = fma32(ta[q].x, ta[q].y, acc);
+            acc = fma32(ta[q].z, ta[q].w, acc);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) ta[q] = *(const float4*)&src[n2 * 256 + slot[q]];
+          if (blk + 1 < nblk) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              acc = fma32(tb[q].x, tb[q].y, acc);
+              acc = fma32(tb[q].z, tb[q].w, acc);
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    const bool chain_lane = cw < 2 && cl < 16;
+    const int chain_ch = cl >> 3;
+#endif
+    const float total = octet_sum(acc);
+    // cfl_sum: ca_x, cb_x, ca_b, cb_b
+    if (chain_lane && l == 0) S.cfl_sum[chain_ch * 2 + cw] = total;
+    __syncthreads();
+    if (tid < 2) {  // FindBestMultiplier tail (:56-61)
+      const float kDistanceMultiplierAC = 1e-3f;
+      const float num = (float)(nblk * 64);
+      float xq = -S.cfl_sum[tid * 2 + 1] / (S.cfl_sum[tid * 2] + num * kDistanceMultiplierAC * 0.5f);
+      xq = fmaxf(-128.0f, fminf(127.0f, roundf(xq)));
+      S.cmap[tid] = (int)xq;
+    }
+  }
+  __syncthreads();
+  JXLT_MARK(10);
+  const int ytox = S.cmap[0], ytob = S.cmap[1];
+  const float kInvColorFactorF = 1.0f / 84;
+  const float cmap_x = (float)ytox * kInvColorFactorF;           // YtoXRatio
+  const float cmap_b = 1.0f + (float)ytob * kInvColorFactorF;    // YtoBRatio
+  if (tid == 0) {
+    A.ytox[(size_t)ty_img * A.g.xsize_tiles + tx_img] = (int8_t)ytox;
+    A.ytob[(size_t)ty_img * A.g.xsize_tiles + tx_img] = (int8_t)ytob;
+  }
+
+  // ---- P6b: entropy estimates (enc_ac_strategy.cc:68-146,187-212) -----------
+  float qmax = 0.0f;  // largest quantised magnitude whose root was taken from the table
+  if (search) {
+    // DCT8 estimate for this octet's own block
+    if (blk_valid) {
+      const float e = estimate_entropy<8, kLutRoots>(c8x, c8y, c8b, S.inv_w + 0, S.inv_w + 64, S.inv_w + 128, l,
+                                                     fmaxf(0.0f, S.aq[oct]), fmaxf(0.0f, S.mask[oct]), cmap_x,
+                                                     cmap_b, A.distance, S.sqrt_lut, &qmax);
+      const float k8x8mul1 = (float)(-0.55 * 0.75f);
+      const float k8x8mul2 = 1.0735757687292623f * 0.75f;
+      const float k8x8base = (float)1.4;
+      const float mul8x8 = k8x8mul2 + div_normal(k8x8mul1, A.strategy_distance + k8x8base);
+      float e8 = 3.0f * mul8x8;
+      e8 += mul8x8 * e;
+      if (l == 0) S.transpose_pad[((oby >> 1) * 4 + (obx >> 1)) * 8 + (oby & 1) * 2 + (obx & 1)] = e8;
+    }
+    // The DCT8 coefficients are needed again in P8; they wait in the (now dead) term area
+    // while the two-block estimate runs, which would otherwise spill.
+    float* park = &S.x[0] + tid;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      park[(r)*kTileThreads] = c8x[r];
+      park[(8 + r) * kTileThreads] = c8y[r];
+      park[(16 + r) * kTileThreads] = c8b[r];
+    }
+    JXLT_SCHED_FENCE();
+    if (cell_valid) {
+      const int o2 = is_tall ? 8 : 1;  // second covered block in the 8x8 tile grid
+      const int bi = cby * 8 + cbx;
+      const float quant = fmaxf(fmaxf(0.0f, S.aq[bi]), S.aq[bi + o2]);
+      const float masking = fmaxf(fmaxf(0.0f, S.mask[bi]), S.mask[bi + o2]);
+      const int toff = is_tall ? 3 : 6;
+      float qmax16 = 0.0f;
+      const float e = estimate_entropy<16, kLutRoots>(c16x, c16y, c16b, S.inv_w + quant_table_offset(toff),
+                                                      S.inv_w + quant_table_offset(toff + 1),
+                                                      S.inv_w + quant_table_offset(toff + 2), l, quant, masking,
+                                                      cmap_x, cmap_b, A.distance, S.sqrt_lut, &qmax16);
+      qmax = fmaxf(qmax, qmax16);
+      const float k8X16mul1 = (float)-0.55, k8X16mul2 = (float)0.9019587899705066,
+                  k8X16base = (float)1.6;
+      const float mul16x8 = k8X16mul2 + div_normal(k8X16mul1, A.strategy_distance + k8X16base);
+      if (l == 0) S.transpose_pad[cell * 8 + (is_tall ? 4 : 6) + (cand & 1)] = mul16x8 * e;
+    }
+    JXLT_SCHED_FENCE();
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      c8x[r] = park[(r)*kTileThreads];
+      c8y[r] = park[(8 + r) * kTileThreads];
+      c8b[r] = park[(16 + r) * kTileThreads];
+    }
+  }
+  // A magnitude beyond the root table invalidates this tile's estimates: the frame is then
+  // redone by the kernel variant that computes every root (jxlt_capi.hip; practically never).
+  if (kLutRoots && (qmax >= (float)kSqrtLutSize || (A.flags & 0x1000u) != 0)) A.lut_overflow[0] = 1u;  // (0x1000: test hook)
+  __syncthreads();
+  JXLT_MARK(6);
+  // ---- P7: decision (:213-237) + AdjustQuantField (:240-266) ------------------
+  if (search && tid < 16) {
+    const int cx = (tid & 3) * 2, cy = (tid >> 2) * 2;
+    if (cx + 1 < nbx && cy + 1 < nby) {
+      const float* e = &S.transpose_pad[tid * 8];
+      const float e00 = e[0], e01 = e[1], e10 = e[2], e11 = e[3];
+      const float l16 = e[4], r16 = e[5], t16 = e[6], b16 = e[7];
+      const float cost16x8 = fminf(l16, e00 + e10) + fminf(r16, e01 + e11);
+      const float cost8x16 = fminf(t16, e00 + e01) + fminf(b16, e10 + e11);
+      const int b00 = cy * 8 + cx;
+      if (cost16x8 < cost8x16) {
+        if (l16 < e00 + e10) { S.strat[b00] = (1 << 1) | 1; S.strat[b00 + 8] = (1 << 1); }
+        if (r16 < e01 + e11) { S.strat[b00 + 1] = (1 << 1) | 1; S.strat[b00 + 9] = (1 << 1); }
+      } else {
+        if (t16 < e00 + e01) { S.strat[b00] = (2 << 1) | 1; S.strat[b00 + 1] = (2 << 1); }
+        if (b16 < e10 + e11) { S.strat[b00 + 8] = (2 << 1) | 1; S.strat[b00 + 9] = (2 << 1); }
+      }
+      if (kDebug && A.dbg_ent8) {
+        const size_t cells_x = (size_t)A.g.xsize_blocks / 2 + 1;
+        float* d = A.dbg_ent8 + (((size_t)(by_img0 + cy) / 2) * cells_x + (size_t)(bx_img0 + cx) / 2) * 8;
+        for (int k = 0; k < 8; k++) d[k] = e[k];
+      }
+      // AdjustQuantField for the cell's transforms
+      for (int k = 0; k < 4; k++) {
+        const int bi = b00 + (k >> 1) * 8 + (k & 1);
+        const uint8_t a = S.strat[bi];
+        if (!(a & 1) || (a >> 1) == 0) continue;
+        const int o2 = (a >> 1) == 1 ? 8 : 1;
+        const uint8_t m = S.raw_quant[bi] > S.raw_quant[bi + o2] ? S.raw_quant[bi] : S.raw_quant[bi + o2];
+        S.raw_quant[bi] = m;
+        S.raw_quant[bi + o2] = m;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 64 && (tid & 7) < nbx && (tid >> 3) < nby) {
+    const uint32_t pos = (uint32_t)(by_img0 + (tid >> 3)) * bstride + (uint32_t)(bx_img0 + (tid & 7));
+    A.strategy[pos] = S.strat[tid];
+    if (S.strat[tid] & 1) atomicAdd(&S.nfirst, 1u);
+    A.raw_quant[pos] = S.raw_quant[tid];
+  }
+  // All pixel reads were done before P5b (the transforms live in registers): from here on the
+  // XYB planes are reused as the quantised-coefficient staging area.  No barrier is needed
+  // between the stores above (they read S.strat / S.raw_quant, final since the barrier before
+  // them) and P8; S.nfirst is read after later barriers.
+#ifdef JXLT_P7_SECOND_BARRIER
+  __syncthreads();
+#endif
+  JXLT_MARK(7);
+  // ---- P8a: the coefficients of the selected transforms -> LDS ------------------
+  // The transforms that the decision kept are quantised in SCAN ORDER by other lanes than the ones that hold
+  // them: per tile every block belongs to exactly one selected transform, so "one wave pass = the 64 scan
+  // positions of one block and channel" always fills its lanes, whatever the mix of strategies -- while the
+  // octets that hold the coefficients are, by construction, idle for every candidate that lost (half of
+  // the two-block candidates at best).  Natural layout [block][channel x, y, b][64] of floats, the second
+  // half of a two-block transform in its second block's slot.
+  float* const stagef = &S.x[0];
+  {
+    // (within a block and channel the slot of coefficient (row r, column l) is l * 8 + r: a lane's eight rows
+    // are two 16-byte stores)
+    auto put8 = [&](float* d, const float* v) {
+      float4 lo, hi;
+      lo.x = v[0]; lo.y = v[1]; lo.z = v[2]; lo.w = v[3];
+      hi.x = v[4]; hi.y = v[5]; hi.z = v[6]; hi.w = v[7];
+      *reinterpret_cast<float4*>(d) = lo;
+      *reinterpret_cast<float4*>(d + 4) = hi;
+    };
+    if (blk_valid && S.strat[oct] == 1) {  // this octet's own block stayed DCT8
+      float* d = stagef + oct * kStageStrideF + l * 8;
+      put8(d, c8x);
+      put8(d + 64, c8y);
+      put8(d + 128, c8b);
+    }
+    const int bi = cby * 8 + cbx;
+    if (cell_valid && S.strat[bi] == (uint8_t)(((is_tall ? 1 : 2) << 1) | 1)) {  // its candidate was selected
+      float* da = stagef + bi * kStageStrideF + l * 8;
+      float* db = stagef + (bi + (is_tall ? 8 : 1)) * kStageStrideF + l * 8;
+      put8(da, c16x);
+      put8(da + 64, c16y);
+      put8(da + 128, c16b);
+      put8(db, c16x + 8);
+      put8(db + 64, c16y + 8);
+      put8(db + 128, c16b + 8);
+    }
+  }
+  __syncthreads();
+  JXLT_MARK(8);
+
+  // ---- P8b + P9: quantise, DC, nzeros, scan-order store (enc_group.cc:166-443) --
+  // One wave pass = one selected transform: lane = scan position (the lane's natural coefficient index, and
+  // with it its quantisation weights and thresholds, are per-lane constants of the strategy class).  The
+  // tile's transforms are dealt out to the waves round robin (in raster order of their first blocks), so every
+  // wave has the same number of them whatever the mix of strategies.  Per transform only the per-coefficient
+  // work is done at once; the DC values and the per-block outputs are collected per lane (lane j = the wave's
+  // j-th transform) and finished in one pass at the end.  Everything else is wave-uniform (scalar unit).
+  {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    uint32_t wave_tokens = 0;
+    struct LaneConsts {
+      float inv[3];  // InvMatrix of x, y, b at the lane's coefficient
+      float ydq;     // dequantisation weight of y
+      float thr[3];  // zeroing threshold of x, y, b (enc_group.cc:227-242)
+    };
+    // (per scan position and position class: tables built by the host, DeviceTables::scan_consts)
+    auto consts_of = [&](int cls) {
+      LaneConsts k;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        k.inv[c] = A.tab->scan_consts[cls][c][lane];
+        k.thr[c] = A.tab->scan_consts[cls][4 + c][lane];
+      }
+      k.ydq = A.tab->scan_consts[cls][3][lane];
+      return k;
+    };
+    const LaneConsts k8 = consts_of(0), k16a = consts_of(1), k16b = consts_of(2);
+    const int slot8 = A.tab->scan_slot[0][lane], slot16a = A.tab->scan_slot[1][lane], slot16b = A.tab->scan_slot[2][lane];
+    // lane b knows block b of the tile; the first blocks of the tile's transforms as a mask
+    const bool lane_blk_valid = (lane & 7) < nbx && (lane >> 3) < nby;
+    const int strat_of_lane = lane_blk_valid ? (int)S.strat[lane] : 0;
+    const int quant_of_lane = (int)S.raw_quant[lane];
+    const float inv_qac_of_lane = A.tab->inv_qac[quant_of_lane];  // (one vector load: no scalar load per transform)
+    // (transform number t, in raster order of the first blocks, goes to wave t mod 8: lane b finds its block's
+    // number as the count of first blocks below it, and the wave's own blocks come out of one more ballot)
+    const unsigned long long firsts = __ballot(strat_of_lane & 1);
+    const int rank_of_lane =
+        (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(firsts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)firsts, 0u));
+    unsigned long long todo = __ballot((strat_of_lane & 1) != 0 && (rank_of_lane & 7) == wave);
+    // staged coefficients of the transform whose first block is b: [half a / b][channel x, y, b]
+    auto fetch = [&](int b, int st, float (*v)[3]) {
+      const int o2 = st == 1 ? 8 : 1;
+      const int i0 = st == 0 ? slot8 : slot16a, i1 = slot16b;  // (bit 6: the transform's second block)
+      const int src0 = (i0 < 64 ? b : b + o2) * kStageStrideF + (i0 & 63);
+      const int src1 = (i1 < 64 ? b : b + o2) * kStageStrideF + (i1 & 63);
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        v[0][c] = stagef[src0 + c * 64];
+        v[1][c] = st != 0 ? stagef[src1 + c * 64] : 0.0f;
+      }
+    };
+    auto scalar_lane = [&](int v, int l_) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l_)); };
+    // collected per transform (lane j = the wave's j-th transform)
+    // (the two lowest frequencies of what was quantised go through LDS: lanes 0 and 1 store them, lane j reads
+    // its transform's six values at the end -- [wave][transform][channel][2] floats behind the staging area)
+    float* const dc_stage = stagef + 64 * kStageStrideF;            // [transform][channel][2]
+    int* const tr_info = reinterpret_cast<int*>(dc_stage + 64 * 6);  // [3][transform]: block | strategy << 8, nzeros, nscan
+    float* const lane_dump = dc_stage + 64 * 6 + 3 * 64 + lane;      // where the stores of the lanes that have nothing to say go
+    // (lane 0 files a wave-uniform value under the transform's number)
+    auto file_int = [&](int which, int t, int v) {
+      (lane == 0 ? tr_info + which * 64 + t : reinterpret_cast<int*>(lane_dump))[0] = v;
+    };
+    // (a use of the loaded value here: the wait for it belongs in front of the loop -- inside, where loads and
+    // stores share one counter, it would wait for the previous transform's coefficient stores every time)
+    JXLT_TOUCH_VGPR(inv_qac_of_lane);
+    for (const LaneConsts* k : {&k8, &k16a, &k16b}) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        JXLT_TOUCH_VGPR(k->inv[c]);
+        JXLT_TOUCH_VGPR(k->thr[c]);
+      }
+      JXLT_TOUCH_VGPR(k->ydq);
+    }
+    JXLT_TOUCH_VGPR(slot8);
+    JXLT_TOUCH_VGPR(slot16a);
+    JXLT_TOUCH_VGPR(slot16b);
+    int ntrans = 0;
+    float next_v[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+    int next_b = todo != 0 ? (int)__builtin_ctzll(todo) : -1, next_st = 0;
+    if (next_b >= 0) {
+      next_st = scalar_lane(strat_of_lane, next_b) >> 1;
+      fetch(next_b, next_st, next_v);
+    }
+    while (next_b >= 0) {
+      const int b = __builtin_amdgcn_readfirstlane(next_b), st = __builtin_amdgcn_readfirstlane(next_st);
+      float in[2][3];
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) in[h][c] = next_v[h][c];
+      todo &= todo - 1;
+      next_b = todo != 0 ? (int)__builtin_ctzll(todo) : -1;
+      if (next_b >= 0) {
+        next_st = scalar_lane(strat_of_lane, next_b) >> 1;
+        fetch(next_b, next_st, next_v);  // (requested before this transform is worked on)
+      }
+      const bool two = st != 0;
+      const int covered = two ? 2 : 1;
+      const int quant_ac = scalar_lane(quant_of_lane, b);
+      const float qac = A.scale * quant_ac;
+      const float inv_qac = __int_as_float(scalar_lane(__float_as_int(inv_qac_of_lane), b));
+      const uint32_t pos0 = (uint32_t)(by_img0 + (b >> 3)) * bstride + (uint32_t)(bx_img0 + (b & 7));
+      const uint32_t pos1 = pos0 + (st == 1 ? bstride : 1u);
+      // per scan position: y first (its round trip feeds the chroma channels, :392-425)
+      float quant[2][3], cur0[3];  // quantised values (integer-valued); first half of what was quantised
+      auto half = [&](const LaneConsts& k, const float* v, float* q, float* cur) {
+        auto quantise = [&](int c, float x, float quantv) {
+          const float qq = k.inv[c] * quantv;
+          const float val = qq * x;
+          return fabsf(val) >= k.thr[c] ? rintf(val) : 0.0f;
+        };
+        q[1] = quantise(1, v[1], qac * 1.0f);
+        const float y_back = (adjust_quant_bias_y(q[1]) * k.ydq) * inv_qac;
+        const float cx_ = nfma32(cmap_x, y_back, v[0]), cb_ = nfma32(cmap_b, y_back, v[2]);
+        q[0] = quantise(0, cx_, qac * A.x_qm_mul);
+        q[2] = quantise(2, cb_, qac * (float)1.0);
+        if (cur) {
+          cur[0] = cx_;
+          cur[1] = v[1];
+          cur[2] = cb_;
+        }
+      };
+      if (two) {
+        half(k16a, in[0], quant[0], cur0);
+        half(k16b, in[1], quant[1], nullptr);
+      } else {
+        half(k8, in[0], quant[0], cur0);
+        quant[1][0] = quant[1][1] = quant[1][2] = 0.0f;
+      }
+      const int t = wave + 8 * ntrans;  // the transform's number in the tile
+      file_int(0, t, b | (st << 8));
+      int nz_packed = 0, nscan_packed = 0;
+      // nzeros (enc_group.cc:51-148) and the scan position behind the last nonzero coefficient: the six ballots
+      // first, then the scalar arithmetic on them, then the stores (no compare -> scalar -> compare round trip
+      // per channel)
+      const unsigned long long llf_mask = covered == 2 ? 3ull : 1ull;  // scan positions < covered: coded as DC
+      unsigned long long m0[3], m1[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        (lane < 2 ? dc_stage + (t * 3 + c) * 2 + lane : lane_dump)[0] = cur0[c];
+        m0[c] = __ballot(quant[0][c] != 0.0f) & ~llf_mask;
+        m1[c] = two ? __ballot(quant[1][c] != 0.0f) : 0ull;
+      }
+      int nscan[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const int nzeros = __popcll(m0[c]) + __popcll(m1[c]);
+        nscan[c] = m1[c] != 0 ? 128 - __clzll((long long)m1[c]) : m0[c] != 0 ? 64 - __clzll((long long)m0[c]) : 0;
+        nz_packed |= nzeros << (8 * c);
+        nscan_packed |= nscan[c] << (8 * c);
+        wave_tokens += 1 + (nscan[c] > covered ? nscan[c] - covered : 0);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        // (the tokeniser takes "nonzeros still to come" and "previous coefficient nonzero" from these masks:
+        // lanes 0 and 1 store the two words)
+        if (lane < 2) A.blk_nzmask[(size_t)(pos0 * 3 + c) * 2 + lane] = lane == 0 ? m0[c] : m1[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        // only scan positions below nscan (= up to the last nonzero) are ever read again
+        int16_t* const out0 = A.coef_scan + (size_t)(pos0 * 3 + c) * 64;
+        int16_t* const out1 = A.coef_scan + (size_t)(pos1 * 3 + c) * 64;
+        if (lane < nscan[c]) out0[lane] = (int16_t)(int)quant[0][c];
+        if (64 + lane < nscan[c]) out1[lane] = (int16_t)(int)quant[1][c];
+      }
+      file_int(1, t, nz_packed);
+      file_int(2, t, nscan_packed);
+      ntrans++;
+    }
+    if (lane == 0 && wave_tokens) atomicAdd(&S.ntok, wave_tokens);
+  }
+  __syncthreads();
+  // the tile's transforms side by side, one per lane of wave 0: DC of the covered blocks (:392-443) and the
+  // per-block outputs
+  if (tid < 64) {
+    const int lane = tid;
+    float* const dc_stage = stagef + 64 * kStageStrideF;
+    const int* const tr_info = reinterpret_cast<const int*>(dc_stage + 64 * 6);
+    const bool lane_blk_valid = (lane & 7) < nbx && (lane >> 3) < nby;
+    const int ntrans = __popcll(__ballot(lane_blk_valid && (S.strat[lane] & 1) != 0));
+    const int col_block = tr_info[lane], col_nz = tr_info[64 + lane], col_nscan = tr_info[128 + lane];
+    if (lane < ntrans) {
+      const int b = col_block & 0xFF, st = col_block >> 8;
+      const bool two = st != 0;
+      const uint32_t pos0 = (uint32_t)(by_img0 + (b >> 3)) * bstride + (uint32_t)(bx_img0 + (b & 7));
+      const uint32_t pos1 = pos0 + (st == 1 ? bstride : 1u);
+      const float kScale1 = (float)0.901764195028874394;
+      const float kInvDCQuant[3] = {4096.0f, 512.0f, 256.0f};
+      int16_t dcy_a = 0, dcy_b = 0;
+#pragma unroll
+      for (int ci = 0; ci < 3; ci++) {
+        const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;  // y first: the chroma DC is coded relative to it
+        const float c0 = dc_stage[(lane * 3 + c) * 2], c1 = dc_stage[(lane * 3 + c) * 2 + 1];
+        const float b0 = c0 * 1.0f * 1.0f, b1 = c1 * 1.0f * kScale1;
+        const float d_a = two ? b0 + b1 : c0, d_b = two ? b0 - b1 : 0.0f;
+        int16_t qdc_a, qdc_b;
+        if (c == 1) {
+          const float inv_factor_y = kInvDCQuant[1] * A.scale_dc;
+          qdc_a = dcy_a = (int16_t)roundf(inv_factor_y * d_a);
+          qdc_b = dcy_b = (int16_t)roundf(inv_factor_y * d_b);
+        } else {
+          const float inv_factor = (c == 0 ? kInvDCQuant[0] : kInvDCQuant[2]) * A.scale_dc;
+          const float cfl_factor = c == 0 ? 0.0f : kInvDCQuant[2] * (1.0f / kInvDCQuant[1]);
+          qdc_a = (int16_t)roundf(d_a * inv_factor - dcy_a * cfl_factor);
+          qdc_b = (int16_t)roundf(d_b * inv_factor - dcy_b * cfl_factor);
+        }
+        // (select, not A.nzgrid[c] / A.quant_dc[c]: indexing a kernel-argument array by a runtime value
+        // would force the argument block into scratch memory)
+        uint8_t* nzg = c == 0 ? A.nzgrid[0] : c == 1 ? A.nzgrid[1] : A.nzgrid[2];
+        int16_t* qdc = c == 0 ? A.quant_dc[0] : c == 1 ? A.quant_dc[1] : A.quant_dc[2];
+        const int nzeros = (col_nz >> (8 * c)) & 0xFF;
+        qdc[pos0] = qdc_a;
+        A.blk_nz[pos0 * 3 + c] = (uint8_t)nzeros;
+        A.blk_nscan[pos0 * 3 + c] = (uint8_t)((col_nscan >> (8 * c)) & 0xFF);
+        if (!two) {
+          nzg[pos0] = (uint8_t)nzeros;
+        } else {
+          qdc[pos1] = qdc_b;
+          const uint8_t shifted = (uint8_t)((nzeros + 1) >> 1);
+          nzg[pos0] = shifted;
+          nzg[pos1] = shifted;
+        }
+      }
+    }
+  }
+  JXLT_MARK(9);
+  if (tid == 0) {
+    const int group = (ty_img >> 2) * A.g.xsize_groups + gx;
+    atomicAdd(&A.group_ntok[group], S.ntok);
+    const int dcg = (ty_img >> 5) * ((A.g.xsize + 2047) / 2048) + (tx_img >> 5);
+    atomicAdd(&A.dc_nac[dcg], S.nfirst);
+  }
+#undef JXLT_MARK
+#undef JXLT_STOP
+#undef SX
+#undef SY
+}
+
+// tile_kernel: roots of the entropy estimate from the LDS table (the product path);
+// tile_kernel_exact_roots: every root computed -- the same results, needed only for frames in
+// which tile_kernel met a quantised magnitude beyond the table.
+__global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A) { tile_kernel_body<true, false>(A); }
+__global__ void __launch_bounds__(kTileThreads, 4) tile_kernel_debug(const TileArgs A) { tile_kernel_body<true, true>(A); }
+__global__ void __launch_bounds__(kTileThreads, 4) tile_kernel_exact_roots(const TileArgs A) {
+  tile_kernel_body<false, true>(A);
+}
+
+}  // namespace jxlt_dev
+
+#endif  // JXLT_TILE_KERNEL_H_

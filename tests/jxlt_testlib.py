@@ -59,8 +59,7 @@ def build_sim(tiny_root_table=False):
     d = ROOT / "tests" / "hipsim"
     name = "libjxlt_sim_lut16.so" if tiny_root_table else "libjxlt_sim.so"
     out = d / name
-    srcs = [d / "sim_encode.cc", d / "hip" / "hip_runtime.h", PKG / "csrc" / "jxlt_device.h",
-            PKG / "csrc" / "jxlt_host_tables.h", PKG / "csrc" / "jxlt_tables.h"]
+    srcs = [d / "sim_encode.cc", d / "hip" / "hip_runtime.h"] + sorted((PKG / "csrc").glob("*.h"))
     if not out.exists() or any(s.stat().st_mtime > out.stat().st_mtime for s in srcs):
         # -Bsymbolic/hidden visibility: the kernels' names also exist (as HIP launch stubs) in
         # libjxltiny_hip.so; the simulator must bind to its own definitions.

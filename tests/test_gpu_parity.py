@@ -419,7 +419,7 @@ def test_context_strategy_distance_survives_host_entry_points(built, enc):
 
 def test_hardware_shortcuts_are_exact_on_this_gpu():
     """tile_kernel replaces two generic IEEE sequences by shorter ones whose exactness depends on
-    the accuracy of this GPU's v_rcp_f32 (jxlt_device.h: rcp_int_exact).  tools/rcp_probe checks
+    the accuracy of this GPU's v_rcp_f32 (jxlt_device_common.h: rcp_int_exact).  tools/rcp_probe checks
     the shortcut against IEEE division for every integer-valued float the quantiser can produce
     (all 2^32 - 1 non-zero int32 values); variant 2 is the one the kernel uses."""
     import pathlib
@@ -437,7 +437,7 @@ def test_hardware_shortcuts_are_exact_on_this_gpu():
 
 def test_short_division_equals_ieee_on_this_gpu():
     """The kernels divide with v_rcp_f32 + the refinement steps of the IEEE expansion, without its operand
-    scaling and fix-up (jxlt_device.h: div_normal).  tools/div_probe compares that with the compiler's
+    scaling and fix-up (jxlt_device_common.h: div_normal).  tools/div_probe compares that with the compiler's
     division on 2^32 operand pairs (magnitudes 2^-40 .. 2^40) and on reciprocals."""
     import pathlib
     root = pathlib.Path(__file__).resolve().parent.parent
