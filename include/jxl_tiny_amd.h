@@ -204,6 +204,12 @@ int jxlt_pack_measure(jxlt_context* ctx, const uint32_t* dc_code_table, const ui
  * while the device still tokenises the AC groups, so their packing fills the time the host needs for
  * the AC code).  A later jxlt_pack_measure takes NULL for that kind's table and does not repeat it. */
 int jxlt_pack_measure_begin(jxlt_context* ctx, int kind, const uint32_t* code_table);
+/* Waits for a pass started with jxlt_pack_measure_begin and returns that kind's section sizes.  With
+ * jxlt_pack_sections_place(kind) behind it the sections of one kind leave for the host while the other kind's
+ * are still being measured: the DC-group sections' position in the codestream does not depend on the AC code
+ * (enc_frame.cc:805-816: DC global, DC groups, AC global, AC groups), and they are a good part of the bytes.
+ * jxlt_output_buffer keeps the buffer's contents when a later call makes it grow. */
+int jxlt_pack_measured(jxlt_context* ctx, int kind, jxlt_packed_sections* out);
 int jxlt_pack_write(jxlt_context* ctx, uint8_t* dc_dst, uint8_t* ac_dst);
 
 /* Timing of the device stages of the last jxlt_encode_enqueue (HIP events on the context's

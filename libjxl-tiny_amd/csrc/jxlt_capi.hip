@@ -108,7 +108,7 @@ struct jxlt_context {
     bool planned = false;          // the frame's tile plan (count / scan / plan kernels) has been queued
     // The writing kernels are queued right behind the measuring kernels (they need nothing from
     // the host): launch i covers tiles [launch_t0[i], launch_t0[i + 1]) and signals launch_done[i].
-    static constexpr int kMaxLaunches = 6;
+    static constexpr int kMaxLaunches = 12;
     int launches = 0;
     uint32_t launch_t0[kMaxLaunches + 1] = {};
     hipEvent_t launch_done[kMaxLaunches] = {};
@@ -1224,7 +1224,8 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
     return rc;
   const PackTileArgs P = TileArgsOf(ctx, kind, nsec);
   const unsigned sec_blocks = (unsigned)((nsec + 255) / 256);
-  hipLaunchKernelGGL(pack_tile_measure_kernel, dim3((unsigned)((max_tiles + kPackTilesPerGroup - 1) / kPackTilesPerGroup)),
+  hipLaunchKernelGGL(pack_tile_measure_kernel,
+                     dim3((unsigned)((max_tiles + kPackMeasureTilesPerGroup - 1) / kPackMeasureTilesPerGroup)),
                      dim3(kPackThreads), 0, ctx->stream, P);
   hipLaunchKernelGGL(pack_tile_offsets_kernel, dim3(sec_blocks), dim3(256), 0, ctx->stream, P);
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, (const uint32_t*)ps.sec_bytes.p,
@@ -1243,12 +1244,21 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
   // queued right here, in a few launches over equal shares of the tile range (an upper bound: the
   // kernel clamps to the real tile count); the host picks the section sizes up meanwhile and
   // later only adds the copies (EnqueueCopies).
-  const int want = kind == 0 ? 1 : 5;
+  // (experiment knobs, tools/: JXLT_PACK_LAUNCHES=<n>, JXLT_PACK_SHRINK=<percent>)
+  static const int ac_launches = [] {
+    const char* e = getenv("JXLT_PACK_LAUNCHES");
+    return e ? std::max(1, std::min(atoi(e), (int)jxlt_context::PackSet::kMaxLaunches)) : 5;
+  }();
+  static const double shrink = [] {
+    const char* e = getenv("JXLT_PACK_SHRINK");
+    return e ? atoi(e) / 100.0 : 0.4;
+  }();
+  const int want = kind == 0 ? 1 : ac_launches;
   ps.launches = (int)std::min<size_t>((size_t)want, std::max<size_t>(1, max_tiles / 64));
   // (shrinking shares: the copy of the last share is the only one nothing overlaps)
   for (int i = 0; i <= ps.launches; i++) {
     const double x = (double)i / ps.launches;
-    ps.launch_t0[i] = i == ps.launches ? (uint32_t)max_tiles : (uint32_t)((double)max_tiles * x * (1.4 - 0.4 * x));
+    ps.launch_t0[i] = i == ps.launches ? (uint32_t)max_tiles : (uint32_t)((double)max_tiles * x * (1.0 + shrink - shrink * x));
   }
   for (int i = 0; i < ps.launches; i++) {
     PackTileArgs W = TileArgsOf(ctx, kind, nsec);
@@ -1256,7 +1266,7 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
     W.tile_end = ps.launch_t0[i + 1];
     if (W.tile_end > W.tile_first)
       hipLaunchKernelGGL(pack_tile_write_kernel,
-                         dim3((unsigned)((W.tile_end - W.tile_first + kPackTilesPerGroup - 1) / kPackTilesPerGroup)),
+                         dim3((unsigned)((W.tile_end - W.tile_first + kPackWriteTilesPerGroup - 1) / kPackWriteTilesPerGroup)),
                          dim3(kPackThreads), 0, ctx->stream, W);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ps.launch_done[i], ctx->stream));
@@ -1401,10 +1411,33 @@ int jxlt_output_buffer(jxlt_context* ctx, size_t bytes, uint8_t** out) {
   if (!ctx || !out) return JXLT_ERR_INVALID_ARGUMENT;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (ctx->h_output.cap < bytes) {
-    const int rc = EnsurePinned(ctx, &ctx->h_output, bytes + bytes / 8 + 65536);
-    if (rc != JXLT_OK) return rc;
+    if (ctx->copies_pending && ctx->h_output.p) {
+      // sections may be on their way into the buffer (jxlt_pack_sections_place): it grows with its contents
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+      PinnedBuf<uint8_t> grown;
+      const int rc = EnsurePinned(ctx, &grown, bytes + bytes / 8 + 65536);
+      if (rc != JXLT_OK) return rc;
+      memcpy(grown.p, ctx->h_output.p, ctx->h_output.cap);
+      FreePinned(&ctx->h_output);
+      ctx->h_output = grown;
+    } else {
+      const int rc = EnsurePinned(ctx, &ctx->h_output, bytes + bytes / 8 + 65536);
+      if (rc != JXLT_OK) return rc;
+    }
   }
   *out = ctx->h_output.p;
+  return JXLT_OK;
+}
+
+int jxlt_pack_measured(jxlt_context* ctx, int kind, jxlt_packed_sections* out) {
+  if (!ctx || !out || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
+  if (ctx->pack[kind].measured_sections == 0) {
+    ctx->error = "jxlt_pack_measured needs jxlt_pack_measure_begin first";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipEventSynchronize(ctx->pack[kind].measured));
+  FillMeasured(ctx, kind, out);
   return JXLT_OK;
 }
 

@@ -137,6 +137,17 @@ JXLT_DI uint32_t pack_thread_record(const PackThreadRecords& r, int j) {  // ctx
   const int byte = 3 * j;
   return __builtin_amdgcn_alignbyte(r.w[(byte >> 2) + 1], r.w[byte >> 2], (uint32_t)(byte & 3)) & 0xFFFFFFu;
 }
+// LDS layouts of the code table.  A tile's records use few (context, symbol) pairs, mostly the small symbols of
+// many contexts: with rows of 64 dwords those all sit in the banks of symbols 0-3.  The 32-bit table rotates every
+// row by its context (symbol 0 of the 64 contexts: 64 banks; 366 -> 129 conflict cycles per wave, same time).  The
+// byte table of the measuring pass stays context-major (symbol-major measured slower: its fill conflicts).
+#ifdef JXLT_PACK_PLAIN_TABLE
+JXLT_DI int pack_table_slot(uint32_t ctx, uint32_t sym) { return (int)(ctx * 64 + sym); }
+JXLT_DI int pack_depth_slot(uint32_t ctx, uint32_t sym) { return (int)(ctx * 64 + sym); }
+#else
+JXLT_DI int pack_table_slot(uint32_t ctx, uint32_t sym) { return (int)(ctx * 64 + ((sym + ctx) & 63u)); }
+JXLT_DI int pack_depth_slot(uint32_t ctx, uint32_t sym) { return (int)(ctx * 64 + sym); }
+#endif
 JXLT_DI void pack_bits_of(uint32_t rec24, const uint32_t* table, uint32_t* nb, uint32_t* data) {
   const uint32_t ctx = rec24 & 0xFFu, value = rec24 >> 8;
   if (ctx >= 128) {
@@ -145,37 +156,48 @@ JXLT_DI void pack_bits_of(uint32_t rec24, const uint32_t* table, uint32_t* nb, u
   } else {
     uint32_t sym, nbits, extra;
     hybrid_uint(value, &sym, &nbits, &extra);
-    const uint32_t e = table[ctx * 64 + sym];
+    const uint32_t e = table[pack_table_slot(ctx, sym)];
     const uint32_t depth = e >> 16;
     *nb = depth + nbits;
     *data = (e & 0xFFFFu) | (extra << depth);
   }
 }
 
-constexpr int kPackTilesPerGroup = 4;  // consecutive tiles per workgroup (amortises the table load)
+// Consecutive tiles per workgroup (amortises the table load).  The writing pass runs as several launches (the
+// copies to the host follow launch by launch), each of which ends with a partly empty machine for as long as a
+// workgroup lives: two tiles per workgroup there (0.735 -> 0.64 Mcycles per 16384^2 frame; one tile: 0.685).
+#ifndef JXLT_PACK_WRITE_TILES
+#define JXLT_PACK_WRITE_TILES 2
+#endif
+#ifndef JXLT_PACK_MEASURE_TILES
+#define JXLT_PACK_MEASURE_TILES 4
+#endif
+constexpr int kPackWriteTilesPerGroup = JXLT_PACK_WRITE_TILES;
+constexpr int kPackMeasureTilesPerGroup = JXLT_PACK_MEASURE_TILES;
 
 __global__ void __launch_bounds__(kPackThreads) pack_tile_measure_kernel(const PackTileArgs A) {
   __shared__ uint8_t depth[64 * 64];
   __shared__ alignas(16) uint32_t stage[kPackTile * 3 / 4 + 4];
-  __shared__ uint32_t total[kPackTilesPerGroup];
+  __shared__ uint32_t total[kPackMeasureTilesPerGroup];
   const int tid = (int)threadIdx.x;
   const uint32_t ntiles_all = umin32((uint32_t)A.tile_base[A.nsec], A.tile_end);
-  const uint32_t first = A.tile_first + blockIdx.x * kPackTilesPerGroup;
+  const uint32_t first = A.tile_first + blockIdx.x * kPackMeasureTilesPerGroup;
   if (first >= ntiles_all) return;
-  for (int i = tid; i < 64 * 64; i += kPackThreads) depth[i] = (uint8_t)(A.code_table[i] >> 16);
-  if (tid < kPackTilesPerGroup) total[tid] = 0;
+  for (int i = tid; i < 64 * 64; i += kPackThreads)
+    depth[pack_depth_slot((uint32_t)i >> 6, (uint32_t)i & 63u)] = (uint8_t)(A.code_table[i] >> 16);
+  if (tid < kPackMeasureTilesPerGroup) total[tid] = 0;
   // The records of tile k + 1 are requested before tile k is summed: its descriptor one tile earlier still.
   PackTileInfo info = A.tile_info[first];
   PackTileInfo next_info = A.tile_info[first + 1 < ntiles_all ? first + 1 : first];
   PackStagedLoads loads;
   pack_request_tile(A.records + 3 * info.rec_first, (int)(info.n_last & 0x7FFFFFFFu), tid, &loads);
-  for (int k = 0; k < kPackTilesPerGroup; k++) {
+  for (int k = 0; k < kPackMeasureTilesPerGroup; k++) {
     const uint32_t tile = first + k;
     if (tile >= ntiles_all) break;
     __syncthreads();  // previous tile's stage consumed; tables loaded
     const int n = (int)(info.n_last & 0x7FFFFFFFu);
     pack_store_tile(loads, n, stage, tid);
-    if (k + 1 < kPackTilesPerGroup && tile + 1 < ntiles_all) {
+    if (k + 1 < kPackMeasureTilesPerGroup && tile + 1 < ntiles_all) {
       info = next_info;
       next_info = A.tile_info[tile + 2 < ntiles_all ? tile + 2 : tile + 1];
       pack_request_tile(A.records + 3 * info.rec_first, (int)(info.n_last & 0x7FFFFFFFu), tid, &loads);
@@ -195,7 +217,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_measure_kernel(const P
         } else {
           uint32_t sym, nbits, extra;
           hybrid_uint(value, &sym, &nbits, &extra);
-          mine += depth[ctx * 64 + sym] + nbits;
+          mine += depth[pack_depth_slot(ctx, sym)] + nbits;
         }
       }
     }
@@ -203,7 +225,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_measure_kernel(const P
     if ((tid & 63) == 0) atomicAdd(&total[k], mine);
   }
   __syncthreads();
-  if (tid < kPackTilesPerGroup && first + tid < ntiles_all) A.tile_bits[first + tid] = total[tid];
+  if (tid < kPackMeasureTilesPerGroup && first + tid < ntiles_all) A.tile_bits[first + tid] = total[tid];
 }
 
 __global__ void __launch_bounds__(256) pack_tile_offsets_kernel(const PackTileArgs A) {
@@ -245,14 +267,17 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
   __shared__ uint32_t wave_sum[kPackThreads / 64];
   const int tid = (int)threadIdx.x;
   const uint32_t ntiles_all = umin32((uint32_t)A.tile_base[A.nsec], A.tile_end);
-  const uint32_t first_tile = A.tile_first + blockIdx.x * kPackTilesPerGroup;
+  const uint32_t first_tile = A.tile_first + blockIdx.x * kPackWriteTilesPerGroup;
   if (first_tile >= ntiles_all) return;
   {  // (all eight loads of the code table in flight before the first LDS store)
     uint32_t tl[64 * 64 / kPackThreads];
 #pragma unroll
     for (int q = 0; q < 64 * 64 / kPackThreads; q++) tl[q] = A.code_table[tid + q * kPackThreads];
 #pragma unroll
-    for (int q = 0; q < 64 * 64 / kPackThreads; q++) table[tid + q * kPackThreads] = tl[q];
+    for (int q = 0; q < 64 * 64 / kPackThreads; q++) {
+      const uint32_t i = (uint32_t)(tid + q * kPackThreads);
+      table[pack_table_slot(i >> 6, i & 63u)] = tl[q];
+    }
   }
   uint32_t* outw = reinterpret_cast<uint32_t*>(A.out);
   // The records of tile kt + 1 are requested before tile kt is packed: its descriptor one tile earlier still.
@@ -260,7 +285,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
   PackTileInfo next_info = A.tile_info[first_tile + 1 < ntiles_all ? first_tile + 1 : first_tile];
   PackStagedLoads loads;
   pack_request_tile(A.records + 3 * info.rec_first, (int)(info.n_last & 0x7FFFFFFFu), tid, &loads);
-  for (int kt = 0; kt < kPackTilesPerGroup; kt++) {
+  for (int kt = 0; kt < kPackWriteTilesPerGroup; kt++) {
     const uint32_t tile = first_tile + kt;
     if (tile >= ntiles_all) break;
     __syncthreads();  // previous tile's window stored, its records consumed; table loaded
@@ -270,7 +295,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
     const uint64_t pos_bit = info.bit_pos;  // where this tile's bits start
     const uint32_t lead = (uint32_t)(pos_bit & 31u);
     const uint64_t word0 = pos_bit >> 5;
-    if (kt + 1 < kPackTilesPerGroup && tile + 1 < ntiles_all) {
+    if (kt + 1 < kPackWriteTilesPerGroup && tile + 1 < ntiles_all) {
       info = next_info;
       next_info = A.tile_info[tile + 2 < ntiles_all ? tile + 2 : tile + 1];
       pack_request_tile(A.records + 3 * info.rec_first, (int)(info.n_last & 0x7FFFFFFFu), tid, &loads);

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
@@ -128,6 +129,7 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   // (the expectation belongs to a frame size: a frame of another size starts without one)
   static thread_local double expected_dc_ms = 0.0, expected_ac_ms = 0.0;
   static thread_local size_t expected_for_pixels = 0;
+  static thread_local size_t last_frame_bytes = 0;  // (sizes the output buffer before the AC sections are measured)
   if (expected_for_pixels != xsize * ysize) {
     expected_for_pixels = xsize * ysize;
     expected_dc_ms = expected_ac_ms = 0.0;
@@ -149,6 +151,13 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
     fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
     return false;
   }
+  // (while the device tokenises the AC groups)
+  FrameGlobals globals;
+  globals.dc_global = BuildDcGlobal(xsize, ysize, distp, dc_code);
+  const size_t pre = (in_context && in_context->prefix) ? in_context->prefix->size() : 0;
+  // (context buffer: the position of the sections is fixed before the head exists -- the head is bounded from
+  // above and right-aligned in front of them)
+  const size_t dc_at = (pre + HeadSizeBound(xsize, ysize, globals) + 255) & ~static_cast<size_t>(255);
   const auto t0b = now();
   {
     const double left = expected_ac_ms - ms(t0, t0b);  // until the AC histogram is expected
@@ -170,28 +179,44 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   // sections straight to their final byte offsets and copies them to where the frame is being
   // assembled, while the host builds header and TOC.
   jxlt_packed_sections dcm, acm;
-  if (jxlt_pack_measure(ctx, nullptr, ac_table.data(), &dcm, &acm) != JXLT_OK) {
+  bool dc_placed = false;
+  if (in_context) {
+    // The AC pass is queued first; then the DC-group sections -- measured and written while the AC code was being
+    // built -- start their way to the host: the link is idle until the first AC sections are written.
+    uint8_t* buf = nullptr;
+    if (jxlt_pack_measure_begin(ctx, 1, ac_table.data()) != JXLT_OK || jxlt_pack_measured(ctx, 0, &dcm) != JXLT_OK) {
+      fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
+      return false;
+    }
+    const size_t dc_size = static_cast<size_t>(dcm.section_offset[dcm.num_sections]);
+    if (jxlt_output_buffer(ctx, std::max(dc_at + dc_size + 16, last_frame_bytes), &buf) != JXLT_OK ||
+        jxlt_pack_sections_place(ctx, 0, buf + dc_at) != JXLT_OK) {
+      fprintf(stderr, "jxl_tiny_amd: section placement failed: %s\n", jxlt_last_error(ctx));
+      return false;
+    }
+    dc_placed = true;
+    if (jxlt_pack_measured(ctx, 1, &acm) != JXLT_OK) {
+      fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
+      return false;
+    }
+  } else if (jxlt_pack_measure(ctx, nullptr, ac_table.data(), &dcm, &acm) != JXLT_OK) {
     fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
     return false;
   }
   const auto t3 = now();
   const PackedSections dc = {nullptr, dcm.section_offset, dcm.section_bits, dcm.num_sections};
   const PackedSections ac = {nullptr, acm.section_offset, acm.section_bits, acm.num_sections};
-  FrameGlobals globals;
-  BuildFrameGlobals(xsize, ysize, distp, dc_code, ac_code, &globals);
+  globals.ac_global = BuildAcGlobal(xsize, ysize, ac_code);
   const size_t dc_bytes = static_cast<size_t>(dc.offset[dc.n]), ac_bytes = static_cast<size_t>(ac.offset[ac.n]);
   const size_t acg_bytes = globals.ac_global.size();
   std::vector<uint8_t> head;
   bool ok = true;
   if (in_context) {
-    // Context buffer: the position of the sections is fixed before the head exists (the head
-    // is bounded from above and right-aligned in front of them), so the device starts at once.
-    const size_t pre = in_context->prefix ? in_context->prefix->size() : 0;
-    const size_t dc_at = (pre + HeadSizeBound(xsize, ysize, globals) + 255) & ~static_cast<size_t>(255);
     const size_t ac_at = dc_at + dc_bytes + acg_bytes;
+    last_frame_bytes = ac_at + ac_bytes + 16;
     uint8_t* buf = nullptr;
-    if (jxlt_output_buffer(ctx, ac_at + ac_bytes + 16, &buf) != JXLT_OK ||
-        jxlt_pack_write(ctx, buf + dc_at, buf + ac_at) != JXLT_OK) {
+    if (!dc_placed || jxlt_output_buffer(ctx, ac_at + ac_bytes + 16, &buf) != JXLT_OK ||
+        jxlt_pack_sections_place(ctx, 1, buf + ac_at) != JXLT_OK) {
       fprintf(stderr, "jxl_tiny_amd: section placement failed: %s\n", jxlt_last_error(ctx));
       return false;
     }

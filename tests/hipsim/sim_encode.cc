@@ -251,7 +251,7 @@ __attribute__((visibility("default"))) int sim_pack_direct(const uint8_t* record
   hipsim::launch(pack_tile_count_kernel, dim3(sec_blocks), dim3(256), P);
   hipsim::launch(group_scan_kernel, dim3(1), dim3(kScanThreads), (const uint32_t*)sec_tiles.data(), tile_base.data(), nsec);
   hipsim::launch(pack_tile_plan_kernel, dim3(sec_blocks), dim3(256), P);
-  hipsim::launch(pack_tile_measure_kernel, dim3((unsigned)((max_tiles + kPackTilesPerGroup - 1) / kPackTilesPerGroup)),
+  hipsim::launch(pack_tile_measure_kernel, dim3((unsigned)((max_tiles + kPackMeasureTilesPerGroup - 1) / kPackMeasureTilesPerGroup)),
                  dim3(kPackThreads), P);
   hipsim::launch(pack_tile_offsets_kernel, dim3(sec_blocks), dim3(256), P);
   hipsim::launch(group_scan_kernel, dim3(1), dim3(kScanThreads), (const uint32_t*)sec_bytes.data(), out_offset, nsec);
@@ -262,7 +262,7 @@ __attribute__((visibility("default"))) int sim_pack_direct(const uint8_t* record
     if (t1 == t0) continue;
     P.tile_first = (uint32_t)t0;
     P.tile_end = (uint32_t)t1;
-    hipsim::launch(pack_tile_write_kernel, dim3((unsigned)((t1 - t0 + kPackTilesPerGroup - 1) / kPackTilesPerGroup)),
+    hipsim::launch(pack_tile_write_kernel, dim3((unsigned)((t1 - t0 + kPackWriteTilesPerGroup - 1) / kPackWriteTilesPerGroup)),
                    dim3(kPackThreads), P);
   }
   return 0;
