@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 
 #include <string>
 #include <atomic>
@@ -108,11 +109,12 @@ struct jxlt_context {
     bool planned = false;          // the frame's tile plan (count / scan / plan kernels) has been queued
     // The writing kernels are queued right behind the measuring kernels (they need nothing from
     // the host): launch i covers tiles [launch_t0[i], launch_t0[i + 1]) and signals launch_done[i].
-    static constexpr int kMaxLaunches = 12;
+    static constexpr int kMaxLaunches = 8;
     int launches = 0;
     uint32_t launch_t0[kMaxLaunches + 1] = {};
     hipEvent_t launch_done[kMaxLaunches] = {};
     hipEvent_t measured = nullptr;  // the host mirrors of the measuring pass are valid
+    hipEvent_t finalized = nullptr; // the measuring pass's kernels are done (the mirrors' copies wait for it)
   } pack[2];
   PinnedBuf<uint8_t> h_output;  // jxlt_output_buffer
 
@@ -258,6 +260,7 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->overflow_ready, hipEventDisableTiming);
   for (auto& ps : ctx->pack) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ps.measured, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ps.finalized, hipEventDisableTiming);
     for (auto& ev : ps.launch_done)
       if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   }
@@ -334,6 +337,7 @@ void jxlt_context_destroy(jxlt_context* ctx) {
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ps : ctx->pack) {
     if (ps.measured) (void)hipEventDestroy(ps.measured);
+    if (ps.finalized) (void)hipEventDestroy(ps.finalized);
     for (auto& ev : ps.launch_done)
       if (ev) (void)hipEventDestroy(ev);
   }
@@ -1232,33 +1236,42 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
                      ps.sec_byte_off.p, (int)nsec);
   hipLaunchKernelGGL(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), 0, ctx->stream, P);
   HIP_TRY(ctx, hipGetLastError());
+  // The three small downloads go by the auxiliary stream (idle by now): on the main stream they would stand
+  // between the measuring kernels and the writing kernels queued below.
+  HIP_TRY(ctx, hipEventRecord(ps.finalized, ctx->stream));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ps.finalized, 0));
   HIP_TRY(ctx, hipMemcpyAsync(ps.h_sec_byte_off.p, ps.sec_byte_off.p, (nsec + 1) * sizeof(uint64_t),
-                              hipMemcpyDeviceToHost, ctx->stream));
+                              hipMemcpyDeviceToHost, ctx->aux_stream));
   HIP_TRY(ctx, hipMemcpyAsync(ps.h_sec_bits.p, ps.sec_bits.p, nsec * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                              ctx->stream));
+                              ctx->aux_stream));
   HIP_TRY(ctx, hipMemcpyAsync(ps.h_tile_base.p, ps.tile_base.p, (nsec + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost,
-                              ctx->stream));
-  HIP_TRY(ctx, hipEventRecord(ps.measured, ctx->stream));
+                              ctx->aux_stream));
+  HIP_TRY(ctx, hipEventRecord(ps.measured, ctx->aux_stream));
   ps.measured_sections = nsec;
   // The writing pass needs nothing from the host (tile positions are in device memory), so it is
-  // queued right here, in a few launches over equal shares of the tile range (an upper bound: the
+  // queued right here, in a few launches over shares of the tile range (an upper bound: the
   // kernel clamps to the real tile count); the host picks the section sizes up meanwhile and
   // later only adds the copies (EnqueueCopies).
-  // (experiment knobs, tools/: JXLT_PACK_LAUNCHES=<n>, JXLT_PACK_SHRINK=<percent>)
+  // The shares GROW (1 : 2 : 4): the kernels write faster than the link carries the bytes away (16384^2: 0.21 ms
+  // against 0.35 ms for the 20 MB of AC sections), so the copies are the critical path and what they cannot
+  // overlap is the FIRST launch; every later share only has to be written before the copy in front of it ends.
+  // (Time from the AC sizes to the last byte in host memory, tools/pack_sweep.sh: five shrinking shares 0.42 ms,
+  // five equal 0.41, five growing 0.39-0.40, four 1:2:4:8 0.38, three 1:2:4 0.37, two 1:4 0.42.)
+  // (experiment knobs, tools/: JXLT_PACK_LAUNCHES=<n>, JXLT_PACK_GROWTH=<percent, each share against the one before>)
   static const int ac_launches = [] {
     const char* e = getenv("JXLT_PACK_LAUNCHES");
-    return e ? std::max(1, std::min(atoi(e), (int)jxlt_context::PackSet::kMaxLaunches)) : 5;
+    return e ? std::max(1, std::min(atoi(e), (int)jxlt_context::PackSet::kMaxLaunches)) : 3;
   }();
-  static const double shrink = [] {
-    const char* e = getenv("JXLT_PACK_SHRINK");
-    return e ? atoi(e) / 100.0 : 0.4;
+  static const double growth = [] {
+    const char* e = getenv("JXLT_PACK_GROWTH");
+    return e ? std::max(1.0, atoi(e) / 100.0) : 2.0;
   }();
   const int want = kind == 0 ? 1 : ac_launches;
   ps.launches = (int)std::min<size_t>((size_t)want, std::max<size_t>(1, max_tiles / 64));
-  // (shrinking shares: the copy of the last share is the only one nothing overlaps)
   for (int i = 0; i <= ps.launches; i++) {
-    const double x = (double)i / ps.launches;
-    ps.launch_t0[i] = i == ps.launches ? (uint32_t)max_tiles : (uint32_t)((double)max_tiles * x * (1.0 + shrink - shrink * x));
+    const double share = growth > 1.0 ? (std::pow(growth, i) - 1.0) / (std::pow(growth, ps.launches) - 1.0)
+                                      : (double)i / ps.launches;
+    ps.launch_t0[i] = i == ps.launches ? (uint32_t)max_tiles : (uint32_t)((double)max_tiles * share);
   }
   for (int i = 0; i < ps.launches; i++) {
     PackTileArgs W = TileArgsOf(ctx, kind, nsec);

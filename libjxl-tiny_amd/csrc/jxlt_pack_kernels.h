@@ -148,20 +148,35 @@ JXLT_DI int pack_depth_slot(uint32_t ctx, uint32_t sym) { return (int)(ctx * 64 
 JXLT_DI int pack_table_slot(uint32_t ctx, uint32_t sym) { return (int)(ctx * 64 + ((sym + ctx) & 63u)); }
 JXLT_DI int pack_depth_slot(uint32_t ctx, uint32_t sym) { return (int)(ctx * 64 + sym); }
 #endif
+// Bit length and bits of one record, without branches (a tile mixes raw-bit records, small values and values with
+// extra bits lane by lane: as branches every record cost the wave all three paths plus the exec-mask bookkeeping).
+// Symbol and extra-bit count of a value >= 16 come from its float form (hybrid_uint_symbol, jxlt_device_common.h);
+// records that are not there (beyond a section's last one) are turned into "zero raw bits" by the callers.
+JXLT_DI void pack_split_value(uint32_t value, uint32_t* sym, uint32_t* nbits) {  // token.h:32-48
+  const uint32_t fbits = __float_as_uint((float)value);
+  const bool big = value >= 16;
+  *sym = big ? (fbits >> 21) - (127u << 2) : value;
+  *nbits = big ? (fbits >> 23) - 129u : 0u;
+}
 JXLT_DI void pack_bits_of(uint32_t rec24, const uint32_t* table, uint32_t* nb, uint32_t* data) {
   const uint32_t ctx = rec24 & 0xFFu, value = rec24 >> 8;
-  if (ctx >= 128) {
-    *nb = ctx - 128;
-    *data = value;
-  } else {
-    uint32_t sym, nbits, extra;
-    hybrid_uint(value, &sym, &nbits, &extra);
-    const uint32_t e = table[pack_table_slot(ctx, sym)];
-    const uint32_t depth = e >> 16;
-    *nb = depth + nbits;
-    *data = (e & 0xFFFFu) | (extra << depth);
-  }
+  uint32_t sym, nbits;
+  pack_split_value(value, &sym, &nbits);
+  const uint32_t extra = __builtin_amdgcn_ubfe(value, 0u, nbits);
+  const uint32_t e = table[pack_table_slot(ctx & 63u, sym)];
+  const uint32_t depth = e >> 16;
+  const bool raw = ctx >= 128;
+  *nb = raw ? ctx - 128u : depth + nbits;
+  *data = raw ? value : ((e & 0xFFFFu) | (extra << depth));
 }
+JXLT_DI uint32_t pack_length_of(uint32_t rec24, const uint8_t* depth) {
+  const uint32_t ctx = rec24 & 0xFFu, value = rec24 >> 8;
+  uint32_t sym, nbits;
+  pack_split_value(value, &sym, &nbits);
+  const uint32_t d = depth[pack_depth_slot(ctx & 63u, sym)];
+  return ctx >= 128 ? ctx - 128u : d + nbits;
+}
+constexpr uint32_t kPackNoRecord = 0x80u;  // a raw-bit record of zero bits
 
 // Consecutive tiles per workgroup (amortises the table load).  The writing pass runs as several launches (the
 // copies to the host follow launch by launch), each of which ends with a partly empty machine for as long as a
@@ -206,21 +221,10 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_measure_kernel(const P
     PackThreadRecords recs;
     pack_load_thread_records(stage, tid, &recs);
     uint32_t mine = 0;
+    const int nvalid = n - tid * kPackPerThread;
 #pragma unroll
-    for (int j = 0; j < kPackPerThread; j++) {
-      const int r = tid * kPackPerThread + j;
-      if (r < n) {
-        const uint32_t rec24 = pack_thread_record(recs, j);
-        const uint32_t ctx = rec24 & 0xFFu, value = rec24 >> 8;
-        if (ctx >= 128) {
-          mine += ctx - 128;
-        } else {
-          uint32_t sym, nbits, extra;
-          hybrid_uint(value, &sym, &nbits, &extra);
-          mine += depth[pack_depth_slot(ctx, sym)] + nbits;
-        }
-      }
-    }
+    for (int j = 0; j < kPackPerThread; j++)
+      mine += pack_length_of(j < nvalid ? pack_thread_record(recs, j) : kPackNoRecord, depth);
     for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
     if ((tid & 63) == 0) atomicAdd(&total[k], mine);
   }
@@ -260,6 +264,10 @@ __global__ void __launch_bounds__(256) pack_tile_finalize_kernel(const PackTileA
   }
 }
 
+// Per tile: records -> (length, bits) per thread, workgroup scan of the lengths, every record OR-ed into the LDS
+// window at its bit position, window -> blob.  Two barriers per tile: the next tile's records go to the staging
+// area right behind the scan's barrier (every thread has its own records in registers by then), and the window is
+// cleared by the threads that store it.
 __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const PackTileArgs A) {
   __shared__ uint32_t table[64 * 64];
   __shared__ alignas(16) uint32_t stage[kPackTile * 3 / 4 + 4];
@@ -269,6 +277,12 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
   const uint32_t ntiles_all = umin32((uint32_t)A.tile_base[A.nsec], A.tile_end);
   const uint32_t first_tile = A.tile_first + blockIdx.x * kPackWriteTilesPerGroup;
   if (first_tile >= ntiles_all) return;
+  const uint32_t last_tile = ntiles_all - 1;
+  // The descriptors of the first two tiles and the first tile's records are requested in front of the code table.
+  PackTileInfo cur = A.tile_info[first_tile];
+  PackTileInfo nxt = A.tile_info[umin32(first_tile + 1, last_tile)];
+  PackStagedLoads loads;
+  pack_request_tile(A.records + 3 * cur.rec_first, (int)(cur.n_last & 0x7FFFFFFFu), tid, &loads);
   {  // (all eight loads of the code table in flight before the first LDS store)
     uint32_t tl[64 * 64 / kPackThreads];
 #pragma unroll
@@ -279,40 +293,33 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
       table[pack_table_slot(i >> 6, i & 63u)] = tl[q];
     }
   }
+  for (int i = tid; i < kPackWindowWords; i += kPackThreads) window[i] = 0u;
+  pack_store_tile(loads, (int)(cur.n_last & 0x7FFFFFFFu), stage, tid);
+  if (kPackWriteTilesPerGroup > 1 && first_tile + 1 < ntiles_all)
+    pack_request_tile(A.records + 3 * nxt.rec_first, (int)(nxt.n_last & 0x7FFFFFFFu), tid, &loads);
   uint32_t* outw = reinterpret_cast<uint32_t*>(A.out);
-  // The records of tile kt + 1 are requested before tile kt is packed: its descriptor one tile earlier still.
-  PackTileInfo info = A.tile_info[first_tile];
-  PackTileInfo next_info = A.tile_info[first_tile + 1 < ntiles_all ? first_tile + 1 : first_tile];
-  PackStagedLoads loads;
-  pack_request_tile(A.records + 3 * info.rec_first, (int)(info.n_last & 0x7FFFFFFFu), tid, &loads);
+  __syncthreads();  // table, first tile's records, clear window
   for (int kt = 0; kt < kPackWriteTilesPerGroup; kt++) {
     const uint32_t tile = first_tile + kt;
     if (tile >= ntiles_all) break;
-    __syncthreads();  // previous tile's window stored, its records consumed; table loaded
-    const int n = (int)(info.n_last & 0x7FFFFFFFu);
-    pack_store_tile(loads, n, stage, tid);
-    for (int i = tid; i < kPackWindowWords; i += kPackThreads) window[i] = 0u;
-    const uint64_t pos_bit = info.bit_pos;  // where this tile's bits start
+    const bool has_next = kt + 1 < kPackWriteTilesPerGroup && tile + 1 < ntiles_all;
+    const bool has_next2 = kt + 2 < kPackWriteTilesPerGroup && tile + 2 < ntiles_all;
+    // (the descriptor of the tile after the next: needed behind the scan, requested here)
+    const PackTileInfo nxt2 = A.tile_info[umin32(tile + 2, last_tile)];
+    const int n = (int)(cur.n_last & 0x7FFFFFFFu);
+    const uint64_t pos_bit = cur.bit_pos;  // where this tile's bits start
     const uint32_t lead = (uint32_t)(pos_bit & 31u);
     const uint64_t word0 = pos_bit >> 5;
-    if (kt + 1 < kPackWriteTilesPerGroup && tile + 1 < ntiles_all) {
-      info = next_info;
-      next_info = A.tile_info[tile + 2 < ntiles_all ? tile + 2 : tile + 1];
-      pack_request_tile(A.records + 3 * info.rec_first, (int)(info.n_last & 0x7FFFFFFFu), tid, &loads);
-    }
-    __syncthreads();  // stage complete, window clear
-    // pass 1: bit length of this thread's records
+    // pass 1: length and bits of this thread's records
     PackThreadRecords recs;
     pack_load_thread_records(stage, tid, &recs);
     uint32_t nb[kPackPerThread];
     uint32_t data[kPackPerThread];
     uint32_t mine = 0;
+    const int nvalid = n - tid * kPackPerThread;
 #pragma unroll
     for (int j = 0; j < kPackPerThread; j++) {
-      const int r = tid * kPackPerThread + j;
-      nb[j] = 0;
-      data[j] = 0;
-      if (r < n) pack_bits_of(pack_thread_record(recs, j), table, &nb[j], &data[j]);
+      pack_bits_of(j < nvalid ? pack_thread_record(recs, j) : kPackNoRecord, table, &nb[j], &data[j]);
       mine += nb[j];
     }
     // exclusive prefix of `mine` over the workgroup: wave scan + per-wave totals
@@ -322,7 +329,9 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
       if ((tid & 63) >= d) incl += o;
     }
     if ((tid & 63) == 63) wave_sum[tid >> 6] = incl;
-    __syncthreads();
+    __syncthreads();  // every thread holds its records: the staging area is free
+    if (has_next) pack_store_tile(loads, (int)(nxt.n_last & 0x7FFFFFFFu), stage, tid);
+    if (has_next2) pack_request_tile(A.records + 3 * nxt2.rec_first, (int)(nxt2.n_last & 0x7FFFFFFFu), tid, &loads);
     uint32_t wave_base = 0, tile_bits = 0;
 #pragma unroll
     for (int w = 0; w < kPackThreads / 64; w++) {
@@ -330,7 +339,20 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
       if (w < (tid >> 6)) wave_base += v;
       tile_bits += v;
     }
-    // pass 2: OR the bits into the window
+    // pass 2: the thread's records concatenated in a register pair, completed dwords OR-ed into the window
+    // (LDS atomics are the expensive part: a record at a time -- 16 per thread -- made the kernel 45 % slower)
+#ifdef JXLT_PACK_RECORD_ATOMICS
+    {
+      uint32_t pos = lead + wave_base + incl - mine;
+#pragma unroll
+      for (int j = 0; j < kPackPerThread; j++) {
+        const unsigned long long v = (unsigned long long)data[j] << (pos & 31u);
+        atomicOr(&window[pos >> 5], (uint32_t)v);
+        atomicOr(&window[(pos >> 5) + 1], (uint32_t)(v >> 32));
+        pos += nb[j];
+      }
+    }
+#else
     {
       const uint32_t pos = lead + wave_base + incl - mine;
       uint32_t w = pos >> 5;
@@ -349,20 +371,24 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
       }
       if (fill) atomicOr(&window[w], (uint32_t)acc);
     }
-    __syncthreads();
+#endif
+    __syncthreads();  // window complete; next tile's records staged
     // stores: the dwords the tile covers completely with plain stores; its first and its last dword, which it
     // may share with its neighbours (tiles of the same section, or the byte-aligned neighbour sections), are
-    // OR-ed into memory that pack_tile_finalize_kernel zeroed
+    // OR-ed into memory that pack_tile_finalize_kernel zeroed.  Whoever stores a dword clears it for the next tile.
     const uint32_t end_bits = lead + tile_bits;
     const uint32_t nwords = (end_bits + 31) >> 5;  // dwords the tile touches
     for (uint32_t i = tid; i < nwords; i += kPackThreads) {
       const uint32_t v = window[i];
+      window[i] = 0u;
       if (i == 0 || (i + 1 == nwords && (end_bits & 31u) != 0)) {
         if (v) atomicOr(&outw[word0 + i], v);
       } else {
         outw[word0 + i] = v;
       }
     }
+    cur = nxt;
+    nxt = nxt2;
   }
 }
 

@@ -256,7 +256,7 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
     }
   }
   if (trace)
-    fprintf(stderr, "jxlt trace: device+histograms %.2f ms | codes %.2f | measure %.2f | head + place %.2f\n",
+    fprintf(stderr, "jxlt trace: device+histograms %.3f ms | codes %.3f | measure %.3f | head + place %.3f\n",
             ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
   (void)num_threads;
   return ok;
