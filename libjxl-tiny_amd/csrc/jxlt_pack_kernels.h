@@ -190,41 +190,59 @@ constexpr uint32_t kPackNoRecord = 0x80u;  // a raw-bit record of zero bits
 constexpr int kPackWriteTilesPerGroup = JXLT_PACK_WRITE_TILES;
 constexpr int kPackMeasureTilesPerGroup = JXLT_PACK_MEASURE_TILES;
 
+// A sum does not care about the order of its terms: every thread takes four consecutive records (12 bytes, three
+// unaligned dword loads straight from global memory -- the lanes of a wave cover 768 contiguous bytes) instead of
+// its eight of the staged tile, so there is no staging area, and no barrier until the workgroup's tiles are summed.
+// All of a workgroup's loads are in flight before the first length is looked up.  (Same speed as the staged version
+// it replaces, 0.283 against 0.288 Mcycles per 16384^2 frame: the pass is bound by its ~22 instructions per record.)
 __global__ void __launch_bounds__(kPackThreads) pack_tile_measure_kernel(const PackTileArgs A) {
   __shared__ uint8_t depth[64 * 64];
-  __shared__ alignas(16) uint32_t stage[kPackTile * 3 / 4 + 4];
   __shared__ uint32_t total[kPackMeasureTilesPerGroup];
+  constexpr int kChunk = 4;                                            // records per thread and step
+  constexpr int kSteps = kPackTile / (kPackThreads * kChunk);          // steps per tile
+  static_assert(kSteps * kPackThreads * kChunk == kPackTile, "whole steps");
   const int tid = (int)threadIdx.x;
   const uint32_t ntiles_all = umin32((uint32_t)A.tile_base[A.nsec], A.tile_end);
   const uint32_t first = A.tile_first + blockIdx.x * kPackMeasureTilesPerGroup;
   if (first >= ntiles_all) return;
+  uint32_t w[kPackMeasureTilesPerGroup][kSteps][3];
+  int nrec[kPackMeasureTilesPerGroup];
+#pragma unroll
+  for (int k = 0; k < kPackMeasureTilesPerGroup; k++) {
+    const uint32_t tile = umin32(first + k, ntiles_all - 1);
+    const PackTileInfo info = A.tile_info[tile];
+    nrec[k] = first + k < ntiles_all ? (int)(info.n_last & 0x7FFFFFFFu) : 0;
+    const uint8_t* src = A.records + 3 * info.rec_first;
+#pragma unroll
+    for (int it = 0; it < kSteps; it++) {
+      const int byte0 = 3 * kChunk * (tid + it * kPackThreads);
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        uint32_t v = 0;
+        if (byte0 + 4 * q < 3 * nrec[k]) __builtin_memcpy(&v, src + byte0 + 4 * q, 4);
+        w[k][it][q] = v;
+      }
+    }
+  }
   for (int i = tid; i < 64 * 64; i += kPackThreads)
     depth[pack_depth_slot((uint32_t)i >> 6, (uint32_t)i & 63u)] = (uint8_t)(A.code_table[i] >> 16);
   if (tid < kPackMeasureTilesPerGroup) total[tid] = 0;
-  // The records of tile k + 1 are requested before tile k is summed: its descriptor one tile earlier still.
-  PackTileInfo info = A.tile_info[first];
-  PackTileInfo next_info = A.tile_info[first + 1 < ntiles_all ? first + 1 : first];
-  PackStagedLoads loads;
-  pack_request_tile(A.records + 3 * info.rec_first, (int)(info.n_last & 0x7FFFFFFFu), tid, &loads);
-  for (int k = 0; k < kPackMeasureTilesPerGroup; k++) {
-    const uint32_t tile = first + k;
-    if (tile >= ntiles_all) break;
-    __syncthreads();  // previous tile's stage consumed; tables loaded
-    const int n = (int)(info.n_last & 0x7FFFFFFFu);
-    pack_store_tile(loads, n, stage, tid);
-    if (k + 1 < kPackMeasureTilesPerGroup && tile + 1 < ntiles_all) {
-      info = next_info;
-      next_info = A.tile_info[tile + 2 < ntiles_all ? tile + 2 : tile + 1];
-      pack_request_tile(A.records + 3 * info.rec_first, (int)(info.n_last & 0x7FFFFFFFu), tid, &loads);
-    }
-    __syncthreads();
-    PackThreadRecords recs;
-    pack_load_thread_records(stage, tid, &recs);
-    uint32_t mine = 0;
-    const int nvalid = n - tid * kPackPerThread;
+  __syncthreads();
 #pragma unroll
-    for (int j = 0; j < kPackPerThread; j++)
-      mine += pack_length_of(j < nvalid ? pack_thread_record(recs, j) : kPackNoRecord, depth);
+  for (int k = 0; k < kPackMeasureTilesPerGroup; k++) {
+    if (first + k >= ntiles_all) break;
+    uint32_t mine = 0;
+#pragma unroll
+    for (int it = 0; it < kSteps; it++) {
+      const int nvalid = nrec[k] - kChunk * (tid + it * kPackThreads);
+#pragma unroll
+      for (int j = 0; j < kChunk; j++) {
+        const int byte = 3 * j;
+        const uint32_t hi = byte >> 2 < 2 ? w[k][it][(byte >> 2) + 1] : 0u;
+        const uint32_t rec24 = __builtin_amdgcn_alignbyte(hi, w[k][it][byte >> 2], (uint32_t)(byte & 3)) & 0xFFFFFFu;
+        mine += pack_length_of(j < nvalid ? rec24 : kPackNoRecord, depth);
+      }
+    }
     for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
     if ((tid & 63) == 0) atomicAdd(&total[k], mine);
   }
