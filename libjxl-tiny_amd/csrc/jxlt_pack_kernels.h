@@ -139,14 +139,12 @@ JXLT_DI uint32_t pack_thread_record(const PackThreadRecords& r, int j) {  // ctx
 }
 // LDS layouts of the code table.  A tile's records use few (context, symbol) pairs, mostly the small symbols of
 // many contexts: with rows of 64 dwords those all sit in the banks of symbols 0-3.  The 32-bit table rotates every
-// row by its context (symbol 0 of the 64 contexts: 64 banks; 366 -> 129 conflict cycles per wave, same time).  The
-// byte table of the measuring pass stays context-major (symbol-major measured slower: its fill conflicts).
+// row by its context (symbol 0 of the 64 contexts: 64 banks; 366 -> 129 conflict cycles per wave, same time).  (The
+// byte table of the measuring pass stays context-major: symbol-major measured slower, its fill conflicts.)
 #ifdef JXLT_PACK_PLAIN_TABLE
 JXLT_DI int pack_table_slot(uint32_t ctx, uint32_t sym) { return (int)(ctx * 64 + sym); }
-JXLT_DI int pack_depth_slot(uint32_t ctx, uint32_t sym) { return (int)(ctx * 64 + sym); }
 #else
 JXLT_DI int pack_table_slot(uint32_t ctx, uint32_t sym) { return (int)(ctx * 64 + ((sym + ctx) & 63u)); }
-JXLT_DI int pack_depth_slot(uint32_t ctx, uint32_t sym) { return (int)(ctx * 64 + sym); }
 #endif
 // Bit length and bits of one record, without branches (a tile mixes raw-bit records, small values and values with
 // extra bits lane by lane: as branches every record cost the wave all three paths plus the exec-mask bookkeeping).
@@ -169,12 +167,15 @@ JXLT_DI void pack_bits_of(uint32_t rec24, const uint32_t* table, uint32_t* nb, u
   *nb = raw ? ctx - 128u : depth + nbits;
   *data = raw ? value : ((e & 0xFFFFu) | (extra << depth));
 }
-JXLT_DI uint32_t pack_length_of(uint32_t rec24, const uint8_t* depth) {
+// The measuring pass looks a record's length up in ONE byte table over the whole context byte: rows 0-63 hold
+// depth + extra bits of (context, symbol), rows 128-255 the raw-bit records' own count (context - 128) whatever
+// the "symbol", rows 64-127 are never addressed.
+constexpr int kPackLengthRows = 256;
+JXLT_DI uint32_t pack_length_of(uint32_t rec24, const uint8_t* length) {
   const uint32_t ctx = rec24 & 0xFFu, value = rec24 >> 8;
-  uint32_t sym, nbits;
-  pack_split_value(value, &sym, &nbits);
-  const uint32_t d = depth[pack_depth_slot(ctx & 63u, sym)];
-  return ctx >= 128 ? ctx - 128u : d + nbits;
+  const uint32_t fbits = __float_as_uint((float)value);
+  const uint32_t sym = value >= 16 ? (fbits >> 21) - (127u << 2) : value;
+  return length[ctx * 64 + sym];
 }
 constexpr uint32_t kPackNoRecord = 0x80u;  // a raw-bit record of zero bits
 
@@ -194,9 +195,9 @@ constexpr int kPackMeasureTilesPerGroup = JXLT_PACK_MEASURE_TILES;
 // unaligned dword loads straight from global memory -- the lanes of a wave cover 768 contiguous bytes) instead of
 // its eight of the staged tile, so there is no staging area, and no barrier until the workgroup's tiles are summed.
 // All of a workgroup's loads are in flight before the first length is looked up.  (Same speed as the staged version
-// it replaces, 0.283 against 0.288 Mcycles per 16384^2 frame: the pass is bound by its ~22 instructions per record.)
+// it replaced, 0.283 against 0.288 Mcycles per 16384^2 frame: the pass is bound by its instructions per record.)
 __global__ void __launch_bounds__(kPackThreads) pack_tile_measure_kernel(const PackTileArgs A) {
-  __shared__ uint8_t depth[64 * 64];
+  __shared__ alignas(16) uint8_t length[kPackLengthRows * 64];
   __shared__ uint32_t total[kPackMeasureTilesPerGroup];
   constexpr int kChunk = 4;                                            // records per thread and step
   constexpr int kSteps = kPackTile / (kPackThreads * kChunk);          // steps per tile
@@ -224,8 +225,23 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_measure_kernel(const P
       }
     }
   }
-  for (int i = tid; i < 64 * 64; i += kPackThreads)
-    depth[pack_depth_slot((uint32_t)i >> 6, (uint32_t)i & 63u)] = (uint8_t)(A.code_table[i] >> 16);
+  {  // the length table, four entries (one dword) at a time
+    uint32_t* const length_w = reinterpret_cast<uint32_t*>(length);
+    for (int i = tid; i < 64 * 64 / 4; i += kPackThreads) {  // rows 0-63: depth + extra bits of the symbol
+      uint32_t packed = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t sym = (uint32_t)(4 * i + q) & 63u;
+        const uint32_t nbits = sym >= 16 ? (sym >> 2) - 2u : 0u;
+        packed |= ((A.code_table[4 * i + q] >> 16) + nbits) << (8 * q);
+      }
+      length_w[i] = packed;
+    }
+    for (int i = 64 * 64 / 4 + tid; i < kPackLengthRows * 64 / 4; i += kPackThreads) {
+      const uint32_t ctx = (uint32_t)i >> 4;  // (16 dwords per row)
+      length_w[i] = ctx >= 128 ? (ctx - 128u) * 0x01010101u : 0u;
+    }
+  }
   if (tid < kPackMeasureTilesPerGroup) total[tid] = 0;
   __syncthreads();
 #pragma unroll
@@ -240,7 +256,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_measure_kernel(const P
         const int byte = 3 * j;
         const uint32_t hi = byte >> 2 < 2 ? w[k][it][(byte >> 2) + 1] : 0u;
         const uint32_t rec24 = __builtin_amdgcn_alignbyte(hi, w[k][it][byte >> 2], (uint32_t)(byte & 3)) & 0xFFFFFFu;
-        mine += pack_length_of(j < nvalid ? rec24 : kPackNoRecord, depth);
+        mine += pack_length_of(j < nvalid ? rec24 : kPackNoRecord, length);
       }
     }
     for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
