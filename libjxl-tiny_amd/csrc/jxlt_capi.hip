@@ -115,6 +115,8 @@ struct jxlt_context {
     hipEvent_t launch_done[kMaxLaunches] = {};
     hipEvent_t measured = nullptr;  // the host mirrors of the measuring pass are valid
     hipEvent_t finalized = nullptr; // the measuring pass's kernels are done (the mirrors' copies wait for it)
+    hipEvent_t plan_done = nullptr; // the tile plan, when it was queued on another stream than the measuring pass
+    bool plan_elsewhere = false;
   } pack[2];
   PinnedBuf<uint8_t> h_output;  // jxlt_output_buffer
 
@@ -261,6 +263,7 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
   for (auto& ps : ctx->pack) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ps.measured, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ps.finalized, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ps.plan_done, hipEventDisableTiming);
     for (auto& ev : ps.launch_done)
       if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   }
@@ -338,6 +341,7 @@ void jxlt_context_destroy(jxlt_context* ctx) {
   for (auto& ps : ctx->pack) {
     if (ps.measured) (void)hipEventDestroy(ps.measured);
     if (ps.finalized) (void)hipEventDestroy(ps.finalized);
+    if (ps.plan_done) (void)hipEventDestroy(ps.plan_done);
     for (auto& ev : ps.launch_done)
       if (ev) (void)hipEventDestroy(ev);
   }
@@ -960,7 +964,14 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
   // way to the host, while the host builds the codes (upper bound of the record count: the buffer's capacity).
   ctx->pack[0].planned = ctx->pack[1].planned = false;
   {
-    const int rcp = EnqueuePlan(ctx, 1, ctx->tokens.cap / 3, ctx->stream);
+    // (one launch for the frame: the auxiliary stream is idle, and on the main stream the plan's three small
+    // kernels would stand in front of the DC-group sections' packing, which the AC measuring pass queues behind)
+    hipStream_t plan_stream = ctx->stream;
+    if (tok_stream == ctx->stream) {
+      plan_stream = ctx->aux_stream;
+      HIP_TRY(ctx, hipStreamWaitEvent(plan_stream, ctx->aux_done, 0));
+    }
+    const int rcp = EnqueuePlan(ctx, 1, ctx->tokens.cap / 3, plan_stream);
     if (rcp != JXLT_OK) return rcp;
   }
   ctx->encoded = true;
@@ -1198,6 +1209,8 @@ int EnqueuePlan(jxlt_context* ctx, int kind, uint64_t rec_bound, hipStream_t str
   hipLaunchKernelGGL(pack_tile_plan_kernel, dim3(sec_blocks), dim3(256), 0, stream, P);
   HIP_TRY(ctx, hipGetLastError());
   ps.planned = true;
+  ps.plan_elsewhere = stream != ctx->stream;
+  if (ps.plan_elsewhere) HIP_TRY(ctx, hipEventRecord(ps.plan_done, stream));
   return JXLT_OK;
 }
 
@@ -1211,6 +1224,7 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
   const size_t max_tiles = (size_t)(rec_bound / kPackTile) + nsec + 1;
   int rc;
   if (!ps.planned && (rc = EnqueuePlan(ctx, kind, rec_bound, ctx->stream)) != JXLT_OK) return rc;
+  if (ps.plan_elsewhere) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ps.plan_done, 0));
   if ((rc = EnsurePinned(ctx, &ps.h_sec_byte_off, nsec + 1)) != JXLT_OK) return rc;
   if ((rc = EnsurePinned(ctx, &ps.h_sec_bits, nsec)) != JXLT_OK) return rc;
   if ((rc = EnsurePinned(ctx, &ps.h_tile_base, nsec + 1)) != JXLT_OK) return rc;
@@ -1227,11 +1241,12 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
   if (ps.packed.cap < blob_bound && (rc = EnsureDevice(ctx, &ps.packed, blob_bound + blob_bound / 8)) != JXLT_OK)
     return rc;
   const PackTileArgs P = TileArgsOf(ctx, kind, nsec);
-  const unsigned sec_blocks = (unsigned)((nsec + 255) / 256);
   hipLaunchKernelGGL(pack_tile_measure_kernel,
                      dim3((unsigned)((max_tiles + kPackMeasureTilesPerGroup - 1) / kPackMeasureTilesPerGroup)),
                      dim3(kPackThreads), 0, ctx->stream, P);
-  hipLaunchKernelGGL(pack_tile_offsets_kernel, dim3(sec_blocks), dim3(256), 0, ctx->stream, P);
+  hipLaunchKernelGGL(pack_tile_offsets_kernel,
+                     dim3((unsigned)((nsec + kPackOffsetsSectionsPerGroup - 1) / kPackOffsetsSectionsPerGroup)),
+                     dim3(64 * kPackOffsetsSectionsPerGroup), 0, ctx->stream, P);
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, (const uint32_t*)ps.sec_bytes.p,
                      ps.sec_byte_off.p, (int)nsec);
   hipLaunchKernelGGL(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), 0, ctx->stream, P);

@@ -253,7 +253,9 @@ __attribute__((visibility("default"))) int sim_pack_direct(const uint8_t* record
   hipsim::launch(pack_tile_plan_kernel, dim3(sec_blocks), dim3(256), P);
   hipsim::launch(pack_tile_measure_kernel, dim3((unsigned)((max_tiles + kPackMeasureTilesPerGroup - 1) / kPackMeasureTilesPerGroup)),
                  dim3(kPackThreads), P);
-  hipsim::launch(pack_tile_offsets_kernel, dim3(sec_blocks), dim3(256), P);
+  hipsim::launch(pack_tile_offsets_kernel,
+                 dim3((unsigned)((nsec + kPackOffsetsSectionsPerGroup - 1) / kPackOffsetsSectionsPerGroup)),
+                 dim3(64 * kPackOffsetsSectionsPerGroup), P);
   hipsim::launch(group_scan_kernel, dim3(1), dim3(kScanThreads), (const uint32_t*)sec_bytes.data(), out_offset, nsec);
   hipsim::launch(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), P);
   const uint64_t ntiles = tile_base[nsec];
