@@ -103,25 +103,55 @@ __global__ void __launch_bounds__(256) dc_elementwise_kernel(const DcArgs A) {
   // DC tokens (WriteDCTokens, enc_frame.cc:287-316): the part's share of the block rows, a thread per block
   // column (a DC group is at most 256 blocks wide: no index divisions), the three channels in turn.
   {
+    // All of the thread's DC values are requested before the first record is stored (its column and the one to
+    // the left, the part's rows and the one above, three channels: 54 independent loads).  As a loop of "load the
+    // neighbours, store the record" every row waited for its own loads: the byte stores of the records may alias
+    // anything, so the compiler keeps the order.
+    constexpr int kRowsMax = 256 / kDcParts;  // a DC group is at most 256 block rows high
     const int rows_per = (d.nby + kDcParts - 1) / kDcParts;
     const int y0 = part * rows_per, y1 = imin(d.nby, y0 + rows_per);
     const int x = tid;
-    if (x < d.nbx) {
-      for (int y = y0; y < y1; y++) {
+    if (x < d.nbx && y0 < y1) {
+      int cur[3][kRowsMax + 1], lft[3][kRowsMax + 1];  // [channel in stream order][row - (y0 - 1)]
+#pragma unroll
+      for (int ci = 0; ci < 3; ci++) {
+        const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
+        const int16_t* q = A.quant_dc[c] + (size_t)d.by0 * bstride + d.bx0 + x;
+#pragma unroll
+        for (int r = 0; r <= kRowsMax; r++) {
+          const int y = y0 - 1 + r;
+          const bool there = y >= 0 && y < y1;
+          const int16_t* qr = q + (ptrdiff_t)(there ? y : y0) * (ptrdiff_t)bstride;
+          cur[ci][r] = there ? (int)qr[0] : 0;
+          lft[ci][r] = (there && x > 0) ? (int)qr[-1] : 0;
+        }
+      }
+      // (likewise the context look-ups: all of them before the first store)
+      uint8_t ctx_of[3][kRowsMax + 1];
+      int res_of[3][kRowsMax + 1];
+#pragma unroll
+      for (int r = 1; r <= kRowsMax; r++) {
+        const int y = y0 - 1 + r;
 #pragma unroll
         for (int ci = 0; ci < 3; ci++) {
-          const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
-          const int16_t* q = A.quant_dc[c] + (size_t)(d.by0 + y) * bstride + d.bx0 + x;
-          const int left = x ? q[-1] : y ? q[-(ptrdiff_t)bstride] : 0;
-          const int top = y ? q[-(ptrdiff_t)bstride] : left;
-          const int topleft = (x && y) ? q[-(ptrdiff_t)bstride - 1] : left;
+          const int left = x ? lft[ci][r] : y ? cur[ci][r - 1] : 0;
+          const int top = y ? cur[ci][r - 1] : left;
+          const int topleft = (x && y) ? lft[ci][r - 1] : left;
           const int guess = clamped_gradient(top, left, topleft);
           int gp = 512 + top + left - topleft;
           gp = gp < 0 ? 0 : gp > 1023 ? 1023 : gp;
-          const int residual = (int)q[0] - guess;
-          put_record(rec, d.pos_dc + (uint32_t)(ci * d.nb + y * d.nbx + x), A.tab->gradient_lut[gp],
-                     pack_signed(residual), hist);
+          res_of[ci][r] = cur[ci][r] - guess;
+          ctx_of[ci][r] = A.tab->gradient_lut[gp];
         }
+      }
+#pragma unroll
+      for (int r = 1; r <= kRowsMax; r++) {
+        const int y = y0 - 1 + r;
+        if (y >= y1) break;
+#pragma unroll
+        for (int ci = 0; ci < 3; ci++)
+          put_record(rec, d.pos_dc + (uint32_t)(ci * d.nb + y * d.nbx + x), ctx_of[ci][r], pack_signed(res_of[ci][r]),
+                     hist);
       }
     }
   }
