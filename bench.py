@@ -53,8 +53,8 @@ CHUNK_ROWS = 1024  # generator granularity: the frame's content does not depend 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=16384, help="frame is size x size pixels")
     ap.add_argument("--distance", type=float, default=1.0)
     ap.add_argument("--cpu-sample", type=int, default=8192,
