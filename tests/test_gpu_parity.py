@@ -164,6 +164,24 @@ def test_device_packed_sections_equal_host_packed(built, enc, w, h, distance):
     assert a == T.assemble_codestream(T.oracle_hot_path(planes, distance), distance)
 
 
+def test_output_buffer_keeps_early_sections_when_it_grows(built):
+    """The DC-group sections leave for the context's page-locked output buffer before the AC sections are
+    measured (jxlt_pack_measured + jxlt_pack_sections_place); when the frame turns out larger than the buffer
+    (sized by the previous frame), jxlt_output_buffer grows WITH its contents.  A fresh context, frames of
+    rising, falling and rising size, each several times (the second encode of a size finds the buffer right)."""
+    e = built.Encoder(0)
+    try:
+        for w, h, d, hard in [(64, 64, 1.0, False), (2100, 1300, 0.5, True), (300, 200, 2.0, False),
+                              (2600, 2100, 1.0, False), (520, 264, 1.0, True)]:
+            planes = T.to_planes(T.synthetic_image(w, h, seed=w + h, hard=hard))
+            want = T.assemble_codestream(T.oracle_hot_path(planes, d), d)
+            e.upload(planes)
+            for _ in range(3):
+                assert e.encode_resident(d, copy=False).tobytes() == want, (w, h)
+    finally:
+        e.close()
+
+
 def test_multi_encoder_two_contexts_equal_single_device(built):
     """jxlt_multi_encoder_* (BASELINE config #4 behind the C boundary): ONE frame cut into row slabs of whole
     DC groups over two device contexts (both on GPU 0 here), histograms summed on the host, every context
