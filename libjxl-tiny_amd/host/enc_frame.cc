@@ -129,6 +129,8 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   // (the expectation belongs to a frame size: a frame of another size starts without one)
   static thread_local double expected_dc_ms = 0.0, expected_ac_ms = 0.0;
   static thread_local size_t expected_for_pixels = 0;
+  // (a code construction that worked alone last time is not announced to the helper threads)
+  static thread_local bool dc_shared = true, ac_shared = true;
   static thread_local size_t last_frame_bytes = 0;  // (sizes the output buffer before the AC sections are measured)
   if (expected_for_pixels != xsize * ysize) {
     expected_for_pixels = xsize * ysize;
@@ -136,7 +138,7 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   }
   EntropyCode ac_code, dc_code;
   std::vector<uint32_t> ac_table(64 * 64), dc_table(64 * 64);
-  if (expected_dc_ms > 1.0) WarmCodeConstruction(expected_dc_ms - 0.5, expected_dc_ms + 1.5);
+  if (expected_dc_ms > 1.0 && dc_shared) WarmCodeConstruction(expected_dc_ms - 0.5, expected_dc_ms + 1.5);
   const uint32_t *ac_hist = nullptr, *dc_hist = nullptr;
   if (jxlt_fetch_dc_histogram(ctx, &dc_hist) != JXLT_OK) {
     fprintf(stderr, "jxl_tiny_amd: fetch failed: %s\n", jxlt_last_error(ctx));
@@ -144,7 +146,9 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   }
   const auto t0a = now();
   expected_dc_ms = ms(t0, t0a);
+  (void)TakeClusteringShared();
   BuildDcCode(dc_hist, &dc_code);
+  dc_shared = TakeClusteringShared();
   FillCodeTable(dc_code, dc_table.data());
   // the DC-group sections are packed behind token_kernel, while the host builds the AC code
   if (jxlt_pack_measure_begin(ctx, 0, dc_table.data()) != JXLT_OK) {
@@ -161,7 +165,8 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   const auto t0b = now();
   {
     const double left = expected_ac_ms - ms(t0, t0b);  // until the AC histogram is expected
-    if (expected_ac_ms > 1.0) WarmCodeConstruction(left > 0.5 ? left - 0.5 : 0.0, (left > 0.0 ? left : 0.0) + 1.5);
+    if (expected_ac_ms > 1.0 && ac_shared)
+      WarmCodeConstruction(left > 0.5 ? left - 0.5 : 0.0, (left > 0.0 ? left : 0.0) + 1.5);
   }
   if (jxlt_fetch_histograms(ctx, &ac_hist, nullptr) != JXLT_OK) {
     fprintf(stderr, "jxl_tiny_amd: fetch failed: %s\n", jxlt_last_error(ctx));
@@ -170,6 +175,7 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   const auto t1 = now();
   expected_ac_ms = ms(t0, t1);
   BuildAcCode(ac_hist, &ac_code);
+  ac_shared = TakeClusteringShared();
   FillCodeTable(ac_code, ac_table.data());
   const auto t2 = now();
   if (trace)

@@ -356,6 +356,15 @@ class ClusterPool {
 
 }  // namespace
 
+namespace {
+thread_local bool t_clustering_shared = false;
+}
+bool TakeClusteringShared() {
+  const bool was = t_clustering_shared;
+  t_clustering_shared = false;
+  return was;
+}
+
 void WarmCodeConstruction(double start_in_ms, double give_up_in_ms) {
   const auto now = std::chrono::steady_clock::now();
   ClusterPool::Get().Warm(now + std::chrono::microseconds(static_cast<long long>(start_in_ms * 1e3)),
@@ -470,6 +479,7 @@ void ClusterHistograms(std::vector<Histogram>* histograms, std::vector<uint8_t>*
     symbols[i] = static_cast<uint32_t>(best);
   }
   if (pooled) pool.Close();
+  if (pooled) t_clustering_shared = true;
   {
     const int ran = pooled ? 1 : 0;  // (a busy pool means the serial way was taken)
     const double ms_taken =

@@ -103,6 +103,9 @@ void CreateHuffmanTree(const uint32_t* counts, size_t length, int tree_limit, ui
 // previous frame's device pipeline) can announce it: the helpers wake up `start_in_ms` from now
 // and spin for the session until `give_up_in_ms` from now.  Purely a latency hint.
 void WarmCodeConstruction(double start_in_ms, double give_up_in_ms);
+// Whether a clustering of the calling thread has used the helper threads since the last call of this function
+// (a caller that announces its code constructions need not announce the ones that work alone).
+bool TakeClusteringShared();
 void ConvertBitDepthsToSymbols(const uint8_t* depth, size_t len, uint16_t* bits);
 
 // Clusters `histograms` (in place, result = cluster histograms) and returns the

@@ -14,7 +14,7 @@ print(sys.argv[1], "step", d["ms_per_step"], "| AC code %.3f ms | DC code %.3f m
 PY
 }
 DIST=${2:-1}
-for rep in 1 2 3; do
+for rep in ${REPS:-1 2 3}; do
   for t in ${1:-auto 0 1}; do
     if [ "$t" = auto ]; then unset JXLT_POOL_MODE; else export JXLT_POOL_MODE=$t; fi
     run "mode=$t"
