@@ -895,7 +895,19 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
       const char* e = getenv("JXLT_TILE_EXTRA_LDS");
       return e ? (unsigned)atoi(e) : 0u;
     }();
-    if (exact_roots)
+    // (experiment knob: JXLT_TILE_WAVES=8|12 selects the 8-wave or the 12-wave variant of the kernel)
+    static const int tile_waves = [] {
+      const char* e = getenv("JXLT_TILE_WAVES");
+      return e && atoi(e) == 12 ? 12 : e && atoi(e) == 8 ? 8 : kDefaultTileWaves;
+    }();
+    if (tile_waves == 12) {
+      if (exact_roots)
+        hipLaunchKernelGGL(tile12_kernel_exact_roots, dim3(slab_tiles), dim3(kTile12Threads), extra_lds, ctx->stream, S);
+      else if (debug || profile)
+        hipLaunchKernelGGL(tile12_kernel_debug, dim3(slab_tiles), dim3(kTile12Threads), extra_lds, ctx->stream, S);
+      else
+        hipLaunchKernelGGL(tile12_kernel, dim3(slab_tiles), dim3(kTile12Threads), extra_lds, ctx->stream, S);
+    } else if (exact_roots)
       hipLaunchKernelGGL(tile_kernel_exact_roots, dim3(slab_tiles), dim3(kTileThreads), extra_lds, ctx->stream, S);
     else if (debug || profile)
       hipLaunchKernelGGL(tile_kernel_debug, dim3(slab_tiles), dim3(kTileThreads), extra_lds, ctx->stream, S);

@@ -139,6 +139,13 @@ struct TokenArgs {
 #define JXLT_TOUCH_VGPR(x) asm volatile("" ::"v"(x))
 #endif
 
+// The value of x from here on is "new" to the compiler (no instruction): nothing computed from the old value can
+// be reused, so what was derived from it does not have to stay in registers.  The CPU execution model defines
+// this as nothing.
+#ifndef JXLT_LAUNDER_VGPR
+#define JXLT_LAUNDER_VGPR(x) asm volatile("" : "+v"(x))
+#endif
+
 JXLT_DI float fma32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 JXLT_DI float nfma32(float a, float b, float c) { return __builtin_fmaf(-a, b, c); }
 // min(max(x, 0), 1): folds into the clamp modifier of the instruction that produces x.
@@ -409,6 +416,10 @@ JXLT_DI void dct8(float* m) {
   m[4] = a2; m[5] = b2; m[6] = a3; m[7] = b3;
 }
 
+// kFenced: scheduling fences between the stages, so that no more than 24 values are live at a time (the 12-wave
+// kernel, which has 80 registers; left to itself the scheduler keeps the inputs, both halves and the first
+// half's transform in flight together).
+template <bool kFenced = false>
 JXLT_DI void dct16(float* m) {
   const float kW[8] = {(float)0.5024192861881557, (float)0.5224986149396889,
                        (float)0.5669440348163577, (float)0.6468217833599901,
@@ -417,9 +428,14 @@ JXLT_DI void dct16(float* m) {
   float a[8], b[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) a[i] = m[i] + m[15 - i];
-  dct8(a);
+  if (!kFenced) dct8(a);
 #pragma unroll
   for (int i = 0; i < 8; i++) b[i] = (m[i] - m[15 - i]) * kW[i];
+  if (kFenced) {
+    JXLT_SCHED_FENCE();
+    dct8(a);
+    JXLT_SCHED_FENCE();
+  }
   dct8(b);
   b[0] = fma32(b[0], JXLT_SQRT2, b[1]);
 #pragma unroll
@@ -484,36 +500,38 @@ constexpr int kTransposePitch = 72;
 #ifndef JXLT_WAVE_SYNC
 #define JXLT_WAVE_SYNC() JXLT_OCTET_SYNC()
 #endif
+// kViaLds = false: the register butterfly (the octets of the 12-wave kernel that have no LDS scratch of their own).
+template <bool kViaLds = (JXLT_LDS_TRANSPOSE != 0)>
 JXLT_DI void octet_transpose(float* v, float* sc, int l) {
-#if JXLT_LDS_TRANSPOSE
-  // Element (row r, column c) lives at (c >> 2) * 36 + r * 4 + (c & 3): the two 16-byte halves of
-  // the rows form two dense 128-byte runs (the reads of the eight lanes are consecutive 16-byte
-  // chunks), and the 4-dword gap between the runs puts the eight dwords a store instruction
-  // writes per octet (column l of row j) into eight consecutive banks.
-  float* const w = sc + (l >> 2) * 36 + (l & 3);
+  if (kViaLds) {
+    // Element (row r, column c) lives at (c >> 2) * 36 + r * 4 + (c & 3): the two 16-byte halves of
+    // the rows form two dense 128-byte runs (the reads of the eight lanes are consecutive 16-byte
+    // chunks), and the 4-dword gap between the runs puts the eight dwords a store instruction
+    // writes per octet (column l of row j) into eight consecutive banks.
+    float* const w = sc + (l >> 2) * 36 + (l & 3);
 #pragma unroll
-  for (int j = 0; j < 8; j++) w[j * 4] = v[j];
-  JXLT_OCTET_SYNC();
-  const float4 a = *reinterpret_cast<const float4*>(sc + l * 4);
-  const float4 b = *reinterpret_cast<const float4*>(sc + 36 + l * 4);
-  JXLT_OCTET_SYNC();  // (the next transpose overwrites the scratch)
-  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-  v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-#else
-  (void)sc;
-  octet_exchange<4>(v[0], v[4], l);
-  octet_exchange<4>(v[1], v[5], l);
-  octet_exchange<4>(v[2], v[6], l);
-  octet_exchange<4>(v[3], v[7], l);
-  octet_exchange<2>(v[0], v[2], l);
-  octet_exchange<2>(v[1], v[3], l);
-  octet_exchange<2>(v[4], v[6], l);
-  octet_exchange<2>(v[5], v[7], l);
-  octet_exchange<1>(v[0], v[1], l);
-  octet_exchange<1>(v[2], v[3], l);
-  octet_exchange<1>(v[4], v[5], l);
-  octet_exchange<1>(v[6], v[7], l);
-#endif
+    for (int j = 0; j < 8; j++) w[j * 4] = v[j];
+    JXLT_OCTET_SYNC();
+    const float4 a = *reinterpret_cast<const float4*>(sc + l * 4);
+    const float4 b = *reinterpret_cast<const float4*>(sc + 36 + l * 4);
+    JXLT_OCTET_SYNC();  // (the next transpose overwrites the scratch)
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+    (void)sc;
+    octet_exchange<4>(v[0], v[4], l);
+    octet_exchange<4>(v[1], v[5], l);
+    octet_exchange<4>(v[2], v[6], l);
+    octet_exchange<4>(v[3], v[7], l);
+    octet_exchange<2>(v[0], v[2], l);
+    octet_exchange<2>(v[1], v[3], l);
+    octet_exchange<2>(v[4], v[6], l);
+    octet_exchange<2>(v[5], v[7], l);
+    octet_exchange<1>(v[0], v[1], l);
+    octet_exchange<1>(v[2], v[3], l);
+    octet_exchange<1>(v[4], v[5], l);
+    octet_exchange<1>(v[6], v[7], l);
+  }
 }
 
 // Block transforms.  `px` points at the block's top-left sample in an LDS plane
@@ -526,31 +544,36 @@ JXLT_DI void octet_transpose(float* v, float* sc, int l) {
 // differences are 0 or >= 1 ulp of O(0.1) values), so both are applied once at the end.
 
 // ComputeScaledDCT<8,8> (enc_transforms-inl.h:527-546): i = h*8 + v
+template <bool kViaLds = (JXLT_LDS_TRANSPOSE != 0)>
 JXLT_DI void block_dct8x8(const float* px, int pitch, int l, float* sc, float* c) {
 #pragma unroll
   for (int y = 0; y < 8; y++) c[y] = px[y * pitch + l];
   dct8(c);
-  octet_transpose(c, sc, l);  // lane v now holds 8*A[v][x], x = 0..7
+  octet_transpose<kViaLds>(c, sc, l);  // lane v now holds 8*A[v][x], x = 0..7
   dct8(c);
 #pragma unroll
   for (int y = 0; y < 8; y++) c[y] = (1.0f / 64) * c[y];  // c[h] = C[h][v=l]
 }
 
 // ComputeScaledDCT<16,8>: 16 rows x 8 cols, i = h*16 + v; r = 2h + (v>=8), lane = v&7
+template <bool kFenced = false>
 JXLT_DI void block_dct16x8(const float* px, int pitch, int l, float* sc, float* c) {
   float col[16];
 #pragma unroll
   for (int y = 0; y < 16; y++) col[y] = px[y * pitch + l];
-  dct16(col);
+  dct16<kFenced>(col);
   float lo[8], hi[8];
 #pragma unroll
   for (int v = 0; v < 8; v++) {
     lo[v] = col[v];
     hi[v] = col[v + 8];
   }
+  if (kFenced) JXLT_SCHED_FENCE();
   octet_transpose(lo, sc, l);  // lane t: A[t][x]
   octet_transpose(hi, sc, l);  // lane t: A[t+8][x]
+  if (kFenced) JXLT_SCHED_FENCE();
   dct8(lo);
+  if (kFenced) JXLT_SCHED_FENCE();
   dct8(hi);
 #pragma unroll
   for (int h = 0; h < 8; h++) {
@@ -560,6 +583,7 @@ JXLT_DI void block_dct16x8(const float* px, int pitch, int l, float* sc, float* 
 }
 
 // ComputeScaledDCT<8,16>: 8 rows x 16 cols, i = v*16 + h; r = 2v + (h>=8), lane = h&7
+template <bool kFenced = false>
 JXLT_DI void block_dct8x16(const float* px, int pitch, int l, float* sc, float* c) {
   float lo[8], hi[8];
 #pragma unroll
@@ -568,7 +592,9 @@ JXLT_DI void block_dct8x16(const float* px, int pitch, int l, float* sc, float* 
     hi[y] = px[y * pitch + l + 8];
   }
   dct8(lo);
+  if (kFenced) JXLT_SCHED_FENCE();
   dct8(hi);
+  if (kFenced) JXLT_SCHED_FENCE();
   octet_transpose(lo, sc, l);  // lane v: A[v][x], x < 8
   octet_transpose(hi, sc, l);  // lane v: A[v][x], x >= 8
   float row[16];
@@ -577,7 +603,8 @@ JXLT_DI void block_dct8x16(const float* px, int pitch, int l, float* sc, float* 
     row[x] = lo[x];
     row[x + 8] = hi[x];
   }
-  dct16(row);
+  if (kFenced) JXLT_SCHED_FENCE();
+  dct16<kFenced>(row);
 #pragma unroll
   for (int h = 0; h < 8; h++) {
     lo[h] = (1.0f / 128) * row[h];

@@ -13,6 +13,12 @@ namespace jxlt_dev {
 // ---------------------------------------------------------------------------
 
 constexpr int kTileThreads = 512;
+// The 12-wave variant (tile12_kernel*): the same tile, the same LDS, 768 threads.  Octets 0-31 hold the DCT8
+// coefficients of TWO blocks each, octets 32-95 one two-block candidate each (the 8-wave kernel keeps a block AND a
+// candidate per octet): half the coefficient registers per thread, 12 waves per workgroup, two workgroups per CU =
+// 6 waves per SIMD instead of 4 when the kernel fits 80 vector registers.
+constexpr int kTile12Threads = 768;
+constexpr int kDefaultTileWaves = 12;  // which variant the C ABI launches (JXLT_TILE_WAVES overrides)
 constexpr int kHalo = 5;                 // AQ: +-4 px window, +-1 px Laplacian tap
 constexpr int kXYPitch = 64 + 2 * kHalo + 1;  // 75 floats (odd: conflict-free columns)
 constexpr int kBPitch = 65;
@@ -34,9 +40,11 @@ struct alignas(16) TileShared {
   //   read is done: 64 blocks x 64 coefficients x (a_x, b_x, a_b, b_b).
   // rowsum..transpose_pad: during the transforms (the AQ buffers are dead by then) the octets'
   // transpose scratch, 64 x kTransposePitch floats.
-  float transpose_pad[64 * 72 - (kCflTermFloats - (2 * 64 * kXYPitch + 64 * kBPitch))];
+  // (+ 192: transpose_pad and sqrt_lut together are the 25 x 128 floats in which the chain waves of the 12-wave
+  // kernel park coefficients during the chains)
+  float transpose_pad[64 * 72 - (kCflTermFloats - (2 * 64 * kXYPitch + 64 * kBPitch)) + 192];
   // (its first 128 floats hold the candidate entropies of the 2x2 cells during the strategy search, "ent8")
-  float sqrt_lut[kSqrtLutSize];  // sqrtf of the quantised magnitudes below kSqrtLutSize
+  float sqrt_lut[1024];  // sqrtf of the quantised magnitudes below kSqrtLutSize (<= 1024; test builds use fewer)
   float inv_w[576];
   float aq[64];            // quant field (tile-local 8x8)
   float mask[64];
@@ -60,7 +68,9 @@ JXLT_DI int imax(int a, int b) { return a > b ? a : b; }
 // read instead of v_sqrt + the exact-rounding fix-up, ~40 cycles); *qmax then receives the
 // largest magnitude seen, and the caller redoes the estimate with kLut = false if it is beyond
 // the table (quantised coefficients >= 1024: practically never, but results must not depend on it).
-template <int NR, bool kLut>
+// kParkedB: the B coefficients are not in registers but in LDS, row r at cb[r * kParkStride] (the 12-wave
+// kernel parks them there for the duration of the estimates: 32 instead of 48 coefficient registers).
+template <int NR, bool kLut, bool kParkedB = false, int kParkStride = 1>
 JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb, const float* inv_x,
                                const float* inv_y, const float* inv_b, int l, float quant,
                                float masking, float cmap_x, float cmap_b, float distance,
@@ -91,7 +101,7 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
     // x + (c ? k : 0) == fma(c, k, x) for c in {0, 1}.
 #pragma unroll
     for (int r = 0; r < NR; r++) {
-      const float in = cin[r];
+      const float in = (kParkedB && c == 2) ? cin[r * kParkStride] : cin[r];
       const float im = inv[r * 8 + l];
       // (skipping the subtraction of cy * 0 for the Y channel saves two instructions per
       // coefficient on paper; the register allocator then spills 90 VGPRs)
@@ -148,12 +158,17 @@ JXLT_DI float adjust_quant_bias_y(float quant) {
 
 // kDebug: the variant that serves the A.dbg_* outputs (per-phase clocks, intermediate planes for
 // the parity tests); the production variant has none of their tests, branches and registers.
-template <bool kLutRoots, bool kDebug>
+template <bool kLutRoots, bool kDebug, int kWaves = 8>
 JXLT_DI void tile_kernel_body(const TileArgs& A) {
+  static_assert(kWaves == 8 || kWaves == 12, "8: an octet per block and candidate; 12: role-split octets");
+  constexpr bool k12 = kWaves == 12;
+  constexpr int kThreads = kWaves * 64;
   __shared__ TileShared S;
-  const int tid = (int)threadIdx.x;
-  const int l = tid & 7;    // lane within octet
-  const int oct = tid >> 3;  // octet index == block index within tile (0..63)
+  // (not const: the 12-wave variant re-derives the per-thread values from a "laundered" thread index at phase
+  // boundaries, so that the values of one phase are not kept in registers across another phase's peak)
+  int tid = (int)threadIdx.x;
+  int l = tid & 7;    // lane within octet
+  int oct = tid >> 3;  // octet index; for octets 0..63 == block index within tile
   const DeviceTables* T = A.tab;
   long long t_prev = (kDebug && A.dbg_phase) ? clock64() : 0;
   // Profiling builds (-DJXLT_PHASE_STOPS, tools/phase_pmc.py) can truncate the kernel after
@@ -192,8 +207,8 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
   const int nbx = imin(8, swp / 8 - tbx0), nby = shp / 8;   // tile size in blocks
   const int px0 = tbx0 * 8;                                 // tile origin in stripe pixels
   const int bx_img0 = gx * 32 + tbx0, by_img0 = ty_img * 8; // image-absolute block origin
-  const int obx = oct & 7, oby = oct >> 3;                  // octet's block in the tile
-  const bool blk_valid = obx < nbx && oby < nby;
+  int obx = oct & 7, oby = oct >> 3;                        // octet's block in the tile
+  bool blk_valid = obx < nbx && oby < nby;
   const uint32_t bstride = (uint32_t)A.g.xsize_blocks;
 
   // ---- P0: tables -> LDS; load + XYB (enc_frame.cc:597-617, enc_xyb.cc) -----
@@ -201,15 +216,15 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
   // pixel requests below, so that all of the tile's global loads are in flight together.  (Loops of "load, wait,
   // store to LDS" in front of the pixel loads cost six serial round trips to L2 per tile.)
   static_assert(kTileThreads == 512 && (kSqrtLutSize <= 512 || kSqrtLutSize == 1024), "table staging below");
-  const float tab_inv0 = T->inv_weights[tid];
+  const float tab_inv0 = T->inv_weights[k12 ? imin(tid, 575) : tid];
   const float tab_inv1 = T->inv_weights[512 + (tid & 63)];
-  const float tab_root0 = T->sqrt_lut[tid & (kSqrtLutSize - 1)];
-  const float tab_root1 = T->sqrt_lut[(512 + tid) & (kSqrtLutSize - 1)];
+  const float tab_root0 = k12 ? 0.0f : T->sqrt_lut[tid & (kSqrtLutSize - 1)];
+  const float tab_root1 = k12 ? 0.0f : T->sqrt_lut[(kThreads + tid) & (kSqrtLutSize - 1)];
   if (tid == 0) {
     S.ntok = 0;
     S.nfirst = 0;
   }
-  {
+  if constexpr (!k12) {
     // 16 lanes along x, 32 rows per pass: a thread owns 5 columns x 2 rows of the
     // (64 + 2*kHalo)-wide window, so the row and column clamps are shared and all thirty loads
     // are in flight before the first use.  Column slots 0-3 cover the 64 interior columns; slot 4
@@ -284,6 +299,65 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
         }
       }
     }
+  } else {
+    // 12 waves: the 64 interior columns along the lanes, wave w takes the rows w, w + 12, ... (six of them for
+    // waves 0-3, five for the others); the ten halo columns (X and Y only) as 6 rows x 10 columns per wave, one
+    // pixel per thread.  All 21 loads of a thread are requested before the first use.
+    constexpr int kWin = 64 + 2 * kHalo;
+    const int c = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: the rows' offsets are scalar)
+    const int xi = px0 + c;
+    const bool xok_i = xi < swp && c < nbx * 8 + kHalo;
+    const int xs_i = (xok_i ? imin(xi, sw - 1) : 0) * A.pix_stride;
+    const int hr = (c * 205) >> 11, hc = c - 10 * hr;  // lane -> (row 0..6, halo column 0..9): c / 10, c % 10
+    const int hy = 6 * w + hr;
+    const int hcx = hc < kHalo ? hc : 64 + hc;          // LDS column of the halo pixel
+    const int hx = px0 - kHalo + hcx;
+    const bool hok = hr < 6 && hy < shp && hx >= 0 && hx < swp && hx < px0 + nbx * 8 + kHalo;
+    const int xs_h = (hok ? imin(hx, sw - 1) : 0) * A.pix_stride;
+    float pr[7], pg[7], pb[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+      const int y = k < 6 ? w + 12 * k : hy;
+      const ptrdiff_t off = (ptrdiff_t)(sy0 + imin(y, sh - 1)) * A.pitch + (ptrdiff_t)sx0 * A.pix_stride +
+                            (k < 6 ? xs_i : xs_h);
+      pr[k] = A.planes[0][off];
+      pg[k] = A.planes[1][off];
+      pb[k] = A.planes[2][off];
+    }
+    if (tid < 576) S.inv_w[tid] = tab_inv0;
+    // (the root table is staged behind the chains of P5b: until then its place in LDS serves the chain waves)
+    if (A.byteswap) {  // big-endian PFM payload (BSwapFloat, read_pfm.cc:206)
+#pragma unroll
+      for (int k = 0; k < 7; k++) {
+        pr[k] = __uint_as_float(__builtin_bswap32(__float_as_uint(pr[k])));
+        pg[k] = __uint_as_float(__builtin_bswap32(__float_as_uint(pg[k])));
+        pb[k] = __uint_as_float(__builtin_bswap32(__float_as_uint(pb[k])));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const int y = w + 12 * k;
+      if (y >= 64 || y >= shp) break;  // (wave-uniform)
+      if (!xok_i) continue;
+      float px_, py_, pb_;
+      linear_to_xyb<true>(pr[k], pg[k], pb[k], &px_, &py_, &pb_);
+      S.x[y * kXYPitch + kHalo + c] = px_;
+      S.y[y * kXYPitch + kHalo + c] = py_;
+      S.b[y * kBPitch + c] = pb_;
+      if (kDebug && A.dbg_xyb[0] && c < nbx * 8) {
+        const size_t d = (size_t)(by_img0 * 8 + y) * ((size_t)bstride * 8) + (size_t)(bx_img0 * 8 + c);
+        A.dbg_xyb[0][d] = px_;
+        A.dbg_xyb[1][d] = py_;
+        A.dbg_xyb[2][d] = pb_;
+      }
+    }
+    if (hok) {
+      float px_, py_, pb_ = 0.0f;
+      linear_to_xyb<false>(pr[6], pg[6], pb[6], &px_, &py_, &pb_);
+      S.x[hy * kXYPitch + hcx] = px_;
+      S.y[hy * kXYPitch + hcx] = py_;
+    }
+    (void)kWin;
   }
   __syncthreads();
   JXLT_MARK(0);
@@ -323,7 +397,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     };
     // (Spreading the last, partly filled pass over all threads row by row changes nothing: the
     // other resident workgroup takes the issue slots the idle waves leave.)
-    for (int i = tid; i < nbands * aq_w; i += kTileThreads) {
+    for (int i = tid; i < nbands * aq_w; i += kThreads) {
       const int q = i / aq_w, x = aq_x0 + i % aq_w;
       const bool vec = x >= vs && x < ve;
       const int xl = x > 0 ? x - 1 : x, xr = x + 1 < swp ? x + 1 : x;
@@ -408,7 +482,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
   __syncthreads();
   JXLT_MARK(2);
   // ---- P4: per-block modulations, one octet per block (:114-285) -------------
-  {
+  if (!k12 || tid < 512) {  // (12 waves: octets 0..63 = waves 0-7)
     float out_val = 0.0f;
     const int bxp = px0 + obx * 8, byp = oby * 8;  // block origin (stripe pixels)
     if (blk_valid) {
@@ -508,42 +582,101 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
   // Waves 0-3 take the 32 DCT16X8 candidates, waves 4-7 the 32 DCT8X16 candidates.
   // Done before chroma-from-luma so that afterwards no pixel is needed any more; the
   // coefficients stay in registers for the entropy estimate and for P8.
-  float* const tsc = &S.rowsum[0] + oct * kTransposePitch;  // octet's transpose scratch (AQ buffers are dead)
-  float c16x[16], c16y[16], c16b[16];
+  // 12 waves: octets 0..31 (waves 0-3) are PAIR octets -- the DCT8 of the blocks (pbx, pby0) and (pbx, pby0 + 1) --
+  // and octets 32..95 the 64 candidate octets (candidate octet co = oct - 32 has the 8-wave kernel's role of
+  // octet co there).  8 waves: every octet is a candidate octet and holds its own block's DCT8 as well.
+  // (the roles are wave-uniform, and the compiler is told so: scalar branches, one set of coefficient registers)
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool pair_role = k12 && wave_u < 4;
+  const bool cand_role = !k12 || wave_u >= 4;
   const bool search = (A.flags & 1u) == 0;
-  const int cand = oct & 31;           // candidate index within its type
-  const int cell = cand >> 1;          // 2x2 cell index (4x4 cells per tile)
-  const int ccx = (cell & 3) * 2, ccy = (cell >> 2) * 2;  // cell origin (tile blocks)
-  const bool is_tall = oct < 32;       // DCT16X8 (16 rows x 8 cols)
-  const int cbx = is_tall ? ccx + (cand & 1) : ccx;       // candidate's first block
-  const int cby = is_tall ? ccy : ccy + (cand & 1);
-  const bool cell_valid = search && (ccx + 1 < nbx) && (ccy + 1 < nby);
-  if (cell_valid) {
+  const bool is_tall = k12 ? wave_u < 8 : oct < 32;  // DCT16X8 (16 rows x 8 cols)
+  int co, pbx, pby0, cand, cell, ccx, ccy, cbx, cby;
+  bool pair_valid0, pair_valid1, cell_valid;
+  float* tsc;
+  auto derive_roles = [&]() {
+    co = k12 ? (oct >= 32 ? oct - 32 : 0) : oct;  // candidate octet index (0..63)
+    pbx = oct & 7, pby0 = (oct >> 3) * 2;          // pair octet's blocks (12 waves)
+    pair_valid0 = pair_role && pbx < nbx && pby0 < nby, pair_valid1 = pair_role && pbx < nbx && pby0 + 1 < nby;
+    tsc = &S.rowsum[0] + co * kTransposePitch;  // candidate octet's transpose scratch (AQ buffers are dead)
+    cand = co & 31;                       // candidate index within its type
+    cell = cand >> 1;                     // 2x2 cell index (4x4 cells per tile)
+    ccx = (cell & 3) * 2, ccy = (cell >> 2) * 2;  // cell origin (tile blocks)
+    cbx = is_tall ? ccx + (cand & 1) : ccx;       // candidate's first block
+    cby = is_tall ? ccy : ccy + (cand & 1);
+    cell_valid = cand_role && search && (ccx + 1 < nbx) && (ccy + 1 < nby);
+  };
+  derive_roles();
+  // Re-derives every per-thread value from the thread index behind a compiler barrier (12 waves only).
+  auto new_phase = [&]() {
+    if constexpr (k12) {
+      JXLT_LAUNDER_VGPR(tid);
+      l = tid & 7;
+      oct = tid >> 3;
+      obx = oct & 7, oby = oct >> 3;
+      blk_valid = obx < nbx && oby < nby;
+      derive_roles();
+    }
+  };
+  new_phase();
+  float c16x[16], c16y[16], c16b[16];
+  // 12 waves: a pair octet's two DCT8 live in the registers a candidate octet uses for its transform (rows 0-7:
+  // first block, rows 8-15: second block), so that a thread needs ONE set of 48 coefficient registers.
+  float s8x[8], s8y[8], s8b[8];  // 8 waves: the octet's own block
+  float* const c8x = k12 ? c16x : s8x;
+  float* const c8y = k12 ? c16y : s8y;
+  float* const c8b = k12 ? c16b : s8b;
+  float* const d8x = c16x + 8;
+  float* const d8y = c16y + 8;
+  float* const d8b = c16b + 8;
+  if (pair_role) {
+    // the pair octets have no LDS scratch (the 64 there are belong to the candidate octets, which transpose
+    // at the same time): their transposes are register butterflies
+    const float* pxp = &S.x[(pby0 * 8) * kXYPitch + pbx * 8 + kHalo];
+    const float* pyp = &S.y[(pby0 * 8) * kXYPitch + pbx * 8 + kHalo];
+    const float* pbp = &S.b[(pby0 * 8) * kBPitch + pbx * 8];
+    if (pair_valid0) {
+      block_dct8x8<false>(pxp, kXYPitch, l, nullptr, c8x);
+      JXLT_SCHED_FENCE();
+      block_dct8x8<false>(pyp, kXYPitch, l, nullptr, c8y);
+      JXLT_SCHED_FENCE();
+      block_dct8x8<false>(pbp, kBPitch, l, nullptr, c8b);
+      JXLT_SCHED_FENCE();
+    }
+    // (blocks outside the frame: the registers stay undefined, every later use is under the same condition)
+    if (pair_valid1) {
+      block_dct8x8<false>(pxp + 8 * kXYPitch, kXYPitch, l, nullptr, d8x);
+      JXLT_SCHED_FENCE();
+      block_dct8x8<false>(pyp + 8 * kXYPitch, kXYPitch, l, nullptr, d8y);
+      JXLT_SCHED_FENCE();
+      block_dct8x8<false>(pbp + 8 * kBPitch, kBPitch, l, nullptr, d8b);
+      JXLT_SCHED_FENCE();
+    }
+  } else if (cell_valid) {
     const float* pxp = &S.x[(cby * 8) * kXYPitch + cbx * 8 + kHalo];
     const float* pyp = &S.y[(cby * 8) * kXYPitch + cbx * 8 + kHalo];
     const float* pbp = &S.b[(cby * 8) * kBPitch + cbx * 8];
     // (scheduling fences: interleaving the three independent transforms would triple the
     // live registers and spill)
     if (is_tall) {
-      block_dct16x8(pxp, kXYPitch, l, tsc, c16x);
+      block_dct16x8<k12>(pxp, kXYPitch, l, tsc, c16x);
       JXLT_SCHED_FENCE();
-      block_dct16x8(pyp, kXYPitch, l, tsc, c16y);
+      block_dct16x8<k12>(pyp, kXYPitch, l, tsc, c16y);
       JXLT_SCHED_FENCE();
-      block_dct16x8(pbp, kBPitch, l, tsc, c16b);
+      block_dct16x8<k12>(pbp, kBPitch, l, tsc, c16b);
     } else {
-      block_dct8x16(pxp, kXYPitch, l, tsc, c16x);
+      block_dct8x16<k12>(pxp, kXYPitch, l, tsc, c16x);
       JXLT_SCHED_FENCE();
-      block_dct8x16(pyp, kXYPitch, l, tsc, c16y);
+      block_dct8x16<k12>(pyp, kXYPitch, l, tsc, c16y);
       JXLT_SCHED_FENCE();
-      block_dct8x16(pbp, kBPitch, l, tsc, c16b);
+      block_dct8x16<k12>(pbp, kBPitch, l, tsc, c16b);
     }
     JXLT_SCHED_FENCE();
   }
   JXLT_MARK(4);
   // ---- P5: DCT8 of every block (kept in registers) + chroma-from-luma -------
   // (enc_chroma_from_luma.cc:40-131)
-  float c8x[8], c8y[8], c8b[8];
-  {
+  if constexpr (!k12) {
     const float* pxp = &S.x[(oby * 8) * kXYPitch + obx * 8 + kHalo];
     const float* pyp = &S.y[(oby * 8) * kXYPitch + obx * 8 + kHalo];
     const float* pbp = &S.b[(oby * 8) * kBPitch + obx * 8];
@@ -561,6 +694,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     }
   }
   __syncthreads();  // all pixel reads done: the planes are dead from here on
+  new_phase();
   JXLT_MARK(5);
   // ---- P5b: chroma-from-luma (enc_chroma_from_luma.cc:40-131) ----------------
   {
@@ -580,8 +714,9 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     const float* qm_b = S.inv_w + 128;  // InvMatrix(DCT, 2)
     const int nblk = nbx * nby;
     const float kInvColorFactor = 1.0f / 84;
-    if (blk_valid) {
-      float* dst = &terms[(oby * nbx + obx) * 256 + l * 32];
+    // (the terms of raster block `rb` of the tile from the lane's rows of its DCT8 coefficients)
+    auto publish = [&](int rb, const float* vx, const float* vy, const float* vb) {
+      float* dst = &terms[rb * 256 + l * 32];
 #pragma unroll
       for (int r = 0; r < 8; r += 2) {
         float4 tx, tb;
@@ -589,7 +724,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
         for (int h = 0; h < 2; h++) {
           const int rr = r + h;
           const bool dc = (rr == 0 && l == 0);  // block_*[0] = 0 (:109-111)
-          const float by_ = dc ? 0.0f : c8y[rr], bx_ = dc ? 0.0f : c8x[rr], bb_ = dc ? 0.0f : c8b[rr];
+          const float by_ = dc ? 0.0f : vy[rr], bx_ = dc ? 0.0f : vx[rr], bb_ = dc ? 0.0f : vb[rr];
           const float qx = qm_x[rr * 8 + l], qb = qm_b[rr * 8 + l];
           const float m_x = by_ * qx, s_x = bx_ * qx, m_b = by_ * qb, s_b = bb_ * qb;
           const float ax = kInvColorFactor * m_x, bx2 = 0.0f * m_x - s_x;
@@ -600,6 +735,12 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
         *(float4*)&dst[(((r >> 1)) ^ lsw) * 4] = tx;
         *(float4*)&dst[((4 + (r >> 1)) ^ lsw) * 4] = tb;
       }
+    };
+    if constexpr (k12) {
+      if (pair_valid0) publish(pby0 * nbx + pbx, c8x, c8y, c8b);
+      if (pair_valid1) publish((pby0 + 1) * nbx + pbx, d8x, d8y, d8b);
+    } else {
+      if (blk_valid) publish(oby * nbx + obx, c8x, c8y, c8b);
     }
     __syncthreads();
     // Chain lanes: wave 0 lanes 0-15 run ca (X: 0-7, B: 8-15), wave 1 lanes 0-15 run cb.
@@ -607,7 +748,17 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     // the critical path of the workgroup: they run at raised issue priority, and the reads
     // of block blk + 1 are issued before the arithmetic of block blk.
     float acc = 0.0f;
-    const int cw = tid >> 6, cl = tid & 63;
+    // (12 waves: the wave index as a scalar)
+    const int cw = k12 ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6, cl = tid & 63;
+    // 12 waves: the waves that wait for the chains fetch the root table meanwhile (two entries per thread); it goes
+    // to LDS behind the chains, where the chain waves' parked coefficients were.
+    float late_root0 = 0.0f, late_root1 = 0.0f;
+    if constexpr (k12) {
+      if (cw >= 2) {
+        late_root0 = T->sqrt_lut[(tid - 128) & (kSqrtLutSize - 1)];
+        late_root1 = T->sqrt_lut[(tid - 128 + 640) & (kSqrtLutSize - 1)];
+      }
+    }
 #ifndef JXLT_CFL_PINGPONG
     // The chains as a RELAY over the four 16-lane rows of the wave.  A row = the 16 chain lanes (X: 8, B: 8); row
     // k handles every fourth block, and the terms of the next four blocks are requested a whole round of four
@@ -620,6 +771,19 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     const int relay_pos = relay_row == 0 ? 0 : relay_row == 1 ? 1 : relay_row == 3 ? 2 : 3;  // place in the relay
     if (cw < 2) {
       __builtin_amdgcn_s_setprio(3);
+      // 12 waves: the chain waves hold 48 coefficients like every other wave, and the two term sets below are
+      // 32 registers more: fifteen of the B coefficients wait in the one piece of LDS that is free right now
+      // (the transposes' pad behind the term area)
+      float* const chain_park = &S.transpose_pad[0] + tid;  // [25][128], into sqrt_lut
+      if constexpr (k12) {
+        static_assert((sizeof(S.transpose_pad) + sizeof(S.sqrt_lut)) / 4 >= 25 * 128, "chain park");
+        static_assert(offsetof(TileShared, sqrt_lut) == offsetof(TileShared, transpose_pad) + sizeof(S.transpose_pad), "");
+#pragma unroll
+        for (int r = 0; r < 16; r++) chain_park[r * 128] = c16b[r];
+#pragma unroll
+        for (int r = 8; r < 16; r++) chain_park[(8 + r) * 128] = c16x[r];
+        chain_park[24 * 128] = c16y[15];
+      }
       const int ch = (cl >> 3) & 1;  // 0: X, 1: B
       const float* src = terms + l * 32;
       int slot[4];
@@ -632,12 +796,18 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       float4 ta[4], tb[4];
 #pragma unroll
       for (int q = 0; q < 4; q++) ta[q] = *(const float4*)&src[imin(relay_pos, last) * 256 + slot[q]];
-      auto round4 = [&](const float4* t, int first) {
+      // (kind: std::true_type = the sums of a * a, false_type = of a * b, nullptr = chosen per step by the wave
+      // index -- the 8-wave kernel's form, which the compiler turns into eight selects per term set)
+      auto round4 = [&](const float4* t, int first, auto kind) {
+        constexpr bool kByWave = std::is_same<decltype(kind), std::nullptr_t>::value;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           if (first + j >= nblk) break;  // (wave-uniform)
           // every lane runs the eight steps; only the row that holds the accumulators has meaningful ones
-          if (cw == 0) {
+          bool squares;
+          if constexpr (kByWave) squares = cw == 0;
+          else squares = decltype(kind)::value;
+          if (squares) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
               acc = fma32(t[q].x, t[q].x, acc);
@@ -658,14 +828,26 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
           if (j == 3) acc = __uint_as_float(__builtin_amdgcn_permlane32_swap(bits, bits, false, false)[1]);
         }
       };
+      auto chain_loop = [&](auto kind) {
 #pragma clang loop unroll(disable)
-      for (int blk = 0; blk < nblk; blk += 8) {
+        for (int blk = 0; blk < nblk; blk += 8) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) tb[q] = *(const float4*)&src[imin(blk + 4 + relay_pos, last) * 256 + slot[q]];
-        round4(ta, blk);
+          for (int q = 0; q < 4; q++) tb[q] = *(const float4*)&src[imin(blk + 4 + relay_pos, last) * 256 + slot[q]];
+          round4(ta, blk, kind);
 #pragma unroll
-        for (int q = 0; q < 4; q++) ta[q] = *(const float4*)&src[imin(blk + 8 + relay_pos, last) * 256 + slot[q]];
-        round4(tb, blk + 4);
+          for (int q = 0; q < 4; q++) ta[q] = *(const float4*)&src[imin(blk + 8 + relay_pos, last) * 256 + slot[q]];
+          round4(tb, blk + 4, kind);
+        }
+      };
+      // (two loops behind a scalar branch -- chain_loop(std::true_type{}) / (std::false_type{}) -- made the
+      // register allocator spill MORE in the 12-wave kernel)
+      chain_loop(nullptr);
+      if constexpr (k12) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) c16b[r] = chain_park[r * 128];
+#pragma unroll
+        for (int r = 8; r < 16; r++) c16x[r] = chain_park[(8 + r) * 128];
+        c16y[15] = chain_park[24 * 128];
       }
       __builtin_amdgcn_s_setprio(0);
     }
@@ -737,6 +919,12 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     // cfl_sum: ca_x, cb_x, ca_b, cb_b
     if (chain_lane && l == 0) S.cfl_sum[chain_ch * 2 + cw] = total;
     __syncthreads();
+    if constexpr (k12) {
+      if (cw >= 2) {  // (visible to P6b behind the barrier below)
+        if (tid - 128 < kSqrtLutSize) S.sqrt_lut[tid - 128] = late_root0;
+        if (tid - 128 + 640 < kSqrtLutSize) S.sqrt_lut[tid - 128 + 640] = late_root1;
+      }
+    }
     if (tid < 2) {  // FindBestMultiplier tail (:56-61)
       const float kDistanceMultiplierAC = 1e-3f;
       const float num = (float)(nblk * 64);
@@ -759,27 +947,45 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
   // ---- P6b: entropy estimates (enc_ac_strategy.cc:68-146,187-212) -----------
   float qmax = 0.0f;  // largest quantised magnitude whose root was taken from the table
   if (search) {
-    // DCT8 estimate for this octet's own block
-    if (blk_valid) {
-      const float e = estimate_entropy<8, kLutRoots>(c8x, c8y, c8b, S.inv_w + 0, S.inv_w + 64, S.inv_w + 128, l,
-                                                     fmaxf(0.0f, S.aq[oct]), fmaxf(0.0f, S.mask[oct]), cmap_x,
-                                                     cmap_b, A.distance, S.sqrt_lut, &qmax);
+    // DCT8 estimate of block (bx, by) of the tile from the lane's rows of its coefficients
+    auto estimate8 = [&](int bx, int by, const float* vx, const float* vy, const float* vb) {
+      const int bi = by * 8 + bx;
+      float qmax8 = 0.0f;
+      const float e = estimate_entropy<8, kLutRoots, k12, kThreads>(
+          vx, vy, vb, S.inv_w + 0, S.inv_w + 64, S.inv_w + 128, l, fmaxf(0.0f, S.aq[bi]), fmaxf(0.0f, S.mask[bi]),
+          cmap_x, cmap_b, A.distance, S.sqrt_lut, &qmax8);
+      qmax = fmaxf(qmax, qmax8);
       const float k8x8mul1 = (float)(-0.55 * 0.75f);
       const float k8x8mul2 = 1.0735757687292623f * 0.75f;
       const float k8x8base = (float)1.4;
       const float mul8x8 = k8x8mul2 + div_normal(k8x8mul1, A.strategy_distance + k8x8base);
       float e8 = 3.0f * mul8x8;
       e8 += mul8x8 * e;
-      if (l == 0) S.transpose_pad[((oby >> 1) * 4 + (obx >> 1)) * 8 + (oby & 1) * 2 + (obx & 1)] = e8;
-    }
-    // The DCT8 coefficients are needed again in P8; they wait in the (now dead) term area
-    // while the two-block estimate runs, which would otherwise spill.
+      if (l == 0) S.transpose_pad[((by >> 1) * 4 + (bx >> 1)) * 8 + (by & 1) * 2 + (bx & 1)] = e8;
+    };
+    // 12 waves: the B coefficients (rows 0..15: a candidate's, or rows 0..7 / 8..15: the two blocks of a pair
+    // octet) wait in the dead term area during the estimates, which read them from there; back in registers
+    // for P8a afterwards.
     float* park = &S.x[0] + tid;
+    if constexpr (k12) {
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-      park[(r)*kTileThreads] = c8x[r];
-      park[(8 + r) * kTileThreads] = c8y[r];
-      park[(16 + r) * kTileThreads] = c8b[r];
+      for (int r = 0; r < 16; r++) park[r * kThreads] = c16b[r];
+      JXLT_SCHED_FENCE();
+      if (pair_valid0) estimate8(pbx, pby0, c8x, c8y, park);
+      JXLT_SCHED_FENCE();
+      if (pair_valid1) estimate8(pbx, pby0 + 1, d8x, d8y, park + 8 * kThreads);
+    } else {
+      if (blk_valid) estimate8(obx, oby, c8x, c8y, c8b);
+    }
+    // 8 waves: the DCT8 coefficients are needed again in P8; they wait in the (now dead) term area
+    // while the two-block estimate runs, which would otherwise spill.
+    if constexpr (!k12) {
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        park[(r)*kTileThreads] = c8x[r];
+        park[(8 + r) * kTileThreads] = c8y[r];
+        park[(16 + r) * kTileThreads] = c8b[r];
+      }
     }
     JXLT_SCHED_FENCE();
     if (cell_valid) {
@@ -789,10 +995,9 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       const float masking = fmaxf(fmaxf(0.0f, S.mask[bi]), S.mask[bi + o2]);
       const int toff = is_tall ? 3 : 6;
       float qmax16 = 0.0f;
-      const float e = estimate_entropy<16, kLutRoots>(c16x, c16y, c16b, S.inv_w + quant_table_offset(toff),
-                                                      S.inv_w + quant_table_offset(toff + 1),
-                                                      S.inv_w + quant_table_offset(toff + 2), l, quant, masking,
-                                                      cmap_x, cmap_b, A.distance, S.sqrt_lut, &qmax16);
+      const float e = estimate_entropy<16, kLutRoots, k12, kThreads>(
+          c16x, c16y, k12 ? park : c16b, S.inv_w + quant_table_offset(toff), S.inv_w + quant_table_offset(toff + 1),
+          S.inv_w + quant_table_offset(toff + 2), l, quant, masking, cmap_x, cmap_b, A.distance, S.sqrt_lut, &qmax16);
       qmax = fmaxf(qmax, qmax16);
       const float k8X16mul1 = (float)-0.55, k8X16mul2 = (float)0.9019587899705066,
                   k8X16base = (float)1.6;
@@ -800,11 +1005,16 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       if (l == 0) S.transpose_pad[cell * 8 + (is_tall ? 4 : 6) + (cand & 1)] = mul16x8 * e;
     }
     JXLT_SCHED_FENCE();
+    if constexpr (!k12) {
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-      c8x[r] = park[(r)*kTileThreads];
-      c8y[r] = park[(8 + r) * kTileThreads];
-      c8b[r] = park[(16 + r) * kTileThreads];
+      for (int r = 0; r < 8; r++) {
+        c8x[r] = park[(r)*kTileThreads];
+        c8y[r] = park[(8 + r) * kTileThreads];
+        c8b[r] = park[(16 + r) * kTileThreads];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; r++) c16b[r] = park[r * kThreads];
     }
   }
   // A magnitude beyond the root table invalidates this tile's estimates: the frame is then
@@ -879,7 +1089,21 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       *reinterpret_cast<float4*>(d) = lo;
       *reinterpret_cast<float4*>(d + 4) = hi;
     };
-    if (blk_valid && S.strat[oct] == 1) {  // this octet's own block stayed DCT8
+    if constexpr (k12) {
+      const int b0 = pby0 * 8 + pbx;
+      if (pair_valid0 && S.strat[b0] == 1) {  // the pair octet's blocks that stayed DCT8
+        float* d = stagef + b0 * kStageStrideF + l * 8;
+        put8(d, c8x);
+        put8(d + 64, c8y);
+        put8(d + 128, c8b);
+      }
+      if (pair_valid1 && S.strat[b0 + 8] == 1) {
+        float* d = stagef + (b0 + 8) * kStageStrideF + l * 8;
+        put8(d, d8x);
+        put8(d + 64, d8y);
+        put8(d + 128, d8b);
+      }
+    } else if (blk_valid && S.strat[oct] == 1) {  // this octet's own block stayed DCT8
       float* d = stagef + oct * kStageStrideF + l * 8;
       put8(d, c8x);
       put8(d + 64, c8y);
@@ -938,7 +1162,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
     const unsigned long long firsts = __ballot(strat_of_lane & 1);
     const int rank_of_lane =
         (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(firsts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)firsts, 0u));
-    unsigned long long todo = __ballot((strat_of_lane & 1) != 0 && (rank_of_lane & 7) == wave);
+    unsigned long long todo = __ballot((strat_of_lane & 1) != 0 && (rank_of_lane % kWaves) == wave);
     // staged coefficients of the transform whose first block is b: [half a / b][channel x, y, b]
     auto fetch = [&](int b, int st, float (*v)[3]) {
       const int o2 = st == 1 ? 8 : 1;
@@ -1029,7 +1253,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
         half(k8, in[0], quant[0], cur0);
         quant[1][0] = quant[1][1] = quant[1][2] = 0.0f;
       }
-      const int t = wave + 8 * ntrans;  // the transform's number in the tile
+      const int t = wave + kWaves * ntrans;  // the transform's number in the tile
       file_int(0, t, b | (st << 8));
       int nz_packed = 0, nscan_packed = 0;
       // nzeros (enc_group.cc:51-148) and the scan position behind the last nonzero coefficient: the six ballots
@@ -1146,6 +1370,12 @@ __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A)
 __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel_debug(const TileArgs A) { tile_kernel_body<true, true>(A); }
 __global__ void __launch_bounds__(kTileThreads, 4) tile_kernel_exact_roots(const TileArgs A) {
   tile_kernel_body<false, true>(A);
+}
+// The 12-wave variants (see kTile12Threads).
+__global__ void __launch_bounds__(kTile12Threads, 6) tile12_kernel(const TileArgs A) { tile_kernel_body<true, false, 12>(A); }
+__global__ void __launch_bounds__(kTile12Threads, 6) tile12_kernel_debug(const TileArgs A) { tile_kernel_body<true, true, 12>(A); }
+__global__ void __launch_bounds__(kTile12Threads, 6) tile12_kernel_exact_roots(const TileArgs A) {
+  tile_kernel_body<false, true, 12>(A);
 }
 
 }  // namespace jxlt_dev

@@ -37,6 +37,8 @@ struct sim_result {
 __attribute__((visibility("default"))) void sim_free(sim_result* r);
 static float g_sim_strategy_distance = 0.0f;
 __attribute__((visibility("default"))) void sim_set_strategy_distance(float d) { g_sim_strategy_distance = d; }
+static int g_sim_tile_waves = 0;  // 0: the product's default variant of tile_kernel, else 8 or 12
+__attribute__((visibility("default"))) void sim_set_tile_waves(int w) { g_sim_tile_waves = w; }
 
 __attribute__((visibility("default"))) int sim_encode(const float* const planes[3], size_t pitch_floats, size_t xsize, size_t ysize,
                float distance, float scale, float inv_scale, float scale_dc, uint32_t x_qm_scale,
@@ -103,20 +105,26 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   uint32_t lut_overflow = 0;
   A.lut_overflow = &lut_overflow;
   // one launch per row of DC groups with the slab arguments of the product (jxlt_host_tables.h: SlabTileArgs)
+  const bool w12 = (g_sim_tile_waves ? g_sim_tile_waves : kDefaultTileWaves) == 12;
   auto launch_tiles = [&](auto kernel) {
     const size_t rows_per_slab = 2048, nsl = (ysize + rows_per_slab - 1) / rows_per_slab;
     for (size_t sl = 0; sl < nsl; sl++) {
       const size_t y0 = sl * rows_per_slab, rows = std::min(rows_per_slab, ysize - y0);
       const TileArgs S = nsl == 1 ? A : SlabTileArgs(A, y0, rows, A.pitch);
-      hipsim::launch(kernel, dim3((unsigned)((size_t)S.g.xsize_tiles * S.g.ysize_tiles)), dim3(kTileThreads), S);
+      hipsim::launch(kernel, dim3((unsigned)((size_t)S.g.xsize_tiles * S.g.ysize_tiles)),
+                     dim3(w12 ? kTile12Threads : kTileThreads), S);
     }
   };
   (void)ntiles;
   if (flags & 0x400u) {
-    launch_tiles(tile_kernel_exact_roots);
+    if (w12) launch_tiles(tile12_kernel_exact_roots);
+    else launch_tiles(tile_kernel_exact_roots);
   } else {
     // 0x800: the production variant (no debug outputs: r->xyb, qf, mask, ent8 stay as initialised)
-    if (flags & 0x800u) launch_tiles(tile_kernel);
+    if (w12) {
+      if (flags & 0x800u) launch_tiles(tile12_kernel);
+      else launch_tiles(tile12_kernel_debug);
+    } else if (flags & 0x800u) launch_tiles(tile_kernel);
     else launch_tiles(tile_kernel_debug);
     if (lut_overflow) {
       sim_free(r);

@@ -43,6 +43,18 @@ def test_production_variant_of_tile_kernel_matches_oracle(built, w, h, distance,
     assert T.compare_results(want, got, "oracle", "kernels", check_debug=False) == []
 
 
+@pytest.mark.parametrize("w,h,distance,hard,dct8", [CASES[0], CASES[3], CASES[7]])
+def test_eight_wave_variant_of_tile_kernel_matches_oracle(built, w, h, distance, hard, dct8):
+    """The product launches the 12-wave variant of tile_kernel (tile12_kernel*, 768 threads, role-split octets);
+    the 8-wave variant stays selectable (JXLT_TILE_WAVES=8) as the reference of the A/B in DESIGN.md."""
+    planes = T.to_planes(T.synthetic_image(w, h, hard=hard))
+    want = T.oracle_hot_path(planes, distance, dct8)
+    got = T.sim_hot_path(planes, distance, dct8, tile_waves=8)
+    assert T.compare_results(want, got, "oracle", "kernels") == []
+    got = T.sim_hot_path(planes, distance, dct8, tile_waves=8, production_variant=True)
+    assert T.compare_results(want, got, "oracle", "kernels", check_debug=False) == []
+
+
 def test_token_kernel_histogram_matches_tokens(built):
     planes = T.to_planes(T.synthetic_image(300, 264))
     got = T.sim_hot_path(planes, 1.0)

@@ -11,7 +11,7 @@ for v in "${VARIANTS[@]}"; do
   make -C libjxl-tiny_amd -s csrc/libjxltiny_hip.so HIPFLAGS_EXTRA="$v" 2>&1 | grep -i error
   echo "== [$v]"
   if [ -n "$PARITY" ]; then timeout 600 python -m pytest tests -m gpu -x -q -k "hot_path or golden or random or values_outside" 2>&1 | tail -1; fi
-  ./tools/tile_cycles.sh 16384 | grep -E "tile_kernel|token_kernel"
+  ./tools/tile_cycles.sh 16384 | grep -E "tile(12)?_kernel|token_kernel"
   if [ -n "$PACK" ]; then ./tools/pack_cycles.sh 16384 pack_tile_; fi
   timeout 200 python bench.py --no-extras --steps 8 2>&1 | tail -1 | python3 -c "
 import json,sys
