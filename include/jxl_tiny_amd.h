@@ -221,6 +221,17 @@ typedef struct {
 } jxlt_kernel_time;
 int jxlt_kernel_times(jxlt_context* ctx, jxlt_kernel_time* out, int cap);
 
+/* Statistics of the last encode of `ctx` (waits for its tile kernels).  The entropy estimate of the transform
+ * search takes a square root per coefficient (enc_ac_strategy.cc:118-126); the kernel reads the roots of quantised
+ * magnitudes below 1024 from a table, and a tile that meets a larger one (tiny distances, samples far above 1.0)
+ * is done again with computed roots by a second, small launch -- same results, the tile's work twice. */
+typedef struct {
+  uint32_t tiles;                      /* 64x64 tiles of the frame */
+  uint32_t tiles_redone_exact_roots;   /* ... of which were redone with computed roots */
+  uint32_t encodes_with_redone_tiles;  /* encodes of this context so far in which any tile was */
+} jxlt_encode_stats_t;
+int jxlt_encode_stats(jxlt_context* ctx, jxlt_encode_stats_t* out);
+
 /* Debug intermediates of the last encode run with JXLT_FLAG_DEBUG_DUMP.
  * what: 0,1,2 = XYB planes f32 (xsize_blocks*8 x ysize_blocks*8);
  *       3 = quant field f32 per block; 4 = masking f32 per block;
@@ -228,8 +239,8 @@ int jxlt_kernel_times(jxlt_context* ctx, jxlt_kernel_time* out, int cap);
  *           (xsize_blocks/2+1) x (ysize_blocks/2+1).
  *       6 = u64[16] shader cycles per tile_kernel phase, summed over tiles (needs
  *           JXLT_FLAG_PROFILE instead of JXLT_FLAG_DEBUG_DUMP).
- *       7 = u32: encodes of this context that were redone with tile_kernel_exact_roots because a
- *           quantised magnitude exceeded tile_kernel's square-root table (always allowed). */
+ *       7 = u32: encodes of this context in which tiles were redone with computed roots (jxlt_encode_stats;
+ *           always allowed). */
 int jxlt_debug_fetch(jxlt_context* ctx, int what, void* host_dst, size_t bytes);
 
 /* ---- libjxltiny_host.so ------------------------------------------------ */

@@ -34,7 +34,7 @@ HIP_SYMBOLS = ["jxlt_context_create", "jxlt_context_destroy", "jxlt_last_error",
                "jxlt_fetch_side_info", "jxlt_fetch_histograms", "jxlt_fetch_dc_histogram", "jxlt_pack_ac_sections", "jxlt_pack_sections",
                "jxlt_pack_sections_sizes", "jxlt_pack_sections_copy", "jxlt_pack_sections_place", "jxlt_pack_measure", "jxlt_pack_measure_begin", "jxlt_pack_measured", "jxlt_pack_write",
                "jxlt_output_buffer",
-               "jxlt_synchronize", "jxlt_fetch_result", "jxlt_kernel_times", "jxlt_debug_fetch"]
+               "jxlt_synchronize", "jxlt_fetch_result", "jxlt_kernel_times", "jxlt_encode_stats", "jxlt_debug_fetch"]
 HOST_SYMBOLS = ["jxlt_compute_distance_params", "jxlt_assemble_frame", "jxlt_assemble_frame_groups",
                 "jxlt_encode_file_planar", "jxlt_encode_pfm_file", "jxlt_emulate_reference_static_constants", "jxlt_emulate_reference_single_symbol_codes", "jxlt_encode_resident", "jxlt_encode_resident_view", "jxlt_write_file_header", "jxlt_build_code_tables", "jxlt_finish_frame",
                 "jxlt_debug_dc_records", "jxlt_free", "jxlt_batch_encoder_create", "jxlt_batch_encoder_create_multi",
@@ -77,6 +77,11 @@ class FrameResult(C.Structure):
 class PackedSections(C.Structure):
     _fields_ = [("bytes", C.POINTER(C.c_uint8)), ("section_offset", C.POINTER(C.c_uint64)),
                 ("section_bits", C.POINTER(C.c_uint32)), ("num_sections", C.c_size_t)]
+
+
+class EncodeStats(C.Structure):
+    _fields_ = [("tiles", C.c_uint32), ("tiles_redone_exact_roots", C.c_uint32),
+                ("encodes_with_redone_tiles", C.c_uint32)]
 
 
 class KernelTime(C.Structure):
@@ -124,6 +129,7 @@ def hip_lib():
                                             C.POINTER(C.POINTER(C.c_uint32))]
         L.jxlt_pack_sections.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(PackedSections)]
         L.jxlt_kernel_times.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_int]
+        L.jxlt_encode_stats.argtypes = [C.c_void_p, C.POINTER(EncodeStats)]
         L.jxlt_debug_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         _hip = L
     return _hip
@@ -328,6 +334,14 @@ class Encoder:
         total = int(off[n])
         data = np.ctypeslib.as_array(ps.bytes, shape=(max(total, 1),))[:total].copy()
         return data, off, bits
+
+    def stats(self):
+        """Statistics of the last encode (jxlt_encode_stats): tiles, tiles redone with computed square roots,
+        encodes of this context in which any tile was."""
+        st = EncodeStats()
+        self._check(self._L.jxlt_encode_stats(self._ctx, C.byref(st)), "jxlt_encode_stats")
+        return {"tiles": int(st.tiles), "tiles_redone_exact_roots": int(st.tiles_redone_exact_roots),
+                "encodes_with_redone_tiles": int(st.encodes_with_redone_tiles)}
 
     def kernel_times(self):
         arr = (KernelTime * 8)()

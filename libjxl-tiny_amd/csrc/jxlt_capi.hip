@@ -139,15 +139,18 @@ struct jxlt_context {
   hipEvent_t dc_hist_ready = nullptr;  // DC histogram of the last enqueue is in h_hist
   hipEvent_t dc_kernels_done = nullptr;  // (the small downloads wait for their kernels on the copy stream, not in front of the next kernel)
   hipEvent_t ac_hist_ready = nullptr;  // AC histogram + total token count of the last enqueue are in their mirrors
-  // Root-table overflow of tile_kernel (a quantised magnitude >= kSqrtLutSize): checked at the
-  // first host synchronisation point; the pipeline is then redone with tile_kernel_exact_roots.
-  DeviceBuf<uint32_t> lut_overflow;
+  // Root-table overflow of tile_kernel (a quantised magnitude >= kSqrtLutSize): the tiles concerned are redone by
+  // tile*_kernel_redo right behind it; their number reaches the host with the first synchronisation point.
+  DeviceBuf<uint32_t> lut_overflow;    // per tile_kernel launch of the frame: tiles redone with computed roots
+  DeviceBuf<uint32_t> overflow_tiles;  // their indices
   DeviceBuf<uint32_t> dc_chain_summary;
   PinnedBuf<uint32_t> h_lut_overflow;
   hipEvent_t overflow_ready = nullptr;
   jxlt_params last_params = {};
   bool overflow_checked = true;
-  uint32_t exact_reruns = 0;
+  size_t overflow_slabs = 0;   // launches of the last encode
+  uint32_t exact_reruns = 0;   // encodes of this context in which some tile was redone
+  uint32_t tiles_redone = 0;   // ... tiles of the last encode
   bool copies_pending = false;
   bool profiled = false;
 };
@@ -350,6 +353,7 @@ void jxlt_context_destroy(jxlt_context* ctx) {
   if (ctx->ac_hist_ready) (void)hipEventDestroy(ctx->ac_hist_ready);
   if (ctx->overflow_ready) (void)hipEventDestroy(ctx->overflow_ready);
   FreeDevice(&ctx->lut_overflow);
+  FreeDevice(&ctx->overflow_tiles);
   FreeDevice(&ctx->dc_chain_summary);
   FreePinned(&ctx->h_lut_overflow);
   for (hipEvent_t ev : ctx->slab_ready)
@@ -679,7 +683,7 @@ int jxlt_image_size(const jxlt_context* ctx, size_t* xsize, size_t* ysize) {
 namespace {
 int EnqueuePlan(jxlt_context* ctx, int kind, uint64_t rec_bound, hipStream_t stream);  // (below)
 
-int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roots) {
+int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   if (!ctx || !params) return JXLT_ERR_INVALID_ARGUMENT;
   if (!ctx->planes[0]) {
     ctx->error = "no image set";
@@ -719,8 +723,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
   ENSURE(dc_records, ndc * kDcStride * 3 + 16);  // (+ slack: tiles are staged with aligned dword loads)
   ENSURE(dc_nac, ndc);
   ENSURE(dc_chain_summary, ndc * kDcChainChunks);
-  ENSURE(lut_overflow, 1);
-  if ((rc = EnsurePinned(ctx, &ctx->h_lut_overflow, 1)) != JXLT_OK) return rc;
+  ENSURE(overflow_tiles, ntiles);
   ENSURE(dc_count, ndc);
   ENSURE(dc_rec_off, ndc + 1);
   if (ctx->dc_rec_off_n != ndc) {
@@ -785,7 +788,6 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
   A.coef_scan = ctx->coef_scan.p;
   A.group_ntok = ctx->group_ntok.p;
   A.dc_nac = ctx->dc_nac.p;
-  A.lut_overflow = ctx->lut_overflow.p;
   A.dbg_qf = debug ? ctx->dbg_qf.p : nullptr;
   A.dbg_mask = debug ? ctx->dbg_mask.p : nullptr;
   A.dbg_ent8 = debug ? ctx->dbg_ent8.p : nullptr;
@@ -809,7 +811,6 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
   HIP_TRY(ctx, hipMemsetAsync(ctx->group_ntok.p, 0, ngroups * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->hist.p, 0, 2 * 64 * 64 * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->dc_nac.p, 0, ndc * sizeof(uint32_t), ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->lut_overflow.p, 0, sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   // A frame that is still in page-locked host memory (jxlt_image_attach_host*) is processed in rows of DC groups
   // (2048 pixel rows) while it arrives.  A slab of whole DC-group rows is a frame of its own to tile_kernel
@@ -841,6 +842,15 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
       pieces.push_back({y, std::min<size_t>(256, ctx->ysize - y), y + 256 >= ctx->ysize});
   }
   const size_t nslabs = pieces.size();
+  {
+    int rc3;
+    if ((rc3 = EnsureDevice(ctx, &ctx->lut_overflow, nslabs)) != JXLT_OK) return rc3;
+    if ((rc3 = EnsurePinned(ctx, &ctx->h_lut_overflow, nslabs)) != JXLT_OK) return rc3;
+  }
+  A.lut_overflow = ctx->lut_overflow.p;
+  A.overflow_tiles = ctx->overflow_tiles.p;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->lut_overflow.p, 0, nslabs * sizeof(uint32_t), ctx->stream));
+  ctx->overflow_slabs = nslabs;
   while (ctx->slab_ready.size() < nslabs || ctx->tile_done.size() < nslabs) {
     hipEvent_t ev = nullptr;
     std::vector<hipEvent_t>& v = ctx->slab_ready.size() < nslabs ? ctx->slab_ready : ctx->tile_done;
@@ -886,7 +896,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
       HIP_TRY(ctx, hipEventRecord(ctx->slab_ready[sl], ctx->upload_stream));
       HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->slab_ready[sl], 0));
     }
-    const TileArgs S = nslabs == 1 ? A : SlabTileArgs(A, y0, rows, ctx->pitch_floats);
+    const TileArgs S = nslabs == 1 ? A : SlabTileArgs(A, y0, rows, ctx->pitch_floats, sl);
     (void)y1;
     const unsigned slab_tiles = (unsigned)((size_t)S.g.xsize_tiles * S.g.ysize_tiles);
     // (experiment knob, tools/: JXLT_TILE_EXTRA_LDS=<bytes> of unused dynamic LDS per workgroup lowers the number
@@ -900,24 +910,28 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
       const char* e = getenv("JXLT_TILE_WAVES");
       return e && atoi(e) == 12 ? 12 : e && atoi(e) == 8 ? 8 : kDefaultTileWaves;
     }();
+    // Behind every launch: the tiles it filed because a quantised magnitude did not fit the root table of its
+    // entropy estimates, again with computed roots (enc_ac_strategy.cc:118-126 takes a Sqrt per coefficient) -- a
+    // small fixed grid whose workgroups usually find an empty list and leave.
+    const unsigned redo_grid = std::min<unsigned>(slab_tiles, kRedoGrid);
     if (tile_waves == 12) {
-      if (exact_roots)
-        hipLaunchKernelGGL(tile12_kernel_exact_roots, dim3(slab_tiles), dim3(kTile12Threads), extra_lds, ctx->stream, S);
-      else if (debug || profile)
+      if (debug || profile)
         hipLaunchKernelGGL(tile12_kernel_debug, dim3(slab_tiles), dim3(kTile12Threads), extra_lds, ctx->stream, S);
       else
         hipLaunchKernelGGL(tile12_kernel, dim3(slab_tiles), dim3(kTile12Threads), extra_lds, ctx->stream, S);
-    } else if (exact_roots)
-      hipLaunchKernelGGL(tile_kernel_exact_roots, dim3(slab_tiles), dim3(kTileThreads), extra_lds, ctx->stream, S);
-    else if (debug || profile)
-      hipLaunchKernelGGL(tile_kernel_debug, dim3(slab_tiles), dim3(kTileThreads), extra_lds, ctx->stream, S);
-    else
-      hipLaunchKernelGGL(tile_kernel, dim3(slab_tiles), dim3(kTileThreads), extra_lds, ctx->stream, S);
+      hipLaunchKernelGGL(tile12_kernel_redo, dim3(redo_grid), dim3(kTile12Threads), 0, ctx->stream, S);
+    } else {
+      if (debug || profile)
+        hipLaunchKernelGGL(tile_kernel_debug, dim3(slab_tiles), dim3(kTileThreads), extra_lds, ctx->stream, S);
+      else
+        hipLaunchKernelGGL(tile_kernel, dim3(slab_tiles), dim3(kTileThreads), extra_lds, ctx->stream, S);
+      hipLaunchKernelGGL(tile_kernel_redo, dim3(redo_grid), dim3(kTileThreads), 0, ctx->stream, S);
+    }
     if (sl + 1 == nslabs) {
       HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-      // (the four bytes leave on the copy stream: a download in front of the DC-group kernels costs them 10 us)
+      // (the counts leave on the copy stream: a download in front of the DC-group kernels costs them 10 us)
       HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[1], 0));
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->h_lut_overflow.p, ctx->lut_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost,
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->h_lut_overflow.p, ctx->lut_overflow.p, nslabs * sizeof(uint32_t), hipMemcpyDeviceToHost,
                                   ctx->copy_stream));
       HIP_TRY(ctx, hipEventRecord(ctx->overflow_ready, ctx->copy_stream));
       ctx->copies_pending = true;
@@ -993,26 +1007,36 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params, bool exact_roo
   ctx->last_flags = params->flags;
   ctx->profiled = true;  // the five stage events are always recorded (a few microseconds per frame)
   ctx->last_params = *params;
-  ctx->overflow_checked = exact_roots;  // (nothing to check after the exact variant)
+  ctx->overflow_checked = false;
   return JXLT_OK;
 }
 
-// First host synchronisation point after an enqueue: did tile_kernel meet a quantised magnitude
-// beyond its root table?  Then its strategy decisions may be wrong: the whole pipeline is redone
-// with the kernel variant that computes every root (identical results otherwise).
+// First host synchronisation point after an enqueue: how many tiles did the device redo with computed roots
+// (statistics only: jxlt_encode_stats; the redo itself needs nothing from the host).
 int ResolveRootTableOverflow(jxlt_context* ctx) {
   if (!ctx->encoded || ctx->overflow_checked) return JXLT_OK;
   HIP_TRY(ctx, hipEventSynchronize(ctx->overflow_ready));
   ctx->overflow_checked = true;
-  if (ctx->h_lut_overflow.p[0] == 0) return JXLT_OK;
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // let the superseded pipeline drain
-  ctx->exact_reruns++;
-  const jxlt_params params = ctx->last_params;
-  return EnqueuePipeline(ctx, &params, true);
+  uint32_t n = 0;
+  for (size_t i = 0; i < ctx->overflow_slabs; i++) n += ctx->h_lut_overflow.p[i];
+  ctx->tiles_redone = n;
+  if (n != 0) ctx->exact_reruns++;
+  return JXLT_OK;
 }
 }  // namespace
 
-int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) { return EnqueuePipeline(ctx, params, false); }
+int jxlt_encode_enqueue(jxlt_context* ctx, const jxlt_params* params) { return EnqueuePipeline(ctx, params); }
+
+int jxlt_encode_stats(jxlt_context* ctx, jxlt_encode_stats_t* out) {
+  if (!ctx || !out) return JXLT_ERR_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int rc0 = ResolveRootTableOverflow(ctx);
+  if (rc0 != JXLT_OK) return rc0;
+  out->tiles_redone_exact_roots = ctx->tiles_redone;
+  out->encodes_with_redone_tiles = ctx->exact_reruns;
+  out->tiles = (uint32_t)((size_t)ctx->geom.xsize_tiles * ctx->geom.ysize_tiles);
+  return JXLT_OK;
+}
 
 int jxlt_set_strategy_distance(jxlt_context* ctx, float first_call_distance) {
   if (!ctx || !(first_call_distance >= 0.0f)) return JXLT_ERR_INVALID_ARGUMENT;

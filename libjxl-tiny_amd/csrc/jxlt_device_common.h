@@ -101,7 +101,8 @@ struct TileArgs {
   int16_t* coef_scan;   // [block*3 + c][64] quantised coefficients in scan order
   uint32_t* group_ntok; // per group token count (atomic)
   uint32_t* dc_nac;     // per DC group: number of first blocks (atomic)
-  uint32_t* lut_overflow;  // [1] set when a quantised magnitude did not fit the root table
+  uint32_t* lut_overflow;    // [1] number of tiles of this launch that met a quantised magnitude beyond the root table
+  uint32_t* overflow_tiles;  // their indices (capacity: the launch's tiles): redone by tile*_kernel_redo
   // debug (may be null)
   float* dbg_xyb[3];
   float* dbg_qf;

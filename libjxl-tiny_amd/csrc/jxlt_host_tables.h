@@ -80,8 +80,11 @@ inline float XQmMultiplier(uint32_t x_qm_scale) {  // pow(1.25f, x_qm_scale - 2.
 // rows inside ONE row of DC groups -- or y0 a multiple of 2048 and any number of rows: then every block / tile /
 // group / DC-group index of the slab is the frame's index minus a constant): the kernel never looks across a group boundary, so only the base pointers move.  `pitch` = A.pitch.
 namespace jxlt_dev {
-inline TileArgs SlabTileArgs(const TileArgs& A, size_t y0, size_t rows, ptrdiff_t pitch) {
+// slab: its number within the frame (every slab counts and lists its root-table overflows for itself)
+inline TileArgs SlabTileArgs(const TileArgs& A, size_t y0, size_t rows, ptrdiff_t pitch, size_t slab) {
   TileArgs S = A;
+  S.lut_overflow = A.lut_overflow + slab;
+  S.overflow_tiles = A.overflow_tiles + (y0 / 64) * (size_t)A.g.xsize_tiles;
   S.g = MakeGeom((size_t)A.g.xsize, rows);
   const size_t xb = (size_t)A.g.xsize_blocks;
   const size_t b0 = (y0 / 8) * xb;  // first block of the slab

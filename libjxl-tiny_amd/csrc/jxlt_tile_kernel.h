@@ -54,6 +54,7 @@ struct alignas(16) TileShared {
   uint8_t strat[64];
   uint32_t ntok;
   uint32_t nfirst;
+  uint32_t overflow;  // a quantised magnitude of this tile did not fit the root table
 };
 // After the last pixel read the XYB planes are dead and are reused: chroma-from-luma terms, the parked
 // DCT8 coefficients of the entropy estimate, then the staging area of the selected transforms' coefficients
@@ -159,7 +160,7 @@ JXLT_DI float adjust_quant_bias_y(float quant) {
 // kDebug: the variant that serves the A.dbg_* outputs (per-phase clocks, intermediate planes for
 // the parity tests); the production variant has none of their tests, branches and registers.
 template <bool kLutRoots, bool kDebug, int kWaves = 8>
-JXLT_DI void tile_kernel_body(const TileArgs& A) {
+JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
   static_assert(kWaves == 8 || kWaves == 12, "8: an octet per block and candidate; 12: role-split octets");
   constexpr bool k12 = kWaves == 12;
   constexpr int kThreads = kWaves * 64;
@@ -187,17 +188,6 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
   JXLT_STOP(i)
 
   // ---- geometry (enc_frame.cc:716-751) ------------------------------------
-  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed placement, used for
-  // speed only), and each XCD has its own L2.  Give every XCD one contiguous raster range
-  // of tiles so that horizontally adjacent tiles -- which share the +-5 px halo columns and
-  // the partially covered 128-byte lines -- are served by the same L2.
-  int tile_id;
-  {
-    const int n = A.g.xsize_tiles * A.g.ysize_tiles;
-    const int b = (int)blockIdx.x, xcd = b & 7, idx = b >> 3;
-    const int q = n >> 3, r = n & 7;
-    tile_id = xcd * q + (xcd < r ? xcd : r) + idx;
-  }
   const int tx_img = tile_id % A.g.xsize_tiles, ty_img = tile_id / A.g.xsize_tiles;
   const int gx = tx_img >> 2;
   const int sx0 = gx * 256, sy0 = ty_img * 64;            // stripe origin (pixels)
@@ -223,6 +213,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
   if (tid == 0) {
     S.ntok = 0;
     S.nfirst = 0;
+    S.overflow = 0;
   }
   if constexpr (!k12) {
     // 16 lanes along x, 32 rows per pass: a thread owns 5 columns x 2 rows of the
@@ -1017,9 +1008,12 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
       for (int r = 0; r < 16; r++) c16b[r] = park[r * kThreads];
     }
   }
-  // A magnitude beyond the root table invalidates this tile's estimates: the frame is then
-  // redone by the kernel variant that computes every root (jxlt_capi.hip; practically never).
-  if (kLutRoots && (qmax >= (float)kSqrtLutSize || (A.flags & 0x1000u) != 0)) A.lut_overflow[0] = 1u;  // (0x1000: test hook)
+  // A magnitude beyond the root table invalidates this tile's estimates: at its end the tile files its index
+  // instead of adding its counts, and the launch behind this one (tile*_kernel_redo) does the listed tiles again
+  // with computed roots, overwriting everything this pass writes.  (The tile runs to its end all the same: an
+  // early exit here changes the control flow of the whole kernel, and with it the register allocation -- the
+  // 12-wave kernel was 12 % slower with it -- for the sake of tiles that practically never occur.)
+  if (kLutRoots && (qmax >= (float)kSqrtLutSize || (A.flags & 0x1000u) != 0)) S.overflow = 1u;  // (0x1000: test hook)
   __syncthreads();
   JXLT_MARK(6);
   // ---- P7: decision (:213-237) + AdjustQuantField (:240-266) ------------------
@@ -1352,10 +1346,14 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
   }
   JXLT_MARK(9);
   if (tid == 0) {
-    const int group = (ty_img >> 2) * A.g.xsize_groups + gx;
-    atomicAdd(&A.group_ntok[group], S.ntok);
-    const int dcg = (ty_img >> 5) * ((A.g.xsize + 2047) / 2048) + (tx_img >> 5);
-    atomicAdd(&A.dc_nac[dcg], S.nfirst);
+    if (kLutRoots && S.overflow != 0) {
+      A.overflow_tiles[atomicAdd(&A.lut_overflow[0], 1u)] = (uint32_t)tile_id;
+    } else {
+      const int group = (ty_img >> 2) * A.g.xsize_groups + gx;
+      atomicAdd(&A.group_ntok[group], S.ntok);
+      const int dcg = (ty_img >> 5) * ((A.g.xsize + 2047) / 2048) + (tx_img >> 5);
+      atomicAdd(&A.dc_nac[dcg], S.nfirst);
+    }
   }
 #undef JXLT_MARK
 #undef JXLT_STOP
@@ -1363,20 +1361,44 @@ JXLT_DI void tile_kernel_body(const TileArgs& A) {
 #undef SY
 }
 
-// tile_kernel: roots of the entropy estimate from the LDS table (the product path);
-// tile_kernel_exact_roots: every root computed -- the same results, needed only for frames in
-// which tile_kernel met a quantised magnitude beyond the table.
-__global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A) { tile_kernel_body<true, false>(A); }
-__global__ void __launch_bounds__(kTileThreads, 4) tile_kernel_debug(const TileArgs A) { tile_kernel_body<true, true>(A); }
-__global__ void __launch_bounds__(kTileThreads, 4) tile_kernel_exact_roots(const TileArgs A) {
-  tile_kernel_body<false, true>(A);
+// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed placement, used for speed only), and each XCD
+// has its own L2.  Every XCD gets one contiguous raster range of tiles so that horizontally adjacent tiles --
+// which share the +-5 px halo columns and the partially covered 128-byte lines -- are served by the same L2.
+JXLT_DI int xcd_ordered_tile(const TileArgs& A) {
+  const int n = A.g.xsize_tiles * A.g.ysize_tiles;
+  const int b = (int)blockIdx.x, xcd = b & 7, idx = b >> 3;
+  const int q = n >> 3, r = n & 7;
+  return xcd * q + (xcd < r ? xcd : r) + idx;
 }
+// The tiles the launch in front filed in A.overflow_tiles, with every root computed (a fixed, small grid:
+// usually the list is empty and every workgroup leaves at once).
+template <int kWaves>
+JXLT_DI void tile_redo_body(const TileArgs& A) {
+  const uint32_t n = A.lut_overflow[0];
+  for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+    tile_kernel_body<false, true, kWaves>(A, (int)A.overflow_tiles[e]);
+    __syncthreads();  // (the next tile starts by writing the shared state this one has just read)
+  }
+}
+constexpr int kRedoGrid = 512;
+
+// tile_kernel: roots of the entropy estimate from the LDS table; tile_kernel_redo: every root computed -- the
+// same results, for the tiles in which tile_kernel met a quantised magnitude beyond the table.
+__global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A) {
+  tile_kernel_body<true, false>(A, xcd_ordered_tile(A));
+}
+__global__ void __launch_bounds__(kTileThreads, 4) tile_kernel_debug(const TileArgs A) {
+  tile_kernel_body<true, true>(A, xcd_ordered_tile(A));
+}
+__global__ void __launch_bounds__(kTileThreads, 4) tile_kernel_redo(const TileArgs A) { tile_redo_body<8>(A); }
 // The 12-wave variants (see kTile12Threads).
-__global__ void __launch_bounds__(kTile12Threads, 6) tile12_kernel(const TileArgs A) { tile_kernel_body<true, false, 12>(A); }
-__global__ void __launch_bounds__(kTile12Threads, 6) tile12_kernel_debug(const TileArgs A) { tile_kernel_body<true, true, 12>(A); }
-__global__ void __launch_bounds__(kTile12Threads, 6) tile12_kernel_exact_roots(const TileArgs A) {
-  tile_kernel_body<false, true, 12>(A);
+__global__ void __launch_bounds__(kTile12Threads, 6) tile12_kernel(const TileArgs A) {
+  tile_kernel_body<true, false, 12>(A, xcd_ordered_tile(A));
 }
+__global__ void __launch_bounds__(kTile12Threads, 6) tile12_kernel_debug(const TileArgs A) {
+  tile_kernel_body<true, true, 12>(A, xcd_ordered_tile(A));
+}
+__global__ void __launch_bounds__(kTile12Threads, 6) tile12_kernel_redo(const TileArgs A) { tile_redo_body<12>(A); }
 
 }  // namespace jxlt_dev
 

@@ -31,7 +31,7 @@ struct sim_result {
   uint64_t* dc_rec_offset;  // [ndc + 1]
   uint32_t* dc_count;   // [ndc]
   size_t num_dc_groups;
-  uint32_t exact_reruns;  // 1: the frame was redone with tile_kernel_exact_roots
+  uint32_t exact_reruns;  // tiles that were redone with computed roots (tile*_kernel_redo)
 };
 
 __attribute__((visibility("default"))) void sim_free(sim_result* r);
@@ -100,42 +100,30 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   A.dbg_ent8 = r->ent8 = (float*)malloc(ncells * 8 * 4);
   for (size_t i = 0; i < ncells * 8; i++) A.dbg_ent8[i] = __builtin_nanf("");
 
-  // as jxlt_capi.hip: the table-root kernel first; a frame with a quantised magnitude beyond the
-  // table is redone from scratch by the variant that computes every root
-  uint32_t lut_overflow = 0;
-  A.lut_overflow = &lut_overflow;
-  // one launch per row of DC groups with the slab arguments of the product (jxlt_host_tables.h: SlabTileArgs)
+  // as jxlt_capi.hip: the table-root kernel, then the redo kernel for the tiles it filed (a quantised magnitude
+  // beyond the table), per launch; one launch per row of DC groups with the slab arguments of the product
+  // (jxlt_host_tables.h: SlabTileArgs)
   const bool w12 = (g_sim_tile_waves ? g_sim_tile_waves : kDefaultTileWaves) == 12;
-  auto launch_tiles = [&](auto kernel) {
-    const size_t rows_per_slab = 2048, nsl = (ysize + rows_per_slab - 1) / rows_per_slab;
-    for (size_t sl = 0; sl < nsl; sl++) {
-      const size_t y0 = sl * rows_per_slab, rows = std::min(rows_per_slab, ysize - y0);
-      const TileArgs S = nsl == 1 ? A : SlabTileArgs(A, y0, rows, A.pitch);
-      hipsim::launch(kernel, dim3((unsigned)((size_t)S.g.xsize_tiles * S.g.ysize_tiles)),
-                     dim3(w12 ? kTile12Threads : kTileThreads), S);
-    }
-  };
-  (void)ntiles;
-  if (flags & 0x400u) {
-    if (w12) launch_tiles(tile12_kernel_exact_roots);
-    else launch_tiles(tile_kernel_exact_roots);
-  } else {
+  const size_t rows_per_slab = 2048, nsl = (ysize + rows_per_slab - 1) / rows_per_slab;
+  std::vector<uint32_t> lut_overflow(nsl, 0), overflow_tiles(ntiles, 0xFFFFFFFFu);
+  A.lut_overflow = lut_overflow.data();
+  A.overflow_tiles = overflow_tiles.data();
+  for (size_t sl = 0; sl < nsl; sl++) {
+    const size_t y0 = sl * rows_per_slab, rows = std::min(rows_per_slab, ysize - y0);
+    const TileArgs S = nsl == 1 ? A : SlabTileArgs(A, y0, rows, A.pitch, sl);
+    const dim3 grid((unsigned)((size_t)S.g.xsize_tiles * S.g.ysize_tiles));
+    const dim3 redo_grid(std::min<unsigned>(grid.x, 3u));  // (fewer workgroups than the product: the loop over the list runs)
     // 0x800: the production variant (no debug outputs: r->xyb, qf, mask, ent8 stay as initialised)
     if (w12) {
-      if (flags & 0x800u) launch_tiles(tile12_kernel);
-      else launch_tiles(tile12_kernel_debug);
-    } else if (flags & 0x800u) launch_tiles(tile_kernel);
-    else launch_tiles(tile_kernel_debug);
-    if (lut_overflow) {
-      sim_free(r);
-      for (int c = 0; c < 3; c++) free(A.nzgrid[c]);
-      free(A.blk_nz); free(A.blk_nscan); free(A.blk_nzmask); free(A.coef_scan); free(A.group_ntok); free(A.dc_nac);
-      delete tab;
-      const int rc = sim_encode(planes, pitch_floats, xsize, ysize, distance, scale, inv_scale, scale_dc, x_qm_scale,
-                                flags | 0x400u, r);
-      r->exact_reruns = 1;
-      return rc;
+      if (flags & 0x800u) hipsim::launch(tile12_kernel, grid, dim3(kTile12Threads), S);
+      else hipsim::launch(tile12_kernel_debug, grid, dim3(kTile12Threads), S);
+      hipsim::launch(tile12_kernel_redo, redo_grid, dim3(kTile12Threads), S);
+    } else {
+      if (flags & 0x800u) hipsim::launch(tile_kernel, grid, dim3(kTileThreads), S);
+      else hipsim::launch(tile_kernel_debug, grid, dim3(kTileThreads), S);
+      hipsim::launch(tile_kernel_redo, redo_grid, dim3(kTileThreads), S);
     }
+    r->exact_reruns += lut_overflow[sl];  // tiles redone
   }
 
   r->group_tok_offset = (uint64_t*)calloc(ngroups + 1, 8);

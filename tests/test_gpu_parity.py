@@ -242,19 +242,19 @@ def test_multi_encoder_grows_its_output_region_and_reports_errors(built):
         built.MultiEncoder([0, 99])  # no such device
 
 
-def test_attached_frame_survives_the_exact_roots_redo(built, enc):
-    """A frame attached from host memory whose encode has to be redone with computed square roots (flag 0x1000
-    makes tile_kernel report a table overflow): the redo must work on the resident copy, not fetch again."""
+def test_attached_frame_with_redone_tiles(built, enc):
+    """A frame that arrives from host memory in pieces (rows of DC groups, the last row in rows of groups), every
+    tile of which is redone with computed square roots (flag 0x1000 makes every tile of tile_kernel report a
+    table overflow): each piece's launch has its own list of tiles and its own redo launch."""
     w, h, d = 300, 2048 + 264, 2.0
     planes = T.to_planes(T.synthetic_image(w, h))
     pinned, owner = built.pinned_empty((3, h, w))
     pinned[...] = planes
     enc.attach_host(pinned)
-    import torch
     dp = enc.enqueue(d, 0x1000)
-    torch.cuda.synchronize()  # the first pipeline (upload included) is done; the redo has not been triggered yet
-    pinned[...] = 0.0  # the host copy is gone: a second fetch would encode zeros
     fr = enc.fetch_raw()
+    st = enc.stats()
+    assert st["tiles_redone_exact_roots"] == st["tiles"] == ((w + 63) // 64) * ((h + 63) // 64)
     frame = enc.assemble(fr, dp, 0)
     assert built.file_header(w, h) + frame == T.assemble_codestream(T.oracle_hot_path(planes, d), d)
 
@@ -493,28 +493,58 @@ def test_pfm_file_ingest_on_device(built, tmp_path):
     assert got == want
 
 
-def test_root_table_overflow_rerun_on_gpu(built, enc):
-    """The C ABI redoes an encode with tile_kernel_exact_roots when tile_kernel reports a
-    quantised magnitude beyond its square-root table (flag 0x1000 makes it report one)."""
+def test_root_table_overflow_redo_on_gpu(built, enc):
+    """Tiles in which tile_kernel meets a quantised magnitude beyond its square-root table are redone with
+    computed roots by a second launch (flag 0x1000 makes every tile report one); jxlt_encode_stats counts them."""
     planes = T.to_planes(T.synthetic_image(300, 264))
     want = T.oracle_hot_path(planes, 2.0)
-
-    def reruns():
-        n = np.zeros(1, np.uint32)
-        enc._check(enc._L.jxlt_debug_fetch(enc._ctx, 7, n.ctypes.data, 4), "jxlt_debug_fetch")
-        return int(n[0])
-
     enc.upload(planes)
-    before = reruns()
+    before = enc.stats()["encodes_with_redone_tiles"]
     dp = enc.enqueue(2.0, 0x1000)
     fr = enc.fetch_raw()
-    assert reruns() == before + 1
+    st = enc.stats()
+    assert st["tiles_redone_exact_roots"] == st["tiles"] == 5 * 5
+    assert st["encodes_with_redone_tiles"] == before + 1
     frame = enc.assemble(fr, dp, 0)
     assert built.file_header(300, 264) + frame == T.assemble_codestream(want, 2.0)
-    # an ordinary encode afterwards is not redone
+    # an ordinary encode afterwards redoes nothing
     enc.enqueue(2.0, 0)
     enc.synchronize()
-    assert reruns() == before + 1
+    st = enc.stats()
+    assert st["tiles_redone_exact_roots"] == 0 and st["encodes_with_redone_tiles"] == before + 1
+
+
+def test_one_hot_tile_is_redone_alone(built, enc):
+    """A real overflow of the root table: a 4096x4096 frame with one 8x8 block of samples far above 1.0 at a
+    tiny distance.  Only the tiles that see it are redone (enc_ac_strategy.cc:118-126 takes a Sqrt per
+    coefficient: the results must not depend on the table), the codestream equals the oracle's on crops around the
+    block and elsewhere, and tile_kernel's time stays that of a frame without the block plus the time ONE tile
+    takes on an otherwise idle chip (the redo launch: about 45 us) -- not twice the frame's, as when the whole
+    pipeline was redone."""
+    size, d = 4096, 0.1
+    img = T.synthetic_image(size, size, seed=77)
+    y0, x0 = 17 * 64 + 24, 23 * 64 + 16
+    cold = img.copy()
+    img[y0:y0 + 8, x0:x0 + 8:2] = 40.0  # checkerboard columns: coefficients of a few thousand quantisation steps
+    planes, cold_planes = T.to_planes(img), T.to_planes(cold)
+
+    def tile_ms(p):
+        enc.upload(p)
+        ts = []
+        for _ in range(6):
+            enc.enqueue(d, 0)
+            enc.synchronize()
+            ts.append(enc.kernel_times()["tile_kernel"])
+        return min(ts[2:]), enc.stats()
+
+    t_cold, st_cold = tile_ms(cold_planes)
+    t_hot, st_hot = tile_ms(planes)
+    assert st_cold["tiles_redone_exact_roots"] == 0
+    assert 1 <= st_hot["tiles_redone_exact_roots"] <= 4, st_hot
+    assert t_hot <= 1.05 * t_cold + 0.06, (t_hot, t_cold)
+    # bytes: the group that holds the block, a neighbour and far ones, against the oracle on the same crops
+    got = built.HotPathOutput(enc.fetch_raw())
+    _check_sampled_groups(planes, got, d, False, [(y0 // 256, x0 // 256), (y0 // 256, x0 // 256 + 1), (0, 0), (15, 15)])
 
 
 def _random_cases(n, seed):

@@ -136,18 +136,22 @@ def test_pfm_payload_ingest_on_cpu_model(built, flavour):
     T.compare_results(a, b, "planar", "pfm payload")
 
 
-def test_root_table_overflow_falls_back_to_computed_roots(built):
-    """tile_kernel takes the square roots of the entropy estimate from a table; a frame with a
-    quantised magnitude beyond it must be detected and redone with computed roots.  Magnitudes
-    >= 1024 hardly occur (the adaptive quantiser sees to that), so this runs a build of the
-    kernels whose table has 16 entries: ordinary images overflow it."""
-    planes = T.to_planes(T.synthetic_image(200, 137, hard=True))
-    got = T.sim_hot_path(planes, 0.5, tiny_root_table=True)
-    assert got.exact_reruns == 1, "the test image no longer overflows the 16-entry root table"
+@pytest.mark.parametrize("waves", [12, 8])
+def test_root_table_overflow_redoes_the_tiles_concerned_with_computed_roots(built, waves):
+    """tile_kernel takes the square roots of the entropy estimate from a table; a tile with a quantised
+    magnitude beyond it must file itself and be redone by tile*_kernel_redo with computed roots -- only that tile.
+    Magnitudes >= 1024 hardly occur (the adaptive quantiser sees to that), so this runs a build of the kernels
+    whose table has 16 entries: the busy tiles of an ordinary image overflow it, the flat ones do not."""
+    img = T.synthetic_image(200, 137, hard=True)
+    img[:64, :64] = 0.25  # a flat tile: every quantised coefficient is 0
+    planes = T.to_planes(img)
+    got = T.sim_hot_path(planes, 0.5, tiny_root_table=True, tile_waves=waves)
+    ntiles = 4 * 3
+    assert 0 < got.exact_reruns < ntiles, "tiles redone: %d" % got.exact_reruns
     want = T.oracle_hot_path(planes, 0.5)
     assert T.compare_results(want, got, "oracle", "cpu model, computed roots") == []
     # the product build stays on the table path for the same image, with the same result
-    same = T.sim_hot_path(planes, 0.5)
+    same = T.sim_hot_path(planes, 0.5, tile_waves=waves)
     assert same.exact_reruns == 0
     assert T.compare_results(want, same, "oracle", "cpu model, table roots") == []
 
@@ -169,10 +173,12 @@ def test_static_constant_emulation_on_cpu_model(built):
     assert (want.strategy != plain.strategy).any()
 
 
-@pytest.mark.parametrize("n", [1, 7, 1023, 1024, 1025, 4096, 5000, 16448, 32768])
+@pytest.mark.parametrize("n", [1, 7, 1023, 1024, 1025, 4096, 5000, 16448, 32768, 32769, 65536, 100003])
 def test_group_scan_kernel_matches_cumsum(built, n):
     """Section bookkeeping of the packing stage: exclusive scan of 32-bit counts into 64-bit offsets, for every
-    run length per thread the kernel can meet (1024 threads, up to 32 counts each), with totals beyond 2^32."""
+    run length per thread the kernel can meet (1024 threads, up to 32 counts each per pass; more than 32 768
+    counts -- narrow and tall frames: 64 x 16M pixels have 65 536 AC groups -- take several passes), with totals
+    beyond 2^32."""
     import ctypes as C
 
     import numpy as np
