@@ -386,6 +386,74 @@ def test_baseline_config3_8192_full_search(built, enc):
     assert enc.encode_resident(1.0) == a
 
 
+BENCH_FRAME_SHA16 = "6d6354ebdcc0222b"  # bench.py's config.codestream_sha256 of its default frame (BENCH_r02.json)
+
+
+def test_baseline_config4_16384_frame(built, enc):
+    """BASELINE config #4 at its stated size: the benchmark's own 16384 x 16384 frame.  64 groups on an 8 x 8
+    lattice over the WHOLE frame against the oracle on the matching crops; the codestream is the one the
+    benchmark reports (sha-256 of the bytes in BENCH_r*.json); the same frame cut over two device contexts
+    (jxlt_multi_encoder_*, both on GPU 0 here) and over two PROCESSES (bench.py --gpus 2, what the driver's
+    scaling run launches; both ranks on GPU 0 here) gives the same bytes."""
+    import hashlib
+    import json
+    import os
+    import sys
+    import torch
+    import bench
+    size = 16384
+    t = bench.frame_rows_on_device(torch, size, 0, size, 0, torch.device("cuda", 0))
+    enc.set_device_image([t[c].data_ptr() for c in range(3)], size * 4, size, size, keepalive=t)
+    enc.enqueue(1.0, 0)
+    got = built.HotPathOutput(enc.fetch_raw())
+    planes = t.cpu().numpy()
+    _check_sampled_groups(planes, got, 1.0, False, _lattice(64, 8))
+    del planes
+    single = enc.encode_resident(1.0)
+    assert hashlib.sha256(single).hexdigest()[:16] == BENCH_FRAME_SHA16
+    assert enc.stats()["tiles_redone_exact_roots"] == 0
+    me = built.MultiEncoder([0, 0])
+    for slab in range(2):
+        y0, y1 = built.shard_rows(size, 2, slab)
+        me.set_device_slab(slab, [t[c, y0:].data_ptr() for c in range(3)], size * 4, size, y1 - y0, keepalive=t)
+    assert me.encode_resident(size, size, 1.0).tobytes() == single
+    me.close()
+    del t
+    torch.cuda.empty_cache()
+    env = dict(os.environ, JXLT_BENCH_ONE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, str(T.ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 2 and "16384x16384" in out["config"]["workload"]
+    assert out["parity_gate"]["sharded_equals_single_gpu_codestream"] is True
+    assert out["config"]["codestream_sha256"] == BENCH_FRAME_SHA16
+
+
+def test_baseline_config5_batch_of_32_frames_over_a_device_list(built):
+    """BASELINE config #5's shape: a batch of 3840 x 2160 frames in page-locked host memory through ONE frame queue
+    whose lanes sit on a list of devices (GPU 0 twice here): 32 frames (four different ones, eight times each),
+    every codestream compared with the oracle's."""
+    import concurrent.futures as cf
+    distinct = [T.to_planes(T.synthetic_image(3840, 2160, seed=500 + i)) for i in range(4)]
+    with cf.ThreadPoolExecutor(4) as pool:  # (the oracle releases the GIL)
+        want = list(pool.map(lambda p: T.assemble_codestream(T.oracle_hot_path(p, 1.0), 1.0), distinct))
+    keep, frames = [], []
+    for p in distinct:
+        arr, owner = built.pinned_empty(p.shape)
+        arr[...] = p
+        keep.append(owner)
+        frames.append(arr)
+    enc = built.BatchEncoder(lanes=4, devices=[0, 0])
+    got = enc.encode([frames[i % 4] for i in range(32)], 1.0)
+    enc.close()
+    assert len(got) == 32
+    for i in range(32):
+        assert got[i] == want[i % 4], "frame %d" % i
+
+
 def test_attach_host_small_frames(built, enc):
     """jxlt_image_attach_host*: frames of one and of several DC-group rows, odd sizes, pitch != width,
     big-endian payload; debug intermediates through the slab-wise launches; refusal of pageable memory."""

@@ -36,6 +36,30 @@ KNOWN = {
 }
 
 
+# Round 2's judge compiled the unmodified /root/reference/encoder/*.cc against a throw-away Highway stand-in (8
+# lanes, halving-tree SumOfLanes, fused MulAdd) and ran it on 14 fresh frames: all 14 files were byte-identical
+# to this oracle's codestreams (which lists the sizes).  Sizes AND sha-256 of those bytes,
+# reference-bytes mode -- a stand-in build pins nothing formally, but this makes the agreement regression-proof.
+# (w, h, distance, seed, hard) -> (bytes, sha-256)
+JUDGE_R2 = {
+    (9, 7, 1.0, 1, False): (185, "68c8935b076a4d52855997b18926911297a178eb170f080084d80a7074e14a7e"),
+    (200, 137, 0.5, 2, False): (6856, "38026278555f454dcac5c91943e252d6de90c91cb1d314d744181dab84fa1a36"),
+    (256, 256, 1.0, 3, False): (6785, "e58ba980e39018d1941d9c74f17186699cfe2b398c7afc1476058abe5926ea51"),
+    # (single-symbol codes: 1376 bytes in the decodable default mode)
+    (264, 260, 8.0, 4, False): (1593, "8331f41265f84fe30a25e12c70cb167b0ce300de175baa1254ca5564640e0dd3"),
+    (512, 512, 1.0, 0, True): (151484, "63da9906b8bac3ca0380c0e7cd8a5198ff992432a3f469388818bfb4abc3288e"),
+    (1024, 1024, 1.0, 1234, False): (97861, "ecfd40b90853d7708d01ba2aa96023a58669ad3caa6581f7605cec686623db80"),
+    (2100, 300, 2.0, 7, False): (23796, "96b628096538f277ae9249b103b6661678fe2aabf9772acdbbe4acb7cc1bb243"),
+    (520, 2100, 4.0, 8, False): (25615, "da0819a71870fc32dcba9af7e8ac8bfda6b4c7d9ec2d33bc1e385d22a5227b20"),
+    (300, 2308, 2.0, 9, False): (26137, "71bd8f9eccd8d1aed1568561eab792a4e20537a97fcdcbffdbf53b75f0ca627d"),
+    (1030, 1030, 0.05, 10, False): (1314466, "2263d1a160743b375e3e72716541ca7e4458c10462b99655e02b78ee5e6ed82c"),
+    (2600, 2100, 1.0, 11, False): (509894, "5d78fbef9822f6dc9f2d13b89c2df628dd6a848470e0f9a3b91d8193486ead86"),
+    (3840, 2160, 1.0, 12, False): (771925, "2c66cc906299cc67b1117bb622ec981c5e9c2e8b68161df08fc10464d19dac8c"),
+    (700, 520, 16.0, 0, True): (9614, "4ebba40ae2a3fc67b5011906cd58afe22e9a54b3c3bce621a265116db8574ee8"),
+    (4200, 4200, 3.0, 14, False): (446457, "7737149a64a8fdab3d1eb3b2048b12afd07d3d9c142420ac4b97e0a246cb5b9c"),  # 9 DC groups
+}
+
+
 def _unfused_lib():
     base = T.oracle()
     lib = C.CDLL(str(T.ROOT / "oracle" / "liboracle_nofma.so"))
@@ -67,6 +91,15 @@ def test_canonical_fused_model_reproduces_reference_sizes(built, key):
 @pytest.mark.parametrize("key", sorted(KNOWN), ids=lambda k: "%dx%d_d%g%s" % (k[0], k[1], k[2], "_noise" if k[3] else ""))
 def test_unfused_variant_reproduces_reference_sizes(built, key):
     assert _size(key, lib=_unfused_lib()) == KNOWN[key][1]
+
+
+@pytest.mark.parametrize("key", sorted(JUDGE_R2), ids=lambda k: "%dx%d_d%g_s%d%s" % (k[0], k[1], k[2], k[3], "_noise" if k[4] else ""))
+def test_bytes_of_the_judges_stand_in_build(built, key):
+    import hashlib
+    w, h, d, seed, hard = key
+    planes = T.to_planes(T.synthetic_image(w, h, seed=seed, hard=hard))
+    cs = T.oracle_codestream(T.oracle_hot_path(planes, d), d, reference_single_symbol=True)
+    assert (len(cs), hashlib.sha256(cs).hexdigest()) == JUDGE_R2[key]
 
 
 def test_decodable_mode_differs_only_where_single_symbol_codes_occur(built):
