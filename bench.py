@@ -63,6 +63,11 @@ def parse_args():
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1: one independent frame per rank (weak scaling) instead of one frame over all ranks")
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / pfm_inclusive / parity legs")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="N > 1: frames in flight over the group (jxlt_shard_pipeline_*): the timed steps then measure "
+                         "THROUGHPUT with this many frames overlapping, not the time of one frame (the default, 1, "
+                         "is the headline: one config-#4 frame at a time; its JSON line reports the two-in-flight "
+                         "rate beside it as in_flight_2)")
     ap.add_argument("--frame-batch", type=int, default=0,
                     help="secondary workload (BASELINE config #5: --frame-batch 256 --gpus 8; PCIe-inclusive, never the "
                          "headline value): a step is a batch of this many --frame-size frames in page-locked HOST "
@@ -200,20 +205,61 @@ def main():
         # the codestream is assembled in the context's page-locked host buffer (no extra copy)
         return enc.encode_resident(d, num_threads=args.host_threads, copy=False)
 
-    for _ in range(args.warmup):
-        jxl = step()
-    barrier()
-    # Per-stage device times of the timed steps themselves: HIP events that the C ABI records on the encoder's
-    # own stream around every stage of every encode (read after each step).
+    def open_pipeline(depth, tag):
+        """jxlt_shard_pipeline_*: rank 0 creates the lanes' segments, the others attach behind the barrier."""
+        pname = "%s-%s" % (name, tag)
+        pipe = pkg.ShardPipeline(pname, 0, world, dev_index, depth, capacity, sections + 64) if rank == 0 else None
+        barrier()
+        if pipe is None:
+            pipe = pkg.ShardPipeline(pname, rank, world, dev_index, depth, capacity, sections + 64)
+        return pipe
+
+    def run_pipelined(pipe, frames, check=None):
+        """`frames` encodes of the frame with pipe.depth of them in flight; returns the seconds they took (max over
+        ranks, barriers on both sides).  check(bytes): called on rank 0 with every codestream."""
+        ptrs = [slab[c].data_ptr() for c in range(3)] if slab is not None else None
+        rows = (y1 - y0) if slab is not None else 0
+        barrier()
+        t = time.perf_counter()
+        tickets = []
+        for k in range(frames):
+            if k >= pipe.depth:
+                v = pipe.wait(tickets[k - pipe.depth])
+                if check is not None and v is not None:
+                    check(v)
+            tickets.append(pipe.submit_device(ptrs, size * 4, size, size, rows, d))
+        for tk in tickets[max(0, frames - pipe.depth):]:
+            v = pipe.wait(tk)
+            if check is not None and v is not None:
+                check(v)
+        barrier()
+        return max_over_ranks(time.perf_counter() - t), v
+
+    pipelined = sharded and args.in_flight > 1
     ktimes = {}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        jxl = step()
-        if slab is not None:
-            for k, v in enc.kernel_times().items():
-                ktimes[k] = ktimes.get(k, 0.0) + v / args.steps
-    barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    if pipelined:
+        pipe = open_pipeline(args.in_flight, "timed")
+        run_pipelined(pipe, max(args.warmup, args.in_flight))
+        elapsed, jxl = run_pipelined(pipe, args.steps)
+        if jxl is not None:
+            jxl = jxl.tobytes()
+        pipe.close()
+    else:
+        for _ in range(args.warmup):
+            jxl = step()
+        barrier()
+        # Per-stage device times of the timed steps themselves: HIP events that the C ABI records on the encoder's
+        # own stream around every stage of every encode (read after each step).
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            jxl = step()
+            if slab is not None:
+                for k, v in enc.kernel_times().items():
+                    ktimes[k] = ktimes.get(k, 0.0) + v / args.steps
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        if jxl is not None:
+            jxl = jxl.tobytes()
 
     frames = world if (world > 1 and args.replicas) else 1
     mpix = size * size / 1e6
@@ -222,17 +268,37 @@ def main():
     slab_pixels = (y1 - y0) * size
     achieved = ALGO_BYTES_PER_PIXEL * slab_pixels / (tile_ms * 1e-3) / 1e9 if slab_pixels else float("nan")
 
+    # ---- legs every rank takes part in (outside the timed region)
+    per_rank_kernel_ms = None
+    in_flight_2 = None
+    if dist is not None:
+        per_rank_kernel_ms = [None] * world
+        dist.all_gather_object(per_rank_kernel_ms, {k: round(v, 3) for k, v in ktimes.items()})
+    if sharded and not args.no_extras and not pipelined:
+        # two frames in flight over the same ranks (jxlt_shard_pipeline_*): what the serial stage of a sharded frame
+        # costs in throughput when the next frame's kernels run beside it
+        mismatches = []
+        pipe = open_pipeline(2, "if2")
+        nfr = max(6, args.steps)
+        run_pipelined(pipe, 4)
+        secs, _ = run_pipelined(pipe, nfr, check=(lambda v: mismatches.append(1) if v.tobytes() != jxl else None))
+        pipe.close()
+        in_flight_2 = {"frames": nfr, "ms_per_frame": round(1e3 * secs / nfr, 3),
+                       "value": round(size * size / 1e6 * nfr / secs, 2), "unit": "Mpixels/s",
+                       "speedup_over_one_at_a_time": round((elapsed / args.steps) / (secs / nfr), 3),
+                       "same_bytes": not mismatches,
+                       "note": "throughput with the kernels of frame k + 1 running beside the code construction and "
+                               "packing of frame k; one frame at a time stays the headline"}
+
     if rank != 0:
         if dist is not None:
-            if sharded and not args.no_extras:
-                dist.barrier()  # rank 0's single-GPU cross-check of the sharded codestream
-            dist.barrier()
+            dist.barrier()  # rank 0's legs (single-GPU cross-check, CPU baseline)
             dist.destroy_process_group()
         if group is not None:
             group.close()
         return
 
-    jxl_bytes = jxl.tobytes()
+    jxl_bytes = jxl
     result = {
         "metric": "Mpixels/s encode (PFM->.jxl), frame resident in HBM, codestream bytes in host memory",
         "value": round(value, 2),
@@ -243,6 +309,7 @@ def main():
         "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True,
         "scaling": "strong" if sharded else "weak",
+        "in_flight": args.in_flight if sharded else 1,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -263,6 +330,12 @@ def main():
                      "note": "rank 0's launch (its slab of the frame)" if sharded else "whole frame"},
         "kernel_ms": {k: round(v, 3) for k, v in ktimes.items()},
     }
+    if per_rank_kernel_ms is not None:
+        result["kernel_ms_per_rank"] = per_rank_kernel_ms
+    if in_flight_2 is not None:
+        result["in_flight_2"] = in_flight_2
+    if pipelined:
+        result["config"]["workload"] += "; THROUGHPUT with %d frames in flight (not one frame's time)" % args.in_flight
     valu = pmc_valu(size)
     if world == 1 and valu is not None and tile_ms == tile_ms:
         # Supplementary: the kernel is VALU-issue bound, not HBM bound.  Instructions per wave from the
@@ -284,21 +357,26 @@ def main():
             single = enc1.encode_resident(d, copy=False).tobytes()
             result["parity_gate"] = {"sharded_equals_single_gpu_codestream": single == jxl_bytes,
                                      "single_gpu_sha256": hashlib.sha256(single).hexdigest()[:16]}
+            if in_flight_2 is not None and not in_flight_2["same_bytes"]:
+                result["parity_gate"]["sharded_equals_single_gpu_codestream"] = False
             enc1.close()
+            # the CPU baseline of the N = 1 line (rank 0's host cores; the other ranks sleep in the barrier below)
+            import jxlt_testlib as T
+            cpu_baseline_leg(args, np, pkg, T, full, dev_index, result)
             del full
-            if dist is not None:
-                dist.barrier()
         else:
             extras_single_gpu(args, np, torch, pkg, enc, slab, dev_index, device, result)
     print(json.dumps(result), flush=True)
-    gate = result.get("parity_gate", {})
-    if gate.get("groups_mismatching", 0) or gate.get("sharded_equals_single_gpu_codestream") is False:
-        raise SystemExit("parity gate failed: %s" % json.dumps(gate))
+    # (the ranks are released and the shared-memory segment closed whatever the gate says: a rank 0 that left
+    # here would leave the others in their barrier until the launcher kills them)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if group is not None:
         group.close()
+    gate = result.get("parity_gate", {})
+    if gate.get("groups_mismatching", 0) or gate.get("sharded_equals_single_gpu_codestream") is False:
+        raise SystemExit("parity gate failed: %s" % json.dumps(gate))
 
 
 def extras_single_gpu(args, np, torch, pkg, enc, frame, dev_index, device, result):
@@ -357,7 +435,51 @@ def extras_single_gpu(args, np, torch, pkg, enc, frame, dev_index, device, resul
                                        "row/column; tokens + side-band grids vs the oracle on the same crops, %.1f s"
                                        % (len(picks), len(lattice), len(lattice), time.perf_counter() - t2)}
 
-    # ---- CPU baseline on a bounded, group-aligned crop of the same frame (centre of the frame)
+    cpu_baseline_leg(args, np, pkg, T, frame, dev_index, result)
+
+    # ---- the metric as written: PFM payload (interleaved, bottom-up f32) in page-locked HOST memory -> .jxl bytes;
+    # the upload is part of the encode, pipelined in DC-group rows under tile_kernel (jxlt_image_attach_host_pfm)
+    try:
+        payload, owner = pkg.pinned_empty((size * size * 3,), np.float32)
+    except pkg.JxlTinyError:
+        payload = None
+    if payload is not None:
+        rows = 2048
+        view = payload.reshape(size, size, 3)
+        for r0 in range(0, size, rows):  # bottom-up: image row y is payload row size - 1 - y
+            blk = frame[:, r0:r0 + rows].permute(1, 2, 0).flip(0).contiguous().cpu().numpy()
+            view[size - r0 - blk.shape[0]:size - r0] = blk
+        enc2 = pkg.Encoder(dev_index)
+        for _ in range(2):
+            enc2.attach_host_pfm(payload, size, size)
+            pfm_jxl = enc2.encode_resident(d, num_threads=args.host_threads, copy=False)
+        reps2 = 3
+        t5 = time.perf_counter()
+        for _ in range(reps2):
+            enc2.attach_host_pfm(payload, size, size)
+            pfm_jxl = enc2.encode_resident(d, num_threads=args.host_threads, copy=False)
+        pfm_s = (time.perf_counter() - t5) / reps2
+        same = hashlib.sha256(pfm_jxl.tobytes()).hexdigest()[:16] == result["config"]["codestream_sha256"]
+        enc2.close()
+        del view, payload, owner
+        bound = PCIE_PEAK_GBS / ALGO_BYTES_PER_PIXEL * 1e3
+        result["pfm_inclusive"] = {
+            "workload": "%dx%d PFM payload in page-locked host memory -> row-wise upload under the kernels -> .jxl "
+                        "bytes in host memory" % (size, size),
+            "ms_per_frame": round(pfm_s * 1e3, 2), "value": round(mpix / pfm_s, 1), "unit": "Mpixels/s",
+            "h2d_gb_s": round(ALGO_BYTES_PER_PIXEL * size * size / pfm_s / 1e9, 1),
+            "pcie_bound_mpix_s": round(bound, 1), "frac_of_pcie_bound": round(mpix / pfm_s / bound, 3),
+            "same_bytes_as_resident_encode": bool(same)}
+        if not same:
+            result["parity_gate"]["groups_mismatching"] += 1
+
+
+def cpu_baseline_leg(args, np, pkg, T, frame, dev_index, result):
+    """cpu_baseline: the oracle (pixel pipeline + bitstream stage) on a bounded crop of the frame on this host's
+    cores, one thread and all cores; the GPU's codestream of that crop must be the oracle's bytes."""
+    size, d = args.size, args.distance
+    result.setdefault("parity_gate", {}).setdefault("groups_mismatching", 0)
+    # a bounded, group-aligned crop of the same frame (centre of the frame)
     s = min(args.cpu_sample, size)
     s -= s % 256 if s >= 256 else 0
     o = ((size - s) // 2) // 256 * 256
@@ -409,41 +531,6 @@ def extras_single_gpu(args, np, torch, pkg, enc, frame, dev_index, device, resul
         if gpu_crop != cpu_jxl:
             result["parity_gate"]["groups_mismatching"] += 1
 
-    # ---- the metric as written: PFM payload (interleaved, bottom-up f32) in page-locked HOST memory -> .jxl bytes;
-    # the upload is part of the encode, pipelined in DC-group rows under tile_kernel (jxlt_image_attach_host_pfm)
-    try:
-        payload, owner = pkg.pinned_empty((size * size * 3,), np.float32)
-    except pkg.JxlTinyError:
-        payload = None
-    if payload is not None:
-        rows = 2048
-        view = payload.reshape(size, size, 3)
-        for r0 in range(0, size, rows):  # bottom-up: image row y is payload row size - 1 - y
-            blk = frame[:, r0:r0 + rows].permute(1, 2, 0).flip(0).contiguous().cpu().numpy()
-            view[size - r0 - blk.shape[0]:size - r0] = blk
-        enc2 = pkg.Encoder(dev_index)
-        for _ in range(2):
-            enc2.attach_host_pfm(payload, size, size)
-            pfm_jxl = enc2.encode_resident(d, num_threads=args.host_threads, copy=False)
-        reps2 = 3
-        t5 = time.perf_counter()
-        for _ in range(reps2):
-            enc2.attach_host_pfm(payload, size, size)
-            pfm_jxl = enc2.encode_resident(d, num_threads=args.host_threads, copy=False)
-        pfm_s = (time.perf_counter() - t5) / reps2
-        same = hashlib.sha256(pfm_jxl.tobytes()).hexdigest()[:16] == result["config"]["codestream_sha256"]
-        enc2.close()
-        del view, payload, owner
-        bound = PCIE_PEAK_GBS / ALGO_BYTES_PER_PIXEL * 1e3
-        result["pfm_inclusive"] = {
-            "workload": "%dx%d PFM payload in page-locked host memory -> row-wise upload under the kernels -> .jxl "
-                        "bytes in host memory" % (size, size),
-            "ms_per_frame": round(pfm_s * 1e3, 2), "value": round(mpix / pfm_s, 1), "unit": "Mpixels/s",
-            "h2d_gb_s": round(ALGO_BYTES_PER_PIXEL * size * size / pfm_s / 1e9, 1),
-            "pcie_bound_mpix_s": round(bound, 1), "frac_of_pcie_bound": round(mpix / pfm_s / bound, 3),
-            "same_bytes_as_resident_encode": bool(same)}
-        if not same:
-            result["parity_gate"]["groups_mismatching"] += 1
 
 
 def run_frame_batch(args, np, torch, pkg, dist, barrier, max_over_ranks, rank, world, dev_index, device):

@@ -88,6 +88,13 @@ int jxlt_context_create(int device_ordinal, jxlt_context** ctx);
 void jxlt_context_destroy(jxlt_context* ctx);
 /* ctx may be NULL: returns the message of the last failed create. */
 const char* jxlt_last_error(const jxlt_context* ctx);
+/* The device ordinal the context was created for. */
+int jxlt_context_device(const jxlt_context* ctx);
+/* Restricts the calling thread -- and the threads it creates afterwards, e.g. the helper threads of the code
+ * construction -- to the CPUs next to the device (its PCI function's local_cpulist, i.e. the GPU's NUMA node), so
+ * that the host side of an encode does not run on the other socket.  JXLT_ERR_UNSUPPORTED when the system does
+ * not say which CPUs those are.  jxlt_shard_encode does this for its caller once (JXLT_NO_AFFINITY=1 disables). */
+int jxlt_bind_thread_near_device(int device_ordinal);
 
 /* Copies three planar f32 linear-sRGB planes (row pitch in bytes, as
  * Image3F::bytes_per_row(), image.h:382) into context-owned HBM.  Replaces the
@@ -232,17 +239,6 @@ typedef struct {
 } jxlt_encode_stats_t;
 int jxlt_encode_stats(jxlt_context* ctx, jxlt_encode_stats_t* out);
 
-/* Debug intermediates of the last encode run with JXLT_FLAG_DEBUG_DUMP.
- * what: 0,1,2 = XYB planes f32 (xsize_blocks*8 x ysize_blocks*8);
- *       3 = quant field f32 per block; 4 = masking f32 per block;
- *       5 = entropy estimates f32, 8 per 2x2-block cell, grid
- *           (xsize_blocks/2+1) x (ysize_blocks/2+1).
- *       6 = u64[16] shader cycles per tile_kernel phase, summed over tiles (needs
- *           JXLT_FLAG_PROFILE instead of JXLT_FLAG_DEBUG_DUMP).
- *       7 = u32: encodes of this context in which tiles were redone with computed roots (jxlt_encode_stats;
- *           always allowed). */
-int jxlt_debug_fetch(jxlt_context* ctx, int what, void* host_dst, size_t bytes);
-
 /* ---- libjxltiny_host.so ------------------------------------------------ */
 
 void jxlt_compute_distance_params(float distance, jxlt_distance_params* out);
@@ -383,22 +379,26 @@ const char* jxlt_shard_group_last_error(const jxlt_shard_group* group);
  * the segment, valid until the next encode); NULL / 0 on the other ranks. */
 int jxlt_shard_encode(jxlt_shard_group* group, jxlt_context* ctx, size_t xsize, size_t ysize, float distance,
                       const uint8_t** bytes, size_t* size);
-/* The same protocol over caller-supplied slab operations instead of a device context (what jxlt_shard_encode
- * binds to the jxlt_* calls named on the right); lets the CPU test-suite run the protocol without a GPU.
- * Every callback returns JXLT_OK or an error; `write` may be asynchronous, `finish` completes it. */
-typedef struct {
-  void* self;
-  int (*enqueue)(void* self, const jxlt_params* params);                     /* jxlt_encode_enqueue */
-  int (*dc_histogram)(void* self, const uint32_t** histogram);               /* jxlt_fetch_dc_histogram */
-  int (*begin_dc_pack)(void* self, const uint32_t* dc_code_table);           /* jxlt_pack_measure_begin(0) */
-  int (*ac_histogram)(void* self, const uint32_t** histogram);               /* jxlt_fetch_histograms */
-  int (*measure)(void* self, const uint32_t* ac_code_table, jxlt_packed_sections* dc,
-                 jxlt_packed_sections* ac);                                  /* jxlt_pack_measure */
-  int (*write)(void* self, uint8_t* dc_dst, uint8_t* ac_dst);                /* jxlt_pack_write */
-  int (*finish)(void* self);                                                 /* jxlt_synchronize */
-} jxlt_slab_ops;
-int jxlt_shard_encode_ops(jxlt_shard_group* group, const jxlt_slab_ops* ops, size_t xsize, size_t ysize,
-                          float distance, const uint8_t** bytes, size_t* size);
+/* Frames in flight over the group.  What does not shrink with the number of GPUs is the stage between the
+ * kernels and the section packing (histogram hand-over, code construction: enc_frame.cc:846-850, layout), during
+ * which every GPU of a jxlt_shard_group waits.  A pipeline is `depth` such groups (segments <shm_name>.<lane>),
+ * each with a device context of its own and a host thread: frame k runs on lane k % depth, so the kernels of
+ * frame k + 1 run on every GPU while frame k is in that stage.  Same contract as jxlt_shard_group_open: rank 0
+ * opens first, then the others; every rank submits the same frames in the same order. */
+typedef struct jxlt_shard_pipeline jxlt_shard_pipeline;
+int jxlt_shard_pipeline_open(const char* shm_name, int rank, int world, int device_ordinal, int depth,
+                             size_t output_capacity, size_t max_sections, jxlt_shard_pipeline** out);
+void jxlt_shard_pipeline_close(jxlt_shard_pipeline* pipeline);
+const char* jxlt_shard_pipeline_last_error(const jxlt_shard_pipeline* pipeline);
+/* This rank's slab of the next frame (rows jxlt_shard_rows(ysize, world, rank); slab_rows 0: none), resident in
+ * device memory and read in place: it must stay valid until the frame's wait has returned.  Returns at once
+ * unless the lane's previous frame (depth frames back) is still being encoded. */
+int jxlt_shard_pipeline_submit_device(jxlt_shard_pipeline* pipeline, const void* const device_planes[3],
+                                      size_t pitch_bytes, size_t xsize, size_t ysize, size_t slab_rows, float distance,
+                                      uint64_t* ticket);
+/* Waits for frame `ticket`.  On rank 0 *bytes / *size receive the codestream (inside the lane's segment: valid
+ * until `depth` further frames have been submitted); NULL / 0 on the other ranks. */
+int jxlt_shard_pipeline_wait(jxlt_shard_pipeline* pipeline, uint64_t ticket, const uint8_t** bytes, size_t* size);
 
 /* Building blocks of the above (also usable on their own): code tables from summed histograms, and the
  * complete codestream from summed histograms + all packed sections in raster order. */
@@ -408,10 +408,6 @@ int jxlt_finish_frame(size_t xsize, size_t ysize, float distance, const uint32_t
                       const uint32_t* dc_histograms, const jxlt_packed_sections* dc_sections,
                       const jxlt_packed_sections* ac_sections, uint8_t** out_bytes, size_t* out_size);
 
-/* Test hook: the raw 3-byte records of DC group `dc_group_index` exactly as the host
- * tokeniser (WriteDCGroup in raw-record form, enc_frame.cc:536-570) produces them. */
-int jxlt_debug_dc_records(const jxlt_frame_result* frame, size_t dc_group_index, uint8_t** out_bytes,
-                          size_t* out_size);
 void jxlt_free(void* p);
 
 #ifdef __cplusplus

@@ -1,0 +1,59 @@
+/* jxl_tiny_amd_testing.h -- entry points of libjxltiny_hip.so / libjxltiny_host.so that exist for the
+ * test-suite and the profiling tools only.  Nothing a libjxl-tiny maintainer binds is declared here: the drop-in
+ * surface is include/jxl_tiny_amd.h. */
+#ifndef JXL_TINY_AMD_TESTING_H_
+#define JXL_TINY_AMD_TESTING_H_
+
+#include "jxl_tiny_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- libjxltiny_hip.so ------------------------------------------------- */
+
+/* Debug intermediates of the last encode run with JXLT_FLAG_DEBUG_DUMP.
+ * what: 0,1,2 = XYB planes f32 (xsize_blocks*8 x ysize_blocks*8);
+ *       3 = quant field f32 per block; 4 = masking f32 per block;
+ *       5 = entropy estimates f32, 8 per 2x2-block cell, grid
+ *           (xsize_blocks/2+1) x (ysize_blocks/2+1).
+ *       6 = u64[16] shader cycles per tile_kernel phase, summed over tiles (needs
+ *           JXLT_FLAG_PROFILE instead of JXLT_FLAG_DEBUG_DUMP).
+ *       7 = u32: encodes of this context in which tiles were redone with computed roots (jxlt_encode_stats;
+ *           always allowed). */
+int jxlt_debug_fetch(jxlt_context* ctx, int what, void* host_dst, size_t bytes);
+
+/* ---- libjxltiny_host.so ------------------------------------------------ */
+
+/* The protocol of jxlt_shard_encode over caller-supplied slab operations instead of a device context (what jxlt_shard_encode
+ * binds to the jxlt_* calls named on the right); lets the CPU test-suite run the protocol without a GPU.
+ * Every callback returns JXLT_OK or an error; `write` may be asynchronous, `finish` completes it. */
+typedef struct {
+  void* self;
+  int (*enqueue)(void* self, const jxlt_params* params);                     /* jxlt_encode_enqueue */
+  int (*dc_histogram)(void* self, const uint32_t** histogram);               /* jxlt_fetch_dc_histogram */
+  int (*begin_dc_pack)(void* self, const uint32_t* dc_code_table);           /* jxlt_pack_measure_begin(0) */
+  int (*ac_histogram)(void* self, const uint32_t** histogram);               /* jxlt_fetch_histograms */
+  int (*measure)(void* self, const uint32_t* ac_code_table, jxlt_packed_sections* dc,
+                 jxlt_packed_sections* ac);                                  /* jxlt_pack_measure */
+  int (*write)(void* self, uint8_t* dc_dst, uint8_t* ac_dst);                /* jxlt_pack_write */
+  int (*finish)(void* self);                                                 /* jxlt_synchronize */
+} jxlt_slab_ops;
+int jxlt_shard_encode_ops(jxlt_shard_group* group, const jxlt_slab_ops* ops, size_t xsize, size_t ysize,
+                          float distance, const uint8_t** bytes, size_t* size);
+
+/* jxlt_shard_pipeline_* over slab operations: lane l of the pipeline runs its frames through lane_ops[l]. */
+int jxlt_shard_pipeline_open_ops(const char* shm_name, int rank, int world, const jxlt_slab_ops* lane_ops, int depth,
+                                 size_t output_capacity, size_t max_sections, jxlt_shard_pipeline** out);
+int jxlt_shard_pipeline_submit_ops(jxlt_shard_pipeline* pipeline, size_t xsize, size_t ysize, float distance,
+                                   uint64_t* ticket);
+
+/* The raw 3-byte records of DC group `dc_group_index` exactly as the host
+ * tokeniser (WriteDCGroup in raw-record form, enc_frame.cc:536-570) produces them. */
+int jxlt_debug_dc_records(const jxlt_frame_result* frame, size_t dc_group_index, uint8_t** out_bytes,
+                          size_t* out_size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JXL_TINY_AMD_TESTING_H_ */

@@ -27,23 +27,29 @@ CJXL_TINY = PKG_DIR / "host" / "cjxl_tiny"
 fp = C.POINTER(C.c_float)
 FLAG_FORCE_DCT8, FLAG_DEBUG_DUMP, FLAG_PROFILE = 1, 2, 4
 
-# Symbols include/jxl_tiny_amd.h declares, per library (checked by the tests).
-HIP_SYMBOLS = ["jxlt_context_create", "jxlt_context_destroy", "jxlt_last_error",
+# Symbols include/jxl_tiny_amd.h declares, per library (checked by the tests); *_TESTING: the ones of
+# include/jxl_tiny_amd_testing.h (test-suite and profiling tools only).
+HIP_SYMBOLS = ["jxlt_context_create", "jxlt_context_destroy", "jxlt_last_error", "jxlt_context_device",
+               "jxlt_bind_thread_near_device",
                "jxlt_image_upload", "jxlt_image_set_device", "jxlt_image_upload_pfm", "jxlt_image_set_device_pfm", "jxlt_image_attach_host", "jxlt_image_attach_host_pfm", "jxlt_image_size", "jxlt_pinned_alloc",
                "jxlt_pinned_free", "jxlt_pinned_register", "jxlt_pinned_unregister", "jxlt_encode_enqueue", "jxlt_set_strategy_distance",
                "jxlt_fetch_side_info", "jxlt_fetch_histograms", "jxlt_fetch_dc_histogram", "jxlt_pack_ac_sections", "jxlt_pack_sections",
                "jxlt_pack_sections_sizes", "jxlt_pack_sections_copy", "jxlt_pack_sections_place", "jxlt_pack_measure", "jxlt_pack_measure_begin", "jxlt_pack_measured", "jxlt_pack_write",
                "jxlt_output_buffer",
-               "jxlt_synchronize", "jxlt_fetch_result", "jxlt_kernel_times", "jxlt_encode_stats", "jxlt_debug_fetch"]
+               "jxlt_synchronize", "jxlt_fetch_result", "jxlt_kernel_times", "jxlt_encode_stats"]
+HIP_SYMBOLS_TESTING = ["jxlt_debug_fetch"]
 HOST_SYMBOLS = ["jxlt_compute_distance_params", "jxlt_assemble_frame", "jxlt_assemble_frame_groups",
                 "jxlt_encode_file_planar", "jxlt_encode_pfm_file", "jxlt_emulate_reference_static_constants", "jxlt_emulate_reference_single_symbol_codes", "jxlt_encode_resident", "jxlt_encode_resident_view", "jxlt_write_file_header", "jxlt_build_code_tables", "jxlt_finish_frame",
-                "jxlt_debug_dc_records", "jxlt_free", "jxlt_batch_encoder_create", "jxlt_batch_encoder_create_multi",
+                "jxlt_free", "jxlt_batch_encoder_create", "jxlt_batch_encoder_create_multi",
                 "jxlt_batch_encoder_destroy", "jxlt_batch_encoder_run",
                 "jxlt_shard_rows", "jxlt_multi_encoder_create", "jxlt_multi_encoder_destroy",
                 "jxlt_multi_encoder_last_error", "jxlt_multi_encoder_encode", "jxlt_multi_encoder_encode_pfm",
                 "jxlt_multi_encoder_set_device_slab", "jxlt_multi_encoder_encode_resident",
                 "jxlt_shard_group_open", "jxlt_shard_group_close", "jxlt_shard_group_last_error",
-                "jxlt_shard_encode", "jxlt_shard_encode_ops"]
+                "jxlt_shard_encode", "jxlt_shard_pipeline_open", "jxlt_shard_pipeline_close",
+                "jxlt_shard_pipeline_last_error", "jxlt_shard_pipeline_submit_device", "jxlt_shard_pipeline_wait"]
+HOST_SYMBOLS_TESTING = ["jxlt_debug_dc_records", "jxlt_shard_encode_ops", "jxlt_shard_pipeline_open_ops",
+                        "jxlt_shard_pipeline_submit_ops"]
 
 
 class JxlTinyError(RuntimeError):
@@ -747,3 +753,77 @@ class ShardGroup:
         out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
         rc = self._L.jxlt_shard_encode_ops(self._g, C.byref(ops), w, h, C.c_float(distance), C.byref(out), C.byref(n))
         return self._result(rc, out, n, "jxlt_shard_encode_ops")
+
+
+class ShardPipeline:
+    """jxlt_shard_pipeline_*: frames in flight over a one-process-per-GPU group -- `depth` lanes (shard group +
+    device context + host thread each), frame k on lane k % depth.  Rank 0 must have returned from the constructor
+    before the other ranks construct theirs.  lane_ops (tests): one SlabOps per lane instead of device contexts."""
+
+    def __init__(self, name, rank, world, device, depth, output_capacity, max_sections, lane_ops=None):
+        self._L = host_lib()
+        L = self._L
+        L.jxlt_shard_pipeline_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
+                                               C.POINTER(C.c_void_p)]
+        L.jxlt_shard_pipeline_open_ops.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(SlabOps), C.c_int, C.c_size_t,
+                                                   C.c_size_t, C.POINTER(C.c_void_p)]
+        L.jxlt_shard_pipeline_close.argtypes = [C.c_void_p]
+        L.jxlt_shard_pipeline_close.restype = None
+        L.jxlt_shard_pipeline_last_error.argtypes = [C.c_void_p]
+        L.jxlt_shard_pipeline_last_error.restype = C.c_char_p
+        L.jxlt_shard_pipeline_submit_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_size_t,
+                                                        C.c_size_t, C.c_size_t, C.c_float, C.POINTER(C.c_uint64)]
+        L.jxlt_shard_pipeline_submit_ops.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_float, C.POINTER(C.c_uint64)]
+        L.jxlt_shard_pipeline_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.POINTER(C.c_uint8)),
+                                               C.POINTER(C.c_size_t)]
+        self.rank, self.world, self.depth = rank, world, depth
+        self._p = C.c_void_p()
+        self._keep = None
+        if lane_ops is not None:
+            arr = (SlabOps * depth)(*lane_ops)
+            self._keep = (arr, lane_ops)
+            rc = L.jxlt_shard_pipeline_open_ops(name.encode(), rank, world, arr, depth, output_capacity, max_sections,
+                                                C.byref(self._p))
+        else:
+            rc = L.jxlt_shard_pipeline_open(name.encode(), rank, world, device, depth, output_capacity, max_sections,
+                                            C.byref(self._p))
+        if rc != 0:
+            raise JxlTinyError("jxlt_shard_pipeline_open(%s, rank %d) failed (%d)" % (name, rank, rc))
+
+    def close(self):
+        if self._p:
+            self._L.jxlt_shard_pipeline_close(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def submit_device(self, plane_ptrs, pitch_bytes, w, h, slab_rows, distance):
+        """This rank's slab (three device pointers; slab_rows 0: none) of the next frame; returns its ticket."""
+        ptrs = (C.c_void_p * 3)(*[C.c_void_p(int(p)) for p in plane_ptrs]) if slab_rows else None
+        t = C.c_uint64()
+        rc = self._L.jxlt_shard_pipeline_submit_device(self._p, ptrs, pitch_bytes, w, h, slab_rows, C.c_float(distance),
+                                                       C.byref(t))
+        if rc != 0:
+            raise JxlTinyError("jxlt_shard_pipeline_submit_device failed (%d)" % rc)
+        return int(t.value)
+
+    def submit_ops(self, w, h, distance):
+        t = C.c_uint64()
+        rc = self._L.jxlt_shard_pipeline_submit_ops(self._p, w, h, C.c_float(distance), C.byref(t))
+        if rc != 0:
+            raise JxlTinyError("jxlt_shard_pipeline_submit_ops failed (%d)" % rc)
+        return int(t.value)
+
+    def wait(self, ticket):
+        """NativeView of frame `ticket`'s codestream on rank 0 (valid until `depth` more frames have been
+        submitted), None elsewhere."""
+        out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+        rc = self._L.jxlt_shard_pipeline_wait(self._p, ticket, C.byref(out), C.byref(n))
+        if rc != 0:
+            raise JxlTinyError("jxlt_shard_pipeline_wait failed (%d): %s" %
+                               (rc, self._L.jxlt_shard_pipeline_last_error(self._p).decode()))
+        return NativeView(out, n.value) if out else None

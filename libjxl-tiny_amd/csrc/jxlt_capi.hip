@@ -9,7 +9,10 @@
 // There is no CPU fallback: without a usable HIP device every entry point
 // returns JXLT_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <ctype.h>
+#include <sched.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -20,7 +23,7 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/jxl_tiny_amd.h"
+#include "../../include/jxl_tiny_amd_testing.h"
 #include "jxlt_device.h"
 #include "jxlt_host_tables.h"
 
@@ -376,6 +379,44 @@ void jxlt_context_destroy(jxlt_context* ctx) {
 
 const char* jxlt_last_error(const jxlt_context* ctx) {
   return ctx ? ctx->error.c_str() : g_create_error.c_str();
+}
+
+int jxlt_context_device(const jxlt_context* ctx) { return ctx ? ctx->device : -1; }
+
+// The CPUs next to a device: /sys/bus/pci/devices/<bus id>/local_cpulist ("0-63,128-191").
+int jxlt_bind_thread_near_device(int device_ordinal) {
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device_ordinal) != hipSuccess) return JXLT_ERR_NO_DEVICE;
+  for (char* p = bus; *p; ++p) *p = (char)tolower((unsigned char)*p);
+  char path[160];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bus);
+  FILE* f = fopen(path, "r");
+  if (!f) return JXLT_ERR_UNSUPPORTED;
+  char list[4096] = {0};
+  const bool got = fgets(list, sizeof(list), f) != nullptr;
+  fclose(f);
+  if (!got) return JXLT_ERR_UNSUPPORTED;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  int n = 0;
+  for (const char* p = list; *p && *p != '\n';) {
+    char* end = nullptr;
+    const long lo = strtol(p, &end, 10);
+    if (end == p) break;
+    long hi = lo;
+    p = end;
+    if (*p == '-') {
+      hi = strtol(p + 1, &end, 10);
+      p = end;
+    }
+    for (long c = lo; c <= hi && c < CPU_SETSIZE; ++c) {
+      CPU_SET((int)c, &set);
+      ++n;
+    }
+    if (*p == ',') ++p;
+  }
+  if (n == 0) return JXLT_ERR_UNSUPPORTED;
+  return sched_setaffinity(0, sizeof(set), &set) == 0 ? JXLT_OK : JXLT_ERR_UNSUPPORTED;
 }
 
 }  // extern "C"

@@ -10,12 +10,15 @@
 // POSIX shared-memory segment (one process per GPU).  All synchronisation is a handful of monotonic
 // atomic counters in that block; nothing here touches the GPUs except through the slab operations.
 #include <fcntl.h>
+#include <limits.h>
+#include <linux/futex.h>
 #include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -28,7 +31,7 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/jxl_tiny_amd.h"
+#include "../../include/jxl_tiny_amd_testing.h"
 #include "encoder/enc_bit_writer.h"
 #include "entropy_coder.h"
 #include "frame_assembler.h"
@@ -57,6 +60,8 @@ struct Control {
   std::atomic<uint64_t> arrived[kNumArrivals];       // += 1 per participant and frame
   std::atomic<uint64_t> published[kNumPublications];  // = frame number
   std::atomic<int32_t> failed;                        // sticky first error
+  std::atomic<uint32_t> sleepers;                     // participants asleep in a futex wait on one of the counters
+  std::atomic<uint32_t> attached;                     // processes that have mapped the segment (its name goes once all have)
   uint64_t dc_at[kMaxWorld], ac_at[kMaxWorld];        // kLayout: where each participant's sections go
   uint32_t dc_table[kHistWords], ac_table[kHistWords];
   uint32_t ac_global_size;                            // kAcTable: the serialised ACGlobal section (its builder is
@@ -79,6 +84,8 @@ struct jxlt_shard_group {
   int world = 1;
   bool shm = false;
   bool registered = false;   // output area page-locked for this process's devices
+  bool unlinked = false;     // (rank 0) the segment's name is gone already
+  bool bound = false;        // the calling thread has been moved next to its device
   std::string name;
   std::string error;         // first failure (several participants of one process may report)
   std::mutex error_mu;
@@ -120,6 +127,8 @@ void InitControl(Control* c, int world, size_t max_sections, size_t output_capac
   for (auto& a : c->arrived) new (&a) std::atomic<uint64_t>(0);
   for (auto& a : c->published) new (&a) std::atomic<uint64_t>(0);
   new (&c->failed) std::atomic<int32_t>(0);
+  new (&c->sleepers) std::atomic<uint32_t>(0);
+  new (&c->attached) std::atomic<uint32_t>(0);
   c->world = static_cast<uint32_t>(world);
   c->max_sections = max_sections;
   c->output_offset = ControlBytes() + TablesBytes(max_sections);
@@ -129,27 +138,66 @@ void InitControl(Control* c, int world, size_t max_sections, size_t output_capac
   c->magic = kMagic;
 }
 
-// Waits until pred() holds; gives up when a participant has failed or after two minutes (a peer died).
-template <typename Pred>
-int WaitFor(jxlt_shard_group* g, const Pred& pred) {
+// The counters are waited for with a bounded spin (the usual case: the other participants are a fraction of a
+// millisecond behind) and then a futex sleep on the counter's low word (the segment is shared between
+// processes: no FUTEX_PRIVATE).  Whoever changes a counter wakes the sleepers, if there are any.
+long Futex(void* addr, int op, uint32_t val, const struct timespec* timeout) {
+  return syscall(SYS_futex, addr, op, val, timeout, nullptr, 0);
+}
+uint32_t* LowWord(std::atomic<uint64_t>* a) { return reinterpret_cast<uint32_t*>(a); }  // (little endian)
+void Wake(Control* c, std::atomic<uint64_t>* a) {
+  if (c->sleepers.load(std::memory_order_seq_cst) != 0) Futex(LowWord(a), FUTEX_WAKE, INT_MAX, nullptr);
+}
+void Arrive(Control* c, int what) {
+  c->arrived[what].fetch_add(1, std::memory_order_seq_cst);
+  Wake(c, &c->arrived[what]);
+}
+void Publish(Control* c, int what, uint64_t frame) {
+  c->published[what].store(frame, std::memory_order_seq_cst);
+  Wake(c, &c->published[what]);
+}
+
+// Waits until *a >= target; gives up when a participant has failed or after two minutes (a peer died).
+int WaitAtLeast(jxlt_shard_group* g, std::atomic<uint64_t>* a, uint64_t target) {
   Control* c = g->ctl;
   const auto t0 = std::chrono::steady_clock::now();
-  for (uint64_t spins = 0;; ++spins) {
-    if (pred()) return JXLT_OK;
+  auto failed = [&]() -> int {
     const int32_t f = c->failed.load(std::memory_order_acquire);
     if (f != 0) {
-      {
-        std::lock_guard<std::mutex> lock(g->error_mu);
-        if (g->error.empty()) g->error = "another participant of the sharded frame failed";
-      }
-      return f;
+      std::lock_guard<std::mutex> lock(g->error_mu);
+      if (g->error.empty()) g->error = "another participant of the sharded frame failed";
     }
-    if ((spins & 63) == 63) sched_yield();
-    if ((spins & 0xFFFF) == 0xFFFF &&
-        std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+    return f;
+  };
+  // Spinning covers every wait INSIDE a frame (the participants are fractions of a millisecond apart, and a futex
+  // wake-up costs 50-100 us of latency, four times per frame); a participant whose peers are far behind -- other
+  // ranks still in a CPU-side leg, a dead peer -- goes to sleep after 2 ms instead of burning its core.
+  for (uint64_t spins = 0;; ++spins) {
+    if (a->load(std::memory_order_acquire) >= target) return JXLT_OK;
+    if ((spins & 63) == 63) {
+      if (const int f = failed()) return f;
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  for (;;) {
+    c->sleepers.fetch_add(1, std::memory_order_seq_cst);
+    const uint64_t v = a->load(std::memory_order_seq_cst);
+    if (v < target && c->failed.load(std::memory_order_acquire) == 0) {
+      const struct timespec ts = {0, 5 * 1000 * 1000};  // (a lost wake-up costs 5 ms, not the frame)
+      Futex(LowWord(a), FUTEX_WAIT, static_cast<uint32_t>(v), &ts);
+    }
+    c->sleepers.fetch_sub(1, std::memory_order_seq_cst);
+    if (a->load(std::memory_order_acquire) >= target) return JXLT_OK;
+    if (const int f = failed()) return f;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
       g->SetError("timed out waiting for the other participants of the sharded frame");
       int32_t expected = 0;
       c->failed.compare_exchange_strong(expected, JXLT_ERR_INTERNAL);
+      for (auto& w : c->arrived) Futex(LowWord(&w), FUTEX_WAKE, INT_MAX, nullptr);
+      for (auto& w : c->published) Futex(LowWord(&w), FUTEX_WAKE, INT_MAX, nullptr);
       return JXLT_ERR_INTERNAL;
     }
   }
@@ -157,8 +205,12 @@ int WaitFor(jxlt_shard_group* g, const Pred& pred) {
 
 int Fail(jxlt_shard_group* g, int rc, const char* what) {
   g->SetError(what);
+  Control* c = g->ctl;
   int32_t expected = 0;
-  g->ctl->failed.compare_exchange_strong(expected, rc);
+  c->failed.compare_exchange_strong(expected, rc);
+  // (whoever sleeps on a counter that will never move now)
+  for (auto& w : c->arrived) Futex(LowWord(&w), FUTEX_WAKE, INT_MAX, nullptr);
+  for (auto& w : c->published) Futex(LowWord(&w), FUTEX_WAKE, INT_MAX, nullptr);
   return rc;
 }
 
@@ -214,17 +266,17 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
   SLAB(ops->dc_histogram(ops->self, &h), "DC histogram fetch failed");
   if (empty) memset(c->hist[rank][1], 0, sizeof(c->hist[rank][1]));
   else memcpy(c->hist[rank][1], h, sizeof(c->hist[rank][1]));
-  c->arrived[kDcHist].fetch_add(1, std::memory_order_acq_rel);
+  Arrive(c, kDcHist);
   SLAB(ops->ac_histogram(ops->self, &h), "AC histogram fetch failed");
   if (empty) memset(c->hist[rank][0], 0, sizeof(c->hist[rank][0]));
   else memcpy(c->hist[rank][0], h, sizeof(c->hist[rank][0]));
-  c->arrived[kAcHist].fetch_add(1, std::memory_order_acq_rel);
+  Arrive(c, kAcHist);
   const int ac_builder = world > 1 ? 1 : 0;
   EntropyCode dc_code, ac_code;
   std::vector<uint32_t> sum(kHistWords);
   FrameGlobals globals;
   auto build_ac = [&]() -> int {
-    const int rcw = WaitFor(g, [&] { return c->arrived[kAcHist].load(std::memory_order_acquire) >= all; });
+    const int rcw = WaitAtLeast(g, &c->arrived[kAcHist], all);
     if (rcw != JXLT_OK) return rcw;
     std::fill(sum.begin(), sum.end(), 0u);
     for (int r = 0; r < world; ++r)
@@ -235,26 +287,23 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
     if (acg.size() > sizeof(c->ac_global)) return Fail(g, JXLT_ERR_INTERNAL, "ACGlobal section larger than expected");
     memcpy(c->ac_global, acg.data(), acg.size());
     c->ac_global_size = static_cast<uint32_t>(acg.size());
-    c->published[kAcTable].store(frame, std::memory_order_release);
+    Publish(c, kAcTable, frame);
     return JXLT_OK;
   };
   if (rank == 0) {
-    if ((rc = WaitFor(g, [&] { return c->arrived[kDcHist].load(std::memory_order_acquire) >= all; })) != JXLT_OK)
-      return rc;
+    if ((rc = WaitAtLeast(g, &c->arrived[kDcHist], all)) != JXLT_OK) return rc;
     std::fill(sum.begin(), sum.end(), 0u);
     for (int r = 0; r < world; ++r)
       for (size_t i = 0; i < kHistWords; ++i) sum[i] += c->hist[r][1][i];
     BuildDcCode(sum.data(), &dc_code);
     FillCodeTable(dc_code, c->dc_table);
-    c->published[kDcTable].store(frame, std::memory_order_release);
+    Publish(c, kDcTable, frame);
     globals.dc_global = BuildDcGlobal(xsize, ysize, distp, dc_code);
   }
   if (rank == ac_builder && (rc = build_ac()) != JXLT_OK) return rc;
-  if ((rc = WaitFor(g, [&] { return c->published[kDcTable].load(std::memory_order_acquire) >= frame; })) != JXLT_OK)
-    return rc;
+  if ((rc = WaitAtLeast(g, &c->published[kDcTable], frame)) != JXLT_OK) return rc;
   SLAB(ops->begin_dc_pack(ops->self, c->dc_table), "DC section measuring failed");
-  if ((rc = WaitFor(g, [&] { return c->published[kAcTable].load(std::memory_order_acquire) >= frame; })) != JXLT_OK)
-    return rc;
+  if ((rc = WaitAtLeast(g, &c->published[kAcTable], frame)) != JXLT_OK) return rc;
   if (rank == 0) globals.ac_global.assign(c->ac_global, c->ac_global + c->ac_global_size);
 
   // ---- exact section sizes of every slab -> layout of the one output buffer
@@ -274,13 +323,12 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
       sizes[ndc_frame + ac_first + i] = static_cast<uint32_t>(acm.section_offset[i + 1] - acm.section_offset[i]);
     }
   }
-  c->arrived[kSizes].fetch_add(1, std::memory_order_acq_rel);
+  Arrive(c, kSizes);
   std::vector<uint64_t> dc_off, ac_off;
   std::vector<uint8_t> file_header;
   size_t dc_begin = 0, ac_global_at = 0, total_end = 0;
   if (rank == 0) {
-    if ((rc = WaitFor(g, [&] { return c->arrived[kSizes].load(std::memory_order_acquire) >= all; })) != JXLT_OK)
-      return rc;
+    if ((rc = WaitAtLeast(g, &c->arrived[kSizes], all)) != JXLT_OK) return rc;
     jxl::BitWriter fh;
     if (!WriteFileHeader(xsize, ysize, &fh)) return Fail(g, JXLT_ERR_INVALID_ARGUMENT, "invalid frame size");
     file_header = fh.TakeBytes();
@@ -303,9 +351,8 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
       c->dc_at[r] = dc_begin + dc_off[xdc * (r0 / 2048)];
       c->ac_at[r] = ac_begin + ac_off[xgroups * (r0 / 256)];
     }
-    c->published[kLayout].store(frame, std::memory_order_release);
-  } else if ((rc = WaitFor(g, [&] { return c->published[kLayout].load(std::memory_order_acquire) >= frame; })) !=
-             JXLT_OK) {
+    Publish(c, kLayout, frame);
+  } else if ((rc = WaitAtLeast(g, &c->published[kLayout], frame)) != JXLT_OK) {
     return rc;
   }
 
@@ -317,8 +364,10 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
     const PackedSections dc = {nullptr, dc_off.data(), g->sec_bits(), ndc_frame};
     const PackedSections ac = {nullptr, ac_off.data(), g->sec_bits() + ndc_frame, ngroups_frame};
     std::vector<uint8_t> head;
-    if (!BuildFrameHead(xsize, ysize, distp, globals, dc, ac, &head))
+    if (!BuildFrameHead(xsize, ysize, distp, globals, dc, ac, &head)) {
+      if (!empty) ops->finish(ops->self);  // (the copies queued above still target the output area)
       return Fail(g, JXLT_ERR_INTERNAL, "frame head construction failed");
+    }
     frame_begin = dc_begin - head.size() - file_header.size();
     memcpy(out + frame_begin, file_header.data(), file_header.size());
     memcpy(out + frame_begin + file_header.size(), head.data(), head.size());
@@ -326,12 +375,17 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
   }
   SLAB(ops->finish(ops->self), "device synchronisation failed");
 #undef SLAB
-  c->arrived[kPlaced].fetch_add(1, std::memory_order_acq_rel);
+  Arrive(c, kPlaced);
   if (rank == 0) {
-    if ((rc = WaitFor(g, [&] { return c->arrived[kPlaced].load(std::memory_order_acquire) >= all; })) != JXLT_OK)
-      return rc;
+    if ((rc = WaitAtLeast(g, &c->arrived[kPlaced], all)) != JXLT_OK) return rc;
     if (bytes) *bytes = out + frame_begin;
     if (size) *size = total_end - frame_begin;
+    // every process has mapped the segment by now (it has taken part in this frame): the name can go, so that a
+    // rank that dies later leaves nothing behind in /dev/shm
+    if (g->shm && !g->unlinked && c->attached.load(std::memory_order_acquire) >= static_cast<uint32_t>(world)) {
+      shm_unlink(g->name.c_str());
+      g->unlinked = true;
+    }
   }
   return JXLT_OK;
 }
@@ -711,6 +765,7 @@ int jxlt_shard_group_open(const char* shm_name, int rank, int world, size_t outp
     delete g;
     return JXLT_ERR_INVALID_ARGUMENT;
   }
+  g->ctl->attached.fetch_add(1, std::memory_order_acq_rel);
   *out = g;
   return JXLT_OK;
 }
@@ -720,7 +775,7 @@ void jxlt_shard_group_close(jxlt_shard_group* g) {
   if (g->registered) jxlt_pinned_unregister(g->output());
   if (g->shm) {
     munmap(g->base, g->bytes);
-    if (g->rank == 0) shm_unlink(g->name.c_str());
+    if (g->rank == 0 && !g->unlinked) shm_unlink(g->name.c_str());
   }
   delete g;
 }
@@ -750,6 +805,12 @@ int jxlt_shard_encode(jxlt_shard_group* g, jxlt_context* ctx, size_t xsize, size
     if (rc != JXLT_OK) g->SetError(std::string("single-device encode failed: ") + jxlt_last_error(ctx));
     return rc;
   }
+  if (!g->bound) {
+    // the host side of the frame (hand-overs, code construction and its helper threads) next to the GPU
+    static const bool no_affinity = getenv("JXLT_NO_AFFINITY") != nullptr;
+    if (!no_affinity) jxlt_bind_thread_near_device(jxlt_context_device(ctx));
+    g->bound = true;
+  }
   if (!g->registered) {
     // the devices copy their sections straight into the segment: page-lock this process's mapping of it
     if (jxlt_pinned_register(g->output(), static_cast<size_t>(g->ctl->output_capacity)) != JXLT_OK)
@@ -758,6 +819,190 @@ int jxlt_shard_encode(jxlt_shard_group* g, jxlt_context* ctx, size_t xsize, size
   }
   const jxlt_slab_ops ops = jxlt::OpsOf(ctx);
   return jxlt::EncodeShard(g, g->rank, &ops, xsize, ysize, distance, bytes, size);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Frames in flight over the group: `depth` lanes, each a shard group of its own (segment <name>.<lane>), a device
+// context and a host thread.  Frame k runs on lane k % depth, so while frame k is in its code construction and
+// section packing -- the part of a sharded frame that does not shrink with the number of GPUs -- the kernels of
+// frame k + 1 already run on every GPU.
+struct jxlt_shard_pipeline {
+  struct Lane {
+    jxlt_shard_group* group = nullptr;
+    jxlt_context* ctx = nullptr;
+    jxlt_slab_ops ops = {};   // testing form (ops.enqueue != nullptr): instead of ctx
+    std::thread thread;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool has_job = false, busy = false, quit = false;
+    uint64_t ticket = 0;      // of the job / of the result
+    const void* planes[3] = {nullptr, nullptr, nullptr};
+    size_t pitch_bytes = 0, xsize = 0, ysize = 0, rows = 0;
+    float distance = 1.0f;
+    int rc = JXLT_OK;
+    const uint8_t* bytes = nullptr;
+    size_t size = 0;
+    std::string error;
+  };
+  std::vector<Lane*> lanes;
+  int rank = 0, world = 1;
+  uint64_t next_ticket = 0;
+  std::string error;
+};
+
+namespace jxlt {
+namespace {
+void LaneLoop(jxlt_shard_pipeline::Lane* lane) {
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lock(lane->mu);
+      lane->cv.wait(lock, [&] { return lane->quit || lane->has_job; });
+      if (lane->quit) return;
+      lane->has_job = false;
+    }
+    int rc = JXLT_OK;
+    const uint8_t* bytes = nullptr;
+    size_t size = 0;
+    if (lane->ops.enqueue != nullptr) {
+      rc = jxlt_shard_encode_ops(lane->group, &lane->ops, lane->xsize, lane->ysize, lane->distance, &bytes, &size);
+    } else {
+      if (lane->rows != 0)
+        rc = jxlt_image_set_device(lane->ctx, lane->planes, lane->pitch_bytes, lane->xsize, lane->rows);
+      if (rc != JXLT_OK) {
+        // (the other ranks must not wait for this one's part of the frame)
+        lane->error = std::string("slab set-up failed: ") + jxlt_last_error(lane->ctx);
+        Fail(lane->group, rc, lane->error.c_str());
+      } else {
+        rc = jxlt_shard_encode(lane->group, lane->ctx, lane->xsize, lane->ysize, lane->distance, &bytes, &size);
+      }
+    }
+    if (rc != JXLT_OK && lane->error.empty()) lane->error = jxlt_shard_group_last_error(lane->group);
+    {
+      std::lock_guard<std::mutex> lock(lane->mu);
+      lane->rc = rc;
+      lane->bytes = bytes;
+      lane->size = size;
+      lane->busy = false;
+    }
+    lane->cv.notify_all();
+  }
+}
+
+int OpenPipeline(const char* shm_name, int rank, int world, int device_ordinal, const jxlt_slab_ops* lane_ops, int depth,
+                 size_t output_capacity, size_t max_sections, jxlt_shard_pipeline** out) {
+  if (!out) return JXLT_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (!shm_name || depth < 1 || depth > 8) return JXLT_ERR_INVALID_ARGUMENT;
+  jxlt_shard_pipeline* p = new jxlt_shard_pipeline;
+  p->rank = rank;
+  p->world = world;
+  int rc = JXLT_OK;
+  for (int l = 0; l < depth && rc == JXLT_OK; ++l) {
+    jxlt_shard_pipeline::Lane* lane = new jxlt_shard_pipeline::Lane;
+    p->lanes.push_back(lane);
+    const std::string name = std::string(shm_name) + "." + std::to_string(l);
+    rc = jxlt_shard_group_open(name.c_str(), rank, world, output_capacity, max_sections, &lane->group);
+    if (rc == JXLT_OK) {
+      if (lane_ops) lane->ops = lane_ops[l];
+      else rc = jxlt_context_create(device_ordinal, &lane->ctx);
+    }
+  }
+  if (rc != JXLT_OK) {
+    for (jxlt_shard_pipeline::Lane* lane : p->lanes) {
+      if (lane->ctx) jxlt_context_destroy(lane->ctx);
+      jxlt_shard_group_close(lane->group);
+      delete lane;
+    }
+    delete p;
+    return rc;
+  }
+  for (jxlt_shard_pipeline::Lane* lane : p->lanes) lane->thread = std::thread(LaneLoop, lane);
+  *out = p;
+  return JXLT_OK;
+}
+
+int Submit(jxlt_shard_pipeline* p, const void* const planes[3], size_t pitch_bytes, size_t xsize, size_t ysize,
+           size_t rows, float distance, uint64_t* ticket) {
+  const uint64_t t = p->next_ticket++;
+  jxlt_shard_pipeline::Lane* lane = p->lanes[t % p->lanes.size()];
+  {
+    std::unique_lock<std::mutex> lock(lane->mu);
+    lane->cv.wait(lock, [&] { return !lane->busy; });  // (the lane's previous frame, depth frames back)
+    for (int c = 0; c < 3; ++c) lane->planes[c] = planes ? planes[c] : nullptr;
+    lane->pitch_bytes = pitch_bytes;
+    lane->xsize = xsize;
+    lane->ysize = ysize;
+    lane->rows = rows;
+    lane->distance = distance;
+    lane->ticket = t;
+    lane->error.clear();
+    lane->busy = true;
+    lane->has_job = true;
+  }
+  lane->cv.notify_all();
+  if (ticket) *ticket = t;
+  return JXLT_OK;
+}
+}  // namespace
+}  // namespace jxlt
+
+int jxlt_shard_pipeline_open(const char* shm_name, int rank, int world, int device_ordinal, int depth,
+                             size_t output_capacity, size_t max_sections, jxlt_shard_pipeline** out) {
+  return jxlt::OpenPipeline(shm_name, rank, world, device_ordinal, nullptr, depth, output_capacity, max_sections, out);
+}
+
+int jxlt_shard_pipeline_open_ops(const char* shm_name, int rank, int world, const jxlt_slab_ops* lane_ops, int depth,
+                                 size_t output_capacity, size_t max_sections, jxlt_shard_pipeline** out) {
+  if (!lane_ops) return JXLT_ERR_INVALID_ARGUMENT;
+  return jxlt::OpenPipeline(shm_name, rank, world, -1, lane_ops, depth, output_capacity, max_sections, out);
+}
+
+void jxlt_shard_pipeline_close(jxlt_shard_pipeline* p) {
+  if (!p) return;
+  for (jxlt_shard_pipeline::Lane* lane : p->lanes) {
+    {
+      std::lock_guard<std::mutex> lock(lane->mu);
+      lane->quit = true;
+    }
+    lane->cv.notify_all();
+    if (lane->thread.joinable()) lane->thread.join();
+    if (lane->ctx) jxlt_context_destroy(lane->ctx);
+    jxlt_shard_group_close(lane->group);
+    delete lane;
+  }
+  delete p;
+}
+
+const char* jxlt_shard_pipeline_last_error(const jxlt_shard_pipeline* p) { return p ? p->error.c_str() : ""; }
+
+int jxlt_shard_pipeline_submit_device(jxlt_shard_pipeline* p, const void* const device_planes[3], size_t pitch_bytes,
+                                      size_t xsize, size_t ysize, size_t slab_rows, float distance, uint64_t* ticket) {
+  if (!p || xsize == 0 || ysize == 0 || (slab_rows != 0 && (!device_planes || !device_planes[0])))
+    return JXLT_ERR_INVALID_ARGUMENT;
+  if (p->lanes[0]->ctx == nullptr) return JXLT_ERR_INVALID_ARGUMENT;  // (opened over slab operations)
+  return jxlt::Submit(p, device_planes, pitch_bytes, xsize, ysize, slab_rows, distance, ticket);
+}
+
+int jxlt_shard_pipeline_submit_ops(jxlt_shard_pipeline* p, size_t xsize, size_t ysize, float distance, uint64_t* ticket) {
+  if (!p || xsize == 0 || ysize == 0 || p->lanes[0]->ops.enqueue == nullptr) return JXLT_ERR_INVALID_ARGUMENT;
+  return jxlt::Submit(p, nullptr, 0, xsize, ysize, 0, distance, ticket);
+}
+
+int jxlt_shard_pipeline_wait(jxlt_shard_pipeline* p, uint64_t ticket, const uint8_t** bytes, size_t* size) {
+  if (!p || ticket >= p->next_ticket) return JXLT_ERR_INVALID_ARGUMENT;
+  if (bytes) *bytes = nullptr;
+  if (size) *size = 0;
+  jxlt_shard_pipeline::Lane* lane = p->lanes[ticket % p->lanes.size()];
+  std::unique_lock<std::mutex> lock(lane->mu);
+  if (lane->ticket != ticket) {
+    p->error = "the frame's result is gone: its lane has been given a later frame";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  lane->cv.wait(lock, [&] { return !lane->busy; });
+  if (lane->rc != JXLT_OK) p->error = lane->error;
+  if (bytes) *bytes = lane->bytes;
+  if (size) *size = lane->size;
+  return lane->rc;
 }
 
 }  // extern "C"

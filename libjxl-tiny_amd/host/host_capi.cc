@@ -5,7 +5,7 @@
 #include <functional>
 #include <vector>
 
-#include "../../include/jxl_tiny_amd.h"
+#include "../../include/jxl_tiny_amd_testing.h"
 #include "encoder/enc_file.h"
 #include "encoder/enc_frame.h"
 #include "frame_assembler.h"

@@ -9,19 +9,24 @@ import pytest
 import jxlt_testlib as T
 
 
-def _declared_functions():
-    text = (T.ROOT / "include" / "jxl_tiny_amd.h").read_text()
+def _declared_functions(header="jxl_tiny_amd.h"):
+    text = (T.ROOT / "include" / header).read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(jxlt_[a-z_0-9]+)\s*\(", text)))
 
 
 def test_every_declared_symbol_is_exported(built):
+    """Both headers: the drop-in surface (jxl_tiny_amd.h) and the test / profiling hooks kept apart from it
+    (jxl_tiny_amd_testing.h)."""
     declared = _declared_functions()
-    assert len(declared) >= 16
+    testing = _declared_functions("jxl_tiny_amd_testing.h")
+    assert len(declared) >= 16 and not set(declared) & set(testing)
     hip, host = built.hip_lib(), built.host_lib()
-    for name in declared:
+    for name in declared + testing:
         assert hasattr(hip, name) or hasattr(host, name), name
     assert sorted(built.HIP_SYMBOLS + built.HOST_SYMBOLS) == declared
+    assert sorted(built.HIP_SYMBOLS_TESTING + built.HOST_SYMBOLS_TESTING) == testing
+    assert not any("debug" in n or n.endswith("_ops") for n in declared)
 
 
 def test_distance_params_match_oracle(built):

@@ -162,6 +162,64 @@ def test_threads_attached_to_one_segment(built, world, h):
         assert results[r] == [None, None], results[r]
 
 
+def _pipeline_worker(rank, world, port, name, q):
+    """Frames in flight (jxlt_shard_pipeline_*): depth 2, five frames of two different images submitted back to
+    back -- frame k + 1 is in its lane's protocol while frame k is in its own."""
+    try:
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        pkg = T.product()
+        w, h, d, depth = 56, 2048 + 2048 + 24, 2.0, 2
+        y0, y1 = pkg.shard_rows(h, world, rank)
+        images = [T.to_planes(T.synthetic_image(w, h, seed=900 + i)) for i in range(2)]
+        # lane l always sees image l (frame k = image k % 2 = lane k % 2): one oracle-backed slab per lane
+        slabs = [OracleSlab(pkg, np.ascontiguousarray(images[l][:, y0:y1]), d) for l in range(depth)]
+        pipe = pkg.ShardPipeline(name, rank, world, -1, depth, 1 << 20, 4096, [s.ops for s in slabs]) if rank == 0 else None
+        dist.barrier()
+        if pipe is None:
+            pipe = pkg.ShardPipeline(name, rank, world, -1, depth, 1 << 20, 4096, [s.ops for s in slabs])
+        out = []
+        tickets = [pipe.submit_ops(w, h, d), pipe.submit_ops(w, h, d)]  # two frames in flight
+        for k in range(2, 5):
+            v = pipe.wait(tickets[k - 2])
+            out.append(v.tobytes() if v is not None else None)
+            tickets.append(pipe.submit_ops(w, h, d))
+        for t in tickets[3:]:
+            v = pipe.wait(t)
+            out.append(v.tobytes() if v is not None else None)
+        dist.barrier()
+        pipe.close()
+        q.put((rank, out))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        q.put((rank, "ERROR: %r" % (e,)))
+
+
+def test_two_process_pipeline_with_two_frames_in_flight(built):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = "/jxlt-test-pipe-%d" % os.getpid()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert not isinstance(results[0], str), results[0]
+    assert not isinstance(results[1], str), results[1]
+    assert results[1] == [None] * 5
+    want = [T.assemble_codestream(T.oracle_hot_path(T.to_planes(T.synthetic_image(56, 2048 + 2048 + 24, seed=900 + i)), 2.0), 2.0)
+            for i in range(2)]
+    assert results[0] == [want[k % 2] for k in range(5)]
+    # nothing is left in /dev/shm: rank 0 drops the segments' names as soon as every rank has mapped them
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith(name[1:])]
+
+
 def test_shard_rows_cover_whole_dc_groups(built):
     for h, world in [(16384, 8), (16384, 3), (5000, 2), (100, 4), (2049, 2), (16384, 64)]:
         rows = [built.shard_rows(h, world, r) for r in range(world)]
