@@ -147,6 +147,14 @@ struct TokenArgs {
 #define JXLT_LAUNDER_VGPR(x) asm volatile("" : "+v"(x))
 #endif
 
+// Nothing is kept in registers across this point that the compiler could re-read from memory instead, and no
+// load behind it is answered from a store in front of it (no instruction).  Used where values are parked in LDS
+// to free their registers: without it the compiler forwards the parked values to the loads that fetch them back
+// and keeps them in registers all the same.
+#ifndef JXLT_COMPILER_FENCE
+#define JXLT_COMPILER_FENCE() asm volatile("" ::: "memory")
+#endif
+
 JXLT_DI float fma32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 JXLT_DI float nfma32(float a, float b, float c) { return __builtin_fmaf(-a, b, c); }
 // min(max(x, 0), 1): folds into the clamp modifier of the instruction that produces x.

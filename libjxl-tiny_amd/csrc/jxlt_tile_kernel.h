@@ -789,14 +789,26 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       for (int q = 0; q < 4; q++) ta[q] = *(const float4*)&src[imin(relay_pos, last) * 256 + slot[q]];
       // (kind: std::true_type = the sums of a * a, false_type = of a * b, nullptr = chosen per step by the wave
       // index -- the 8-wave kernel's form, which the compiler turns into eight selects per term set)
-      auto round4 = [&](const float4* t, int first, auto kind) {
+      auto round4 = [&](float4* t, int first, auto kind) {
         constexpr bool kByWave = std::is_same<decltype(kind), std::nullptr_t>::value;
+        if constexpr (k12) {
+          // (12 waves: the second factor of every product -- a for the sums of a * a, b for the sums of a * b --
+          // is selected IN PLACE once per term set, instead of into eight more registers)
+          if (first < nblk) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              t[q].y = cw == 0 ? t[q].x : t[q].y;
+              t[q].w = cw == 0 ? t[q].z : t[q].w;
+            }
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           if (first + j >= nblk) break;  // (wave-uniform)
           // every lane runs the eight steps; only the row that holds the accumulators has meaningful ones
           bool squares;
-          if constexpr (kByWave) squares = cw == 0;
+          if constexpr (k12) squares = false;
+          else if constexpr (kByWave) squares = cw == 0;
           else squares = decltype(kind)::value;
           if (squares) {
 #pragma unroll
@@ -834,6 +846,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       // register allocator spill MORE in the 12-wave kernel)
       chain_loop(nullptr);
       if constexpr (k12) {
+        JXLT_COMPILER_FENCE();
 #pragma unroll
         for (int r = 0; r < 16; r++) c16b[r] = chain_park[r * 128];
 #pragma unroll
@@ -925,6 +938,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     }
   }
   __syncthreads();
+  new_phase();  // (what the phases below derive from the thread index does not stay in registers across the chains)
   JXLT_MARK(10);
   const int ytox = S.cmap[0], ytob = S.cmap[1];
   const float kInvColorFactorF = 1.0f / 84;
@@ -1004,6 +1018,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
         c8b[r] = park[(16 + r) * kTileThreads];
       }
     } else {
+      JXLT_COMPILER_FENCE();
 #pragma unroll
       for (int r = 0; r < 16; r++) c16b[r] = park[r * kThreads];
     }

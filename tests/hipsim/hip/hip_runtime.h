@@ -381,6 +381,7 @@ inline void __builtin_amdgcn_s_setprio(int) {}  // issue priority: no effect on 
 inline void __builtin_amdgcn_sched_barrier(int) {}  // compiler scheduling fence
 #define JXLT_TOUCH_VGPR(x) ((void)(x))
 #define JXLT_LAUNDER_VGPR(x) ((void)(x))
+#define JXLT_COMPILER_FENCE() ((void)0)
 
 // v_rcp_f32 (1 ulp on hardware; the model returns the correctly rounded reciprocal)
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }

@@ -17,10 +17,13 @@ timeout 300 python3 bench.py 2>/dev/null | tail -1 > $OUT/bench_line.json
 if [ ! -x tools/fetch_calib ]; then hipcc --offload-arch=gfx950 -O2 -o tools/fetch_calib tools/fetch_calib.hip; fi
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/calib_$c -- ./tools/fetch_calib > $OUT/calib_$c.log 2>&1
-  timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/enc_$c -- python3 tools/run_encode.py $SIZE 3 > $OUT/enc_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/enc_$c -- python3 tools/run_resident.py $SIZE 3 > $OUT/enc_$c.log 2>&1
 done
 f() { find $OUT/$1 -name '*counter_collection.csv' | head -1; }
-python3 tools/collect_traffic.py "$(f calib_FETCH_SIZE)" "$(f calib_WRITE_SIZE)" "$(f enc_FETCH_SIZE)" "$(f enc_WRITE_SIZE)" $SIZE $OUT/traffic_$SIZE.json
+python3 tools/collect_traffic.py "$(f calib_FETCH_SIZE)" "$(f calib_WRITE_SIZE)" "$(f enc_FETCH_SIZE)" "$(f enc_WRITE_SIZE)" $SIZE $OUT/traffic_$SIZE.json 3
+./tools/pack_cycles.sh $SIZE jxlt_dev > $OUT/kernel_cycles_$SIZE.txt 2>&1
+./tools/pmc_util.sh 8192 > $OUT/tile8192_valu_util.txt 2>&1
+python3 tools/config_table.py 2>/dev/null > $OUT/config_table.jsonl
 find $OUT/bench_stats -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 head -8 $OUT/kernel_stats.csv | cut -c1-160
 cat $OUT/bench_line.json | cut -c1-600

@@ -39,10 +39,12 @@ def main():
             out = enc.encode_resident(distance, copy=False)
         dt = (time.perf_counter() - t0) / reps
         kt = enc.kernel_times()
+        st = enc.stats()
         fr = enc.fetch_raw()
         tok = int(fr.group_token_offset[fr.num_groups])
         rows.append({"workload": name, "ms_per_frame": round(dt * 1e3, 3), "mpix_s": round(size * size / dt / 1e6, 1),
                      "codestream_bytes": len(out), "token_bytes_per_pixel": round(tok / (size * size), 3),
+                     "tiles_redone_exact_roots": "%d of %d" % (st["tiles_redone_exact_roots"], st["tiles"]),
                      "kernel_ms": {k: round(v, 3) for k, v in kt.items()}})
         enc.close()
 
@@ -73,6 +75,10 @@ def main():
     resident("config #4 (one GPU's view): 16384x16384, .jxl bytes in host memory", f, 16384)
     resident("16384x16384 at distance 0.5", f, 16384, distance=0.5, reps=3)
     resident("16384x16384 at distance 4", f, 16384, distance=4.0, reps=3)
+    resident("16384x16384 at distance 0.1", f, 16384, distance=0.1, reps=3)
+    f *= 4.0  # samples up to 4.0 (the reference documents values outside [0, 1] as legal)
+    resident("16384x16384 HDR (the frame's samples x 4: up to 4.0), distance 1", f, 16384, reps=3)
+    resident("16384x16384 HDR (samples up to 4.0) at distance 0.1", f, 16384, distance=0.1, reps=3)
     del f
     f = noise_frame(torch, 8192, dev)
     resident("token-heavy: 8192x8192 uniform noise (SURVEY 8(d) 'hard' set)", f, 8192, reps=3)

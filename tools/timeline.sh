@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 rm -rf gpurun_out/tl
-timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/tl -- python3 bench.py --no-extras --steps 3 --warmup 1 > gpurun_out/tl.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/tl -- python3 bench.py --no-extras --steps 3 --warmup 1 "$@" > gpurun_out/tl.log 2>&1
 python3 - <<'PY'
 import csv,glob
 ev=[]
@@ -17,9 +17,10 @@ ev.sort()
 # the second-to-last timed step: from its tile_kernel to the next one
 idx=[i for i,e in enumerate(ev) if "measure" in e[2]]
 i0=idx[len(idx)//2]
-while "tile_kernel" not in ev[i0][2]: i0-=1
+is_tile=lambda n: ("tile_kernel" in n or "tile12_kernel" in n) and "redo" not in n
+while not is_tile(ev[i0][2]): i0-=1
 t0=ev[i0][0]
-for k,(s,e,n) in enumerate(ev[i0:i0+60]):
-    if k and "tile_kernel" in n: break
+for k,(s,e,n) in enumerate(ev[i0:i0+80]):
+    if k and is_tile(n): break
     print("%9.3f %9.3f  %s" % ((s-t0)/1e6,(e-s)/1e6,n))
 PY
