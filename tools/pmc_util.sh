@@ -18,7 +18,7 @@ import csv, glob, collections
 agg = collections.defaultdict(list)
 for f in glob.glob("gpurun_out/pmc_util/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "tile_kernel" in r["Kernel_Name"] or "tile12_kernel" in r["Kernel_Name"]:
+        if ("tile_kernel" in r["Kernel_Name"] or "tile12_kernel" in r["Kernel_Name"]) and "redo" not in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(agg):
     print("%-28s %16.0f" % (k, sum(agg[k]) / len(agg[k])))
