@@ -16,6 +16,7 @@
 #define HIPSIM_HIP_RUNTIME_H_
 
 #include <math.h>
+#include <setjmp.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -58,7 +59,9 @@ constexpr int kRing = 256;
 enum State { kRunnable, kAtBlockBarrier, kAtWaveBarrier, kWaitLane, kDone };
 
 struct Fiber {
-  ucontext_t ctx;
+  ucontext_t ctx;    // entered once per workgroup (makecontext / setcontext); every later switch is a
+  jmp_buf jb;        // _setjmp / _longjmp pair -- swapcontext saves the signal mask with a system call per switch,
+  bool started = false;  // which was a third of the simulator's run time
   std::vector<char> stack;
   State state = kRunnable;
   dim3 tid;
@@ -78,6 +81,7 @@ struct Fiber {
 struct Machine {
   std::vector<Fiber> fibers;
   ucontext_t sched;
+  jmp_buf sched_jb;
   int current = -1;
   dim3 block_idx, block_dim, grid_dim;
   std::function<void()> body;
@@ -89,7 +93,19 @@ inline Machine& M() {
   return m;
 }
 inline Fiber& cur() { return M().fibers[M().current]; }
-inline void yield_to_scheduler() { swapcontext(&cur().ctx, &M().sched); }
+inline void yield_to_scheduler() {
+  if (_setjmp(cur().jb) == 0) _longjmp(M().sched_jb, 1);
+}
+inline void resume(Fiber& f) {
+  if (_setjmp(M().sched_jb) == 0) {
+    if (!f.started) {
+      f.started = true;
+      setcontext(&f.ctx);
+    } else {
+      _longjmp(f.jb, 1);
+    }
+  }
+}
 
 inline void trampoline() {
   M().body();
@@ -110,6 +126,7 @@ inline void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
     Fiber& f = m.fibers[i];
     if (f.stack.empty()) f.stack.resize(128 * 1024);
     f.state = kRunnable;
+    f.started = false;
     f.shfl_epoch[0] = f.shfl_epoch[1] = 0;
     f.tid = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
     getcontext(&f.ctx);
@@ -133,7 +150,7 @@ inline void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
       }
       if (f.state == kRunnable) {
         m.current = i;
-        swapcontext(&m.sched, &f.ctx);
+        resume(f);
         progress = true;
       }
       if (f.state == kDone) done++;

@@ -119,7 +119,10 @@ def test_pack_tiles_with_short_codes(built):
 def test_dc_kernels_match_oracle_tokeniser(built, w, h, distance):
     """dc_elementwise_kernel + dc_chain_kernel vs the oracle's WriteDCGroup restatement."""
     planes = T.to_planes(T.synthetic_image(w, h))
-    got = T.sim_hot_path(planes, distance)
+    # (the 2 x 2 DC groups of the large frame are a thousand tiles on the fiber model: there the tile kernel that
+    # feeds the DC kernels is the production build of the 8-wave variant, two thirds of the fibers)
+    big = w * h > 1 << 20
+    got = T.sim_hot_path(planes, distance, production_variant=big, tile_waves=8 if big else 0)
     want = T.oracle_dc_records(got)
     assert got.dc_records == want
     h = sum((T.token_histogram(r) for r in want))
