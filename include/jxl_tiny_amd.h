@@ -90,6 +90,8 @@ void jxlt_context_destroy(jxlt_context* ctx);
 const char* jxlt_last_error(const jxlt_context* ctx);
 /* The device ordinal the context was created for. */
 int jxlt_context_device(const jxlt_context* ctx);
+/* Number of usable HIP devices (0: none -- every other entry then fails with JXLT_ERR_NO_DEVICE). */
+int jxlt_device_count(void);
 /* Restricts the calling thread -- and the threads it creates afterwards, e.g. the helper threads of the code
  * construction -- to the CPUs next to the device (its PCI function's local_cpulist, i.e. the GPU's NUMA node), so
  * that the host side of an encode does not run on the other socket.  JXLT_ERR_UNSUPPORTED when the system does

@@ -383,6 +383,11 @@ const char* jxlt_last_error(const jxlt_context* ctx) {
 
 int jxlt_context_device(const jxlt_context* ctx) { return ctx ? ctx->device : -1; }
 
+int jxlt_device_count(void) {
+  int count = 0;
+  return hipGetDeviceCount(&count) == hipSuccess && count > 0 ? count : 0;
+}
+
 // The CPUs next to a device: /sys/bus/pci/devices/<bus id>/local_cpulist ("0-63,128-191").
 int jxlt_bind_thread_near_device(int device_ordinal) {
   char bus[64] = {0};

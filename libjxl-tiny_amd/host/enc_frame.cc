@@ -317,7 +317,11 @@ namespace jxl {
 
 namespace {
 // The process-wide device list for sharded frames (SetEncoderDevices / JXLT_DEVICES) and the encoder built
-// on it.  One frame at a time: the multi encoder is not re-entrant, callers are serialised.
+// on it.  One frame at a time: the multi encoder is not re-entrant, so concurrent callers of EncodeFile /
+// EncodeFrame / EncodePFMFile are SERIALISED while a device list of more than one GPU is set (a frame then has
+// all the listed GPUs to itself; callers that want frames side by side use one GPU per thread --
+// SetEncoderDevice -- or the batch encoder).  The encoder and its worker threads go when the list is cleared or
+// changed, and at process exit.
 std::mutex g_multi_mu;
 std::vector<int> g_devices;
 bool g_devices_from_env_done = false;
@@ -330,14 +334,8 @@ void DevicesFromEnvironment() {
   const char* e = getenv("JXLT_DEVICES");
   if (!e || !*e || !g_devices.empty()) return;
   if (strcmp(e, "all") == 0) {
-    // as many contexts as the runtime reports: probe by creating throw-away contexts is wasteful, so ask
-    // for ordinals until one is refused
-    for (int d = 0; d < 64; ++d) {
-      jxlt_context* probe = nullptr;
-      if (jxlt_context_create(d, &probe) != JXLT_OK) break;
-      jxlt_context_destroy(probe);
-      g_devices.push_back(d);
-    }
+    const int n = jxlt_device_count();
+    for (int d = 0; d < n && d < 64; ++d) g_devices.push_back(d);
     return;
   }
   for (const char* p = e; *p;) {
@@ -350,10 +348,23 @@ void DevicesFromEnvironment() {
 }
 }  // namespace
 
+namespace {
+void DestroyMultiEncoderLocked() {
+  if (g_multi) jxlt_multi_encoder_destroy(g_multi);
+  g_multi = nullptr;
+  g_multi_devices.clear();
+}
+void DestroyMultiEncoderAtExit() {
+  std::lock_guard<std::mutex> lock(g_multi_mu);
+  DestroyMultiEncoderLocked();
+}
+}  // namespace
+
 void SetEncoderDevices(const int* device_ordinals, int n) {
   std::lock_guard<std::mutex> lock(g_multi_mu);
   g_devices_from_env_done = true;  // an explicit call wins over the environment
   g_devices.assign(device_ordinals, device_ordinals + (n > 0 && device_ordinals ? n : 0));
+  if (g_multi && g_multi_devices != g_devices) DestroyMultiEncoderLocked();  // (incl. a cleared list)
 }
 
 }  // namespace jxl
@@ -369,11 +380,10 @@ bool EncodeOnDeviceList(const float* const planes[3], size_t pitch_bytes, const 
   DevicesFromEnvironment();
   *used = g_devices.size() > 1 && ysize > 2048;
   if (!*used) return true;
-  if (g_multi && g_multi_devices != g_devices) {
-    jxlt_multi_encoder_destroy(g_multi);
-    g_multi = nullptr;
-  }
+  if (g_multi && g_multi_devices != g_devices) DestroyMultiEncoderLocked();
   if (!g_multi) {
+    static const bool registered = (atexit(DestroyMultiEncoderAtExit), true);
+    (void)registered;
     if (jxlt_multi_encoder_create(g_devices.data(), static_cast<int>(g_devices.size()), &g_multi) != JXLT_OK) {
       fprintf(stderr, "jxl_tiny_amd: cannot create device contexts: %s\n", jxlt_last_error(nullptr));
       g_multi = nullptr;
