@@ -324,7 +324,11 @@ def main():
             "rows_on_rank0": [y0, y1], "codestream_bytes": len(jxl_bytes),
             "codestream_sha256": hashlib.sha256(jxl_bytes).hexdigest()[:16]},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(size) if world == 1 else None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     # (the committed PMC profile is of the whole frame on one GPU; a slab's launch moves its share of
+                     # those bytes: the kernel's traffic is per tile, tiles do not share data beyond the halo columns)
+                     "traffic": (None if pmc_traffic(size) is None else
+                                 int(pmc_traffic(size) * slab_pixels / float(size * size))),
                      "kernel": "tile_kernel", "kernel_ms": round(tile_ms, 3),
                      "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PIXEL * slab_pixels,
                      "note": "rank 0's launch (its slab of the frame)" if sharded else "whole frame"},
