@@ -43,6 +43,17 @@ def test_file_header_bits(built):
         built.file_header(0, 5)
 
 
+def test_device_count_without_gpu(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    hip = built.hip_lib()
+    hip.jxlt_device_count.restype = C.c_int
+    assert hip.jxlt_device_count() == 0
+    hip.jxlt_bind_thread_near_device.argtypes = [C.c_int]
+    assert hip.jxlt_bind_thread_near_device(0) != 0  # no device: an error code, no crash
+
+
 def test_no_cpu_fallback_without_gpu(built):
     import torch
     if torch.cuda.is_available():

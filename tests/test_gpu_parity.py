@@ -5,6 +5,8 @@ seeded inputs.  Bar: bit-exact -- XYB / quant-field / masking / entropy floats t
 operation), every integer output and the token stream byte for byte."""
 import subprocess
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -452,6 +454,37 @@ def test_baseline_config5_batch_of_32_frames_over_a_device_list(built):
     assert len(got) == 32
     for i in range(32):
         assert got[i] == want[i % 4], "frame %d" % i
+
+
+def test_thread_binding_next_to_the_device(built):
+    """jxlt_bind_thread_near_device: the calling thread ends up on the CPUs the device's PCI function lists as
+    local (or the call says the system does not tell); jxlt_device_count / jxlt_context_device agree with torch."""
+    import os
+    import threading
+    import torch
+    hip = built.hip_lib()
+    hip.jxlt_device_count.restype = C.c_int
+    hip.jxlt_bind_thread_near_device.argtypes = [C.c_int]
+    hip.jxlt_context_device.argtypes = [C.c_void_p]
+    assert hip.jxlt_device_count() == torch.cuda.device_count() >= 1
+    enc = built.Encoder(0)
+    assert hip.jxlt_context_device(enc._ctx) == 0
+    enc.close()
+    result = {}
+
+    def run():  # (in a thread of its own: the test process keeps its affinity)
+        before = os.sched_getaffinity(0)
+        rc = hip.jxlt_bind_thread_near_device(0)
+        after = os.sched_getaffinity(0)
+        result.update(rc=rc, before=before, after=after)
+
+    t = threading.Thread(target=run)
+    t.start()
+    t.join()
+    assert result["rc"] in (0, -4), result  # JXLT_OK or JXLT_ERR_UNSUPPORTED
+    assert len(result["after"]) >= 1
+    if result["rc"] != 0:
+        assert result["after"] == result["before"]
 
 
 def test_attach_host_small_frames(built, enc):
