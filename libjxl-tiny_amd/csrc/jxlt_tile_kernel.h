@@ -566,7 +566,13 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       }
     }
   }
+  // (no barrier here: what P4 writes -- the final quant field, raw_quant, the initial strategies -- is first read
+  // behind later barriers, the transforms below read the pixel planes only, and their LDS scratch lies over the
+  // adaptive-quantisation buffers, which nobody reads behind the barrier in front of P4.  The waves that have no
+  // block in P4 -- 8 to 11 of the 12-wave kernel -- start their transforms at once.)
+#ifdef JXLT_P4_BARRIER
   __syncthreads();
+#endif
   JXLT_MARK(3);
 
   // ---- P6a: candidate two-block transforms (enc_ac_strategy.cc:62-66) -------
