@@ -473,12 +473,66 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
   __syncthreads();
   JXLT_MARK(2);
   // ---- P4: per-block modulations, one octet per block (:114-285) -------------
-  if (!k12 || tid < 512) {  // (12 waves: octets 0..63 = waves 0-7)
-    float out_val = 0.0f;
-    const int bxp = px0 + obx * 8, byp = oby * 8;  // block origin (stripe pixels)
-    if (blk_valid) {
-      out_val = compute_mask(S.aq[oct]);
+  // The per-block part behind the four sums (:52-75, :146-285, :518-534): from the erosion value and the sums to the
+  // quant field.  8 waves: every lane of the block's octet computes it (lane 0 stores).  12 waves: the octets leave
+  // their sums in LDS and ONE wave does it for the tile's 64 blocks, a lane each, while the terms of
+  // chroma-from-luma are published -- an eighth of the instructions, and off the path of the waves that do P4.
+  auto block_quant_field = [&](float erosion, float hf, float red, float blue, float gam) {
+    const float kRedRampLength = (float)0.019421555948474039;
+    const float kBlueRampLength = (float)0.086890611400405895;
+    float out_val = compute_mask(erosion);
+    out_val = fma32(hf, -2.0052193233688884f / 112, out_val);
+    {
+      const float kStrengthMul = (float)2.177823400325309;
+      const double butteraugli_target = (double)A.distance;
+      const float strength = (float)(kStrengthMul * (1.0f - 0.25f * butteraugli_target));
+      if (!(strength < 0)) {
+        const float red_strength = strength * 5.992297772961519f;
+        const float blue_strength = strength;
+        const float offset = strength * -0.009174542291185913f;
+        out_val = out_val + offset;
+        const float ratio = 30.610615782142737f;
+        float overall_red = fminf(red, ratio * kRedRampLength);
+        overall_red = overall_red * (red_strength / ratio);
+        float overall_blue = fminf(blue, ratio * kBlueRampLength);
+        overall_blue = overall_blue * (blue_strength / ratio);
+        out_val = overall_red + (overall_blue + out_val);
+      }
     }
+    {
+      const float overall_ratio = gam * (1.0f / 64);
+      const float kGam = -0.15526878023684174f * 0.693147180559945f;
+      out_val = fma32(kGam, fast_log2f(overall_ratio), out_val);
+    }
+    // PerBlockModulations tail (:249-285)
+    const float kAcQuant = 0.8294f;
+    const float scale = div_normal(kAcQuant, A.distance);
+    const float base_level = 0.5f * scale;
+    float dampen = 1.0f;
+    if (A.distance >= 7.0f) {
+      dampen = 1.0f - ((A.distance - 7.0f) / (14.0f - 7.0f));
+      if (dampen < 0) dampen = 0;
+    }
+    const float mul = scale * dampen;
+    const float add = (1.0f - dampen) * base_level;
+    return fast_pow2f(out_val * 1.442695041f) * mul + add;
+  };
+  // ... and what is stored per block (raw quant :518-534, the initial strategy)
+  auto store_block_quant = [&](int b, float qf) {
+    S.aq[b] = qf;
+    int v = (int)(qf * A.inv_scale + 0.5f);
+    v = v < 1 ? 1 : v > 255 ? 255 : v;
+    S.raw_quant[b] = (uint8_t)v;
+    S.strat[b] = 1;  // DCT8, first block (FillDCT8)
+    if (kDebug && A.dbg_qf) {
+      const uint32_t pos = (uint32_t)(by_img0 + (b >> 3)) * bstride + (uint32_t)(bx_img0 + (b & 7));
+      A.dbg_qf[pos] = qf;
+      A.dbg_mask[pos] = S.mask[b];
+    }
+  };
+  float* const p4_sums = &S.sqrt_lut[0];  // 12 waves: [block][hf, red, blue, gamma] (the root table is staged later)
+  if (!k12 || tid < 512) {  // (12 waves: octets 0..63 = waves 0-7)
+    const int bxp = px0 + obx * 8, byp = oby * 8;  // block origin (stripe pixels)
     // HfModulation (:209-247): lane l = column l of the block
     float hf = 0.0f, red = 0.0f, blue = 0.0f, gam = 0.0f;
     const float kBias = 0.16f;
@@ -517,52 +571,15 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     blue = octet_sum(blue);
     gam = octet_sum(gam);
     if (blk_valid) {
-      out_val = fma32(hf, -2.0052193233688884f / 112, out_val);
-      {
-        const float kStrengthMul = (float)2.177823400325309;
-        const double butteraugli_target = (double)A.distance;
-        const float strength = (float)(kStrengthMul * (1.0f - 0.25f * butteraugli_target));
-        if (!(strength < 0)) {
-          const float red_strength = strength * 5.992297772961519f;
-          const float blue_strength = strength;
-          const float offset = strength * -0.009174542291185913f;
-          out_val = out_val + offset;
-          const float ratio = 30.610615782142737f;
-          float overall_red = fminf(red, ratio * kRedRampLength);
-          overall_red = overall_red * (red_strength / ratio);
-          float overall_blue = fminf(blue, ratio * kBlueRampLength);
-          overall_blue = overall_blue * (blue_strength / ratio);
-          out_val = overall_red + (overall_blue + out_val);
+      if constexpr (k12) {
+        if (l == 0) {
+          float4 sums;
+          sums.x = hf; sums.y = red; sums.z = blue; sums.w = gam;
+          *reinterpret_cast<float4*>(p4_sums + oct * 4) = sums;
         }
-      }
-      {
-        const float overall_ratio = gam * (1.0f / 64);
-        const float kGam = -0.15526878023684174f * 0.693147180559945f;
-        out_val = fma32(kGam, fast_log2f(overall_ratio), out_val);
-      }
-      // PerBlockModulations tail (:249-285) + raw quant (:518-534)
-      const float kAcQuant = 0.8294f;
-      const float scale = div_normal(kAcQuant, A.distance);
-      const float base_level = 0.5f * scale;
-      float dampen = 1.0f;
-      if (A.distance >= 7.0f) {
-        dampen = 1.0f - ((A.distance - 7.0f) / (14.0f - 7.0f));
-        if (dampen < 0) dampen = 0;
-      }
-      const float mul = scale * dampen;
-      const float add = (1.0f - dampen) * base_level;
-      const float qf = fast_pow2f(out_val * 1.442695041f) * mul + add;
-      if (l == 0) {
-        S.aq[oct] = qf;
-        int v = (int)(qf * A.inv_scale + 0.5f);
-        v = v < 1 ? 1 : v > 255 ? 255 : v;
-        S.raw_quant[oct] = (uint8_t)v;
-        S.strat[oct] = 1;  // DCT8, first block (FillDCT8)
-        if (kDebug && A.dbg_qf) {
-          const uint32_t pos = (uint32_t)(by_img0 + oby) * bstride + (uint32_t)(bx_img0 + obx);
-          A.dbg_qf[pos] = qf;
-          A.dbg_mask[pos] = S.mask[oct];
-        }
+      } else {
+        const float qf = block_quant_field(S.aq[oct], hf, red, blue, gam);
+        if (l == 0) store_block_quant(oct, qf);
       }
     }
   }
@@ -692,6 +709,17 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
   }
   __syncthreads();  // all pixel reads done: the planes are dead from here on
   new_phase();
+  if constexpr (k12) {
+    // the blocks' quant fields from the sums P4 left (see block_quant_field): wave 11, a lane per block, beside the
+    // publishing of the terms; first read behind the chains
+    if (wave_u == 11) {
+      const int b = tid & 63;
+      if ((b & 7) < nbx && (b >> 3) < nby) {
+        const float4 sums = *reinterpret_cast<const float4*>(p4_sums + b * 4);
+        store_block_quant(b, block_quant_field(S.aq[b], sums.x, sums.y, sums.z, sums.w));
+      }
+    }
+  }
   JXLT_MARK(5);
   // ---- P5b: chroma-from-luma (enc_chroma_from_luma.cc:40-131) ----------------
   {
