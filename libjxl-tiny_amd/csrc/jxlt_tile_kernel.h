@@ -29,6 +29,21 @@ constexpr int kCflTermFloats = 64 * 64 * 4;  // LDS floats overlaid by the CfL t
 constexpr int kStageStrideF = 200;
 
 struct alignas(16) TileShared {
+  // The tables and the per-block state come FIRST: an LDS address below 64 KB folds into the 16-bit offset field
+  // of the instruction that uses it.  Behind the 64 KB of planes / terms the entropy estimate paid two address
+  // instructions per coefficient (an add for the root table's base, an or for the weight's row).
+  float inv_w[576];
+  float sqrt_lut[1024];  // sqrtf of the quantised magnitudes below kSqrtLutSize (<= 1024; test builds use fewer)
+  float aq[64];            // quant field (tile-local 8x8)
+  float mask[64];
+  float cfl_sum[4];        // ca_x, cb_x, ca_b, cb_b
+  int cmap[2];             // ytox, ytob
+  uint8_t raw_quant[64];
+  uint8_t strat[64];
+  uint32_t ntok;
+  uint32_t nfirst;
+  uint32_t overflow;  // a quantised magnitude of this tile did not fit the root table
+  uint32_t pad_to_16[3];
   float x[64 * kXYPitch];
   float y[64 * kXYPitch];
   float b[64 * kBPitch];
@@ -40,22 +55,12 @@ struct alignas(16) TileShared {
   //   read is done: 64 blocks x 64 coefficients x (a_x, b_x, a_b, b_b).
   // rowsum..transpose_pad: during the transforms (the AQ buffers are dead by then) the octets'
   // transpose scratch, 64 x kTransposePitch floats.
-  // (+ 192: transpose_pad and sqrt_lut together are the 25 x 128 floats in which the chain waves of the 12-wave
+  // (+ 192: 17 x 128 floats -- with the 8 x 128 of sqrt_lut the 25 x 128 in which the chain waves of the 12-wave
   // kernel park coefficients during the chains)
   float transpose_pad[64 * 72 - (kCflTermFloats - (2 * 64 * kXYPitch + 64 * kBPitch)) + 192];
   // (its first 128 floats hold the candidate entropies of the 2x2 cells during the strategy search, "ent8")
-  float sqrt_lut[1024];  // sqrtf of the quantised magnitudes below kSqrtLutSize (<= 1024; test builds use fewer)
-  float inv_w[576];
-  float aq[64];            // quant field (tile-local 8x8)
-  float mask[64];
-  float cfl_sum[4];        // ca_x, cb_x, ca_b, cb_b
-  int cmap[2];             // ytox, ytob
-  uint8_t raw_quant[64];
-  uint8_t strat[64];
-  uint32_t ntok;
-  uint32_t nfirst;
-  uint32_t overflow;  // a quantised magnitude of this tile did not fit the root table
 };
+static_assert(offsetof(TileShared, x) % 16 == 0, "the term area is accessed in 16-byte chunks");
 // After the last pixel read the XYB planes are dead and are reused: chroma-from-luma terms, the parked
 // DCT8 coefficients of the entropy estimate, then the staging area of the selected transforms' coefficients
 // (64 blocks x 3 channels x 64 floats).
@@ -799,15 +804,17 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       // 12 waves: the chain waves hold 48 coefficients like every other wave, and the two term sets below are
       // 32 registers more: fifteen of the B coefficients wait in the one piece of LDS that is free right now
       // (the transposes' pad behind the term area)
-      float* const chain_park = &S.transpose_pad[0] + tid;  // [25][128], into sqrt_lut
+      // rows 0..16 in the transposes' pad, rows 17..24 in the root table's place
+      auto chain_park = [&](int r) -> float& {
+        return r < 17 ? S.transpose_pad[r * 128 + tid] : S.sqrt_lut[(r - 17) * 128 + tid];
+      };
       if constexpr (k12) {
-        static_assert((sizeof(S.transpose_pad) + sizeof(S.sqrt_lut)) / 4 >= 25 * 128, "chain park");
-        static_assert(offsetof(TileShared, sqrt_lut) == offsetof(TileShared, transpose_pad) + sizeof(S.transpose_pad), "");
+        static_assert(sizeof(S.transpose_pad) / 4 >= 17 * 128 && sizeof(S.sqrt_lut) / 4 >= 8 * 128, "chain park");
 #pragma unroll
-        for (int r = 0; r < 16; r++) chain_park[r * 128] = c16b[r];
+        for (int r = 0; r < 16; r++) chain_park(r) = c16b[r];
 #pragma unroll
-        for (int r = 8; r < 16; r++) chain_park[(8 + r) * 128] = c16x[r];
-        chain_park[24 * 128] = c16y[15];
+        for (int r = 8; r < 16; r++) chain_park(8 + r) = c16x[r];
+        chain_park(24) = c16y[15];
       }
       const int ch = (cl >> 3) & 1;  // 0: X, 1: B
       const float* src = terms + l * 32;
@@ -882,10 +889,10 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       if constexpr (k12) {
         JXLT_COMPILER_FENCE();
 #pragma unroll
-        for (int r = 0; r < 16; r++) c16b[r] = chain_park[r * 128];
+        for (int r = 0; r < 16; r++) c16b[r] = chain_park(r);
 #pragma unroll
-        for (int r = 8; r < 16; r++) c16x[r] = chain_park[(8 + r) * 128];
-        c16y[15] = chain_park[24 * 128];
+        for (int r = 8; r < 16; r++) c16x[r] = chain_park(8 + r);
+        c16y[15] = chain_park(24);
       }
       __builtin_amdgcn_s_setprio(0);
     }
