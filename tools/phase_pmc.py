@@ -41,7 +41,7 @@ def report(d):
     rows = []
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         rows += list(csv.DictReader(open(f)))
-    tile = [r for r in rows if "tile_kernel" in r["Kernel_Name"] or "tile12_kernel" in r["Kernel_Name"]]
+    tile = [r for r in rows if ("tile_kernel" in r["Kernel_Name"] or "tile12_kernel" in r["Kernel_Name"]) and "redo" not in r["Kernel_Name"]]
     by_set = {}
     # several rocprofv3 passes (one directory each) may be reported together: dispatch order within a pass
     for r in tile:
