@@ -73,15 +73,15 @@ def main():
     del f
     f = bench.make_frame_on_device(torch, 16384, 0, dev)
     resident("config #4 (one GPU's view): 16384x16384, .jxl bytes in host memory", f, 16384)
-    resident("16384x16384 at distance 0.5", f, 16384, distance=0.5, reps=3)
-    resident("16384x16384 at distance 4", f, 16384, distance=4.0, reps=3)
-    resident("16384x16384 at distance 0.1", f, 16384, distance=0.1, reps=3)
+    resident("16384x16384 at distance 0.5", f, 16384, distance=0.5, reps=10)
+    resident("16384x16384 at distance 4", f, 16384, distance=4.0, reps=10)
+    resident("16384x16384 at distance 0.1", f, 16384, distance=0.1, reps=6)
     f *= 4.0  # samples up to 4.0 (the reference documents values outside [0, 1] as legal)
-    resident("16384x16384 HDR (the frame's samples x 4: up to 4.0), distance 1", f, 16384, reps=3)
-    resident("16384x16384 HDR (samples up to 4.0) at distance 0.1", f, 16384, distance=0.1, reps=3)
+    resident("16384x16384 HDR (the frame's samples x 4: up to 4.0), distance 1", f, 16384, reps=10)
+    resident("16384x16384 HDR (samples up to 4.0) at distance 0.1", f, 16384, distance=0.1, reps=6)
     del f
     f = noise_frame(torch, 8192, dev)
-    resident("token-heavy: 8192x8192 uniform noise (SURVEY 8(d) 'hard' set)", f, 8192, reps=3)
+    resident("token-heavy: 8192x8192 uniform noise (SURVEY 8(d) 'hard' set)", f, 8192, reps=10)
     del f
     for r in rows:
         print(json.dumps(r), flush=True)
