@@ -220,6 +220,47 @@ def test_two_process_pipeline_with_two_frames_in_flight(built):
     assert not [f for f in os.listdir("/dev/shm") if f.startswith(name[1:])]
 
 
+def test_pipeline_failure_releases_every_rank(built):
+    """A lane whose slab operation fails on one rank: the frame's wait returns an error on BOTH ranks (no hang), and
+    the other lane's frame, already in flight, still completes."""
+    world, w, h, d, depth = 2, 40, 4096, 1.0, 2
+    name = "/jxlt-test-pipefail-%d" % os.getpid()
+    barrier = threading.Barrier(world)
+    outcome = [None] * world
+
+    def run(rank):
+        planes = T.to_planes(T.synthetic_image(w, h))
+        y0, y1 = built.shard_rows(h, world, rank)
+        slabs = [OracleSlab(built, np.ascontiguousarray(planes[:, y0:y1]), d) for _ in range(depth)]
+        if rank == 1:  # lane 1 of rank 1 fails in the middle of the protocol
+            slabs[1]._cb["ac_histogram"] = built._SLAB_FN["ac_histogram"](lambda _s, _o: -5)
+            slabs[1].ops.ac_histogram = slabs[1]._cb["ac_histogram"]
+        pipe = built.ShardPipeline(name, rank, world, -1, depth, 1 << 20, 4096, [s.ops for s in slabs]) if rank == 0 else None
+        barrier.wait()
+        if pipe is None:
+            pipe = built.ShardPipeline(name, rank, world, -1, depth, 1 << 20, 4096, [s.ops for s in slabs])
+        t0, t1 = pipe.submit_ops(w, h, d), pipe.submit_ops(w, h, d)
+        good = pipe.wait(t0)
+        try:
+            pipe.wait(t1)
+            bad = None
+        except built.JxlTinyError as e:
+            bad = str(e)
+        outcome[rank] = (good.tobytes() if good is not None else None, bad)
+        barrier.wait()
+        pipe.close()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    want = T.assemble_codestream(T.oracle_hot_path(T.to_planes(T.synthetic_image(w, h)), d), d)
+    assert outcome[0] is not None and outcome[1] is not None, outcome
+    assert outcome[0][0] == want and outcome[1][0] is None
+    assert outcome[0][1] is not None and outcome[1][1] is not None, outcome
+
+
 def test_shard_rows_cover_whole_dc_groups(built):
     for h, world in [(16384, 8), (16384, 3), (5000, 2), (100, 4), (2049, 2), (16384, 64)]:
         rows = [built.shard_rows(h, world, r) for r in range(world)]
