@@ -18,6 +18,10 @@ constexpr int kTileThreads = 512;
 // candidate per octet): half the coefficient registers per thread, 12 waves per workgroup, two workgroups per CU =
 // 6 waves per SIMD instead of 4 when the kernel fits 80 vector registers.
 constexpr int kTile12Threads = 768;
+// 12 waves: LDS copy of the per-scan-position tables of the quantisation phase (DeviceTables::scan_consts, scan_slot,
+// inv_qac), in the term area behind the staging of the selected transforms' coefficients
+constexpr int kP8ScanWords = 3 * 7 * 64 + 3 * 64 / 4;  // scan_consts + scan_slot
+constexpr int kP8TabOffset = 13568;                    // floats from the start of the term area (54 272 B)
 constexpr int kDefaultTileWaves = 12;  // which variant the C ABI launches (JXLT_TILE_WAVES overrides)
 constexpr int kHalo = 5;                 // AQ: +-4 px window, +-1 px Laplacian tap
 constexpr int kXYPitch = 64 + 2 * kHalo + 1;  // 75 floats (odd: conflict-free columns)
@@ -783,10 +787,21 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     // 12 waves: the waves that wait for the chains fetch the root table meanwhile (two entries per thread); it goes
     // to LDS behind the chains, where the chain waves' parked coefficients were.
     float late_root0 = 0.0f, late_root1 = 0.0f;
+    // ... and what the scan-order quantisation (P8b) needs per lane: its constants per scan position, the staging slots
+    // and the inverse quantiser steps -- 1648 words that every wave would otherwise fetch from global memory, 25 loads
+    // per thread, at the start of that phase, with nothing to do meanwhile
+    uint32_t late_p8[3] = {0u, 0u, 0u};
     if constexpr (k12) {
       if (cw >= 2) {
         late_root0 = T->sqrt_lut[(tid - 128) & (kSqrtLutSize - 1)];
         late_root1 = T->sqrt_lut[(tid - 128 + 640) & (kSqrtLutSize - 1)];
+        const uint32_t* const scan_words = reinterpret_cast<const uint32_t*>(&T->scan_consts[0][0][0]);
+        const uint32_t* const qac_words = reinterpret_cast<const uint32_t*>(&T->inv_qac[0]);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const int w = tid - 128 + 640 * j;
+          late_p8[j] = w < kP8ScanWords ? scan_words[w] : qac_words[imin(w - kP8ScanWords, 255)];
+        }
       }
     }
 #ifndef JXLT_CFL_PINGPONG
@@ -968,6 +983,12 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       if (cw >= 2) {  // (visible to P6b behind the barrier below)
         if (tid - 128 < kSqrtLutSize) S.sqrt_lut[tid - 128] = late_root0;
         if (tid - 128 + 640 < kSqrtLutSize) S.sqrt_lut[tid - 128 + 640] = late_root1;
+        uint32_t* const p8_tab = reinterpret_cast<uint32_t*>(&S.x[0]) + kP8TabOffset;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const int w = tid - 128 + 640 * j;
+          if (w < kP8ScanWords + 256) p8_tab[w] = late_p8[j];
+        }
       }
     }
     if (tid < 2) {  // FindBestMultiplier tail (:56-61)
@@ -1107,11 +1128,17 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     }
   }
   __syncthreads();
-  if (tid < 64 && (tid & 7) < nbx && (tid >> 3) < nby) {
-    const uint32_t pos = (uint32_t)(by_img0 + (tid >> 3)) * bstride + (uint32_t)(bx_img0 + (tid & 7));
-    A.strategy[pos] = S.strat[tid];
-    if (S.strat[tid] & 1) atomicAdd(&S.nfirst, 1u);
-    A.raw_quant[pos] = S.raw_quant[tid];
+  if (tid < 64) {  // (wave 0: a lane per block)
+    const bool in_frame = (tid & 7) < nbx && (tid >> 3) < nby;
+    const uint32_t st = in_frame ? S.strat[tid] : 0u;
+    if (in_frame) {
+      const uint32_t pos = (uint32_t)(by_img0 + (tid >> 3)) * bstride + (uint32_t)(bx_img0 + (tid & 7));
+      A.strategy[pos] = (uint8_t)st;
+      A.raw_quant[pos] = S.raw_quant[tid];
+    }
+    // the tile's first blocks: one ballot instead of an LDS atomic per first block
+    const unsigned long long firsts = __ballot((st & 1u) != 0);
+    if (tid == 0) S.nfirst = (uint32_t)__popcll(firsts);
   }
   // All pixel reads were done before P5b (the transforms live in registers): from here on the
   // XYB planes are reused as the quantised-coefficient staging area.  No barrier is needed
@@ -1190,23 +1217,28 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       float thr[3];  // zeroing threshold of x, y, b (enc_group.cc:227-242)
     };
     // (per scan position and position class: tables built by the host, DeviceTables::scan_consts)
+    // (12 waves: from the copy in LDS that the waves waiting for the chains made, see late_p8)
+    const float* const p8_consts = k12 ? &S.x[0] + kP8TabOffset : &A.tab->scan_consts[0][0][0];
+    const uint8_t* const p8_slots =
+        k12 ? reinterpret_cast<const uint8_t*>(&S.x[0] + kP8TabOffset + 3 * 7 * 64) : &A.tab->scan_slot[0][0];
+    const float* const p8_inv_qac = k12 ? &S.x[0] + kP8TabOffset + kP8ScanWords : &A.tab->inv_qac[0];
     auto consts_of = [&](int cls) {
       LaneConsts k;
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        k.inv[c] = A.tab->scan_consts[cls][c][lane];
-        k.thr[c] = A.tab->scan_consts[cls][4 + c][lane];
+        k.inv[c] = p8_consts[(cls * 7 + c) * 64 + lane];
+        k.thr[c] = p8_consts[(cls * 7 + 4 + c) * 64 + lane];
       }
-      k.ydq = A.tab->scan_consts[cls][3][lane];
+      k.ydq = p8_consts[(cls * 7 + 3) * 64 + lane];
       return k;
     };
     const LaneConsts k8 = consts_of(0), k16a = consts_of(1), k16b = consts_of(2);
-    const int slot8 = A.tab->scan_slot[0][lane], slot16a = A.tab->scan_slot[1][lane], slot16b = A.tab->scan_slot[2][lane];
+    const int slot8 = p8_slots[lane], slot16a = p8_slots[64 + lane], slot16b = p8_slots[128 + lane];
     // lane b knows block b of the tile; the first blocks of the tile's transforms as a mask
     const bool lane_blk_valid = (lane & 7) < nbx && (lane >> 3) < nby;
     const int strat_of_lane = lane_blk_valid ? (int)S.strat[lane] : 0;
     const int quant_of_lane = (int)S.raw_quant[lane];
-    const float inv_qac_of_lane = A.tab->inv_qac[quant_of_lane];  // (one vector load: no scalar load per transform)
+    const float inv_qac_of_lane = p8_inv_qac[quant_of_lane];  // (one vector load: no scalar load per transform)
     // (transform number t, in raster order of the first blocks, goes to wave t mod 8: lane b finds its block's
     // number as the count of first blocks below it, and the wave's own blocks come out of one more ballot)
     const unsigned long long firsts = __ballot(strat_of_lane & 1);
