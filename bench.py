@@ -502,7 +502,12 @@ def cpu_baseline_leg(args, np, pkg, T, frame, dev_index, result):
     from concurrent.futures import ThreadPoolExecutor
     ng = s // 256
     if ng >= 2:
-        nthr = max(1, min(ng * ng, os.cpu_count() or 1))
+        # (the CPUs this process may run on: a rank of an N > 1 run is bound to its GPU's NUMA node)
+        try:
+            usable = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            usable = os.cpu_count() or 1
+        nthr = max(1, min(ng * ng, usable))
         tiles = [(gy, gx) for gy in range(ng) for gx in range(ng)]
         t4 = time.perf_counter()
         with ThreadPoolExecutor(nthr) as ex:
