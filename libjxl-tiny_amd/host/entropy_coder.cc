@@ -383,47 +383,26 @@ void ClusterHistograms(std::vector<Histogram>* histograms, std::vector<uint8_t>*
   // The independent cost evaluations of each step run on the helper pool when it is free;
   // selections and ties are then resolved serially in the reference's order.
   ClusterPool& pool = ClusterPool::Get();
-  // Whether sharing pays depends on the histograms AND on the machine: a Huffman cost over a dozen symbols takes a
-  // third of a microsecond where the histogram is cached, and several times that on a core of another CCD that has
-  // to fetch it first.  (16384^2 bench frame, EPYC 9575F, 7 helpers -- AC: 64 histograms with 379 non-zero counts:
-  // shared 0.16-0.19 ms, alone 0.09; DC: 45 histograms, 830 counts: 0.30 against 0.55 ms; DC at distance 4, 468
-  // counts: 0.24 against 0.38; AC at distance 0.5, 607 counts: about equal.)  No static rule separates these, so
-  // the choice is made from what this thread has seen for histogram sets of this kind (their number and the
-  // rough number of non-zero counts): the first call follows the prior "shared from 520 counts on", the second
-  // tries the other way, afterwards the faster one is used and the other re-tried every 32nd call.  The result
-  // does not depend on the choice.
+  // Whether sharing pays depends on the histograms: a Huffman cost over a dozen symbols takes a third of a
+  // microsecond where the histogram is cached, and several times that on a core that has to fetch it first, so
+  // few, small evaluations are done faster alone.  (16384^2 bench frame, EPYC 9575F, 7 helpers -- AC: 64 histograms
+  // with 379 non-zero counts: shared 0.16-0.19 ms, alone 0.09; DC: 45 histograms, 830 counts: 0.30 against 0.55 ms;
+  // DC at distance 4, 468 counts: 0.24 against 0.38; AC at distance 0.5, 607 counts: about equal.)  A fixed rule
+  // separates these cases -- shared from 450 non-zero counts on -- and makes the latency of a code construction a
+  // function of its input alone (until round 3 the choice was learnt per calling thread, with an exploratory call
+  // every 32nd time: the results never depended on it, the latency did).
   size_t nonzero = 0;
   for (const Histogram& h : in)
     for (size_t i = 0; i < kAlphabetSize; ++i) nonzero += h.counts[i] != 0;
-  struct ModeStats {
-    double best_ms[2] = {0.0, 0.0};  // [serial, shared]
-    unsigned seen[2] = {0, 0}, calls = 0;
-  };
-  static thread_local std::map<uint64_t, ModeStats> stats_of;
-  ModeStats& stats = stats_of[(static_cast<uint64_t>(in.size()) << 32) | (nonzero / 128)];
   static const int forced = [] {
     const char* e = getenv("JXLT_POOL_MODE");  // (experiment knob, tools/code_probe.sh: 0 = never, 1 = always)
     return e ? atoi(e) : -1;
   }();
-  const int prior = nonzero >= 520 ? 1 : 0;
-  int mode = prior;
-  if (forced >= 0) {
-    mode = forced != 0;
-  } else if (stats.seen[prior] != 0) {
-    const int other = 1 - prior;
-    if (stats.seen[other] == 0) {
-      mode = other;
-    } else {
-      const int faster = stats.best_ms[1] < stats.best_ms[0] ? 1 : 0;
-      mode = stats.calls % 32 == 31 ? 1 - faster : faster;
-    }
-  }
-  ++stats.calls;
+  const int mode = forced >= 0 ? (forced != 0) : (nonzero >= 450 ? 1 : 0);
   static const bool trace = getenv("JXLT_TRACE") != nullptr;
   if (trace)
     fprintf(stderr, "jxlt trace: clustering %zu histograms, %zu non-zero counts, %s\n", in.size(), nonzero,
             mode ? "shared" : "alone");
-  const auto cluster_t0 = std::chrono::steady_clock::now();
   const bool pooled = mode == 1 && in.size() >= 16 && pool.Open();
   auto parallel_for = [&](size_t n, const std::function<void(size_t)>& fn) {
     if (pooled) {
@@ -480,13 +459,6 @@ void ClusterHistograms(std::vector<Histogram>* histograms, std::vector<uint8_t>*
   }
   if (pooled) pool.Close();
   if (pooled) t_clustering_shared = true;
-  {
-    const int ran = pooled ? 1 : 0;  // (a busy pool means the serial way was taken)
-    const double ms_taken =
-        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - cluster_t0).count();
-    // (the best time seen, forgetting slowly: 5 % per observation)
-    stats.best_ms[ran] = stats.seen[ran]++ == 0 ? ms_taken : std::min(ms_taken, stats.best_ms[ran] * 1.05);
-  }
   // Canonical renumbering in order of first use (enc_cluster.cc:98-115).
   std::vector<Histogram> tmp(out);
   std::map<uint32_t, uint32_t> new_index;
