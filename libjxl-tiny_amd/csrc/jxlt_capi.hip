@@ -33,6 +33,10 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// Largest frame of the device path, in 8x8 blocks.  The kernels index blocks -- and up to twelve 32-bit words per
+// block (jxlt_token_kernel.h: mask_at) -- with 32 bits; coefficients (192 per block) are indexed with 64.
+constexpr size_t kMaxFrameBlocks = size_t(1) << 28;
+
 template <typename T>
 struct DeviceBuf {
   T* p = nullptr;
@@ -213,9 +217,11 @@ int CheckImageArgs(jxlt_context* ctx, const void* const planes[3], size_t pitch_
     ctx->error = "invalid image arguments";
     return JXLT_ERR_INVALID_ARGUMENT;
   }
-  if (((xsize + 7) / 8) * ((ysize + 7) / 8) > (size_t(1) << 24)) {
-    // the kernels index blocks with 32 bits (2^24 blocks = 1 Gpixel per frame)
-    ctx->error = "frames above 2^24 8x8 blocks are not supported by the device path";
+  if (((xsize + 7) / 8) * ((ysize + 7) / 8) > kMaxFrameBlocks) {
+    // the kernels index blocks, and up to twelve words per block, with 32 bits: 2^28 blocks = 17 Gpixel per frame
+    // -- more than the ~30 bytes per pixel of planes, coefficients and worst-case token space leave room for in
+    // 288 GB, so what a frame below this meets first is JXLT_ERR_OUT_OF_MEMORY
+    ctx->error = "frames above 2^28 8x8 blocks are not supported by the device path";
     return JXLT_ERR_UNSUPPORTED;
   }
   if (xsize <= 8 && ysize <= 8) {
@@ -1018,7 +1024,10 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
       const char* e = getenv("JXLT_TOKEN_EXTRA_LDS");
       return e ? (unsigned)atoi(e) : 0u;
     }();
-    hipLaunchKernelGGL(token_kernel, dim3((unsigned)ng), dim3(kTokenThreads), token_extra_lds, tok_stream, K);
+    if (nblocks > kTokenNarrowBlocks)
+      hipLaunchKernelGGL(token_kernel_wide, dim3((unsigned)ng), dim3(kTokenThreads), token_extra_lds, tok_stream, K);
+    else
+      hipLaunchKernelGGL(token_kernel, dim3((unsigned)ng), dim3(kTokenThreads), token_extra_lds, tok_stream, K);
   }
   HIP_TRY(ctx, hipGetLastError());
   ctx->host_src_kind = 0;  // the frame is resident now (a redo with exact roots must not fetch it again)

@@ -65,7 +65,11 @@ constexpr int kTokenThreads = 512;
 // 64-lane pass per entry, the structure until the end of round 2, filled 18 % of its lane slots on ordinary
 // content -- 39 tokens per Y entry, 0.6 per chroma entry -- and kept the CU's one scalar unit busy with
 // per-entry bookkeeping.)  The nzeros tokens (one per entry) are written by a thread-per-block pass.
-__global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A) {
+// kWide: the frame has more than kTokenNarrowBlocks blocks -- coefficient indices (192 per block) need 64 bits
+// (+190 VALU per wave, 2.7 % of the kernel's time: frames below the bound run the 32-bit variant).
+constexpr size_t kTokenNarrowBlocks = (size_t(1) << 32) / 192;  // 22.4 M blocks = 1.43 Gpixel
+template <bool kWide>
+JXLT_DI void token_kernel_body(const TokenArgs& A) {
   // per block, two words: strategy byte | nzeros y << 8 | nscan y << 16 | nzeros x << 24, nscan x | nzeros b << 8 |
   // nscan b << 16 (the entries in stream order y, x, b; 40 KB of LDS in all: four workgroups per CU)
   __shared__ uint2 meta[1024];
@@ -112,8 +116,8 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
   const int ggx = group % A.g.xsize_groups, ggy = group / A.g.xsize_groups;
   const int bx0 = ggx * 32, by0 = ggy * 32;
   const int nbx = imin(32, A.g.xsize_blocks - bx0), nby = imin(32, A.g.ysize_blocks - by0);
-  // 32-bit block / record indices (the C ABI limits a frame to 2^24 blocks, a group's tokens to
-  // 196 608 records): addresses are scalar base + 32-bit lane offset, no 64-bit vector arithmetic
+  // 32-bit block indices and per-block word indices (the C ABI limits a frame to 2^28 blocks -- block * 12 stays
+  // below 2^32 --, a group's tokens to 196 608 records); only the coefficient index is formed in 64 bits
   const uint32_t bstride = (uint32_t)A.g.xsize_blocks;
   const uint32_t nbx_magic = 65536u / (uint32_t)nbx + 1u;  // b / nbx == (b * magic) >> 16 for b < 1024, nbx <= 32
 
@@ -252,7 +256,8 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     int k;               // scan position
     int nzeros;          // of its entry
     int st_ci;           // strategy code | channel in stream order << 8 | counts (a real token) << 16
-    uint32_t coef_at, mask_at;  // where its coefficient / its entry's nonzero masks are (element / word index)
+    uint32_t coef_at, mask_at;  // where its coefficient / its entry's nonzero masks are: element index (kWide: index
+                                // of the 64-coefficient run, block * 3 + channel, that holds scan position k) / word index
     int coef;            // requested
     uint32_t nz[4];      // requested: the entry's nonzero masks, positions covered .. 127
   };
@@ -306,11 +311,19 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     const int cby = (int)(((uint32_t)blk * nbx_magic) >> 16), cbx = blk - cby * nbx;
     const uint32_t pos = (uint32_t)(by0 + cby) * bstride + (uint32_t)(bx0 + cbx);
     const uint32_t pos1 = pos + (st == 1 ? bstride : 1u);
-    t.coef_at = t.k < 64 ? (pos * 3 + (uint32_t)c) * 64 + (uint32_t)t.k : (pos1 * 3 + (uint32_t)c) * 64 + (uint32_t)(t.k - 64);
+    if constexpr (kWide) {
+      t.coef_at = (t.k < 64 ? pos : pos1) * 3 + (uint32_t)c;
+    } else {
+      t.coef_at = t.k < 64 ? (pos * 3 + (uint32_t)c) * 64 + (uint32_t)t.k : (pos1 * 3 + (uint32_t)c) * 64 + (uint32_t)(t.k - 64);
+    }
     t.mask_at = (pos * 3 + (uint32_t)c) * 4;
   };
   auto request = [&](Located& t) {
-    t.coef = (int)A.coef_scan[t.coef_at];
+    if constexpr (kWide) {
+      t.coef = (int)A.coef_scan[((size_t)t.coef_at << 6) + (size_t)(t.k & 63)];
+    } else {
+      t.coef = (int)A.coef_scan[t.coef_at];
+    }
     const uint32_t* nzw = reinterpret_cast<const uint32_t*>(A.blk_nzmask) + t.mask_at;
 #pragma unroll
     for (int j = 0; j < 4; j++) t.nz[j] = nzw[j];
@@ -375,6 +388,9 @@ __global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A)
     }
   }
 }
+
+__global__ void __launch_bounds__(kTokenThreads) token_kernel(const TokenArgs A) { token_kernel_body<false>(A); }
+__global__ void __launch_bounds__(kTokenThreads) token_kernel_wide(const TokenArgs A) { token_kernel_body<true>(A); }
 
 }  // namespace jxlt_dev
 

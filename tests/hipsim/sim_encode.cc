@@ -80,7 +80,7 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   A.inv_scale = inv_scale;
   A.scale_dc = scale_dc;
   A.x_qm_mul = XQmMultiplier(x_qm_scale);
-  A.flags = flags;
+  A.flags = flags & ~0x4000u;  // (0x4000 selects a kernel here, it is not a kernel flag)
   A.tab = tab;
   A.raw_quant = r->raw_quant = (uint8_t*)calloc(nblocks, 1);
   A.strategy = r->strategy = (uint8_t*)calloc(nblocks, 1);
@@ -149,7 +149,10 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   for (size_t sl = 0; sl < nslabs; sl++) {
     const size_t y0 = sl * 2048, rows = std::min<size_t>(2048, ysize - y0);
     K.group_first = (int)((y0 / 256) * (size_t)g.xsize_groups);
-    hipsim::launch(token_kernel, dim3((unsigned)(((rows + 255) / 256) * (size_t)g.xsize_groups)), dim3(kTokenThreads), K);
+    const dim3 tok_grid((unsigned)(((rows + 255) / 256) * (size_t)g.xsize_groups));
+    // (0x4000: the variant with 64-bit coefficient indices, which the product launches for frames above 1.43 Gpixel)
+    if (flags & 0x4000u) hipsim::launch(token_kernel_wide, tok_grid, dim3(kTokenThreads), K);
+    else hipsim::launch(token_kernel, tok_grid, dim3(kTokenThreads), K);
   }
 
   {

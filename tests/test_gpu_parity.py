@@ -336,7 +336,10 @@ def _check_sampled_groups(planes, got, distance, dct8, picks):
     size_y, size_x = planes.shape[1], planes.shape[2]
     gpr = (size_x + 255) // 256
     for gy, gx in picks:
-        crop = np.ascontiguousarray(planes[:, gy * 256:(gy + 1) * 256, gx * 256:(gx + 1) * 256])
+        crop = planes[:, gy * 256:(gy + 1) * 256, gx * 256:(gx + 1) * 256]
+        if hasattr(crop, "cpu"):  # (a frame that stays on the device: only the crops come to the host)
+            crop = crop.cpu().numpy()
+        crop = np.ascontiguousarray(crop)
         want = T.oracle_hot_path(crop, distance, dct8)
         assert got.group_tokens[gy * gpr + gx] == want.group_tokens[0], (gy, gx)
         hb, wb = want.raw_quant.shape
@@ -432,6 +435,37 @@ def test_baseline_config4_16384_frame(built, enc):
     assert out["n_gpus"] == 2 and "16384x16384" in out["config"]["workload"]
     assert out["parity_gate"]["sharded_equals_single_gpu_codestream"] is True
     assert out["config"]["codestream_sha256"] == BENCH_FRAME_SHA16
+
+
+def test_frame_above_one_gigapixel(built, enc):
+    """The reference takes frames of up to 2^30 - 1 pixels per side (enc_file.cc:41-43); the device path indexes
+    blocks with 32 bits and coefficients with 64.  32768 x 45056 = 1.48 Gpixel = 23.1 M blocks: past the 2^24 blocks
+    that were the limit until round 3, and past the 22.4 M blocks from which a coefficient index needs more than
+    32 bits (the last five rows of groups lie beyond).  Groups over the whole frame against the oracle on the
+    matching crops; the codestream of the device-side packing equals the one the host packs from the raw tokens
+    and the one of the frame cut over two device contexts."""
+    import torch
+    import bench
+    xs, ys = 32768, 45056
+    assert (xs // 8) * (ys // 8) * 192 > 1 << 32
+    t = bench.frame_rows_on_device(torch, xs, 0, ys, 7, torch.device("cuda", 0))
+    enc.set_device_image([t[c].data_ptr() for c in range(3)], xs * 4, xs, ys, keepalive=t)
+    enc.enqueue(1.0, 0)
+    got = built.HotPathOutput(enc.fetch_raw())
+    assert got.strategy.shape == (ys // 8, xs // 8)
+    first_beyond = ((1 << 32) // 192) // (xs // 8) // 32  # row of groups in which the 32-bit index would wrap
+    rows = [0, 60, first_beyond - 1, first_beyond, first_beyond + 1, ys // 256 - 1]
+    _check_sampled_groups(t, got, 1.0, False, [(gy, gx) for gy in rows for gx in (0, 77, xs // 256 - 1)])
+    del got
+    single = enc.encode_resident(1.0)
+    assert enc.stats()["tiles"] == (xs // 64) * (ys // 64)
+    assert enc.encode_resident_raw_tokens(1.0) == single
+    me = built.MultiEncoder([0, 0])
+    for slab in range(2):
+        y0, y1 = built.shard_rows(ys, 2, slab)
+        me.set_device_slab(slab, [t[c, y0:].data_ptr() for c in range(3)], xs * 4, xs, y1 - y0, keepalive=t)
+    assert me.encode_resident(xs, ys, 1.0).tobytes() == single
+    me.close()
 
 
 def test_baseline_config5_batch_of_32_frames_over_a_device_list(built):

@@ -55,6 +55,16 @@ def test_eight_wave_variant_of_tile_kernel_matches_oracle(built, w, h, distance,
     assert T.compare_results(want, got, "oracle", "kernels", check_debug=False) == []
 
 
+@pytest.mark.parametrize("w,h,distance,hard,dct8", [CASES[0], CASES[3], CASES[7]])
+def test_wide_index_variant_of_token_kernel_matches_oracle(built, w, h, distance, hard, dct8):
+    """token_kernel_wide forms coefficient indices in 64 bits; the product launches it for frames above 2^32 / 192
+    blocks (1.43 Gpixel: `-m gpu` has one), here it runs on ordinary frames."""
+    planes = T.to_planes(T.synthetic_image(w, h, hard=hard))
+    want = T.oracle_hot_path(planes, distance, dct8)
+    got = T.sim_hot_path(planes, distance, dct8, wide_token_index=True)
+    assert T.compare_results(want, got, "oracle", "kernels") == []
+
+
 def test_token_kernel_histogram_matches_tokens(built):
     planes = T.to_planes(T.synthetic_image(300, 264))
     got = T.sim_hot_path(planes, 1.0)
