@@ -3,6 +3,8 @@
 // output contract and are kept identical (citations inline).
 #include "entropy_coder.h"
 
+#include <immintrin.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -126,11 +128,39 @@ void ConvertBitDepthsToSymbols(const uint8_t* depth, size_t len, uint16_t* bits)
 // ---------------------------------------------------------------------------
 namespace {
 
+// Ascending sort of n <= 64 distinct keys.  With AVX-512 by ranks: a key's place is the number of keys below it --
+// n * n / 8 vector comparisons without a branch; std::sort spends ~30 cycles per key on mispredicted comparisons
+// at these sizes.
+__attribute__((target("avx512f,avx512vl"))) void SortKeysByRank(uint64_t* keys, size_t n) {
+  // (256-bit vectors: the 512-bit ones make some hosts lower their clock for a code path this short)
+  alignas(64) uint64_t in[kAlphabetSize];
+  const size_t vectors = (n + 3) >> 2;
+  for (size_t i = 0; i < n; ++i) in[i] = keys[i];
+  for (size_t i = n; i < 4 * vectors; ++i) in[i] = ~uint64_t(0);
+  for (size_t i = 0; i < n; ++i) {
+    const __m256i key = _mm256_set1_epi64x(static_cast<long long>(in[i]));
+    unsigned below = 0;
+    for (size_t j = 0; j < vectors; ++j) {
+      const __m256i v = _mm256_load_si256(reinterpret_cast<const __m256i*>(in + 4 * j));
+      below += static_cast<unsigned>(__builtin_popcount(_mm256_cmplt_epu64_mask(v, key)));
+    }
+    keys[below] = in[i];
+  }
+}
+void SortKeys(uint64_t* keys, size_t n) {
+  static const bool by_rank = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl");
+  if (by_rank) {
+    SortKeysByRank(keys, n);
+  } else {
+    std::sort(keys, keys + n);
+  }
+}
+
 // sum of counts[i] * depth[i] over the code CreateHuffmanTree(counts, kAlphabetSize, 15) would build, without
 // building the depths when the first tree is not deeper than 15 (then the sum is the sum of the inner nodes'
 // weights): the clustering evaluates about a thousand such costs per frame and needs nothing else of them.
 size_t HuffmanBitCost(const uint32_t* counts) {
-  uint64_t keys[kAlphabetSize];
+  alignas(64) uint64_t keys[kAlphabetSize];
   size_t n = 0;
   for (size_t i = kAlphabetSize; i != 0;) {  // the gathering order and the keys of CreateHuffmanTree, count_limit 1
     --i;
@@ -141,7 +171,7 @@ size_t HuffmanBitCost(const uint32_t* counts) {
   }
   if (n == 0) return 0;
   if (n == 1) return counts[keys[0] & 0xFF];  // ("fake" depth 1)
-  std::sort(keys, keys + n);
+  SortKeys(keys, n);
   // two-queue merge (ties prefer the leaf queue); node weights wrap at 32 bits as the tree's do, the sums
   // that make up the cost do not
   uint32_t weight[2 * kAlphabetSize + 2];
@@ -168,12 +198,64 @@ size_t HuffmanBitCost(const uint32_t* counts) {
     weight[size++] = kSentinel;
   }
   if (height[2 * n - 1] <= 15) return cost;
-  // deeper than the limit: the general construction (minimum count doubled until the tree fits)
-  uint8_t depths[kAlphabetSize] = {};
-  CreateHuffmanTree(counts, kAlphabetSize, 15, depths);
-  cost = 0;
-  for (size_t i = 0; i < kAlphabetSize; ++i) cost += static_cast<size_t>(counts[i]) * depths[i];
-  return cost;
+  // Deeper than the limit (four in ten of the clustering's evaluations on ordinary DC histograms): the later
+  // rounds of CreateHuffmanTree -- every count below count_limit - 1 raised to it, count_limit doubled until the
+  // tree fits -- without their sorts.  A round's leaf order follows from the first round's: the raised leaves
+  // (equal counts) in gathering order, i.e. the set bits of a mask of gathering positions, then the others as they
+  // are.  A round is given up at the first node that is too high (the root can only be higher), and only the
+  // round that fits walks its tree.  (The general function here cost 5-9 k cycles per call, three quarters of
+  // the clustering's time.)
+  uint8_t symbol_at[kAlphabetSize];  // gathering position -> symbol
+  for (size_t k = 0; k < n; ++k) symbol_at[(keys[k] >> 8) & 0xFF] = static_cast<uint8_t>(keys[k] & 0xFF);
+  uint8_t leaf_symbol[kAlphabetSize];
+  uint8_t left[2 * kAlphabetSize + 2], right[2 * kAlphabetSize + 2];
+  size_t raised = 0;        // keys[0 .. raised) have counts <= count_limit - 1
+  uint64_t raised_at = 0;   // their gathering positions
+  for (uint32_t count_limit = 2;; count_limit *= 2) {
+    const uint32_t floor = count_limit - 1;
+    while (raised < n && (keys[raised] >> 16) <= floor) {
+      raised_at |= uint64_t(1) << ((keys[raised] >> 8) & 0xFF);
+      ++raised;
+    }
+    size_t k = 0;
+    for (uint64_t m = raised_at; m != 0; m &= m - 1, ++k) {
+      weight[k] = floor;
+      leaf_symbol[k] = symbol_at[__builtin_ctzll(m)];
+    }
+    for (size_t q = raised; q < n; ++q, ++k) {
+      weight[k] = static_cast<uint32_t>(keys[q] >> 16);
+      leaf_symbol[k] = static_cast<uint8_t>(keys[q] & 0xFF);
+    }
+    weight[n] = kSentinel;
+    weight[n + 1] = kSentinel;
+    size = n + 2, leaf = 0, inner = n + 1;
+    bool fits = true;
+    for (size_t j = n - 1; j != 0; --j) {
+      size_t l, r;
+      if (weight[leaf] <= weight[inner]) l = leaf++; else l = inner++;
+      if (weight[leaf] <= weight[inner]) r = leaf++; else r = inner++;
+      const size_t parent = size - 1;
+      weight[parent] = weight[l] + weight[r];
+      left[parent] = static_cast<uint8_t>(l);
+      right[parent] = static_cast<uint8_t>(r);
+      height[parent] = static_cast<uint8_t>(std::max(height[l], height[r]) + 1);
+      if (height[parent] > 15) {
+        fits = false;
+        break;
+      }
+      weight[size++] = kSentinel;
+    }
+    if (!fits) continue;
+    // depths from the root down (children have smaller indices than their parent), as AssignDepths finds them
+    uint8_t level[2 * kAlphabetSize + 2];
+    level[2 * n - 1] = 0;
+    for (size_t node = 2 * n - 1; node > n; --node) {
+      level[left[node]] = level[right[node]] = static_cast<uint8_t>(level[node] + 1);
+    }
+    cost = 0;
+    for (size_t q = 0; q < n; ++q) cost += static_cast<size_t>(counts[leaf_symbol[q]]) * level[q];
+    return cost;
+  }
 }
 
 void ComputeBitCost(Histogram* h) {  // enc_cluster.cc:18-26
@@ -383,14 +465,16 @@ void ClusterHistograms(std::vector<Histogram>* histograms, std::vector<uint8_t>*
   // The independent cost evaluations of each step run on the helper pool when it is free;
   // selections and ties are then resolved serially in the reference's order.
   ClusterPool& pool = ClusterPool::Get();
-  // Whether sharing pays depends on the histograms: a Huffman cost over a dozen symbols takes a third of a
+  // Whether sharing pays depends on the histograms: a Huffman cost over a dozen symbols takes a fifth of a
   // microsecond where the histogram is cached, and several times that on a core that has to fetch it first, so
-  // few, small evaluations are done faster alone.  (16384^2 bench frame, EPYC 9575F, 7 helpers -- AC: 64 histograms
-  // with 379 non-zero counts: shared 0.16-0.19 ms, alone 0.09; DC: 45 histograms, 830 counts: 0.30 against 0.55 ms;
-  // DC at distance 4, 468 counts: 0.24 against 0.38; AC at distance 0.5, 607 counts: about equal.)  A fixed rule
-  // separates these cases -- shared from 450 non-zero counts on -- and makes the latency of a code construction a
-  // function of its input alone (until round 3 the choice was learnt per calling thread, with an exploratory call
-  // every 32nd time: the results never depended on it, the latency did).
+  // few, small evaluations are done faster alone.  (16384^2 bench frame, EPYC 9575F, 7 helpers, inside complete
+  // encodes, tools/code_probe.sh -- AC, 64 histograms with 379 non-zero counts: shared 0.18-0.19 ms, alone 0.09;
+  // AC at distance 0.5, 607 counts: 0.25 against 0.23; DC, 45 histograms, 830 counts: 0.31 against 0.33; DC at
+  // distance 0.5, 1029 counts: 0.29 against 0.40.  Until the depth-limited costs lost their sorts -- HuffmanBitCost
+  // -- alone was twice as slow and the line lay at 450 counts.)  A fixed rule separates these cases -- shared from
+  // 900 non-zero counts on -- and makes the latency of a code construction a function of its input alone (until
+  // round 3 the choice was learnt per calling thread, with an exploratory call every 32nd time: the results never
+  // depended on it, the latency did).
   size_t nonzero = 0;
   for (const Histogram& h : in)
     for (size_t i = 0; i < kAlphabetSize; ++i) nonzero += h.counts[i] != 0;
@@ -398,7 +482,7 @@ void ClusterHistograms(std::vector<Histogram>* histograms, std::vector<uint8_t>*
     const char* e = getenv("JXLT_POOL_MODE");  // (experiment knob, tools/code_probe.sh: 0 = never, 1 = always)
     return e ? atoi(e) : -1;
   }();
-  const int mode = forced >= 0 ? (forced != 0) : (nonzero >= 450 ? 1 : 0);
+  const int mode = forced >= 0 ? (forced != 0) : (nonzero >= 900 ? 1 : 0);
   static const bool trace = getenv("JXLT_TRACE") != nullptr;
   if (trace)
     fprintf(stderr, "jxlt trace: clustering %zu histograms, %zu non-zero counts, %s\n", in.size(), nonzero,
