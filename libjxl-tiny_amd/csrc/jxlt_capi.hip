@@ -144,6 +144,8 @@ struct jxlt_context {
   // jxlt_pack_write: packing on `stream`, chunked copies to the destination on `copy_stream`
   hipStream_t copy_stream = nullptr;
   hipEvent_t dc_hist_ready = nullptr;  // DC histogram of the last enqueue is in h_hist
+  bool dc_elementwise_split = false;
+  hipEvent_t dc_elementwise_done = nullptr;  // (resident frames: dc_elementwise_kernel runs beside the two chain kernels)
   hipEvent_t dc_kernels_done = nullptr;  // (the small downloads wait for their kernels on the copy stream, not in front of the next kernel)
   hipEvent_t ac_hist_ready = nullptr;  // AC histogram + total token count of the last enqueue are in their mirrors
   // Root-table overflow of tile_kernel (a quantised magnitude >= kSqrtLutSize): the tiles concerned are redone by
@@ -270,6 +272,7 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->dc_hist_ready, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->dc_kernels_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->dc_elementwise_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ac_hist_ready, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->overflow_ready, hipEventDisableTiming);
   for (auto& ps : ctx->pack) {
@@ -359,6 +362,7 @@ void jxlt_context_destroy(jxlt_context* ctx) {
   }
   if (ctx->dc_hist_ready) (void)hipEventDestroy(ctx->dc_hist_ready);
   if (ctx->dc_kernels_done) (void)hipEventDestroy(ctx->dc_kernels_done);
+  if (ctx->dc_elementwise_done) (void)hipEventDestroy(ctx->dc_elementwise_done);
   if (ctx->ac_hist_ready) (void)hipEventDestroy(ctx->ac_hist_ready);
   if (ctx->overflow_ready) (void)hipEventDestroy(ctx->overflow_ready);
   FreeDevice(&ctx->lut_overflow);
@@ -998,7 +1002,21 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
     dc_rows_done = dc_row1;
     const size_t slab_dc = (dc_row1 - dc_row0) * xdc;  // DC groups of this launch
     D.dcg_first = (int)(dc_row0 * xdc);
-    hipLaunchKernelGGL(dc_elementwise_kernel, dim3((unsigned)(slab_dc * kDcParts)), dim3(256), 0, tok_stream, D);
+    // (a resident frame: the element-wise kernel and the two chain kernels do not depend on each other and none of
+    // them fills the chip -- side by side on two streams; experiment knob JXLT_DC_SPLIT=0: one after the other)
+    static const bool dc_split = [] {
+      const char* e = getenv("JXLT_DC_SPLIT");
+      return !e || atoi(e) != 0;
+    }();
+    const bool split = dc_split && nslabs == 1;
+    ctx->dc_elementwise_split = split;
+    const hipStream_t elem_stream = split ? ctx->aux_stream : tok_stream;
+    if (split) HIP_TRY(ctx, hipStreamWaitEvent(elem_stream, ctx->tile_done[sl], 0));
+    hipLaunchKernelGGL(dc_elementwise_kernel, dim3((unsigned)(slab_dc * kDcParts)), dim3(256), 0, elem_stream, D);
+    if (split) {
+      HIP_TRY(ctx, hipEventRecord(ctx->dc_elementwise_done, elem_stream));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->dc_elementwise_done, 0));  // (the histogram's download)
+    }
     hipLaunchKernelGGL(dc_chain_summary_kernel, dim3((unsigned)(slab_dc * kDcChainChunks)), dim3(kDcChainThreads), 0,
                        tok_stream, D);
     hipLaunchKernelGGL(dc_chain_kernel, dim3((unsigned)(slab_dc * kDcChainChunks)), dim3(kDcChainThreads), 0,
@@ -1040,6 +1058,8 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   HIP_TRY(ctx, hipEventRecord(ctx->aux_done, tok_stream));
   // whatever is queued on the main stream from here on (section packing) comes after the tokenisation
   if (tok_stream != ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_done, 0));
+  // (the DC-group sections' packing reads what dc_elementwise_kernel wrote)
+  if (nslabs == 1 && ctx->dc_elementwise_split) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->dc_elementwise_done, 0));
   ctx->geom = g;
   // The tile plan of the AC sections needs the groups' token offsets only: it runs now, behind the histogram's
   // way to the host, while the host builds the codes (upper bound of the record count: the buffer's capacity).
