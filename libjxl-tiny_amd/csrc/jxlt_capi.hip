@@ -104,12 +104,17 @@ struct jxlt_context {
   size_t dc_rec_off_n = 0;
   // section packing, [0] = DC groups, [1] = AC groups
   struct PackSet {
-    DeviceBuf<uint32_t> code_table, sec_bits, sec_bytes, sec_tiles, tile_bits;
+    DeviceBuf<uint32_t> code_table, sec_bytes, sec_tiles, tile_bits;
+    // sec_byte_off: [nsec + 1] byte offsets of the sections, and right behind them [nsec] 32-bit bit counts -- what
+    // the host needs of a measuring pass, in one piece (one download)
     DeviceBuf<uint64_t> sec_byte_off, tile_base;
     DeviceBuf<PackTileInfo> tile_info;
     DeviceBuf<uint8_t> packed;  // the sections at their final byte offsets
-    PinnedBuf<uint64_t> h_sec_byte_off, h_tile_base;
-    PinnedBuf<uint32_t> h_sec_bits;
+    PinnedBuf<uint64_t> h_sec_byte_off, h_tile_base;  // (h_sec_byte_off: the same layout as sec_byte_off)
+    static size_t SizesWords(size_t nsec) { return nsec + 1 + (nsec + 1) / 2; }
+    uint32_t* sec_bits(size_t nsec) const { return reinterpret_cast<uint32_t*>(sec_byte_off.p + nsec + 1); }
+    uint32_t* h_sec_bits(size_t nsec) const { return reinterpret_cast<uint32_t*>(h_sec_byte_off.p + nsec + 1); }
+    hipEvent_t tile_base_fetched = nullptr;  // h_tile_base holds the plan's tile_base
     PinnedBuf<uint8_t> h_packed;
     PinnedBuf<uint32_t> h_code_table;  // staging of the caller's table (asynchronous upload needs page-locked memory)
     size_t measured_sections = 0;  // sections of the last measuring pass (0: none for this frame)
@@ -279,6 +284,7 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ps.measured, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ps.finalized, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ps.plan_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ps.tile_base_fetched, hipEventDisableTiming);
     for (auto& ev : ps.launch_done)
       if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   }
@@ -326,7 +332,6 @@ void jxlt_context_destroy(jxlt_context* ctx) {
   FreePinned(&ctx->h_hist);
   for (auto& ps : ctx->pack) {
     FreeDevice(&ps.code_table);
-    FreeDevice(&ps.sec_bits);
     FreeDevice(&ps.sec_bytes);
     FreeDevice(&ps.sec_byte_off);
     FreeDevice(&ps.sec_tiles);
@@ -336,7 +341,6 @@ void jxlt_context_destroy(jxlt_context* ctx) {
     FreeDevice(&ps.packed);
     FreePinned(&ps.h_tile_base);
     FreePinned(&ps.h_sec_byte_off);
-    FreePinned(&ps.h_sec_bits);
     FreePinned(&ps.h_packed);
     FreePinned(&ps.h_code_table);
   }
@@ -357,6 +361,7 @@ void jxlt_context_destroy(jxlt_context* ctx) {
     if (ps.measured) (void)hipEventDestroy(ps.measured);
     if (ps.finalized) (void)hipEventDestroy(ps.finalized);
     if (ps.plan_done) (void)hipEventDestroy(ps.plan_done);
+    if (ps.tile_base_fetched) (void)hipEventDestroy(ps.tile_base_fetched);
     for (auto& ev : ps.launch_done)
       if (ev) (void)hipEventDestroy(ev);
   }
@@ -1279,7 +1284,7 @@ PackTileArgs TileArgsOf(jxlt_context* ctx, int kind, size_t nsec) {
   P.tile_base = ps.tile_base.p;
   P.tile_bits = ps.tile_bits.p;
   P.tile_info = ps.tile_info.p;
-  P.sec_bits = ps.sec_bits.p;
+  P.sec_bits = ps.sec_bits(nsec);
   P.sec_bytes = ps.sec_bytes.p;
   P.sec_byte_offset = ps.sec_byte_off.p;
   P.out = ps.packed.p;
@@ -1304,9 +1309,8 @@ int EnqueuePlan(jxlt_context* ctx, int kind, uint64_t rec_bound, hipStream_t str
   int rc;
 #define ENSURE(buf, n) if ((rc = EnsureDevice(ctx, &ps.buf, (n))) != JXLT_OK) return rc
   ENSURE(code_table, 64 * 64);
-  ENSURE(sec_bits, nsec);
   ENSURE(sec_bytes, nsec);
-  ENSURE(sec_byte_off, nsec + 1);
+  ENSURE(sec_byte_off, jxlt_context::PackSet::SizesWords(nsec));
   ENSURE(sec_tiles, nsec);
   ENSURE(tile_base, nsec + 1);
   ENSURE(tile_bits, max_tiles);
@@ -1319,6 +1323,12 @@ int EnqueuePlan(jxlt_context* ctx, int kind, uint64_t rec_bound, hipStream_t str
                      ps.tile_base.p, (int)nsec);
   hipLaunchKernelGGL(pack_tile_plan_kernel, dim3(sec_blocks), dim3(256), 0, stream, P);
   HIP_TRY(ctx, hipGetLastError());
+  // (which sections a launch of the writing pass completes -- EnqueueCopies -- follows from the plan alone: the
+  // host has it long before the sizes)
+  if ((rc = EnsurePinned(ctx, &ps.h_tile_base, nsec + 1)) != JXLT_OK) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ps.h_tile_base.p, ps.tile_base.p, (nsec + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                              stream));
+  HIP_TRY(ctx, hipEventRecord(ps.tile_base_fetched, stream));
   ps.planned = true;
   ps.plan_elsewhere = stream != ctx->stream;
   if (ps.plan_elsewhere) HIP_TRY(ctx, hipEventRecord(ps.plan_done, stream));
@@ -1336,9 +1346,7 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
   int rc;
   if (!ps.planned && (rc = EnqueuePlan(ctx, kind, rec_bound, ctx->stream)) != JXLT_OK) return rc;
   if (ps.plan_elsewhere) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ps.plan_done, 0));
-  if ((rc = EnsurePinned(ctx, &ps.h_sec_byte_off, nsec + 1)) != JXLT_OK) return rc;
-  if ((rc = EnsurePinned(ctx, &ps.h_sec_bits, nsec)) != JXLT_OK) return rc;
-  if ((rc = EnsurePinned(ctx, &ps.h_tile_base, nsec + 1)) != JXLT_OK) return rc;
+  if ((rc = EnsurePinned(ctx, &ps.h_sec_byte_off, jxlt_context::PackSet::SizesWords(nsec))) != JXLT_OK) return rc;
   // The caller's table is pageable as a rule: an asynchronous copy from it would make this call wait for
   // everything queued on the stream (token_kernel!).  Staged through the context's page-locked copy instead;
   // its previous use (last frame's upload) finished before that frame's sizes were returned.
@@ -1360,19 +1368,19 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
                      dim3(64 * kPackOffsetsSectionsPerGroup), 0, ctx->stream, P);
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, (const uint32_t*)ps.sec_bytes.p,
                      ps.sec_byte_off.p, (int)nsec);
-  hipLaunchKernelGGL(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), 0, ctx->stream, P);
-  HIP_TRY(ctx, hipGetLastError());
-  // The three small downloads go by the auxiliary stream (idle by now): on the main stream they would stand
-  // between the measuring kernels and the writing kernels queued below.
+  // The sizes are final behind the scan (the last kernel of the pass only moves the tiles to their places): ONE
+  // download -- offsets and bit counts lie behind each other -- by the auxiliary stream (idle by now), beside that
+  // kernel; on the main stream it would stand between the measuring kernels and the writing kernels queued below.
+  // (Until round 3: three downloads behind the last kernel; the host had the sizes 25 us later, and the link waited
+  // for the first copy that long.)
   HIP_TRY(ctx, hipEventRecord(ps.finalized, ctx->stream));
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ps.finalized, 0));
-  HIP_TRY(ctx, hipMemcpyAsync(ps.h_sec_byte_off.p, ps.sec_byte_off.p, (nsec + 1) * sizeof(uint64_t),
-                              hipMemcpyDeviceToHost, ctx->aux_stream));
-  HIP_TRY(ctx, hipMemcpyAsync(ps.h_sec_bits.p, ps.sec_bits.p, nsec * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                              ctx->aux_stream));
-  HIP_TRY(ctx, hipMemcpyAsync(ps.h_tile_base.p, ps.tile_base.p, (nsec + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost,
+  HIP_TRY(ctx, hipMemcpyAsync(ps.h_sec_byte_off.p, ps.sec_byte_off.p,
+                              jxlt_context::PackSet::SizesWords(nsec) * sizeof(uint64_t), hipMemcpyDeviceToHost,
                               ctx->aux_stream));
   HIP_TRY(ctx, hipEventRecord(ps.measured, ctx->aux_stream));
+  hipLaunchKernelGGL(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), 0, ctx->stream, P);
+  HIP_TRY(ctx, hipGetLastError());
   ps.measured_sections = nsec;
   // The writing pass needs nothing from the host (tile positions are in device memory), so it is
   // queued right here, in a few launches over shares of the tile range (an upper bound: the
@@ -1417,7 +1425,7 @@ void FillMeasured(jxlt_context* ctx, int kind, jxlt_packed_sections* out) {
   jxlt_context::PackSet& ps = ctx->pack[kind];
   out->bytes = nullptr;
   out->section_offset = ps.h_sec_byte_off.p;
-  out->section_bits = ps.h_sec_bits.p;
+  out->section_bits = ps.h_sec_bits(ps.measured_sections);
   out->num_sections = ps.measured_sections;
 }
 
@@ -1428,6 +1436,7 @@ int EnqueueCopies(jxlt_context* ctx, int kind, uint8_t* dst) {
   jxlt_context::PackSet& ps = ctx->pack[kind];
   const size_t nsec = ps.measured_sections;
   HIP_TRY(ctx, hipEventSynchronize(ps.measured));
+  HIP_TRY(ctx, hipEventSynchronize(ps.tile_base_fetched));
   const uint64_t* off = ps.h_sec_byte_off.p;
   const uint64_t* tb = ps.h_tile_base.p;
   size_t s_lo = 0;
