@@ -219,6 +219,15 @@ int jxlt_pack_measure_begin(jxlt_context* ctx, int kind, const uint32_t* code_ta
  * (enc_frame.cc:805-816: DC global, DC groups, AC global, AC groups), and they are a good part of the bytes.
  * jxlt_output_buffer keeps the buffer's contents when a later call makes it grow. */
 int jxlt_pack_measured(jxlt_context* ctx, int kind, jxlt_packed_sections* out);
+/* jxlt_pack_measure_begin in two halves: the measuring pass alone, and the writing launches behind it.  For a
+ * caller that has the AC code before the DC code (small frames: the DC code is not ready when the AC histogram
+ * arrives): measure the AC sections, pack the DC-group sections -- their total size positions the AC sections --,
+ * then write the AC sections.  jxlt_pack_sections_place / jxlt_pack_write queue missing writing launches themselves. */
+int jxlt_pack_measure_only(jxlt_context* ctx, int kind, const uint32_t* code_table);
+int jxlt_pack_write_begin(jxlt_context* ctx, int kind);
+/* 1 when jxlt_fetch_histograms would return without waiting (the AC histogram of the last jxlt_encode_enqueue has
+ * arrived), 0 when not yet, < 0 on error. */
+int jxlt_histograms_ready(jxlt_context* ctx);
 int jxlt_pack_write(jxlt_context* ctx, uint8_t* dc_dst, uint8_t* ac_dst);
 
 /* Timing of the device stages of the last jxlt_encode_enqueue (HIP events on the context's

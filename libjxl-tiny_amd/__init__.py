@@ -34,7 +34,7 @@ HIP_SYMBOLS = ["jxlt_context_create", "jxlt_context_destroy", "jxlt_last_error",
                "jxlt_image_upload", "jxlt_image_set_device", "jxlt_image_upload_pfm", "jxlt_image_set_device_pfm", "jxlt_image_attach_host", "jxlt_image_attach_host_pfm", "jxlt_image_size", "jxlt_pinned_alloc",
                "jxlt_pinned_free", "jxlt_pinned_register", "jxlt_pinned_unregister", "jxlt_encode_enqueue", "jxlt_set_strategy_distance",
                "jxlt_fetch_side_info", "jxlt_fetch_histograms", "jxlt_fetch_dc_histogram", "jxlt_pack_ac_sections", "jxlt_pack_sections",
-               "jxlt_pack_sections_sizes", "jxlt_pack_sections_copy", "jxlt_pack_sections_place", "jxlt_pack_measure", "jxlt_pack_measure_begin", "jxlt_pack_measured", "jxlt_pack_write",
+               "jxlt_pack_sections_sizes", "jxlt_pack_sections_copy", "jxlt_pack_sections_place", "jxlt_pack_measure", "jxlt_pack_measure_begin", "jxlt_pack_measure_only", "jxlt_pack_write_begin", "jxlt_histograms_ready", "jxlt_pack_measured", "jxlt_pack_write",
                "jxlt_output_buffer",
                "jxlt_synchronize", "jxlt_fetch_result", "jxlt_kernel_times", "jxlt_encode_stats"]
 HIP_SYMBOLS_TESTING = ["jxlt_debug_fetch"]

@@ -115,6 +115,8 @@ struct jxlt_context {
     uint32_t* sec_bits(size_t nsec) const { return reinterpret_cast<uint32_t*>(sec_byte_off.p + nsec + 1); }
     uint32_t* h_sec_bits(size_t nsec) const { return reinterpret_cast<uint32_t*>(h_sec_byte_off.p + nsec + 1); }
     hipEvent_t tile_base_fetched = nullptr;  // h_tile_base holds the plan's tile_base
+    size_t max_tiles = 0;        // of the measuring pass (bounds the writing launches)
+    bool writes_queued = false;  // the writing launches of the last measuring pass are queued
     PinnedBuf<uint8_t> h_packed;
     PinnedBuf<uint32_t> h_code_table;  // staging of the caller's table (asynchronous upload needs page-locked memory)
     size_t measured_sections = 0;  // sections of the last measuring pass (0: none for this frame)
@@ -1337,7 +1339,9 @@ int EnqueuePlan(jxlt_context* ctx, int kind, uint64_t rec_bound, hipStream_t str
 
 // Measuring pass for the sections of `kind` (asynchronous): exact bit / byte size of every
 // section, byte offsets, tile bookkeeping; results are copied to the pinned mirrors.
-int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
+int EnqueueWrites(jxlt_context* ctx, int kind);  // (below)
+// queue_writes = false: the writing launches are left to a later EnqueueWrites (jxlt_pack_write_begin).
+int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table, bool queue_writes = true) {
   jxlt_context::PackSet& ps = ctx->pack[kind];
   const size_t nsec = NumSections(ctx, kind);
   // upper bound of the record count (the exact per-section counts live on the device)
@@ -1382,6 +1386,18 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
   hipLaunchKernelGGL(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), 0, ctx->stream, P);
   HIP_TRY(ctx, hipGetLastError());
   ps.measured_sections = nsec;
+  ps.max_tiles = max_tiles;
+  ps.writes_queued = false;
+  return queue_writes ? EnqueueWrites(ctx, kind) : JXLT_OK;
+}
+
+// The writing pass of the sections of `kind` behind their measuring pass (asynchronous).
+int EnqueueWrites(jxlt_context* ctx, int kind) {
+  jxlt_context::PackSet& ps = ctx->pack[kind];
+  if (ps.writes_queued) return JXLT_OK;
+  ps.writes_queued = true;
+  const size_t nsec = ps.measured_sections;
+  const size_t max_tiles = ps.max_tiles;
   // The writing pass needs nothing from the host (tile positions are in device memory), so it is
   // queued right here, in a few launches over shares of the tile range (an upper bound: the
   // kernel clamps to the real tile count); the host picks the section sizes up meanwhile and
@@ -1435,6 +1451,10 @@ void FillMeasured(jxlt_context* ctx, int kind, jxlt_packed_sections* out) {
 int EnqueueCopies(jxlt_context* ctx, int kind, uint8_t* dst) {
   jxlt_context::PackSet& ps = ctx->pack[kind];
   const size_t nsec = ps.measured_sections;
+  if (!ps.writes_queued) {
+    const int rcw = EnqueueWrites(ctx, kind);
+    if (rcw != JXLT_OK) return rcw;
+  }
   HIP_TRY(ctx, hipEventSynchronize(ps.measured));
   HIP_TRY(ctx, hipEventSynchronize(ps.tile_base_fetched));
   const uint64_t* off = ps.h_sec_byte_off.p;
@@ -1519,6 +1539,44 @@ int jxlt_pack_measure_begin(jxlt_context* ctx, int kind, const uint32_t* code_ta
     if (rc0 != JXLT_OK) return rc0;
   }
   return EnqueueMeasure(ctx, kind, code_table);
+}
+
+int jxlt_pack_measure_only(jxlt_context* ctx, int kind, const uint32_t* code_table) {
+  if (!ctx || !code_table || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
+  if (!ctx->encoded || (kind == 1 && !ctx->offsets_fetched)) {
+    ctx->error = "jxlt_pack_measure_only needs jxlt_encode_enqueue (+ jxlt_fetch_histograms for the AC sections) first";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    const int rc0 = ResolveRootTableOverflow(ctx);
+    if (rc0 != JXLT_OK) return rc0;
+  }
+  return EnqueueMeasure(ctx, kind, code_table, /*queue_writes=*/false);
+}
+
+int jxlt_pack_write_begin(jxlt_context* ctx, int kind) {
+  if (!ctx || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
+  if (ctx->pack[kind].measured_sections == 0) {
+    ctx->error = "jxlt_pack_write_begin needs jxlt_pack_measure_only first";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return EnqueueWrites(ctx, kind);
+}
+
+int jxlt_histograms_ready(jxlt_context* ctx) {
+  if (!ctx) return JXLT_ERR_INVALID_ARGUMENT;
+  if (!ctx->encoded) {
+    ctx->error = "jxlt_histograms_ready needs jxlt_encode_enqueue first";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const hipError_t e = hipEventQuery(ctx->ac_hist_ready);
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) return 0;
+  HIP_TRY(ctx, e);
+  return 0;
 }
 
 int jxlt_pack_measure(jxlt_context* ctx, const uint32_t* dc_code_table, const uint32_t* ac_code_table,
