@@ -196,9 +196,11 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   // (a code construction that worked alone last time is not announced to the helper threads)
   static thread_local bool dc_shared = true, ac_shared = true;
   static thread_local size_t last_frame_bytes = 0;  // (sizes the output buffer before the AC sections are measured)
+  static thread_local size_t last_dc_bytes = 0;     // (of the DC-group sections; 0: not known for this frame size)
   if (expected_for_pixels != xsize * ysize) {
     expected_for_pixels = xsize * ysize;
     expected_dc_ms = expected_ac_ms = 0.0;
+    last_dc_bytes = 0;
   }
   EntropyCode ac_code, dc_code;
   std::vector<uint32_t> ac_table(64 * 64), dc_table(64 * 64);
@@ -273,7 +275,18 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   ac_shared = TakeClusteringShared();
   FillCodeTable(ac_code, ac_table.data());
   const auto t2 = now();
-  if (ac_first) {
+  // AC code first, codestream assembled in the context's buffer, and the size of the DC-group sections known from
+  // the last frame of this size: the AC sections do not wait for the DC code at all -- they are placed where that
+  // size (and a quarter) leaves room in front of them, and head, DC-group sections and ACGlobal are set against them
+  // from the right when they exist (below).
+  static const bool allow_decoupled = getenv("JXLT_NO_DECOUPLE") == nullptr;  // (experiment knob)
+  const bool decoupled = allow_decoupled && ac_first && in_context != nullptr && last_dc_bytes != 0;
+  if (decoupled) {
+    if (jxlt_pack_measure_begin(ctx, 1, ac_table.data()) != JXLT_OK) {
+      fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
+      return false;
+    }
+  } else if (ac_first) {
     // AC sections measured, DC-group sections packed, AC sections written -- in this order on the device
     if (jxlt_pack_measure_only(ctx, 1, ac_table.data()) != JXLT_OK) {
       fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
@@ -289,7 +302,7 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   // (context buffer: the position of the sections is fixed before the head exists -- the head is bounded from
   // above and right-aligned in front of them; the DC code, and with it globals.dc_global, is complete here in
   // either order)
-  const size_t dc_at = (pre + HeadSizeBound(xsize, ysize, globals) + 255) & ~static_cast<size_t>(255);
+  size_t dc_at = decoupled ? 0 : (pre + HeadSizeBound(xsize, ysize, globals) + 255) & ~static_cast<size_t>(255);
   if (trace)
     fprintf(stderr, "jxlt trace: dc histogram after %.2f ms, %s first | ac histogram after %.2f ms, ac code %.3f ms\n",
             ms(t0, t0a), ac_first ? "AC code" : "DC code", ms(t0, t1), ms(t1, t2));
@@ -298,7 +311,51 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   // assembled, while the host builds header and TOC.
   jxlt_packed_sections dcm, acm;
   bool dc_placed = false;
-  if (in_context) {
+  size_t decoupled_ac_at = 0;
+  if (decoupled) {
+    globals.ac_global = BuildAcGlobal(xsize, ysize, ac_code);
+    if (jxlt_pack_measured(ctx, 1, &acm) != JXLT_OK) {
+      fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
+      return false;
+    }
+    const size_t ac_size = static_cast<size_t>(acm.section_offset[acm.num_sections]);
+    const size_t acg = globals.ac_global.size();
+    const auto align = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+    // frame header + TOC (HeadSizeBound without its DCGlobal) + 16 KB for DCGlobal + the DC-group sections + ACGlobal
+    size_t ac_at = align(pre + 64 + 4 * (2 + num_dc_groups + num_groups) + 16384 + last_dc_bytes + last_dc_bytes / 4 +
+                         65536 + acg);
+    uint8_t* buf = nullptr;
+    if (jxlt_output_buffer(ctx, std::max(ac_at + ac_size + 16, last_frame_bytes), &buf) != JXLT_OK ||
+        jxlt_pack_sections_place(ctx, 1, buf + ac_at) != JXLT_OK) {
+      fprintf(stderr, "jxl_tiny_amd: section placement failed: %s\n", jxlt_last_error(ctx));
+      return false;
+    }
+    worker->Wait();
+    dc_shared = dc_shared_now;
+    if (jxlt_pack_measure_begin(ctx, 0, dc_table.data()) != JXLT_OK || jxlt_pack_measured(ctx, 0, &dcm) != JXLT_OK) {
+      fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
+      return false;
+    }
+    const size_t dc_size = static_cast<size_t>(dcm.section_offset[dcm.num_sections]);
+    const size_t need = pre + HeadSizeBound(xsize, ysize, globals) + dc_size + acg;
+    if (need > ac_at) {
+      // (the DC-group sections grew by more than a quarter against the last frame: the AC sections once more,
+      // further to the right -- their blob is still on the device)
+      ac_at = align(need + 4096);
+      if (jxlt_output_buffer(ctx, ac_at + ac_size + 16, &buf) != JXLT_OK ||
+          jxlt_pack_sections_place(ctx, 1, buf + ac_at) != JXLT_OK) {
+        fprintf(stderr, "jxl_tiny_amd: section placement failed: %s\n", jxlt_last_error(ctx));
+        return false;
+      }
+    }
+    dc_at = ac_at - acg - dc_size;
+    if (jxlt_pack_sections_place(ctx, 0, buf + dc_at) != JXLT_OK) {
+      fprintf(stderr, "jxl_tiny_amd: section placement failed: %s\n", jxlt_last_error(ctx));
+      return false;
+    }
+    dc_placed = true;
+    decoupled_ac_at = ac_at;
+  } else if (in_context) {
     // The AC pass is queued first; then the DC-group sections -- measured and written while the AC code was being
     // built -- start their way to the host: the link is idle until the first AC sections are written.
     uint8_t* buf = nullptr;
@@ -325,17 +382,19 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   const auto t3 = now();
   const PackedSections dc = {nullptr, dcm.section_offset, dcm.section_bits, dcm.num_sections};
   const PackedSections ac = {nullptr, acm.section_offset, acm.section_bits, acm.num_sections};
-  globals.ac_global = BuildAcGlobal(xsize, ysize, ac_code);
+  if (!decoupled) globals.ac_global = BuildAcGlobal(xsize, ysize, ac_code);
   const size_t dc_bytes = static_cast<size_t>(dc.offset[dc.n]), ac_bytes = static_cast<size_t>(ac.offset[ac.n]);
+  last_dc_bytes = dc_bytes;
   const size_t acg_bytes = globals.ac_global.size();
   std::vector<uint8_t> head;
   bool ok = true;
   if (in_context) {
     const size_t ac_at = dc_at + dc_bytes + acg_bytes;
-    last_frame_bytes = ac_at + ac_bytes + 16;
+    last_frame_bytes = std::max(last_frame_bytes, ac_at + ac_bytes + 16);
     uint8_t* buf = nullptr;
     if (!dc_placed || jxlt_output_buffer(ctx, ac_at + ac_bytes + 16, &buf) != JXLT_OK ||
-        jxlt_pack_sections_place(ctx, 1, buf + ac_at) != JXLT_OK) {
+        (!decoupled && jxlt_pack_sections_place(ctx, 1, buf + ac_at) != JXLT_OK) ||
+        (decoupled && ac_at != decoupled_ac_at)) {
       fprintf(stderr, "jxl_tiny_amd: section placement failed: %s\n", jxlt_last_error(ctx));
       return false;
     }

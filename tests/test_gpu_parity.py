@@ -437,6 +437,28 @@ def test_baseline_config4_16384_frame(built, enc):
     assert out["config"]["codestream_sha256"] == BENCH_FRAME_SHA16
 
 
+def test_frames_in_a_row_whose_ac_code_is_ready_first(built, enc):
+    """Small frames: the AC histogram arrives before the DC code is built, so the host builds both codes at the same
+    time and has the AC sections measured, written and on their way before the DC-group sections exist -- at a place
+    that leaves room for what the LAST frame of this size had in front of them (host/enc_frame.cc).  A row of frames
+    of one size whose DC-group sections shrink and grow (flat, busy, flat ...; a frame that needs more room than a
+    quarter above its predecessor's sends its AC sections a second time): every codestream equals the oracle's."""
+    w, h = 1096, 840
+    busy = T.to_planes(T.synthetic_image(w, h, hard=True))
+    calm = T.to_planes(T.synthetic_image(w, h))
+    flat = np.full_like(calm, 0.25)
+    flat[:, ::64, ::64] = 0.3
+    want = {}
+    for name, planes in (("flat", flat), ("calm", calm), ("busy", busy)):
+        want[name] = T.assemble_codestream(T.oracle_hot_path(planes, 1.0), 1.0)
+    assert len(want["busy"]) > 2 * len(want["flat"])
+    frames = {"flat": flat, "calm": calm, "busy": busy}
+    for name in ("flat", "flat", "busy", "busy", "calm", "flat", "busy", "calm", "calm"):
+        enc.upload(frames[name])
+        assert enc.encode_resident(1.0) == want[name], name
+        assert enc.encode_resident(1.0, copy=False).tobytes() == want[name], name
+
+
 def test_frame_above_one_gigapixel(built, enc):
     """The reference takes frames of up to 2^30 - 1 pixels per side (enc_file.cc:41-43); the device path indexes
     blocks with 32 bits and coefficients with 64.  32768 x 45056 = 1.48 Gpixel = 23.1 M blocks: past the 2^24 blocks
