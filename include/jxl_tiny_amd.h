@@ -90,6 +90,13 @@ void jxlt_context_destroy(jxlt_context* ctx);
 const char* jxlt_last_error(const jxlt_context* ctx);
 /* The device ordinal the context was created for. */
 int jxlt_context_device(const jxlt_context* ctx);
+/* jxlt_context_destroy keeps the context's device buffers (blocks of 1 MB and more) for the next context of the
+ * process on that device instead of returning them to the HIP runtime: on this stack memory that was freed and is
+ * handed out again makes kernels and downloads measurably slower.  At most JXLT_DEVICE_CACHE_MB
+ * (environment, default 32768; 0 = keep nothing) are held, oldest blocks released first.  This call returns all of
+ * them for `device_ordinal` (-1: every device) to the runtime; the number of bytes released. */
+size_t jxlt_release_cached_memory(int device_ordinal);
+
 /* Number of usable HIP devices (0: none -- every other entry then fails with JXLT_ERR_NO_DEVICE). */
 int jxlt_device_count(void);
 /* Restricts the calling thread -- and the threads it creates afterwards, e.g. the helper threads of the code

@@ -34,7 +34,7 @@ HIP_SYMBOLS = ["jxlt_context_create", "jxlt_context_destroy", "jxlt_last_error",
                "jxlt_image_upload", "jxlt_image_set_device", "jxlt_image_upload_pfm", "jxlt_image_set_device_pfm", "jxlt_image_attach_host", "jxlt_image_attach_host_pfm", "jxlt_image_size", "jxlt_pinned_alloc",
                "jxlt_pinned_free", "jxlt_pinned_register", "jxlt_pinned_unregister", "jxlt_encode_enqueue", "jxlt_set_strategy_distance",
                "jxlt_fetch_side_info", "jxlt_fetch_histograms", "jxlt_fetch_dc_histogram", "jxlt_pack_ac_sections", "jxlt_pack_sections",
-               "jxlt_pack_sections_sizes", "jxlt_pack_sections_copy", "jxlt_pack_sections_place", "jxlt_pack_measure", "jxlt_pack_measure_begin", "jxlt_pack_measure_only", "jxlt_pack_write_begin", "jxlt_histograms_ready", "jxlt_pack_measured", "jxlt_pack_write",
+               "jxlt_pack_sections_sizes", "jxlt_pack_sections_copy", "jxlt_pack_sections_place", "jxlt_pack_measure", "jxlt_pack_measure_begin", "jxlt_pack_measure_only", "jxlt_release_cached_memory", "jxlt_pack_write_begin", "jxlt_histograms_ready", "jxlt_pack_measured", "jxlt_pack_write",
                "jxlt_output_buffer",
                "jxlt_synchronize", "jxlt_fetch_result", "jxlt_kernel_times", "jxlt_encode_stats"]
 HIP_SYMBOLS_TESTING = ["jxlt_debug_fetch"]
@@ -123,6 +123,8 @@ def hip_lib():
         L.jxlt_context_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.jxlt_context_destroy.argtypes = [C.c_void_p]
         L.jxlt_context_destroy.restype = None
+        L.jxlt_release_cached_memory.argtypes = [C.c_int]
+        L.jxlt_release_cached_memory.restype = C.c_size_t
         L.jxlt_last_error.argtypes = [C.c_void_p]
         L.jxlt_last_error.restype = C.c_char_p
         L.jxlt_image_upload.argtypes = [C.c_void_p, C.POINTER(fp), C.c_size_t, C.c_size_t, C.c_size_t]
@@ -401,6 +403,12 @@ class Encoder:
         dp = self.enqueue(distance, flags)
         fr = self.fetch_raw()
         return file_header(fr.xsize, fr.ysize) + self.assemble(fr, dp, num_threads)
+
+
+def release_cached_memory(device=-1):
+    """Device memory that destroyed contexts left for their successors goes back to the HIP runtime
+    (jxlt_release_cached_memory); returns the number of bytes released."""
+    return int(hip_lib().jxlt_release_cached_memory(device))
 
 
 def build_code_tables(ac_hist, dc_hist):

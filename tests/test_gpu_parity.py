@@ -512,6 +512,31 @@ def test_baseline_config5_batch_of_32_frames_over_a_device_list(built):
         assert got[i] == want[i % 4], "frame %d" % i
 
 
+def test_device_memory_of_a_destroyed_context_serves_the_next_one(built):
+    """jxlt_context_destroy keeps device blocks of 1 MB and more for the next context of the process (memory that went
+    through hipFree and comes back from hipMalloc is slower on this stack); jxlt_release_cached_memory
+    returns them to the runtime.  Contexts in a row give the same bytes, the memory held does not grow with them, and
+    after the release torch sees the memory free again."""
+    import torch
+    built.release_cached_memory()
+    planes = T.to_planes(T.synthetic_image(2048, 1536))
+    want = T.assemble_codestream(T.oracle_hot_path(planes, 1.0), 1.0)
+    free0 = torch.cuda.mem_get_info(0)[0]
+    held = []
+    for _ in range(4):
+        e = built.Encoder(0)
+        e.upload(planes)
+        assert e.encode_resident(1.0) == want
+        e.close()
+        held.append(free0 - torch.cuda.mem_get_info(0)[0])
+    assert held[0] > (20 << 20), held           # the first context's buffers are still allocated ...
+    assert held[3] <= held[0] + (8 << 20), held  # ... and served the later ones
+    released = built.release_cached_memory(0)
+    assert released >= (20 << 20)
+    assert free0 - torch.cuda.mem_get_info(0)[0] < (8 << 20)
+    assert built.release_cached_memory() == 0
+
+
 def test_thread_binding_next_to_the_device(built):
     """jxlt_bind_thread_near_device: the calling thread ends up on the CPUs the device's PCI function lists as
     local (or the call says the system does not tell); jxlt_device_count / jxlt_context_device agree with torch."""
