@@ -236,6 +236,8 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
     ~Joiner() { w->Wait(); }
   } joiner{worker.get()};
   bool ac_first = false;
+  static const bool sequential = getenv("JXLT_CODES_SEQUENTIAL") != nullptr;  // (experiment knob: DC code, then AC code)
+  if (sequential) worker->Wait();
   for (;;) {
     if (worker->Done()) break;
     const int ready = jxlt_histograms_ready(ctx);
@@ -247,9 +249,13 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
       ac_first = true;
       break;
     }
+    // (a query takes the runtime's lock: a couple of microseconds between two of them leave it to the other
+    // encoding threads of the process -- the lanes of a batch encoder)
+    for (int spin = 0; spin < 64 && !worker->Done(); ++spin) {
 #if defined(__x86_64__)
-    __builtin_ia32_pause();
+      __builtin_ia32_pause();
 #endif
+    }
   }
   if (!ac_first) {
     dc_shared = dc_shared_now;
