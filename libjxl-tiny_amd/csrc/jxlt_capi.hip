@@ -1168,6 +1168,17 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
     hipStream_t plan_stream = ctx->stream;
     if (tok_stream == ctx->stream) {
       plan_stream = ctx->aux_stream;
+      // (the DC-group sections' plan first, behind the DC-group kernels and beside token_kernel: for a small frame
+      // those sections' packing is what the frame waits for last, and the plan is a third of its launches)
+      static const bool dc_plan_early = [] {
+        const char* e = getenv("JXLT_DC_PLAN_EARLY");  // (experiment knob)
+        return !e || atoi(e) != 0;
+      }();
+      if (dc_plan_early) {
+        HIP_TRY(ctx, hipStreamWaitEvent(plan_stream, ctx->dc_kernels_done, 0));
+        const int rcd = EnqueuePlan(ctx, 0, ctx->dc_records.cap / 3, plan_stream);
+        if (rcd != JXLT_OK) return rcd;
+      }
       HIP_TRY(ctx, hipStreamWaitEvent(plan_stream, ctx->aux_done, 0));
     }
     const int rcp = EnqueuePlan(ctx, 1, ctx->tokens.cap / 3, plan_stream);

@@ -94,11 +94,11 @@ def test_code_tables_from_random_histograms(built, seed):
 
 @pytest.mark.parametrize("distance", ["0.1", "0.5", "1", "4"])
 def test_code_tables_from_the_bench_frames_histograms(built, distance):
-    """The histograms of the 16384 x 16384 bench frame at four distances (tests/golden/bench_histograms.npz: counts
+    """The histograms of the 16384 x 16384 bench frame at four distances (tests/golden/histograms/bench_histograms.npz: counts
     up to 10^8, written on the GPU box by tools/dump_histograms.py -- data, not code).  Four in ten of the
     clustering's Huffman costs on the DC histograms end in a tree deeper than 15 bits and take the depth-limited
     rounds of host/entropy_coder.cc (HuffmanBitCost); the tables must be the oracle's all the same."""
-    h = np.load(T.ROOT / "tests" / "golden" / "bench_histograms.npz")
+    h = np.load(T.ROOT / "tests" / "golden" / "histograms" / "bench_histograms.npz")
     ac, dc = h["ac_" + distance], h["dc_" + distance]
     want = T.oracle_code_tables(ac, dc, reference_single_symbol=False)
     got = built.build_code_tables(ac, dc)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Host time of the code construction (histogram clustering + Huffman codes, host/entropy_coder.cc) on the histograms
-of the 16384^2 bench frame at four distances (tests/golden/bench_histograms.npz, written by tools/dump_histograms.py on
+of the 16384^2 bench frame at four distances (tests/golden/histograms/bench_histograms.npz, written by tools/dump_histograms.py on
 the GPU box).  No GPU needed.  JXLT_POOL_MODE=0/1 forces the clustering to work alone / with the helper threads."""
 import sys
 import time
@@ -13,7 +13,7 @@ sys.path.insert(0, str(ROOT))
 import __graft_entry__  # noqa: E402
 
 pkg = __graft_entry__.load_package()
-H = np.load(ROOT / "tests" / "golden" / "bench_histograms.npz")
+H = np.load(ROOT / "tests" / "golden" / "histograms" / "bench_histograms.npz")
 zero = np.zeros((64, 64), np.uint32)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 for key in sorted(H.files):
