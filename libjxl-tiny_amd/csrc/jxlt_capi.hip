@@ -1487,6 +1487,10 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table, bool
   HIP_TRY(ctx, hipEventRecord(ps.measured, ctx->aux_stream));
   hipLaunchKernelGGL(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), 0, ctx->stream, P);
   HIP_TRY(ctx, hipGetLastError());
+  // (the plan is used up: the kernel above has replaced every tile's section index by the section's bit position.  A
+  // second measuring pass of the same encode -- jxlt_pack_sections behind a complete encode -- plans again; until
+  // round 3 it did not, read section offsets at those bit positions and wrote wherever they pointed.)
+  ps.planned = false;
   ps.measured_sections = nsec;
   ps.max_tiles = max_tiles;
   ps.writes_queued = false;

@@ -347,6 +347,7 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
     if (need > ac_at) {
       // (the DC-group sections grew by more than a quarter against the last frame: the AC sections once more,
       // further to the right -- their blob is still on the device)
+      if (trace) fprintf(stderr, "jxlt trace: %zu bytes in front of the AC sections, room for %zu: AC sections placed again\n", need, ac_at);
       ac_at = align(need + 4096);
       if (jxlt_output_buffer(ctx, ac_at + ac_size + 16, &buf) != JXLT_OK ||
           jxlt_pack_sections_place(ctx, 1, buf + ac_at) != JXLT_OK) {

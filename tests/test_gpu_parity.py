@@ -457,6 +457,23 @@ def test_frames_in_a_row_whose_ac_code_is_ready_first(built, enc):
         enc.upload(frames[name])
         assert enc.encode_resident(1.0) == want[name], name
         assert enc.encode_resident(1.0, copy=False).tobytes() == want[name], name
+    # a size at which the DC-group sections of an ordinary frame are hundreds of KB: behind a flat frame they do not
+    # fit the room its successor's AC sections left in front of them (last frame's size + a quarter + 64 KB)
+    size = 4096
+    calm = T.to_planes(T.synthetic_image(size, size))
+    flat = np.full_like(calm, 0.25)
+    flat[:, ::64, ::64] = 0.3
+    frames = {"flat": flat, "calm": calm}
+    want = {k: T.assemble_codestream(T.oracle_hot_path(v, 1.0), 1.0) for k, v in frames.items()}
+    dc_bytes = {}
+    for name in ("flat", "flat", "calm", "calm", "flat", "calm"):
+        enc.upload(frames[name])
+        # (the codestream in the context's buffer: jxlt_encode_resident_view, the entry point the bench uses)
+        assert enc.encode_resident(1.0, copy=False).tobytes() == want[name], name
+        # (a second measuring pass behind a complete encode: until round 3 it ran on the used-up tile plan)
+        sizes = enc.pack_sections(0, built.build_code_tables(*enc.fetch_histograms())[1])
+        dc_bytes[name] = int(sizes[1][-1])
+    assert dc_bytes["calm"] > dc_bytes["flat"] * 5 // 4 + (96 << 10), dc_bytes
 
 
 def test_frame_above_one_gigapixel(built, enc):
