@@ -476,6 +476,54 @@ def test_frames_in_a_row_whose_ac_code_is_ready_first(built, enc):
     assert dc_bytes["calm"] > dc_bytes["flat"] * 5 // 4 + (96 << 10), dc_bytes
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_sequences_of_calls_on_one_context(built, enc, seed):
+    """The C ABI's calls in random order on ONE context: frames of three sizes set in turn, complete encodes through
+    both entry points and through the raw-token route, the device pipeline alone, section packing behind a complete
+    encode (a second measuring pass), statistics in between.  Every codestream and every packed section must be what
+    a fresh context gives -- state left behind by one call must not leak into the next."""
+    rng = np.random.default_rng(seed)
+    frames = [T.to_planes(T.synthetic_image(w, h, seed=40 + i, hard=(i == 1)))
+              for i, (w, h) in enumerate([(300, 264), (96, 72), (520, 2100)])]
+    want = [T.assemble_codestream(T.oracle_hot_path(p, 1.0), 1.0) for p in frames]
+    tokens = [T.oracle_hot_path(p, 1.0).all_tokens() for p in frames]
+    cur = 0
+    enc.upload(frames[cur])
+    encoded = False
+    for step in range(70):
+        op = int(rng.integers(0, 8))
+        if op == 0:
+            cur = int(rng.integers(0, 3))
+            enc.upload(frames[cur])
+            encoded = False
+        elif op == 1:
+            assert enc.encode_resident(1.0) == want[cur], (step, cur)
+            encoded = True
+        elif op == 2:
+            assert enc.encode_resident(1.0, copy=False).tobytes() == want[cur], (step, cur)
+            encoded = True
+        elif op == 3:
+            assert enc.encode_resident_raw_tokens(1.0) == want[cur], (step, cur)
+            encoded = True
+        elif op == 4:
+            enc.enqueue(1.0, 0)
+            assert built.HotPathOutput(enc.fetch_raw()).all_tokens() == tokens[cur], (step, cur)
+            encoded = True
+        elif op == 5 and encoded:
+            ac, dc = enc.fetch_histograms()
+            at, dt = built.build_code_tables(ac, dc)
+            kind = int(rng.integers(0, 2))
+            data, off, bits = enc.pack_sections(kind, at if kind else dt)
+            assert len(data) == int(off[-1]) and ((bits + 7) // 8 == np.diff(off)).all(), (step, cur, kind)
+            if kind == 1 and cur != 1:  # the AC sections are the tail of the codestream (not of a single-group frame's,
+                                        # whose sections are concatenated bit by bit)
+                assert want[cur].endswith(data.tobytes()), (step, cur)
+        elif op == 6 and encoded:
+            assert enc.stats()["tiles_redone_exact_roots"] == 0
+        elif op == 7 and encoded:
+            assert set(enc.kernel_times()) == {"tile_kernel", "tokenisation_after_tile_kernel"}
+
+
 def test_frame_above_one_gigapixel(built, enc):
     """The reference takes frames of up to 2^30 - 1 pixels per side (enc_file.cc:41-43); the device path indexes
     blocks with 32 bits and coefficients with 64.  32768 x 45056 = 1.48 Gpixel = 23.1 M blocks: past the 2^24 blocks
