@@ -255,7 +255,10 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
   SLAB(ops->enqueue(ops->self, &params), "device pipeline failed");
   // participants 0 and 1 build the codes: their helper threads (entropy_coder.h) stop sleeping now and spin
   // for the histograms -- a wake-up would cost as much as half of a code construction
-  if (rank == 0 || rank == 1) WarmCodeConstruction(0.0, 8.0);
+  // (only when this thread's last code construction did share its work with them: most histograms are clustered
+  // faster alone -- entropy_coder.cc -- and helpers that are woken for nothing spin through the frame)
+  static thread_local bool code_shared_last_time = true;
+  if ((rank == 0 || rank == 1) && code_shared_last_time) WarmCodeConstruction(0.0, 8.0);
 
   // ---- both histograms leave for the meeting point, then the two codes are built IN PARALLEL by two
   // participants: 0 builds the DC code, 1 the AC code (each in its own process / thread, with whatever helper
@@ -281,7 +284,9 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
     std::fill(sum.begin(), sum.end(), 0u);
     for (int r = 0; r < world; ++r)
       for (size_t i = 0; i < kHistWords; ++i) sum[i] += c->hist[r][0][i];
+    (void)TakeClusteringShared();
     BuildAcCode(sum.data(), &ac_code);
+    code_shared_last_time = TakeClusteringShared();
     FillCodeTable(ac_code, c->ac_table);
     const std::vector<uint8_t> acg = BuildAcGlobal(xsize, ysize, ac_code);
     if (acg.size() > sizeof(c->ac_global)) return Fail(g, JXLT_ERR_INTERNAL, "ACGlobal section larger than expected");
@@ -295,7 +300,9 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
     std::fill(sum.begin(), sum.end(), 0u);
     for (int r = 0; r < world; ++r)
       for (size_t i = 0; i < kHistWords; ++i) sum[i] += c->hist[r][1][i];
+    (void)TakeClusteringShared();
     BuildDcCode(sum.data(), &dc_code);
+    code_shared_last_time = TakeClusteringShared();
     FillCodeTable(dc_code, c->dc_table);
     Publish(c, kDcTable, frame);
     globals.dc_global = BuildDcGlobal(xsize, ysize, distp, dc_code);
