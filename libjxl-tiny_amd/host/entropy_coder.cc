@@ -3,7 +3,9 @@
 // output contract and are kept identical (citations inline).
 #include "entropy_coder.h"
 
+#if defined(__x86_64__)
 #include <immintrin.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -131,6 +133,7 @@ namespace {
 // Ascending sort of n <= 64 distinct keys.  With AVX-512 by ranks: a key's place is the number of keys below it --
 // n * n / 8 vector comparisons without a branch; std::sort spends ~30 cycles per key on mispredicted comparisons
 // at these sizes.
+#if defined(__x86_64__)
 __attribute__((target("avx512f,avx512vl"))) void SortKeysByRank(uint64_t* keys, size_t n) {
   // (256-bit vectors: the 512-bit ones make some hosts lower their clock for a code path this short)
   alignas(64) uint64_t in[kAlphabetSize];
@@ -155,6 +158,9 @@ void SortKeys(uint64_t* keys, size_t n) {
     std::sort(keys, keys + n);
   }
 }
+#else
+void SortKeys(uint64_t* keys, size_t n) { std::sort(keys, keys + n); }
+#endif
 
 // sum of counts[i] * depth[i] over the code CreateHuffmanTree(counts, kAlphabetSize, 15) would build, without
 // building the depths when the first tree is not deeper than 15 (then the sum is the sum of the inner nodes'
