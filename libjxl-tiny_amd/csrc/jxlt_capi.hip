@@ -277,7 +277,14 @@ int EnsureDevice(jxlt_context* ctx, DeviceBuf<T>* b, size_t n) {
     b->cap = got / sizeof(T);
     return JXLT_OK;
   }
-  HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&b->p), bytes));
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&b->p), bytes);
+  if (e == hipErrorOutOfMemory) {
+    // (what destroyed contexts left behind must not stand in the way of a living one)
+    (void)hipGetLastError();
+    b->p = nullptr;
+    if (DeviceBlockCache::Get().Release(ctx->device) != 0) e = hipMalloc(reinterpret_cast<void**>(&b->p), bytes);
+  }
+  HIP_TRY(ctx, e);
   b->cap = n;
   return JXLT_OK;
 }
