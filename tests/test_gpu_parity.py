@@ -612,34 +612,37 @@ def test_device_memory_of_a_destroyed_context_serves_the_next_one(built):
 
 def test_cached_device_memory_gives_way_when_memory_runs_out(built):
     """What a destroyed context left for its successors must not stand in the way of a living one: a context whose
-    allocation does not fit beside the cached blocks gets them released and tries again."""
+    allocation does not fit beside the cached blocks gets them released and tries again.  (A frame of half the size
+    after a large one: its requests are too small for the cached blocks -- a block serves requests down to a
+    quarter below its size -- and need memory of their own.)"""
     import torch
     import bench
     built.release_cached_memory()
     dev = torch.device("cuda", 0)
-    small = bench.frame_rows_on_device(torch, 8192, 0, 4096, 3, dev)   # 8192 x 4096
-    large = bench.frame_rows_on_device(torch, 8192, 0, 8192, 3, dev)   # 8192 x 8192: needs about twice the memory
+    large = bench.frame_rows_on_device(torch, 8192, 0, 8192, 3, dev)   # 8192 x 8192
+    small = bench.frame_rows_on_device(torch, 8192, 0, 4096, 3, dev)   # 8192 x 4096: half the memory
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     free0 = torch.cuda.mem_get_info(0)[0]
     e = built.Encoder(0)
-    e.set_device_image([small[c].data_ptr() for c in range(3)], 8192 * 4, 8192, 4096, keepalive=small)
+    e.set_device_image([large[c].data_ptr() for c in range(3)], 8192 * 4, 8192, 8192, keepalive=large)
     a = e.encode_resident(1.0)
     e.close()
     held = free0 - torch.cuda.mem_get_info(0)[0]
-    assert held > (200 << 20), held
-    # leave one and a half times `held` free: the large frame's buffers (about 2 x held) do not fit -- unless the
-    # cached blocks (1 x held) go
-    filler = torch.empty(torch.cuda.mem_get_info(0)[0] - held * 3 // 2, dtype=torch.uint8, device=dev)
+    assert held > (400 << 20), held
+    # leave a quarter of `held` free: the small frame's buffers (about half of `held`) do not fit -- unless the
+    # cached blocks go
+    filler = torch.empty(torch.cuda.mem_get_info(0)[0] - held // 4, dtype=torch.uint8, device=dev)
     e = built.Encoder(0)
-    e.set_device_image([large[c].data_ptr() for c in range(3)], 8192 * 4, 8192, 8192, keepalive=large)
+    e.set_device_image([small[c].data_ptr() for c in range(3)], 8192 * 4, 8192, 4096, keepalive=small)
     b = e.encode_resident(1.0)
-    assert len(b) > len(a)
+    assert 0 < len(b) < len(a)
+    assert built.release_cached_memory(0) == 0  # (the first context's blocks went when the memory ran out)
     del filler
     torch.cuda.empty_cache()
     # ... and the bytes are what a context in plenty of memory gives
     e2 = built.Encoder(0)
-    e2.set_device_image([large[c].data_ptr() for c in range(3)], 8192 * 4, 8192, 8192, keepalive=large)
+    e2.set_device_image([small[c].data_ptr() for c in range(3)], 8192 * 4, 8192, 4096, keepalive=small)
     assert e2.encode_resident(1.0) == b
     e.close()
     e2.close()
