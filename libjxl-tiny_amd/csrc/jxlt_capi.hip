@@ -969,10 +969,6 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   K.tokens = ctx->tokens.p;
   K.histogram = ctx->hist.p;
 
-  HIP_TRY(ctx, hipMemsetAsync(ctx->group_ntok.p, 0, ngroups * sizeof(uint32_t), ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->hist.p, 0, 2 * 64 * 64 * sizeof(uint32_t), ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->dc_nac.p, 0, ndc * sizeof(uint32_t), ctx->stream));
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   // A frame that is still in page-locked host memory (jxlt_image_attach_host*) is processed in rows of DC groups
   // (2048 pixel rows) while it arrives.  A slab of whole DC-group rows is a frame of its own to tile_kernel
   // (nothing crosses a group boundary): same code, base pointers moved to the slab.
@@ -1010,7 +1006,23 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   }
   A.lut_overflow = ctx->lut_overflow.p;
   A.overflow_tiles = ctx->overflow_tiles.p;
-  HIP_TRY(ctx, hipMemsetAsync(ctx->lut_overflow.p, 0, nslabs * sizeof(uint32_t), ctx->stream));
+  // the frame's counters and histograms start at zero: ONE small kernel (four hipMemsetAsync were four fill kernels,
+  // 5-9 us apart, in front of every frame's first tile_kernel launch)
+  {
+    ClearArgs C;
+    C.p[0] = ctx->group_ntok.p;
+    C.n[0] = (uint32_t)ngroups;
+    C.p[1] = ctx->hist.p;
+    C.n[1] = 2 * 64 * 64;
+    C.p[2] = ctx->dc_nac.p;
+    C.n[2] = (uint32_t)ndc;
+    C.p[3] = ctx->lut_overflow.p;
+    C.n[3] = (uint32_t)nslabs;
+    const uint32_t most = std::max(std::max(C.n[0], C.n[1]), std::max(C.n[2], C.n[3]));
+    hipLaunchKernelGGL(clear_counters_kernel, dim3((most + 255) / 256), dim3(256), 0, ctx->stream, C);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   ctx->overflow_slabs = nslabs;
   while (ctx->slab_ready.size() < nslabs || ctx->tile_done.size() < nslabs) {
     hipEvent_t ev = nullptr;

@@ -7,6 +7,18 @@
 
 namespace jxlt_dev {
 
+// Zeroes up to four small arrays of 32-bit words in one launch (the per-frame counters and histograms).
+struct ClearArgs {
+  uint32_t* p[4];
+  uint32_t n[4];
+};
+__global__ void __launch_bounds__(256) clear_counters_kernel(const ClearArgs A) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (i < A.n[k]) A.p[k][i] = 0u;
+}
+
 // ---------------------------------------------------------------------------
 // Exclusive scan of up to a few ten thousand 32-bit counts into 64-bit offsets (single workgroup):
 // offsets[i] = counts[0] + ... + counts[i - 1], offsets[n] = the total.  Every thread owns a contiguous run
