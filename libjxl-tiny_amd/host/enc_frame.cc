@@ -397,7 +397,7 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   bool ok = true;
   if (in_context) {
     const size_t ac_at = dc_at + dc_bytes + acg_bytes;
-    last_frame_bytes = std::max(last_frame_bytes, ac_at + ac_bytes + 16);
+    last_frame_bytes = ac_at + ac_bytes + 16;  // (the LAST frame: a thread that once had a large frame does not ask for its size for ever)
     uint8_t* buf = nullptr;
     if (!dc_placed || jxlt_output_buffer(ctx, ac_at + ac_bytes + 16, &buf) != JXLT_OK ||
         (!decoupled && jxlt_pack_sections_place(ctx, 1, buf + ac_at) != JXLT_OK) ||
