@@ -100,6 +100,23 @@ def test_error_behaviour(built, enc):
     # images that fit one 8x8 block trap in the reference; here: an error
     with pytest.raises(built.JxlTinyError):
         enc.upload(np.zeros((3, 8, 8), np.float32))
+    # calls out of order say so instead of reading what is not there
+    hip = built.hip_lib()
+    fresh = built.Encoder(0)
+    table = np.zeros(4096, np.uint32)
+    hip.jxlt_histograms_ready.argtypes = [C.c_void_p]
+    hip.jxlt_pack_measure_only.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    hip.jxlt_pack_write_begin.argtypes = [C.c_void_p, C.c_int]
+    assert hip.jxlt_histograms_ready(fresh._ctx) < 0              # nothing enqueued
+    assert hip.jxlt_pack_measure_only(fresh._ctx, 1, table.ctypes.data) < 0
+    assert hip.jxlt_pack_write_begin(fresh._ctx, 1) < 0              # nothing measured
+    assert hip.jxlt_pack_write_begin(fresh._ctx, 2) < 0              # no such kind
+    fresh.upload(planes)
+    fresh.enqueue(1.0, 0)
+    assert hip.jxlt_pack_measure_only(fresh._ctx, 1, table.ctypes.data) < 0   # AC sections need the histograms first
+    fresh.synchronize()
+    assert hip.jxlt_histograms_ready(fresh._ctx) == 1
+    fresh.close()
 
 
 def test_values_outside_unit_range(enc):
