@@ -237,6 +237,7 @@ def main():
 
     pipelined = sharded and args.in_flight > 1
     ktimes = {}
+    step_ms, warmup_ms, first_kernel_ms = [], [], []
     if pipelined:
         pipe = open_pipeline(args.in_flight, "timed")
         run_pipelined(pipe, max(args.warmup, args.in_flight))
@@ -245,17 +246,30 @@ def main():
             jxl = jxl.tobytes()
         pipe.close()
     else:
+        tw = time.perf_counter()
         for _ in range(args.warmup):
             jxl = step()
+            tn = time.perf_counter()
+            warmup_ms.append(round(1e3 * (tn - tw), 3))
+            tw = tn
         barrier()
         # Per-stage device times of the timed steps themselves: HIP events that the C ABI records on the encoder's
-        # own stream around every stage of every encode (read after each step).
+        # own stream around every stage of every encode (read after each step).  The time of every single step
+        # (this rank's clock) and the stage times of the first eight go into the line as well: a run whose early
+        # steps are slow shows whether the kernels were (clocks still rising) or the host's share was.
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        tp = t0
+        for i in range(args.steps):
             jxl = step()
             if slab is not None:
-                for k, v in enc.kernel_times().items():
+                kt = enc.kernel_times()
+                for k, v in kt.items():
                     ktimes[k] = ktimes.get(k, 0.0) + v / args.steps
+                if i < 8:
+                    first_kernel_ms.append({k: round(v, 3) for k, v in kt.items()})
+            tn = time.perf_counter()
+            step_ms.append(round(1e3 * (tn - tp), 3))
+            tp = tn
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
         if jxl is not None:
@@ -329,11 +343,23 @@ def main():
                      # those bytes: the kernel's traffic is per tile, tiles do not share data beyond the halo columns)
                      "traffic": (None if pmc_traffic(size) is None else
                                  int(pmc_traffic(size) * slab_pixels / float(size * size))),
-                     "kernel": "tile_kernel", "kernel_ms": round(tile_ms, 3),
+                     "kernel": "tile12_kernel", "kernel_ms": round(tile_ms, 3),
                      "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PIXEL * slab_pixels,
                      "note": "rank 0's launch (its slab of the frame)" if sharded else "whole frame"},
         "kernel_ms": {k: round(v, 3) for k, v in ktimes.items()},
     }
+    if step_ms:
+        srt = sorted(step_ms)
+        result["ms_per_step_median"] = srt[len(srt) // 2] if len(srt) % 2 else round((srt[len(srt) // 2 - 1] + srt[len(srt) // 2]) / 2, 3)
+        result["ms_per_step_min"] = srt[0]
+        result["step_ms"] = step_ms
+        result["warmup_step_ms"] = warmup_ms
+        result["kernel_ms_first_steps"] = first_kernel_ms
+    # (traffic and instruction counts come from committed counter profiles, not from this run: say which, and
+    # whether the device code has changed since they were collected)
+    _, fresh = pmc_traffic(size, with_doc=True)
+    if fresh is not None:
+        result["roofline"]["traffic_profile"] = fresh
     if per_rank_kernel_ms is not None:
         result["kernel_ms_per_rank"] = per_rank_kernel_ms
     if in_flight_2 is not None:
@@ -350,7 +376,8 @@ def main():
         ach = valu["valu_insts_per_wave"] * valu["waves"] / (tile_ms * 1e-3) / 1e12
         result["roofline"]["valu_issue"] = {"achieved": round(ach, 4), "peak": round(peak, 4),
                                             "unit": "T wave64 VALU instructions/s", "frac": round(ach / peak, 4),
-                                            "valu_insts_per_wave": valu["valu_insts_per_wave"]}
+                                            "valu_insts_per_wave": valu["valu_insts_per_wave"],
+                                            "profile": valu["freshness"]}
 
     if not args.no_extras:
         if sharded:
@@ -605,18 +632,40 @@ def run_frame_batch(args, np, torch, pkg, dist, barrier, max_over_ranks, rank, w
         dist.destroy_process_group()
 
 
-def pmc_traffic(size):
+def kernel_source_sha16():
+    """Fingerprint of the device code (every file under libjxl-tiny_amd/csrc but built objects): the counter
+    profiles under profiles/ store the fingerprint of the sources they were collected with, and the bench line
+    says whether that still is what runs (there is no .git on the GPU box to ask for a commit)."""
+    h = hashlib.sha256()
+    for p in sorted((ROOT / "libjxl-tiny_amd" / "csrc").iterdir()):
+        if p.suffix in (".h", ".hip"):
+            h.update(p.name.encode())
+            h.update(p.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def profile_freshness(path, doc):
+    stored = doc.get("kernel_source_sha16")
+    now = kernel_source_sha16()
+    return {"file": "profiles/" + Path(path).name, "collected_with_kernel_source_sha16": stored,
+            "current_kernel_source_sha16": now, "stale": (None if stored is None else stored != now)}
+
+
+def pmc_traffic(size, with_doc=False):
     """HBM bytes per tile_kernel launch from the committed PMC profile of this workload
     (profiles/*_traffic_<size>.json, made by tools/collect_traffic.py from separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes with the calibrated gfx950 correction);
     None when no profile of this frame size is committed."""
     best = None
+    fresh = None
     for p in sorted((ROOT / "profiles").glob("*_traffic_%d.json" % size)):
         try:
-            best = json.load(open(p))["kernels"]["tile_kernel"]["hbm_bytes"]
+            doc = json.load(open(p))
+            best = doc["kernels"]["tile_kernel"]["hbm_bytes"]
+            fresh = profile_freshness(p, doc)
         except (OSError, KeyError, ValueError):
             pass
-    return best
+    return (best, fresh) if with_doc else best
 
 
 def pmc_valu(size):
@@ -627,6 +676,7 @@ def pmc_valu(size):
         try:
             best = json.load(open(p))
             best["valu_insts_per_wave"], best["waves"]
+            best["freshness"] = profile_freshness(p, best)
         except (OSError, KeyError, ValueError):
             best = None
     return best

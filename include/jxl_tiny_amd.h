@@ -90,11 +90,13 @@ void jxlt_context_destroy(jxlt_context* ctx);
 const char* jxlt_last_error(const jxlt_context* ctx);
 /* The device ordinal the context was created for. */
 int jxlt_context_device(const jxlt_context* ctx);
-/* jxlt_context_destroy keeps the context's device buffers (blocks of 1 MB and more) for the next context of the
- * process on that device instead of returning them to the HIP runtime: on this stack memory that was freed and is
- * handed out again makes kernels and downloads measurably slower.  At most JXLT_DEVICE_CACHE_MB
- * (environment, default 32768; 0 = keep nothing) are held, oldest blocks released first.  This call returns all of
- * them for `device_ordinal` (-1: every device) to the runtime; the number of bytes released. */
+/* While a device has another living context of this library, jxlt_context_destroy keeps the destroyed context's
+ * device buffers (blocks of 1 MB and more, at most 8 GB) for the next context instead of returning them to the HIP
+ * runtime: on this stack memory that was freed and is handed out again makes kernels and downloads measurably slower
+ * (DESIGN.md 3).  When the LAST context of a device is destroyed everything kept for that device is returned, so a
+ * co-resident allocator (PyTorch, ...) sees the memory again.  JXLT_DEVICE_CACHE_MB=<n> (environment) opts in to
+ * keeping up to n MB beyond the last context (0: never keep anything).  This call returns all kept blocks of
+ * `device_ordinal` (-1: every device) to the runtime at once; the number of bytes released. */
 size_t jxlt_release_cached_memory(int device_ordinal);
 
 /* Number of usable HIP devices (0: none -- every other entry then fails with JXLT_ERR_NO_DEVICE). */
@@ -102,7 +104,10 @@ int jxlt_device_count(void);
 /* Restricts the calling thread -- and the threads it creates afterwards, e.g. the helper threads of the code
  * construction -- to the CPUs next to the device (its PCI function's local_cpulist, i.e. the GPU's NUMA node), so
  * that the host side of an encode does not run on the other socket.  JXLT_ERR_UNSUPPORTED when the system does
- * not say which CPUs those are.  jxlt_shard_encode does this for its caller once (JXLT_NO_AFFINITY=1 disables). */
+ * not say which CPUs those are.  The library binds only threads it owns (pipeline lanes, the code construction's
+ * workers); jxlt_shard_encode binds its caller for the duration of the call and restores the caller's mask before it
+ * returns (JXLT_NO_AFFINITY=1 disables both).  An application that wants its encoding thread next to the GPU for
+ * good calls this itself. */
 int jxlt_bind_thread_near_device(int device_ordinal);
 
 /* Copies three planar f32 linear-sRGB planes (row pitch in bytes, as
@@ -402,7 +407,10 @@ int jxlt_shard_encode(jxlt_shard_group* group, jxlt_context* ctx, size_t xsize, 
  * which every GPU of a jxlt_shard_group waits.  A pipeline is `depth` such groups (segments <shm_name>.<lane>),
  * each with a device context of its own and a host thread: frame k runs on lane k % depth, so the kernels of
  * frame k + 1 run on every GPU while frame k is in that stage.  Same contract as jxlt_shard_group_open: rank 0
- * opens first, then the others; every rank submits the same frames in the same order. */
+ * opens first, then the others; every rank submits the same frames in the same order.  jxlt_shard_pipeline_close
+ * encodes what has been submitted before it returns.  A frame that fails on any rank fails on all of them, and the
+ * failure is sticky for its lane (the ranks cannot agree on a reset while some of them may still be inside the
+ * frame): close the pipeline on every rank and open a new one. */
 typedef struct jxlt_shard_pipeline jxlt_shard_pipeline;
 int jxlt_shard_pipeline_open(const char* shm_name, int rank, int world, int device_ordinal, int depth,
                              size_t output_capacity, size_t max_sections, jxlt_shard_pipeline** out);

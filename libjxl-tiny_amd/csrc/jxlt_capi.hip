@@ -36,7 +36,10 @@ thread_local std::string g_create_error;
 
 // Largest frame of the device path, in 8x8 blocks.  The kernels index blocks -- and up to twelve 32-bit words per
 // block (jxlt_token_kernel.h: mask_at) -- with 32 bits; coefficients (192 per block) are indexed with 64.
-constexpr size_t kMaxFrameBlocks = size_t(1) << 28;
+// The limit is what the test-suite exercises (test_frame_above_one_gigapixel: 23.1 M blocks, which crosses
+// kTokenNarrowBlocks and the 32-bit coefficient index) rounded up to the next power of two, not what the index
+// widths would allow on paper (2^28): 2^25 blocks = 2.1 Gpixel, e.g. 46 340 x 46 340.
+constexpr size_t kMaxFrameBlocks = size_t(1) << 25;
 
 template <typename T>
 struct DeviceBuf {
@@ -170,6 +173,7 @@ struct jxlt_context {
   uint32_t tiles_redone = 0;   // ... tiles of the last encode
   bool copies_pending = false;
   bool profiled = false;
+  bool counted = false;  // DeviceBlockCache knows this context as a living one
 };
 
 namespace {
@@ -188,13 +192,37 @@ namespace {
 // a context created after another one of the same frame size was destroyed ran tile_kernel 8 % slower (4.22 ->
 // 4.57 ms at 16384^2) and its downloads at half the rate (59 MB in 2.1 instead of 0.96 ms), tools/seq_probe.py; with
 // the first context's buffers leaked instead of freed the second was as fast as the first.  Blocks of 1 MB and more,
-// per device, handed out again for requests of their size (up to a quarter less); the oldest go back to the runtime
-// when more than JXLT_DEVICE_CACHE_MB (default 32768) are held, all of them with jxlt_release_cached_memory().
+// per device, handed out again for requests of their size (up to a quarter less).
+// What is kept, and for how long (memory a co-resident allocator cannot see must not outlive its use):
+//  * default: blocks are kept only while the device has another LIVING context of this library (a pipeline lane that
+//    is re-created, a batch encoder's lanes, contexts of several sizes side by side); when the last context of a
+//    device is destroyed everything kept for that device goes back to the runtime.  At most 8 GB are held.
+//  * JXLT_DEVICE_CACHE_MB=<n> (environment) opts in to keeping up to n MB beyond the last context -- what a process
+//    that creates and destroys encoders in a row wants (tools/config_table.py, tools/soak.py); 0 keeps nothing, ever.
+//  jxlt_release_cached_memory() returns everything at once in either mode.
 class DeviceBlockCache {
  public:
   static DeviceBlockCache& Get() {
     static DeviceBlockCache* cache = new DeviceBlockCache;  // (never destroyed: the runtime may be gone by then)
     return *cache;
+  }
+  void ContextCreated(int device) {
+    std::lock_guard<std::mutex> lock(mu_);
+    if (device >= 0) {
+      if (live_.size() <= (size_t)device) live_.resize((size_t)device + 1, 0);
+      live_[(size_t)device]++;
+    }
+  }
+  // The last context of a device is gone: what was kept for its successors goes back to the runtime, unless the
+  // process asked for a cache that outlives its contexts.
+  void ContextDestroyed(int device) {
+    bool release = false;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      if (device >= 0 && (size_t)device < live_.size() && live_[(size_t)device] > 0)
+        release = --live_[(size_t)device] == 0 && !persistent_;
+    }
+    if (release) (void)Release(device);
   }
   void* Take(int device, size_t bytes, size_t* got) {
     std::lock_guard<std::mutex> lock(mu_);
@@ -251,7 +279,8 @@ class DeviceBlockCache {
  private:
   DeviceBlockCache() {
     const char* e = getenv("JXLT_DEVICE_CACHE_MB");
-    limit_ = (e ? static_cast<size_t>(atoll(e)) : size_t(32768)) << 20;
+    persistent_ = e != nullptr && *e != '\0';
+    limit_ = (persistent_ ? static_cast<size_t>(atoll(e)) : size_t(8192)) << 20;
   }
   static constexpr size_t kMinBytes = size_t(1) << 20;
   struct Block {
@@ -261,7 +290,9 @@ class DeviceBlockCache {
   };
   std::mutex mu_;
   std::vector<Block> blocks_;
+  std::vector<int> live_;  // living contexts per device
   size_t total_ = 0, limit_ = 0;
+  bool persistent_ = false;  // JXLT_DEVICE_CACHE_MB given: blocks outlive the last context
 };
 
 template <typename T>
@@ -323,10 +354,9 @@ int CheckImageArgs(jxlt_context* ctx, const void* const planes[3], size_t pitch_
     return JXLT_ERR_INVALID_ARGUMENT;
   }
   if (((xsize + 7) / 8) * ((ysize + 7) / 8) > kMaxFrameBlocks) {
-    // the kernels index blocks, and up to twelve words per block, with 32 bits: 2^28 blocks = 17 Gpixel per frame
-    // -- more than the ~30 bytes per pixel of planes, coefficients and worst-case token space leave room for in
-    // 288 GB, so what a frame below this meets first is JXLT_ERR_OUT_OF_MEMORY
-    ctx->error = "frames above 2^28 8x8 blocks are not supported by the device path";
+    // (the kernels' 32-bit block indices would reach 2^28 blocks; frames above 2^25 -- 2.1 Gpixel -- are refused
+    // because nothing larger has ever been run through them)
+    ctx->error = "frames above 2^25 8x8 blocks (2.1 Gpixel) are not supported by the device path";
     return JXLT_ERR_UNSUPPORTED;
   }
   if (xsize <= 8 && ysize <= 8) {
@@ -391,6 +421,8 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
     jxlt_context_destroy(ctx);  // (handles partially built contexts: every handle is checked for null)
     return e == hipErrorOutOfMemory ? JXLT_ERR_OUT_OF_MEMORY : JXLT_ERR_NO_DEVICE;
   }
+  ctx->counted = true;
+  DeviceBlockCache::Get().ContextCreated(ctx->device);
   *out = ctx;
   return JXLT_OK;
 }
@@ -398,9 +430,11 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
 void jxlt_context_destroy(jxlt_context* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  // (everything the context has queued on any of its streams: its device buffers are kept for the next context --
-  // DeviceBlockCache -- and not synchronised by a hipFree)
-  (void)hipDeviceSynchronize();
+  // (everything the context has queued on any of ITS streams -- other contexts, lanes and frameworks on the device
+  // are not waited for: its device buffers may be kept for the next context, DeviceBlockCache, and are then not
+  // synchronised by a hipFree)
+  for (hipStream_t st : {ctx->stream, ctx->aux_stream, ctx->copy_stream, ctx->upload_stream})
+    if (st) (void)hipStreamSynchronize(st);
   FreeDevice(&ctx->own_payload);
   for (int c = 0; c < 3; c++) {
     FreeDevice(&ctx->own_planes[c]);
@@ -489,7 +523,10 @@ void jxlt_context_destroy(jxlt_context* ctx) {
   }
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  const bool counted = ctx->counted;
+  const int device = ctx->device;
   delete ctx;
+  if (counted) DeviceBlockCache::Get().ContextDestroyed(device);
 }
 
 const char* jxlt_last_error(const jxlt_context* ctx) {

@@ -92,11 +92,6 @@ bool EncodeFile(const Image3F& input, float distance, std::vector<uint8_t>* outp
 bool EncodePFMFile(const char* filename, float distance, std::vector<uint8_t>* output, size_t* xsize_out,
                    size_t* ysize_out) {
   if (!jxlt::NormalizeDistance(&distance)) return false;
-  jxlt_context* ctx = jxlt::AcquireThreadContext();
-  if (!ctx) {
-    fprintf(stderr, "jxl_tiny_amd: no usable HIP device (there is no CPU fallback)\n");
-    return false;
-  }
   // The file is mapped, not read: its pages go from the page cache into the device library's
   // page-locked staging buffers (several threads) and from there over PCIe, overlapped.
   const int fd = open(filename, O_RDONLY);
@@ -120,6 +115,14 @@ bool EncodePFMFile(const char* filename, float distance, std::vector<uint8_t>* o
   bool ok = jxlt::ParsePFMHeader(data, size, &xsize, &ysize, &big_endian, &payload_offset);
   if (ok && xsize_out) *xsize_out = xsize;
   if (ok && ysize_out) *ysize_out = ysize;
+  // (the device comes behind the file: a readable image on a machine without a GPU is reported as an encoding
+  // failure, like a reference whose EncodeFile fails, not as an unreadable file)
+  jxlt_context* ctx = ok ? jxlt::AcquireThreadContext() : nullptr;
+  if (ok && !ctx) {
+    fprintf(stderr, "jxl_tiny_amd: no usable HIP device (there is no CPU fallback)\n");
+    munmap(map, size);
+    return false;
+  }
   if (ok) {  // several GPUs configured: the payload's row slabs go to one GPU each
     bool used = false;
     const bool done = jxlt::EncodeOnDeviceList(nullptr, 0, data + payload_offset, big_endian ? 1 : 0, xsize, ysize,

@@ -85,7 +85,6 @@ struct jxlt_shard_group {
   bool shm = false;
   bool registered = false;   // output area page-locked for this process's devices
   bool unlinked = false;     // (rank 0) the segment's name is gone already
-  bool bound = false;        // the calling thread has been moved next to its device
   std::string name;
   std::string error;         // first failure (several participants of one process may report)
   std::mutex error_mu;
@@ -812,12 +811,22 @@ int jxlt_shard_encode(jxlt_shard_group* g, jxlt_context* ctx, size_t xsize, size
     if (rc != JXLT_OK) g->SetError(std::string("single-device encode failed: ") + jxlt_last_error(ctx));
     return rc;
   }
-  if (!g->bound) {
-    // the host side of the frame (hand-overs, code construction and its helper threads) next to the GPU
-    static const bool no_affinity = getenv("JXLT_NO_AFFINITY") != nullptr;
-    if (!no_affinity) jxlt_bind_thread_near_device(jxlt_context_device(ctx));
-    g->bound = true;
-  }
+  // The host side of the frame (hand-overs, code construction) next to the GPU -- for the duration of this call only:
+  // the caller's own affinity mask is put back before it returns (a library call must not re-pin the
+  // application's thread for good).  Threads the library creates from inside the call -- the code construction's
+  // worker and helper threads -- inherit the bound mask and keep it: they are the library's own.
+  struct ScopedNearDevice {
+    cpu_set_t saved;
+    bool restore = false;
+    explicit ScopedNearDevice(int device) {
+      static const bool no_affinity = getenv("JXLT_NO_AFFINITY") != nullptr;
+      if (no_affinity || sched_getaffinity(0, sizeof(saved), &saved) != 0) return;
+      restore = jxlt_bind_thread_near_device(device) == JXLT_OK;
+    }
+    ~ScopedNearDevice() {
+      if (restore) (void)sched_setaffinity(0, sizeof(saved), &saved);
+    }
+  } near_device(jxlt_context_device(ctx));
   if (!g->registered) {
     // the devices copy their sections straight into the segment: page-lock this process's mapping of it
     if (jxlt_pinned_register(g->output(), static_cast<size_t>(g->ctl->output_capacity)) != JXLT_OK)
@@ -860,11 +869,15 @@ struct jxlt_shard_pipeline {
 namespace jxlt {
 namespace {
 void LaneLoop(jxlt_shard_pipeline::Lane* lane) {
+  // (a lane's thread is the library's own: it lives next to its GPU for good)
+  if (lane->ctx && getenv("JXLT_NO_AFFINITY") == nullptr) (void)jxlt_bind_thread_near_device(jxlt_context_device(lane->ctx));
   for (;;) {
     {
       std::unique_lock<std::mutex> lock(lane->mu);
       lane->cv.wait(lock, [&] { return lane->quit || lane->has_job; });
-      if (lane->quit) return;
+      // (a frame that has been submitted is encoded before the lane goes: the other ranks have started it, and
+      // would wait for this rank's part until their time-out -- ADVICE r3)
+      if (!lane->has_job) return;
       lane->has_job = false;
     }
     int rc = JXLT_OK;

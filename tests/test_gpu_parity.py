@@ -594,11 +594,11 @@ def test_baseline_config5_batch_of_32_frames_over_a_device_list(built):
         assert got[i] == want[i % 4], "frame %d" % i
 
 
-def test_device_memory_of_a_destroyed_context_serves_the_next_one(built):
-    """jxlt_context_destroy keeps device blocks of 1 MB and more for the next context of the process (memory that went
-    through hipFree and comes back from hipMalloc is slower on this stack); jxlt_release_cached_memory
-    returns them to the runtime.  Contexts in a row give the same bytes, the memory held does not grow with them, and
-    after the release torch sees the memory free again."""
+def test_device_memory_of_a_destroyed_context_serves_the_next_one(built, enc):
+    """While the device has a living context (`enc`), jxlt_context_destroy keeps device blocks of 1 MB and more for the
+    next context of the process (memory that went through hipFree and comes back from hipMalloc is slower on this
+    stack); jxlt_release_cached_memory returns them to the runtime.  Contexts in a row give the same
+    bytes, the memory held does not grow with them, and after the release torch sees the memory free again."""
     import torch
     built.release_cached_memory()
     planes = T.to_planes(T.synthetic_image(2048, 1536))
@@ -627,7 +627,48 @@ def test_device_memory_of_a_destroyed_context_serves_the_next_one(built):
     assert built.release_cached_memory() == 0
 
 
-def test_cached_device_memory_gives_way_when_memory_runs_out(built):
+def test_nothing_is_kept_beyond_the_last_context_unless_asked_for(built):
+    """Default: when the LAST context of a device is destroyed, the blocks kept for its successors go back to the
+    runtime (a co-resident allocator sees the memory again without anybody calling jxlt_release_cached_memory, ADVICE
+    r3); JXLT_DEVICE_CACHE_MB=<n> opts in to a cache that outlives the contexts.  In child processes: this one has
+    living contexts of other tests."""
+    import os
+    import sys
+    script = """
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+import __graft_entry__ as G
+import jxlt_testlib as T
+pkg = G.load_package()
+torch.cuda.init(); torch.zeros(1, device="cuda")
+planes = T.to_planes(T.synthetic_image(2048, 1536))
+keeper = pkg.Encoder(0)           # (the runtime's own first-use allocations happen here)
+keeper.upload(planes); keeper.encode_resident(1.0)
+free_with_keeper = torch.cuda.mem_get_info(0)[0]
+e = pkg.Encoder(0); e.upload(planes); a = e.encode_resident(1.0); e.close()
+held_beside_keeper = free_with_keeper - torch.cuda.mem_get_info(0)[0]
+keeper.close()                    # the last context of the device
+kept_after_last = pkg.release_cached_memory(0)
+print("RESULT", held_beside_keeper, kept_after_last, len(a))
+""" % (str(T.ROOT), str(T.ROOT / "tests"))
+    def run(env_extra):
+        env = dict(os.environ)
+        env.pop("JXLT_DEVICE_CACHE_MB", None)
+        env.update(env_extra)
+        out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+        assert line, out.stdout + out.stderr
+        return [int(v) for v in line[0].split()[1:]]
+    held, kept, n = run({})
+    assert held > (20 << 20) and kept == 0 and n > 0, (held, kept)       # kept beside a living context, gone with the last
+    held, kept, n = run({"JXLT_DEVICE_CACHE_MB": "4096"})
+    assert held > (20 << 20) and kept > (40 << 20), (held, kept)          # opted in: both contexts' blocks outlive them
+    held, kept, n = run({"JXLT_DEVICE_CACHE_MB": "0"})
+    assert held < (8 << 20) and kept == 0, (held, kept)                   # 0: nothing is ever kept
+
+
+def test_cached_device_memory_gives_way_when_memory_runs_out(built, enc):
     """What a destroyed context left for its successors must not stand in the way of a living one: a context whose
     allocation does not fit beside the cached blocks gets them released and tries again.  (A frame of half the size
     after a large one: its requests are too small for the cached blocks -- a block serves requests down to a
@@ -877,6 +918,34 @@ def test_random_frames_codestream_equals_oracle(built, w, h, distance, seed):
     planes = T.to_planes(img)
     want = T.assemble_codestream(T.oracle_hot_path(planes, distance), distance)
     assert built.encode_file(planes, distance) == want
+
+
+def _judge_cases():
+    import test_oracle_known_answers as K
+    cases = [("r2",) + k for k in sorted(K.JUDGE_R2)] + [("r3",) + k for k in sorted(K.JUDGE_R3)]
+    return cases
+
+
+@pytest.mark.parametrize("case", _judge_cases(), ids=lambda c: "%s_%dx%d_d%g_s%d_%s" % c)
+def test_product_bytes_equal_the_judges_stand_in_builds(built, case):
+    """The drop-in's codestream, reference-bytes mode, against the size + sha-256 of the bytes the unmodified
+    reference sources produced in the judges' stand-in builds (VERDICT.md rounds 2 and 3) -- compared with the
+    recorded hashes directly, no oracle in between."""
+    import hashlib
+    import test_oracle_known_answers as K
+    which, w, h, d, seed, kind = case
+    if which == "r2":
+        img = T.synthetic_image(w, h, seed=seed, hard=kind)
+        want = K.JUDGE_R2[(w, h, d, seed, kind)]
+    else:
+        img = K.judge_r3_image(w, h, seed, kind)
+        want = K.JUDGE_R3[(w, h, d, seed, kind)]
+    built.emulate_reference_single_symbol_codes(True)
+    try:
+        got = built.encode_file(T.to_planes(img), d)
+    finally:
+        built.emulate_reference_single_symbol_codes(False)
+    assert (len(got), hashlib.sha256(got).hexdigest()) == want
 
 
 def test_static_constant_emulation_on_gpu(built, enc):

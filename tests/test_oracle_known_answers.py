@@ -60,6 +60,33 @@ JUDGE_R2 = {
 }
 
 
+# Round 3's judge repeated it with nine more frames: negative / HDR samples, flat
+# content with single-symbol codes, 1 x N and N x 1 DC-group shapes.  (w, h, distance, seed, kind) -> (bytes, sha-256)
+JUDGE_R3 = {
+    (8, 9, 1.0, 31, "smooth"): (191, "dcd0686b9ecbd94626747dc8b06df30f253e0f232e2da5d2ee52ec2882ee48b7"),
+    (64, 2049, 1.0, 32, "hdr"): (45077, "f19d2a5b14b97de44943db59025d9eef34ed5ac10e30d4aebb8d88c36881ba2d"),
+    (2049, 64, 0.5, 0, "flat"): (2268, "0a64ec4b05ea90846fb7d7334636d360efc92f901666f116c5107aeda377ba16"),
+    (2304, 2304, 1.5, 34, "smooth"): (275272, "976033826769191ad311ae8abe0c3bd8ddad2b21da6ddcc0087ddb19d116dd93"),
+    (4100, 260, 6.0, 35, "hdr"): (63379, "b2661a2f689c9af4afa5131be81ac068f47dfe576d8c166f0697b876d975332d"),
+    (1000, 1000, 0.04, 0, "flat"): (17026, "762d33945afa7b516143ed0d3a86b85609a55558b8fd67caa6d825c5a12d3e50"),
+    (333, 4111, 12.0, 37, "smooth"): (25383, "03ae3af0936e080ed3431f98b229e64efacd5e4b58000fcbcf4eaba2250d2d5c"),
+    (5000, 3000, 2.5, 38, "hdr"): (2101446, "9c2689f4c5c21cae61fe6055f31a70fcb9736b4fb3ed33e9ea8b956b59901537"),
+    (6200, 2100, 0.8, 39, "smooth"): (1685726, "48d240cf6bdd75a6ba4e505a08a10555c53e6e3058019f36f76cc9d46c524f7a"),
+}
+
+
+def judge_r3_image(w, h, seed, kind):
+    """The judge's three kinds of frame, as VERDICT.md (round 3) defines them."""
+    if kind == "flat":
+        img = np.full((h, w, 3), 0.25, np.float32)
+        img[::64, ::64] = 0.3
+        return img
+    img = T.synthetic_image(w, h, seed=seed)
+    if kind == "hdr":
+        img = (img * np.float32(3.5) - np.float32(0.2)).astype(np.float32)
+    return img
+
+
 def _unfused_lib():
     base = T.oracle()
     lib = C.CDLL(str(T.ROOT / "oracle" / "liboracle_nofma.so"))
@@ -100,6 +127,15 @@ def test_bytes_of_the_judges_stand_in_build(built, key):
     planes = T.to_planes(T.synthetic_image(w, h, seed=seed, hard=hard))
     cs = T.oracle_codestream(T.oracle_hot_path(planes, d), d, reference_single_symbol=True)
     assert (len(cs), hashlib.sha256(cs).hexdigest()) == JUDGE_R2[key]
+
+
+@pytest.mark.parametrize("key", sorted(JUDGE_R3), ids=lambda k: "%dx%d_d%g_s%d_%s" % k)
+def test_bytes_of_the_round3_judges_stand_in_build(built, key):
+    import hashlib
+    w, h, d, seed, kind = key
+    planes = T.to_planes(judge_r3_image(w, h, seed, kind))
+    cs = T.oracle_codestream(T.oracle_hot_path(planes, d), d, reference_single_symbol=True)
+    assert (len(cs), hashlib.sha256(cs).hexdigest()) == JUDGE_R3[key]
 
 
 def test_decodable_mode_differs_only_where_single_symbol_codes_occur(built):

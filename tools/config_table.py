@@ -9,6 +9,9 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
+import os  # noqa: E402
+# (contexts in a row: keep the device blocks of destroyed contexts beyond the last one -- an opt-in since round 4)
+os.environ.setdefault("JXLT_DEVICE_CACHE_MB", "32768")
 import __graft_entry__  # noqa: E402
 import bench  # noqa: E402
 
