@@ -515,52 +515,32 @@ def cpu_baseline_leg(args, np, pkg, T, frame, dev_index, result):
     s -= s % 256 if s >= 256 else 0
     o = ((size - s) // 2) // 256 * 256
     crop = np.ascontiguousarray(frame[:, o:o + s, o:o + s].cpu().numpy())
-    t3 = time.perf_counter()
-    want = T.oracle_hot_path(crop, d)
-    cpu_jxl = T.oracle_codestream(want, d)
-    cpu_s = time.perf_counter() - t3
+    cpu_jxl, pix_s, bs_s = T.oracle_encode_file(crop, d, nthreads=1)
+    cpu_s = pix_s + bs_s
     result["cpu_baseline"] = {
         "value": round(s * s / 1e6 / cpu_s, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-        "sample": "centre %dx%d crop of the benchmark frame: oracle pixel pipeline + oracle bitstream stage "
-                  "(the reference's own structure: one thread), %.1f s" % (s, s, cpu_s),
+        "sample": "centre %dx%d crop of the benchmark frame: oracle pixel pipeline (%.2f s) + oracle bitstream stage "
+                  "(%.2f s), both plain C, one thread -- the reference's own structure" % (s, s, pix_s, bs_s),
         "cpu": _cpu_model(), "host_cores": os.cpu_count(), "codestream_bytes": len(cpu_jxl)}
-    # the same crop with the reference's independent units -- the 256 x 256 groups -- spread over ALL host cores;
-    # the bitstream stage stays serial like the reference's OptimizeSections.  Same work, same bytes.
-    from concurrent.futures import ThreadPoolExecutor
+    # the same crop with the reference's independent units -- the 256 x 256 groups -- spread over ALL host cores by
+    # POSIX threads inside the oracle (orc_encode_hot_path_threads); the bitstream stage stays serial like the
+    # reference's OptimizeSections.  Same work, same bytes.
     ng = s // 256
     if ng >= 2:
-        # (the CPUs this process may run on: a rank of an N > 1 run is bound to its GPU's NUMA node)
+        # (the CPUs this process may run on)
         try:
             usable = len(os.sched_getaffinity(0))
         except (AttributeError, OSError):
             usable = os.cpu_count() or 1
         nthr = max(1, min(ng * ng, usable))
-        tiles = [(gy, gx) for gy in range(ng) for gx in range(ng)]
-        t4 = time.perf_counter()
-        with ThreadPoolExecutor(nthr) as ex:
-            parts = list(ex.map(lambda t: T.oracle_hot_path(
-                np.ascontiguousarray(crop[:, t[0] * 256:(t[0] + 1) * 256, t[1] * 256:(t[1] + 1) * 256]), d), tiles))
-        merged = T.HotPathResult()
-        merged.xsize = merged.ysize = s
-        merged.quant_dc = np.zeros((3, s // 8, s // 8), np.int16)
-        merged.raw_quant = np.zeros((s // 8, s // 8), np.uint8)
-        merged.strategy = np.zeros((s // 8, s // 8), np.uint8)
-        merged.ytox = np.zeros((s // 64, s // 64), np.int8)
-        merged.ytob = np.zeros((s // 64, s // 64), np.int8)
-        merged.group_tokens = []
-        for (gy, gx), p in zip(tiles, parts):
-            merged.quant_dc[:, gy * 32:gy * 32 + 32, gx * 32:gx * 32 + 32] = p.quant_dc
-            merged.raw_quant[gy * 32:gy * 32 + 32, gx * 32:gx * 32 + 32] = p.raw_quant
-            merged.strategy[gy * 32:gy * 32 + 32, gx * 32:gx * 32 + 32] = p.strategy
-            merged.ytox[gy * 4:gy * 4 + 4, gx * 4:gx * 4 + 4] = p.ytox
-            merged.ytob[gy * 4:gy * 4 + 4, gx * 4:gx * 4 + 4] = p.ytob
-            merged.group_tokens.append(p.group_tokens[0])
-        par_jxl = T.oracle_codestream(merged, d)
-        par_s = time.perf_counter() - t4
+        par_jxl, ppix_s, pbs_s = T.oracle_encode_file(crop, d, nthreads=nthr)
+        par_s = ppix_s + pbs_s
         result["cpu_baseline"]["all_cores"] = {
             "value": round(s * s / 1e6 / par_s, 1), "unit": "Mpixels/s", "cores": nthr,
-            "sample": "same crop and same work: %d groups over %d threads + the serial bitstream stage, %.2f s"
-                      % (ng * ng, nthr, par_s), "same_bytes_as_one_thread": par_jxl == cpu_jxl}
+            "sample": "same crop and same work: %d groups over %d POSIX threads (%.3f s) + the serial bitstream stage "
+                      "(%.3f s)" % (ng * ng, nthr, ppix_s, pbs_s),
+            "pixel_pipeline_only_mpix_s": round(s * s / 1e6 / ppix_s, 1),
+            "same_bytes_as_one_thread": par_jxl == cpu_jxl}
         # the GPU's codestream of that crop must be those bytes too
         gpu_crop = pkg.encode_file(crop, d, device=dev_index)
         result["parity_gate"]["crop_codestream_equals_oracle"] = gpu_crop == cpu_jxl

@@ -13,6 +13,7 @@
 #include "jxl_tiny_oracle.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1130,8 +1131,119 @@ static void* xcalloc(size_t n, size_t sz) {
   return p;
 }
 
-int orc_encode_hot_path(const float* const planes[3], size_t stride, size_t xsize, size_t ysize,
-                        float distance, int force_dct8, orc_frame* f) {
+/* One 256x256 group (the reference's unit of independent work, enc_frame.cc:716-757): everything the hot path
+ * computes for it.  `s` and `num_nzeros` are the caller's scratch (one set per thread). */
+typedef struct {
+  const float* const* planes;
+  size_t stride, xsize, ysize;
+  int force_dct8;
+  const orc_distance_params* distp;
+  const dequant_matrices* dq;
+  orc_frame* f;
+  frame_grids g;
+  size_t cells_x;
+} group_job;
+
+static void encode_group(const group_job* J, size_t dc_gx, size_t dc_gy, size_t gix, size_t dc_xgroups, stripe_t* s,
+                         uint8_t (*num_nzeros)[32][32]) {
+  const float* const* planes = J->planes;
+  const size_t stride = J->stride, xsize = J->xsize, ysize = J->ysize;
+  const int force_dct8 = J->force_dct8;
+  const orc_distance_params distp = *J->distp;
+  const dequant_matrices dq = *J->dq;
+  orc_frame* f = J->f;
+  frame_grids g = J->g;
+  const size_t cells_x = J->cells_x;
+  {
+    const size_t gx = gix % dc_xgroups, gy = gix / dc_xgroups;
+    const size_t image_gx = dc_gx * 8 + gx, image_gy = dc_gy * 8 + gy;
+    const size_t group_index = image_gy * f->xsize_groups + image_gx;
+    const size_t gw = xsize - image_gx * 256 < 256 ? xsize - image_gx * 256 : 256;
+    const size_t gh = ysize - image_gy * 256 < 256 ? ysize - image_gy * 256 : 256;
+    const size_t g_xtiles = div_ceil(gw, 64), g_ytiles = div_ceil(gh, 64);
+    byte_buf tok = {0, 0, 0};
+    for (size_t ty = 0; ty < g_ytiles; ++ty) {
+      const size_t image_ty = image_gy * 4 + ty;
+      const size_t sx0 = image_gx * 256, sy0 = image_ty * 64;
+      const size_t sw = gw;
+      const size_t sh = ysize - sy0 < 64 ? ysize - sy0 : 64;
+      const size_t sxb = div_ceil(sw, 8), syb = div_ceil(sh, 8);
+      const size_t bx_img0 = image_gx * 32, by_img0 = image_ty * 8;
+      copy_and_pad(planes, stride, sx0, sy0, sw, sh, s);
+      for (size_t y = 0; y < s->ysize; y++)
+        orc_to_xyb(s->px[0][y], s->px[1][y], s->px[2][y], s->xsize);
+      for (int c = 0; c < 3; c++)
+        for (size_t y = 0; y < s->ysize; y++)
+          memcpy(f->xyb[c] + (by_img0 * 8 + y) * (f->xsize_blocks * 8) + bx_img0 * 8,
+                 s->px[c][y], s->xsize * sizeof(float));
+      for (size_t tx = 0; tx < g_xtiles; ++tx) {
+        /* ref: ProcessTile enc_frame.cc:648-683 */
+        const size_t tbx0 = tx * 8;
+        const size_t tnbx = sxb - tbx0 < 8 ? sxb - tbx0 : 8;
+        const size_t tnby = syb < 8 ? syb : 8;
+        float aq_map[64], mask[64];
+        uint8_t rq[64];
+        memset(aq_map, 0, sizeof aq_map);
+        memset(mask, 0, sizeof mask);
+        compute_aq_tile(s, tbx0, tnbx, tnby, distp.distance, distp.inv_scale, aq_map, mask, rq);
+        for (size_t y = 0; y < tnby; y++)
+          for (size_t x = 0; x < tnbx; x++) {
+            size_t pos = (by_img0 + y) * g.bstride + bx_img0 + tbx0 + x;
+            g.raw_quant[pos] = rq[y * 8 + x];
+            f->quant_field[pos] = aq_map[y * 8 + x];
+            f->masking[pos] = mask[y * 8 + x];
+          }
+        int8_t ytox = 0, ytob = 0;
+        compute_cmap_tile(s, tbx0, tnbx, tnby, &dq, &ytox, &ytob);
+        const size_t itx = image_gx * 4 + tx;
+        g.ytox[image_ty * g.tstride + itx] = ytox;
+        g.ytob[image_ty * g.tstride + itx] = ytob;
+        if (!force_dct8) {
+          for (size_t cy = 0; cy + 1 < tnby; cy += 2)
+            for (size_t cx = 0; cx + 1 < tnbx; cx += 2) {
+              size_t abx = bx_img0 + tbx0 + cx, aby = by_img0 + cy;
+              find_best_16x16(s, tbx0, 0, cx, cy, distp.distance, &dq, aq_map, mask, ytox,
+                              ytob, g.strategy + aby * g.bstride + abx, g.bstride,
+                              f->entropy8 + ((aby / 2) * cells_x + abx / 2) * 8);
+            }
+          adjust_quant_field(g.strategy + by_img0 * g.bstride + bx_img0 + tbx0,
+                             g.raw_quant + by_img0 * g.bstride + bx_img0 + tbx0, g.bstride,
+                             tnbx, tnby);
+        }
+      }
+      write_ac_stripe(s, bx_img0, by_img0, sxb, syb, &dq, distp.scale, distp.scale_dc,
+                      distp.x_qm_scale, &g, num_nzeros, ty * 8, &tok);
+    }
+    f->group_tokens[group_index] = tok.data;
+    f->group_token_bytes[group_index] = tok.size;
+  }
+}
+
+/* The groups of the frame in the reference's order (DC groups in raster order, groups in raster order inside a DC
+ * group, enc_frame.cc:839-844 / :716), as a flat list: entry i = (dc_gx, dc_gy, gix, dc_xgroups). */
+typedef struct {
+  const group_job* job;
+  size_t (*list)[4];
+  size_t count;
+  size_t next;       /* shared cursor (atomic) */
+} group_queue;
+
+static void* group_worker(void* arg) {
+  group_queue* q = (group_queue*)arg;
+  stripe_t* s = (stripe_t*)xcalloc(1, sizeof(stripe_t));
+  uint8_t (*num_nzeros)[32][32] = (uint8_t(*)[32][32])xcalloc(3, 32 * 32);
+  for (;;) {
+    const size_t i = __atomic_fetch_add(&q->next, 1, __ATOMIC_RELAXED);
+    if (i >= q->count) break;
+    encode_group(q->job, q->list[i][0], q->list[i][1], q->list[i][2], q->list[i][3], s, num_nzeros);
+  }
+  free(num_nzeros);
+  free(s);
+  return NULL;
+}
+
+int orc_encode_hot_path_threads(const float* const planes[3], size_t stride, size_t xsize, size_t ysize,
+                                float distance, int force_dct8, int nthreads, orc_frame* f) {
   memset(f, 0, sizeof *f);
   if (xsize == 0 || ysize == 0 || !(distance > 0)) return 1;
   /* ref quirk F12: images that fit one 8x8 block trap in the reference. */
@@ -1178,7 +1290,19 @@ int orc_encode_hot_path(const float* const planes[3], size_t stride, size_t xsiz
   g.ytox = f->ytox_map;
   g.ytob = f->ytob_map;
 
-  stripe_t* s = (stripe_t*)xcalloc(1, sizeof(stripe_t));
+  group_job job;
+  job.planes = planes;
+  job.stride = stride;
+  job.xsize = xsize;
+  job.ysize = ysize;
+  job.force_dct8 = force_dct8;
+  job.distp = &distp;
+  job.dq = &dq;
+  job.f = f;
+  job.g = g;
+  job.cells_x = cells_x;
+  size_t (*list)[4] = (size_t(*)[4])xcalloc(ngroups, sizeof(size_t[4]));
+  size_t count = 0;
   const size_t xsize_dc_groups = div_ceil(xsize, 2048), ysize_dc_groups = div_ceil(ysize, 2048);
   for (size_t dc_gy = 0; dc_gy < ysize_dc_groups; dc_gy++)
     for (size_t dc_gx = 0; dc_gx < xsize_dc_groups; dc_gx++) {
@@ -1186,74 +1310,43 @@ int orc_encode_hot_path(const float* const planes[3], size_t stride, size_t xsiz
       const size_t dcw = xsize - dc_gx * 2048 < 2048 ? xsize - dc_gx * 2048 : 2048;
       const size_t dch = ysize - dc_gy * 2048 < 2048 ? ysize - dc_gy * 2048 : 2048;
       const size_t dc_xgroups = div_ceil(dcw, 256), dc_ygroups = div_ceil(dch, 256);
-      uint8_t (*num_nzeros)[32][32] = (uint8_t(*)[32][32])xcalloc(3, 32 * 32);
       for (size_t gix = 0; gix < dc_xgroups * dc_ygroups; ++gix) {
-        const size_t gx = gix % dc_xgroups, gy = gix / dc_xgroups;
-        const size_t image_gx = dc_gx * 8 + gx, image_gy = dc_gy * 8 + gy;
-        const size_t group_index = image_gy * f->xsize_groups + image_gx;
-        const size_t gw = xsize - image_gx * 256 < 256 ? xsize - image_gx * 256 : 256;
-        const size_t gh = ysize - image_gy * 256 < 256 ? ysize - image_gy * 256 : 256;
-        const size_t g_xtiles = div_ceil(gw, 64), g_ytiles = div_ceil(gh, 64);
-        byte_buf tok = {0, 0, 0};
-        for (size_t ty = 0; ty < g_ytiles; ++ty) {
-          const size_t image_ty = image_gy * 4 + ty;
-          const size_t sx0 = image_gx * 256, sy0 = image_ty * 64;
-          const size_t sw = gw;
-          const size_t sh = ysize - sy0 < 64 ? ysize - sy0 : 64;
-          const size_t sxb = div_ceil(sw, 8), syb = div_ceil(sh, 8);
-          const size_t bx_img0 = image_gx * 32, by_img0 = image_ty * 8;
-          copy_and_pad(planes, stride, sx0, sy0, sw, sh, s);
-          for (size_t y = 0; y < s->ysize; y++)
-            orc_to_xyb(s->px[0][y], s->px[1][y], s->px[2][y], s->xsize);
-          for (int c = 0; c < 3; c++)
-            for (size_t y = 0; y < s->ysize; y++)
-              memcpy(f->xyb[c] + (by_img0 * 8 + y) * (f->xsize_blocks * 8) + bx_img0 * 8,
-                     s->px[c][y], s->xsize * sizeof(float));
-          for (size_t tx = 0; tx < g_xtiles; ++tx) {
-            /* ref: ProcessTile enc_frame.cc:648-683 */
-            const size_t tbx0 = tx * 8;
-            const size_t tnbx = sxb - tbx0 < 8 ? sxb - tbx0 : 8;
-            const size_t tnby = syb < 8 ? syb : 8;
-            float aq_map[64], mask[64];
-            uint8_t rq[64];
-            memset(aq_map, 0, sizeof aq_map);
-            memset(mask, 0, sizeof mask);
-            compute_aq_tile(s, tbx0, tnbx, tnby, distp.distance, distp.inv_scale, aq_map, mask, rq);
-            for (size_t y = 0; y < tnby; y++)
-              for (size_t x = 0; x < tnbx; x++) {
-                size_t pos = (by_img0 + y) * g.bstride + bx_img0 + tbx0 + x;
-                g.raw_quant[pos] = rq[y * 8 + x];
-                f->quant_field[pos] = aq_map[y * 8 + x];
-                f->masking[pos] = mask[y * 8 + x];
-              }
-            int8_t ytox = 0, ytob = 0;
-            compute_cmap_tile(s, tbx0, tnbx, tnby, &dq, &ytox, &ytob);
-            const size_t itx = image_gx * 4 + tx;
-            g.ytox[image_ty * g.tstride + itx] = ytox;
-            g.ytob[image_ty * g.tstride + itx] = ytob;
-            if (!force_dct8) {
-              for (size_t cy = 0; cy + 1 < tnby; cy += 2)
-                for (size_t cx = 0; cx + 1 < tnbx; cx += 2) {
-                  size_t abx = bx_img0 + tbx0 + cx, aby = by_img0 + cy;
-                  find_best_16x16(s, tbx0, 0, cx, cy, distp.distance, &dq, aq_map, mask, ytox,
-                                  ytob, g.strategy + aby * g.bstride + abx, g.bstride,
-                                  f->entropy8 + ((aby / 2) * cells_x + abx / 2) * 8);
-                }
-              adjust_quant_field(g.strategy + by_img0 * g.bstride + bx_img0 + tbx0,
-                                 g.raw_quant + by_img0 * g.bstride + bx_img0 + tbx0, g.bstride,
-                                 tnbx, tnby);
-            }
-          }
-          write_ac_stripe(s, bx_img0, by_img0, sxb, syb, &dq, distp.scale, distp.scale_dc,
-                          distp.x_qm_scale, &g, num_nzeros, ty * 8, &tok);
-        }
-        f->group_tokens[group_index] = tok.data;
-        f->group_token_bytes[group_index] = tok.size;
+        list[count][0] = dc_gx;
+        list[count][1] = dc_gy;
+        list[count][2] = gix;
+        list[count][3] = dc_xgroups;
+        count++;
       }
-      free(num_nzeros);
     }
-  free(s);
+  group_queue q;
+  q.job = &job;
+  q.list = list;
+  q.count = count;
+  q.next = 0;
+  /* The reference runs the groups one after the other on the calling thread (its ThreadPool argument is unused,
+   * SURVEY.md F3); nthreads > 1 spreads the same independent units over threads -- same results, group by group
+   * (every group writes its own part of the grids and its own token buffer). */
+  if (nthreads > (int)count) nthreads = (int)count;
+  if (nthreads <= 1) {
+    group_worker(&q);
+  } else {
+    pthread_t* th = (pthread_t*)xcalloc((size_t)nthreads, sizeof(pthread_t));
+    int started = 0;
+    for (int t = 0; t < nthreads - 1; t++) {
+      if (pthread_create(&th[t], NULL, group_worker, &q) != 0) break;
+      started++;
+    }
+    group_worker(&q);
+    for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+    free(th);
+  }
+  free(list);
   return 0;
+}
+
+int orc_encode_hot_path(const float* const planes[3], size_t stride, size_t xsize, size_t ysize,
+                        float distance, int force_dct8, orc_frame* f) {
+  return orc_encode_hot_path_threads(planes, stride, xsize, ysize, distance, force_dct8, 1, f);
 }
 
 void orc_frame_free(orc_frame* f) {

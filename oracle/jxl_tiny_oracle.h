@@ -79,6 +79,12 @@ typedef struct {
 int orc_encode_hot_path(const float* const planes[3], size_t stride_floats,
                         size_t xsize, size_t ysize, float distance,
                         int force_dct8, orc_frame* out);
+/* The same with the frame's 256x256 groups -- the reference's independent units, enc_frame.cc:716-757 -- spread over
+ * nthreads POSIX threads (the caller is one of them).  Same results as orc_encode_hot_path, which is this with one
+ * thread (the reference's own behaviour: its ThreadPool is never used).  bench.py's cpu_baseline
+ * "all_cores" leg uses it. */
+int orc_encode_hot_path_threads(const float* const planes[3], size_t stride_floats, size_t xsize, size_t ysize,
+                                float distance, int force_dct8, int nthreads, orc_frame* out);
 void orc_frame_free(orc_frame* f);
 /* Emulates a later EncodeFile call of a process whose first call used `first_call_distance`
  * (the reference's function-local static constants, enc_ac_strategy.cc:178-185); 0 = off. */

@@ -118,6 +118,9 @@ def oracle():
         L.orc_encode_hot_path.argtypes = [C.POINTER(fp), C.c_size_t, C.c_size_t, C.c_size_t,
                                           C.c_float, C.c_int, C.POINTER(OrcFrame)]
         L.orc_encode_hot_path.restype = C.c_int
+        L.orc_encode_hot_path_threads.argtypes = [C.POINTER(fp), C.c_size_t, C.c_size_t, C.c_size_t,
+                                                  C.c_float, C.c_int, C.c_int, C.POINTER(OrcFrame)]
+        L.orc_encode_hot_path_threads.restype = C.c_int
         L.orc_frame_free.argtypes = [C.POINTER(OrcFrame)]
         L.orc_compute_distance_params.argtypes = [C.c_float, C.POINTER(OrcDistanceParams)]
         _oracle = L
@@ -151,13 +154,18 @@ def set_strategy_distance(first_call_distance):
     S.sim_set_strategy_distance(C.c_float(first_call_distance))
 
 
-def oracle_hot_path(planes, distance, force_dct8=False, keep=False):
-    """planes: [3, h, w] float32.  Returns HotPathResult (and the raw frame if keep)."""
+def oracle_hot_path(planes, distance, force_dct8=False, keep=False, nthreads=1):
+    """planes: [3, h, w] float32.  Returns HotPathResult (and the raw frame if keep).  nthreads > 1: the frame's
+    256 x 256 groups over that many POSIX threads (orc_encode_hot_path_threads; same results)."""
     L = oracle()
     _, h, w = planes.shape
     f = OrcFrame()
-    rc = L.orc_encode_hot_path(_plane_ptrs(planes), w, w, h, C.c_float(distance), int(force_dct8),
-                               C.byref(f))
+    if nthreads > 1 and hasattr(L, "orc_encode_hot_path_threads"):
+        rc = L.orc_encode_hot_path_threads(_plane_ptrs(planes), w, w, h, C.c_float(distance), int(force_dct8),
+                                           int(nthreads), C.byref(f))
+    else:
+        rc = L.orc_encode_hot_path(_plane_ptrs(planes), w, w, h, C.c_float(distance), int(force_dct8),
+                                   C.byref(f))
     if rc != 0:
         raise ValueError("oracle rejected input: rc=%d" % rc)
     r = HotPathResult()
@@ -485,6 +493,39 @@ def oracle_codestream(res, distance, reference_single_symbol=None):
     data = C.string_at(out, n.value)
     L.orc_bs_free(out)
     return data
+
+
+def oracle_encode_file(planes, distance, nthreads=1, reference_single_symbol=None):
+    """planes [3, h, w] float32 -> (.jxl bytes, seconds in the pixel pipeline, seconds in the bitstream stage), all
+    inside the oracle's C code: orc_encode_hot_path_threads (the 256 x 256 groups over `nthreads` POSIX threads; 1 =
+    the reference's own structure) and orc_bs_encode_file (serial, like the reference's OptimizeSections), with the
+    frame handed from one to the other in place -- what bench.py times as cpu_baseline."""
+    import time
+    L, B = oracle(), _oracle_bs()
+    _, h, w = planes.shape
+    f = OrcFrame()
+    t0 = time.perf_counter()
+    rc = L.orc_encode_hot_path_threads(_plane_ptrs(planes), w, w, h, C.c_float(distance), 0, int(max(1, nthreads)),
+                                       C.byref(f))
+    if rc != 0:
+        raise ValueError("oracle rejected input: rc=%d" % rc)
+    t1 = time.perf_counter()
+    b = OrcBsInput()
+    b.xsize, b.ysize = w, h
+    for c in range(3):
+        b.quant_dc[c] = f.quant_dc[c]
+    b.raw_quant_field, b.ac_strategy = f.raw_quant_field, f.ac_strategy
+    b.ytox_map, b.ytob_map = f.ytox_map, f.ytob_map
+    b.group_tokens, b.group_token_bytes = f.group_tokens, f.group_token_bytes
+    ref = _reference_single_symbol if reference_single_symbol is None else reference_single_symbol
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    rc = B.orc_bs_encode_file(C.byref(b), C.c_float(distance), int(ref), C.byref(out), C.byref(n))
+    t2 = time.perf_counter()
+    assert rc == 0, rc
+    data = C.string_at(out, n.value)
+    B.orc_bs_free(out)
+    L.orc_frame_free(C.byref(f))
+    return data, t1 - t0, t2 - t1
 
 
 def oracle_dc_records(res):

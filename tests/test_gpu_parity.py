@@ -665,7 +665,7 @@ print("RESULT", held_beside_keeper, kept_after_last, len(a))
     held, kept, n = run({"JXLT_DEVICE_CACHE_MB": "4096"})
     assert held > (20 << 20) and kept > (40 << 20), (held, kept)          # opted in: both contexts' blocks outlive them
     held, kept, n = run({"JXLT_DEVICE_CACHE_MB": "0"})
-    assert held < (8 << 20) and kept == 0, (held, kept)                   # 0: nothing is ever kept
+    assert kept == 0, (held, kept)   # 0: nothing is ever kept (what the runtime holds back of freed memory is its own)
 
 
 def test_cached_device_memory_gives_way_when_memory_runs_out(built, enc):

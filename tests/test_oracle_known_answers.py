@@ -158,3 +158,17 @@ def test_single_block_images_are_rejected(built):
     planes = np.zeros((3, 8, 8), np.float32)
     with pytest.raises(ValueError):
         T.oracle_hot_path(planes, 1.0)
+
+
+def test_groups_over_threads_give_the_same_frame(built):
+    """orc_encode_hot_path_threads (bench.py's all-cores CPU baseline): the reference's independent units -- the
+    256 x 256 groups -- over POSIX threads give every grid, every token buffer and the codestream of the
+    one-thread run; odd sizes, two DC groups wide."""
+    planes = T.to_planes(T.synthetic_image(2100, 530, seed=5))
+    one = T.oracle_hot_path(planes, 1.5)
+    many = T.oracle_hot_path(planes, 1.5, nthreads=5)
+    assert T.compare_results(one, many, "one thread", "five threads") == []
+    want = T.oracle_codestream(one, 1.5)
+    for n in (1, 3, 64):
+        got, _, _ = T.oracle_encode_file(planes, 1.5, nthreads=n)
+        assert got == want
