@@ -170,77 +170,53 @@ int jxlt_set_strategy_distance(jxlt_context* ctx, float first_call_distance);
 /* Copies results to pinned host memory (blocking) and fills *out. */
 int jxlt_fetch_result(jxlt_context* ctx, jxlt_frame_result* out);
 
-/* Production path: the raw tokens stay in HBM.
- * jxlt_fetch_side_info copies only the side-band grids and the AC symbol
- * histograms ([64 pre-clustered contexts][64 hybrid-uint symbols], u32, what
- * OptimizeSections counts at enc_frame.cc:767-782); out->tokens is NULL.
- * jxlt_pack_ac_sections then entropy-codes every AC group section on the device
- * (the WriteToken loop of enc_frame.cc:784-800) with the caller's prefix code:
- * code_table[ctx * 64 + symbol] = (depth << 16) | bits for pre-clustered context
- * ctx, and returns the byte-aligned sections concatenated in group order. */
+/* Production path: the raw tokens stay in HBM; only the two [64][64] symbol histograms leave the device -- AC
+ * (pre-clustered contexts, static_entropy_codes.h:165; what OptimizeSections counts at enc_frame.cc:767-782) and DC
+ * (the 45 DC / metadata contexts of WriteDCTokens / WriteACMetadataTokens, enc_frame.cc:287-424, which the device
+ * tokenises too).  The DC histogram is complete before the AC tokenisation runs: jxlt_fetch_dc_histogram returns it
+ * as soon as it is there, so that the DC code is built while the device is still busy.  jxlt_histograms_ready: 1
+ * when jxlt_fetch_histograms would return without waiting, 0 when not yet (a read of host memory, no call into the
+ * HIP runtime), < 0 on error. */
+int jxlt_fetch_dc_histogram(jxlt_context* ctx, const uint32_t** dc_histogram);
+int jxlt_fetch_histograms(jxlt_context* ctx, const uint32_t** ac_histograms, const uint32_t** dc_histograms);
+int jxlt_histograms_ready(jxlt_context* ctx);
+
+/* Section packing on the device -- the WriteToken loops of enc_frame.cc:784-800 with the caller's prefix codes
+ * (code_table[ctx * 64 + symbol] = (depth << 16) | bits), kind 0 = DC-group sections (the raw-record form of
+ * WriteDCGroup, enc_frame.cc:536-570), kind 1 = AC-group sections -- in three calls:
+ *
+ *   jxlt_pack_begin(kind, table)    asynchronous: measures every section of the kind, lays them out back to back
+ *                                   (byte aligned, enc_frame.cc:804-816) and entropy-codes them into a device blob
+ *   jxlt_pack_sizes(kind, &out)     waits for the measuring pass: byte offsets + exact bit counts of the sections
+ *                                   (all the TOC needs, enc_frame.cc:572-595); out->bytes is NULL
+ *   jxlt_pack_deliver(kind, dst..)  asynchronous: the sections leave the device for `dst` -- page-locked host
+ *                                   memory (jxlt_output_buffer / jxlt_pinned_alloc / jxlt_pinned_register) or
+ *                                   device memory -- written there by the device itself, range by range while later
+ *                                   sections are still being coded.  The byte ranges are read on the device, so the
+ *                                   call need not wait for jxlt_pack_sizes.  Complete after jxlt_synchronize.
+ *
+ * jxlt_pack_deliver places all sections of the kind back to back STARTING at dst (end_aligned 0) or ENDING at dst
+ * (end_aligned 1: for a kind whose total size the caller does not know yet -- the DC-group sections are set against
+ * the start of ACGlobal from the right, the frame's head against them).  With `runs` the sections go out in pieces
+ * instead: run r = sections [first_section, first_section + num_sections) of this context's frame, back to back at
+ * dst + dst_offset (a slab of a frame that several GPUs share owns several ranges of the codestream). */
 typedef struct {
-  const uint8_t* bytes;            /* pinned host memory, owned by the context */
-  const uint64_t* section_offset;  /* [num_sections + 1] byte offsets into bytes */
+  const uint8_t* bytes;            /* NULL, or pinned host memory owned by the context */
+  const uint64_t* section_offset;  /* [num_sections + 1] byte offsets of the sections laid out back to back */
   const uint32_t* section_bits;    /* [num_sections] exact bit length of each section */
   size_t num_sections;
 } jxlt_packed_sections;
-int jxlt_fetch_side_info(jxlt_context* ctx, jxlt_frame_result* out, const uint32_t** ac_histograms);
-int jxlt_pack_ac_sections(jxlt_context* ctx, const uint32_t* code_table, jxlt_packed_sections* out);
-/* Leanest form: only the two [64][64] symbol histograms leave the device -- AC
- * (pre-clustered contexts, static_entropy_codes.h:165) and DC (the 45 DC/metadata
- * contexts of WriteDCTokens/WriteACMetadataTokens, enc_frame.cc:287-424, which the
- * device tokenises too).  jxlt_pack_sections(kind): 0 = DC-group sections (the
- * raw-record form of WriteDCGroup, enc_frame.cc:536-570), 1 = AC-group sections. */
-int jxlt_fetch_histograms(jxlt_context* ctx, const uint32_t** ac_histograms, const uint32_t** dc_histograms);
-/* The DC histogram alone, as soon as the DC-group tokenisation is done (it runs before the AC
- * tokenisation): lets the caller build the DC code while the device is still busy. */
-int jxlt_fetch_dc_histogram(jxlt_context* ctx, const uint32_t** dc_histogram);
-int jxlt_pack_sections(jxlt_context* ctx, int kind, const uint32_t* code_table, jxlt_packed_sections* out);
-/* The same in two steps, so that the (large) AC blob can land directly where the caller is
- * assembling the codestream: _sizes runs the kernels and returns offsets/bit counts
- * (out->bytes is NULL), _copy then copies the concatenated sections to `dst` (host memory,
- * ideally page-locked).  jxlt_output_buffer lends a page-locked, context-owned buffer of at
- * least `bytes` bytes (valid until the next call that asks for a larger one / destroy). */
-int jxlt_pack_sections_sizes(jxlt_context* ctx, int kind, const uint32_t* code_table,
-                             jxlt_packed_sections* out);
-int jxlt_pack_sections_copy(jxlt_context* ctx, int kind, uint8_t* dst);
-/* Asynchronous variant for a destination in page-locked host memory obtained from
- * jxlt_output_buffer / jxlt_pinned_alloc (or in device memory): the sections leave the device blob
- * for `dst` range by range on a copy stream, each range as soon as the writing kernels have
- * completed it.  Complete after the next jxlt_synchronize. */
-int jxlt_pack_sections_place(jxlt_context* ctx, int kind, uint8_t* dst);
+typedef struct {
+  uint32_t first_section, num_sections;
+  uint64_t dst_offset;
+} jxlt_section_run;
+int jxlt_pack_begin(jxlt_context* ctx, int kind, const uint32_t* code_table);
+int jxlt_pack_sizes(jxlt_context* ctx, int kind, jxlt_packed_sections* out);
+int jxlt_pack_deliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_section_run* runs, size_t num_runs,
+                      int end_aligned);
+/* A page-locked, context-owned buffer of at least `bytes` bytes to assemble a codestream in (valid until the next
+ * call that asks for a larger one / destroy; it keeps its contents when it grows). */
 int jxlt_output_buffer(jxlt_context* ctx, size_t bytes, uint8_t** out);
-/* Copy-free packing in two passes.  jxlt_pack_measure uploads both code tables and returns
- * the exact bit / byte sizes of every DC-group and AC-group section (bytes == NULL), which is
- * all the TOC needs.  jxlt_pack_write then entropy-codes the sections again, this time storing
- * every section at its final place: dc_dst / ac_dst receive the byte-aligned sections of each
- * kind back to back (offsets as returned by jxlt_pack_measure).  Both destinations must be
- * device-visible (page-locked host memory from jxlt_output_buffer / jxlt_pinned_alloc, or device
- * memory); the call is asynchronous and complete after the next jxlt_synchronize.
- * (The writing kernels are queued by the measuring call itself -- they need nothing from the host --
- * and fill a device blob; jxlt_pack_write adds the copies, range by range as the kernels finish.) */
-int jxlt_pack_measure(jxlt_context* ctx, const uint32_t* dc_code_table, const uint32_t* ac_code_table,
-                      jxlt_packed_sections* dc, jxlt_packed_sections* ac);
-/* Starts the pass of one kind early and asynchronously (0 = DC-group sections: their code is known
- * while the device still tokenises the AC groups, so their packing fills the time the host needs for
- * the AC code).  A later jxlt_pack_measure takes NULL for that kind's table and does not repeat it. */
-int jxlt_pack_measure_begin(jxlt_context* ctx, int kind, const uint32_t* code_table);
-/* Waits for a pass started with jxlt_pack_measure_begin and returns that kind's section sizes.  With
- * jxlt_pack_sections_place(kind) behind it the sections of one kind leave for the host while the other kind's
- * are still being measured: the DC-group sections' position in the codestream does not depend on the AC code
- * (enc_frame.cc:805-816: DC global, DC groups, AC global, AC groups), and they are a good part of the bytes.
- * jxlt_output_buffer keeps the buffer's contents when a later call makes it grow. */
-int jxlt_pack_measured(jxlt_context* ctx, int kind, jxlt_packed_sections* out);
-/* jxlt_pack_measure_begin in two halves: the measuring pass alone, and the writing launches behind it.  For a
- * caller that has the AC code before the DC code (small frames: the DC code is not ready when the AC histogram
- * arrives): measure the AC sections, pack the DC-group sections -- their total size positions the AC sections --,
- * then write the AC sections.  jxlt_pack_sections_place / jxlt_pack_write queue missing writing launches themselves. */
-int jxlt_pack_measure_only(jxlt_context* ctx, int kind, const uint32_t* code_table);
-int jxlt_pack_write_begin(jxlt_context* ctx, int kind);
-/* 1 when jxlt_fetch_histograms would return without waiting (the AC histogram of the last jxlt_encode_enqueue has
- * arrived), 0 when not yet, < 0 on error. */
-int jxlt_histograms_ready(jxlt_context* ctx);
-int jxlt_pack_write(jxlt_context* ctx, uint8_t* dc_dst, uint8_t* ac_dst);
 
 /* Timing of the device stages of the last jxlt_encode_enqueue (HIP events on the context's
  * stream, always recorded): writes up to `cap` entries; returns the number of stages, or < 0.

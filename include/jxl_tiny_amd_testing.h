@@ -23,6 +23,14 @@ extern "C" {
  *           always allowed). */
 int jxlt_debug_fetch(jxlt_context* ctx, int what, void* host_dst, size_t bytes);
 
+/* The side-band grids and the AC symbol histograms of the last encode without its raw tokens (out->tokens is NULL):
+ * what a reference-style caller that packs on the device would fetch.  The test-suite compares the grids. */
+int jxlt_fetch_side_info(jxlt_context* ctx, jxlt_frame_result* out, const uint32_t** ac_histograms);
+/* jxlt_pack_begin + jxlt_pack_sizes + jxlt_pack_deliver into a page-locked buffer of the context + jxlt_synchronize:
+ * the byte-aligned sections of one kind, concatenated in section order, with their bytes (out->bytes), for
+ * comparisons with the host's and the oracle's bit packing. */
+int jxlt_pack_sections(jxlt_context* ctx, int kind, const uint32_t* code_table, jxlt_packed_sections* out);
+
 /* ---- libjxltiny_host.so ------------------------------------------------ */
 
 /* The protocol of jxlt_shard_encode over caller-supplied slab operations instead of a device context (what jxlt_shard_encode
@@ -32,11 +40,11 @@ typedef struct {
   void* self;
   int (*enqueue)(void* self, const jxlt_params* params);                     /* jxlt_encode_enqueue */
   int (*dc_histogram)(void* self, const uint32_t** histogram);               /* jxlt_fetch_dc_histogram */
-  int (*begin_dc_pack)(void* self, const uint32_t* dc_code_table);           /* jxlt_pack_measure_begin(0) */
+  int (*begin_dc_pack)(void* self, const uint32_t* dc_code_table);           /* jxlt_pack_begin(0) */
   int (*ac_histogram)(void* self, const uint32_t** histogram);               /* jxlt_fetch_histograms */
   int (*measure)(void* self, const uint32_t* ac_code_table, jxlt_packed_sections* dc,
-                 jxlt_packed_sections* ac);                                  /* jxlt_pack_measure */
-  int (*write)(void* self, uint8_t* dc_dst, uint8_t* ac_dst);                /* jxlt_pack_write */
+                 jxlt_packed_sections* ac);                                  /* jxlt_pack_begin(1) + jxlt_pack_sizes(0 / 1) */
+  int (*write)(void* self, uint8_t* dc_dst, uint8_t* ac_dst);                /* jxlt_pack_deliver(0 / 1) */
   int (*finish)(void* self);                                                 /* jxlt_synchronize */
 } jxlt_slab_ops;
 int jxlt_shard_encode_ops(jxlt_shard_group* group, const jxlt_slab_ops* ops, size_t xsize, size_t ysize,

@@ -33,11 +33,11 @@ HIP_SYMBOLS = ["jxlt_context_create", "jxlt_context_destroy", "jxlt_last_error",
                "jxlt_device_count", "jxlt_bind_thread_near_device",
                "jxlt_image_upload", "jxlt_image_set_device", "jxlt_image_upload_pfm", "jxlt_image_set_device_pfm", "jxlt_image_attach_host", "jxlt_image_attach_host_pfm", "jxlt_image_size", "jxlt_pinned_alloc",
                "jxlt_pinned_free", "jxlt_pinned_register", "jxlt_pinned_unregister", "jxlt_encode_enqueue", "jxlt_set_strategy_distance",
-               "jxlt_fetch_side_info", "jxlt_fetch_histograms", "jxlt_fetch_dc_histogram", "jxlt_pack_ac_sections", "jxlt_pack_sections",
-               "jxlt_pack_sections_sizes", "jxlt_pack_sections_copy", "jxlt_pack_sections_place", "jxlt_pack_measure", "jxlt_pack_measure_begin", "jxlt_pack_measure_only", "jxlt_release_cached_memory", "jxlt_pack_write_begin", "jxlt_histograms_ready", "jxlt_pack_measured", "jxlt_pack_write",
+               "jxlt_fetch_histograms", "jxlt_fetch_dc_histogram", "jxlt_histograms_ready",
+               "jxlt_pack_begin", "jxlt_pack_sizes", "jxlt_pack_deliver", "jxlt_release_cached_memory",
                "jxlt_output_buffer",
                "jxlt_synchronize", "jxlt_fetch_result", "jxlt_kernel_times", "jxlt_encode_stats"]
-HIP_SYMBOLS_TESTING = ["jxlt_debug_fetch"]
+HIP_SYMBOLS_TESTING = ["jxlt_debug_fetch", "jxlt_fetch_side_info", "jxlt_pack_sections"]
 HOST_SYMBOLS = ["jxlt_compute_distance_params", "jxlt_assemble_frame", "jxlt_assemble_frame_groups",
                 "jxlt_encode_file_planar", "jxlt_encode_pfm_file", "jxlt_emulate_reference_static_constants", "jxlt_emulate_reference_single_symbol_codes", "jxlt_encode_resident", "jxlt_encode_resident_view", "jxlt_write_file_header", "jxlt_build_code_tables", "jxlt_finish_frame",
                 "jxlt_free", "jxlt_batch_encoder_create", "jxlt_batch_encoder_create_multi",

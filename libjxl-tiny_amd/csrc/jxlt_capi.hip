@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 
 #include <mutex>
@@ -114,11 +115,12 @@ struct jxlt_context {
     DeviceBuf<uint64_t> sec_byte_off, tile_base;
     DeviceBuf<PackTileInfo> tile_info;
     DeviceBuf<uint8_t> packed;  // the sections at their final byte offsets
-    PinnedBuf<uint64_t> h_sec_byte_off, h_tile_base;  // (h_sec_byte_off: the same layout as sec_byte_off)
+    PinnedBuf<uint64_t> h_sec_byte_off;  // (the same layout as sec_byte_off; filled by publish_kernel)
+    DeviceBuf<uint32_t> launch_sec_end;  // sections complete behind each writing launch (pack_tile_finalize_kernel)
+    uint32_t pack_seq = 0;               // measuring passes of this kind so far: what the sizes' flag carries
     static size_t SizesWords(size_t nsec) { return nsec + 1 + (nsec + 1) / 2; }
     uint32_t* sec_bits(size_t nsec) const { return reinterpret_cast<uint32_t*>(sec_byte_off.p + nsec + 1); }
     uint32_t* h_sec_bits(size_t nsec) const { return reinterpret_cast<uint32_t*>(h_sec_byte_off.p + nsec + 1); }
-    hipEvent_t tile_base_fetched = nullptr;  // h_tile_base holds the plan's tile_base
     size_t max_tiles = 0;        // of the measuring pass (bounds the writing launches)
     bool writes_queued = false;  // the writing launches of the last measuring pass are queued
     PinnedBuf<uint8_t> h_packed;
@@ -131,12 +133,28 @@ struct jxlt_context {
     int launches = 0;
     uint32_t launch_t0[kMaxLaunches + 1] = {};
     hipEvent_t launch_done[kMaxLaunches] = {};
-    hipEvent_t measured = nullptr;  // the host mirrors of the measuring pass are valid
     hipEvent_t finalized = nullptr; // the measuring pass's kernels are done (the mirrors' copies wait for it)
     hipEvent_t plan_done = nullptr; // the tile plan, when it was queued on another stream than the measuring pass
     bool plan_elsewhere = false;
   } pack[2];
   PinnedBuf<uint8_t> h_output;  // jxlt_output_buffer
+  // What kernels tell the host without a copy command and an event in between (publish_kernel, pack_deliver_kernel):
+  // sequence words in page-locked memory that the host polls, every word in a cache line of its own.
+  struct HostMail {
+    uint32_t dc_hist_seq;  // = seq: the DC histogram (h_hist + 4096) and the root-table overflow counts are there
+    uint32_t pad0[15];
+    uint32_t ac_hist_seq;  // = seq: the AC histogram (h_hist) and token_total are there
+    uint32_t pad1[15];
+    uint32_t sizes_seq[2][16];  // [kind][0] = pack[kind].pack_seq: h_sec_byte_off of that kind is complete
+    uint32_t delivered_seq;     // = deliver_seq: every hand-over kernel queued so far has finished
+    uint32_t pad2[15];
+    unsigned long long token_total;  // records of all AC groups (sizes the packing's tile arrays)
+  };
+  PinnedBuf<HostMail> mail;
+  uint32_t seq = 0;          // encodes enqueued on this context
+  uint32_t deliver_seq = 0;  // hand-over kernels with a completion flag queued so far
+  bool deliveries_pending = false;
+  DeviceBuf<uint32_t> deliver_counter;
 
   // pinned host mirrors
   PinnedBuf<int16_t> h_quant_dc[3];
@@ -154,24 +172,21 @@ struct jxlt_context {
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   // jxlt_pack_write: packing on `stream`, chunked copies to the destination on `copy_stream`
   hipStream_t copy_stream = nullptr;
-  hipEvent_t dc_hist_ready = nullptr;  // DC histogram of the last enqueue is in h_hist
   bool dc_elementwise_split = false;
   hipEvent_t dc_elementwise_done = nullptr;  // (resident frames: dc_elementwise_kernel runs beside the two chain kernels)
   hipEvent_t dc_kernels_done = nullptr;  // (the small downloads wait for their kernels on the copy stream, not in front of the next kernel)
-  hipEvent_t ac_hist_ready = nullptr;  // AC histogram + total token count of the last enqueue are in their mirrors
   // Root-table overflow of tile_kernel (a quantised magnitude >= kSqrtLutSize): the tiles concerned are redone by
   // tile*_kernel_redo right behind it; their number reaches the host with the first synchronisation point.
   DeviceBuf<uint32_t> lut_overflow;    // per tile_kernel launch of the frame: tiles redone with computed roots
   DeviceBuf<uint32_t> overflow_tiles;  // their indices
   DeviceBuf<uint32_t> dc_chain_summary;
   PinnedBuf<uint32_t> h_lut_overflow;
-  hipEvent_t overflow_ready = nullptr;
   jxlt_params last_params = {};
   bool overflow_checked = true;
   size_t overflow_slabs = 0;   // launches of the last encode
   uint32_t exact_reruns = 0;   // encodes of this context in which some tile was redone
   uint32_t tiles_redone = 0;   // ... tiles of the last encode
-  bool copies_pending = false;
+  bool copies_pending = false;  // (hipMemcpyAsync on the copy stream: the raw-token / debug routes only)
   bool profiled = false;
   bool counted = false;  // DeviceBlockCache knows this context as a living one
 };
@@ -403,16 +418,21 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
     if (e == hipSuccess) e = hipEventCreate(&ev);
   for (auto& ev : ctx->stage_done)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->dc_hist_ready, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->dc_kernels_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->dc_elementwise_done, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ac_hist_ready, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->overflow_ready, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&ctx->mail.p), sizeof(jxlt_context::HostMail), hipHostMallocDefault);
+  if (e == hipSuccess) {
+    ctx->mail.cap = 1;
+    memset(ctx->mail.p, 0, sizeof(jxlt_context::HostMail));
+    e = hipMalloc(reinterpret_cast<void**>(&ctx->deliver_counter.p), 64);
+  }
+  if (e == hipSuccess) {
+    ctx->deliver_counter.cap = 16;
+    e = hipMemset(ctx->deliver_counter.p, 0, 64);
+  }
   for (auto& ps : ctx->pack) {
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ps.measured, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ps.finalized, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ps.plan_done, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ps.tile_base_fetched, hipEventDisableTiming);
     for (auto& ev : ps.launch_done)
       if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   }
@@ -473,7 +493,7 @@ void jxlt_context_destroy(jxlt_context* ctx) {
     FreeDevice(&ps.tile_base);
     FreeDevice(&ps.tile_info);
     FreeDevice(&ps.packed);
-    FreePinned(&ps.h_tile_base);
+    FreeDevice(&ps.launch_sec_end);
     FreePinned(&ps.h_sec_byte_off);
     FreePinned(&ps.h_packed);
     FreePinned(&ps.h_code_table);
@@ -492,18 +512,16 @@ void jxlt_context_destroy(jxlt_context* ctx) {
   for (auto& ev : ctx->ev)
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ps : ctx->pack) {
-    if (ps.measured) (void)hipEventDestroy(ps.measured);
     if (ps.finalized) (void)hipEventDestroy(ps.finalized);
     if (ps.plan_done) (void)hipEventDestroy(ps.plan_done);
-    if (ps.tile_base_fetched) (void)hipEventDestroy(ps.tile_base_fetched);
     for (auto& ev : ps.launch_done)
       if (ev) (void)hipEventDestroy(ev);
   }
-  if (ctx->dc_hist_ready) (void)hipEventDestroy(ctx->dc_hist_ready);
+  FreePinned(&ctx->mail);
+  if (ctx->deliver_counter.p) (void)hipFree(ctx->deliver_counter.p);
+  ctx->deliver_counter.p = nullptr;
   if (ctx->dc_kernels_done) (void)hipEventDestroy(ctx->dc_kernels_done);
   if (ctx->dc_elementwise_done) (void)hipEventDestroy(ctx->dc_elementwise_done);
-  if (ctx->ac_hist_ready) (void)hipEventDestroy(ctx->ac_hist_ready);
-  if (ctx->overflow_ready) (void)hipEventDestroy(ctx->overflow_ready);
   FreeDevice(&ctx->lut_overflow);
   FreeDevice(&ctx->overflow_tiles);
   FreeDevice(&ctx->dc_chain_summary);
@@ -881,6 +899,72 @@ int jxlt_image_size(const jxlt_context* ctx, size_t* xsize, size_t* ysize) {
 namespace {
 int EnqueuePlan(jxlt_context* ctx, int kind, uint64_t rec_bound, hipStream_t stream);  // (below)
 
+// Waits until a kernel has stored `want` to a sequence word in page-locked memory (HostMail).  Spins: the waits
+// inside a frame are fractions of a millisecond, and the word is seen ~6 us earlier than an event would be
+// (tools/d2h_probe.hip).  A device fault would leave the word unwritten for ever: the stream is asked for errors
+// every couple of milliseconds, and a wait gives up after two minutes.
+int WaitWord(jxlt_context* ctx, const uint32_t* word, uint32_t want, hipStream_t stream, const char* what) {
+  const volatile uint32_t* w = word;
+  if (*w == want) return JXLT_OK;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto next_check = t0 + std::chrono::milliseconds(2);
+  for (;;) {
+    for (int spin = 0; spin < 256; spin++) {
+      if (*w == want) return JXLT_OK;
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    const auto now = std::chrono::steady_clock::now();
+    if (now < next_check) continue;
+    next_check = now + std::chrono::milliseconds(2);
+    const hipError_t e = hipStreamQuery(stream);
+    if (e != hipSuccess && e != hipErrorNotReady) {
+      ctx->error = std::string(what) + ": " + hipGetErrorString(e);
+      return JXLT_ERR_NO_DEVICE;
+    }
+    if (e == hipSuccess && *w != want) {
+      // the stream has drained: give the word's store a moment to arrive, then it never will
+      std::this_thread::sleep_for(std::chrono::milliseconds(1));
+      if (*w == want) return JXLT_OK;
+      if (hipStreamQuery(stream) == hipSuccess && *w != want &&
+          now - t0 > std::chrono::milliseconds(200)) {
+        ctx->error = std::string(what) + ": the device finished without reporting";
+        return JXLT_ERR_INTERNAL;
+      }
+    }
+    if (now - t0 > std::chrono::seconds(120)) {
+      ctx->error = std::string(what) + ": timed out";
+      return JXLT_ERR_INTERNAL;
+    }
+  }
+}
+
+// publish_kernel on `stream`: up to kPublishSegments (device source, host destination, dwords) pairs, an optional
+// 64-bit word, then `seq` to the host word `flag`.
+struct PublishSeg {
+  const void* src;
+  void* dst;
+  size_t words;
+};
+int EnqueuePublish(jxlt_context* ctx, hipStream_t stream, const PublishSeg* segs, int nsegs, const unsigned long long* src64,
+                   unsigned long long* dst64, uint32_t* flag, uint32_t seq) {
+  PublishArgs P;
+  memset(&P, 0, sizeof(P));
+  for (int i = 0; i < nsegs && i < kPublishSegments; i++) {
+    P.src[i] = static_cast<const uint32_t*>(segs[i].src);
+    P.dst[i] = static_cast<uint32_t*>(segs[i].dst);
+    P.words[i] = (uint32_t)segs[i].words;
+  }
+  P.src64 = src64;
+  P.dst64 = dst64;
+  P.flag = flag;
+  P.seq = seq;
+  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(kPublishThreads), 0, stream, P);
+  HIP_TRY(ctx, hipGetLastError());
+  return JXLT_OK;
+}
+
 int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   if (!ctx || !params) return JXLT_ERR_INVALID_ARGUMENT;
   if (!ctx->planes[0]) {
@@ -892,6 +976,13 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
     return JXLT_ERR_INVALID_ARGUMENT;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->deliveries_pending) {
+    // (sections of the previous encode may still be leaving the blobs this encode is about to overwrite)
+    const int rcw = WaitWord(ctx, &ctx->mail.p->delivered_seq, ctx->deliver_seq, ctx->copy_stream, "section hand-over");
+    if (rcw != JXLT_OK) return rcw;
+    ctx->deliveries_pending = false;
+  }
+  const uint32_t frame_seq = ++ctx->seq;  // (what this encode's publish kernels store to the host's sequence words)
   const FrameGeom g = MakeGeom(ctx->xsize, ctx->ysize);
   const size_t nblocks = (size_t)g.xsize_blocks * g.ysize_blocks;
   const size_t ntiles = (size_t)g.xsize_tiles * g.ysize_tiles;
@@ -1137,15 +1228,8 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
         hipLaunchKernelGGL(tile_kernel, dim3(slab_tiles), dim3(kTileThreads), extra_lds, ctx->stream, S);
       hipLaunchKernelGGL(tile_kernel_redo, dim3(redo_grid), dim3(kTileThreads), 0, ctx->stream, S);
     }
-    if (sl + 1 == nslabs) {
-      HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-      // (the counts leave on the copy stream: a download in front of the DC-group kernels costs them 10 us)
-      HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[1], 0));
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->h_lut_overflow.p, ctx->lut_overflow.p, nslabs * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                                  ctx->copy_stream));
-      HIP_TRY(ctx, hipEventRecord(ctx->overflow_ready, ctx->copy_stream));
-      ctx->copies_pending = true;
-    }
+    // (the counts of redone tiles leave with the DC histogram, below)
+    if (sl + 1 == nslabs) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->tile_done[sl], ctx->stream));
     if (!pieces[sl].ends_dc_row) continue;
     // ---- tokenisation of the row(s) of DC groups this piece completes, on the aux stream
@@ -1176,13 +1260,15 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
     hipLaunchKernelGGL(dc_chain_kernel, dim3((unsigned)(slab_dc * kDcChainChunks)), dim3(kDcChainThreads), 0,
                        tok_stream, D);
     if (sl + 1 == nslabs) {
-      // (likewise: the DC histogram leaves beside token_kernel, not in front of it)
+      // The DC histogram (and the counts of the tiles redone with computed roots) leaves beside token_kernel, not
+      // in front of it: one small kernel on the copy stream stores both to the host's page-locked memory and then
+      // the frame's sequence number to the word the host polls.
       HIP_TRY(ctx, hipEventRecord(ctx->dc_kernels_done, tok_stream));
       HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->dc_kernels_done, 0));
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hist.p + 64 * 64, ctx->hist.p + 64 * 64, 64 * 64 * sizeof(uint32_t),
-                                  hipMemcpyDeviceToHost, ctx->copy_stream));
-      HIP_TRY(ctx, hipEventRecord(ctx->dc_hist_ready, ctx->copy_stream));
-      ctx->copies_pending = true;
+      const PublishSeg segs[2] = {{ctx->hist.p + 64 * 64, ctx->h_hist.p + 64 * 64, 64 * 64},
+                                  {ctx->lut_overflow.p, ctx->h_lut_overflow.p, nslabs}};
+      const int rcp = EnqueuePublish(ctx, ctx->copy_stream, segs, 2, nullptr, nullptr, &ctx->mail.p->dc_hist_seq, frame_seq);
+      if (rcp != JXLT_OK) return rcp;
     }
     const size_t ty0 = dc_row0 * 2048, ty1 = std::min(ctx->ysize, dc_row1 * 2048);  // pixel rows being tokenised
     const size_t g0 = (ty0 / 256) * (size_t)g.xsize_groups;
@@ -1203,13 +1289,15 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   }
   HIP_TRY(ctx, hipGetLastError());
   ctx->host_src_kind = 0;  // the frame is resident now (a redo with exact roots must not fetch it again)
-  // AC histogram + total token count leave right behind the last token_kernel
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hist.p, ctx->hist.p, 64 * 64 * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                              tok_stream));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_group_off.p + ngroups, ctx->group_off.p + ngroups, sizeof(uint64_t),
-                              hipMemcpyDeviceToHost, tok_stream));
-  HIP_TRY(ctx, hipEventRecord(ctx->ac_hist_ready, tok_stream));
+  // AC histogram + total token count leave right behind the last token_kernel (publish_kernel: no copy command, no
+  // event -- the host polls the sequence word)
   HIP_TRY(ctx, hipEventRecord(ctx->aux_done, tok_stream));
+  {
+    const PublishSeg seg = {ctx->hist.p, ctx->h_hist.p, 64 * 64};
+    const int rcp = EnqueuePublish(ctx, tok_stream, &seg, 1, reinterpret_cast<const unsigned long long*>(ctx->group_off.p + ngroups),
+                                   &ctx->mail.p->token_total, &ctx->mail.p->ac_hist_seq, frame_seq);
+    if (rcp != JXLT_OK) return rcp;
+  }
   // whatever is queued on the main stream from here on (section packing) comes after the tokenisation
   if (tok_stream != ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_done, 0));
   // (the DC-group sections' packing reads what dc_elementwise_kernel wrote)
@@ -1255,7 +1343,10 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
 // (statistics only: jxlt_encode_stats; the redo itself needs nothing from the host).
 int ResolveRootTableOverflow(jxlt_context* ctx) {
   if (!ctx->encoded || ctx->overflow_checked) return JXLT_OK;
-  HIP_TRY(ctx, hipEventSynchronize(ctx->overflow_ready));
+  {  // (the counts arrive with the DC histogram)
+    const int rcw = WaitWord(ctx, &ctx->mail.p->dc_hist_seq, ctx->seq, ctx->copy_stream, "device pipeline");
+    if (rcw != JXLT_OK) return rcw;
+  }
   ctx->overflow_checked = true;
   uint32_t n = 0;
   for (size_t i = 0; i < ctx->overflow_slabs; i++) n += ctx->h_lut_overflow.p[i];
@@ -1290,6 +1381,21 @@ int jxlt_synchronize(jxlt_context* ctx) {
   {
     const int rc0 = ResolveRootTableOverflow(ctx);
     if (rc0 != JXLT_OK) return rc0;
+  }
+  if (ctx->deliveries_pending) {
+    // The last hand-over kernel stands behind everything the frame has queued (it waits for the last writing
+    // launch, which stands behind the whole pipeline on the main stream): its word is the frame's completion, seen
+    // without a call into the runtime.
+    const int rcw = WaitWord(ctx, &ctx->mail.p->delivered_seq, ctx->deliver_seq, ctx->copy_stream, "section hand-over");
+    if (rcw != JXLT_OK) return rcw;
+    ctx->deliveries_pending = false;
+    // (the section sizes of both kinds have been published by kernels in front of the hand-over's writes)
+    for (int kind = 0; kind < 2; kind++) {
+      if (ctx->pack[kind].measured_sections == 0) continue;
+      const int rcs = WaitWord(ctx, &ctx->mail.p->sizes_seq[kind][0], ctx->pack[kind].pack_seq, ctx->aux_stream, "section sizes");
+      if (rcs != JXLT_OK) return rcs;
+    }
+    if (!ctx->copies_pending) return JXLT_OK;
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->copies_pending) {
@@ -1403,7 +1509,7 @@ int jxlt_fetch_dc_histogram(jxlt_context* ctx, const uint32_t** dc_histogram) {
     const int rc0 = ResolveRootTableOverflow(ctx);
     if (rc0 != JXLT_OK) return rc0;
   }
-  HIP_TRY(ctx, hipEventSynchronize(ctx->dc_hist_ready));
+  // (ResolveRootTableOverflow above has waited for the word that announces the DC histogram)
   *dc_histogram = ctx->h_hist.p + 64 * 64;
   return JXLT_OK;
 }
@@ -1421,9 +1527,12 @@ int jxlt_fetch_histograms(jxlt_context* ctx, const uint32_t** ac_histograms, con
   }
   const FrameGeom& g = ctx->geom;
   const size_t ngroups = (size_t)g.xsize_groups * g.ysize_groups;
-  (void)ngroups;
-  // (both halves were copied right behind their kernels, see jxlt_encode_enqueue)
-  HIP_TRY(ctx, hipEventSynchronize(ctx->ac_hist_ready));
+  // (both halves were published right behind their kernels, see jxlt_encode_enqueue)
+  {
+    const int rcw = WaitWord(ctx, &ctx->mail.p->ac_hist_seq, ctx->seq, ctx->stream, "tokenisation");
+    if (rcw != JXLT_OK) return rcw;
+  }
+  ctx->h_group_off.p[ngroups] = ctx->mail.p->token_total;
   ctx->offsets_fetched = true;
   if (ac_histograms) *ac_histograms = ctx->h_hist.p;
   if (dc_histograms) *dc_histograms = ctx->h_hist.p + 64 * 64;
@@ -1435,6 +1544,7 @@ namespace {
 PackTileArgs TileArgsOf(jxlt_context* ctx, int kind, size_t nsec) {
   jxlt_context::PackSet& ps = ctx->pack[kind];
   PackTileArgs P;
+  memset(&P, 0, sizeof(P));
   P.records = kind == 1 ? ctx->tokens.p : ctx->dc_records.p;
   P.sec_rec_offset = kind == 1 ? ctx->group_off.p : ctx->dc_rec_off.p;
   P.sec_rec_count = kind == 1 ? nullptr : ctx->dc_count.p;
@@ -1450,6 +1560,9 @@ PackTileArgs TileArgsOf(jxlt_context* ctx, int kind, size_t nsec) {
   P.out = ps.packed.p;
   P.tile_first = 0;
   P.tile_end = 0xFFFFFFFFu;
+  P.launches = (uint32_t)ps.launches;
+  for (int i = 0; i <= ps.launches && i <= kPackMaxLaunches; i++) P.launch_t0[i] = ps.launch_t0[i];
+  P.launch_sec_end = ps.launch_sec_end.p;
   return P;
 }
 
@@ -1475,6 +1588,7 @@ int EnqueuePlan(jxlt_context* ctx, int kind, uint64_t rec_bound, hipStream_t str
   ENSURE(tile_base, nsec + 1);
   ENSURE(tile_bits, max_tiles);
   ENSURE(tile_info, max_tiles);
+  ENSURE(launch_sec_end, kPackMaxLaunches);
 #undef ENSURE
   const PackTileArgs P = TileArgsOf(ctx, kind, nsec);
   const unsigned sec_blocks = (unsigned)((nsec + 255) / 256);
@@ -1483,23 +1597,19 @@ int EnqueuePlan(jxlt_context* ctx, int kind, uint64_t rec_bound, hipStream_t str
                      ps.tile_base.p, (int)nsec);
   hipLaunchKernelGGL(pack_tile_plan_kernel, dim3(sec_blocks), dim3(256), 0, stream, P);
   HIP_TRY(ctx, hipGetLastError());
-  // (which sections a launch of the writing pass completes -- EnqueueCopies -- follows from the plan alone: the
-  // host has it long before the sizes)
-  if ((rc = EnsurePinned(ctx, &ps.h_tile_base, nsec + 1)) != JXLT_OK) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(ps.h_tile_base.p, ps.tile_base.p, (nsec + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost,
-                              stream));
-  HIP_TRY(ctx, hipEventRecord(ps.tile_base_fetched, stream));
+  // (which sections a launch of the writing pass completes follows from the plan and is worked out on the device --
+  // pack_tile_finalize_kernel --: the host does not fetch the plan any more)
   ps.planned = true;
   ps.plan_elsewhere = stream != ctx->stream;
   if (ps.plan_elsewhere) HIP_TRY(ctx, hipEventRecord(ps.plan_done, stream));
   return JXLT_OK;
 }
 
-// Measuring pass for the sections of `kind` (asynchronous): exact bit / byte size of every
-// section, byte offsets, tile bookkeeping; results are copied to the pinned mirrors.
+// Measuring pass for the sections of `kind` (asynchronous): exact bit / byte size of every section, byte offsets,
+// tile bookkeeping; the sizes are published to the host's page-locked mirror by a kernel (its sequence word:
+// HostMail::sizes_seq).  The writing launches follow at once (they need nothing from the host).
 int EnqueueWrites(jxlt_context* ctx, int kind);  // (below)
-// queue_writes = false: the writing launches are left to a later EnqueueWrites (jxlt_pack_write_begin).
-int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table, bool queue_writes = true) {
+int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
   jxlt_context::PackSet& ps = ctx->pack[kind];
   const size_t nsec = NumSections(ctx, kind);
   // upper bound of the record count (the exact per-section counts live on the device)
@@ -1521,52 +1631,11 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table, bool
   const uint64_t blob_bound = rec_bound * 4 + nsec * 8 + 64;
   if (ps.packed.cap < blob_bound && (rc = EnsureDevice(ctx, &ps.packed, blob_bound + blob_bound / 8)) != JXLT_OK)
     return rc;
-  const PackTileArgs P = TileArgsOf(ctx, kind, nsec);
-  hipLaunchKernelGGL(pack_tile_measure_kernel,
-                     dim3((unsigned)((max_tiles + kPackMeasureTilesPerGroup - 1) / kPackMeasureTilesPerGroup)),
-                     dim3(kPackThreads), 0, ctx->stream, P);
-  hipLaunchKernelGGL(pack_tile_offsets_kernel,
-                     dim3((unsigned)((nsec + kPackOffsetsSectionsPerGroup - 1) / kPackOffsetsSectionsPerGroup)),
-                     dim3(64 * kPackOffsetsSectionsPerGroup), 0, ctx->stream, P);
-  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, (const uint32_t*)ps.sec_bytes.p,
-                     ps.sec_byte_off.p, (int)nsec);
-  // The sizes are final behind the scan (the last kernel of the pass only moves the tiles to their places): ONE
-  // download -- offsets and bit counts lie behind each other -- by the auxiliary stream (idle by now), beside that
-  // kernel; on the main stream it would stand between the measuring kernels and the writing kernels queued below.
-  // (Until round 3: three downloads behind the last kernel; the host had the sizes 25 us later, and the link waited
-  // for the first copy that long.)
-  HIP_TRY(ctx, hipEventRecord(ps.finalized, ctx->stream));
-  HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ps.finalized, 0));
-  HIP_TRY(ctx, hipMemcpyAsync(ps.h_sec_byte_off.p, ps.sec_byte_off.p,
-                              jxlt_context::PackSet::SizesWords(nsec) * sizeof(uint64_t), hipMemcpyDeviceToHost,
-                              ctx->aux_stream));
-  HIP_TRY(ctx, hipEventRecord(ps.measured, ctx->aux_stream));
-  hipLaunchKernelGGL(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), 0, ctx->stream, P);
-  HIP_TRY(ctx, hipGetLastError());
-  // (the plan is used up: the kernel above has replaced every tile's section index by the section's bit position.  A
-  // second measuring pass of the same encode -- jxlt_pack_sections behind a complete encode -- plans again; until
-  // round 3 it did not, read section offsets at those bit positions and wrote wherever they pointed.)
-  ps.planned = false;
-  ps.measured_sections = nsec;
-  ps.max_tiles = max_tiles;
-  ps.writes_queued = false;
-  return queue_writes ? EnqueueWrites(ctx, kind) : JXLT_OK;
-}
-
-// The writing pass of the sections of `kind` behind their measuring pass (asynchronous).
-int EnqueueWrites(jxlt_context* ctx, int kind) {
-  jxlt_context::PackSet& ps = ctx->pack[kind];
-  if (ps.writes_queued) return JXLT_OK;
-  ps.writes_queued = true;
-  const size_t nsec = ps.measured_sections;
-  const size_t max_tiles = ps.max_tiles;
-  // The writing pass needs nothing from the host (tile positions are in device memory), so it is
-  // queued right here, in a few launches over shares of the tile range (an upper bound: the
-  // kernel clamps to the real tile count); the host picks the section sizes up meanwhile and
-  // later only adds the copies (EnqueueCopies).
+  // The writing pass runs as a few launches over shares of the tile range (an upper bound: the kernels clamp to
+  // the real tile count), each followed by the hand-over of the sections it has completed (EnqueueDeliver).
   // The shares GROW (1 : 2 : 4): the kernels write faster than the link carries the bytes away (16384^2: 0.21 ms
-  // against 0.35 ms for the 20 MB of AC sections), so the copies are the critical path and what they cannot
-  // overlap is the FIRST launch; every later share only has to be written before the copy in front of it ends.
+  // against 0.35 ms for the 20 MB of AC sections), so the hand-over is the critical path and what it cannot
+  // overlap is the FIRST launch; every later share only has to be written before the hand-over in front of it ends.
   // (Time from the AC sizes to the last byte in host memory, tools/pack_sweep.sh: five shrinking shares 0.42 ms,
   // five equal 0.41, five growing 0.39-0.40, four 1:2:4:8 0.38, three 1:2:4 0.37, two 1:4 0.42.)
   // (experiment knobs, tools/: JXLT_PACK_LAUNCHES=<n>, JXLT_PACK_GROWTH=<percent, each share against the one before>)
@@ -1585,6 +1654,46 @@ int EnqueueWrites(jxlt_context* ctx, int kind) {
                                       : (double)i / ps.launches;
     ps.launch_t0[i] = i == ps.launches ? (uint32_t)max_tiles : (uint32_t)((double)max_tiles * share);
   }
+  const PackTileArgs P = TileArgsOf(ctx, kind, nsec);
+  hipLaunchKernelGGL(pack_tile_measure_kernel,
+                     dim3((unsigned)((max_tiles + kPackMeasureTilesPerGroup - 1) / kPackMeasureTilesPerGroup)),
+                     dim3(kPackThreads), 0, ctx->stream, P);
+  hipLaunchKernelGGL(pack_tile_offsets_kernel,
+                     dim3((unsigned)((nsec + kPackOffsetsSectionsPerGroup - 1) / kPackOffsetsSectionsPerGroup)),
+                     dim3(64 * kPackOffsetsSectionsPerGroup), 0, ctx->stream, P);
+  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, (const uint32_t*)ps.sec_bytes.p,
+                     ps.sec_byte_off.p, (int)nsec);
+  // The sizes are final behind the scan (the last kernel of the pass only moves the tiles to their places): they
+  // leave for the host by the auxiliary stream (idle by now), beside that kernel -- offsets and bit counts lie
+  // behind each other, one publish_kernel stores them to the page-locked mirror and then the pass's number to the
+  // word the host polls.  (Rounds 1-3: hipMemcpyAsync + event; the copy alone took 20 us of device time.)
+  HIP_TRY(ctx, hipEventRecord(ps.finalized, ctx->stream));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ps.finalized, 0));
+  ps.pack_seq++;
+  {
+    const PublishSeg seg = {ps.sec_byte_off.p, ps.h_sec_byte_off.p, jxlt_context::PackSet::SizesWords(nsec) * 2};
+    if ((rc = EnqueuePublish(ctx, ctx->aux_stream, &seg, 1, nullptr, nullptr, &ctx->mail.p->sizes_seq[kind][0],
+                             ps.pack_seq)) != JXLT_OK)
+      return rc;
+  }
+  hipLaunchKernelGGL(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), 0, ctx->stream, P);
+  HIP_TRY(ctx, hipGetLastError());
+  // (the plan is used up: the kernel above has replaced every tile's section index by the section's bit position.  A
+  // second measuring pass of the same encode plans again; until round 3 it did not, read section offsets at those
+  // bit positions and wrote wherever they pointed.)
+  ps.planned = false;
+  ps.measured_sections = nsec;
+  ps.max_tiles = max_tiles;
+  ps.writes_queued = false;
+  return EnqueueWrites(ctx, kind);
+}
+
+// The writing pass of the sections of `kind` behind their measuring pass (asynchronous).
+int EnqueueWrites(jxlt_context* ctx, int kind) {
+  jxlt_context::PackSet& ps = ctx->pack[kind];
+  if (ps.writes_queued) return JXLT_OK;
+  ps.writes_queued = true;
+  const size_t nsec = ps.measured_sections;
   for (int i = 0; i < ps.launches; i++) {
     PackTileArgs W = TileArgsOf(ctx, kind, nsec);
     W.tile_first = ps.launch_t0[i];
@@ -1607,125 +1716,69 @@ void FillMeasured(jxlt_context* ctx, int kind, jxlt_packed_sections* out) {
   out->num_sections = ps.measured_sections;
 }
 
-// The copies of the measured and (being) written sections of `kind` to `dst` (asynchronous, on the
-// copy stream): after every launch of the writing pass the whole sections it completed leave,
-// while later launches are still packing.  Needs the host mirrors (wait for ps.measured first).
-int EnqueueCopies(jxlt_context* ctx, int kind, uint8_t* dst) {
+// The hand-over of the measured and (being) written sections of `kind` to `dst` (asynchronous, kernels on the copy
+// stream that store to the destination themselves -- page-locked host memory or device memory): behind every launch
+// of the writing pass the whole sections it completed leave, while later launches are still packing.  The kernels
+// read their byte ranges from the device-side layout: the host does not have to know a size before the bytes leave.
+// runs == nullptr: all sections back to back, starting at dst (end_aligned: ENDING at dst).
+int EnqueueDeliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_section_run* runs, size_t nruns, int end_aligned) {
   jxlt_context::PackSet& ps = ctx->pack[kind];
   const size_t nsec = ps.measured_sections;
-  if (!ps.writes_queued) {
-    const int rcw = EnqueueWrites(ctx, kind);
-    if (rcw != JXLT_OK) return rcw;
-  }
-  HIP_TRY(ctx, hipEventSynchronize(ps.measured));
-  HIP_TRY(ctx, hipEventSynchronize(ps.tile_base_fetched));
-  const uint64_t* off = ps.h_sec_byte_off.p;
-  const uint64_t* tb = ps.h_tile_base.p;
-  size_t s_lo = 0;
-  for (int i = 0; i < ps.launches; i++) {
-    // sections whose tiles all lie in front of the end of launch i
-    size_t s_hi = nsec;
-    if (i + 1 < ps.launches) {
-      s_hi = (size_t)(std::upper_bound(tb, tb + nsec + 1, (uint64_t)ps.launch_t0[i + 1]) - tb) - 1;
-      if (s_hi < s_lo) s_hi = s_lo;
-    }
-    if (off[s_hi] > off[s_lo]) {
+  DeliverArgs D;
+  memset(&D, 0, sizeof(D));
+  D.blob = ps.packed.p;
+  D.sec_byte_offset = ps.sec_byte_off.p;
+  D.launch_sec_end = ps.launch_sec_end.p;
+  D.dst = dst;
+  D.nsec = (int)nsec;
+  D.end_aligned = end_aligned;
+  D.counter = ctx->deliver_counter.p;
+  // workgroups per hand-over kernel: the link is saturated from 64 on (tools/d2h_probe.hip); small shares take fewer
+  auto grid_for = [&](size_t tiles) { return (unsigned)std::min<size_t>(256, std::max<size_t>(8, tiles / 2)); };
+  if (runs == nullptr) {
+    for (int i = 0; i < ps.launches; i++) {
       HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ps.launch_done[i], 0));
-      HIP_TRY(ctx, hipMemcpyAsync(dst + off[s_lo], ps.packed.p + off[s_lo], off[s_hi] - off[s_lo], hipMemcpyDefault,
-                                  ctx->copy_stream));
-      ctx->copies_pending = true;
+      D.launch = i;
+      D.nruns = 0;
+      const bool last = i + 1 == ps.launches;
+      D.flag = last ? &ctx->mail.p->delivered_seq : nullptr;
+      D.seq = last ? ++ctx->deliver_seq : 0;
+      hipLaunchKernelGGL(pack_deliver_kernel, dim3(grid_for(ps.launch_t0[i + 1] - ps.launch_t0[i])), dim3(kDeliverThreads), 0,
+                         ctx->copy_stream, D);
+      HIP_TRY(ctx, hipGetLastError());
     }
-    s_lo = s_hi;
+  } else {
+    for (size_t r = 0; r < nruns; r++) {
+      if ((size_t)runs[r].first_section + runs[r].num_sections > nsec) {
+        ctx->error = "jxlt_pack_deliver: a run names sections the measuring pass did not see";
+        return JXLT_ERR_INVALID_ARGUMENT;
+      }
+    }
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ps.launch_done[ps.launches - 1], 0));
+    D.launch = -1;
+    for (size_t r0 = 0; r0 < nruns; r0 += kDeliverMaxRuns) {
+      const size_t n = std::min<size_t>(kDeliverMaxRuns, nruns - r0);
+      D.nruns = (int)n;
+      for (size_t r = 0; r < n; r++) {
+        D.runs[r].first = runs[r0 + r].first_section;
+        D.runs[r].count = runs[r0 + r].num_sections;
+        D.runs[r].dst_offset = runs[r0 + r].dst_offset;
+      }
+      const bool last = r0 + n >= nruns;
+      D.flag = last ? &ctx->mail.p->delivered_seq : nullptr;
+      D.seq = last ? ++ctx->deliver_seq : 0;
+      hipLaunchKernelGGL(pack_deliver_kernel, dim3(grid_for(ps.max_tiles)), dim3(kDeliverThreads), 0, ctx->copy_stream, D);
+      HIP_TRY(ctx, hipGetLastError());
+    }
   }
+  ctx->deliveries_pending = true;
   return JXLT_OK;
 }
 
-int CheckPackCall(jxlt_context* ctx, const char* what) {
-  if (!ctx->encoded || !ctx->offsets_fetched) {
-    ctx->error = std::string(what) + " needs jxlt_encode_enqueue + jxlt_fetch_histograms/side_info first";
-    return JXLT_ERR_INVALID_ARGUMENT;
-  }
-  return JXLT_OK;
+int WaitSizes(jxlt_context* ctx, int kind) {
+  return WaitWord(ctx, &ctx->mail.p->sizes_seq[kind][0], ctx->pack[kind].pack_seq, ctx->aux_stream, "section measuring");
 }
 }  // namespace
-
-int jxlt_pack_sections_sizes(jxlt_context* ctx, int kind, const uint32_t* code_table, jxlt_packed_sections* out) {
-  if (!ctx || !code_table || !out || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
-  int rc = CheckPackCall(ctx, "jxlt_pack_sections_sizes");
-  if (rc != JXLT_OK) return rc;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if ((rc = EnqueueMeasure(ctx, kind, code_table)) != JXLT_OK) return rc;
-  HIP_TRY(ctx, hipEventSynchronize(ctx->pack[kind].measured));
-  FillMeasured(ctx, kind, out);
-  return JXLT_OK;
-}
-
-int jxlt_pack_sections_place(jxlt_context* ctx, int kind, uint8_t* dst) {
-  if (!ctx || !dst || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
-  if (ctx->pack[kind].measured_sections == 0) {
-    ctx->error = "jxlt_pack_sections_place needs jxlt_pack_sections_sizes first";
-    return JXLT_ERR_INVALID_ARGUMENT;
-  }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  return EnqueueCopies(ctx, kind, dst);
-}
-
-int jxlt_pack_sections_copy(jxlt_context* ctx, int kind, uint8_t* dst) {
-  const int rc = jxlt_pack_sections_place(ctx, kind, dst);
-  if (rc != JXLT_OK) return rc;
-  return jxlt_synchronize(ctx);
-}
-
-int jxlt_pack_sections(jxlt_context* ctx, int kind, const uint32_t* code_table, jxlt_packed_sections* out) {
-  int rc = jxlt_pack_sections_sizes(ctx, kind, code_table, out);
-  if (rc != JXLT_OK) return rc;
-  jxlt_context::PackSet& ps = ctx->pack[kind];
-  const uint64_t total_bytes = ps.h_sec_byte_off.p[ps.measured_sections];
-  if (ps.h_packed.cap < total_bytes + 1 &&
-      (rc = EnsurePinned(ctx, &ps.h_packed, total_bytes + total_bytes / 4 + 4096)) != JXLT_OK)
-    return rc;
-  if ((rc = jxlt_pack_sections_copy(ctx, kind, ps.h_packed.p)) != JXLT_OK) return rc;
-  out->bytes = ps.h_packed.p;
-  return JXLT_OK;
-}
-
-int jxlt_pack_measure_begin(jxlt_context* ctx, int kind, const uint32_t* code_table) {
-  if (!ctx || !code_table || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
-  if (!ctx->encoded || (kind == 1 && !ctx->offsets_fetched)) {
-    ctx->error = "jxlt_pack_measure_begin needs jxlt_encode_enqueue (+ jxlt_fetch_histograms for the AC sections) first";
-    return JXLT_ERR_INVALID_ARGUMENT;
-  }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  {
-    const int rc0 = ResolveRootTableOverflow(ctx);
-    if (rc0 != JXLT_OK) return rc0;
-  }
-  return EnqueueMeasure(ctx, kind, code_table);
-}
-
-int jxlt_pack_measure_only(jxlt_context* ctx, int kind, const uint32_t* code_table) {
-  if (!ctx || !code_table || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
-  if (!ctx->encoded || (kind == 1 && !ctx->offsets_fetched)) {
-    ctx->error = "jxlt_pack_measure_only needs jxlt_encode_enqueue (+ jxlt_fetch_histograms for the AC sections) first";
-    return JXLT_ERR_INVALID_ARGUMENT;
-  }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  {
-    const int rc0 = ResolveRootTableOverflow(ctx);
-    if (rc0 != JXLT_OK) return rc0;
-  }
-  return EnqueueMeasure(ctx, kind, code_table, /*queue_writes=*/false);
-}
-
-int jxlt_pack_write_begin(jxlt_context* ctx, int kind) {
-  if (!ctx || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
-  if (ctx->pack[kind].measured_sections == 0) {
-    ctx->error = "jxlt_pack_write_begin needs jxlt_pack_measure_only first";
-    return JXLT_ERR_INVALID_ARGUMENT;
-  }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  return EnqueueWrites(ctx, kind);
-}
 
 int jxlt_histograms_ready(jxlt_context* ctx) {
   if (!ctx) return JXLT_ERR_INVALID_ARGUMENT;
@@ -1733,46 +1786,91 @@ int jxlt_histograms_ready(jxlt_context* ctx) {
     ctx->error = "jxlt_histograms_ready needs jxlt_encode_enqueue first";
     return JXLT_ERR_INVALID_ARGUMENT;
   }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const hipError_t e = hipEventQuery(ctx->ac_hist_ready);
-  if (e == hipSuccess) return 1;
-  if (e == hipErrorNotReady) return 0;
-  HIP_TRY(ctx, e);
-  return 0;
+  // (a read of host memory: no call into the runtime, nothing another encoding thread of the process could wait for)
+  return *(const volatile uint32_t*)&ctx->mail.p->ac_hist_seq == ctx->seq ? 1 : 0;
 }
 
-int jxlt_pack_measure(jxlt_context* ctx, const uint32_t* dc_code_table, const uint32_t* ac_code_table,
-                      jxlt_packed_sections* dc, jxlt_packed_sections* ac) {
-  if (!ctx || !dc || !ac) return JXLT_ERR_INVALID_ARGUMENT;
-  int rc = CheckPackCall(ctx, "jxlt_pack_measure");
-  if (rc != JXLT_OK) return rc;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  // (a kind whose pass was started with jxlt_pack_measure_begin is not measured again)
-  for (int kind = 0; kind < 2; kind++) {
-    const uint32_t* table = kind == 0 ? dc_code_table : ac_code_table;
-    if (!table) {
-      if (ctx->pack[kind].measured_sections == 0) return JXLT_ERR_INVALID_ARGUMENT;
-      continue;
-    }
-    if ((rc = EnqueueMeasure(ctx, kind, table)) != JXLT_OK) return rc;
-  }
-  HIP_TRY(ctx, hipEventSynchronize(ctx->pack[0].measured));
-  HIP_TRY(ctx, hipEventSynchronize(ctx->pack[1].measured));
-  FillMeasured(ctx, 0, dc);
-  FillMeasured(ctx, 1, ac);
-  return JXLT_OK;
-}
-
-int jxlt_pack_write(jxlt_context* ctx, uint8_t* dc_dst, uint8_t* ac_dst) {
-  if (!ctx || !dc_dst || !ac_dst) return JXLT_ERR_INVALID_ARGUMENT;
-  if (ctx->pack[0].measured_sections == 0 || ctx->pack[1].measured_sections == 0) {
-    ctx->error = "jxlt_pack_write needs jxlt_pack_measure first";
+// ---- the packing stage's three calls (include/jxl_tiny_amd.h) -------------------------------------------------
+int jxlt_pack_begin(jxlt_context* ctx, int kind, const uint32_t* code_table) {
+  if (!ctx || !code_table || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
+  if (!ctx->encoded || (kind == 1 && !ctx->offsets_fetched)) {
+    ctx->error = "jxlt_pack_begin needs jxlt_encode_enqueue (+ jxlt_fetch_histograms for the AC sections) first";
     return JXLT_ERR_INVALID_ARGUMENT;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const int rc = EnqueueCopies(ctx, 0, dc_dst);
+  {
+    const int rc0 = ResolveRootTableOverflow(ctx);
+    if (rc0 != JXLT_OK) return rc0;
+  }
+  if (ctx->deliveries_pending && ctx->pack[kind].measured_sections != 0) {
+    // (a second pass of this kind within one encode overwrites the blob the first pass's hand-over reads)
+    const int rcw = WaitWord(ctx, &ctx->mail.p->delivered_seq, ctx->deliver_seq, ctx->copy_stream, "section hand-over");
+    if (rcw != JXLT_OK) return rcw;
+  }
+  return EnqueueMeasure(ctx, kind, code_table);
+}
+
+int jxlt_pack_sizes(jxlt_context* ctx, int kind, jxlt_packed_sections* out) {
+  if (!ctx || !out || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
+  if (ctx->pack[kind].measured_sections == 0) {
+    ctx->error = "jxlt_pack_sizes needs jxlt_pack_begin first";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  const int rc = WaitSizes(ctx, kind);
   if (rc != JXLT_OK) return rc;
-  return EnqueueCopies(ctx, 1, ac_dst);
+  FillMeasured(ctx, kind, out);
+  return JXLT_OK;
+}
+
+int jxlt_pack_deliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_section_run* runs, size_t num_runs,
+                      int end_aligned) {
+  if (!ctx || !dst || (kind != 0 && kind != 1) || (runs == nullptr) != (num_runs == 0) || (runs && end_aligned))
+    return JXLT_ERR_INVALID_ARGUMENT;
+  if (ctx->pack[kind].measured_sections == 0) {
+    ctx->error = "jxlt_pack_deliver needs jxlt_pack_begin first";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // the destination must be memory a kernel can store to: page-locked host memory or device memory
+  hipPointerAttribute_t attr;
+  const hipError_t pe = hipPointerGetAttributes(&attr, dst);
+  (void)hipGetLastError();
+  if (pe != hipSuccess || (attr.type != hipMemoryTypeHost && attr.type != hipMemoryTypeDevice)) {
+    ctx->error = "jxlt_pack_deliver needs page-locked host memory (jxlt_output_buffer / jxlt_pinned_alloc / "
+                 "jxlt_pinned_register) or device memory as destination";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  uint8_t* dev_dst = dst;
+  if (attr.type == hipMemoryTypeHost) {
+    void* mapped = nullptr;
+    if (hipHostGetDevicePointer(&mapped, dst, 0) != hipSuccess || !mapped) {
+      (void)hipGetLastError();
+      ctx->error = "jxlt_pack_deliver: the destination is page-locked but not mapped into the device's address space";
+      return JXLT_ERR_INVALID_ARGUMENT;
+    }
+    dev_dst = static_cast<uint8_t*>(mapped);
+  }
+  return EnqueueDeliver(ctx, kind, dev_dst, runs, num_runs, end_aligned);
+}
+
+// ---- test-suite forms on top of the three calls (include/jxl_tiny_amd_testing.h) -------------------------------
+int jxlt_pack_sections(jxlt_context* ctx, int kind, const uint32_t* code_table, jxlt_packed_sections* out) {
+  if (!ctx || !code_table || !out || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
+  if (!ctx->encoded || !ctx->offsets_fetched) {
+    ctx->error = "jxlt_pack_sections needs jxlt_encode_enqueue + jxlt_fetch_histograms/side_info first";
+    return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  int rc = jxlt_pack_begin(ctx, kind, code_table);
+  if (rc != JXLT_OK || (rc = jxlt_pack_sizes(ctx, kind, out)) != JXLT_OK) return rc;
+  jxlt_context::PackSet& ps = ctx->pack[kind];
+  const uint64_t total_bytes = ps.h_sec_byte_off.p[ps.measured_sections];
+  if (ps.h_packed.cap < total_bytes + 16 &&
+      (rc = EnsurePinned(ctx, &ps.h_packed, total_bytes + total_bytes / 4 + 4096)) != JXLT_OK)
+    return rc;
+  if ((rc = jxlt_pack_deliver(ctx, kind, ps.h_packed.p, nullptr, 0, 0)) != JXLT_OK) return rc;
+  if ((rc = jxlt_synchronize(ctx)) != JXLT_OK) return rc;
+  out->bytes = ps.h_packed.p;
+  return JXLT_OK;
 }
 
 size_t jxlt_release_cached_memory(int device_ordinal) { return DeviceBlockCache::Get().Release(device_ordinal); }
@@ -1781,9 +1879,14 @@ int jxlt_output_buffer(jxlt_context* ctx, size_t bytes, uint8_t** out) {
   if (!ctx || !out) return JXLT_ERR_INVALID_ARGUMENT;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (ctx->h_output.cap < bytes) {
-    if (ctx->copies_pending && ctx->h_output.p) {
-      // sections may be on their way into the buffer (jxlt_pack_sections_place): it grows with its contents
-      HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+    if ((ctx->copies_pending || ctx->deliveries_pending) && ctx->h_output.p) {
+      // sections may be on their way into the buffer (jxlt_pack_deliver): it grows with its contents
+      if (ctx->deliveries_pending) {
+        const int rcw = WaitWord(ctx, &ctx->mail.p->delivered_seq, ctx->deliver_seq, ctx->copy_stream, "section hand-over");
+        if (rcw != JXLT_OK) return rcw;
+        ctx->deliveries_pending = false;
+      }
+      if (ctx->copies_pending) HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
       PinnedBuf<uint8_t> grown;
       const int rc = EnsurePinned(ctx, &grown, bytes + bytes / 8 + 65536);
       if (rc != JXLT_OK) return rc;
@@ -1799,21 +1902,6 @@ int jxlt_output_buffer(jxlt_context* ctx, size_t bytes, uint8_t** out) {
   return JXLT_OK;
 }
 
-int jxlt_pack_measured(jxlt_context* ctx, int kind, jxlt_packed_sections* out) {
-  if (!ctx || !out || (kind != 0 && kind != 1)) return JXLT_ERR_INVALID_ARGUMENT;
-  if (ctx->pack[kind].measured_sections == 0) {
-    ctx->error = "jxlt_pack_measured needs jxlt_pack_measure_begin first";
-    return JXLT_ERR_INVALID_ARGUMENT;
-  }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipEventSynchronize(ctx->pack[kind].measured));
-  FillMeasured(ctx, kind, out);
-  return JXLT_OK;
-}
-
-int jxlt_pack_ac_sections(jxlt_context* ctx, const uint32_t* code_table, jxlt_packed_sections* out) {
-  return jxlt_pack_sections(ctx, 1, code_table, out);
-}
 
 int jxlt_kernel_times(jxlt_context* ctx, jxlt_kernel_time* out, int cap) {
   if (!ctx || !out || cap < 0) return JXLT_ERR_INVALID_ARGUMENT;

@@ -39,6 +39,8 @@ constexpr int kPackWindowWords = kPackTile * 28 / 32 + 4;        // <= 28 bits p
 // while seven waited, 64 extra records staged per tile, two more barriers.)  Up to 3 bytes behind a
 // blob's last section are zeroed.
 // ---------------------------------------------------------------------------
+constexpr int kPackMaxLaunches = 8;
+
 struct alignas(16) PackTileInfo {
   uint64_t rec_first;      // absolute index of the tile's first record
   uint64_t bit_pos;        // bit position of the tile in the blob (section-relative until finalised)
@@ -63,6 +65,13 @@ struct PackTileArgs {
   uint8_t* out;                     // blob (4-byte aligned)
   uint32_t tile_first;              // first tile of this launch
   uint32_t tile_end;                // one past the last tile of this launch (clamped to the tile count)
+  // The writing pass runs as `launches` launches over the tile ranges [launch_t0[i], launch_t0[i + 1]);
+  // pack_tile_finalize_kernel files in launch_sec_end[i] how many sections are complete behind launch i (all their
+  // tiles lie below launch_t0[i + 1]), so that the hand-over kernel behind launch i knows its byte range without the
+  // host (pack_deliver_kernel).  launch_sec_end may be null (no hand-over by launches).
+  uint32_t launches;
+  uint32_t launch_t0[kPackMaxLaunches + 1];
+  uint32_t* launch_sec_end;         // [launches]
 };
 
 JXLT_DI uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
@@ -294,9 +303,28 @@ __global__ void __launch_bounds__(64 * kPackOffsetsSectionsPerGroup) pack_tile_o
 
 __global__ void __launch_bounds__(256) pack_tile_finalize_kernel(const PackTileArgs A) {
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= (uint32_t)A.tile_base[A.nsec]) return;
+  if (t >= (uint32_t)A.tile_base[A.nsec]) {
+    // (no tile at all -- every section is empty: every launch "completes" all of them)
+    if (t == 0 && A.launch_sec_end)
+      for (uint32_t i = 0; i < A.launches; i++) A.launch_sec_end[i] = (uint32_t)A.nsec;
+    return;
+  }
   PackTileInfo info = A.tile_info[t];
   const uint32_t sec = (uint32_t)info.sec_start_bit;
+  // The sections that are complete behind writing launch i: everything in front of the section that holds the
+  // first tile of launch i + 1 (the last launch completes them all).  Filed by the thread of that tile; boundaries
+  // at or beyond the tile count by the thread of the last tile.
+  if (A.launch_sec_end) {
+    const uint32_t ntiles = (uint32_t)A.tile_base[A.nsec];
+    for (uint32_t i = 0; i < A.launches; i++) {
+      const uint32_t b = A.launch_t0[i + 1];
+      if (i + 1 == A.launches || b >= ntiles) {
+        if (t == ntiles - 1) A.launch_sec_end[i] = (uint32_t)A.nsec;
+      } else if (b == t) {
+        A.launch_sec_end[i] = sec;
+      }
+    }
+  }
   const uint64_t start = 8 * A.sec_byte_offset[sec];
   info.bit_pos += start;
   info.sec_start_bit = start;
@@ -436,6 +464,131 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
     }
     cur = nxt;
     nxt = nxt2;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Hand-over to the host without the host (round 4).
+//
+// Until round 3 every result the host waited for came through hipMemcpyAsync + an event: ~20 us of device time for a
+// 16 KB download (tools/d2h_probe.hip: the runtime's copy kernel) and ~12 us for the host to notice the event, six
+// to eight times per frame; and the section bytes could only leave once the HOST had read their sizes and issued the
+// copies.  Now kernels store to the host's page-locked memory themselves:
+//   publish_kernel        small results (histograms, counts, section sizes) + a sequence word the host polls
+//   pack_deliver_kernel   the packed sections, at byte ranges it reads from the device-side layout
+// A 16 KB publish takes ~6 us and its flag is seen ~6 us after the launch; the section bytes travel at the link's
+// rate (54 GB/s, the same as hipMemcpyAsync) with no host round trip in front of them.
+// ---------------------------------------------------------------------------
+#ifndef JXLT_THREADFENCE_SYSTEM
+#define JXLT_THREADFENCE_SYSTEM() __threadfence_system()
+#endif
+
+constexpr int kPublishThreads = 1024;
+constexpr int kPublishSegments = 4;
+struct PublishArgs {
+  const uint32_t* src[kPublishSegments];  // device memory, dword granular
+  uint32_t* dst[kPublishSegments];        // page-locked host memory (mapped)
+  uint32_t words[kPublishSegments];
+  // optional: one 64-bit word of device memory copied behind the segments (a total the host wants with them)
+  const unsigned long long* src64;
+  unsigned long long* dst64;
+  uint32_t* flag;   // host memory: receives `seq` when everything above is visible to the host
+  uint32_t seq;
+};
+// ONE workgroup (the payloads are a few KB to a few hundred KB): no cross-workgroup completion protocol.
+__global__ void __launch_bounds__(kPublishThreads) publish_kernel(const PublishArgs A) {
+  const uint32_t tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < kPublishSegments; k++) {
+    const uint32_t n = A.words[k];
+    const uint32_t* src = A.src[k];
+    uint32_t* dst = A.dst[k];
+    for (uint32_t i = tid; i < n; i += kPublishThreads) dst[i] = src[i];
+  }
+  if (tid == 0 && A.src64) *A.dst64 = *A.src64;
+  JXLT_THREADFENCE_SYSTEM();
+  __syncthreads();
+  if (tid == 0) {
+    *(volatile uint32_t*)A.flag = A.seq;
+  }
+}
+
+// The packed sections of one kind leave the device blob for the destination (page-locked host memory, or device
+// memory): `nruns` runs of consecutive sections, run r = sections [first, first + count) -> dst + dst_offset[r]
+// (their bytes are contiguous in the blob: sec_byte_offset).  Three ways to say which:
+//   launch >= 0   ONE run, the sections writing launch `launch` has completed (launch_sec_end, filed by
+//                 pack_tile_finalize_kernel), at dst + their offset in the blob
+//   nruns > 0     the caller's runs (a slab of a frame that is shared by several GPUs: its sections are not one
+//                 range of the codestream)
+// end_aligned: the destination is where the LAST byte of all sections ends (dst - total + offset): the sections of a
+// kind whose size the host does not know yet can be set against a fixed end.
+constexpr int kDeliverThreads = 256;
+constexpr int kDeliverMaxRuns = 48;
+struct DeliverRun {
+  uint32_t first, count;
+  uint64_t dst_offset;
+};
+struct DeliverArgs {
+  const uint8_t* blob;
+  const uint64_t* sec_byte_offset;  // [nsec + 1]
+  const uint32_t* launch_sec_end;   // [launches] (launch mode)
+  uint8_t* dst;
+  int nsec;
+  int launch;       // >= 0: launch mode
+  int nruns;        // run mode
+  int end_aligned;
+  DeliverRun runs[kDeliverMaxRuns];
+  // completion: the last workgroup to finish stores `seq` to *flag (host memory); counter: device memory, zero
+  // between launches (the last workgroup resets it).  flag may be null.
+  uint32_t* counter;
+  uint32_t* flag;
+  uint32_t seq;
+};
+JXLT_DI void deliver_bytes(const uint8_t* src, uint8_t* dst, uint64_t n, uint64_t wg, uint64_t nwg, uint32_t tid) {
+  // destination-aligned 16-byte chunks (what the link likes); the source may sit at any byte (unaligned 16-byte
+  // loads are single instructions on gfx950); head and tail bytes by the first workgroup
+  const uint64_t head = (16 - ((uintptr_t)dst & 15)) & 15;
+  const uint64_t h = head < n ? head : n;
+  const uint64_t body = (n - h) >> 4;
+  if (wg == 0) {
+    if (tid < h) dst[tid] = src[tid];
+    const uint64_t tail0 = h + (body << 4);
+    if (tail0 + tid < n && tid < 16) dst[tail0 + tid] = src[tail0 + tid];
+  }
+  uint4* d16 = reinterpret_cast<uint4*>(dst + h);
+  const uint8_t* s = src + h;
+  for (uint64_t i = wg * kDeliverThreads + tid; i < body; i += nwg * kDeliverThreads) {
+    uint4 v;
+    __builtin_memcpy(&v, s + (i << 4), 16);
+    d16[i] = v;
+  }
+}
+__global__ void __launch_bounds__(kDeliverThreads) pack_deliver_kernel(const DeliverArgs A) {
+  const uint32_t tid = threadIdx.x;
+  const uint64_t total = A.sec_byte_offset[A.nsec];
+  const int64_t shift = A.end_aligned ? -(int64_t)total : 0;
+  if (A.launch >= 0) {
+    const uint32_t s_lo = A.launch > 0 ? A.launch_sec_end[A.launch - 1] : 0u;
+    const uint32_t s_hi = A.launch_sec_end[A.launch];
+    const uint64_t lo = A.sec_byte_offset[s_lo], hi = A.sec_byte_offset[s_hi > s_lo ? s_hi : s_lo];
+    deliver_bytes(A.blob + lo, A.dst + shift + (int64_t)lo, hi - lo, blockIdx.x, gridDim.x, tid);
+  } else {
+    // every workgroup takes a share of every run (runs are few and long, or few and short)
+    for (int r = 0; r < A.nruns; r++) {
+      const uint64_t lo = A.sec_byte_offset[A.runs[r].first], hi = A.sec_byte_offset[A.runs[r].first + A.runs[r].count];
+      deliver_bytes(A.blob + lo, A.dst + shift + (int64_t)A.runs[r].dst_offset, hi - lo, blockIdx.x, gridDim.x, tid);
+    }
+  }
+  if (A.flag) {
+    JXLT_THREADFENCE_SYSTEM();
+    __syncthreads();
+    if (tid == 0) {
+      if (atomicAdd(A.counter, 1u) == gridDim.x - 1) {
+        *A.counter = 0u;
+        JXLT_THREADFENCE_SYSTEM();
+        *(volatile uint32_t*)A.flag = A.seq;
+      }
+    }
   }
 }
 

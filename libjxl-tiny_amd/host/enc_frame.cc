@@ -195,12 +195,9 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   static thread_local size_t expected_for_pixels = 0;
   // (a code construction that worked alone last time is not announced to the helper threads)
   static thread_local bool dc_shared = true, ac_shared = true;
-  static thread_local size_t last_frame_bytes = 0;  // (sizes the output buffer before the AC sections are measured)
-  static thread_local size_t last_dc_bytes = 0;     // (of the DC-group sections; 0: not known for this frame size)
   if (expected_for_pixels != xsize * ysize) {
     expected_for_pixels = xsize * ysize;
     expected_dc_ms = expected_ac_ms = 0.0;
-    last_dc_bytes = 0;
   }
   EntropyCode ac_code, dc_code;
   std::vector<uint32_t> ac_table(64 * 64), dc_table(64 * 64);
@@ -214,11 +211,14 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   expected_dc_ms = ms(t0, t0a);
   // The DC code is built by the helper thread.  Whatever is ready first goes to the device first:
   //  * the DC code (large resident frames: token_kernel runs for longer than a DC code construction): the DC-group
-  //    sections are packed behind token_kernel, while this thread builds the AC code;
-  //  * the AC histogram: this thread builds the AC code at once and has the AC sections MEASURED; the DC-group
-  //    sections are packed behind that (their total size positions the AC sections in the codestream), the AC
-  //    sections written behind them.  (Until round 3 the AC histogram waited for the DC code: 0.17 of the 0.78 ms
-  //    of a 4096^2 frame, 0.25 of the 1.83 ms of an 8192^2 one, 0.3 ms of every frame that arrives over PCIe.)
+  //    sections are packed behind token_kernel and leave for the host while this thread builds the AC code;
+  //  * the AC histogram (small frames, frames that came over PCIe, slabs): this thread builds the AC code at once,
+  //    the AC sections are packed and leave; the DC-group sections follow when their code exists.
+  // Neither kind waits for the other, because nothing in the codestream is placed from the left: the AC sections
+  // start at a position that is fixed before any size is known (E0 + ACGlobal, E0 = a bound of what stands in front),
+  // the DC-group sections END at E0 -- the device right-aligns them itself (jxlt_pack_deliver, end_aligned) --, and
+  // the head (file header, frame header, TOC, DCGlobal) is set against them from the right when the sizes have
+  // arrived.  The codestream then starts a little way into the buffer.
   static thread_local std::unique_ptr<CodeWorker> worker;
   if (!worker) worker.reset(new CodeWorker);
   FrameGlobals globals;
@@ -240,7 +240,7 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   if (sequential) worker->Wait();
   for (;;) {
     if (worker->Done()) break;
-    const int ready = jxlt_histograms_ready(ctx);
+    const int ready = jxlt_histograms_ready(ctx);  // (a read of host memory)
     if (ready < 0) {
       fprintf(stderr, "jxl_tiny_amd: device encode failed: %s\n", jxlt_last_error(ctx));
       return false;
@@ -249,22 +249,49 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
       ac_first = true;
       break;
     }
-    // (a query takes the runtime's lock: a couple of microseconds between two of them leave it to the other
-    // encoding threads of the process -- the lanes of a batch encoder)
-    for (int spin = 0; spin < 64 && !worker->Done(); ++spin) {
 #if defined(__x86_64__)
-      __builtin_ia32_pause();
+    __builtin_ia32_pause();
 #endif
-    }
-  }
-  if (!ac_first) {
-    dc_shared = dc_shared_now;
-    if (jxlt_pack_measure_begin(ctx, 0, dc_table.data()) != JXLT_OK) {
-      fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
-      return false;
-    }
   }
   const size_t pre = (in_context && in_context->prefix) ? in_context->prefix->size() : 0;
+  const auto align = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+  // Bytes the sections of a kind can take at most: their tokens' code lengths from the histogram -- with the code's
+  // own lengths when it exists (exact but for the padding of every section to a byte and the handful of raw bits a
+  // DC-group section starts with), with the longest code word possible (15 bits) when it does not.
+  const auto section_bytes_bound = [](const uint32_t* hist, const uint32_t* table, size_t nsec) {
+    uint64_t bits = 0;
+    for (size_t ctx_i = 0; ctx_i < 64; ++ctx_i)
+      for (size_t sym = 0; sym < 64; ++sym) {
+        const uint32_t n = hist[ctx_i * 64 + sym];
+        if (n == 0) continue;
+        const uint32_t extra = sym >= 16 ? static_cast<uint32_t>(sym >> 2) - 2u : 0u;  // (token.h:32-48)
+        bits += static_cast<uint64_t>(n) * ((table ? table[ctx_i * 64 + sym] >> 16 : 15u) + extra);
+      }
+    return static_cast<size_t>(bits / 8) + 16 * nsec + 64;
+  };
+  static thread_local size_t last_frame_bytes = 0;  // (sizes the output buffer before the AC sections' size is known)
+  size_t e0 = 0;       // where the DC-group sections end and ACGlobal starts
+  uint8_t* buf = nullptr;
+  bool dc_begun = false;
+  const auto begin_dc = [&]() -> bool {
+    // (the DC code, and with it globals.dc_global, is complete here)
+    dc_shared = dc_shared_now;
+    if (jxlt_pack_begin(ctx, 0, dc_table.data()) != JXLT_OK ||
+        jxlt_pack_deliver(ctx, 0, buf + e0, nullptr, 0, /*end_aligned=*/1) != JXLT_OK) {
+      fprintf(stderr, "jxl_tiny_amd: section packing failed: %s\n", jxlt_last_error(ctx));
+      return false;
+    }
+    dc_begun = true;
+    return true;
+  };
+  if (!ac_first) {
+    e0 = align(pre + HeadSizeBound(xsize, ysize, globals) + section_bytes_bound(dc_hist, dc_table.data(), num_dc_groups));
+    if (jxlt_output_buffer(ctx, std::max(e0 + 4096, last_frame_bytes), &buf) != JXLT_OK) {
+      fprintf(stderr, "jxl_tiny_amd: output buffer: %s\n", jxlt_last_error(ctx));
+      return false;
+    }
+    if (!begin_dc()) return false;
+  }
   const auto t0b = now();
   {
     const double left = expected_ac_ms - ms(t0, t0b);  // until the AC histogram is expected
@@ -280,168 +307,74 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   BuildAcCode(ac_hist, &ac_code);
   ac_shared = TakeClusteringShared();
   FillCodeTable(ac_code, ac_table.data());
+  globals.ac_global = BuildAcGlobal(xsize, ysize, ac_code);
   const auto t2 = now();
-  // AC code first, codestream assembled in the context's buffer, and the size of the DC-group sections known from
-  // the last frame of this size: the AC sections do not wait for the DC code at all -- they are placed where that
-  // size (and a quarter) leaves room in front of them, and head, DC-group sections and ACGlobal are set against them
-  // from the right when they exist (below).
-  static const bool allow_decoupled = getenv("JXLT_NO_DECOUPLE") == nullptr;  // (experiment knob)
-  const bool decoupled = allow_decoupled && ac_first && in_context != nullptr && last_dc_bytes != 0;
-  if (decoupled) {
-    if (jxlt_pack_measure_begin(ctx, 1, ac_table.data()) != JXLT_OK) {
-      fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
-      return false;
-    }
-  } else if (ac_first) {
-    // AC sections measured, DC-group sections packed, AC sections written -- in this order on the device
-    if (jxlt_pack_measure_only(ctx, 1, ac_table.data()) != JXLT_OK) {
-      fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
-      return false;
-    }
-    worker->Wait();
-    dc_shared = dc_shared_now;
-    if (jxlt_pack_measure_begin(ctx, 0, dc_table.data()) != JXLT_OK || jxlt_pack_write_begin(ctx, 1) != JXLT_OK) {
-      fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
-      return false;
-    }
+  const size_t acg_bytes = globals.ac_global.size();
+  if (ac_first) {
+    // (DCGlobal does not exist yet: its bound -- context tree + one clustered code for 45 contexts -- is 16 KB)
+    FrameGlobals none;
+    e0 = align(pre + HeadSizeBound(xsize, ysize, none) + 16384 + section_bytes_bound(dc_hist, nullptr, num_dc_groups));
   }
-  // (context buffer: the position of the sections is fixed before the head exists -- the head is bounded from
-  // above and right-aligned in front of them; the DC code, and with it globals.dc_global, is complete here in
-  // either order)
-  size_t dc_at = decoupled ? 0 : (pre + HeadSizeBound(xsize, ysize, globals) + 255) & ~static_cast<size_t>(255);
+  const size_t ac_bound = section_bytes_bound(ac_hist, ac_table.data(), num_groups);
+  // (with DC-group sections on their way the buffer grows with its contents; normally it has its size from the last frame)
+  if (jxlt_output_buffer(ctx, e0 + acg_bytes + ac_bound + 16, &buf) != JXLT_OK) {
+    fprintf(stderr, "jxl_tiny_amd: output buffer: %s\n", jxlt_last_error(ctx));
+    return false;
+  }
+  if (jxlt_pack_begin(ctx, 1, ac_table.data()) != JXLT_OK ||
+      jxlt_pack_deliver(ctx, 1, buf + e0 + acg_bytes, nullptr, 0, /*end_aligned=*/0) != JXLT_OK) {
+    fprintf(stderr, "jxl_tiny_amd: section packing failed: %s\n", jxlt_last_error(ctx));
+    return false;
+  }
+  memcpy(buf + e0, globals.ac_global.data(), acg_bytes);
   if (trace)
     fprintf(stderr, "jxlt trace: dc histogram after %.2f ms, %s first | ac histogram after %.2f ms, ac code %.3f ms\n",
             ms(t0, t0a), ac_first ? "AC code" : "DC code", ms(t0, t1), ms(t1, t2));
-  // One pass measures every section (all the TOC needs); then the device entropy-codes the
-  // sections straight to their final byte offsets and copies them to where the frame is being
-  // assembled, while the host builds header and TOC.
-  jxlt_packed_sections dcm, acm;
-  bool dc_placed = false;
-  size_t decoupled_ac_at = 0;
-  if (decoupled) {
-    globals.ac_global = BuildAcGlobal(xsize, ysize, ac_code);
-    if (jxlt_pack_measured(ctx, 1, &acm) != JXLT_OK) {
-      fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
-      return false;
-    }
-    const size_t ac_size = static_cast<size_t>(acm.section_offset[acm.num_sections]);
-    const size_t acg = globals.ac_global.size();
-    const auto align = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
-    // frame header + TOC (HeadSizeBound without its DCGlobal) + 16 KB for DCGlobal + the DC-group sections + ACGlobal
-    size_t ac_at = align(pre + 64 + 4 * (2 + num_dc_groups + num_groups) + 16384 + last_dc_bytes + last_dc_bytes / 4 +
-                         65536 + acg);
-    uint8_t* buf = nullptr;
-    if (jxlt_output_buffer(ctx, std::max(ac_at + ac_size + 16, last_frame_bytes), &buf) != JXLT_OK ||
-        jxlt_pack_sections_place(ctx, 1, buf + ac_at) != JXLT_OK) {
-      fprintf(stderr, "jxl_tiny_amd: section placement failed: %s\n", jxlt_last_error(ctx));
-      return false;
-    }
+  if (!dc_begun) {
     worker->Wait();
-    dc_shared = dc_shared_now;
-    if (jxlt_pack_measure_begin(ctx, 0, dc_table.data()) != JXLT_OK || jxlt_pack_measured(ctx, 0, &dcm) != JXLT_OK) {
-      fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
-      return false;
-    }
-    const size_t dc_size = static_cast<size_t>(dcm.section_offset[dcm.num_sections]);
-    const size_t need = pre + HeadSizeBound(xsize, ysize, globals) + dc_size + acg;
-    if (need > ac_at) {
-      // (the DC-group sections grew by more than a quarter against the last frame: the AC sections once more,
-      // further to the right -- their blob is still on the device)
-      if (trace) fprintf(stderr, "jxlt trace: %zu bytes in front of the AC sections, room for %zu: AC sections placed again\n", need, ac_at);
-      ac_at = align(need + 4096);
-      if (jxlt_output_buffer(ctx, ac_at + ac_size + 16, &buf) != JXLT_OK ||
-          jxlt_pack_sections_place(ctx, 1, buf + ac_at) != JXLT_OK) {
-        fprintf(stderr, "jxl_tiny_amd: section placement failed: %s\n", jxlt_last_error(ctx));
-        return false;
-      }
-    }
-    dc_at = ac_at - acg - dc_size;
-    if (jxlt_pack_sections_place(ctx, 0, buf + dc_at) != JXLT_OK) {
-      fprintf(stderr, "jxl_tiny_amd: section placement failed: %s\n", jxlt_last_error(ctx));
-      return false;
-    }
-    dc_placed = true;
-    decoupled_ac_at = ac_at;
-  } else if (in_context) {
-    // The AC pass is queued first; then the DC-group sections -- measured and written while the AC code was being
-    // built -- start their way to the host: the link is idle until the first AC sections are written.
-    uint8_t* buf = nullptr;
-    if ((!ac_first && jxlt_pack_measure_begin(ctx, 1, ac_table.data()) != JXLT_OK) ||
-        jxlt_pack_measured(ctx, 0, &dcm) != JXLT_OK) {
-      fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
-      return false;
-    }
-    const size_t dc_size = static_cast<size_t>(dcm.section_offset[dcm.num_sections]);
-    if (jxlt_output_buffer(ctx, std::max(dc_at + dc_size + 16, last_frame_bytes), &buf) != JXLT_OK ||
-        jxlt_pack_sections_place(ctx, 0, buf + dc_at) != JXLT_OK) {
-      fprintf(stderr, "jxl_tiny_amd: section placement failed: %s\n", jxlt_last_error(ctx));
-      return false;
-    }
-    dc_placed = true;
-    if (jxlt_pack_measured(ctx, 1, &acm) != JXLT_OK) {
-      fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
-      return false;
-    }
-  } else if (jxlt_pack_measure(ctx, nullptr, ac_first ? nullptr : ac_table.data(), &dcm, &acm) != JXLT_OK) {
+    if (!begin_dc()) return false;
+  }
+  // The sizes of both kinds (all the TOC needs) arrive while the sections are being written and handed over.
+  jxlt_packed_sections dcm, acm;
+  if (jxlt_pack_sizes(ctx, 0, &dcm) != JXLT_OK || jxlt_pack_sizes(ctx, 1, &acm) != JXLT_OK) {
     fprintf(stderr, "jxl_tiny_amd: section measuring failed: %s\n", jxlt_last_error(ctx));
     return false;
   }
   const auto t3 = now();
   const PackedSections dc = {nullptr, dcm.section_offset, dcm.section_bits, dcm.num_sections};
   const PackedSections ac = {nullptr, acm.section_offset, acm.section_bits, acm.num_sections};
-  if (!decoupled) globals.ac_global = BuildAcGlobal(xsize, ysize, ac_code);
   const size_t dc_bytes = static_cast<size_t>(dc.offset[dc.n]), ac_bytes = static_cast<size_t>(ac.offset[ac.n]);
-  last_dc_bytes = dc_bytes;
-  const size_t acg_bytes = globals.ac_global.size();
   std::vector<uint8_t> head;
-  bool ok = true;
-  if (in_context) {
-    const size_t ac_at = dc_at + dc_bytes + acg_bytes;
-    last_frame_bytes = ac_at + ac_bytes + 16;  // (the LAST frame: a thread that once had a large frame does not ask for its size for ever)
-    uint8_t* buf = nullptr;
-    if (!dc_placed || jxlt_output_buffer(ctx, ac_at + ac_bytes + 16, &buf) != JXLT_OK ||
-        (!decoupled && jxlt_pack_sections_place(ctx, 1, buf + ac_at) != JXLT_OK) ||
-        (decoupled && ac_at != decoupled_ac_at)) {
-      fprintf(stderr, "jxl_tiny_amd: section placement failed: %s\n", jxlt_last_error(ctx));
-      return false;
-    }
-    if (!BuildFrameHead(xsize, ysize, distp, globals, dc, ac, &head)) return false;
-    uint8_t* dst = buf + dc_at - (pre + head.size());
-    in_context->data = dst;
-    in_context->size = pre + head.size() + dc_bytes + acg_bytes + ac_bytes;
-    if (pre) memcpy(dst, in_context->prefix->data(), pre);
-    memcpy(dst + pre, head.data(), head.size());
-    memcpy(buf + dc_at + dc_bytes, globals.ac_global.data(), acg_bytes);
-    ok = jxlt_synchronize(ctx) == JXLT_OK;
-  } else {
-    if (!BuildFrameHead(xsize, ysize, distp, globals, dc, ac, &head)) return false;
-    const size_t frame_bytes = head.size() + dc_bytes + acg_bytes + ac_bytes;
-    if (writer) {
-      // BitWriter API of the drop-in EncodeFrame: the sections pass through the page-locked buffer
-      uint8_t* tmp = nullptr;
-      ok = jxlt_output_buffer(ctx, dc_bytes + ac_bytes + 16, &tmp) == JXLT_OK &&
-           jxlt_pack_write(ctx, tmp, tmp + dc_bytes) == JXLT_OK && jxlt_synchronize(ctx) == JXLT_OK;
-      if (ok) {
-        writer->Reserve(frame_bytes);
-        writer->AppendBytes(head.data(), head.size());
-        writer->AppendBytes(tmp, dc_bytes);
-        writer->AppendBytes(globals.ac_global.data(), acg_bytes);
-        writer->AppendBytes(tmp + dc_bytes, ac_bytes);
-      }
+  if (!BuildFrameHead(xsize, ysize, distp, globals, dc, ac, &head)) return false;
+  if (pre + head.size() + dc_bytes > e0 || ac_bytes > ac_bound) {
+    // (cannot happen: both bounds are sums of the code lengths of the very tokens that were packed)
+    fprintf(stderr, "jxl_tiny_amd: internal error: sections larger than their bound\n");
+    (void)jxlt_synchronize(ctx);
+    return false;
+  }
+  uint8_t* const frame_at = buf + e0 - dc_bytes - head.size();
+  const size_t frame_bytes = head.size() + dc_bytes + acg_bytes + ac_bytes;
+  if (pre) memcpy(frame_at - pre, in_context->prefix->data(), pre);
+  memcpy(frame_at, head.data(), head.size());
+  last_frame_bytes = e0 + acg_bytes + ac_bytes + 16;  // (the LAST frame: a thread that once had a large frame does not ask for its size for ever)
+  bool ok = jxlt_synchronize(ctx) == JXLT_OK;
+  if (ok) {
+    if (in_context) {
+      in_context->data = frame_at - pre;
+      in_context->size = pre + frame_bytes;
+    } else if (writer) {
+      // BitWriter API of the drop-in EncodeFrame: the frame is appended from the page-locked buffer
+      writer->Reserve(frame_bytes);
+      writer->AppendBytes(frame_at, frame_bytes);
     } else {
       // placer(frame_bytes) returns where the frame must be written
       uint8_t* dst = (*placer)(frame_bytes);
-      ok = dst != nullptr &&
-           jxlt_pack_write(ctx, dst + head.size(), dst + head.size() + dc_bytes + acg_bytes) == JXLT_OK;
-      if (ok) {
-        memcpy(dst, head.data(), head.size());
-        memcpy(dst + head.size() + dc_bytes, globals.ac_global.data(), acg_bytes);
-        ok = jxlt_synchronize(ctx) == JXLT_OK;
-      }
+      ok = dst != nullptr;
+      if (ok) memcpy(dst, frame_at, frame_bytes);
     }
   }
   if (trace)
-    fprintf(stderr, "jxlt trace: device+histograms %.3f ms | codes %.3f | measure %.3f | head + place %.3f\n",
+    fprintf(stderr, "jxlt trace: device+histograms %.3f ms | codes %.3f | sizes %.3f | head + hand-over %.3f\n",
             ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
   (void)num_threads;
   return ok;

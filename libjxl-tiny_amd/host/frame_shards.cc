@@ -403,15 +403,21 @@ int CtxEnqueue(void* self, const jxlt_params* p) {
   return jxlt_encode_enqueue(ctx, p);
 }
 int CtxDcHist(void* self, const uint32_t** h) { return jxlt_fetch_dc_histogram(static_cast<jxlt_context*>(self), h); }
-int CtxBeginDc(void* self, const uint32_t* t) { return jxlt_pack_measure_begin(static_cast<jxlt_context*>(self), 0, t); }
+int CtxBeginDc(void* self, const uint32_t* t) { return jxlt_pack_begin(static_cast<jxlt_context*>(self), 0, t); }
 int CtxAcHist(void* self, const uint32_t** h) {
   return jxlt_fetch_histograms(static_cast<jxlt_context*>(self), h, nullptr);
 }
 int CtxMeasure(void* self, const uint32_t* t, jxlt_packed_sections* dc, jxlt_packed_sections* ac) {
-  return jxlt_pack_measure(static_cast<jxlt_context*>(self), nullptr, t, dc, ac);
+  jxlt_context* ctx = static_cast<jxlt_context*>(self);
+  int rc = jxlt_pack_begin(ctx, 1, t);
+  if (rc == JXLT_OK) rc = jxlt_pack_sizes(ctx, 0, dc);
+  if (rc == JXLT_OK) rc = jxlt_pack_sizes(ctx, 1, ac);
+  return rc;
 }
 int CtxWrite(void* self, uint8_t* dc_dst, uint8_t* ac_dst) {
-  return jxlt_pack_write(static_cast<jxlt_context*>(self), dc_dst, ac_dst);
+  jxlt_context* ctx = static_cast<jxlt_context*>(self);
+  const int rc = jxlt_pack_deliver(ctx, 0, dc_dst, nullptr, 0, 0);
+  return rc != JXLT_OK ? rc : jxlt_pack_deliver(ctx, 1, ac_dst, nullptr, 0, 0);
 }
 int CtxFinish(void* self) { return jxlt_synchronize(static_cast<jxlt_context*>(self)); }
 

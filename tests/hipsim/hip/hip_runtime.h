@@ -257,6 +257,10 @@ inline uint64_t exchange(uint64_t v, int src_lane_in_wave, int scope = 0) {
 #define blockDim (hipsim::M().block_dim)
 #define gridDim (hipsim::M().grid_dim)
 
+// (one workgroup runs at a time and stores are not reordered: fences are no-ops)
+inline void __threadfence_system() {}
+inline void __threadfence() {}
+
 inline void __syncthreads() {
   hipsim::cur().state = hipsim::kAtBlockBarrier;
   hipsim::yield_to_scheduler();

@@ -269,6 +269,108 @@ __attribute__((visibility("default"))) int sim_pack_direct(const uint8_t* record
   return 0;
 }
 
+// The product's hand-over (EnqueueMeasure / EnqueueDeliver of jxlt_capi.hip): the writing pass in `nlaunch` GROWING
+// shares of an upper bound of the tile count, pack_tile_finalize_kernel filing the sections every launch completes,
+// and pack_deliver_kernel behind every launch copying those sections from the blob to `dst` (+ dst_shift bytes, any
+// alignment): mode 0 = launch mode, start-aligned at dst + dst_shift; 1 = launch mode, END-aligned at dst + dst_shift;
+// 2 = run mode, runs given as (first, count, dst_offset) triples of 64-bit words.
+__attribute__((visibility("default"))) int sim_pack_deliver(const uint8_t* records, const uint64_t* sec_rec_offset,
+                                                             int nsec, const uint32_t* code_table, int nlaunch, int mode,
+                                                             uint8_t* dst, uint64_t dst_shift, const uint64_t* runs,
+                                                             int nruns, int grid, uint64_t* out_offset,
+                                                             uint32_t* out_bits, uint32_t* out_flag) {
+  const uint64_t total = sec_rec_offset[nsec];
+  const size_t max_tiles = total / kPackTile + nsec + 1 + 37;  // (an upper bound, like the product's)
+  std::vector<uint32_t> sec_bytes(nsec), sec_tiles(nsec), tile_bits(max_tiles, 0xDEADu), launch_sec_end(kPackMaxLaunches, 0xDEADu);
+  std::vector<PackTileInfo> tile_info(max_tiles);
+  std::vector<uint64_t> tile_base(nsec + 1);
+  std::vector<uint8_t> blob(4 * total + 8 * nsec + 128, 0xEE);
+  PackTileArgs P = {};
+  P.records = records;
+  P.sec_rec_offset = sec_rec_offset;
+  P.nsec = nsec;
+  P.code_table = code_table;
+  P.sec_tiles = sec_tiles.data();
+  P.tile_base = tile_base.data();
+  P.tile_bits = tile_bits.data();
+  P.tile_info = tile_info.data();
+  P.sec_bits = out_bits;
+  P.sec_bytes = sec_bytes.data();
+  P.sec_byte_offset = out_offset;
+  P.out = blob.data();
+  P.tile_end = 0xFFFFFFFFu;
+  P.launches = (uint32_t)nlaunch;
+  for (int i = 0; i <= nlaunch; i++)
+    P.launch_t0[i] = i == nlaunch ? (uint32_t)max_tiles
+                                  : (uint32_t)((double)max_tiles * ((double)((1 << i) - 1) / (double)((1 << nlaunch) - 1)));
+  P.launch_sec_end = launch_sec_end.data();
+  const unsigned sec_blocks = (unsigned)((nsec + 255) / 256);
+  hipsim::launch(pack_tile_count_kernel, dim3(sec_blocks), dim3(256), P);
+  hipsim::launch(group_scan_kernel, dim3(1), dim3(kScanThreads), (const uint32_t*)sec_tiles.data(), tile_base.data(), nsec);
+  hipsim::launch(pack_tile_plan_kernel, dim3(sec_blocks), dim3(256), P);
+  hipsim::launch(pack_tile_measure_kernel, dim3((unsigned)((max_tiles + kPackMeasureTilesPerGroup - 1) / kPackMeasureTilesPerGroup)),
+                 dim3(kPackThreads), P);
+  hipsim::launch(pack_tile_offsets_kernel,
+                 dim3((unsigned)((nsec + kPackOffsetsSectionsPerGroup - 1) / kPackOffsetsSectionsPerGroup)),
+                 dim3(64 * kPackOffsetsSectionsPerGroup), P);
+  hipsim::launch(group_scan_kernel, dim3(1), dim3(kScanThreads), (const uint32_t*)sec_bytes.data(), out_offset, nsec);
+  hipsim::launch(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), P);
+  uint32_t counter = 0;
+  DeliverArgs D = {};
+  D.blob = blob.data();
+  D.sec_byte_offset = out_offset;
+  D.launch_sec_end = launch_sec_end.data();
+  D.dst = dst + dst_shift;
+  D.nsec = nsec;
+  D.end_aligned = mode == 1;
+  D.counter = &counter;
+  for (int c = 0; c < nlaunch; c++) {
+    PackTileArgs W = P;
+    W.tile_first = P.launch_t0[c];
+    W.tile_end = P.launch_t0[c + 1];
+    if (W.tile_end > W.tile_first)
+      hipsim::launch(pack_tile_write_kernel,
+                     dim3((unsigned)((W.tile_end - W.tile_first + kPackWriteTilesPerGroup - 1) / kPackWriteTilesPerGroup)),
+                     dim3(kPackThreads), W);
+    if (mode != 2) {
+      D.launch = c;
+      D.flag = c + 1 == nlaunch ? out_flag : nullptr;
+      D.seq = 77;
+      hipsim::launch(pack_deliver_kernel, dim3((unsigned)grid), dim3(kDeliverThreads), D);
+    }
+  }
+  if (mode == 2) {
+    D.launch = -1;
+    for (int r0 = 0; r0 < nruns; r0 += kDeliverMaxRuns) {
+      const int n = nruns - r0 < kDeliverMaxRuns ? nruns - r0 : kDeliverMaxRuns;
+      D.nruns = n;
+      for (int r = 0; r < n; r++) {
+        D.runs[r].first = (uint32_t)runs[3 * (r0 + r)];
+        D.runs[r].count = (uint32_t)runs[3 * (r0 + r) + 1];
+        D.runs[r].dst_offset = runs[3 * (r0 + r) + 2];
+      }
+      D.flag = r0 + n >= nruns ? out_flag : nullptr;
+      D.seq = 77;
+      hipsim::launch(pack_deliver_kernel, dim3((unsigned)grid), dim3(kDeliverThreads), D);
+    }
+  }
+  return counter == 0 ? 0 : 1;  // (the last workgroup resets the completion counter)
+}
+
+// publish_kernel: segments of dwords + a 64-bit word + the sequence word
+__attribute__((visibility("default"))) void sim_publish(const uint32_t* a, uint32_t* da, uint32_t na, const uint32_t* b,
+                                                         uint32_t* db, uint32_t nb, const unsigned long long* s64,
+                                                         unsigned long long* d64, uint32_t* flag, uint32_t seq) {
+  PublishArgs P = {};
+  P.src[0] = a; P.dst[0] = da; P.words[0] = na;
+  P.src[1] = b; P.dst[1] = db; P.words[1] = nb;
+  P.src64 = s64;
+  P.dst64 = d64;
+  P.flag = flag;
+  P.seq = seq;
+  hipsim::launch(publish_kernel, dim3(1), dim3(kPublishThreads), P);
+}
+
 }  // extern "C"
 
 // group_scan_kernel alone: offsets[0..n] = exclusive scan of counts[0..n)

@@ -224,6 +224,11 @@ def _sim_lib(tiny_root_table=False):
                                     C.POINTER(SimResult)]
         _sim.sim_pack_direct.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_int, C.c_void_p, C.c_void_p]
+        _sim.sim_pack_deliver.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                          C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _sim.sim_publish.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        _sim.sim_publish.restype = None
     return _sim
 
 
@@ -288,6 +293,33 @@ def sim_pack_sections(sections, table, misalign=0, nlaunch=1):
     assert np.isin(out[base + total:base + total + tail], (0, 0xCD)).all(), "stray stores"
     body = out[base:base + total]
     return [(body[int(out_off[i]):int(out_off[i + 1])].tobytes(), int(out_bits[i])) for i in range(len(sections))]
+
+
+def sim_pack_deliver(sections, table, nlaunch=3, mode=0, shift=0, runs=None, grid=5):
+    """Measure, write in growing shares and hand over (pack_deliver_kernel) on the CPU execution model.  mode 0: all
+    sections back to back starting `shift` bytes into the destination; 1: ENDING there; 2: the runs (first section,
+    count, destination offset) only.  Returns (destination bytes, where the hand-over starts, section byte offsets,
+    section bits); the destination arrives poisoned with 0xCD."""
+    L = _sim_lib()
+    blob = np.frombuffer(b"".join(sections) + b"\0\0\0\0", np.uint8).copy()
+    offs = np.zeros(len(sections) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(x) // 3 for x in sections])
+    table = np.ascontiguousarray(table, np.uint32)
+    cap = 4 * int(offs[-1]) + 8 * len(sections) + 4096 + shift
+    if runs is not None:
+        cap = max(cap, max(int(r[2]) for r in runs) + 4 * int(offs[-1]) + 4096)
+    dst = np.full(cap, 0xCD, np.uint8)
+    out_off = np.zeros(len(sections) + 1, np.uint64)
+    out_bits = np.zeros(len(sections), np.uint32)
+    flag = np.zeros(1, np.uint32)
+    r = np.ascontiguousarray(np.array(runs if runs is not None else [[0, 0, 0]], np.uint64).reshape(-1))
+    rc = L.sim_pack_deliver(blob.ctypes.data, offs.ctypes.data, len(sections), table.ctypes.data, nlaunch, mode,
+                            dst.ctypes.data, shift, r.ctypes.data, 0 if runs is None else len(runs), grid,
+                            out_off.ctypes.data, out_bits.ctypes.data, flag.ctypes.data)
+    assert rc == 0 and int(flag[0]) == 77, "completion protocol of the hand-over"
+    total = int(out_off[-1])
+    start = shift - total if mode == 1 else shift
+    return dst, start, out_off, out_bits
 
 
 def pfm_payload(planes, big_endian=False):

@@ -105,17 +105,34 @@ def test_error_behaviour(built, enc):
     fresh = built.Encoder(0)
     table = np.zeros(4096, np.uint32)
     hip.jxlt_histograms_ready.argtypes = [C.c_void_p]
-    hip.jxlt_pack_measure_only.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-    hip.jxlt_pack_write_begin.argtypes = [C.c_void_p, C.c_int]
+    hip.jxlt_pack_begin.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    hip.jxlt_pack_sizes.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    hip.jxlt_pack_deliver.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.jxlt_output_buffer.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    sizes = built.PackedSections()
+    out = C.c_void_p()
+    assert hip.jxlt_output_buffer(fresh._ctx, 1 << 20, C.byref(out)) == 0
     assert hip.jxlt_histograms_ready(fresh._ctx) < 0              # nothing enqueued
-    assert hip.jxlt_pack_measure_only(fresh._ctx, 1, table.ctypes.data) < 0
-    assert hip.jxlt_pack_write_begin(fresh._ctx, 1) < 0              # nothing measured
-    assert hip.jxlt_pack_write_begin(fresh._ctx, 2) < 0              # no such kind
+    assert hip.jxlt_pack_begin(fresh._ctx, 1, table.ctypes.data) < 0
+    assert hip.jxlt_pack_sizes(fresh._ctx, 1, C.byref(sizes)) < 0    # nothing measured
+    assert hip.jxlt_pack_deliver(fresh._ctx, 1, out, None, 0, 0) < 0  # nothing measured
+    assert hip.jxlt_pack_begin(fresh._ctx, 2, table.ctypes.data) < 0  # no such kind
     fresh.upload(planes)
     fresh.enqueue(1.0, 0)
-    assert hip.jxlt_pack_measure_only(fresh._ctx, 1, table.ctypes.data) < 0   # AC sections need the histograms first
+    assert hip.jxlt_pack_begin(fresh._ctx, 1, table.ctypes.data) < 0   # AC sections need the histograms first
     fresh.synchronize()
+    ac, dc = fresh.fetch_histograms()
     assert hip.jxlt_histograms_ready(fresh._ctx) == 1
+    at, dt = built.build_code_tables(ac, dc)
+    assert hip.jxlt_pack_begin(fresh._ctx, 0, dt.ctypes.data) == 0
+    pageable = np.zeros(1 << 16, np.uint8)
+    assert hip.jxlt_pack_deliver(fresh._ctx, 0, pageable.ctypes.data, None, 0, 0) < 0   # a kernel cannot store there
+    assert b"page-locked" in hip.jxlt_last_error(fresh._ctx)
+    run = (C.c_uint32 * 4)(0, 5, 0, 0)  # (first 0, five sections of a one-section frame)
+    assert hip.jxlt_pack_deliver(fresh._ctx, 0, out, run, 1, 0) < 0    # a run beyond the sections
+    assert hip.jxlt_pack_deliver(fresh._ctx, 0, out, run, 1, 1) < 0    # runs are not end-aligned
+    assert hip.jxlt_pack_deliver(fresh._ctx, 0, out, None, 0, 0) == 0
+    fresh.synchronize()
     fresh.close()
 
 
@@ -184,9 +201,9 @@ def test_device_packed_sections_equal_host_packed(built, enc, w, h, distance):
 
 
 def test_output_buffer_keeps_early_sections_when_it_grows(built):
-    """The DC-group sections leave for the context's page-locked output buffer before the AC sections are
-    measured (jxlt_pack_measured + jxlt_pack_sections_place); when the frame turns out larger than the buffer
-    (sized by the previous frame), jxlt_output_buffer grows WITH its contents.  A fresh context, frames of
+    """The DC-group sections leave for the context's page-locked output buffer before the AC sections' size is
+    known (jxlt_pack_deliver, end-aligned); when the frame turns out larger than the buffer (sized by the previous
+    frame), jxlt_output_buffer grows WITH its contents.  A fresh context, frames of
     rising, falling and rising size, each several times (the second encode of a size finds the buffer right)."""
     e = built.Encoder(0)
     try:
@@ -457,9 +474,9 @@ def test_baseline_config4_16384_frame(built, enc):
 def test_frames_in_a_row_whose_ac_code_is_ready_first(built, enc):
     """Small frames: the AC histogram arrives before the DC code is built, so the host builds both codes at the same
     time and has the AC sections measured, written and on their way before the DC-group sections exist -- at a place
-    that leaves room for what the LAST frame of this size had in front of them (host/enc_frame.cc).  A row of frames
-    of one size whose DC-group sections shrink and grow (flat, busy, flat ...; a frame that needs more room than a
-    quarter above its predecessor's sends its AC sections a second time): every codestream equals the oracle's."""
+    that is fixed before any size is known (a bound of what stands in front: host/enc_frame.cc); the DC-group
+    sections are set against them from the right by the device.  A row of frames of one size whose DC-group sections
+    shrink and grow (flat, busy, flat ...): every codestream equals the oracle's."""
     w, h = 1096, 840
     busy = T.to_planes(T.synthetic_image(w, h, hard=True))
     calm = T.to_planes(T.synthetic_image(w, h))
@@ -474,8 +491,7 @@ def test_frames_in_a_row_whose_ac_code_is_ready_first(built, enc):
         enc.upload(frames[name])
         assert enc.encode_resident(1.0) == want[name], name
         assert enc.encode_resident(1.0, copy=False).tobytes() == want[name], name
-    # a size at which the DC-group sections of an ordinary frame are hundreds of KB: behind a flat frame they do not
-    # fit the room its successor's AC sections left in front of them (last frame's size + a quarter + 64 KB)
+    # a size at which the DC-group sections of an ordinary frame are hundreds of KB, many times a flat frame's
     size = 4096
     calm = T.to_planes(T.synthetic_image(size, size))
     flat = np.full_like(calm, 0.25)

@@ -102,6 +102,80 @@ def test_pack_kernel_matches_reference_packer(built, sizes):
         assert T.sim_pack_sections(sections, table, words, nlaunch=1 + words) == want
 
 
+def _random_sections(rng, sizes):
+    import numpy as np
+    sections = []
+    for n in sizes:
+        ctx = rng.integers(0, 64, size=n).astype(np.uint8)
+        val = np.where(rng.random(n) < 0.8, rng.integers(0, 20, size=n), rng.integers(0, 65536, size=n)).astype(np.uint16)
+        rec = np.stack([ctx, (val & 0xFF).astype(np.uint8), (val >> 8).astype(np.uint8)], axis=1)
+        sections.append(rec.astype(np.uint8).tobytes())
+    return sections
+
+
+@pytest.mark.parametrize("sizes", [[0], [7], [5, 0, 17], [4095, 4096, 4097, 1], [0, 0, 0], [20000, 3, 9000, 0, 12345],
+                                   [600] * 23])
+@pytest.mark.parametrize("nlaunch", [1, 3, 4])
+def test_hand_over_kernel_delivers_every_section_once(built, sizes, nlaunch):
+    """pack_deliver_kernel behind the writing launches (round 4: the sections leave the device without the host
+    knowing their sizes): whatever the shares of the launches, every section arrives exactly once, byte for byte what
+    the reference packer gives, at any alignment of the destination, start- and end-aligned; nothing else is written;
+    the last workgroup reports completion."""
+    import numpy as np
+    rng = np.random.default_rng(len(sizes) * 1000 + sum(sizes) + nlaunch)
+    table = _random_code_table(rng)
+    sections = _random_sections(rng, sizes)
+    want = T.pack_sections_python(sections, table)
+    want_bytes = b"".join(b for b, _ in want)
+    for mode, shift, grid in [(0, 0, 5), (0, 3, 1), (0, 21, 64), (1, 100000 + 7, 3), (1, 200001, 16)]:
+        if mode == 1 and shift < len(want_bytes):
+            continue
+        dst, start, off, bits = T.sim_pack_deliver(sections, table, nlaunch=nlaunch, mode=mode, shift=shift, grid=grid)
+        assert [int(b) for b in bits] == [nb for _, nb in want]
+        assert int(off[-1]) == len(want_bytes)
+        assert dst[start:start + len(want_bytes)].tobytes() == want_bytes
+        assert (dst[:start] == 0xCD).all() and (dst[start + len(want_bytes):] == 0xCD).all(), "stray stores"
+
+
+def test_hand_over_kernel_in_runs(built):
+    """Run mode (a slab of a frame that several GPUs share owns several ranges of the codestream): runs of
+    consecutive sections go to the offsets the caller names, more runs than one launch takes."""
+    import numpy as np
+    rng = np.random.default_rng(99)
+    table = _random_code_table(rng)
+    sizes = [int(v) for v in rng.integers(0, 900, size=130)]
+    sections = _random_sections(rng, sizes)
+    want = T.pack_sections_python(sections, table)
+    lens = [len(b) for b, _ in want]
+    # runs of 1..3 sections, scattered: run k goes to k * 4000 + k (odd alignments)
+    runs, s = [], 0
+    while s < len(sections):
+        n = min(len(sections) - s, 1 + len(runs) % 3)
+        runs.append([s, n, len(runs) * 4001 + 13])
+        s += n
+    assert len(runs) > 48
+    dst, start, off, bits = T.sim_pack_deliver(sections, table, nlaunch=2, mode=2, shift=0, runs=runs, grid=4)
+    touched = np.zeros(len(dst), bool)
+    for first, n, at in runs:
+        chunk = b"".join(want[i][0] for i in range(first, first + n))
+        assert dst[at:at + len(chunk)].tobytes() == chunk
+        touched[at:at + len(chunk)] = True
+    assert (dst[~touched] == 0xCD).all(), "stray stores"
+
+
+def test_publish_kernel(built):
+    import ctypes as C
+    import numpy as np
+    L = T._sim_lib()
+    a = np.arange(5000, dtype=np.uint32)
+    b = np.arange(3, dtype=np.uint32) + 9
+    da, db = np.zeros(5000, np.uint32), np.zeros(3, np.uint32)
+    s64, d64, flag = np.array([2 ** 40 + 5], np.uint64), np.zeros(1, np.uint64), np.zeros(1, np.uint32)
+    L.sim_publish(a.ctypes.data, da.ctypes.data, 5000, b.ctypes.data, db.ctypes.data, 3, s64.ctypes.data, d64.ctypes.data,
+                  flag.ctypes.data, 41)
+    assert (da == a).all() and (db == b).all() and int(d64[0]) == 2 ** 40 + 5 and int(flag[0]) == 41
+
+
 def test_pack_tiles_with_short_codes(built):
     """Tile boundaries inside a dword: the later tile re-derives its predecessors' trailing bits.
     One-bit codes and zero-length escapes make many records share one dword, also across more
