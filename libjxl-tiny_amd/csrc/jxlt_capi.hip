@@ -118,6 +118,7 @@ struct jxlt_context {
     PinnedBuf<uint64_t> h_sec_byte_off;  // (the same layout as sec_byte_off; filled by publish_kernel)
     DeviceBuf<uint32_t> launch_sec_end;  // sections complete behind each writing launch (pack_tile_finalize_kernel)
     uint32_t pack_seq = 0;               // measuring passes of this kind so far: what the sizes' flag carries
+    uint32_t* h_launch_sec_end = nullptr;  // host mirror of launch_sec_end (inside the context's HostMail)
     static size_t SizesWords(size_t nsec) { return nsec + 1 + (nsec + 1) / 2; }
     uint32_t* sec_bits(size_t nsec) const { return reinterpret_cast<uint32_t*>(sec_byte_off.p + nsec + 1); }
     uint32_t* h_sec_bits(size_t nsec) const { return reinterpret_cast<uint32_t*>(h_sec_byte_off.p + nsec + 1); }
@@ -146,13 +147,13 @@ struct jxlt_context {
     uint32_t ac_hist_seq;  // = seq: the AC histogram (h_hist) and token_total are there
     uint32_t pad1[15];
     uint32_t sizes_seq[2][16];  // [kind][0] = pack[kind].pack_seq: h_sec_byte_off of that kind is complete
-    uint32_t delivered_seq;     // = deliver_seq: every hand-over kernel queued so far has finished
-    uint32_t pad2[15];
+    uint32_t delivered_seq[2][16];  // [kind][0] = deliver_seq[kind]: every hand-over of that kind queued so far has finished
     unsigned long long token_total;  // records of all AC groups (sizes the packing's tile arrays)
+    uint32_t launch_sec_end[2][16];  // [kind]: sections complete behind each writing launch (published with the sizes)
   };
   PinnedBuf<HostMail> mail;
   uint32_t seq = 0;          // encodes enqueued on this context
-  uint32_t deliver_seq = 0;  // hand-over kernels with a completion flag queued so far
+  uint32_t deliver_seq[2] = {0, 0};  // hand-overs queued so far, per kind (each kind leaves on a stream of its own)
   bool deliveries_pending = false;
   DeviceBuf<uint32_t> deliver_counter;
 
@@ -172,6 +173,7 @@ struct jxlt_context {
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   // jxlt_pack_write: packing on `stream`, chunked copies to the destination on `copy_stream`
   hipStream_t copy_stream = nullptr;
+  hipStream_t dc_copy_stream = nullptr;  // the DC-group sections' hand-over (beside the AC sections' on copy_stream)
   bool dc_elementwise_split = false;
   hipEvent_t dc_elementwise_done = nullptr;  // (resident frames: dc_elementwise_kernel runs beside the two chain kernels)
   hipEvent_t dc_kernels_done = nullptr;  // (the small downloads wait for their kernels on the copy stream, not in front of the next kernel)
@@ -189,6 +191,13 @@ struct jxlt_context {
   bool copies_pending = false;  // (hipMemcpyAsync on the copy stream: the raw-token / debug routes only)
   bool profiled = false;
   bool counted = false;  // DeviceBlockCache knows this context as a living one
+  // JXLT_TRACE_EVENTS=1 (tools/): timed events at points of interest of the last encode, printed by jxlt_synchronize
+  struct TraceEvent {
+    const char* name;
+    hipEvent_t ev;
+  };
+  std::vector<TraceEvent> trace;
+  size_t trace_used = 0;
 };
 
 namespace {
@@ -341,7 +350,12 @@ int EnsurePinned(jxlt_context* ctx, PinnedBuf<T>* b, size_t n) {
   if (b->p) HIP_TRY(ctx, hipHostFree(b->p));
   b->p = nullptr;
   b->cap = 0;
-  HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&b->p), (n ? n : 1) * sizeof(T), hipHostMallocDefault));
+  // (experiment knob: JXLT_PINNED_FLAGS=<hipHostMalloc flags, hex or decimal>)
+  static const unsigned pinned_flags = [] {
+    const char* e = getenv("JXLT_PINNED_FLAGS");
+    return e ? (unsigned)strtoul(e, nullptr, 0) : (unsigned)hipHostMallocDefault;
+  }();
+  HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&b->p), (n ? n : 1) * sizeof(T), pinned_flags));
   b->cap = n;
   return JXLT_OK;
 }
@@ -411,6 +425,7 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
   }
   // every stream / event of the context; a failure anywhere releases what exists so far
   e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->dc_copy_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&ctx->aux_done);
@@ -424,6 +439,7 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
   if (e == hipSuccess) {
     ctx->mail.cap = 1;
     memset(ctx->mail.p, 0, sizeof(jxlt_context::HostMail));
+    for (int k = 0; k < 2; k++) ctx->pack[k].h_launch_sec_end = ctx->mail.p->launch_sec_end[k];
     e = hipMalloc(reinterpret_cast<void**>(&ctx->deliver_counter.p), 64);
   }
   if (e == hipSuccess) {
@@ -453,7 +469,7 @@ void jxlt_context_destroy(jxlt_context* ctx) {
   // (everything the context has queued on any of ITS streams -- other contexts, lanes and frameworks on the device
   // are not waited for: its device buffers may be kept for the next context, DeviceBlockCache, and are then not
   // synchronised by a hipFree)
-  for (hipStream_t st : {ctx->stream, ctx->aux_stream, ctx->copy_stream, ctx->upload_stream})
+  for (hipStream_t st : {ctx->stream, ctx->aux_stream, ctx->copy_stream, ctx->dc_copy_stream, ctx->upload_stream})
     if (st) (void)hipStreamSynchronize(st);
   FreeDevice(&ctx->own_payload);
   for (int c = 0; c < 3; c++) {
@@ -540,6 +556,7 @@ void jxlt_context_destroy(jxlt_context* ctx) {
     (void)hipStreamDestroy(ctx->upload_stream);
   }
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  if (ctx->dc_copy_stream) (void)hipStreamDestroy(ctx->dc_copy_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   const bool counted = ctx->counted;
   const int device = ctx->device;
@@ -899,6 +916,36 @@ int jxlt_image_size(const jxlt_context* ctx, size_t* xsize, size_t* ysize) {
 namespace {
 int EnqueuePlan(jxlt_context* ctx, int kind, uint64_t rec_bound, hipStream_t stream);  // (below)
 
+// (diagnostics, JXLT_TRACE_EVENTS=1: a timed event on `stream`, listed against the encode's first event by jxlt_synchronize)
+bool TraceEventsOn() {
+  static const bool on = [] {
+    const char* e = getenv("JXLT_TRACE_EVENTS");
+    return e && atoi(e) != 0;
+  }();
+  return on;
+}
+void TraceMark(jxlt_context* ctx, const char* name, hipStream_t stream) {
+  if (!TraceEventsOn()) return;
+  if (ctx->trace_used == ctx->trace.size()) {
+    hipEvent_t ev = nullptr;
+    if (hipEventCreate(&ev) != hipSuccess) return;
+    ctx->trace.push_back({name, ev});
+  }
+  ctx->trace[ctx->trace_used].name = name;
+  (void)hipEventRecord(ctx->trace[ctx->trace_used].ev, stream);
+  ctx->trace_used++;
+}
+void TraceDump(jxlt_context* ctx) {
+  if (!TraceEventsOn() || ctx->trace_used == 0) return;
+  (void)hipDeviceSynchronize();
+  for (size_t i = 0; i < ctx->trace_used; i++) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->trace[i].ev) == hipSuccess)
+      fprintf(stderr, "jxlt event: %9.3f ms  %s\n", ms, ctx->trace[i].name);
+  }
+  ctx->trace_used = 0;
+}
+
 // Waits until a kernel has stored `want` to a sequence word in page-locked memory (HostMail).  Spins: the waits
 // inside a frame are fractions of a millisecond, and the word is seen ~6 us earlier than an event would be
 // (tools/d2h_probe.hip).  A device fault would leave the word unwritten for ever: the stream is asked for errors
@@ -940,6 +987,16 @@ int WaitWord(jxlt_context* ctx, const uint32_t* word, uint32_t want, hipStream_t
   }
 }
 
+// Every hand-over queued so far (both kinds) has finished.
+int WaitDeliveries(jxlt_context* ctx) {
+  for (int kind = 0; kind < 2; kind++) {
+    const int rc = WaitWord(ctx, &ctx->mail.p->delivered_seq[kind][0], ctx->deliver_seq[kind],
+                            kind ? ctx->copy_stream : ctx->dc_copy_stream, "section hand-over");
+    if (rc != JXLT_OK) return rc;
+  }
+  return JXLT_OK;
+}
+
 // publish_kernel on `stream`: up to kPublishSegments (device source, host destination, dwords) pairs, an optional
 // 64-bit word, then `seq` to the host word `flag`.
 struct PublishSeg {
@@ -978,7 +1035,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (ctx->deliveries_pending) {
     // (sections of the previous encode may still be leaving the blobs this encode is about to overwrite)
-    const int rcw = WaitWord(ctx, &ctx->mail.p->delivered_seq, ctx->deliver_seq, ctx->copy_stream, "section hand-over");
+    const int rcw = WaitDeliveries(ctx);
     if (rcw != JXLT_OK) return rcw;
     ctx->deliveries_pending = false;
   }
@@ -1251,23 +1308,22 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
     const hipStream_t elem_stream = split ? ctx->aux_stream : tok_stream;
     if (split) HIP_TRY(ctx, hipStreamWaitEvent(elem_stream, ctx->tile_done[sl], 0));
     hipLaunchKernelGGL(dc_elementwise_kernel, dim3((unsigned)(slab_dc * kDcParts)), dim3(256), 0, elem_stream, D);
-    if (split) {
-      HIP_TRY(ctx, hipEventRecord(ctx->dc_elementwise_done, elem_stream));
-      HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->dc_elementwise_done, 0));  // (the histogram's download)
-    }
+    if (split) HIP_TRY(ctx, hipEventRecord(ctx->dc_elementwise_done, elem_stream));
     hipLaunchKernelGGL(dc_chain_summary_kernel, dim3((unsigned)(slab_dc * kDcChainChunks)), dim3(kDcChainThreads), 0,
                        tok_stream, D);
     hipLaunchKernelGGL(dc_chain_kernel, dim3((unsigned)(slab_dc * kDcChainChunks)), dim3(kDcChainThreads), 0,
                        tok_stream, D);
     if (sl + 1 == nslabs) {
-      // The DC histogram (and the counts of the tiles redone with computed roots) leaves beside token_kernel, not
-      // in front of it: one small kernel on the copy stream stores both to the host's page-locked memory and then
-      // the frame's sequence number to the word the host polls.
+      // The DC histogram (and the counts of the tiles redone with computed roots) leaves IN FRONT of token_kernel: one
+      // small kernel stores both to the host's page-locked memory and then the frame's sequence number to the word
+      // the host polls (~6 us on the stream).  Beside token_kernel -- on the copy stream, where rounds 2-3 had the
+      // download -- the kernel does not get a wave slot before token_kernel's workgroups begin to retire: the
+      // histogram arrived 0.4 ms late and the DC code was built behind the AC code (round 4, first version).
       HIP_TRY(ctx, hipEventRecord(ctx->dc_kernels_done, tok_stream));
-      HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->dc_kernels_done, 0));
+      if (split) HIP_TRY(ctx, hipStreamWaitEvent(tok_stream, ctx->dc_elementwise_done, 0));
       const PublishSeg segs[2] = {{ctx->hist.p + 64 * 64, ctx->h_hist.p + 64 * 64, 64 * 64},
                                   {ctx->lut_overflow.p, ctx->h_lut_overflow.p, nslabs}};
-      const int rcp = EnqueuePublish(ctx, ctx->copy_stream, segs, 2, nullptr, nullptr, &ctx->mail.p->dc_hist_seq, frame_seq);
+      const int rcp = EnqueuePublish(ctx, tok_stream, segs, 2, nullptr, nullptr, &ctx->mail.p->dc_hist_seq, frame_seq);
       if (rcp != JXLT_OK) return rcp;
     }
     const size_t ty0 = dc_row0 * 2048, ty1 = std::min(ctx->ysize, dc_row1 * 2048);  // pixel rows being tokenised
@@ -1292,6 +1348,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   // AC histogram + total token count leave right behind the last token_kernel (publish_kernel: no copy command, no
   // event -- the host polls the sequence word)
   HIP_TRY(ctx, hipEventRecord(ctx->aux_done, tok_stream));
+  TraceMark(ctx, "token_kernel done", tok_stream);
   {
     const PublishSeg seg = {ctx->hist.p, ctx->h_hist.p, 64 * 64};
     const int rcp = EnqueuePublish(ctx, tok_stream, &seg, 1, reinterpret_cast<const unsigned long long*>(ctx->group_off.p + ngroups),
@@ -1344,7 +1401,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
 int ResolveRootTableOverflow(jxlt_context* ctx) {
   if (!ctx->encoded || ctx->overflow_checked) return JXLT_OK;
   {  // (the counts arrive with the DC histogram)
-    const int rcw = WaitWord(ctx, &ctx->mail.p->dc_hist_seq, ctx->seq, ctx->copy_stream, "device pipeline");
+    const int rcw = WaitWord(ctx, &ctx->mail.p->dc_hist_seq, ctx->seq, ctx->stream, "device pipeline");
     if (rcw != JXLT_OK) return rcw;
   }
   ctx->overflow_checked = true;
@@ -1386,9 +1443,10 @@ int jxlt_synchronize(jxlt_context* ctx) {
     // The last hand-over kernel stands behind everything the frame has queued (it waits for the last writing
     // launch, which stands behind the whole pipeline on the main stream): its word is the frame's completion, seen
     // without a call into the runtime.
-    const int rcw = WaitWord(ctx, &ctx->mail.p->delivered_seq, ctx->deliver_seq, ctx->copy_stream, "section hand-over");
+    const int rcw = WaitDeliveries(ctx);
     if (rcw != JXLT_OK) return rcw;
     ctx->deliveries_pending = false;
+    TraceDump(ctx);
     // (the section sizes of both kinds have been published by kernels in front of the hand-over's writes)
     for (int kind = 0; kind < 2; kind++) {
       if (ctx->pack[kind].measured_sections == 0) continue;
@@ -1624,8 +1682,13 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
   // its previous use (last frame's upload) finished before that frame's sizes were returned.
   if ((rc = EnsurePinned(ctx, &ps.h_code_table, 64 * 64)) != JXLT_OK) return rc;
   memcpy(ps.h_code_table.p, code_table, 64 * 64 * sizeof(uint32_t));
-  HIP_TRY(ctx, hipMemcpyAsync(ps.code_table.p, ps.h_code_table.p, 64 * 64 * sizeof(uint32_t), hipMemcpyHostToDevice,
-                              ctx->stream));
+  // (fetched by a kernel that reads the page-locked copy, not by a copy command: a copy command queues behind the
+  // other kind's sections on the DMA engine -- the AC measuring pass started 85 us late behind the DC-group sections'
+  // download, JXLT_TRACE_EVENTS)
+  {
+    const PublishSeg seg = {ps.h_code_table.p, ps.code_table.p, 64 * 64};
+    if ((rc = EnqueuePublish(ctx, ctx->stream, &seg, 1, nullptr, nullptr, nullptr, 0)) != JXLT_OK) return rc;
+  }
   // Blob capacity: <= 28 bits per record.  (Allocated before the measuring pass: its last kernel zeroes the
   // dwords in which tiles and sections meet.)
   const uint64_t blob_bound = rec_bound * 4 + nsec * 8 + 64;
@@ -1655,6 +1718,7 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
     ps.launch_t0[i] = i == ps.launches ? (uint32_t)max_tiles : (uint32_t)((double)max_tiles * share);
   }
   const PackTileArgs P = TileArgsOf(ctx, kind, nsec);
+  TraceMark(ctx, kind ? "AC measure start" : "DC measure start", ctx->stream);
   hipLaunchKernelGGL(pack_tile_measure_kernel,
                      dim3((unsigned)((max_tiles + kPackMeasureTilesPerGroup - 1) / kPackMeasureTilesPerGroup)),
                      dim3(kPackThreads), 0, ctx->stream, P);
@@ -1667,17 +1731,19 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
   // leave for the host by the auxiliary stream (idle by now), beside that kernel -- offsets and bit counts lie
   // behind each other, one publish_kernel stores them to the page-locked mirror and then the pass's number to the
   // word the host polls.  (Rounds 1-3: hipMemcpyAsync + event; the copy alone took 20 us of device time.)
+  TraceMark(ctx, kind ? "AC scan done" : "DC scan done", ctx->stream);
+  hipLaunchKernelGGL(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), 0, ctx->stream, P);
+  HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ps.finalized, ctx->stream));
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ps.finalized, 0));
   ps.pack_seq++;
   {
-    const PublishSeg seg = {ps.sec_byte_off.p, ps.h_sec_byte_off.p, jxlt_context::PackSet::SizesWords(nsec) * 2};
-    if ((rc = EnqueuePublish(ctx, ctx->aux_stream, &seg, 1, nullptr, nullptr, &ctx->mail.p->sizes_seq[kind][0],
+    const PublishSeg segs[2] = {{ps.sec_byte_off.p, ps.h_sec_byte_off.p, jxlt_context::PackSet::SizesWords(nsec) * 2},
+                                {ps.launch_sec_end.p, ps.h_launch_sec_end, (size_t)kPackMaxLaunches}};
+    if ((rc = EnqueuePublish(ctx, ctx->aux_stream, segs, 2, nullptr, nullptr, &ctx->mail.p->sizes_seq[kind][0],
                              ps.pack_seq)) != JXLT_OK)
       return rc;
   }
-  hipLaunchKernelGGL(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), 0, ctx->stream, P);
-  HIP_TRY(ctx, hipGetLastError());
   // (the plan is used up: the kernel above has replaced every tile's section index by the section's bit position.  A
   // second measuring pass of the same encode plans again; until round 3 it did not, read section offsets at those
   // bit positions and wrote wherever they pointed.)
@@ -1704,8 +1770,13 @@ int EnqueueWrites(jxlt_context* ctx, int kind) {
                          dim3(kPackThreads), 0, ctx->stream, W);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ps.launch_done[i], ctx->stream));
+    TraceMark(ctx, kind ? "AC write launch done" : "DC write launch done", ctx->stream);
   }
   return JXLT_OK;
+}
+
+int WaitSizes(jxlt_context* ctx, int kind) {
+  return WaitWord(ctx, &ctx->mail.p->sizes_seq[kind][0], ctx->pack[kind].pack_seq, ctx->aux_stream, "section measuring");
 }
 
 void FillMeasured(jxlt_context* ctx, int kind, jxlt_packed_sections* out) {
@@ -1724,6 +1795,9 @@ void FillMeasured(jxlt_context* ctx, int kind, jxlt_packed_sections* out) {
 int EnqueueDeliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_section_run* runs, size_t nruns, int end_aligned) {
   jxlt_context::PackSet& ps = ctx->pack[kind];
   const size_t nsec = ps.measured_sections;
+  // (the two kinds leave on streams of their own: two copy commands in flight hide each other's start-up, and the
+  // DC-group sections -- a fifth of the bytes -- do not stand in front of the first AC sections)
+  const hipStream_t out_stream = kind ? ctx->copy_stream : ctx->dc_copy_stream;
   DeliverArgs D;
   memset(&D, 0, sizeof(D));
   D.blob = ps.packed.p;
@@ -1732,20 +1806,87 @@ int EnqueueDeliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_section
   D.dst = dst;
   D.nsec = (int)nsec;
   D.end_aligned = end_aligned;
-  D.counter = ctx->deliver_counter.p;
+  D.counter = ctx->deliver_counter.p + kind * 8;  // (a counter per kind: the two kinds may be handed over side by side)
   // workgroups per hand-over kernel: the link is saturated from 64 on (tools/d2h_probe.hip); small shares take fewer
-  auto grid_for = [&](size_t tiles) { return (unsigned)std::min<size_t>(256, std::max<size_t>(8, tiles / 2)); };
+  // (experiment knob, tools/: JXLT_DELIVER_WGS)
+  static const size_t max_wgs = [] {
+    const char* e = getenv("JXLT_DELIVER_WGS");
+    return e ? (size_t)std::max(1, std::min(atoi(e), 1024)) : (size_t)8;
+  }();
+  auto grid_for = [&](size_t tiles) { return (unsigned)std::min<size_t>(max_wgs, std::max<size_t>(2, tiles / 8)); };
+  // A hand-over workgroup gets a CU to ITSELF: it reserves (unused) LDS so that no workgroup of the kernels that
+  // run beside the hand-over fits next to it.  A compute workgroup that shares its CU's memory pipeline with waves
+  // that wait for the PCIe link falls behind the rest of its kernel, and the kernel ends with its slowest workgroup:
+  // beside eight unreserved hand-over workgroups the AC measuring pass took 0.18 ms instead of 0.09 (JXLT_TRACE_EVENTS).
+  // (experiment knob: JXLT_DELIVER_LDS=<bytes>)
+  static const unsigned deliver_lds = [] {
+    const char* e = getenv("JXLT_DELIVER_LDS");
+    const unsigned v = e ? (unsigned)atoi(e) : 147456u;
+    if (v > 65536u) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pack_deliver_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)v);
+    return v;
+  }();
+  // The bytes travel by COPY COMMANDS (hipMemcpyAsync: the DMA engines), issued by the host once it has the sizes
+  // -- not by a kernel that stores to the destination itself, although such a kernel needs no host round trip
+  // (pack_deliver_kernel: byte ranges read on the device; round 4's first version).  A kernel that stores to host
+  // memory and an HBM-bound kernel beside it slow each other down badly -- tools/d2h_interfere_probe.hip: the
+  // hand-over falls from 54 to 20-37 GB/s and the other kernel takes 20-35 % longer, whatever the grid, the
+  // alignment or the kind of store -- while a copy command keeps 53 GB/s and costs its neighbour 2 %.  In the
+  // frame: AC measuring pass 0.18 instead of 0.09 ms, writing launches 1.3-1.6x, step 5.41-5.48 against 5.26-5.31 ms.
+  // (experiment knob: JXLT_DELIVER_KERNEL=1 selects the kernel)
+  static const bool by_kernel = [] {
+    const char* e = getenv("JXLT_DELIVER_KERNEL");
+    return e && atoi(e) != 0;
+  }();
+  if (!by_kernel) {
+    const int rcs = WaitSizes(ctx, kind);
+    if (rcs != JXLT_OK) return rcs;
+    const uint64_t* off = ps.h_sec_byte_off.p;
+    if (runs == nullptr) {
+      const int64_t shift = end_aligned ? -(int64_t)off[nsec] : 0;
+      uint32_t s_lo = 0;
+      for (int i = 0; i < ps.launches; i++) {
+        const uint32_t s_hi = std::min<uint32_t>((uint32_t)nsec, std::max(s_lo, ps.h_launch_sec_end[i]));
+        if (off[s_hi] > off[s_lo]) {
+          HIP_TRY(ctx, hipStreamWaitEvent(out_stream, ps.launch_done[i], 0));
+          TraceMark(ctx, kind ? "AC copy start" : "DC copy start", out_stream);
+          HIP_TRY(ctx, hipMemcpyAsync(dst + shift + (int64_t)off[s_lo], ps.packed.p + off[s_lo], off[s_hi] - off[s_lo],
+                                      hipMemcpyDefault, out_stream));
+          TraceMark(ctx, kind ? "AC copy done" : "DC copy done", out_stream);
+        }
+        s_lo = s_hi;
+      }
+    } else {
+      HIP_TRY(ctx, hipStreamWaitEvent(out_stream, ps.launch_done[ps.launches - 1], 0));
+      for (size_t r = 0; r < nruns; r++) {
+        if ((size_t)runs[r].first_section + runs[r].num_sections > nsec) {
+          ctx->error = "jxlt_pack_deliver: a run names sections the measuring pass did not see";
+          return JXLT_ERR_INVALID_ARGUMENT;
+        }
+        const uint64_t lo = off[runs[r].first_section], hi = off[runs[r].first_section + runs[r].num_sections];
+        if (hi > lo)
+          HIP_TRY(ctx, hipMemcpyAsync(dst + runs[r].dst_offset, ps.packed.p + lo, hi - lo, hipMemcpyDefault, out_stream));
+      }
+    }
+    // completion: a one-workgroup kernel behind the copies stores the hand-over's number to the word the host polls
+    const int rcp = EnqueuePublish(ctx, out_stream, nullptr, 0, nullptr, nullptr, &ctx->mail.p->delivered_seq[kind][0], ++ctx->deliver_seq[kind]);
+    if (rcp != JXLT_OK) return rcp;
+    ctx->deliveries_pending = true;
+    return JXLT_OK;
+  }
   if (runs == nullptr) {
     for (int i = 0; i < ps.launches; i++) {
-      HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ps.launch_done[i], 0));
+      HIP_TRY(ctx, hipStreamWaitEvent(out_stream, ps.launch_done[i], 0));
       D.launch = i;
       D.nruns = 0;
       const bool last = i + 1 == ps.launches;
-      D.flag = last ? &ctx->mail.p->delivered_seq : nullptr;
-      D.seq = last ? ++ctx->deliver_seq : 0;
-      hipLaunchKernelGGL(pack_deliver_kernel, dim3(grid_for(ps.launch_t0[i + 1] - ps.launch_t0[i])), dim3(kDeliverThreads), 0,
-                         ctx->copy_stream, D);
+      D.flag = last ? &ctx->mail.p->delivered_seq[kind][0] : nullptr;
+      D.seq = last ? ++ctx->deliver_seq[kind] : 0;
+      TraceMark(ctx, kind ? "AC deliver start" : "DC deliver start", out_stream);
+      hipLaunchKernelGGL(pack_deliver_kernel, dim3(grid_for(ps.launch_t0[i + 1] - ps.launch_t0[i])), dim3(kDeliverThreads), deliver_lds,
+                         out_stream, D);
       HIP_TRY(ctx, hipGetLastError());
+      TraceMark(ctx, kind ? "AC deliver done" : "DC deliver done", out_stream);
     }
   } else {
     for (size_t r = 0; r < nruns; r++) {
@@ -1754,7 +1895,7 @@ int EnqueueDeliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_section
         return JXLT_ERR_INVALID_ARGUMENT;
       }
     }
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ps.launch_done[ps.launches - 1], 0));
+    HIP_TRY(ctx, hipStreamWaitEvent(out_stream, ps.launch_done[ps.launches - 1], 0));
     D.launch = -1;
     for (size_t r0 = 0; r0 < nruns; r0 += kDeliverMaxRuns) {
       const size_t n = std::min<size_t>(kDeliverMaxRuns, nruns - r0);
@@ -1765,9 +1906,9 @@ int EnqueueDeliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_section
         D.runs[r].dst_offset = runs[r0 + r].dst_offset;
       }
       const bool last = r0 + n >= nruns;
-      D.flag = last ? &ctx->mail.p->delivered_seq : nullptr;
-      D.seq = last ? ++ctx->deliver_seq : 0;
-      hipLaunchKernelGGL(pack_deliver_kernel, dim3(grid_for(ps.max_tiles)), dim3(kDeliverThreads), 0, ctx->copy_stream, D);
+      D.flag = last ? &ctx->mail.p->delivered_seq[kind][0] : nullptr;
+      D.seq = last ? ++ctx->deliver_seq[kind] : 0;
+      hipLaunchKernelGGL(pack_deliver_kernel, dim3(grid_for(ps.max_tiles)), dim3(kDeliverThreads), deliver_lds, out_stream, D);
       HIP_TRY(ctx, hipGetLastError());
     }
   }
@@ -1775,9 +1916,6 @@ int EnqueueDeliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_section
   return JXLT_OK;
 }
 
-int WaitSizes(jxlt_context* ctx, int kind) {
-  return WaitWord(ctx, &ctx->mail.p->sizes_seq[kind][0], ctx->pack[kind].pack_seq, ctx->aux_stream, "section measuring");
-}
 }  // namespace
 
 int jxlt_histograms_ready(jxlt_context* ctx) {
@@ -1804,7 +1942,7 @@ int jxlt_pack_begin(jxlt_context* ctx, int kind, const uint32_t* code_table) {
   }
   if (ctx->deliveries_pending && ctx->pack[kind].measured_sections != 0) {
     // (a second pass of this kind within one encode overwrites the blob the first pass's hand-over reads)
-    const int rcw = WaitWord(ctx, &ctx->mail.p->delivered_seq, ctx->deliver_seq, ctx->copy_stream, "section hand-over");
+    const int rcw = WaitDeliveries(ctx);
     if (rcw != JXLT_OK) return rcw;
   }
   return EnqueueMeasure(ctx, kind, code_table);
@@ -1831,24 +1969,29 @@ int jxlt_pack_deliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_sect
     return JXLT_ERR_INVALID_ARGUMENT;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  // the destination must be memory a kernel can store to: page-locked host memory or device memory
-  hipPointerAttribute_t attr;
-  const hipError_t pe = hipPointerGetAttributes(&attr, dst);
-  (void)hipGetLastError();
-  if (pe != hipSuccess || (attr.type != hipMemoryTypeHost && attr.type != hipMemoryTypeDevice)) {
-    ctx->error = "jxlt_pack_deliver needs page-locked host memory (jxlt_output_buffer / jxlt_pinned_alloc / "
-                 "jxlt_pinned_register) or device memory as destination";
-    return JXLT_ERR_INVALID_ARGUMENT;
-  }
+  // The destination must be memory a kernel can store to: page-locked host memory or device memory.  (The context's
+  // own output buffer is known to be; anything else is looked up, every time -- a range that was page-locked at the
+  // last call may have been freed since.)
   uint8_t* dev_dst = dst;
-  if (attr.type == hipMemoryTypeHost) {
-    void* mapped = nullptr;
-    if (hipHostGetDevicePointer(&mapped, dst, 0) != hipSuccess || !mapped) {
-      (void)hipGetLastError();
-      ctx->error = "jxlt_pack_deliver: the destination is page-locked but not mapped into the device's address space";
+  const bool own_output = ctx->h_output.p && dst >= ctx->h_output.p && dst <= ctx->h_output.p + ctx->h_output.cap;
+  if (!own_output) {
+    hipPointerAttribute_t attr;
+    const hipError_t pe = hipPointerGetAttributes(&attr, dst);
+    (void)hipGetLastError();
+    if (pe != hipSuccess || (attr.type != hipMemoryTypeHost && attr.type != hipMemoryTypeDevice)) {
+      ctx->error = "jxlt_pack_deliver needs page-locked host memory (jxlt_output_buffer / jxlt_pinned_alloc / "
+                   "jxlt_pinned_register) or device memory as destination";
       return JXLT_ERR_INVALID_ARGUMENT;
     }
-    dev_dst = static_cast<uint8_t*>(mapped);
+    if (attr.type == hipMemoryTypeHost) {
+      void* mapped = nullptr;
+      if (hipHostGetDevicePointer(&mapped, dst, 0) != hipSuccess || !mapped) {
+        (void)hipGetLastError();
+        ctx->error = "jxlt_pack_deliver: the destination is page-locked but not mapped into the device's address space";
+        return JXLT_ERR_INVALID_ARGUMENT;
+      }
+      dev_dst = static_cast<uint8_t*>(mapped);
+    }
   }
   return EnqueueDeliver(ctx, kind, dev_dst, runs, num_runs, end_aligned);
 }
@@ -1882,7 +2025,7 @@ int jxlt_output_buffer(jxlt_context* ctx, size_t bytes, uint8_t** out) {
     if ((ctx->copies_pending || ctx->deliveries_pending) && ctx->h_output.p) {
       // sections may be on their way into the buffer (jxlt_pack_deliver): it grows with its contents
       if (ctx->deliveries_pending) {
-        const int rcw = WaitWord(ctx, &ctx->mail.p->delivered_seq, ctx->deliver_seq, ctx->copy_stream, "section hand-over");
+        const int rcw = WaitDeliveries(ctx);
         if (rcw != JXLT_OK) return rcw;
         ctx->deliveries_pending = false;
       }

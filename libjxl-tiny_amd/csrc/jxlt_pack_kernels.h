@@ -483,7 +483,8 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
 #define JXLT_THREADFENCE_SYSTEM() __threadfence_system()
 #endif
 
-constexpr int kPublishThreads = 1024;
+// (four waves: a workgroup that fits whatever is free on a CU that another kernel fills)
+constexpr int kPublishThreads = 256;
 constexpr int kPublishSegments = 4;
 struct PublishArgs {
   const uint32_t* src[kPublishSegments];  // device memory, dword granular
@@ -503,12 +504,18 @@ __global__ void __launch_bounds__(kPublishThreads) publish_kernel(const PublishA
     const uint32_t n = A.words[k];
     const uint32_t* src = A.src[k];
     uint32_t* dst = A.dst[k];
-    for (uint32_t i = tid; i < n; i += kPublishThreads) dst[i] = src[i];
+    // 16 bytes per lane where both sides allow it (segments start 16-byte aligned as a rule), dwords for the rest
+    const bool wide = (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+    const uint32_t n4 = wide ? n >> 2 : 0;
+    const uint4* src4 = reinterpret_cast<const uint4*>(src);
+    uint4* dst4 = reinterpret_cast<uint4*>(dst);
+    for (uint32_t i = tid; i < n4; i += kPublishThreads) dst4[i] = src4[i];
+    for (uint32_t i = 4 * n4 + tid; i < n; i += kPublishThreads) dst[i] = src[i];
   }
   if (tid == 0 && A.src64) *A.dst64 = *A.src64;
   JXLT_THREADFENCE_SYSTEM();
   __syncthreads();
-  if (tid == 0) {
+  if (tid == 0 && A.flag) {
     *(volatile uint32_t*)A.flag = A.seq;
   }
 }
@@ -522,7 +529,7 @@ __global__ void __launch_bounds__(kPublishThreads) publish_kernel(const PublishA
 //                 range of the codestream)
 // end_aligned: the destination is where the LAST byte of all sections ends (dst - total + offset): the sections of a
 // kind whose size the host does not know yet can be set against a fixed end.
-constexpr int kDeliverThreads = 256;
+constexpr int kDeliverThreads = 1024;
 constexpr int kDeliverMaxRuns = 48;
 struct DeliverRun {
   uint32_t first, count;
@@ -555,13 +562,42 @@ JXLT_DI void deliver_bytes(const uint8_t* src, uint8_t* dst, uint64_t n, uint64_
     const uint64_t tail0 = h + (body << 4);
     if (tail0 + tid < n && tid < 16) dst[tail0 + tid] = src[tail0 + tid];
   }
-  uint4* d16 = reinterpret_cast<uint4*>(dst + h);
+#ifdef __clang__
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+#else
+  typedef unsigned int v4u __attribute__((vector_size(16)));  // (the CPU model of tests/hipsim is built with g++)
+#endif
+  v4u* d16 = reinterpret_cast<v4u*>(dst + h);
   const uint8_t* s = src + h;
-  for (uint64_t i = wg * kDeliverThreads + tid; i < body; i += nwg * kDeliverThreads) {
-    uint4 v;
-    __builtin_memcpy(&v, s + (i << 4), 16);
-    d16[i] = v;
+  // four chunks per lane and round: all four loads are requested before the first store, so that a handful of
+  // workgroups keep the link busy (the fewer waves the hand-over occupies, the less it holds up the kernels that
+  // run beside it: 8 workgroups were faster for the frame than 64, tools/handover_sweep.sh)
+  const uint64_t stride = nwg * kDeliverThreads;
+  uint64_t i = wg * kDeliverThreads + tid;
+#if defined(JXLT_DELIVER_PLAIN_STORES) || !defined(__clang__)
+#define JXLT_DELIVER_STORE(p, v) *(p) = (v)
+#else
+  // (non-temporal: the bytes are on their way out of the device -- they must not displace what the kernels running
+  // beside the hand-over keep in the L2)
+#define JXLT_DELIVER_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#endif
+  for (; i + 3 * stride < body; i += 4 * stride) {
+    v4u v0, v1, v2, v3;
+    __builtin_memcpy(&v0, s + (i << 4), 16);
+    __builtin_memcpy(&v1, s + ((i + stride) << 4), 16);
+    __builtin_memcpy(&v2, s + ((i + 2 * stride) << 4), 16);
+    __builtin_memcpy(&v3, s + ((i + 3 * stride) << 4), 16);
+    JXLT_DELIVER_STORE(&d16[i], v0);
+    JXLT_DELIVER_STORE(&d16[i + stride], v1);
+    JXLT_DELIVER_STORE(&d16[i + 2 * stride], v2);
+    JXLT_DELIVER_STORE(&d16[i + 3 * stride], v3);
   }
+  for (; i < body; i += stride) {
+    v4u v;
+    __builtin_memcpy(&v, s + (i << 4), 16);
+    JXLT_DELIVER_STORE(&d16[i], v);
+  }
+#undef JXLT_DELIVER_STORE
 }
 __global__ void __launch_bounds__(kDeliverThreads) pack_deliver_kernel(const DeliverArgs A) {
   const uint32_t tid = threadIdx.x;

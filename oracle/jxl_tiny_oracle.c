@@ -1172,7 +1172,7 @@ static void encode_group(const group_job* J, size_t dc_gx, size_t dc_gy, size_t 
       copy_and_pad(planes, stride, sx0, sy0, sw, sh, s);
       for (size_t y = 0; y < s->ysize; y++)
         orc_to_xyb(s->px[0][y], s->px[1][y], s->px[2][y], s->xsize);
-      for (int c = 0; c < 3; c++)
+      for (int c = 0; c < 3 && f->xyb[c]; c++)
         for (size_t y = 0; y < s->ysize; y++)
           memcpy(f->xyb[c] + (by_img0 * 8 + y) * (f->xsize_blocks * 8) + bx_img0 * 8,
                  s->px[c][y], s->xsize * sizeof(float));
@@ -1190,8 +1190,10 @@ static void encode_group(const group_job* J, size_t dc_gx, size_t dc_gy, size_t 
           for (size_t x = 0; x < tnbx; x++) {
             size_t pos = (by_img0 + y) * g.bstride + bx_img0 + tbx0 + x;
             g.raw_quant[pos] = rq[y * 8 + x];
-            f->quant_field[pos] = aq_map[y * 8 + x];
-            f->masking[pos] = mask[y * 8 + x];
+            if (f->quant_field) {
+              f->quant_field[pos] = aq_map[y * 8 + x];
+              f->masking[pos] = mask[y * 8 + x];
+            }
           }
         int8_t ytox = 0, ytob = 0;
         compute_cmap_tile(s, tbx0, tnbx, tnby, &dq, &ytox, &ytob);
@@ -1204,7 +1206,7 @@ static void encode_group(const group_job* J, size_t dc_gx, size_t dc_gy, size_t 
               size_t abx = bx_img0 + tbx0 + cx, aby = by_img0 + cy;
               find_best_16x16(s, tbx0, 0, cx, cy, distp.distance, &dq, aq_map, mask, ytox,
                               ytob, g.strategy + aby * g.bstride + abx, g.bstride,
-                              f->entropy8 + ((aby / 2) * cells_x + abx / 2) * 8);
+                              f->entropy8 ? f->entropy8 + ((aby / 2) * cells_x + abx / 2) * 8 : NULL);
             }
           adjust_quant_field(g.strategy + by_img0 * g.bstride + bx_img0 + tbx0,
                              g.raw_quant + by_img0 * g.bstride + bx_img0 + tbx0, g.bstride,
@@ -1243,7 +1245,7 @@ static void* group_worker(void* arg) {
 }
 
 int orc_encode_hot_path_threads(const float* const planes[3], size_t stride, size_t xsize, size_t ysize,
-                                float distance, int force_dct8, int nthreads, orc_frame* f) {
+                                float distance, int force_dct8, int nthreads, int keep_intermediates, orc_frame* f) {
   memset(f, 0, sizeof *f);
   if (xsize == 0 || ysize == 0 || !(distance > 0)) return 1;
   /* ref quirk F12: images that fit one 8x8 block trap in the reference. */
@@ -1266,7 +1268,7 @@ int orc_encode_hot_path_threads(const float* const planes[3], size_t stride, siz
   const size_t ngroups = f->xsize_groups * f->ysize_groups;
   for (int c = 0; c < 3; c++) {
     f->quant_dc[c] = (int16_t*)xcalloc(nblocks, sizeof(int16_t));
-    f->xyb[c] = (float*)xcalloc(nblocks * 64, sizeof(float));
+    if (keep_intermediates) f->xyb[c] = (float*)xcalloc(nblocks * 64, sizeof(float));
   }
   f->raw_quant_field = (uint8_t*)xcalloc(nblocks, 1);
   f->ac_strategy = (uint8_t*)xcalloc(nblocks, 1);
@@ -1275,11 +1277,14 @@ int orc_encode_hot_path_threads(const float* const planes[3], size_t stride, siz
   f->ytob_map = (int8_t*)xcalloc(ntiles, 1);
   f->group_tokens = (uint8_t**)xcalloc(ngroups, sizeof(uint8_t*));
   f->group_token_bytes = (size_t*)xcalloc(ngroups, sizeof(size_t));
-  f->quant_field = (float*)xcalloc(nblocks, sizeof(float));
-  f->masking = (float*)xcalloc(nblocks, sizeof(float));
   const size_t cells_x = f->xsize_blocks / 2 + 1, cells_y = f->ysize_blocks / 2 + 1;
-  f->entropy8 = (float*)xcalloc(cells_x * cells_y * 8, sizeof(float));
-  for (size_t i = 0; i < cells_x * cells_y * 8; i++) f->entropy8[i] = NAN;
+  if (keep_intermediates) {
+    /* (debug outputs for the parity tests: 13 bytes per pixel that the timed CPU baseline does not fill) */
+    f->quant_field = (float*)xcalloc(nblocks, sizeof(float));
+    f->masking = (float*)xcalloc(nblocks, sizeof(float));
+    f->entropy8 = (float*)xcalloc(cells_x * cells_y * 8, sizeof(float));
+    for (size_t i = 0; i < cells_x * cells_y * 8; i++) f->entropy8[i] = NAN;
+  }
 
   frame_grids g;
   g.bstride = f->xsize_blocks;
@@ -1346,7 +1351,7 @@ int orc_encode_hot_path_threads(const float* const planes[3], size_t stride, siz
 
 int orc_encode_hot_path(const float* const planes[3], size_t stride, size_t xsize, size_t ysize,
                         float distance, int force_dct8, orc_frame* f) {
-  return orc_encode_hot_path_threads(planes, stride, xsize, ysize, distance, force_dct8, 1, f);
+  return orc_encode_hot_path_threads(planes, stride, xsize, ysize, distance, force_dct8, 1, 1, f);
 }
 
 void orc_frame_free(orc_frame* f) {

@@ -82,9 +82,10 @@ int orc_encode_hot_path(const float* const planes[3], size_t stride_floats,
 /* The same with the frame's 256x256 groups -- the reference's independent units, enc_frame.cc:716-757 -- spread over
  * nthreads POSIX threads (the caller is one of them).  Same results as orc_encode_hot_path, which is this with one
  * thread (the reference's own behaviour: its ThreadPool is never used).  bench.py's cpu_baseline
- * "all_cores" leg uses it. */
+ * legs use it.  keep_intermediates 0: the optional intermediates of orc_frame (xyb, quant_field, masking,
+ * entropy8) stay NULL -- the reference does not keep them either. */
 int orc_encode_hot_path_threads(const float* const planes[3], size_t stride_floats, size_t xsize, size_t ysize,
-                                float distance, int force_dct8, int nthreads, orc_frame* out);
+                                float distance, int force_dct8, int nthreads, int keep_intermediates, orc_frame* out);
 void orc_frame_free(orc_frame* f);
 /* Emulates a later EncodeFile call of a process whose first call used `first_call_distance`
  * (the reference's function-local static constants, enc_ac_strategy.cc:178-185); 0 = off. */

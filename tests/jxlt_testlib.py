@@ -119,7 +119,7 @@ def oracle():
                                           C.c_float, C.c_int, C.POINTER(OrcFrame)]
         L.orc_encode_hot_path.restype = C.c_int
         L.orc_encode_hot_path_threads.argtypes = [C.POINTER(fp), C.c_size_t, C.c_size_t, C.c_size_t,
-                                                  C.c_float, C.c_int, C.c_int, C.POINTER(OrcFrame)]
+                                                  C.c_float, C.c_int, C.c_int, C.c_int, C.POINTER(OrcFrame)]
         L.orc_encode_hot_path_threads.restype = C.c_int
         L.orc_frame_free.argtypes = [C.POINTER(OrcFrame)]
         L.orc_compute_distance_params.argtypes = [C.c_float, C.POINTER(OrcDistanceParams)]
@@ -162,7 +162,7 @@ def oracle_hot_path(planes, distance, force_dct8=False, keep=False, nthreads=1):
     f = OrcFrame()
     if nthreads > 1 and hasattr(L, "orc_encode_hot_path_threads"):
         rc = L.orc_encode_hot_path_threads(_plane_ptrs(planes), w, w, h, C.c_float(distance), int(force_dct8),
-                                           int(nthreads), C.byref(f))
+                                           int(nthreads), 1, C.byref(f))
     else:
         rc = L.orc_encode_hot_path(_plane_ptrs(planes), w, w, h, C.c_float(distance), int(force_dct8),
                                    C.byref(f))
@@ -538,7 +538,7 @@ def oracle_encode_file(planes, distance, nthreads=1, reference_single_symbol=Non
     f = OrcFrame()
     t0 = time.perf_counter()
     rc = L.orc_encode_hot_path_threads(_plane_ptrs(planes), w, w, h, C.c_float(distance), 0, int(max(1, nthreads)),
-                                       C.byref(f))
+                                       0, C.byref(f))
     if rc != 0:
         raise ValueError("oracle rejected input: rc=%d" % rc)
     t1 = time.perf_counter()
