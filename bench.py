@@ -170,15 +170,18 @@ def main():
     size, d = args.size, args.distance
     sharded = world > 1 and not args.replicas
     if sharded:
-        y0, y1 = pkg.shard_rows(size, world, rank)
+        # this rank's rectangle of whole DC groups (16384^2 over 1 / 2 / 4 / 8: rows of DC groups)
+        x0, y0, x1, y1 = pkg.shard_rect(size, size, world, rank)
     else:
-        y0, y1 = 0, size
+        x0, y0, x1, y1 = 0, 0, size, size
     seed = rank if (world > 1 and args.replicas) else 0
     slab = frame_rows_on_device(torch, size, y0, y1, seed, device) if y1 > y0 else None
+    if slab is not None and (x0, x1) != (0, size):
+        slab = slab[:, :, x0:x1].contiguous()  # (the rectangle alone stays resident)
     torch.cuda.synchronize()
     enc = pkg.Encoder(dev_index)
     if slab is not None:
-        enc.set_device_image([slab[c].data_ptr() for c in range(3)], size * 4, size, y1 - y0, keepalive=slab)
+        enc.set_device_image([slab[c].data_ptr() for c in range(3)], (x1 - x0) * 4, x1 - x0, y1 - y0, keepalive=slab)
 
     group = None
     if sharded:
@@ -227,7 +230,7 @@ def main():
                 v = pipe.wait(tickets[k - pipe.depth])
                 if check is not None and v is not None:
                     check(v)
-            tickets.append(pipe.submit_device(ptrs, size * 4, size, size, rows, d))
+            tickets.append(pipe.submit_device(ptrs, (x1 - x0) * 4, size, size, rows, d))
         for tk in tickets[max(0, frames - pipe.depth):]:
             v = pipe.wait(tk)
             if check is not None and v is not None:
@@ -279,7 +282,7 @@ def main():
     mpix = size * size / 1e6
     value = frames * mpix * args.steps / elapsed
     tile_ms = ktimes.get("tile_kernel", float("nan"))
-    slab_pixels = (y1 - y0) * size
+    slab_pixels = (y1 - y0) * (x1 - x0)
     achieved = ALGO_BYTES_PER_PIXEL * slab_pixels / (tile_ms * 1e-3) / 1e9 if slab_pixels else float("nan")
 
     # ---- legs every rank takes part in (outside the timed region)
@@ -330,12 +333,12 @@ def main():
         "config": {
             "workload": ("ONE %dx%d synthetic linear-sRGB frame%s, distance %.2f, full 8x8/16x8/8x16 strategy search + "
                          "adaptive quant + chroma-from-luma" %
-                         (size, size, " sharded over %d GPUs in row slabs of whole DC groups (BASELINE config #4)" % world
+                         (size, size, " sharded over %d GPUs in rectangles of whole DC groups (here: rows of DC groups; BASELINE config #4)" % world
                           if sharded else (" per GPU (independent replicas)" if world > 1 else ""), d)),
-            "parallelism": ("DC-group rows r -> GPU r*N/rows; host-side histogram sum on rank 0 (shared memory), every "
+            "parallelism": ("DC groups -> GPUs by index (rectangles of whole DC groups); host-side histogram sum on rank 0 (shared memory), every "
                             "GPU writes its sections into one output buffer; no RCCL on the data path" if sharded else
                             "one independent frame per rank, no data-path collective" if world > 1 else "single GPU"),
-            "rows_on_rank0": [y0, y1], "codestream_bytes": len(jxl_bytes),
+            "rect_on_rank0": [x0, y0, x1, y1], "codestream_bytes": len(jxl_bytes),
             "codestream_sha256": hashlib.sha256(jxl_bytes).hexdigest()[:16]},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),

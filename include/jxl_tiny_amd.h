@@ -326,7 +326,7 @@ int jxlt_write_file_header(size_t xsize, size_t ysize, uint8_t** out_bytes, size
 /* ---- one frame sharded over several GPUs (BASELINE config #4) -----------------
  * The reference's unit of independent work is the DC group (the loop enc_frame.cc:839-844); its one global
  * synchronisation point is the code optimisation over all sections (enc_frame.cc:846-850).  Here a frame is
- * cut into row slabs of whole DC groups (2048 rows; jxlt_shard_rows), one per participant; every participant
+ * cut into rectangles of whole DC groups (2048 x 2048 pixels; jxlt_shard_rect), one per participant; every participant
  * runs the complete device pipeline on its slab with its own device context.  The only exchange is on the
  * host: the 2 x 64 x 64 symbol histograms are summed by participant 0, which builds the two prefix codes and
  * hands the code tables back; every participant then entropy-codes its sections on its GPU and copies them
@@ -337,9 +337,13 @@ int jxlt_write_file_header(size_t xsize, size_t ysize, uint8_t** out_bytes, size
  * jxl::SetEncoderDevices / JXLT_DEVICES names several GPUs) or one process per GPU that meet in a POSIX
  * shared-memory segment (jxlt_shard_group_*: what bench.py's ranks use). */
 
-/* Rows [*y0, *y1) of participant `rank` of `world` for a frame of ysize rows: whole DC-group rows, balanced,
- * in order (an empty range when there are fewer DC-group rows than participants). */
-int jxlt_shard_rows(size_t ysize, int world, int rank, size_t* y0, size_t* y1);
+/* The pixels [*x0, *x1) x [*y0, *y1) of participant `rank` of `world` for an xsize x ysize frame: a rectangle of
+ * whole DC groups ("groups shard by index": the frame's grid of DC groups is cut into bands of rows and every band
+ * into column ranges, so that the largest rectangle is as small as possible -- 16384^2 over 8: eight rows of DC
+ * groups; 16384 x 2048 over 8: one DC group each; 8192^2 over 8: 2 x 1 DC groups each).  An empty rectangle when
+ * there are fewer DC groups than participants.  A rectangle's sections are not one range of the codestream: every
+ * participant's device writes one run of bytes per row of its DC groups / groups (jxlt_pack_deliver, runs). */
+int jxlt_shard_rect(size_t xsize, size_t ysize, int world, int rank, size_t* x0, size_t* y0, size_t* x1, size_t* y1);
 
 typedef struct jxlt_multi_encoder jxlt_multi_encoder;
 /* One device context + one host thread per entry of device_ordinals (an ordinal may repeat: several
@@ -356,10 +360,11 @@ int jxlt_multi_encoder_encode(jxlt_multi_encoder* enc, const float* const planes
 /* The same for the raw sample payload of a PFM file (jxlt_image_upload_pfm). */
 int jxlt_multi_encoder_encode_pfm(jxlt_multi_encoder* enc, const void* host_payload, size_t xsize, size_t ysize,
                                   int big_endian, float distance, const uint8_t** bytes, size_t* size);
-/* A frame that already is in the devices' HBM: slab `slab` (rows jxlt_shard_rows(ysize, num_devices, slab))
- * as three planes in the memory of that slab's device; then encode.  The planes are read in place. */
+/* A frame that already is in the devices' HBM: slab `slab` -- the rectangle jxlt_shard_rect(xsize, ysize,
+ * num_devices, slab), xsize_of_slab x rows pixels -- as three planes in the memory of that slab's device; then
+ * encode.  The planes are read in place. */
 int jxlt_multi_encoder_set_device_slab(jxlt_multi_encoder* enc, int slab, const void* const device_planes[3],
-                                       size_t pitch_bytes, size_t xsize, size_t rows);
+                                       size_t pitch_bytes, size_t xsize_of_slab, size_t rows);
 int jxlt_multi_encoder_encode_resident(jxlt_multi_encoder* enc, size_t xsize, size_t ysize, float distance,
                                        const uint8_t** bytes, size_t* size);
 
@@ -373,7 +378,7 @@ int jxlt_shard_group_open(const char* shm_name, int rank, int world, size_t outp
 void jxlt_shard_group_close(jxlt_shard_group* group);
 const char* jxlt_shard_group_last_error(const jxlt_shard_group* group);
 /* Collective over the group's ranks: `ctx` holds this rank's slab of an xsize x ysize frame (rows
- * jxlt_shard_rows(ysize, world, rank); jxlt_image_upload* / jxlt_image_set_device* with that many rows; ranks
+ * jxlt_shard_rect(xsize, ysize, world, rank); jxlt_image_upload* / jxlt_image_set_device* with its width and height; ranks
  * with an empty range pass any context).  On rank 0 *bytes / *size receive the complete codestream (inside
  * the segment, valid until the next encode); NULL / 0 on the other ranks. */
 int jxlt_shard_encode(jxlt_shard_group* group, jxlt_context* ctx, size_t xsize, size_t ysize, float distance,
@@ -392,7 +397,8 @@ int jxlt_shard_pipeline_open(const char* shm_name, int rank, int world, int devi
                              size_t output_capacity, size_t max_sections, jxlt_shard_pipeline** out);
 void jxlt_shard_pipeline_close(jxlt_shard_pipeline* pipeline);
 const char* jxlt_shard_pipeline_last_error(const jxlt_shard_pipeline* pipeline);
-/* This rank's slab of the next frame (rows jxlt_shard_rows(ysize, world, rank); slab_rows 0: none), resident in
+/* This rank's slab of the next frame (the rectangle jxlt_shard_rect(xsize, ysize, world, rank), device_planes
+ * pointing at its first sample, slab_rows its height; slab_rows 0: none), resident in
  * device memory and read in place: it must stay valid until the frame's wait has returned.  Returns at once
  * unless the lane's previous frame (depth frames back) is still being encoded. */
 int jxlt_shard_pipeline_submit_device(jxlt_shard_pipeline* pipeline, const void* const device_planes[3],

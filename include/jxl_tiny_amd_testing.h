@@ -44,7 +44,8 @@ typedef struct {
   int (*ac_histogram)(void* self, const uint32_t** histogram);               /* jxlt_fetch_histograms */
   int (*measure)(void* self, const uint32_t* ac_code_table, jxlt_packed_sections* dc,
                  jxlt_packed_sections* ac);                                  /* jxlt_pack_begin(1) + jxlt_pack_sizes(0 / 1) */
-  int (*write)(void* self, uint8_t* dc_dst, uint8_t* ac_dst);                /* jxlt_pack_deliver(0 / 1) */
+  int (*write)(void* self, uint8_t* out, const jxlt_section_run* dc_runs, size_t num_dc_runs,
+               const jxlt_section_run* ac_runs, size_t num_ac_runs);         /* jxlt_pack_deliver(0 / 1, out, runs) */
   int (*finish)(void* self);                                                 /* jxlt_synchronize */
 } jxlt_slab_ops;
 int jxlt_shard_encode_ops(jxlt_shard_group* group, const jxlt_slab_ops* ops, size_t xsize, size_t ysize,

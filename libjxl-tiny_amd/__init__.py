@@ -42,7 +42,7 @@ HOST_SYMBOLS = ["jxlt_compute_distance_params", "jxlt_assemble_frame", "jxlt_ass
                 "jxlt_encode_file_planar", "jxlt_encode_pfm_file", "jxlt_emulate_reference_static_constants", "jxlt_emulate_reference_single_symbol_codes", "jxlt_encode_resident", "jxlt_encode_resident_view", "jxlt_write_file_header", "jxlt_build_code_tables", "jxlt_finish_frame",
                 "jxlt_free", "jxlt_batch_encoder_create", "jxlt_batch_encoder_create_multi",
                 "jxlt_batch_encoder_destroy", "jxlt_batch_encoder_run",
-                "jxlt_shard_rows", "jxlt_multi_encoder_create", "jxlt_multi_encoder_destroy",
+                "jxlt_shard_rect", "jxlt_multi_encoder_create", "jxlt_multi_encoder_destroy",
                 "jxlt_multi_encoder_last_error", "jxlt_multi_encoder_encode", "jxlt_multi_encoder_encode_pfm",
                 "jxlt_multi_encoder_set_device_slab", "jxlt_multi_encoder_encode_resident",
                 "jxlt_shard_group_open", "jxlt_shard_group_close", "jxlt_shard_group_last_error",
@@ -610,14 +610,16 @@ class BatchEncoder:
 
 
 # --------------------------------------------------------------------------- one frame over several GPUs
-def shard_rows(ysize, world, rank):
-    """(y0, y1): rows of participant `rank` of `world` (whole DC-group rows; jxlt_shard_rows)."""
+def shard_rect(xsize, ysize, world, rank):
+    """(x0, y0, x1, y1): the pixels of participant `rank` of `world` -- a rectangle of whole DC groups, empty when
+    there are fewer DC groups than participants (jxlt_shard_rect)."""
     L = host_lib()
-    L.jxlt_shard_rows.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
-    y0, y1 = C.c_size_t(), C.c_size_t()
-    if L.jxlt_shard_rows(ysize, world, rank, C.byref(y0), C.byref(y1)) != 0:
-        raise JxlTinyError("jxlt_shard_rows: invalid arguments")
-    return y0.value, y1.value
+    sz = C.POINTER(C.c_size_t)
+    L.jxlt_shard_rect.argtypes = [C.c_size_t, C.c_size_t, C.c_int, C.c_int, sz, sz, sz, sz]
+    v = [C.c_size_t() for _ in range(4)]
+    if L.jxlt_shard_rect(xsize, ysize, world, rank, *[C.byref(t) for t in v]) != 0:
+        raise JxlTinyError("jxlt_shard_rect: invalid arguments")
+    return tuple(int(t.value) for t in v)
 
 
 class MultiEncoder:
@@ -695,13 +697,20 @@ class MultiEncoder:
         return NativeView(out, n.value)
 
 
+class SectionRun(C.Structure):
+    """jxlt_section_run: sections [first_section, first_section + num_sections) of a context's frame go, back to
+    back, to dst_offset bytes into the destination."""
+    _fields_ = [("first_section", C.c_uint32), ("num_sections", C.c_uint32), ("dst_offset", C.c_uint64)]
+
+
 _SLAB_FN = {
     "enqueue": C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Params)),
     "dc_histogram": C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.POINTER(C.c_uint32))),
     "begin_dc_pack": C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32)),
     "ac_histogram": C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.POINTER(C.c_uint32))),
     "measure": C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(PackedSections), C.POINTER(PackedSections)),
-    "write": C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)),
+    "write": C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(SectionRun), C.c_size_t,
+                         C.POINTER(SectionRun), C.c_size_t),
     "finish": C.CFUNCTYPE(C.c_int, C.c_void_p),
 }
 

@@ -493,14 +493,14 @@ void SetEncoderDevices(const int* device_ordinals, int n) {
 
 namespace jxlt {
 // The frame over the process's device list (jxl::SetEncoderDevices / JXLT_DEVICES) when that names several
-// GPUs and the frame has more than one row of DC groups.  *used = false: not applicable, nothing done.
+// GPUs and the frame has more than one DC group (a PFM payload: more than one row of DC groups).  *used = false: not applicable, nothing done.
 // Otherwise the complete codestream (file header + frame) is in *codestream, or false is returned.
 bool EncodeOnDeviceList(const float* const planes[3], size_t pitch_bytes, const void* pfm_payload, int big_endian,
                         size_t xsize, size_t ysize, float distance, std::vector<uint8_t>* codestream, bool* used) {
   using namespace jxl;
   std::lock_guard<std::mutex> lock(g_multi_mu);
   DevicesFromEnvironment();
-  *used = g_devices.size() > 1 && ysize > 2048;
+  *used = g_devices.size() > 1 && (ysize > 2048 || (xsize > 2048 && pfm_payload == nullptr));
   if (!*used) return true;
   if (g_multi && g_multi_devices != g_devices) DestroyMultiEncoderLocked();
   if (!g_multi) {

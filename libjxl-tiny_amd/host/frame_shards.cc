@@ -62,7 +62,8 @@ struct Control {
   std::atomic<int32_t> failed;                        // sticky first error
   std::atomic<uint32_t> sleepers;                     // participants asleep in a futex wait on one of the counters
   std::atomic<uint32_t> attached;                     // processes that have mapped the segment (its name goes once all have)
-  uint64_t dc_at[kMaxWorld], ac_at[kMaxWorld];        // kLayout: where each participant's sections go
+  uint64_t dc_begin, ac_begin;                        // kLayout: where the DC-group / AC-group sections start in the output
+                                                      // (every section's offset from there: the sec_off table)
   uint32_t dc_table[kHistWords], ac_table[kHistWords];
   uint32_t ac_global_size;                            // kAcTable: the serialised ACGlobal section (its builder is
   uint8_t ac_global[16384];                           // not the participant that assembles the frame)
@@ -71,7 +72,8 @@ struct Control {
 static_assert(std::atomic<uint64_t>::is_always_lock_free, "the control block needs lock-free atomics");
 
 size_t ControlBytes() { return (sizeof(Control) + 4095) & ~size_t(4095); }
-size_t TablesBytes(size_t max_sections) { return (2 * max_sections * sizeof(uint32_t) + 4095) & ~size_t(4095); }
+// (per section: bits u32, bytes u32, offset u64 -- the offset from the start of its kind's sections, kLayout)
+size_t TablesBytes(size_t max_sections) { return (max_sections * (2 * sizeof(uint32_t) + sizeof(uint64_t)) + 8 + 4095) & ~size_t(4095); }
 
 }  // namespace
 }  // namespace jxlt
@@ -95,29 +97,92 @@ struct jxlt_shard_group {
   uint64_t frame[jxlt::kMaxWorld] = {};  // frames begun, per participant of this process
   uint32_t* sec_bits() const { return reinterpret_cast<uint32_t*>(base + jxlt::ControlBytes()); }
   uint32_t* sec_bytes() const { return sec_bits() + ctl->max_sections; }
+  uint64_t* sec_off() const { return reinterpret_cast<uint64_t*>(sec_bits() + 2 * ((ctl->max_sections + 1) & ~uint64_t(1))); }
   uint8_t* output() const { return base + ctl->output_offset; }
 };
 
 namespace jxlt {
 namespace {
 
-void ShardRows(size_t ysize, int world, int rank, size_t* y0, size_t* y1) {
-  // whole DC-group rows, the remainder to the first participants (so a frame with a single
-  // DC-group row belongs to participant 0)
-  const size_t ndc = (ysize + 2047) / 2048, w = static_cast<size_t>(world), r = static_cast<size_t>(rank);
-  const size_t lo = (ndc / w) * r + std::min(r, ndc % w);
-  const size_t hi = lo + ndc / w + (r < ndc % w ? 1 : 0);
-  *y0 = std::min(ysize, lo * 2048);
-  *y1 = std::min(ysize, hi * 2048);
+// The frame's DC groups (2048 x 2048 pixels: the reference's unit of independent work, enc_frame.cc:839-844) dealt
+// out to `world` participants as RECTANGLES of whole DC groups -- a slab must be a rectangle of pixels to be a frame
+// of its own to the kernels, and a rectangle's sections are a few runs of the codestream (one per row of DC groups /
+// of groups).  The grid of xdc x ydc DC groups is cut into B bands of rows; band b is cut into n_b column ranges,
+// sum n_b = the participants that get work (at most one per DC group); band heights follow the n_b.  Of all B the
+// one with the smallest largest rectangle wins, ties go to the larger B (fewer column cuts: fewer runs).  Examples:
+// 8 x 8 (16384^2) over 8: eight rows of DC groups, as in rounds 1-3; 8 x 1 (16384 x 2048) over 8: one DC group
+// each; 4 x 4 (8192^2) over 8: four bands of two rectangles of 2 x 1; 8 x 8 over 5: two bands (three rectangles
+// of 3|3|2 x 5, two of 4 x 3) -- 15 DC groups at most instead of 16 with rows alone.
+// rows_only: bands only, one participant per band (a PFM payload is cut along its rows: they are contiguous in the file).
+struct DcRect {
+  size_t x0 = 0, y0 = 0, x1 = 0, y1 = 0;  // in DC groups; empty: no work for this participant
+  bool empty() const { return x1 <= x0 || y1 <= y0; }
+};
+void ShardPartition(size_t xdc, size_t ydc, int world, bool rows_only, DcRect* out) {
+  for (int r = 0; r < world; ++r) out[r] = DcRect();
+  const size_t w = std::min<size_t>(static_cast<size_t>(world), rows_only ? ydc : xdc * ydc);  // participants with work
+  if (w == 0) return;
+  size_t best_b = 0, best_cost = ~size_t(0);
+  std::vector<size_t> edges, best_edges;
+  const size_t b_lo = rows_only ? w : 1, b_hi = std::min(ydc, w);
+  for (size_t nb = b_lo; nb <= b_hi; ++nb) {
+    const size_t base = w / nb, extra = w % nb;  // band k has base + (k < extra) participants
+    if (base + (extra ? 1 : 0) > xdc) continue;
+    // band boundaries: heights proportional to the bands' participants, every band at least one row
+    edges.assign(nb + 1, 0);
+    size_t cum = 0, cost = 0;
+    for (size_t k = 0; k < nb; ++k) {
+      const size_t n = base + (k < extra ? 1 : 0);
+      cum += n;
+      size_t e = k + 1 == nb ? ydc : (ydc * cum + w / 2) / w;
+      e = std::max(e, edges[k] + 1);
+      e = std::min(e, ydc - (nb - 1 - k));
+      edges[k + 1] = e;
+      cost = std::max(cost, ((xdc + n - 1) / n) * (e - edges[k]));
+    }
+    if (cost < best_cost || (cost == best_cost && nb > best_b)) {
+      best_cost = cost;
+      best_b = nb;
+      best_edges = edges;
+    }
+  }
+  if (best_b == 0) return;
+  const size_t base = w / best_b, extra = w % best_b;
+  int r = 0;
+  for (size_t k = 0; k < best_b; ++k) {
+    const size_t n = base + (k < extra ? 1 : 0);
+    for (size_t j = 0; j < n; ++j, ++r) {
+      out[r].x0 = xdc * j / n;
+      out[r].x1 = xdc * (j + 1) / n;
+      out[r].y0 = best_edges[k];
+      out[r].y1 = best_edges[k + 1];
+    }
+  }
 }
 
-int NonEmptySlabs(size_t ysize, int world) {
+// Participant `rank`'s rectangle of an xsize x ysize frame, in pixels.
+struct PixelRect {
+  size_t x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  bool empty() const { return x1 <= x0 || y1 <= y0; }
+  size_t width() const { return x1 - x0; }
+  size_t height() const { return y1 - y0; }
+};
+PixelRect ShardRect(size_t xsize, size_t ysize, int world, int rank, bool rows_only = false) {
+  const size_t xdc = (xsize + 2047) / 2048, ydc = (ysize + 2047) / 2048;
+  DcRect all[kMaxWorld];
+  ShardPartition(xdc, ydc, world, rows_only, all);
+  PixelRect p;
+  if (all[rank].empty()) return p;
+  p.x0 = all[rank].x0 * 2048;
+  p.y0 = all[rank].y0 * 2048;
+  p.x1 = std::min(xsize, all[rank].x1 * 2048);
+  p.y1 = std::min(ysize, all[rank].y1 * 2048);
+  return p;
+}
+
+int NonEmptySlabs(size_t xsize, size_t ysize, int world, bool rows_only = false) {
   int n = 0;
-  for (int r = 0; r < world; ++r) {
-    size_t y0, y1;
-    ShardRows(ysize, world, r, &y0, &y1);
-    n += y1 > y0;
-  }
+  for (int r = 0; r < world; ++r) n += !ShardRect(xsize, ysize, world, r, rows_only).empty();
   return n;
 }
 
@@ -215,7 +280,7 @@ int Fail(jxlt_shard_group* g, int rc, const char* what) {
 
 // The protocol, run by every participant with its own slab operations.
 int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t xsize, size_t ysize,
-                float distance, const uint8_t** bytes, size_t* size) {
+                float distance, const uint8_t** bytes, size_t* size, bool rows_only = false) {
   Control* c = g->ctl;
   const int world = g->world;
   if (bytes) *bytes = nullptr;
@@ -226,14 +291,20 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
   }
   const uint64_t frame = ++g->frame[rank];
   const uint64_t all = frame * static_cast<uint64_t>(world);
-  size_t y0, y1;
-  ShardRows(ysize, world, rank, &y0, &y1);
-  const bool empty = y1 == y0;
+  const PixelRect rect = ShardRect(xsize, ysize, world, rank, rows_only);
+  const bool empty = rect.empty();
   const size_t xdc = (xsize + 2047) / 2048, xgroups = (xsize + 255) / 256;
   const size_t ndc_frame = xdc * ((ysize + 2047) / 2048), ngroups_frame = xgroups * ((ysize + 255) / 256);
-  // first section of this slab in the frame's raster order
-  const size_t dc_first = xdc * (y0 / 2048), ac_first = xgroups * (y0 / 256);
-  const size_t ndc = xdc * ((y1 - y0 + 2047) / 2048), nac = xgroups * ((y1 - y0 + 255) / 256);
+  // The slab's sections in the frame's raster order: its DC groups / AC groups are a rectangle of the frame's grid,
+  // row `j` of it (sw_* sections wide) starts at frame index *_first + j * (row length of the frame).  The slab's own
+  // section order (a frame of its own to the device) is the same rectangle in raster order.
+  const size_t dc_first = empty ? 0 : xdc * (rect.y0 / 2048) + rect.x0 / 2048;
+  const size_t ac_first = empty ? 0 : xgroups * (rect.y0 / 256) + rect.x0 / 256;
+  const size_t sw_dc = empty ? 0 : (rect.width() + 2047) / 2048, sh_dc = empty ? 0 : (rect.height() + 2047) / 2048;
+  const size_t sw_ac = empty ? 0 : (rect.width() + 255) / 256, sh_ac = empty ? 0 : (rect.height() + 255) / 256;
+  const size_t ndc = sw_dc * sh_dc, nac = sw_ac * sh_ac;
+  const auto dc_frame_index = [&](size_t i) { return dc_first + (i / sw_dc) * xdc + i % sw_dc; };
+  const auto ac_frame_index = [&](size_t i) { return ac_first + (i / sw_ac) * xgroups + i % sw_ac; };
   if (ndc_frame + ngroups_frame > c->max_sections)
     return Fail(g, JXLT_ERR_OUT_OF_MEMORY, "frame has more sections than the shard group was opened for");
   if (ndc_frame + ngroups_frame == 2)
@@ -321,12 +392,12 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
     uint32_t* bits = g->sec_bits();
     uint32_t* sizes = g->sec_bytes();
     for (size_t i = 0; i < ndc; ++i) {
-      bits[dc_first + i] = dcm.section_bits[i];
-      sizes[dc_first + i] = static_cast<uint32_t>(dcm.section_offset[i + 1] - dcm.section_offset[i]);
+      bits[dc_frame_index(i)] = dcm.section_bits[i];
+      sizes[dc_frame_index(i)] = static_cast<uint32_t>(dcm.section_offset[i + 1] - dcm.section_offset[i]);
     }
     for (size_t i = 0; i < nac; ++i) {
-      bits[ndc_frame + ac_first + i] = acm.section_bits[i];
-      sizes[ndc_frame + ac_first + i] = static_cast<uint32_t>(acm.section_offset[i + 1] - acm.section_offset[i]);
+      bits[ndc_frame + ac_frame_index(i)] = acm.section_bits[i];
+      sizes[ndc_frame + ac_frame_index(i)] = static_cast<uint32_t>(acm.section_offset[i + 1] - acm.section_offset[i]);
     }
   }
   Arrive(c, kSizes);
@@ -351,20 +422,42 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
     total_end = ac_begin + ac_off[ngroups_frame];
     if (total_end + 16 > c->output_capacity)
       return Fail(g, JXLT_ERR_OUT_OF_MEMORY, "codestream does not fit the shard group's output area");
-    for (int r = 0; r < world; ++r) {
-      size_t r0, r1;
-      ShardRows(ysize, world, r, &r0, &r1);
-      c->dc_at[r] = dc_begin + dc_off[xdc * (r0 / 2048)];
-      c->ac_at[r] = ac_begin + ac_off[xgroups * (r0 / 256)];
-    }
+    // every participant places its own sections: their offsets from the start of their kind, for all to read
+    uint64_t* off = g->sec_off();
+    for (size_t i = 0; i < ndc_frame; ++i) off[i] = dc_off[i];
+    for (size_t i = 0; i < ngroups_frame; ++i) off[ndc_frame + i] = ac_off[i];
+    c->dc_begin = dc_begin;
+    c->ac_begin = ac_begin;
     Publish(c, kLayout, frame);
   } else if ((rc = WaitAtLeast(g, &c->published[kLayout], frame)) != JXLT_OK) {
     return rc;
   }
 
-  // ---- every participant's device writes its sections in place
+  // ---- every participant's device writes its sections in place: a run of the codestream per row of the slab's
+  // DC groups / groups (rows that follow each other in the frame's order -- a slab as wide as the frame -- are one run)
   uint8_t* out = g->output();
-  SLAB(ops->write(ops->self, out + c->dc_at[rank], out + c->ac_at[rank]), "section placement failed");
+  std::vector<jxlt_section_run> dc_runs, ac_runs;
+  if (!empty) {
+    const uint64_t* off = g->sec_off();
+    const auto runs_of = [&](size_t sw, size_t sh, size_t first, size_t frame_row, uint64_t begin, const uint64_t* o,
+                             std::vector<jxlt_section_run>* runs) {
+      for (size_t j = 0; j < sh; ++j) {
+        const size_t f = first + j * frame_row;  // frame index of the row's first section
+        if (!runs->empty() && sw == frame_row) {
+          runs->back().num_sections += static_cast<uint32_t>(sw);  // (continues the run before it)
+          continue;
+        }
+        jxlt_section_run run;
+        run.first_section = static_cast<uint32_t>(j * sw);
+        run.num_sections = static_cast<uint32_t>(sw);
+        run.dst_offset = begin + o[f];
+        runs->push_back(run);
+      }
+    };
+    runs_of(sw_dc, sh_dc, dc_first, xdc, c->dc_begin, off, &dc_runs);
+    runs_of(sw_ac, sh_ac, ac_first, xgroups, c->ac_begin, off + ndc_frame, &ac_runs);
+  }
+  SLAB(ops->write(ops->self, out, dc_runs.data(), dc_runs.size(), ac_runs.data(), ac_runs.size()), "section placement failed");
   size_t frame_begin = 0;
   if (rank == 0) {
     const PackedSections dc = {nullptr, dc_off.data(), g->sec_bits(), ndc_frame};
@@ -414,10 +507,11 @@ int CtxMeasure(void* self, const uint32_t* t, jxlt_packed_sections* dc, jxlt_pac
   if (rc == JXLT_OK) rc = jxlt_pack_sizes(ctx, 1, ac);
   return rc;
 }
-int CtxWrite(void* self, uint8_t* dc_dst, uint8_t* ac_dst) {
+int CtxWrite(void* self, uint8_t* out, const jxlt_section_run* dc_runs, size_t n_dc, const jxlt_section_run* ac_runs,
+             size_t n_ac) {
   jxlt_context* ctx = static_cast<jxlt_context*>(self);
-  const int rc = jxlt_pack_deliver(ctx, 0, dc_dst, nullptr, 0, 0);
-  return rc != JXLT_OK ? rc : jxlt_pack_deliver(ctx, 1, ac_dst, nullptr, 0, 0);
+  const int rc = jxlt_pack_deliver(ctx, 0, out, dc_runs, n_dc, 0);
+  return rc != JXLT_OK ? rc : jxlt_pack_deliver(ctx, 1, out, ac_runs, n_ac, 0);
 }
 int CtxFinish(void* self) { return jxlt_synchronize(static_cast<jxlt_context*>(self)); }
 
@@ -458,8 +552,7 @@ struct jxlt_multi_encoder {
   const uint8_t* out_bytes = nullptr;
   size_t out_size = 0;
   // frames set slab by slab (jxlt_multi_encoder_set_device_slab)
-  std::vector<size_t> slab_rows;
-  size_t resident_xsize = 0;
+  std::vector<size_t> slab_rows, slab_cols;
 };
 
 namespace jxlt {
@@ -494,22 +587,24 @@ int EnsureLocalRegion(jxlt_multi_encoder* enc, size_t xsize, size_t ysize) {
 // What participant `rank` does for the current job.
 int RunParticipant(jxlt_multi_encoder* enc, int rank, const uint8_t** bytes, size_t* size) {
   jxlt_context* ctx = enc->ctx[rank];
-  size_t y0, y1;
-  ShardRows(enc->ysize, enc->group.world, rank, &y0, &y1);
+  // (a PFM payload is cut along its rows only: they are contiguous in the file, its columns are not)
+  const bool rows_only = enc->source == jxlt_multi_encoder::kHostPfm;
+  const PixelRect rect = ShardRect(enc->xsize, enc->ysize, enc->group.world, rank, rows_only);
   int rc = JXLT_OK;
-  if (y1 > y0) {
+  if (!rect.empty()) {
     if (enc->source == jxlt_multi_encoder::kHostPlanes) {
+      // the slab is a rectangle of the caller's planes: same pitch, moved base
       const float* slab[3];
       for (int c = 0; c < 3; ++c)
-        slab[c] = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(enc->planes[c]) + y0 * enc->pitch_bytes);
+        slab[c] = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(enc->planes[c]) + rect.y0 * enc->pitch_bytes) + rect.x0;
       // page-locked memory: the upload is pipelined under the slab's kernels; anything else is staged
-      rc = jxlt_image_attach_host(ctx, slab, enc->pitch_bytes, enc->xsize, y1 - y0);
-      if (rc != JXLT_OK) rc = jxlt_image_upload(ctx, slab, enc->pitch_bytes, enc->xsize, y1 - y0);
+      rc = jxlt_image_attach_host(ctx, slab, enc->pitch_bytes, rect.width(), rect.height());
+      if (rc != JXLT_OK) rc = jxlt_image_upload(ctx, slab, enc->pitch_bytes, rect.width(), rect.height());
     } else if (enc->source == jxlt_multi_encoder::kHostPfm) {
       // bottom-up payload: rows [y0, y1) from the top are the payload rows [ysize - y1, ysize - y0)
-      const uint8_t* slab = enc->pfm + (enc->ysize - y1) * enc->xsize * 3 * sizeof(float);
-      rc = jxlt_image_attach_host_pfm(ctx, slab, enc->xsize, y1 - y0, enc->pfm_big_endian);
-      if (rc != JXLT_OK) rc = jxlt_image_upload_pfm(ctx, slab, enc->xsize, y1 - y0, enc->pfm_big_endian);
+      const uint8_t* slab = enc->pfm + (enc->ysize - rect.y1) * enc->xsize * 3 * sizeof(float);
+      rc = jxlt_image_attach_host_pfm(ctx, slab, enc->xsize, rect.height(), enc->pfm_big_endian);
+      if (rc != JXLT_OK) rc = jxlt_image_upload_pfm(ctx, slab, enc->xsize, rect.height(), enc->pfm_big_endian);
     }
     if (rc != JXLT_OK) {
       enc->group.SetError(std::string("slab upload failed: ") + jxlt_last_error(ctx));
@@ -519,7 +614,7 @@ int RunParticipant(jxlt_multi_encoder* enc, int rank, const uint8_t** bytes, siz
     }
   }
   const jxlt_slab_ops ops = OpsOf(ctx);
-  return EncodeShard(&enc->group, rank, &ops, enc->xsize, enc->ysize, enc->distance, bytes, size);
+  return EncodeShard(&enc->group, rank, &ops, enc->xsize, enc->ysize, enc->distance, bytes, size, rows_only);
 }
 
 void WorkerLoop(jxlt_multi_encoder* enc, int rank) {
@@ -554,9 +649,12 @@ int RunJob(jxlt_multi_encoder* enc, const uint8_t** bytes, size_t* size) {
     enc->error = "empty frame";
     return JXLT_ERR_INVALID_ARGUMENT;
   }
-  if (NonEmptySlabs(enc->ysize, world) <= 1) {
-    // one DC-group row (or a single-group frame): nothing to shard -- the ordinary path on participant 0's
-    // device, which owns the only slab (ShardRows)
+  if (NonEmptySlabs(enc->xsize, enc->ysize, world, enc->source == jxlt_multi_encoder::kHostPfm) <= 1) {
+    // one DC group (or one row of DC groups of a PFM payload): nothing to shard -- the ordinary path on participant
+    // 0's device, which owns the only slab (ShardPartition)
+    if (enc->source == jxlt_multi_encoder::kResident) {
+      // (the caller has set the whole frame as slab 0)
+    }
     jxlt_context* ctx = enc->ctx[0];
     int rc = JXLT_OK;
     if (enc->source == jxlt_multi_encoder::kHostPlanes)
@@ -624,9 +722,15 @@ int RunJob(jxlt_multi_encoder* enc, const uint8_t** bytes, size_t* size) {
 
 extern "C" {
 
-int jxlt_shard_rows(size_t ysize, int world, int rank, size_t* y0, size_t* y1) {
-  if (!y0 || !y1 || world < 1 || world > jxlt::kMaxWorld || rank < 0 || rank >= world) return JXLT_ERR_INVALID_ARGUMENT;
-  jxlt::ShardRows(ysize, world, rank, y0, y1);
+int jxlt_shard_rect(size_t xsize, size_t ysize, int world, int rank, size_t* x0, size_t* y0, size_t* x1, size_t* y1) {
+  if (!x0 || !y0 || !x1 || !y1 || xsize == 0 || ysize == 0 || world < 1 || world > jxlt::kMaxWorld || rank < 0 ||
+      rank >= world)
+    return JXLT_ERR_INVALID_ARGUMENT;
+  const jxlt::PixelRect r = jxlt::ShardRect(xsize, ysize, world, rank);
+  *x0 = r.x0;
+  *y0 = r.y0;
+  *x1 = r.x1;
+  *y1 = r.y1;
   return JXLT_OK;
 }
 
@@ -649,6 +753,7 @@ int jxlt_multi_encoder_create(const int* device_ordinals, int num_devices, jxlt_
     enc->ctx.push_back(ctx);
   }
   enc->slab_rows.assign(num_devices, 0);
+  enc->slab_cols.assign(num_devices, 0);
   for (int r = 1; r < num_devices; ++r) enc->workers.emplace_back(jxlt::WorkerLoop, enc, r);
   *out = enc;
   return JXLT_OK;
@@ -704,7 +809,7 @@ int jxlt_multi_encoder_set_device_slab(jxlt_multi_encoder* enc, int slab, const 
     return rc;
   }
   enc->slab_rows[slab] = rows;
-  enc->resident_xsize = xsize;
+  enc->slab_cols[slab] = xsize;
   return JXLT_OK;
 }
 
@@ -712,10 +817,9 @@ int jxlt_multi_encoder_encode_resident(jxlt_multi_encoder* enc, size_t xsize, si
                                        const uint8_t** bytes, size_t* size) {
   if (!enc || !bytes || !size) return JXLT_ERR_INVALID_ARGUMENT;
   for (int r = 0; r < enc->group.world; ++r) {
-    size_t y0, y1;
-    jxlt::ShardRows(ysize, enc->group.world, r, &y0, &y1);
-    if (y1 > y0 && (enc->slab_rows[r] != y1 - y0 || enc->resident_xsize != xsize)) {
-      enc->error = "slab " + std::to_string(r) + " was not set with the rows jxlt_shard_rows gives for this frame";
+    const jxlt::PixelRect rect = jxlt::ShardRect(xsize, ysize, enc->group.world, r);
+    if (!rect.empty() && (enc->slab_rows[r] != rect.height() || enc->slab_cols[r] != rect.width())) {
+      enc->error = "slab " + std::to_string(r) + " was not set with the rectangle jxlt_shard_rect gives for this frame";
       return JXLT_ERR_INVALID_ARGUMENT;
     }
   }
@@ -809,8 +913,8 @@ int jxlt_shard_encode(jxlt_shard_group* g, jxlt_context* ctx, size_t xsize, size
   if (bytes) *bytes = nullptr;
   if (size) *size = 0;
   if (!jxlt::NormalizeDistance(&distance) || xsize == 0 || ysize == 0) return JXLT_ERR_INVALID_ARGUMENT;
-  if (jxlt::NonEmptySlabs(ysize, g->world) <= 1) {
-    // nothing to shard: rank 0 owns the only slab (jxlt_shard_rows) and encodes it the ordinary way; the
+  if (jxlt::NonEmptySlabs(xsize, ysize, g->world) <= 1) {
+    // nothing to shard: rank 0 owns the only slab (jxlt_shard_rect) and encodes it the ordinary way; the
     // other ranks have nothing to do and the control block is not involved
     if (g->rank != 0) return JXLT_OK;
     const int rc = jxlt_encode_resident_view(ctx, distance, 0, bytes, size);
@@ -892,11 +996,19 @@ void LaneLoop(jxlt_shard_pipeline::Lane* lane) {
     if (lane->ops.enqueue != nullptr) {
       rc = jxlt_shard_encode_ops(lane->group, &lane->ops, lane->xsize, lane->ysize, lane->distance, &bytes, &size);
     } else {
-      if (lane->rows != 0)
-        rc = jxlt_image_set_device(lane->ctx, lane->planes, lane->pitch_bytes, lane->xsize, lane->rows);
+      if (lane->rows != 0) {
+        // the rank's slab: the rectangle jxlt_shard_rect gives it, starting at the planes' first sample
+        const PixelRect rect = ShardRect(lane->xsize, lane->ysize, lane->group->world, lane->group->rank);
+        if (rect.empty() || rect.height() != lane->rows) {
+          rc = JXLT_ERR_INVALID_ARGUMENT;
+          lane->error = "slab_rows is not the height of the rectangle jxlt_shard_rect gives this rank";
+        } else {
+          rc = jxlt_image_set_device(lane->ctx, lane->planes, lane->pitch_bytes, rect.width(), rect.height());
+          if (rc != JXLT_OK) lane->error = std::string("slab set-up failed: ") + jxlt_last_error(lane->ctx);
+        }
+      }
       if (rc != JXLT_OK) {
         // (the other ranks must not wait for this one's part of the frame)
-        lane->error = std::string("slab set-up failed: ") + jxlt_last_error(lane->ctx);
         Fail(lane->group, rc, lane->error.c_str());
       } else {
         rc = jxlt_shard_encode(lane->group, lane->ctx, lane->xsize, lane->ysize, lane->distance, &bytes, &size);

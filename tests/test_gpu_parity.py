@@ -239,8 +239,8 @@ def test_multi_encoder_two_contexts_equal_single_device(built):
     # slabs resident in device memory
     t = torch.from_numpy(planes).cuda()
     for slab in range(2):
-        y0, y1 = built.shard_rows(h, 2, slab)
-        me.set_device_slab(slab, [t[c, y0:].data_ptr() for c in range(3)], w * 4, w, y1 - y0, keepalive=t)
+        x0, y0, x1, y1 = built.shard_rect(w, h, 2, slab)
+        me.set_device_slab(slab, [t[c, y0:, x0:].data_ptr() for c in range(3)], w * 4, x1 - x0, y1 - y0, keepalive=t)
     assert me.encode_resident(w, h, d).tobytes() == want
     # a frame of a single DC-group row takes the ordinary path on the first context
     small = T.to_planes(T.synthetic_image(300, 264))
@@ -253,6 +253,35 @@ def test_multi_encoder_two_contexts_equal_single_device(built):
     me3 = built.MultiEncoder([0, 0, 0])
     assert me3.encode(p2, 0.5).tobytes() == T.assemble_codestream(T.oracle_hot_path(p2, 0.5), 0.5)
     me3.close()
+
+
+def test_multi_encoder_shards_dc_groups_by_index(built):
+    """Round 4: a frame's DC groups are dealt out as rectangles, not as rows only.  A frame of
+    ONE row of DC groups over four contexts (until round 3: "nothing to shard"), 8192 x 8192 = 4 x 4 DC groups over
+    eight contexts (2 x 1 each; until round 3 at most four could work), an uneven 3 x 2 over five -- from host planes
+    and from rectangles that already are in device memory; every codestream equals the single-context one, which the
+    other tests pin to the oracle."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    enc1 = built.Encoder(0)
+    for w, h, n, d in [(4 * 2048 - 100, 300, 4, 1.0), (2 * 2048 + 300, 2048 + 20, 5, 2.0), (8192, 8192, 8, 1.0)]:
+        t = bench.frame_rows_on_device(torch, w, 0, (h + 1023) // 1024 * 1024, 7, dev)[:, :h].contiguous()
+        torch.cuda.synchronize()
+        enc1.set_device_image([t[c].data_ptr() for c in range(3)], w * 4, w, h, keepalive=t)
+        single = enc1.encode_resident(d)
+        me = built.MultiEncoder([0] * n)
+        rects = [built.shard_rect(w, h, n, r) for r in range(n)]
+        assert sum(1 for r in rects if r[2] > r[0]) == min(n, ((w + 2047) // 2048) * ((h + 2047) // 2048))
+        for slab, (x0, y0, x1, y1) in enumerate(rects):
+            if x1 > x0:
+                me.set_device_slab(slab, [t[c, y0:, x0:].data_ptr() for c in range(3)], w * 4, x1 - x0, y1 - y0, keepalive=t)
+        assert me.encode_resident(w, h, d).tobytes() == single, (w, h, n)
+        if w * h < (1 << 24):  # ... and from host planes, each context uploading its own rectangle
+            assert me.encode(t.cpu().numpy(), d).tobytes() == single, (w, h, n)
+        me.close()
+        del t
+    enc1.close()
 
 
 def test_multi_encoder_grows_its_output_region_and_reports_errors(built):
@@ -301,10 +330,10 @@ def _shard_rank(rank, world, name, w, h, d, q, barrier):
         sys.path.insert(0, str(T.ROOT / "tests"))
         pkg = T.product()
         planes = T.to_planes(T.synthetic_image(w, h))
-        y0, y1 = pkg.shard_rows(h, world, rank)
+        x0, y0, x1, y1 = pkg.shard_rect(w, h, world, rank)
         enc = pkg.Encoder(0)
         if y1 > y0:
-            enc.upload(np.ascontiguousarray(planes[:, y0:y1]))
+            enc.upload(np.ascontiguousarray(planes[:, y0:y1, x0:x1]))
         grp = pkg.ShardGroup(name, 0, world, 8 << 20, 4096) if rank == 0 else None
         barrier.wait()
         if grp is None:
@@ -453,8 +482,8 @@ def test_baseline_config4_16384_frame(built, enc):
     assert enc.stats()["tiles_redone_exact_roots"] == 0
     me = built.MultiEncoder([0, 0])
     for slab in range(2):
-        y0, y1 = built.shard_rows(size, 2, slab)
-        me.set_device_slab(slab, [t[c, y0:].data_ptr() for c in range(3)], size * 4, size, y1 - y0, keepalive=t)
+        x0, y0, x1, y1 = built.shard_rect(size, size, 2, slab)
+        me.set_device_slab(slab, [t[c, y0:, x0:].data_ptr() for c in range(3)], size * 4, x1 - x0, y1 - y0, keepalive=t)
     assert me.encode_resident(size, size, 1.0).tobytes() == single
     me.close()
     del t
@@ -582,8 +611,8 @@ def test_frame_above_one_gigapixel(built, enc):
     assert enc.encode_resident_raw_tokens(1.0) == single
     me = built.MultiEncoder([0, 0])
     for slab in range(2):
-        y0, y1 = built.shard_rows(ys, 2, slab)
-        me.set_device_slab(slab, [t[c, y0:].data_ptr() for c in range(3)], xs * 4, xs, y1 - y0, keepalive=t)
+        x0, y0, x1, y1 = built.shard_rect(xs, ys, 2, slab)
+        me.set_device_slab(slab, [t[c, y0:, x0:].data_ptr() for c in range(3)], xs * 4, x1 - x0, y1 - y0, keepalive=t)
     assert me.encode_resident(xs, ys, 1.0).tobytes() == single
     me.close()
 

@@ -72,24 +72,39 @@ class OracleSlab:
             dst.contents.num_sections = len(packed)
         return 0
 
-    def _write(self, _self, dc_dst, ac_dst):
-        C.memmove(dc_dst, self.packed[0], len(self.packed[0]))
-        C.memmove(ac_dst, self.packed[1], len(self.packed[1]))
+    def _write(self, _self, out, dc_runs, n_dc, ac_runs, n_ac):
+        base = C.addressof(out.contents)
+        for kind, runs, n in ((0, dc_runs, n_dc), (1, ac_runs, n_ac)):
+            off = self.keep[2 * kind]
+            for i in range(n):
+                r = runs[i]
+                lo, hi = int(off[r.first_section]), int(off[r.first_section + r.num_sections])
+                C.memmove(base + r.dst_offset, self.packed[kind][lo:hi], hi - lo)
         return 0
 
     def _finish(self, _self):
         return 0
 
 
-def _participant(pkg, name, rank, world, w, h, d, after_create=None):
-    planes = T.to_planes(T.synthetic_image(w, h))
-    y0, y1 = pkg.shard_rows(h, world, rank)
-    grp = pkg.ShardGroup(name, rank, world, 1 << 20, 4096) if rank == 0 else None
+def _test_frame(w, h, flat=False):
+    """The survey's generator, or (flat) a grey frame with a lattice of dots: few tokens, so that the reference bit
+    packer -- Python, a record at a time -- stays cheap on frames of several DC groups."""
+    if not flat:
+        return T.to_planes(T.synthetic_image(w, h))
+    img = np.full((h, w, 3), 0.25, np.float32)
+    img[::61, ::67] = (0.4, 0.3, 0.2)
+    return T.to_planes(img)
+
+
+def _participant(pkg, name, rank, world, w, h, d, after_create=None, flat=False):
+    planes = _test_frame(w, h, flat)
+    x0, y0, x1, y1 = pkg.shard_rect(w, h, world, rank)
+    grp = pkg.ShardGroup(name, rank, world, 4 << 20, 4096) if rank == 0 else None
     if after_create:
         after_create()
     if grp is None:
-        grp = pkg.ShardGroup(name, rank, world, 1 << 20, 4096)
-    slab = OracleSlab(pkg, np.ascontiguousarray(planes[:, y0:y1]), d)
+        grp = pkg.ShardGroup(name, rank, world, 4 << 20, 4096)
+    slab = OracleSlab(pkg, np.ascontiguousarray(planes[:, y0:y1, x0:x1]), d)
     out = []
     for _ in range(2):  # two frames through the same group: the control block is reusable
         view = grp.encode_ops(slab.ops, w, h, d)
@@ -100,12 +115,12 @@ def _participant(pkg, name, rank, world, w, h, d, after_create=None):
     return out
 
 
-def _worker(rank, world, port, name, q):
+def _worker(rank, world, port, name, q, w=W, h=H):
     try:
         import torch.distributed as dist
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        out = _participant(T.product(), name, rank, world, W, H, D, after_create=dist.barrier)
+        out = _participant(T.product(), name, rank, world, w, h, D, after_create=dist.barrier)
         q.put((rank, out))
         dist.barrier()
         dist.destroy_process_group()
@@ -134,18 +149,49 @@ def test_two_process_sharded_frame_equals_single_process(built):
     assert results[0] == [want, want]
 
 
-@pytest.mark.parametrize("world,h", [(3, 2048 + 2048 + 40), (8, 2048 + 300), (2, 2048 * 2)])
-def test_threads_attached_to_one_segment(built, world, h):
+def test_two_process_frame_of_one_row_of_dc_groups(built):
+    """World size 2 over gloo, a frame that is ONE row of DC groups (2 x 1): until round 3 such a frame could not be
+    sharded at all (row slabs only); now every rank takes a DC group, and rank 1's sections are runs in the middle of
+    the codestream (DC groups, then its AC groups row by row between rank 0's)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = "/jxlt-test-x-%d" % os.getpid()
+    w, h = 2048 + 300, 300
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q, w, h)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert not isinstance(results[0], str), results[0]
+    assert not isinstance(results[1], str), results[1]
+    planes = T.to_planes(T.synthetic_image(w, h))
+    want = T.assemble_codestream(T.oracle_hot_path(planes, D), D)
+    assert results[0] == [want, want] and results[1] == [None, None]
+
+
+@pytest.mark.parametrize("world,w,h", [(3, 40, 2048 + 2048 + 40), (8, 40, 2048 + 300), (2, 40, 2048 * 2),
+                                       (8, 7 * 2048 + 100, 24),          # ONE row of 8 DC groups, one each
+                                       (8, 3 * 2048 + 9, 2048 + 70),     # 4 x 2 DC groups over 8: two bands of four
+                                       (5, 2 * 2048 + 300, 2048 + 20),   # 3 x 2 over 5: the bands are cut differently
+                                       (3, 2048 + 40, 16)])              # 2 x 1 DC groups over 3: one participant idles
+def test_threads_attached_to_one_segment(built, world, w, h):
     """Uneven slabs (3 participants, 3 DC-group rows of which the last is short), participants
-    without rows (8 participants, 2 rows), exact multiples."""
-    w, d = 40, 2.0
+    without work (8 participants, 2 rows), exact multiples; frames that are cut along x as well (round 4: DC groups
+    shard by index -- a one-row frame over 8 participants, 4 x 4 DC groups over 8, 3 x 3 over 5): a participant's
+    sections are then several runs of the codestream."""
+    d = 2.0
+    flat = w > 2048 and h > 2048
     name = "/jxlt-test-thr-%d-%d" % (os.getpid(), world)
     barrier = threading.Barrier(world)
     results = [None] * world
 
     def run(rank):
         try:
-            results[rank] = _participant(built, name, rank, world, w, h, d, after_create=barrier.wait)
+            results[rank] = _participant(built, name, rank, world, w, h, d, after_create=barrier.wait, flat=flat)
         except Exception as e:  # pragma: no cover
             results[rank] = "ERROR: %r" % (e,)
             barrier.abort()
@@ -155,7 +201,7 @@ def test_threads_attached_to_one_segment(built, world, h):
         t.start()
     for t in threads:
         t.join(timeout=600)
-    planes = T.to_planes(T.synthetic_image(w, h))
+    planes = _test_frame(w, h, flat)
     want = T.assemble_codestream(T.oracle_hot_path(planes, d), d)
     assert results[0] == [want, want], results[0] if isinstance(results[0], str) else "codestream differs"
     for r in range(1, world):
@@ -171,10 +217,10 @@ def _pipeline_worker(rank, world, port, name, q):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         pkg = T.product()
         w, h, d, depth = 56, 2048 + 2048 + 24, 2.0, 2
-        y0, y1 = pkg.shard_rows(h, world, rank)
+        x0, y0, x1, y1 = pkg.shard_rect(w, h, world, rank)
         images = [T.to_planes(T.synthetic_image(w, h, seed=900 + i)) for i in range(2)]
         # lane l always sees image l (frame k = image k % 2 = lane k % 2): one oracle-backed slab per lane
-        slabs = [OracleSlab(pkg, np.ascontiguousarray(images[l][:, y0:y1]), d) for l in range(depth)]
+        slabs = [OracleSlab(pkg, np.ascontiguousarray(images[l][:, y0:y1, x0:x1]), d) for l in range(depth)]
         pipe = pkg.ShardPipeline(name, rank, world, -1, depth, 1 << 20, 4096, [s.ops for s in slabs]) if rank == 0 else None
         dist.barrier()
         if pipe is None:
@@ -230,8 +276,8 @@ def test_pipeline_failure_releases_every_rank(built):
 
     def run(rank):
         planes = T.to_planes(T.synthetic_image(w, h))
-        y0, y1 = built.shard_rows(h, world, rank)
-        slabs = [OracleSlab(built, np.ascontiguousarray(planes[:, y0:y1]), d) for _ in range(depth)]
+        x0, y0, x1, y1 = built.shard_rect(w, h, world, rank)
+        slabs = [OracleSlab(built, np.ascontiguousarray(planes[:, y0:y1, x0:x1]), d) for _ in range(depth)]
         if rank == 1:  # lane 1 of rank 1 fails in the middle of the protocol
             slabs[1]._cb["ac_histogram"] = built._SLAB_FN["ac_histogram"](lambda _s, _o: -5)
             slabs[1].ops.ac_histogram = slabs[1]._cb["ac_histogram"]
@@ -261,15 +307,31 @@ def test_pipeline_failure_releases_every_rank(built):
     assert outcome[0][1] is not None and outcome[1][1] is not None, outcome
 
 
-def test_shard_rows_cover_whole_dc_groups(built):
-    for h, world in [(16384, 8), (16384, 3), (5000, 2), (100, 4), (2049, 2), (16384, 64)]:
-        rows = [built.shard_rows(h, world, r) for r in range(world)]
-        assert rows[0][0] == 0 and rows[-1][1] == h
-        for (a0, a1), (b0, b1) in zip(rows, rows[1:]):
-            assert a1 == b0 and (a1 % 2048 == 0 or a1 == h)
-        sizes = [(y1 - y0 + 2047) // 2048 for y0, y1 in rows]
-        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
-    assert built.shard_rows(1000, 4, 0) == (0, 1000)  # a single DC-group row belongs to participant 0
+def test_shard_rectangles_tile_the_frame_in_whole_dc_groups(built):
+    """jxlt_shard_rect: the participants' rectangles are disjoint, cover the frame, consist of whole DC groups, and
+    the largest is as small as bands of rows cut into column ranges allow (BASELINE config #4 and the frames VERDICT
+    r3 names: a one-row frame over 8, 8192^2 over 8)."""
+    def dc(v):
+        return (v + 2047) // 2048
+    for w, h, world, largest in [(16384, 16384, 8, 8), (16384, 2048, 8, 1), (8192, 8192, 8, 2), (16384, 16384, 3, 24),
+                                 (16384, 16384, 5, 15), (16384, 16384, 64, 1), (5000, 5000, 2, 6), (100, 100, 4, 1),
+                                 (2049, 50, 2, 1), (2048, 2049, 3, 1), (6000, 2048 * 11, 7, 6)]:
+        rects = [built.shard_rect(w, h, world, r) for r in range(world)]
+        cover = np.zeros((dc(h), dc(w)), np.int32)
+        areas = []
+        for x0, y0, x1, y1 in rects:
+            if x1 <= x0 or y1 <= y0:
+                assert (x0, y0, x1, y1) == (0, 0, 0, 0)
+                continue
+            assert x0 % 2048 == 0 and y0 % 2048 == 0 and (x1 % 2048 == 0 or x1 == w) and (y1 % 2048 == 0 or y1 == h)
+            cover[y0 // 2048:dc(y1), x0 // 2048:dc(x1)] += 1
+            areas.append((dc(y1) - y0 // 2048) * (dc(x1) - x0 // 2048))
+        assert (cover == 1).all(), (w, h, world)
+        assert max(areas) == largest, (w, h, world, areas)
+        assert len(areas) == min(world, dc(w) * dc(h))
+    # rows of DC groups where that is as good (fewer runs per participant): 16384^2 over 8 = rounds 1-3's slabs
+    assert [built.shard_rect(16384, 16384, 8, r) for r in range(8)] == [(0, 2048 * r, 16384, 2048 * (r + 1)) for r in range(8)]
+    assert built.shard_rect(1000, 1000, 4, 0) == (0, 0, 1000, 1000)  # a single DC group belongs to participant 0
 
 
 def test_failures_propagate_instead_of_hanging(built):
@@ -281,12 +343,12 @@ def test_failures_propagate_instead_of_hanging(built):
 
     def run(rank):
         planes = T.to_planes(T.synthetic_image(w, h))
-        y0, y1 = built.shard_rows(h, world, rank)
+        x0, y0, x1, y1 = built.shard_rect(w, h, world, rank)
         grp = built.ShardGroup(name, rank, world, 1 << 20, 4096) if rank == 0 else None
         barrier.wait()
         if grp is None:
             grp = built.ShardGroup(name, rank, world, 1 << 20, 4096)
-        slab = OracleSlab(built, np.ascontiguousarray(planes[:, y0:y1]), d)
+        slab = OracleSlab(built, np.ascontiguousarray(planes[:, y0:y1, x0:x1]), d)
         if rank == 1:
             slab._cb["ac_histogram"] = built._SLAB_FN["ac_histogram"](lambda _s, _o: -5)
             slab.ops.ac_histogram = slab._cb["ac_histogram"]

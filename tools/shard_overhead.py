@@ -34,9 +34,9 @@ def main():
     for n in (2, 4, 8):
         me = pkg.MultiEncoder([0] * n)
         for slab in range(n):
-            y0, y1 = pkg.shard_rows(size, n, slab)
+            x0, y0, x1, y1 = pkg.shard_rect(size, size, n, slab)
             if y1 > y0:
-                me.set_device_slab(slab, [t[c, y0:].data_ptr() for c in range(3)], size * 4, size, y1 - y0, keepalive=t)
+                me.set_device_slab(slab, [t[c, y0:, x0:].data_ptr() for c in range(3)], size * 4, x1 - x0, y1 - y0, keepalive=t)
         for _ in range(5):
             out = me.encode_resident(size, size, 1.0)
         t0 = time.perf_counter()
