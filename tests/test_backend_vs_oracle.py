@@ -92,6 +92,44 @@ def test_code_tables_from_random_histograms(built, seed):
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_code_tables_when_many_histograms_are_alike(built, seed):
+    """The selection rounds of the clustering are evaluated lazily since round 4 (a histogram whose upper bound is
+    below another's exact distance is not compared with the newest cluster at all): the choices must be the
+    reference's also where distances TIE -- copies of one histogram, copies scaled by a constant, near copies that
+    differ in one count, zero distances, fewer distinct histograms than clusters."""
+    rng = np.random.default_rng(1000 + seed)
+
+    def make(nctx):
+        h = np.zeros((64, 64), np.uint32)
+        nbase = int(rng.integers(1, 12))
+        base = []
+        for _ in range(nbase):
+            n = int(rng.integers(1, 40))
+            b = np.zeros(64, np.uint32)
+            b[rng.choice(64, size=n, replace=False)] = rng.integers(1, 1 << int(rng.integers(1, 16)), size=n)
+            base.append(b)
+        for c in range(nctx):
+            kind = int(rng.integers(0, 5))
+            b = base[int(rng.integers(0, nbase))].copy()
+            if kind == 0:
+                continue                      # empty context
+            if kind == 2:
+                b = b * np.uint32(rng.integers(2, 5))   # the same shape, another weight
+            if kind == 3:
+                b[int(rng.integers(0, 64))] += 1        # a near copy
+            h[c] = b
+        if not h.any():
+            h[0, 0] = 1
+        return h
+
+    for _ in range(10):
+        ac, dc = make(64), make(45)
+        want = T.oracle_code_tables(ac, dc, reference_single_symbol=False)
+        got = built.build_code_tables(ac, dc)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
 @pytest.mark.parametrize("distance", ["0.1", "0.5", "1", "4"])
 def test_code_tables_from_the_bench_frames_histograms(built, distance):
     """The histograms of the 16384 x 16384 bench frame at four distances (tests/golden/histograms/bench_histograms.npz: counts
