@@ -610,6 +610,19 @@ class BatchEncoder:
 
 
 # --------------------------------------------------------------------------- one frame over several GPUs
+def bind_thread_near_device(device=0):
+    """jxlt_bind_thread_near_device: the calling thread (and the threads it creates from now on) on the CPUs next to
+    the GPU.  Returns the previous affinity mask (for os.sched_setaffinity) or None when nothing was changed."""
+    import os
+    L = hip_lib()
+    L.jxlt_bind_thread_near_device.argtypes = [C.c_int]
+    try:
+        before = os.sched_getaffinity(0)
+    except (AttributeError, OSError):
+        return None
+    return before if L.jxlt_bind_thread_near_device(device) == 0 else None
+
+
 def shard_rect(xsize, ysize, world, rank):
     """(x0, y0, x1, y1): the pixels of participant `rank` of `world` -- a rectangle of whole DC groups, empty when
     there are fewer DC groups than participants (jxlt_shard_rect)."""

@@ -381,24 +381,35 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     const int ve = vs + 8 * nvec;
     const int nbands = nby * 2;
     // One pixel's term from its own value, the sum of its vertical neighbours and its horizontal
-    // neighbours; both association orders are computed and selected (a branch per pixel would wait
-    // for the LDS before and after each arm).
-    auto pixel_term = [&](bool vec, float in, float du, float in_l, float in_r, float ix, float dux, float ix_l,
-                          float ix_r) {
-      const float base = 0.25f * (vec ? (in_r + in_l) + du : (du + in_l) + in_r);
+    // neighbours.  kAllVec: the position is one of the reference's vector loop (its association order, its fused
+    // multiply-add) -- known at compile time.  Otherwise both association orders are computed and selected (a
+    // branch per pixel would wait for the LDS before and after each arm).
+    auto pixel_term = [&](auto all_vec, bool vec, float in, float du, float in_l, float in_r, float ix, float dux,
+                          float ix_l, float ix_r) {
+      constexpr bool kAllVec = decltype(all_vec)::value;
       const float gammac = ratio_of_derivatives(in + match_gamma_offset, false);
-      float diff = gammac * (in - base);
-      diff = diff * diff;
-      const float base_x = 0.25f * (vec ? (ix_r + ix_l) + dux : (dux + ix_l) + ix_r);
-      float diff_x = gammac * (ix - base_x);
-      diff_x = diff_x * diff_x;
-      const float fused = fma32(kXMul, diff_x, diff), unfused = diff + kXMul * diff_x;
-      return masking_sqrt(vec ? fused : unfused, sqrt_mul);
+      if constexpr (kAllVec) {
+        const float base = 0.25f * ((in_r + in_l) + du);
+        float diff = gammac * (in - base);
+        diff = diff * diff;
+        const float base_x = 0.25f * ((ix_r + ix_l) + dux);
+        float diff_x = gammac * (ix - base_x);
+        diff_x = diff_x * diff_x;
+        return masking_sqrt(fma32(kXMul, diff_x, diff), sqrt_mul);
+      } else {
+        const float base = 0.25f * (vec ? (in_r + in_l) + du : (du + in_l) + in_r);
+        float diff = gammac * (in - base);
+        diff = diff * diff;
+        const float base_x = 0.25f * (vec ? (ix_r + ix_l) + dux : (dux + ix_l) + ix_r);
+        float diff_x = gammac * (ix - base_x);
+        diff_x = diff_x * diff_x;
+        const float fused = fma32(kXMul, diff_x, diff), unfused = diff + kXMul * diff_x;
+        return masking_sqrt(vec ? fused : unfused, sqrt_mul);
+      }
     };
-    // (Spreading the last, partly filled pass over all threads row by row changes nothing: the
-    // other resident workgroup takes the issue slots the idle waves leave.)
-    for (int i = tid; i < nbands * aq_w; i += kThreads) {
-      const int q = i / aq_w, x = aq_x0 + i % aq_w;
+    // One band column (band q = rows 4q .. 4q + 3, stripe column x): its four pixel terms summed, then P2's
+    // 4-column average inside the quad of lanes that holds the four columns of one average.
+    auto band_column = [&](auto all_vec, int q, int x, bool first_of_quad) {
       const bool vec = x >= vs && x < ve;
       const int xl = x > 0 ? x - 1 : x, xr = x + 1 < swp ? x + 1 : x;
       // The band's column, rows y0-1 .. y0+4 (clamped to the stripe: only the first and the
@@ -422,7 +433,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       float acc = 0.0f;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const float diff = pixel_term(vec, cy[k + 1], cy[k + 2] + cy[k], ly4[k], ry4[k], cxx[k + 1],
+        const float diff = pixel_term(all_vec, vec, cy[k + 1], cy[k + 2] + cy[k], ly4[k], ry4[k], cxx[k + 1],
                                       cxx[k + 2] + cxx[k], lx4[k], rx4[k]);
         acc = (k == 0) ? diff : acc + diff;
       }
@@ -432,7 +443,41 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       float s4 = acc + quad_lane<1>(acc);
       s4 = s4 + quad_lane<2>(acc);
       s4 = s4 + quad_lane<3>(acc);
-      if ((i & 3) == 0) S.pre_erosion[q * kPrePitch + ((x - aq_x0) >> 2)] = s4 * 0.25f;
+      if (first_of_quad) S.pre_erosion[q * kPrePitch + ((x - aq_x0) >> 2)] = s4 * 0.25f;
+    };
+#ifndef JXLT_P1_SPLIT
+#define JXLT_P1_SPLIT 0
+#endif
+    if constexpr (k12 && JXLT_P1_SPLIT != 0) {
+      // Round 4: the 4-column groups that lie in the vector loop's range entirely -- 15 or 16 of a tile's 17 or 18 --
+      // take the vector path alone (no second association order, no selects: -16 % of the phase's instructions);
+      // the one or two groups left go to the waves that have a single pass of the others (10 and 11).
+      const int ga0 = (vs - aq_x0 + 3) >> 2, ga1 = nvec ? (ve - aq_x0) >> 2 : 0;
+      const int na = ga1 > ga0 ? ga1 - ga0 : 0;           // full-vector groups per band
+      const int nb = (aq_w >> 2) - na;                    // the others: groups [0, ga0) and [ga1, aq_w / 4)
+      const int items_a = nbands * na * 4, items_b = nbands * nb * 4;
+      for (int i = tid; i < items_a; i += kThreads) {
+        const int q = i / (na * 4), r = i - q * (na * 4);
+        band_column(std::true_type{}, q, aq_x0 + 4 * ga0 + r, (i & 3) == 0);
+      }
+      // (few: on the last threads, one pass; many -- a narrow tile at the frame's right edge, where the vector
+      // loop's range is short or empty: from thread 0 on, like the others)
+      const bool rotate = items_b <= 192;
+      const int first_b = rotate ? tid - (kThreads - 192) : tid;
+      for (int i = first_b; i < items_b; i += kThreads) {
+        if (i < 0) continue;
+        const int q = i / (nb * 4), r = i - q * (nb * 4);
+        const int g = r >> 2;                              // the band's g-th group outside the vector range
+        const int x = aq_x0 + 4 * (g < ga0 || na == 0 ? g : g + na) + (r & 3);
+        band_column(std::false_type{}, q, x, (i & 3) == 0);
+      }
+    } else {
+      // (Spreading the last, partly filled pass over all threads row by row changes nothing: the
+      // other resident workgroup takes the issue slots the idle waves leave.)
+      for (int i = tid; i < nbands * aq_w; i += kThreads) {
+        const int q = i / aq_w, x = aq_x0 + i % aq_w;
+        band_column(std::false_type{}, q, x, (i & 3) == 0);
+      }
     }
   }
   __syncthreads();
