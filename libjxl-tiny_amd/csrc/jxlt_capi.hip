@@ -1309,11 +1309,32 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
     if (split) HIP_TRY(ctx, hipStreamWaitEvent(elem_stream, ctx->tile_done[sl], 0));
     hipLaunchKernelGGL(dc_elementwise_kernel, dim3((unsigned)(slab_dc * kDcParts)), dim3(256), 0, elem_stream, D);
     if (split) HIP_TRY(ctx, hipEventRecord(ctx->dc_elementwise_done, elem_stream));
+    // A resident frame of up to 1024 groups (8192^2): the two chain kernels and the histogram's publication on a
+    // stream of their own, submitted in front of token_kernel but not waited for by it -- token_kernel is short there
+    // (0.06-0.19 ms) and starts 0.03 ms earlier (4096^2: 0.65-0.69 -> 0.64 ms, 8192^2: 1.59 -> 1.55-1.57).  Larger
+    // frames keep the DC-group kernels in FRONT of token_kernel: beside it they do not get a CU before its
+    // workgroups retire, the DC histogram arrives with the AC histogram (16384^2: at 4.52 instead of 4.09 ms) and the
+    // DC code is built behind token_kernel instead of under it (5.36 against 5.18 ms).
+    // (experiment knob: JXLT_DC_BESIDE_TOKEN=0 / 1 forces either)
+    static const int dc_beside = [] {
+      const char* e = getenv("JXLT_DC_BESIDE_TOKEN");
+      return e ? atoi(e) : -1;
+    }();
+    const bool beside = nslabs == 1 && split && (dc_beside >= 0 ? dc_beside != 0 : ngroups <= 1024);
+    const hipStream_t chain_stream = beside ? ctx->upload_stream : tok_stream;
+    if (beside) HIP_TRY(ctx, hipStreamWaitEvent(chain_stream, ctx->tile_done[sl], 0));
     hipLaunchKernelGGL(dc_chain_summary_kernel, dim3((unsigned)(slab_dc * kDcChainChunks)), dim3(kDcChainThreads), 0,
-                       tok_stream, D);
+                       chain_stream, D);
     hipLaunchKernelGGL(dc_chain_kernel, dim3((unsigned)(slab_dc * kDcChainChunks)), dim3(kDcChainThreads), 0,
-                       tok_stream, D);
-    if (sl + 1 == nslabs) {
+                       chain_stream, D);
+    if (beside) {
+      HIP_TRY(ctx, hipStreamWaitEvent(chain_stream, ctx->dc_elementwise_done, 0));
+      const PublishSeg segs[2] = {{ctx->hist.p + 64 * 64, ctx->h_hist.p + 64 * 64, 64 * 64},
+                                  {ctx->lut_overflow.p, ctx->h_lut_overflow.p, nslabs}};
+      const int rcp = EnqueuePublish(ctx, chain_stream, segs, 2, nullptr, nullptr, &ctx->mail.p->dc_hist_seq, frame_seq);
+      if (rcp != JXLT_OK) return rcp;
+      HIP_TRY(ctx, hipEventRecord(ctx->dc_kernels_done, chain_stream));
+    } else if (sl + 1 == nslabs) {
       // The DC histogram (and the counts of the tiles redone with computed roots) leaves IN FRONT of token_kernel: one
       // small kernel stores both to the host's page-locked memory and then the frame's sequence number to the word
       // the host polls (~6 us on the stream).  Beside token_kernel -- on the copy stream, where rounds 2-3 had the
@@ -1342,6 +1363,8 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
       hipLaunchKernelGGL(token_kernel_wide, dim3((unsigned)ng), dim3(kTokenThreads), token_extra_lds, tok_stream, K);
     else
       hipLaunchKernelGGL(token_kernel, dim3((unsigned)ng), dim3(kTokenThreads), token_extra_lds, tok_stream, K);
+    // (whatever follows on the main stream -- the sections' packing -- reads what the DC-group kernels wrote)
+    if (beside) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->dc_kernels_done, 0));
   }
   HIP_TRY(ctx, hipGetLastError());
   ctx->host_src_kind = 0;  // the frame is resident now (a redo with exact roots must not fetch it again)
