@@ -1263,28 +1263,15 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
       const char* e = getenv("JXLT_TILE_EXTRA_LDS");
       return e ? (unsigned)atoi(e) : 0u;
     }();
-    // (experiment knob: JXLT_TILE_WAVES=8|12 selects the 8-wave or the 12-wave variant of the kernel)
-    static const int tile_waves = [] {
-      const char* e = getenv("JXLT_TILE_WAVES");
-      return e && atoi(e) == 12 ? 12 : e && atoi(e) == 8 ? 8 : kDefaultTileWaves;
-    }();
     // Behind every launch: the tiles it filed because a quantised magnitude did not fit the root table of its
     // entropy estimates, again with computed roots (enc_ac_strategy.cc:118-126 takes a Sqrt per coefficient) -- a
     // small fixed grid whose workgroups usually find an empty list and leave.
     const unsigned redo_grid = std::min<unsigned>(slab_tiles, kRedoGrid);
-    if (tile_waves == 12) {
-      if (debug || profile)
-        hipLaunchKernelGGL(tile12_kernel_debug, dim3(slab_tiles), dim3(kTile12Threads), extra_lds, ctx->stream, S);
-      else
-        hipLaunchKernelGGL(tile12_kernel, dim3(slab_tiles), dim3(kTile12Threads), extra_lds, ctx->stream, S);
-      hipLaunchKernelGGL(tile12_kernel_redo, dim3(redo_grid), dim3(kTile12Threads), 0, ctx->stream, S);
-    } else {
-      if (debug || profile)
-        hipLaunchKernelGGL(tile_kernel_debug, dim3(slab_tiles), dim3(kTileThreads), extra_lds, ctx->stream, S);
-      else
-        hipLaunchKernelGGL(tile_kernel, dim3(slab_tiles), dim3(kTileThreads), extra_lds, ctx->stream, S);
-      hipLaunchKernelGGL(tile_kernel_redo, dim3(redo_grid), dim3(kTileThreads), 0, ctx->stream, S);
-    }
+    if (debug || profile)
+      hipLaunchKernelGGL(tile12_kernel_debug, dim3(slab_tiles), dim3(kTile12Threads), extra_lds, ctx->stream, S);
+    else
+      hipLaunchKernelGGL(tile12_kernel, dim3(slab_tiles), dim3(kTile12Threads), extra_lds, ctx->stream, S);
+    hipLaunchKernelGGL(tile12_kernel_redo, dim3(redo_grid), dim3(kTile12Threads), 0, ctx->stream, S);
     // (the counts of redone tiles leave with the DC histogram, below)
     if (sl + 1 == nslabs) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->tile_done[sl], ctx->stream));

@@ -1,4 +1,4 @@
-// jxlt_tile_kernel.h -- tile_kernel: one 512-thread workgroup per 64x64 tile, pixels to scan-ordered
+// jxlt_tile_kernel.h -- tile12_kernel: one 768-thread workgroup per 64x64 tile, pixels to scan-ordered
 // quantised coefficients and side-band grids (enc_frame.cc:597-683 + enc_group.cc:304-443).
 // Part of jxlt_device.h (include that one).
 #ifndef JXLT_TILE_KERNEL_H_
@@ -12,17 +12,15 @@ namespace jxlt_dev {
 // Tile kernel
 // ---------------------------------------------------------------------------
 
-constexpr int kTileThreads = 512;
-// The 12-wave variant (tile12_kernel*): the same tile, the same LDS, 768 threads.  Octets 0-31 hold the DCT8
-// coefficients of TWO blocks each, octets 32-95 one two-block candidate each (the 8-wave kernel keeps a block AND a
-// candidate per octet): half the coefficient registers per thread, 12 waves per workgroup, two workgroups per CU =
+// Twelve waves per tile (768 threads).  Octets 0-31 hold the DCT8 coefficients of TWO blocks each, octets 32-95 one
+// two-block candidate each (the 8-wave kernel of rounds 1-2, removed in round 4, kept a block AND a candidate per
+// octet): half the coefficient registers per thread, 12 waves per workgroup, two workgroups per CU =
 // 6 waves per SIMD instead of 4 when the kernel fits 80 vector registers.
 constexpr int kTile12Threads = 768;
 // 12 waves: LDS copy of the per-scan-position tables of the quantisation phase (DeviceTables::scan_consts, scan_slot,
 // inv_qac), in the term area behind the staging of the selected transforms' coefficients
 constexpr int kP8ScanWords = 3 * 7 * 64 + 3 * 64 / 4;  // scan_consts + scan_slot
 constexpr int kP8TabOffset = 13568;                    // floats from the start of the term area (54 272 B)
-constexpr int kDefaultTileWaves = 12;  // which variant the C ABI launches (JXLT_TILE_WAVES overrides)
 constexpr int kHalo = 5;                 // AQ: +-4 px window, +-1 px Laplacian tap
 constexpr int kXYPitch = 64 + 2 * kHalo + 1;  // 75 floats (odd: conflict-free columns)
 constexpr int kBPitch = 65;
@@ -168,11 +166,10 @@ JXLT_DI float adjust_quant_bias_y(float quant) {
 
 // kDebug: the variant that serves the A.dbg_* outputs (per-phase clocks, intermediate planes for
 // the parity tests); the production variant has none of their tests, branches and registers.
-template <bool kLutRoots, bool kDebug, int kWaves = 8>
+template <bool kLutRoots, bool kDebug>
 JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
-  static_assert(kWaves == 8 || kWaves == 12, "8: an octet per block and candidate; 12: role-split octets");
-  constexpr bool k12 = kWaves == 12;
-  constexpr int kThreads = kWaves * 64;
+  constexpr int kWaves = 12;
+  constexpr int kThreads = kTile12Threads;
   __shared__ TileShared S;
   // (not const: the 12-wave variant re-derives the per-thread values from a "laundered" thread index at phase
   // boundaries, so that the values of one phase are not kept in registers across another phase's peak)
@@ -214,92 +211,14 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
   // The table values are REQUESTED here (every lane, clamped indices: no branches) and stored to LDS behind the
   // pixel requests below, so that all of the tile's global loads are in flight together.  (Loops of "load, wait,
   // store to LDS" in front of the pixel loads cost six serial round trips to L2 per tile.)
-  static_assert(kTileThreads == 512 && (kSqrtLutSize <= 512 || kSqrtLutSize == 1024), "table staging below");
-  const float tab_inv0 = T->inv_weights[k12 ? imin(tid, 575) : tid];
-  const float tab_inv1 = T->inv_weights[512 + (tid & 63)];
-  const float tab_root0 = k12 ? 0.0f : T->sqrt_lut[tid & (kSqrtLutSize - 1)];
-  const float tab_root1 = k12 ? 0.0f : T->sqrt_lut[(kThreads + tid) & (kSqrtLutSize - 1)];
+  static_assert(kSqrtLutSize <= 512 || kSqrtLutSize == 1024, "table staging below");
+  const float tab_inv0 = T->inv_weights[imin(tid, 575)];
   if (tid == 0) {
     S.ntok = 0;
     S.nfirst = 0;
     S.overflow = 0;
   }
-  if constexpr (!k12) {
-    // 16 lanes along x, 32 rows per pass: a thread owns 5 columns x 2 rows of the
-    // (64 + 2*kHalo)-wide window, so the row and column clamps are shared and all thirty loads
-    // are in flight before the first use.  Column slots 0-3 cover the 64 interior columns; slot 4
-    // takes the ten halo columns (lanes 0-4 left, 5-9 right), which need X and Y only.
-    constexpr int kWin = 64 + 2 * kHalo;
-    const int base = px0 - kHalo;  // stripe x of LDS column 0
-    const int lx = tid & 15, ly = tid >> 4;
-    const float* rowp[2][3];
-    bool yok[2];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int y = ly + 32 * h;
-      yok[h] = y < shp;
-      const ptrdiff_t off = (ptrdiff_t)(sy0 + imin(y, sh - 1)) * A.pitch + (ptrdiff_t)sx0 * A.pix_stride;
-      rowp[h][0] = A.planes[0] + off;
-      rowp[h][1] = A.planes[1] + off;
-      rowp[h][2] = A.planes[2] + off;
-    }
-    // (scalar arithmetic on purpose: on gfx950 a packed v_pk_*_f32 costs at least as much as its
-    // two scalar halves -- tools/pk_probe.hip -- and the packed variant of this loop measured
-    // 3 % slower for the whole kernel)
-    float pr[5][2], pg[5][2], pb[5][2];
-    bool xok[5];
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-      const int cx = j < 4 ? kHalo + lx + 16 * j : (lx < kHalo ? lx : lx < 2 * kHalo ? 64 + lx : kWin);
-      const int x = base + cx;
-      xok[j] = cx < kWin && x >= 0 && x < swp && x < px0 + nbx * 8 + kHalo;
-      const int xs = (xok[j] ? imin(x, sw - 1) : 0) * A.pix_stride;
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        pr[j][h] = rowp[h][0][xs];
-        pg[j][h] = rowp[h][1][xs];
-        pb[j][h] = rowp[h][2][xs];
-      }
-    }
-    // (table values -> LDS while the pixels are on their way; they were requested first, so the wait is theirs only)
-    S.inv_w[tid] = tab_inv0;
-    if (tid < 64) S.inv_w[512 + tid] = tab_inv1;
-    if (tid < kSqrtLutSize) S.sqrt_lut[tid] = tab_root0;
-    if (kSqrtLutSize > 512) S.sqrt_lut[(512 + tid) & (kSqrtLutSize - 1)] = tab_root1;
-    if (A.byteswap) {  // big-endian PFM payload (BSwapFloat, read_pfm.cc:206)
-#pragma unroll
-      for (int j = 0; j < 5; j++) {
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          pr[j][h] = __uint_as_float(__builtin_bswap32(__float_as_uint(pr[j][h])));
-          pg[j][h] = __uint_as_float(__builtin_bswap32(__float_as_uint(pg[j][h])));
-          pb[j][h] = __uint_as_float(__builtin_bswap32(__float_as_uint(pb[j][h])));
-        }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-      if (!xok[j]) continue;
-      const int cx = j < 4 ? kHalo + lx + 16 * j : (lx < kHalo ? lx : 64 + lx);
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        if (!yok[h]) continue;
-        const int y = ly + 32 * h;
-        float px_, py_, pb_ = 0.0f;
-        if (j < 4) linear_to_xyb<true>(pr[j][h], pg[j][h], pb[j][h], &px_, &py_, &pb_);
-        else linear_to_xyb<false>(pr[j][h], pg[j][h], pb[j][h], &px_, &py_, &pb_);
-        S.x[y * kXYPitch + cx] = px_;
-        S.y[y * kXYPitch + cx] = py_;
-        if (j < 4) S.b[y * kBPitch + cx - kHalo] = pb_;
-        if (kDebug && j < 4 && A.dbg_xyb[0] && cx < kHalo + nbx * 8) {
-          const size_t d = (size_t)(by_img0 * 8 + y) * ((size_t)bstride * 8) + (size_t)(bx_img0 * 8 + cx - kHalo);
-          A.dbg_xyb[0][d] = px_;
-          A.dbg_xyb[1][d] = py_;
-          A.dbg_xyb[2][d] = pb_;
-        }
-      }
-    }
-  } else {
+  {
     // 12 waves: the 64 interior columns along the lanes, wave w takes the rows w, w + 12, ... (six of them for
     // waves 0-3, five for the others); the ten halo columns (X and Y only) as 6 rows x 10 columns per wave, one
     // pixel per thread.  All 21 loads of a thread are requested before the first use.
@@ -448,7 +367,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
 #ifndef JXLT_P1_SPLIT
 #define JXLT_P1_SPLIT 0
 #endif
-    if constexpr (k12 && JXLT_P1_SPLIT != 0) {
+    if constexpr (JXLT_P1_SPLIT != 0) {
       // Round 4: the 4-column groups that lie in the vector loop's range entirely -- 15 or 16 of a tile's 17 or 18 --
       // take the vector path alone (no second association order, no selects: -16 % of the phase's instructions);
       // the one or two groups left go to the waves that have a single pass of the others (10 and 11).
@@ -528,7 +447,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
   JXLT_MARK(2);
   // ---- P4: per-block modulations, one octet per block (:114-285) -------------
   // The per-block part behind the four sums (:52-75, :146-285, :518-534): from the erosion value and the sums to the
-  // quant field.  8 waves: every lane of the block's octet computes it (lane 0 stores).  12 waves: the octets leave
+  // quant field.  The octets leave
   // their sums in LDS and ONE wave does it for the tile's 64 blocks, a lane each, while the terms of
   // chroma-from-luma are published -- an eighth of the instructions, and off the path of the waves that do P4.
   auto block_quant_field = [&](float erosion, float hf, float red, float blue, float gam) {
@@ -585,7 +504,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     }
   };
   float* const p4_sums = &S.sqrt_lut[0];  // 12 waves: [block][hf, red, blue, gamma] (the root table is staged later)
-  if (!k12 || tid < 512) {  // (12 waves: octets 0..63 = waves 0-7)
+  if (tid < 512) {  // (octets 0..63 = waves 0-7)
     const int bxp = px0 + obx * 8, byp = oby * 8;  // block origin (stripe pixels)
     // HfModulation (:209-247): lane l = column l of the block
     float hf = 0.0f, red = 0.0f, blue = 0.0f, gam = 0.0f;
@@ -625,15 +544,12 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     blue = octet_sum(blue);
     gam = octet_sum(gam);
     if (blk_valid) {
-      if constexpr (k12) {
+      {
         if (l == 0) {
           float4 sums;
           sums.x = hf; sums.y = red; sums.z = blue; sums.w = gam;
           *reinterpret_cast<float4*>(p4_sums + oct * 4) = sums;
         }
-      } else {
-        const float qf = block_quant_field(S.aq[oct], hf, red, blue, gam);
-        if (l == 0) store_block_quant(oct, qf);
       }
     }
   }
@@ -651,19 +567,18 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
   // Done before chroma-from-luma so that afterwards no pixel is needed any more; the
   // coefficients stay in registers for the entropy estimate and for P8.
   // 12 waves: octets 0..31 (waves 0-3) are PAIR octets -- the DCT8 of the blocks (pbx, pby0) and (pbx, pby0 + 1) --
-  // and octets 32..95 the 64 candidate octets (candidate octet co = oct - 32 has the 8-wave kernel's role of
-  // octet co there).  8 waves: every octet is a candidate octet and holds its own block's DCT8 as well.
+  // and octets 32..95 the 64 candidate octets (candidate octet co = oct - 32).
   // (the roles are wave-uniform, and the compiler is told so: scalar branches, one set of coefficient registers)
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool pair_role = k12 && wave_u < 4;
-  const bool cand_role = !k12 || wave_u >= 4;
+  const bool pair_role = wave_u < 4;
+  const bool cand_role = wave_u >= 4;
   const bool search = (A.flags & 1u) == 0;
-  const bool is_tall = k12 ? wave_u < 8 : oct < 32;  // DCT16X8 (16 rows x 8 cols)
+  const bool is_tall = wave_u < 8;  // DCT16X8 (16 rows x 8 cols)
   int co, pbx, pby0, cand, cell, ccx, ccy, cbx, cby;
   bool pair_valid0, pair_valid1, cell_valid;
   float* tsc;
   auto derive_roles = [&]() {
-    co = k12 ? (oct >= 32 ? oct - 32 : 0) : oct;  // candidate octet index (0..63)
+    co = oct >= 32 ? oct - 32 : 0;  // candidate octet index (0..63)
     pbx = oct & 7, pby0 = (oct >> 3) * 2;          // pair octet's blocks (12 waves)
     pair_valid0 = pair_role && pbx < nbx && pby0 < nby, pair_valid1 = pair_role && pbx < nbx && pby0 + 1 < nby;
     tsc = &S.rowsum[0] + co * kTransposePitch;  // candidate octet's transpose scratch (AQ buffers are dead)
@@ -677,7 +592,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
   derive_roles();
   // Re-derives every per-thread value from the thread index behind a compiler barrier (12 waves only).
   auto new_phase = [&]() {
-    if constexpr (k12) {
+    {
       JXLT_LAUNDER_VGPR(tid);
       l = tid & 7;
       oct = tid >> 3;
@@ -690,10 +605,9 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
   float c16x[16], c16y[16], c16b[16];
   // 12 waves: a pair octet's two DCT8 live in the registers a candidate octet uses for its transform (rows 0-7:
   // first block, rows 8-15: second block), so that a thread needs ONE set of 48 coefficient registers.
-  float s8x[8], s8y[8], s8b[8];  // 8 waves: the octet's own block
-  float* const c8x = k12 ? c16x : s8x;
-  float* const c8y = k12 ? c16y : s8y;
-  float* const c8b = k12 ? c16b : s8b;
+  float* const c8x = c16x;
+  float* const c8y = c16y;
+  float* const c8b = c16b;
   float* const d8x = c16x + 8;
   float* const d8y = c16y + 8;
   float* const d8b = c16b + 8;
@@ -727,43 +641,26 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     // (scheduling fences: interleaving the three independent transforms would triple the
     // live registers and spill)
     if (is_tall) {
-      block_dct16x8<k12>(pxp, kXYPitch, l, tsc, c16x);
+      block_dct16x8<true>(pxp, kXYPitch, l, tsc, c16x);
       JXLT_SCHED_FENCE();
-      block_dct16x8<k12>(pyp, kXYPitch, l, tsc, c16y);
+      block_dct16x8<true>(pyp, kXYPitch, l, tsc, c16y);
       JXLT_SCHED_FENCE();
-      block_dct16x8<k12>(pbp, kBPitch, l, tsc, c16b);
+      block_dct16x8<true>(pbp, kBPitch, l, tsc, c16b);
     } else {
-      block_dct8x16<k12>(pxp, kXYPitch, l, tsc, c16x);
+      block_dct8x16<true>(pxp, kXYPitch, l, tsc, c16x);
       JXLT_SCHED_FENCE();
-      block_dct8x16<k12>(pyp, kXYPitch, l, tsc, c16y);
+      block_dct8x16<true>(pyp, kXYPitch, l, tsc, c16y);
       JXLT_SCHED_FENCE();
-      block_dct8x16<k12>(pbp, kBPitch, l, tsc, c16b);
+      block_dct8x16<true>(pbp, kBPitch, l, tsc, c16b);
     }
     JXLT_SCHED_FENCE();
   }
   JXLT_MARK(4);
-  // ---- P5: DCT8 of every block (kept in registers) + chroma-from-luma -------
+  // ---- P5: chroma-from-luma (the DCT8 of every block is in the pair octets' registers) -------
   // (enc_chroma_from_luma.cc:40-131)
-  if constexpr (!k12) {
-    const float* pxp = &S.x[(oby * 8) * kXYPitch + obx * 8 + kHalo];
-    const float* pyp = &S.y[(oby * 8) * kXYPitch + obx * 8 + kHalo];
-    const float* pbp = &S.b[(oby * 8) * kBPitch + obx * 8];
-    if (blk_valid) {
-      block_dct8x8(pxp, kXYPitch, l, tsc, c8x);
-      JXLT_SCHED_FENCE();
-      block_dct8x8(pyp, kXYPitch, l, tsc, c8y);
-      JXLT_SCHED_FENCE();
-      block_dct8x8(pbp, kBPitch, l, tsc, c8b);
-      JXLT_SCHED_FENCE();
-    } else {
-      // (cross-lane traffic never leaves an octet, so idle octets may skip it)
-#pragma unroll
-      for (int r = 0; r < 8; r++) c8x[r] = c8y[r] = c8b[r] = 0.0f;
-    }
-  }
   __syncthreads();  // all pixel reads done: the planes are dead from here on
   new_phase();
-  if constexpr (k12) {
+  {
     // the blocks' quant fields from the sums P4 left (see block_quant_field): wave 11, a lane per block, beside the
     // publishing of the terms; first read behind the chains
     if (wave_u == 11) {
@@ -815,11 +712,9 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
         *(float4*)&dst[((4 + (r >> 1)) ^ lsw) * 4] = tb;
       }
     };
-    if constexpr (k12) {
+    {
       if (pair_valid0) publish(pby0 * nbx + pbx, c8x, c8y, c8b);
       if (pair_valid1) publish((pby0 + 1) * nbx + pbx, d8x, d8y, d8b);
-    } else {
-      if (blk_valid) publish(oby * nbx + obx, c8x, c8y, c8b);
     }
     __syncthreads();
     // Chain lanes: wave 0 lanes 0-15 run ca (X: 0-7, B: 8-15), wave 1 lanes 0-15 run cb.
@@ -828,7 +723,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     // of block blk + 1 are issued before the arithmetic of block blk.
     float acc = 0.0f;
     // (12 waves: the wave index as a scalar)
-    const int cw = k12 ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6, cl = tid & 63;
+    const int cw = __builtin_amdgcn_readfirstlane(tid >> 6), cl = tid & 63;
     // 12 waves: the waves that wait for the chains fetch the root table meanwhile (two entries per thread); it goes
     // to LDS behind the chains, where the chain waves' parked coefficients were.
     float late_root0 = 0.0f, late_root1 = 0.0f;
@@ -836,7 +731,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     // and the inverse quantiser steps -- 1648 words that every wave would otherwise fetch from global memory, 25 loads
     // per thread, at the start of that phase, with nothing to do meanwhile
     uint32_t late_p8[3] = {0u, 0u, 0u};
-    if constexpr (k12) {
+    {
       if (cw >= 2) {
         late_root0 = T->sqrt_lut[(tid - 128) & (kSqrtLutSize - 1)];
         late_root1 = T->sqrt_lut[(tid - 128 + 640) & (kSqrtLutSize - 1)];
@@ -868,7 +763,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       auto chain_park = [&](int r) -> float& {
         return r < 17 ? S.transpose_pad[r * 128 + tid] : S.sqrt_lut[(r - 17) * 128 + tid];
       };
-      if constexpr (k12) {
+      {
         static_assert(sizeof(S.transpose_pad) / 4 >= 17 * 128 && sizeof(S.sqrt_lut) / 4 >= 8 * 128, "chain park");
 #pragma unroll
         for (int r = 0; r < 16; r++) chain_park(r) = c16b[r];
@@ -888,12 +783,9 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       float4 ta[4], tb[4];
 #pragma unroll
       for (int q = 0; q < 4; q++) ta[q] = *(const float4*)&src[imin(relay_pos, last) * 256 + slot[q]];
-      // (kind: std::true_type = the sums of a * a, false_type = of a * b, nullptr = chosen per step by the wave
-      // index -- the 8-wave kernel's form, which the compiler turns into eight selects per term set)
-      auto round4 = [&](float4* t, int first, auto kind) {
-        constexpr bool kByWave = std::is_same<decltype(kind), std::nullptr_t>::value;
-        if constexpr (k12) {
-          // (12 waves: the second factor of every product -- a for the sums of a * a, b for the sums of a * b --
+      auto round4 = [&](float4* t, int first) {
+        {
+          // (the second factor of every product -- a for the sums of a * a, b for the sums of a * b --
           // is selected IN PLACE once per term set, instead of into eight more registers)
           if (first < nblk) {
 #pragma unroll
@@ -907,22 +799,10 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
         for (int j = 0; j < 4; j++) {
           if (first + j >= nblk) break;  // (wave-uniform)
           // every lane runs the eight steps; only the row that holds the accumulators has meaningful ones
-          bool squares;
-          if constexpr (k12) squares = false;
-          else if constexpr (kByWave) squares = cw == 0;
-          else squares = decltype(kind)::value;
-          if (squares) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-              acc = fma32(t[q].x, t[q].x, acc);
-              acc = fma32(t[q].z, t[q].z, acc);
-            }
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              acc = fma32(t[q].x, t[q].y, acc);
-              acc = fma32(t[q].z, t[q].w, acc);
-            }
+          for (int q = 0; q < 4; q++) {
+            acc = fma32(t[q].x, t[q].y, acc);
+            acc = fma32(t[q].z, t[q].w, acc);
           }
           // the accumulators move on: rows 0 -> 1 and 3 -> 2 with a 16-lane swap, 1 -> 3 and 2 -> 0 with a 32-lane one
           const unsigned bits = __float_as_uint(acc);
@@ -932,21 +812,21 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
           if (j == 3) acc = __uint_as_float(__builtin_amdgcn_permlane32_swap(bits, bits, false, false)[1]);
         }
       };
-      auto chain_loop = [&](auto kind) {
+      auto chain_loop = [&]() {
 #pragma clang loop unroll(disable)
         for (int blk = 0; blk < nblk; blk += 8) {
 #pragma unroll
           for (int q = 0; q < 4; q++) tb[q] = *(const float4*)&src[imin(blk + 4 + relay_pos, last) * 256 + slot[q]];
-          round4(ta, blk, kind);
+          round4(ta, blk);
 #pragma unroll
           for (int q = 0; q < 4; q++) ta[q] = *(const float4*)&src[imin(blk + 8 + relay_pos, last) * 256 + slot[q]];
-          round4(tb, blk + 4, kind);
+          round4(tb, blk + 4);
         }
       };
       // (two loops behind a scalar branch -- chain_loop(std::true_type{}) / (std::false_type{}) -- made the
       // register allocator spill MORE in the 12-wave kernel)
-      chain_loop(nullptr);
-      if constexpr (k12) {
+      chain_loop();
+      {
         JXLT_COMPILER_FENCE();
 #pragma unroll
         for (int r = 0; r < 16; r++) c16b[r] = chain_park(r);
@@ -1024,7 +904,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     // cfl_sum: ca_x, cb_x, ca_b, cb_b
     if (chain_lane && l == 0) S.cfl_sum[chain_ch * 2 + cw] = total;
     __syncthreads();
-    if constexpr (k12) {
+    {
       if (cw >= 2) {  // (visible to P6b behind the barrier below)
         if (tid - 128 < kSqrtLutSize) S.sqrt_lut[tid - 128] = late_root0;
         if (tid - 128 + 640 < kSqrtLutSize) S.sqrt_lut[tid - 128 + 640] = late_root1;
@@ -1063,7 +943,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     auto estimate8 = [&](int bx, int by, const float* vx, const float* vy, const float* vb) {
       const int bi = by * 8 + bx;
       float qmax8 = 0.0f;
-      const float e = estimate_entropy<8, kLutRoots, k12, kThreads>(
+      const float e = estimate_entropy<8, kLutRoots, true, kThreads>(
           vx, vy, vb, S.inv_w + 0, S.inv_w + 64, S.inv_w + 128, l, fmaxf(0.0f, S.aq[bi]), fmaxf(0.0f, S.mask[bi]),
           cmap_x, cmap_b, A.distance, S.sqrt_lut, &qmax8);
       qmax = fmaxf(qmax, qmax8);
@@ -1079,25 +959,13 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     // octet) wait in the dead term area during the estimates, which read them from there; back in registers
     // for P8a afterwards.
     float* park = &S.x[0] + tid;
-    if constexpr (k12) {
+    {
 #pragma unroll
       for (int r = 0; r < 16; r++) park[r * kThreads] = c16b[r];
       JXLT_SCHED_FENCE();
       if (pair_valid0) estimate8(pbx, pby0, c8x, c8y, park);
       JXLT_SCHED_FENCE();
       if (pair_valid1) estimate8(pbx, pby0 + 1, d8x, d8y, park + 8 * kThreads);
-    } else {
-      if (blk_valid) estimate8(obx, oby, c8x, c8y, c8b);
-    }
-    // 8 waves: the DCT8 coefficients are needed again in P8; they wait in the (now dead) term area
-    // while the two-block estimate runs, which would otherwise spill.
-    if constexpr (!k12) {
-#pragma unroll
-      for (int r = 0; r < 8; r++) {
-        park[(r)*kTileThreads] = c8x[r];
-        park[(8 + r) * kTileThreads] = c8y[r];
-        park[(16 + r) * kTileThreads] = c8b[r];
-      }
     }
     JXLT_SCHED_FENCE();
     if (cell_valid) {
@@ -1107,8 +975,8 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       const float masking = fmaxf(fmaxf(0.0f, S.mask[bi]), S.mask[bi + o2]);
       const int toff = is_tall ? 3 : 6;
       float qmax16 = 0.0f;
-      const float e = estimate_entropy<16, kLutRoots, k12, kThreads>(
-          c16x, c16y, k12 ? park : c16b, S.inv_w + quant_table_offset(toff), S.inv_w + quant_table_offset(toff + 1),
+      const float e = estimate_entropy<16, kLutRoots, true, kThreads>(
+          c16x, c16y, park, S.inv_w + quant_table_offset(toff), S.inv_w + quant_table_offset(toff + 1),
           S.inv_w + quant_table_offset(toff + 2), l, quant, masking, cmap_x, cmap_b, A.distance, S.sqrt_lut, &qmax16);
       qmax = fmaxf(qmax, qmax16);
       const float k8X16mul1 = (float)-0.55, k8X16mul2 = (float)0.9019587899705066,
@@ -1117,14 +985,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       if (l == 0) S.transpose_pad[cell * 8 + (is_tall ? 4 : 6) + (cand & 1)] = mul16x8 * e;
     }
     JXLT_SCHED_FENCE();
-    if constexpr (!k12) {
-#pragma unroll
-      for (int r = 0; r < 8; r++) {
-        c8x[r] = park[(r)*kTileThreads];
-        c8y[r] = park[(8 + r) * kTileThreads];
-        c8b[r] = park[(16 + r) * kTileThreads];
-      }
-    } else {
+    {
       JXLT_COMPILER_FENCE();
 #pragma unroll
       for (int r = 0; r < 16; r++) c16b[r] = park[r * kThreads];
@@ -1211,7 +1072,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       *reinterpret_cast<float4*>(d) = lo;
       *reinterpret_cast<float4*>(d + 4) = hi;
     };
-    if constexpr (k12) {
+    {
       const int b0 = pby0 * 8 + pbx;
       if (pair_valid0 && S.strat[b0] == 1) {  // the pair octet's blocks that stayed DCT8
         float* d = stagef + b0 * kStageStrideF + l * 8;
@@ -1225,11 +1086,6 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
         put8(d + 64, d8y);
         put8(d + 128, d8b);
       }
-    } else if (blk_valid && S.strat[oct] == 1) {  // this octet's own block stayed DCT8
-      float* d = stagef + oct * kStageStrideF + l * 8;
-      put8(d, c8x);
-      put8(d + 64, c8y);
-      put8(d + 128, c8b);
     }
     const int bi = cby * 8 + cbx;
     if (cell_valid && S.strat[bi] == (uint8_t)(((is_tall ? 1 : 2) << 1) | 1)) {  // its candidate was selected
@@ -1263,10 +1119,10 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     };
     // (per scan position and position class: tables built by the host, DeviceTables::scan_consts)
     // (12 waves: from the copy in LDS that the waves waiting for the chains made, see late_p8)
-    const float* const p8_consts = k12 ? &S.x[0] + kP8TabOffset : &A.tab->scan_consts[0][0][0];
+    const float* const p8_consts = &S.x[0] + kP8TabOffset;
     const uint8_t* const p8_slots =
-        k12 ? reinterpret_cast<const uint8_t*>(&S.x[0] + kP8TabOffset + 3 * 7 * 64) : &A.tab->scan_slot[0][0];
-    const float* const p8_inv_qac = k12 ? &S.x[0] + kP8TabOffset + kP8ScanWords : &A.tab->inv_qac[0];
+        reinterpret_cast<const uint8_t*>(&S.x[0] + kP8TabOffset + 3 * 7 * 64);
+    const float* const p8_inv_qac = &S.x[0] + kP8TabOffset + kP8ScanWords;
     auto consts_of = [&](int cls) {
       LaneConsts k;
 #pragma unroll
@@ -1505,33 +1361,26 @@ JXLT_DI int xcd_ordered_tile(const TileArgs& A) {
 }
 // The tiles the launch in front filed in A.overflow_tiles, with every root computed (a fixed, small grid:
 // usually the list is empty and every workgroup leaves at once).
-template <int kWaves>
 JXLT_DI void tile_redo_body(const TileArgs& A) {
   const uint32_t n = A.lut_overflow[0];
   for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
-    tile_kernel_body<false, true, kWaves>(A, (int)A.overflow_tiles[e]);
+    tile_kernel_body<false, true>(A, (int)A.overflow_tiles[e]);
     __syncthreads();  // (the next tile starts by writing the shared state this one has just read)
   }
 }
 constexpr int kRedoGrid = 512;
 
-// tile_kernel: roots of the entropy estimate from the LDS table; tile_kernel_redo: every root computed -- the
-// same results, for the tiles in which tile_kernel met a quantised magnitude beyond the table.
-__global__ void __launch_bounds__(kTileThreads, 4) tile_kernel(const TileArgs A) {
+// tile12_kernel: roots of the entropy estimate from the LDS table; tile12_kernel_redo: every root computed -- the
+// same results, for the tiles in which tile12_kernel met a quantised magnitude beyond the table.  (Rounds 1-2 ran
+// this tile with 8 waves -- a block AND a candidate per octet, 125 registers, 4 waves per SIMD; the variant was kept
+// selectable through round 3 as the reference of the A/B in DESIGN.md 4.1.0 and went in round 4.)
+__global__ void __launch_bounds__(kTile12Threads, 6) tile12_kernel(const TileArgs A) {
   tile_kernel_body<true, false>(A, xcd_ordered_tile(A));
 }
-__global__ void __launch_bounds__(kTileThreads, 4) tile_kernel_debug(const TileArgs A) {
+__global__ void __launch_bounds__(kTile12Threads, 6) tile12_kernel_debug(const TileArgs A) {
   tile_kernel_body<true, true>(A, xcd_ordered_tile(A));
 }
-__global__ void __launch_bounds__(kTileThreads, 4) tile_kernel_redo(const TileArgs A) { tile_redo_body<8>(A); }
-// The 12-wave variants (see kTile12Threads).
-__global__ void __launch_bounds__(kTile12Threads, 6) tile12_kernel(const TileArgs A) {
-  tile_kernel_body<true, false, 12>(A, xcd_ordered_tile(A));
-}
-__global__ void __launch_bounds__(kTile12Threads, 6) tile12_kernel_debug(const TileArgs A) {
-  tile_kernel_body<true, true, 12>(A, xcd_ordered_tile(A));
-}
-__global__ void __launch_bounds__(kTile12Threads, 6) tile12_kernel_redo(const TileArgs A) { tile_redo_body<12>(A); }
+__global__ void __launch_bounds__(kTile12Threads, 6) tile12_kernel_redo(const TileArgs A) { tile_redo_body(A); }
 
 }  // namespace jxlt_dev
 

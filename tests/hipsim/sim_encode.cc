@@ -37,8 +37,6 @@ struct sim_result {
 __attribute__((visibility("default"))) void sim_free(sim_result* r);
 static float g_sim_strategy_distance = 0.0f;
 __attribute__((visibility("default"))) void sim_set_strategy_distance(float d) { g_sim_strategy_distance = d; }
-static int g_sim_tile_waves = 0;  // 0: the product's default variant of tile_kernel, else 8 or 12
-__attribute__((visibility("default"))) void sim_set_tile_waves(int w) { g_sim_tile_waves = w; }
 
 __attribute__((visibility("default"))) int sim_encode(const float* const planes[3], size_t pitch_floats, size_t xsize, size_t ysize,
                float distance, float scale, float inv_scale, float scale_dc, uint32_t x_qm_scale,
@@ -103,7 +101,6 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   // as jxlt_capi.hip: the table-root kernel, then the redo kernel for the tiles it filed (a quantised magnitude
   // beyond the table), per launch; one launch per row of DC groups with the slab arguments of the product
   // (jxlt_host_tables.h: SlabTileArgs)
-  const bool w12 = (g_sim_tile_waves ? g_sim_tile_waves : kDefaultTileWaves) == 12;
   const size_t rows_per_slab = 2048, nsl = (ysize + rows_per_slab - 1) / rows_per_slab;
   std::vector<uint32_t> lut_overflow(nsl, 0), overflow_tiles(ntiles, 0xFFFFFFFFu);
   A.lut_overflow = lut_overflow.data();
@@ -114,15 +111,9 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
     const dim3 grid((unsigned)((size_t)S.g.xsize_tiles * S.g.ysize_tiles));
     const dim3 redo_grid(std::min<unsigned>(grid.x, 3u));  // (fewer workgroups than the product: the loop over the list runs)
     // 0x800: the production variant (no debug outputs: r->xyb, qf, mask, ent8 stay as initialised)
-    if (w12) {
-      if (flags & 0x800u) hipsim::launch(tile12_kernel, grid, dim3(kTile12Threads), S);
-      else hipsim::launch(tile12_kernel_debug, grid, dim3(kTile12Threads), S);
-      hipsim::launch(tile12_kernel_redo, redo_grid, dim3(kTile12Threads), S);
-    } else {
-      if (flags & 0x800u) hipsim::launch(tile_kernel, grid, dim3(kTileThreads), S);
-      else hipsim::launch(tile_kernel_debug, grid, dim3(kTileThreads), S);
-      hipsim::launch(tile_kernel_redo, redo_grid, dim3(kTileThreads), S);
-    }
+    if (flags & 0x800u) hipsim::launch(tile12_kernel, grid, dim3(kTile12Threads), S);
+    else hipsim::launch(tile12_kernel_debug, grid, dim3(kTile12Threads), S);
+    hipsim::launch(tile12_kernel_redo, redo_grid, dim3(kTile12Threads), S);
     r->exact_reruns += lut_overflow[sl];  // tiles redone
   }
 

@@ -330,15 +330,13 @@ def pfm_payload(planes, big_endian=False):
 
 
 def sim_hot_path(planes, distance, force_dct8=False, as_pfm=None, tiny_root_table=False, production_variant=False,
-                 tile_waves=0, wide_token_index=False):
+                 wide_token_index=False):
     """Runs the product's HIP kernels on the CPU execution model (tests only).  as_pfm = "le" /
     "be": the kernels read the frame from a raw PFM payload instead of planar planes.
     production_variant: tile_kernel as the product launches it (without the debug outputs xyb, qf,
-    mask, ent8) instead of tile_kernel_debug.  tile_waves: 8 / 12 selects that variant of tile_kernel
-    (0: the one the product launches by default).  wide_token_index: token_kernel_wide (64-bit coefficient indices:
+    mask, ent8) instead of tile12_kernel_debug.  wide_token_index: token_kernel_wide (64-bit coefficient indices:
     what the product launches for frames above 1.43 Gpixel) instead of token_kernel."""
     _sim = _sim_lib(tiny_root_table)
-    _sim.sim_set_tile_waves(int(tile_waves))
     _, h, w = planes.shape
     p = distance_params(distance)
     s = SimResult()

@@ -44,18 +44,6 @@ def test_production_variant_of_tile_kernel_matches_oracle(built, w, h, distance,
 
 
 @pytest.mark.parametrize("w,h,distance,hard,dct8", [CASES[0], CASES[3], CASES[7]])
-def test_eight_wave_variant_of_tile_kernel_matches_oracle(built, w, h, distance, hard, dct8):
-    """The product launches the 12-wave variant of tile_kernel (tile12_kernel*, 768 threads, role-split octets);
-    the 8-wave variant stays selectable (JXLT_TILE_WAVES=8) as the reference of the A/B in DESIGN.md."""
-    planes = T.to_planes(T.synthetic_image(w, h, hard=hard))
-    want = T.oracle_hot_path(planes, distance, dct8)
-    got = T.sim_hot_path(planes, distance, dct8, tile_waves=8)
-    assert T.compare_results(want, got, "oracle", "kernels") == []
-    got = T.sim_hot_path(planes, distance, dct8, tile_waves=8, production_variant=True)
-    assert T.compare_results(want, got, "oracle", "kernels", check_debug=False) == []
-
-
-@pytest.mark.parametrize("w,h,distance,hard,dct8", [CASES[0], CASES[3], CASES[7]])
 def test_wide_index_variant_of_token_kernel_matches_oracle(built, w, h, distance, hard, dct8):
     """token_kernel_wide forms coefficient indices in 64 bits; the product launches it for frames above 2^32 / 192
     blocks (1.43 Gpixel: `-m gpu` has one), here it runs on ordinary frames."""
@@ -204,9 +192,9 @@ def test_dc_kernels_match_oracle_tokeniser(built, w, h, distance):
     """dc_elementwise_kernel + dc_chain_kernel vs the oracle's WriteDCGroup restatement."""
     planes = T.to_planes(T.synthetic_image(w, h))
     # (the 2 x 2 DC groups of the large frame are a thousand tiles on the fiber model: there the tile kernel that
-    # feeds the DC kernels is the production build of the 8-wave variant, two thirds of the fibers)
+    # feeds the DC kernels is the production build, without the debug outputs)
     big = w * h > 1 << 20
-    got = T.sim_hot_path(planes, distance, production_variant=big, tile_waves=8 if big else 0)
+    got = T.sim_hot_path(planes, distance, production_variant=big)
     want = T.oracle_dc_records(got)
     assert got.dc_records == want
     h = sum((T.token_histogram(r) for r in want))
@@ -223,8 +211,7 @@ def test_pfm_payload_ingest_on_cpu_model(built, flavour):
     T.compare_results(a, b, "planar", "pfm payload")
 
 
-@pytest.mark.parametrize("waves", [12, 8])
-def test_root_table_overflow_redoes_the_tiles_concerned_with_computed_roots(built, waves):
+def test_root_table_overflow_redoes_the_tiles_concerned_with_computed_roots(built):
     """tile_kernel takes the square roots of the entropy estimate from a table; a tile with a quantised
     magnitude beyond it must file itself and be redone by tile*_kernel_redo with computed roots -- only that tile.
     Magnitudes >= 1024 hardly occur (the adaptive quantiser sees to that), so this runs a build of the kernels
@@ -232,13 +219,13 @@ def test_root_table_overflow_redoes_the_tiles_concerned_with_computed_roots(buil
     img = T.synthetic_image(200, 137, hard=True)
     img[:64, :64] = 0.25  # a flat tile: every quantised coefficient is 0
     planes = T.to_planes(img)
-    got = T.sim_hot_path(planes, 0.5, tiny_root_table=True, tile_waves=waves)
+    got = T.sim_hot_path(planes, 0.5, tiny_root_table=True)
     ntiles = 4 * 3
     assert 0 < got.exact_reruns < ntiles, "tiles redone: %d" % got.exact_reruns
     want = T.oracle_hot_path(planes, 0.5)
     assert T.compare_results(want, got, "oracle", "cpu model, computed roots") == []
     # the product build stays on the table path for the same image, with the same result
-    same = T.sim_hot_path(planes, 0.5, tile_waves=waves)
+    same = T.sim_hot_path(planes, 0.5)
     assert same.exact_reruns == 0
     assert T.compare_results(want, same, "oracle", "cpu model, table roots") == []
 
