@@ -218,15 +218,6 @@ int jxlt_pack_deliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_sect
  * call that asks for a larger one / destroy; it keeps its contents when it grows). */
 int jxlt_output_buffer(jxlt_context* ctx, size_t bytes, uint8_t** out);
 
-/* Timing of the device stages of the last jxlt_encode_enqueue (HIP events on the context's
- * stream, always recorded): writes up to `cap` entries; returns the number of stages, or < 0.
- * Waits for the device pipeline of that encode. */
-typedef struct {
-  const char* name;
-  float milliseconds;
-} jxlt_kernel_time;
-int jxlt_kernel_times(jxlt_context* ctx, jxlt_kernel_time* out, int cap);
-
 /* Statistics of the last encode of `ctx` (waits for its tile kernels).  The entropy estimate of the transform
  * search takes a square root per coefficient (enc_ac_strategy.cc:118-126); the kernel reads the roots of quantised
  * magnitudes below 1024 from a table, and a tile that meets a larger one (tiny distances, samples far above 1.0)
@@ -247,11 +238,6 @@ void jxlt_compute_distance_params(float distance, jxlt_distance_params* out);
  * (*out_bytes, caller frees with jxlt_free).  num_threads <= 0: all cores. */
 int jxlt_assemble_frame(const jxlt_frame_result* frame, const jxlt_distance_params* distp,
                         int num_threads, uint8_t** out_bytes, size_t* out_size);
-/* As above but with separately allocated per-group token buffers. */
-int jxlt_assemble_frame_groups(const jxlt_frame_result* frame, const uint8_t* const* group_tokens,
-                               const size_t* group_token_bytes, const jxlt_distance_params* distp,
-                               int num_threads, uint8_t** out_bytes, size_t* out_size);
-
 /* Full codestream (file header + frame) of the image currently set on `ctx`
  * (jxlt_image_upload / jxlt_image_set_device): device pipeline, device-side
  * section packing, host assembly.  malloc'ed result, free with jxlt_free. */
@@ -407,14 +393,6 @@ int jxlt_shard_pipeline_submit_device(jxlt_shard_pipeline* pipeline, const void*
 /* Waits for frame `ticket`.  On rank 0 *bytes / *size receive the codestream (inside the lane's segment: valid
  * until `depth` further frames have been submitted); NULL / 0 on the other ranks. */
 int jxlt_shard_pipeline_wait(jxlt_shard_pipeline* pipeline, uint64_t ticket, const uint8_t** bytes, size_t* size);
-
-/* Building blocks of the above (also usable on their own): code tables from summed histograms, and the
- * complete codestream from summed histograms + all packed sections in raster order. */
-int jxlt_build_code_tables(const uint32_t* ac_histograms, const uint32_t* dc_histograms,
-                           uint32_t* ac_code_table, uint32_t* dc_code_table);
-int jxlt_finish_frame(size_t xsize, size_t ysize, float distance, const uint32_t* ac_histograms,
-                      const uint32_t* dc_histograms, const jxlt_packed_sections* dc_sections,
-                      const jxlt_packed_sections* ac_sections, uint8_t** out_bytes, size_t* out_size);
 
 void jxlt_free(void* p);
 

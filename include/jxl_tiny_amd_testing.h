@@ -23,6 +23,16 @@ extern "C" {
  *           always allowed). */
 int jxlt_debug_fetch(jxlt_context* ctx, int what, void* host_dst, size_t bytes);
 
+/* Timing of the device stages of the last jxlt_encode_enqueue (HIP events on the context's
+ * stream, always recorded): writes up to `cap` entries; returns the number of stages, or < 0.
+ * Waits for the device pipeline of that encode. */
+typedef struct {
+  const char* name;
+  float milliseconds;
+} jxlt_kernel_time;
+int jxlt_kernel_times(jxlt_context* ctx, jxlt_kernel_time* out, int cap);
+
+
 /* The side-band grids and the AC symbol histograms of the last encode without its raw tokens (out->tokens is NULL):
  * what a reference-style caller that packs on the device would fetch.  The test-suite compares the grids. */
 int jxlt_fetch_side_info(jxlt_context* ctx, jxlt_frame_result* out, const uint32_t** ac_histograms);
@@ -32,6 +42,21 @@ int jxlt_fetch_side_info(jxlt_context* ctx, jxlt_frame_result* out, const uint32
 int jxlt_pack_sections(jxlt_context* ctx, int kind, const uint32_t* code_table, jxlt_packed_sections* out);
 
 /* ---- libjxltiny_host.so ------------------------------------------------ */
+
+/* jxlt_assemble_frame with separately allocated per-group token buffers. */
+int jxlt_assemble_frame_groups(const jxlt_frame_result* frame, const uint8_t* const* group_tokens,
+                               const size_t* group_token_bytes, const jxlt_distance_params* distp,
+                               int num_threads, uint8_t** out_bytes, size_t* out_size);
+
+
+/* Building blocks of the sharded frame, for stage-by-stage comparisons with the oracle: code tables from summed
+ * histograms, and the complete codestream from summed histograms + all packed sections in raster order. */
+int jxlt_build_code_tables(const uint32_t* ac_histograms, const uint32_t* dc_histograms,
+                           uint32_t* ac_code_table, uint32_t* dc_code_table);
+int jxlt_finish_frame(size_t xsize, size_t ysize, float distance, const uint32_t* ac_histograms,
+                      const uint32_t* dc_histograms, const jxlt_packed_sections* dc_sections,
+                      const jxlt_packed_sections* ac_sections, uint8_t** out_bytes, size_t* out_size);
+
 
 /* The protocol of jxlt_shard_encode over caller-supplied slab operations instead of a device context (what jxlt_shard_encode
  * binds to the jxlt_* calls named on the right); lets the CPU test-suite run the protocol without a GPU.

@@ -36,10 +36,10 @@ HIP_SYMBOLS = ["jxlt_context_create", "jxlt_context_destroy", "jxlt_last_error",
                "jxlt_fetch_histograms", "jxlt_fetch_dc_histogram", "jxlt_histograms_ready",
                "jxlt_pack_begin", "jxlt_pack_sizes", "jxlt_pack_deliver", "jxlt_release_cached_memory",
                "jxlt_output_buffer",
-               "jxlt_synchronize", "jxlt_fetch_result", "jxlt_kernel_times", "jxlt_encode_stats"]
-HIP_SYMBOLS_TESTING = ["jxlt_debug_fetch", "jxlt_fetch_side_info", "jxlt_pack_sections"]
-HOST_SYMBOLS = ["jxlt_compute_distance_params", "jxlt_assemble_frame", "jxlt_assemble_frame_groups",
-                "jxlt_encode_file_planar", "jxlt_encode_pfm_file", "jxlt_emulate_reference_static_constants", "jxlt_emulate_reference_single_symbol_codes", "jxlt_encode_resident", "jxlt_encode_resident_view", "jxlt_write_file_header", "jxlt_build_code_tables", "jxlt_finish_frame",
+               "jxlt_synchronize", "jxlt_fetch_result", "jxlt_encode_stats"]
+HIP_SYMBOLS_TESTING = ["jxlt_debug_fetch", "jxlt_fetch_side_info", "jxlt_pack_sections", "jxlt_kernel_times"]
+HOST_SYMBOLS = ["jxlt_compute_distance_params", "jxlt_assemble_frame",
+                "jxlt_encode_file_planar", "jxlt_encode_pfm_file", "jxlt_emulate_reference_static_constants", "jxlt_emulate_reference_single_symbol_codes", "jxlt_encode_resident", "jxlt_encode_resident_view", "jxlt_write_file_header",
                 "jxlt_free", "jxlt_batch_encoder_create", "jxlt_batch_encoder_create_multi",
                 "jxlt_batch_encoder_destroy", "jxlt_batch_encoder_run",
                 "jxlt_shard_rect", "jxlt_multi_encoder_create", "jxlt_multi_encoder_destroy",
@@ -48,7 +48,8 @@ HOST_SYMBOLS = ["jxlt_compute_distance_params", "jxlt_assemble_frame", "jxlt_ass
                 "jxlt_shard_group_open", "jxlt_shard_group_close", "jxlt_shard_group_last_error",
                 "jxlt_shard_encode", "jxlt_shard_pipeline_open", "jxlt_shard_pipeline_close",
                 "jxlt_shard_pipeline_last_error", "jxlt_shard_pipeline_submit_device", "jxlt_shard_pipeline_wait"]
-HOST_SYMBOLS_TESTING = ["jxlt_debug_dc_records", "jxlt_shard_encode_ops", "jxlt_shard_pipeline_open_ops",
+HOST_SYMBOLS_TESTING = ["jxlt_debug_dc_records", "jxlt_assemble_frame_groups", "jxlt_build_code_tables", "jxlt_finish_frame",
+                        "jxlt_shard_encode_ops", "jxlt_shard_pipeline_open_ops",
                         "jxlt_shard_pipeline_submit_ops"]
 
 
