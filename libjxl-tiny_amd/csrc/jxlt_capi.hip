@@ -80,6 +80,21 @@ struct jxlt_context {
   // DC-group tokenisation + AC tokenisation of one row of DC groups run on `aux_stream` as soon as that row's
   // tile_kernel launch is done, i.e. beside the next row's tile_kernel (latency-bound kernels under a VALU-bound one)
   hipStream_t aux_stream = nullptr;
+  // The DC-group sections are packed on a stream of their own, of the highest priority the device offers: their
+  // code is ready while token_kernel is still running, and behind token_kernel on the main stream their packing
+  // (and the 5 MB they send over the link, 16384^2) would stand in front of the AC sections'.
+  hipStream_t dc_pack_stream = nullptr;
+  // A hand-over of the DC-group sections asked for before their sizes have arrived (the copy commands need the sizes):
+  // kept here and issued as soon as they are there -- from inside whatever wait of the library comes next (WaitWord),
+  // at the latest by jxlt_pack_sizes / jxlt_synchronize.  The caller does not block for it and does not have to
+  // come back for it.
+  struct DeferredDeliver {
+    bool pending = false;
+    uint8_t* dst = nullptr;
+    int end_aligned = 0;
+    std::vector<jxlt_section_run> runs;
+  } deferred_dc;
+  bool in_deferred = false;  // (IssueDeferred is running: its own waits must not start it again)
   std::vector<hipEvent_t> tile_done;
   hipEvent_t aux_done = nullptr;   // everything queued on aux_stream for the frame (timing enabled: the token tail)
 
@@ -119,6 +134,14 @@ struct jxlt_context {
     DeviceBuf<uint32_t> launch_sec_end;  // sections complete behind each writing launch (pack_tile_finalize_kernel)
     uint32_t pack_seq = 0;               // measuring passes of this kind so far: what the sizes' flag carries
     uint32_t* h_launch_sec_end = nullptr;  // host mirror of launch_sec_end (inside the context's HostMail)
+    DeviceBuf<unsigned long long> tile_state;  // single pass: what every tile tells the tiles behind it (PackTileState)
+    bool streamed = false;          // the last pass of this kind was a single pass (no measuring pass)
+    // (single pass: the host turns the sections' bit counts into byte offsets, launch by launch)
+    size_t state_tiles = 0;               // tile_state: the block states start behind this many tile states
+    hipStream_t stream = nullptr;         // where this kind's packing kernels are queued (set by jxlt_pack_begin)
+    int launches_seen = 0;                // launches whose word the host has seen
+    uint32_t offsets_done_sections = 0;   // sections whose byte offsets the host has worked out
+    uint64_t zeroed_bytes = 0;            // how much of the blob was zeroed in front of the pass
     static size_t SizesWords(size_t nsec) { return nsec + 1 + (nsec + 1) / 2; }
     uint32_t* sec_bits(size_t nsec) const { return reinterpret_cast<uint32_t*>(sec_byte_off.p + nsec + 1); }
     uint32_t* h_sec_bits(size_t nsec) const { return reinterpret_cast<uint32_t*>(h_sec_byte_off.p + nsec + 1); }
@@ -150,6 +173,8 @@ struct jxlt_context {
     uint32_t delivered_seq[2][16];  // [kind][0] = deliver_seq[kind]: every hand-over of that kind queued so far has finished
     unsigned long long token_total;  // records of all AC groups (sizes the packing's tile arrays)
     uint32_t launch_sec_end[2][16];  // [kind]: sections complete behind each writing launch (published with the sizes)
+    uint32_t stream_seq[2][kPackMaxLaunches][16];  // [kind][launch][0] = pack_seq: that launch of a single pass is done,
+                                                   // the bit counts of the sections it completed are in the host's mirror
   };
   PinnedBuf<HostMail> mail;
   uint32_t seq = 0;          // encodes enqueued on this context
@@ -428,6 +453,11 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->dc_copy_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    e = hipStreamCreateWithPriority(&ctx->dc_pack_stream, hipStreamNonBlocking, greatest);
+  }
   if (e == hipSuccess) e = hipEventCreate(&ctx->aux_done);
   for (auto& ev : ctx->ev)
     if (e == hipSuccess) e = hipEventCreate(&ev);
@@ -440,11 +470,11 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
     ctx->mail.cap = 1;
     memset(ctx->mail.p, 0, sizeof(jxlt_context::HostMail));
     for (int k = 0; k < 2; k++) ctx->pack[k].h_launch_sec_end = ctx->mail.p->launch_sec_end[k];
-    e = hipMalloc(reinterpret_cast<void**>(&ctx->deliver_counter.p), 64);
+    e = hipMalloc(reinterpret_cast<void**>(&ctx->deliver_counter.p), 128);  // (+ 64 bytes of look-back statistics)
   }
   if (e == hipSuccess) {
     ctx->deliver_counter.cap = 16;
-    e = hipMemset(ctx->deliver_counter.p, 0, 64);
+    e = hipMemset(ctx->deliver_counter.p, 0, 128);
   }
   for (auto& ps : ctx->pack) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ps.finalized, hipEventDisableTiming);
@@ -469,7 +499,7 @@ void jxlt_context_destroy(jxlt_context* ctx) {
   // (everything the context has queued on any of ITS streams -- other contexts, lanes and frameworks on the device
   // are not waited for: its device buffers may be kept for the next context, DeviceBlockCache, and are then not
   // synchronised by a hipFree)
-  for (hipStream_t st : {ctx->stream, ctx->aux_stream, ctx->copy_stream, ctx->dc_copy_stream, ctx->upload_stream})
+  for (hipStream_t st : {ctx->stream, ctx->aux_stream, ctx->dc_pack_stream, ctx->copy_stream, ctx->dc_copy_stream, ctx->upload_stream})
     if (st) (void)hipStreamSynchronize(st);
   FreeDevice(&ctx->own_payload);
   for (int c = 0; c < 3; c++) {
@@ -510,6 +540,7 @@ void jxlt_context_destroy(jxlt_context* ctx) {
     FreeDevice(&ps.tile_info);
     FreeDevice(&ps.packed);
     FreeDevice(&ps.launch_sec_end);
+    FreeDevice(&ps.tile_state);
     FreePinned(&ps.h_sec_byte_off);
     FreePinned(&ps.h_packed);
     FreePinned(&ps.h_code_table);
@@ -555,6 +586,7 @@ void jxlt_context_destroy(jxlt_context* ctx) {
     (void)hipStreamSynchronize(ctx->upload_stream);
     (void)hipStreamDestroy(ctx->upload_stream);
   }
+  if (ctx->dc_pack_stream) (void)hipStreamDestroy(ctx->dc_pack_stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->dc_copy_stream) (void)hipStreamDestroy(ctx->dc_copy_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -915,6 +947,7 @@ int jxlt_image_size(const jxlt_context* ctx, size_t* xsize, size_t* ysize) {
 
 namespace {
 int EnqueuePlan(jxlt_context* ctx, int kind, uint64_t rec_bound, hipStream_t stream);  // (below)
+int WaitSizes(jxlt_context* ctx, int kind);  // (below)
 
 // (diagnostics, JXLT_TRACE_EVENTS=1: a timed event on `stream`, listed against the encode's first event by jxlt_synchronize)
 bool TraceEventsOn() {
@@ -938,6 +971,16 @@ void TraceMark(jxlt_context* ctx, const char* name, hipStream_t stream) {
 void TraceDump(jxlt_context* ctx) {
   if (!TraceEventsOn() || ctx->trace_used == 0) return;
   (void)hipDeviceSynchronize();
+  if (ctx->deliver_counter.p) {
+    uint32_t st[8];
+    if (hipMemcpy(st, ctx->deliver_counter.p + 16, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess) {
+      for (int k = 0; k < 2; k++)
+        if (st[k * 4])
+          fprintf(stderr, "jxlt look-back (%s): %u tiles, %.2f windows per tile (most %u), %.2f reloads per tile\n", k ? "AC" : "DC",
+                  st[k * 4], (double)st[k * 4 + 1] / st[k * 4], st[k * 4 + 3], (double)st[k * 4 + 2] / st[k * 4]);
+      (void)hipMemset(ctx->deliver_counter.p + 16, 0, sizeof(st));
+    }
+  }
   for (size_t i = 0; i < ctx->trace_used; i++) {
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->trace[i].ev) == hipSuccess)
@@ -950,6 +993,7 @@ void TraceDump(jxlt_context* ctx) {
 // inside a frame are fractions of a millisecond, and the word is seen ~6 us earlier than an event would be
 // (tools/d2h_probe.hip).  A device fault would leave the word unwritten for ever: the stream is asked for errors
 // every couple of milliseconds, and a wait gives up after two minutes.
+int IssueDeferred(jxlt_context* ctx, bool wait);  // (below)
 int WaitWord(jxlt_context* ctx, const uint32_t* word, uint32_t want, hipStream_t stream, const char* what) {
   const volatile uint32_t* w = word;
   if (*w == want) return JXLT_OK;
@@ -961,6 +1005,10 @@ int WaitWord(jxlt_context* ctx, const uint32_t* word, uint32_t want, hipStream_t
 #if defined(__x86_64__)
       __builtin_ia32_pause();
 #endif
+    }
+    if (ctx->deferred_dc.pending && !ctx->in_deferred) {
+      const int rcd = IssueDeferred(ctx, /*wait=*/false);
+      if (rcd != JXLT_OK) return rcd;
     }
     const auto now = std::chrono::steady_clock::now();
     if (now < next_check) continue;
@@ -989,6 +1037,10 @@ int WaitWord(jxlt_context* ctx, const uint32_t* word, uint32_t want, hipStream_t
 
 // Every hand-over queued so far (both kinds) has finished.
 int WaitDeliveries(jxlt_context* ctx) {
+  if (ctx->deferred_dc.pending) {
+    const int rcd = IssueDeferred(ctx, /*wait=*/true);
+    if (rcd != JXLT_OK) return rcd;
+  }
   for (int kind = 0; kind < 2; kind++) {
     const int rc = WaitWord(ctx, &ctx->mail.p->delivered_seq[kind][0], ctx->deliver_seq[kind],
                             kind ? ctx->copy_stream : ctx->dc_copy_stream, "section hand-over");
@@ -1039,6 +1091,10 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
     if (rcw != JXLT_OK) return rcw;
     ctx->deliveries_pending = false;
   }
+  // (the previous encode's DC-group sections may have been packed on their own stream and never handed over: this
+  // encode's kernels overwrite what that packing reads)
+  if (ctx->pack[0].stream == ctx->dc_pack_stream && ctx->pack[0].launches > 0)
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->pack[0].launch_done[ctx->pack[0].launches - 1], 0));
   const uint32_t frame_seq = ++ctx->seq;  // (what this encode's publish kernels store to the host's sequence words)
   const FrameGeom g = MakeGeom(ctx->xsize, ctx->ysize);
   const size_t nblocks = (size_t)g.xsize_blocks * g.ysize_blocks;
@@ -1373,6 +1429,22 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   // The tile plan of the AC sections needs the groups' token offsets only: it runs now, behind the histogram's
   // way to the host, while the host builds the codes (upper bound of the record count: the buffer's capacity).
   ctx->pack[0].planned = ctx->pack[1].planned = false;
+  // Where the sections are packed: the AC sections behind token_kernel on the main stream; the DC-group sections on
+  // their own stream of high priority, behind the DC-group kernels only (experiment knob JXLT_DC_PACK_STREAM=0: on
+  // the main stream as well, rounds 1-3).
+  static const int dc_own_stream_knob = [] {
+    const char* e = getenv("JXLT_DC_PACK_STREAM");
+    return e ? atoi(e) : -1;
+  }();
+  // (above 1024 groups, where the DC-group kernels stand in front of token_kernel: 16384^2 5.22-5.27 -> 5.18-5.22 ms;
+  // below, the DC-group sections' packing is short and the extra stream costs more than it saves, 8192^2 1.55 -> 1.57-1.60)
+  const bool dc_own_stream = dc_own_stream_knob >= 0 ? dc_own_stream_knob != 0 : ngroups > 1024;
+  ctx->pack[1].stream = ctx->stream;
+  ctx->pack[0].stream = dc_own_stream ? ctx->dc_pack_stream : ctx->stream;
+  if (dc_own_stream) {
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->dc_pack_stream, ctx->dc_kernels_done, 0));
+    if (nslabs == 1 && ctx->dc_elementwise_split) HIP_TRY(ctx, hipStreamWaitEvent(ctx->dc_pack_stream, ctx->dc_elementwise_done, 0));
+  }
   {
     // (one launch for the frame: the auxiliary stream is idle, and on the main stream the plan's three small
     // kernels would stand in front of the DC-group sections' packing, which the AC measuring pass queues behind)
@@ -1460,12 +1532,13 @@ int jxlt_synchronize(jxlt_context* ctx) {
     // (the section sizes of both kinds have been published by kernels in front of the hand-over's writes)
     for (int kind = 0; kind < 2; kind++) {
       if (ctx->pack[kind].measured_sections == 0) continue;
-      const int rcs = WaitWord(ctx, &ctx->mail.p->sizes_seq[kind][0], ctx->pack[kind].pack_seq, ctx->aux_stream, "section sizes");
+      const int rcs = WaitSizes(ctx, kind);
       if (rcs != JXLT_OK) return rcs;
     }
     if (!ctx->copies_pending) return JXLT_OK;
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->pack[0].stream == ctx->dc_pack_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->dc_pack_stream));
   if (ctx->copies_pending) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
     ctx->copies_pending = false;
@@ -1608,6 +1681,25 @@ int jxlt_fetch_histograms(jxlt_context* ctx, const uint32_t** ac_histograms, con
 }
 
 namespace {
+// One pass or two.  ONE (pack_tile_stream_kernel: every tile takes its bit position from the tiles in front of it
+// while it runs; no measuring pass, none of its offsets / scan / finalize kernels, no second read of the records) for
+// frames of up to 1024 groups (8192^2), TWO (measure, lay out, write: rounds 1-3) above: the single pass saves the
+// chain of small kernels -- 2048^2: 0.41 -> 0.375 ms, 4096^2: 0.62 -> 0.59, 8192^2: 1.56 -> 1.54 -- but its kernel
+// packs 75-85 tiles per us where the two-pass form's writing pass does 120 (one tile per workgroup, and the waits
+// for the neighbours' sizes), and from ~20 000 tiles on that costs more than the measuring pass did (16384^2: 5.26
+// against 5.18-5.22 ms).  JXLT_PACK_TWO_PASS=1 / 0 forces either; the kernel hand-over (JXLT_DELIVER_KERNEL=1)
+// needs two passes.
+bool PackSinglePass(const jxlt_context* ctx) {
+  static const int forced = [] {
+    const char* two = getenv("JXLT_PACK_TWO_PASS");
+    const char* kern = getenv("JXLT_DELIVER_KERNEL");
+    if (kern && atoi(kern) != 0) return 0;
+    return two ? (atoi(two) != 0 ? 0 : 1) : -1;
+  }();
+  if (forced >= 0) return forced != 0;
+  return (size_t)ctx->geom.xsize_groups * ctx->geom.ysize_groups <= 1024;
+}
+
 // Common argument block of the tile-granular packing kernels for sections of `kind`.
 PackTileArgs TileArgsOf(jxlt_context* ctx, int kind, size_t nsec) {
   jxlt_context::PackSet& ps = ctx->pack[kind];
@@ -1631,6 +1723,13 @@ PackTileArgs TileArgsOf(jxlt_context* ctx, int kind, size_t nsec) {
   P.launches = (uint32_t)ps.launches;
   for (int i = 0; i <= ps.launches && i <= kPackMaxLaunches; i++) P.launch_t0[i] = ps.launch_t0[i];
   P.launch_sec_end = ps.launch_sec_end.p;
+  P.tile_state = PackSinglePass(ctx) ? ps.tile_state.p : nullptr;
+  P.block_state = PackSinglePass(ctx) && ps.tile_state.p ? ps.tile_state.p + ps.state_tiles : nullptr;
+  static const bool stats_on = [] {
+    const char* e = getenv("JXLT_LOOKBACK_STATS");  // (with JXLT_TRACE_EVENTS; the counting slows the pass down)
+    return e && atoi(e) != 0;
+  }();
+  P.lookback_stats = stats_on && TraceEventsOn() && ctx->deliver_counter.p ? ctx->deliver_counter.p + 16 + kind * 4 : nullptr;
   return P;
 }
 
@@ -1657,6 +1756,10 @@ int EnqueuePlan(jxlt_context* ctx, int kind, uint64_t rec_bound, hipStream_t str
   ENSURE(tile_bits, max_tiles);
   ENSURE(tile_info, max_tiles);
   ENSURE(launch_sec_end, kPackMaxLaunches);
+  if (PackSinglePass(ctx)) {  // (tile states, block states behind them)
+    ENSURE(tile_state, max_tiles + max_tiles / kPackBlockTiles + 2);
+    ps.state_tiles = max_tiles;
+  }
 #undef ENSURE
   const PackTileArgs P = TileArgsOf(ctx, kind, nsec);
   const unsigned sec_blocks = (unsigned)((nsec + 255) / 256);
@@ -1668,7 +1771,7 @@ int EnqueuePlan(jxlt_context* ctx, int kind, uint64_t rec_bound, hipStream_t str
   // (which sections a launch of the writing pass completes follows from the plan and is worked out on the device --
   // pack_tile_finalize_kernel --: the host does not fetch the plan any more)
   ps.planned = true;
-  ps.plan_elsewhere = stream != ctx->stream;
+  ps.plan_elsewhere = stream != ps.stream;
   if (ps.plan_elsewhere) HIP_TRY(ctx, hipEventRecord(ps.plan_done, stream));
   return JXLT_OK;
 }
@@ -1684,8 +1787,8 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
   const uint64_t rec_bound = kind == 1 ? ctx->h_group_off.p[nsec] : ctx->dc_records.cap / 3;
   const size_t max_tiles = (size_t)(rec_bound / kPackTile) + nsec + 1;
   int rc;
-  if (!ps.planned && (rc = EnqueuePlan(ctx, kind, rec_bound, ctx->stream)) != JXLT_OK) return rc;
-  if (ps.plan_elsewhere) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ps.plan_done, 0));
+  if (!ps.planned && (rc = EnqueuePlan(ctx, kind, rec_bound, ps.stream)) != JXLT_OK) return rc;
+  if (ps.plan_elsewhere) HIP_TRY(ctx, hipStreamWaitEvent(ps.stream, ps.plan_done, 0));
   if ((rc = EnsurePinned(ctx, &ps.h_sec_byte_off, jxlt_context::PackSet::SizesWords(nsec))) != JXLT_OK) return rc;
   // The caller's table is pageable as a rule: an asynchronous copy from it would make this call wait for
   // everything queued on the stream (token_kernel!).  Staged through the context's page-locked copy instead;
@@ -1697,7 +1800,7 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
   // download, JXLT_TRACE_EVENTS)
   {
     const PublishSeg seg = {ps.h_code_table.p, ps.code_table.p, 64 * 64};
-    if ((rc = EnqueuePublish(ctx, ctx->stream, &seg, 1, nullptr, nullptr, nullptr, 0)) != JXLT_OK) return rc;
+    if ((rc = EnqueuePublish(ctx, ps.stream, &seg, 1, nullptr, nullptr, nullptr, 0)) != JXLT_OK) return rc;
   }
   // Blob capacity: <= 28 bits per record.  (Allocated before the measuring pass: its last kernel zeroes the
   // dwords in which tiles and sections meet.)
@@ -1728,23 +1831,23 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
     ps.launch_t0[i] = i == ps.launches ? (uint32_t)max_tiles : (uint32_t)((double)max_tiles * share);
   }
   const PackTileArgs P = TileArgsOf(ctx, kind, nsec);
-  TraceMark(ctx, kind ? "AC measure start" : "DC measure start", ctx->stream);
+  TraceMark(ctx, kind ? "AC measure start" : "DC measure start", ps.stream);
   hipLaunchKernelGGL(pack_tile_measure_kernel,
                      dim3((unsigned)((max_tiles + kPackMeasureTilesPerGroup - 1) / kPackMeasureTilesPerGroup)),
-                     dim3(kPackThreads), 0, ctx->stream, P);
+                     dim3(kPackThreads), 0, ps.stream, P);
   hipLaunchKernelGGL(pack_tile_offsets_kernel,
                      dim3((unsigned)((nsec + kPackOffsetsSectionsPerGroup - 1) / kPackOffsetsSectionsPerGroup)),
-                     dim3(64 * kPackOffsetsSectionsPerGroup), 0, ctx->stream, P);
-  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, (const uint32_t*)ps.sec_bytes.p,
+                     dim3(64 * kPackOffsetsSectionsPerGroup), 0, ps.stream, P);
+  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(kScanThreads), 0, ps.stream, (const uint32_t*)ps.sec_bytes.p,
                      ps.sec_byte_off.p, (int)nsec);
   // The sizes are final behind the scan (the last kernel of the pass only moves the tiles to their places): they
   // leave for the host by the auxiliary stream (idle by now), beside that kernel -- offsets and bit counts lie
   // behind each other, one publish_kernel stores them to the page-locked mirror and then the pass's number to the
   // word the host polls.  (Rounds 1-3: hipMemcpyAsync + event; the copy alone took 20 us of device time.)
-  TraceMark(ctx, kind ? "AC scan done" : "DC scan done", ctx->stream);
-  hipLaunchKernelGGL(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), 0, ctx->stream, P);
+  TraceMark(ctx, kind ? "AC scan done" : "DC scan done", ps.stream);
+  hipLaunchKernelGGL(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), 0, ps.stream, P);
   HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipEventRecord(ps.finalized, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ps.finalized, ps.stream));
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ps.finalized, 0));
   ps.pack_seq++;
   {
@@ -1761,7 +1864,124 @@ int EnqueueMeasure(jxlt_context* ctx, int kind, const uint32_t* code_table) {
   ps.measured_sections = nsec;
   ps.max_tiles = max_tiles;
   ps.writes_queued = false;
+  ps.streamed = false;
   return EnqueueWrites(ctx, kind);
+}
+
+// Bytes the sections of `kind` take at most with this code: the code lengths of the context's own tokens (its
+// histograms are in the host's mirror by now) + the raw bits and the padding a section can add.
+uint64_t SectionBytesBound(const jxlt_context* ctx, int kind, const uint32_t* table, size_t nsec) {
+  const uint32_t* hist = ctx->h_hist.p + (kind == 1 ? 0 : 64 * 64);
+  uint64_t bits = 0;
+  for (uint32_t c = 0; c < 64; c++)
+    for (uint32_t sym = 0; sym < 64; sym++) {
+      const uint32_t n = hist[c * 64 + sym];
+      if (n) bits += (uint64_t)n * ((table[c * 64 + sym] >> 16) + (sym >= 16 ? (sym >> 2) - 2u : 0u));
+    }
+  return bits / 8 + 32 * (uint64_t)nsec + 256;
+}
+
+// The single pass over the sections of `kind` (asynchronous; the default, see PackSinglePass): plan (if it is not
+// there yet), code table, a zeroed blob, and the launches of pack_tile_stream_kernel over growing shares of the
+// tiles.  Behind every launch a publish_kernel on the auxiliary stream carries the sections' bit counts and "which
+// sections are complete" to the host's mirror and sets that launch's word (HostMail::stream_seq): the host turns
+// bit counts into byte offsets itself (a prefix sum over a few thousand numbers) and issues the copy commands.
+int EnqueueStream(jxlt_context* ctx, int kind, const uint32_t* code_table) {
+  jxlt_context::PackSet& ps = ctx->pack[kind];
+  const size_t nsec = NumSections(ctx, kind);
+  const uint64_t rec_bound = kind == 1 ? ctx->h_group_off.p[nsec] : ctx->dc_records.cap / 3;
+  const size_t max_tiles = (size_t)(rec_bound / kPackTile) + nsec + 1;
+  int rc;
+  if (!ps.planned && (rc = EnqueuePlan(ctx, kind, rec_bound, ps.stream)) != JXLT_OK) return rc;
+  if (ps.plan_elsewhere) HIP_TRY(ctx, hipStreamWaitEvent(ps.stream, ps.plan_done, 0));
+  if ((rc = EnsurePinned(ctx, &ps.h_sec_byte_off, jxlt_context::PackSet::SizesWords(nsec))) != JXLT_OK) return rc;
+  if ((rc = EnsurePinned(ctx, &ps.h_code_table, 64 * 64)) != JXLT_OK) return rc;
+  memcpy(ps.h_code_table.p, code_table, 64 * 64 * sizeof(uint32_t));
+  {
+    const PublishSeg seg = {ps.h_code_table.p, ps.code_table.p, 64 * 64};
+    if ((rc = EnqueuePublish(ctx, ps.stream, &seg, 1, nullptr, nullptr, nullptr, 0)) != JXLT_OK) return rc;
+  }
+  const uint64_t blob_bound = rec_bound * 4 + nsec * 8 + 64;
+  if (ps.packed.cap < blob_bound && (rc = EnsureDevice(ctx, &ps.packed, blob_bound + blob_bound / 8)) != JXLT_OK)
+    return rc;
+  // (the tiles OR their first and last dwords into the blob: zero up to where the sections can reach with this code)
+  ps.zeroed_bytes = std::min<uint64_t>(SectionBytesBound(ctx, kind, code_table, nsec), ps.packed.cap);
+  HIP_TRY(ctx, hipMemsetAsync(ps.packed.p, 0, ps.zeroed_bytes, ps.stream));
+  static const int ac_launches = [] {
+    const char* e = getenv("JXLT_PACK_LAUNCHES");
+    return e ? std::max(1, std::min(atoi(e), (int)jxlt_context::PackSet::kMaxLaunches)) : 3;
+  }();
+  static const double growth = [] {
+    const char* e = getenv("JXLT_PACK_GROWTH");
+    return e ? std::max(1.0, atoi(e) / 100.0) : 2.0;
+  }();
+  const int want = kind == 0 ? 1 : ac_launches;
+  ps.launches = (int)std::min<size_t>((size_t)want, std::max<size_t>(1, max_tiles / 64));
+  for (int i = 0; i <= ps.launches; i++) {
+    const double share = growth > 1.0 ? (std::pow(growth, i) - 1.0) / (std::pow(growth, ps.launches) - 1.0)
+                                      : (double)i / ps.launches;
+    ps.launch_t0[i] = i == ps.launches ? (uint32_t)max_tiles : (uint32_t)((double)max_tiles * share);
+  }
+  ps.pack_seq++;
+  for (int i = 0; i < ps.launches; i++) {
+    PackTileArgs W = TileArgsOf(ctx, kind, nsec);
+    W.tile_first = ps.launch_t0[i];
+    W.tile_end = ps.launch_t0[i + 1];
+    W.launch_index = (uint32_t)i;
+    TraceMark(ctx, kind ? "AC stream launch start" : "DC stream launch start", ps.stream);
+    if (W.tile_end > W.tile_first)
+      hipLaunchKernelGGL(pack_tile_stream_kernel,
+                         dim3((unsigned)((W.tile_end - W.tile_first + kPackStreamTilesPerGroup - 1) / kPackStreamTilesPerGroup)),
+                         dim3(kPackThreads), 0, ps.stream, W);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ps.launch_done[i], ps.stream));
+    TraceMark(ctx, kind ? "AC stream launch done" : "DC stream launch done", ps.stream);
+    // (IN the stream: a one-workgroup kernel on another stream waits for a free slot behind the next launch's
+    // workgroups -- the first launch's word arrived when the last launch had ended)
+    const PublishSeg segs[2] = {{ps.sec_bits(nsec), ps.h_sec_bits(nsec), nsec},
+                                {ps.launch_sec_end.p, ps.h_launch_sec_end, (size_t)kPackMaxLaunches}};
+    if ((rc = EnqueuePublish(ctx, ps.stream, segs, 2, nullptr, nullptr, &ctx->mail.p->stream_seq[kind][i][0],
+                             ps.pack_seq)) != JXLT_OK)
+      return rc;
+  }
+  ps.planned = false;
+  ps.measured_sections = nsec;
+  ps.max_tiles = max_tiles;
+  ps.writes_queued = true;
+  ps.streamed = true;
+  ps.offsets_done_sections = 0;
+  ps.h_sec_byte_off.p[0] = 0;
+  ps.launches_seen = 0;
+  return JXLT_OK;
+}
+
+// Single pass: waits for launch `i` and extends the host's byte offsets over the sections that launch completed.
+// Returns the number of sections whose offsets are final in *sections_done.
+int StreamAdvance(jxlt_context* ctx, int kind, int upto_launch, uint32_t* sections_done) {
+  jxlt_context::PackSet& ps = ctx->pack[kind];
+  const size_t nsec = ps.measured_sections;
+  while (ps.launches_seen <= upto_launch) {
+    const int i = ps.launches_seen;
+    const int rcw = WaitWord(ctx, &ctx->mail.p->stream_seq[kind][i][0], ps.pack_seq, ps.stream, "section packing");
+    if (rcw != JXLT_OK) return rcw;
+    // (launch_sec_end[i]: 0xFFFFFFFF = the launch had no tile of its own)
+    const uint32_t filed = ps.h_launch_sec_end[i];
+    uint32_t s_hi = i + 1 == ps.launches ? (uint32_t)nsec
+                    : filed == 0xFFFFFFFFu ? ps.offsets_done_sections
+                                           : std::min<uint32_t>(filed, (uint32_t)nsec);
+    s_hi = std::max(s_hi, ps.offsets_done_sections);
+    uint64_t* off = ps.h_sec_byte_off.p;
+    const uint32_t* bits = ps.h_sec_bits(nsec);
+    for (uint32_t s = ps.offsets_done_sections; s < s_hi; s++) off[s + 1] = off[s] + ((bits[s] + 7u) >> 3);
+    ps.offsets_done_sections = s_hi;
+    ps.launches_seen++;
+  }
+  if (ps.offsets_done_sections == nsec && ps.h_sec_byte_off.p[nsec] > ps.zeroed_bytes) {
+    ctx->error = "section packing: the sections outgrew the bound computed from the histograms (internal error)";
+    return JXLT_ERR_INTERNAL;
+  }
+  if (sections_done) *sections_done = ps.offsets_done_sections;
+  return JXLT_OK;
 }
 
 // The writing pass of the sections of `kind` behind their measuring pass (asynchronous).
@@ -1777,15 +1997,21 @@ int EnqueueWrites(jxlt_context* ctx, int kind) {
     if (W.tile_end > W.tile_first)
       hipLaunchKernelGGL(pack_tile_write_kernel,
                          dim3((unsigned)((W.tile_end - W.tile_first + kPackWriteTilesPerGroup - 1) / kPackWriteTilesPerGroup)),
-                         dim3(kPackThreads), 0, ctx->stream, W);
+                         dim3(kPackThreads), 0, ps.stream, W);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ps.launch_done[i], ctx->stream));
-    TraceMark(ctx, kind ? "AC write launch done" : "DC write launch done", ctx->stream);
+    HIP_TRY(ctx, hipEventRecord(ps.launch_done[i], ps.stream));
+    TraceMark(ctx, kind ? "AC write launch done" : "DC write launch done", ps.stream);
   }
   return JXLT_OK;
 }
 
+bool SizesReady(const jxlt_context* ctx, int kind) {
+  const jxlt_context::PackSet& ps = ctx->pack[kind];
+  const volatile uint32_t* w = ps.streamed ? &ctx->mail.p->stream_seq[kind][ps.launches - 1][0] : &ctx->mail.p->sizes_seq[kind][0];
+  return *w == ps.pack_seq;
+}
 int WaitSizes(jxlt_context* ctx, int kind) {
+  if (ctx->pack[kind].streamed) return StreamAdvance(ctx, kind, ctx->pack[kind].launches - 1, nullptr);
   return WaitWord(ctx, &ctx->mail.p->sizes_seq[kind][0], ctx->pack[kind].pack_seq, ctx->aux_stream, "section measuring");
 }
 
@@ -1848,7 +2074,28 @@ int EnqueueDeliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_section
     const char* e = getenv("JXLT_DELIVER_KERNEL");
     return e && atoi(e) != 0;
   }();
-  if (!by_kernel) {
+  if (ps.streamed && runs == nullptr && !end_aligned) {
+    // single pass, sections back to back from dst on: behind every launch the sections it completed leave
+    const uint64_t* off = ps.h_sec_byte_off.p;
+    uint32_t s_lo = 0;
+    for (int i = 0; i < ps.launches; i++) {
+      uint32_t s_hi = 0;
+      const int rca = StreamAdvance(ctx, kind, i, &s_hi);
+      if (rca != JXLT_OK) return rca;
+      if (off[s_hi] > off[s_lo]) {
+        // (the launch is over -- the host has seen its word --: no event in front of the copy)
+        TraceMark(ctx, kind ? "AC copy start" : "DC copy start", out_stream);
+        HIP_TRY(ctx, hipMemcpyAsync(dst + off[s_lo], ps.packed.p + off[s_lo], off[s_hi] - off[s_lo], hipMemcpyDefault, out_stream));
+        TraceMark(ctx, kind ? "AC copy done" : "DC copy done", out_stream);
+      }
+      s_lo = s_hi;
+    }
+    const int rcp = EnqueuePublish(ctx, out_stream, nullptr, 0, nullptr, nullptr, &ctx->mail.p->delivered_seq[kind][0], ++ctx->deliver_seq[kind]);
+    if (rcp != JXLT_OK) return rcp;
+    ctx->deliveries_pending = true;
+    return JXLT_OK;
+  }
+  if (!by_kernel || ps.streamed) {
     const int rcs = WaitSizes(ctx, kind);
     if (rcs != JXLT_OK) return rcs;
     const uint64_t* off = ps.h_sec_byte_off.p;
@@ -1856,7 +2103,8 @@ int EnqueueDeliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_section
       const int64_t shift = end_aligned ? -(int64_t)off[nsec] : 0;
       uint32_t s_lo = 0;
       for (int i = 0; i < ps.launches; i++) {
-        const uint32_t s_hi = std::min<uint32_t>((uint32_t)nsec, std::max(s_lo, ps.h_launch_sec_end[i]));
+        const uint32_t s_hi = ps.streamed ? (i + 1 == ps.launches ? (uint32_t)nsec : s_lo)
+                                          : std::min<uint32_t>((uint32_t)nsec, std::max(s_lo, ps.h_launch_sec_end[i]));
         if (off[s_hi] > off[s_lo]) {
           HIP_TRY(ctx, hipStreamWaitEvent(out_stream, ps.launch_done[i], 0));
           TraceMark(ctx, kind ? "AC copy start" : "DC copy start", out_stream);
@@ -1926,6 +2174,19 @@ int EnqueueDeliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_section
   return JXLT_OK;
 }
 
+// The DC-group sections' hand-over that was asked for before their sizes had arrived: issued now if the sizes are
+// there (wait: whether or not -- waits for them).
+int IssueDeferred(jxlt_context* ctx, bool wait) {
+  jxlt_context::DeferredDeliver& d = ctx->deferred_dc;
+  if (!d.pending || ctx->in_deferred) return JXLT_OK;
+  if (!wait && !SizesReady(ctx, 0)) return JXLT_OK;
+  ctx->in_deferred = true;
+  d.pending = false;
+  const int rc = EnqueueDeliver(ctx, 0, d.dst, d.runs.empty() ? nullptr : d.runs.data(), d.runs.size(), d.end_aligned);
+  ctx->in_deferred = false;
+  return rc;
+}
+
 }  // namespace
 
 int jxlt_histograms_ready(jxlt_context* ctx) {
@@ -1950,12 +2211,16 @@ int jxlt_pack_begin(jxlt_context* ctx, int kind, const uint32_t* code_table) {
     const int rc0 = ResolveRootTableOverflow(ctx);
     if (rc0 != JXLT_OK) return rc0;
   }
+  if (kind == 0 && ctx->deferred_dc.pending) {
+    const int rcd = IssueDeferred(ctx, /*wait=*/true);
+    if (rcd != JXLT_OK) return rcd;
+  }
   if (ctx->deliveries_pending && ctx->pack[kind].measured_sections != 0) {
     // (a second pass of this kind within one encode overwrites the blob the first pass's hand-over reads)
     const int rcw = WaitDeliveries(ctx);
     if (rcw != JXLT_OK) return rcw;
   }
-  return EnqueueMeasure(ctx, kind, code_table);
+  return PackSinglePass(ctx) ? EnqueueStream(ctx, kind, code_table) : EnqueueMeasure(ctx, kind, code_table);
 }
 
 int jxlt_pack_sizes(jxlt_context* ctx, int kind, jxlt_packed_sections* out) {
@@ -1966,6 +2231,10 @@ int jxlt_pack_sizes(jxlt_context* ctx, int kind, jxlt_packed_sections* out) {
   }
   const int rc = WaitSizes(ctx, kind);
   if (rc != JXLT_OK) return rc;
+  if (kind == 0 && ctx->deferred_dc.pending) {
+    const int rcd = IssueDeferred(ctx, /*wait=*/true);
+    if (rcd != JXLT_OK) return rcd;
+  }
   FillMeasured(ctx, kind, out);
   return JXLT_OK;
 }
@@ -2001,6 +2270,28 @@ int jxlt_pack_deliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_sect
         return JXLT_ERR_INVALID_ARGUMENT;
       }
       dev_dst = static_cast<uint8_t*>(mapped);
+    }
+  }
+  if (kind == 0) {
+    if (ctx->deferred_dc.pending) {  // (a second hand-over of the kind: the first one first)
+      const int rcd = IssueDeferred(ctx, /*wait=*/true);
+      if (rcd != JXLT_OK) return rcd;
+    }
+    if (!SizesReady(ctx, 0)) {
+      jxlt_context::DeferredDeliver& d = ctx->deferred_dc;
+      d.pending = true;
+      d.dst = dev_dst;
+      d.end_aligned = end_aligned;
+      d.runs.assign(runs, runs + num_runs);
+      for (size_t r = 0; r < num_runs; r++) {
+        if ((size_t)runs[r].first_section + runs[r].num_sections > ctx->pack[0].measured_sections) {
+          d.pending = false;
+          ctx->error = "jxlt_pack_deliver: a run names sections the measuring pass did not see";
+          return JXLT_ERR_INVALID_ARGUMENT;
+        }
+      }
+      ctx->deliveries_pending = true;
+      return JXLT_OK;
     }
   }
   return EnqueueDeliver(ctx, kind, dev_dst, runs, num_runs, end_aligned);

@@ -72,7 +72,172 @@ struct PackTileArgs {
   uint32_t launches;
   uint32_t launch_t0[kPackMaxLaunches + 1];
   uint32_t* launch_sec_end;         // [launches]
+  // Single pass (pack_tile_stream_kernel, round 4): no measuring pass -- every tile learns where its bits start from
+  // the tiles in front of it while it runs (tile_state: a 64-bit word per tile, see PackTileState), the sections'
+  // bit counts are summed up by their tiles (sec_bits, zeroed by the plan).
+  unsigned long long* tile_state;   // [tiles]
+  unsigned long long* block_state;  // [tiles / 64 + 1]
+  uint32_t launch_index;            // which of the writing launches this is (its last tile files launch_sec_end)
+  uint32_t* lookback_stats;         // optional (JXLT_TRACE_EVENTS): [0] tiles [1] windows looked at [2] reloads of a window
+                                    // [3] most windows one tile looked at
 };
+
+// What the tiles of the single pass tell the tiles behind them.  Naturally aligned 64-bit words, each written by ONE
+// agent-scope store and read by agent-scope loads -- the data carries its own tag, so no flag, no fence (the
+// hand-off the CDNA guide calls "data-tagged granule").  Two levels, because what limits such a pass on this machine
+// is the round trip between workgroups on different XCDs (store visible behind the other XCD's L2 + load +
+// reduction, ~2.4 us measured): a tile can settle its position only once some tile inside its look-back window
+// knows its END, so with one level the ENDs advance one window per round trip -- 64 tiles per window gave 26 tiles
+// per us, 256 gave ~60, the writing pass of the two-pass form does 120.
+//   tile_state[t]   status (bits 63..62) 0 nothing yet | 1 SIZE: bits 31..0 = the tile's bit count, bit 61 = it is the
+//                   first tile of a section (its start is rounded up to a byte)
+//   block_state[b]  (block b = tiles 64 b ... 64 b + 63)  0 nothing yet | 1 what the block does to the position in
+//                   front of it (PackWindowAhead: bit 61 rounds, bits 60..31 pre, bits 30..0 rest), stored by the
+//                   block's last tile as soon as it has seen the sizes of the other 63 | 2 the block's END in the
+//                   blob, in bits (bits 61..0), stored by the same tile when it knows where it starts
+// A tile needs the SIZEs of the tiles in front of it in its own block (started within a microsecond of it) and, of the
+// blocks in front, the nearest END and what the blocks between do: 64 blocks = 4096 tiles per window, five times
+// what is in flight, so one round trip behind the slowest size settles every position -- no chain of ends.
+constexpr unsigned long long kPackStateSize = 1ull << 62, kPackStateEnd = 2ull << 62, kPackStateFirst = 1ull << 61;
+constexpr int kPackBlockTiles = 64;
+#if defined(__HIP_DEVICE_COMPILE__)
+JXLT_DI unsigned long long pack_state_load(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+JXLT_DI void pack_state_store(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+JXLT_DI void pack_state_wait() { __builtin_amdgcn_s_sleep(2); }
+#else
+JXLT_DI unsigned long long pack_state_load(const unsigned long long* p) { return *(const volatile unsigned long long*)p; }
+JXLT_DI void pack_state_store(unsigned long long* p, unsigned long long v) { *(volatile unsigned long long*)p = v; }
+JXLT_DI void pack_state_wait() {}
+#endif
+
+// What a run of tiles does to the position in front of it: p -> round8(p + pre) + rest (a section starts inside the
+// run), or p -> p + pre.  32 bits do for 64 tiles of < 2^17 bits and for 64 blocks of < 2^23.
+struct PackWindowAhead {
+  uint32_t pre, rest, rounds;
+};
+JXLT_DI PackWindowAhead pack_window_concat(const PackWindowAhead& a, const PackWindowAhead& b) {  // a (older), then b
+  PackWindowAhead r;
+  const bool ar = a.rounds != 0, br = b.rounds != 0;
+  r.rounds = a.rounds | b.rounds;
+  r.pre = ar ? a.pre : a.pre + b.pre;
+  const uint32_t joined = a.rest + b.pre;
+  r.rest = br ? (ar ? ((joined + 7u) & ~7u) + b.rest : b.rest) : (ar ? joined : 0u);
+  return r;
+}
+JXLT_DI unsigned long long pack_ahead_apply(const PackWindowAhead& a, unsigned long long p) {
+  return a.rounds ? ((p + a.pre + 7) & ~7ull) + a.rest : p + a.pre;
+}
+JXLT_DI PackWindowAhead pack_ahead_of_tile(uint32_t bits, bool first) {
+  PackWindowAhead one;
+  one.pre = first ? 0u : bits;
+  one.rest = first ? bits : 0u;
+  one.rounds = first ? 1u : 0u;
+  return one;
+}
+JXLT_DI PackWindowAhead pack_ahead_of_state(unsigned long long st, bool block) {
+  if (!block) return pack_ahead_of_tile((uint32_t)st, (st & kPackStateFirst) != 0);
+  PackWindowAhead one;
+  one.rounds = (uint32_t)(st >> 61) & 1u;
+  one.pre = (uint32_t)(st >> 31) & 0x3FFFFFFFu;
+  one.rest = (uint32_t)st & 0x7FFFFFFFu;
+  return one;
+}
+JXLT_DI unsigned long long pack_block_state_of(const PackWindowAhead& a) {
+  return kPackStateSize | ((unsigned long long)(a.rounds & 1u) << 61) | ((unsigned long long)a.pre << 31) | a.rest;
+}
+// Lanes 63 ... 0 hold runs, oldest in the highest lane: their concatenation, in every lane (six exchange steps; a
+// lane-by-lane loop took ~1.3 us per window).
+JXLT_DI PackWindowAhead pack_wave_concat(PackWindowAhead v, int lane) {
+  for (int d = 1; d < 64; d <<= 1) {
+    PackWindowAhead o;
+    o.pre = __shfl(v.pre, (lane + d) & 63);
+    o.rest = __shfl(v.rest, (lane + d) & 63);
+    o.rounds = __shfl(v.rounds, (lane + d) & 63);
+    if (lane + d >= 64) o.pre = o.rest = o.rounds = 0u;
+    v = pack_window_concat(o, v);
+  }
+  PackWindowAhead r;
+  r.pre = __shfl(v.pre, 0);
+  r.rest = __shfl(v.rest, 0);
+  r.rounds = __shfl(v.rounds, 0);
+  return r;
+}
+
+// The states of the tiles in front of `tile` in its own block: lane l holds tile - 1 - l (lanes beyond the block's
+// first tile: an empty size).  Requested right behind the tile's own size, looked at behind the packing.
+JXLT_DI unsigned long long pack_mates_load(const unsigned long long* tile_state, uint32_t tile, int lane) {
+  return lane < (int)(tile & (kPackBlockTiles - 1)) ? pack_state_load(tile_state + (tile - 1 - (uint32_t)lane)) : kPackStateSize;
+}
+// ... and of the 64 blocks in front of block `nearest + 1`: lane l holds block nearest - l (in front of block 0:
+// an END at position 0).
+JXLT_DI unsigned long long pack_blocks_load(const unsigned long long* block_state, long long nearest, int lane) {
+  const long long idx = nearest - lane;
+  return idx >= 0 ? pack_state_load(block_state + idx) : kPackStateEnd;
+}
+// What the tiles in front of `tile` in its block do to the block's start.  One wave, the same value in every lane;
+// waits for mates that have not said their size yet (they run beside this tile).
+JXLT_DI PackWindowAhead pack_block_mates(const unsigned long long* tile_state, uint32_t tile, int lane, unsigned long long loaded,
+                                         uint32_t* reloads) {
+  unsigned long long st = loaded;
+  while (__ballot((st >> 62) == 0) != 0) {
+    pack_state_wait();
+    st = pack_mates_load(tile_state, tile, lane);
+    ++*reloads;
+  }
+  return pack_wave_concat(pack_ahead_of_state(st, false), lane);
+}
+// Where block `block` starts: the nearest block in front that knows its END, moved through the blocks between.
+JXLT_DI unsigned long long pack_block_start(const unsigned long long* block_state, uint32_t block, int lane,
+                                            unsigned long long loaded, uint32_t* windows, uint32_t* reloads) {
+  PackWindowAhead ahead = {0u, 0u, 0u};  // the blocks between the one that knows its end and `block`
+  unsigned long long ahead_pre = 0, ahead_rest = 0;  // (64 bits across windows)
+  bool ahead_rounds = false;
+  unsigned long long base = 0;
+  unsigned long long st = loaded;
+  for (long long nearest = (long long)block - 1; nearest >= 0; nearest -= 64) {
+    if (nearest != (long long)block - 1) st = pack_blocks_load(block_state, nearest, lane);
+    int end_lane;
+    for (;;) {
+      const unsigned long long knows_end = __ballot((st >> 62) == 2);
+      const unsigned long long silent = __ballot((st >> 62) == 0);
+      end_lane = knows_end ? (int)__builtin_ctzll(knows_end) : 64;
+      if ((silent & (end_lane >= 64 ? ~0ull : ((1ull << end_lane) - 1))) == 0) break;
+      pack_state_wait();
+      st = pack_blocks_load(block_state, nearest, lane);
+      ++*reloads;
+    }
+    ++*windows;
+    PackWindowAhead v = {0u, 0u, 0u};
+    if (lane < end_lane) v = pack_ahead_of_state(st, true);
+    const PackWindowAhead w = pack_wave_concat(v, lane);
+    // w (older), then what has been gathered so far
+    if (!ahead_rounds) {
+      if (w.rounds) {
+        ahead_rounds = true;
+        ahead_rest = w.rest + ahead_pre;
+        ahead_pre = w.pre;
+      } else {
+        ahead_pre += w.pre;
+      }
+    } else if (w.rounds) {
+      ahead_rest = ((w.rest + ahead_pre + 7) & ~7ull) + ahead_rest;
+      ahead_pre = w.pre;
+    } else {
+      ahead_pre += w.pre;
+    }
+    if (end_lane < 64) {
+      const uint32_t elo = __shfl((uint32_t)st, end_lane), ehi = __shfl((uint32_t)(st >> 32), end_lane);
+      base = (((unsigned long long)ehi << 32) | elo) & ~(3ull << 62);
+      break;
+    }
+  }
+  (void)ahead;
+  return ahead_rounds ? ((base + ahead_pre + 7) & ~7ull) + ahead_rest : base + ahead_pre;
+}
 
 JXLT_DI uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 JXLT_DI uint32_t pack_section_records(const PackTileArgs& A, int sec) {
@@ -90,7 +255,16 @@ __global__ void __launch_bounds__(256) pack_tile_plan_kernel(const PackTileArgs 
   const uint32_t t0 = (uint32_t)A.tile_base[s], t1 = (uint32_t)A.tile_base[s + 1];
   const uint32_t cnt = pack_section_records(A, s);
   const uint64_t rec0 = A.sec_rec_offset[s];
+  if (A.tile_state) {  // (single pass: the tiles sum the section's bits up themselves)
+    A.sec_bits[s] = 0;
+    if (s == 0 && A.launch_sec_end)
+      for (int i = 0; i < kPackMaxLaunches; i++) A.launch_sec_end[i] = 0xFFFFFFFFu;  // "no tile in this launch"
+  }
   for (uint32_t t = t0; t < t1; t++) {
+    if (A.tile_state) {
+      A.tile_state[t] = 0;
+      if ((t & (kPackBlockTiles - 1)) == 0) A.block_state[t / kPackBlockTiles] = 0;
+    }
     const uint32_t before = (t - t0) * kPackTile;
     const uint32_t n = cnt - before < (uint32_t)kPackTile ? cnt - before : (uint32_t)kPackTile;
     PackTileInfo info;
@@ -343,14 +517,23 @@ __global__ void __launch_bounds__(256) pack_tile_finalize_kernel(const PackTileA
 // window at its bit position, window -> blob.  Two barriers per tile: the next tile's records go to the staging
 // area right behind the scan's barrier (every thread has its own records in registers by then), and the window is
 // cleared by the threads that store it.
-__global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const PackTileArgs A) {
+// kStream: the single pass -- the tile's bit position is not in its descriptor (there was no measuring pass) but
+// comes from the tiles in front of it (pack_tile_start), between the scan of the lengths and the packing; the blob
+// was zeroed as a whole before the launch (the dwords in which tiles meet are OR-ed into, as in the two-pass form).
+// (ONE tile per workgroup in the single pass: a workgroup's second tile says its size only when the first has its
+// position, and the first tile of the next workgroup waits for that size -- with two tiles per workgroup the whole
+// launch became one chain, 46 ms instead of 0.3 for the 16384^2 frame)
+constexpr int kPackStreamTilesPerGroup = 1;
+template <bool kStream, int kTilesPerGroup>
+JXLT_DI void pack_tile_write_body(const PackTileArgs& A) {
   __shared__ uint32_t table[64 * 64];
   __shared__ alignas(16) uint32_t stage[kPackTile * 3 / 4 + 4];
   __shared__ alignas(16) uint32_t window[kPackWindowWords];
   __shared__ uint32_t wave_sum[kPackThreads / 64];
+  __shared__ unsigned long long stream_start;
   const int tid = (int)threadIdx.x;
   const uint32_t ntiles_all = umin32((uint32_t)A.tile_base[A.nsec], A.tile_end);
-  const uint32_t first_tile = A.tile_first + blockIdx.x * kPackWriteTilesPerGroup;
+  const uint32_t first_tile = A.tile_first + blockIdx.x * kTilesPerGroup;
   if (first_tile >= ntiles_all) return;
   const uint32_t last_tile = ntiles_all - 1;
   // The descriptors of the first two tiles and the first tile's records are requested in front of the code table.
@@ -370,21 +553,18 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
   }
   for (int i = tid; i < kPackWindowWords; i += kPackThreads) window[i] = 0u;
   pack_store_tile(loads, (int)(cur.n_last & 0x7FFFFFFFu), stage, tid);
-  if (kPackWriteTilesPerGroup > 1 && first_tile + 1 < ntiles_all)
+  if (kTilesPerGroup > 1 && first_tile + 1 < ntiles_all)
     pack_request_tile(A.records + 3 * nxt.rec_first, (int)(nxt.n_last & 0x7FFFFFFFu), tid, &loads);
   uint32_t* outw = reinterpret_cast<uint32_t*>(A.out);
   __syncthreads();  // table, first tile's records, clear window
-  for (int kt = 0; kt < kPackWriteTilesPerGroup; kt++) {
+  for (int kt = 0; kt < kTilesPerGroup; kt++) {
     const uint32_t tile = first_tile + kt;
     if (tile >= ntiles_all) break;
-    const bool has_next = kt + 1 < kPackWriteTilesPerGroup && tile + 1 < ntiles_all;
-    const bool has_next2 = kt + 2 < kPackWriteTilesPerGroup && tile + 2 < ntiles_all;
+    const bool has_next = kt + 1 < kTilesPerGroup && tile + 1 < ntiles_all;
+    const bool has_next2 = kt + 2 < kTilesPerGroup && tile + 2 < ntiles_all;
     // (the descriptor of the tile after the next: needed behind the scan, requested here)
     const PackTileInfo nxt2 = A.tile_info[umin32(tile + 2, last_tile)];
     const int n = (int)(cur.n_last & 0x7FFFFFFFu);
-    const uint64_t pos_bit = cur.bit_pos;  // where this tile's bits start
-    const uint32_t lead = (uint32_t)(pos_bit & 31u);
-    const uint64_t word0 = pos_bit >> 5;
     // pass 1: length and bits of this thread's records
     PackThreadRecords recs;
     pack_load_thread_records(stage, tid, &recs);
@@ -414,6 +594,25 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
       if (w < (tid >> 6)) wave_base += v;
       tile_bits += v;
     }
+    uint64_t pos_bit = cur.bit_pos;  // where this tile's bits start
+    [[maybe_unused]] unsigned long long mates_loaded = 0, blocks_loaded = 0;
+    if constexpr (kStream) {
+      static_assert(kTilesPerGroup == 1, "the single pass packs one tile per workgroup");
+      // Wave 0 tells the tiles behind this one its size and asks for the states of the tiles in front of it in its
+      // block and of the blocks in front; the answers are looked at behind the packing (which does not need the
+      // position: the window is packed from bit 0 on and shifted to the position's low five bits when it is stored).
+      if (tid < 64) {
+        if (tid == 0) {
+          if (tile_bits) atomicAdd(&A.sec_bits[(uint32_t)cur.sec_start_bit], tile_bits);
+          pack_state_store(A.tile_state + tile, kPackStateSize | (cur.before == 0 ? kPackStateFirst : 0ull) | tile_bits);
+        }
+        mates_loaded = pack_mates_load(A.tile_state, tile, tid);
+        blocks_loaded = pack_blocks_load(A.block_state, (long long)(tile / kPackBlockTiles) - 1, tid);
+      }
+      pos_bit = 0;
+    }
+    const uint32_t lead = (uint32_t)(pos_bit & 31u);
+    const uint64_t word0 = pos_bit >> 5;
     // pass 2: the thread's records concatenated in a register pair, completed dwords OR-ed into the window
     // (LDS atomics are the expensive part: a record at a time -- 16 per thread -- made the kernel 45 % slower)
 #ifdef JXLT_PACK_RECORD_ATOMICS
@@ -447,6 +646,51 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
       if (fill) atomicOr(&window[w], (uint32_t)acc);
     }
 #endif
+    if constexpr (kStream) {
+      if (tid < 64) {
+        const uint32_t sec = (uint32_t)cur.sec_start_bit;  // (the plan's section index: nothing has replaced it)
+        const bool first = cur.before == 0;
+        const uint32_t block = tile / kPackBlockTiles;
+        const bool closes_block = (tile & (kPackBlockTiles - 1)) == kPackBlockTiles - 1;
+        uint32_t windows = 0, reloads = 0;
+        const PackWindowAhead mates = pack_block_mates(A.tile_state, tile, tid, mates_loaded, &reloads);
+        // (the block's last tile says what the block does to a position as soon as it can: the blocks behind do not
+        // have to wait until it knows where it starts)
+        if (closes_block && tid == 0)
+          pack_state_store(A.block_state + block, pack_block_state_of(pack_window_concat(mates, pack_ahead_of_tile(tile_bits, first))));
+        const unsigned long long block_start = pack_block_start(A.block_state, block, tid, blocks_loaded, &windows, &reloads);
+        unsigned long long start = pack_ahead_apply(mates, block_start);
+        if (first) start = (start + 7) & ~7ull;
+        if (tid == 0) {
+          if (closes_block) pack_state_store(A.block_state + block, kPackStateEnd | (start + tile_bits));
+          stream_start = start;
+          // (the launch's last tile says which sections the launch has completed)
+          if (tile == last_tile && A.launch_sec_end) A.launch_sec_end[A.launch_index] = (cur.n_last >> 31) ? sec + 1 : sec;
+          if (A.lookback_stats) {
+            atomicAdd(&A.lookback_stats[0], 1u);
+            atomicAdd(&A.lookback_stats[1], windows);
+            atomicAdd(&A.lookback_stats[2], reloads);
+            atomicMax(&A.lookback_stats[3], windows);
+          }
+        }
+      }
+      __syncthreads();  // window complete, position known
+      const unsigned long long start = stream_start;
+      const uint32_t shift = (uint32_t)(start & 31u);
+      const uint64_t first_word = start >> 5;
+      const uint32_t end_bits = shift + tile_bits;
+      const uint32_t nwords = (end_bits + 31) >> 5;
+      for (uint32_t i = tid; i < nwords; i += kPackThreads) {
+        const uint32_t hi = window[i], lo = i ? window[i - 1] : 0u;
+        const uint32_t v = shift ? (hi << shift) | (lo >> (32u - shift)) : hi;
+        if (i == 0 || (i + 1 == nwords && (end_bits & 31u) != 0)) {
+          if (v) atomicOr(&outw[first_word + i], v);
+        } else {
+          outw[first_word + i] = v;
+        }
+      }
+      break;  // (one tile per workgroup: nothing to clear, nothing to hand on)
+    }
     __syncthreads();  // window complete; next tile's records staged
     // stores: the dwords the tile covers completely with plain stores; its first and its last dword, which it
     // may share with its neighbours (tiles of the same section, or the byte-aligned neighbour sections), are
@@ -466,6 +710,8 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const Pac
     nxt = nxt2;
   }
 }
+__global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const PackTileArgs A) { pack_tile_write_body<false, kPackWriteTilesPerGroup>(A); }
+__global__ void __launch_bounds__(kPackThreads) pack_tile_stream_kernel(const PackTileArgs A) { pack_tile_write_body<true, kPackStreamTilesPerGroup>(A); }
 
 // ---------------------------------------------------------------------------
 // Hand-over to the host without the host (round 4).

@@ -273,10 +273,8 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   size_t e0 = 0;       // where the DC-group sections end and ACGlobal starts
   uint8_t* buf = nullptr;
   bool dc_begun = false;
-  // (the hand-over of a kind waits for that kind's sizes -- the copy commands need them --, and the DC-group
-  // sections' sizes arrive behind token_kernel: their hand-over is issued when the AC pass has been queued, not
-  // before the AC code is built)
-  bool dc_deliver_owed = false;
+  // (the DC-group sections' hand-over is asked for at once: the library issues the copy commands when the sections'
+  // sizes arrive -- from inside its next wait, e.g. the one for the AC histogram -- and does not block for them)
   const auto begin_dc = [&]() -> bool {
     // (the DC code, and with it globals.dc_global, is complete here)
     dc_shared = dc_shared_now;
@@ -285,7 +283,10 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
       return false;
     }
     dc_begun = true;
-    dc_deliver_owed = true;
+    if (jxlt_pack_deliver(ctx, 0, buf + e0, nullptr, 0, /*end_aligned=*/1) != JXLT_OK) {
+      fprintf(stderr, "jxl_tiny_amd: section hand-over failed: %s\n", jxlt_last_error(ctx));
+      return false;
+    }
     return true;
   };
   if (!ac_first) {
@@ -326,12 +327,10 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
     return false;
   }
   if (jxlt_pack_begin(ctx, 1, ac_table.data()) != JXLT_OK ||
-      (dc_deliver_owed && jxlt_pack_deliver(ctx, 0, buf + e0, nullptr, 0, /*end_aligned=*/1) != JXLT_OK) ||
       jxlt_pack_deliver(ctx, 1, buf + e0 + acg_bytes, nullptr, 0, /*end_aligned=*/0) != JXLT_OK) {
     fprintf(stderr, "jxl_tiny_amd: section packing failed: %s\n", jxlt_last_error(ctx));
     return false;
   }
-  dc_deliver_owed = false;
   memcpy(buf + e0, globals.ac_global.data(), acg_bytes);
   if (trace)
     fprintf(stderr, "jxlt trace: dc histogram after %.2f ms, %s first | ac histogram after %.2f ms, ac code %.3f ms\n",
@@ -339,10 +338,6 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   if (!dc_begun) {
     worker->Wait();
     if (!begin_dc()) return false;
-    if (dc_deliver_owed && jxlt_pack_deliver(ctx, 0, buf + e0, nullptr, 0, /*end_aligned=*/1) != JXLT_OK) {
-      fprintf(stderr, "jxl_tiny_amd: section hand-over failed: %s\n", jxlt_last_error(ctx));
-      return false;
-    }
   }
   // The sizes of both kinds (all the TOC needs) arrive while the sections are being written and handed over.
   jxlt_packed_sections dcm, acm;

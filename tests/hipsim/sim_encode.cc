@@ -348,6 +348,83 @@ __attribute__((visibility("default"))) int sim_pack_deliver(const uint8_t* recor
   return counter == 0 ? 0 : 1;  // (the last workgroup resets the completion counter)
 }
 
+// The look-back of the single pass on its own: one wave asks for the start of `tile` given the states of the tiles
+// in front of it in its block and of the blocks in front (which the caller makes up).
+namespace jxlt_dev {
+__global__ void pack_lookback_probe_kernel(const unsigned long long* tile_state, const unsigned long long* block_state, uint32_t tile,
+                                           int first, unsigned long long* out) {
+  const int lane = (int)threadIdx.x;
+  uint32_t windows = 0, reloads = 0;
+  const PackWindowAhead mates = pack_block_mates(tile_state, tile, lane, pack_mates_load(tile_state, tile, lane), &reloads);
+  const uint32_t block = tile / kPackBlockTiles;
+  const unsigned long long block_start =
+      pack_block_start(block_state, block, lane, pack_blocks_load(block_state, (long long)block - 1, lane), &windows, &reloads);
+  unsigned long long start = pack_ahead_apply(mates, block_start);
+  if (first) start = (start + 7) & ~7ull;
+  out[lane] = start;
+  // what the block does to a position, as its last tile would say it (the tile's own size is made up: 5 bits)
+  out[64 + lane] = pack_block_state_of(pack_window_concat(mates, pack_ahead_of_tile(5u, first != 0)));
+}
+}  // namespace jxlt_dev
+__attribute__((visibility("default"))) int sim_pack_lookback(const unsigned long long* tile_state, const unsigned long long* block_state,
+                                                              uint32_t tile, int first, unsigned long long* out128) {
+  hipsim::launch(jxlt_dev::pack_lookback_probe_kernel, dim3(1), dim3(64), tile_state, block_state, tile, first, out128);
+  return 0;
+}
+
+// The single pass (pack_tile_stream_kernel, EnqueueStream of jxlt_capi.hip): plan (which also clears the tiles' states
+// and the sections' bit counts), then the writing launches over growing shares of an upper bound of the tile count
+// -- no measuring pass, every tile takes its position from the tiles in front of it.  `blob` must arrive zeroed
+// (the product clears it with a memset in front of the first launch); out_bits: the sections' bit counts;
+// out_launch_end: which sections every launch has completed.
+__attribute__((visibility("default"))) int sim_pack_stream(const uint8_t* records, const uint64_t* sec_rec_offset, int nsec,
+                                                            const uint32_t* code_table, int nlaunch, uint8_t* blob,
+                                                            uint32_t* out_bits, uint32_t* out_launch_end) {
+  const uint64_t total = sec_rec_offset[nsec];
+  const size_t max_tiles = total / kPackTile + nsec + 1 + 37;
+  std::vector<uint32_t> sec_bytes(nsec), sec_tiles(nsec);
+  std::vector<PackTileInfo> tile_info(max_tiles);
+  std::vector<uint64_t> tile_base(nsec + 1), sec_off(nsec + 1, 0);
+  std::vector<unsigned long long> tile_state(max_tiles, 0xDEADDEADDEADDEADull);
+  std::vector<unsigned long long> block_state(max_tiles / kPackBlockTiles + 2, 0xDEADDEADDEADDEADull);
+  for (int i = 0; i < nsec; i++) out_bits[i] = 0xDEADu;
+  PackTileArgs P = {};
+  P.records = records;
+  P.sec_rec_offset = sec_rec_offset;
+  P.nsec = nsec;
+  P.code_table = code_table;
+  P.sec_tiles = sec_tiles.data();
+  P.tile_base = tile_base.data();
+  P.tile_info = tile_info.data();
+  P.sec_bits = out_bits;
+  P.sec_bytes = sec_bytes.data();
+  P.sec_byte_offset = sec_off.data();
+  P.out = blob;
+  P.tile_end = 0xFFFFFFFFu;
+  P.launches = (uint32_t)nlaunch;
+  for (int i = 0; i <= nlaunch; i++)
+    P.launch_t0[i] = i == nlaunch ? (uint32_t)max_tiles
+                                  : (uint32_t)((double)max_tiles * ((double)((1 << i) - 1) / (double)((1 << nlaunch) - 1)));
+  P.launch_sec_end = out_launch_end;
+  P.tile_state = tile_state.data();
+  P.block_state = block_state.data();
+  const unsigned sec_blocks = (unsigned)((nsec + 255) / 256);
+  hipsim::launch(pack_tile_count_kernel, dim3(sec_blocks), dim3(256), P);
+  hipsim::launch(group_scan_kernel, dim3(1), dim3(kScanThreads), (const uint32_t*)sec_tiles.data(), tile_base.data(), nsec);
+  hipsim::launch(pack_tile_plan_kernel, dim3(sec_blocks), dim3(256), P);
+  for (int c = 0; c < nlaunch; c++) {
+    PackTileArgs W = P;
+    W.tile_first = P.launch_t0[c];
+    W.tile_end = P.launch_t0[c + 1];
+    W.launch_index = (uint32_t)c;
+    if (W.tile_end > W.tile_first)
+      hipsim::launch(pack_tile_stream_kernel,
+                     dim3((unsigned)((W.tile_end - W.tile_first + kPackStreamTilesPerGroup - 1) / kPackStreamTilesPerGroup)),
+                     dim3(kPackThreads), W);
+  }
+  return 0;
+}
+
 // publish_kernel: segments of dwords + a 64-bit word + the sequence word
 __attribute__((visibility("default"))) void sim_publish(const uint32_t* a, uint32_t* da, uint32_t na, const uint32_t* b,
                                                          uint32_t* db, uint32_t nb, const unsigned long long* s64,

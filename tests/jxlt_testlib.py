@@ -226,6 +226,9 @@ def _sim_lib(tiny_root_table=False):
                                          C.c_int, C.c_void_p, C.c_void_p]
         _sim.sim_pack_deliver.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                           C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _sim.sim_pack_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]
+        _sim.sim_pack_lookback.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         _sim.sim_publish.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         _sim.sim_publish.restype = None
@@ -293,6 +296,41 @@ def sim_pack_sections(sections, table, misalign=0, nlaunch=1):
     assert np.isin(out[base + total:base + total + tail], (0, 0xCD)).all(), "stray stores"
     body = out[base:base + total]
     return [(body[int(out_off[i]):int(out_off[i + 1])].tobytes(), int(out_bits[i])) for i in range(len(sections))]
+
+
+def sim_pack_stream(sections, table, nlaunch=3):
+    """The single pass on the CPU execution model: plan, then pack_tile_stream_kernel in `nlaunch` growing shares into a
+    zeroed blob.  Returns ([(section bytes, section bits)], sections completed behind every launch); checks that
+    nothing behind the last section (but the rest of its last dword) was written."""
+    L = _sim_lib()
+    rec = np.frombuffer(b"".join(sections) + b"\0\0\0\0", np.uint8).copy()
+    offs = np.zeros(len(sections) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(x) // 3 for x in sections])
+    table = np.ascontiguousarray(table, np.uint32)
+    blob = np.zeros(4 * int(offs[-1]) + 8 * len(sections) + 256, np.uint8)
+    bits = np.zeros(len(sections), np.uint32)
+    launch_end = np.full(8, 0xABCD, np.uint32)
+    assert L.sim_pack_stream(rec.ctypes.data, offs.ctypes.data, len(sections), table.ctypes.data, nlaunch, blob.ctypes.data,
+                             bits.ctypes.data, launch_end.ctypes.data) == 0
+    nbytes = (bits.astype(np.int64) + 7) // 8
+    start = np.concatenate([[0], np.cumsum(nbytes)])
+    assert not blob[(int(start[-1]) + 3) // 4 * 4:].any(), "stray stores behind the last section"
+    out = [(blob[int(start[i]):int(start[i + 1])].tobytes(), int(bits[i])) for i in range(len(sections))]
+    return out, [int(v) for v in launch_end[:nlaunch]]
+
+
+def sim_pack_lookback(tile_states, block_states, tile, first):
+    """The look-back of the single pass on the CPU execution model: the bit position at which `tile` starts, given
+    the 64-bit states of the tiles in front of it in its block and of the blocks in front.  Returns (start, what the
+    tile's block does to a position if the tile were its last and 5 bits long, as the 64-bit block state); every lane
+    of the wave must have come up with the same."""
+    L = _sim_lib()
+    ts = np.ascontiguousarray(tile_states, np.uint64)
+    bs = np.ascontiguousarray(block_states, np.uint64)
+    out = np.zeros(128, np.uint64)
+    assert L.sim_pack_lookback(ts.ctypes.data, bs.ctypes.data, tile, int(first), out.ctypes.data) == 0
+    assert (out[:64] == out[0]).all() and (out[64:] == out[64]).all()
+    return int(out[0]), int(out[64])
 
 
 def sim_pack_deliver(sections, table, nlaunch=3, mode=0, shift=0, runs=None, grid=5):

@@ -672,6 +672,46 @@ def test_device_memory_of_a_destroyed_context_serves_the_next_one(built, enc):
     assert built.release_cached_memory() == 0
 
 
+def test_every_form_of_the_packing_stage_gives_the_oracles_bytes(built):
+    """The packing stage has two forms -- one pass, in which every tile takes its bit position from the tiles in front
+    of it (frames of up to 1024 groups), and measure + write (larger frames) -- and packs the DC-group sections on
+    the main stream or on one of their own (above 1024 groups).  The size rules keep half of those combinations away
+    from frames the suite can afford an oracle run for: here every combination is forced (JXLT_PACK_TWO_PASS,
+    JXLT_DC_PACK_STREAM) on the same frames, in child processes, and must give the oracle's file -- several
+    distances, a frame with ragged edges, one with more than one DC group, repeated encodes on one context."""
+    import os
+    import sys
+    script = """
+import sys, hashlib
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+import __graft_entry__ as G
+import jxlt_testlib as T
+pkg = G.load_package()
+out = []
+for (w, h, d) in [(1000, 700, 1.0), (2304, 2100, 2.5), (4200, 520, 0.6)]:
+    planes = T.to_planes(T.synthetic_image(w, h, seed=w + h))
+    e = pkg.Encoder(0); e.upload(planes)
+    for rep in range(3):
+        data = bytes(e.encode_resident(d))
+        out.append(hashlib.sha256(data).hexdigest())
+    e.close()
+print("RESULT", " ".join(out))
+""" % (str(T.ROOT), str(T.ROOT / "tests"))
+    want = []
+    for (w, h, d) in [(1000, 700, 1.0), (2304, 2100, 2.5), (4200, 520, 0.6)]:
+        import hashlib
+        ref = T.oracle_encode_file(T.to_planes(T.synthetic_image(w, h, seed=w + h)), d)[0]
+        want += [hashlib.sha256(bytes(ref)).hexdigest()] * 3
+    for two_pass in ("0", "1"):
+        for dc_stream in ("0", "1"):
+            env = dict(os.environ, JXLT_PACK_TWO_PASS=two_pass, JXLT_DC_PACK_STREAM=dc_stream)
+            r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=900)
+            line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+            assert line, r.stdout + r.stderr
+            assert line[0].split()[1:] == want, (two_pass, dc_stream)
+
+
 def test_nothing_is_kept_beyond_the_last_context_unless_asked_for(built):
     """Default: when the LAST context of a device is destroyed, the blocks kept for its successors go back to the
     runtime (a co-resident allocator sees the memory again without anybody calling jxlt_release_cached_memory, ADVICE

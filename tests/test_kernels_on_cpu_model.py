@@ -4,6 +4,7 @@ with the oracle for every intermediate and output.  This is test infrastructure
 only -- the product never runs on the CPU -- and lets kernel changes be checked
 in a container without a GPU; the `-m gpu` tests repeat the comparison on a real
 MI355X through the C ABI."""
+import numpy as np
 import pytest
 
 import jxlt_testlib as T
@@ -123,6 +124,102 @@ def test_hand_over_kernel_delivers_every_section_once(built, sizes, nlaunch):
         assert int(off[-1]) == len(want_bytes)
         assert dst[start:start + len(want_bytes)].tobytes() == want_bytes
         assert (dst[:start] == 0xCD).all() and (dst[start + len(want_bytes):] == 0xCD).all(), "stray stores"
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_single_pass_look_back_composes_sizes_and_section_starts(built, seed):
+    """The look-back of the single pass: where a tile starts follows from the SIZES of the tiles in front of it in
+    its block of 64, the nearest block in front that knows its END and what the blocks between do to a position -- a
+    size moves the position on, a tile that starts a section rounds it up to a byte first.  (On the CPU model
+    workgroups run one after the other, so inside sim_pack_stream every tile finds the END of the block right in
+    front of it; here the states are made up: ends at any distance -- in the first window of 64 blocks, windows
+    back, none at all (block 0's position) --, section starts anywhere, states behind the nearest END holding junk.)"""
+    rng = np.random.default_rng(7000 + seed)
+    SIZE, END, FIRST = 1 << 62, 2 << 62, 1 << 61
+    ntiles = int(rng.choice([1, 2, 5, 63, 64, 65, 255, 256, 257, 300, 4096 + 70, 64 * 150 + 3]))
+    bits = rng.integers(0, 1 << 17, ntiles)
+    bits[rng.random(ntiles) < 0.1] = 0
+    first = rng.random(ntiles) < [0.0, 0.03, 0.3, 1.0][seed % 4]
+    first[0] = True
+    # the truth: positions tile by tile
+    start = np.zeros(ntiles + 1, np.uint64)
+    pos = 0
+    for t in range(ntiles):
+        if first[t]:
+            pos = (pos + 7) & ~7
+        start[t] = pos
+        pos += int(bits[t])
+    start[ntiles] = pos
+
+    def run_of(t0, t1):  # what tiles t0 .. t1 - 1 do to a position: (rounds, pre, rest)
+        rounds, pre, rest = 0, 0, 0
+        for t in range(t0, t1):
+            if first[t]:
+                rest = ((rest + 7) & ~7) + int(bits[t]) if rounds else int(bits[t])
+                rounds = 1
+            elif rounds:
+                rest += int(bits[t])
+            else:
+                pre += int(bits[t])
+        return rounds, pre, rest
+
+    nblocks = (ntiles + 63) // 64
+    for trial in range(6):
+        tile = ntiles - 1 if trial == 0 else int(rng.integers(0, ntiles))
+        block = tile // 64
+        # the nearest block that knows its end: none (trial 1), or `gap` blocks in front
+        gap = block + 1 if trial == 1 else int(rng.integers(1, block + 2))
+        tile_states = np.zeros(ntiles + 1, np.uint64)
+        for t in range(ntiles):
+            # (only the tiles in front of `tile` in its own block are looked at: everything else is junk)
+            if block * 64 <= t < tile:
+                tile_states[t] = SIZE | (FIRST if first[t] else 0) | int(bits[t])
+            else:
+                tile_states[t] = int(rng.choice([0, SIZE | 12345, SIZE | FIRST | 7]))
+        block_states = np.zeros(nblocks + 1, np.uint64)
+        for b in range(nblocks):
+            if b == block - gap:
+                block_states[b] = END | int(start[64 * b + 64])
+            elif block - gap < b < block:
+                rounds, pre, rest = run_of(64 * b, 64 * b + 64)
+                block_states[b] = SIZE | (rounds << 61) | (pre << 31) | rest
+            else:
+                block_states[b] = int(rng.choice([0, SIZE | 12345, END | 99, SIZE | FIRST | 7]))
+        got, whole = T.sim_pack_lookback(tile_states, block_states, tile, bool(first[tile]))
+        assert got == int(start[tile]), (ntiles, tile, gap)
+        # ... and what the block would tell the blocks behind it if this tile closed it with 5 bits of its own
+        rounds, pre, rest = run_of(64 * block, tile)
+        if first[tile]:
+            rest = ((rest + 7) & ~7) + 5 if rounds else 5
+            rounds = 1
+        elif rounds:
+            rest += 5
+        else:
+            pre += 5
+        assert whole == SIZE | (rounds << 61) | (pre << 31) | rest
+
+
+@pytest.mark.parametrize("sizes", [[0], [7], [5, 0, 17], [4095, 4096, 4097, 1], [0, 0, 0], [20000, 3, 9000, 0, 12345],
+                                   [600] * 23, [1] * 300, [0, 4096 * 3, 0, 0, 1]])
+@pytest.mark.parametrize("nlaunch", [1, 3, 4])
+def test_single_pass_packing_matches_reference_packer(built, sizes, nlaunch):
+    """pack_tile_stream_kernel (round 4): no measuring pass -- a tile takes its bit position from the tiles in front
+    of it (sizes of the ones that do not know their end yet, byte rounding where a section begins) and the sections'
+    bit counts are summed by their tiles.  Sections of every size incl. empty ones and one-record ones (many section
+    starts inside one look-back window), short codes (tiles of a few bits), every launch split."""
+    import numpy as np
+    rng = np.random.default_rng(len(sizes) * 77 + sum(sizes) + nlaunch)
+    for table in (_random_code_table(rng), ((np.ones(4096, np.int64) << 16) | rng.integers(0, 2, size=4096)).astype("uint32")):
+        sections = _random_sections(rng, sizes)
+        want = T.pack_sections_python(sections, table)
+        got, launch_end = T.sim_pack_stream(sections, table, nlaunch=nlaunch)
+        assert got == want
+        # the sections every launch completes: non-decreasing, and the last launch that has tiles completes them all
+        ends = [e for e in launch_end if e != 0xFFFFFFFF]
+        assert ends == sorted(ends) and all(e <= len(sizes) for e in ends)
+        if sum(sizes):
+            last_nonempty = max(i for i, n in enumerate(sizes) if n)
+            assert ends and ends[-1] == last_nonempty + 1
 
 
 def test_hand_over_kernel_in_runs(built):
