@@ -185,15 +185,19 @@ int jxlt_histograms_ready(jxlt_context* ctx);
  * (code_table[ctx * 64 + symbol] = (depth << 16) | bits), kind 0 = DC-group sections (the raw-record form of
  * WriteDCGroup, enc_frame.cc:536-570), kind 1 = AC-group sections -- in three calls:
  *
- *   jxlt_pack_begin(kind, table)    asynchronous: measures every section of the kind, lays them out back to back
- *                                   (byte aligned, enc_frame.cc:804-816) and entropy-codes them into a device blob
- *   jxlt_pack_sizes(kind, &out)     waits for the measuring pass: byte offsets + exact bit counts of the sections
+ *   jxlt_pack_begin(kind, table)    asynchronous: lays the sections of the kind out back to back (byte aligned,
+ *                                   enc_frame.cc:804-816) and entropy-codes them into a device blob -- in one pass
+ *                                   (frames of up to 1024 groups) or a measuring and a writing pass
+ *   jxlt_pack_sizes(kind, &out)     waits until the sizes are known: byte offsets + exact bit counts of the sections
  *                                   (all the TOC needs, enc_frame.cc:572-595); out->bytes is NULL
  *   jxlt_pack_deliver(kind, dst..)  asynchronous: the sections leave the device for `dst` -- page-locked host
  *                                   memory (jxlt_output_buffer / jxlt_pinned_alloc / jxlt_pinned_register) or
- *                                   device memory -- written there by the device itself, range by range while later
- *                                   sections are still being coded.  The byte ranges are read on the device, so the
- *                                   call need not wait for jxlt_pack_sizes.  Complete after jxlt_synchronize.
+ *                                   device memory -- range by range while later sections are still being coded.
+ *                                   Kind 1 waits for the sizes of the sections it sends (a fraction of a millisecond
+ *                                   behind jxlt_pack_begin); kind 0 never waits: if the DC-group sections' sizes
+ *                                   have not arrived, the library issues the copies itself when they do (from its
+ *                                   next wait, at the latest in jxlt_pack_sizes / jxlt_synchronize).  Complete
+ *                                   after jxlt_synchronize.
  *
  * jxlt_pack_deliver places all sections of the kind back to back STARTING at dst (end_aligned 0) or ENDING at dst
  * (end_aligned 1: for a kind whose total size the caller does not know yet -- the DC-group sections are set against

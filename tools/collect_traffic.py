@@ -13,6 +13,7 @@ import collections
 import csv
 import json
 import sys
+from pathlib import Path
 
 
 def per_kernel(path, per=1):
@@ -58,6 +59,10 @@ def main():
     # (bench.py's roofline.traffic reads "tile_kernel": the variant the product launches)
     if "tile12_kernel" in res["kernels"] and "tile_kernel" not in res["kernels"]:
         res["kernels"]["tile_kernel"] = dict(res["kernels"]["tile12_kernel"], variant="tile12_kernel (12 waves)")
+    # (bench.py's roofline.traffic_profile compares this with the sources it runs)
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+    res["kernel_source_sha16"] = bench.kernel_source_sha16()
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 
