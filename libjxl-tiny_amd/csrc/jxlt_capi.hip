@@ -1723,6 +1723,7 @@ PackTileArgs TileArgsOf(jxlt_context* ctx, int kind, size_t nsec) {
   P.launches = (uint32_t)ps.launches;
   for (int i = 0; i <= ps.launches && i <= kPackMaxLaunches; i++) P.launch_t0[i] = ps.launch_t0[i];
   P.launch_sec_end = ps.launch_sec_end.p;
+  P.tile_ticket = ps.launch_sec_end.p ? ps.launch_sec_end.p + kPackMaxLaunches : nullptr;
   P.tile_state = PackSinglePass(ctx) ? ps.tile_state.p : nullptr;
   P.block_state = PackSinglePass(ctx) && ps.tile_state.p ? ps.tile_state.p + ps.state_tiles : nullptr;
   static const bool stats_on = [] {
@@ -1755,7 +1756,7 @@ int EnqueuePlan(jxlt_context* ctx, int kind, uint64_t rec_bound, hipStream_t str
   ENSURE(tile_base, nsec + 1);
   ENSURE(tile_bits, max_tiles);
   ENSURE(tile_info, max_tiles);
-  ENSURE(launch_sec_end, kPackMaxLaunches);
+  ENSURE(launch_sec_end, 2 * kPackMaxLaunches);  // (+ the single pass's tickets)
   if (PackSinglePass(ctx)) {  // (tile states, block states behind them)
     ENSURE(tile_state, max_tiles + max_tiles / kPackBlockTiles + 2);
     ps.state_tiles = max_tiles;

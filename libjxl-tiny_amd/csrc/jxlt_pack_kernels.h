@@ -77,6 +77,7 @@ struct PackTileArgs {
   // bit counts are summed up by their tiles (sec_bits, zeroed by the plan).
   unsigned long long* tile_state;   // [tiles]
   unsigned long long* block_state;  // [tiles / 64 + 1]
+  uint32_t* tile_ticket;            // [kPackMaxLaunches]: how many workgroups of a launch have started (zeroed by the plan)
   uint32_t launch_index;            // which of the writing launches this is (its last tile files launch_sec_end)
   uint32_t* lookback_stats;         // optional (JXLT_TRACE_EVENTS): [0] tiles [1] windows looked at [2] reloads of a window
                                     // [3] most windows one tile looked at
@@ -258,7 +259,10 @@ __global__ void __launch_bounds__(256) pack_tile_plan_kernel(const PackTileArgs 
   if (A.tile_state) {  // (single pass: the tiles sum the section's bits up themselves)
     A.sec_bits[s] = 0;
     if (s == 0 && A.launch_sec_end)
-      for (int i = 0; i < kPackMaxLaunches; i++) A.launch_sec_end[i] = 0xFFFFFFFFu;  // "no tile in this launch"
+      for (int i = 0; i < kPackMaxLaunches; i++) {
+        A.launch_sec_end[i] = 0xFFFFFFFFu;  // "no tile in this launch"
+        A.tile_ticket[i] = 0;
+      }
   }
   for (uint32_t t = t0; t < t1; t++) {
     if (A.tile_state) {
@@ -533,15 +537,41 @@ JXLT_DI void pack_tile_write_body(const PackTileArgs& A) {
   __shared__ unsigned long long stream_start;
   const int tid = (int)threadIdx.x;
   const uint32_t ntiles_all = umin32((uint32_t)A.tile_base[A.nsec], A.tile_end);
-  const uint32_t first_tile = A.tile_first + blockIdx.x * kTilesPerGroup;
-  if (first_tile >= ntiles_all) return;
-  const uint32_t last_tile = ntiles_all - 1;
-  // The descriptors of the first two tiles and the first tile's records are requested in front of the code table.
-  PackTileInfo cur = A.tile_info[first_tile];
-  PackTileInfo nxt = A.tile_info[umin32(first_tile + 1, last_tile)];
+  // Which tile: the two-pass form's writing pass takes them by workgroup index.  The single pass hands them out in the
+  // order in which workgroups START (a ticket per launch): a tile waits for the tiles in front of it, and with
+  // tickets those belong to workgroups that are running or done, whatever else shares the device.  By workgroup
+  // index a tile can wait for one that has not been dispatched because every slot of its XCD is held by waiting tiles
+  // of ANOTHER context's single pass, whose own predecessors wait for a slot the same way: two contexts packing
+  // 16384^2 halves on one GPU took 12 SECONDS per frame (tools/shard_overhead.py, first version).
+  __shared__ uint32_t ticket;
+  uint32_t first_tile;
+  PackTileInfo cur, nxt;
   PackStagedLoads loads;
-  pack_request_tile(A.records + 3 * cur.rec_first, (int)(cur.n_last & 0x7FFFFFFFu), tid, &loads);
-  {  // (all eight loads of the code table in flight before the first LDS store)
+  if constexpr (kStream) {
+    if (tid == 0) ticket = A.tile_first + atomicAdd(&A.tile_ticket[A.launch_index], 1u);
+    // (the code table does not depend on the tile: its loads are in flight while the ticket arrives)
+    uint32_t tl[64 * 64 / kPackThreads];
+#pragma unroll
+    for (int q = 0; q < 64 * 64 / kPackThreads; q++) tl[q] = A.code_table[tid + q * kPackThreads];
+    __syncthreads();
+    first_tile = ticket;
+    if (first_tile >= ntiles_all) return;
+    cur = A.tile_info[first_tile];
+    nxt = cur;
+    pack_request_tile(A.records + 3 * cur.rec_first, (int)(cur.n_last & 0x7FFFFFFFu), tid, &loads);
+#pragma unroll
+    for (int q = 0; q < 64 * 64 / kPackThreads; q++) {
+      const uint32_t i = (uint32_t)(tid + q * kPackThreads);
+      table[pack_table_slot(i >> 6, i & 63u)] = tl[q];
+    }
+  } else {
+    first_tile = A.tile_first + blockIdx.x * kTilesPerGroup;
+    if (first_tile >= ntiles_all) return;
+    // The descriptors of the first two tiles and the first tile's records are requested in front of the code table.
+    cur = A.tile_info[first_tile];
+    nxt = A.tile_info[umin32(first_tile + 1, ntiles_all - 1)];
+    pack_request_tile(A.records + 3 * cur.rec_first, (int)(cur.n_last & 0x7FFFFFFFu), tid, &loads);
+    // (all eight loads of the code table in flight before the first LDS store)
     uint32_t tl[64 * 64 / kPackThreads];
 #pragma unroll
     for (int q = 0; q < 64 * 64 / kPackThreads; q++) tl[q] = A.code_table[tid + q * kPackThreads];
@@ -551,6 +581,7 @@ JXLT_DI void pack_tile_write_body(const PackTileArgs& A) {
       table[pack_table_slot(i >> 6, i & 63u)] = tl[q];
     }
   }
+  const uint32_t last_tile = ntiles_all - 1;
   for (int i = tid; i < kPackWindowWords; i += kPackThreads) window[i] = 0u;
   pack_store_tile(loads, (int)(cur.n_last & 0x7FFFFFFFu), stage, tid);
   if (kTilesPerGroup > 1 && first_tile + 1 < ntiles_all)

@@ -326,19 +326,25 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
     fprintf(stderr, "jxl_tiny_amd: output buffer: %s\n", jxlt_last_error(ctx));
     return false;
   }
-  if (jxlt_pack_begin(ctx, 1, ac_table.data()) != JXLT_OK ||
-      jxlt_pack_deliver(ctx, 1, buf + e0 + acg_bytes, nullptr, 0, /*end_aligned=*/0) != JXLT_OK) {
+  if (jxlt_pack_begin(ctx, 1, ac_table.data()) != JXLT_OK) {
     fprintf(stderr, "jxl_tiny_amd: section packing failed: %s\n", jxlt_last_error(ctx));
+    return false;
+  }
+  // (AC code first: the DC code was started before it on the other thread and is shorter -- its sections are queued
+  // BEFORE the AC sections' hand-over is asked for, which returns when the last AC launch has reported: 4096^2, the
+  // DC-group sections' kernel started 0.04 ms behind the last AC launch instead of right behind it)
+  if (!dc_begun) {
+    worker->Wait();
+    if (!begin_dc()) return false;
+  }
+  if (jxlt_pack_deliver(ctx, 1, buf + e0 + acg_bytes, nullptr, 0, /*end_aligned=*/0) != JXLT_OK) {
+    fprintf(stderr, "jxl_tiny_amd: section hand-over failed: %s\n", jxlt_last_error(ctx));
     return false;
   }
   memcpy(buf + e0, globals.ac_global.data(), acg_bytes);
   if (trace)
     fprintf(stderr, "jxlt trace: dc histogram after %.2f ms, %s first | ac histogram after %.2f ms, ac code %.3f ms\n",
             ms(t0, t0a), ac_first ? "AC code" : "DC code", ms(t0, t1), ms(t1, t2));
-  if (!dc_begun) {
-    worker->Wait();
-    if (!begin_dc()) return false;
-  }
   // The sizes of both kinds (all the TOC needs) arrive while the sections are being written and handed over.
   jxlt_packed_sections dcm, acm;
   if (jxlt_pack_sizes(ctx, 0, &dcm) != JXLT_OK || jxlt_pack_sizes(ctx, 1, &acm) != JXLT_OK) {

@@ -408,6 +408,8 @@ __attribute__((visibility("default"))) int sim_pack_stream(const uint8_t* record
   P.launch_sec_end = out_launch_end;
   P.tile_state = tile_state.data();
   P.block_state = block_state.data();
+  std::vector<uint32_t> tickets(kPackMaxLaunches, 0xDEADu);
+  P.tile_ticket = tickets.data();
   const unsigned sec_blocks = (unsigned)((nsec + 255) / 256);
   hipsim::launch(pack_tile_count_kernel, dim3(sec_blocks), dim3(256), P);
   hipsim::launch(group_scan_kernel, dim3(1), dim3(kScanThreads), (const uint32_t*)sec_tiles.data(), tile_base.data(), nsec);

@@ -284,6 +284,49 @@ def test_multi_encoder_shards_dc_groups_by_index(built):
     enc1.close()
 
 
+def test_single_pass_packing_of_several_contexts_on_one_device_does_not_stall(built):
+    """Tiles of the single pass wait for the tiles in front of them.  Handed out by workgroup index, a tile could wait
+    for one that was never dispatched because another context's waiting tiles held every slot of its XCD -- and the
+    other way round: two contexts packing halves of a 16384^2 frame on one GPU took 12 s per frame (round 4, first
+    version).  Tiles are handed out by ticket since (in the order in which workgroups START), so what a tile waits
+    for is running or done whatever shares the device.  Here: the single pass forced for every size, two and four
+    contexts on one GPU, launches of thousands of tiles each, in a child process with a time limit."""
+    import os
+    import sys
+    script = """
+import sys, time
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+import __graft_entry__ as G
+import bench
+pkg = G.load_package()
+size = 8192
+t = bench.frame_rows_on_device(torch, size, 0, size, 3, torch.device("cuda", 0))
+torch.cuda.synchronize()
+enc = pkg.Encoder(0)
+enc.set_device_image([t[c].data_ptr() for c in range(3)], size * 4, size, size, keepalive=t)
+single = bytes(enc.encode_resident(1.0))
+worst = 0.0
+for n in (2, 4):
+    me = pkg.MultiEncoder([0] * n)
+    for slab in range(n):
+        x0, y0, x1, y1 = pkg.shard_rect(size, size, n, slab)
+        me.set_device_slab(slab, [t[c, y0:, x0:].data_ptr() for c in range(3)], size * 4, x1 - x0, y1 - y0, keepalive=t)
+    for rep in range(6):
+        t0 = time.perf_counter()
+        out = me.encode_resident(size, size, 1.0).tobytes()
+        worst = max(worst, time.perf_counter() - t0) if rep else worst
+        assert out == single, (n, rep)
+    me.close()
+print("RESULT %%.4f" %% worst)
+""" % (str(T.ROOT), str(T.ROOT / "tests"))
+    env = dict(os.environ, JXLT_PACK_TWO_PASS="0")
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+    assert line, r.stdout + r.stderr
+    assert float(line[0].split()[1]) < 0.1, line  # (a frame takes ~2 ms; the stall was seconds)
+
+
 def test_multi_encoder_grows_its_output_region_and_reports_errors(built):
     """Incompressible content at a tiny distance needs more than the byte per pixel the output region starts
     with: the encoder redoes the frame with the packer's worst case.  Then: frames of changing geometry through
