@@ -2024,6 +2024,16 @@ void FillMeasured(jxlt_context* ctx, int kind, jxlt_packed_sections* out) {
   out->num_sections = ps.measured_sections;
 }
 
+// The DC-group sections of a two-pass frame leave by pack_deliver_kernel (experiment knob JXLT_DC_DELIVER_KERNEL=1):
+// queued at once behind their writing launch, byte ranges read on the device -- no host in between.
+bool DcDeliverByKernel(const jxlt_context* ctx, int kind) {
+  static const bool on = [] {
+    const char* e = getenv("JXLT_DC_DELIVER_KERNEL");
+    return e && atoi(e) != 0;
+  }();
+  return on && kind == 0 && !ctx->pack[0].streamed;
+}
+
 // The hand-over of the measured and (being) written sections of `kind` to `dst` (asynchronous, kernels on the copy
 // stream that store to the destination themselves -- page-locked host memory or device memory): behind every launch
 // of the writing pass the whole sections it completed leave, while later launches are still packing.  The kernels
@@ -2096,7 +2106,7 @@ int EnqueueDeliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_section
     ctx->deliveries_pending = true;
     return JXLT_OK;
   }
-  if (!by_kernel || ps.streamed) {
+  if (!(by_kernel || DcDeliverByKernel(ctx, kind)) || ps.streamed) {
     const int rcs = WaitSizes(ctx, kind);
     if (rcs != JXLT_OK) return rcs;
     const uint64_t* off = ps.h_sec_byte_off.p;
@@ -2278,7 +2288,7 @@ int jxlt_pack_deliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_sect
       const int rcd = IssueDeferred(ctx, /*wait=*/true);
       if (rcd != JXLT_OK) return rcd;
     }
-    if (!SizesReady(ctx, 0)) {
+    if (!SizesReady(ctx, 0) && !DcDeliverByKernel(ctx, 0)) {
       jxlt_context::DeferredDeliver& d = ctx->deferred_dc;
       d.pending = true;
       d.dst = dev_dst;
