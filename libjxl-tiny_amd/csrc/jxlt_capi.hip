@@ -1908,9 +1908,13 @@ int EnqueueStream(jxlt_context* ctx, int kind, const uint32_t* code_table) {
   // (the tiles OR their first and last dwords into the blob: zero up to where the sections can reach with this code)
   ps.zeroed_bytes = std::min<uint64_t>(SectionBytesBound(ctx, kind, code_table, nsec), ps.packed.cap);
   HIP_TRY(ctx, hipMemsetAsync(ps.packed.p, 0, ps.zeroed_bytes, ps.stream));
+  // ONE launch is the default here: the frames the single pass is used for (up to 1024 groups, 6 MB of AC sections)
+  // are packed in 0.02-0.1 ms, and every further launch costs a publish kernel, a copy command and a ramp -- 2048^2:
+  // 0.355 / 0.377 / 0.382 ms with one / two / three launches, 4096^2: 0.578 / 0.591 / 0.613, 8192^2: 1.562 / 1.568 /
+  // 1.596, 48 resident 3840x2160 frames over six lanes: 3423 / 3370 / 3284 frames per second (tools/launches_small.sh).
   static const int ac_launches = [] {
     const char* e = getenv("JXLT_PACK_LAUNCHES");
-    return e ? std::max(1, std::min(atoi(e), (int)jxlt_context::PackSet::kMaxLaunches)) : 3;
+    return e ? std::max(1, std::min(atoi(e), (int)jxlt_context::PackSet::kMaxLaunches)) : 1;
   }();
   static const double growth = [] {
     const char* e = getenv("JXLT_PACK_GROWTH");
