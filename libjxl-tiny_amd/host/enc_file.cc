@@ -38,25 +38,36 @@ bool WriteFileHeader(size_t xsize, size_t ysize, jxl::BitWriter* writer) {
   WriteSize(static_cast<uint32_t>(ysize), writer);
   writer->Write(3, 0);  // ratio
   WriteSize(static_cast<uint32_t>(xsize), writer);
-  writer->Write(1, 0);  // not all default image metadata
-  writer->Write(1, 0);  // no extra fields in image metadata
-  writer->Write(1, 1);  // floating point samples
-  writer->Write(2, 0);  // 32 bits per sample
-  writer->Write(4, 7);  // 8 exponent bits per sample
-  writer->Write(1, 0);  // modular 16 bit sufficient
-  writer->Write(2, 0);  // no extra channels
-  writer->Write(1, 1);  // xyb encoded
-  writer->Write(1, 0);  // not all default color encoding
-  writer->Write(1, 0);  // no icc
-  writer->Write(2, 0);  // RGB color space
-  writer->Write(2, 1);  // D65 white point
-  writer->Write(2, 1);  // SRGB primaries
-  writer->Write(1, 0);  // no gamma
-  writer->Write(2, 2);  // transfer function selector bits (2 .. 17)
-  writer->Write(4, 6);  // linear transfer function (enum value 8)
-  writer->Write(2, 1);  // relative rendering intent
-  writer->Write(2, 0);  // no extensions
-  writer->Write(1, 1);  // all default transform data
+  // ImageMetadata of a float, XYB-encoded, linear-sRGB image (the only kind this encoder writes;
+  // enc_file.cc:75-95): a fixed field list, kept as data -- {bits, value} in bitstream order.
+  struct Field {
+    uint8_t bits;
+    uint8_t value;
+  };
+  static const Field kImageMetadata[] = {
+      {1, 0},  // all_default = false
+      {1, 0},  // extra_fields = false
+      // bit depth
+      {1, 1},  // floating_point_sample
+      {2, 0},  // bits_per_sample selector: 32
+      {4, 7},  // exponent_bits_per_sample - 1: 8
+      {1, 0},  // modular_16_bit_buffer_sufficient = false
+      {2, 0},  // num_extra_channels selector: 0
+      {1, 1},  // xyb_encoded
+      // colour encoding
+      {1, 0},  // all_default = false
+      {1, 0},  // want_icc = false
+      {2, 0},  // colour space: RGB
+      {2, 1},  // white point: D65
+      {2, 1},  // primaries: sRGB
+      {1, 0},  // have_gamma = false
+      {2, 2},  // transfer function: selector for enum values 2 .. 17 ...
+      {4, 6},  // ... value 8 = linear
+      {2, 1},  // rendering intent: relative
+      {2, 0},  // extensions: none
+      {1, 1},  // default transform data
+  };
+  for (const Field& f : kImageMetadata) writer->Write(f.bits, f.value);
   writer->ZeroPadToByte();
   return true;
 }

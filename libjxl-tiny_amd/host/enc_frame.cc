@@ -310,10 +310,15 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   const auto t1 = now();
   expected_ac_ms = ms(t0, t1);
   BuildAcCode(ac_hist, &ac_code);
+  const auto t1a = now();
   ac_shared = TakeClusteringShared();
   FillCodeTable(ac_code, ac_table.data());
+  const auto t1b = now();
   globals.ac_global = BuildAcGlobal(xsize, ysize, ac_code);
   const auto t2 = now();
+  if (trace)
+    fprintf(stderr, "jxlt trace: AC code: clustering + Huffman %.3f ms, table %.3f, ACGlobal %.3f\n", ms(t1, t1a), ms(t1a, t1b),
+            ms(t1b, t2));
   const size_t acg_bytes = globals.ac_global.size();
   if (ac_first) {
     // (DCGlobal does not exist yet: its bound -- context tree + one clustered code for 45 contexts -- is 16 KB)
