@@ -1724,6 +1724,7 @@ PackTileArgs TileArgsOf(jxlt_context* ctx, int kind, size_t nsec) {
   for (int i = 0; i <= ps.launches && i <= kPackMaxLaunches; i++) P.launch_t0[i] = ps.launch_t0[i];
   P.launch_sec_end = ps.launch_sec_end.p;
   P.tile_ticket = ps.launch_sec_end.p ? ps.launch_sec_end.p + kPackMaxLaunches : nullptr;
+  P.sized_count = ps.launch_sec_end.p ? ps.launch_sec_end.p + 2 * kPackMaxLaunches : nullptr;
   P.tile_state = PackSinglePass(ctx) ? ps.tile_state.p : nullptr;
   P.block_state = PackSinglePass(ctx) && ps.tile_state.p ? ps.tile_state.p + ps.state_tiles : nullptr;
   static const bool stats_on = [] {
@@ -1756,7 +1757,7 @@ int EnqueuePlan(jxlt_context* ctx, int kind, uint64_t rec_bound, hipStream_t str
   ENSURE(tile_base, nsec + 1);
   ENSURE(tile_bits, max_tiles);
   ENSURE(tile_info, max_tiles);
-  ENSURE(launch_sec_end, 2 * kPackMaxLaunches);  // (+ the single pass's tickets)
+  ENSURE(launch_sec_end, 3 * kPackMaxLaunches);  // (+ the single pass's tickets and size counters)
   if (PackSinglePass(ctx)) {  // (tile states, block states behind them)
     ENSURE(tile_state, max_tiles + max_tiles / kPackBlockTiles + 2);
     ps.state_tiles = max_tiles;
@@ -1928,11 +1929,27 @@ int EnqueueStream(jxlt_context* ctx, int kind, const uint32_t* code_table) {
     ps.launch_t0[i] = i == ps.launches ? (uint32_t)max_tiles : (uint32_t)((double)max_tiles * share);
   }
   ps.pack_seq++;
+  // (experiment knob JXLT_PACK_SIZES_IN_KERNEL=1, one launch only: the tile that is the last to say its size stores the
+  // sections' bit counts to the host's mirror and sets the launch's word itself, while the launch is still packing --
+  // no publish kernel behind the launch, the copy command queued behind the launch's event before the launch ends.
+  // Measured and not kept: the counter every tile draws from needs acquire + release at agent scope, i.e. an L2
+  // write-back and invalidate per tile -- 8192^2 1.66-1.67 against 1.55-1.58 ms, 1024^2 ... 4096^2 and the 4K
+  // batch inside the noise, tools/sizes_in_kernel_ab.sh)
+  static const bool sizes_in_kernel = [] {
+    const char* e = getenv("JXLT_PACK_SIZES_IN_KERNEL");
+    return e && atoi(e) != 0;
+  }();
+  const bool in_kernel_sizes = sizes_in_kernel && ps.launches == 1;
   for (int i = 0; i < ps.launches; i++) {
     PackTileArgs W = TileArgsOf(ctx, kind, nsec);
     W.tile_first = ps.launch_t0[i];
     W.tile_end = ps.launch_t0[i + 1];
     W.launch_index = (uint32_t)i;
+    if (in_kernel_sizes) {
+      W.host_sec_bits = ps.h_sec_bits(nsec);
+      W.host_flag = &ctx->mail.p->stream_seq[kind][i][0];
+      W.host_seq = ps.pack_seq;
+    }
     TraceMark(ctx, kind ? "AC stream launch start" : "DC stream launch start", ps.stream);
     if (W.tile_end > W.tile_first)
       hipLaunchKernelGGL(pack_tile_stream_kernel,
@@ -1941,6 +1958,7 @@ int EnqueueStream(jxlt_context* ctx, int kind, const uint32_t* code_table) {
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ps.launch_done[i], ps.stream));
     TraceMark(ctx, kind ? "AC stream launch done" : "DC stream launch done", ps.stream);
+    if (in_kernel_sizes) continue;  // (the launch reports the sizes itself, see PackTileArgs::host_flag)
     // (IN the stream: a one-workgroup kernel on another stream waits for a free slot behind the next launch's
     // workgroups -- the first launch's word arrived when the last launch had ended)
     const PublishSeg segs[2] = {{ps.sec_bits(nsec), ps.h_sec_bits(nsec), nsec},
@@ -2098,7 +2116,8 @@ int EnqueueDeliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_section
       const int rca = StreamAdvance(ctx, kind, i, &s_hi);
       if (rca != JXLT_OK) return rca;
       if (off[s_hi] > off[s_lo]) {
-        // (the launch is over -- the host has seen its word --: no event in front of the copy)
+        // (the launch's word may have been set by the launch itself, before its end: the copy waits for the end)
+        HIP_TRY(ctx, hipStreamWaitEvent(out_stream, ps.launch_done[i], 0));
         TraceMark(ctx, kind ? "AC copy start" : "DC copy start", out_stream);
         HIP_TRY(ctx, hipMemcpyAsync(dst + off[s_lo], ps.packed.p + off[s_lo], off[s_hi] - off[s_lo], hipMemcpyDefault, out_stream));
         TraceMark(ctx, kind ? "AC copy done" : "DC copy done", out_stream);

@@ -78,6 +78,14 @@ struct PackTileArgs {
   unsigned long long* tile_state;   // [tiles]
   unsigned long long* block_state;  // [tiles / 64 + 1]
   uint32_t* tile_ticket;            // [kPackMaxLaunches]: how many workgroups of a launch have started (zeroed by the plan)
+  // Single pass with ONE launch: the tile that is the last to say its size knows that the sections' bit counts are
+  // complete -- it stores them to the host's page-locked mirror and then `host_seq` to the word the host polls, while
+  // the launch is still packing (no publish kernel behind the launch: the host has the sizes, and has queued the copy
+  // behind the launch's event, before the launch ends).  NULL: a publish kernel behind the launch does it.
+  uint32_t* sized_count;            // [kPackMaxLaunches] tiles that have said their size (zeroed by the plan)
+  uint32_t* host_sec_bits;          // [nsec], page-locked host memory (mapped)
+  uint32_t* host_flag;
+  uint32_t host_seq;
   uint32_t launch_index;            // which of the writing launches this is (its last tile files launch_sec_end)
   uint32_t* lookback_stats;         // optional (JXLT_TRACE_EVENTS): [0] tiles [1] windows looked at [2] reloads of a window
                                     // [3] most windows one tile looked at
@@ -99,6 +107,9 @@ struct PackTileArgs {
 // A tile needs the SIZEs of the tiles in front of it in its own block (started within a microsecond of it) and, of the
 // blocks in front, the nearest END and what the blocks between do: 64 blocks = 4096 tiles per window, five times
 // what is in flight, so one round trip behind the slowest size settles every position -- no chain of ends.
+#ifndef JXLT_THREADFENCE_SYSTEM
+#define JXLT_THREADFENCE_SYSTEM() __threadfence_system()
+#endif
 constexpr unsigned long long kPackStateSize = 1ull << 62, kPackStateEnd = 2ull << 62, kPackStateFirst = 1ull << 61;
 constexpr int kPackBlockTiles = 64;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -109,11 +120,24 @@ JXLT_DI void pack_state_store(unsigned long long* p, unsigned long long v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 JXLT_DI void pack_state_wait() { __builtin_amdgcn_s_sleep(2); }
+// (acquire + release: whoever draws the last number sees what every earlier drawer did before drawing)
+JXLT_DI uint32_t pack_count_up(uint32_t* p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT); }
+JXLT_DI uint32_t pack_bits_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #else
 JXLT_DI unsigned long long pack_state_load(const unsigned long long* p) { return *(const volatile unsigned long long*)p; }
 JXLT_DI void pack_state_store(unsigned long long* p, unsigned long long v) { *(volatile unsigned long long*)p = v; }
 JXLT_DI void pack_state_wait() {}
+JXLT_DI uint32_t pack_count_up(uint32_t* p) { return (*p)++; }
+JXLT_DI uint32_t pack_bits_load(const uint32_t* p) { return *(const volatile uint32_t*)p; }
 #endif
+// The sections' bit counts -> the host's mirror, then the pass's number to the word the host polls (one wave).
+JXLT_DI void pack_publish_sizes(const uint32_t* sec_bits, uint32_t* host_sec_bits, int nsec, uint32_t* host_flag, uint32_t seq,
+                                int lane) {
+  for (int i = lane; i < nsec; i += 64) host_sec_bits[i] = pack_bits_load(sec_bits + i);
+  JXLT_THREADFENCE_SYSTEM();
+  JXLT_WAVE_SYNC();
+  if (lane == 0) *(volatile uint32_t*)host_flag = seq;
+}
 
 // What a run of tiles does to the position in front of it: p -> round8(p + pre) + rest (a section starts inside the
 // run), or p -> p + pre.  32 bits do for 64 tiles of < 2^17 bits and for 64 blocks of < 2^23.
@@ -262,6 +286,7 @@ __global__ void __launch_bounds__(256) pack_tile_plan_kernel(const PackTileArgs 
       for (int i = 0; i < kPackMaxLaunches; i++) {
         A.launch_sec_end[i] = 0xFFFFFFFFu;  // "no tile in this launch"
         A.tile_ticket[i] = 0;
+        A.sized_count[i] = 0;
       }
   }
   for (uint32_t t = t0; t < t1; t++) {
@@ -555,7 +580,12 @@ JXLT_DI void pack_tile_write_body(const PackTileArgs& A) {
     for (int q = 0; q < 64 * 64 / kPackThreads; q++) tl[q] = A.code_table[tid + q * kPackThreads];
     __syncthreads();
     first_tile = ticket;
-    if (first_tile >= ntiles_all) return;
+    if (first_tile >= ntiles_all) {
+      // (a launch without a single tile: the first workgroup reports the sizes -- all zero)
+      if (A.host_flag && first_tile == A.tile_first && tid < 64)
+        pack_publish_sizes(A.sec_bits, A.host_sec_bits, A.nsec, A.host_flag, A.host_seq, tid);
+      return;
+    }
     cur = A.tile_info[first_tile];
     nxt = cur;
     pack_request_tile(A.records + 3 * cur.rec_first, (int)(cur.n_last & 0x7FFFFFFFu), tid, &loads);
@@ -639,6 +669,12 @@ JXLT_DI void pack_tile_write_body(const PackTileArgs& A) {
         }
         mates_loaded = pack_mates_load(A.tile_state, tile, tid);
         blocks_loaded = pack_blocks_load(A.block_state, (long long)(tile / kPackBlockTiles) - 1, tid);
+        if (A.host_flag) {
+          uint32_t said = 0;
+          if (tid == 0) said = pack_count_up(A.sized_count + A.launch_index) + 1u;
+          said = (uint32_t)__shfl((int)said, 0);
+          if (said == ntiles_all - A.tile_first) pack_publish_sizes(A.sec_bits, A.host_sec_bits, A.nsec, A.host_flag, A.host_seq, tid);
+        }
       }
       pos_bit = 0;
     }
@@ -756,9 +792,6 @@ __global__ void __launch_bounds__(kPackThreads) pack_tile_stream_kernel(const Pa
 // A 16 KB publish takes ~6 us and its flag is seen ~6 us after the launch; the section bytes travel at the link's
 // rate (54 GB/s, the same as hipMemcpyAsync) with no host round trip in front of them.
 // ---------------------------------------------------------------------------
-#ifndef JXLT_THREADFENCE_SYSTEM
-#define JXLT_THREADFENCE_SYSTEM() __threadfence_system()
-#endif
 
 // (four waves: a workgroup that fits whatever is free on a CU that another kernel fills)
 constexpr int kPublishThreads = 256;

@@ -408,8 +408,17 @@ __attribute__((visibility("default"))) int sim_pack_stream(const uint8_t* record
   P.launch_sec_end = out_launch_end;
   P.tile_state = tile_state.data();
   P.block_state = block_state.data();
-  std::vector<uint32_t> tickets(kPackMaxLaunches, 0xDEADu);
+  std::vector<uint32_t> tickets(kPackMaxLaunches, 0xDEADu), sized(kPackMaxLaunches, 0xDEADu);
   P.tile_ticket = tickets.data();
+  P.sized_count = sized.data();
+  // (one launch: the launch reports the sections' bit counts itself, as in the product)
+  std::vector<uint32_t> reported(nsec + 1, 0xDEADu);
+  uint32_t reported_flag = 0;
+  if (nlaunch == 1) {
+    P.host_sec_bits = reported.data();
+    P.host_flag = &reported_flag;
+    P.host_seq = 4711u;
+  }
   const unsigned sec_blocks = (unsigned)((nsec + 255) / 256);
   hipsim::launch(pack_tile_count_kernel, dim3(sec_blocks), dim3(256), P);
   hipsim::launch(group_scan_kernel, dim3(1), dim3(kScanThreads), (const uint32_t*)sec_tiles.data(), tile_base.data(), nsec);
@@ -423,6 +432,12 @@ __attribute__((visibility("default"))) int sim_pack_stream(const uint8_t* record
       hipsim::launch(pack_tile_stream_kernel,
                      dim3((unsigned)((W.tile_end - W.tile_first + kPackStreamTilesPerGroup - 1) / kPackStreamTilesPerGroup)),
                      dim3(kPackThreads), W);
+  }
+  if (nlaunch == 1) {
+    if (reported_flag != 4711u) return 3;
+    for (int i = 0; i < nsec; i++)
+      if (reported[i] != out_bits[i]) return 4;
+    if (reported[nsec] != 0xDEADu) return 5;
   }
   return 0;
 }
