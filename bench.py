@@ -540,12 +540,15 @@ def cpu_baseline_leg(args, np, pkg, T, frame, dev_index, result):
     # reference's OptimizeSections.  Same work, same bytes.
     ng = s // 256
     if ng >= 2:
-        # (the CPUs this process may run on)
+        # (the CPUs this process may run on, and how many of them its control group lets it use at a time: on the
+        # GPU boxes of this pool 16 of 256 -- threads beyond the quota are throttled, 256 threads ran at a third of
+        # the rate of 16, tools/cpu_scaling_probe.py)
         try:
             usable = len(os.sched_getaffinity(0))
         except (AttributeError, OSError):
             usable = os.cpu_count() or 1
-        nthr = max(1, min(ng * ng, usable))
+        quota = _cgroup_cpu_quota()
+        nthr = max(1, min(ng * ng, usable if quota is None else min(usable, quota)))
         par_jxl, ppix_s, pbs_s = T.oracle_encode_file(crop, d, nthreads=nthr)
         par_s = ppix_s + pbs_s
         result["cpu_baseline"]["all_cores"] = {
@@ -553,6 +556,7 @@ def cpu_baseline_leg(args, np, pkg, T, frame, dev_index, result):
             "sample": "same crop and same work: %d groups over %d POSIX threads (%.3f s) + the serial bitstream stage "
                       "(%.3f s)" % (ng * ng, nthr, ppix_s, pbs_s),
             "pixel_pipeline_only_mpix_s": round(s * s / 1e6 / ppix_s, 1),
+            "cpus_in_affinity_mask": usable, "cgroup_cpu_quota": quota,
             "same_bytes_as_one_thread": par_jxl == cpu_jxl}
         # the GPU's codestream of that crop must be those bytes too
         gpu_crop = pkg.encode_file(crop, d, device=dev_index)
@@ -673,6 +677,24 @@ def pmc_valu(size):
         except (OSError, KeyError, ValueError):
             best = None
     return best
+
+
+def _cgroup_cpu_quota():
+    """CPUs the process's control group may use at a time (cgroup v2 cpu.max / v1 cfs quota), rounded up; None if
+    unlimited or unknown."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            return max(1, -(-int(quota) // int(period)))
+        return None
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return max(1, -(-quota // period)) if quota > 0 and period > 0 else None
+    except (OSError, ValueError):
+        return None
 
 
 def _cpu_model():
