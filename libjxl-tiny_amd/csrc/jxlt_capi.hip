@@ -1699,6 +1699,16 @@ bool PackSinglePass(const jxlt_context* ctx) {
   if (forced >= 0) return forced != 0;
   return (size_t)ctx->geom.xsize_groups * ctx->geom.ysize_groups <= 1024;
 }
+// ... and, when the AC sections' record count is known (jxlt_pack_begin), by what really decides: the number of
+// tiles.  A frame of 1024 groups of uniform noise has 142 M records = 35 000 tiles, more than the 16384^2 bench frame:
+// in one pass 3.24 ms, in two 2.88; 8192^2 at d = 0.5 (63 M records) 2.02 against 2.11, 4096^2 at d = 0.1 (40 M)
+// 1.29 against 1.76 (tools/token_heavy_ab.sh).  One pass up to 80 M records (19 500 tiles; the 16384^2 bench frame
+// has 105 M, the 8192^2 frame at d = 1 26 M).
+bool PackSinglePassFor(const jxlt_context* ctx, int kind, uint64_t records) {
+  if (!PackSinglePass(ctx)) return false;
+  static const bool forced = getenv("JXLT_PACK_TWO_PASS") != nullptr;
+  return forced || kind == 0 || records <= (80ull << 20);
+}
 
 // Common argument block of the tile-granular packing kernels for sections of `kind`.
 PackTileArgs TileArgsOf(jxlt_context* ctx, int kind, size_t nsec) {
@@ -2254,7 +2264,8 @@ int jxlt_pack_begin(jxlt_context* ctx, int kind, const uint32_t* code_table) {
     const int rcw = WaitDeliveries(ctx);
     if (rcw != JXLT_OK) return rcw;
   }
-  return PackSinglePass(ctx) ? EnqueueStream(ctx, kind, code_table) : EnqueueMeasure(ctx, kind, code_table);
+  const uint64_t records = kind == 1 ? ctx->h_group_off.p[NumSections(ctx, 1)] : 0;
+  return PackSinglePassFor(ctx, kind, records) ? EnqueueStream(ctx, kind, code_table) : EnqueueMeasure(ctx, kind, code_table);
 }
 
 int jxlt_pack_sizes(jxlt_context* ctx, int kind, jxlt_packed_sections* out) {
