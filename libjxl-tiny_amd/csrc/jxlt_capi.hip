@@ -1682,32 +1682,35 @@ int jxlt_fetch_histograms(jxlt_context* ctx, const uint32_t** ac_histograms, con
 
 namespace {
 // One pass or two.  ONE (pack_tile_stream_kernel: every tile takes its bit position from the tiles in front of it
-// while it runs; no measuring pass, none of its offsets / scan / finalize kernels, no second read of the records) for
-// frames of up to 1024 groups (8192^2), TWO (measure, lay out, write: rounds 1-3) above: the single pass saves the
-// chain of small kernels -- 2048^2: 0.41 -> 0.375 ms, 4096^2: 0.62 -> 0.59, 8192^2: 1.56 -> 1.54 -- but its kernel
-// packs 75-85 tiles per us where the two-pass form's writing pass does 120 (one tile per workgroup, and the waits
-// for the neighbours' sizes), and from ~20 000 tiles on that costs more than the measuring pass did (16384^2: 5.26
-// against 5.18-5.22 ms).  JXLT_PACK_TWO_PASS=1 / 0 forces either; the kernel hand-over (JXLT_DELIVER_KERNEL=1)
+// while it runs; no measuring pass, none of its offsets / scan / finalize kernels, no second read of the records) up
+// to 1024 groups and ~20 000 tiles, TWO (measure, lay out, write: rounds 1-3) above.  The single pass saves the chain of small
+// kernels -- 2048^2: 0.41 -> 0.36 ms, 4096^2: 0.62 -> 0.58, 8192^2: 1.56 -> 1.54 -- but its kernel packs 55-85 tiles
+// per us where the two-pass form's writing pass does 120 (one tile per workgroup, a ticket and the waits for the
+// neighbours' sizes in front of every tile), and from ~20 000 tiles on that costs more than the measuring pass did
+// (the AC sections of the 16384^2 bench frame, 25 700 tiles: 5.21-5.26 against 5.14-5.22 ms; 8192^2 of uniform noise,
+// 34 700 tiles: 3.24 against 2.88; 8192^2 at d = 0.5, 15 400 tiles: 2.02 against 2.11; 4096^2 at d = 0.1, 9 800 tiles:
+// 1.29 against 1.76 -- tools/ab_stream.sh, tools/token_heavy_ab.sh).  What counts is the number of tiles: the AC
+// sections' record count is known when their packing is asked for.  JXLT_PACK_TWO_PASS=1 / 0 forces either; the kernel hand-over (JXLT_DELIVER_KERNEL=1)
 // needs two passes.
-bool PackSinglePass(const jxlt_context* ctx) {
+int PackPassesForced() {  // 1 / 2, or 0: by size
   static const int forced = [] {
     const char* two = getenv("JXLT_PACK_TWO_PASS");
     const char* kern = getenv("JXLT_DELIVER_KERNEL");
-    if (kern && atoi(kern) != 0) return 0;
-    return two ? (atoi(two) != 0 ? 0 : 1) : -1;
+    if (kern && atoi(kern) != 0) return 2;
+    return two ? (atoi(two) != 0 ? 2 : 1) : 0;
   }();
-  if (forced >= 0) return forced != 0;
-  return (size_t)ctx->geom.xsize_groups * ctx->geom.ysize_groups <= 1024;
+  return forced;
 }
-// ... and, when the AC sections' record count is known (jxlt_pack_begin), by what really decides: the number of
-// tiles.  A frame of 1024 groups of uniform noise has 142 M records = 35 000 tiles, more than the 16384^2 bench frame:
-// in one pass 3.24 ms, in two 2.88; 8192^2 at d = 0.5 (63 M records) 2.02 against 2.11, 4096^2 at d = 0.1 (40 M)
-// 1.29 against 1.76 (tools/token_heavy_ab.sh).  One pass up to 80 M records (19 500 tiles; the 16384^2 bench frame
-// has 105 M, the 8192^2 frame at d = 1 26 M).
+// (may a single pass be asked for at all: the plans then prepare the tiles' states)
+bool PackSinglePass(const jxlt_context*) { return PackPassesForced() != 2; }
 bool PackSinglePassFor(const jxlt_context* ctx, int kind, uint64_t records) {
-  if (!PackSinglePass(ctx)) return false;
-  static const bool forced = getenv("JXLT_PACK_TWO_PASS") != nullptr;
-  return forced || kind == 0 || records <= (80ull << 20);
+  if (PackPassesForced() != 0) return PackPassesForced() == 1;
+  // (a section has at least one tile: a frame of 4096 groups is 4096 workgroups with a ticket, a code table and a
+  // look-back each even when they hold a handful of records -- 16384^2 at d = 4, 1 800 tiles' worth of records: 4.55-4.58
+  // ms in one pass, 4.52-4.53 in two; the DC-group sections of the 16384^2 frame alone in one pass: 5.26-5.28
+  // against 5.24-5.26, tools/mixed_ab.sh)
+  if ((size_t)ctx->geom.xsize_groups * ctx->geom.ysize_groups > 1024) return false;
+  return kind == 0 || records <= (80ull << 20);
 }
 
 // Common argument block of the tile-granular packing kernels for sections of `kind`.
