@@ -314,6 +314,12 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   ac_shared = TakeClusteringShared();
   FillCodeTable(ac_code, ac_table.data());
   const auto t1b = now();
+  // (the device needs the table only: the AC sections' packing is queued before ACGlobal -- the code's serialisation,
+  // 10 us -- is written, and runs beside it)
+  if (jxlt_pack_begin(ctx, 1, ac_table.data()) != JXLT_OK) {
+    fprintf(stderr, "jxl_tiny_amd: section packing failed: %s\n", jxlt_last_error(ctx));
+    return false;
+  }
   globals.ac_global = BuildAcGlobal(xsize, ysize, ac_code);
   const auto t2 = now();
   if (trace)
@@ -329,10 +335,6 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   // (with DC-group sections on their way the buffer grows with its contents; normally it has its size from the last frame)
   if (jxlt_output_buffer(ctx, e0 + acg_bytes + ac_bound + 16, &buf) != JXLT_OK) {
     fprintf(stderr, "jxl_tiny_amd: output buffer: %s\n", jxlt_last_error(ctx));
-    return false;
-  }
-  if (jxlt_pack_begin(ctx, 1, ac_table.data()) != JXLT_OK) {
-    fprintf(stderr, "jxl_tiny_amd: section packing failed: %s\n", jxlt_last_error(ctx));
     return false;
   }
   // (AC code first: the DC code was started before it on the other thread and is shorter -- its sections are queued
