@@ -284,6 +284,21 @@ def test_multi_encoder_shards_dc_groups_by_index(built):
     enc1.close()
 
 
+def test_frames_of_one_column_or_one_row_of_groups(built):
+    """Narrow / tall and wide / flat frames: hundreds of groups and dozens of DC groups in ONE column or row (every
+    section is small, the sections are many -- the look-back of the single pass crosses a section start in almost
+    every tile, the tile plan is all first tiles), a frame eight pixels wide, one nine pixels high.  Against the
+    oracle, twice in a row on one context."""
+    for (w, h, d) in [(256, 65536, 1.0), (65536, 200, 2.0), (300, 30000, 0.5), (8, 40000, 1.0), (50000, 9, 1.0)]:
+        img = T.to_planes(T.synthetic_image(w, h, seed=w ^ h))
+        want = bytes(T.oracle_encode_file(img, d, nthreads=8)[0])
+        e = built.Encoder(0)
+        e.upload(img)
+        assert bytes(e.encode_resident(d)) == want, (w, h)
+        assert bytes(e.encode_resident(d)) == want, (w, h)
+        e.close()
+
+
 def test_single_pass_packing_of_several_contexts_on_one_device_does_not_stall(built):
     """Tiles of the single pass wait for the tiles in front of them.  Handed out by workgroup index, a tile could wait
     for one that was never dispatched because another context's waiting tiles held every slot of its XCD -- and the
