@@ -465,6 +465,10 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     e = hipStreamCreateWithPriority(&ctx->dc_pack_stream, hipStreamNonBlocking, greatest);
+    if (e != hipSuccess) {  // (a runtime without stream priorities: an ordinary stream does the same work)
+      (void)hipGetLastError();
+      e = hipStreamCreateWithFlags(&ctx->dc_pack_stream, hipStreamNonBlocking);
+    }
   }
   if (e == hipSuccess) e = hipEventCreate(&ctx->aux_done);
   for (auto& ev : ctx->ev)
