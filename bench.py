@@ -44,6 +44,15 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
+# CPU hygiene of the harness (before numpy / torch are imported).  The pool's boxes show 256 CPUs and grant a process
+# 16 at a time (cgroup cpu.max): the OpenMP / MKL thread pools that numpy and torch size by the CPU count keep
+# spinning for a while after their last parallel region, the control group runs out of its quota and EVERY thread of
+# the process -- the encoding thread too -- is stopped for the rest of the 100 ms period.  Seen as steps of 12-18 ms
+# among steps of 5.2 (tools/outlier_probe.sh: two throttlings per run, in the warm-up or the first timed steps).
+for _k, _v in (("OMP_NUM_THREADS", "8"), ("MKL_NUM_THREADS", "8"), ("OPENBLAS_NUM_THREADS", "8"),
+               ("OMP_WAIT_POLICY", "PASSIVE"), ("KMP_BLOCKTIME", "0"), ("GOMP_SPINCOUNT", "0")):
+    os.environ.setdefault(_k, _v)
+
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PCIE_PEAK_GBS = 63.0   # same guide: PCIe Gen5 x16 host link
 ALGO_BYTES_PER_PIXEL = 12.0  # 3 planes x f32, each pixel read once
@@ -127,6 +136,7 @@ def main():
 
     import numpy as np
     import torch
+    torch.set_num_threads(8)  # (see the note on CPU hygiene at the top)
     import __graft_entry__
     pkg = __graft_entry__.load_package()
 

@@ -390,6 +390,17 @@ int EnsurePinned(jxlt_context* ctx, PinnedBuf<T>* b, size_t n) {
   }();
   HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&b->p), (n ? n : 1) * sizeof(T), pinned_flags));
   b->cap = n;
+  // A large page-locked buffer is written once by the CPU here.  The device's FIRST write to a part of such a buffer
+  // that nothing has touched yet runs at ~1.6 GB/s instead of 55: the 11 MB of the last AC copy took 7 ms the first
+  // time the sections landed in a new part of the output buffer -- the first frame whose DC code was ready before
+  // its AC code, one of frames 2 to 6: a step of 12 ms among steps of 5.2, inside the driver's twenty timed steps
+  // as often as not (tools/outlier_probe.sh; JXLT_TRACE_EVENTS: "AC copy start 6.002 ms ... done 12.996").
+  // (experiment knob: JXLT_PINNED_TOUCH=0)
+  static const bool touch = [] {
+    const char* e = getenv("JXLT_PINNED_TOUCH");
+    return !e || atoi(e) != 0;
+  }();
+  if (touch && n * sizeof(T) >= ((size_t)1 << 20)) memset(b->p, 0, n * sizeof(T));
   return JXLT_OK;
 }
 
