@@ -390,17 +390,6 @@ int EnsurePinned(jxlt_context* ctx, PinnedBuf<T>* b, size_t n) {
   }();
   HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&b->p), (n ? n : 1) * sizeof(T), pinned_flags));
   b->cap = n;
-  // A large page-locked buffer is written once by the CPU here.  The device's FIRST write to a part of such a buffer
-  // that nothing has touched yet runs at ~1.6 GB/s instead of 55: the 11 MB of the last AC copy took 7 ms the first
-  // time the sections landed in a new part of the output buffer -- the first frame whose DC code was ready before
-  // its AC code, one of frames 2 to 6: a step of 12 ms among steps of 5.2, inside the driver's twenty timed steps
-  // as often as not (tools/outlier_probe.sh; JXLT_TRACE_EVENTS: "AC copy start 6.002 ms ... done 12.996").
-  // (experiment knob: JXLT_PINNED_TOUCH=0)
-  static const bool touch = [] {
-    const char* e = getenv("JXLT_PINNED_TOUCH");
-    return !e || atoi(e) != 0;
-  }();
-  if (touch && n * sizeof(T) >= ((size_t)1 << 20)) memset(b->p, 0, n * sizeof(T));
   return JXLT_OK;
 }
 
@@ -443,6 +432,62 @@ int CheckImageArgs(jxlt_context* ctx, const void* const planes[3], size_t pitch_
 }  // namespace
 
 extern "C" {
+
+namespace {
+__global__ void delay_kernel(unsigned long long cycles) {
+  const unsigned long long t0 = clock64();
+  while (clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(8);
+}
+// The runtime creates the queue of a copy engine (SDMA) the first time it turns to that engine, inside the
+// hipMemcpyAsync call that needs it: 5-7 ms on the host, during which nothing else is issued.  Which engine a copy gets
+// depends on what is in flight when it is issued, so a context met such calls in its first frame (+10 ms) and ONCE
+// MORE in one of frames 2 to 6 -- the first frame whose DC-group sections leave beside its AC sections: a step of 12 ms
+// among steps of 5.2, followed by three or four slow ones (the GPU's clock coming back up), in the driver's warm-up
+// or in its timed steps as luck had it (tools/outlier_probe.sh: 5 of 8 runs; JXLT_TRACE_EVENTS names the call; with
+// HSA_ENABLE_SDMA=0 no such step ever, but every step 5.7 ms -- blit kernels beside the packing kernels).  So the copy
+// commands of a frame are issued once when the first context of a device is made -- device-to-host copies of section
+// size on the hand-over streams, side by side, each WAITING for an event of the main stream that has not happened yet
+// (mode 2: 2 of 8 runs still met an engine for the first time later), and more of them in flight than a frame ever
+// has, over four streams (mode 3, the default: 0 of 16 runs; first frame 11 instead of 22-25 ms).
+void CopyWarmup(jxlt_context* ctx, int mode) {
+  const size_t n = (size_t)12 << 20;
+  uint8_t *dsrc = nullptr, *hdst = nullptr;
+  hipEvent_t ev = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&dsrc), 3 * n) == hipSuccess &&
+      hipHostMalloc(reinterpret_cast<void**>(&hdst), 3 * n, hipHostMallocDefault) == hipSuccess &&
+      hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+    for (int rep = 0; rep < 2; rep++) {
+      if (mode >= 2) {
+        hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, ctx->stream, 200000ull);  // ~2 ms at 100 MHz
+        (void)hipEventRecord(ev, ctx->stream);
+        (void)hipStreamWaitEvent(ctx->dc_copy_stream, ev, 0);
+        (void)hipStreamWaitEvent(ctx->copy_stream, ev, 0);
+      }
+      (void)hipMemcpyAsync(hdst + n, dsrc + n, n * 2 / 3, hipMemcpyDefault, ctx->dc_copy_stream);
+      (void)hipMemcpyAsync(hdst, dsrc, n / 4, hipMemcpyDefault, ctx->copy_stream);
+      (void)hipMemcpyAsync(hdst + n / 4, dsrc + n / 4, n / 2, hipMemcpyDefault, ctx->copy_stream);
+      (void)hipMemcpyAsync(hdst + 2 * n, dsrc + 2 * n, n, hipMemcpyDefault, ctx->copy_stream);
+      if (mode >= 3) {  // (more copies in flight than a frame ever has: every engine the runtime may turn to)
+        (void)hipStreamWaitEvent(ctx->aux_stream, ev, 0);
+        (void)hipStreamWaitEvent(ctx->upload_stream, ev, 0);
+        (void)hipMemcpyAsync(hdst + n, dsrc + n, n / 3, hipMemcpyDefault, ctx->aux_stream);
+        (void)hipMemcpyAsync(hdst + n + n / 3, dsrc + n + n / 3, n / 3, hipMemcpyDefault, ctx->upload_stream);
+        (void)hipMemcpyAsync(hdst + n / 2, dsrc + n / 2, n / 3, hipMemcpyDefault, ctx->dc_copy_stream);
+        (void)hipMemcpyAsync(hdst + 2 * n, dsrc + 2 * n, n / 5, hipMemcpyDefault, ctx->aux_stream);
+        (void)hipStreamSynchronize(ctx->aux_stream);
+        (void)hipStreamSynchronize(ctx->upload_stream);
+      }
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipStreamSynchronize(ctx->copy_stream);
+      (void)hipStreamSynchronize(ctx->dc_copy_stream);
+    }
+  }
+  if (ev) (void)hipEventDestroy(ev);
+  if (dsrc) (void)hipFree(dsrc);
+  if (hdst) (void)hipHostFree(hdst);
+  (void)hipGetLastError();
+}
+}  // namespace
 
 int jxlt_context_create(int device_ordinal, jxlt_context** out) {
   if (!out) return JXLT_ERR_INVALID_ARGUMENT;
@@ -510,6 +555,14 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
     jxlt_context_destroy(ctx);  // (handles partially built contexts: every handle is checked for null)
     return e == hipErrorOutOfMemory ? JXLT_ERR_OUT_OF_MEMORY : JXLT_ERR_NO_DEVICE;
   }
+  // The copy pattern of a frame, and then some, once per device and process (CopyWarmup; JXLT_COPY_WARMUP=0: not at
+  // all, 1 / 2: the weaker forms that were tried first).
+  static const int copy_warmup = [] {
+    const char* e2 = getenv("JXLT_COPY_WARMUP");
+    return e2 ? atoi(e2) : 3;
+  }();
+  static std::atomic<bool> warmed[64];
+  if (copy_warmup && device_ordinal >= 0 && device_ordinal < 64 && !warmed[device_ordinal].exchange(true)) CopyWarmup(ctx, copy_warmup);
   ctx->counted = true;
   DeviceBlockCache::Get().ContextCreated(ctx->device);
   *out = ctx;
@@ -2121,6 +2174,16 @@ bool DcDeliverByKernel(const jxlt_context* ctx, int kind) {
   return on && kind == 0 && !ctx->pack[0].streamed;
 }
 
+// hipMemcpyAsync with the time the CALL took on the host (JXLT_TRACE_EVENTS: calls of more than 0.5 ms are reported)
+hipError_t TimedCopy(void* dst, const void* src, size_t bytes, hipStream_t stream, const char* what) {
+  if (!TraceEventsOn()) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, stream);
+  const auto t0 = std::chrono::steady_clock::now();
+  const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, stream);
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (ms > 0.5) fprintf(stderr, "jxlt slow call: hipMemcpyAsync (%s, %zu bytes) took %.3f ms on the host\n", what, bytes, ms);
+  return e;
+}
+
 // The hand-over of the measured and (being) written sections of `kind` to `dst` (asynchronous, kernels on the copy
 // stream that store to the destination themselves -- page-locked host memory or device memory): behind every launch
 // of the writing pass the whole sections it completed leave, while later launches are still packing.  The kernels
@@ -2184,7 +2247,7 @@ int EnqueueDeliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_section
         // (the launch's word may have been set by the launch itself, before its end: the copy waits for the end)
         HIP_TRY(ctx, hipStreamWaitEvent(out_stream, ps.launch_done[i], 0));
         TraceMark(ctx, kind ? "AC copy start" : "DC copy start", out_stream);
-        HIP_TRY(ctx, hipMemcpyAsync(dst + off[s_lo], ps.packed.p + off[s_lo], off[s_hi] - off[s_lo], hipMemcpyDefault, out_stream));
+        HIP_TRY(ctx, TimedCopy(dst + off[s_lo], ps.packed.p + off[s_lo], off[s_hi] - off[s_lo], out_stream, kind ? "AC sections" : "DC-group sections"));
         TraceMark(ctx, kind ? "AC copy done" : "DC copy done", out_stream);
       }
       s_lo = s_hi;
@@ -2207,8 +2270,8 @@ int EnqueueDeliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_section
         if (off[s_hi] > off[s_lo]) {
           HIP_TRY(ctx, hipStreamWaitEvent(out_stream, ps.launch_done[i], 0));
           TraceMark(ctx, kind ? "AC copy start" : "DC copy start", out_stream);
-          HIP_TRY(ctx, hipMemcpyAsync(dst + shift + (int64_t)off[s_lo], ps.packed.p + off[s_lo], off[s_hi] - off[s_lo],
-                                      hipMemcpyDefault, out_stream));
+          HIP_TRY(ctx, TimedCopy(dst + shift + (int64_t)off[s_lo], ps.packed.p + off[s_lo], off[s_hi] - off[s_lo], out_stream,
+                                 kind ? "AC sections" : "DC-group sections"));
           TraceMark(ctx, kind ? "AC copy done" : "DC copy done", out_stream);
         }
         s_lo = s_hi;

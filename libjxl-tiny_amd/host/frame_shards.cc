@@ -577,9 +577,6 @@ int EnsureLocalRegion(jxlt_multi_encoder* enc, size_t xsize, size_t ysize) {
     enc->error = "cannot allocate the page-locked output region (no usable HIP device?)";
     return JXLT_ERR_NO_DEVICE;
   }
-  // (written once by the CPU: a device's first write to an untouched part of page-locked memory runs at a thirtieth
-  // of the link's rate)
-  memset(g.base, 0, bytes);
   g.bytes = bytes;
   g.ctl = reinterpret_cast<Control*>(g.base);
   InitControl(g.ctl, g.world, max_sections, want_out, bytes);
@@ -702,7 +699,6 @@ int RunJob(jxlt_multi_encoder* enc, const uint8_t** bytes, size_t* size) {
         enc->error = "cannot allocate the page-locked output region";
         return JXLT_ERR_OUT_OF_MEMORY;
       }
-      memset(enc->group.base, 0, bytes_needed);  // (CPU's first touch, as above)
       enc->group.bytes = bytes_needed;
       enc->group.ctl = reinterpret_cast<Control*>(enc->group.base);
       InitControl(enc->group.ctl, world, max_sections, worst, bytes_needed);
@@ -879,8 +875,6 @@ int jxlt_shard_group_open(const char* shm_name, int rank, int world, size_t outp
   g->name = shm_name;
   if (rank == 0) {
     jxlt::InitControl(g->ctl, world, max_sections, (output_capacity + 4095) & ~size_t(4095), bytes);
-    // (the segment's pages come into being here, not under the devices' first copies into them)
-    memset(g->output(), 0, static_cast<size_t>(g->ctl->output_capacity));
   } else if (g->ctl->magic != jxlt::kMagic || g->ctl->world != static_cast<uint32_t>(world) ||
              g->ctl->region_bytes != bytes) {
     munmap(map, bytes);
