@@ -476,6 +476,9 @@ void CopyWarmup(jxlt_context* ctx, int mode) {
         // engines after a warm-up of eight: 8.2 instead of 6.7 ms per frame over ten frames)
         for (int k = 0; k < 20; k++)
           (void)hipMemcpyAsync(hdst + (size_t)k * (n / 8), dsrc + (size_t)k * (n / 8), n / 8, hipMemcpyDefault, four[k & 3]);
+        // (... and the other direction: frames that come over PCIe are uploaded in rows, several copies in flight)
+        for (int k = 0; k < 8; k++)
+          (void)hipMemcpyAsync(dsrc + (size_t)k * (n / 8), hdst + (size_t)k * (n / 8), n / 8, hipMemcpyDefault, four[k & 1]);
         (void)hipStreamSynchronize(ctx->aux_stream);
         (void)hipStreamSynchronize(ctx->upload_stream);
       }
