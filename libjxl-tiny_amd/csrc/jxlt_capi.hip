@@ -2186,6 +2186,8 @@ hipError_t TimedCopy(void* dst, const void* src, size_t bytes, hipStream_t strea
   const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, stream);
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (ms > 0.5) fprintf(stderr, "jxlt slow call: hipMemcpyAsync (%s, %zu bytes) took %.3f ms on the host\n", what, bytes, ms);
+  static const bool every = getenv("JXLT_TRACE_COPY_CALLS") != nullptr;
+  if (every) fprintf(stderr, "jxlt copy call: %s %zu bytes %.1f us on the host\n", what, bytes, ms * 1e3);
   return e;
 }
 
