@@ -80,9 +80,9 @@ struct jxlt_context {
   // DC-group tokenisation + AC tokenisation of one row of DC groups run on `aux_stream` as soon as that row's
   // tile_kernel launch is done, i.e. beside the next row's tile_kernel (latency-bound kernels under a VALU-bound one)
   hipStream_t aux_stream = nullptr;
-  // The DC-group sections are packed on a stream of their own, of the highest priority the device offers: their
-  // code is ready while token_kernel is still running, and behind token_kernel on the main stream their packing
-  // (and the 5 MB they send over the link, 16384^2) would stand in front of the AC sections'.
+  // The DC-group sections are packed on a stream of their own: their code is ready while token_kernel is still
+  // running, and behind token_kernel on the main stream their packing (and the 5 MB they send over the link, 16384^2)
+  // would stand in front of the AC sections'.
   hipStream_t dc_pack_stream = nullptr;
   // A hand-over of the DC-group sections asked for before their sizes have arrived (the copy commands need the sizes):
   // kept here and issued as soon as they are there -- from inside whatever wait of the library comes next (WaitWord),
@@ -523,9 +523,20 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
   if (e == hipSuccess) {
+    // An ORDINARY stream.  Until the end of round 4 it was created with the device's highest priority -- which bought
+    // nothing (the DC-group sections' kernels do not get in beside token_kernel either way) and could
+    // cost 18 %: in a process whose FIRST HIP streams are this context's (the context made before the application's
+    // own first allocation or kernel), every kernel of the main stream ran slower -- tile12_kernel 4.75 instead of
+    // 4.05 ms, the same wave-cycles in 16 % more busy cycles -- as long as that high-priority stream existed
+    // (bench.py with BENCH_CONTEXT_FIRST=1, tools/alloc_order_probe.sh; neither the address translation nor the
+    // instruction cache counters move).  (experiment knob: JXLT_DC_STREAM_PRIORITY=1)
+    static const bool with_priority = [] {
+      const char* e2 = getenv("JXLT_DC_STREAM_PRIORITY");
+      return e2 && atoi(e2) != 0;
+    }();
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    e = hipStreamCreateWithPriority(&ctx->dc_pack_stream, hipStreamNonBlocking, greatest);
+    e = with_priority ? hipStreamCreateWithPriority(&ctx->dc_pack_stream, hipStreamNonBlocking, greatest) : hipErrorNotSupported;
     if (e != hipSuccess) {  // (a runtime without stream priorities: an ordinary stream does the same work)
       (void)hipGetLastError();
       e = hipStreamCreateWithFlags(&ctx->dc_pack_stream, hipStreamNonBlocking);
@@ -1511,7 +1522,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   // way to the host, while the host builds the codes (upper bound of the record count: the buffer's capacity).
   ctx->pack[0].planned = ctx->pack[1].planned = false;
   // Where the sections are packed: the AC sections behind token_kernel on the main stream; the DC-group sections on
-  // their own stream of high priority, behind the DC-group kernels only (experiment knob JXLT_DC_PACK_STREAM=0: on
+  // their own stream, behind the DC-group kernels only (experiment knob JXLT_DC_PACK_STREAM=0: on
   // the main stream as well, rounds 1-3).
   static const int dc_own_stream_knob = [] {
     const char* e = getenv("JXLT_DC_PACK_STREAM");
