@@ -510,6 +510,19 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
   }
   jxlt_context* ctx = new jxlt_context;
   ctx->device = device_ordinal;
+  {
+    // (experiment knob JXLT_STREAM_SKEW=<k>: k streams created -- and kept -- in front of the context's own, which shifts
+    // the runtime's round-robin assignment of streams to its four hardware queues)
+    static const int skew = [] {
+      const char* e2 = getenv("JXLT_STREAM_SKEW");
+      return e2 ? atoi(e2) : 0;
+    }();
+    if (hipSetDevice(device_ordinal) == hipSuccess)
+      for (int k = 0; k < skew; k++) {
+        hipStream_t dummy = nullptr;
+        (void)hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking);
+      }
+  }
   if ((e = hipSetDevice(device_ordinal)) != hipSuccess ||
       (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipMalloc(reinterpret_cast<void**>(&ctx->d_tab), sizeof(DeviceTables))) != hipSuccess) {
