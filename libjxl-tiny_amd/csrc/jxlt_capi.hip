@@ -555,6 +555,28 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
       e = hipStreamCreateWithFlags(&ctx->dc_pack_stream, hipStreamNonBlocking);
     }
   }
+  if (e == hipSuccess) {
+    // (experiment knob JXLT_STREAM_ROLES=<five digits>: which of the five streams made above -- in the order copy,
+    // DC copy, upload, auxiliary, DC packing, i.e. on the runtime's hardware queues 1, 2, 3, 0, 1 when the main stream
+    // is on 0 -- plays which role; "01234" is the order as made)
+    const char* roles = getenv("JXLT_STREAM_ROLES");
+    if (roles && strlen(roles) == 5) {
+      const hipStream_t made[5] = {ctx->copy_stream, ctx->dc_copy_stream, ctx->upload_stream, ctx->aux_stream, ctx->dc_pack_stream};
+      bool used[5] = {false, false, false, false, false};
+      bool ok = true;
+      for (int k = 0; k < 5; k++) {
+        const int d = roles[k] - '0';
+        if (d < 0 || d > 4 || used[d]) ok = false; else used[d] = true;
+      }
+      if (ok) {
+        ctx->copy_stream = made[roles[0] - '0'];
+        ctx->dc_copy_stream = made[roles[1] - '0'];
+        ctx->upload_stream = made[roles[2] - '0'];
+        ctx->aux_stream = made[roles[3] - '0'];
+        ctx->dc_pack_stream = made[roles[4] - '0'];
+      }
+    }
+  }
   if (e == hipSuccess) e = hipEventCreate(&ctx->aux_done);
   for (auto& ev : ctx->ev)
     if (e == hipSuccess) e = hipEventCreate(&ev);
