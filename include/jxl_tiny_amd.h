@@ -30,7 +30,10 @@ extern "C" {
 #define JXLT_ERR_INVALID_ARGUMENT (-1)
 #define JXLT_ERR_NO_DEVICE (-2)   /* no usable HIP device / HIP runtime error */
 #define JXLT_ERR_OUT_OF_MEMORY (-3)
-#define JXLT_ERR_UNSUPPORTED (-4) /* e.g. image that fits one 8x8 block (reference traps) */
+#define JXLT_ERR_UNSUPPORTED (-4) /* image that fits one 8x8 block (reference traps); a frame with values the     \
+                                     codestream cannot carry: a quantised coefficient whose token needs more than   \
+                                     16 bits (reference: debug assert only, enc_bit_writer.cc:120) or a DC value    \
+                                     beyond int16 -- reported by every call about that encode */
 #define JXLT_ERR_INTERNAL (-5)
 
 /* Scalars of the reference's DistanceParams (enc_frame.cc:104-156) that the

@@ -218,6 +218,7 @@ struct jxlt_context {
   PinnedBuf<uint32_t> h_lut_overflow;
   jxlt_params last_params = {};
   bool overflow_checked = true;
+  int encode_status = JXLT_OK;  // JXLT_ERR_UNSUPPORTED: the last encode met values the format cannot carry
   size_t overflow_slabs = 0;   // launches of the last encode
   uint32_t exact_reruns = 0;   // encodes of this context in which some tile was redone
   uint32_t tiles_redone = 0;   // ... tiles of the last encode
@@ -1073,6 +1074,9 @@ int jxlt_image_size(const jxlt_context* ctx, size_t* xsize, size_t* ysize) {
 }
 
 namespace {
+const char kUnsupportedValues[] =
+    "the frame has values the codestream cannot carry (a quantised coefficient beyond 16 bits or a DC value beyond "
+    "int16: samples around 1e38 or infinities)";
 int EnqueuePlan(jxlt_context* ctx, int kind, uint64_t rec_bound, hipStream_t stream);  // (below)
 int WaitSizes(jxlt_context* ctx, int kind);  // (below)
 
@@ -1304,6 +1308,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   A.inv_scale = params->inv_scale;
   A.scale_dc = params->scale_dc;
   A.x_qm_mul = XQmMultiplier(params->x_qm_scale);
+  SetStrategyScalars(&A);
   A.flags = (params->flags & JXLT_FLAG_FORCE_DCT8) ? 1u : 0u;
   A.flags |= params->flags & 0x1F00u;  // profiling only: truncate tile_kernel after phase n-1 (tools/profile_phases.py)
   A.tab = ctx->d_tab;
@@ -1369,11 +1374,13 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   const size_t nslabs = pieces.size();
   {
     int rc3;
-    if ((rc3 = EnsureDevice(ctx, &ctx->lut_overflow, nslabs)) != JXLT_OK) return rc3;
-    if ((rc3 = EnsurePinned(ctx, &ctx->h_lut_overflow, nslabs)) != JXLT_OK) return rc3;
+    // (+ 1: the frame's count of tiles with values the format cannot carry, TileArgs::unsupported)
+    if ((rc3 = EnsureDevice(ctx, &ctx->lut_overflow, nslabs + 1)) != JXLT_OK) return rc3;
+    if ((rc3 = EnsurePinned(ctx, &ctx->h_lut_overflow, nslabs + 1)) != JXLT_OK) return rc3;
   }
   A.lut_overflow = ctx->lut_overflow.p;
   A.overflow_tiles = ctx->overflow_tiles.p;
+  A.unsupported = ctx->lut_overflow.p + nslabs;
   // the frame's counters and histograms start at zero: ONE small kernel (four hipMemsetAsync were four fill kernels,
   // 5-9 us apart, in front of every frame's first tile_kernel launch)
   {
@@ -1385,7 +1392,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
     C.p[2] = ctx->dc_nac.p;
     C.n[2] = (uint32_t)ndc;
     C.p[3] = ctx->lut_overflow.p;
-    C.n[3] = (uint32_t)nslabs;
+    C.n[3] = (uint32_t)nslabs + 1;
     const uint32_t most = std::max(std::max(C.n[0], C.n[1]), std::max(C.n[2], C.n[3]));
     hipLaunchKernelGGL(clear_counters_kernel, dim3((most + 255) / 256), dim3(256), 0, ctx->stream, C);
     HIP_TRY(ctx, hipGetLastError());
@@ -1500,7 +1507,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
     if (beside) {
       HIP_TRY(ctx, hipStreamWaitEvent(chain_stream, ctx->dc_elementwise_done, 0));
       const PublishSeg segs[2] = {{ctx->hist.p + 64 * 64, ctx->h_hist.p + 64 * 64, 64 * 64},
-                                  {ctx->lut_overflow.p, ctx->h_lut_overflow.p, nslabs}};
+                                  {ctx->lut_overflow.p, ctx->h_lut_overflow.p, nslabs + 1}};
       const int rcp = EnqueuePublish(ctx, chain_stream, segs, 2, nullptr, nullptr, &ctx->mail.p->dc_hist_seq, frame_seq);
       if (rcp != JXLT_OK) return rcp;
       HIP_TRY(ctx, hipEventRecord(ctx->dc_kernels_done, chain_stream));
@@ -1513,7 +1520,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
       HIP_TRY(ctx, hipEventRecord(ctx->dc_kernels_done, tok_stream));
       if (split) HIP_TRY(ctx, hipStreamWaitEvent(tok_stream, ctx->dc_elementwise_done, 0));
       const PublishSeg segs[2] = {{ctx->hist.p + 64 * 64, ctx->h_hist.p + 64 * 64, 64 * 64},
-                                  {ctx->lut_overflow.p, ctx->h_lut_overflow.p, nslabs}};
+                                  {ctx->lut_overflow.p, ctx->h_lut_overflow.p, nslabs + 1}};
       const int rcp = EnqueuePublish(ctx, tok_stream, segs, 2, nullptr, nullptr, &ctx->mail.p->dc_hist_seq, frame_seq);
       if (rcp != JXLT_OK) return rcp;
     }
@@ -1610,13 +1617,19 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   ctx->profiled = true;  // the five stage events are always recorded (a few microseconds per frame)
   ctx->last_params = *params;
   ctx->overflow_checked = false;
+  ctx->encode_status = JXLT_OK;
   return JXLT_OK;
 }
 
 // First host synchronisation point after an enqueue: how many tiles did the device redo with computed roots
 // (statistics only: jxlt_encode_stats; the redo itself needs nothing from the host).
 int ResolveRootTableOverflow(jxlt_context* ctx) {
-  if (!ctx->encoded || ctx->overflow_checked) return JXLT_OK;
+  if (!ctx->encoded) return JXLT_OK;
+  if (ctx->overflow_checked) {
+    // (an encode that met values the format cannot carry stays refused until the next one is enqueued)
+    if (ctx->encode_status != JXLT_OK) ctx->error = kUnsupportedValues;
+    return ctx->encode_status;
+  }
   {  // (the counts arrive with the DC histogram)
     // (off unless JXLT_WAIT_SLEEP=1: with it the 16384^2 step is 5.19-5.20 against 5.15-5.19 ms, one run 5.59 -- a
     // sleeping thread depends on the host's scheduler for its wake-up --, 48 resident 3840x2160 frames over eight lanes
@@ -1647,7 +1660,14 @@ int ResolveRootTableOverflow(jxlt_context* ctx) {
   for (size_t i = 0; i < ctx->overflow_slabs; i++) n += ctx->h_lut_overflow.p[i];
   ctx->tiles_redone = n;
   if (n != 0) ctx->exact_reruns++;
-  return JXLT_OK;
+  if (ctx->h_lut_overflow.p[ctx->overflow_slabs] != 0) {
+    // A quantised AC coefficient whose token does not fit the format's 16 bits, or a quantised DC value beyond int16
+    // (samples around 1e38, infinities): the reference traps on it in debug builds (enc_bit_writer.cc:120) and writes
+    // a stream no decoder accepts otherwise.  Refused, for every later call about this encode.
+    ctx->encode_status = JXLT_ERR_UNSUPPORTED;
+    ctx->error = kUnsupportedValues;
+  }
+  return ctx->encode_status;
 }
 }  // namespace
 

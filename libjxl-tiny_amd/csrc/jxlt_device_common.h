@@ -19,7 +19,10 @@ namespace jxlt_dev {
 // Constant tables, resident in HBM (built on the host by jxlt_capi.hip).
 struct DeviceTables {
   float weights[576];      // dequant weights (quant_weights.cc:17-134)
-  float inv_weights[576];  // float(1.0 / w), LLF zeroed (quant_weights.cc:144-153)
+  // float(1.0 / w), LLF zeroed (quant_weights.cc:144-153) -- TIMES the normalisation the kernels' transforms leave
+  // out: tile_kernel keeps its coefficients unnormalised (kDct8Norm / kDct16Norm times the reference's, see
+  // block_dct8x8), and every use of a coefficient is a product with one of these tables
+  float inv_weights[576];
   float inv_qac[256];      // float(1.0 / (double)(scale * q)) (enc_group.cc:289)
   uint16_t table_offset[9];  // host copy of quant_table_offset() below (checked when the tables are built)
   uint8_t coeff_order[192];
@@ -31,12 +34,18 @@ struct DeviceTables {
   float sqrt_lut[1024];        // sqrtf(i), correctly rounded (EstimateEntropy's cost of a coefficient)
   // What the quantisation needs to know of scan position p (tile_kernel quantises in scan order, lane = scan
   // position), per position class -- 0: DCT8, 1 / 2: first / second 64 positions of a two-block transform:
-  // [0..2] InvMatrix of x, y, b at the position's coefficient, [3] dequantisation weight of y, [4..6] zeroing
-  // threshold of x, y, b (enc_group.cc:227-242); scan_slot: where the staging area keeps that coefficient
-  // (bit 6: in the transform's second block).
+  // [0..2] InvMatrix of x, y, b at the position's coefficient (normalisation included, as in inv_weights), [3]
+  // dequantisation weight of y times kDct8Norm / kDct16Norm (the dequantised y meets unnormalised coefficients),
+  // [4..6] zeroing threshold of x, y, b (enc_group.cc:227-242); scan_slot: where the staging area keeps that
+  // coefficient (bit 6: in the transform's second block).
   float scan_consts[3][7][64];
   uint8_t scan_slot[3][64];
+  // EstimateEntropy's cost of coding the number of non-zeros of a channel (enc_ac_strategy.cc:133-139), as a function
+  // of that number n = 0 .. 128: kZerosMul * (CeilLog2Nonzero(nbits + 17) + nbits), nbits = CeilLog2Nonzero(n + 1) + 1
+  // -- twenty integer instructions per channel and estimate in the kernel until round 4, a table word now.
+  float zeros_cost[132];
 };
+constexpr int kZerosCostEntries = 129;
 
 // The quantiser's zeroing threshold (enc_group.cc:227-242) of channel c in quadrant `quad` of a one-block
 // (8x8) or two-block transform; quadrants: 8x8: (row >= 4) * 2 + (column >= 4); two-block, coefficient
@@ -52,6 +61,15 @@ __host__ __device__ inline float quant_zeroing_threshold(int c, bool two_block, 
   }
   return quad == 0 ? t0 : quad == 1 ? t1 : quad == 2 ? t2 : t3;
 }
+
+// The kernels' block transforms leave out the reference's normalisation (1/8 per 8-point pass, 1/16 per 16-point
+// pass, StoreToBlockAndScale, enc_transforms-inl.h:387-390): their coefficients are kDct8Norm (one-block) or
+// kDct16Norm (two-block) times the reference's.  Powers of two commute exactly with every rounded operation, and a
+// coefficient is only ever used in products with table values (InvMatrix in the entropy estimate, the chroma-from-luma
+// terms and the quantisation; the dequantisation weight on the way back), so the factor lives in the host-built
+// tables and costs nothing: 48 multiplications per thread less.
+constexpr float kDct8Norm = 64.0f;
+constexpr float kDct16Norm = 128.0f;
 
 // Offset of quant table n = strategy * 3 + channel inside weights[] / inv_weights[]: three
 // 64-entry DCT8 tables, then three 128-entry tables shared by DCT16X8 and DCT8X16.
@@ -86,6 +104,10 @@ struct TileArgs {
   float x_qm_mul;  // 1.25^(x_qm_scale-2)
   float strategy_distance;  // distance behind mul8x8 / mul16x8 (enc_ac_strategy.cc:178-185: the
                             // reference freezes them at its first call; normally == distance)
+  // Wave-uniform factors of the strategy search, computed once on the host (jxlt_host_tables.h: SetStrategyScalars;
+  // IEEE float arithmetic, what the kernels computed per estimate until round 4): mul8x8 / mul16x8 of
+  // enc_ac_strategy.cc:178-185 from strategy_distance, 3 * mul8x8 (:203), cost_of_1 (:93-96) from distance
+  float mul8x8, bias8x8, mul16x8, cost_of_1;
   uint32_t flags;  // bit0: force DCT8
   const DeviceTables* tab;
   // outputs (image-absolute grids)
@@ -103,6 +125,11 @@ struct TileArgs {
   uint32_t* dc_nac;     // per DC group: number of first blocks (atomic)
   uint32_t* lut_overflow;    // [1] number of tiles of this launch that met a quantised magnitude beyond the root table
   uint32_t* overflow_tiles;  // their indices (capacity: the launch's tiles): redone by tile*_kernel_redo
+  // [1] (one word per frame) incremented for every tile / wave that met a value the format cannot carry: a quantised
+  // AC coefficient whose token does not fit 16 bits (the reference asserts it in debug builds only,
+  // enc_bit_writer.cc:120, and writes a broken stream otherwise) or a quantised DC value beyond int16 (DCGroupData's
+  // type, dc_group_data.h:19-37).  The C ABI turns a non-zero count into JXLT_ERR_UNSUPPORTED.
+  uint32_t* unsupported;
   // debug (may be null)
   float* dbg_xyb[3];
   float* dbg_qf;
@@ -145,6 +172,33 @@ struct TokenArgs {
 // this as nothing.
 #ifndef JXLT_LAUNDER_VGPR
 #define JXLT_LAUNDER_VGPR(x) asm volatile("" : "+v"(x))
+#endif
+
+// x is "written" here as far as the compiler can tell (no instruction: it holds whatever the register held).  For
+// values that are computed under a condition and only ever used under the same condition: without a definition on
+// the other path the compiler zero-initialises them in front of the branch -- 48 v_mov per thread for the coefficient
+// registers of tile_kernel's transform phase.  The CPU execution model defines this as x = 0.
+#ifndef JXLT_DEFINE_VGPR
+#define JXLT_DEFINE_VGPR(x) asm volatile("" : "=v"(x))
+#endif
+
+// The root table's byte offset as the device uses it.  (The CPU execution model -- where an offset beyond the table
+// would leave the process's memory instead of reading a harmless word -- wraps it into the table.)
+#ifndef JXLT_LUT_WRAP
+#define JXLT_LUT_WRAP(off) (off)
+#endif
+
+// Pointers to read-only bytes / floats in global memory, for the places that make a pointer opaque
+// (JXLT_LAUNDER_SGPR) and have to say what it points into afterwards.  (The CPU execution model: plain pointers.)
+#ifndef JXLT_GLOBAL_POINTER_TYPES
+#define JXLT_GLOBAL_POINTER_TYPES
+typedef __attribute__((address_space(1))) const char* JxltGlobalBytes;
+typedef __attribute__((address_space(1))) const float* JxltGlobalFloats;
+#endif
+
+// The same for a wave-uniform value in scalar registers (a pointer, an index).
+#ifndef JXLT_LAUNDER_SGPR
+#define JXLT_LAUNDER_SGPR(x) asm volatile("" : "+s"(x))
 #endif
 
 // Nothing is kept in registers across this point that the compiler could re-read from memory instead, and no
@@ -193,11 +247,32 @@ JXLT_DI float octet_xor(float v) {
 }
 
 // SumOfLanes over the 8 lanes of an octet: (i)+(i^4), (i)+(i^2), (i)+(i^1).
+// Four DPP-fused adds (16 issue cycles).  Left to the compiler the first step is a zero-initialising move, two
+// bank-masked DPP moves and an add, and the last one a DPP move and an add: 22 cycles -- it fuses only the middle
+// step (GCNDPPCombine does not merge a DPP move whose bank mask is partial).  Floating-point addition is
+// commutative, so "partner + own" equals the reference's "own + partner" bit for bit.
+// (s_nop 1: a VALU write of a register is followed by two wait states before a DPP instruction may read it; the
+// compiler's hazard recogniser does not look into inline assembly.  The CPU execution model of the tests defines
+// JXLT_OCTET_SUM_PORTABLE and runs the three exchange steps below.)
 JXLT_DI float octet_sum(float v) {
+#ifdef JXLT_OCTET_SUM_PORTABLE
   v = v + octet_xor<4>(v);
   v = v + octet_xor<2>(v);
   v = v + octet_xor<1>(v);
   return v;
+#else
+  float r;
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+      : "=&v"(r)
+      : "v"(v));
+  return r;
+#endif
 }
 JXLT_DI int octet_sum_int(int v) {
   v = v + octet_xor_i<4>(v);
@@ -350,6 +425,28 @@ JXLT_DI float cube_root_and_add(float x, float add) {
 JXLT_DI float clamped_cube_root_and_add(float mixed, float add) {
 #ifdef JXLT_CBRT_REFERENCE_SHAPE
   return cube_root_and_add(zero_if_negative(mixed), add);
+#elif !defined(JXLT_CBRT_SELECT)
+  // Round 5: ONE v_max instead of a compare and a select (all three of the 4-cycle kind).  An input at or below
+  // kFloor = 2^-90 is replaced by kFloor, whose result is `add` exactly -- as the reference's for an input clamped to
+  // zero: the cube root of 2^-90 is 2^-30, far below half an ulp of add (2^-27 for add = -0.1559...), and r stays
+  // finite on the way (r ~ x^(-1/3) = 2^30, r^4 = 2^120).  Inputs in (0, 2^-90] -- biased mixes that cancel to
+  // within 1e-27: where the reference's own iteration overflows (r^4 > 2^128 below 2^-96) -- are outside the domain
+  // of the guarantee like every other route to a NaN.
+  const float k1_3 = 1.0f / 3, k4_3 = 4.0f / 3;
+  const float kFloor = 8.0779356694631609e-28f;  // 2^-90
+  const float x = fmaxf(mixed, kFloor);
+  const float xa_3 = k1_3 * x;
+  const int32_t e = (int32_t)__builtin_amdgcn_ubfe(__float_as_uint(x), 23, 8);
+  float r = __int_as_float(e * -0x002AAAAA + 0x54800000);
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const float r2 = r * r;
+    r = nfma32(xa_3, r2 * r2, k4_3 * r);
+  }
+  float r2 = r * r;
+  r = fma32(k1_3, nfma32(x, r2 * r2, r), r);
+  r2 = r * r;
+  return fma32(r2, x, add);
 #else
   const float k1_3 = 1.0f / 3, k4_3 = 4.0f / 3;
   const float x = mixed;
@@ -543,25 +640,69 @@ JXLT_DI void octet_transpose(float* v, float* sc, int l) {
   }
 }
 
+// The same transpose through HALF an area: 32 floats per octet, the 256 floats of a wave's eight octets side by side
+// (round 5: the pair octets of the 12-wave kernel, which have no area of 72 floats -- the 64 there are belong to the
+// candidate octets -- and until round 4 transposed in registers: 24 DPP moves + 16 selects + a dozen copies, ~175 issue
+// cycles each, six per thread, the longest path through the transform phase).  Rows 0-3 go to the area, lanes 0-3 read
+// their rows back; then rows 4-7 and lanes 4-7.  Element (row r of the half, column c) of octet o lives at
+// r * 64 + o * 8 + (c ^ 4 * (r & 1)): a store instruction's 64 lanes fill 64 consecutive floats (no bank conflict,
+// immediate row offsets), and the 32 lanes of a 16-byte load -- octets o and o + 4 share a bank group, rows of
+// different parity do not -- meet four to a bank group, which is what 512 bytes over 32 banks take anyway.
+// An octet reads only what its own eight lanes wrote (octets of a wave may have diverged: edge tiles).
+JXLT_DI void octet_transpose_half(float* v, float* wave_area, int o, int l) {
+  float* const w_even = wave_area + o * 8 + l;
+  float* const w_odd = wave_area + o * 8 + (l ^ 4);
+  const int lr = l & 3;
+  const float* const r_lo = wave_area + lr * 64 + o * 8 + 4 * (lr & 1);  // columns 0-3 of row lr (of the half)
+  const float* const r_hi = wave_area + lr * 64 + o * 8 + 4 * ((lr & 1) ^ 1);
+  float4 a, b;
+  w_even[0] = v[0];
+  w_odd[64] = v[1];
+  w_even[128] = v[2];
+  w_odd[192] = v[3];
+  JXLT_OCTET_SYNC();
+  if (l < 4) {
+    a = *reinterpret_cast<const float4*>(r_lo);
+    b = *reinterpret_cast<const float4*>(r_hi);
+  }
+  JXLT_OCTET_SYNC();
+  w_even[0] = v[4];
+  w_odd[64] = v[5];
+  w_even[128] = v[6];
+  w_odd[192] = v[7];
+  JXLT_OCTET_SYNC();
+  if (l >= 4) {
+    a = *reinterpret_cast<const float4*>(r_lo);
+    b = *reinterpret_cast<const float4*>(r_hi);
+  }
+  JXLT_OCTET_SYNC();  // (the next transpose overwrites the area)
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
 // Block transforms.  `px` points at the block's top-left sample in an LDS plane
 // of row pitch `pitch`; l = lane within the octet.  Results are the lane's
 // "rows of 8": coefficient index i = r*8 + l (the reference's SIMD layout).
 
 // The reference scales by 1/N after each 1-D pass (StoreToBlockAndScale, :387-390).  Those
 // factors are powers of two, and scaling by a power of two commutes exactly with every
-// rounded add/mul/fma of the second pass (no over/underflow at these magnitudes: pixel
-// differences are 0 or >= 1 ulp of O(0.1) values), so both are applied once at the end.
+// rounded add/mul/fma (no over/underflow at these magnitudes: pixel differences are 0 or
+// >= 1 ulp of O(0.1) values), so they are not applied here at all: the results are kDct8Norm /
+// kDct16Norm times the reference's coefficients and the tables they are multiplied with carry
+// the inverse (DeviceTables::inv_weights, scan_consts).
 
 // ComputeScaledDCT<8,8> (enc_transforms-inl.h:527-546): i = h*8 + v
-template <bool kViaLds = (JXLT_LDS_TRANSPOSE != 0)>
-JXLT_DI void block_dct8x8(const float* px, int pitch, int l, float* sc, float* c) {
+// kMode 1: transpose through the octet's LDS area `sc`; 0: in registers; 2: through the wave's half-size area
+// `sc` (octet_transpose_half; `o` = the octet's number within its wave).
+template <int kMode = (JXLT_LDS_TRANSPOSE != 0)>
+JXLT_DI void block_dct8x8(const float* px, int pitch, int l, float* sc, float* c, int o = 0) {
 #pragma unroll
   for (int y = 0; y < 8; y++) c[y] = px[y * pitch + l];
   dct8(c);
-  octet_transpose<kViaLds>(c, sc, l);  // lane v now holds 8*A[v][x], x = 0..7
-  dct8(c);
-#pragma unroll
-  for (int y = 0; y < 8; y++) c[y] = (1.0f / 64) * c[y];  // c[h] = C[h][v=l]
+  // lane v then holds 8*A[v][x], x = 0..7
+  if (kMode == 2) octet_transpose_half(c, sc, o, l);
+  else octet_transpose<kMode == 1>(c, sc, l);
+  dct8(c);  // c[h] = kDct8Norm * C[h][v=l]
 }
 
 // ComputeScaledDCT<16,8>: 16 rows x 8 cols, i = h*16 + v; r = 2h + (v>=8), lane = v&7
@@ -585,9 +726,9 @@ JXLT_DI void block_dct16x8(const float* px, int pitch, int l, float* sc, float* 
   if (kFenced) JXLT_SCHED_FENCE();
   dct8(hi);
 #pragma unroll
-  for (int h = 0; h < 8; h++) {
-    c[2 * h] = (1.0f / 128) * lo[h];
-    c[2 * h + 1] = (1.0f / 128) * hi[h];
+  for (int h = 0; h < 8; h++) {  // (kDct16Norm times the reference's)
+    c[2 * h] = lo[h];
+    c[2 * h + 1] = hi[h];
   }
 }
 
@@ -615,9 +756,9 @@ JXLT_DI void block_dct8x16(const float* px, int pitch, int l, float* sc, float* 
   if (kFenced) JXLT_SCHED_FENCE();
   dct16<kFenced>(row);
 #pragma unroll
-  for (int h = 0; h < 8; h++) {
-    lo[h] = (1.0f / 128) * row[h];
-    hi[h] = (1.0f / 128) * row[h + 8];
+  for (int h = 0; h < 8; h++) {  // (kDct16Norm times the reference's)
+    lo[h] = row[h];
+    hi[h] = row[h + 8];
   }
   octet_transpose(lo, sc, l);  // lane t: C[v][h=t], v = 0..7
   octet_transpose(hi, sc, l);  // lane t: C[v][h=t+8]

@@ -11,6 +11,13 @@
 
 namespace jxlt_dev {
 
+// ceil(log2(x)) for x >= 1 (common.h: CeilLog2Nonzero)
+inline int HostCeilLog2Nonzero(uint32_t x) {
+  int fl = 0;
+  while ((x >> (fl + 1)) != 0) fl++;
+  return (x & (x - 1)) == 0 ? fl : fl + 1;
+}
+
 // `scale` is DistanceParams.scale (enc_frame.cc:129); the per-quant reciprocal
 // float(1.0 / (scale * q)) is evaluated in double exactly as
 // QuantizeRoundtripYBlockAC does (enc_group.cc:289).
@@ -28,6 +35,8 @@ inline void BuildDeviceTables(float scale, DeviceTables* t) {
     }
     for (int b = 0; b < JXLT_kQuantTableLLF[n]; b++) t->inv_weights[JXLT_kQuantTableOffset[n] + b] = 0.0f;
   }
+  // the kernels' transforms are unnormalised (jxlt_device_common.h: kDct8Norm / kDct16Norm): exact power-of-two scaling
+  for (int i = 0; i < 576; i++) t->inv_weights[i] *= i < 192 ? 1.0f / kDct8Norm : 1.0f / kDct16Norm;
   t->inv_qac[0] = 0.0f;
   for (int q = 1; q < 256; q++) t->inv_qac[q] = static_cast<float>(1.0 / (scale * q));
   memcpy(t->coeff_order, JXLT_kCoeffOrder, sizeof(t->coeff_order));
@@ -37,6 +46,10 @@ inline void BuildDeviceTables(float scale, DeviceTables* t) {
   memcpy(t->ac_context_map, JXLT_kACContextMap, sizeof(t->ac_context_map));
   memcpy(t->gradient_lut, JXLT_kGradientContextLut, sizeof(t->gradient_lut));
   for (int i = 0; i < 1024; i++) t->sqrt_lut[i] = sqrtf((float)i);  // IEEE: correctly rounded
+  for (int n = 0; n < 132; n++) {
+    const int nbits = HostCeilLog2Nonzero((uint32_t)n + 1) + 1;
+    t->zeros_cost[n] = 7.565053364251793f * (float)(HostCeilLog2Nonzero((uint32_t)nbits + 17) + nbits);
+  }
   // quantisation in scan order: the constants of scan position p, per position class
   for (int cls = 0; cls < 3; cls++) {
     const bool two_block = cls != 0;
@@ -48,11 +61,32 @@ inline void BuildDeviceTables(float scale, DeviceTables* t) {
         t->scan_consts[cls][c][p] = t->inv_weights[quant_table_offset((two_block ? 3 : 0) + c) + n];
         t->scan_consts[cls][4 + c][p] = quant_zeroing_threshold(c, two_block, quad);
       }
-      t->scan_consts[cls][3][p] = t->weights[quant_table_offset(two_block ? 4 : 1) + n];
+      t->scan_consts[cls][3][p] = t->weights[quant_table_offset(two_block ? 4 : 1) + n] * (two_block ? kDct16Norm : kDct8Norm);
       // staging slot of coefficient (row r, column l) within its block: l * 8 + (r & 7), second block: bit 6
       t->scan_slot[cls][p] = static_cast<uint8_t>((n & 64) | ((n & 7) << 3) | ((n >> 3) & 7));
     }
   }
+}
+
+// TileArgs::mul8x8 / bias8x8 / mul16x8 / cost_of_1 from A->distance and A->strategy_distance: the very float
+// expressions of enc_ac_strategy.cc (:93-96, :178-185, :203), one IEEE operation each (this header is compiled with
+// -ffp-contract=off wherever it is used).
+inline void SetStrategyScalars(TileArgs* A) {
+  const float k8x8mul1 = (float)(-0.55 * 0.75f);
+  const float k8x8mul2 = 1.0735757687292623f * 0.75f;
+  const float k8x8base = (float)1.4;
+  volatile float den8 = A->strategy_distance + k8x8base;
+  volatile float quot8 = k8x8mul1 / den8;
+  A->mul8x8 = k8x8mul2 + quot8;
+  A->bias8x8 = 3.0f * A->mul8x8;
+  const float k8X16mul1 = (float)-0.55, k8X16mul2 = (float)0.9019587899705066, k8X16base = (float)1.6;
+  volatile float den16 = A->strategy_distance + k8X16base;
+  volatile float quot16 = k8X16mul1 / den16;
+  A->mul16x8 = k8X16mul2 + quot16;
+  volatile float third = A->distance * (1.0f / 3);
+  const float slope = third < 1.0f ? third : 1.0f;
+  volatile float scaled = slope * 8.8703248061477744f;
+  A->cost_of_1 = 1 + scaled;
 }
 
 inline FrameGeom MakeGeom(size_t xsize, size_t ysize) {

@@ -21,6 +21,10 @@ constexpr int kTile12Threads = 768;
 // inv_qac), in the term area behind the staging of the selected transforms' coefficients
 constexpr int kP8ScanWords = 3 * 7 * 64 + 3 * 64 / 4;  // scan_consts + scan_slot
 constexpr int kP8TabOffset = 13568;                    // floats from the start of the term area (54 272 B)
+// ... and in front of it the entropy estimate's table DeviceTables::zeros_cost (behind the 16 x 768 floats in which
+// the estimates park the B coefficients)
+constexpr int kZerosCostOffset = 16 * kTile12Threads;
+static_assert(kZerosCostOffset + kZerosCostEntries <= kP8TabOffset, "zeros_cost lies between the parks and the P8 tables");
 constexpr int kHalo = 5;                 // AQ: +-4 px window, +-1 px Laplacian tap
 constexpr int kXYPitch = 64 + 2 * kHalo + 1;  // 75 floats (odd: conflict-free columns)
 constexpr int kBPitch = 65;
@@ -59,7 +63,10 @@ struct alignas(16) TileShared {
   // transpose scratch, 64 x kTransposePitch floats.
   // (+ 192: 17 x 128 floats -- with the 8 x 128 of sqrt_lut the 25 x 128 in which the chain waves of the 12-wave
   // kernel park coefficients during the chains)
-  float transpose_pad[64 * 72 - (kCflTermFloats - (2 * 64 * kXYPitch + 64 * kBPitch)) + 192];
+  // (+ 64: its last 256 floats -- behind the 64 transpose areas -- hold the four sums per block that P4 leaves for the
+  // wave that finishes the quant field, "p4_sums"; until round 4 those sat in sqrt_lut, which is the pair octets'
+  // transpose scratch now)
+  float transpose_pad[64 * 72 - (kCflTermFloats - (2 * 64 * kXYPitch + 64 * kBPitch)) + 192 + 64];
   // (its first 128 floats hold the candidate entropies of the 2x2 cells during the strategy search, "ent8")
 };
 static_assert(offsetof(TileShared, x) % 16 == 0, "the term area is accessed in 16-byte chunks");
@@ -81,19 +88,20 @@ JXLT_DI int imax(int a, int b) { return a > b ? a : b; }
 template <int NR, bool kLut, bool kParkedB = false, int kParkStride = 1>
 JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb, const float* inv_x,
                                const float* inv_y, const float* inv_b, int l, float quant,
-                               float masking, float cmap_x, float cmap_b, float distance,
-                               const float* sqrt_lut, float* qmax) {
+                               float masking, float cmap_x, float cmap_b, float cost_of_1,
+                               const float* sqrt_lut, const float* zeros_cost, float* qmax) {
   const float num_blocks = (float)(NR / 8);
   const float kInfoLossMultiplier = 138.0f;
   const float kInfoLossMultiplier2 = (float)50.46839691767866;
   const float kCost2 = 4.4628149885273363f;
   const float kCostDelta = 5.3359184934516337f;
-  const float kZerosMul = 7.565053364251793f;
-  const float slope = fminf(1.0f, distance * (1.0f / 3));
-  const float cost_of_1 = 1 + slope * 8.8703248061477744f;
+  // (cost_of_1 = 1 + min(1, distance / 3) * 8.87...: wave-uniform, from the host -- TileArgs::cost_of_1)
   float entropy = 0.0f;
   float info_loss = 0.0f, info_loss2 = 0.0f;
   uint32_t qbits = 0;  // OR of the offset words before masking (a v_or is cheaper than a v_max)
+  float lut_step = __uint_as_float(4u);  // 2^-147: q * lut_step has the bit pattern 4 * q
+  JXLT_LAUNDER_VGPR(lut_step);           // (in a vector register, not an SGPR or a literal: see below)
+  (void)lut_step;
   // One copy of the body per channel (no per-coefficient operand selects); the scheduling
   // fences keep the channels from being interleaved, which would spill.
 #pragma unroll
@@ -111,8 +119,10 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
     for (int r = 0; r < NR; r++) {
       const float in = (kParkedB && c == 2) ? cin[r * kParkStride] : cin[r];
       const float im = inv[r * 8 + l];
-      // (skipping the subtraction of cy * 0 for the Y channel saves two instructions per
-      // coefficient on paper; the register allocator then spills 90 VGPRs)
+      // (skipping the subtraction of cy * 0 for the Y channel saves two instructions per coefficient on paper; the
+      // register allocator then spills: 90 VGPRs in rounds 1 and 3, 388-408 B of scratch in round 5 -- also with
+      // scheduling fences every 2 / 4 / 8 rows of the Y pass, with the rows of that pass chained through empty asm
+      // statements, and with a copy of cy[r] in place of the two instructions)
       const float val = (in - cy[r] * cmap_factor) * (im * quant);
       const float rval = rintf(val);
       const float diff = fabsf(val - rval);
@@ -122,15 +132,25 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
       entropy_v = fma32(clamp01(q - 1.0f), kCost2, entropy_v);  // + (q >= 1.5 ? kCost2 : 0)
       float root;
       if (kLut) {
-        // byte offset 4 * q, wrapped into the table (a wrapped read is redone by the caller)
-        // 4 * q + 2^23 is exact for q < 2^21 and its bit pattern is 0x4B000000 + 4 * q: the byte
-        // offset comes out of a multiply-add and a mask, no float -> int conversion (a full-rate
-        // instruction, tools/op_probe.hip).  Larger q (or NaN) disturb the bits above the offset
-        // field, which the OR below keeps for the caller's overflow test.
+#ifndef JXLT_LUT_OFFSET_BY_FMA
+        // The byte offset 4 * q as the bit pattern of the DENORMAL q * 2^-147 (= 4 q units of 2^-149; the kernels run
+        // with denormals on, hipcc's default): ONE multiplication, no float -> int conversion (a 4-cycle instruction)
+        // and no mask.  q >= kSqrtLutSize reads beyond the table -- other LDS words of the tile or, beyond the
+        // workgroup's allocation, the zero the hardware returns for such a read; q >= 2^21, infinities and NaNs give
+        // patterns with exponent bits set -- and every such tile is redone by the caller (the OR below keeps the bits
+        // for its test).  The multiplier sits in a vector register (a VOP3 instruction takes no literal on gfx950, and
+        // one with an SGPR source costs four cycles instead of two).
+        const uint32_t off_raw = __float_as_uint(q * lut_step);
+        root = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sqrt_lut) + JXLT_LUT_WRAP(off_raw));
+        qbits |= off_raw;
+#else
+        // (rounds 2-4) 4 * q + 2^23 is exact for q < 2^21 and its bit pattern is 0x4B000000 + 4 * q: the byte
+        // offset comes out of a multiply-add and a mask.
         const uint32_t off_raw = __float_as_uint(fma32(q, 4.0f, 8388608.0f));
         const uint32_t off = off_raw & (uint32_t)(kSqrtLutSize * 4 - 4);
         root = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sqrt_lut) + off);
         qbits |= off_raw;
+#endif
       } else {
         // (skipping the root with a branch where a whole wave has q <= 1 was tried: control flow
         // inside this loop makes the register allocator spill)
@@ -141,15 +161,22 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
     }
     entropy_v = fma32(nzeros_v, cost_of_1, entropy_v);
     entropy += octet_sum(entropy_v);
-    const uint32_t num_nzeros = (uint32_t)octet_sum(nzeros_v);
-    const uint32_t nbits = (uint32_t)ceil_log2_nonzero(num_nzeros + 1) + 1;
-    entropy += kZerosMul * (float)(ceil_log2_nonzero(nbits + 17) + nbits);
+    // kZerosMul * (CeilLog2Nonzero(nbits + 17) + nbits) with nbits = CeilLog2Nonzero(num_nzeros + 1) + 1 (:133-139)
+    // from the table DeviceTables::zeros_cost (its LDS copy): the count -- an integer below 129 held in a float -- times
+    // 2^-147 has the bit pattern 4 * count, the table's byte offset (as for the roots above)
+    const uint32_t zoff = __float_as_uint(octet_sum(nzeros_v) * lut_step);
+    entropy += *reinterpret_cast<const float*>(reinterpret_cast<const char*>(zeros_cost) + zoff);
   }
   const float infoloss = octet_sum(info_loss);
   const float infoloss2 = sqrtf(num_blocks * octet_sum(info_loss2));
   const float info_loss_score = (kInfoLossMultiplier * infoloss + kInfoLossMultiplier2 * infoloss2);
+#ifndef JXLT_LUT_OFFSET_BY_FMA
+  // every offset stayed inside the table <=> no bit above the offset field is set
+  if (kLut) *qmax = (qbits & ~(uint32_t)(kSqrtLutSize * 4 - 1)) != 0u ? (float)kSqrtLutSize : 0.0f;
+#else
   // every offset stayed inside the table <=> nothing above the offset field differs from 2^23's pattern
   if (kLut) *qmax = ((qbits | 0x4B000000u) & ~(uint32_t)(kSqrtLutSize * 4 - 1)) != 0x4B000000u ? (float)kSqrtLutSize : 0.0f;
+#endif
   return entropy + masking * info_loss_score;
 }
 
@@ -185,12 +212,20 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
 #else
 #define JXLT_STOP(i)
 #endif
+  // -DJXLT_ASM_MARKERS (tools/asm_budget.py): an assembly comment where phase i ends, so that the kernel's
+  // instruction stream can be split into phases (no instruction; production builds leave it out).
+#ifdef JXLT_ASM_MARKERS
+#define JXLT_ASM_PHASE_END(i) asm volatile("; JXLT_PHASE after_" #i)
+#else
+#define JXLT_ASM_PHASE_END(i)
+#endif
 #define JXLT_MARK(i)                                                        \
   if (kDebug && A.dbg_phase && tid == 0) {                                  \
     const long long t_now = clock64();                                      \
     atomicAdd(&A.dbg_phase[i], (unsigned long long)(t_now - t_prev));       \
     t_prev = t_now;                                                         \
   }                                                                         \
+  JXLT_ASM_PHASE_END(i);                                                    \
   JXLT_STOP(i)
 
   // ---- geometry (enc_frame.cc:716-751) ------------------------------------
@@ -234,14 +269,33 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     const bool hok = hr < 6 && hy < shp && hx >= 0 && hx < swp && hx < px0 + nbx * 8 + kHalo;
     const int xs_h = (hok ? imin(hx, sw - 1) : 0) * A.pix_stride;
     float pr[7], pg[7], pb[7];
+    // The six interior rows of a wave are wave-uniform: their base addresses are computed on the scalar unit and the
+    // lane adds a 32-bit byte offset (global_load with a scalar base -- no vector instruction per load; as one 64-bit
+    // expression per load the compiler spent a 64-bit multiply-add, a shift and three 64-bit adds per row on it).
+    const ptrdiff_t col_off = (ptrdiff_t)sx0 * A.pix_stride;
+    const uint32_t byte_i = (uint32_t)xs_i * 4u;
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-      const int y = k < 6 ? w + 12 * k : hy;
-      const ptrdiff_t off = (ptrdiff_t)(sy0 + imin(y, sh - 1)) * A.pitch + (ptrdiff_t)sx0 * A.pix_stride +
-                            (k < 6 ? xs_i : xs_h);
-      pr[k] = A.planes[0][off];
-      pg[k] = A.planes[1][off];
-      pb[k] = A.planes[2][off];
+    for (int k = 0; k < 6; k++) {
+      const ptrdiff_t row_off = (ptrdiff_t)(sy0 + imin(w + 12 * k, sh - 1)) * A.pitch + col_off;  // (scalar)
+      // (the row's base pointers are opaque to the compiler: it would otherwise add the lane's offset to the plane's
+      // base first and the row's offset per load, a 64-bit vector add each)
+      // (... and typed as pointers to GLOBAL memory: behind the opaque point the compiler no longer knows where they
+      // came from and would use flat loads)
+      JxltGlobalBytes r0 = (JxltGlobalBytes)(A.planes[0] + row_off);
+      JxltGlobalBytes r1 = (JxltGlobalBytes)(A.planes[1] + row_off);
+      JxltGlobalBytes r2 = (JxltGlobalBytes)(A.planes[2] + row_off);
+      JXLT_LAUNDER_SGPR(r0);
+      JXLT_LAUNDER_SGPR(r1);
+      JXLT_LAUNDER_SGPR(r2);
+      pr[k] = *(JxltGlobalFloats)(r0 + byte_i);
+      pg[k] = *(JxltGlobalFloats)(r1 + byte_i);
+      pb[k] = *(JxltGlobalFloats)(r2 + byte_i);
+    }
+    {  // (the halo pixel: its row depends on the lane)
+      const ptrdiff_t off = (ptrdiff_t)(sy0 + imin(hy, sh - 1)) * A.pitch + col_off + xs_h;
+      pr[6] = A.planes[0][off];
+      pg[6] = A.planes[1][off];
+      pb[6] = A.planes[2][off];
     }
     if (tid < 576) S.inv_w[tid] = tab_inv0;
     // (the root table is staged behind the chains of P5b: until then its place in LDS serves the chain waves)
@@ -316,10 +370,17 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
         diff_x = diff_x * diff_x;
         return masking_sqrt(fma32(kXMul, diff_x, diff), sqrt_mul);
       } else {
+        // the vector loop adds (right + left) + vertical, the scalar loop (vertical + left) + right: ONE sum of the
+        // form (a + left) + c whose outer operands are selected (two selects instead of four additions and a select)
+#ifndef JXLT_P1_BOTH_ORDERS
+        const float base = 0.25f * (((vec ? in_r : du) + in_l) + (vec ? du : in_r));
+        const float base_x = 0.25f * (((vec ? ix_r : dux) + ix_l) + (vec ? dux : ix_r));
+#else
         const float base = 0.25f * (vec ? (in_r + in_l) + du : (du + in_l) + in_r);
+        const float base_x = 0.25f * (vec ? (ix_r + ix_l) + dux : (dux + ix_l) + ix_r);
+#endif
         float diff = gammac * (in - base);
         diff = diff * diff;
-        const float base_x = 0.25f * (vec ? (ix_r + ix_l) + dux : (dux + ix_l) + ix_r);
         float diff_x = gammac * (ix - base_x);
         diff_x = diff_x * diff_x;
         const float fused = fma32(kXMul, diff_x, diff), unfused = diff + kXMul * diff_x;
@@ -503,7 +564,10 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       A.dbg_mask[pos] = S.mask[b];
     }
   };
-  float* const p4_sums = &S.sqrt_lut[0];  // 12 waves: [block][hf, red, blue, gamma] (the root table is staged later)
+  // [block][hf, red, blue, gamma]: behind the transpose areas (read before the chain waves park there)
+  float* const p4_sums = &S.transpose_pad[sizeof(S.transpose_pad) / sizeof(float) - 256];
+  static_assert(sizeof(S.transpose_pad) / sizeof(float) - 256 >= 64 * kTransposePitch - (kCflTermFloats - (2 * 64 * kXYPitch + 64 * kBPitch)),
+                "p4_sums lies behind the candidate octets' transpose areas");
   if (tid < 512) {  // (octets 0..63 = waves 0-7)
     const int bxp = px0 + obx * 8, byp = oby * 8;  // block origin (stripe pixels)
     // HfModulation (:209-247): lane l = column l of the block
@@ -603,6 +667,17 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
   };
   new_phase();
   float c16x[16], c16y[16], c16b[16];
+  // The transforms below run under conditions (block in the frame, search on) and so does every later use of their
+  // results.  On the other path the registers are "defined" without an instruction (JXLT_DEFINE_VGPR): left undefined,
+  // the compiler zero-initialised all 48 in front of the branch, 32 v_mov per thread and tile.
+  auto leave_undefined = [&](int r0, int r1) {
+#pragma unroll
+    for (int r = r0; r < r1; r++) {
+      JXLT_DEFINE_VGPR(c16x[r]);
+      JXLT_DEFINE_VGPR(c16y[r]);
+      JXLT_DEFINE_VGPR(c16b[r]);
+    }
+  };
   // 12 waves: a pair octet's two DCT8 live in the registers a candidate octet uses for its transform (rows 0-7:
   // first block, rows 8-15: second block), so that a thread needs ONE set of 48 coefficient registers.
   float* const c8x = c16x;
@@ -612,27 +687,39 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
   float* const d8y = c16y + 8;
   float* const d8b = c16b + 8;
   if (pair_role) {
-    // the pair octets have no LDS scratch (the 64 there are belong to the candidate octets, which transpose
-    // at the same time): their transposes are register butterflies
+    // The pair octets have no transpose area of their own (the 64 there are belong to the candidate octets, which
+    // transpose at the same time): they go through HALF an area each, in the place of the root table (free until the
+    // chains: 4 waves x 256 floats), octet_transpose_half.  (Rounds 3-4: register butterflies, kPairMode 0.)
+#ifndef JXLT_PAIR_TRANSPOSE_MODE
+#define JXLT_PAIR_TRANSPOSE_MODE 2
+#endif
+    constexpr int kPairMode = JXLT_PAIR_TRANSPOSE_MODE;
+    static_assert(sizeof(S.sqrt_lut) >= 4 * 256 * sizeof(float), "the pair waves' transpose areas");
+    float* const psc = &S.sqrt_lut[0] + wave_u * 256;
+    const int po = oct & 7;
     const float* pxp = &S.x[(pby0 * 8) * kXYPitch + pbx * 8 + kHalo];
     const float* pyp = &S.y[(pby0 * 8) * kXYPitch + pbx * 8 + kHalo];
     const float* pbp = &S.b[(pby0 * 8) * kBPitch + pbx * 8];
     if (pair_valid0) {
-      block_dct8x8<false>(pxp, kXYPitch, l, nullptr, c8x);
+      block_dct8x8<kPairMode>(pxp, kXYPitch, l, psc, c8x, po);
       JXLT_SCHED_FENCE();
-      block_dct8x8<false>(pyp, kXYPitch, l, nullptr, c8y);
+      block_dct8x8<kPairMode>(pyp, kXYPitch, l, psc, c8y, po);
       JXLT_SCHED_FENCE();
-      block_dct8x8<false>(pbp, kBPitch, l, nullptr, c8b);
+      block_dct8x8<kPairMode>(pbp, kBPitch, l, psc, c8b, po);
       JXLT_SCHED_FENCE();
+    } else {
+      leave_undefined(0, 8);
     }
     // (blocks outside the frame: the registers stay undefined, every later use is under the same condition)
     if (pair_valid1) {
-      block_dct8x8<false>(pxp + 8 * kXYPitch, kXYPitch, l, nullptr, d8x);
+      block_dct8x8<kPairMode>(pxp + 8 * kXYPitch, kXYPitch, l, psc, d8x, po);
       JXLT_SCHED_FENCE();
-      block_dct8x8<false>(pyp + 8 * kXYPitch, kXYPitch, l, nullptr, d8y);
+      block_dct8x8<kPairMode>(pyp + 8 * kXYPitch, kXYPitch, l, psc, d8y, po);
       JXLT_SCHED_FENCE();
-      block_dct8x8<false>(pbp + 8 * kBPitch, kBPitch, l, nullptr, d8b);
+      block_dct8x8<kPairMode>(pbp + 8 * kBPitch, kBPitch, l, psc, d8b, po);
       JXLT_SCHED_FENCE();
+    } else {
+      leave_undefined(8, 16);
     }
   } else if (cell_valid) {
     const float* pxp = &S.x[(cby * 8) * kXYPitch + cbx * 8 + kHalo];
@@ -654,6 +741,8 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       block_dct8x16<true>(pbp, kBPitch, l, tsc, c16b);
     }
     JXLT_SCHED_FENCE();
+  } else {
+    leave_undefined(0, 16);
   }
   JXLT_MARK(4);
   // ---- P5: chroma-from-luma (the DCT8 of every block is in the pair octets' registers) -------
@@ -731,8 +820,10 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     // and the inverse quantiser steps -- 1648 words that every wave would otherwise fetch from global memory, 25 loads
     // per thread, at the start of that phase, with nothing to do meanwhile
     uint32_t late_p8[3] = {0u, 0u, 0u};
+    float late_zeros_cost = 0.0f;
     {
       if (cw >= 2) {
+        late_zeros_cost = T->zeros_cost[imin(tid - 128, kZerosCostEntries - 1)];
         late_root0 = T->sqrt_lut[(tid - 128) & (kSqrtLutSize - 1)];
         late_root1 = T->sqrt_lut[(tid - 128 + 640) & (kSqrtLutSize - 1)];
         const uint32_t* const scan_words = reinterpret_cast<const uint32_t*>(&T->scan_consts[0][0][0]);
@@ -908,6 +999,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       if (cw >= 2) {  // (visible to P6b behind the barrier below)
         if (tid - 128 < kSqrtLutSize) S.sqrt_lut[tid - 128] = late_root0;
         if (tid - 128 + 640 < kSqrtLutSize) S.sqrt_lut[tid - 128 + 640] = late_root1;
+        if (tid - 128 < kZerosCostEntries) (&S.x[0] + kZerosCostOffset)[tid - 128] = late_zeros_cost;
         uint32_t* const p8_tab = reinterpret_cast<uint32_t*>(&S.x[0]) + kP8TabOffset;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
@@ -938,6 +1030,9 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
 
   // ---- P6b: entropy estimates (enc_ac_strategy.cc:68-146,187-212) -----------
   float qmax = 0.0f;  // largest quantised magnitude whose root was taken from the table
+  // (the LDS copy of DeviceTables::zeros_cost: in the dead term area, between the parked coefficients and the
+  // quantisation phase's tables; staged behind the chains with the root table)
+  const float* const zeros_cost = &S.x[0] + kZerosCostOffset;
   if (search) {
     // DCT8 estimate of block (bx, by) of the tile from the lane's rows of its coefficients
     auto estimate8 = [&](int bx, int by, const float* vx, const float* vy, const float* vb) {
@@ -945,14 +1040,11 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       float qmax8 = 0.0f;
       const float e = estimate_entropy<8, kLutRoots, true, kThreads>(
           vx, vy, vb, S.inv_w + 0, S.inv_w + 64, S.inv_w + 128, l, fmaxf(0.0f, S.aq[bi]), fmaxf(0.0f, S.mask[bi]),
-          cmap_x, cmap_b, A.distance, S.sqrt_lut, &qmax8);
+          cmap_x, cmap_b, A.cost_of_1, S.sqrt_lut, zeros_cost, &qmax8);
       qmax = fmaxf(qmax, qmax8);
-      const float k8x8mul1 = (float)(-0.55 * 0.75f);
-      const float k8x8mul2 = 1.0735757687292623f * 0.75f;
-      const float k8x8base = (float)1.4;
-      const float mul8x8 = k8x8mul2 + div_normal(k8x8mul1, A.strategy_distance + k8x8base);
-      float e8 = 3.0f * mul8x8;
-      e8 += mul8x8 * e;
+      // mul8x8 = k8x8mul2 + k8x8mul1 / (strategy_distance + k8x8base), 3 * mul8x8 (:178-185, :203): from the host
+      float e8 = A.bias8x8;
+      e8 += A.mul8x8 * e;
       if (l == 0) S.transpose_pad[((by >> 1) * 4 + (bx >> 1)) * 8 + (by & 1) * 2 + (bx & 1)] = e8;
     };
     // 12 waves: the B coefficients (rows 0..15: a candidate's, or rows 0..7 / 8..15: the two blocks of a pair
@@ -977,12 +1069,10 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       float qmax16 = 0.0f;
       const float e = estimate_entropy<16, kLutRoots, true, kThreads>(
           c16x, c16y, park, S.inv_w + quant_table_offset(toff), S.inv_w + quant_table_offset(toff + 1),
-          S.inv_w + quant_table_offset(toff + 2), l, quant, masking, cmap_x, cmap_b, A.distance, S.sqrt_lut, &qmax16);
+          S.inv_w + quant_table_offset(toff + 2), l, quant, masking, cmap_x, cmap_b, A.cost_of_1, S.sqrt_lut,
+          zeros_cost, &qmax16);
       qmax = fmaxf(qmax, qmax16);
-      const float k8X16mul1 = (float)-0.55, k8X16mul2 = (float)0.9019587899705066,
-                  k8X16base = (float)1.6;
-      const float mul16x8 = k8X16mul2 + div_normal(k8X16mul1, A.strategy_distance + k8X16base);
-      if (l == 0) S.transpose_pad[cell * 8 + (is_tall ? 4 : 6) + (cand & 1)] = mul16x8 * e;
+      if (l == 0) S.transpose_pad[cell * 8 + (is_tall ? 4 : 6) + (cand & 1)] = A.mul16x8 * e;
     }
     JXLT_SCHED_FENCE();
     {
@@ -1065,6 +1155,10 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
   {
     // (within a block and channel the slot of coefficient (row r, column l) is l * 8 + r: a lane's eight rows
     // are two 16-byte stores)
+    // (two 16-byte stores per channel and block half.  The eight values have to be copied into aligned register
+    // quadruples first -- 76 v_mov in the kernel --; four ds_write2_b32 per call, which take their values from any two
+    // registers, were tried in round 5: no copies, but dword pairs at a lane stride of eight floats meet 16 to a bank --
+    // 9.35 against 8.87 M cycles per 16384^2 launch.)
     auto put8 = [&](float* d, const float* v) {
       float4 lo, hi;
       lo.x = v[0]; lo.y = v[1]; lo.z = v[2]; lo.w = v[3];
@@ -1184,6 +1278,14 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     JXLT_TOUCH_VGPR(slot16a);
     JXLT_TOUCH_VGPR(slot16b);
     int ntrans = 0;
+    // Guard against coefficients the token format cannot carry (PackSigned(q) must fit 16 bits: -32768 <= q <= 32767;
+    // the reference only asserts it in debug builds, enc_bit_writer.cc:120, and the coefficient store below keeps 16
+    // bits).  The table-root pass only sums q * q per lane -- one cheap instruction per value --: a sum below 2^30
+    // proves that every magnitude is below 2^15; anything else (a huge value, an infinity, or many large values) makes
+    // the tile "suspect", and a suspect tile is filed like one that overflowed the root table and done again by
+    // tile*_kernel_redo, which tests every value exactly and counts the tile in A.unsupported if one fails.
+    float q_energy = 0.0f;
+    bool q_bad = false;
     float next_v[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
     int next_b = todo != 0 ? (int)__builtin_ctzll(todo) : -1, next_st = 0;
     if (next_b >= 0) {
@@ -1236,6 +1338,13 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
         half(k8, in[0], quant[0], cur0);
         quant[1][0] = quant[1][1] = quant[1][2] = 0.0f;
       }
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          if (kLutRoots) q_energy = fma32(quant[h][c], quant[h][c], q_energy);
+          else q_bad = q_bad || !(fabsf(quant[h][c] + 0.5f) <= 32767.5f);  // (exact: q is an integer)
+        }
       const int t = wave + kWaves * ntrans;  // the transform's number in the tile
       file_int(0, t, b | (st << 8));
       int nz_packed = 0, nscan_packed = 0;
@@ -1278,6 +1387,11 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       ntrans++;
     }
     if (lane == 0 && wave_tokens) atomicAdd(&S.ntok, wave_tokens);
+    if (kLutRoots) {
+      if (__ballot(!(q_energy < 1073741824.0f)) != 0 && lane == 0) S.overflow = 1u;  // (suspect: see q_energy)
+    } else {
+      if (__ballot(q_bad) != 0 && lane == 0) atomicAdd(A.unsupported, 1u);
+    }
   }
   __syncthreads();
   // the tile's transforms side by side, one per lane of wave 0: DC of the covered blocks (:392-443) and the
@@ -1297,23 +1411,33 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       const float kScale1 = (float)0.901764195028874394;
       const float kInvDCQuant[3] = {4096.0f, 512.0f, 256.0f};
       int16_t dcy_a = 0, dcy_b = 0;
+      bool dc_bad = false;
 #pragma unroll
       for (int ci = 0; ci < 3; ci++) {
         const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;  // y first: the chroma DC is coded relative to it
-        const float c0 = dc_stage[(lane * 3 + c) * 2], c1 = dc_stage[(lane * 3 + c) * 2 + 1];
+        // (the staged coefficients are unnormalised: kDct8Norm / kDct16Norm times the reference's)
+        const float unnorm = two ? 1.0f / kDct16Norm : 1.0f / kDct8Norm;
+        const float c0 = dc_stage[(lane * 3 + c) * 2] * unnorm, c1 = dc_stage[(lane * 3 + c) * 2 + 1] * unnorm;
         const float b0 = c0 * 1.0f * 1.0f, b1 = c1 * 1.0f * kScale1;
         const float d_a = two ? b0 + b1 : c0, d_b = two ? b0 - b1 : 0.0f;
         int16_t qdc_a, qdc_b;
+        float fdc_a, fdc_b;
         if (c == 1) {
           const float inv_factor_y = kInvDCQuant[1] * A.scale_dc;
-          qdc_a = dcy_a = (int16_t)roundf(inv_factor_y * d_a);
-          qdc_b = dcy_b = (int16_t)roundf(inv_factor_y * d_b);
+          fdc_a = roundf(inv_factor_y * d_a);
+          fdc_b = roundf(inv_factor_y * d_b);
+          qdc_a = dcy_a = (int16_t)fdc_a;
+          qdc_b = dcy_b = (int16_t)fdc_b;
         } else {
           const float inv_factor = (c == 0 ? kInvDCQuant[0] : kInvDCQuant[2]) * A.scale_dc;
           const float cfl_factor = c == 0 ? 0.0f : kInvDCQuant[2] * (1.0f / kInvDCQuant[1]);
-          qdc_a = (int16_t)roundf(d_a * inv_factor - dcy_a * cfl_factor);
-          qdc_b = (int16_t)roundf(d_b * inv_factor - dcy_b * cfl_factor);
+          fdc_a = roundf(d_a * inv_factor - dcy_a * cfl_factor);
+          fdc_b = roundf(d_b * inv_factor - dcy_b * cfl_factor);
+          qdc_a = (int16_t)fdc_a;
+          qdc_b = (int16_t)fdc_b;
         }
+        // (a quantised DC value beyond int16 -- DCGroupData's type -- or not a number: the frame is refused)
+        dc_bad = dc_bad || !(fdc_a >= -32768.0f && fdc_a <= 32767.0f && fdc_b >= -32768.0f && fdc_b <= 32767.0f);
         // (select, not A.nzgrid[c] / A.quant_dc[c]: indexing a kernel-argument array by a runtime value
         // would force the argument block into scratch memory)
         uint8_t* nzg = c == 0 ? A.nzgrid[0] : c == 1 ? A.nzgrid[1] : A.nzgrid[2];
@@ -1331,6 +1455,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
           nzg[pos1] = shifted;
         }
       }
+      if (dc_bad) atomicAdd(A.unsupported, 1u);
     }
   }
   JXLT_MARK(9);
@@ -1345,6 +1470,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     }
   }
 #undef JXLT_MARK
+#undef JXLT_ASM_PHASE_END
 #undef JXLT_STOP
 #undef SX
 #undef SY

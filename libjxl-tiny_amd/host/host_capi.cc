@@ -128,6 +128,13 @@ int jxlt_encode_file_planar(const float* const planes[3], size_t pitch_bytes, si
 }
 
 namespace {
+// What a failed encode on `ctx` returns: JXLT_ERR_UNSUPPORTED when the device refused the frame's values (a quantised
+// coefficient beyond the token format's 16 bits, a DC value beyond int16 -- the status sticks to the context until
+// the next encode), JXLT_ERR_INTERNAL otherwise.
+int FailureCode(jxlt_context* ctx) {
+  jxlt_encode_stats_t st;
+  return jxlt_encode_stats(ctx, &st) == JXLT_ERR_UNSUPPORTED ? JXLT_ERR_UNSUPPORTED : JXLT_ERR_INTERNAL;
+}
 // Shared by the two resident entry points: file header + frame into the buffer `alloc` returns.
 int EncodeResident(jxlt_context* ctx, float distance, int num_threads,
                    const std::function<uint8_t*(size_t)>& alloc, size_t* out_size) {
@@ -144,7 +151,7 @@ int EncodeResident(jxlt_context* ctx, float distance, int num_threads,
     *out_size = file_header.size() + frame_bytes;
     return buf + file_header.size();
   };
-  return jxlt::EncodeFrameOnContext(ctx, distance, num_threads, nullptr, &placer) ? JXLT_OK : JXLT_ERR_INTERNAL;
+  return jxlt::EncodeFrameOnContext(ctx, distance, num_threads, nullptr, &placer) ? JXLT_OK : FailureCode(ctx);
 }
 }  // namespace
 
@@ -180,7 +187,7 @@ int jxlt_encode_resident_view(jxlt_context* ctx, float distance, int num_threads
   // writes the AC sections there itself (jxlt_pack_sections_place).
   jxlt::ContextOutput out;
   out.prefix = &file_header;
-  if (!jxlt::EncodeFrameOnContext(ctx, distance, num_threads, nullptr, nullptr, &out)) return JXLT_ERR_INTERNAL;
+  if (!jxlt::EncodeFrameOnContext(ctx, distance, num_threads, nullptr, nullptr, &out)) return FailureCode(ctx);
   *bytes = out.data;
   *size = out.size;
   return JXLT_OK;

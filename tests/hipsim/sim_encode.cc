@@ -32,6 +32,7 @@ struct sim_result {
   uint32_t* dc_count;   // [ndc]
   size_t num_dc_groups;
   uint32_t exact_reruns;  // tiles that were redone with computed roots (tile*_kernel_redo)
+  uint32_t unsupported;   // TileArgs::unsupported: non-zero = the C ABI would answer JXLT_ERR_UNSUPPORTED
 };
 
 __attribute__((visibility("default"))) void sim_free(sim_result* r);
@@ -78,6 +79,7 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   A.inv_scale = inv_scale;
   A.scale_dc = scale_dc;
   A.x_qm_mul = XQmMultiplier(x_qm_scale);
+  SetStrategyScalars(&A);
   A.flags = flags & ~0x4000u;  // (0x4000 selects a kernel here, it is not a kernel flag)
   A.tab = tab;
   A.raw_quant = r->raw_quant = (uint8_t*)calloc(nblocks, 1);
@@ -105,6 +107,8 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   std::vector<uint32_t> lut_overflow(nsl, 0), overflow_tiles(ntiles, 0xFFFFFFFFu);
   A.lut_overflow = lut_overflow.data();
   A.overflow_tiles = overflow_tiles.data();
+  uint32_t unsupported = 0;
+  A.unsupported = &unsupported;
   for (size_t sl = 0; sl < nsl; sl++) {
     const size_t y0 = sl * rows_per_slab, rows = std::min(rows_per_slab, ysize - y0);
     const TileArgs S = nsl == 1 ? A : SlabTileArgs(A, y0, rows, A.pitch, sl);
@@ -116,6 +120,7 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
     hipsim::launch(tile12_kernel_redo, redo_grid, dim3(kTile12Threads), S);
     r->exact_reruns += lut_overflow[sl];  // tiles redone
   }
+  r->unsupported = unsupported;
 
   r->group_tok_offset = (uint64_t*)calloc(ngroups + 1, 8);
   // (token_kernel finds every group's token offset itself; the total sizes the token buffer here)

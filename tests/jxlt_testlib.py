@@ -102,7 +102,7 @@ class HotPathResult:
     """Plain numpy view of one hot-path run (oracle, simulator or GPU)."""
     __slots__ = ("quant_dc", "raw_quant", "strategy", "ytox", "ytob", "group_tokens",
                  "xyb", "qf", "mask", "ent8", "xsize", "ysize", "histogram", "dc_histogram", "dc_records",
-                 "exact_reruns")
+                 "exact_reruns", "unsupported")
 
     def all_tokens(self):
         return b"".join(self.group_tokens)
@@ -199,7 +199,7 @@ class SimResult(C.Structure):
                 ("xyb", fp * 3), ("qf", fp), ("mask", fp), ("ent8", fp),
                 ("histogram", C.POINTER(C.c_uint32)), ("dc_records", C.POINTER(C.c_uint8)),
                 ("dc_rec_offset", C.POINTER(C.c_uint64)), ("dc_count", C.POINTER(C.c_uint32)),
-                ("num_dc_groups", C.c_size_t), ("exact_reruns", C.c_uint32)]
+                ("num_dc_groups", C.c_size_t), ("exact_reruns", C.c_uint32), ("unsupported", C.c_uint32)]
 
 
 _sim = None
@@ -400,6 +400,7 @@ def sim_hot_path(planes, distance, force_dct8=False, as_pfm=None, tiny_root_tabl
     blob = C.string_at(s.tokens, offs[ng] * 3)
     r.group_tokens = [blob[3 * offs[g]:3 * offs[g + 1]] for g in range(ng)]
     r.exact_reruns = int(s.exact_reruns)
+    r.unsupported = int(s.unsupported)
     r.xyb = np.stack([_np(s.xyb[c], (yb * 8, xb * 8), np.float32) for c in range(3)])
     r.qf = _np(s.qf, (yb, xb), np.float32)
     r.mask = _np(s.mask, (yb, xb), np.float32)

@@ -52,6 +52,17 @@ def test_codestream_decodes_and_resembles_the_input(built, w, h, distance, hard,
     assert D.psnr_opsin_db(planes, dec.linear_rgb) >= min_psnr
 
 
+def test_frame_whose_corner_dc_group_is_one_block_decodes(built):
+    """2049 x 2049: four DC groups, the last of them a single 8 x 8 block (its colour-correlation map, its DC image
+    and its AC metadata are 1 x 1).  The reference traps on this shape (enc_frame.cc:335-339); the oracle
+    -- and with it the product, tests/test_gpu_parity.py -- writes a stream that reads back to the last bit."""
+    planes = T.to_planes(T.synthetic_image(2049, 2049, seed=102))
+    jxl = bytes(T.oracle_encode_file(planes, 0.7, nthreads=8)[0])
+    dec = D.decode(jxl)
+    assert (dec.xsize, dec.ysize) == (2049, 2049)
+    assert D.psnr_opsin_db(planes, dec.linear_rgb) > 37.0
+
+
 def test_quality_follows_distance(built):
     planes = T.to_planes(T.synthetic_image(264, 200))
     psnr, size = [], []

@@ -299,6 +299,66 @@ def test_frames_of_one_column_or_one_row_of_groups(built):
         e.close()
 
 
+@pytest.mark.parametrize("w,h,d", [(2049, 2049, 0.7), (2056, 2049, 1.0), (4097, 2049, 2.0)])
+def test_frames_whose_corner_dc_group_is_one_block(built, w, h, d):
+    """Frames that end 1..8 pixels behind a DC-group boundary on both axes: the corner DC group is ONE block (or a
+    row / column of blocks one block thick).  The reference traps on them (enc_frame.cc:335-339 -> the CfL allotment of
+    a 1 x 1 DC group, base/padded_bytes.h:174) -- the product encodes them like any other frame: the
+    oracle's bytes, and the first one is read back by the independent decoder."""
+    planes = T.to_planes(T.synthetic_image(w, h, seed=102))
+    want = bytes(T.oracle_encode_file(planes, d, nthreads=8)[0])
+    assert built.encode_file(planes, d) == want
+    e = built.Encoder(0)
+    e.upload(planes)
+    assert bytes(e.encode_resident(d)) == want
+    e.close()
+    if (w, h) == (2049, 2049):
+        import jxl_decoder as D
+        dec = D.decode(want)
+        assert (dec.xsize, dec.ysize) == (w, h)
+        assert D.psnr_opsin_db(planes, dec.linear_rgb) > 37.0
+
+
+@pytest.mark.parametrize("poison", [1e38, float("inf"), float("nan"), -1e38], ids=["1e38", "inf", "nan", "-1e38"])
+def test_values_the_format_cannot_carry_are_refused(built, poison):
+    """40 samples of 1e38 / +Inf / NaN / -1e38 in a 136 x 72 frame.  A quantised coefficient
+    whose token does not fit 16 bits makes the reference trap in debug builds (enc_bit_writer.cc:120) and write a
+    stream no decoder accepts otherwise; the device counts such tiles and every entry point answers
+    JXLT_ERR_UNSUPPORTED (-4) -- or the stream is one the independent reader accepts to the last bit.  The context
+    encodes ordinary frames afterwards as if nothing had happened."""
+    import jxl_decoder as D
+    img = T.synthetic_image(136, 72, seed=3)
+    idx = np.random.default_rng(7).integers(0, img.size, size=40)
+    img.reshape(-1)[idx] = np.float32(poison)
+    planes = T.to_planes(img)
+    e = built.Encoder(0)
+    e.upload(planes)
+    refused = False
+    try:
+        jxl = bytes(e.encode_resident(1.0))
+    except built.JxlTinyError as err:
+        refused = True
+        assert "(-4)" in str(err), str(err)
+    if poison > 1e30:
+        assert refused
+    if not refused:
+        D.decode(jxl)
+    # ... and the raw-token route says the same
+    try:
+        e.hot_path(planes, 1.0)
+        assert not refused
+    except built.JxlTinyError as err:
+        assert refused and "(-4)" in str(err), str(err)
+    good = T.to_planes(T.synthetic_image(136, 72, seed=3))
+    e.upload(good)
+    assert bytes(e.encode_resident(1.0)) == T.assemble_codestream(T.oracle_hot_path(good, 1.0), 1.0)
+    e.close()
+    # the drop-in's entry point: false / an error, no bytes
+    if refused:
+        with pytest.raises(built.JxlTinyError):
+            built.encode_file(planes, 1.0)
+
+
 def test_single_pass_packing_of_several_contexts_on_one_device_does_not_stall(built):
     """Tiles of the single pass wait for the tiles in front of them.  Handed out by workgroup index, a tile could wait
     for one that was never dispatched because another context's waiting tiles held every slot of its XCD -- and the
@@ -1076,13 +1136,14 @@ def test_random_frames_codestream_equals_oracle(built, w, h, distance, seed):
 def _judge_cases():
     import test_oracle_known_answers as K
     cases = [("r2",) + k for k in sorted(K.JUDGE_R2)] + [("r3",) + k for k in sorted(K.JUDGE_R3)]
+    cases += [("r4", k[1], k[2], k[3], k[4], k[0]) for k in sorted(K.JUDGE_R4)]
     return cases
 
 
 @pytest.mark.parametrize("case", _judge_cases(), ids=lambda c: "%s_%dx%d_d%g_s%d_%s" % c)
 def test_product_bytes_equal_the_judges_stand_in_builds(built, case):
     """The drop-in's codestream, reference-bytes mode, against the size + sha-256 of the bytes the unmodified
-    reference sources produced in the judges' stand-in builds (VERDICT.md rounds 2 and 3) -- compared with the
+    reference sources produced in the judges' stand-in builds (VERDICT.md rounds 2, 3 and 4) -- compared with the
     recorded hashes directly, no oracle in between."""
     import hashlib
     import test_oracle_known_answers as K
@@ -1090,9 +1151,12 @@ def test_product_bytes_equal_the_judges_stand_in_builds(built, case):
     if which == "r2":
         img = T.synthetic_image(w, h, seed=seed, hard=kind)
         want = K.JUDGE_R2[(w, h, d, seed, kind)]
-    else:
+    elif which == "r3":
         img = K.judge_r3_image(w, h, seed, kind)
         want = K.JUDGE_R3[(w, h, d, seed, kind)]
+    else:
+        img = K.judge_r4_image(kind, w, h, seed)
+        want = K.JUDGE_R4[(kind, w, h, d, seed)]
     built.emulate_reference_single_symbol_codes(True)
     try:
         got = built.encode_file(T.to_planes(img), d)

@@ -362,3 +362,43 @@ def test_group_scan_kernel_matches_cumsum(built, n):
     L.sim_group_scan(counts.ctypes.data, n, got.ctypes.data)
     want = np.concatenate([[0], np.cumsum(counts.astype(np.uint64))]).astype(np.uint64)
     assert (got == want).all()
+
+
+def _poisoned_frame(poison, seed=7):
+    """136 x 72: forty samples of the smooth test frame replaced by `poison`."""
+    img = T.synthetic_image(136, 72, seed=3)
+    idx = np.random.default_rng(seed).integers(0, img.size, size=40)
+    img.reshape(-1)[idx] = np.float32(poison)
+    return T.to_planes(img)
+
+
+@pytest.mark.parametrize("poison", [1e38, -1e38, float("inf"), float("nan")], ids=["1e38", "-1e38", "inf", "nan"])
+def test_values_the_format_cannot_carry_are_refused_or_leave_a_decodable_stream(built, poison):
+    """A quantised coefficient whose token does not fit the format's 16 bits (the reference only asserts it in debug
+    builds, enc_bit_writer.cc:120, and otherwise writes a stream no decoder accepts) or a DC value beyond int16 must
+    be COUNTED by the kernels (TileArgs::unsupported: the C ABI answers JXLT_ERR_UNSUPPORTED) -- or the tokens must
+    still be a well-formed stream.  Samples of +1e38 and +Inf overflow and must be counted (-1e38 is clamped to zero by
+    the colour transform, enc_xyb.cc:73-75, and is an ordinary frame)."""
+    import jxl_decoder as D
+    got = T.sim_hot_path(_poisoned_frame(poison), 1.0)
+    if poison > 1e30:
+        assert got.unsupported > 0
+    if got.unsupported == 0:
+        D.decode(T.oracle_codestream(got, 1.0))  # (raises on a malformed stream)
+
+
+def test_ordinary_frames_are_not_refused(built):
+    """... and nothing is counted for frames the format can carry: HDR noise up to 40 at distance 0.05 (quantised
+    magnitudes of several hundred), also when the tiles go through tile*_kernel_redo, where every value is tested
+    exactly (the build with a 16-entry root table: every busy tile is redone)."""
+    img = (T.synthetic_image(136, 72, seed=5, hard=True) * np.float32(40.0)).astype(np.float32)
+    planes = T.to_planes(img)
+    want = T.oracle_hot_path(planes, 0.05)
+    got = T.sim_hot_path(planes, 0.05)
+    assert got.unsupported == 0
+    assert T.compare_results(want, got, "oracle", "cpu model") == []
+    redone = T.sim_hot_path(planes, 0.05, tiny_root_table=True)
+    assert redone.unsupported == 0 and redone.exact_reruns > 0
+    assert T.compare_results(want, redone, "oracle", "cpu model, computed roots") == []
+    # (the same noise at distance 0.02 is beyond the format: its quantised DC values leave int16)
+    assert T.sim_hot_path(planes, 0.02).unsupported > 0

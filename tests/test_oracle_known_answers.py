@@ -87,6 +87,56 @@ def judge_r3_image(w, h, seed, kind):
     return img
 
 
+# Round 4's judge: fifteen more frames through the unmodified reference sources built against a fresh stand-in (8
+# lanes, halving-tree SumOfLanes, fused MulAdd, exact reciprocal), four content kinds no earlier fixture had
+# (checkerboard, gradient, sparse impulses, HDR x5), d = 0.25 ... 25.  A sixteenth,
+# 2049 x 2049, makes the reference trap (enc_frame.cc:335-339: its corner DC group is ONE block) -- no answer exists;
+# see test_frames_whose_corner_dc_group_is_one_block in test_gpu_parity.py.
+# (kind, w, h, distance, seed) -> (bytes, sha-256)
+JUDGE_R4 = {
+    ("smooth", 777, 333, 1.3, 101): (17545, "6200aa7f4a36dd03fcd3def6a504ad3efea323949b1ab12ae1aec1f78200d7a0"),
+    ("hdr", 4097, 130, 2.2, 103): (103590, "5ed4a2eaceada9ad9976c3290cdf3e6f8ebb5e29254e840bbba54c30c9f603e2"),
+    ("checker", 130, 4097, 5.0, 104): (85055, "ed322fc9cd9434cfa50ae4edacbd1bc25fb40df8e555f08f1f146dfeaf749f9a"),
+    ("noise", 1500, 1500, 0.3, 105): (2725197, "81c788956ec8f32d94901a254963b06cd9c3b33ac04440683be7f57a00677856"),
+    ("smooth", 3000, 2000, 9.5, 106): (115131, "46c80b198c9d167dba59071783be92936cedf73e924663bf3913186ac6a5178f"),
+    ("grad", 640, 480, 0.25, 107): (12551, "e92720cce06af436cd8902b0561fd3b4a0ca596f695750fb0c93a38eb93aea35"),
+    ("smooth", 2560, 1440, 7.5, 108): (72686, "aecb7082b725498dbc1d7eed0cd3db70a9a10651c512a478e3420f28bd7a275c"),
+    ("smooth", 256, 256, 25.0, 109): (1240, "b25d64e8b8e2aacbf5cba5bea0875518fbac40109f769851cb16cef1a67e290a"),
+    ("smooth", 8, 16, 1.0, 110): (196, "17412c51493e9342b91938028d9174f0dbd9deb46d61f63c20286a017d7c94b3"),
+    ("sparse", 1111, 999, 1.0, 111): (34963, "dcf298a8d165850c64fa524d7b56c09b08cba06af2c09e1d151f5010ea1ad489"),
+    ("checker", 2100, 2100, 1.0, 112): (1740443, "b39397b1070acaed5946ccb8fcf7c6166ba3ba9eaa0adde2b5c8852e4e6c416a"),
+    ("grad", 4096, 4096, 1.0, 113): (239329, "5e457fa8fe7fdc67079baec35a0cfaa1559cedd0518a9a69b3321bd98eec5a0b"),
+    ("hdr", 3840, 2160, 0.5, 114): (4278049, "533a5a96d253cf80ba37f45308c52f94b614e50b5e1e267cc323d0a484a4a012"),
+    ("sparse", 600, 5000, 3.3, 115): (52994, "cce882ad7249475b2dd4e2b0e3a2b6e0cd2af59dfb257fac0fd86af8596dc861"),
+    ("noise", 520, 260, 14.0, 116): (4917, "1ec54627ed22cc3e60de440f5872fe58cba27294dc196dc9516dad08771adf2c"),
+}
+
+
+def judge_r4_image(kind, w, h, seed):
+    """The judge's six generators, as VERDICT.md (round 4, item 4c) writes them."""
+    rng = np.random.default_rng(seed)
+    S = T.synthetic_image
+    if kind == "smooth":
+        return S(w, h, seed=seed)
+    if kind == "noise":
+        return S(w, h, seed=seed, hard=True)
+    if kind == "hdr":
+        return (S(w, h, seed=seed) * np.float32(5.0) - np.float32(0.5)).astype(np.float32)
+    y, x = np.mgrid[0:h, 0:w]
+    if kind == "checker":
+        a = (((x // 5) + (y // 3)) % 2).astype(np.float32)
+        out = np.stack([a * 0.9 + 0.02, (1 - a) * 0.7 + 0.1, a * 0.3 + 0.3], -1).astype(np.float32)
+        return out + rng.normal(0, 0.003, out.shape).astype(np.float32)
+    if kind == "grad":
+        out = np.stack([x / max(w - 1, 1), y / max(h - 1, 1), (x + y) / max(w + h - 2, 1)], -1).astype(np.float32)
+        return (out ** np.float32(2.2)).astype(np.float32)
+    assert kind == "sparse"
+    out = np.full((h, w, 3), 0.1, np.float32)
+    idx = rng.integers(0, h * w, size=max(4, h * w // 997))
+    out.reshape(-1, 3)[idx] = rng.random((len(idx), 3)).astype(np.float32)
+    return out
+
+
 def _unfused_lib():
     base = T.oracle()
     lib = C.CDLL(str(T.ROOT / "oracle" / "liboracle_nofma.so"))
@@ -136,6 +186,15 @@ def test_bytes_of_the_round3_judges_stand_in_build(built, key):
     planes = T.to_planes(judge_r3_image(w, h, seed, kind))
     cs = T.oracle_codestream(T.oracle_hot_path(planes, d), d, reference_single_symbol=True)
     assert (len(cs), hashlib.sha256(cs).hexdigest()) == JUDGE_R3[key]
+
+
+@pytest.mark.parametrize("key", sorted(JUDGE_R4), ids=lambda k: "%s_%dx%d_d%g_s%d" % k)
+def test_bytes_of_the_round4_judges_stand_in_build(built, key):
+    import hashlib
+    kind, w, h, d, seed = key
+    planes = T.to_planes(judge_r4_image(kind, w, h, seed))
+    cs = T.oracle_codestream(T.oracle_hot_path(planes, d), d, reference_single_symbol=True)
+    assert (len(cs), hashlib.sha256(cs).hexdigest()) == JUDGE_R4[key]
 
 
 def test_decodable_mode_differs_only_where_single_symbol_codes_occur(built):
