@@ -6,7 +6,10 @@
 #include <math.h>
 #include <string.h>
 
-#include "jxlt_device.h"
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "jxlt_device_common.h"
 #include "jxlt_tables.h"
 
 namespace jxlt_dev {

@@ -39,15 +39,9 @@ constexpr int kPackWindowWords = kPackTile * 28 / 32 + 4;        // <= 28 bits p
 // while seven waited, 64 extra records staged per tile, two more barriers.)  Up to 3 bytes behind a
 // blob's last section are zeroed.
 // ---------------------------------------------------------------------------
-constexpr int kPackMaxLaunches = 8;
+// (kPackMaxLaunches: jxlt_device_common.h)
 
-struct alignas(16) PackTileInfo {
-  uint64_t rec_first;      // absolute index of the tile's first record
-  uint64_t bit_pos;        // bit position of the tile in the blob (section-relative until finalised)
-  uint64_t sec_start_bit;  // bit position of the tile's section in the blob (section index until finalised)
-  uint32_t n_last;         // records in the tile | last tile of its section << 31
-  uint32_t before;         // records of the section in front of the tile
-};
+// (PackTileInfo: jxlt_device_common.h)
 
 struct PackTileArgs {
   const uint8_t* records;           // 3-byte records
@@ -67,8 +61,8 @@ struct PackTileArgs {
   uint32_t tile_end;                // one past the last tile of this launch (clamped to the tile count)
   // The writing pass runs as `launches` launches over the tile ranges [launch_t0[i], launch_t0[i + 1]);
   // pack_tile_finalize_kernel files in launch_sec_end[i] how many sections are complete behind launch i (all their
-  // tiles lie below launch_t0[i + 1]), so that the hand-over kernel behind launch i knows its byte range without the
-  // host (pack_deliver_kernel).  launch_sec_end may be null (no hand-over by launches).
+  // tiles lie below launch_t0[i + 1]): the host issues the copy of exactly those sections behind launch i.
+  // launch_sec_end may be null (no hand-over by launches).
   uint32_t launches;
   uint32_t launch_t0[kPackMaxLaunches + 1];
   uint32_t* launch_sec_end;         // [launches]
@@ -78,14 +72,6 @@ struct PackTileArgs {
   unsigned long long* tile_state;   // [tiles]
   unsigned long long* block_state;  // [tiles / 64 + 1]
   uint32_t* tile_ticket;            // [kPackMaxLaunches]: how many workgroups of a launch have started (zeroed by the plan)
-  // Single pass with ONE launch: the tile that is the last to say its size knows that the sections' bit counts are
-  // complete -- it stores them to the host's page-locked mirror and then `host_seq` to the word the host polls, while
-  // the launch is still packing (no publish kernel behind the launch: the host has the sizes, and has queued the copy
-  // behind the launch's event, before the launch ends).  NULL: a publish kernel behind the launch does it.
-  uint32_t* sized_count;            // [kPackMaxLaunches] tiles that have said their size (zeroed by the plan)
-  uint32_t* host_sec_bits;          // [nsec], page-locked host memory (mapped)
-  uint32_t* host_flag;
-  uint32_t host_seq;
   uint32_t launch_index;            // which of the writing launches this is (its last tile files launch_sec_end)
   uint32_t* lookback_stats;         // optional (JXLT_TRACE_EVENTS): [0] tiles [1] windows looked at [2] reloads of a window
                                     // [3] most windows one tile looked at
@@ -120,25 +106,11 @@ JXLT_DI void pack_state_store(unsigned long long* p, unsigned long long v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 JXLT_DI void pack_state_wait() { __builtin_amdgcn_s_sleep(2); }
-// (acquire + release: whoever draws the last number sees what every earlier drawer did before drawing)
-JXLT_DI uint32_t pack_count_up(uint32_t* p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT); }
-JXLT_DI uint32_t pack_bits_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #else
 JXLT_DI unsigned long long pack_state_load(const unsigned long long* p) { return *(const volatile unsigned long long*)p; }
 JXLT_DI void pack_state_store(unsigned long long* p, unsigned long long v) { *(volatile unsigned long long*)p = v; }
 JXLT_DI void pack_state_wait() {}
-JXLT_DI uint32_t pack_count_up(uint32_t* p) { return (*p)++; }
-JXLT_DI uint32_t pack_bits_load(const uint32_t* p) { return *(const volatile uint32_t*)p; }
 #endif
-// The sections' bit counts -> the host's mirror, then the pass's number to the word the host polls (one wave).
-JXLT_DI void pack_publish_sizes(const uint32_t* sec_bits, uint32_t* host_sec_bits, int nsec, uint32_t* host_flag, uint32_t seq,
-                                int lane) {
-  for (int i = lane; i < nsec; i += 64) host_sec_bits[i] = pack_bits_load(sec_bits + i);
-  JXLT_THREADFENCE_SYSTEM();
-  JXLT_WAVE_SYNC();
-  if (lane == 0) *(volatile uint32_t*)host_flag = seq;
-}
-
 // What a run of tiles does to the position in front of it: p -> round8(p + pre) + rest (a section starts inside the
 // run), or p -> p + pre.  32 bits do for 64 tiles of < 2^17 bits and for 64 blocks of < 2^23.
 struct PackWindowAhead {
@@ -269,6 +241,52 @@ JXLT_DI uint32_t pack_section_records(const PackTileArgs& A, int sec) {
   return A.sec_rec_count ? A.sec_rec_count[sec] : (uint32_t)(A.sec_rec_offset[sec + 1] - A.sec_rec_offset[sec]);
 }
 
+// ---------------------------------------------------------------------------
+// Exclusive scan of up to a few ten thousand 32-bit counts into 64-bit offsets (single workgroup):
+// offsets[i] = counts[0] + ... + counts[i - 1], offsets[n] = the total.  Every thread owns a contiguous run
+// (all of its loads in flight together), one wave scan + one barrier for the runs' totals.
+// ---------------------------------------------------------------------------
+constexpr int kScanThreads = 1024;
+constexpr int kScanMaxPerThread = 32;  // counts per thread and pass: frames of the usual shapes (<= 32 768 sections of a
+                                       // kind) take one pass, narrow and tall ones (64 x 16M: 65 536 AC groups) several
+__global__ void __launch_bounds__(kScanThreads) group_scan_kernel(const uint32_t* counts, uint64_t* offsets, int n) {
+  __shared__ uint64_t wave_total[kScanThreads / 64];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int kPass = kScanThreads * kScanMaxPerThread;
+  uint64_t carry = 0;  // the total of the passes before this one
+  for (int base = 0; base < n || base == 0; base += kPass) {
+    const int m = imin(n - base, kPass);
+    const int per = (m + kScanThreads - 1) / kScanThreads;
+    const int beg = base + tid * per, end = imin(base + m, beg + per);
+    uint32_t v[kScanMaxPerThread];
+    uint64_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < kScanMaxPerThread; k++) {
+      v[k] = (k < per && beg + k < end) ? counts[beg + k] : 0u;
+      mine += v[k];
+    }
+    uint64_t incl = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_total[wave] = incl;
+    __syncthreads();
+    uint64_t run = carry + incl - mine;
+    for (int w = 0; w < wave; w++) run += wave_total[w];
+    for (int w = 0; w < kScanThreads / 64; w++) carry += wave_total[w];
+#pragma unroll
+    for (int k = 0; k < kScanMaxPerThread; k++) {
+      if (k < per && beg + k < end) {
+        offsets[beg + k] = run;
+        run += v[k];
+      }
+    }
+    __syncthreads();  // (the next pass overwrites wave_total)
+  }
+  if (tid == 0) offsets[n] = carry;
+}
+
 __global__ void __launch_bounds__(256) pack_tile_count_kernel(const PackTileArgs A) {
   const int s = (int)(blockIdx.x * 256 + threadIdx.x);
   if (s < A.nsec) A.sec_tiles[s] = (pack_section_records(A, s) + kPackTile - 1) / kPackTile;
@@ -286,7 +304,6 @@ __global__ void __launch_bounds__(256) pack_tile_plan_kernel(const PackTileArgs 
       for (int i = 0; i < kPackMaxLaunches; i++) {
         A.launch_sec_end[i] = 0xFFFFFFFFu;  // "no tile in this launch"
         A.tile_ticket[i] = 0;
-        A.sized_count[i] = 0;
       }
   }
   for (uint32_t t = t0; t < t1; t++) {
@@ -353,11 +370,7 @@ JXLT_DI uint32_t pack_thread_record(const PackThreadRecords& r, int j) {  // ctx
 // many contexts: with rows of 64 dwords those all sit in the banks of symbols 0-3.  The 32-bit table rotates every
 // row by its context (symbol 0 of the 64 contexts: 64 banks; 366 -> 129 conflict cycles per wave, same time).  (The
 // byte table of the measuring pass stays context-major: symbol-major measured slower, its fill conflicts.)
-#ifdef JXLT_PACK_PLAIN_TABLE
-JXLT_DI int pack_table_slot(uint32_t ctx, uint32_t sym) { return (int)(ctx * 64 + sym); }
-#else
 JXLT_DI int pack_table_slot(uint32_t ctx, uint32_t sym) { return (int)(ctx * 64 + ((sym + ctx) & 63u)); }
-#endif
 // Bit length and bits of one record, without branches (a tile mixes raw-bit records, small values and values with
 // extra bits lane by lane: as branches every record cost the wave all three paths plus the exec-mask bookkeeping).
 // Symbol and extra-bit count of a value >= 16 come from its float form (hybrid_uint_symbol, jxlt_device_common.h);
@@ -394,14 +407,8 @@ constexpr uint32_t kPackNoRecord = 0x80u;  // a raw-bit record of zero bits
 // Consecutive tiles per workgroup (amortises the table load).  The writing pass runs as several launches (the
 // copies to the host follow launch by launch), each of which ends with a partly empty machine for as long as a
 // workgroup lives: two tiles per workgroup there (0.735 -> 0.64 Mcycles per 16384^2 frame; one tile: 0.685).
-#ifndef JXLT_PACK_WRITE_TILES
-#define JXLT_PACK_WRITE_TILES 2
-#endif
-#ifndef JXLT_PACK_MEASURE_TILES
-#define JXLT_PACK_MEASURE_TILES 4
-#endif
-constexpr int kPackWriteTilesPerGroup = JXLT_PACK_WRITE_TILES;
-constexpr int kPackMeasureTilesPerGroup = JXLT_PACK_MEASURE_TILES;
+constexpr int kPackWriteTilesPerGroup = 2;
+constexpr int kPackMeasureTilesPerGroup = 4;
 
 // A sum does not care about the order of its terms: every thread takes four consecutive records (12 bytes, three
 // unaligned dword loads straight from global memory -- the lanes of a wave cover 768 contiguous bytes) instead of
@@ -580,12 +587,7 @@ JXLT_DI void pack_tile_write_body(const PackTileArgs& A) {
     for (int q = 0; q < 64 * 64 / kPackThreads; q++) tl[q] = A.code_table[tid + q * kPackThreads];
     __syncthreads();
     first_tile = ticket;
-    if (first_tile >= ntiles_all) {
-      // (a launch without a single tile: the first workgroup reports the sizes -- all zero)
-      if (A.host_flag && first_tile == A.tile_first && tid < 64)
-        pack_publish_sizes(A.sec_bits, A.host_sec_bits, A.nsec, A.host_flag, A.host_seq, tid);
-      return;
-    }
+    if (first_tile >= ntiles_all) return;
     cur = A.tile_info[first_tile];
     nxt = cur;
     pack_request_tile(A.records + 3 * cur.rec_first, (int)(cur.n_last & 0x7FFFFFFFu), tid, &loads);
@@ -669,12 +671,6 @@ JXLT_DI void pack_tile_write_body(const PackTileArgs& A) {
         }
         mates_loaded = pack_mates_load(A.tile_state, tile, tid);
         blocks_loaded = pack_blocks_load(A.block_state, (long long)(tile / kPackBlockTiles) - 1, tid);
-        if (A.host_flag) {
-          uint32_t said = 0;
-          if (tid == 0) said = pack_count_up(A.sized_count + A.launch_index) + 1u;
-          said = (uint32_t)__shfl((int)said, 0);
-          if (said == ntiles_all - A.tile_first) pack_publish_sizes(A.sec_bits, A.host_sec_bits, A.nsec, A.host_flag, A.host_seq, tid);
-        }
       }
       pos_bit = 0;
     }
@@ -682,18 +678,6 @@ JXLT_DI void pack_tile_write_body(const PackTileArgs& A) {
     const uint64_t word0 = pos_bit >> 5;
     // pass 2: the thread's records concatenated in a register pair, completed dwords OR-ed into the window
     // (LDS atomics are the expensive part: a record at a time -- 16 per thread -- made the kernel 45 % slower)
-#ifdef JXLT_PACK_RECORD_ATOMICS
-    {
-      uint32_t pos = lead + wave_base + incl - mine;
-#pragma unroll
-      for (int j = 0; j < kPackPerThread; j++) {
-        const unsigned long long v = (unsigned long long)data[j] << (pos & 31u);
-        atomicOr(&window[pos >> 5], (uint32_t)v);
-        atomicOr(&window[(pos >> 5) + 1], (uint32_t)(v >> 32));
-        pos += nb[j];
-      }
-    }
-#else
     {
       const uint32_t pos = lead + wave_base + incl - mine;
       uint32_t w = pos >> 5;
@@ -712,7 +696,6 @@ JXLT_DI void pack_tile_write_body(const PackTileArgs& A) {
       }
       if (fill) atomicOr(&window[w], (uint32_t)acc);
     }
-#endif
     if constexpr (kStream) {
       if (tid < 64) {
         const uint32_t sec = (uint32_t)cur.sec_start_bit;  // (the plan's section index: nothing has replaced it)
@@ -779,164 +762,6 @@ JXLT_DI void pack_tile_write_body(const PackTileArgs& A) {
 }
 __global__ void __launch_bounds__(kPackThreads) pack_tile_write_kernel(const PackTileArgs A) { pack_tile_write_body<false, kPackWriteTilesPerGroup>(A); }
 __global__ void __launch_bounds__(kPackThreads) pack_tile_stream_kernel(const PackTileArgs A) { pack_tile_write_body<true, kPackStreamTilesPerGroup>(A); }
-
-// ---------------------------------------------------------------------------
-// Hand-over to the host without the host (round 4).
-//
-// Until round 3 every result the host waited for came through hipMemcpyAsync + an event: ~20 us of device time for a
-// 16 KB download (tools/d2h_probe.hip: the runtime's copy kernel) and ~12 us for the host to notice the event, six
-// to eight times per frame; and the section bytes could only leave once the HOST had read their sizes and issued the
-// copies.  Now kernels store to the host's page-locked memory themselves:
-//   publish_kernel        small results (histograms, counts, section sizes) + a sequence word the host polls
-//   pack_deliver_kernel   the packed sections, at byte ranges it reads from the device-side layout
-// A 16 KB publish takes ~6 us and its flag is seen ~6 us after the launch; the section bytes travel at the link's
-// rate (54 GB/s, the same as hipMemcpyAsync) with no host round trip in front of them.
-// ---------------------------------------------------------------------------
-
-// (four waves: a workgroup that fits whatever is free on a CU that another kernel fills)
-constexpr int kPublishThreads = 256;
-constexpr int kPublishSegments = 4;
-struct PublishArgs {
-  const uint32_t* src[kPublishSegments];  // device memory, dword granular
-  uint32_t* dst[kPublishSegments];        // page-locked host memory (mapped)
-  uint32_t words[kPublishSegments];
-  // optional: one 64-bit word of device memory copied behind the segments (a total the host wants with them)
-  const unsigned long long* src64;
-  unsigned long long* dst64;
-  uint32_t* flag;   // host memory: receives `seq` when everything above is visible to the host
-  uint32_t seq;
-};
-// ONE workgroup (the payloads are a few KB to a few hundred KB): no cross-workgroup completion protocol.
-__global__ void __launch_bounds__(kPublishThreads) publish_kernel(const PublishArgs A) {
-  const uint32_t tid = threadIdx.x;
-#pragma unroll
-  for (int k = 0; k < kPublishSegments; k++) {
-    const uint32_t n = A.words[k];
-    const uint32_t* src = A.src[k];
-    uint32_t* dst = A.dst[k];
-    // 16 bytes per lane where both sides allow it (segments start 16-byte aligned as a rule), dwords for the rest
-    const bool wide = (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
-    const uint32_t n4 = wide ? n >> 2 : 0;
-    const uint4* src4 = reinterpret_cast<const uint4*>(src);
-    uint4* dst4 = reinterpret_cast<uint4*>(dst);
-    for (uint32_t i = tid; i < n4; i += kPublishThreads) dst4[i] = src4[i];
-    for (uint32_t i = 4 * n4 + tid; i < n; i += kPublishThreads) dst[i] = src[i];
-  }
-  if (tid == 0 && A.src64) *A.dst64 = *A.src64;
-  JXLT_THREADFENCE_SYSTEM();
-  __syncthreads();
-  if (tid == 0 && A.flag) {
-    *(volatile uint32_t*)A.flag = A.seq;
-  }
-}
-
-// The packed sections of one kind leave the device blob for the destination (page-locked host memory, or device
-// memory): `nruns` runs of consecutive sections, run r = sections [first, first + count) -> dst + dst_offset[r]
-// (their bytes are contiguous in the blob: sec_byte_offset).  Three ways to say which:
-//   launch >= 0   ONE run, the sections writing launch `launch` has completed (launch_sec_end, filed by
-//                 pack_tile_finalize_kernel), at dst + their offset in the blob
-//   nruns > 0     the caller's runs (a slab of a frame that is shared by several GPUs: its sections are not one
-//                 range of the codestream)
-// end_aligned: the destination is where the LAST byte of all sections ends (dst - total + offset): the sections of a
-// kind whose size the host does not know yet can be set against a fixed end.
-constexpr int kDeliverThreads = 1024;
-constexpr int kDeliverMaxRuns = 48;
-struct DeliverRun {
-  uint32_t first, count;
-  uint64_t dst_offset;
-};
-struct DeliverArgs {
-  const uint8_t* blob;
-  const uint64_t* sec_byte_offset;  // [nsec + 1]
-  const uint32_t* launch_sec_end;   // [launches] (launch mode)
-  uint8_t* dst;
-  int nsec;
-  int launch;       // >= 0: launch mode
-  int nruns;        // run mode
-  int end_aligned;
-  DeliverRun runs[kDeliverMaxRuns];
-  // completion: the last workgroup to finish stores `seq` to *flag (host memory); counter: device memory, zero
-  // between launches (the last workgroup resets it).  flag may be null.
-  uint32_t* counter;
-  uint32_t* flag;
-  uint32_t seq;
-};
-JXLT_DI void deliver_bytes(const uint8_t* src, uint8_t* dst, uint64_t n, uint64_t wg, uint64_t nwg, uint32_t tid) {
-  // destination-aligned 16-byte chunks (what the link likes); the source may sit at any byte (unaligned 16-byte
-  // loads are single instructions on gfx950); head and tail bytes by the first workgroup
-  const uint64_t head = (16 - ((uintptr_t)dst & 15)) & 15;
-  const uint64_t h = head < n ? head : n;
-  const uint64_t body = (n - h) >> 4;
-  if (wg == 0) {
-    if (tid < h) dst[tid] = src[tid];
-    const uint64_t tail0 = h + (body << 4);
-    if (tail0 + tid < n && tid < 16) dst[tail0 + tid] = src[tail0 + tid];
-  }
-#ifdef __clang__
-  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-#else
-  typedef unsigned int v4u __attribute__((vector_size(16)));  // (the CPU model of tests/hipsim is built with g++)
-#endif
-  v4u* d16 = reinterpret_cast<v4u*>(dst + h);
-  const uint8_t* s = src + h;
-  // four chunks per lane and round: all four loads are requested before the first store, so that a handful of
-  // workgroups keep the link busy (the fewer waves the hand-over occupies, the less it holds up the kernels that
-  // run beside it: 8 workgroups were faster for the frame than 64, tools/handover_sweep.sh)
-  const uint64_t stride = nwg * kDeliverThreads;
-  uint64_t i = wg * kDeliverThreads + tid;
-#if defined(JXLT_DELIVER_PLAIN_STORES) || !defined(__clang__)
-#define JXLT_DELIVER_STORE(p, v) *(p) = (v)
-#else
-  // (non-temporal: the bytes are on their way out of the device -- they must not displace what the kernels running
-  // beside the hand-over keep in the L2)
-#define JXLT_DELIVER_STORE(p, v) __builtin_nontemporal_store((v), (p))
-#endif
-  for (; i + 3 * stride < body; i += 4 * stride) {
-    v4u v0, v1, v2, v3;
-    __builtin_memcpy(&v0, s + (i << 4), 16);
-    __builtin_memcpy(&v1, s + ((i + stride) << 4), 16);
-    __builtin_memcpy(&v2, s + ((i + 2 * stride) << 4), 16);
-    __builtin_memcpy(&v3, s + ((i + 3 * stride) << 4), 16);
-    JXLT_DELIVER_STORE(&d16[i], v0);
-    JXLT_DELIVER_STORE(&d16[i + stride], v1);
-    JXLT_DELIVER_STORE(&d16[i + 2 * stride], v2);
-    JXLT_DELIVER_STORE(&d16[i + 3 * stride], v3);
-  }
-  for (; i < body; i += stride) {
-    v4u v;
-    __builtin_memcpy(&v, s + (i << 4), 16);
-    JXLT_DELIVER_STORE(&d16[i], v);
-  }
-#undef JXLT_DELIVER_STORE
-}
-__global__ void __launch_bounds__(kDeliverThreads) pack_deliver_kernel(const DeliverArgs A) {
-  const uint32_t tid = threadIdx.x;
-  const uint64_t total = A.sec_byte_offset[A.nsec];
-  const int64_t shift = A.end_aligned ? -(int64_t)total : 0;
-  if (A.launch >= 0) {
-    const uint32_t s_lo = A.launch > 0 ? A.launch_sec_end[A.launch - 1] : 0u;
-    const uint32_t s_hi = A.launch_sec_end[A.launch];
-    const uint64_t lo = A.sec_byte_offset[s_lo], hi = A.sec_byte_offset[s_hi > s_lo ? s_hi : s_lo];
-    deliver_bytes(A.blob + lo, A.dst + shift + (int64_t)lo, hi - lo, blockIdx.x, gridDim.x, tid);
-  } else {
-    // every workgroup takes a share of every run (runs are few and long, or few and short)
-    for (int r = 0; r < A.nruns; r++) {
-      const uint64_t lo = A.sec_byte_offset[A.runs[r].first], hi = A.sec_byte_offset[A.runs[r].first + A.runs[r].count];
-      deliver_bytes(A.blob + lo, A.dst + shift + (int64_t)A.runs[r].dst_offset, hi - lo, blockIdx.x, gridDim.x, tid);
-    }
-  }
-  if (A.flag) {
-    JXLT_THREADFENCE_SYSTEM();
-    __syncthreads();
-    if (tid == 0) {
-      if (atomicAdd(A.counter, 1u) == gridDim.x - 1) {
-        *A.counter = 0u;
-        JXLT_THREADFENCE_SYSTEM();
-        *(volatile uint32_t*)A.flag = A.seq;
-      }
-    }
-  }
-}
 
 }  // namespace jxlt_dev
 

@@ -34,7 +34,7 @@ constexpr int kCflTermFloats = 64 * 64 * 4;  // LDS floats overlaid by the CfL t
 // the eight 32-byte runs the octets of a wave store at a time land in different banks
 constexpr int kStageStrideF = 200;
 
-struct alignas(16) TileShared {
+struct alignas(256) TileShared {
   // The tables and the per-block state come FIRST: an LDS address below 64 KB folds into the 16-bit offset field
   // of the instruction that uses it.  Behind the 64 KB of planes / terms the entropy estimate paid two address
   // instructions per coefficient (an add for the root table's base, an or for the weight's row).
@@ -49,7 +49,9 @@ struct alignas(16) TileShared {
   uint32_t ntok;
   uint32_t nfirst;
   uint32_t overflow;  // a quantised magnitude of this tile did not fit the root table
-  uint32_t pad_to_16[3];
+  // (the planes, and with them the transpose areas behind them, start on a multiple of 256 bytes: an area's chunk
+  // numbers are address bits, octet_transpose)
+  uint32_t pad_to_256[3 + 20];
   float x[64 * kXYPitch];
   float y[64 * kXYPitch];
   float b[64 * kBPitch];
@@ -59,23 +61,30 @@ struct alignas(16) TileShared {
   float cfl_pad[kCflTermFloats - (2 * 64 * kXYPitch + 64 * kBPitch + 16 * 72 + 16 * kPrePitch + 16 * 16)];
   // ^ x..cfl_pad (64 KB) are overlaid by the chroma-from-luma terms once every pixel
   //   read is done: 64 blocks x 64 coefficients x (a_x, b_x, a_b, b_b).
-  // rowsum..transpose_pad: during the transforms (the AQ buffers are dead by then) the octets'
-  // transpose scratch, 64 x kTransposePitch floats.
+  // rowsum..transpose_pad: during the transforms (the AQ buffers are dead by then) the candidate octets'
+  // transpose areas, 64 x kTransposePitch floats, behind them the fourth pair wave's half-size rows
+  // (kHalfTransposeWaveFloats; the other three pair waves' are in sqrt_lut) and at the very end p4_sums.
   // (+ 192: 17 x 128 floats -- with the 8 x 128 of sqrt_lut the 25 x 128 in which the chain waves of the 12-wave
   // kernel park coefficients during the chains)
   // (+ 64: its last 256 floats -- behind the 64 transpose areas -- hold the four sums per block that P4 leaves for the
   // wave that finishes the quant field, "p4_sums"; until round 4 those sat in sqrt_lut, which is the pair octets'
   // transpose scratch now)
   float transpose_pad[64 * 72 - (kCflTermFloats - (2 * 64 * kXYPitch + 64 * kBPitch)) + 192 + 64];
+  static constexpr int kScratchFloats = 16 * 72 + 16 * kPrePitch + 16 * 16 +
+                                        (kCflTermFloats - (2 * 64 * kXYPitch + 64 * kBPitch + 16 * 72 + 16 * kPrePitch + 16 * 16)) +
+                                        (64 * 72 - (kCflTermFloats - (2 * 64 * kXYPitch + 64 * kBPitch)) + 192 + 64);
   // (its first 128 floats hold the candidate entropies of the 2x2 cells during the strategy search, "ent8")
 };
-static_assert(offsetof(TileShared, x) % 16 == 0, "the term area is accessed in 16-byte chunks");
+static_assert(offsetof(TileShared, x) % 256 == 0 && offsetof(TileShared, rowsum) % 256 == 0 &&
+                  offsetof(TileShared, sqrt_lut) % 256 == 0,
+              "the term area is accessed in 16-byte chunks, the transpose areas are 256-byte aligned");
+static_assert(TileShared::kScratchFloats >= 64 * kTransposePitch + kHalfTransposeWaveFloats + 256,
+              "candidate areas + one pair wave's rows + p4_sums");
+static_assert(sizeof(TileShared) <= 81920, "two workgroups per CU");
 // After the last pixel read the XYB planes are dead and are reused: chroma-from-luma terms, the parked
 // DCT8 coefficients of the entropy estimate, then the staging area of the selected transforms' coefficients
 // (64 blocks x 3 channels x 64 floats).
 
-JXLT_DI int imin(int a, int b) { return a < b ? a : b; }
-JXLT_DI int imax(int a, int b) { return a > b ? a : b; }
 
 // Per-octet entropy estimate of one transform (enc_ac_strategy.cc:51-146).
 // cy/cx/cb: the lane's rows of the Y/X/B coefficients; NR rows (8 or 16).
@@ -132,25 +141,17 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
       entropy_v = fma32(clamp01(q - 1.0f), kCost2, entropy_v);  // + (q >= 1.5 ? kCost2 : 0)
       float root;
       if (kLut) {
-#ifndef JXLT_LUT_OFFSET_BY_FMA
         // The byte offset 4 * q as the bit pattern of the DENORMAL q * 2^-147 (= 4 q units of 2^-149; the kernels run
         // with denormals on, hipcc's default): ONE multiplication, no float -> int conversion (a 4-cycle instruction)
         // and no mask.  q >= kSqrtLutSize reads beyond the table -- other LDS words of the tile or, beyond the
         // workgroup's allocation, the zero the hardware returns for such a read; q >= 2^21, infinities and NaNs give
         // patterns with exponent bits set -- and every such tile is redone by the caller (the OR below keeps the bits
         // for its test).  The multiplier sits in a vector register (a VOP3 instruction takes no literal on gfx950, and
-        // one with an SGPR source costs four cycles instead of two).
+        // one with an SGPR source costs four cycles instead of two).  (Rounds 2-4: the pattern of 4 q + 2^23, a
+        // multiply-add and a mask.)
         const uint32_t off_raw = __float_as_uint(q * lut_step);
         root = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sqrt_lut) + JXLT_LUT_WRAP(off_raw));
         qbits |= off_raw;
-#else
-        // (rounds 2-4) 4 * q + 2^23 is exact for q < 2^21 and its bit pattern is 0x4B000000 + 4 * q: the byte
-        // offset comes out of a multiply-add and a mask.
-        const uint32_t off_raw = __float_as_uint(fma32(q, 4.0f, 8388608.0f));
-        const uint32_t off = off_raw & (uint32_t)(kSqrtLutSize * 4 - 4);
-        root = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sqrt_lut) + off);
-        qbits |= off_raw;
-#endif
       } else {
         // (skipping the root with a branch where a whole wave has q <= 1 was tried: control flow
         // inside this loop makes the register allocator spill)
@@ -170,13 +171,8 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
   const float infoloss = octet_sum(info_loss);
   const float infoloss2 = sqrtf(num_blocks * octet_sum(info_loss2));
   const float info_loss_score = (kInfoLossMultiplier * infoloss + kInfoLossMultiplier2 * infoloss2);
-#ifndef JXLT_LUT_OFFSET_BY_FMA
   // every offset stayed inside the table <=> no bit above the offset field is set
   if (kLut) *qmax = (qbits & ~(uint32_t)(kSqrtLutSize * 4 - 1)) != 0u ? (float)kSqrtLutSize : 0.0f;
-#else
-  // every offset stayed inside the table <=> nothing above the offset field differs from 2^23's pattern
-  if (kLut) *qmax = ((qbits | 0x4B000000u) & ~(uint32_t)(kSqrtLutSize * 4 - 1)) != 0x4B000000u ? (float)kSqrtLutSize : 0.0f;
-#endif
   return entropy + masking * info_loss_score;
 }
 
@@ -353,43 +349,27 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     const int nvec = (aq_x1 - 10 >= vs) ? ((aq_x1 - 10 - vs) / 8 + 1) : 0;
     const int ve = vs + 8 * nvec;
     const int nbands = nby * 2;
-    // One pixel's term from its own value, the sum of its vertical neighbours and its horizontal
-    // neighbours.  kAllVec: the position is one of the reference's vector loop (its association order, its fused
-    // multiply-add) -- known at compile time.  Otherwise both association orders are computed and selected (a
-    // branch per pixel would wait for the LDS before and after each arm).
-    auto pixel_term = [&](auto all_vec, bool vec, float in, float du, float in_l, float in_r, float ix, float dux,
-                          float ix_l, float ix_r) {
-      constexpr bool kAllVec = decltype(all_vec)::value;
+    // One pixel's term from its own value, the sum of its vertical neighbours and its horizontal neighbours.  `vec`:
+    // the position is one of the reference's vector loop (its association order, its fused multiply-add); the other
+    // positions take the scalar loop's.  Both are computed and selected: a branch per pixel would wait for the LDS
+    // before and after each arm.
+    auto pixel_term = [&](bool vec, float in, float du, float in_l, float in_r, float ix, float dux, float ix_l,
+                          float ix_r) {
       const float gammac = ratio_of_derivatives(in + match_gamma_offset, false);
-      if constexpr (kAllVec) {
-        const float base = 0.25f * ((in_r + in_l) + du);
-        float diff = gammac * (in - base);
-        diff = diff * diff;
-        const float base_x = 0.25f * ((ix_r + ix_l) + dux);
-        float diff_x = gammac * (ix - base_x);
-        diff_x = diff_x * diff_x;
-        return masking_sqrt(fma32(kXMul, diff_x, diff), sqrt_mul);
-      } else {
-        // the vector loop adds (right + left) + vertical, the scalar loop (vertical + left) + right: ONE sum of the
-        // form (a + left) + c whose outer operands are selected (two selects instead of four additions and a select)
-#ifndef JXLT_P1_BOTH_ORDERS
-        const float base = 0.25f * (((vec ? in_r : du) + in_l) + (vec ? du : in_r));
-        const float base_x = 0.25f * (((vec ? ix_r : dux) + ix_l) + (vec ? dux : ix_r));
-#else
-        const float base = 0.25f * (vec ? (in_r + in_l) + du : (du + in_l) + in_r);
-        const float base_x = 0.25f * (vec ? (ix_r + ix_l) + dux : (dux + ix_l) + ix_r);
-#endif
-        float diff = gammac * (in - base);
-        diff = diff * diff;
-        float diff_x = gammac * (ix - base_x);
-        diff_x = diff_x * diff_x;
-        const float fused = fma32(kXMul, diff_x, diff), unfused = diff + kXMul * diff_x;
-        return masking_sqrt(vec ? fused : unfused, sqrt_mul);
-      }
+      // the vector loop adds (right + left) + vertical, the scalar loop (vertical + left) + right: ONE sum of the
+      // form (a + left) + c whose outer operands are selected (two selects instead of four additions and a select)
+      const float base = 0.25f * (((vec ? in_r : du) + in_l) + (vec ? du : in_r));
+      const float base_x = 0.25f * (((vec ? ix_r : dux) + ix_l) + (vec ? dux : ix_r));
+      float diff = gammac * (in - base);
+      diff = diff * diff;
+      float diff_x = gammac * (ix - base_x);
+      diff_x = diff_x * diff_x;
+      const float fused = fma32(kXMul, diff_x, diff), unfused = diff + kXMul * diff_x;
+      return masking_sqrt(vec ? fused : unfused, sqrt_mul);
     };
     // One band column (band q = rows 4q .. 4q + 3, stripe column x): its four pixel terms summed, then P2's
     // 4-column average inside the quad of lanes that holds the four columns of one average.
-    auto band_column = [&](auto all_vec, int q, int x, bool first_of_quad) {
+    auto band_column = [&](int q, int x, bool first_of_quad) {
       const bool vec = x >= vs && x < ve;
       const int xl = x > 0 ? x - 1 : x, xr = x + 1 < swp ? x + 1 : x;
       // The band's column, rows y0-1 .. y0+4 (clamped to the stripe: only the first and the
@@ -413,7 +393,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       float acc = 0.0f;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const float diff = pixel_term(all_vec, vec, cy[k + 1], cy[k + 2] + cy[k], ly4[k], ry4[k], cxx[k + 1],
+        const float diff = pixel_term(vec, cy[k + 1], cy[k + 2] + cy[k], ly4[k], ry4[k], cxx[k + 1],
                                       cxx[k + 2] + cxx[k], lx4[k], rx4[k]);
         acc = (k == 0) ? diff : acc + diff;
       }
@@ -425,39 +405,13 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       s4 = s4 + quad_lane<3>(acc);
       if (first_of_quad) S.pre_erosion[q * kPrePitch + ((x - aq_x0) >> 2)] = s4 * 0.25f;
     };
-#ifndef JXLT_P1_SPLIT
-#define JXLT_P1_SPLIT 0
-#endif
-    if constexpr (JXLT_P1_SPLIT != 0) {
-      // Round 4: the 4-column groups that lie in the vector loop's range entirely -- 15 or 16 of a tile's 17 or 18 --
-      // take the vector path alone (no second association order, no selects: -16 % of the phase's instructions);
-      // the one or two groups left go to the waves that have a single pass of the others (10 and 11).
-      const int ga0 = (vs - aq_x0 + 3) >> 2, ga1 = nvec ? (ve - aq_x0) >> 2 : 0;
-      const int na = ga1 > ga0 ? ga1 - ga0 : 0;           // full-vector groups per band
-      const int nb = (aq_w >> 2) - na;                    // the others: groups [0, ga0) and [ga1, aq_w / 4)
-      const int items_a = nbands * na * 4, items_b = nbands * nb * 4;
-      for (int i = tid; i < items_a; i += kThreads) {
-        const int q = i / (na * 4), r = i - q * (na * 4);
-        band_column(std::true_type{}, q, aq_x0 + 4 * ga0 + r, (i & 3) == 0);
-      }
-      // (few: on the last threads, one pass; many -- a narrow tile at the frame's right edge, where the vector
-      // loop's range is short or empty: from thread 0 on, like the others)
-      const bool rotate = items_b <= 192;
-      const int first_b = rotate ? tid - (kThreads - 192) : tid;
-      for (int i = first_b; i < items_b; i += kThreads) {
-        if (i < 0) continue;
-        const int q = i / (nb * 4), r = i - q * (nb * 4);
-        const int g = r >> 2;                              // the band's g-th group outside the vector range
-        const int x = aq_x0 + 4 * (g < ga0 || na == 0 ? g : g + na) + (r & 3);
-        band_column(std::false_type{}, q, x, (i & 3) == 0);
-      }
-    } else {
-      // (Spreading the last, partly filled pass over all threads row by row changes nothing: the
-      // other resident workgroup takes the issue slots the idle waves leave.)
-      for (int i = tid; i < nbands * aq_w; i += kThreads) {
-        const int q = i / aq_w, x = aq_x0 + i % aq_w;
-        band_column(std::false_type{}, q, x, (i & 3) == 0);
-      }
+    // (Spreading the last, partly filled pass over all threads row by row changes nothing: the other resident
+    // workgroup takes the issue slots the idle waves leave.  The 4-column groups that lie entirely in the vector
+    // loop's range on a path of their own -- no second association order, no selects, 15-16 of a tile's 17-18 groups --
+    // was built in round 4 and lost: 3860 against 3886 VALU per wave, 9.41 against 9.33 M cycles)
+    for (int i = tid; i < nbands * aq_w; i += kThreads) {
+      const int q = i / aq_w, x = aq_x0 + i % aq_w;
+      band_column(q, x, (i & 3) == 0);
     }
   }
   __syncthreads();
@@ -566,8 +520,9 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
   };
   // [block][hf, red, blue, gamma]: behind the transpose areas (read before the chain waves park there)
   float* const p4_sums = &S.transpose_pad[sizeof(S.transpose_pad) / sizeof(float) - 256];
-  static_assert(sizeof(S.transpose_pad) / sizeof(float) - 256 >= 64 * kTransposePitch - (kCflTermFloats - (2 * 64 * kXYPitch + 64 * kBPitch)),
-                "p4_sums lies behind the candidate octets' transpose areas");
+  static_assert(offsetof(TileShared, transpose_pad) + sizeof(S.transpose_pad) - 1024 >=
+                    offsetof(TileShared, rowsum) + (64 * kTransposePitch + kHalfTransposeWaveFloats) * sizeof(float),
+                "p4_sums lies behind the transpose areas");
   if (tid < 512) {  // (octets 0..63 = waves 0-7)
     const int bxp = px0 + obx * 8, byp = oby * 8;  // block origin (stripe pixels)
     // HfModulation (:209-247): lane l = column l of the block
@@ -621,9 +576,6 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
   // behind later barriers, the transforms below read the pixel planes only, and their LDS scratch lies over the
   // adaptive-quantisation buffers, which nobody reads behind the barrier in front of P4.  The waves that have no
   // block in P4 -- 8 to 11 of the 12-wave kernel -- start their transforms at once.)
-#ifdef JXLT_P4_BARRIER
-  __syncthreads();
-#endif
   JXLT_MARK(3);
 
   // ---- P6a: candidate two-block transforms (enc_ac_strategy.cc:62-66) -------
@@ -645,7 +597,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     co = oct >= 32 ? oct - 32 : 0;  // candidate octet index (0..63)
     pbx = oct & 7, pby0 = (oct >> 3) * 2;          // pair octet's blocks (12 waves)
     pair_valid0 = pair_role && pbx < nbx && pby0 < nby, pair_valid1 = pair_role && pbx < nbx && pby0 + 1 < nby;
-    tsc = &S.rowsum[0] + co * kTransposePitch;  // candidate octet's transpose scratch (AQ buffers are dead)
+    tsc = &S.rowsum[0] + co * kTransposePitch;  // candidate octet's transpose area (AQ buffers are dead)
     cand = co & 31;                       // candidate index within its type
     cell = cand >> 1;                     // 2x2 cell index (4x4 cells per tile)
     ccx = (cell & 3) * 2, ccy = (cell >> 2) * 2;  // cell origin (tile blocks)
@@ -688,14 +640,13 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
   float* const d8b = c16b + 8;
   if (pair_role) {
     // The pair octets have no transpose area of their own (the 64 there are belong to the candidate octets, which
-    // transpose at the same time): they go through HALF an area each, in the place of the root table (free until the
-    // chains: 4 waves x 256 floats), octet_transpose_half.  (Rounds 3-4: register butterflies, kPairMode 0.)
-#ifndef JXLT_PAIR_TRANSPOSE_MODE
-#define JXLT_PAIR_TRANSPOSE_MODE 2
-#endif
-    constexpr int kPairMode = JXLT_PAIR_TRANSPOSE_MODE;
-    static_assert(sizeof(S.sqrt_lut) >= 4 * 256 * sizeof(float), "the pair waves' transpose areas");
-    float* const psc = &S.sqrt_lut[0] + wave_u * 256;
+    // transpose at the same time): they go through half-size rows per wave, octet_transpose_half -- three waves' in
+    // the place of the root table (free until the chains), the fourth's behind the candidate areas.  (Rounds 3-4:
+    // register butterflies.)
+    constexpr bool kPairMode = true;
+    static_assert(sizeof(S.sqrt_lut) >= 3 * kHalfTransposeWaveFloats * sizeof(float), "three pair waves' rows");
+    // (waves 0-2: in the root table's place; wave 3: behind the candidate octets' areas)
+    float* const psc = wave_u < 3 ? &S.sqrt_lut[0] + wave_u * kHalfTransposeWaveFloats : &S.rowsum[0] + 64 * kTransposePitch;
     const int po = oct & 7;
     const float* pxp = &S.x[(pby0 * 8) * kXYPitch + pbx * 8 + kHalo];
     const float* pyp = &S.y[(pby0 * 8) * kXYPitch + pbx * 8 + kHalo];
@@ -728,17 +679,17 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     // (scheduling fences: interleaving the three independent transforms would triple the
     // live registers and spill)
     if (is_tall) {
-      block_dct16x8<true>(pxp, kXYPitch, l, tsc, c16x);
+      block_dct16x8<true>(pxp, kXYPitch, l, tsc, c16x, oct & 7);
       JXLT_SCHED_FENCE();
-      block_dct16x8<true>(pyp, kXYPitch, l, tsc, c16y);
+      block_dct16x8<true>(pyp, kXYPitch, l, tsc, c16y, oct & 7);
       JXLT_SCHED_FENCE();
-      block_dct16x8<true>(pbp, kBPitch, l, tsc, c16b);
+      block_dct16x8<true>(pbp, kBPitch, l, tsc, c16b, oct & 7);
     } else {
-      block_dct8x16<true>(pxp, kXYPitch, l, tsc, c16x);
+      block_dct8x16<true>(pxp, kXYPitch, l, tsc, c16x, oct & 7);
       JXLT_SCHED_FENCE();
-      block_dct8x16<true>(pyp, kXYPitch, l, tsc, c16y);
+      block_dct8x16<true>(pyp, kXYPitch, l, tsc, c16y, oct & 7);
       JXLT_SCHED_FENCE();
-      block_dct8x16<true>(pbp, kBPitch, l, tsc, c16b);
+      block_dct8x16<true>(pbp, kBPitch, l, tsc, c16b, oct & 7);
     }
     JXLT_SCHED_FENCE();
   } else {
@@ -835,7 +786,6 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
         }
       }
     }
-#ifndef JXLT_CFL_PINGPONG
     // The chains as a RELAY over the four 16-lane rows of the wave.  A row = the 16 chain lanes (X: 8, B: 8); row
     // k handles every fourth block, and the terms of the next four blocks are requested a whole round of four
     // blocks ahead of their use -- in registers the other rows' lanes have anyway.  The
@@ -930,67 +880,6 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     const int final_pos = nblk & 3;  // where the accumulators are after the last hop
     const bool chain_lane = cw < 2 && relay_pos == final_pos;
     const int chain_ch = (cl >> 3) & 1;
-#else
-    if (cw < 2 && cl < 16) {
-      __builtin_amdgcn_s_setprio(3);
-      const int ch = cl >> 3;  // 0: X, 1: B
-      const float* src = terms + l * 32;
-      int slot[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) slot[q] = ((ch * 4 + q) ^ lsw) * 4;
-      // two blocks per iteration, ping-pong buffers (no register copies in the loop)
-      float4 ta[4], tb[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) ta[q] = *(const float4*)&src[slot[q]];
-      const int last = nblk - 1;
-      if (cw == 0) {
-#pragma clang loop unroll(disable)
-        for (int blk = 0; blk < nblk; blk += 2) {
-          const int n1 = imin(blk + 1, last), n2 = imin(blk + 2, last);
-#pragma unroll
-          for (int q = 0; q < 4; q++) tb[q] = *(const float4*)&src[n1 * 256 + slot[q]];
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            acc = fma32(ta[q].x, ta[q].x, acc);
-            acc = fma32(ta[q].z, ta[q].z, acc);
-          }
-#pragma unroll
-          for (int q = 0; q < 4; q++) ta[q] = *(const float4*)&src[n2 * 256 + slot[q]];
-          if (blk + 1 < nblk) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              acc = fma32(tb[q].x, tb[q].x, acc);
-              acc = fma32(tb[q].z, tb[q].z, acc);
-            }
-          }
-        }
-      } else {
-#pragma clang loop unroll(disable)
-        for (int blk = 0; blk < nblk; blk += 2) {
-          const int n1 = imin(blk + 1, last), n2 = imin(blk + 2, last);
-#pragma unroll
-          for (int q = 0; q < 4; q++) tb[q] = *(const float4*)&src[n1 * 256 + slot[q]];
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            acc = fma32(ta[q].x, ta[q].y, acc);
-            acc = fma32(ta[q].z, ta[q].w, acc);
-          }
-#pragma unroll
-          for (int q = 0; q < 4; q++) ta[q] = *(const float4*)&src[n2 * 256 + slot[q]];
-          if (blk + 1 < nblk) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              acc = fma32(tb[q].x, tb[q].y, acc);
-              acc = fma32(tb[q].z, tb[q].w, acc);
-            }
-          }
-        }
-      }
-      __builtin_amdgcn_s_setprio(0);
-    }
-    const bool chain_lane = cw < 2 && cl < 16;
-    const int chain_ch = cl >> 3;
-#endif
     const float total = octet_sum(acc);
     // cfl_sum: ca_x, cb_x, ca_b, cb_b
     if (chain_lane && l == 0) S.cfl_sum[chain_ch * 2 + cw] = total;
@@ -1140,9 +1029,6 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
   // XYB planes are reused as the quantised-coefficient staging area.  No barrier is needed
   // between the stores above (they read S.strat / S.raw_quant, final since the barrier before
   // them) and P8; S.nfirst is read after later barriers.
-#ifdef JXLT_P7_SECOND_BARRIER
-  __syncthreads();
-#endif
   JXLT_MARK(7);
   // ---- P8a: the coefficients of the selected transforms -> LDS ------------------
   // The transforms that the decision kept are quantised in SCAN ORDER by other lanes than the ones that hold

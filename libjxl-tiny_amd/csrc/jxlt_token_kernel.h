@@ -19,51 +19,6 @@ __global__ void __launch_bounds__(256) clear_counters_kernel(const ClearArgs A) 
     if (i < A.n[k]) A.p[k][i] = 0u;
 }
 
-// ---------------------------------------------------------------------------
-// Exclusive scan of up to a few ten thousand 32-bit counts into 64-bit offsets (single workgroup):
-// offsets[i] = counts[0] + ... + counts[i - 1], offsets[n] = the total.  Every thread owns a contiguous run
-// (all of its loads in flight together), one wave scan + one barrier for the runs' totals.
-// ---------------------------------------------------------------------------
-constexpr int kScanThreads = 1024;
-constexpr int kScanMaxPerThread = 32;  // counts per thread and pass: frames of the usual shapes (<= 32 768 sections of a
-                                       // kind) take one pass, narrow and tall ones (64 x 16M: 65 536 AC groups) several
-__global__ void __launch_bounds__(kScanThreads) group_scan_kernel(const uint32_t* counts, uint64_t* offsets, int n) {
-  __shared__ uint64_t wave_total[kScanThreads / 64];
-  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int kPass = kScanThreads * kScanMaxPerThread;
-  uint64_t carry = 0;  // the total of the passes before this one
-  for (int base = 0; base < n || base == 0; base += kPass) {
-    const int m = imin(n - base, kPass);
-    const int per = (m + kScanThreads - 1) / kScanThreads;
-    const int beg = base + tid * per, end = imin(base + m, beg + per);
-    uint32_t v[kScanMaxPerThread];
-    uint64_t mine = 0;
-#pragma unroll
-    for (int k = 0; k < kScanMaxPerThread; k++) {
-      v[k] = (k < per && beg + k < end) ? counts[beg + k] : 0u;
-      mine += v[k];
-    }
-    uint64_t incl = mine;
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint64_t o = __shfl_up(incl, d);
-      if (lane >= d) incl += o;
-    }
-    if (lane == 63) wave_total[wave] = incl;
-    __syncthreads();
-    uint64_t run = carry + incl - mine;
-    for (int w = 0; w < wave; w++) run += wave_total[w];
-    for (int w = 0; w < kScanThreads / 64; w++) carry += wave_total[w];
-#pragma unroll
-    for (int k = 0; k < kScanMaxPerThread; k++) {
-      if (k < per && beg + k < end) {
-        offsets[beg + k] = run;
-        run += v[k];
-      }
-    }
-    __syncthreads();  // (the next pass overwrites wave_total)
-  }
-  if (tid == 0) offsets[n] = carry;
-}
 
 // ---------------------------------------------------------------------------
 // Token kernel: one workgroup per 256x256 group (enc_group.cc:444-494)
@@ -105,11 +60,7 @@ JXLT_DI void token_kernel_body(const TokenArgs& A) {
   const bool do_hist = A.histogram != nullptr;
   // LDS histogram slot of (pre-clustered context, symbol): the symbol is rotated by the context, so that the
   // small symbols nearly all tokens have do not land in the same few banks for every context
-#ifdef JXLT_HIST_PLAIN
-  auto hist_slot = [](uint32_t cm, uint32_t sym) { return cm * 64u + sym; };
-#else
   auto hist_slot = [](uint32_t cm, uint32_t sym) { return cm * 64u + ((sym + cm) & 63u); };
-#endif
   if (do_hist)
     for (int i = tid; i < 64 * 64; i += kTokenThreads) hist[i] = 0;
   for (int i = tid; i < 1980; i += kTokenThreads) s_ctx_map[i] = T->ac_context_map[i];

@@ -236,8 +236,6 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
     ~Joiner() { w->Wait(); }
   } joiner{worker.get()};
   bool ac_first = false;
-  static const bool sequential = getenv("JXLT_CODES_SEQUENTIAL") != nullptr;  // (experiment knob: DC code, then AC code)
-  if (sequential) worker->Wait();
   for (;;) {
     if (worker->Done()) break;
     const int ready = jxlt_histograms_ready(ctx);  // (a read of host memory)

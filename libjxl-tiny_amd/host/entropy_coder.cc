@@ -499,10 +499,7 @@ void ClusterHistograms(std::vector<Histogram>* histograms, std::vector<uint8_t>*
   // (only the loops over all histograms are handed out -- the bit costs, the selection rounds; a loop of a handful of
   // evaluations -- the assignment phase compares one histogram with <= 8 clusters -- costs less than the hand-over.
   // tools/code_bench.py, EPYC 9575F, shared: DC at d = 0.5 0.22 -> 0.19 ms, AC at d = 0.1 0.34 -> 0.24; alone 0.21 / 0.35)
-  static const size_t min_shared = [] {
-    const char* e = getenv("JXLT_POOL_MIN_LOOP");  // (experiment knob)
-    return e ? static_cast<size_t>(atoi(e)) : size_t(32);
-  }();
+  const size_t min_shared = 32;
   auto parallel_for = [&](size_t n, const std::function<void(size_t)>& fn) {
     if (pooled && n >= min_shared) {
       pool.Run(n, fn);

@@ -405,6 +405,7 @@ inline void __builtin_amdgcn_sched_barrier(int) {}  // compiler scheduling fence
 #define JXLT_OCTET_SUM_PORTABLE 1  // (octet_sum: the exchange steps instead of the inline assembly)
 #define JXLT_LAUNDER_VGPR(x) ((void)(x))
 #define JXLT_DEFINE_VGPR(x) ((x) = 0)
+#define JXLT_LDS_STORE_ROW(row_base, off, val) ((row_base)[(off) / 4 + hipsim_lane()] = (val))
 #define JXLT_LAUNDER_SGPR(x) ((void)(x))
 #define JXLT_GLOBAL_POINTER_TYPES
 typedef const char* JxltGlobalBytes;

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "../../libjxl-tiny_amd/csrc/jxlt_device.h"
 #include "../../libjxl-tiny_amd/csrc/jxlt_host_tables.h"
 
 using namespace jxlt_dev;
@@ -100,7 +101,7 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
   A.dbg_ent8 = r->ent8 = (float*)malloc(ncells * 8 * 4);
   for (size_t i = 0; i < ncells * 8; i++) A.dbg_ent8[i] = __builtin_nanf("");
 
-  // as jxlt_capi.hip: the table-root kernel, then the redo kernel for the tiles it filed (a quantised magnitude
+  // as jxlt_capi_encode.hip: the table-root kernel, then the redo kernel for the tiles it filed (a quantised magnitude
   // beyond the table), per launch; one launch per row of DC groups with the slab arguments of the product
   // (jxlt_host_tables.h: SlabTileArgs)
   const size_t rows_per_slab = 2048, nsl = (ysize + rows_per_slab - 1) / rows_per_slab;
@@ -265,11 +266,12 @@ __attribute__((visibility("default"))) int sim_pack_direct(const uint8_t* record
   return 0;
 }
 
-// The product's hand-over (EnqueueMeasure / EnqueueDeliver of jxlt_capi.hip): the writing pass in `nlaunch` GROWING
+// The product's hand-over (EnqueueMeasure / EnqueueDeliver of jxlt_capi_pack.hip): the writing pass in `nlaunch` GROWING
 // shares of an upper bound of the tile count, pack_tile_finalize_kernel filing the sections every launch completes,
-// and pack_deliver_kernel behind every launch copying those sections from the blob to `dst` (+ dst_shift bytes, any
-// alignment): mode 0 = launch mode, start-aligned at dst + dst_shift; 1 = launch mode, END-aligned at dst + dst_shift;
-// 2 = run mode, runs given as (first, count, dst_offset) triples of 64-bit words.
+// and behind every launch the copy of exactly those sections from the blob to `dst` (+ dst_shift bytes, any
+// alignment) -- a memcpy here, a copy command in the product (the kernel that did it in round 4 is gone): mode 0 =
+// launch mode, start-aligned at dst + dst_shift; 1 = launch mode, END-aligned at dst + dst_shift; 2 = run mode, runs
+// given as (first, count, dst_offset) triples of 64-bit words, copied behind the last launch.
 __attribute__((visibility("default"))) int sim_pack_deliver(const uint8_t* records, const uint64_t* sec_rec_offset,
                                                              int nsec, const uint32_t* code_table, int nlaunch, int mode,
                                                              uint8_t* dst, uint64_t dst_shift, const uint64_t* runs,
@@ -311,15 +313,9 @@ __attribute__((visibility("default"))) int sim_pack_deliver(const uint8_t* recor
                  dim3(64 * kPackOffsetsSectionsPerGroup), P);
   hipsim::launch(group_scan_kernel, dim3(1), dim3(kScanThreads), (const uint32_t*)sec_bytes.data(), out_offset, nsec);
   hipsim::launch(pack_tile_finalize_kernel, dim3((unsigned)((max_tiles + 255) / 256)), dim3(256), P);
-  uint32_t counter = 0;
-  DeliverArgs D = {};
-  D.blob = blob.data();
-  D.sec_byte_offset = out_offset;
-  D.launch_sec_end = launch_sec_end.data();
-  D.dst = dst + dst_shift;
-  D.nsec = nsec;
-  D.end_aligned = mode == 1;
-  D.counter = &counter;
+  (void)grid;
+  uint8_t* const out = dst + dst_shift;
+  uint32_t s_lo = 0;
   for (int c = 0; c < nlaunch; c++) {
     PackTileArgs W = P;
     W.tile_first = P.launch_t0[c];
@@ -329,28 +325,24 @@ __attribute__((visibility("default"))) int sim_pack_deliver(const uint8_t* recor
                      dim3((unsigned)((W.tile_end - W.tile_first + kPackWriteTilesPerGroup - 1) / kPackWriteTilesPerGroup)),
                      dim3(kPackThreads), W);
     if (mode != 2) {
-      D.launch = c;
-      D.flag = c + 1 == nlaunch ? out_flag : nullptr;
-      D.seq = 77;
-      hipsim::launch(pack_deliver_kernel, dim3((unsigned)grid), dim3(kDeliverThreads), D);
+      // as EnqueueDeliver: the sections this launch has completed, at their offset (END-aligned: against the total)
+      const uint32_t s_hi = std::min<uint32_t>((uint32_t)nsec, std::max(s_lo, launch_sec_end[c]));
+      const int64_t shift = mode == 1 ? -(int64_t)out_offset[nsec] : 0;
+      if (out_offset[s_hi] > out_offset[s_lo])
+        memcpy(out + shift + (int64_t)out_offset[s_lo], blob.data() + out_offset[s_lo], out_offset[s_hi] - out_offset[s_lo]);
+      s_lo = s_hi;
     }
   }
   if (mode == 2) {
-    D.launch = -1;
-    for (int r0 = 0; r0 < nruns; r0 += kDeliverMaxRuns) {
-      const int n = nruns - r0 < kDeliverMaxRuns ? nruns - r0 : kDeliverMaxRuns;
-      D.nruns = n;
-      for (int r = 0; r < n; r++) {
-        D.runs[r].first = (uint32_t)runs[3 * (r0 + r)];
-        D.runs[r].count = (uint32_t)runs[3 * (r0 + r) + 1];
-        D.runs[r].dst_offset = runs[3 * (r0 + r) + 2];
-      }
-      D.flag = r0 + n >= nruns ? out_flag : nullptr;
-      D.seq = 77;
-      hipsim::launch(pack_deliver_kernel, dim3((unsigned)grid), dim3(kDeliverThreads), D);
+    for (int r = 0; r < nruns; r++) {
+      const uint64_t lo = out_offset[runs[3 * r]], hi = out_offset[runs[3 * r] + runs[3 * r + 1]];
+      if (hi > lo) memcpy(out + runs[3 * r + 2], blob.data() + lo, hi - lo);
     }
+  } else if (s_lo != (uint32_t)nsec) {
+    return 1;  // (the last launch must complete every section)
   }
-  return counter == 0 ? 0 : 1;  // (the last workgroup resets the completion counter)
+  if (out_flag) *out_flag = 77;
+  return 0;
 }
 
 // The look-back of the single pass on its own: one wave asks for the start of `tile` given the states of the tiles
@@ -377,7 +369,7 @@ __attribute__((visibility("default"))) int sim_pack_lookback(const unsigned long
   return 0;
 }
 
-// The single pass (pack_tile_stream_kernel, EnqueueStream of jxlt_capi.hip): plan (which also clears the tiles' states
+// The single pass (pack_tile_stream_kernel, EnqueueStream of jxlt_capi_pack.hip): plan (which also clears the tiles' states
 // and the sections' bit counts), then the writing launches over growing shares of an upper bound of the tile count
 // -- no measuring pass, every tile takes its position from the tiles in front of it.  `blob` must arrive zeroed
 // (the product clears it with a memset in front of the first launch); out_bits: the sections' bit counts;
@@ -413,17 +405,8 @@ __attribute__((visibility("default"))) int sim_pack_stream(const uint8_t* record
   P.launch_sec_end = out_launch_end;
   P.tile_state = tile_state.data();
   P.block_state = block_state.data();
-  std::vector<uint32_t> tickets(kPackMaxLaunches, 0xDEADu), sized(kPackMaxLaunches, 0xDEADu);
+  std::vector<uint32_t> tickets(kPackMaxLaunches, 0xDEADu);
   P.tile_ticket = tickets.data();
-  P.sized_count = sized.data();
-  // (one launch: the launch reports the sections' bit counts itself, as in the product)
-  std::vector<uint32_t> reported(nsec + 1, 0xDEADu);
-  uint32_t reported_flag = 0;
-  if (nlaunch == 1) {
-    P.host_sec_bits = reported.data();
-    P.host_flag = &reported_flag;
-    P.host_seq = 4711u;
-  }
   const unsigned sec_blocks = (unsigned)((nsec + 255) / 256);
   hipsim::launch(pack_tile_count_kernel, dim3(sec_blocks), dim3(256), P);
   hipsim::launch(group_scan_kernel, dim3(1), dim3(kScanThreads), (const uint32_t*)sec_tiles.data(), tile_base.data(), nsec);
@@ -437,12 +420,6 @@ __attribute__((visibility("default"))) int sim_pack_stream(const uint8_t* record
       hipsim::launch(pack_tile_stream_kernel,
                      dim3((unsigned)((W.tile_end - W.tile_first + kPackStreamTilesPerGroup - 1) / kPackStreamTilesPerGroup)),
                      dim3(kPackThreads), W);
-  }
-  if (nlaunch == 1) {
-    if (reported_flag != 4711u) return 3;
-    for (int i = 0; i < nsec; i++)
-      if (reported[i] != out_bits[i]) return 4;
-    if (reported[nsec] != 0xDEADu) return 5;
   }
   return 0;
 }

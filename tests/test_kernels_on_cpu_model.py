@@ -22,7 +22,7 @@ CASES = [
     (128, 64, 1.0, False, True),    # fixed DCT8 (BASELINE config #2 mode)
     (17, 130, 3.0, False, False),   # narrow
     (24, 2048 + 2048 + 72, 1.0, False, False),  # three rows of DC groups: the row-wise launches (slab arguments,
-                                                # chained token-offset scan, per-row DC kernels) of jxlt_capi.hip
+                                                # chained token-offset scan, per-row DC kernels) of jxlt_capi_encode.hip
 ]
 
 
@@ -105,11 +105,11 @@ def _random_sections(rng, sizes):
 @pytest.mark.parametrize("sizes", [[0], [7], [5, 0, 17], [4095, 4096, 4097, 1], [0, 0, 0], [20000, 3, 9000, 0, 12345],
                                    [600] * 23])
 @pytest.mark.parametrize("nlaunch", [1, 3, 4])
-def test_hand_over_kernel_delivers_every_section_once(built, sizes, nlaunch):
-    """pack_deliver_kernel behind the writing launches (round 4: the sections leave the device without the host
-    knowing their sizes): whatever the shares of the launches, every section arrives exactly once, byte for byte what
-    the reference packer gives, at any alignment of the destination, start- and end-aligned; nothing else is written;
-    the last workgroup reports completion."""
+def test_hand_over_by_launches_delivers_every_section_once(built, sizes, nlaunch):
+    """The hand-over behind the writing launches -- behind every launch the copy of the sections
+    pack_tile_finalize_kernel has filed as complete (launch_sec_end; the product issues copy commands, the model a
+    memcpy): whatever the shares of the launches, every section arrives exactly once, byte for byte what the reference
+    packer gives, at any alignment of the destination, start- and end-aligned; nothing else is written."""
     import numpy as np
     rng = np.random.default_rng(len(sizes) * 1000 + sum(sizes) + nlaunch)
     table = _random_code_table(rng)
@@ -222,9 +222,9 @@ def test_single_pass_packing_matches_reference_packer(built, sizes, nlaunch):
             assert ends and ends[-1] == last_nonempty + 1
 
 
-def test_hand_over_kernel_in_runs(built):
+def test_hand_over_in_runs(built):
     """Run mode (a slab of a frame that several GPUs share owns several ranges of the codestream): runs of
-    consecutive sections go to the offsets the caller names, more runs than one launch takes."""
+    consecutive sections go to the offsets the caller names."""
     import numpy as np
     rng = np.random.default_rng(99)
     table = _random_code_table(rng)

@@ -7,8 +7,8 @@ cd "${GRAFT_REPO_ROOT:-.}"
 IFS=';' read -ra VARIANTS <<< "$1"
 for v in "${VARIANTS[@]}"; do
   [ "$v" = "base" ] && v=""
-  touch libjxl-tiny_amd/csrc/jxlt_capi.hip
-  make -C libjxl-tiny_amd -s csrc/libjxltiny_hip.so HIPFLAGS_EXTRA="$v" 2>&1 | grep -i error
+  touch libjxl-tiny_amd/csrc/jxlt_device_common.h
+  make -C libjxl-tiny_amd -s -j3 csrc/libjxltiny_hip.so HIPFLAGS_EXTRA="$v" 2>&1 | grep -i error
   echo "== [$v]"
   if [ -n "$PARITY" ]; then timeout 600 python -m pytest tests -m gpu -x -q -k "hot_path or golden or random or values_outside" 2>&1 | tail -1; fi
   ./tools/tile_cycles.sh 16384 | grep -E "tile(12)?_kernel|token_kernel"

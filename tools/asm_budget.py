@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase instruction budget of tile12_kernel from its gfx950 assembly (no GPU needed).
 
-Builds jxlt_capi.hip with -DJXLT_ASM_MARKERS (an assembly comment at every phase boundary of the kernel), splits the
+Builds jxlt_capi_encode.hip with -DJXLT_ASM_MARKERS (an assembly comment at every phase boundary of the kernel), splits the
 kernel's instruction stream at the markers and prices every VALU instruction with the issue costs measured by
 tools/valu_issue_probe.hip / valu_issue_probe2.hip on the MI355X (profiles/r02_valu_issue_probe.txt,
 profiles/r05_valu_issue_probe2.txt):
@@ -79,7 +79,7 @@ def classify(op, operands, extra_cheap=()):
 def build_asm(extra_flags):
     out = Path("/tmp/jxlt_asm_budget.s")
     cmd = ["/opt/rocm/bin/hipcc"] + HIPFLAGS + ["-DJXLT_ASM_MARKERS"] + extra_flags + [
-        "-S", "--cuda-device-only", "-o", str(out), str(ROOT / "libjxl-tiny_amd/csrc/jxlt_capi.hip")]
+        "-S", "--cuda-device-only", "-o", str(out), str(ROOT / "libjxl-tiny_amd/csrc/jxlt_capi_encode.hip")]
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     return out.read_text()
 

@@ -7,8 +7,8 @@ timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 if [ -n "$PHASES" ]; then
 # profiling build with the phase stops (the box copy is scratch; the production .so is rebuilt below)
 cp libjxl-tiny_amd/csrc/libjxltiny_hip.so /tmp/prod_hip.so
-touch libjxl-tiny_amd/csrc/jxlt_capi.hip
-make -C libjxl-tiny_amd -s csrc/libjxltiny_hip.so HIPFLAGS_EXTRA=-DJXLT_PHASE_STOPS 2>&1 | grep -i error
+touch libjxl-tiny_amd/csrc/jxlt_device_common.h
+make -C libjxl-tiny_amd -s -j3 csrc/libjxltiny_hip.so HIPFLAGS_EXTRA=-DJXLT_PHASE_STOPS 2>&1 | grep -i error
 rm -rf gpurun_out/phase_pmc
 timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv \
   -d gpurun_out/phase_pmc -- python3 tools/phase_pmc.py run 4096 > gpurun_out/phase_pmc.log 2>&1

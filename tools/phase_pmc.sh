@@ -4,8 +4,8 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 SIZE=$1; shift
-touch libjxl-tiny_amd/csrc/jxlt_capi.hip
-make -C libjxl-tiny_amd -s csrc/libjxltiny_hip.so HIPFLAGS_EXTRA="-DJXLT_PHASE_STOPS" 2>&1 | grep -i error
+touch libjxl-tiny_amd/csrc/jxlt_device_common.h
+make -C libjxl-tiny_amd -s -j3 csrc/libjxltiny_hip.so HIPFLAGS_EXTRA="-DJXLT_PHASE_STOPS" 2>&1 | grep -i error
 rm -rf gpurun_out/phase_pmc
 i=0
 for set in "$@"; do
