@@ -260,7 +260,8 @@ def main():
 
     pipelined = sharded and args.in_flight > 1
     ktimes = {}
-    step_ms, warmup_ms, first_kernel_ms = [], [], []
+    step_ms, warmup_ms, step_kernel_ms, step_copy, step_stages = [], [], [], [], []
+    probe = None
     if pipelined:
         pipe = open_pipeline(args.in_flight, "timed")
         run_pipelined(pipe, max(args.warmup, args.in_flight))
@@ -280,6 +281,13 @@ def main():
         # own stream around every stage of every encode (read after each step).  The time of every single step
         # (this rank's clock) and the stage times of the first eight go into the line as well: a run whose early
         # steps are slow shows whether the kernels were (clocks still rising) or the host's share was.
+        # ... and what could make a step slow that is not the library's doing: the control group's CPU
+        # throttling (cpu.stat, read through a descriptor opened beforehand), the encoding thread's context switches
+        # (getrusage of the thread: no file), and the host time inside the longest copy command of the step
+        # (jxlt_encode_stats: a call that meets the runtime creating a copy engine's queue takes milliseconds).  A few
+        # microseconds per step, all of them read between two steps.
+        probe = StepProbe()
+        probe.sample()
         t0 = time.perf_counter()
         tp = t0
         for i in range(args.steps):
@@ -288,8 +296,13 @@ def main():
                 kt = enc.kernel_times()
                 for k, v in kt.items():
                     ktimes[k] = ktimes.get(k, 0.0) + v / args.steps
-                if i < 8:
-                    first_kernel_ms.append({k: round(v, 3) for k, v in kt.items()})
+                step_kernel_ms.append({k: round(v, 3) for k, v in kt.items()})
+                st = enc.stats()
+                step_copy.append((st["copy_calls"], round(st["longest_copy_call_us"], 1)))
+                tl = pkg.last_frame_timeline()
+                if tl is not None:
+                    step_stages.append({k: round(v, 3) for k, v in tl.items()})
+            probe.sample()
             tn = time.perf_counter()
             step_ms.append(round(1e3 * (tn - tp), 3))
             tp = tn
@@ -382,7 +395,8 @@ def main():
         result["ms_per_step_min"] = srt[0]
         result["step_ms"] = step_ms
         result["warmup_step_ms"] = warmup_ms
-        result["kernel_ms_first_steps"] = first_kernel_ms
+        result["kernel_ms_per_step"] = step_kernel_ms
+        result["step_diagnostics"] = step_diagnostics(step_ms, step_kernel_ms, step_copy, probe, step_stages)
     # (traffic and instruction counts come from committed counter profiles, not from this run: say which, and
     # whether the device code has changed since they were collected)
     _, fresh = pmc_traffic(size, with_doc=True)
@@ -436,6 +450,121 @@ def main():
     gate = result.get("parity_gate", {})
     if gate.get("groups_mismatching", 0) or gate.get("sharded_equals_single_gpu_codestream") is False:
         raise SystemExit("parity gate failed: %s" % json.dumps(gate))
+
+
+class StepProbe:
+    """Between two timed steps: the control group's throttling counters and the calling thread's context switches.
+    Raw samples are kept; deltas per step are worked out behind the timed region."""
+
+    def __init__(self):
+        import resource
+        self._resource = resource
+        self._fd = None
+        for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+            try:
+                self._fd = os.open(path, os.O_RDONLY)
+                break
+            except OSError:
+                pass
+        self.samples = []
+
+    def sample(self):
+        ru = self._resource.getrusage(self._resource.RUSAGE_THREAD)
+        raw = b""
+        if self._fd is not None:
+            try:
+                raw = os.pread(self._fd, 512, 0)
+            except OSError:
+                pass
+        self.samples.append((ru.ru_nvcsw, ru.ru_nivcsw, raw))
+
+    def deltas(self):
+        def parse(raw):
+            out = {}
+            for line in raw.decode("ascii", "replace").splitlines():
+                parts = line.split()
+                if len(parts) == 2 and parts[0] in ("nr_throttled", "throttled_usec", "throttled_time"):
+                    out[parts[0]] = int(parts[1])
+            return out
+        res = []
+        for a, b in zip(self.samples, self.samples[1:]):
+            pa, pb = parse(a[2]), parse(b[2])
+            thr_us = (pb.get("throttled_usec", 0) - pa.get("throttled_usec", 0)) or \
+                     (pb.get("throttled_time", 0) - pa.get("throttled_time", 0)) // 1000
+            res.append({"voluntary_ctxsw": b[0] - a[0], "involuntary_ctxsw": b[1] - a[1],
+                        "nr_throttled": pb.get("nr_throttled", 0) - pa.get("nr_throttled", 0), "throttled_usec": thr_us})
+        return res
+
+
+def step_diagnostics(step_ms, step_kernel_ms, step_copy, probe, step_stages=()):
+    """Why was a step slow?  For every timed step above 1.15 x the median: what differs from the run's typical step --
+    device time (the kernels' HIP-event times of that very step: clocks, pre-emption, another tenant on the device),
+    the host's view of the frame's stages (jxlt_last_frame_timeline: when the DC histogram, the AC histogram, the
+    codes, the sizes and the last byte arrived -- a stage that took longer while the kernels did not is a queue
+    delay in front of a kernel, a slow link, or the host), CPU throttling of the control group, involuntary context
+    switches of the encoding thread, the longest copy command's host time.  `cause` names whatever explains at least a
+    fifth of the excess; "unattributed" otherwise."""
+    srt = sorted(step_ms)
+    median = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+    mean = sum(step_ms) / len(step_ms)
+    deltas = probe.deltas() if probe is not None else []
+
+    def med(vals):
+        v = sorted(vals)
+        return v[len(v) // 2] if v else 0.0
+    kernel_sum = [sum(k.values()) for k in step_kernel_ms]
+    kmed = med(kernel_sum)
+    copy_med = med([c[1] for c in step_copy])
+    # stage DURATIONS from the timeline's time stamps: device pipeline up to the DC histogram, tokenisation behind it,
+    # code construction, section sizes, hand-over of the bytes
+    names = ("until_dc_histogram", "dc_to_ac_histogram", "codes", "sizes", "hand_over")
+    keys = ("dc_histogram_ms", "ac_histogram_ms", "codes_ms", "sizes_ms", "done_ms")
+    durs = []
+    for tl in step_stages:
+        t = [tl[k] for k in keys]
+        durs.append({names[0]: t[0], names[1]: max(0.0, t[1] - t[0]), names[2]: max(0.0, t[2] - t[1]),
+                     names[3]: max(0.0, t[3] - t[2]), names[4]: max(0.0, t[4] - t[3])})
+    dur_med = {n: med([d[n] for d in durs]) for n in names} if durs else {}
+    out = {"median_ms": round(median, 3), "mean_minus_median_ms": round(mean - median, 3),
+           "host_stage_ms_median": {n: round(v, 3) for n, v in dur_med.items()},
+           "threshold": "steps above 1.15 x the median", "slow_steps": [],
+           "totals": {"nr_throttled": sum(d["nr_throttled"] for d in deltas),
+                      "throttled_usec": sum(d["throttled_usec"] for d in deltas),
+                      "involuntary_ctxsw": sum(d["involuntary_ctxsw"] for d in deltas),
+                      "voluntary_ctxsw": sum(d["voluntary_ctxsw"] for d in deltas),
+                      "longest_copy_call_us": max([c[1] for c in step_copy], default=0.0)}}
+    for i, ms in enumerate(step_ms):
+        if ms <= 1.15 * median:
+            continue
+        excess = ms - median
+        entry = {"step": i, "ms": ms, "excess_ms": round(excess, 3)}
+        cause = {}
+        if i < len(kernel_sum):
+            entry["kernel_ms"] = step_kernel_ms[i]
+            dk = kernel_sum[i] - kmed
+            if dk > 0.2 * excess:
+                cause["device_kernels_ms"] = round(dk, 3)
+        if i < len(durs):
+            entry["host_stage_ms"] = {n: round(durs[i][n], 3) for n in names}
+            for n in names:
+                dd = durs[i][n] - dur_med[n]
+                if dd > 0.2 * excess:
+                    cause["host_stage_%s_ms_over_median" % n] = round(dd, 3)
+        if i < len(step_copy):
+            entry["copy_calls"], entry["longest_copy_call_us"] = step_copy[i]
+            if (step_copy[i][1] - copy_med) * 1e-3 > 0.2 * excess:
+                cause["copy_call_on_host_ms"] = round((step_copy[i][1] - copy_med) * 1e-3, 3)
+        if i < len(deltas):
+            entry.update(deltas[i])
+            if deltas[i]["throttled_usec"] * 1e-3 > 0.2 * excess or deltas[i]["nr_throttled"]:
+                cause["cgroup_throttled_ms"] = round(deltas[i]["throttled_usec"] * 1e-3, 3)
+            if deltas[i]["involuntary_ctxsw"]:
+                cause["involuntary_ctxsw"] = deltas[i]["involuntary_ctxsw"]
+        if i > 0 and step_ms[i - 1] > 1.15 * median and "device_kernels_ms" in cause:
+            cause["follows_a_slow_step"] = True  # (the GPU's clock coming back up)
+        entry["cause"] = cause if cause else {"unattributed_ms": round(excess, 3)}
+        out["slow_steps"].append(entry)
+    return out
 
 
 def extras_single_gpu(args, np, torch, pkg, enc, frame, dev_index, device, result):

@@ -233,6 +233,11 @@ typedef struct {
   uint32_t tiles;                      /* 64x64 tiles of the frame */
   uint32_t tiles_redone_exact_roots;   /* ... of which were redone with computed roots */
   uint32_t encodes_with_redone_tiles;  /* encodes of this context so far in which any tile was */
+  /* Host time inside the copy commands the library has issued for the last encode (hipMemcpyAsync of the packed
+   * sections): how many, and the longest CALL in microseconds -- a call that runs into the runtime creating a copy
+   * engine's queue takes milliseconds; bench.py attributes slow steps with it. */
+  uint32_t copy_calls;
+  float longest_copy_call_us;
 } jxlt_encode_stats_t;
 int jxlt_encode_stats(jxlt_context* ctx, jxlt_encode_stats_t* out);
 
@@ -263,6 +268,13 @@ int jxlt_encode_resident_view(jxlt_context* ctx, float distance, int num_threads
 int jxlt_encode_file_planar(const float* const planes[3], size_t pitch_bytes, size_t xsize,
                             size_t ysize, float distance, int device_ordinal,
                             uint8_t** out_bytes, size_t* out_size);
+/* The same over a LIST of devices (jxl::SetEncoderDevices + jxl::EncodeFile in one call): a frame of more than one DC
+ * group is cut into rectangles of whole DC groups, one per listed device; same bytes.  The list and the encoder built
+ * on it belong to the calling thread (two threads with two lists encode side by side).  num_devices <= 1, or a frame
+ * of one DC group: as jxlt_encode_file_planar on device_ordinals[0]. */
+int jxlt_encode_file_planar_devices(const float* const planes[3], size_t pitch_bytes, size_t xsize, size_t ysize,
+                                    float distance, const int* device_ordinals, int num_devices, uint8_t** out_bytes,
+                                    size_t* out_size);
 /* cjxl_tiny's whole job in one call: PFM file -> .jxl codestream (malloc'ed, free with
  * jxlt_free), with the PFM payload de-interleaved / flipped / byte-swapped by the device
  * kernels (jxlt_image_upload_pfm) instead of by a host pass. */
@@ -314,6 +326,15 @@ void jxlt_emulate_reference_static_constants(int on);
  * codestream equals the reference's whenever the reference's is decodable.  1: the reference's
  * bytes in every case. */
 void jxlt_emulate_reference_single_symbol_codes(int on);
+/* Host-side stage times of the calling thread's last frame through jxl::EncodeFrame / EncodeFile /
+ * jxlt_encode_resident* (what JXLT_TRACE=1 prints), milliseconds from the start of the call: the DC histogram in host
+ * memory (= the tile kernels are done), the AC histogram (= tokenisation done), both codes built and handed to the
+ * device, both kinds' section sizes known, the last section byte in host memory (= the call's end).  bench.py
+ * attributes slow steps with it.  Returns JXLT_ERR_INVALID_ARGUMENT before the thread's first frame. */
+typedef struct {
+  double dc_histogram_ms, ac_histogram_ms, codes_ms, sizes_ms, done_ms;
+} jxlt_frame_timeline;
+int jxlt_last_frame_timeline(jxlt_frame_timeline* out);
 /* Codestream + image headers that precede the frame (enc_file.cc:70-95). */
 int jxlt_write_file_header(size_t xsize, size_t ysize, uint8_t** out_bytes, size_t* out_size);
 /* ---- one frame sharded over several GPUs (BASELINE config #4) -----------------

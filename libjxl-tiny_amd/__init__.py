@@ -39,7 +39,7 @@ HIP_SYMBOLS = ["jxlt_context_create", "jxlt_context_destroy", "jxlt_last_error",
                "jxlt_synchronize", "jxlt_fetch_result", "jxlt_encode_stats"]
 HIP_SYMBOLS_TESTING = ["jxlt_debug_fetch", "jxlt_fetch_side_info", "jxlt_pack_sections", "jxlt_kernel_times"]
 HOST_SYMBOLS = ["jxlt_compute_distance_params", "jxlt_assemble_frame",
-                "jxlt_encode_file_planar", "jxlt_encode_pfm_file", "jxlt_emulate_reference_static_constants", "jxlt_emulate_reference_single_symbol_codes", "jxlt_encode_resident", "jxlt_encode_resident_view", "jxlt_write_file_header",
+                "jxlt_encode_file_planar", "jxlt_encode_file_planar_devices", "jxlt_encode_pfm_file", "jxlt_emulate_reference_static_constants", "jxlt_emulate_reference_single_symbol_codes", "jxlt_encode_resident", "jxlt_encode_resident_view", "jxlt_write_file_header", "jxlt_last_frame_timeline",
                 "jxlt_free", "jxlt_batch_encoder_create", "jxlt_batch_encoder_create_multi",
                 "jxlt_batch_encoder_destroy", "jxlt_batch_encoder_run",
                 "jxlt_shard_rect", "jxlt_multi_encoder_create", "jxlt_multi_encoder_destroy",
@@ -88,7 +88,8 @@ class PackedSections(C.Structure):
 
 class EncodeStats(C.Structure):
     _fields_ = [("tiles", C.c_uint32), ("tiles_redone_exact_roots", C.c_uint32),
-                ("encodes_with_redone_tiles", C.c_uint32)]
+                ("encodes_with_redone_tiles", C.c_uint32), ("copy_calls", C.c_uint32),
+                ("longest_copy_call_us", C.c_float)]
 
 
 class KernelTime(C.Structure):
@@ -160,6 +161,9 @@ def host_lib():
                                                  C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         L.jxlt_encode_file_planar.argtypes = [C.POINTER(fp), C.c_size_t, C.c_size_t, C.c_size_t, C.c_float,
                                               C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        L.jxlt_encode_file_planar_devices.argtypes = [C.POINTER(fp), C.c_size_t, C.c_size_t, C.c_size_t, C.c_float,
+                                                      C.POINTER(C.c_int), C.c_int, C.POINTER(C.POINTER(C.c_uint8)),
+                                                      C.POINTER(C.c_size_t)]
         L.jxlt_encode_resident.argtypes = [C.c_void_p, C.c_float, C.c_int, C.POINTER(C.POINTER(C.c_uint8)),
                                            C.POINTER(C.c_size_t)]
         L.jxlt_encode_resident_view.argtypes = [C.c_void_p, C.c_float, C.c_int, C.POINTER(C.POINTER(C.c_uint8)),
@@ -350,7 +354,8 @@ class Encoder:
         st = EncodeStats()
         self._check(self._L.jxlt_encode_stats(self._ctx, C.byref(st)), "jxlt_encode_stats")
         return {"tiles": int(st.tiles), "tiles_redone_exact_roots": int(st.tiles_redone_exact_roots),
-                "encodes_with_redone_tiles": int(st.encodes_with_redone_tiles)}
+                "encodes_with_redone_tiles": int(st.encodes_with_redone_tiles), "copy_calls": int(st.copy_calls),
+                "longest_copy_call_us": float(st.longest_copy_call_us)}
 
     def kernel_times(self):
         arr = (KernelTime * 8)()
@@ -487,6 +492,34 @@ def encode_file(planes, distance, device=0):
                                             C.byref(n))
     if rc != 0:
         raise JxlTinyError("jxlt_encode_file_planar failed (%d)" % rc)
+    return _take_bytes(out, n)
+
+
+class FrameTimeline(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("dc_histogram_ms", "ac_histogram_ms", "codes_ms", "sizes_ms", "done_ms")]
+
+
+def last_frame_timeline():
+    """jxlt_last_frame_timeline: host-side stage times (ms from the call's start) of this thread's last frame."""
+    tl = FrameTimeline()
+    L = host_lib()
+    L.jxlt_last_frame_timeline.argtypes = [C.POINTER(FrameTimeline)]
+    if L.jxlt_last_frame_timeline(C.byref(tl)) != 0:
+        return None
+    return {k: getattr(tl, k) for k, _ in FrameTimeline._fields_}
+
+
+def encode_file_devices(planes, distance, devices):
+    """jxlt_encode_file_planar_devices: the drop-in's EncodeFile over the calling thread's device list."""
+    planes = np.ascontiguousarray(planes, dtype=np.float32)
+    _, h, w = planes.shape
+    ptrs = (fp * 3)(*[planes[c].ctypes.data_as(fp) for c in range(3)])
+    devs = (C.c_int * len(devices))(*devices)
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    rc = host_lib().jxlt_encode_file_planar_devices(ptrs, w * 4, w, h, C.c_float(distance), devs, len(devices),
+                                                    C.byref(out), C.byref(n))
+    if rc != 0:
+        raise JxlTinyError("jxlt_encode_file_planar_devices failed (%d)" % rc)
     return _take_bytes(out, n)
 
 

@@ -526,6 +526,8 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   ctx->last_params = *params;
   ctx->overflow_checked = false;
   ctx->encode_status = JXLT_OK;
+  ctx->copy_calls = 0;
+  ctx->longest_copy_call_us = 0.0f;
   return JXLT_OK;
 }
 
@@ -569,6 +571,8 @@ int jxlt_encode_stats(jxlt_context* ctx, jxlt_encode_stats_t* out) {
   if (rc0 != JXLT_OK) return rc0;
   out->tiles_redone_exact_roots = ctx->tiles_redone;
   out->encodes_with_redone_tiles = ctx->exact_reruns;
+  out->copy_calls = ctx->copy_calls;
+  out->longest_copy_call_us = ctx->longest_copy_call_us;
   out->tiles = (uint32_t)((size_t)ctx->geom.xsize_tiles * ctx->geom.ysize_tiles);
   return JXLT_OK;
 }

@@ -358,14 +358,19 @@ void FillMeasured(jxlt_context* ctx, int kind, jxlt_packed_sections* out) {
   out->num_sections = ps.measured_sections;
 }
 
-// hipMemcpyAsync with the time the CALL took on the host (JXLT_TRACE_EVENTS: calls of more than 0.5 ms are reported)
-hipError_t TimedCopy(void* dst, const void* src, size_t bytes, hipStream_t stream, const char* what) {
-  if (!TraceEventsOn()) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, stream);
+// hipMemcpyAsync with the time the CALL took on the host: kept per encode (jxlt_encode_stats: a call that meets the
+// runtime creating a copy engine's queue takes milliseconds); JXLT_TRACE_EVENTS reports calls of more
+// than 0.5 ms (level 2: every call).
+hipError_t TimedCopy(jxlt_context* ctx, void* dst, const void* src, size_t bytes, hipStream_t stream, const char* what) {
   const auto t0 = std::chrono::steady_clock::now();
   const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, stream);
-  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  if (ms > 0.5) fprintf(stderr, "jxlt slow call: hipMemcpyAsync (%s, %zu bytes) took %.3f ms on the host\n", what, bytes, ms);
-  if (TraceLevel() >= 2) fprintf(stderr, "jxlt copy call: %s %zu bytes %.1f us on the host\n", what, bytes, ms * 1e3);
+  const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  ctx->copy_calls++;
+  if (us > ctx->longest_copy_call_us) ctx->longest_copy_call_us = (float)us;
+  if (TraceEventsOn()) {
+    if (us > 500.0) fprintf(stderr, "jxlt slow call: hipMemcpyAsync (%s, %zu bytes) took %.3f ms on the host\n", what, bytes, us * 1e-3);
+    if (TraceLevel() >= 2) fprintf(stderr, "jxlt copy call: %s %zu bytes %.1f us on the host\n", what, bytes, us);
+  }
   return e;
 }
 
@@ -397,7 +402,7 @@ int EnqueueDeliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_section
         // (the launch's word may have been set by the launch itself, before its end: the copy waits for the end)
         HIP_TRY(ctx, hipStreamWaitEvent(out_stream, ps.launch_done[i], 0));
         TraceMark(ctx, kind ? "AC copy start" : "DC copy start", out_stream);
-        HIP_TRY(ctx, TimedCopy(dst + off[s_lo], ps.packed.p + off[s_lo], off[s_hi] - off[s_lo], out_stream, kind ? "AC sections" : "DC-group sections"));
+        HIP_TRY(ctx, TimedCopy(ctx, dst + off[s_lo], ps.packed.p + off[s_lo], off[s_hi] - off[s_lo], out_stream, kind ? "AC sections" : "DC-group sections"));
         TraceMark(ctx, kind ? "AC copy done" : "DC copy done", out_stream);
       }
       s_lo = s_hi;
@@ -420,7 +425,7 @@ int EnqueueDeliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_section
         if (off[s_hi] > off[s_lo]) {
           HIP_TRY(ctx, hipStreamWaitEvent(out_stream, ps.launch_done[i], 0));
           TraceMark(ctx, kind ? "AC copy start" : "DC copy start", out_stream);
-          HIP_TRY(ctx, TimedCopy(dst + shift + (int64_t)off[s_lo], ps.packed.p + off[s_lo], off[s_hi] - off[s_lo], out_stream,
+          HIP_TRY(ctx, TimedCopy(ctx, dst + shift + (int64_t)off[s_lo], ps.packed.p + off[s_lo], off[s_hi] - off[s_lo], out_stream,
                                  kind ? "AC sections" : "DC-group sections"));
           TraceMark(ctx, kind ? "AC copy done" : "DC copy done", out_stream);
         }
@@ -435,7 +440,7 @@ int EnqueueDeliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_section
         }
         const uint64_t lo = off[runs[r].first_section], hi = off[runs[r].first_section + runs[r].num_sections];
         if (hi > lo)
-          HIP_TRY(ctx, hipMemcpyAsync(dst + runs[r].dst_offset, ps.packed.p + lo, hi - lo, hipMemcpyDefault, out_stream));
+          HIP_TRY(ctx, TimedCopy(ctx, dst + runs[r].dst_offset, ps.packed.p + lo, hi - lo, out_stream, kind ? "AC sections (run)" : "DC-group sections (run)"));
       }
     }
     // completion: a one-workgroup kernel behind the copies stores the hand-over's number to the word the host polls

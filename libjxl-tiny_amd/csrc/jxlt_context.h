@@ -216,6 +216,8 @@ struct jxlt_context {
   DeviceBuf<uint32_t> dc_chain_summary;
   PinnedBuf<uint32_t> h_lut_overflow;
   jxlt_params last_params = {};
+  uint32_t copy_calls = 0;            // copy commands issued for the last encode's sections ...
+  float longest_copy_call_us = 0.0f;  // ... and the longest of those calls on the host (jxlt_encode_stats)
   bool overflow_checked = true;
   int encode_status = JXLT_OK;  // JXLT_ERR_UNSUPPORTED: the last encode met values the format cannot carry
   size_t overflow_slabs = 0;   // launches of the last encode

@@ -206,6 +206,18 @@ struct TokenArgs {
 #define JXLT_GLOBAL_POINTER_TYPES
 typedef __attribute__((address_space(1))) const char* JxltGlobalBytes;
 typedef __attribute__((address_space(1))) const float* JxltGlobalFloats;
+typedef __attribute__((address_space(1))) int16_t* JxltGlobalShorts;
+#endif
+
+// p[i] = v for a wave-uniform 64-bit value and a wave-uniform, 8-byte aligned address in global memory: ONE scalar
+// store (s_store_dwordx2; i: a compile-time index) instead of moves to vector registers and a vector store by one
+// lane.  Scalar stores go through the scalar data cache: JXLT_SCALAR_STORES_DONE() (s_dcache_wb) behind the last of
+// them writes it back -- the compiler does that at a kernel's end only for scalar stores of its own making.  Nothing
+// in the kernels READS these locations through the scalar cache.  (The CPU execution model: plain stores.)
+#ifndef JXLT_SCALAR_STORE64
+#define JXLT_SCALAR_STORE64(p, i, v) \
+  asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"((unsigned long long)(v)), "s"(p), "n"((i) * 8) : "memory")
+#define JXLT_SCALAR_STORES_DONE() asm volatile("s_dcache_wb" ::: "memory")
 #endif
 
 // The same for a wave-uniform value in scalar registers (a pointer, an index).
@@ -288,6 +300,33 @@ JXLT_DI float octet_sum(float v) {
   return r;
 #endif
 }
+// Two octet sums for the price of one: lanes 0-3 of the octet receive SumOfLanes(a), lanes 4-7 SumOfLanes(b) -- the
+// first exchange step adds the partner's `a` in the lower half and the partner's `b` in the upper half (bank-masked
+// DPP adds), the other two steps stay inside the halves.  Same additions in the same order as octet_sum for either.
+JXLT_DI float octet_sum_pair(float a, float b, int l) {
+#ifdef JXLT_OCTET_SUM_PORTABLE
+  const float sa = octet_sum(a), sb = octet_sum(b);
+  return l < 4 ? sa : sb;
+#else
+  (void)l;
+  float r;
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+      : "=&v"(r)
+      : "v"(a), "v"(b));
+  return r;
+#endif
+}
+// The value lanes 4-7 of the octet hold, in lanes 0-3 (lane l reads lane l + 4; lanes 4-7 keep their own).
+JXLT_DI float octet_upper_to_lower(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), kDppRowShl4, 0xF, 0x5, false));
+}
+
 JXLT_DI int octet_sum_int(int v) {
   v = v + octet_xor_i<4>(v);
   v = v + octet_xor_i<2>(v);
@@ -339,6 +378,26 @@ JXLT_DI float sqrt_exact_midrange(float x) {
   float r = (r_dn <= 0.0f) ? s_dn : s;
   r = (r_up > 0.0f) ? s_up : r;
   return r;
+}
+
+// Correctly rounded sqrtf for x in [2^-27, 2^63] from the reciprocal square root: v_rsq_f32, two multiplications and five
+// fused multiply-adds (the rsq form of the compiler's own IEEE expansion, without its range scaling) -- no compare, no
+// select, one instruction fewer than sqrt_exact_midrange and none of the 4-cycle kind.  tools/sqrt_rsq_probe.hip
+// compares it with IEEE sqrtf on all 90 x 2^23 floats of that range on the GPU (tests/test_gpu_parity.py runs it);
+// the CPU execution model, whose "rsq" is not this GPU's, takes sqrtf.
+JXLT_DI float sqrt_exact_by_rsq(float x) {
+#ifdef JXLT_SQRT_PORTABLE
+  return sqrtf(x);
+#else
+  const float r = __builtin_amdgcn_rsqf(x);
+  float g = x * r;
+  float h = 0.5f * r;
+  const float e = nfma32(h, g, 0.5f);
+  g = fma32(g, e, g);
+  h = fma32(h, e, h);
+  const float d = nfma32(g, g, x);
+  return fma32(d, h, g);
+#endif
 }
 
 // Correctly rounded 1.0f / q for integer-valued q (0 < |q| <= 2^31): the hardware reciprocal
@@ -758,7 +817,7 @@ JXLT_DI float ratio_of_derivatives(float v, bool invert) {
 // so that it is computed once (correctly rounded) per thread.
 JXLT_DI float masking_sqrt(float v, float sqrt_mul) {
   const float kLogOffset = 26.481471032459346f;
-  return 0.25f * sqrt_exact_midrange(fma32(v, sqrt_mul, kLogOffset));  // argument >= kLogOffset
+  return 0.25f * sqrt_exact_by_rsq(fma32(v, sqrt_mul, kLogOffset));  // argument >= kLogOffset = 26.48
 }
 JXLT_DI float masking_sqrt_mul() {
   const float kMul = 211.50759899638012f;

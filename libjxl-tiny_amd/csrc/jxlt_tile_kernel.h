@@ -161,15 +161,23 @@ JXLT_DI float estimate_entropy(const float* cx, const float* cy, const float* cb
       nzeros_v = nzeros_v + clamp01(4.0f * q);  // + (q == 0 ? 0 : 1)
     }
     entropy_v = fma32(nzeros_v, cost_of_1, entropy_v);
-    entropy += octet_sum(entropy_v);
+    // The two sums of the channel in ONE butterfly (octet_sum_pair): the lower half of the octet gets the entropy's,
+    // the upper half the non-zero count's.  The upper half turns its count into
     // kZerosMul * (CeilLog2Nonzero(nbits + 17) + nbits) with nbits = CeilLog2Nonzero(num_nzeros + 1) + 1 (:133-139)
-    // from the table DeviceTables::zeros_cost (its LDS copy): the count -- an integer below 129 held in a float -- times
-    // 2^-147 has the bit pattern 4 * count, the table's byte offset (as for the roots above)
-    const uint32_t zoff = __float_as_uint(octet_sum(nzeros_v) * lut_step);
-    entropy += *reinterpret_cast<const float*>(reinterpret_cast<const char*>(zeros_cost) + zoff);
+    // by a look-up in DeviceTables::zeros_cost (its LDS copy): the count -- an integer below 129 held in a float -- times
+    // 2^-147 has the bit pattern 4 * count, the table's byte offset (as for the roots above); the lower half, whose
+    // "count" is an entropy, reads some aligned word there that nobody uses; the cost then moves down to the lower
+    // half, where `entropy` is kept (its value is used from lane 0 alone).
+    const float sums = octet_sum_pair(entropy_v, nzeros_v, l);
+    const uint32_t zoff = __float_as_uint(sums * lut_step) & 0x3FCu;
+    const float zcost = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(zeros_cost) + zoff);
+    entropy += sums;
+    entropy += octet_upper_to_lower(zcost);
   }
-  const float infoloss = octet_sum(info_loss);
-  const float infoloss2 = sqrtf(num_blocks * octet_sum(info_loss2));
+  // (the two information-loss sums likewise: the upper half takes the root, the lower half the weighted sum)
+  const float losses = octet_sum_pair(info_loss, info_loss2, l);
+  const float infoloss = losses;
+  const float infoloss2 = octet_upper_to_lower(sqrtf(num_blocks * losses));
   const float info_loss_score = (kInfoLossMultiplier * infoloss + kInfoLossMultiplier2 * infoloss2);
   // every offset stayed inside the table <=> no bit above the offset field is set
   if (kLut) *qmax = (qbits & ~(uint32_t)(kSqrtLutSize * 4 - 1)) != 0u ? (float)kSqrtLutSize : 0.0f;
@@ -1254,24 +1262,35 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
         nscan_packed |= nscan[c] << (8 * c);
         wave_tokens += 1 + (nscan[c] > covered ? nscan[c] - covered : 0);
       }
+      // (the tokeniser takes "nonzeros still to come" and "previous coefficient nonzero" from these masks.  They are
+      // wave-uniform -- ballots, in scalar registers -- and leave by SCALAR stores: six s_store_dwordx2 to 48 contiguous
+      // bytes.  As vector stores by lanes 0 and 1 they cost eight vector instructions per channel: the scalar values
+      // moved to vector registers, selected per lane, a 64-bit address.)
+      {
+        unsigned long long* const masks = A.blk_nzmask + (size_t)pos0 * 6;
 #pragma unroll
-      for (int c = 0; c < 3; c++) {
-        // (the tokeniser takes "nonzeros still to come" and "previous coefficient nonzero" from these masks:
-        // lanes 0 and 1 store the two words)
-        if (lane < 2) A.blk_nzmask[(size_t)(pos0 * 3 + c) * 2 + lane] = lane == 0 ? m0[c] : m1[c];
+        for (int c = 0; c < 3; c++) {
+          JXLT_SCALAR_STORE64(masks, 2 * c, m0[c]);
+          JXLT_SCALAR_STORE64(masks, 2 * c + 1, m1[c]);
+        }
       }
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         // only scan positions below nscan (= up to the last nonzero) are ever read again
-        int16_t* const out0 = A.coef_scan + (size_t)(pos0 * 3 + c) * 64;
-        int16_t* const out1 = A.coef_scan + (size_t)(pos1 * 3 + c) * 64;
-        if (lane < nscan[c]) out0[lane] = (int16_t)(int)quant[0][c];
-        if (64 + lane < nscan[c]) out1[lane] = (int16_t)(int)quant[1][c];
+        // (the 64 slots of a block and channel: a wave-uniform base the compiler cannot look through + the lane's 16-bit
+        // slot -- a store with a scalar base, no 64-bit vector add per store)
+        JxltGlobalShorts out0 = (JxltGlobalShorts)(A.coef_scan + (size_t)(pos0 * 3 + c) * 64);
+        JxltGlobalShorts out1 = (JxltGlobalShorts)(A.coef_scan + (size_t)(pos1 * 3 + c) * 64);
+        JXLT_LAUNDER_SGPR(out0);
+        JXLT_LAUNDER_SGPR(out1);
+        if (lane < nscan[c]) out0[(uint32_t)lane] = (int16_t)(int)quant[0][c];
+        if (64 + lane < nscan[c]) out1[(uint32_t)lane] = (int16_t)(int)quant[1][c];
       }
       file_int(1, t, nz_packed);
       file_int(2, t, nscan_packed);
       ntrans++;
     }
+    JXLT_SCALAR_STORES_DONE();  // (the masks above: out of the scalar data cache)
     if (lane == 0 && wave_tokens) atomicAdd(&S.ntok, wave_tokens);
     if (kLutRoots) {
       if (__ballot(!(q_energy < 1073741824.0f)) != 0 && lane == 0) S.overflow = 1u;  // (suspect: see q_energy)

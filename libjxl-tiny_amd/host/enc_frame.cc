@@ -136,6 +136,15 @@ class CodeWorker {
   std::thread thread_;
 };
 
+// (jxlt_last_frame_timeline: the stage times of the calling thread's last frame)
+thread_local jxlt_frame_timeline g_last_timeline = {0, 0, 0, 0, 0};
+thread_local bool g_have_timeline = false;
+bool LastFrameTimeline(jxlt_frame_timeline* out) {
+  if (!g_have_timeline) return false;
+  *out = g_last_timeline;
+  return true;
+}
+
 bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jxl::BitWriter* writer,
                           const std::function<uint8_t*(size_t)>* placer, ContextOutput* in_context) {
   static const bool trace = getenv("JXLT_TRACE") != nullptr;
@@ -389,9 +398,12 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
       if (ok) memcpy(dst, frame_at, frame_bytes);
     }
   }
+  const auto t4 = now();
+  g_last_timeline = {ms(t0, t0a), ms(t0, t1), ms(t0, t2), ms(t0, t3), ms(t0, t4)};
+  g_have_timeline = true;
   if (trace)
     fprintf(stderr, "jxlt trace: device+histograms %.3f ms | codes %.3f | sizes %.3f | head + hand-over %.3f\n",
-            ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
+            ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4));
   (void)num_threads;
   return ok;
 }
@@ -444,81 +456,78 @@ jxlt_context* AcquireThreadContext() { return jxl::AcquireContextForThread(); }
 namespace jxl {
 
 namespace {
-// The process-wide device list for sharded frames (SetEncoderDevices / JXLT_DEVICES) and the encoder built
-// on it.  One frame at a time: the multi encoder is not re-entrant, so concurrent callers of EncodeFile /
-// EncodeFrame / EncodePFMFile are SERIALISED while a device list of more than one GPU is set (a frame then has
-// all the listed GPUs to itself; callers that want frames side by side use one GPU per thread --
-// SetEncoderDevice -- or the batch encoder).  The encoder and its worker threads go when the list is cleared or
-// changed, and at process exit.
-std::mutex g_multi_mu;
-std::vector<int> g_devices;
-bool g_devices_from_env_done = false;
-jxlt_multi_encoder* g_multi = nullptr;
-std::vector<int> g_multi_devices;
-
-void DevicesFromEnvironment() {
-  if (g_devices_from_env_done) return;
-  g_devices_from_env_done = true;
-  const char* e = getenv("JXLT_DEVICES");
-  if (!e || !*e || !g_devices.empty()) return;
-  if (strcmp(e, "all") == 0) {
-    const int n = jxlt_device_count();
-    for (int d = 0; d < n && d < 64; ++d) g_devices.push_back(d);
-    return;
+// The device list for frames over several GPUs and the encoder built on it belong to the CALLING THREAD, like the
+// single device of SetEncoderDevice and its context: every thread that encodes over a list owns a
+// jxlt_multi_encoder (contexts + worker threads) of its own, made at its first such frame and destroyed with the
+// thread or when its list changes.  Two threads with two lists -- or with the same list -- encode side by side;
+// nothing is process-wide, nothing is locked.  (Until round 4: ONE process-wide list and encoder behind a mutex,
+// concurrent callers serialised)  A thread that has not called SetEncoderDevices takes the
+// list of the environment variable JXLT_DEVICES ("0,1,2,3" or "all"), read once.
+struct ThreadDeviceList {
+  bool explicit_list = false;   // SetEncoderDevices was called on this thread
+  std::vector<int> devices;     // ... with this list
+  jxlt_multi_encoder* enc = nullptr;
+  std::vector<int> enc_devices;  // what `enc` was made for
+  void Drop() {
+    if (enc) jxlt_multi_encoder_destroy(enc);
+    enc = nullptr;
+    enc_devices.clear();
   }
-  for (const char* p = e; *p;) {
-    char* end = nullptr;
-    const long v = strtol(p, &end, 10);
-    if (end == p) break;
-    if (v >= 0 && v < 1024) g_devices.push_back(static_cast<int>(v));
-    p = *end == ',' ? end + 1 : end;
-  }
-}
-}  // namespace
+  ~ThreadDeviceList() { Drop(); }
+};
+thread_local ThreadDeviceList t_list;
 
-namespace {
-void DestroyMultiEncoderLocked() {
-  if (g_multi) jxlt_multi_encoder_destroy(g_multi);
-  g_multi = nullptr;
-  g_multi_devices.clear();
-}
-void DestroyMultiEncoderAtExit() {
-  std::lock_guard<std::mutex> lock(g_multi_mu);
-  DestroyMultiEncoderLocked();
+const std::vector<int>& DevicesFromEnvironment() {
+  static const std::vector<int> devices = [] {
+    std::vector<int> v;
+    const char* e = getenv("JXLT_DEVICES");
+    if (!e || !*e) return v;
+    if (strcmp(e, "all") == 0) {
+      const int n = jxlt_device_count();
+      for (int d = 0; d < n && d < 64; ++d) v.push_back(d);
+      return v;
+    }
+    for (const char* p = e; *p;) {
+      char* end = nullptr;
+      const long d = strtol(p, &end, 10);
+      if (end == p) break;
+      if (d >= 0 && d < 1024) v.push_back(static_cast<int>(d));
+      p = *end == ',' ? end + 1 : end;
+    }
+    return v;
+  }();
+  return devices;
 }
 }  // namespace
 
 void SetEncoderDevices(const int* device_ordinals, int n) {
-  std::lock_guard<std::mutex> lock(g_multi_mu);
-  g_devices_from_env_done = true;  // an explicit call wins over the environment
-  g_devices.assign(device_ordinals, device_ordinals + (n > 0 && device_ordinals ? n : 0));
-  if (g_multi && g_multi_devices != g_devices) DestroyMultiEncoderLocked();  // (incl. a cleared list)
+  t_list.explicit_list = true;  // an explicit call wins over the environment (also an empty list)
+  t_list.devices.assign(device_ordinals, device_ordinals + (n > 0 && device_ordinals ? n : 0));
+  if (t_list.enc && t_list.enc_devices != t_list.devices) t_list.Drop();
 }
 
 }  // namespace jxl
 
 namespace jxlt {
-// The frame over the process's device list (jxl::SetEncoderDevices / JXLT_DEVICES) when that names several
+// The frame over the calling thread's device list (jxl::SetEncoderDevices / JXLT_DEVICES) when that names several
 // GPUs and the frame has more than one DC group (a PFM payload: more than one row of DC groups).  *used = false: not applicable, nothing done.
 // Otherwise the complete codestream (file header + frame) is in *codestream, or false is returned.
 bool EncodeOnDeviceList(const float* const planes[3], size_t pitch_bytes, const void* pfm_payload, int big_endian,
                         size_t xsize, size_t ysize, float distance, std::vector<uint8_t>* codestream, bool* used) {
   using namespace jxl;
-  std::lock_guard<std::mutex> lock(g_multi_mu);
-  DevicesFromEnvironment();
-  *used = g_devices.size() > 1 && (ysize > 2048 || (xsize > 2048 && pfm_payload == nullptr));
+  const std::vector<int>& devices = t_list.explicit_list ? t_list.devices : DevicesFromEnvironment();
+  *used = devices.size() > 1 && (ysize > 2048 || (xsize > 2048 && pfm_payload == nullptr));
   if (!*used) return true;
-  if (g_multi && g_multi_devices != g_devices) DestroyMultiEncoderLocked();
-  if (!g_multi) {
-    static const bool registered = (atexit(DestroyMultiEncoderAtExit), true);
-    (void)registered;
-    if (jxlt_multi_encoder_create(g_devices.data(), static_cast<int>(g_devices.size()), &g_multi) != JXLT_OK) {
+  if (t_list.enc && t_list.enc_devices != devices) t_list.Drop();
+  if (!t_list.enc) {
+    if (jxlt_multi_encoder_create(devices.data(), static_cast<int>(devices.size()), &t_list.enc) != JXLT_OK) {
       fprintf(stderr, "jxl_tiny_amd: cannot create device contexts: %s\n", jxlt_last_error(nullptr));
-      g_multi = nullptr;
+      t_list.enc = nullptr;
       return false;  // no CPU fallback by design
     }
-    g_multi_devices = g_devices;
+    t_list.enc_devices = devices;
   }
+  jxlt_multi_encoder* const g_multi = t_list.enc;
   const uint8_t* bytes = nullptr;
   size_t size = 0;
   const int rc = pfm_payload

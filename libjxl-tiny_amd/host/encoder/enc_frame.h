@@ -19,11 +19,15 @@ Status EncodeFrame(float distance, const Image3F& linear, ThreadPool* pool, BitW
 // Not in the reference: HIP device ordinal used by the calling thread's
 // subsequent EncodeFrame/EncodeFile calls (default 0).
 void SetEncoderDevice(int device_ordinal);
-// Not in the reference: several GPUs for ONE frame (process-wide).  With more than one ordinal, frames of
+// Not in the reference: several GPUs for ONE frame, for the calling thread's subsequent calls (like
+// SetEncoderDevice: every thread has its own list and its own encoder over it, so two threads with two lists -- or
+// with the same list -- encode side by side; until round 4 the list was process-wide and concurrent callers were
+// serialised).  With more than one ordinal, frames of
 // at least two DC-group rows (> 2048 pixel rows) are cut into row slabs of whole DC groups, one per device
 // (the reference's loop over DC groups, enc_frame.cc:839-844, spread over the GPUs; include/jxl_tiny_amd.h,
 // jxlt_multi_encoder_*); same bytes as on one GPU.  n <= 1 returns to the single-device path.  The environment
-// variable JXLT_DEVICES ("0,1,2,3" or "all") sets the same list for unmodified callers such as cjxl_tiny.
+// variable JXLT_DEVICES ("0,1,2,3" or "all") is the list of every thread that has not called this function
+// (unmodified callers such as cjxl_tiny).
 void SetEncoderDevices(const int* device_ordinals, int n);
 
 // Not in the reference: the reference derives two multipliers of its transform search from the

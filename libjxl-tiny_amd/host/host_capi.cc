@@ -127,6 +127,25 @@ int jxlt_encode_file_planar(const float* const planes[3], size_t pitch_bytes, si
   return jxlt_encode_resident(ctx, distance, 0, out_bytes, out_size);
 }
 
+int jxlt_encode_file_planar_devices(const float* const planes[3], size_t pitch_bytes, size_t xsize, size_t ysize,
+                                    float distance, const int* device_ordinals, int num_devices, uint8_t** out_bytes,
+                                    size_t* out_size) {
+  if (!planes || !out_bytes || !out_size || xsize == 0 || ysize == 0 || pitch_bytes < xsize * sizeof(float) ||
+      pitch_bytes % sizeof(float) || (num_devices > 0 && !device_ordinals))
+    return JXLT_ERR_INVALID_ARGUMENT;
+  {
+    float d = distance;
+    if (!jxlt::NormalizeDistance(&d)) return JXLT_ERR_INVALID_ARGUMENT;
+  }
+  jxl::SetEncoderDevices(device_ordinals, num_devices);  // (the calling thread's list)
+  std::vector<uint8_t> whole;
+  bool used = false;
+  if (!jxlt::EncodeOnDeviceList(planes, pitch_bytes, nullptr, 0, xsize, ysize, distance, &whole, &used)) return JXLT_ERR_INTERNAL;
+  if (used) return ToMalloc(whole, out_bytes, out_size);
+  return jxlt_encode_file_planar(planes, pitch_bytes, xsize, ysize, distance, num_devices > 0 ? device_ordinals[0] : 0,
+                                 out_bytes, out_size);
+}
+
 namespace {
 // What a failed encode on `ctx` returns: JXLT_ERR_UNSUPPORTED when the device refused the frame's values (a quantised
 // coefficient beyond the token format's 16 bits, a DC value beyond int16 -- the status sticks to the context until
@@ -191,6 +210,10 @@ int jxlt_encode_resident_view(jxlt_context* ctx, float distance, int num_threads
   *bytes = out.data;
   *size = out.size;
   return JXLT_OK;
+}
+
+int jxlt_last_frame_timeline(jxlt_frame_timeline* out) {
+  return out && jxlt::LastFrameTimeline(out) ? JXLT_OK : JXLT_ERR_INVALID_ARGUMENT;
 }
 
 int jxlt_build_code_tables(const uint32_t* ac_histograms, const uint32_t* dc_histograms,

@@ -8,6 +8,7 @@
 #include <functional>
 #include <vector>
 
+#include "../../include/jxl_tiny_amd.h"
 #include "encoder/enc_bit_writer.h"
 
 struct jxlt_context;
@@ -26,7 +27,7 @@ struct ContextOutput {
 bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jxl::BitWriter* writer,
                           const std::function<uint8_t*(size_t)>* placer, ContextOutput* in_context = nullptr);
 bool WriteFileHeader(size_t xsize, size_t ysize, jxl::BitWriter* writer);
-// One frame over the process's device list (jxl::SetEncoderDevices / JXLT_DEVICES); see enc_frame.cc.
+// One frame over the calling thread's device list (jxl::SetEncoderDevices / JXLT_DEVICES); see enc_frame.cc.
 bool EncodeOnDeviceList(const float* const planes[3], size_t pitch_bytes, const void* pfm_payload, int big_endian,
                         size_t xsize, size_t ysize, float distance, std::vector<uint8_t>* codestream, bool* used);
 bool ParsePFMHeader(const uint8_t* data, size_t size, size_t* xsize, size_t* ysize, bool* big_endian,
@@ -36,6 +37,7 @@ void SetStaticConstantEmulation(bool on);  // jxl::EmulateReferenceStaticConstan
 // While that emulation is on: latches the process's first distance and sets it on `ctx` (a context's own
 // jxlt_set_strategy_distance setting is left alone otherwise).
 void ApplyStrategyDistanceEmulation(jxlt_context* ctx, float distance);
+bool LastFrameTimeline(jxlt_frame_timeline* out);  // (enc_frame.cc)
 }  // namespace jxlt
 
 #endif  // JXLT_HOST_INTERNAL_H_

@@ -402,7 +402,8 @@ inline void __builtin_amdgcn_s_setprio(int) {}  // issue priority: no effect on 
 inline void __builtin_amdgcn_sched_barrier(int) {}  // compiler scheduling fence
 #define JXLT_TOUCH_VGPR(x) ((void)(x))
 #define JXLT_LUT_WRAP(off) ((off) & (uint32_t)(kSqrtLutSize * 4 - 4))  // (see jxlt_device_common.h)
-#define JXLT_OCTET_SUM_PORTABLE 1  // (octet_sum: the exchange steps instead of the inline assembly)
+#define JXLT_OCTET_SUM_PORTABLE 1
+#define JXLT_SQRT_PORTABLE 1  // (sqrt_exact_by_rsq: sqrtf)  // (octet_sum: the exchange steps instead of the inline assembly)
 #define JXLT_LAUNDER_VGPR(x) ((void)(x))
 #define JXLT_DEFINE_VGPR(x) ((x) = 0)
 #define JXLT_LDS_STORE_ROW(row_base, off, val) ((row_base)[(off) / 4 + hipsim_lane()] = (val))
@@ -410,6 +411,9 @@ inline void __builtin_amdgcn_sched_barrier(int) {}  // compiler scheduling fence
 #define JXLT_GLOBAL_POINTER_TYPES
 typedef const char* JxltGlobalBytes;
 typedef const float* JxltGlobalFloats;
+typedef int16_t* JxltGlobalShorts;
+#define JXLT_SCALAR_STORE64(p, i, v) ((p)[i] = (v))
+#define JXLT_SCALAR_STORES_DONE() ((void)0)
 #define JXLT_COMPILER_FENCE() ((void)0)
 
 // v_rcp_f32 (1 ulp on hardware; the model returns the correctly rounded reciprocal)
