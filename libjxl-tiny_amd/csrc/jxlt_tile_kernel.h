@@ -1180,19 +1180,17 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     // tile*_kernel_redo, which tests every value exactly and counts the tile in A.unsupported if one fails.
     float q_energy = 0.0f;
     bool q_bad = false;
-    float next_v[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+    // Two sets of staged coefficients used in turn (the transform being worked on / the next one, requested before
+    // the work starts): as ONE set that is copied at the top of the loop the copies were six v_mov per transform.
+    float set_a[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}}, set_b[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
     int next_b = todo != 0 ? (int)__builtin_ctzll(todo) : -1, next_st = 0;
     if (next_b >= 0) {
       next_st = scalar_lane(strat_of_lane, next_b) >> 1;
-      fetch(next_b, next_st, next_v);
+      fetch(next_b, next_st, set_a);
     }
-    while (next_b >= 0) {
+    // one transform: `in` holds its staged coefficients, the next transform's are requested into `next_v`
+    auto one_transform = [&](float (*in)[3], float (*next_v)[3]) {
       const int b = __builtin_amdgcn_readfirstlane(next_b), st = __builtin_amdgcn_readfirstlane(next_st);
-      float in[2][3];
-#pragma unroll
-      for (int h = 0; h < 2; h++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) in[h][c] = next_v[h][c];
       todo &= todo - 1;
       next_b = todo != 0 ? (int)__builtin_ctzll(todo) : -1;
       if (next_b >= 0) {
@@ -1289,6 +1287,11 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       file_int(1, t, nz_packed);
       file_int(2, t, nscan_packed);
       ntrans++;
+    };
+    while (next_b >= 0) {
+      one_transform(set_a, set_b);
+      if (next_b < 0) break;
+      one_transform(set_b, set_a);
     }
     JXLT_SCALAR_STORES_DONE();  // (the masks above: out of the scalar data cache)
     if (lane == 0 && wave_tokens) atomicAdd(&S.ntok, wave_tokens);
