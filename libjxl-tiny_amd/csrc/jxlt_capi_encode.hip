@@ -454,7 +454,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
     // (every token_kernel workgroup finds its group's token offset itself: the counts of all groups before it,
     // whichever launch tokenised them, are final by now)
     K.group_first = (int)g0;
-    if (nblocks > kTokenNarrowBlocks)
+    if ((uint32_t)g.xsize_blocks > kTokenNarrowWidth)
       hipLaunchKernelGGL(token_kernel_wide, dim3((unsigned)ng), dim3(kTokenThreads), 0, tok_stream, K);
     else
       hipLaunchKernelGGL(token_kernel, dim3((unsigned)ng), dim3(kTokenThreads), 0, tok_stream, K);

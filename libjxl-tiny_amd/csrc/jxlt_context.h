@@ -33,7 +33,7 @@ namespace jxlt_host {
 // Largest frame of the device path, in 8x8 blocks.  The kernels index blocks -- and up to twelve 32-bit words per
 // block (jxlt_token_kernel.h: mask_at) -- with 32 bits; coefficients (192 per block) are indexed with 64.
 // The limit is what the test-suite exercises (test_frame_above_one_gigapixel: 23.1 M blocks, which crosses
-// kTokenNarrowBlocks and the 32-bit coefficient index) rounded up to the next power of two, not what the index
+// the 32-bit coefficient index) rounded up to the next power of two, not what the index
 // widths would allow on paper (2^28): 2^25 blocks = 2.1 Gpixel, e.g. 46 340 x 46 340.
 constexpr size_t kMaxFrameBlocks = size_t(1) << 25;
 

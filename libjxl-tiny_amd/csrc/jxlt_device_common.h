@@ -119,7 +119,8 @@ struct TileArgs {
   uint8_t* nzgrid[3];   // value used for context prediction, per block & channel
   uint8_t* blk_nz;      // [block*3 + c]: number of nonzeros (token value)
   uint8_t* blk_nscan;   // [block*3 + c]: scan positions up to the last nonzero
-  unsigned long long* blk_nzmask;  // [block*3 + c][2]: which of the scan positions covered .. 127 are nonzero
+  unsigned long long* blk_nzmask;  // [block*3 + c][2]: which of the scan positions covered .. 127 are nonzero; bit
+                                   // covered - 1: nzeros <= 4 * covered (the first coefficient token's "previous")
   int16_t* coef_scan;   // [block*3 + c][64] quantised coefficients in scan order
   uint32_t* group_ntok; // per group token count (atomic)
   uint32_t* dc_nac;     // per DC group: number of first blocks (atomic)
@@ -207,6 +208,8 @@ struct TokenArgs {
 typedef __attribute__((address_space(1))) const char* JxltGlobalBytes;
 typedef __attribute__((address_space(1))) const float* JxltGlobalFloats;
 typedef __attribute__((address_space(1))) int16_t* JxltGlobalShorts;
+typedef __attribute__((address_space(1))) const int16_t* JxltGlobalConstShorts;
+typedef __attribute__((address_space(1))) const uint32_t* JxltGlobalConstWords;
 #endif
 
 // p[i] = v for a wave-uniform 64-bit value and a wave-uniform, 8-byte aligned address in global memory: ONE scalar

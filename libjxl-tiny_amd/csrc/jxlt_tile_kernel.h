@@ -1259,6 +1259,10 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
         nz_packed |= nzeros << (8 * c);
         nscan_packed |= nscan[c] << (8 * c);
         wave_tokens += 1 + (nscan[c] > covered ? nscan[c] - covered : 0);
+        // (scan position covered - 1 of the mask: what the entry's first coefficient token takes in place of "previous
+        // coefficient nonzero", enc_group.cc:476-480 -- token_kernel's emit reads it like any other position)
+        // (1 << (covered - 1) is `covered` itself)
+        m0[c] |= (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(nzeros <= 4 * covered ? covered : 0);
       }
       // (the tokeniser takes "nonzeros still to come" and "previous coefficient nonzero" from these masks.  They are
       // wave-uniform -- ballots, in scalar registers -- and leave by SCALAR stores: six s_store_dwordx2 to 48 contiguous

@@ -412,6 +412,8 @@ inline void __builtin_amdgcn_sched_barrier(int) {}  // compiler scheduling fence
 typedef const char* JxltGlobalBytes;
 typedef const float* JxltGlobalFloats;
 typedef int16_t* JxltGlobalShorts;
+typedef const int16_t* JxltGlobalConstShorts;
+typedef const uint32_t* JxltGlobalConstWords;
 #define JXLT_SCALAR_STORE64(p, i, v) ((p)[i] = (v))
 #define JXLT_SCALAR_STORES_DONE() ((void)0)
 #define JXLT_COMPILER_FENCE() ((void)0)
