@@ -29,7 +29,7 @@ struct DeviceTables {
   uint16_t freq_context[64];
   uint16_t nnz_context[64];
   uint8_t block_context_map[81];
-  uint8_t ac_context_map[1980];
+  alignas(4) uint8_t ac_context_map[1980];  // (token_kernel copies it to LDS as 495 words)
   uint8_t gradient_lut[1024];  // enc_frame.cc:226-281
   float sqrt_lut[1024];        // sqrtf(i), correctly rounded (EstimateEntropy's cost of a coefficient)
   // What the quantisation needs to know of scan position p (tile_kernel quantises in scan order, lane = scan
@@ -220,7 +220,11 @@ typedef __attribute__((address_space(1))) const uint32_t* JxltGlobalConstWords;
 #ifndef JXLT_SCALAR_STORE64
 #define JXLT_SCALAR_STORE64(p, i, v) \
   asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"((unsigned long long)(v)), "s"(p), "n"((i) * 8) : "memory")
-#define JXLT_SCALAR_STORES_DONE() asm volatile("s_dcache_wb" ::: "memory")
+// (Scalar memory operations complete out of order: the wait IN FRONT of s_dcache_wb is what makes it cover the stores
+// above it.  Without it the last stores of a wave could reach the cache behind the write-back and stay there, dirty,
+// until some later wave of those CUs wrote the cache back -- on a small frame nobody did before token_kernel read
+// the masks: one wrong context byte in two of six runs of the HDR tests, round 5.)
+#define JXLT_SCALAR_STORES_DONE() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory")
 #endif
 
 // The same for a wave-uniform value in scalar registers (a pointer, an index).
@@ -234,6 +238,13 @@ typedef __attribute__((address_space(1))) const uint32_t* JxltGlobalConstWords;
 // and keeps them in registers all the same.
 #ifndef JXLT_COMPILER_FENCE
 #define JXLT_COMPILER_FENCE() asm volatile("" ::: "memory")
+#endif
+
+// The wave's global stores so far are written (acknowledged by L2) -- for bytes that another wave of the workgroup
+// overwrites behind a barrier: __syncthreads() alone orders the workgroup's LDS traffic, it does not wait for
+// outstanding vector stores.
+#ifndef JXLT_STORES_WRITTEN
+#define JXLT_STORES_WRITTEN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
 
 JXLT_DI int imin(int a, int b) { return a < b ? a : b; }

@@ -68,7 +68,7 @@ JXLT_DI void token_kernel_body(const TokenArgs& A) {
   // position -- for one-block transforms ([0, 64)) and two-block transforms ([64, 192): the index halved, rounded
   // up for the nonzeros, enc_group.cc:468-475): a lane adds 0 or 64 to its index instead of shifting it.
   __shared__ uint8_t s_nnz_tab[192], s_freq_tab[192];
-  __shared__ uint8_t s_ctx_map[1980];
+  __shared__ alignas(4) uint8_t s_ctx_map[1980];
   // nzeros grid of the group (PredictFromTopAndLeft input of the nzeros tokens); once those are written its first
   // 512 bytes are `flags`: per wave, "a listed block starts at this position of the window"
   __shared__ alignas(4) uint8_t s_nzg[3 * 1024];
@@ -84,7 +84,9 @@ JXLT_DI void token_kernel_body(const TokenArgs& A) {
   auto hist_slot = [](uint32_t cm, uint32_t sym) { return cm * 64u + ((sym + cm) & 63u); };
   if (do_hist)
     for (int i = tid; i < 64 * 64; i += kTokenThreads) hist[i] = 0;
-  for (int i = tid; i < 1980; i += kTokenThreads) s_ctx_map[i] = T->ac_context_map[i];
+  static_assert(1980 % 4 == 0 && 1980 / 4 <= kTokenThreads, "one word per thread");
+  if (tid < 1980 / 4)
+    reinterpret_cast<uint32_t*>(s_ctx_map)[tid] = reinterpret_cast<const uint32_t*>(T->ac_context_map)[tid];
   if (tid < 192) {  // (entry 0 of the reference's tables is a marker no token reaches)
     s_nnz_tab[tid] = (uint8_t)T->nnz_context[tid < 64 ? tid : (tid - 64 + 1) >> 1];
     s_freq_tab[tid] = (uint8_t)T->freq_context[tid < 64 ? tid : (tid - 64) >> 1];
@@ -238,15 +240,26 @@ JXLT_DI void token_kernel_body(const TokenArgs& A) {
       const int ctx = bucket * 4 + (ci == 0 ? bctx_y : bctx_c);
       uint8_t* o = out + 3u * tl;
       const uint8_t cm = s_ctx_map[ctx];
-      o[0] = cm;
-      o[1] = (uint8_t)(nzl & 0xFF);
-      o[2] = (uint8_t)(nzl >> 8);
+      // (Every lane's record lies in a cache line of its own here -- a store instruction is 64 requests --, so ONE
+      // unaligned 32-bit store where the byte behind the record is written later anyway: by this thread (the block's
+      // next nzeros token) or by the coefficient-token loop behind the barrier (the entry's first coefficient token).
+      // Only a block's LAST token is followed by another thread's record: the three bytes alone there.  As a byte and
+      // a 16-bit store everywhere this pass cost 0.085 of the kernel's 0.83 Mcycles at 16384^2.)
+      if (ci < 2 || blk_nscan[r][2] != 0) {
+        typedef uint32_t __attribute__((aligned(1))) UnalignedWord;
+        *reinterpret_cast<UnalignedWord*>(o) = (uint32_t)cm | ((uint32_t)nzl << 8);
+      } else {
+        o[0] = cm;
+        o[1] = (uint8_t)(nzl & 0xFF);
+        o[2] = (uint8_t)(nzl >> 8);
+      }
       if (do_hist) {
         atomicAdd(&hist[hist_slot(cm, hybrid_uint_symbol((uint32_t)nzl))], 1u);
       }
       tl += 1 + blk_nscan[r][ci];
     }
   }
+  JXLT_STORES_WRITTEN();  // (the byte behind an nzeros record, see above: written before another wave overwrites it)
   __syncthreads();  // the list and the window index are complete; the nzeros grid is read
 
   // ---- the coefficient tokens: wave w takes windows w, w + 8, ... ---------------------------------------------
@@ -337,7 +350,7 @@ JXLT_DI void token_kernel_body(const TokenArgs& A) {
       for (int j = 0; j < 4; j++) t.nz[j] = nzw[j];
     }
   };
-  auto emit = [&](const Located& t) {
+  auto emit = [&](const Located& t, bool counts) {
     // Nonzeros at the scan positions in front of k, and whether the previous one is nonzero -- for the entry's first
     // token (k = covered) "previous" is instead "nzeros <= size / 16" (enc_group.cc:476-480): tile_kernel leaves that
     // bit at scan position covered - 1 of the mask (the masks proper hold positions covered .. 127), and nz_adj counts
@@ -358,30 +371,44 @@ JXLT_DI void token_kernel_body(const TokenArgs& A) {
     o[0] = cm;
     o[1] = (uint8_t)(val & 0xFF);
     o[2] = (uint8_t)((val >> 8) & 0xFF);
-    if (do_hist && t.real) {
+    if (do_hist && counts && t.real) {
       const uint32_t slot = hist_slot(cm, hybrid_uint_symbol(val & 0xFFFFu));
       atomicAdd(&hist[slot], 1u);
     }
   };
-  // Three windows in flight per wave: window q is emitted (the first use of its requested values: with loads
-  // and stores on one counter that is a wait for everything the wave has issued), window q + 8 is requested,
-  // window q + 16 is located -- so that a wait comes a whole "locate" (LDS round trips only) behind the last
-  // request and the last stores.  Two sets of registers used in turn, no copies (a copy would be a use).
-  Located even, odd;
-  if (wave < nwin) {
-    locate(wave, even);
-    request(even);
-    if (wave + kWaves < nwin) locate(wave + kWaves, odd);
-  }
-  for (int q = wave; q < nwin; q += 2 * kWaves) {
-    emit(even);
-    if (q + kWaves >= nwin) break;
-    request(odd);
-    if (q + 2 * kWaves < nwin) locate(q + 2 * kWaves, even);
-    emit(odd);
-    if (q + 2 * kWaves >= nwin) break;
-    request(even);
-    if (q + 3 * kWaves < nwin) locate(q + 3 * kWaves, odd);
+  // Four windows in flight per wave: window n of the wave is emitted (the first use of its requested values), the
+  // requests of window n + 1 are on their way, window n + 2 is requested and window n + 3 located -- a use comes two
+  // "locate"s (LDS round trips only) behind its request, and the wait in front of it is a COUNT that leaves the next
+  // window's two loads (and the two stores in between) outstanding: loads and stores share one counter, which
+  // returns in order.  For the compiler to see that count, every path to an emit issues the same sequence of loads
+  // and stores: requests and emits are unconditional -- behind the wave's last window they repeat a window that has
+  // been emitted (same bytes to the same places; nothing counted) -- and the loop is entered behind the first emit.
+  // (Round 4: three windows, the wait for "everything the wave has issued"; with the per-block work out of the loop
+  // -- 160 -> 90 vector instructions per window -- one "locate" no longer covered the latency: the loop without its
+  // loads took 0.58 instead of 0.83 Mcycles.)  Three sets of registers used in turn, no copies (a copy would be a use).
+  const int cnt = (nwin - wave + kWaves - 1) / kWaves;  // this wave's windows: wave, wave + 8, ...
+  if (cnt > 0) {
+    Located s0, s1, s2;
+    auto window = [&](int n) { return wave + imin(n, cnt - 1) * kWaves; };
+    locate(window(0), s0);
+    request(s0);
+    locate(window(1), s1);
+    request(s1);
+    locate(window(2), s2);
+    emit(s0, true);
+    request(s2);
+    if (3 < cnt) locate(window(3), s0);
+    for (int n = 1; n < cnt; n += 3) {
+      emit(s1, true);
+      request(s0);
+      if (n + 3 < cnt) locate(window(n + 3), s1);
+      emit(s2, n + 1 < cnt);
+      request(s1);
+      if (n + 4 < cnt) locate(window(n + 4), s2);
+      emit(s0, n + 2 < cnt);
+      request(s2);
+      if (n + 5 < cnt) locate(window(n + 5), s0);
+    }
   }
   if (do_hist) {
     __syncthreads();

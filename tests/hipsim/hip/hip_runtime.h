@@ -417,6 +417,7 @@ typedef const uint32_t* JxltGlobalConstWords;
 #define JXLT_SCALAR_STORE64(p, i, v) ((p)[i] = (v))
 #define JXLT_SCALAR_STORES_DONE() ((void)0)
 #define JXLT_COMPILER_FENCE() ((void)0)
+#define JXLT_STORES_WRITTEN() ((void)0)
 
 // v_rcp_f32 (1 ulp on hardware; the model returns the correctly rounded reciprocal)
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }

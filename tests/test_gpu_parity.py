@@ -144,6 +144,23 @@ def test_values_outside_unit_range(enc):
     assert T.compare_results(want, got, "oracle", "gpu") == []
 
 
+def test_small_frames_give_the_same_tokens_every_time(enc):
+    """The nonzero masks leave tile_kernel by scalar stores through the scalar data cache (jxlt_device_common.h:
+    JXLT_SCALAR_STORE64 / JXLT_SCALAR_STORES_DONE).  On a frame of a few tiles nothing but the kernel's own
+    write-back puts them in memory before token_kernel reads them: with the write-back issued ahead of the stores it
+    was meant to cover (scalar memory operations complete out of order) one context byte in this frame's 26 578
+    records was wrong in about every third run (round 5).  Sixty runs here."""
+    rng = np.random.default_rng(7)
+    planes = (rng.random((3, 72, 136)) * 3.0 - 1.0).astype(np.float32)  # the frame of test_values_outside_unit_range
+    want = T.oracle_hot_path(planes, 1.0)
+    wrong = []
+    for i in range(60):
+        got = enc.hot_path(planes, 1.0)
+        if got.all_tokens() != want.all_tokens():
+            wrong.append(i)
+    assert wrong == []
+
+
 def test_full_size_properties(built, enc):
     """BASELINE-scale input (4096x4096 = config #2 size, too slow for a full oracle
     pass in the test budget): size-independent properties instead.

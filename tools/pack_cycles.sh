@@ -19,6 +19,7 @@ for f in glob.glob("gpurun_out/pk/**/*counter_collection.csv", recursive=True):
             if r["Counter_Name"] == "SQ_WAVES": calls[k] += 1
 for k, c in agg.items():
     w = max(1.0, c["SQ_WAVES"])
-    print("%-28s %2d launches/encode %8.3f Mcycles/encode  %6.0f VALU/wave %5.0f LDS/wave  %6.0f bank-conflict cycles/wave" % (
-        k, calls[k] // n, c["GRBM_GUI_ACTIVE"] / 8 / n / 1e6, c["SQ_INSTS_VALU"] / w, c["SQ_INSTS_LDS"] / w, c["SQ_LDS_BANK_CONFLICT"] / w))
+    print("%-28s %2d launches/encode %8.3f Mcycles/encode  %6.0f VALU/wave %5.0f LDS/wave  %6.0f bank-conflict cycles/wave  (%d launches seen, %.3f Mcycles each)" % (
+        k, calls[k] // n, c["GRBM_GUI_ACTIVE"] / 8 / n / 1e6, c["SQ_INSTS_VALU"] / w, c["SQ_INSTS_LDS"] / w, c["SQ_LDS_BANK_CONFLICT"] / w,
+        calls[k], c["GRBM_GUI_ACTIVE"] / 8 / max(1, calls[k]) / 1e6))
 PY
