@@ -1268,25 +1268,36 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       // wave-uniform -- ballots, in scalar registers -- and leave by SCALAR stores: six s_store_dwordx2 to 48 contiguous
       // bytes.  As vector stores by lanes 0 and 1 they cost eight vector instructions per channel: the scalar values
       // moved to vector registers, selected per lane, a 64-bit address.)
+      // (scalar address arithmetic is not free here: in this phase every wave of the CU runs on the ONE scalar unit the
+      // four SIMDs share -- 462 scalar against 368 vector instructions per wave, round 5's per-phase counters --, so:
+      // one base per block with the channels at constant offsets, 32-bit products where the frame limit allows them
+      // (2^25 blocks * 48 bytes of masks), and nothing at all for the second block of a one-block transform.)
       {
-        unsigned long long* const masks = A.blk_nzmask + (size_t)pos0 * 6;
+        unsigned long long* masks = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(A.blk_nzmask) + pos0 * 48u);
+        JXLT_LAUNDER_SGPR(masks);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
           JXLT_SCALAR_STORE64(masks, 2 * c, m0[c]);
           JXLT_SCALAR_STORE64(masks, 2 * c + 1, m1[c]);
         }
       }
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
+      {
         // only scan positions below nscan (= up to the last nonzero) are ever read again
-        // (the 64 slots of a block and channel: a wave-uniform base the compiler cannot look through + the lane's 16-bit
-        // slot -- a store with a scalar base, no 64-bit vector add per store)
-        JxltGlobalShorts out0 = (JxltGlobalShorts)(A.coef_scan + (size_t)(pos0 * 3 + c) * 64);
-        JxltGlobalShorts out1 = (JxltGlobalShorts)(A.coef_scan + (size_t)(pos1 * 3 + c) * 64);
+        // (the 192 slots of a block: a wave-uniform base the compiler cannot look through + the channel's constant
+        // offset + the lane's 16-bit slot -- a store with a scalar base, no 64-bit vector add per store)
+        JxltGlobalBytes out0 = (JxltGlobalBytes)(A.coef_scan + (size_t)pos0 * 192);
         JXLT_LAUNDER_SGPR(out0);
-        JXLT_LAUNDER_SGPR(out1);
-        if (lane < nscan[c]) out0[(uint32_t)lane] = (int16_t)(int)quant[0][c];
-        if (64 + lane < nscan[c]) out1[(uint32_t)lane] = (int16_t)(int)quant[1][c];
+        const uint32_t slot = (uint32_t)lane * 2u;
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+          if (lane < nscan[c]) *(JxltGlobalShorts)(out0 + (c * 128 + slot)) = (int16_t)(int)quant[0][c];
+        if (two) {
+          JxltGlobalBytes out1 = (JxltGlobalBytes)(A.coef_scan + (size_t)pos1 * 192);
+          JXLT_LAUNDER_SGPR(out1);
+#pragma unroll
+          for (int c = 0; c < 3; c++)
+            if (64 + lane < nscan[c]) *(JxltGlobalShorts)(out1 + (c * 128 + slot)) = (int16_t)(int)quant[1][c];
+        }
       }
       file_int(1, t, nz_packed);
       file_int(2, t, nscan_packed);
