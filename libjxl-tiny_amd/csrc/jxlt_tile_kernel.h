@@ -987,47 +987,56 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
   __syncthreads();
   JXLT_MARK(6);
   // ---- P7: decision (:213-237) + AdjustQuantField (:240-266) ------------------
-  if (search && tid < 16) {
-    const int cx = (tid & 3) * 2, cy = (tid >> 2) * 2;
-    if (cx + 1 < nbx && cy + 1 < nby) {
-      const float* e = &S.transpose_pad[tid * 8];
-      const float e00 = e[0], e01 = e[1], e10 = e[2], e11 = e[3];
-      const float l16 = e[4], r16 = e[5], t16 = e[6], b16 = e[7];
-      const float cost16x8 = fminf(l16, e00 + e10) + fminf(r16, e01 + e11);
-      const float cost8x16 = fminf(t16, e00 + e01) + fminf(b16, e10 + e11);
-      const int b00 = cy * 8 + cx;
-      if (cost16x8 < cost8x16) {
-        if (l16 < e00 + e10) { S.strat[b00] = (1 << 1) | 1; S.strat[b00 + 8] = (1 << 1); }
-        if (r16 < e01 + e11) { S.strat[b00 + 1] = (1 << 1) | 1; S.strat[b00 + 9] = (1 << 1); }
-      } else {
-        if (t16 < e00 + e01) { S.strat[b00] = (2 << 1) | 1; S.strat[b00 + 1] = (2 << 1); }
-        if (b16 < e10 + e11) { S.strat[b00 + 8] = (2 << 1) | 1; S.strat[b00 + 9] = (2 << 1); }
-      }
-      if (kDebug && A.dbg_ent8) {
-        const size_t cells_x = (size_t)A.g.xsize_blocks / 2 + 1;
-        float* d = A.dbg_ent8 + (((size_t)(by_img0 + cy) / 2) * cells_x + (size_t)(bx_img0 + cx) / 2) * 8;
-        for (int k = 0; k < 8; k++) d[k] = e[k];
-      }
-      // AdjustQuantField for the cell's transforms
-      for (int k = 0; k < 4; k++) {
-        const int bi = b00 + (k >> 1) * 8 + (k & 1);
-        const uint8_t a = S.strat[bi];
-        if (!(a & 1) || (a >> 1) == 0) continue;
-        const int o2 = (a >> 1) == 1 ? 8 : 1;
-        const uint8_t m = S.raw_quant[bi] > S.raw_quant[bi + o2] ? S.raw_quant[bi] : S.raw_quant[bi + o2];
-        S.raw_quant[bi] = m;
-        S.raw_quant[bi + o2] = m;
+  // Wave 0 alone, with the other eleven waiting: what counts is the length of this part (as 16 threads walking the
+  // four blocks of their cell through LDS, with a barrier of its own, it was ~900 cycles per tile; round 5).  The
+  // decision by a lane per 16x16 cell, then AdjustQuantField by a lane per BLOCK: a block of a two-block transform
+  // takes the larger of its own and its partner's quantiser -- all lanes read, then all write.
+  uint32_t p7_strat = 0u, p7_quant = 0u;
+  if (tid < 64) {
+    if (search && tid < 16) {
+      const int cx = (tid & 3) * 2, cy = (tid >> 2) * 2;
+      if (cx + 1 < nbx && cy + 1 < nby) {
+        const float* e = &S.transpose_pad[tid * 8];
+        const float e00 = e[0], e01 = e[1], e10 = e[2], e11 = e[3];
+        const float l16 = e[4], r16 = e[5], t16 = e[6], b16 = e[7];
+        const float cost16x8 = fminf(l16, e00 + e10) + fminf(r16, e01 + e11);
+        const float cost8x16 = fminf(t16, e00 + e01) + fminf(b16, e10 + e11);
+        const int b00 = cy * 8 + cx;
+        if (cost16x8 < cost8x16) {
+          if (l16 < e00 + e10) { S.strat[b00] = (1 << 1) | 1; S.strat[b00 + 8] = (1 << 1); }
+          if (r16 < e01 + e11) { S.strat[b00 + 1] = (1 << 1) | 1; S.strat[b00 + 9] = (1 << 1); }
+        } else {
+          if (t16 < e00 + e01) { S.strat[b00] = (2 << 1) | 1; S.strat[b00 + 1] = (2 << 1); }
+          if (b16 < e10 + e11) { S.strat[b00 + 8] = (2 << 1) | 1; S.strat[b00 + 9] = (2 << 1); }
+        }
+        if (kDebug && A.dbg_ent8) {
+          const size_t cells_x = (size_t)A.g.xsize_blocks / 2 + 1;
+          float* d = A.dbg_ent8 + (((size_t)(by_img0 + cy) / 2) * cells_x + (size_t)(bx_img0 + cx) / 2) * 8;
+          for (int k = 0; k < 8; k++) d[k] = e[k];
+        }
       }
     }
+    JXLT_WAVE_SYNC();  // (the wave's LDS operations execute in order)
+    const bool in_frame = (tid & 7) < nbx && (tid >> 3) < nby;
+    p7_strat = in_frame ? S.strat[tid] : 0u;
+    p7_quant = S.raw_quant[tid];
+    const uint32_t code = p7_strat >> 1;  // 0: one block; 1: partner below / above; 2: beside
+    if (code != 0) {
+      const int o2 = code == 1 ? 8 : 1;
+      const uint32_t other = S.raw_quant[(p7_strat & 1u) ? tid + o2 : tid - o2];
+      p7_quant = other > p7_quant ? other : p7_quant;
+    }
+    JXLT_WAVE_SYNC();  // (every lane has read)
+    if (code != 0) S.raw_quant[tid] = (uint8_t)p7_quant;
   }
   __syncthreads();
   if (tid < 64) {  // (wave 0: a lane per block)
     const bool in_frame = (tid & 7) < nbx && (tid >> 3) < nby;
-    const uint32_t st = in_frame ? S.strat[tid] : 0u;
+    const uint32_t st = p7_strat;
     if (in_frame) {
       const uint32_t pos = (uint32_t)(by_img0 + (tid >> 3)) * bstride + (uint32_t)(bx_img0 + (tid & 7));
       A.strategy[pos] = (uint8_t)st;
-      A.raw_quant[pos] = S.raw_quant[tid];
+      A.raw_quant[pos] = (uint8_t)p7_quant;
     }
     // the tile's first blocks: one ballot instead of an LDS atomic per first block
     const unsigned long long firsts = __ballot((st & 1u) != 0);
@@ -1128,6 +1137,8 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     const int strat_of_lane = lane_blk_valid ? (int)S.strat[lane] : 0;
     const int quant_of_lane = (int)S.raw_quant[lane];
     const float inv_qac_of_lane = p8_inv_qac[quant_of_lane];  // (one vector load: no scalar load per transform)
+    // (and its place in the frame: the transform's comes by v_readlane instead of six scalar instructions)
+    const uint32_t pos_of_lane = (uint32_t)(by_img0 + (lane >> 3)) * bstride + (uint32_t)(bx_img0 + (lane & 7));
     // (transform number t, in raster order of the first blocks, goes to wave t mod 8: lane b finds its block's
     // number as the count of first blocks below it, and the wave's own blocks come out of one more ballot)
     const unsigned long long firsts = __ballot(strat_of_lane & 1);
@@ -1174,11 +1185,12 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     int ntrans = 0;
     // Guard against coefficients the token format cannot carry (PackSigned(q) must fit 16 bits: -32768 <= q <= 32767;
     // the reference only asserts it in debug builds, enc_bit_writer.cc:120, and the coefficient store below keeps 16
-    // bits).  The table-root pass only sums q * q per lane -- one cheap instruction per value --: a sum below 2^30
-    // proves that every magnitude is below 2^15; anything else (a huge value, an infinity, or many large values) makes
-    // the tile "suspect", and a suspect tile is filed like one that overflowed the root table and done again by
-    // tile*_kernel_redo, which tests every value exactly and counts the tile in A.unsupported if one fails.
-    float q_energy = 0.0f;
+    // bits).  The table-root pass only keeps the largest magnitude per lane -- three v_max3_f32 per transform; a
+    // quantised value is never a NaN (the zeroing threshold's comparison turns one into 0), an infinity stays one --:
+    // below 32768 nothing is wrong; anything else makes the tile "suspect", and a suspect tile is filed like one that
+    // overflowed the root table and done again by tile*_kernel_redo, which tests every value exactly (-32768 is
+    // legal) and counts the tile in A.unsupported if one fails.
+    float q_largest = 0.0f;
     bool q_bad = false;
     // Two sets of staged coefficients used in turn (the transform being worked on / the next one, requested before
     // the work starts): as ONE set that is copied at the top of the loop the copies were six v_mov per transform.
@@ -1202,7 +1214,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       const int quant_ac = scalar_lane(quant_of_lane, b);
       const float qac = A.scale * quant_ac;
       const float inv_qac = __int_as_float(scalar_lane(__float_as_int(inv_qac_of_lane), b));
-      const uint32_t pos0 = (uint32_t)(by_img0 + (b >> 3)) * bstride + (uint32_t)(bx_img0 + (b & 7));
+      const uint32_t pos0 = (uint32_t)scalar_lane((int)pos_of_lane, b);
       const uint32_t pos1 = pos0 + (st == 1 ? bstride : 1u);
       // per scan position: y first (its round trip feeds the chroma channels, :392-425)
       float quant[2][3], cur0[3];  // quantised values (integer-valued); first half of what was quantised
@@ -1234,9 +1246,13 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       for (int h = 0; h < 2; h++)
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-          if (kLutRoots) q_energy = fma32(quant[h][c], quant[h][c], q_energy);
-          else q_bad = q_bad || !(fabsf(quant[h][c] + 0.5f) <= 32767.5f);  // (exact: q is an integer)
+          if (!kLutRoots) q_bad = q_bad || !(fabsf(quant[h][c] + 0.5f) <= 32767.5f);  // (exact: q is an integer)
         }
+      if (kLutRoots) {  // (three v_max3_f32 with |.| modifiers for the six values)
+        q_largest = fmaxf(fmaxf(q_largest, fabsf(quant[0][0])), fabsf(quant[0][1]));
+        q_largest = fmaxf(fmaxf(q_largest, fabsf(quant[0][2])), fabsf(quant[1][0]));
+        q_largest = fmaxf(fmaxf(q_largest, fabsf(quant[1][1])), fabsf(quant[1][2]));
+      }
       const int t = wave + kWaves * ntrans;  // the transform's number in the tile
       file_int(0, t, b | (st << 8));
       int nz_packed = 0, nscan_packed = 0;
@@ -1311,16 +1327,20 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     JXLT_SCALAR_STORES_DONE();  // (the masks above: out of the scalar data cache)
     if (lane == 0 && wave_tokens) atomicAdd(&S.ntok, wave_tokens);
     if (kLutRoots) {
-      if (__ballot(!(q_energy < 1073741824.0f)) != 0 && lane == 0) S.overflow = 1u;  // (suspect: see q_energy)
+      if (__ballot(!(q_largest < 32768.0f)) != 0 && lane == 0) S.overflow = 1u;  // (suspect: see q_largest)
     } else {
       if (__ballot(q_bad) != 0 && lane == 0) atomicAdd(A.unsupported, 1u);
     }
   }
   __syncthreads();
-  // the tile's transforms side by side, one per lane of wave 0: DC of the covered blocks (:392-443) and the
-  // per-block outputs
-  if (tid < 64) {
-    const int lane = tid;
+  // the tile's transforms side by side, one per lane: DC of the covered blocks (:392-443) and the per-block outputs.
+  // Waves 0, 1, 2 take the channels x, y, b (the chroma waves work y's quantised DC out for themselves, :415-425):
+  // this part runs with the other waves idle and the workgroup's LDS held, so its LENGTH counts, not its instruction
+  // count -- as one wave doing the three channels in turn (until round 5) the kernel took 1 % longer; with the token
+  // count of the tile added to it, 2 % more.
+  if (tid < 192) {
+    const int lane = tid & 63;
+    const int c = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave's channel
     float* const dc_stage = stagef + 64 * kStageStrideF;
     const int* const tr_info = reinterpret_cast<const int*>(dc_stage + 64 * 6);
     const bool lane_blk_valid = (lane & 7) < nbx && (lane >> 3) < nby;
@@ -1333,50 +1353,46 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       const uint32_t pos1 = pos0 + (st == 1 ? bstride : 1u);
       const float kScale1 = (float)0.901764195028874394;
       const float kInvDCQuant[3] = {4096.0f, 512.0f, 256.0f};
-      int16_t dcy_a = 0, dcy_b = 0;
-      bool dc_bad = false;
-#pragma unroll
-      for (int ci = 0; ci < 3; ci++) {
-        const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;  // y first: the chroma DC is coded relative to it
-        // (the staged coefficients are unnormalised: kDct8Norm / kDct16Norm times the reference's)
-        const float unnorm = two ? 1.0f / kDct16Norm : 1.0f / kDct8Norm;
-        const float c0 = dc_stage[(lane * 3 + c) * 2] * unnorm, c1 = dc_stage[(lane * 3 + c) * 2 + 1] * unnorm;
+      // (the staged coefficients are unnormalised: kDct8Norm / kDct16Norm times the reference's)
+      const float unnorm = two ? 1.0f / kDct16Norm : 1.0f / kDct8Norm;
+      auto dc_pair = [&](int ch, float* d_a, float* d_b) {
+        const float c0 = dc_stage[(lane * 3 + ch) * 2] * unnorm, c1 = dc_stage[(lane * 3 + ch) * 2 + 1] * unnorm;
         const float b0 = c0 * 1.0f * 1.0f, b1 = c1 * 1.0f * kScale1;
-        const float d_a = two ? b0 + b1 : c0, d_b = two ? b0 - b1 : 0.0f;
-        int16_t qdc_a, qdc_b;
-        float fdc_a, fdc_b;
-        if (c == 1) {
-          const float inv_factor_y = kInvDCQuant[1] * A.scale_dc;
-          fdc_a = roundf(inv_factor_y * d_a);
-          fdc_b = roundf(inv_factor_y * d_b);
-          qdc_a = dcy_a = (int16_t)fdc_a;
-          qdc_b = dcy_b = (int16_t)fdc_b;
-        } else {
-          const float inv_factor = (c == 0 ? kInvDCQuant[0] : kInvDCQuant[2]) * A.scale_dc;
-          const float cfl_factor = c == 0 ? 0.0f : kInvDCQuant[2] * (1.0f / kInvDCQuant[1]);
-          fdc_a = roundf(d_a * inv_factor - dcy_a * cfl_factor);
-          fdc_b = roundf(d_b * inv_factor - dcy_b * cfl_factor);
-          qdc_a = (int16_t)fdc_a;
-          qdc_b = (int16_t)fdc_b;
-        }
-        // (a quantised DC value beyond int16 -- DCGroupData's type -- or not a number: the frame is refused)
-        dc_bad = dc_bad || !(fdc_a >= -32768.0f && fdc_a <= 32767.0f && fdc_b >= -32768.0f && fdc_b <= 32767.0f);
-        // (select, not A.nzgrid[c] / A.quant_dc[c]: indexing a kernel-argument array by a runtime value
-        // would force the argument block into scratch memory)
-        uint8_t* nzg = c == 0 ? A.nzgrid[0] : c == 1 ? A.nzgrid[1] : A.nzgrid[2];
-        int16_t* qdc = c == 0 ? A.quant_dc[0] : c == 1 ? A.quant_dc[1] : A.quant_dc[2];
-        const int nzeros = (col_nz >> (8 * c)) & 0xFF;
-        qdc[pos0] = qdc_a;
-        A.blk_nz[pos0 * 3 + c] = (uint8_t)nzeros;
-        A.blk_nscan[pos0 * 3 + c] = (uint8_t)((col_nscan >> (8 * c)) & 0xFF);
-        if (!two) {
-          nzg[pos0] = (uint8_t)nzeros;
-        } else {
-          qdc[pos1] = qdc_b;
-          const uint8_t shifted = (uint8_t)((nzeros + 1) >> 1);
-          nzg[pos0] = shifted;
-          nzg[pos1] = shifted;
-        }
+        *d_a = two ? b0 + b1 : c0;
+        *d_b = two ? b0 - b1 : 0.0f;
+      };
+      // y: every wave (the chroma DC is coded relative to it)
+      float y_a, y_b;
+      dc_pair(1, &y_a, &y_b);
+      const float inv_factor_y = kInvDCQuant[1] * A.scale_dc;
+      float fdc_a = roundf(inv_factor_y * y_a), fdc_b = roundf(inv_factor_y * y_b);
+      if (c != 1) {
+        const int16_t dcy_a = (int16_t)fdc_a, dcy_b = (int16_t)fdc_b;
+        float d_a, d_b;
+        dc_pair(c, &d_a, &d_b);
+        const float inv_factor = (c == 0 ? kInvDCQuant[0] : kInvDCQuant[2]) * A.scale_dc;
+        const float cfl_factor = c == 0 ? 0.0f : kInvDCQuant[2] * (1.0f / kInvDCQuant[1]);
+        fdc_a = roundf(d_a * inv_factor - dcy_a * cfl_factor);
+        fdc_b = roundf(d_b * inv_factor - dcy_b * cfl_factor);
+      }
+      const int16_t qdc_a = (int16_t)fdc_a, qdc_b = (int16_t)fdc_b;
+      // (a quantised DC value beyond int16 -- DCGroupData's type -- or not a number: the frame is refused)
+      const bool dc_bad = !(fdc_a >= -32768.0f && fdc_a <= 32767.0f && fdc_b >= -32768.0f && fdc_b <= 32767.0f);
+      // (select, not A.nzgrid[c] / A.quant_dc[c]: indexing a kernel-argument array by a runtime value
+      // would force the argument block into scratch memory)
+      uint8_t* nzg = c == 0 ? A.nzgrid[0] : c == 1 ? A.nzgrid[1] : A.nzgrid[2];
+      int16_t* qdc = c == 0 ? A.quant_dc[0] : c == 1 ? A.quant_dc[1] : A.quant_dc[2];
+      const int nzeros = (col_nz >> (8 * c)) & 0xFF;
+      qdc[pos0] = qdc_a;
+      A.blk_nz[pos0 * 3 + c] = (uint8_t)nzeros;
+      A.blk_nscan[pos0 * 3 + c] = (uint8_t)((col_nscan >> (8 * c)) & 0xFF);
+      if (!two) {
+        nzg[pos0] = (uint8_t)nzeros;
+      } else {
+        qdc[pos1] = qdc_b;
+        const uint8_t shifted = (uint8_t)((nzeros + 1) >> 1);
+        nzg[pos0] = shifted;
+        nzg[pos1] = shifted;
       }
       if (dc_bad) atomicAdd(A.unsupported, 1u);
     }
