@@ -232,12 +232,16 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
   if (!worker) worker.reset(new CodeWorker);
   FrameGlobals globals;
   bool dc_shared_now = false;
+  double dc_job_ms[3] = {0, 0, 0};  // (trace: start of the helper's job, code, table + DCGlobal; from the DC histogram's arrival)
   worker->Start([&] {
+    dc_job_ms[0] = ms(t0a, now());
     (void)TakeClusteringShared();
     BuildDcCode(dc_hist, &dc_code);
     dc_shared_now = TakeClusteringShared();
+    dc_job_ms[1] = ms(t0a, now());
     FillCodeTable(dc_code, dc_table.data());
     globals.dc_global = BuildDcGlobal(xsize, ysize, distp, dc_code);
+    dc_job_ms[2] = ms(t0a, now());
   });
   // (a worker that is still busy at a return would write to this frame's locals)
   struct Joiner {
@@ -356,6 +360,9 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
     return false;
   }
   memcpy(buf + e0, globals.ac_global.data(), acg_bytes);
+  if (trace)
+    fprintf(stderr, "jxlt trace: helper: job started %.3f ms after the DC histogram, DC code %.3f, table + DCGlobal %.3f\n",
+            dc_job_ms[0], dc_job_ms[1], dc_job_ms[2]);
   if (trace)
     fprintf(stderr, "jxlt trace: dc histogram after %.2f ms, %s first | ac histogram after %.2f ms, ac code %.3f ms\n",
             ms(t0, t0a), ac_first ? "AC code" : "DC code", ms(t0, t1), ms(t1, t2));
