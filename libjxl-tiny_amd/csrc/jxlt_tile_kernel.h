@@ -765,9 +765,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       if (pair_valid1) publish((pby0 + 1) * nbx + pbx, d8x, d8y, d8b);
     }
     __syncthreads();
-    // Chain lanes: wave 0 runs the two chains of X (lanes 0-7 of a row: ca = sum a * a, lanes 8-15: cb = sum a * b),
-    // wave 1 those of B -- a channel's two sums meet in ONE wave, which finishes FindBestMultiplier (:56-61) itself
-    // (until round 5: wave 0 ran ca of both channels, wave 1 cb, and two threads divided behind one more barrier).
+    // Chain lanes: wave 0 lanes 0-15 run ca (X: 0-7, B: 8-15), wave 1 lanes 0-15 run cb.
     // The 512 fused multiply-adds of a chain are strictly sequential, so these two waves are
     // the critical path of the workgroup: they run at raised issue priority, and the reads
     // of block blk + 1 are issued before the arithmetic of block blk.
@@ -822,8 +820,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
         for (int r = 8; r < 16; r++) chain_park(8 + r) = c16x[r];
         chain_park(24) = c16y[15];
       }
-      const int ch = cw;  // 0: X, 1: B (the two halves of a row read the same terms: a broadcast)
-      const bool sum_ab = ((cl >> 3) & 1) != 0;  // lanes 8-15 of a row: cb
+      const int ch = (cl >> 3) & 1;  // 0: X, 1: B
       const float* src = terms + l * 32;
       int slot[4];
 #pragma unroll
@@ -842,8 +839,8 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
           if (first < nblk) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-              t[q].y = sum_ab ? t[q].y : t[q].x;
-              t[q].w = sum_ab ? t[q].w : t[q].z;
+              t[q].y = cw == 0 ? t[q].x : t[q].y;
+              t[q].w = cw == 0 ? t[q].z : t[q].w;
             }
           }
         }
@@ -889,17 +886,11 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       __builtin_amdgcn_s_setprio(0);
     }
     const int final_pos = nblk & 3;  // where the accumulators are after the last hop
+    const bool chain_lane = cw < 2 && relay_pos == final_pos;
+    const int chain_ch = (cl >> 3) & 1;
     const float total = octet_sum(acc);
-    if (cw < 2) {  // FindBestMultiplier tail (:56-61): lane 0 of the row that holds the sums has ca, its lane 8 cb
-      const int final_row = final_pos == 0 ? 0 : final_pos == 1 ? 1 : final_pos == 2 ? 3 : 2;
-      const float ca_sum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(total), final_row * 16));
-      const float cb_sum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(total), final_row * 16 + 8));
-      const float kDistanceMultiplierAC = 1e-3f;
-      const float num = (float)(nblk * 64);
-      float xq = -cb_sum / (ca_sum + num * kDistanceMultiplierAC * 0.5f);
-      xq = fmaxf(-128.0f, fminf(127.0f, roundf(xq)));
-      if (cl == 0) S.cmap[cw] = (int)xq;
-    }
+    // cfl_sum: ca_x, cb_x, ca_b, cb_b
+    if (chain_lane && l == 0) S.cfl_sum[chain_ch * 2 + cw] = total;
     __syncthreads();
     {
       if (cw >= 2) {  // (visible to P6b behind the barrier below)
@@ -913,6 +904,13 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
           if (w < kP8ScanWords + 256) p8_tab[w] = late_p8[j];
         }
       }
+    }
+    if (tid < 2) {  // FindBestMultiplier tail (:56-61)
+      const float kDistanceMultiplierAC = 1e-3f;
+      const float num = (float)(nblk * 64);
+      float xq = -S.cfl_sum[tid * 2 + 1] / (S.cfl_sum[tid * 2] + num * kDistanceMultiplierAC * 0.5f);
+      xq = fmaxf(-128.0f, fminf(127.0f, roundf(xq)));
+      S.cmap[tid] = (int)xq;
     }
   }
   __syncthreads();
