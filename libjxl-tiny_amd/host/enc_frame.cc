@@ -534,14 +534,14 @@ bool EncodeOnDeviceList(const float* const planes[3], size_t pitch_bytes, const 
     }
     t_list.enc_devices = devices;
   }
-  jxlt_multi_encoder* const g_multi = t_list.enc;
+  jxlt_multi_encoder* const list_encoder = t_list.enc;
   const uint8_t* bytes = nullptr;
   size_t size = 0;
   const int rc = pfm_payload
-                     ? jxlt_multi_encoder_encode_pfm(g_multi, pfm_payload, xsize, ysize, big_endian, distance, &bytes, &size)
-                     : jxlt_multi_encoder_encode(g_multi, planes, pitch_bytes, xsize, ysize, distance, &bytes, &size);
+                     ? jxlt_multi_encoder_encode_pfm(list_encoder, pfm_payload, xsize, ysize, big_endian, distance, &bytes, &size)
+                     : jxlt_multi_encoder_encode(list_encoder, planes, pitch_bytes, xsize, ysize, distance, &bytes, &size);
   if (rc != JXLT_OK) {
-    fprintf(stderr, "jxl_tiny_amd: sharded encode failed: %s\n", jxlt_multi_encoder_last_error(g_multi));
+    fprintf(stderr, "jxl_tiny_amd: sharded encode failed: %s\n", jxlt_multi_encoder_last_error(list_encoder));
     return false;
   }
   codestream->assign(bytes, bytes + size);
