@@ -262,11 +262,14 @@ def main():
     # HERE, in front of the warm-up -- the GPU's clock needs some 75 ms under load to reach its level, which five warm-up
     # steps of 5 ms are not (BENCH_r04 and the round-5 runs of the driver's command: tile_kernel 4.0 -> 3.75 ms over the
     # first ten steps), and of the line's legs this is the one that is only kernels.  
+    # The line says so itself (`harness`: what ran in front, for how long, the first and the last timed step's
+    # tile_kernel time -- VERDICT r5 item 6 / ADVICE r5: a reader of the JSON alone can tell clock ramp from code).
+    result_early = {}
+    pre_warm_ms = 0.0
     if not sharded and not args.no_extras and slab is not None:
-        result_early = {}
+        t_pre = time.perf_counter()
         device_only_leg(args, enc, result_early, size * size / 1e6)
-    else:
-        result_early = {}
+        pre_warm_ms = 1e3 * (time.perf_counter() - t_pre)
     pipelined = sharded and args.in_flight > 1
     ktimes = {}
     step_ms, warmup_ms, step_kernel_ms, step_copy, step_stages = [], [], [], [], []
@@ -297,10 +300,16 @@ def main():
         # microseconds per step, all of them read between two steps.
         probe = StepProbe()
         probe.sample()
+        # (step_ms = the encode call alone; the diagnostic reads behind it -- HIP-event times of the step that has just
+        # ended, counters, the host's stage times -- are inside `elapsed`, i.e. counted against `value`, and their
+        # cost is reported as harness.diagnostic_calls_ms_per_step)
+        diag_s = 0.0
         t0 = time.perf_counter()
         tp = t0
         for i in range(args.steps):
             jxl = step()
+            tn = time.perf_counter()
+            step_ms.append(round(1e3 * (tn - tp), 3))
             if slab is not None:
                 kt = enc.kernel_times()
                 for k, v in kt.items():
@@ -312,9 +321,8 @@ def main():
                 if tl is not None:
                     step_stages.append({k: round(v, 3) for k, v in tl.items()})
             probe.sample()
-            tn = time.perf_counter()
-            step_ms.append(round(1e3 * (tn - tp), 3))
-            tp = tn
+            tp = time.perf_counter()
+            diag_s += tp - tn
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
         if jxl is not None:
@@ -399,6 +407,18 @@ def main():
         "kernel_ms": {k: round(v, 3) for k, v in ktimes.items()},
     }
     if step_ms:
+        tk = [k.get("tile_kernel") for k in step_kernel_ms]
+        result["harness"] = {
+            "pre_warm": ("device-only leg (kernels without code construction and packing, %d launches) in FRONT of the "
+                         "warm-up steps: the GPU's clock is at its level when the timed region starts" % (3 + max(3, args.steps))
+                         if pre_warm_ms else "none (warm-up steps only)"),
+            "pre_warm_ms": round(pre_warm_ms, 1),
+            "warmup_steps_ms_total": round(sum(warmup_ms), 1),
+            "tile_kernel_ms_first_timed_step": tk[0] if tk else None,
+            "tile_kernel_ms_last_timed_step": tk[-1] if tk else None,
+            "tile_kernel_ms_first_minus_last": round(tk[0] - tk[-1], 3) if tk and tk[0] is not None and tk[-1] is not None else None,
+            "diagnostic_calls_ms_per_step": round(1e3 * diag_s / max(1, len(step_ms)), 4),
+            "note": "ms_per_step and value include the diagnostic calls; step_ms lists the encode calls alone"}
         srt = sorted(step_ms)
         result["ms_per_step_median"] = srt[len(srt) // 2] if len(srt) % 2 else round((srt[len(srt) // 2 - 1] + srt[len(srt) // 2]) / 2, 3)
         result["ms_per_step_min"] = srt[0]
@@ -807,10 +827,21 @@ def kernel_source_sha16():
 
 
 def profile_freshness(path, doc):
+    """Which committed counter profile a figure comes from and whether it still describes what runs: `stale_reason` is
+    null only when the profile carries the fingerprint of the CURRENT device sources; otherwise it says why not, and
+    stderr says it too (the check fails loudly)."""
     stored = doc.get("kernel_source_sha16")
     now = kernel_source_sha16()
+    reason = None
+    if stored is None:
+        reason = "the profile carries no fingerprint of the device sources it was collected with"
+    elif stored != now:
+        reason = ("collected with device sources %s, the sources now are %s: the kernels have changed since -- "
+                  "run tools/collect_profiles.sh" % (stored, now))
+    if reason is not None:
+        print("bench.py: WARNING: profiles/%s is stale: %s" % (Path(path).name, reason), file=sys.stderr, flush=True)
     return {"file": "profiles/" + Path(path).name, "collected_with_kernel_source_sha16": stored,
-            "current_kernel_source_sha16": now, "stale": (None if stored is None else stored != now)}
+            "current_kernel_source_sha16": now, "stale": reason is not None, "stale_reason": reason}
 
 
 def pmc_traffic(size, with_doc=False):

@@ -23,6 +23,11 @@ extern "C" {
  *           always allowed). */
 int jxlt_debug_fetch(jxlt_context* ctx, int what, void* host_dst, size_t bytes);
 
+/* The self-check jxlt_context_create runs once per device: the bit pattern of 3.0f x 2^-147 as the DEVICE computes it.
+ * 12 when FP32 denormals are kept, which tile12_kernel's table offsets rely on (csrc/jxlt_tile_kernel.h); 0 when the
+ * device code flushes them (a build without -fno-gpu-flush-denormals-to-zero on a target that defaults to flushing). */
+int jxlt_debug_denormal_probe(jxlt_context* ctx, uint32_t* bits);
+
 /* Timing of the device stages of the last jxlt_encode_enqueue (HIP events on the context's
  * stream, always recorded): writes up to `cap` entries; returns the number of stages, or < 0.
  * Waits for the device pipeline of that encode. */

@@ -37,7 +37,8 @@ HIP_SYMBOLS = ["jxlt_context_create", "jxlt_context_destroy", "jxlt_last_error",
                "jxlt_pack_begin", "jxlt_pack_sizes", "jxlt_pack_deliver", "jxlt_release_cached_memory",
                "jxlt_output_buffer",
                "jxlt_synchronize", "jxlt_fetch_result", "jxlt_encode_stats"]
-HIP_SYMBOLS_TESTING = ["jxlt_debug_fetch", "jxlt_fetch_side_info", "jxlt_pack_sections", "jxlt_kernel_times"]
+HIP_SYMBOLS_TESTING = ["jxlt_debug_fetch", "jxlt_fetch_side_info", "jxlt_pack_sections", "jxlt_kernel_times",
+                       "jxlt_debug_denormal_probe"]
 HOST_SYMBOLS = ["jxlt_compute_distance_params", "jxlt_assemble_frame",
                 "jxlt_encode_file_planar", "jxlt_encode_file_planar_devices", "jxlt_encode_pfm_file", "jxlt_emulate_reference_static_constants", "jxlt_emulate_reference_single_symbol_codes", "jxlt_encode_resident", "jxlt_encode_resident_view", "jxlt_write_file_header", "jxlt_last_frame_timeline",
                 "jxlt_free", "jxlt_batch_encoder_create", "jxlt_batch_encoder_create_multi",
@@ -891,3 +892,16 @@ class ShardPipeline:
             raise JxlTinyError("jxlt_shard_pipeline_wait failed (%d): %s" %
                                (rc, self._L.jxlt_shard_pipeline_last_error(self._p).decode()))
         return NativeView(out, n.value) if out else None
+
+
+def denormal_self_check(enc):
+    """The bits of 3.0f x 2^-147 as the device computes it (testing header: jxlt_debug_denormal_probe); 12 when FP32
+    denormals are kept."""
+    L = hip_lib()
+    L.jxlt_debug_denormal_probe.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    L.jxlt_debug_denormal_probe.restype = C.c_int
+    bits = C.c_uint32(0)
+    rc = L.jxlt_debug_denormal_probe(enc._ctx, C.byref(bits))
+    if rc != 0:
+        raise JxlTinyError("jxlt_debug_denormal_probe failed: %d" % rc)
+    return int(bits.value)

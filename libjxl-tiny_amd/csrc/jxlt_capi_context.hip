@@ -38,6 +38,20 @@ int CheckImageArgs(jxlt_context* ctx, const void* const planes[3], size_t pitch_
 extern "C" {
 
 namespace {
+// The arithmetic the kernels rely on beyond IEEE operations: FP32 DENORMALS ARE KEPT.  tile12_kernel takes the byte
+// offset of a quantised magnitude's square root (and of its zeros' cost) as the bit pattern of q x 2^-147
+// (jxlt_tile_kernel.h): with denormals flushed every offset would be 0, no overflow would be flagged and the transform
+// search would go wrong without a sign.  The Makefile pins -fno-gpu-flush-denormals-to-zero; this
+// kernel checks the product on the device itself -- once per device and process, in jxlt_context_create, which fails
+// loudly if it does not hold: bits(3.0f x 2^-147) = 12.
+__global__ void denormal_probe_kernel(float q, uint32_t* out) { *out = __float_as_uint(q * 0x1p-147f); }
+uint32_t DenormalProbe(jxlt_context* ctx) {
+  uint32_t* slot = &ctx->mail.p->denormal_probe;
+  *slot = 0xFFFFFFFFu;
+  hipLaunchKernelGGL(denormal_probe_kernel, dim3(1), dim3(1), 0, ctx->stream, 3.0f, slot);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return 0xFFFFFFFFu;
+  return *(volatile uint32_t*)slot;
+}
 __global__ void delay_kernel(unsigned long long cycles) {
   const unsigned long long t0 = clock64();
   while (clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(8);
@@ -165,11 +179,30 @@ int jxlt_context_create(int device_ordinal, jxlt_context** out) {
     const char* e2 = getenv("JXLT_COPY_WARMUP");
     return e2 ? atoi(e2) : 3;
   }();
-  static std::atomic<bool> warmed[64];
+  static std::atomic<bool> warmed[64], denormals_checked[64];
+  if (device_ordinal < 64 && !denormals_checked[device_ordinal].exchange(true)) {
+    const uint32_t bits = DenormalProbe(ctx);
+    if (bits != 12u) {
+      denormals_checked[device_ordinal] = false;
+      char msg[160];
+      snprintf(msg, sizeof(msg), "the device code does not keep FP32 denormals (3.0f * 2^-147 has the bits 0x%08x, not 12): "
+               "build with -fno-gpu-flush-denormals-to-zero", bits);
+      g_create_error = msg;
+      jxlt_context_destroy(ctx);
+      return JXLT_ERR_INTERNAL;
+    }
+  }
   if (copy_warmup && device_ordinal >= 0 && device_ordinal < 64 && !warmed[device_ordinal].exchange(true)) CopyWarmup(ctx, copy_warmup);
   ctx->counted = true;
   DeviceBlockCache::Get().ContextCreated(ctx->device);
   *out = ctx;
+  return JXLT_OK;
+}
+
+int jxlt_debug_denormal_probe(jxlt_context* ctx, uint32_t* bits) {
+  if (!ctx || !bits) return JXLT_ERR_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  *bits = DenormalProbe(ctx);
   return JXLT_OK;
 }
 

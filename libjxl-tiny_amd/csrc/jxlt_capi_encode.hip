@@ -152,6 +152,12 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
     ctx->error = "invalid encode parameters";
     return JXLT_ERR_INVALID_ARGUMENT;
   }
+  // A new encode begins: whatever the previous one left on the context -- "encoded", a refusal of its values -- ends
+  // HERE, not at the end of a successful enqueue: a frame that fails on its way in (out of memory, a HIP error) must
+  // not be reported with the previous frame's JXLT_ERR_UNSUPPORTED.
+  ctx->encoded = false;
+  ctx->overflow_checked = true;
+  ctx->encode_status = JXLT_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (ctx->deliveries_pending) {
     // (sections of the previous encode may still be leaving the blobs this encode is about to overwrite)

@@ -518,32 +518,22 @@ int jxlt_pack_deliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_sect
     ctx->error = "jxlt_pack_deliver needs jxlt_pack_begin first";
     return JXLT_ERR_INVALID_ARGUMENT;
   }
-  ctx->delivered_kinds |= 1u << kind;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  // The destination must be memory a kernel can store to: page-locked host memory or device memory.  (The context's
-  // own output buffer is known to be; anything else is looked up, every time -- a range that was page-locked at the
-  // last call may have been freed since.)
-  uint8_t* dev_dst = dst;
-  const bool own_output = ctx->h_output.p && dst >= ctx->h_output.p && dst <= ctx->h_output.p + ctx->h_output.cap;
-  if (!own_output) {
-    hipPointerAttribute_t attr;
-    const hipError_t pe = hipPointerGetAttributes(&attr, dst);
-    (void)hipGetLastError();
-    if (pe != hipSuccess || (attr.type != hipMemoryTypeHost && attr.type != hipMemoryTypeDevice)) {
-      ctx->error = "jxlt_pack_deliver needs page-locked host memory (jxlt_output_buffer / jxlt_pinned_alloc / "
-                   "jxlt_pinned_register) or device memory as destination";
+  // The sections travel by copy commands (hipMemcpyAsync, hipMemcpyDefault), so the destination may be anything a
+  // copy command accepts and the caller's pointer is passed through as it is: device memory; page-locked host memory
+  // (jxlt_output_buffer / jxlt_pinned_alloc / jxlt_pinned_register / hipHostRegister with or without the mapped flag)
+  // -- the copies then run beside the caller, who reads the bytes behind jxlt_synchronize; or ordinary pageable host
+  // memory, the SYNCHRONOUS fallback: the runtime stages such a copy and the call that issues it (this one, or for the
+  // DC-group sections the library's next wait) returns only when the bytes have arrived.  (Until round 5 a kernel
+  // stored the bytes and the destination had to be mapped into the device's address space: ADVICE r5.)
+  uint8_t* const dev_dst = dst;
+  for (size_t r = 0; r < num_runs; r++) {
+    if ((size_t)runs[r].first_section + runs[r].num_sections > ctx->pack[kind].measured_sections) {
+      ctx->error = "jxlt_pack_deliver: a run names sections the measuring pass did not see";
       return JXLT_ERR_INVALID_ARGUMENT;
     }
-    if (attr.type == hipMemoryTypeHost) {
-      void* mapped = nullptr;
-      if (hipHostGetDevicePointer(&mapped, dst, 0) != hipSuccess || !mapped) {
-        (void)hipGetLastError();
-        ctx->error = "jxlt_pack_deliver: the destination is page-locked but not mapped into the device's address space";
-        return JXLT_ERR_INVALID_ARGUMENT;
-      }
-      dev_dst = static_cast<uint8_t*>(mapped);
-    }
   }
+  ctx->delivered_kinds |= 1u << kind;  // (only a request that passed validation counts as a hand-over of the kind)
   if (kind == 0) {
     if (ctx->deferred_dc.pending) {  // (a second hand-over of the kind: the first one first)
       const int rcd = IssueDeferred(ctx, /*wait=*/true);
@@ -555,13 +545,6 @@ int jxlt_pack_deliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_sect
       d.dst = dev_dst;
       d.end_aligned = end_aligned;
       d.runs.assign(runs, runs + num_runs);
-      for (size_t r = 0; r < num_runs; r++) {
-        if ((size_t)runs[r].first_section + runs[r].num_sections > ctx->pack[0].measured_sections) {
-          d.pending = false;
-          ctx->error = "jxlt_pack_deliver: a run names sections the measuring pass did not see";
-          return JXLT_ERR_INVALID_ARGUMENT;
-        }
-      }
       ctx->deliveries_pending = true;
       return JXLT_OK;
     }

@@ -181,6 +181,7 @@ struct jxlt_context {
     uint32_t launch_sec_end[2][16];  // [kind]: sections complete behind each writing launch (published with the sizes)
     uint32_t stream_seq[2][kPackMaxLaunches][16];  // [kind][launch][0] = pack_seq: that launch of a single pass is done,
                                                    // the bit counts of the sections it completed are in the host's mirror
+    uint32_t denormal_probe;  // bits of 3.0f x 2^-147 as the device computes it (jxlt_context_create's self-check)
   };
   PinnedBuf<HostMail> mail;
   uint32_t seq = 0;          // encodes enqueued on this context

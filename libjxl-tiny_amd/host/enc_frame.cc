@@ -518,10 +518,13 @@ void SetEncoderDevices(const int* device_ordinals, int n) {
 namespace jxlt {
 // The frame over the calling thread's device list (jxl::SetEncoderDevices / JXLT_DEVICES) when that names several
 // GPUs and the frame has more than one DC group (a PFM payload: more than one row of DC groups).  *used = false: not applicable, nothing done.
-// Otherwise the complete codestream (file header + frame) is in *codestream, or false is returned.
+// Otherwise the complete codestream (file header + frame) is in *codestream, or false is returned and
+// *failure_code says why (the participants' own code: JXLT_ERR_UNSUPPORTED when a device refused the frame's values).
 bool EncodeOnDeviceList(const float* const planes[3], size_t pitch_bytes, const void* pfm_payload, int big_endian,
-                        size_t xsize, size_t ysize, float distance, std::vector<uint8_t>* codestream, bool* used) {
+                        size_t xsize, size_t ysize, float distance, std::vector<uint8_t>* codestream, bool* used,
+                        int* failure_code) {
   using namespace jxl;
+  if (failure_code) *failure_code = JXLT_ERR_INTERNAL;
   const std::vector<int>& devices = t_list.explicit_list ? t_list.devices : DevicesFromEnvironment();
   *used = devices.size() > 1 && (ysize > 2048 || (xsize > 2048 && pfm_payload == nullptr));
   if (!*used) return true;
@@ -530,6 +533,7 @@ bool EncodeOnDeviceList(const float* const planes[3], size_t pitch_bytes, const 
     if (jxlt_multi_encoder_create(devices.data(), static_cast<int>(devices.size()), &t_list.enc) != JXLT_OK) {
       fprintf(stderr, "jxl_tiny_amd: cannot create device contexts: %s\n", jxlt_last_error(nullptr));
       t_list.enc = nullptr;
+      if (failure_code) *failure_code = JXLT_ERR_NO_DEVICE;
       return false;  // no CPU fallback by design
     }
     t_list.enc_devices = devices;
@@ -542,6 +546,7 @@ bool EncodeOnDeviceList(const float* const planes[3], size_t pitch_bytes, const 
                      : jxlt_multi_encoder_encode(list_encoder, planes, pitch_bytes, xsize, ysize, distance, &bytes, &size);
   if (rc != JXLT_OK) {
     fprintf(stderr, "jxl_tiny_amd: sharded encode failed: %s\n", jxlt_multi_encoder_last_error(list_encoder));
+    if (failure_code) *failure_code = rc;
     return false;
   }
   codestream->assign(bytes, bytes + size);

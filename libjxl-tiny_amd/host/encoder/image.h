@@ -6,9 +6,13 @@
 #ifndef JXLT_HOST_ENCODER_IMAGE_H_
 #define JXLT_HOST_ENCODER_IMAGE_H_
 
+// The reference's image.h:12-15 brings <inttypes.h> and <string.h> to everything that includes it
+// (its cjxl_main.cc calls strcmp / strerror on the strength of that): kept, callers compile unchanged.
+#include <inttypes.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <utility>
 

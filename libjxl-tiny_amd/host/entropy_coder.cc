@@ -705,116 +705,103 @@ namespace {
 
 constexpr int kCodeLengthCodes = 18;
 
-// Run-length pieces of the code-length sequence (enc_entropy_code.cc:125-196).
-void EmitRepeat(uint8_t previous_value, uint8_t value, size_t reps, std::vector<uint8_t>* tree,
-                std::vector<uint8_t>* extra) {
-  if (previous_value != value) {
-    tree->push_back(value);
-    extra->push_back(0);
-    --reps;
-  }
-  if (reps == 7) {
-    tree->push_back(value);
-    extra->push_back(0);
-    --reps;
-  }
-  if (reps < 3) {
-    for (size_t i = 0; i < reps; ++i) {
-      tree->push_back(value);
-      extra->push_back(0);
+// The code-length sequence of a complex prefix code (what enc_entropy_code.cc:125-275 produces; the thresholds
+// decide bytes, the structure is this file's own): the depths, trailing zeros dropped, are cut into RUNS of equal
+// values; a run leaves either as that many literals or as one repeat code -- symbol 16 "previous non-zero length
+// again" with 2 extra bits per code, symbol 17 "zeros" with 3 -- whose count is spread over as many codes as its
+// digits need.
+struct LengthSymbol {
+  uint8_t symbol;  // 0…15 a literal depth, 16 / 17 the repeat codes
+  uint8_t extra;   // the repeat code's extra bits
+};
+
+struct RepeatCode {
+  uint8_t symbol;
+  int extra_bits;
+  // A count of 3 + 2^extra_bits is the first that needs two repeat codes; one literal + one code is cheaper.
+  size_t FirstTwoCodeCount() const { return 3 + (size_t{1} << extra_bits); }
+};
+constexpr RepeatCode kRepeatPrevious = {16, 2};
+constexpr RepeatCode kRepeatZeros = {17, 3};
+
+// Calls f(value, reps, first index) for the maximal runs of depth[0, n).
+template <typename F>
+void ForEachRun(const uint8_t* depth, size_t n, F f) {
+  for (size_t i = 0, end; i < n; i = end) {
+    for (end = i + 1; end < n && depth[end] == depth[i]; ++end) {
     }
-  } else {
-    reps -= 3;
-    const size_t start = tree->size();
-    while (true) {
-      tree->push_back(16);
-      extra->push_back(reps & 0x3);
-      reps >>= 2;
-      if (reps == 0) break;
-      --reps;
-    }
-    std::reverse(tree->begin() + start, tree->end());
-    std::reverse(extra->begin() + start, extra->end());
+    f(depth[i], end - i, i);
   }
 }
 
-void EmitZeroRepeat(size_t reps, std::vector<uint8_t>* tree, std::vector<uint8_t>* extra) {
-  if (reps == 11) {
-    tree->push_back(0);
-    extra->push_back(0);
-    --reps;
+// `count` further copies of `literal`: literals while they are cheaper, otherwise the repeat code.  A chain of k
+// repeat codes with extras e_1 … e_k (most significant first) stands for 3 + e_k + Σ_{j<k} (e_j + 1)·B^(k-j),
+// B = 2^extra_bits -- each code before the last scales what follows, hence the "minus one" per digit.
+void AppendCopies(uint8_t literal, size_t count, const RepeatCode& rc, std::vector<LengthSymbol>* out) {
+  if (count == rc.FirstTwoCodeCount()) {
+    out->push_back({literal, 0});
+    --count;
   }
-  if (reps < 3) {
-    for (size_t i = 0; i < reps; ++i) {
-      tree->push_back(0);
-      extra->push_back(0);
-    }
-  } else {
-    reps -= 3;
-    const size_t start = tree->size();
-    while (true) {
-      tree->push_back(17);
-      extra->push_back(reps & 0x7);
-      reps >>= 3;
-      if (reps == 0) break;
-      --reps;
-    }
-    std::reverse(tree->begin() + start, tree->end());
-    std::reverse(extra->begin() + start, extra->end());
+  if (count < 3) {
+    out->insert(out->end(), count, LengthSymbol{literal, 0});
+    return;
   }
+  const size_t mask = (size_t{1} << rc.extra_bits) - 1;
+  uint8_t digits[24];
+  int num = 0;
+  for (size_t rest = count - 3;; rest = (rest >> rc.extra_bits) - 1) {
+    digits[num++] = static_cast<uint8_t>(rest & mask);
+    if ((rest >> rc.extra_bits) == 0) break;
+  }
+  while (num > 0) out->push_back({rc.symbol, digits[--num]});
 }
 
-// enc_entropy_code.cc:198-224
-void DecideRle(const uint8_t* depth, size_t length, bool* rle_nonzero, bool* rle_zero) {
-  size_t total_zero = 0, total_nonzero = 0, count_zero = 1, count_nonzero = 1;
-  for (size_t i = 0; i < length;) {
-    const uint8_t value = depth[i];
-    size_t reps = 1;
-    for (size_t k = i + 1; k < length && depth[k] == value; ++k) ++reps;
-    if (reps >= 3 && value == 0) {
-      total_zero += reps;
-      ++count_zero;
-    }
-    if (reps >= 4 && value != 0) {
-      total_nonzero += reps;
-      ++count_nonzero;
-    }
-    i += reps;
+std::vector<LengthSymbol> CodeLengthSequence(const uint8_t* depth, size_t length) {
+  size_t used = length;
+  while (used > 0 && depth[used - 1] == 0) --used;
+  // Whether repeat codes are used at all, per class (zeros / non-zeros): only alphabets above 50 symbols, and only
+  // when the runs long enough to gain (zeros from 3, others from 4) cover more than twice their number + 1.
+  bool repeat_zeros = false, repeat_others = false;
+  if (length > 50) {
+    size_t covered[2] = {0, 0}, runs[2] = {1, 1};
+    ForEachRun(depth, used, [&](uint8_t value, size_t reps, size_t) {
+      const int cls = value != 0;
+      if (reps >= size_t(3 + cls)) {
+        covered[cls] += reps;
+        ++runs[cls];
+      }
+    });
+    repeat_zeros = covered[0] > 2 * runs[0];
+    repeat_others = covered[1] > 2 * runs[1];
   }
-  *rle_nonzero = total_nonzero > count_nonzero * 2;
-  *rle_zero = total_zero > count_zero * 2;
-}
-
-// enc_entropy_code.cc:229-275
-void CodeLengthSequence(const uint8_t* depth, size_t length, std::vector<uint8_t>* tree,
-                        std::vector<uint8_t>* extra) {
-  uint8_t previous_value = 8;
-  size_t new_length = length;
-  while (new_length > 0 && depth[new_length - 1] == 0) --new_length;
-  bool rle_nonzero = false, rle_zero = false;
-  if (length > 50) DecideRle(depth, new_length, &rle_nonzero, &rle_zero);
-  for (size_t i = 0; i < new_length;) {
-    const uint8_t value = depth[i];
-    size_t reps = 1;
-    if ((value != 0 && rle_nonzero) || (value == 0 && rle_zero)) {
-      for (size_t k = i + 1; k < new_length && depth[k] == value; ++k) ++reps;
-    }
+  std::vector<LengthSymbol> out;
+  uint8_t previous = 8;  // the format's initial "previous non-zero length"
+  ForEachRun(depth, used, [&](uint8_t value, size_t reps, size_t) {
     if (value == 0) {
-      EmitZeroRepeat(reps, tree, extra);
-    } else {
-      EmitRepeat(previous_value, value, reps, tree, extra);
-      previous_value = value;
+      if (repeat_zeros) AppendCopies(0, reps, kRepeatZeros, &out);
+      else out.insert(out.end(), reps, LengthSymbol{0, 0});
+      return;
     }
-    i += reps;
-  }
+    if (!repeat_others) {
+      out.insert(out.end(), reps, LengthSymbol{value, 0});
+    } else {
+      // Symbol 16 repeats the PREVIOUS non-zero length: a new value goes out once as a literal first.
+      if (previous != value) {
+        out.push_back({value, 0});
+        --reps;
+      }
+      AppendCopies(value, reps, kRepeatPrevious, &out);
+    }
+    previous = value;
+  });
+  return out;
 }
 
 // enc_entropy_code.cc:326-375 + :22-66 + :68-87
 void StoreComplexPrefixCode(const uint8_t* depths, size_t num, jxl::BitWriter* writer) {
-  std::vector<uint8_t> tree, extra;
-  CodeLengthSequence(depths, num, &tree, &extra);
+  const std::vector<LengthSymbol> tree = CodeLengthSequence(depths, num);
   uint32_t histogram[kCodeLengthCodes] = {0};
-  for (uint8_t s : tree) ++histogram[s];
+  for (const LengthSymbol& s : tree) ++histogram[s.symbol];
   int num_codes = 0, single_code = 0;
   for (int i = 0; i < kCodeLengthCodes; ++i) {
     if (histogram[i]) {
@@ -854,11 +841,10 @@ void StoreComplexPrefixCode(const uint8_t* depths, size_t num, jxl::BitWriter* w
     writer->Write(kLenBits[l], kLenSymbols[l]);
   }
   if (num_codes == 1) cl_depth[single_code] = 0;
-  for (size_t i = 0; i < tree.size(); ++i) {
-    const size_t ix = tree[i];
-    writer->Write(cl_depth[ix], cl_bits[ix]);
-    if (ix == 16) writer->Write(2, extra[i]);
-    if (ix == 17) writer->Write(3, extra[i]);
+  for (const LengthSymbol& s : tree) {
+    writer->Write(cl_depth[s.symbol], cl_bits[s.symbol]);
+    if (s.symbol == kRepeatPrevious.symbol) writer->Write(kRepeatPrevious.extra_bits, s.extra);
+    if (s.symbol == kRepeatZeros.symbol) writer->Write(kRepeatZeros.extra_bits, s.extra);
   }
 }
 

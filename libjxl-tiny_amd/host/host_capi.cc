@@ -140,7 +140,8 @@ int jxlt_encode_file_planar_devices(const float* const planes[3], size_t pitch_b
   jxl::SetEncoderDevices(device_ordinals, num_devices);  // (the calling thread's list)
   std::vector<uint8_t> whole;
   bool used = false;
-  if (!jxlt::EncodeOnDeviceList(planes, pitch_bytes, nullptr, 0, xsize, ysize, distance, &whole, &used)) return JXLT_ERR_INTERNAL;
+  int code = JXLT_ERR_INTERNAL;
+  if (!jxlt::EncodeOnDeviceList(planes, pitch_bytes, nullptr, 0, xsize, ysize, distance, &whole, &used, &code)) return code;
   if (used) return ToMalloc(whole, out_bytes, out_size);
   return jxlt_encode_file_planar(planes, pitch_bytes, xsize, ysize, distance, num_devices > 0 ? device_ordinals[0] : 0,
                                  out_bytes, out_size);
@@ -202,8 +203,8 @@ int jxlt_encode_resident_view(jxlt_context* ctx, float distance, int num_threads
   jxl::BitWriter writer;
   if (!jxlt::WriteFileHeader(xsize, ysize, &writer)) return JXLT_ERR_INVALID_ARGUMENT;
   const std::vector<uint8_t> file_header = writer.TakeBytes();
-  // The codestream is assembled in the context's page-locked output buffer; the device
-  // writes the AC sections there itself (jxlt_pack_sections_place).
+  // The codestream is assembled in the context's page-locked output buffer; the sections arrive
+  // there by the copy commands of jxlt_pack_deliver, header + TOC are set in front of them.
   jxlt::ContextOutput out;
   out.prefix = &file_header;
   if (!jxlt::EncodeFrameOnContext(ctx, distance, num_threads, nullptr, nullptr, &out)) return FailureCode(ctx);

@@ -29,7 +29,8 @@ bool EncodeFrameOnContext(jxlt_context* ctx, float distance, int num_threads, jx
 bool WriteFileHeader(size_t xsize, size_t ysize, jxl::BitWriter* writer);
 // One frame over the calling thread's device list (jxl::SetEncoderDevices / JXLT_DEVICES); see enc_frame.cc.
 bool EncodeOnDeviceList(const float* const planes[3], size_t pitch_bytes, const void* pfm_payload, int big_endian,
-                        size_t xsize, size_t ysize, float distance, std::vector<uint8_t>* codestream, bool* used);
+                        size_t xsize, size_t ysize, float distance, std::vector<uint8_t>* codestream, bool* used,
+                        int* failure_code = nullptr);
 bool ParsePFMHeader(const uint8_t* data, size_t size, size_t* xsize, size_t* ysize, bool* big_endian,
                     size_t* payload_offset);
 bool NormalizeDistance(float* distance);

@@ -28,3 +28,18 @@ def test_slow_steps_get_a_cause():
     assert flat["slow_steps"][0]["cause"] == {"unattributed_ms": 1.8}
     # and a flat run lists nothing
     assert bench.step_diagnostics([5.2, 5.21, 5.19], [usual] * 3, [(4, 20.0)] * 3, None)["slow_steps"] == []
+
+
+def test_a_counter_profile_of_other_kernel_sources_is_called_stale(capsys):
+    """roofline.traffic / valu_issue come from committed counter profiles; the line must say loudly
+    when those were collected with other device sources than the ones that run."""
+    import bench
+    now = bench.kernel_source_sha16()
+    fresh = bench.profile_freshness("profiles/x_traffic_1.json", {"kernel_source_sha16": now})
+    assert fresh["stale"] is False and fresh["stale_reason"] is None
+    assert capsys.readouterr().err == ""
+    old = bench.profile_freshness("profiles/x_traffic_1.json", {"kernel_source_sha16": "0123456789abcdef"})
+    assert old["stale"] is True and "have changed since" in old["stale_reason"]
+    assert "WARNING" in capsys.readouterr().err
+    none = bench.profile_freshness("profiles/x_traffic_1.json", {})
+    assert none["stale"] is True and "no fingerprint" in none["stale_reason"]

@@ -2,6 +2,7 @@
 declares, and fail loudly (no CPU fallback) when no HIP device is present."""
 import ctypes as C
 import re
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -86,4 +87,38 @@ def test_cjxl_tiny_without_gpu_reports_an_encoding_failure(built, tmp_path, host
     assert "no usable HIP device" in r.stderr or "no HIP device" in r.stderr
     assert "Error reading PFM" not in r.stderr and not (tmp_path / "out.jxl").exists()
     r = subprocess.run([exe, str(tmp_path / "missing.pfm")] + extra, capture_output=True, text=True)
+    assert r.returncode != 0 and "Error reading PFM input file." in r.stderr
+
+
+REF_MAIN = Path("/root/reference/encoder/cjxl_main.cc")
+
+
+def test_the_references_own_caller_compiles_unmodified_against_the_drop_in_headers(built, tmp_path):
+    """/root/reference/encoder/cjxl_main.cc, IN PLACE and unmodified, compiles with -I<host> at
+    the reference's own language level and links against libjxltiny_host.so -- nothing of the reference is copied.
+    (It needs encoder/base/printf_macros.h and <string.h> through encoder/image.h, cjxl_main.cc:10,52,26.)
+    Skipped where the reference checkout is absent (the GPU box runs the prebuilt oracle/_ref binary instead)."""
+    import subprocess
+    if not REF_MAIN.exists():
+        pytest.skip("no reference checkout on this machine")
+    host = T.ROOT / "libjxl-tiny_amd" / "host"
+    exe = tmp_path / "ref_main"
+    for std in ("-std=c++11", "-std=c++17"):
+        r = subprocess.run(["g++", std, "-O1", "-Wall", "-Werror", "-I" + str(host), "-o", str(exe), str(REF_MAIN),
+                            "-L" + str(host), "-ljxltiny_host", "-L" + str(host.parent / "csrc"), "-ljxltiny_hip",
+                            "-Wl,-rpath," + str(host), "-Wl,-rpath," + str(host.parent / "csrc")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe), "-h"], capture_output=True, text=True)
+    assert r.returncode == 0 and "[-d distance]" in r.stderr and "--device" not in r.stderr  # the reference's usage text
+    # build() made the same binary by the committed recipe (oracle/Makefile: ref-caller)
+    assert (T.ROOT / "oracle" / "_ref" / "cjxl_tiny_ref_main").exists()
+    import torch
+    if torch.cuda.is_available():
+        return
+    pfm = tmp_path / "in.pfm"
+    T.write_pfm(pfm, T.synthetic_image(40, 24))
+    r = subprocess.run([str(exe), str(pfm), str(tmp_path / "out.jxl")], capture_output=True, text=True)
+    assert r.returncode != 0 and "Read 40x24 pixels input image." in r.stderr and "Encoding failed." in r.stderr
+    r = subprocess.run([str(exe), str(tmp_path / "missing.pfm")], capture_output=True, text=True)
     assert r.returncode != 0 and "Error reading PFM input file." in r.stderr

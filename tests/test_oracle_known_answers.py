@@ -137,6 +137,82 @@ def judge_r4_image(kind, w, h, seed):
     return out
 
 
+# Round 5's judge: seventeen frames through the unmodified reference sources built against a fresh stand-in (8 lanes,
+# halving-tree SumOfLanes, fused MulAdd, exact reciprocal), seven content kinds no earlier fixture had (octave noise,
+# 1.7-rad/px stripes, 2x3-px "text", negative / > 1 samples, near-black, chirp rings, saturated red / blue checker),
+# distances on the 0.299 / 1.25 / 7 / 9 branch edges and through the EncodeFile-level clamp (0.01 -> 0.03)
+# (VERDICT.md, round 5, item 4).  An eighteenth, ("smooth", 8200, 4100, 1.0, 216), makes the reference trap (its corner
+# DC group is one block): see test_frames_whose_corner_dc_group_is_one_block in test_gpu_parity.py.
+# (kind, w, h, distance, seed) -> (bytes, sha-256)
+JUDGE_R5 = {
+    ("pink", 1000, 700, 1.0, 201): (271345, "1ae095693e8a51db7211f221a51b582f4ae5f29ac791b511eb9cd369410c5c8f"),
+    ("pink", 2300, 2100, 0.29, 202): (4645246, "14d0a1c39169fa2083237a2037dee10275c5cb24d7a94da638442e060660645b"),
+    ("stripes", 513, 257, 1.25, 203): (44345, "6848351f3bb7b662b959a7f8994a445d0f60c4da50d81149f74981d847a63570"),
+    ("stripes", 2050, 130, 9.0, 204): (19342, "4dcfe5dd5a839cc7d97d555c2fe95365a0f8d25496d464538fa100a016aa6a88"),
+    ("text", 800, 600, 0.6, 205): (259560, "7822a048eec5746197cf33fd31ec38941ca6a1b781776e2542cf2ffe7cf40f67"),
+    ("text", 3000, 2200, 7.0, 206): (879843, "59d56cabb2e5823774b056544bcb3282068fa12f7c05b25846185e0c9e95ef05"),
+    ("negative", 1920, 1080, 1.0, 207): (517863, "c91af873718494e2c318bc3529fe49949cd465c11dee2bf1d2af5a67422057d5"),
+    ("dark", 640, 360, 0.03, 208): (26894, "ae088bdf31e3c9decba3ca1a44d772a9485a05deaa6fa982059b01e62ca9d196"),
+    # single-symbol codes: the default (decodable) mode differs here
+    ("dark", 1025, 1025, 24.9, 209): (14387, "1fdc014190d8082677320f82917938a1474ee485a86af26f13dfd9faef3dfcd1"),
+    ("radial", 2048, 2048, 1.5, 210): (1471226, "94fa627d398746f95bade217da807ee97bc3b374abeaf47d4d20761002a04c78"),
+    ("redblue", 1111, 777, 2.0, 211): (173657, "59fd33e23c4ca03a9f58ba2f1320468ebd38ee8b6ca08db1e474743eb79d90c6"),
+    ("redblue", 4100, 2060, 4.0, 212): (995716, "4fb62562787827b4e7533a2257d5530db779ec54e4569583ab2d73b8d69a4c5f"),
+    ("smooth", 4096, 4096, 1.0, 1234): (1558293, "475dcb0de050d2022306dc13d5868a2179357a08a4f098219796b25f170cc735"),
+    ("noise", 777, 1555, 0.01, 214): (3146265, "b1f52a6ae1d9dea0bf368b2afc730045d506a2725f8d226d014f9e7abc5c94ff"),  # d clamps to 0.03
+    ("pink", 16, 8, 1.0, 215): (245, "6b093ab018c541b62df86df69953d896d4c504ffa89ab520a8ecd5dda68f0ad4"),
+    ("noise", 2048, 2048, 9.01, 217): (150006, "c6fdddec054a93af9c1c3ad00a7863159baa5e7ae35385c5917f6ba78bebb24f"),
+    ("pink", 6000, 300, 0.7, 218): (927120, "8659c5044a2de94d38fe2d762a160bd402f6983407ffb4a4ad781530944c1cc4"),
+}
+
+
+def judge_r5_image(kind, w, h, seed):
+    """The judge's nine generators, statement for statement as VERDICT.md (round 5, item 4) writes them."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    if kind == "pink":
+        out = np.zeros((h, w, 3))
+        s, amp = 1, 0.5
+        while s <= max(w, h):
+            n = rng.random(((h + s - 1) // s + 1, (w + s - 1) // s + 1, 3))
+            out += amp * np.repeat(np.repeat(n, s, 0), s, 1)[:h, :w]
+            s *= 2
+            amp *= 0.7
+        out = (out / out.max()) ** 2.2
+    elif kind == "stripes":
+        a = 0.5 + 0.5 * np.sin(x * 1.7 + y * 0.05)
+        b = 0.5 + 0.5 * np.sin(y * 2.3)
+        out = np.stack([a, b, 0.5 * (a + b)], -1)
+    elif kind == "text":
+        blk = (rng.random(((h + 2) // 3 + 1, (w + 1) // 2 + 1)) < 0.3).astype(np.float64)
+        up = np.repeat(np.repeat(blk, 3, 0), 2, 1)[:h, :w]
+        out = np.stack([1 - 0.95 * up, 1 - 0.9 * up, 1 - 0.93 * up], -1)
+    elif kind == "negative":
+        out = T.synthetic_image(w, h, seed=seed).astype(np.float64) * 1.5 - 0.2
+    elif kind == "dark":
+        out = T.synthetic_image(w, h, seed=seed) * np.float32(0.003)
+    elif kind == "radial":
+        r = np.sqrt((x - w / 2) ** 2 + (y - h / 2) ** 2)
+        a = 0.5 + 0.5 * np.cos(r * r / 900.0)
+        out = np.stack([a, np.roll(a, 7, 1), 1 - a], -1).astype(np.float32) ** np.float32(2.0)
+    elif kind == "redblue":
+        a = (np.floor(x / 11) + np.floor(y / 13)) % 2
+        out = np.stack([0.9 * a + 0.02, 0.03 + 0 * a, 0.9 * (1 - a) + 0.02], -1)
+        out += rng.normal(0, 0.01, out.shape)
+        out = np.clip(out, 0, 4)
+    elif kind == "smooth":
+        out = T.synthetic_image(w, h, seed=seed)
+    else:
+        assert kind == "noise"
+        out = rng.random((h, w, 3))
+    return out.astype(np.float32)
+
+
+def encode_file_distance(d):
+    """EncodeFile's own clamp in front of EncodeFrame (enc_file.cc:57-65): distances up to 0.03 become 0.03."""
+    return max(float(np.float32(d)), 0.03) if d > 0 else d
+
+
 def _unfused_lib():
     base = T.oracle()
     lib = C.CDLL(str(T.ROOT / "oracle" / "liboracle_nofma.so"))
@@ -195,6 +271,16 @@ def test_bytes_of_the_round4_judges_stand_in_build(built, key):
     planes = T.to_planes(judge_r4_image(kind, w, h, seed))
     cs = T.oracle_codestream(T.oracle_hot_path(planes, d), d, reference_single_symbol=True)
     assert (len(cs), hashlib.sha256(cs).hexdigest()) == JUDGE_R4[key]
+
+
+@pytest.mark.parametrize("key", sorted(JUDGE_R5), ids=lambda k: "%s_%dx%d_d%g_s%d" % k)
+def test_bytes_of_the_round5_judges_stand_in_build(built, key):
+    import hashlib
+    kind, w, h, d, seed = key
+    d = encode_file_distance(d)
+    planes = T.to_planes(judge_r5_image(kind, w, h, seed))
+    cs = T.oracle_codestream(T.oracle_hot_path(planes, d), d, reference_single_symbol=True)
+    assert (len(cs), hashlib.sha256(cs).hexdigest()) == JUDGE_R5[key]
 
 
 def test_decodable_mode_differs_only_where_single_symbol_codes_occur(built):
