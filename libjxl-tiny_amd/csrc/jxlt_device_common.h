@@ -240,6 +240,30 @@ typedef __attribute__((address_space(1))) const uint32_t* JxltGlobalConstWords;
 #define JXLT_COMPILER_FENCE() asm volatile("" ::: "memory")
 #endif
 
+// A 16-byte LDS load that is ISSUED WHERE IT STANDS, and the wait that goes with it.  Software pipelining of a loop
+// ("request the next round's operands, work on this round's") does not survive the compiler: loads whose values are
+// first used in another basic block are sunk to that use, and every round waits for its own operands (round 6: the
+// chroma-from-luma chains ran that way; `volatile` is no way out -- on this target it turns the load into a flat,
+// system-coherent one with a full wait behind it).  So the load is an assembly statement, and because the compiler
+// does not count what assembly has in flight, so is its wait: JXLT_LDS_WAIT4(n, a, b, c, d) = "all but my n newest
+// LDS operations have returned" (they return in order) and ties the four registers to that point -- as inputs, so
+// that they stay allocated until the data is there, and as outputs, so that no use is moved in front of it.
+// `p`: a pointer into LDS, `byte_off`: a compile-time constant.  The CPU execution model loads plainly.
+#ifndef JXLT_LDS_LOAD4_NOW
+typedef float JxltFloat4 __attribute__((ext_vector_type(4)));
+#define JXLT_LDS_LOAD4_NOW(dst, p, byte_off)                                                                   \
+  asm volatile("ds_read_b128 %0, %1 offset:%2"                                                                 \
+               : "=v"(dst)                                                                                     \
+               : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(p)), "n"(byte_off))
+// (the 32-bit LDS address of a pointer into LDS, for address arithmetic in integers)
+#define JXLT_LDS_ADDRESS(p) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(p))
+#define JXLT_LDS_LOAD4_NOW_AT(dst, addr, byte_off) \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(byte_off))
+#define JXLT_LDS_WAIT4(n, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+// (for registers whose contents are NOT used afterwards: they only have to stay allocated until the data is there)
+#define JXLT_LDS_DRAIN4(a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(a), "v"(b), "v"(c), "v"(d))
+#endif
+
 // The wave's global stores so far are written (acknowledged by L2) -- for bytes that another wave of the workgroup
 // overwrites behind a barrier: __syncthreads() alone orders the workgroup's LDS traffic, it does not wait for
 // outstanding vector stores.

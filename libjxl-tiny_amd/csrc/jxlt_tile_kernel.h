@@ -725,27 +725,30 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     // Every octet publishes the terms of its block, a = m/84 and b = base*m - s with
     // m = Y*qm, s = C*qm (:49-53,117-120); then four sequential per-lane fma chains
     // (ca = sum a*a, cb = sum a*b, for X and for B) run over the blocks in raster order.
-    // Term layout: [block][lane l][chunk], a chunk = (a, b) of two consecutive rows of one
-    // chroma channel (chunk = channel * 4 + row / 2), i.e. the eight rows a chain lane needs
-    // from a block are four 16-byte reads.  The chunk slot is XORed with l so that the eight
-    // lanes of an octet hit different banks.
+    // Term layout (round 6): [block][q][lane l][channel X, B][4 floats], q = 0: a of rows 0-3, 1: a of rows 4-7,
+    // 2: b of rows 0-3, 3: b of rows 4-7 -- a chain lane reads FIRST factors (always a) from q = 0, 1 and SECOND
+    // factors from q = 0, 1 (the sums of a * a: wave 0) or q = 2, 3 (the sums of a * b: wave 1): the two chain waves
+    // run the same instructions on two base addresses, no selects.  The sixteen chain lanes of a 16-lane row
+    // (channel, l) read l * 8 + channel * 4 + {0..3} + a multiple of 64: all 64 banks once, and q is an immediate
+    // offset -- no swizzle, one address per factor.  (Rounds 2-5: chunks of (a, b) pairs of two rows, XOR-swizzled;
+    // the second factor was selected in place, eight v_cndmask per round of four blocks on the chain waves.)
     float* terms = &S.x[0];
-    // (swizzle key: l for lanes 0-3, l ^ 1 for lanes 4-7 -- a 16-byte LDS load is serviced in 16-lane
-    // groups that pair lanes 0-3 of the X chain with lanes 4-7 of the B chain, MI355X_MICROARCH.md;
-    // with the plain key those read the same banks)
-    const int lsw = l ^ (l >> 2);
     const float* qm_x = S.inv_w + 0;    // InvMatrix(DCT, 0)
     const float* qm_b = S.inv_w + 128;  // InvMatrix(DCT, 2)
     const int nblk = nbx * nby;
+    // The chains run in ROUNDS of four blocks (below): a tile at the frame's edge whose block count is not a multiple
+    // of four gets up to three blocks of zero terms -- fma(0, 0, acc) leaves an accumulator as it is (it is never -0:
+    // it starts at +0 and x + y is -0 only for two -0).
+    const int nblk_pad = (nblk + 3) & ~3;
     const float kInvColorFactor = 1.0f / 84;
     // (the terms of raster block `rb` of the tile from the lane's rows of its DCT8 coefficients)
     auto publish = [&](int rb, const float* vx, const float* vy, const float* vb) {
-      float* dst = &terms[rb * 256 + l * 32];
+      float* dst = &terms[rb * 256 + l * 8];
 #pragma unroll
-      for (int r = 0; r < 8; r += 2) {
-        float4 tx, tb;
+      for (int r = 0; r < 8; r += 4) {
+        float4 ax4, bx4, ab4, bb4;
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < 4; h++) {
           const int rr = r + h;
           const bool dc = (rr == 0 && l == 0);  // block_*[0] = 0 (:109-111)
           const float by_ = dc ? 0.0f : vy[rr], bx_ = dc ? 0.0f : vx[rr], bb_ = dc ? 0.0f : vb[rr];
@@ -753,16 +756,24 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
           const float m_x = by_ * qx, s_x = bx_ * qx, m_b = by_ * qb, s_b = bb_ * qb;
           const float ax = kInvColorFactor * m_x, bx2 = 0.0f * m_x - s_x;
           const float ab = kInvColorFactor * m_b, bb2 = 1.0f * m_b - s_b;
-          if (h == 0) { tx.x = ax; tx.y = bx2; tb.x = ab; tb.y = bb2; }
-          else { tx.z = ax; tx.w = bx2; tb.z = ab; tb.w = bb2; }
+          (&ax4.x)[h] = ax;
+          (&bx4.x)[h] = bx2;
+          (&ab4.x)[h] = ab;
+          (&bb4.x)[h] = bb2;
         }
-        *(float4*)&dst[(((r >> 1)) ^ lsw) * 4] = tx;
-        *(float4*)&dst[((4 + (r >> 1)) ^ lsw) * 4] = tb;
+        const int half = r >> 2;
+        *(float4*)&dst[(0 + half) * 64] = ax4;
+        *(float4*)&dst[(2 + half) * 64] = bx4;
+        *(float4*)&dst[(0 + half) * 64 + 4] = ab4;
+        *(float4*)&dst[(2 + half) * 64 + 4] = bb4;
       }
     };
     {
       if (pair_valid0) publish(pby0 * nbx + pbx, c8x, c8y, c8b);
       if (pair_valid1) publish((pby0 + 1) * nbx + pbx, d8x, d8y, d8b);
+      if (nblk_pad != nblk) {  // (wave-uniform; tiles at the frame's edge only)
+        if (tid < (nblk_pad - nblk) * 256) terms[nblk * 256 + tid] = 0.0f;
+      }
     }
     __syncthreads();
     // Chain lanes: wave 0 lanes 0-15 run ca (X: 0-7, B: 8-15), wave 1 lanes 0-15 run cb.
@@ -774,12 +785,14 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     const int cw = __builtin_amdgcn_readfirstlane(tid >> 6), cl = tid & 63;
     // 12 waves: the waves that wait for the chains fetch the root table meanwhile (two entries per thread); it goes
     // to LDS behind the chains, where the chain waves' parked coefficients were.
-    float late_root0 = 0.0f, late_root1 = 0.0f;
+    // (round 6: NOT initialised -- the chain waves would carry six zeros through their loop, the kernel's register peak;
+    // they "define" them behind it, JXLT_DEFINE_VGPR, and never store them)
+    float late_root0, late_root1;
     // ... and what the scan-order quantisation (P8b) needs per lane: its constants per scan position, the staging slots
     // and the inverse quantiser steps -- 1648 words that every wave would otherwise fetch from global memory, 25 loads
     // per thread, at the start of that phase, with nothing to do meanwhile
-    uint32_t late_p8[3] = {0u, 0u, 0u};
-    float late_zeros_cost = 0.0f;
+    uint32_t late_p8[3];
+    float late_zeros_cost;
     {
       if (cw >= 2) {
         late_zeros_cost = T->zeros_cost[imin(tid - 128, kZerosCostEntries - 1)];
@@ -801,6 +814,11 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     // v_permlane32_swap per block (tools/permlane_probe.hip).  With ping-pong buffers in sixteen lanes the terms
     // of block blk + 1 were requested only eight dependent multiply-adds before their use: less than an LDS round
     // trip, and the chains are the workgroup's critical path.
+    // A lone wave issues an instruction every ~5 cycles whatever it is (tools/valu_issue_probe.hip), so
+    // what the chain waves issue BESIDE the 512 dependent multiply-adds is what the phase costs (round 5: ~16
+    // instructions per block).  Round 6: no select of the second factor (term layout above), no test per block (whole
+    // rounds, zero terms behind the tile's last block), and the accumulators hop between TWO registers -- a swap
+    // exchanges rows of two registers, so the row that receives them is the other register's: no copy per hop.
     const int relay_row = cl >> 4;
     const int relay_pos = relay_row == 0 ? 0 : relay_row == 1 ? 1 : relay_row == 3 ? 2 : 3;  // place in the relay
     if (cw < 2) {
@@ -821,60 +839,80 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
         chain_park(24) = c16y[15];
       }
       const int ch = (cl >> 3) & 1;  // 0: X, 1: B
-      const float* src = terms + l * 32;
-      int slot[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) slot[q] = ((ch * 4 + q) ^ lsw) * 4;
-      const int last = nblk - 1;
+      const float* const first_factors = terms + l * 8 + ch * 4;
+      const float* const second_factors = first_factors + cw * 128;  // (a again, or b)
+      const int last = nblk_pad - 1;
       // Two register sets, used in turn by ROUNDS of four blocks (one per row): at the start of a round every row
       // requests the block it will handle in the NEXT round -- one wave-wide set of four 16-byte loads, a whole
       // round (32 dependent multiply-adds and four hops) ahead of its use.
-      float4 ta[4], tb[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) ta[q] = *(const float4*)&src[imin(relay_pos, last) * 256 + slot[q]];
-      auto round4 = [&](float4* t, int first) {
-        {
-          // (the second factor of every product -- a for the sums of a * a, b for the sums of a * b --
-          // is selected IN PLACE once per term set, instead of into eight more registers)
-          if (first < nblk) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              t[q].y = cw == 0 ? t[q].x : t[q].y;
-              t[q].w = cw == 0 ? t[q].z : t[q].w;
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          if (first + j >= nblk) break;  // (wave-uniform)
-          // every lane runs the eight steps; only the row that holds the accumulators has meaningful ones
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            acc = fma32(t[q].x, t[q].y, acc);
-            acc = fma32(t[q].z, t[q].w, acc);
-          }
-          // the accumulators move on: rows 0 -> 1 and 3 -> 2 with a 16-lane swap, 1 -> 3 and 2 -> 0 with a 32-lane one
-          const unsigned bits = __float_as_uint(acc);
-          if (j == 0) acc = __uint_as_float(__builtin_amdgcn_permlane16_swap(bits, bits, false, false)[0]);
-          if (j == 1) acc = __uint_as_float(__builtin_amdgcn_permlane32_swap(bits, bits, false, false)[0]);
-          if (j == 2) acc = __uint_as_float(__builtin_amdgcn_permlane16_swap(bits, bits, false, false)[1]);
-          if (j == 3) acc = __uint_as_float(__builtin_amdgcn_permlane32_swap(bits, bits, false, false)[1]);
-        }
+      JxltFloat4 ta[4], tb[4];  // [0], [1]: first factors of rows 0-3, 4-7; [2], [3]: second factors
+      // (issued HERE, a round ahead of their use: as plain loads the compiler sinks them to their first use behind the
+      // loop's exit test and every round waits for the LDS -- JXLT_LDS_LOAD4_NOW, jxlt_device_common.h)
+      // (addresses in integers, from bases the compiler cannot look through: a minimum, and one shift-and-add per
+      // factor -- it made six instructions of the pointer form)
+      auto f1_base = JXLT_LDS_ADDRESS(first_factors), f2_base = JXLT_LDS_ADDRESS(second_factors);
+      JXLT_LAUNDER_VGPR(f1_base);
+      JXLT_LAUNDER_VGPR(f2_base);
+      auto request = [&](JxltFloat4* t, int first) {
+        const int blk_of_row = imin(first + relay_pos, last);
+        const auto a1 = f1_base + (decltype(f1_base))(blk_of_row << 10), a2 = f2_base + (decltype(f1_base))(blk_of_row << 10);
+        JXLT_LDS_LOAD4_NOW_AT(t[0], a1, 0);
+        JXLT_LDS_LOAD4_NOW_AT(t[2], a2, 0);
+        JXLT_LDS_LOAD4_NOW_AT(t[1], a1, 256);
+        JXLT_LDS_LOAD4_NOW_AT(t[3], a2, 256);
       };
-      auto chain_loop = [&]() {
+      float acc2 = 0.0f;  // (the accumulators' other register)
+      // every lane runs the eight steps; only the row that holds the accumulators has meaningful ones
+      auto block_steps = [&](float& a, const JxltFloat4* t) {
+        a = fma32(t[0].x, t[2].x, a);
+        a = fma32(t[0].y, t[2].y, a);
+        a = fma32(t[0].z, t[2].z, a);
+        a = fma32(t[0].w, t[2].w, a);
+        a = fma32(t[1].x, t[3].x, a);
+        a = fma32(t[1].y, t[3].y, a);
+        a = fma32(t[1].z, t[3].z, a);
+        a = fma32(t[1].w, t[3].w, a);
+      };
+      // (a swap trades the odd rows / the upper half of its first operand for the even rows / the lower half of its
+      // second one; both results are kept, so the instruction works in place)
+      auto hop16 = [&](float& vdst, float& src0) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(vdst), __float_as_uint(src0), false, false);
+        vdst = __uint_as_float(r[0]);
+        src0 = __uint_as_float(r[1]);
+      };
+      auto hop32 = [&](float& vdst, float& src0) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(vdst), __float_as_uint(src0), false, false);
+        vdst = __uint_as_float(r[0]);
+        src0 = __uint_as_float(r[1]);
+      };
+      // one round: the set `t` has arrived when all but the four loads of the OTHER set, requested behind it, have
+      auto round4 = [&](JxltFloat4* t) {
+        JXLT_LDS_WAIT4(4, t[0], t[1], t[2], t[3]);
+        block_steps(acc, t);   // row 0
+        hop16(acc2, acc);      // acc row 0 -> acc2 row 1
+        block_steps(acc2, t);  // row 1
+        hop32(acc, acc2);      // acc2 row 1 -> acc row 3
+        block_steps(acc, t);   // row 3
+        hop16(acc, acc2);      // acc row 3 -> acc2 row 2
+        block_steps(acc2, t);  // row 2
+        hop32(acc2, acc);      // acc2 row 2 -> acc row 0
+      };
+      request(ta, 0);
 #pragma clang loop unroll(disable)
-        for (int blk = 0; blk < nblk; blk += 8) {
+      for (int blk = 0; blk < nblk_pad; blk += 8) {
+        request(tb, blk + 4);
+        round4(ta);
+        request(ta, blk + 8);
+        if (blk + 4 < nblk_pad) round4(tb);  // (wave-uniform: an odd number of rounds ends here)
+      }
+      // (whatever was requested last is not used; it has arrived before its registers serve anything else)
+      JXLT_LDS_DRAIN4(ta[0], ta[1], ta[2], ta[3]);
+      JXLT_LDS_DRAIN4(tb[0], tb[1], tb[2], tb[3]);
+      JXLT_DEFINE_VGPR(late_root0);
+      JXLT_DEFINE_VGPR(late_root1);
+      JXLT_DEFINE_VGPR(late_zeros_cost);
 #pragma unroll
-          for (int q = 0; q < 4; q++) tb[q] = *(const float4*)&src[imin(blk + 4 + relay_pos, last) * 256 + slot[q]];
-          round4(ta, blk);
-#pragma unroll
-          for (int q = 0; q < 4; q++) ta[q] = *(const float4*)&src[imin(blk + 8 + relay_pos, last) * 256 + slot[q]];
-          round4(tb, blk + 4);
-        }
-      };
-      // (two loops behind a scalar branch -- chain_loop(std::true_type{}) / (std::false_type{}) -- made the
-      // register allocator spill MORE in the 12-wave kernel)
-      chain_loop();
+      for (int j = 0; j < 3; j++) JXLT_DEFINE_VGPR(late_p8[j]);
       {
         JXLT_COMPILER_FENCE();
 #pragma unroll
@@ -885,7 +923,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       }
       __builtin_amdgcn_s_setprio(0);
     }
-    const int final_pos = nblk & 3;  // where the accumulators are after the last hop
+    const int final_pos = 0;  // (whole rounds: the accumulators end where they started, in row 0)
     const bool chain_lane = cw < 2 && relay_pos == final_pos;
     const int chain_ch = (cl >> 3) & 1;
     const float total = octet_sum(acc);

@@ -417,6 +417,12 @@ typedef const uint32_t* JxltGlobalConstWords;
 #define JXLT_SCALAR_STORE64(p, i, v) ((p)[i] = (v))
 #define JXLT_SCALAR_STORES_DONE() ((void)0)
 #define JXLT_COMPILER_FENCE() ((void)0)
+typedef float4 JxltFloat4;  // (see jxlt_device_common.h: issue order and waits have no meaning here)
+#define JXLT_LDS_LOAD4_NOW(dst, p, byte_off) ((dst) = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p) + (byte_off)))
+#define JXLT_LDS_ADDRESS(p) ((uintptr_t)(p))  // (no separate LDS address space here: the pointer itself)
+#define JXLT_LDS_LOAD4_NOW_AT(dst, addr, byte_off) ((dst) = *reinterpret_cast<const float4*>((addr) + (byte_off)))
+#define JXLT_LDS_WAIT4(n, a, b, c, d) ((void)0)
+#define JXLT_LDS_DRAIN4(a, b, c, d) ((void)0)
 #define JXLT_STORES_WRITTEN() ((void)0)
 
 // v_rcp_f32 (1 ulp on hardware; the model returns the correctly rounded reciprocal)

@@ -143,14 +143,22 @@ def test_error_behaviour(built, enc):
     assert hip.jxlt_histograms_ready(fresh._ctx) == 1
     at, dt = built.build_code_tables(ac, dc)
     assert hip.jxlt_pack_begin(fresh._ctx, 0, dt.ctypes.data) == 0
-    pageable = np.zeros(1 << 16, np.uint8)
-    assert hip.jxlt_pack_deliver(fresh._ctx, 0, pageable.ctypes.data, None, 0, 0) < 0   # a kernel cannot store there
-    assert b"page-locked" in hip.jxlt_last_error(fresh._ctx)
     run = (C.c_uint32 * 4)(0, 5, 0, 0)  # (first 0, five sections of a one-section frame)
     assert hip.jxlt_pack_deliver(fresh._ctx, 0, out, run, 1, 0) < 0    # a run beyond the sections
     assert hip.jxlt_pack_deliver(fresh._ctx, 0, out, run, 1, 1) < 0    # runs are not end-aligned
     assert hip.jxlt_pack_deliver(fresh._ctx, 0, out, None, 0, 0) == 0
     fresh.synchronize()
+    # The sections travel by copy commands since round 5, so ANY destination a copy command takes is accepted
+    # (until then a kernel stored the bytes and pageable memory was refused): ordinary host memory is the
+    # synchronous fallback and receives the same bytes as the context's page-locked buffer.
+    assert hip.jxlt_pack_sizes(fresh._ctx, 0, C.byref(sizes)) == 0
+    nbytes = int(sizes.section_offset[sizes.num_sections])
+    assert 0 < nbytes < (1 << 16)
+    pinned_bytes = C.string_at(out, nbytes)
+    pageable = np.full(1 << 16, 0xAB, np.uint8)
+    assert hip.jxlt_pack_deliver(fresh._ctx, 0, pageable.ctypes.data, None, 0, 0) == 0
+    fresh.synchronize()
+    assert pageable[:nbytes].tobytes() == pinned_bytes and (pageable[nbytes + 8:] == 0xAB).all()
     fresh.close()
 
 

@@ -4,6 +4,7 @@
 # 16384^2 launch, alternating, REPS times each (the pool's boxes differ by ~1 % in cycles: only runs on one box compare).
 ROOT="${GRAFT_REPO_ROOT:-$PWD}"
 OTHER="$ROOT/${1:-ab_prev}"
+mkdir -p "$OTHER/gpurun_out"
 SIZE=${SIZE:-16384}
 for rep in $(seq 1 ${REPS:-3}); do
   echo -n "this  "; GRAFT_REPO_ROOT="$ROOT" "$ROOT/tools/tile_cycles.sh" $SIZE | grep -E "tile12_kernel  "
