@@ -81,6 +81,13 @@ typedef struct {
 int jxlt_shard_encode_ops(jxlt_shard_group* group, const jxlt_slab_ops* ops, size_t xsize, size_t ysize,
                           float distance, const uint8_t** bytes, size_t* size);
 
+/* Host-side stage times of the caller's last frame on this group, milliseconds from the start of its
+ * jxlt_shard_encode* call: [0] device pipeline enqueued, [1] own DC histogram here, [2] own AC histogram here, [3] both
+ * code tables here (the sum over the participants + the code construction on participants 0 and 1 lie in front),
+ * [4] own section sizes here, [5] the layout here (participant 0: made), [6] own hand-over issued, [7] participant 0:
+ * every participant has placed its sections.  What tools/slab_of_8.py splits a rank's serial stage with. */
+int jxlt_shard_group_last_timeline(const jxlt_shard_group* group, double* ms8);
+
 /* jxlt_shard_pipeline_* over slab operations: lane l of the pipeline runs its frames through lane_ops[l]. */
 int jxlt_shard_pipeline_open_ops(const char* shm_name, int rank, int world, const jxlt_slab_ops* lane_ops, int depth,
                                  size_t output_capacity, size_t max_sections, jxlt_shard_pipeline** out);

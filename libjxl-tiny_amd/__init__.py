@@ -50,6 +50,7 @@ HOST_SYMBOLS = ["jxlt_compute_distance_params", "jxlt_assemble_frame",
                 "jxlt_shard_encode", "jxlt_shard_pipeline_open", "jxlt_shard_pipeline_close",
                 "jxlt_shard_pipeline_last_error", "jxlt_shard_pipeline_submit_device", "jxlt_shard_pipeline_wait"]
 HOST_SYMBOLS_TESTING = ["jxlt_debug_dc_records", "jxlt_assemble_frame_groups", "jxlt_build_code_tables", "jxlt_finish_frame",
+                        "jxlt_shard_group_last_timeline",
                         "jxlt_shard_encode_ops", "jxlt_shard_pipeline_open_ops",
                         "jxlt_shard_pipeline_submit_ops"]
 
@@ -806,6 +807,16 @@ class ShardGroup:
         if rc != 0:
             raise JxlTinyError("%s failed (%d): %s" % (what, rc, self._L.jxlt_shard_group_last_error(self._g).decode()))
         return NativeView(out, n.value) if out else None
+
+    STAGES = ("enqueued", "dc_histogram", "ac_histogram", "code_tables", "own_sizes", "layout", "hand_over_issued", "all_placed")
+
+    def last_timeline(self):
+        """Host-side stage times of this rank's last frame, ms from the call's start (testing header)."""
+        self._L.jxlt_shard_group_last_timeline.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        ms = (C.c_double * 8)()
+        if self._L.jxlt_shard_group_last_timeline(self._g, ms) != 0:
+            return None
+        return dict(zip(self.STAGES, [float(v) for v in ms]))
 
     def encode(self, enc, w, h, distance):
         """Collective: `enc` (an Encoder) holds this rank's slab; returns a NativeView of the whole codestream

@@ -11,6 +11,10 @@ namespace jxlt_dev {
 // ---------------------------------------------------------------------------
 // Tile kernel
 // ---------------------------------------------------------------------------
+// (probe builds of round 6, tools/ab_cycles.sh: parts of the scan-order quantisation left out -- WRONG results, timing only)
+#ifndef JXLT_ABL_P9
+#define JXLT_ABL_P9 0
+#endif
 
 // Twelve waves per tile (768 threads).  Octets 0-31 hold the DCT8 coefficients of TWO blocks each, octets 32-95 one
 // two-block candidate each (the 8-wave kernel of rounds 1-2, removed in round 4, kept a block AND a candidate per
@@ -417,7 +421,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     // workgroup takes the issue slots the idle waves leave.  The 4-column groups that lie entirely in the vector
     // loop's range on a path of their own -- no second association order, no selects, 15-16 of a tile's 17-18 groups --
     // was built in round 4 and lost: 3860 against 3886 VALU per wave, 9.41 against 9.33 M cycles)
-    for (int i = tid; i < nbands * aq_w; i += kThreads) {
+    for (int i = tid; i < ((JXLT_ABL_P9 & 128) ? 0 : nbands * aq_w); i += kThreads) {
       const int q = i / aq_w, x = aq_x0 + i % aq_w;
       band_column(q, x, (i & 3) == 0);
     }
@@ -541,7 +545,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     const float kBlueRampLength = (float)0.086890611400405895;
     const float kBlueRampStart = (float)0.26973418507870539;
     const int right_step = l < 7 ? 1 : 0;
-    if (blk_valid) {
+    if (blk_valid && !(JXLT_ABL_P9 & 256)) {
 #pragma unroll
       for (int dy = 0; dy < 8; dy++) {
         const int yy = byp + dy, xx = bxp + l;
@@ -680,7 +684,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     } else {
       leave_undefined(8, 16);
     }
-  } else if (cell_valid) {
+  } else if (cell_valid && !(JXLT_ABL_P9 & 512)) {
     const float* pxp = &S.x[(cby * 8) * kXYPitch + cbx * 8 + kHalo];
     const float* pyp = &S.y[(cby * 8) * kXYPitch + cbx * 8 + kHalo];
     const float* pbp = &S.b[(cby * 8) * kBPitch + cbx * 8];
@@ -899,7 +903,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       };
       request(ta, 0);
 #pragma clang loop unroll(disable)
-      for (int blk = 0; blk < nblk_pad; blk += 8) {
+      for (int blk = 0; blk < ((JXLT_ABL_P9 & 32) ? 0 : nblk_pad); blk += 8) {
         request(tb, blk + 4);
         round4(ta);
         request(ta, blk + 8);
@@ -990,12 +994,12 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
 #pragma unroll
       for (int r = 0; r < 16; r++) park[r * kThreads] = c16b[r];
       JXLT_SCHED_FENCE();
-      if (pair_valid0) estimate8(pbx, pby0, c8x, c8y, park);
+      if (pair_valid0 && !(JXLT_ABL_P9 & 64)) estimate8(pbx, pby0, c8x, c8y, park);
       JXLT_SCHED_FENCE();
-      if (pair_valid1) estimate8(pbx, pby0 + 1, d8x, d8y, park + 8 * kThreads);
+      if (pair_valid1 && !(JXLT_ABL_P9 & 64)) estimate8(pbx, pby0 + 1, d8x, d8y, park + 8 * kThreads);
     }
     JXLT_SCHED_FENCE();
-    if (cell_valid) {
+    if (cell_valid && !(JXLT_ABL_P9 & 64)) {
       const int o2 = is_tall ? 8 : 1;  // second covered block in the 8x8 tile grid
       const int bi = cby * 8 + cbx;
       const float quant = fmaxf(fmaxf(0.0f, S.aq[bi]), S.aq[bi + o2]);
@@ -1308,8 +1312,8 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       int nscan[3];
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        const int nzeros = __popcll(m0[c]) + __popcll(m1[c]);
-        nscan[c] = m1[c] != 0 ? 128 - __clzll((long long)m1[c]) : m0[c] != 0 ? 64 - __clzll((long long)m0[c]) : 0;
+        const int nzeros = (JXLT_ABL_P9 & 16) ? 3 : __popcll(m0[c]) + __popcll(m1[c]);
+        nscan[c] = (JXLT_ABL_P9 & 16) ? 40 : m1[c] != 0 ? 128 - __clzll((long long)m1[c]) : m0[c] != 0 ? 64 - __clzll((long long)m0[c]) : 0;
         nz_packed |= nzeros << (8 * c);
         nscan_packed |= nscan[c] << (8 * c);
         wave_tokens += 1 + (nscan[c] > covered ? nscan[c] - covered : 0);
@@ -1331,6 +1335,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
         JXLT_LAUNDER_SGPR(masks);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
+          if (JXLT_ABL_P9 & 2) continue;
           JXLT_SCALAR_STORE64(masks, 2 * c, m0[c]);
           JXLT_SCALAR_STORE64(masks, 2 * c + 1, m1[c]);
         }
@@ -1344,8 +1349,8 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
         const uint32_t slot = (uint32_t)lane * 2u;
 #pragma unroll
         for (int c = 0; c < 3; c++)
-          if (lane < nscan[c]) *(JxltGlobalShorts)(out0 + (c * 128 + slot)) = (int16_t)(int)quant[0][c];
-        if (two) {
+          if (!(JXLT_ABL_P9 & 1) && lane < nscan[c]) *(JxltGlobalShorts)(out0 + (c * 128 + slot)) = (int16_t)(int)quant[0][c];
+        if (two && !(JXLT_ABL_P9 & 1)) {
           JxltGlobalBytes out1 = (JxltGlobalBytes)(A.coef_scan + (size_t)pos1 * 192);
           JXLT_LAUNDER_SGPR(out1);
 #pragma unroll
@@ -1357,12 +1362,13 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       file_int(2, t, nscan_packed);
       ntrans++;
     };
+    if (JXLT_ABL_P9 & 8) next_b = -1;  // (no transform at all)
     while (next_b >= 0) {
       one_transform(set_a, set_b);
       if (next_b < 0) break;
       one_transform(set_b, set_a);
     }
-    JXLT_SCALAR_STORES_DONE();  // (the masks above: out of the scalar data cache)
+    if (!(JXLT_ABL_P9 & 2)) JXLT_SCALAR_STORES_DONE();  // (the masks above: out of the scalar data cache)
     if (lane == 0 && wave_tokens) atomicAdd(&S.ntok, wave_tokens);
     if (kLutRoots) {
       if (__ballot(!(q_largest < 32768.0f)) != 0 && lane == 0) S.overflow = 1u;  // (suspect: see q_largest)
@@ -1376,7 +1382,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
   // this part runs with the other waves idle and the workgroup's LDS held, so its LENGTH counts, not its instruction
   // count -- as one wave doing the three channels in turn (until round 5) the kernel took 1 % longer; with the token
   // count of the tile added to it, 2 % more.
-  if (tid < 192) {
+  if (tid < 192 && !(JXLT_ABL_P9 & 8)) {
     const int lane = tid & 63;
     const int c = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave's channel
     float* const dc_stage = stagef + 64 * kStageStrideF;

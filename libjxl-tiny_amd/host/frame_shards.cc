@@ -95,6 +95,10 @@ struct jxlt_shard_group {
     if (error.empty() || ctl == nullptr || ctl->failed.load() == 0) error = what;
   }
   uint64_t frame[jxlt::kMaxWorld] = {};  // frames begun, per participant of this process
+  // Host-side stage times of the last frame of the participant this handle belongs to (rank >= 0; an in-process
+  // group keeps participant 0's), milliseconds from the call's start: device pipeline enqueued; DC histogram here; AC
+  // histogram here; both code tables here; own section sizes here; layout here; section hand-over issued; all placed.
+  double timeline_ms[8] = {};
   uint32_t* sec_bits() const { return reinterpret_cast<uint32_t*>(base + jxlt::ControlBytes()); }
   uint32_t* sec_bytes() const { return sec_bits() + ctl->max_sections; }
   uint64_t* sec_off() const { return reinterpret_cast<uint64_t*>(sec_bits() + 2 * ((ctl->max_sections + 1) & ~uint64_t(1))); }
@@ -310,6 +314,11 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
   if (ndc_frame + ngroups_frame == 2)
     return Fail(g, JXLT_ERR_UNSUPPORTED, "single-group frames are not sharded");
 
+  const auto t_start = std::chrono::steady_clock::now();
+  const bool keeps_timeline = g->rank >= 0 || rank == 0;
+  const auto stamp = [&](int i) {
+    if (keeps_timeline) g->timeline_ms[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+  };
   const DistanceParams distp = ComputeDistanceParams(distance);
   jxlt_params params;
   params.distance = distp.distance;
@@ -323,6 +332,7 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
   if (!empty && (rc = (call)) != JXLT_OK) return Fail(g, rc, what)
 
   SLAB(ops->enqueue(ops->self, &params), "device pipeline failed");
+  stamp(0);
   // participants 0 and 1 build the codes: their helper threads (entropy_coder.h) stop sleeping now and spin
   // for the histograms -- a wake-up would cost as much as half of a code construction
   // (only when this thread's last code construction did share its work with them: most histograms are clustered
@@ -339,10 +349,12 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
   SLAB(ops->dc_histogram(ops->self, &h), "DC histogram fetch failed");
   if (empty) memset(c->hist[rank][1], 0, sizeof(c->hist[rank][1]));
   else memcpy(c->hist[rank][1], h, sizeof(c->hist[rank][1]));
+  stamp(1);
   Arrive(c, kDcHist);
   SLAB(ops->ac_histogram(ops->self, &h), "AC histogram fetch failed");
   if (empty) memset(c->hist[rank][0], 0, sizeof(c->hist[rank][0]));
   else memcpy(c->hist[rank][0], h, sizeof(c->hist[rank][0]));
+  stamp(2);
   Arrive(c, kAcHist);
   const int ac_builder = world > 1 ? 1 : 0;
   EntropyCode dc_code, ac_code;
@@ -381,6 +393,7 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
   if ((rc = WaitAtLeast(g, &c->published[kDcTable], frame)) != JXLT_OK) return rc;
   SLAB(ops->begin_dc_pack(ops->self, c->dc_table), "DC section measuring failed");
   if ((rc = WaitAtLeast(g, &c->published[kAcTable], frame)) != JXLT_OK) return rc;
+  stamp(3);
   if (rank == 0) globals.ac_global.assign(c->ac_global, c->ac_global + c->ac_global_size);
 
   // ---- exact section sizes of every slab -> layout of the one output buffer
@@ -400,6 +413,7 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
       sizes[ndc_frame + ac_frame_index(i)] = static_cast<uint32_t>(acm.section_offset[i + 1] - acm.section_offset[i]);
     }
   }
+  stamp(4);
   Arrive(c, kSizes);
   std::vector<uint64_t> dc_off, ac_off;
   std::vector<uint8_t> file_header;
@@ -433,6 +447,7 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
     return rc;
   }
 
+  stamp(5);
   // ---- every participant's device writes its sections in place: a run of the codestream per row of the slab's
   // DC groups / groups (rows that follow each other in the frame's order -- a slab as wide as the frame -- are one run)
   uint8_t* out = g->output();
@@ -458,6 +473,7 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
     runs_of(sw_ac, sh_ac, ac_first, xgroups, c->ac_begin, off + ndc_frame, &ac_runs);
   }
   SLAB(ops->write(ops->self, out, dc_runs.data(), dc_runs.size(), ac_runs.data(), ac_runs.size()), "section placement failed");
+  stamp(6);
   size_t frame_begin = 0;
   if (rank == 0) {
     const PackedSections dc = {nullptr, dc_off.data(), g->sec_bits(), ndc_frame};
@@ -477,6 +493,7 @@ int EncodeShard(jxlt_shard_group* g, int rank, const jxlt_slab_ops* ops, size_t 
   Arrive(c, kPlaced);
   if (rank == 0) {
     if ((rc = WaitAtLeast(g, &c->arrived[kPlaced], all)) != JXLT_OK) return rc;
+    stamp(7);
     if (bytes) *bytes = out + frame_begin;
     if (size) *size = total_end - frame_begin;
     // every process has mapped the segment by now (it has taken part in this frame): the name can go, so that a
@@ -897,6 +914,11 @@ void jxlt_shard_group_close(jxlt_shard_group* g) {
 }
 
 const char* jxlt_shard_group_last_error(const jxlt_shard_group* g) { return g ? g->error.c_str() : ""; }
+int jxlt_shard_group_last_timeline(const jxlt_shard_group* g, double* ms8) {
+  if (!g || !ms8) return JXLT_ERR_INVALID_ARGUMENT;
+  memcpy(ms8, g->timeline_ms, sizeof(g->timeline_ms));
+  return JXLT_OK;
+}
 
 int jxlt_shard_encode_ops(jxlt_shard_group* g, const jxlt_slab_ops* ops, size_t xsize, size_t ysize, float distance,
                           const uint8_t** bytes, size_t* size) {

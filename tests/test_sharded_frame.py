@@ -109,6 +109,10 @@ def _participant(pkg, name, rank, world, w, h, d, after_create=None, flat=False)
     for _ in range(2):  # two frames through the same group: the control block is reusable
         view = grp.encode_ops(slab.ops, w, h, d)
         out.append(view.tobytes() if view is not None else None)
+        # the stage times the protocol keeps per rank (testing header; tools/slab_of_8.py): in protocol order
+        tl = grp.last_timeline()
+        stamps = [tl[k] for k in grp.STAGES[:7 if rank else 8]]
+        assert all(b >= a >= 0.0 for a, b in zip(stamps, stamps[1:])), tl
     if after_create:
         after_create()  # rank 0 must not unlink the segment while others still use it
     grp.close()

@@ -18,8 +18,8 @@ Usage: slab_of_8.py [size] [frames] [out.json]"""
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
-import threading
 import time
 from pathlib import Path
 
@@ -29,54 +29,28 @@ import __graft_entry__  # noqa: E402
 import bench  # noqa: E402
 
 
-class ReplaySlab:
-    """jxlt_slab_ops that hand back recorded results (see the module text)."""
+class ReplayRecord(C.Structure):
+    """tools/slab_replay.cc: slab_replay_record"""
+    _fields_ = [("dc_hist", C.POINTER(C.c_uint32)), ("ac_hist", C.POINTER(C.c_uint32)),
+                ("bytes", C.POINTER(C.c_uint8) * 2), ("off", C.POINTER(C.c_uint64) * 2), ("bits", C.POINTER(C.c_uint32) * 2),
+                ("nsec", C.c_size_t * 2)]
 
-    def __init__(self, pkg, rec):
-        import numpy as np
-        self.np, self.rec = np, rec
-        fn = pkg._SLAB_FN
-        self.ops = pkg.SlabOps()
-        self._cb = {k: fn[k](getattr(self, "_" + k)) for k in fn}
-        for k, cb in self._cb.items():
-            setattr(self.ops, k, cb)
 
-    def _enqueue(self, _self, params):
-        return 0
-
-    def _dc_histogram(self, _self, out):
-        out[0] = self.rec["dc_hist"].ctypes.data_as(C.POINTER(C.c_uint32))
-        return 0
-
-    def _begin_dc_pack(self, _self, table):
-        return 0
-
-    def _ac_histogram(self, _self, out):
-        out[0] = self.rec["ac_hist"].ctypes.data_as(C.POINTER(C.c_uint32))
-        return 0
-
-    def _measure(self, _self, table, dc, ac):
-        for kind, dst in ((0, dc), (1, ac)):
-            _, off, bits = self.rec["sections"][kind]
-            dst.contents.bytes = None
-            dst.contents.section_offset = off.ctypes.data_as(C.POINTER(C.c_uint64))
-            dst.contents.section_bits = bits.ctypes.data_as(C.POINTER(C.c_uint32))
-            dst.contents.num_sections = len(bits)
-        return 0
-
-    def _write(self, _self, out, dc_runs, n_dc, ac_runs, n_ac):
-        base = C.addressof(out.contents)
-        for kind, runs, n in ((0, dc_runs, n_dc), (1, ac_runs, n_ac)):
-            data, off, _ = self.rec["sections"][kind]
-            for i in range(n):
-                r = runs[i]
-                lo, hi = int(off[r.first_section]), int(off[r.first_section + r.num_sections])
-                if hi > lo:
-                    C.memmove(base + r.dst_offset, data.ctypes.data + lo, hi - lo)
-        return 0
-
-    def _finish(self, _self):
-        return 0
+def replay_lib():
+    """The seven replaying participants as native threads (tools/slab_replay.cc), built on demand."""
+    here = ROOT / "tools"
+    so, src = here / "libslab_replay.so", here / "slab_replay.cc"
+    if not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-I" + str(ROOT / "include"), "-o", str(so), str(src),
+                        "-L" + str(ROOT / "libjxl-tiny_amd" / "host"), "-ljxltiny_host",
+                        "-L" + str(ROOT / "libjxl-tiny_amd" / "csrc"), "-ljxltiny_hip", "-pthread",
+                        "-Wl,-rpath," + str(ROOT / "libjxl-tiny_amd" / "host"), "-Wl,-rpath," + str(ROOT / "libjxl-tiny_amd" / "csrc")],
+                       check=True)
+    lib = C.CDLL(str(so))
+    lib.slab_replay_start.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(ReplayRecord),
+                                      C.c_size_t, C.c_size_t, C.c_float, C.c_int]
+    lib.slab_replay_join.restype = C.c_int
+    return lib
 
 
 def main():
@@ -124,40 +98,42 @@ def main():
         e.close()
     enc0 = encs[0]  # participant 0 keeps its context (and its rectangle)
 
-    # ---- the protocol: participant 0 on the device, 1..7 replaying
+    # ---- the protocol: participant 0 on the device (this thread), 1..7 replaying as native threads
     name = "/jxlt-slab8-%d" % os.getpid()
     sections = ((size + 2047) // 2048) ** 2 + ((size + 255) // 256) ** 2
     capacity = max(32 << 20, size * size // 4)
-    groups = [pkg.ShardGroup(name, 0, world, capacity, sections + 64)]
-    groups += [pkg.ShardGroup(name, r, world, capacity, sections + 64) for r in range(1, world)]
-    replay = [None] + [ReplaySlab(pkg, records[r]) for r in range(1, world)]
+    group0 = pkg.ShardGroup(name, 0, world, capacity, sections + 64)
     total = frames + 5
-    errors = []
-
-    def peer(r):
-        try:
-            for _ in range(total):
-                groups[r].encode_ops(replay[r].ops, size, size, d)
-        except Exception as e:  # noqa: BLE001
-            errors.append("participant %d: %r" % (r, e))
-
-    threads = [threading.Thread(target=peer, args=(r,)) for r in range(1, world)]
-    for t in threads:
-        t.start()
-    step_ms, kernel_ms, same = [], [], True
+    recs = (ReplayRecord * (world - 1))()
+    keep = []
+    for r in range(1, world):
+        rec, out = records[r], recs[r - 1]
+        out.dc_hist = rec["dc_hist"].ctypes.data_as(C.POINTER(C.c_uint32))
+        out.ac_hist = rec["ac_hist"].ctypes.data_as(C.POINTER(C.c_uint32))
+        for kind in (0, 1):
+            data, off, bits = rec["sections"][kind]
+            data, off, bits = np.ascontiguousarray(data), np.ascontiguousarray(off, np.uint64), np.ascontiguousarray(bits, np.uint32)
+            keep.append((data, off, bits))
+            out.bytes[kind] = data.ctypes.data_as(C.POINTER(C.c_uint8))
+            out.off[kind] = off.ctypes.data_as(C.POINTER(C.c_uint64))
+            out.bits[kind] = bits.ctypes.data_as(C.POINTER(C.c_uint32))
+            out.nsec[kind] = len(bits)
+    lib = replay_lib()
+    if lib.slab_replay_start(name.encode(), world, 1, capacity, sections + 64, recs, size, size, C.c_float(d), total) != 0:
+        raise SystemExit("slab_replay_start failed")
+    step_ms, kernel_ms, stages, same = [], [], [], True
     for i in range(total):
         t0 = time.perf_counter()
-        view = groups[0].encode(enc0, size, size, d)
+        view = group0.encode(enc0, size, size, d)
         dt = (time.perf_counter() - t0) * 1e3
         if i >= 5:
             step_ms.append(round(dt, 3))
             kernel_ms.append({k: round(v, 3) for k, v in enc0.kernel_times().items()})
+            stages.append(group0.last_timeline())
         if i in (0, total - 1):
             same = same and view.tobytes() == single
-    for t in threads:
-        t.join(timeout=120)
-    for g in groups:
-        g.close()
+    errors = ["%d replaying participant(s) failed" % n for n in [lib.slab_replay_join()] if n]
+    group0.close()
     enc0.close()
     srt = sorted(step_ms)
     med = lambda v: sorted(v)[len(v) // 2]
@@ -168,10 +144,17 @@ def main():
            "kernel_ms_median": {k: med([km[k] for km in kernel_ms]) for k in kernel_ms[0]},
            "whole_frame_on_this_gpu_ms": round(one_gpu_ms, 3),
            "ratio_whole_frame_over_one_rank_median": round(one_gpu_ms / srt[len(srt) // 2], 2),
-           "step_ms": step_ms,
+           "step_ms": step_ms, "slowest_step_over_median": round(srt[-1] / srt[len(srt) // 2], 2),
+           "host_stage_ms_median": {k: round(med([st[k] for st in stages]), 3) for k in stages[0]} if stages and stages[0] else None,
+           "stage_split_ms_median": (lambda m: {"kernels_until_ac_histogram": round(m["ac_histogram"], 3),
+                                                "sums_and_codes": round(m["code_tables"] - m["ac_histogram"], 3),
+                                                "own_sizes": round(m["own_sizes"] - m["code_tables"], 3),
+                                                "layout": round(m["layout"] - m["own_sizes"], 3),
+                                                "hand_over_and_placed": round(m["all_placed"] - m["layout"], 3)})(
+               {k: med([st[k] for st in stages]) for k in stages[0]}) if stages and stages[0] else None,
            "same_bytes_as_single_gpu": bool(same), "errors": errors,
-           "note": "serial stage + hand-over = ms_per_frame_median - kernels (the mean carries the Python harness's outliers: seven replaying "
-                   "participants are Python threads whose callbacks take turns on the interpreter lock); the peers answer at once, so nothing here is waiting for a slower "
+           "note": "serial stage + hand-over = ms_per_frame_median - kernels; the seven replaying participants are native threads "
+                   "(tools/slab_replay.cc; round 5: Python threads taking turns on the interpreter lock); the peers answer at once, so nothing here is waiting for a slower "
                    "GPU; every participant's section bytes land in one shared output buffer (participant 0's by DMA from the GPU, the "
                    "others' by memcpy)"}
     line = json.dumps(doc)
