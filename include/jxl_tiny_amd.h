@@ -170,6 +170,12 @@ int jxlt_synchronize(jxlt_context* ctx);
  * enc_ac_strategy.cc:178-185).  To reproduce a later call of such a process bit for bit, pass
  * that first distance here; 0 (default) = every encode uses its own distance. */
 int jxlt_set_strategy_distance(jxlt_context* ctx, float first_call_distance);
+/* How the library's calls wait for the device on this context.  0 (default), for one frame at a time: a wait that was
+ * long the last two times (the kernels of a large frame) sleeps through most of the expected time and then polls, so
+ * that results are seen within microseconds without a core spinning for milliseconds.  1, for contexts that share a GPU
+ * and the host's CPUs with others (what the lanes of a jxlt_batch_encoder set): a few microseconds of polling, then
+ * short sleeps -- a later wake-up is covered by the other contexts' frames.  Results do not depend on it. */
+int jxlt_context_set_wait_mode(jxlt_context* ctx, int shared_device);
 /* Copies results to pinned host memory (blocking) and fills *out. */
 int jxlt_fetch_result(jxlt_context* ctx, jxlt_frame_result* out);
 

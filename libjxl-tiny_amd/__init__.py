@@ -32,7 +32,7 @@ FLAG_FORCE_DCT8, FLAG_DEBUG_DUMP, FLAG_PROFILE = 1, 2, 4
 HIP_SYMBOLS = ["jxlt_context_create", "jxlt_context_destroy", "jxlt_last_error", "jxlt_context_device",
                "jxlt_device_count", "jxlt_bind_thread_near_device",
                "jxlt_image_upload", "jxlt_image_set_device", "jxlt_image_upload_pfm", "jxlt_image_set_device_pfm", "jxlt_image_attach_host", "jxlt_image_attach_host_pfm", "jxlt_image_size", "jxlt_pinned_alloc",
-               "jxlt_pinned_free", "jxlt_pinned_register", "jxlt_pinned_unregister", "jxlt_encode_enqueue", "jxlt_set_strategy_distance",
+               "jxlt_pinned_free", "jxlt_pinned_register", "jxlt_pinned_unregister", "jxlt_encode_enqueue", "jxlt_set_strategy_distance", "jxlt_context_set_wait_mode",
                "jxlt_fetch_histograms", "jxlt_fetch_dc_histogram", "jxlt_histograms_ready",
                "jxlt_pack_begin", "jxlt_pack_sizes", "jxlt_pack_deliver", "jxlt_release_cached_memory",
                "jxlt_output_buffer",

@@ -71,10 +71,40 @@ int WaitWord(jxlt_context* ctx, const uint32_t* word, uint32_t want, hipStream_t
   const volatile uint32_t* w = word;
   if (*w == want) return JXLT_OK;
   const auto t0 = std::chrono::steady_clock::now();
-  auto next_check = t0 + std::chrono::milliseconds(2);
+  // the site's memory (see jxlt_context::WaitSite)
+  if (ctx->wait_geometry[0] != ctx->xsize || ctx->wait_geometry[1] != ctx->ysize) {
+    for (auto& site : ctx->wait_sites) site = jxlt_context::WaitSite();
+    ctx->wait_geometry[0] = ctx->xsize;
+    ctx->wait_geometry[1] = ctx->ysize;
+  }
+  jxlt_context::WaitSite* site = nullptr;
+  for (auto& s : ctx->wait_sites) {
+    if (s.what == what || s.what == nullptr) {
+      s.what = what;
+      site = &s;
+      break;
+    }
+  }
+  const auto done = [&]() {
+    if (site) {
+      site->last_us[1] = site->last_us[0];
+      site->last_us[0] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return JXLT_OK;
+  };
+  const bool deferred_work = ctx->deferred_dc.pending && !ctx->in_deferred;  // (this wait has something to issue: no sleep)
+  if (!ctx->throughput_waits && site && !deferred_work) {
+    const float expect = std::min(site->last_us[0], site->last_us[1]);
+    if (expect > 400.0f) {
+      std::this_thread::sleep_for(std::chrono::microseconds((long)(expect * 0.7f)));
+      if (*w == want) return done();
+    }
+  }
+  auto next_check = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+  int rounds = 0;
   for (;;) {
     for (int spin = 0; spin < 256; spin++) {
-      if (*w == want) return JXLT_OK;
+      if (*w == want) return done();
 #if defined(__x86_64__)
       __builtin_ia32_pause();
 #endif
@@ -82,6 +112,11 @@ int WaitWord(jxlt_context* ctx, const uint32_t* word, uint32_t want, hipStream_t
     if (ctx->deferred_dc.pending && !ctx->in_deferred) {
       const int rcd = IssueDeferred(ctx, /*wait=*/false);
       if (rcd != JXLT_OK) return rcd;
+    }
+    // (a batch lane: ~5 us of spinning, then short sleeps -- the thread's timer slack is a microsecond, frame_batch.cc)
+    if (ctx->throughput_waits && ++rounds >= 2) {
+      struct timespec ts = {0, 8000};
+      nanosleep(&ts, nullptr);
     }
     const auto now = std::chrono::steady_clock::now();
     if (now < next_check) continue;
@@ -94,7 +129,7 @@ int WaitWord(jxlt_context* ctx, const uint32_t* word, uint32_t want, hipStream_t
     if (e == hipSuccess && *w != want) {
       // the stream has drained: give the word's store a moment to arrive, then it never will
       std::this_thread::sleep_for(std::chrono::milliseconds(1));
-      if (*w == want) return JXLT_OK;
+      if (*w == want) return done();
       if (hipStreamQuery(stream) == hipSuccess && *w != want &&
           now - t0 > std::chrono::milliseconds(200)) {
         ctx->error = std::string(what) + ": the device finished without reporting";
@@ -586,6 +621,12 @@ int jxlt_encode_stats(jxlt_context* ctx, jxlt_encode_stats_t* out) {
 int jxlt_set_strategy_distance(jxlt_context* ctx, float first_call_distance) {
   if (!ctx || !(first_call_distance >= 0.0f)) return JXLT_ERR_INVALID_ARGUMENT;
   ctx->strategy_distance = first_call_distance;
+  return JXLT_OK;
+}
+
+int jxlt_context_set_wait_mode(jxlt_context* ctx, int shared_device) {
+  if (!ctx) return JXLT_ERR_INVALID_ARGUMENT;
+  ctx->throughput_waits = shared_device != 0;
   return JXLT_OK;
 }
 

@@ -97,6 +97,19 @@ struct jxlt_context {
     std::vector<jxlt_section_run> runs;
   } deferred_dc;
   bool in_deferred = false;  // (IssueDeferred is running: its own waits must not start it again)
+  // How WaitWord waits (round 6; until then it spun from the first to the last microsecond of every wait -- a full core for
+  // the whole tile kernel of every frame).  Per wait site (the `what` literal) the last waits' lengths are remembered:
+  // a site whose waits have been LONG (> 0.4 ms, twice in a row) sleeps through the first 70 % of the expected time
+  // and spins for the rest -- the word is still seen within a few microseconds of its store.  The memory goes with the
+  // frame's geometry.  throughput_waits (the lanes of a batch encoder: several contexts share a GPU and the host's CPU
+  // quota): spin for a few microseconds, then poll in short sleeps -- a lane's wake-up latency is covered by the other
+  // lanes' frames, and sixteen spinning threads are not.
+  struct WaitSite {
+    const char* what = nullptr;
+    float last_us[2] = {0.0f, 0.0f};
+  } wait_sites[8];
+  size_t wait_geometry[2] = {0, 0};  // the frame size the remembered waits belong to
+  bool throughput_waits = false;
   std::vector<hipEvent_t> tile_done;
   hipEvent_t aux_done = nullptr;   // everything queued on aux_stream for the frame (timing enabled: the token tail)
   // the streams that carry the last encode's publications of the DC / AC histogram: what a wait for their words asks

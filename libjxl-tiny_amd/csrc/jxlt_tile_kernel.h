@@ -11,10 +11,6 @@ namespace jxlt_dev {
 // ---------------------------------------------------------------------------
 // Tile kernel
 // ---------------------------------------------------------------------------
-// (probe builds of round 6, tools/ab_cycles.sh: parts of the scan-order quantisation left out -- WRONG results, timing only)
-#ifndef JXLT_ABL_P9
-#define JXLT_ABL_P9 0
-#endif
 
 // Twelve waves per tile (768 threads).  Octets 0-31 hold the DCT8 coefficients of TWO blocks each, octets 32-95 one
 // two-block candidate each (the 8-wave kernel of rounds 1-2, removed in round 4, kept a block AND a candidate per
@@ -315,11 +311,13 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
         pb[k] = __uint_as_float(__builtin_bswap32(__float_as_uint(pb[k])));
       }
     }
+    // (one exec-mask region around the six rows -- the lane's column is in the window or not, whatever the row --
+    // instead of one per row)
+    if (xok_i) {
 #pragma unroll
     for (int k = 0; k < 6; k++) {
       const int y = w + 12 * k;
       if (y >= 64 || y >= shp) break;  // (wave-uniform)
-      if (!xok_i) continue;
       float px_, py_, pb_;
       linear_to_xyb<true>(pr[k], pg[k], pb[k], &px_, &py_, &pb_);
       S.x[y * kXYPitch + kHalo + c] = px_;
@@ -331,6 +329,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
         A.dbg_xyb[1][d] = py_;
         A.dbg_xyb[2][d] = pb_;
       }
+    }
     }
     if (hok) {
       float px_, py_, pb_ = 0.0f;
@@ -421,7 +420,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     // workgroup takes the issue slots the idle waves leave.  The 4-column groups that lie entirely in the vector
     // loop's range on a path of their own -- no second association order, no selects, 15-16 of a tile's 17-18 groups --
     // was built in round 4 and lost: 3860 against 3886 VALU per wave, 9.41 against 9.33 M cycles)
-    for (int i = tid; i < ((JXLT_ABL_P9 & 128) ? 0 : nbands * aq_w); i += kThreads) {
+    for (int i = tid; i < nbands * aq_w; i += kThreads) {
       const int q = i / aq_w, x = aq_x0 + i % aq_w;
       band_column(q, x, (i & 3) == 0);
     }
@@ -545,7 +544,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     const float kBlueRampLength = (float)0.086890611400405895;
     const float kBlueRampStart = (float)0.26973418507870539;
     const int right_step = l < 7 ? 1 : 0;
-    if (blk_valid && !(JXLT_ABL_P9 & 256)) {
+    if (blk_valid) {
 #pragma unroll
       for (int dy = 0; dy < 8; dy++) {
         const int yy = byp + dy, xx = bxp + l;
@@ -684,7 +683,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
     } else {
       leave_undefined(8, 16);
     }
-  } else if (cell_valid && !(JXLT_ABL_P9 & 512)) {
+  } else if (cell_valid) {
     const float* pxp = &S.x[(cby * 8) * kXYPitch + cbx * 8 + kHalo];
     const float* pyp = &S.y[(cby * 8) * kXYPitch + cbx * 8 + kHalo];
     const float* pbp = &S.b[(cby * 8) * kBPitch + cbx * 8];
@@ -845,25 +844,27 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       const int ch = (cl >> 3) & 1;  // 0: X, 1: B
       const float* const first_factors = terms + l * 8 + ch * 4;
       const float* const second_factors = first_factors + cw * 128;  // (a again, or b)
-      const int last = nblk_pad - 1;
       // Two register sets, used in turn by ROUNDS of four blocks (one per row): at the start of a round every row
       // requests the block it will handle in the NEXT round -- one wave-wide set of four 16-byte loads, a whole
       // round (32 dependent multiply-adds and four hops) ahead of its use.
       JxltFloat4 ta[4], tb[4];  // [0], [1]: first factors of rows 0-3, 4-7; [2], [3]: second factors
       // (issued HERE, a round ahead of their use: as plain loads the compiler sinks them to their first use behind the
       // loop's exit test and every round waits for the LDS -- JXLT_LDS_LOAD4_NOW, jxlt_device_common.h)
-      // (addresses in integers, from bases the compiler cannot look through: a minimum, and one shift-and-add per
-      // factor -- it made six instructions of the pointer form)
-      auto f1_base = JXLT_LDS_ADDRESS(first_factors), f2_base = JXLT_LDS_ADDRESS(second_factors);
-      JXLT_LAUNDER_VGPR(f1_base);
-      JXLT_LAUNDER_VGPR(f2_base);
-      auto request = [&](JxltFloat4* t, int first) {
-        const int blk_of_row = imin(first + relay_pos, last);
-        const auto a1 = f1_base + (decltype(f1_base))(blk_of_row << 10), a2 = f2_base + (decltype(f1_base))(blk_of_row << 10);
+      // (addresses in integers that move on by a round -- 4 KB -- per request: two additions.  No clamp at the end of
+      // the tile: what the last requests fetch is never used -- with an even number of rounds one round beyond the
+      // terms, with an odd number two, i.e. never more than 4 KB beyond the term area's 64 blocks --, and those 4 KB lie
+      // inside the workgroup's LDS: the transposes' pad, static_assert below.)
+      auto a1 = JXLT_LDS_ADDRESS(first_factors) + (decltype(JXLT_LDS_ADDRESS(first_factors)))(relay_pos << 10);
+      auto a2 = JXLT_LDS_ADDRESS(second_factors) + (decltype(a1))(relay_pos << 10);
+      static_assert(offsetof(TileShared, x) + (size_t)kCflTermFloats * 4 + 4 * 1024 <= sizeof(TileShared),
+                    "the chains request up to a round beyond the term area");
+      auto request = [&](JxltFloat4* t) {
         JXLT_LDS_LOAD4_NOW_AT(t[0], a1, 0);
         JXLT_LDS_LOAD4_NOW_AT(t[2], a2, 0);
         JXLT_LDS_LOAD4_NOW_AT(t[1], a1, 256);
         JXLT_LDS_LOAD4_NOW_AT(t[3], a2, 256);
+        a1 += 4096;
+        a2 += 4096;
       };
       float acc2 = 0.0f;  // (the accumulators' other register)
       // every lane runs the eight steps; only the row that holds the accumulators has meaningful ones
@@ -901,12 +902,12 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
         block_steps(acc2, t);  // row 2
         hop32(acc2, acc);      // acc2 row 2 -> acc row 0
       };
-      request(ta, 0);
+      request(ta);
 #pragma clang loop unroll(disable)
-      for (int blk = 0; blk < ((JXLT_ABL_P9 & 32) ? 0 : nblk_pad); blk += 8) {
-        request(tb, blk + 4);
+      for (int blk = 0; blk < nblk_pad; blk += 8) {
+        request(tb);
         round4(ta);
-        request(ta, blk + 8);
+        request(ta);
         if (blk + 4 < nblk_pad) round4(tb);  // (wave-uniform: an odd number of rounds ends here)
       }
       // (whatever was requested last is not used; it has arrived before its registers serve anything else)
@@ -994,12 +995,12 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
 #pragma unroll
       for (int r = 0; r < 16; r++) park[r * kThreads] = c16b[r];
       JXLT_SCHED_FENCE();
-      if (pair_valid0 && !(JXLT_ABL_P9 & 64)) estimate8(pbx, pby0, c8x, c8y, park);
+      if (pair_valid0) estimate8(pbx, pby0, c8x, c8y, park);
       JXLT_SCHED_FENCE();
-      if (pair_valid1 && !(JXLT_ABL_P9 & 64)) estimate8(pbx, pby0 + 1, d8x, d8y, park + 8 * kThreads);
+      if (pair_valid1) estimate8(pbx, pby0 + 1, d8x, d8y, park + 8 * kThreads);
     }
     JXLT_SCHED_FENCE();
-    if (cell_valid && !(JXLT_ABL_P9 & 64)) {
+    if (cell_valid) {
       const int o2 = is_tall ? 8 : 1;  // second covered block in the 8x8 tile grid
       const int bi = cby * 8 + cbx;
       const float quant = fmaxf(fmaxf(0.0f, S.aq[bi]), S.aq[bi + o2]);
@@ -1312,8 +1313,8 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       int nscan[3];
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        const int nzeros = (JXLT_ABL_P9 & 16) ? 3 : __popcll(m0[c]) + __popcll(m1[c]);
-        nscan[c] = (JXLT_ABL_P9 & 16) ? 40 : m1[c] != 0 ? 128 - __clzll((long long)m1[c]) : m0[c] != 0 ? 64 - __clzll((long long)m0[c]) : 0;
+        const int nzeros = __popcll(m0[c]) + __popcll(m1[c]);
+        nscan[c] = m1[c] != 0 ? 128 - __clzll((long long)m1[c]) : m0[c] != 0 ? 64 - __clzll((long long)m0[c]) : 0;
         nz_packed |= nzeros << (8 * c);
         nscan_packed |= nscan[c] << (8 * c);
         wave_tokens += 1 + (nscan[c] > covered ? nscan[c] - covered : 0);
@@ -1335,7 +1336,6 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
         JXLT_LAUNDER_SGPR(masks);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-          if (JXLT_ABL_P9 & 2) continue;
           JXLT_SCALAR_STORE64(masks, 2 * c, m0[c]);
           JXLT_SCALAR_STORE64(masks, 2 * c + 1, m1[c]);
         }
@@ -1349,8 +1349,8 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
         const uint32_t slot = (uint32_t)lane * 2u;
 #pragma unroll
         for (int c = 0; c < 3; c++)
-          if (!(JXLT_ABL_P9 & 1) && lane < nscan[c]) *(JxltGlobalShorts)(out0 + (c * 128 + slot)) = (int16_t)(int)quant[0][c];
-        if (two && !(JXLT_ABL_P9 & 1)) {
+          if (lane < nscan[c]) *(JxltGlobalShorts)(out0 + (c * 128 + slot)) = (int16_t)(int)quant[0][c];
+        if (two) {
           JxltGlobalBytes out1 = (JxltGlobalBytes)(A.coef_scan + (size_t)pos1 * 192);
           JXLT_LAUNDER_SGPR(out1);
 #pragma unroll
@@ -1362,13 +1362,12 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
       file_int(2, t, nscan_packed);
       ntrans++;
     };
-    if (JXLT_ABL_P9 & 8) next_b = -1;  // (no transform at all)
     while (next_b >= 0) {
       one_transform(set_a, set_b);
       if (next_b < 0) break;
       one_transform(set_b, set_a);
     }
-    if (!(JXLT_ABL_P9 & 2)) JXLT_SCALAR_STORES_DONE();  // (the masks above: out of the scalar data cache)
+    JXLT_SCALAR_STORES_DONE();  // (the masks above: out of the scalar data cache)
     if (lane == 0 && wave_tokens) atomicAdd(&S.ntok, wave_tokens);
     if (kLutRoots) {
       if (__ballot(!(q_largest < 32768.0f)) != 0 && lane == 0) S.overflow = 1u;  // (suspect: see q_largest)
@@ -1382,7 +1381,7 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
   // this part runs with the other waves idle and the workgroup's LDS held, so its LENGTH counts, not its instruction
   // count -- as one wave doing the three channels in turn (until round 5) the kernel took 1 % longer; with the token
   // count of the tile added to it, 2 % more.
-  if (tid < 192 && !(JXLT_ABL_P9 & 8)) {
+  if (tid < 192) {
     const int lane = tid & 63;
     const int c = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave's channel
     float* const dc_stage = stagef + 64 * kStageStrideF;
