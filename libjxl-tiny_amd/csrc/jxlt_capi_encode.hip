@@ -254,8 +254,10 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   }
   const bool profile = (params->flags & JXLT_FLAG_PROFILE) != 0;
   if (profile) {
-    ENSURE(dbg_phase, 16);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->dbg_phase.p, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    // (kPhaseClockCopies copies of the 16 phase sums, indexed by the workgroup: every tile adding to ONE set of 16
+    // addresses serialised the whole launch -- 786 k atomics on 12 addresses doubled the kernel's time, round 6)
+    ENSURE(dbg_phase, 16 * kPhaseClockCopies);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dbg_phase.p, 0, 16 * kPhaseClockCopies * sizeof(unsigned long long), ctx->stream));
   }
 #undef ENSURE
 
@@ -429,7 +431,11 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
     // entropy estimates, again with computed roots (enc_ac_strategy.cc:118-126 takes a Sqrt per coefficient) -- a
     // small fixed grid whose workgroups usually find an empty list and leave.
     const unsigned redo_grid = std::min<unsigned>(slab_tiles, kRedoGrid);
+#ifdef JXLT_TIMING_MARKS
+    if (debug)
+#else
     if (debug || profile)
+#endif
       hipLaunchKernelGGL(tile12_kernel_debug, dim3(slab_tiles), dim3(kTile12Threads), 0, ctx->stream, S);
     else
       hipLaunchKernelGGL(tile12_kernel, dim3(slab_tiles), dim3(kTile12Threads), 0, ctx->stream, S);
@@ -859,7 +865,13 @@ int jxlt_debug_fetch(jxlt_context* ctx, int what, void* host_dst, size_t bytes) 
       return JXLT_ERR_INVALID_ARGUMENT;
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(host_dst, ctx->dbg_phase.p, bytes, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> copies(16 * kPhaseClockCopies);
+    HIP_TRY(ctx, hipMemcpy(copies.data(), ctx->dbg_phase.p, copies.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long* out = static_cast<unsigned long long*>(host_dst);
+    for (int i = 0; i < 16; i++) {
+      out[i] = 0;
+      for (int c = 0; c < kPhaseClockCopies; c++) out[i] += copies[16 * c + i];
+    }
     return JXLT_OK;
   }
   if (!(ctx->last_flags & JXLT_FLAG_DEBUG_DUMP)) {

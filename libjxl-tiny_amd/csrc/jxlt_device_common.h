@@ -142,6 +142,7 @@ struct TileArgs {
 // The writing pass of the section packing runs as up to this many launches (jxlt_pack_kernels.h; the host's mail
 // words are laid out for them).
 constexpr int kPackMaxLaunches = 8;
+constexpr int kPhaseClockCopies = 512;  // TileArgs::dbg_phase: [copies][16] sums of the per-phase clocks (profiling)
 
 struct alignas(16) PackTileInfo {
   uint64_t rec_first;      // absolute index of the tile's first record

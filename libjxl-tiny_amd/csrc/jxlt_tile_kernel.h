@@ -208,7 +208,14 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
   int l = tid & 7;    // lane within octet
   int oct = tid >> 3;  // octet index; for octets 0..63 == block index within tile
   const DeviceTables* T = A.tab;
-  long long t_prev = (kDebug && A.dbg_phase) ? clock64() : 0;
+  // (-DJXLT_TIMING_MARKS, tools/profile_phases.py: the per-phase clocks of thread 0 in the PRODUCTION variant too -- the
+  // debug variant's phases are not the production kernel's: it spills and stores the intermediate planes)
+#ifdef JXLT_TIMING_MARKS
+  constexpr bool kMarks = true;
+#else
+  constexpr bool kMarks = kDebug;
+#endif
+  long long t_prev = (kMarks && A.dbg_phase) ? clock64() : 0;
   // Profiling builds (-DJXLT_PHASE_STOPS, tools/phase_pmc.py) can truncate the kernel after
   // phase i; the early exits perturb code generation, so production builds leave them out.
 #ifdef JXLT_PHASE_STOPS
@@ -224,9 +231,9 @@ JXLT_DI void tile_kernel_body(const TileArgs& A, const int tile_id) {
 #define JXLT_ASM_PHASE_END(i)
 #endif
 #define JXLT_MARK(i)                                                        \
-  if (kDebug && A.dbg_phase && tid == 0) {                                  \
+  if (kMarks && A.dbg_phase && tid == 0) {                                  \
     const long long t_now = clock64();                                      \
-    atomicAdd(&A.dbg_phase[i], (unsigned long long)(t_now - t_prev));       \
+    atomicAdd(&A.dbg_phase[i + 16 * (blockIdx.x % kPhaseClockCopies)], (unsigned long long)(t_now - t_prev)); \
     t_prev = t_now;                                                         \
   }                                                                         \
   JXLT_ASM_PHASE_END(i);                                                    \
