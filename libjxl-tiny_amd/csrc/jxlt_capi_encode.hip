@@ -93,6 +93,7 @@ int WaitWord(jxlt_context* ctx, const uint32_t* word, uint32_t want, hipStream_t
     return JXLT_OK;
   };
   const bool deferred_work = ctx->deferred_dc.pending && !ctx->in_deferred;  // (this wait has something to issue: no sleep)
+  // (measured: 4.80-4.83 ms per 16384^2 step with the sleep, 4.80-4.86 without -- the same, minus a spinning core)
   if (!ctx->throughput_waits && site && !deferred_work) {
     const float expect = std::min(site->last_us[0], site->last_us[1]);
     if (expect > 400.0f) {
