@@ -151,8 +151,27 @@ int WaitDeliveries(jxlt_context* ctx) {
     if (rcd != JXLT_OK) return rcd;
   }
   for (int kind = 0; kind < 2; kind++) {
-    const int rc = WaitWord(ctx, &ctx->mail.p->delivered_seq[kind][0], ctx->deliver_seq[kind],
-                            kind ? ctx->copy_stream : ctx->dc_copy_stream, "section hand-over");
+    const hipStream_t out_stream = kind ? ctx->copy_stream : ctx->dc_copy_stream;
+    if (ctx->deliver_by_query[kind]) {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (;;) {
+        const hipError_t e = hipStreamQuery(out_stream);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) {
+          ctx->error = std::string("section hand-over: ") + hipGetErrorString(e);
+          return JXLT_ERR_NO_DEVICE;
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+          ctx->error = "section hand-over: timed out";
+          return JXLT_ERR_INTERNAL;
+        }
+        struct timespec ts = {0, 8000};
+        nanosleep(&ts, nullptr);
+      }
+      ctx->deliver_by_query[kind] = false;
+      continue;
+    }
+    const int rc = WaitWord(ctx, &ctx->mail.p->delivered_seq[kind][0], ctx->deliver_seq[kind], out_stream, "section hand-over");
     if (rc != JXLT_OK) return rc;
   }
   return JXLT_OK;
@@ -161,7 +180,7 @@ int WaitDeliveries(jxlt_context* ctx) {
 // publish_kernel on `stream`: up to kPublishSegments (device source, host destination, dwords) pairs, an optional
 // 64-bit word, then `seq` to the host word `flag`.
 int EnqueuePublish(jxlt_context* ctx, hipStream_t stream, const PublishSeg* segs, int nsegs, const unsigned long long* src64,
-                   unsigned long long* dst64, uint32_t* flag, uint32_t seq) {
+                   unsigned long long* dst64, uint32_t* flag, uint32_t seq, uint32_t* flag2) {
   PublishArgs P;
   memset(&P, 0, sizeof(P));
   for (int i = 0; i < nsegs && i < kPublishSegments; i++) {
@@ -172,6 +191,7 @@ int EnqueuePublish(jxlt_context* ctx, hipStream_t stream, const PublishSeg* segs
   P.src64 = src64;
   P.dst64 = dst64;
   P.flag = flag;
+  P.flag2 = flag2;
   P.seq = seq;
   hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(kPublishThreads), 0, stream, P);
   HIP_TRY(ctx, hipGetLastError());
@@ -408,6 +428,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   const size_t ndc_rows = (ctx->ysize + 2047) / 2048;
   const hipStream_t tok_stream = nslabs == 1 ? ctx->stream : ctx->aux_stream;  // (one launch: nothing to overlap)
   size_t dc_rows_done = 0;  // rows of DC groups whose tokenisation has been queued
+  bool merged_hist_publish = false;  // (throughput mode, small frames: the DC histogram leaves with the AC histogram)
   for (size_t sl = 0; sl < nslabs; sl++) {
     const size_t y0 = pieces[sl].y0, rows = pieces[sl].rows, y1 = y0 + rows;
     if (from_host) {
@@ -474,7 +495,13 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
                        chain_stream, D);
     hipLaunchKernelGGL(dc_chain_kernel, dim3((unsigned)(slab_dc * kDcChainChunks)), dim3(kDcChainThreads), 0,
                        chain_stream, D);
-    if (beside) {
+    if (beside && ctx->throughput_waits) {
+      // (a lane of a batch: the DC histogram leaves WITH the AC histogram, one publication for the two -- token_kernel
+      // takes ~10 us on frames this small, and the seven microseconds of a publish kernel count where a batch of small
+      // frames is bound by the sum of its small launches, round 6)
+      merged_hist_publish = true;
+      HIP_TRY(ctx, hipEventRecord(ctx->dc_kernels_done, chain_stream));
+    } else if (beside) {
       HIP_TRY(ctx, hipStreamWaitEvent(chain_stream, ctx->dc_elementwise_done, 0));
       const PublishSeg segs[2] = {{ctx->hist.p + 64 * 64, ctx->h_hist.p + 64 * 64, 64 * 64},
                                   {ctx->lut_overflow.p, ctx->h_lut_overflow.p, nslabs + 1}};
@@ -515,7 +542,16 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   // event -- the host polls the sequence word)
   HIP_TRY(ctx, hipEventRecord(ctx->aux_done, tok_stream));
   TraceMark(ctx, "token_kernel done", tok_stream);
-  {
+  if (merged_hist_publish) {
+    // (both histograms -- they lie behind each other -- and the counts of redone tiles; the DC-group kernels have run)
+    HIP_TRY(ctx, hipStreamWaitEvent(tok_stream, ctx->dc_kernels_done, 0));
+    HIP_TRY(ctx, hipStreamWaitEvent(tok_stream, ctx->dc_elementwise_done, 0));
+    const PublishSeg segs[2] = {{ctx->hist.p, ctx->h_hist.p, 2 * 64 * 64}, {ctx->lut_overflow.p, ctx->h_lut_overflow.p, nslabs + 1}};
+    const int rcp = EnqueuePublish(ctx, tok_stream, segs, 2, reinterpret_cast<const unsigned long long*>(ctx->group_off.p + ngroups),
+                                   &ctx->mail.p->token_total, &ctx->mail.p->ac_hist_seq, frame_seq, &ctx->mail.p->dc_hist_seq);
+    if (rcp != JXLT_OK) return rcp;
+    ctx->ac_hist_stream = ctx->dc_hist_stream = tok_stream;
+  } else {
     const PublishSeg seg = {ctx->hist.p, ctx->h_hist.p, 64 * 64};
     const int rcp = EnqueuePublish(ctx, tok_stream, &seg, 1, reinterpret_cast<const unsigned long long*>(ctx->group_off.p + ngroups),
                                    &ctx->mail.p->token_total, &ctx->mail.p->ac_hist_seq, frame_seq);
@@ -550,7 +586,15 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
     // (one launch for the frame: the auxiliary stream is idle, and on the main stream the plan's three small
     // kernels would stand in front of the DC-group sections' packing, which the AC measuring pass queues behind)
     hipStream_t plan_stream = ctx->stream;
-    if (tok_stream == ctx->stream) {
+    const bool both_plans_at_once = tok_stream == ctx->stream && ctx->throughput_waits && ngroups <= 1024 && ndc <= 1024;
+    if (both_plans_at_once) {
+      // (a lane of a batch: the two plans in one launch, behind the tokenisation)
+      plan_stream = ctx->aux_stream;
+      HIP_TRY(ctx, hipStreamWaitEvent(plan_stream, ctx->dc_kernels_done, 0));
+      HIP_TRY(ctx, hipStreamWaitEvent(plan_stream, ctx->aux_done, 0));
+      const int rcb = EnqueuePlanBoth(ctx, ctx->dc_records.cap / 3, ctx->tokens.cap / 3, plan_stream);
+      if (rcb != JXLT_OK) return rcb;
+    } else if (tok_stream == ctx->stream) {
       plan_stream = ctx->aux_stream;
       // (the DC-group sections' plan first, behind the DC-group kernels and beside token_kernel: for a small frame
       // those sections' packing is what the frame waits for last, and the plan is a third of its launches)
@@ -561,8 +605,10 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
       }
       HIP_TRY(ctx, hipStreamWaitEvent(plan_stream, ctx->aux_done, 0));
     }
-    const int rcp = EnqueuePlan(ctx, 1, ctx->tokens.cap / 3, plan_stream);
-    if (rcp != JXLT_OK) return rcp;
+    if (!both_plans_at_once) {
+      const int rcp = EnqueuePlan(ctx, 1, ctx->tokens.cap / 3, plan_stream);
+      if (rcp != JXLT_OK) return rcp;
+    }
   }
   ctx->encoded = true;
   ctx->offsets_fetched = false;

@@ -110,6 +110,10 @@ struct jxlt_context {
   } wait_sites[8];
   size_t wait_geometry[2] = {0, 0};  // the frame size the remembered waits belong to
   bool throughput_waits = false;
+  // (throughput mode: a hand-over's completion is its copy stream having drained -- asked for with hipStreamQuery between
+  // short sleeps -- instead of a publish kernel behind the copies: a batch of small frames is bound by the number and the
+  // 7 us of its small launches, round 6)
+  bool deliver_by_query[2] = {false, false};
   std::vector<hipEvent_t> tile_done;
   hipEvent_t aux_done = nullptr;   // everything queued on aux_stream for the frame (timing enabled: the token tail)
   // the streams that carry the last encode's publications of the DC / AC histogram: what a wait for their words asks
@@ -432,10 +436,11 @@ struct PublishSeg {
   size_t words;
 };
 int EnqueuePublish(jxlt_context* ctx, hipStream_t stream, const PublishSeg* segs, int nsegs, const unsigned long long* src64,
-                   unsigned long long* dst64, uint32_t* flag, uint32_t seq);
+                   unsigned long long* dst64, uint32_t* flag, uint32_t seq, uint32_t* flag2 = nullptr);
 int ResolveRootTableOverflow(jxlt_context* ctx);
 // jxlt_capi_pack.hip
 int EnqueuePlan(jxlt_context* ctx, int kind, uint64_t rec_bound, hipStream_t stream);
+int EnqueuePlanBoth(jxlt_context* ctx, uint64_t dc_rec_bound, uint64_t ac_rec_bound, hipStream_t stream);
 int WaitSizes(jxlt_context* ctx, int kind);
 int IssueDeferred(jxlt_context* ctx, bool wait);
 

@@ -323,6 +323,86 @@ __global__ void __launch_bounds__(256) pack_tile_plan_kernel(const PackTileArgs 
   }
 }
 
+// The tile plan of up to 1024 sections in ONE launch (round 6): count, exclusive scan and plan by one workgroup, a
+// thread per section -- for the frames of a batch the three launches of the plan (x 2 kinds) were a seventh of a
+// frame's ~28 launches, and many small launches from several host threads are what a batch of small frames is bound by.
+constexpr int kPackPlanSmallSections = 1024;
+JXLT_DI void pack_tile_plan_small_body(const PackTileArgs& A, uint64_t* tile_base_out) {
+  __shared__ uint32_t wave_total[kPackPlanSmallSections / 64];
+  const int s = (int)threadIdx.x, lane = s & 63, wave = s >> 6;
+  const uint32_t cnt = s < A.nsec ? pack_section_records(A, s) : 0u;
+  const uint32_t tiles = (cnt + kPackTile - 1) / kPackTile;
+  uint32_t incl = tiles;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) wave_total[wave] = incl;
+  __syncthreads();
+  uint32_t t0 = incl - tiles;
+  for (int w = 0; w < wave; w++) t0 += wave_total[w];
+  if (s < A.nsec) {
+    A.sec_tiles[s] = tiles;
+    tile_base_out[s] = t0;
+    if (s + 1 == A.nsec) tile_base_out[A.nsec] = t0 + tiles;
+    const uint32_t t1 = t0 + tiles;
+    const uint64_t rec0 = A.sec_rec_offset[s];
+    if (A.tile_state) {
+      A.sec_bits[s] = 0;
+      if (s == 0 && A.launch_sec_end)
+        for (int i = 0; i < kPackMaxLaunches; i++) {
+          A.launch_sec_end[i] = 0xFFFFFFFFu;
+          A.tile_ticket[i] = 0;
+        }
+    }
+    for (uint32_t t = t0; t < t1; t++) {
+      if (A.tile_state) {
+        A.tile_state[t] = 0;
+        if ((t & (kPackBlockTiles - 1)) == 0) A.block_state[t / kPackBlockTiles] = 0;
+      }
+      const uint32_t before = (t - t0) * kPackTile;
+      const uint32_t n = cnt - before < (uint32_t)kPackTile ? cnt - before : (uint32_t)kPackTile;
+      PackTileInfo info;
+      info.rec_first = rec0 + before;
+      info.bit_pos = 0;
+      info.sec_start_bit = (uint64_t)s;
+      info.n_last = n | (t + 1 == t1 ? 0x80000000u : 0u);
+      info.before = before;
+      A.tile_info[t] = info;
+    }
+  }
+}
+__global__ void __launch_bounds__(kPackPlanSmallSections) pack_tile_plan_small_kernel(const PackTileArgs A, uint64_t* tile_base_out) {
+  pack_tile_plan_small_body(A, tile_base_out);
+}
+// ... and the plans of BOTH kinds of section in one launch (workgroup 0: the DC-group sections, 1: the AC sections)
+__global__ void __launch_bounds__(kPackPlanSmallSections) pack_tile_plan_small2_kernel(const PackTileArgs A0, uint64_t* base0,
+                                                                                        const PackTileArgs A1, uint64_t* base1) {
+  if (blockIdx.x == 0) pack_tile_plan_small_body(A0, base0);
+  else pack_tile_plan_small_body(A1, base1);
+}
+
+// In front of a single pass (round 6): the code table fetched from the host's page-locked copy AND the blob zeroed, in
+// one launch instead of a publish kernel + the runtime's fill kernel(s).  Workgroup 0 fetches the table, all zero
+// their share of the blob (16-byte stores; `zero_bytes` is a multiple of 16).
+constexpr int kPackPrepareThreads = 256;
+__global__ void __launch_bounds__(kPackPrepareThreads) pack_prepare_kernel(const uint32_t* table_src, uint32_t* table_dst,
+                                                                           uint8_t* blob, unsigned long long zero_bytes) {
+  const uint32_t tid = threadIdx.x;
+  if (blockIdx.x == 0) {
+    const uint4* src4 = reinterpret_cast<const uint4*>(table_src);
+    uint4* dst4 = reinterpret_cast<uint4*>(table_dst);
+    for (uint32_t i = tid; i < 64 * 64 / 4; i += kPackPrepareThreads) dst4[i] = src4[i];
+  }
+  uint4* out = reinterpret_cast<uint4*>(blob);
+  const unsigned long long n16 = zero_bytes >> 4;
+  uint4 zero;
+  zero.x = zero.y = zero.z = zero.w = 0u;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * kPackPrepareThreads + tid; i < n16;
+       i += (unsigned long long)gridDim.x * kPackPrepareThreads)
+    out[i] = zero;
+}
+
 // Records of a tile -> registers -> LDS, so that the first record starts at stage[0].  The records start at
 // any byte: unaligned dword loads (one instruction each on gfx950).  Fixed trip count, every load issued
 // before the first use (a loop over a run-time count waits for each load in turn); the two halves are

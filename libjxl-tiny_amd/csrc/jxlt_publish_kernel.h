@@ -37,6 +37,7 @@ struct PublishArgs {
   const unsigned long long* src64;
   unsigned long long* dst64;
   uint32_t* flag;   // host memory: receives `seq` when everything above is visible to the host
+  uint32_t* flag2;  // optional: a second word that receives `seq` (one publication that stands for two)
   uint32_t seq;
 };
 // ONE workgroup (the payloads are a few KB to a few hundred KB): no cross-workgroup completion protocol.
@@ -60,6 +61,7 @@ __global__ void __launch_bounds__(kPublishThreads) publish_kernel(const PublishA
   __syncthreads();
   if (tid == 0 && A.flag) {
     *(volatile uint32_t*)A.flag = A.seq;
+    if (A.flag2) *(volatile uint32_t*)A.flag2 = A.seq;
   }
 }
 

@@ -408,9 +408,13 @@ __attribute__((visibility("default"))) int sim_pack_stream(const uint8_t* record
   std::vector<uint32_t> tickets(kPackMaxLaunches, 0xDEADu);
   P.tile_ticket = tickets.data();
   const unsigned sec_blocks = (unsigned)((nsec + 255) / 256);
-  hipsim::launch(pack_tile_count_kernel, dim3(sec_blocks), dim3(256), P);
-  hipsim::launch(group_scan_kernel, dim3(1), dim3(kScanThreads), (const uint32_t*)sec_tiles.data(), tile_base.data(), nsec);
-  hipsim::launch(pack_tile_plan_kernel, dim3(sec_blocks), dim3(256), P);
+  if (nsec <= kPackPlanSmallSections) {  // (as EnqueuePlan: the plan of up to 1024 sections is one launch)
+    hipsim::launch(pack_tile_plan_small_kernel, dim3(1), dim3(kPackPlanSmallSections), P, tile_base.data());
+  } else {
+    hipsim::launch(pack_tile_count_kernel, dim3(sec_blocks), dim3(256), P);
+    hipsim::launch(group_scan_kernel, dim3(1), dim3(kScanThreads), (const uint32_t*)sec_tiles.data(), tile_base.data(), nsec);
+    hipsim::launch(pack_tile_plan_kernel, dim3(sec_blocks), dim3(256), P);
+  }
   for (int c = 0; c < nlaunch; c++) {
     PackTileArgs W = P;
     W.tile_first = P.launch_t0[c];
