@@ -277,6 +277,14 @@ class Encoder:
             raise JxlTinyError("%s failed (%d): %s" % (what, rc, self._L.jxlt_last_error(self._ctx).decode()))
         return rc
 
+    def set_wait_mode(self, mode):
+        """0: the calls wait for the device spinning / sleeping through long waits (lowest latency of one frame);
+        1: throughput mode, what the lanes of a batch use -- short sleeps, and the frame's small launches shared where
+        they can be (jxlt_context_set_wait_mode)."""
+        self._L.jxlt_context_set_wait_mode.argtypes = [C.c_void_p, C.c_int]
+        self._L.jxlt_context_set_wait_mode.restype = C.c_int
+        self._check(self._L.jxlt_context_set_wait_mode(self._ctx, int(mode)), "jxlt_context_set_wait_mode")
+
     def upload(self, planes):
         """planes: float32 [3, h, w] C-contiguous host array."""
         assert planes.dtype == np.float32 and planes.ndim == 3 and planes.shape[0] == 3

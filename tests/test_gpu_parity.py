@@ -732,13 +732,18 @@ def test_frames_in_a_row_whose_ac_code_is_ready_first(built, enc):
     assert dc_bytes["calm"] > dc_bytes["flat"] * 5 // 4 + (96 << 10), dc_bytes
 
 
+@pytest.mark.parametrize("throughput_mode", [0, 1])
 @pytest.mark.parametrize("seed", [1, 2, 3])
-def test_random_sequences_of_calls_on_one_context(built, enc, seed):
+def test_random_sequences_of_calls_on_one_context(built, enc, seed, throughput_mode):
     """The C ABI's calls in random order on ONE context: frames of three sizes set in turn, complete encodes through
     both entry points and through the raw-token route, the device pipeline alone, section packing behind a complete
     encode (a second measuring pass), statistics in between.  Every codestream and every packed section must be what
-    a fresh context gives -- state left behind by one call must not leak into the next."""
+    a fresh context gives -- state left behind by one call must not leak into the next.  throughput_mode: the
+    context as a lane of a batch holds it (jxlt_context_set_wait_mode(ctx, 1)): the two kinds' section packing shares its
+    launches, the DC-group sections' pass is put off until the AC sections' is asked for (or until somebody wants its sizes),
+    and a frame's last publication leaves the counters clean for the next frame, whatever its size."""
     rng = np.random.default_rng(seed)
+    enc.set_wait_mode(throughput_mode)
     frames = [T.to_planes(T.synthetic_image(w, h, seed=40 + i, hard=(i == 1)))
               for i, (w, h) in enumerate([(300, 264), (96, 72), (520, 2100)])]
     want = [T.assemble_codestream(T.oracle_hot_path(p, 1.0), 1.0) for p in frames]
@@ -778,6 +783,7 @@ def test_random_sequences_of_calls_on_one_context(built, enc, seed):
             assert enc.stats()["tiles_redone_exact_roots"] == 0
         elif op == 7 and encoded:
             assert set(enc.kernel_times()) == {"tile_kernel", "tokenisation_after_tile_kernel"}
+    enc.set_wait_mode(0)  # (the context is the module's)
 
 
 def test_frame_above_one_gigapixel(built, enc):

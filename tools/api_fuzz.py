@@ -38,6 +38,7 @@ bad = 0
 for seed in range(seeds):
     rng = np.random.default_rng(1000 + seed)
     enc = built.Encoder(0)
+    enc.set_wait_mode(seed % 3 == 2)  # (every third seed: the context as a lane of a batch holds it)
     cur = 0
     enc.upload(frames[cur])
     encoded = None
