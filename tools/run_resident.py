@@ -29,12 +29,17 @@ def main():
     import time
     n = 0
     t0 = None
+    each = []
     for i in range(passes):
         if i == passes // 2:
             t0 = time.perf_counter()
+        t1 = time.perf_counter()
         n = enc.encode_resident(distance, copy=False)
+        each.append((time.perf_counter() - t1) * 1e3)
     ms = (time.perf_counter() - t0) / (passes - passes // 2) * 1e3
-    print("done", size, passes, len(n), "%.3f ms per encode" % ms, {k: round(v, 3) for k, v in enc.kernel_times().items()})
+    half = sorted(each[passes // 2:])
+    print("done", size, passes, len(n), "%.3f ms per encode" % ms, {k: round(v, 3) for k, v in enc.kernel_times().items()},
+          "median %.3f min %.3f" % (half[len(half) // 2], half[0]))
 
 
 if __name__ == "__main__":
