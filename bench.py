@@ -462,9 +462,8 @@ def main():
             if in_flight_2 is not None and not in_flight_2["same_bytes"]:
                 result["parity_gate"]["sharded_equals_single_gpu_codestream"] = False
             enc1.close()
-            # the CPU baseline of the N = 1 line (rank 0's host cores; the other ranks sleep in the barrier below)
-            import jxlt_testlib as T
-            cpu_baseline_leg(args, np, pkg, T, full, dev_index, result)
+            # (no cpu_baseline at N > 1: it is a figure of the N = 1 line, and the other ranks would sit in the barrier
+            # below for the ten seconds it takes)
             del full
         else:
             result.update(result_early)
