@@ -410,7 +410,8 @@ def main():
         tk = [k.get("tile_kernel") for k in step_kernel_ms]
         result["harness"] = {
             "pre_warm": ("device-only leg (kernels without code construction and packing, %d launches) in FRONT of the "
-                         "warm-up steps: the GPU's clock is at its level when the timed region starts" % (3 + max(3, args.steps))
+                         "warm-up steps: most of the GPU's clock ramp lies in front of the timed region; what is left of it shows as "
+                         "tile_kernel_ms_first_minus_last" % (3 + max(3, args.steps))
                          if pre_warm_ms else "none (warm-up steps only)"),
             "pre_warm_ms": round(pre_warm_ms, 1),
             "warmup_steps_ms_total": round(sum(warmup_ms), 1),
@@ -849,28 +850,32 @@ def pmc_traffic(size, with_doc=False):
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes with the calibrated gfx950 correction);
     None when no profile of this frame size is committed."""
     best = None
-    fresh = None
+    used = None
     for p in sorted((ROOT / "profiles").glob("*_traffic_%d.json" % size)):
         try:
             doc = json.load(open(p))
             best = doc["kernels"]["tile_kernel"]["hbm_bytes"]
-            fresh = profile_freshness(p, doc)
+            used = (p, doc)
         except (OSError, KeyError, ValueError):
             pass
+    # (the freshness of the profile that is USED -- the latest round's --, not of every older one beside it)
+    fresh = profile_freshness(*used) if used is not None and with_doc else None
     return (best, fresh) if with_doc else best
 
 
 def pmc_valu(size):
     """VALU instructions per wave of tile_kernel from the committed counter profile
     (profiles/*_tile_valu_<size>.json, made with tools/tile_cycles.sh); None if absent."""
-    best = None
+    best, path = None, None
     for p in sorted((ROOT / "profiles").glob("*_tile_valu_%d.json" % size)):
         try:
-            best = json.load(open(p))
-            best["valu_insts_per_wave"], best["waves"]
-            best["freshness"] = profile_freshness(p, best)
+            doc = json.load(open(p))
+            doc["valu_insts_per_wave"], doc["waves"]
+            best, path = doc, p
         except (OSError, KeyError, ValueError):
-            best = None
+            pass
+    if best is not None:
+        best["freshness"] = profile_freshness(path, best)
     return best
 
 
