@@ -493,8 +493,8 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
     if (beside) HIP_TRY(ctx, hipStreamWaitEvent(chain_stream, ctx->tile_done[sl], 0));
     hipLaunchKernelGGL(dc_chain_summary_kernel, dim3((unsigned)(slab_dc * kDcChainChunks)), dim3(kDcChainThreads), 0,
                        chain_stream, D);
-    hipLaunchKernelGGL(dc_chain_kernel, dim3((unsigned)(slab_dc * kDcChainChunks)), dim3(kDcChainThreads), 0,
-                       chain_stream, D);
+    hipLaunchKernelGGL(dc_chain_kernel, dim3((unsigned)std::min<size_t>(slab_dc * kDcChainChunks, kDcChainGrid)), dim3(kDcChainThreads), 0,
+                       chain_stream, D, (int)(slab_dc * kDcChainChunks));
     if (beside && ctx->throughput_waits) {
       // (a lane of a batch: the DC histogram leaves WITH the AC histogram, one publication for the two -- token_kernel
       // takes ~10 us on frames this small, and the seven microseconds of a publish kernel count where a batch of small

@@ -177,14 +177,19 @@ __global__ void __launch_bounds__(256) dc_elementwise_kernel(const DcArgs A) {
     if (hist[i]) atomicAdd(&A.histogram[i], hist[i]);
 }
 
-constexpr int kDcChainThreads = 1024;
-
 // The two per-first-block token runs need, for every first block, its rank among the DC group's
 // first blocks and the previous first block's (strategy code, quant field).  One workgroup per
-// chunk of kDcChainThreads blocks (64 chunks per full DC group, all of them in parallel):
+// chunk of kDcChainBlocks blocks (64 chunks per full DC group, all of them in parallel):
 // dc_chain_summary_kernel records each chunk's first-block count and its last first block's
 // values; dc_chain_kernel derives a chunk's carry from the summaries of its predecessors.
-constexpr int kDcChainChunks = 65536 / kDcChainThreads;  // per DC group (256 x 256 blocks)
+// A thread has kDcChainPasses blocks of its chunk, kDcChainThreads apart (round 6; one block per thread until then:
+// 4096 workgroups of 1024 threads are eight rounds of workgroups over the chip for a few dozen instructions each --
+// 20 + 55 us in front of every large frame's token_kernel; with a quarter of the threads they are two).
+constexpr int kDcChainThreads = 256;
+constexpr int kDcChainBlocks = 1024;                             // blocks per chunk
+constexpr int kDcChainPasses = kDcChainBlocks / kDcChainThreads;  // blocks per thread
+constexpr int kDcChainChunks = 65536 / kDcChainBlocks;           // per DC group (256 x 256 blocks)
+static_assert(kDcChainChunks == 64, "a chunk's carry is worked out by one wave, a lane per preceding chunk");
 
 struct DcChunkBlock {
   bool first;
@@ -202,6 +207,8 @@ JXLT_DI DcChunkBlock dc_chunk_block(const DcArgs& A, const DcGeom& d, int i) {
   return b;
 }
 
+// (a workgroup per chunk: with several chunks per workgroup -- as dc_chain_kernel below -- this kernel, which has no
+// histogram to add, got slower: 0.046 / 0.047 / 0.056 / 0.078 Mcycles with 4096 / 2048 / 1024 / 512 workgroups at 16384^2)
 __global__ void __launch_bounds__(kDcChainThreads) dc_chain_summary_kernel(const DcArgs A) {
   __shared__ uint32_t count;
   __shared__ int last_idx;
@@ -215,69 +222,94 @@ __global__ void __launch_bounds__(kDcChainThreads) dc_chain_summary_kernel(const
     last_val = 0;
   }
   __syncthreads();
-  const DcChunkBlock b = dc_chunk_block(A, d, chunk * kDcChainThreads + tid);
-  const unsigned long long m = __ballot(b.first);
-  if ((tid & 63) == 0 && m != 0) {
-    atomicAdd(&count, (uint32_t)__popcll(m));
-    atomicMax(&last_idx, (tid & ~63) + 63 - __clzll((long long)m));
+  DcChunkBlock b[kDcChainPasses];
+#pragma unroll
+  for (int k = 0; k < kDcChainPasses; k++) b[k] = dc_chunk_block(A, d, chunk * kDcChainBlocks + k * kDcChainThreads + tid);
+#pragma unroll
+  for (int k = 0; k < kDcChainPasses; k++) {
+    const unsigned long long m = __ballot(b[k].first);
+    if ((tid & 63) == 0 && m != 0) {
+      atomicAdd(&count, (uint32_t)__popcll(m));
+      atomicMax(&last_idx, k * kDcChainThreads + (tid & ~63) + 63 - __clzll((long long)m));
+    }
   }
   __syncthreads();
-  if (b.first && tid == last_idx) last_val = (uint32_t)((b.code << 8) | b.qfm1);
+#pragma unroll
+  for (int k = 0; k < kDcChainPasses; k++)
+    if (b[k].first && k * kDcChainThreads + tid == last_idx) last_val = (uint32_t)((b[k].code << 8) | b[k].qfm1);
   __syncthreads();
   if (tid == 0) A.chain_summary[dcg * kDcChainChunks + chunk] = count | (last_val << 16);
 }
 
-__global__ void __launch_bounds__(kDcChainThreads) dc_chain_kernel(const DcArgs A) {
+// (`items` chunks = DC groups of the launch x kDcChainChunks; a workgroup takes the chunks blockIdx.x, + gridDim.x, ...
+// and adds its histogram to the frame's ONCE: with a workgroup per chunk 4096 workgroups added ~30 words each to the same
+// ~30 addresses, and those 4096 device-scope atomics per address were most of the kernel's 57 us -- round 6)
+constexpr int kDcChainGrid = 1024;
+__global__ void __launch_bounds__(kDcChainThreads) dc_chain_kernel(const DcArgs A, int items) {
   __shared__ uint32_t hist[16 * 64];  // the two runs only use contexts 3..10
-  __shared__ uint32_t wsum[kDcChainThreads / 64];
-  __shared__ uint16_t compact[kDcChainThreads + 1];  // (code << 8) | (qf - 1) of the chunk's first blocks
+  __shared__ uint32_t wsum[kDcChainBlocks / 64];  // first blocks per 64 consecutive blocks of the chunk
+  __shared__ uint16_t compact[kDcChainBlocks + 1];  // (code << 8) | (qf - 1) of the chunk's first blocks
   __shared__ uint32_t carry_rank;
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int dcg = A.dcg_first + (int)blockIdx.x / kDcChainChunks, chunk = (int)blockIdx.x % kDcChainChunks;
-  const uint32_t nac = A.dc_nac[dcg];
-  const DcGeom d = dc_geom(A.g, dcg, nac);
-  if (chunk * kDcChainThreads >= d.nb) return;  // (partial DC groups have fewer chunks)
   for (int i = tid; i < 16 * 64; i += kDcChainThreads) hist[i] = 0;
-  uint8_t* rec = A.records + 3 * A.dc_rec_offset[dcg];
   const size_t bstride = (size_t)A.g.xsize_blocks;
-  // "left" before the first first-block: 0 for the strategy run, StrategyCode(acs(0,0)) for
-  // the quant-field run (sic, enc_frame.cc:386)
-  const uint8_t a00 = A.strategy[(size_t)d.by0 * bstride + d.bx0];
-  const int code00 = (a00 >> 1) == 0 ? 0 : (a00 >> 1) == 1 ? 6 : 7;
-  if (tid < 64) {
-    // carry from the preceding chunks: their first-block counts, and the values of the last
-    // first block before this chunk (lane c looks at chunk c; 64 chunks = one wave)
-    const uint32_t sm = (tid < chunk) ? A.chain_summary[dcg * kDcChainChunks + tid] : 0u;
-    uint32_t cnt = sm & 0xFFFFu;
-    const unsigned long long nonempty = __ballot(cnt != 0);
-    for (int dd = 32; dd >= 1; dd >>= 1) cnt += __shfl_xor(cnt, dd);
-    const int src = nonempty ? 63 - __clzll((long long)nonempty) : 0;
-    const uint32_t prev = __shfl(sm >> 16, src);
-    if (tid == 0) {
-      carry_rank = cnt;
-      compact[0] = nonempty ? (uint16_t)prev : (uint16_t)((0 << 8) | code00);  // predecessor of the chunk's first entry
+  for (int item = (int)blockIdx.x; item < items; item += (int)gridDim.x) {
+    const int dcg = A.dcg_first + item / kDcChainChunks, chunk = item % kDcChainChunks;
+    const uint32_t nac = A.dc_nac[dcg];
+    const DcGeom d = dc_geom(A.g, dcg, nac);
+    if (chunk * kDcChainBlocks >= d.nb) continue;  // (partial DC groups have fewer chunks; the same for every thread)
+    uint8_t* rec = A.records + 3 * A.dc_rec_offset[dcg];
+    // (the thread's blocks: requested in front of the carry's loads)
+    DcChunkBlock b[kDcChainPasses];
+#pragma unroll
+    for (int k = 0; k < kDcChainPasses; k++) b[k] = dc_chunk_block(A, d, chunk * kDcChainBlocks + k * kDcChainThreads + tid);
+    // "left" before the first first-block: 0 for the strategy run, StrategyCode(acs(0,0)) for
+    // the quant-field run (sic, enc_frame.cc:386)
+    const uint8_t a00 = A.strategy[(size_t)d.by0 * bstride + d.bx0];
+    const int code00 = (a00 >> 1) == 0 ? 0 : (a00 >> 1) == 1 ? 6 : 7;
+    if (tid < 64) {
+      // carry from the preceding chunks: their first-block counts, and the values of the last
+      // first block before this chunk (lane c looks at chunk c; 64 chunks = one wave)
+      const uint32_t sm = (tid < chunk) ? A.chain_summary[dcg * kDcChainChunks + tid] : 0u;
+      uint32_t cnt = sm & 0xFFFFu;
+      const unsigned long long nonempty = __ballot(cnt != 0);
+      for (int dd = 32; dd >= 1; dd >>= 1) cnt += __shfl_xor(cnt, dd);
+      const int src = nonempty ? 63 - __clzll((long long)nonempty) : 0;
+      const uint32_t prev = __shfl(sm >> 16, src);
+      if (tid == 0) {
+        carry_rank = cnt;
+        compact[0] = nonempty ? (uint16_t)prev : (uint16_t)((0 << 8) | code00);  // predecessor of the chunk's first entry
+      }
     }
-  }
-  __syncthreads();
-  {
-    const DcChunkBlock b = dc_chunk_block(A, d, chunk * kDcChainThreads + tid);
-    const bool first = b.first;
-    const int code = b.code, qfm1 = b.qfm1;
-    // exclusive rank of first blocks inside the chunk
-    const unsigned long long m = __ballot(first);
-    const uint32_t in_wave = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) wsum[wave] = (uint32_t)__popcll(m);
+    // exclusive rank of the first blocks inside the chunk: blocks 64 (4 k + wave) ... + 63 are pass k of this wave
+    uint32_t in_wave[kDcChainPasses];
+#pragma unroll
+    for (int k = 0; k < kDcChainPasses; k++) {
+      const unsigned long long m = __ballot(b[k].first);
+      in_wave[k] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) wsum[k * (kDcChainThreads / 64) + wave] = (uint32_t)__popcll(m);
+    }
     __syncthreads();
-    uint32_t wbase = 0;
-    for (int w = 0; w < kDcChainThreads / 64; w++)
-      if (w < wave) wbase += wsum[w];
-    const uint32_t r = wbase + in_wave;  // rank within chunk
-    if (first) compact[1 + r] = (uint16_t)((code << 8) | qfm1);
+    uint32_t rank[kDcChainPasses];
+    {
+      uint32_t running = 0;
+      int next = 0;
+#pragma unroll
+      for (int k = 0; k < kDcChainPasses; k++) {
+        const int mine = k * (kDcChainThreads / 64) + wave;
+        for (; next < mine; next++) running += wsum[next];
+        rank[k] = running + in_wave[k];
+        if (b[k].first) compact[1 + rank[k]] = (uint16_t)((b[k].code << 8) | b[k].qfm1);
+      }
+    }
     __syncthreads();
-    if (first) {
-      const uint16_t prev = compact[r];  // previous first block (or the carried one)
-      const uint32_t grank = carry_rank + r;
+#pragma unroll
+    for (int k = 0; k < kDcChainPasses; k++) {
+      if (!b[k].first) continue;
+      const int code = b[k].code, qfm1 = b[k].qfm1;
+      const uint16_t prev = compact[rank[k]];  // previous first block (or the carried one)
+      const uint32_t grank = carry_rank + rank[k];
       // strategy token (enc_frame.cc:364-383): left = previous code (0 for the very first)
       const int left_s = (grank == 0) ? 0 : (prev >> 8);
       const uint32_t ctx_s = left_s > 11 ? 7 : left_s > 5 ? 8 : left_s > 3 ? 9 : 10;
@@ -287,6 +319,7 @@ __global__ void __launch_bounds__(kDcChainThreads) dc_chain_kernel(const DcArgs 
       const uint32_t ctx_q = left_q > 11 ? 3 : left_q > 5 ? 4 : left_q > 3 ? 5 : 6;
       put_record(rec, d.pos_qf + grank, ctx_q, pack_signed(qfm1 - left_q), hist);
     }
+    __syncthreads();  // (compact, wsum and carry_rank serve the next chunk)
   }
   __syncthreads();
   for (int i = tid; i < 16 * 64; i += kDcChainThreads)

@@ -181,7 +181,9 @@ __attribute__((visibility("default"))) int sim_encode(const float* const planes[
       D.dcg_first = (int)(sl * xdc);
       hipsim::launch(dc_elementwise_kernel, dim3((unsigned)(xdc * kDcParts)), dim3(256), D);
       hipsim::launch(dc_chain_summary_kernel, dim3((unsigned)(xdc * kDcChainChunks)), dim3(kDcChainThreads), D);
-      hipsim::launch(dc_chain_kernel, dim3((unsigned)(xdc * kDcChainChunks)), dim3(kDcChainThreads), D);
+      // (a small grid here, so that a workgroup has several chunks of several DC groups in turn)
+      hipsim::launch(dc_chain_kernel, dim3((unsigned)std::min<size_t>(xdc * kDcChainChunks, 24)), dim3(kDcChainThreads), D,
+                     (int)(xdc * kDcChainChunks));
     }
   }
   free(A.dc_nac);
