@@ -383,7 +383,9 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   A.overflow_tiles = ctx->overflow_tiles.p;
   A.unsupported = ctx->lut_overflow.p + nslabs;
   // the frame's counters and histograms start at zero: ONE small kernel (four hipMemsetAsync were four fill kernels,
-  // 5-9 us apart, in front of every frame's first tile_kernel launch)
+  // 5-9 us apart, in front of every frame's first tile_kernel launch).  The stage event stands in FRONT of it (an event
+  // between it and tile_kernel is 6 us of nothing on the stream): "tile_kernel" of jxlt_kernel_times includes its 3 us.
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   {
     ClearArgs C;
     C.p[0] = ctx->group_ntok.p;
@@ -398,7 +400,6 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
     hipLaunchKernelGGL(clear_counters_kernel, dim3((most + 255) / 256), dim3(256), 0, ctx->stream, C);
     HIP_TRY(ctx, hipGetLastError());
   }
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   ctx->overflow_slabs = nslabs;
   while (ctx->slab_ready.size() < nslabs || ctx->tile_done.size() < nslabs) {
     hipEvent_t ev = nullptr;
@@ -429,6 +430,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   const hipStream_t tok_stream = nslabs == 1 ? ctx->stream : ctx->aux_stream;  // (one launch: nothing to overlap)
   size_t dc_rows_done = 0;  // rows of DC groups whose tokenisation has been queued
   bool merged_hist_publish = false;  // (throughput mode, small frames: the DC histogram leaves with the AC histogram)
+  bool dc_kernels_beside = false;    // (the DC-group kernels run on a stream of their own, beside token_kernel)
   for (size_t sl = 0; sl < nslabs; sl++) {
     const size_t y0 = pieces[sl].y0, rows = pieces[sl].rows, y1 = y0 + rows;
     if (from_host) {
@@ -463,11 +465,20 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
       hipLaunchKernelGGL(tile12_kernel, dim3(slab_tiles), dim3(kTile12Threads), 0, ctx->stream, S);
     hipLaunchKernelGGL(tile12_kernel_redo, dim3(redo_grid), dim3(kTile12Threads), 0, ctx->stream, S);
     // (the counts of redone tiles leave with the DC histogram, below)
-    if (sl + 1 == nslabs) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->tile_done[sl], ctx->stream));
+    // (an event record between two kernels of a stream is a barrier packet of its own: ~6 us in which the stream runs
+    // nothing, where two kernels queued back to back follow each other within 0.1 us -- kernel trace, round 6.  The
+    // last piece's "tiles done" is therefore the stage event itself, and the records below stand BEHIND the small
+    // kernels that carry results to the host, not in front of them.)
+    hipEvent_t tiles_done = ctx->tile_done[sl];
+    if (sl + 1 == nslabs) {
+      tiles_done = ctx->ev[1];
+      HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    } else {
+      HIP_TRY(ctx, hipEventRecord(ctx->tile_done[sl], ctx->stream));
+    }
     if (!pieces[sl].ends_dc_row) continue;
     // ---- tokenisation of the row(s) of DC groups this piece completes, on the aux stream
-    if (tok_stream != ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(tok_stream, ctx->tile_done[sl], 0));
+    if (tok_stream != ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(tok_stream, tiles_done, 0));
     // DC groups first: their histogram leaves for the host as soon as the last row's is complete, so that the DC
     // code is built while token_kernel is still running
     const size_t dc_row0 = dc_rows_done, dc_row1 = nslabs == 1 ? ndc_rows : dc_row0 + 1;
@@ -479,7 +490,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
     const bool split = nslabs == 1;
     ctx->dc_elementwise_split = split;
     const hipStream_t elem_stream = split ? ctx->aux_stream : tok_stream;
-    if (split) HIP_TRY(ctx, hipStreamWaitEvent(elem_stream, ctx->tile_done[sl], 0));
+    if (split) HIP_TRY(ctx, hipStreamWaitEvent(elem_stream, tiles_done, 0));
     hipLaunchKernelGGL(dc_elementwise_kernel, dim3((unsigned)(slab_dc * kDcParts)), dim3(256), 0, elem_stream, D);
     if (split) HIP_TRY(ctx, hipEventRecord(ctx->dc_elementwise_done, elem_stream));
     // A resident frame of up to 1024 groups (8192^2): the two chain kernels and the histogram's publication on a
@@ -490,7 +501,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
     // DC code is built behind token_kernel instead of under it (5.36 against 5.18 ms).
     const bool beside = nslabs == 1 && split && ngroups <= 1024;
     const hipStream_t chain_stream = beside ? ctx->upload_stream : tok_stream;
-    if (beside) HIP_TRY(ctx, hipStreamWaitEvent(chain_stream, ctx->tile_done[sl], 0));
+    if (beside) HIP_TRY(ctx, hipStreamWaitEvent(chain_stream, tiles_done, 0));
     hipLaunchKernelGGL(dc_chain_summary_kernel, dim3((unsigned)(slab_dc * kDcChainChunks)), dim3(kDcChainThreads), 0,
                        chain_stream, D);
     hipLaunchKernelGGL(dc_chain_kernel, dim3((unsigned)std::min<size_t>(slab_dc * kDcChainChunks, kDcChainGrid)), dim3(kDcChainThreads), 0,
@@ -515,13 +526,13 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
       // the host polls (~6 us on the stream).  Beside token_kernel -- on the copy stream, where rounds 2-3 had the
       // download -- the kernel does not get a wave slot before token_kernel's workgroups begin to retire: the
       // histogram arrived 0.4 ms late and the DC code was built behind the AC code (round 4, first version).
-      HIP_TRY(ctx, hipEventRecord(ctx->dc_kernels_done, tok_stream));
       if (split) HIP_TRY(ctx, hipStreamWaitEvent(tok_stream, ctx->dc_elementwise_done, 0));
       const PublishSeg segs[2] = {{ctx->hist.p + 64 * 64, ctx->h_hist.p + 64 * 64, 64 * 64},
                                   {ctx->lut_overflow.p, ctx->h_lut_overflow.p, nslabs + 1}};
       const int rcp = EnqueuePublish(ctx, tok_stream, segs, 2, nullptr, nullptr, &ctx->mail.p->dc_hist_seq, frame_seq);
       if (rcp != JXLT_OK) return rcp;
       ctx->dc_hist_stream = tok_stream;
+      HIP_TRY(ctx, hipEventRecord(ctx->dc_kernels_done, tok_stream));  // (behind the publication)
     }
     const size_t ty0 = dc_row0 * 2048, ty1 = std::min(ctx->ysize, dc_row1 * 2048);  // pixel rows being tokenised
     const size_t g0 = (ty0 / 256) * (size_t)g.xsize_groups;
@@ -533,14 +544,12 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
       hipLaunchKernelGGL(token_kernel_wide, dim3((unsigned)ng), dim3(kTokenThreads), 0, tok_stream, K);
     else
       hipLaunchKernelGGL(token_kernel, dim3((unsigned)ng), dim3(kTokenThreads), 0, tok_stream, K);
-    // (whatever follows on the main stream -- the sections' packing -- reads what the DC-group kernels wrote)
-    if (beside) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->dc_kernels_done, 0));
+    dc_kernels_beside = beside;
   }
   HIP_TRY(ctx, hipGetLastError());
   ctx->host_src_kind = 0;  // the frame is resident now (a redo with exact roots must not fetch it again)
   // AC histogram + total token count leave right behind the last token_kernel (publish_kernel: no copy command, no
   // event -- the host polls the sequence word)
-  HIP_TRY(ctx, hipEventRecord(ctx->aux_done, tok_stream));
   TraceMark(ctx, "token_kernel done", tok_stream);
   if (merged_hist_publish) {
     // (both histograms -- they lie behind each other -- and the counts of redone tiles; the DC-group kernels have run)
@@ -558,6 +567,12 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
     if (rcp != JXLT_OK) return rcp;
     ctx->ac_hist_stream = tok_stream;
   }
+  // (the tokenisation's stage event, behind the histogram's publication: "tokenisation_after_tile_kernel" of
+  // jxlt_kernel_times includes those ~6 us)
+  HIP_TRY(ctx, hipEventRecord(ctx->aux_done, tok_stream));
+  // (whatever follows on the main stream -- the sections' packing -- reads what the DC-group kernels wrote; behind the
+  // AC histogram's publication, which does not)
+  if (dc_kernels_beside && !merged_hist_publish) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->dc_kernels_done, 0));
   // whatever is queued on the main stream from here on (section packing) comes after the tokenisation
   if (tok_stream != ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_done, 0));
   // (the DC-group sections' packing reads what dc_elementwise_kernel wrote)
