@@ -165,8 +165,10 @@ int WaitDeliveries(jxlt_context* ctx) {
           ctx->error = "section hand-over: timed out";
           return JXLT_ERR_INTERNAL;
         }
-        struct timespec ts = {0, 8000};
-        nanosleep(&ts, nullptr);
+        if (ctx->throughput_waits) {
+          struct timespec ts = {0, 8000};
+          nanosleep(&ts, nullptr);
+        }
       }
       ctx->deliver_by_query[kind] = false;
       continue;

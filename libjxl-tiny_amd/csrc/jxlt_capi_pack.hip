@@ -397,6 +397,18 @@ void FillMeasured(jxlt_context* ctx, int kind, jxlt_packed_sections* out) {
   out->num_sections = ps.measured_sections;
 }
 
+// How the host learns that a hand-over is complete: from a one-workgroup kernel behind the copies that stores the
+// hand-over's number to a word the host polls -- or, for the short hand-overs of a small frame (up to 256 groups; and
+// for every one of a batch lane, which polls in short sleeps), by asking the copy stream itself (hipStreamQuery in
+// WaitDeliveries): the kernel behind a copy costs its launch, ~6 us of a 0.5 ms frame (4096^2 0.494-0.503 -> 0.480-0.488
+// ms, 2048^2 0.299-0.306 -> 0.289-0.299), while a host thread that asks the runtime in a loop during the 0.1-0.4 ms of a
+// large frame's copies gets in the way of the copy commands now and then (one run in three: 8192^2 1.50 instead of
+// 1.33-1.35 ms, 16384^2 5.0 instead of 4.73).  Both kinds of a frame the same way (8192^2 with only the DC-group
+// sections' hand-over asked for: 1.35-1.37 against 1.35).
+static bool CompletionByQuery(const jxlt_context* ctx) {
+  return ctx->throughput_waits || (size_t)ctx->geom.xsize_groups * ctx->geom.ysize_groups <= 256;
+}
+
 // hipMemcpyAsync with the time the CALL took on the host: kept per encode (jxlt_encode_stats: a call that meets the
 // runtime creating a copy engine's queue takes milliseconds); JXLT_TRACE_EVENTS reports calls of more
 // than 0.5 ms (level 2: every call).
@@ -446,7 +458,7 @@ int EnqueueDeliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_section
       }
       s_lo = s_hi;
     }
-    if (ctx->throughput_waits) {
+    if (CompletionByQuery(ctx)) {
       ctx->deliver_by_query[kind] = true;  // (completion = the copy stream having drained: WaitDeliveries)
     } else {
       const int rcp = EnqueuePublish(ctx, out_stream, nullptr, 0, nullptr, nullptr, &ctx->mail.p->delivered_seq[kind][0], ++ctx->deliver_seq[kind]);
@@ -487,7 +499,7 @@ int EnqueueDeliver(jxlt_context* ctx, int kind, uint8_t* dst, const jxlt_section
       }
     }
     // completion: a one-workgroup kernel behind the copies stores the hand-over's number to the word the host polls
-    if (ctx->throughput_waits) {
+    if (CompletionByQuery(ctx)) {
       ctx->deliver_by_query[kind] = true;  // (completion = the copy stream having drained: WaitDeliveries)
     } else {
       const int rcp = EnqueuePublish(ctx, out_stream, nullptr, 0, nullptr, nullptr, &ctx->mail.p->delivered_seq[kind][0], ++ctx->deliver_seq[kind]);

@@ -110,9 +110,9 @@ struct jxlt_context {
   } wait_sites[8];
   size_t wait_geometry[2] = {0, 0};  // the frame size the remembered waits belong to
   bool throughput_waits = false;
-  // (throughput mode: a hand-over's completion is its copy stream having drained -- asked for with hipStreamQuery between
-  // short sleeps -- instead of a publish kernel behind the copies: a batch of small frames is bound by the number and the
-  // 7 us of its small launches, round 6)
+  // (throughput mode, and frames of up to 256 groups: a hand-over's completion is its copy stream having drained -- asked
+  // for with hipStreamQuery, between short sleeps in throughput mode -- instead of a publish kernel behind the copies,
+  // jxlt_capi_pack.hip CompletionByQuery)
   bool deliver_by_query[2] = {false, false};
   std::vector<hipEvent_t> tile_done;
   hipEvent_t aux_done = nullptr;   // everything queued on aux_stream for the frame (timing enabled: the token tail)
