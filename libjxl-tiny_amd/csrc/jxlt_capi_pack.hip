@@ -305,6 +305,12 @@ int EnqueueStream(jxlt_context* ctx, int kind, const uint32_t* code_table) {
                          dim3((unsigned)((W.tile_end - W.tile_first + kPackStreamTilesPerGroup - 1) / kPackStreamTilesPerGroup)),
                          dim3(kPackThreads), 0, ps.stream, W);
     HIP_TRY(ctx, hipGetLastError());
+    // (the launch's event -- what its sections' copy waits for.  One frame at a time: BEHIND the publication below.  The
+    // copy cannot be issued before the host has the sizes anyway, and an event record between the launch and the publish
+    // kernel is a barrier packet of its own, 6 us on the way of the sizes to the host.  A lane of a batch: right here,
+    // as until round 6 -- with the record behind the publication the resident 3840x2160 batch lost 8 %, 34.0 against
+    // 35.9-37.2 GP/s with four lanes on the same box; every other record of R6.10 is neutral there)
+    if (ctx->throughput_waits) HIP_TRY(ctx, hipEventRecord(ps.launch_done[i], ps.stream));
     TraceMark(ctx, kind ? "AC stream launch done" : "DC stream launch done", ps.stream);
     // (IN the stream: a one-workgroup kernel on another stream waits for a free slot behind the next launch's
     // workgroups -- the first launch's word arrived when the last launch had ended)
@@ -313,10 +319,7 @@ int EnqueueStream(jxlt_context* ctx, int kind, const uint32_t* code_table) {
     if ((rc = EnqueuePublish(ctx, ps.stream, segs, 2, nullptr, nullptr, &ctx->mail.p->stream_seq[kind][i][0],
                              ps.pack_seq)) != JXLT_OK)
       return rc;
-    // (the launch's event -- what its sections' copy waits for -- BEHIND the publication: the copy cannot be issued
-    // before the host has the sizes anyway, and an event record between the launch and the publish kernel is a
-    // barrier packet of its own, 6 us on the way of the sizes to the host)
-    HIP_TRY(ctx, hipEventRecord(ps.launch_done[i], ps.stream));
+    if (!ctx->throughput_waits) HIP_TRY(ctx, hipEventRecord(ps.launch_done[i], ps.stream));
   }
   ps.planned = false;
   ps.measured_sections = nsec;
