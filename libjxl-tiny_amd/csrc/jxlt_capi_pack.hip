@@ -28,12 +28,19 @@ int PackPassesForced() {  // 1 / 2, or 0: by size
 bool PackSinglePass(const jxlt_context*) { return PackPassesForced() != 2; }
 bool PackSinglePassFor(const jxlt_context* ctx, int kind, uint64_t records) {
   if (PackPassesForced() != 0) return PackPassesForced() == 1;
-  // (a section has at least one tile: a frame of 4096 groups is 4096 workgroups with a ticket, a code table and a
-  // look-back each even when they hold a handful of records -- 16384^2 at d = 4, 1 800 tiles' worth of records: 4.55-4.58
-  // ms in one pass, 4.52-4.53 in two; the DC-group sections of the 16384^2 frame alone in one pass: 5.26-5.28
-  // against 5.24-5.26, tools/mixed_ab.sh)
+  // The DC-group sections (few, long: 64 at 16384^2): always one pass.  On the large frame their two passes -- nine
+  // launches, 0.095 ms -- were still on the device when the AC sections' measuring pass was queued (the AC code is
+  // ready 0.09 ms behind token_kernel) and held it back by 0.04 ms; one pass is three launches and 0.05 ms: 16384^2
+  // 4.677 / 4.644 / 4.654 against 4.703 / 4.693 / 4.701 ms (round 6, same box, alternating; round 4 had measured the
+  // opposite by 0.02 ms -- with a memset and a separate table fetch in front of the single pass, and events between its
+  // kernels).
+  if (kind == 0) return true;
+  // The AC sections: a section has at least one tile -- a frame of 4096 groups is 4096 workgroups with a ticket, a code
+  // table and a look-back each even when they hold a handful of records (16384^2 at d = 4, 1 800 tiles' worth of
+  // records: 4.55-4.58 ms in one pass, 4.52-4.53 in two) --, and above 80 M records the writing pass's three launches
+  // with their copies in between win.
   if ((size_t)ctx->geom.xsize_groups * ctx->geom.ysize_groups > 1024) return false;
-  return kind == 0 || records <= (80ull << 20);
+  return records <= (80ull << 20);
 }
 
 // JXLT_PACK_LAUNCHES=<n>: the number of writing launches of the AC sections (default: 3 in two passes, 1 in one).
