@@ -219,7 +219,9 @@ size_t HuffmanBitCost(const uint32_t* counts) {
   uint8_t left[2 * kAlphabetSize + 2], right[2 * kAlphabetSize + 2];
   size_t raised = 0;        // keys[0 .. raised) have counts <= count_limit - 1
   uint64_t raised_at = 0;   // their gathering positions
-  for (uint32_t count_limit = 2;; count_limit *= 2) {
+  // (count_limit = 2 -- a floor of 1 under counts that are all >= 1 -- is the round above over again, enc_huffman_tree.cc:71-80
+  // with count_limit - 1 = 1: same weights, same order, same tree, too deep again.  The first round that can differ: 4.)
+  for (uint32_t count_limit = 4;; count_limit *= 2) {
     const uint32_t floor = count_limit - 1;
     while (raised < n && (keys[raised] >> 16) <= floor) {
       raised_at |= uint64_t(1) << ((keys[raised] >> 8) & 0xFF);
