@@ -175,9 +175,10 @@ int jxlt_set_strategy_distance(jxlt_context* ctx, float first_call_distance);
  * that results are seen within microseconds without a core spinning for milliseconds.  1, for contexts that share a GPU
  * and the host's CPUs with others (what the lanes of a jxlt_batch_encoder set): a few microseconds of polling, then
  * short sleeps -- a later wake-up is covered by the other contexts' frames; the context also trades a frame's latency for
- * fewer launches (frames of up to 1024 groups: the DC histogram leaves with the AC histogram in one publication, both
+ * fewer launches and events (resident frames of up to 1024 groups: every kernel of the frame on one stream, in order --
+ * the other contexts' frames fill the device --, the DC histogram leaves with the AC histogram in one publication, both
  * section kinds' tile plans are one launch, a hand-over's completion is read off its copy stream instead of being
- * published by a kernel).  Results do not depend on it. */
+ * published by a kernel, no stage events: jxlt_kernel_times is not available).  Results do not depend on it. */
 int jxlt_context_set_wait_mode(jxlt_context* ctx, int shared_device);
 /* Copies results to pinned host memory (blocking) and fills *out. */
 int jxlt_fetch_result(jxlt_context* ctx, jxlt_frame_result* out);

@@ -29,8 +29,10 @@ int jxlt_debug_fetch(jxlt_context* ctx, int what, void* host_dst, size_t bytes);
 int jxlt_debug_denormal_probe(jxlt_context* ctx, uint32_t* bits);
 
 /* Timing of the device stages of the last jxlt_encode_enqueue (HIP events on the context's
- * stream, always recorded): writes up to `cap` entries; returns the number of stages, or < 0.
- * Waits for the device pipeline of that encode. */
+ * stream): writes up to `cap` entries; returns the number of stages, or < 0.
+ * Waits for the device pipeline of that encode.  Not for a batch lane's frames (a context with
+ * jxlt_context_set_wait_mode(ctx, 1), resident frame of up to 1024 groups): those carry no stage
+ * events -- every event is a packet the device has to work through -- and the call fails. */
 typedef struct {
   const char* name;
   float milliseconds;

@@ -387,7 +387,15 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   // the frame's counters and histograms start at zero: ONE small kernel (four hipMemsetAsync were four fill kernels,
   // 5-9 us apart, in front of every frame's first tile_kernel launch).  The stage event stands in FRONT of it (an event
   // between it and tile_kernel is 6 us of nothing on the stream): "tile_kernel" of jxlt_kernel_times includes its 3 us.
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+  // A lane of a batch (jxlt_context_set_wait_mode(ctx, 1)), resident frame of up to 1024 groups: EVERY kernel of the frame on
+  // the main stream, in order, and no stage events -- the only events left are the two the sections' copies wait for.
+  // What a frame gains from its DC-group kernels, its tile plans and its tokenisation running side by side on three
+  // streams (one frame at a time: 0.03-0.05 ms) a batch does not need -- the other lanes' frames fill the device --, and
+  // the events that tie the streams together are packets the device works through one after the other: 48 resident
+  // 3840x2160 frames over 4 / 6 / 8 lanes 37.8-38.1 / 38.1-38.3 / 37.3-37.9 -> 43.1-44.2 / 45.0-45.8 / 45.1-46.8 GP/s
+  // (round 6, same box, alternating; with the stage events kept: 40.0-41.8 / 44.8-46.3 / 44.3-46.1).
+  const bool lane_frame = ctx->throughput_waits && !from_host && ngroups <= 1024 && ndc <= 1024;
+  if (!lane_frame) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   {
     ClearArgs C;
     C.p[0] = ctx->group_ntok.p;
@@ -474,7 +482,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
     hipEvent_t tiles_done = ctx->tile_done[sl];
     if (sl + 1 == nslabs) {
       tiles_done = ctx->ev[1];
-      HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+      if (!lane_frame) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     } else {
       HIP_TRY(ctx, hipEventRecord(ctx->tile_done[sl], ctx->stream));
     }
@@ -489,7 +497,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
     D.dcg_first = (int)(dc_row0 * xdc);
     // (a resident frame: the element-wise kernel and the two chain kernels do not depend on each other and none of
     // them fills the chip -- side by side on two streams)
-    const bool split = nslabs == 1;
+    const bool split = nslabs == 1 && !lane_frame;
     ctx->dc_elementwise_split = split;
     const hipStream_t elem_stream = split ? ctx->aux_stream : tok_stream;
     if (split) HIP_TRY(ctx, hipStreamWaitEvent(elem_stream, tiles_done, 0));
@@ -508,7 +516,9 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
                        chain_stream, D);
     hipLaunchKernelGGL(dc_chain_kernel, dim3((unsigned)std::min<size_t>(slab_dc * kDcChainChunks, kDcChainGrid)), dim3(kDcChainThreads), 0,
                        chain_stream, D, (int)(slab_dc * kDcChainChunks));
-    if (beside && ctx->throughput_waits) {
+    if (lane_frame) {
+      merged_hist_publish = true;  // (everything of the frame on one stream, in order: no events between its kernels)
+    } else if (beside && ctx->throughput_waits) {
       // (a lane of a batch: the DC histogram leaves WITH the AC histogram, one publication for the two -- token_kernel
       // takes ~10 us on frames this small, and the seven microseconds of a publish kernel count where a batch of small
       // frames is bound by the sum of its small launches, round 6)
@@ -555,8 +565,10 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   TraceMark(ctx, "token_kernel done", tok_stream);
   if (merged_hist_publish) {
     // (both histograms -- they lie behind each other -- and the counts of redone tiles; the DC-group kernels have run)
-    HIP_TRY(ctx, hipStreamWaitEvent(tok_stream, ctx->dc_kernels_done, 0));
-    HIP_TRY(ctx, hipStreamWaitEvent(tok_stream, ctx->dc_elementwise_done, 0));
+    if (!lane_frame) {
+      HIP_TRY(ctx, hipStreamWaitEvent(tok_stream, ctx->dc_kernels_done, 0));
+      HIP_TRY(ctx, hipStreamWaitEvent(tok_stream, ctx->dc_elementwise_done, 0));
+    }
     const PublishSeg segs[2] = {{ctx->hist.p, ctx->h_hist.p, 2 * 64 * 64}, {ctx->lut_overflow.p, ctx->h_lut_overflow.p, nslabs + 1}};
     const int rcp = EnqueuePublish(ctx, tok_stream, segs, 2, reinterpret_cast<const unsigned long long*>(ctx->group_off.p + ngroups),
                                    &ctx->mail.p->token_total, &ctx->mail.p->ac_hist_seq, frame_seq, &ctx->mail.p->dc_hist_seq);
@@ -571,7 +583,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   }
   // (the tokenisation's stage event, behind the histogram's publication: "tokenisation_after_tile_kernel" of
   // jxlt_kernel_times includes those ~6 us)
-  HIP_TRY(ctx, hipEventRecord(ctx->aux_done, tok_stream));
+  if (!lane_frame) HIP_TRY(ctx, hipEventRecord(ctx->aux_done, tok_stream));
   // (whatever follows on the main stream -- the sections' packing -- reads what the DC-group kernels wrote; behind the
   // AC histogram's publication, which does not)
   if (dc_kernels_beside && !merged_hist_publish) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->dc_kernels_done, 0));
@@ -604,7 +616,10 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
     // kernels would stand in front of the DC-group sections' packing, which the AC measuring pass queues behind)
     hipStream_t plan_stream = ctx->stream;
     const bool both_plans_at_once = tok_stream == ctx->stream && ctx->throughput_waits && ngroups <= 1024 && ndc <= 1024;
-    if (both_plans_at_once) {
+    if (both_plans_at_once && lane_frame) {
+      const int rcb = EnqueuePlanBoth(ctx, ctx->dc_records.cap / 3, ctx->tokens.cap / 3, ctx->stream);
+      if (rcb != JXLT_OK) return rcb;
+    } else if (both_plans_at_once) {
       // (a lane of a batch: the two plans in one launch, behind the tokenisation)
       plan_stream = ctx->aux_stream;
       HIP_TRY(ctx, hipStreamWaitEvent(plan_stream, ctx->dc_kernels_done, 0));
@@ -633,7 +648,7 @@ int EnqueuePipeline(jxlt_context* ctx, const jxlt_params* params) {
   ctx->pack[0].launches = ctx->pack[1].launches = 0;
   ctx->delivered_kinds = 0;
   ctx->last_flags = params->flags;
-  ctx->profiled = true;  // the five stage events are always recorded (a few microseconds per frame)
+  ctx->profiled = !lane_frame;  // (the stage events are recorded for every frame but a batch lane's)
   ctx->last_params = *params;
   ctx->overflow_checked = false;
   ctx->encode_status = JXLT_OK;
@@ -888,7 +903,8 @@ int jxlt_histograms_ready(jxlt_context* ctx) {
 int jxlt_kernel_times(jxlt_context* ctx, jxlt_kernel_time* out, int cap) {
   if (!ctx || !out || cap < 0) return JXLT_ERR_INVALID_ARGUMENT;
   if (!ctx->profiled) {
-    ctx->error = "nothing encoded yet";
+    ctx->error = "jxlt_kernel_times: nothing encoded yet, or the last frame was a batch lane's (jxlt_context_set_wait_mode(ctx, 1): "
+                 "such frames carry no stage events)";
     return JXLT_ERR_INVALID_ARGUMENT;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
